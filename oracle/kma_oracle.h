@@ -1,0 +1,76 @@
+/* kma_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the KMA 1.5.1 seed-and-extend hot path, written
+ * from the algorithm description in SURVEY.md / the reference sources (each
+ * function cites the reference file:line whose behaviour it restates). It is
+ * the checker that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg compare the HIP path against; nothing in kma_amd/ may link or call it.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks this library
+ * byte-for-byte against stream taps (-s2, frag_raw) produced by the compiled
+ * reference (oracle/_ref/kma) and committed under tests/golden/.
+ */
+#ifndef KMA_ORACLE_H
+#define KMA_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scoring constants, penalties.h:22-33, defaults kma.c:327-336,1307-1328 */
+typedef struct {
+	int M, MM, U, W1, Wl, Mn, PE;
+	int d[5][5];
+} orc_rewards;
+
+/* in-memory image of <prefix>.comp.b (hashmapkma.h:26-48, App. A) plus
+ * <prefix>.length.b and <prefix>.seq.b */
+typedef struct {
+	uint32_t DB_size, mlen, prefix_len, kmersize, flag;
+	uint64_t prefix, size /* mask after load */, n, v_index, null_index;
+	uint32_t *exist;      /* size+1 entries */
+	uint32_t *key32;      /* n+1, when mlen <= 16 */
+	uint64_t *key64;      /* n+1, when mlen > 16 */
+	uint32_t *value_index;/* n */
+	uint16_t *values16;   /* DB_size < 65535 */
+	uint32_t *values32;
+	/* template store */
+	int32_t *tlen;        /* DB_size entries, tlen[0] = kmerindex */
+	uint64_t *tseq;       /* concatenated 2-bit words */
+	int64_t *tseq_off;    /* word offset of template i */
+} orc_db;
+
+void orc_default_rewards(orc_rewards *r);
+orc_db *orc_db_load(const char *prefix);
+void orc_db_free(orc_db *db);
+/* returns value offset (element index into values) or -1 */
+int64_t orc_hash_get(const orc_db *db, uint64_t key);
+
+/* 2-bit codec, compdna.c:99-127, 228-256 */
+void orc_pack(const uint8_t *codes, int len, uint64_t *seq, int *N /* N[0]=count */);
+void orc_rc(const uint64_t *seq, int seqlen, const int *N, uint64_t *rseq, int *rN);
+
+/* stage 2, -1t1 single end: savekmers.c:2442-3065.
+ * seq must have complen+1 readable words. N = position list, nN entries.
+ * Output: returns 1 if the read is emitted (mapped), 0 otherwise.
+ * out_rc_flag = +-bestScore, out_flag = 0|16, T = template ids (negative =
+ * reverse strand entries of a strand tie), *nT their count. emit_rc = 1 when
+ * the reverse-complemented sequence is the one written to the S2 stream. */
+int orc_scan_se(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                const uint64_t *seq, int seqlen, const int *N, int nN,
+                int *out_rc_flag, int *out_flag, int *T, int *nT, int *emit_rc);
+
+/* batched form over a CSR read set; T_off has n+1 entries on return.
+ * Returns total number of template ids written (<= T_cap) or -needed. */
+int64_t orc_scan_se_batch(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                          int64_t n_reads, const uint64_t *seq, const int64_t *seq_off,
+                          const int32_t *len, const int32_t *N, const int64_t *N_off,
+                          int32_t *rc_flag, int32_t *flag, int64_t *T_off,
+                          int32_t *T, int64_t T_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""Unpack the committed golden fixtures (tests/golden/) into a temp dir."""
+import gzip
+import lzma
+import os
+import shutil
+
+import numpy as np
+
+from kma_amd import formats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _gunzip(path):
+    with gzip.open(path, "rb") as f:
+        return f.read()
+
+
+def reads_from_s1(recs):
+    reads = []
+    for r in recs:
+        codes = formats.unpack_words(r["seq"], r["seqlen"]).copy()
+        if len(r["N"]):
+            codes[r["N"]] = 4
+        reads.append(codes)
+    return reads
+
+
+def load_se(tmp, name="se"):
+    src = os.path.join(GOLD, name)
+    tmp = str(tmp)
+    prefix = os.path.join(tmp, "db")
+    with lzma.open(os.path.join(src, "db.comp.b.xz"), "rb") as f, open(prefix + ".comp.b", "wb") as g:
+        shutil.copyfileobj(f, g)
+    for ext in (".length.b", ".seq.b", ".name"):
+        shutil.copy(os.path.join(src, "db" + ext), prefix + ext)
+    s1 = formats.parse_s1(_gunzip(os.path.join(src, "s1.bin.gz")))
+    s2, n2 = formats.parse_s2(_gunzip(os.path.join(src, "s2.bin.gz")))
+    s2x, _ = formats.parse_s2(_gunzip(os.path.join(src, "s2_ex.bin.gz")))
+    reads = reads_from_s1(s1)
+    return dict(dir=src, prefix=prefix, s1=s1, s2=s2, s2_ex=s2x, n_reads=n2, reads=reads,
+                batch=formats.pack_ragged(reads))
+
+
+def check_scan_against_s2(s1, s2, rc_flag, flag, T_off, T):
+    """Stage-2 result arrays vs the reference S2 tap, keyed by header."""
+    exp = {r["hdr"]: r for r in s2}
+    assert len(exp) == len(s2), "duplicate headers in fixture"
+    seen = 0
+    for i, r in enumerate(s1):
+        got_T = T[T_off[i]:T_off[i + 1]]
+        e = exp.get(r["hdr"])
+        if e is None:
+            assert len(got_T) == 0, f"read {r['hdr']} mapped but reference dropped it"
+            continue
+        seen += 1
+        assert len(got_T) > 0, f"read {r['hdr']} unmapped but reference mapped it"
+        assert e["rc_flag"] == rc_flag[i], (r["hdr"], e["rc_flag"], rc_flag[i])
+        assert e["flag"] == flag[i], (r["hdr"], e["flag"], flag[i])
+        assert np.array_equal(e["T"], got_T), (r["hdr"], e["T"], got_T)
+    assert seen == len(s2)
+    return seen

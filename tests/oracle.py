@@ -1,0 +1,90 @@
+"""ctypes view of oracle/libkma_oracle.so -- the CPU checker (test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libkma_oracle.so")
+REF_KMA = os.path.join(ORACLE_DIR, "_ref", "kma")
+
+
+class Rewards(C.Structure):
+    _fields_ = [("M", C.c_int), ("MM", C.c_int), ("U", C.c_int), ("W1", C.c_int),
+                ("Wl", C.c_int), ("Mn", C.c_int), ("PE", C.c_int), ("d", (C.c_int * 5) * 5)]
+
+
+def _build():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _build()
+        L = C.CDLL(LIB)
+        L.orc_db_load.restype = C.c_void_p
+        L.orc_db_load.argtypes = [C.c_char_p]
+        L.orc_db_free.argtypes = [C.c_void_p]
+        L.orc_default_rewards.argtypes = [C.POINTER(Rewards)]
+        L.orc_hash_get.restype = C.c_int64
+        L.orc_hash_get.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_scan_se_batch.restype = C.c_int64
+        L.orc_scan_se_batch.argtypes = [C.c_void_p, C.POINTER(Rewards), C.c_int, C.c_int64] + [C.c_void_p] * 9 + [C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleDB:
+    def __init__(self, prefix):
+        self.h = lib().orc_db_load(prefix.encode())
+        if not self.h:
+            raise RuntimeError(f"oracle: cannot load index {prefix}")
+        self.rw = Rewards()
+        lib().orc_default_rewards(C.byref(self.rw))
+
+    def close(self):
+        if self.h:
+            lib().orc_db_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def hash_get(self, key):
+        return lib().orc_hash_get(self.h, int(key))
+
+    def scan_se(self, batch, exhaustive=0, t_cap=None):
+        """-> rc_flag[n], flag[n], T_off[n+1], T[...] (numpy)."""
+        n = batch.n
+        rc_flag = np.zeros(n, np.int32)
+        flag = np.zeros(n, np.int32)
+        T_off = np.zeros(n + 1, np.int64)
+        cap = t_cap or max(1024, 64 * n)
+        while True:
+            T = np.zeros(cap, np.int32)
+            seq = np.ascontiguousarray(batch.seq)
+            Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32))
+            r = lib().orc_scan_se_batch(self.h, C.byref(self.rw), exhaustive, n, _p(seq), _p(batch.seq_off),
+                                        _p(batch.length), _p(Nn), _p(batch.N_off),
+                                        _p(rc_flag), _p(flag), _p(T_off), _p(T), cap)
+            if r >= 0:
+                return rc_flag, flag, T_off, T[:r]
+            cap = -r + 16
