@@ -1,0 +1,164 @@
+/* kmahip.h -- C ABI of libkmahip.so: the MI355X (gfx950) implementation of KMA's
+ * seed-and-extend mapping core (stage 2 "k-mer scan" and stage 3a "alignment
+ * score"), batched.  Plain C types only; every function returns 0 on success or
+ * a negative KMAHIP_E* code (never exit()s; the reference's ERROR() ->
+ * exit(errno) convention, pherror.h:27, is left to the calling host program).
+ *
+ * What each entry point replaces in the reference (file:line into KMA 1.5.1):
+ *   kmahip_db_open            hashMapKMA_load           hashmapkma.c:275-455
+ *                             load_DBs_KMA + seq_indexes runkma.c:160-220
+ *                             alignLoad_fly/hashMapCCI_load (lazy per template)
+ *                                                        hashmapcci.c:470-505,616
+ *   kmahip_scan_se[_dev]      save_kmers_batch body:    kmers.h:22, kmers.c:51-290
+ *                             worker loop save_kmers_threaded savekmers.c:94-271
+ *                             with kmerScan = save_kmers (savekmers.h:50,
+ *                             savekmers.c:2442-3065) and hashMap_get
+ *                             (hashmapkma.h:59, hashmapkma.c:149-178); the
+ *                             result arrays carry the S2 record fields that
+ *                             print_ankers writes (ankers.c:30-50)
+ *   kmahip_align_se[_dev]     alnFrags_threaded body (alnfrags.c:2150-2294) with
+ *                             alnFragsSE (alnfrags.c:1052-1218): KMA_score
+ *                             (align.h:33, align.c:509-748), chainSeeds
+ *                             (chain.h:39, chain.c:79-260), NW_score /
+ *                             NW_band_score (nw.h:62-63, nw.c:642-1188),
+ *                             update_Scores (updatescores.c:203-298)
+ *   kmahip_allreduce_scores   (new) SUM of alignment_scores/uniq_alignment_scores
+ *                             across read shards before runConClave
+ *                             (runkma.c:563-594); see INTEGRATION.md
+ *
+ * Ownership: the caller owns every host and device buffer it passes in; the
+ * library owns the database image in HBM and its private workspaces.
+ * Threading: one kmahip_db may be used from several host threads as long as
+ * each call uses its own kmahip_ws (workspace) and stream.
+ */
+#ifndef KMAHIP_H
+#define KMAHIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMAHIP_OK            0
+#define KMAHIP_EINVAL       -1  /* bad argument */
+#define KMAHIP_EIO          -2  /* cannot read an index file */
+#define KMAHIP_EFORMAT      -3  /* index variant not supported (megamap, k>16 keys, flag!=0) */
+#define KMAHIP_ENOMEM       -4  /* host or device allocation failed */
+#define KMAHIP_EDEVICE      -5  /* HIP runtime error (see kmahip_last_error) */
+#define KMAHIP_EOVERFLOW    -6  /* an output capacity given by the caller was too small */
+
+typedef struct kmahip_db kmahip_db;
+typedef struct kmahip_ws kmahip_ws;
+
+/* scoring constants: Penalties, penalties.h:22-33 (d is the 5x5 substitution
+ * matrix built at kma.c:1307-1328) */
+typedef struct kmahip_rewards {
+	int32_t M, MM, U, W1, Wl, Mn, PE;
+	int32_t d[5][5];
+} kmahip_rewards;
+
+/* run parameters (the subset of kma.c flags the path reads) */
+typedef struct kmahip_params {
+	kmahip_rewards rw;
+	int32_t exhaustive;   /* -ex_mode */
+	int32_t minlen;       /* -ml, default 16 */
+	int32_t mq;           /* -mq, default 0 */
+	double scoreT;        /* -mrs, default 0.5 */
+	double mrc;           /* -mrc, default 0.0 */
+	double minFrac;       /* 1.0 */
+} kmahip_params;
+
+typedef struct kmahip_db_info {
+	uint32_t DB_size;     /* templates + 1 (ids are 1-based) */
+	uint32_t kmersize;
+	uint64_t n_kmers;     /* distinct k-mers */
+	uint64_t n_values;    /* elements in the value-list array */
+	uint64_t hash_bytes;  /* bytes of the probe table in HBM */
+	uint64_t total_bytes; /* all DB bytes resident in HBM */
+	uint64_t tseq_words;  /* 2-bit template store, u64 words */
+} kmahip_db_info;
+
+/* A batch of 2-bit packed reads (CompDNA, compdna.h:23-30), CSR layout.
+ * seq: u64 words, 32 bases per word MSB-first, N packed as A; each read is
+ * followed by at least one readable pad word (getKmer_macro reads word+1,
+ * stdnuc.h:27-30).  N: sorted N positions.  All pointers are HOST pointers for
+ * the plain calls and DEVICE pointers for the *_dev calls. */
+typedef struct kmahip_reads {
+	int64_t n_reads;
+	const uint64_t *seq;
+	const int64_t *seq_off;   /* n_reads+1 word offsets */
+	const int32_t *len;       /* n_reads */
+	const int32_t *N;
+	const int64_t *N_off;     /* n_reads+1 */
+	int64_t seq_words;        /* total words in seq (host calls: bytes to stage) */
+	int64_t N_total;
+} kmahip_reads;
+
+/* Stage-2 result, one entry per read = the S2 record fields (ankers.c:30-50):
+ * rc_flag = +-best k-mer score (negative: both strands tie), flag = 0 | 16
+ * (16: the reverse-complemented read is the one passed on), T = candidate
+ * template ids (negative id: reverse strand entry of a tie). Reads the
+ * reference would not emit have T_off[i+1] == T_off[i]. */
+typedef struct kmahip_cands {
+	int32_t *rc_flag;     /* n_reads */
+	int32_t *flag;        /* n_reads */
+	int64_t *T_off;       /* n_reads + 1 */
+	int32_t *T;           /* T_cap */
+	int64_t T_cap;
+} kmahip_cands;
+
+/* Stage-3a result per read (what update_Scores keeps, updatescores.c:203-298,
+ * = one frag_raw record): hits in candidate order. */
+typedef struct kmahip_hits {
+	int32_t *n_hits;      /* n_reads: 0 = unmapped after alignment */
+	int32_t *best_score;  /* n_reads: best_read_score */
+	int64_t *H_off;       /* n_reads + 1 (same shape as T_off) */
+	int32_t *tmpl;        /* H_cap: signed template id */
+	int32_t *score;       /* H_cap */
+	int32_t *start;       /* H_cap */
+	int32_t *end;         /* H_cap */
+	int64_t H_cap;
+} kmahip_hits;
+
+void kmahip_default_params(kmahip_params *p);
+const char *kmahip_last_error(void);
+
+/* device selection: one process per GPU (LOCAL_RANK), call before db_open */
+int kmahip_init(int device);
+
+int kmahip_db_open(const char *prefix, kmahip_db **out);
+void kmahip_db_close(kmahip_db *db);
+int kmahip_db_get_info(const kmahip_db *db, kmahip_db_info *info);
+
+int kmahip_ws_create(kmahip_db *db, kmahip_ws **out);
+void kmahip_ws_destroy(kmahip_ws *ws);
+
+/* Stage 2, single-end `-1t1`.  Host buffers in, host buffers out (PCIe
+ * inclusive).  Returns KMAHIP_EOVERFLOW if T_cap is too small; T_off[n] then
+ * holds the needed capacity. */
+int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
+                   const kmahip_params *p, kmahip_cands *out);
+/* Same with everything resident in HBM; asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream). */
+int kmahip_scan_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
+                       const kmahip_params *p, kmahip_cands *out, void *stream);
+/* status of the last *_dev call on this workspace after the stream has been
+ * synchronised: 0 or KMAHIP_EOVERFLOW */
+int kmahip_ws_status(kmahip_ws *ws, void *stream);
+
+/* Algorithmic work counters of the last scan on this workspace (read after a
+ * sync): probes issued, probe-table bytes they touched, value-list bytes. */
+typedef struct kmahip_scan_stats {
+	uint64_t probes;
+	uint64_t value_elems;
+	uint64_t active_strands;
+} kmahip_scan_stats;
+/* counting costs atomics in the kernel: off by default */
+int kmahip_scan_set_stats(kmahip_ws *ws, int on);
+int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

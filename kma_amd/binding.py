@@ -1,0 +1,165 @@
+"""ctypes binding of libkmahip.so (include/kmahip.h) -- the only way Python
+reaches the HIP path.  There is no CPU fallback: if the shared library is not
+built (python -c 'import __graft_entry__ as g; g.build()') import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmahip.so")
+
+
+class Rewards(C.Structure):
+    _fields_ = [("M", C.c_int32), ("MM", C.c_int32), ("U", C.c_int32), ("W1", C.c_int32),
+                ("Wl", C.c_int32), ("Mn", C.c_int32), ("PE", C.c_int32), ("d", (C.c_int32 * 5) * 5)]
+
+
+class Params(C.Structure):
+    _fields_ = [("rw", Rewards), ("exhaustive", C.c_int32), ("minlen", C.c_int32), ("mq", C.c_int32),
+                ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double)]
+
+
+class DBInfo(C.Structure):
+    _fields_ = [("DB_size", C.c_uint32), ("kmersize", C.c_uint32), ("n_kmers", C.c_uint64),
+                ("n_values", C.c_uint64), ("hash_bytes", C.c_uint64), ("total_bytes", C.c_uint64),
+                ("tseq_words", C.c_uint64)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("len", C.c_void_p),
+                ("N", C.c_void_p), ("N_off", C.c_void_p), ("seq_words", C.c_int64), ("N_total", C.c_int64)]
+
+
+class Cands(C.Structure):
+    _fields_ = [("rc_flag", C.c_void_p), ("flag", C.c_void_p), ("T_off", C.c_void_p), ("T", C.c_void_p),
+                ("T_cap", C.c_int64)]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64)]
+
+
+class KmaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KmaHipError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.kmahip_last_error.restype = C.c_char_p
+        L.kmahip_default_params.argtypes = [C.POINTER(Params)]
+        L.kmahip_default_params.restype = None
+        L.kmahip_init.argtypes = [C.c_int]
+        L.kmahip_db_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.kmahip_db_close.argtypes = [C.c_void_p]
+        L.kmahip_db_close.restype = None
+        L.kmahip_db_get_info.argtypes = [C.c_void_p, C.POINTER(DBInfo)]
+        L.kmahip_ws_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.kmahip_ws_destroy.argtypes = [C.c_void_p]
+        L.kmahip_ws_destroy.restype = None
+        L.kmahip_scan_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands)]
+        L.kmahip_scan_se_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.c_void_p]
+        L.kmahip_ws_status.argtypes = [C.c_void_p, C.c_void_p]
+        L.kmahip_scan_set_stats.argtypes = [C.c_void_p, C.c_int]
+        L.kmahip_scan_get_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats), C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise KmaHipError(f"kmahip error {rc}: {lib().kmahip_last_error().decode()}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params() -> Params:
+    p = Params()
+    lib().kmahip_default_params(C.byref(p))
+    return p
+
+
+class KmaHipDB:
+    """An index resident in HBM + one workspace."""
+
+    def __init__(self, prefix: str, device: int = 0):
+        L = lib()
+        _check(L.kmahip_init(device))
+        self.h = C.c_void_p()
+        _check(L.kmahip_db_open(prefix.encode(), C.byref(self.h)))
+        self.ws = C.c_void_p()
+        _check(L.kmahip_ws_create(self.h, C.byref(self.ws)))
+        self.info = DBInfo()
+        _check(L.kmahip_db_get_info(self.h, C.byref(self.info)))
+        self.params = default_params()
+
+    def close(self):
+        if getattr(self, "ws", None):
+            lib().kmahip_ws_destroy(self.ws)
+            self.ws = None
+        if getattr(self, "h", None):
+            lib().kmahip_db_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host buffers in / out ------------------------------------------------
+    def scan_se(self, batch, exhaustive=0, t_cap=None):
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N))
+        rc_flag = np.zeros(max(n, 1), np.int32)
+        flag = np.zeros(max(n, 1), np.int32)
+        T_off = np.zeros(n + 1, np.int64)
+        cap = t_cap or max(1024, 8 * n)
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        for _ in range(4):
+            T = np.zeros(cap, np.int32)
+            out = Cands(_p(rc_flag), _p(flag), _p(T_off), _p(T), cap)
+            rc = lib().kmahip_scan_se(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out))
+            if rc == -6:  # KMAHIP_EOVERFLOW
+                cap = max(cap * 2, int(T_off[n]) + 16)
+                continue
+            _check(rc)
+            return rc_flag[:n], flag[:n], T_off, T[:T_off[n]]
+        raise KmaHipError("scan_se: output capacity kept overflowing")
+
+    # -- device resident (torch tensors) -----------------------------------------
+    def scan_se_dev(self, seq, seq_off, length, N, N_off, rc_flag, flag, T_off, T, exhaustive=0, stream=None):
+        """All arguments are CUDA(HIP) torch tensors; asynchronous on `stream`."""
+        n = length.numel()
+        r = Reads(n, seq.data_ptr(), seq_off.data_ptr(), length.data_ptr(), N.data_ptr(), N_off.data_ptr(),
+                  seq.numel(), N.numel())
+        out = Cands(rc_flag.data_ptr(), flag.data_ptr(), T_off.data_ptr(), T.data_ptr(), T.numel())
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        _check(lib().kmahip_scan_se_dev(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.c_void_p(stream or 0)))
+
+    def status(self, stream=None):
+        _check(lib().kmahip_ws_status(self.ws, C.c_void_p(stream or 0)))
+
+    def set_stats(self, on: bool):
+        _check(lib().kmahip_scan_set_stats(self.ws, int(on)))
+
+    def get_stats(self, stream=None) -> ScanStats:
+        st = ScanStats()
+        _check(lib().kmahip_scan_get_stats(self.ws, C.byref(st), C.c_void_p(stream or 0)))
+        return st

@@ -1,0 +1,163 @@
+// db.hip -- host side of libkmahip: reads the reference's on-disk index
+// (<prefix>.comp.b/.length.b/.seq.b; written by `kma index`,
+// hashmapkma.c:722-775) and lays the database out in HBM for the gfx950 kernels.
+#include "kmahip_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void kmahip_set_error(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char *kmahip_last_error(void) { return g_err; }
+
+extern "C" void kmahip_default_params(kmahip_params *p) {
+	// kma.c:327-336 defaults; MM = (Ts + Tv - 1) / 2 (kma.c:1308); d: kma.c:1309-1328
+	const int Ts = -2, Tv = -2;
+	memset(p, 0, sizeof *p);
+	p->rw.M = 1; p->rw.U = -1; p->rw.W1 = -3; p->rw.Wl = -6; p->rw.Mn = 0; p->rw.PE = 7;
+	p->rw.MM = (Ts + Tv - 1) / 2;
+	for(int i = 0; i < 4; ++i) {
+		for(int j = 0; j < 4; ++j) p->rw.d[i][j] = Tv;
+		p->rw.d[i][4] = p->rw.Mn;
+		p->rw.d[i][i ^ 2] = Ts;
+		p->rw.d[i][i] = p->rw.M;
+	}
+	for(int j = 0; j < 5; ++j) p->rw.d[4][j] = p->rw.Mn;
+	p->rw.d[4][4] = 0;
+	p->exhaustive = 0; p->minlen = 16; p->mq = 0;
+	p->scoreT = 0.5; p->mrc = 0.0; p->minFrac = 1.0;
+}
+
+static int g_device = 0;
+
+extern "C" int kmahip_init(int device) {
+	int n = 0;
+	HIP_TRY(hipGetDeviceCount(&n));
+	if(device < 0 || device >= n) { kmahip_set_error("device %d out of range (%d visible)", device, n); return KMAHIP_EINVAL; }
+	HIP_TRY(hipSetDevice(device));
+	g_device = device;
+	return KMAHIP_OK;
+}
+
+template <class T>
+static int upload(kmahip_db *db, const T *src, size_t count, const T **dst) {
+	void *d = nullptr;
+	size_t bytes = (count ? count : 1) * sizeof(T);
+	HIP_TRY(hipMalloc(&d, bytes));
+	db->allocs.push_back(d);
+	if(count) HIP_TRY(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+	*dst = (const T *) d;
+	db->info.total_bytes += bytes;
+	return KMAHIP_OK;
+}
+
+static bool read_exact(FILE *f, void *dst, size_t bytes) { return fread(dst, 1, bytes, f) == bytes; }
+
+static inline uint32_t home_bucket(uint32_t key, uint32_t nb_log2) {
+	return (uint32_t) (key * 0x9E3779B1u) >> (32 - nb_log2);
+}
+
+extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
+	if(!prefix || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	*out = nullptr;
+	std::string base(prefix);
+	FILE *f = fopen((base + ".comp.b").c_str(), "rb");
+	if(!f) { kmahip_set_error("cannot open %s.comp.b", prefix); return KMAHIP_EIO; }
+	uint32_t h32[3];
+	uint64_t h64[5];
+	if(!read_exact(f, h32, 12) || !read_exact(f, h64, 40)) { fclose(f); kmahip_set_error("short header in %s.comp.b", prefix); return KMAHIP_EIO; }
+	const uint32_t DB_size = h32[0], mlen = h32[1];
+	const uint64_t size = h64[1], n = h64[2], v_index = h64[3];
+	if(mlen == 0 || mlen > 16) { fclose(f); kmahip_set_error("k-mer length %u needs 64-bit keys: not supported", mlen); return KMAHIP_EFORMAT; }
+	const uint64_t kmask = (1ull << (2 * mlen)) - 1;
+	if(size - 1 == kmask) { fclose(f); kmahip_set_error("direct-address (megamap) index not supported"); return KMAHIP_EFORMAT; }
+	if(size < n || n > 0xFFFFFFFFull || v_index >= 0xFFFFFFFFull || n == 0) { fclose(f); kmahip_set_error("index too large or old format"); return KMAHIP_EFORMAT; }
+
+	// exist[] is only the reference's bucket directory: skipped
+	if(fseek(f, (long) (size * 4), SEEK_CUR)) { fclose(f); return KMAHIP_EIO; }
+	const bool u16 = DB_size < 65535; // hashmapkma.c:340-348
+	std::vector<uint8_t> values(v_index * (u16 ? 2 : 4));
+	std::vector<uint32_t> keys(n + 1), vidx(n);
+	uint32_t tail[2] = {mlen, 0};
+	bool ok = read_exact(f, values.data(), values.size()) && read_exact(f, keys.data(), (n + 1) * 4) && read_exact(f, vidx.data(), n * 4);
+	if(ok && read_exact(f, &tail[0], 4)) ok = read_exact(f, &tail[1], 4);
+	fclose(f);
+	if(!ok) { kmahip_set_error("truncated %s.comp.b", prefix); return KMAHIP_EIO; }
+	if(tail[1] != 0) { kmahip_set_error("minimizer / homopolymer-compressed index (flag %u) not supported", tail[1]); return KMAHIP_EFORMAT; }
+	if(tail[0] != mlen) { kmahip_set_error("kmersize %u != mlen %u not supported", tail[0], mlen); return KMAHIP_EFORMAT; }
+
+	kmahip_db *db = new kmahip_db();
+	memset(&db->info, 0, sizeof db->info);
+	db->device = g_device;
+	db->info.DB_size = DB_size; db->info.kmersize = tail[0]; db->info.n_kmers = n; db->info.n_values = v_index;
+
+	// probe table: >= 2n slots -> load factor in (0.25, 0.5]
+	uint32_t nb_log2 = 4;
+	while(((uint64_t) KMAHIP_BUCKET_SLOTS << nb_log2) < 2 * n) ++nb_log2;
+	if(nb_log2 > 31) { delete db; kmahip_set_error("index too large"); return KMAHIP_EFORMAT; }
+	const uint64_t nb = 1ull << nb_log2;
+	std::vector<uint2> slots(nb * KMAHIP_BUCKET_SLOTS, make_uint2(0u, KMAHIP_EMPTY_VI));
+	for(uint64_t i = 0; i < n; ++i) {
+		uint64_t b = home_bucket(keys[i], nb_log2);
+		for(;;) {
+			uint2 *s = &slots[b * KMAHIP_BUCKET_SLOTS];
+			int j = 0;
+			while(j < KMAHIP_BUCKET_SLOTS && s[j].y != KMAHIP_EMPTY_VI) ++j;
+			if(j < KMAHIP_BUCKET_SLOTS) { s[j] = make_uint2(keys[i], vidx[i]); break; }
+			b = (b + 1) & (nb - 1);
+		}
+	}
+	db->info.hash_bytes = slots.size() * sizeof(uint2);
+
+	int rc;
+	DevDB &d = db->dev;
+	memset(&d, 0, sizeof d);
+	d.DB_size = DB_size; d.kmersize = tail[0]; d.mlen = mlen; d.nb_log2 = nb_log2; d.values_u16 = u16;
+	if((rc = upload(db, slots.data(), slots.size(), &d.slots))) { kmahip_db_close(db); return rc; }
+	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index, &d.values16);
+	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index, &d.values32);
+	if(rc) { kmahip_db_close(db); return rc; }
+
+	// template lengths + 2-bit template store (needed by stage 3a)
+	f = fopen((base + ".length.b").c_str(), "rb");
+	if(f) {
+		int32_t cnt = 0;
+		if(!read_exact(f, &cnt, 4) || (uint32_t) cnt != DB_size) { fclose(f); kmahip_db_close(db); kmahip_set_error("bad %s.length.b", prefix); return KMAHIP_EIO; }
+		db->h_tlen.resize(DB_size);
+		if(!read_exact(f, db->h_tlen.data(), (size_t) DB_size * 4)) { fclose(f); kmahip_db_close(db); return KMAHIP_EIO; }
+		fclose(f);
+		std::vector<int64_t> off(DB_size + 1);
+		off[0] = 0; if(DB_size > 0) off[1] = 0;
+		for(uint32_t i = 2; i <= DB_size; ++i) off[i] = off[i - 1] + (db->h_tlen[i - 1] >> 5) + 1; // runkma.c:214-220
+		std::vector<uint64_t> tseq((size_t) off[DB_size] + 2, 0);
+		f = fopen((base + ".seq.b").c_str(), "rb");
+		if(!f || !read_exact(f, tseq.data(), (size_t) off[DB_size] * 8)) { if(f) fclose(f); kmahip_db_close(db); kmahip_set_error("bad %s.seq.b", prefix); return KMAHIP_EIO; }
+		fclose(f);
+		db->info.tseq_words = off[DB_size];
+		if((rc = upload(db, db->h_tlen.data(), db->h_tlen.size(), &d.tlen)) ||
+		   (rc = upload(db, tseq.data(), tseq.size(), &d.tseq)) ||
+		   (rc = upload(db, off.data(), off.size(), &d.tseq_off))) { kmahip_db_close(db); return rc; }
+	}
+	*out = db;
+	return KMAHIP_OK;
+}
+
+extern "C" void kmahip_db_close(kmahip_db *db) {
+	if(!db) return;
+	for(void *p : db->allocs) (void) hipFree(p);
+	delete db;
+}
+
+extern "C" int kmahip_db_get_info(const kmahip_db *db, kmahip_db_info *info) {
+	if(!db || !info) return KMAHIP_EINVAL;
+	*info = db->info;
+	return KMAHIP_OK;
+}

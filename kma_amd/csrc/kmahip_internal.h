@@ -1,0 +1,73 @@
+// kmahip_internal.h -- shared between the host-side loader and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/kmahip.h"
+
+#define KMAHIP_EMPTY_VI 0xFFFFFFFFu
+#define KMAHIP_BUCKET_SLOTS 4
+
+// Probe table in HBM: open hashing over 32-byte buckets of 4 (key, value_offset)
+// slots. bucket(key) = (key * GOLD) >> (32 - nb_log2); a key lives in the first
+// bucket at or after its home bucket (cyclic) that had a free slot at build
+// time, so a lookup stops at the first bucket holding either the key (hit) or
+// an empty slot (miss). This replaces the reference's three dependent gathers
+// exist[] -> key_index[] -> value_index[] (hashmapkma.c:149-178) by one 32-byte
+// gather in the common case.
+struct DevDB {
+	uint32_t DB_size;
+	uint32_t kmersize;
+	uint32_t mlen;
+	uint32_t nb_log2;
+	uint32_t values_u16;          // 1: values16 valid, 0: values32
+	const uint2 *slots;           // (1 << nb_log2) * 4
+	const uint16_t *values16;     // [cnt, t1..tcnt] lists, offsets = value_index of the index file
+	const uint32_t *values32;
+	const int32_t *tlen;          // DB_size, tlen[0] = kmerindex
+	const uint64_t *tseq;         // 2-bit template store (.seq.b image + pad)
+	const int64_t *tseq_off;      // DB_size + 1 word offsets
+};
+
+struct kmahip_db {
+	DevDB dev;                    // device pointers
+	kmahip_db_info info;
+	int device;
+	std::vector<void *> allocs;   // device allocations owned by the db
+	// host copies needed by host-side stages
+	std::vector<int32_t> h_tlen;
+};
+
+// per-call scratch, grown on demand
+struct kmahip_ws {
+	kmahip_db *db;
+	int64_t cap_reads;
+	// per strand item (2 per read)
+	int32_t *item_score;
+	int32_t *item_n;
+	int64_t *item_off;
+	// candidate pool
+	int32_t *pool;
+	int64_t pool_cap;
+	// counters: [0] pool top, [1] status, [2] n_overflow, [3] probes, [4] value elems, [5] active strands
+	unsigned long long *counters;
+	int64_t *overflow_items;
+	int stats_on;
+	// slow-path dense scratch
+	int32_t *dense;
+	int64_t dense_slots;
+	// scan workspace for CSR offsets
+	int64_t *blk_sums;
+	int64_t blk_cap;
+	// staging for host calls
+	void *stage[8];
+	size_t stage_bytes[8];
+};
+
+void kmahip_set_error(const char *fmt, ...);
+#define HIP_TRY(expr) do { hipError_t e__ = (expr); if(e__ != hipSuccess) { \
+	kmahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return KMAHIP_EDEVICE; } } while(0)
+
+int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
+                          const kmahip_params *p, kmahip_cands *out, hipStream_t stream);
