@@ -158,6 +158,12 @@ typedef struct kmahip_scan_stats {
 int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
 
+/* Kernel timing: when on, every *_dev call records a HIP event pair around its
+ * dominant kernel (scan_se_kernel) on the caller's stream; get_timing waits
+ * for them, returns the summed milliseconds and launch count, and resets. */
+int kmahip_ws_set_timing(kmahip_ws *ws, int on);
+int kmahip_ws_get_timing(kmahip_ws *ws, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

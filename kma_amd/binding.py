@@ -72,6 +72,8 @@ def lib():
         L.kmahip_ws_status.argtypes = [C.c_void_p, C.c_void_p]
         L.kmahip_scan_set_stats.argtypes = [C.c_void_p, C.c_int]
         L.kmahip_scan_get_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats), C.c_void_p]
+        L.kmahip_ws_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.kmahip_ws_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -163,3 +165,11 @@ class KmaHipDB:
         st = ScanStats()
         _check(lib().kmahip_scan_get_stats(self.ws, C.byref(st), C.c_void_p(stream or 0)))
         return st
+
+    def set_timing(self, on: bool):
+        _check(lib().kmahip_ws_set_timing(self.ws, int(on)))
+
+    def get_timing(self):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().kmahip_ws_get_timing(self.ws, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

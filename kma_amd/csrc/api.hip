@@ -17,6 +17,10 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->pool); (void) hipFree(ws->counters); (void) hipFree(ws->overflow_items);
 	(void) hipFree(ws->dense); (void) hipFree(ws->blk_sums);
 	for(int i = 0; i < 8; ++i) (void) hipFree(ws->stage[i]);
+	if(ws->events) {
+		for(auto &e : *ws->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+		delete ws->events;
+	}
 	delete ws;
 }
 
@@ -104,5 +108,26 @@ extern "C" int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	const int64_t total = out->T_off[n];
 	if(total > out->T_cap) { kmahip_set_error("T_cap %lld too small, need %lld", (long long) out->T_cap, (long long) total); return KMAHIP_EOVERFLOW; }
 	if(total) HIP_TRY(hipMemcpy(out->T, o.T, (size_t) total * 4, hipMemcpyDeviceToHost));
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_ws_set_timing(kmahip_ws *ws, int on) {
+	if(!ws) return KMAHIP_EINVAL;
+	ws->timing_on = on;
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_ws_get_timing(kmahip_ws *ws, double *total_ms, int64_t *launches) {
+	if(!ws || !total_ms || !launches) return KMAHIP_EINVAL;
+	*total_ms = 0.0; *launches = 0;
+	if(!ws->events) return KMAHIP_OK;
+	for(auto &e : *ws->events) {
+		float ms = 0.f;
+		HIP_TRY(hipEventSynchronize(e.second));
+		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+		*total_ms += ms; *launches += 1;
+		(void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second);
+	}
+	ws->events->clear();
 	return KMAHIP_OK;
 }

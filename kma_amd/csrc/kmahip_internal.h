@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/kmahip.h"
 
@@ -54,6 +55,8 @@ struct kmahip_ws {
 	unsigned long long *counters;
 	int64_t *overflow_items;
 	int stats_on;
+	int timing_on;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events;
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;

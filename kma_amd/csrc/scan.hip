@@ -573,8 +573,18 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	}
 	const int64_t items = 2 * n;
 	const unsigned grid = (unsigned) ((items + ITEMS - 1) / ITEMS);
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if(ws->timing_on) {
+		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+		HIP_TRY(hipEventRecord(ev0, stream));
+	}
 	if(ws->stats_on) hipLaunchKernelGGL(scan_se_kernel<true>, dim3(grid), dim3(THREADS), 0, stream, A);
 	else hipLaunchKernelGGL(scan_se_kernel<false>, dim3(grid), dim3(THREADS), 0, stream, A);
+	if(ws->timing_on) {
+		HIP_TRY(hipEventRecord(ev1, stream));
+		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+		ws->events->push_back({ev0, ev1});
+	}
 	{
 		const unsigned dgrid = (unsigned) ((ws->dense_slots + 63) / 64);
 		hipLaunchKernelGGL(scan_dense_kernel, dim3(dgrid), dim3(64), 0, stream, A);
