@@ -1,0 +1,596 @@
+/* oracle/align.c -- TEST INFRASTRUCTURE (see kma_oracle.h).
+ * CPU restatement of stage 3a for single-end reads:
+ *   per-template position index   hashmapcci.c:95-199,470-505 (semantics only:
+ *                                 k-mer -> ascending occurrence list, poly-A
+ *                                 k-mer 0 never indexed :414-417)
+ *   MEM seeding + stitching       KMA_score, align.c:509-748
+ *   tails                         leadTailAln/trailTailAln, align.c:53-212
+ *   chaining                      chainSeeds, chain.c:79-260
+ *   global/semi-global DP         NW_score nw.c:642-890, NW_band_score :892-1188
+ *   per-read filters              alnFragsSE alnfrags.c:1052-1218
+ *   hit selection + accumulators  update_Scores updatescores.c:203-298
+ */
+#include "kma_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int tnuc(const uint64_t *s, int pos) { return (int) ((s[pos >> 5] << ((pos & 31) << 1)) >> 62); }
+
+static inline uint64_t kmer_at(const uint64_t *seq, int pos, int k) {
+	int ip = (pos & 31) << 1, w = pos >> 5, sh = 64 - (k << 1);
+	if(ip <= sh) return (seq[w] << ip) >> sh;
+	return ((seq[w] << ip) | (seq[w + 1] >> (64 - ip))) >> sh;
+}
+
+/* ---- per-template occurrence index ---------------------------------------- */
+typedef struct { uint64_t key; int pos; } occ;
+typedef struct { occ *o; int n; } tindex;
+
+static int occ_cmp(const void *a, const void *b) {
+	const occ *x = a, *y = b;
+	if(x->key != y->key) return x->key < y->key ? -1 : 1;
+	return x->pos - y->pos;
+}
+
+static void tindex_build(tindex *ix, const uint64_t *tseq, int tlen, int k) {
+	int n = tlen - k + 1, c = 0;
+	if(n < 0) n = 0;
+	ix->o = malloc(sizeof(occ) * (size_t) (n ? n : 1));
+	for(int i = 0; i < n; ++i) {
+		uint64_t key = kmer_at(tseq, i, k);
+		if(key == 0) continue;                 /* hashmapcci.c:414-417 */
+		ix->o[c].key = key; ix->o[c].pos = i + 1; ++c;
+	}
+	qsort(ix->o, (size_t) c, sizeof(occ), occ_cmp);
+	ix->n = c;
+}
+
+/* first index of key, *cnt = occurrences */
+static int tindex_find(const tindex *ix, uint64_t key, int *cnt) {
+	int lo = 0, hi = ix->n;
+	while(lo < hi) { int mid = (lo + hi) >> 1; if(ix->o[mid].key < key) lo = mid + 1; else hi = mid; }
+	int e = lo;
+	while(e < ix->n && ix->o[e].key == key) ++e;
+	*cnt = e - lo;
+	return lo;
+}
+
+/* ---- DP workspace --------------------------------------------------------- */
+typedef struct {
+	int *D[2], *P[2]; long rowcap;
+	uint8_t *E; long ecap;
+	/* MEM arrays */
+	int *tS, *tE, *qS, *qE, *w, *sc, *nx; int pcap, plen;
+} aws;
+
+static void aws_rows(aws *w, long need) {
+	if(w->rowcap > need) return;
+	long cap = need * 2 + 64;
+	for(int i = 0; i < 2; ++i) { free(w->D[i]); free(w->P[i]); w->D[i] = calloc((size_t) cap, sizeof(int)); w->P[i] = calloc((size_t) cap, sizeof(int)); }
+	w->rowcap = cap;
+}
+static void aws_E(aws *w, long need) {
+	if(w->ecap > need) return;
+	free(w->E); w->ecap = need * 2 + 64; w->E = calloc((size_t) w->ecap, 1);
+}
+static void aws_points(aws *w, int need) {
+	if(w->pcap > need) return;
+	int cap = need * 2 + 64;
+	w->tS = realloc(w->tS, sizeof(int) * (size_t) cap); w->tE = realloc(w->tE, sizeof(int) * (size_t) cap);
+	w->qS = realloc(w->qS, sizeof(int) * (size_t) cap); w->qE = realloc(w->qE, sizeof(int) * (size_t) cap);
+	w->w = realloc(w->w, sizeof(int) * (size_t) cap); w->sc = realloc(w->sc, sizeof(int) * (size_t) cap);
+	w->nx = realloc(w->nx, sizeof(int) * (size_t) cap);
+	w->pcap = cap;
+}
+
+typedef struct { int score, len, pos, match, tGaps, qGaps; } aln;
+
+/* call counters for tests: [0] full NW, [1] banded NW, [2] DP cells, [3] chain calls */
+int64_t orc_counters[4] = {0, 0, 0, 0};
+
+static aln degenerate(int t_len, int q_len, const orc_rewards *rw) {
+	/* nw.c:662-684 */
+	aln s = {0, 0, 0, 0, 0, 0};
+	if(t_len == q_len) return s;
+	if(t_len == 0) { s.len = q_len; s.tGaps = q_len; s.score = rw->W1 + (q_len - 1) * rw->U; }
+	else { s.len = t_len; s.qGaps = t_len; s.score = rw->W1 + (t_len - 1) * rw->U; }
+	return s;
+}
+
+/* walk the move matrix (nw.c:846-886): moves 1 diag, 2/3 gap in template
+ * (query consumed), 4/5 gap in query (template consumed); a gap run ends on the
+ * first cell carrying EITHER "may open" bit (16 | 32). stride = row pitch,
+ * dn = column change per template step (0 full matrix, -1 banded). */
+static void walk(const uint8_t *E, long stride, int m, int n, int dn, aln *s) {
+	const uint8_t *row = E + (long) m * stride;
+	s->len = s->match = s->tGaps = s->qGaps = 0;
+	while(row[n] != 0) {
+		int mv = row[n] & 7;
+		if(mv == 1) {
+			++s->match; row += stride; n += 1 + dn;
+		} else if(mv >= 4) {
+			while(!(row[n] >> 4)) { row += stride; n += dn; ++s->len; ++s->qGaps; }
+			++s->qGaps; row += stride; n += dn;
+		} else {
+			while(!(row[n] >> 3)) { ++n; ++s->len; ++s->tGaps; }
+			++s->tGaps; ++n;
+		}
+		++s->len;
+	}
+}
+
+static aln nw_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int k, int t_s, int t_e, int q_s, int q_e,
+                    const orc_rewards *rw, int tlen_total) {
+	/* nw.c:642-890 */
+	const int W1 = rw->W1, U = rw->U;
+	int t_len = t_e - t_s, q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	const uint8_t *q = qorg + q_s;
+	if(t_len == 0 || q_len == 0) return degenerate(t_len, q_len, rw);
+	orc_counters[0]++; orc_counters[2] += (int64_t) t_len * q_len;
+	aws_rows(w, q_len + 2);
+	aws_E(w, (long) (q_len + 2) * (t_len + 2));
+	const long pitch = q_len + 1;
+	const int low = (t_len + q_len) * (rw->MM + U + W1);
+	int *Dc = w->D[0], *Dp = w->D[1], *Pc = w->P[0], *Pp = w->P[1];
+	uint8_t *E = w->E, *Er = E + pitch * t_len; /* boundary row m = t_len */
+	aln s; s.pos = 0; s.score = low;
+	/* last column + last row by mode (nw.c:703-750) */
+	for(int m = 0; m < t_len; ++m) E[pitch * m + q_len] = (0 < k) ? 0 : 5;
+	if(!(0 < k)) E[pitch * (t_len - 1) + q_len] = 36;
+	if(k == 2) {
+		for(int n = q_len; n >= 0; --n) { Dp[n] = 0; Pp[n] = low; Er[n] = 0; }
+	} else {
+		for(int n = q_len - 1; n >= 0; --n) { Dp[n] = W1 + (q_len - 1 - n) * U; Pp[n] = low; Er[n] = 3; }
+		Er[q_len - 1] = 18; Er[q_len] = 0; Dp[q_len] = 0; Pp[q_len] = 0;
+	}
+	int best_m = 0;
+	int npos = t_e - 1;
+	for(int m = t_len - 1; m >= 0; --m, --npos) {
+		if(npos < 0) npos = tlen_total - 1;
+		uint8_t *e = E + pitch * m;
+		Dc[q_len] = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+		int Qprev = low;
+		const int tn = tnuc(tseq, npos);
+		for(int n = q_len - 1; n >= 0; --n) {
+			uint8_t cell = 0, mv;
+			int Q = Dc[n + 1] + W1;
+			int P = Dp[n] + W1;
+			int D;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+			x = Pp[n] + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+			x = Dp[n + 1] + rw->d[tn][q[n]];
+			if(D <= x) { D = x; cell |= 1; } else cell |= mv;
+			Dc[n] = D; Pc[n] = P; e[n] = cell; Qprev = Q;
+		}
+		if(k < 0 && s.score < Dc[0]) { s.score = Dc[0]; best_m = m; }
+		int *t = Dc; Dc = Dp; Dp = t; t = Pc; Pc = Pp; Pp = t;
+	}
+	int sm = 0, sn = 0;
+	if(k < 0) {
+		sm = best_m;
+		if(k == -2) {
+			for(int n = 0; n < q_len; ++n) if(s.score <= Dp[n]) { s.score = Dp[n]; sm = 0; sn = n; }
+		}
+	} else {
+		s.score = Dp[0];
+	}
+	walk(E, pitch, sm, sn, 0, &s);
+	return s;
+}
+
+static aln nw_band_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int k, int t_s, int t_e, int q_s, int q_e,
+                         int band, const orc_rewards *rw, int tlen_total) {
+	/* nw.c:892-1188. Band columns are indexed relative to a centre diagonal
+	 * that moves one query position per template row; column n of row m is
+	 * column n-1 of row m+1. */
+	const int W1 = rw->W1, U = rw->U;
+	int t_len = t_e - t_s, q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	const uint8_t *q = qorg + q_s;
+	if(t_len == 0 || q_len == 0) return degenerate(t_len, q_len, rw);
+	if(band & 1) ++band;
+	orc_counters[1]++; orc_counters[2] += (int64_t) t_len * (band + 1);
+	const int half = band >> 1, bq = band + 1;
+	aws_rows(w, (long) band * 2 + 8);
+	aws_E(w, (long) (band + 3) * (t_len + 2));
+	const long pitch = bq + 1;
+	const int low = (t_len + q_len) * (rw->MM + U + W1);
+	int *Dc = w->D[0], *Dp = w->D[1], *Pc = w->P[0], *Pp = w->P[1];
+	uint8_t *E = w->E, *Er = E + pitch * t_len;
+	aln s; s.pos = 0; s.score = low;
+	int c = (t_len + q_len) >> 1;
+	int sn = q_len - 1 - (c - half);
+	if(k != 2) {
+		for(int n = sn - 1; n >= 0; --n) { Dp[n] = W1 + (sn - n - 1) * U; Pp[n] = low; Er[n] = 3; }
+		Er[sn - 1] = 18; Er[sn] = 0; Dp[sn] = 0; Pp[sn] = 0;
+	} else {
+		for(int n = sn; n >= 0; --n) { Dp[n] = 0; Pp[n] = low; Er[n] = 0; }
+	}
+	int bm = 0, bn = 0, en = 0, n = 0;
+	int npos = t_e - 1;
+	for(int m = t_len - 1; m >= 0; --m, --npos, --c) {
+		if(npos < 0) npos = tlen_total - 1;
+		uint8_t *e = E + pitch * m;
+		int sq = c + half, eq = c - half;
+		if(eq < 0) { eq = 0; ++en; } else en = 0;
+		int Qprev = low;
+		if(sq < q_len - 1) {
+			sn = bq - 1; Dc[bq] = low; e[bq] = 37;
+		} else {
+			sq = q_len - 1; sn = en + (q_len - eq);
+			Dc[sn] = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			e[sn] = (0 < k) ? 0 : 37;
+			--sn;
+		}
+		const int tn = tnuc(tseq, npos);
+		int qp = sq;
+		for(n = sn; n > en; --qp, --n) {
+			uint8_t cell = 0, mv;
+			int Q = Dc[n + 1] + W1;
+			int P = Dp[n - 1] + W1;
+			int D;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+			x = Pp[n - 1] + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+			x = Dp[n] + rw->d[tn][q[qp]];
+			if(D <= x) { D = x; cell |= 1; } else cell |= mv;
+			Dc[n] = D; Pc[n] = P; e[n] = cell; Qprev = Q;
+		}
+		/* band edge: no gap-in-query state (nw.c:1079-1105) */
+		{
+			uint8_t cell = 0, mv;
+			int Q = Dc[n + 1] + W1, x = Qprev + U;
+			if(Q < x) { Q = x; mv = 3; } else { mv = 2; cell |= 16; }
+			Pc[n] = low;
+			int D = Dp[n] + rw->d[tn][q[qp]];
+			if(Q <= D) cell |= 1; else { D = Q; cell |= mv; }
+			Dc[n] = D; e[n] = cell;
+		}
+		if(eq == 0 && k < 0 && s.score < Dc[n]) { s.score = Dc[n]; bm = m; bn = n; }
+		int *t = Dc; Dc = Dp; Dp = t; t = Pc; Pc = Pp; Pp = t;
+	}
+	if(bm == 0) { bn = en; s.score = Dp[en]; }
+	if(k == -2) {
+		for(n = en; n < bq; ++n) if(s.score <= Dp[n]) { s.score = Dp[n]; bm = 0; bn = n; }
+	}
+	walk(E, pitch, bm, bn, -1, &s);
+	return s;
+}
+
+/* ---- chaining, chain.c:79-260 ------------------------------------------- */
+static int mism_score(int span, int k, const orc_rewards *rw) {
+	/* heuristic substitution model shared by the end / link / start terms */
+	int Ms, MMs;
+	if(span == 2) { MMs = 2; Ms = 0; }
+	else {
+		MMs = span / k + (span % k ? 1 : 0);
+		if(MMs < 2) MMs = 2;
+		Ms = span - MMs; if(k < Ms) Ms = k; if(MMs < Ms) Ms = MMs;
+	}
+	return Ms * rw->M + MMs * rw->MM;
+}
+
+static int chain_seeds(aws *w, int q_len, int t_len, int k, const orc_rewards *rw, unsigned *mapQ) {
+	const int W1 = rw->W1, U = rw->U, M = rw->M;
+	const int n = w->plen;
+	int best = 0, second = 0, bestPos = n - 1;
+	w->sc[n] = 0; w->nx[n] = 0;
+	for(int i = n - 1; i >= 0; --i) {
+		const int weight = w->w[i] * M, tEnd = w->tE[i], qEnd = w->qE[i];
+		w->nx[i] = 0;
+		int span = (t_len - tEnd < q_len - qEnd) ? t_len - tEnd : q_len - qEnd;
+		int gap = span - 1;
+		gap = gap ? gap * U + W1 : W1;                  /* chain.c:104-111 (negative falls in the first arm) */
+		int sub = mism_score(span, k, rw);
+		int score = weight + (sub < gap ? gap : sub);
+		const int lim = (n < i + 128) ? n : i + 128;
+		for(int j = i + 1; j < lim; ++j) {
+			if(qEnd < w->qS[j]) {
+				if(tEnd < w->tS[j]) {
+					const int tGap = w->tS[j] - tEnd, qGap = w->qS[j] - qEnd;
+					int g = abs(tGap - qGap);
+					if(g) g = (g - 1) * U + W1;
+					g += weight + w->sc[j] + mism_score(tGap < qGap ? tGap : qGap, k, rw);
+					if(score <= g) { score = g; w->nx[i] = j; }
+				} else if(k <= w->tE[j] - tEnd) {
+					int g = w->qS[j] - qEnd;
+					if(g) g = (g - 1) * U + W1;
+					g += weight + w->sc[j] - (w->tS[j] - tEnd) * M;
+					if(score < g) { score = g; w->nx[i] = j; }
+				}
+			} else if(k <= w->qE[j] - qEnd) {
+				const int tStart = w->tS[j] + qEnd - w->qS[j];
+				if(tEnd < tStart) {
+					int g = tStart - tEnd;
+					if(g) g = (g - 1) * U + W1;
+					g += weight + w->sc[j] - (tStart - tEnd) * M;
+					if(score < g) { score = g; w->nx[i] = j; }
+				}
+			}
+		}
+		if(w->nx[i]) w->w[i] += w->w[w->nx[i]] - k + 1; else w->w[i] -= k - 1;
+		w->sc[i] = score;
+		span = (w->tS[i] < w->qS[i]) ? w->tS[i] : w->qS[i];
+		gap = span - 1;
+		if(0 < gap) gap = gap * U + W1; else if(gap == 0) gap = W1; else gap = 0;
+		sub = mism_score(span, k, rw);
+		score += sub < gap ? gap : sub;
+		if(best <= score) {
+			if(w->nx[i] != bestPos) second = best;
+			best = score; bestPos = i;
+		} else if(second <= score && w->nx[i] != bestPos) {
+			second = best;
+		}
+	}
+	if(0 < best) {
+		double wq = w->w[bestPos] / 10.0; if(1 < wq) wq = 1;
+		*mapQ = (unsigned) ceil(40 * (1 - 1.0 * second / best) * wq * log(best));
+	} else *mapQ = 0;
+	w->sc[bestPos] = best;
+	return bestPos;
+}
+
+/* ---- tails, align.c:53-212 ------------------------------------------------ */
+static aln lead_tail(aws *w, const uint64_t *tseq, const uint8_t *qseq, int t_e, int t_len, int q_e, int bw, const orc_rewards *rw) {
+	aln s = {0, 0, t_e, 0, 0, 0};
+	if(!q_e) return s;
+	int t_s = 0, q_s = 0;
+	if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+	else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+	if(t_e - t_s > 0 && q_e - q_s > 0) {
+		const int band = abs(t_e - t_s - q_e + q_s) + bw;
+		const int mode = -1 - (t_s == 0);
+		aln r;
+		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len);
+		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len);
+		s.pos -= r.len - r.tGaps;
+		s.score = r.score; s.len = r.len; s.match = r.match; s.tGaps = r.tGaps; s.qGaps = r.qGaps;
+	}
+	return s;
+}
+
+static void trail_tail(aws *w, aln *s, const uint64_t *tseq, const uint8_t *qseq, int t_s, int t_len, int q_s, int q_len, int bw, const orc_rewards *rw) {
+	int q_e = q_len, t_e = t_len;
+	if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+		t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+	} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+		q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+	}
+	if(t_e - t_s > 0 && q_e - q_s > 0) {
+		const int band = abs(t_e - t_s - q_e + q_s) + bw;
+		const int mode = 1 + (t_e == t_len);
+		aln r;
+		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len);
+		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len);
+		s->score += r.score; s->len += r.len; s->match += r.match; s->tGaps += r.tGaps; s->qGaps += r.qGaps;
+	}
+}
+
+/* ---- KMA_score, align.c:509-748 ------------------------------------------ */
+static void add_mem(aws *w, const uint64_t *tseq, int t_len, const uint8_t *qseq, int j, int pos1, int k, int segstop, int *qend_out) {
+	aws_points(w, w->plen + 2);
+	int prev = pos1 - 2, kk;
+	for(kk = j - 1; 0 <= kk && 0 <= prev && qseq[kk] == tnuc(tseq, prev); --kk) --prev;
+	const int m = w->plen;
+	w->qS[m] = kk + 1; w->tS[m] = prev + 2;
+	int value = pos1 + k - 1, l = j + k;
+	while(l < segstop && value < t_len && qseq[l] == tnuc(tseq, value)) { ++l; ++value; }
+	w->qE[m] = l; w->tE[m] = value + 1;
+	w->w[m] = w->qE[m] - w->qS[m];
+	w->plen = m + 1;
+	*qend_out = l;
+}
+
+static const aln FAIL = {0, 1, 0, 0, 0, 0};
+
+static aln kma_score(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k, const uint8_t *qseq, int q_len,
+                     int q_start, int q_end, const uint64_t *qcomp, const int *N /* N[0] = count incl. sentinel */,
+                     int mq, const orc_rewards *rw) {
+	const int bw = 64;
+	w->plen = 0;
+	int j = q_start;
+	for(int i = 1; i <= N[0]; ++i) {
+		int end = (i != N[0]) ? N[i] - k + 1 : q_end - k + 1;
+		while(j < end) {
+			int cnt;
+			const uint64_t key = kmer_at(qcomp, j, k);
+			const int first = key ? tindex_find(ix, key, &cnt) : (cnt = 0, 0);
+			if(cnt == 0) { ++j; continue; }
+			const int segstop = end + k - 1;
+			if(cnt == 1) {
+				int qe;
+				add_mem(w, tseq, t_len, qseq, j, ix->o[first].pos, k, segstop, &qe);
+				j = qe;
+			} else {
+				int bias = j;
+				for(int c = 0; c < cnt; ++c) {
+					int qe;
+					add_mem(w, tseq, t_len, qseq, j, ix->o[first + c].pos, k, segstop, &qe);
+					if(bias < qe) bias = qe;
+				}
+				j = bias + 1;
+			}
+		}
+		j = N[i] + 1;
+	}
+	if(!w->plen) return FAIL;
+	aws_points(w, w->plen + 2);
+	unsigned mapQ = 0;
+	int start = chain_seeds(w, q_len, t_len, k, rw, &mapQ);
+	if(mapQ < (unsigned) mq || w->sc[start] < k) return FAIL;
+	aln S = lead_tail(w, tseq, qseq, w->tS[start] - 1, t_len, w->qS[start], bw, rw);
+	for(;;) {
+		const int span = w->qE[start] - w->qS[start];
+		S.len += span; S.match += span;
+		for(int i = w->qS[start]; i < w->qE[start]; ++i) S.score += rw->d[qseq[i]][qseq[i]];
+		if(!w->nx[start]) break;
+		int q_s = w->qE[start], t_s = w->tE[start] - 1, t_l;
+		start = w->nx[start];
+		if(w->qS[start] < q_s) { w->tS[start] += q_s - w->qS[start]; w->qS[start] = q_s; }
+		int t_e = w->tS[start] - 1;
+		if(t_e < t_s) {
+			if(t_s <= w->tE[start]) { w->qS[start] += t_s - t_e; t_e = t_s; t_l = 0; }
+			else t_l = t_len - t_s + t_e;
+		} else t_l = t_e - t_s;
+		const int q_e = w->qS[start];
+		if(abs(t_l - q_e + q_s) * rw->U > q_len * rw->M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+		if(t_l > 0 || q_e - q_s > 0) {
+			const int band = abs(t_l - q_e + q_s) + bw;
+			aln r;
+			if(q_e - q_s <= band || t_l <= band) r = nw_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, rw, t_len);
+			else r = nw_band_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, band, rw, t_len);
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+	}
+	trail_tail(w, &S, tseq, qseq, w->tE[start] - 1, t_len, w->qE[start], q_len, bw, rw);
+	return S;
+}
+
+/* ---- alnFragsSE + update_Scores ----------------------------------------- */
+struct orc_aligner {
+	const orc_db *db;
+	tindex *ix;      /* lazily built, one per template */
+	aws w;
+	uint8_t *q, *qr; uint64_t *rc; int *Nf, *Nr; int qcap, ncap;
+	int *bt, *bs, *be, *bsc, *bl; int hcap;
+};
+
+orc_aligner *orc_aligner_new(const orc_db *db) {
+	orc_aligner *a = calloc(1, sizeof *a);
+	a->db = db;
+	a->ix = calloc(db->DB_size + 1, sizeof(tindex));
+	return a;
+}
+
+void orc_aligner_free(orc_aligner *a) {
+	if(!a) return;
+	for(uint32_t i = 0; i <= a->db->DB_size; ++i) free(a->ix[i].o);
+	free(a->ix);
+	for(int i = 0; i < 2; ++i) { free(a->w.D[i]); free(a->w.P[i]); }
+	free(a->w.E); free(a->w.tS); free(a->w.tE); free(a->w.qS); free(a->w.qE); free(a->w.w); free(a->w.sc); free(a->w.nx);
+	free(a->q); free(a->qr); free(a->rc); free(a->Nf); free(a->Nr);
+	free(a->bt); free(a->bs); free(a->be); free(a->bsc); free(a->bl);
+	free(a);
+}
+
+static void unpack_bytes(const uint64_t *seq, int len, const int *N, uint8_t *out) {
+	for(int i = 0; i < len; ++i) out[i] = (uint8_t) tnuc(seq, i);
+	for(int i = 1; i <= N[0]; ++i) out[N[i]] = 4;
+	out[len] = 0;
+}
+
+int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap,
+                 const uint64_t *seq, int seqlen, const int *N, int nN,
+                 int rc_flag, int flag, const int *T, int nT,
+                 int *n_hits, int *best_score, int *out_flag, int *ht, int *hs, int *he, int *hscore,
+                 uint64_t *alignment_scores, uint64_t *uniq_alignment_scores) {
+	const orc_db *db = a->db;
+	const int k = db->kmersize, q_len = seqlen;
+	*n_hits = 0; *best_score = 0; *out_flag = flag;
+	if(nT == 0 || q_len < k) return 0;
+	if(rc_flag < 0) { *n_hits = -1; return 0; }   /* strand tie (anker_rc_comp path): not restated */
+	const int words = (seqlen + 31) >> 5;
+	if(a->qcap < seqlen + 2) {
+		a->qcap = 2 * seqlen + 66;
+		a->q = realloc(a->q, (size_t) a->qcap); a->qr = realloc(a->qr, (size_t) a->qcap);
+		a->rc = realloc(a->rc, sizeof(uint64_t) * (size_t) ((a->qcap >> 5) + 4));
+	}
+	if(a->ncap < nN + 3) { a->ncap = 2 * nN + 66; a->Nf = realloc(a->Nf, sizeof(int) * (size_t) a->ncap); a->Nr = realloc(a->Nr, sizeof(int) * (size_t) a->ncap); }
+	if(a->hcap < nT + 1) {
+		a->hcap = 2 * nT + 16;
+		a->bt = realloc(a->bt, sizeof(int) * (size_t) a->hcap); a->bs = realloc(a->bs, sizeof(int) * (size_t) a->hcap);
+		a->be = realloc(a->be, sizeof(int) * (size_t) a->hcap); a->bsc = realloc(a->bsc, sizeof(int) * (size_t) a->hcap);
+		a->bl = realloc(a->bl, sizeof(int) * (size_t) a->hcap);
+	}
+	a->Nf[0] = nN; memcpy(a->Nf + 1, N, sizeof(int) * (size_t) nN);
+	/* the S2 stream carries the reverse-complemented read when flag & 16 (savekmers.c:3049) */
+	const uint64_t *qcomp = seq; int *Nq = a->Nf;
+	if(flag & 16) {
+		orc_rc(seq, seqlen, a->Nf, a->rc, a->Nr);
+		a->rc[words] = 0;
+		qcomp = a->rc; Nq = a->Nr;
+	}
+	unpack_bytes(qcomp, seqlen, Nq, a->q);
+	Nq[0] += 1; Nq[Nq[0]] = q_len;        /* sentinel, alnfrags.c:1071-1072 */
+
+	double bestScore = 0; int bestRead = 0, hits = 0;
+	for(int ti = 0; ti < nT; ++ti) {
+		const int tmpl = T[ti], at = abs(tmpl);
+		const int t_len = db->tlen[at];
+		const uint64_t *tseq = db->tseq + db->tseq_off[at];
+		if(!a->ix[at].o) tindex_build(&a->ix[at], tseq, t_len, k);
+		aln st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, a->q, q_len, 0, q_len, qcomp, Nq, ap->mq, rw);
+		const int aln_len = st.len, start = st.pos;
+		int end = start + aln_len - st.tGaps;
+		if(t_len < end) end -= t_len;
+		double denom;
+		if(q_len <= aln_len || t_len <= aln_len) denom = aln_len; else denom = q_len < t_len ? q_len : t_len;
+		int read_score = st.score; double score;
+		if(ap->minlen <= aln_len && ((ap->mrc * q_len <= st.len - st.qGaps) || (ap->mrc * t_len <= st.len - st.tGaps))) score = read_score / denom;
+		else { read_score = 0; score = 0; }
+		if(k < read_score && ap->scoreT <= score) {
+			a->bt[hits] = tmpl; a->bs[hits] = start; a->be[hits] = end; a->bsc[hits] = read_score; a->bl[hits] = aln_len; ++hits;
+			if(bestScore < score) bestScore = score;
+			if(bestRead < read_score) bestRead = read_score;
+		}
+	}
+	Nq[0] -= 1;
+	if(!(bestRead > k)) { *out_flag = flag | 4; return 0; }
+	/* update_Scores, minFrac == 1.0 branch (updatescores.c:217-234) */
+	int c = 0;
+	for(int i = 0; i < hits; ++i) {
+		const double ms = a->bsc[i] / a->bl[i];       /* integer division, then widened */
+		if(ms == bestScore || a->bsc[i] == bestRead) {
+			ht[c] = a->bt[i]; hs[c] = a->bs[i]; he[c] = a->be[i]; hscore[c] = a->bsc[i]; ++c;
+			if(alignment_scores) alignment_scores[abs(a->bt[i])] += (uint64_t) a->bsc[i];
+		}
+	}
+	if(c == 1 && uniq_alignment_scores) uniq_alignment_scores[abs(ht[0])] += (uint64_t) bestRead;
+	*n_hits = c; *best_score = bestRead;
+	return c;
+}
+
+/* function-level taps for kernel tests */
+void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
+                int band /* < 0: full matrix */, const orc_rewards *rw, int out[6]) {
+	aws w; memset(&w, 0, sizeof w);
+	aln r = band < 0 ? nw_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, rw, tlen_total)
+	                 : nw_band_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, band, rw, tlen_total);
+	out[0] = r.score; out[1] = r.len; out[2] = r.pos; out[3] = r.match; out[4] = r.tGaps; out[5] = r.qGaps;
+	for(int i = 0; i < 2; ++i) { free(w.D[i]); free(w.P[i]); }
+	free(w.E);
+}
+
+int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_align_params *ap,
+                           int64_t n_reads, const uint64_t *seq, const int64_t *seq_off,
+                           const int32_t *len, const int32_t *N, const int64_t *N_off,
+                           const int32_t *rc_flag, const int32_t *flag, const int64_t *T_off, const int32_t *T,
+                           int32_t *n_hits, int32_t *best_score, int32_t *out_flag,
+                           int32_t *ht, int32_t *hs, int32_t *he, int32_t *hscore,
+                           uint64_t *alignment_scores, uint64_t *uniq_alignment_scores) {
+	/* hits of read r are written at [T_off[r], T_off[r] + n_hits[r]) */
+	orc_aligner *a = orc_aligner_new(db);
+	int64_t mapped = 0;
+	for(int64_t r = 0; r < n_reads; ++r) {
+		const int words = (len[r] + 31) >> 5;
+		uint64_t *s = malloc(((size_t) words + 2) * 8);
+		memcpy(s, seq + seq_off[r], (size_t) words * 8); s[words] = 0; s[words + 1] = 0;
+		const int64_t o = T_off[r];
+		int nh = 0, bs = 0, of = 0;
+		orc_align_se(a, rw, ap, s, len[r], N + N_off[r], (int) (N_off[r + 1] - N_off[r]), rc_flag[r], flag[r],
+		             T + o, (int) (T_off[r + 1] - o), &nh, &bs, &of, ht + o, hs + o, he + o, hscore + o,
+		             alignment_scores, uniq_alignment_scores);
+		n_hits[r] = nh; best_score[r] = bs; out_flag[r] = of;
+		if(nh > 0) ++mapped;
+		free(s);
+	}
+	orc_aligner_free(a);
+	return mapped;
+}

@@ -70,6 +70,30 @@ int64_t orc_scan_se_batch(const orc_db *db, const orc_rewards *rw, int exhaustiv
                           int32_t *rc_flag, int32_t *flag, int64_t *T_off,
                           int32_t *T, int64_t T_cap);
 
+/* ---- stage 3a (oracle/align.c) ------------------------------------------ */
+typedef struct orc_aligner orc_aligner;
+typedef struct { int minlen, mq; double scoreT, mrc, minFrac; } orc_align_params;
+orc_aligner *orc_aligner_new(const orc_db *db);
+void orc_aligner_free(orc_aligner *a);
+/* one read: alnFragsSE (alnfrags.c:1052-1218) + update_Scores (updatescores.c:203-298).
+ * seq/N are the ORIGINAL read; flag & 16 selects its reverse complement as the
+ * S2 stream would carry it. Outputs (capacity nT each): kept hits in candidate
+ * order. n_hits = -1 marks a strand tie (rc_flag < 0), which is not restated. */
+int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap,
+                 const uint64_t *seq, int seqlen, const int *N, int nN,
+                 int rc_flag, int flag, const int *T, int nT,
+                 int *n_hits, int *best_score, int *out_flag, int *ht, int *hs, int *he, int *hscore,
+                 uint64_t *alignment_scores, uint64_t *uniq_alignment_scores);
+int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_align_params *ap,
+                           int64_t n_reads, const uint64_t *seq, const int64_t *seq_off,
+                           const int32_t *len, const int32_t *N, const int64_t *N_off,
+                           const int32_t *rc_flag, const int32_t *flag, const int64_t *T_off, const int32_t *T,
+                           int32_t *n_hits, int32_t *best_score, int32_t *out_flag,
+                           int32_t *ht, int32_t *hs, int32_t *he, int32_t *hscore,
+                           uint64_t *alignment_scores, uint64_t *uniq_alignment_scores);
+void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
+                int band, const orc_rewards *rw, int out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,3 +17,9 @@ def golden_se(tmp_path_factory):
     """Unpacked tests/golden/se fixture: dict with paths + parsed streams."""
     import golden_util
     return golden_util.load_se(tmp_path_factory.mktemp("golden_se"))
+
+
+@pytest.fixture(scope="session")
+def golden_long(tmp_path_factory):
+    import golden_util
+    return golden_util.load_se(tmp_path_factory.mktemp("golden_long"), "long")

@@ -144,8 +144,81 @@ def make_se(outdir, seed=7):
         shutil.copy(os.path.join(tmp, "out.frag_raw.gz"), os.path.join(outdir, "out.frag_raw.gz"))
 
 
+def long_reads(seqs, n, seed):
+    """Long reads that force banded NW: divergent internal blocks (no shared
+    16-mer for 70-160 bases), junk flanks > 128 bases, indel-rich stretches."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(350, min(1400, len(s))))
+        st = int(rng.integers(0, len(s) - L + 1))
+        r = s[st:st + L].copy()
+        kind = rng.random()
+        if kind < 0.45:      # divergent block(s): every 7th-9th base substituted
+            for _ in range(int(rng.integers(1, 3))):
+                b0 = int(rng.integers(40, L - 200)); bl = int(rng.integers(70, 160))
+                step = int(rng.integers(5, 10))
+                idx = np.arange(b0, min(L - 30, b0 + bl), step)
+                r[idx] = (r[idx] + rng.integers(1, 4, len(idx), dtype=np.uint8)) & 3
+                if rng.random() < 0.5:   # plus a length change inside the block
+                    p = b0 + bl // 2
+                    if rng.random() < 0.5:
+                        r = np.delete(r, slice(p, p + int(rng.integers(1, 12))))
+                    else:
+                        r = np.insert(r, p, rng.integers(0, 4, int(rng.integers(1, 12)), dtype=np.uint8))
+                    L = len(r)
+        elif kind < 0.75:    # junk flanks
+            a = rng.integers(0, 4, int(rng.integers(100, 260)), dtype=np.uint8)
+            b = rng.integers(0, 4, int(rng.integers(0, 260)), dtype=np.uint8)
+            r = np.concatenate([a, r, b]) if rng.random() < 0.5 else np.concatenate([b, r, a])
+        else:                # ONT-like
+            m = rng.random(len(r)) < 0.04
+            r[m] = (r[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            keep = rng.random(len(r)) >= 0.02
+            r = r[keep]
+            ip = np.nonzero(rng.random(len(r)) < 0.02)[0]
+            r = np.insert(r, ip, rng.integers(0, 4, len(ip), dtype=np.uint8))
+        if rng.random() < 0.1:
+            m = rng.random(len(r)) < 0.004
+            r[m] = 4
+        if rng.random() < 0.5:
+            r = synth.revcomp_codes(r)
+        out.append(np.ascontiguousarray(r.astype(np.uint8)))
+    return out
+
+
+def make_long(outdir, seed=21):
+    os.makedirs(outdir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        names, seqs = synth.make_gene_db(6, 3, 1800, 2600, 0.03, seed)
+        fa = os.path.join(tmp, "db.fsa")
+        synth.write_fasta(fa, names, seqs)
+        reads = long_reads(seqs, 260, seed + 1)
+        fq = os.path.join(tmp, "reads.fq")
+        synth.write_fastq(fq, reads)
+        db = os.path.join(tmp, "db")
+        run([KMA, "index", "-i", fa, "-o", db])
+        base = [KMA, "-i", fq, "-o", os.path.join(tmp, "out"), "-t_db", db, "-1t1", "-t", "1"]
+        with open(os.path.join(tmp, "s1.bin"), "wb") as f:
+            run(base + ["-s1"], stdout=f)
+        with open(os.path.join(tmp, "s2.bin"), "wb") as f:
+            run(base + ["-s2"], stdout=f)
+        run(base + ["-a"])
+        gz(fa, os.path.join(outdir, "db.fsa.gz"))
+        gz(fq, os.path.join(outdir, "reads.fq.gz"))
+        xz(db + ".comp.b", os.path.join(outdir, "db.comp.b.xz"))
+        for ext in (".length.b", ".seq.b", ".name"):
+            shutil.copy(db + ext, os.path.join(outdir, "db" + ext))
+        for b in ("s1.bin", "s2.bin"):
+            gz(os.path.join(tmp, b), os.path.join(outdir, b + ".gz"))
+        shutil.copy(os.path.join(tmp, "out.res"), os.path.join(outdir, "out.res"))
+        shutil.copy(os.path.join(tmp, "out.frag_raw.gz"), os.path.join(outdir, "out.frag_raw.gz"))
+
+
 if __name__ == "__main__":
     if not os.path.exists(KMA):
         sys.exit("oracle/_ref/kma missing: run `make -C oracle ref` first")
     make_se(os.path.join(HERE, "se"))
+    make_long(os.path.join(HERE, "long"))
     print("golden fixtures written")

@@ -37,7 +37,9 @@ def load_se(tmp, name="se"):
         shutil.copy(os.path.join(src, "db" + ext), prefix + ext)
     s1 = formats.parse_s1(_gunzip(os.path.join(src, "s1.bin.gz")))
     s2, n2 = formats.parse_s2(_gunzip(os.path.join(src, "s2.bin.gz")))
-    s2x, _ = formats.parse_s2(_gunzip(os.path.join(src, "s2_ex.bin.gz")))
+    s2x = None
+    if os.path.exists(os.path.join(src, "s2_ex.bin.gz")):
+        s2x, _ = formats.parse_s2(_gunzip(os.path.join(src, "s2_ex.bin.gz")))
     reads = reads_from_s1(s1)
     return dict(dir=src, prefix=prefix, s1=s1, s2=s2, s2_ex=s2x, n_reads=n2, reads=reads,
                 batch=formats.pack_ragged(reads))
@@ -61,3 +63,31 @@ def check_scan_against_s2(s1, s2, rc_flag, flag, T_off, T):
         assert np.array_equal(e["T"], got_T), (r["hdr"], e["T"], got_T)
     assert seen == len(s2)
     return seen
+
+
+def load_frag_raw(name="se"):
+    """frag_raw text tap (frags.c:64): header -> (nHits, score, starts, ends, templates)."""
+    out = {}
+    with gzip.open(os.path.join(GOLD, name, "out.frag_raw.gz"), "rt") as f:
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            out[c[6]] = (int(c[1]), int(c[2]), [int(x) for x in c[3].split(",")],
+                         [int(x) for x in c[4].split(",")], [int(x) for x in c[5].split(",")])
+    return out
+
+
+def check_align_against_frag_raw(s1, frag, T_off, res):
+    """Stage-3a result arrays vs the reference frag_raw tap."""
+    n_ok = 0
+    for i, r in enumerate(s1):
+        h = r["hdr"].rstrip(b"\0").decode()
+        nh, o = int(res["n_hits"][i]), int(T_off[i])
+        got = None
+        if nh > 0:
+            got = (nh, int(res["best_score"][i]), res["start"][o:o + nh].tolist(), res["end"][o:o + nh].tolist(),
+                   res["tmpl"][o:o + nh].tolist())
+        assert nh >= 0, f"{h}: strand tie not handled"
+        assert got == frag.get(h), (h, frag.get(h), got)
+        n_ok += got is not None
+    assert n_ok == len(frag)
+    return n_ok

@@ -21,6 +21,10 @@ class Rewards(C.Structure):
                 ("Wl", C.c_int), ("Mn", C.c_int), ("PE", C.c_int), ("d", (C.c_int * 5) * 5)]
 
 
+class AlignParams(C.Structure):
+    _fields_ = [("minlen", C.c_int), ("mq", C.c_int), ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double)]
+
+
 def _build():
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
@@ -44,6 +48,10 @@ def lib():
         L.orc_hash_get.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_scan_se_batch.restype = C.c_int64
         L.orc_scan_se_batch.argtypes = [C.c_void_p, C.POINTER(Rewards), C.c_int, C.c_int64] + [C.c_void_p] * 9 + [C.c_int64]
+        L.orc_align_se_batch.restype = C.c_int64
+        L.orc_align_se_batch.argtypes = [C.c_void_p, C.POINTER(Rewards), C.POINTER(AlignParams), C.c_int64] + [C.c_void_p] * 18
+        L.orc_nw_tap.restype = None
+        L.orc_nw_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(Rewards), C.c_void_p]
         _lib = L
     return _lib
 
@@ -54,6 +62,7 @@ def _p(a):
 
 class OracleDB:
     def __init__(self, prefix):
+        self.prefix = prefix
         self.h = lib().orc_db_load(prefix.encode())
         if not self.h:
             raise RuntimeError(f"oracle: cannot load index {prefix}")
@@ -88,3 +97,26 @@ class OracleDB:
             if r >= 0:
                 return rc_flag, flag, T_off, T[:r]
             cap = -r + 16
+
+    def align_se(self, batch, rc_flag, flag, T_off, T, minlen=16, mq=0, scoreT=0.5, mrc=0.0):
+        """-> dict(n_hits, best_score, out_flag, tmpl, start, end, score (CSR at T_off), alignment_scores, uniq)"""
+        n = batch.n
+        ap = AlignParams(minlen, mq, scoreT, mrc, 1.0)
+        cap = max(1, len(T))
+        out = dict(n_hits=np.zeros(n, np.int32), best_score=np.zeros(n, np.int32), out_flag=np.zeros(n, np.int32),
+                   tmpl=np.zeros(cap, np.int32), start=np.zeros(cap, np.int32), end=np.zeros(cap, np.int32),
+                   score=np.zeros(cap, np.int32))
+        import struct
+        dbsize = struct.unpack("<I", open(self.prefix + ".comp.b", "rb").read(4))[0]
+        out["alignment_scores"] = np.zeros(dbsize, np.uint64)
+        out["uniq_alignment_scores"] = np.zeros(dbsize, np.uint64)
+        seq = np.ascontiguousarray(batch.seq)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32))
+        Tn = np.ascontiguousarray(T if len(T) else np.zeros(1, np.int32), np.int32)
+        lib().orc_align_se_batch(self.h, C.byref(self.rw), C.byref(ap), n, _p(seq), _p(batch.seq_off), _p(batch.length),
+                                 _p(Nn), _p(batch.N_off), _p(np.ascontiguousarray(rc_flag, np.int32)),
+                                 _p(np.ascontiguousarray(flag, np.int32)), _p(np.ascontiguousarray(T_off, np.int64)), _p(Tn),
+                                 _p(out["n_hits"]), _p(out["best_score"]), _p(out["out_flag"]), _p(out["tmpl"]),
+                                 _p(out["start"]), _p(out["end"]), _p(out["score"]),
+                                 _p(out["alignment_scores"]), _p(out["uniq_alignment_scores"]))
+        return out

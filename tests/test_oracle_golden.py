@@ -57,3 +57,59 @@ def test_index_writer_semantics(golden_se, tmp_path):
     golden_util.check_scan_against_s2(golden_se["s1"], golden_se["s2"], rc_flag, flag, T_off, T)
     for ext in (".length.b", ".seq.b"):
         assert open(golden_se["prefix"] + ext, "rb").read() == open(str(tmp_path / "mine") + ext, "rb").read()
+
+
+def _oracle_align(g):
+    db = oracle.OracleDB(g["prefix"])
+    rc_flag, flag, T_off, T = db.scan_se(g["batch"])
+    golden_util.check_scan_against_s2(g["s1"], g["s2"], rc_flag, flag, T_off, T)
+    return T_off, db.align_se(g["batch"], rc_flag, flag, T_off, T)
+
+
+def test_oracle_align_matches_frag_raw_tap(golden_se):
+    # stage 3a: KMA_score + chainSeeds + NW_score + alnFragsSE + update_Scores vs `-a` tap
+    T_off, res = _oracle_align(golden_se)
+    n = golden_util.check_align_against_frag_raw(golden_se["s1"], golden_util.load_frag_raw("se"), T_off, res)
+    assert n > 900
+
+
+def test_oracle_align_matches_frag_raw_tap_long_reads(golden_long):
+    # long reads with divergent blocks / junk flanks: exercises NW_band_score (nw.c:892-1188)
+    import ctypes
+    c = (ctypes.c_int64 * 4).in_dll(oracle.lib(), "orc_counters")
+    before = c[1]
+    T_off, res = _oracle_align(golden_long)
+    n = golden_util.check_align_against_frag_raw(golden_long["s1"], golden_util.load_frag_raw("long"), T_off, res)
+    assert n > 200
+    assert c[1] - before > 100, "banded NW not exercised"
+
+
+def test_reference_binary_accepts_our_index(golden_se, tmp_path):
+    # the reference `kma` run on an index written by formats.write_index yields the
+    # same S2 stream and .res as on its own `kma index` output
+    import gzip
+    import os
+    import subprocess
+    if not os.path.exists(oracle.REF_KMA):
+        import pytest
+        pytest.skip("oracle/_ref/kma not built")
+    lut = np.full(256, 255, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    names, seqs = [], []
+    with gzip.open(golden_se["dir"] + "/db.fsa.gz", "rb") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(b">"):
+                names.append(line[1:].decode())
+            else:
+                seqs.append(lut[np.frombuffer(line, np.uint8)])
+    prefix = str(tmp_path / "mine")
+    formats.write_index(prefix, names, seqs)
+    fq = str(tmp_path / "r.fq")
+    open(fq, "wb").write(gzip.open(golden_se["dir"] + "/reads.fq.gz", "rb").read())
+    base = [oracle.REF_KMA, "-i", fq, "-o", str(tmp_path / "o"), "-t_db", prefix, "-1t1", "-t", "1"]
+    s2 = subprocess.run(base + ["-s2"], capture_output=True, check=True).stdout
+    assert s2 == gzip.open(golden_se["dir"] + "/s2.bin.gz", "rb").read()
+    subprocess.run(base, capture_output=True, check=True)
+    assert open(str(tmp_path / "o.res")).read() == open(golden_se["dir"] + "/out.res").read()
