@@ -93,6 +93,7 @@ typedef struct kmahip_reads {
 	const int64_t *N_off;     /* n_reads+1 */
 	int64_t seq_words;        /* total words in seq (host calls: bytes to stage) */
 	int64_t N_total;
+	int32_t max_len;          /* longest read in the batch (sizes the align scratch) */
 } kmahip_reads;
 
 /* Stage-2 result, one entry per read = the S2 record fields (ankers.c:30-50):
@@ -108,17 +109,24 @@ typedef struct kmahip_cands {
 	int64_t T_cap;
 } kmahip_cands;
 
-/* Stage-3a result per read (what update_Scores keeps, updatescores.c:203-298,
- * = one frag_raw record): hits in candidate order. */
+/* Stage-3a result (what update_Scores keeps, updatescores.c:203-298 = one
+ * frag_raw record per read).  Hits of read i are stored at
+ * [T_off[i], T_off[i] + n_hits[i]) of tmpl/score/start/end, in candidate order,
+ * so these arrays need the same capacity as kmahip_cands.T.  n_hits[i] == -1
+ * marks a read whose two strands tied in stage 2 (rc_flag < 0): that path
+ * (anker_rc_comp, align.c:993-1176) is not on the device yet.
+ * alignment_scores / uniq_alignment_scores are the two u64[DB_size] ConClave
+ * vectors (updatescores.c:228,276); the call ADDS into them (caller zeroes). */
 typedef struct kmahip_hits {
-	int32_t *n_hits;      /* n_reads: 0 = unmapped after alignment */
+	int32_t *n_hits;      /* n_reads */
 	int32_t *best_score;  /* n_reads: best_read_score */
-	int64_t *H_off;       /* n_reads + 1 (same shape as T_off) */
-	int32_t *tmpl;        /* H_cap: signed template id */
-	int32_t *score;       /* H_cap */
-	int32_t *start;       /* H_cap */
-	int32_t *end;         /* H_cap */
-	int64_t H_cap;
+	int32_t *flag;        /* n_reads: stage-2 flag, |= 4 when unmapped after alignment */
+	int32_t *tmpl;        /* signed template id */
+	int32_t *score;
+	int32_t *start;
+	int32_t *end;
+	uint64_t *alignment_scores;       /* DB_size, may be NULL */
+	uint64_t *uniq_alignment_scores;  /* DB_size, may be NULL */
 } kmahip_hits;
 
 void kmahip_default_params(kmahip_params *p);
@@ -143,6 +151,15 @@ int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
  * (a hipStream_t, NULL = default stream). */
 int kmahip_scan_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
                        const kmahip_params *p, kmahip_cands *out, void *stream);
+/* Stage 3a, single end: alignment score of every (read, candidate) pair,
+ * per-read hit selection and ConClave accumulators.  `cands` is the output of
+ * kmahip_scan_se_dev on the same `reads` (device pointers). */
+int kmahip_align_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                        const kmahip_params *p, kmahip_hits *out, void *stream);
+/* Stages 2 + 3a with host buffers in and out (reads staged once). */
+int kmahip_map_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                  kmahip_cands *cands_out, kmahip_hits *hits_out);
+
 /* status of the last *_dev call on this workspace after the stream has been
  * synchronised: 0 or KMAHIP_EOVERFLOW */
 int kmahip_ws_status(kmahip_ws *ws, void *stream);
@@ -159,10 +176,11 @@ int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
 
 /* Kernel timing: when on, every *_dev call records a HIP event pair around its
- * dominant kernel (scan_se_kernel) on the caller's stream; get_timing waits
+ * two main kernels (scan_se_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
  * for them, returns the summed milliseconds and launch count, and resets. */
 int kmahip_ws_set_timing(kmahip_ws *ws, int on);
-int kmahip_ws_get_timing(kmahip_ws *ws, double *total_ms, int64_t *launches);
+int kmahip_ws_get_timing(kmahip_ws *ws, int kernel /* 0 scan_se_kernel, 1 align_tasks_kernel */,
+                         double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -31,12 +31,19 @@ class DBInfo(C.Structure):
 
 class Reads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("len", C.c_void_p),
-                ("N", C.c_void_p), ("N_off", C.c_void_p), ("seq_words", C.c_int64), ("N_total", C.c_int64)]
+                ("N", C.c_void_p), ("N_off", C.c_void_p), ("seq_words", C.c_int64), ("N_total", C.c_int64),
+                ("max_len", C.c_int32)]
 
 
 class Cands(C.Structure):
     _fields_ = [("rc_flag", C.c_void_p), ("flag", C.c_void_p), ("T_off", C.c_void_p), ("T", C.c_void_p),
                 ("T_cap", C.c_int64)]
+
+
+class Hits(C.Structure):
+    _fields_ = [("n_hits", C.c_void_p), ("best_score", C.c_void_p), ("flag", C.c_void_p), ("tmpl", C.c_void_p),
+                ("score", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p),
+                ("alignment_scores", C.c_void_p), ("uniq_alignment_scores", C.c_void_p)]
 
 
 class ScanStats(C.Structure):
@@ -73,7 +80,10 @@ def lib():
         L.kmahip_scan_set_stats.argtypes = [C.c_void_p, C.c_int]
         L.kmahip_scan_get_stats.argtypes = [C.c_void_p, C.POINTER(ScanStats), C.c_void_p]
         L.kmahip_ws_set_timing.argtypes = [C.c_void_p, C.c_int]
-        L.kmahip_ws_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.kmahip_ws_get_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.kmahip_align_se_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Cands), C.POINTER(Params),
+                                          C.POINTER(Hits), C.c_void_p]
+        L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
         _lib = L
     return _lib
 
@@ -126,7 +136,8 @@ class KmaHipDB:
         n = batch.n
         seq = np.ascontiguousarray(batch.seq, np.uint64)
         Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
-        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N))
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
         rc_flag = np.zeros(max(n, 1), np.int32)
         flag = np.zeros(max(n, 1), np.int32)
         T_off = np.zeros(n + 1, np.int64)
@@ -149,7 +160,7 @@ class KmaHipDB:
         """All arguments are CUDA(HIP) torch tensors; asynchronous on `stream`."""
         n = length.numel()
         r = Reads(n, seq.data_ptr(), seq_off.data_ptr(), length.data_ptr(), N.data_ptr(), N_off.data_ptr(),
-                  seq.numel(), N.numel())
+                  seq.numel(), N.numel(), 0)
         out = Cands(rc_flag.data_ptr(), flag.data_ptr(), T_off.data_ptr(), T.data_ptr(), T.numel())
         p = Params.from_buffer_copy(self.params)
         p.exhaustive = exhaustive
@@ -169,7 +180,56 @@ class KmaHipDB:
     def set_timing(self, on: bool):
         _check(lib().kmahip_ws_set_timing(self.ws, int(on)))
 
-    def get_timing(self):
+    def get_timing(self, kernel=0):
+        """kernel 0 = scan_se_kernel, 1 = align_tasks_kernel -> (summed ms, launches)"""
         ms, n = C.c_double(), C.c_int64()
-        _check(lib().kmahip_ws_get_timing(self.ws, C.byref(ms), C.byref(n)))
+        _check(lib().kmahip_ws_get_timing(self.ws, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # -- stages 2 + 3a, host buffers ------------------------------------------
+    def map_se(self, batch, exhaustive=0, t_cap=None):
+        """-> (rc_flag, flag, T_off, T), hits dict (n_hits, best_score, flag, tmpl, score, start, end,
+        alignment_scores, uniq_alignment_scores)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        rc_flag = np.zeros(max(n, 1), np.int32)
+        flag = np.zeros(max(n, 1), np.int32)
+        T_off = np.zeros(n + 1, np.int64)
+        cap = t_cap or max(1024, 8 * n)
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        D = int(self.info.DB_size)
+        for _ in range(4):
+            T = np.zeros(cap, np.int32)
+            h = dict(n_hits=np.zeros(max(n, 1), np.int32), best_score=np.zeros(max(n, 1), np.int32),
+                     flag=np.zeros(max(n, 1), np.int32), tmpl=np.zeros(cap, np.int32), score=np.zeros(cap, np.int32),
+                     start=np.zeros(cap, np.int32), end=np.zeros(cap, np.int32),
+                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64))
+            out = Cands(_p(rc_flag), _p(flag), _p(T_off), _p(T), cap)
+            hs = Hits(_p(h["n_hits"]), _p(h["best_score"]), _p(h["flag"]), _p(h["tmpl"]), _p(h["score"]), _p(h["start"]),
+                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]))
+            rc = lib().kmahip_map_se(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.byref(hs))
+            if rc == -6 and int(T_off[n]) > cap:
+                cap = max(cap * 2, int(T_off[n]) + 16)
+                continue
+            _check(rc)
+            for key in ("n_hits", "best_score", "flag"):
+                h[key] = h[key][:n]
+            return (rc_flag[:n], flag[:n], T_off, T[:T_off[n]]), h
+        raise KmaHipError("map_se: output capacity kept overflowing")
+
+    def align_se_dev(self, seq, seq_off, length, N, N_off, max_len, rc_flag, flag, T_off, T,
+                     n_hits, best_score, out_flag, h_tmpl, h_score, h_start, h_end, aln_scores, uniq_scores, stream=None):
+        """Stage 3a on device tensors (outputs of scan_se_dev); asynchronous on `stream`."""
+        n = length.numel()
+        r = Reads(n, seq.data_ptr(), seq_off.data_ptr(), length.data_ptr(), N.data_ptr(), N_off.data_ptr(),
+                  seq.numel(), N.numel(), int(max_len))
+        c = Cands(rc_flag.data_ptr(), flag.data_ptr(), T_off.data_ptr(), T.data_ptr(), T.numel())
+        h = Hits(n_hits.data_ptr(), best_score.data_ptr(), out_flag.data_ptr(), h_tmpl.data_ptr(), h_score.data_ptr(),
+                 h_start.data_ptr(), h_end.data_ptr(), aln_scores.data_ptr(), uniq_scores.data_ptr())
+        p = Params.from_buffer_copy(self.params)
+        _check(lib().kmahip_align_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(p), C.byref(h),
+                                         C.c_void_p(stream or 0)))

@@ -1,0 +1,663 @@
+// align.hip -- stage 3a of KMA on gfx950: for every (read, candidate template)
+// task find the maximal exact matches against the template position index,
+// chain them, stitch the chain with global / banded Needleman-Wunsch on the gaps
+// and tails, then filter and pick per read.  Behaviour restated from
+//   KMA_score        align.c:509-748      chainSeeds      chain.c:79-260
+//   lead/trailTailAln align.c:53-212      NW_score        nw.c:642-890
+//   alnFragsSE       alnfrags.c:1052-1218 NW_band_score   nw.c:892-1188
+//   update_Scores    updatescores.c:203-298
+//
+// Structure (new): one lane per task, grid-stride over the CSR candidate list
+// written by the scan stage; all per-lane working arrays (MEMs, DP rows) live
+// in an HBM scratch laid out [index][lane] so lanes of a wave that walk in step
+// touch consecutive addresses.  The DP keeps ONE row in place and no traceback
+// matrix: the reference fills a byte matrix E and then walks it only to count
+// (len, match, tGaps, qGaps); because that walk from a cell visits only cells
+// filled earlier, the counts of the walk from every cell are carried beside
+// D/P/Q as three packed 21-bit counters ("count-carrying DP"), including the
+// walk's quirk that a gap run ends on the first cell with EITHER may-open bit.
+#include "kmahip_internal.h"
+
+namespace {
+
+constexpr int ATHREADS = 256;
+constexpr uint64_t MA = 1ull;             // one diagonal step
+constexpr uint64_t TG = 1ull << 21;       // one gap-in-template step (query consumed)
+constexpr uint64_t QG = 1ull << 42;       // one gap-in-query step (template consumed)
+constexpr uint64_t FMASK = (1ull << 21) - 1;
+
+struct AlignArgs {
+	DevDB db;
+	int64_t n_reads;
+	const uint64_t *seq;
+	const int64_t *seq_off;
+	const int32_t *len;
+	const int32_t *N;
+	const int64_t *N_off;
+	const int32_t *rc_flag;
+	const int32_t *flag;
+	const int64_t *T_off;
+	const int32_t *T;
+	int M, MM, U, W1;
+	int d[25];
+	int minlen, mq;
+	double scoreT, mrc;
+	// per task
+	int32_t *t_score, *t_alen, *t_start, *t_end;
+	double *t_norm;
+	// scratch
+	int32_t *s32;
+	uint64_t *s64;
+	int64_t lanes;
+	int mem_cap;     // MEM slots per lane (arrays hold mem_cap + 1)
+	int ncols;       // DP columns per lane
+	unsigned long long *counters;   // [1] status
+};
+
+struct Aln { int score, len, pos, match, tGaps, qGaps; };
+
+struct QView {
+	const uint64_t *w;
+	const int32_t *N;
+	int L, nN, rc;
+};
+
+__device__ __forceinline__ int q2(const QView &q, int i) {
+	const int p = q.rc ? q.L - 1 - i : i;
+	const int b = (int) ((q.w[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
+	return q.rc ? 3 - b : b;
+}
+
+__device__ __forceinline__ bool q_is_N(const QView &q, int i) {
+	if(q.nN == 0) return false;
+	const int p = q.rc ? q.L - 1 - i : i;
+	int lo = 0, hi = q.nN;
+	while(lo < hi) { const int mid = (lo + hi) >> 1; if(q.N[mid] < p) lo = mid + 1; else hi = mid; }
+	return lo < q.nN && q.N[lo] == p;
+}
+
+// byte code of the oriented query: 0-3, 4 = N (unCompDNA, compdna.c:178-203)
+__device__ __forceinline__ int qn(const QView &q, int i) { return q_is_N(q, i) ? 4 : q2(q, i); }
+
+// i-th (1-based) oriented N position; i > nN -> L (the sentinel alnFragsSE appends)
+__device__ __forceinline__ int qN_at(const QView &q, int i) {
+	if(i > q.nN) return q.L;
+	return q.rc ? (q.L - 1 - q.N[q.nN - i]) : q.N[i - 1];
+}
+
+__device__ __forceinline__ uint32_t q_kmer(const QView &q, int j, int k) {
+	const int p = q.rc ? q.L - k - j : j;
+	const int ip = (p & 31) << 1, w = p >> 5;
+	uint64_t x = q.w[w] << ip;
+	if(ip) x |= q.w[w + 1] >> (64 - ip);
+	x >>= (64 - 2 * k);
+	if(q.rc) {
+		x = ~x;
+		x = __brevll(x);
+		x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+		x >>= (64 - 2 * k);
+	}
+	return (uint32_t) x;
+}
+
+__device__ __forceinline__ int tn(const uint64_t *ts, int pos) {
+	return (int) ((ts[pos >> 5] >> (62 - ((pos & 31) << 1))) & 3ull);
+}
+
+// hashMapCCI_get semantics (hashmapcci.c:95-124): 0 absent, +pos unique, negative = duplicated
+__device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
+	if(km == 0) return 0;
+	const uint32_t sh = db.tpos_shift[t];
+	const uint2 *tab = db.tpos_slots + db.tpos_off[t];
+	const uint32_t msk = (1u << (32 - sh)) - 1u;
+	uint32_t sl = (km * 0x9E3779B1u) >> sh;
+	for(;;) {
+		const uint2 e = tab[sl];
+		if(e.y == 0) return 0;
+		if(e.x == km) return (int) e.y;
+		sl = (sl + 1u) & msk;
+	}
+}
+
+struct Lane {
+	int32_t *s32;
+	uint64_t *s64;
+	int64_t lanes;
+	int cap1;    // mem_cap + 1
+	int ncols;
+	const int *d;   // 25 ints in LDS
+	int M, MM, U, W1;
+};
+
+// MEM arrays: 0 tS, 1 tE, 2 qS, 3 qE, 4 weight, 5 score, 6 next
+#define MEMA(L, a, m) (L).s32[((int64_t) ((a) * (L).cap1 + (m))) * (L).lanes]
+#define ROWD(L, n) (L).s32[((int64_t) (7 * (L).cap1 + (n))) * (L).lanes]
+#define ROWP(L, n) (L).s32[((int64_t) (7 * (L).cap1 + (L).ncols + (n))) * (L).lanes]
+#define ROWTD(L, n) (L).s64[((int64_t) (n)) * (L).lanes]
+#define ROWTP(L, n) (L).s64[((int64_t) ((L).ncols + (n))) * (L).lanes]
+
+__device__ __forceinline__ Aln aln_from(int score, uint64_t st) {
+	Aln a;
+	a.score = score; a.pos = 0;
+	a.match = (int) (st & FMASK); a.tGaps = (int) ((st >> 21) & FMASK); a.qGaps = (int) ((st >> 42) & FMASK);
+	a.len = a.match + a.tGaps + a.qGaps;
+	return a;
+}
+
+__device__ Aln nw_degenerate(int t_len, int q_len, int U, int W1) {
+	Aln s = {0, 0, 0, 0, 0, 0};
+	if(t_len == q_len) return s;
+	if(t_len == 0) { s.len = q_len; s.tGaps = q_len; s.score = W1 + (q_len - 1) * U; }
+	else { s.len = t_len; s.qGaps = t_len; s.score = W1 + (t_len - 1) * U; }
+	return s;
+}
+
+// NW_score, nw.c:642-890 (mode k: 0 global, -1/-2 free leading template / both, +1/+2 free trailing)
+__device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
+                       int t_s, int t_e, int q_s, int q_e) {
+	const int U = L.U, W1 = L.W1;
+	int t_len = t_e - t_s;
+	const int q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	if(t_len == 0 || q_len == 0) return nw_degenerate(t_len, q_len, U, W1);
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(k == 2) {
+		for(int n = 0; n <= q_len; ++n) { ROWD(L, n) = 0; ROWP(L, n) = low; ROWTD(L, n) = 0; ROWTP(L, n) = 0; }
+	} else {
+		for(int n = 0; n < q_len; ++n) {
+			ROWD(L, n) = W1 + (q_len - 1 - n) * U; ROWP(L, n) = low;
+			ROWTD(L, n) = TG * (uint64_t) (q_len - n); ROWTP(L, n) = 0;
+		}
+		ROWD(L, q_len) = 0; ROWP(L, q_len) = 0; ROWTD(L, q_len) = 0; ROWTP(L, q_len) = 0;
+	}
+	int best = low;
+	uint64_t bestTD = 0;
+	int npos = t_e - 1;
+	for(int m = t_len - 1; m >= 0; --m, --npos) {
+		if(npos < 0) npos = tlen_total - 1;
+		int diagD = ROWD(L, q_len);
+		uint64_t diagTD = ROWTD(L, q_len);
+		int Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+		uint64_t TDright = (0 < k) ? 0ull : QG * (uint64_t) (t_len - m);
+		uint64_t TQright = 0;
+		ROWD(L, q_len) = Dright; ROWTD(L, q_len) = TDright;
+		int Qprev = low;
+		const int *drow = L.d + 5 * tn(ts, npos);
+		for(int n = q_len - 1; n >= 0; --n) {
+			const int Dp = ROWD(L, n), Pp = ROWP(L, n);
+			const uint64_t TDp = ROWTD(L, n), TPp = ROWTP(L, n);
+			int Q = Dright + W1, P = Dp + W1, D, mv;
+			bool ob = false;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
+			x = Pp + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
+			x = diagD + drow[qn(q, q_s + n)];
+			if(D <= x) { D = x; mv = 1; }
+			const uint64_t TQ = TG + (ob ? TDright : TQright);
+			const uint64_t TP = QG + (ob ? TDp : TPp);
+			const uint64_t TD = (mv == 1) ? (MA + diagTD) : (mv >= 4 ? TP : TQ);
+			ROWD(L, n) = D; ROWP(L, n) = P; ROWTD(L, n) = TD; ROWTP(L, n) = TP;
+			diagD = Dp; diagTD = TDp; Dright = D; TDright = TD; TQright = TQ; Qprev = Q;
+		}
+		if(k < 0 && best < Dright) { best = Dright; bestTD = TDright; }
+	}
+	if(k < 0) {
+		if(k == -2) {
+			for(int n = 0; n < q_len; ++n) {
+				const int D = ROWD(L, n);
+				if(best <= D) { best = D; bestTD = ROWTD(L, n); }
+			}
+		}
+		return aln_from(best, bestTD);
+	}
+	return aln_from(ROWD(L, 0), ROWTD(L, 0));
+}
+
+// NW_band_score, nw.c:892-1188. Column n of row m is column n-1 of row m+1.
+__device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
+                       int t_s, int t_e, int q_s, int q_e, int band) {
+	const int U = L.U, W1 = L.W1;
+	int t_len = t_e - t_s;
+	const int q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	if(t_len == 0 || q_len == 0) return nw_degenerate(t_len, q_len, U, W1);
+	if(band & 1) ++band;
+	const int half = band >> 1, bq = band + 1;
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	int c = (t_len + q_len) >> 1;
+	int sn = q_len - 1 - (c - half);
+	// rows are never read outside what the previous row wrote, except for cells the
+	// reference itself leaves to whatever the buffers held; start from zeroes like the oracle
+	for(int n = 0; n <= bq + 1; ++n) { ROWD(L, n) = 0; ROWP(L, n) = 0; ROWTD(L, n) = 0; ROWTP(L, n) = 0; }
+	if(k != 2) {
+		for(int n = sn - 1; n >= 0; --n) { ROWD(L, n) = W1 + (sn - n - 1) * U; ROWP(L, n) = low; ROWTD(L, n) = TG * (uint64_t) (sn - n); }
+		ROWD(L, sn) = 0; ROWP(L, sn) = 0; ROWTD(L, sn) = 0;
+	} else {
+		for(int n = sn; n >= 0; --n) { ROWD(L, n) = 0; ROWP(L, n) = low; ROWTD(L, n) = 0; }
+	}
+	int best = low, bm = 0, en = 0, n = 0;
+	uint64_t bestTD = 0;
+	int npos = t_e - 1;
+	for(int m = t_len - 1; m >= 0; --m, --npos, --c) {
+		if(npos < 0) npos = tlen_total - 1;
+		int sq = c + half, eq = c - half;
+		if(eq < 0) { eq = 0; ++en; } else en = 0;
+		int Qprev = low;
+		int Dright;
+		uint64_t TDright, TQright = 0;
+		if(sq < q_len - 1) {
+			sn = bq - 1;
+			// cell bq: D = low, E = 37 (query-gap extension carrying its open bit)
+			Dright = low;
+			TDright = QG + ROWTD(L, bq - 1);
+			ROWD(L, bq) = Dright; ROWTD(L, bq) = TDright;
+		} else {
+			sq = q_len - 1; sn = en + (q_len - eq);
+			Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			TDright = (0 < k) ? 0ull : (QG + ROWTD(L, sn - 1));
+			ROWD(L, sn) = Dright; ROWTD(L, sn) = TDright;
+			--sn;
+		}
+		const int *drow = L.d + 5 * tn(ts, npos);
+		int qp = sq;
+		for(n = sn; n > en; --qp, --n) {
+			const int Dp1 = ROWD(L, n - 1), Pp1 = ROWP(L, n - 1), Dp = ROWD(L, n);
+			const uint64_t TDp1 = ROWTD(L, n - 1), TPp1 = ROWTP(L, n - 1), TDp = ROWTD(L, n);
+			int Q = Dright + W1, P = Dp1 + W1, D, mv;
+			bool ob = false;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
+			x = Pp1 + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
+			x = Dp + drow[qn(q, q_s + qp)];
+			if(D <= x) { D = x; mv = 1; }
+			const uint64_t TQ = TG + (ob ? TDright : TQright);
+			const uint64_t TP = QG + (ob ? TDp1 : TPp1);
+			const uint64_t TD = (mv == 1) ? (MA + TDp) : (mv >= 4 ? TP : TQ);
+			ROWD(L, n) = D; ROWP(L, n) = P; ROWTD(L, n) = TD; ROWTP(L, n) = TP;
+			Dright = D; TDright = TD; TQright = TQ; Qprev = Q;
+		}
+		{	// band edge (nw.c:1079-1105): no gap-in-query state
+			const int Dp = ROWD(L, n);
+			const uint64_t TDp = ROWTD(L, n);
+			int Q = Dright + W1, mv;
+			bool ob = false;
+			const int x = Qprev + U;
+			if(Q < x) { Q = x; mv = 3; } else { mv = 2; ob = true; }
+			int D = Dp + drow[qn(q, q_s + qp)];
+			if(Q <= D) mv = 1; else D = Q;
+			const uint64_t TQ = TG + (ob ? TDright : TQright);
+			const uint64_t TD = (mv == 1) ? (MA + TDp) : TQ;
+			ROWD(L, n) = D; ROWP(L, n) = low; ROWTD(L, n) = TD; ROWTP(L, n) = 0;
+			if(eq == 0 && k < 0 && best < D) { best = D; bestTD = TD; bm = m; }
+		}
+	}
+	if(bm == 0) { best = ROWD(L, en); bestTD = ROWTD(L, en); }
+	if(k == -2) {
+		for(n = en; n < bq; ++n) {
+			const int D = ROWD(L, n);
+			if(best <= D) { best = D; bestTD = ROWTD(L, n); }
+		}
+	}
+	return aln_from(best, bestTD);
+}
+
+__device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
+                                       int t_s, int t_e, int q_s, int q_e, int tspan, int band) {
+	if(q_e - q_s <= band || tspan <= band) return nw_full(L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
+}
+
+// heuristic substitution model of chain.c (end / link / start terms)
+__device__ __forceinline__ int mism_score(int span, int k, int M, int MM) {
+	int Ms, MMs;
+	if(span == 2) { MMs = 2; Ms = 0; }
+	else {
+		MMs = span / k + (span % k ? 1 : 0);
+		MMs = max(2, MMs);
+		Ms = min(min(span - MMs, k), MMs);
+	}
+	return Ms * M + MMs * MM;
+}
+
+// chainSeeds, chain.c:79-260; returns best start, *bestScore its score
+__device__ int chain_seeds(const Lane &L, int n, int q_len, int t_len, int k, unsigned *mapQ) {
+	const int W1 = L.W1, U = L.U, M = L.M, MM = L.MM;
+	int best = 0, second = 0, bestPos = n - 1;
+	MEMA(L, 5, n) = 0; MEMA(L, 6, n) = 0;
+	for(int i = n - 1; i >= 0; --i) {
+		const int wi = MEMA(L, 4, i);
+		const int weight = wi * M, tEnd = MEMA(L, 1, i), qEnd = MEMA(L, 3, i);
+		int nxt = 0;
+		int span = min(t_len - tEnd, q_len - qEnd);
+		int gap = span - 1;
+		gap = gap ? gap * U + W1 : W1;
+		int sub = mism_score(span, k, M, MM);
+		int score = weight + (sub < gap ? gap : sub);
+		const int lim = min(n, i + 128);
+		for(int j = i + 1; j < lim; ++j) {
+			const int qSj = MEMA(L, 2, j), tSj = MEMA(L, 0, j);
+			if(qEnd < qSj) {
+				if(tEnd < tSj) {
+					const int tGap = tSj - tEnd, qGap = qSj - qEnd;
+					int g = abs(tGap - qGap);
+					if(g) g = (g - 1) * U + W1;
+					g += weight + MEMA(L, 5, j) + mism_score(min(tGap, qGap), k, M, MM);
+					if(score <= g) { score = g; nxt = j; }
+				} else if(k <= MEMA(L, 1, j) - tEnd) {
+					int g = qSj - qEnd;
+					if(g) g = (g - 1) * U + W1;
+					g += weight + MEMA(L, 5, j) - (tSj - tEnd) * M;
+					if(score < g) { score = g; nxt = j; }
+				}
+			} else if(k <= MEMA(L, 3, j) - qEnd) {
+				const int tStart = tSj + qEnd - qSj;
+				if(tEnd < tStart) {
+					int g = tStart - tEnd;
+					if(g) g = (g - 1) * U + W1;
+					g += weight + MEMA(L, 5, j) - (tStart - tEnd) * M;
+					if(score < g) { score = g; nxt = j; }
+				}
+			}
+		}
+		MEMA(L, 6, i) = nxt;
+		MEMA(L, 4, i) = nxt ? (wi + MEMA(L, 4, nxt) - k + 1) : (wi - (k - 1));
+		MEMA(L, 5, i) = score;
+		span = min(MEMA(L, 0, i), MEMA(L, 2, i));
+		gap = span - 1;
+		if(0 < gap) gap = gap * U + W1; else if(gap == 0) gap = W1; else gap = 0;
+		sub = mism_score(span, k, M, MM);
+		score += sub < gap ? gap : sub;
+		if(best <= score) {
+			if(nxt != bestPos) second = best;
+			best = score; bestPos = i;
+		} else if(second <= score && nxt != bestPos) {
+			second = best;
+		}
+	}
+	if(0 < best) {
+		const double wq = fmin(1.0, MEMA(L, 4, bestPos) / 10.0);
+		*mapQ = (unsigned) ceil(40 * (1 - 1.0 * second / best) * wq * log((double) best));
+	} else *mapQ = 0;
+	MEMA(L, 5, bestPos) = best;
+	return bestPos;
+}
+
+// one maximal exact match through k-mer hit (q pos j, template 1-based pos1); returns its query end
+__device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, const QView &q, int j, int pos1, int k, int segstop) {
+	int prev = pos1 - 2, kk;
+	for(kk = j - 1; 0 <= kk && 0 <= prev && qn(q, kk) == tn(ts, prev); --kk) --prev;
+	MEMA(L, 2, m) = kk + 1; MEMA(L, 0, m) = prev + 2;
+	int value = pos1 + k - 1, l = j + k;
+	while(l < segstop && value < t_len && qn(q, l) == tn(ts, value)) { ++l; ++value; }
+	MEMA(L, 3, m) = l; MEMA(L, 1, m) = value + 1;
+	MEMA(L, 4, m) = l - (kk + 1);
+	return l;
+}
+
+// KMA_score, align.c:509-748. status: 0 ok, 1 = MEM capacity exceeded
+__device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq, int *status) {
+	const Aln FAIL = {0, 1, 0, 0, 0, 0};
+	const int k = (int) db.kmersize, q_len = q.L, bw = 64, cap = L.cap1 - 1;
+	int nm = 0, j = 0;
+	for(int i = 1; i <= q.nN + 1; ++i) {
+		const int Ni = qN_at(q, i);
+		const int end = (i != q.nN + 1) ? Ni - k + 1 : q_len - k + 1;
+		const int segstop = end + k - 1;
+		while(j < end) {
+			const int v = tpos_get(db, t, q_kmer(q, j, k));
+			if(v == 0) { ++j; continue; }
+			if(v > 0) {
+				if(nm >= cap) { *status = 1; return FAIL; }
+				j = add_mem(L, nm, ts, t_len, q, j, v, k, segstop);
+				++nm;
+			} else {
+				const int32_t *dl = db.tpos_dups + (-v - 1);
+				const int cnt = dl[0];
+				int bias = j;
+				for(int c = 1; c <= cnt; ++c) {
+					if(nm >= cap) { *status = 1; return FAIL; }
+					const int qe = add_mem(L, nm, ts, t_len, q, j, dl[c], k, segstop);
+					++nm;
+					bias = max(bias, qe);
+				}
+				j = bias + 1;
+			}
+		}
+		j = Ni + 1;
+	}
+	if(!nm) return FAIL;
+	unsigned mapQ = 0;
+	int start = chain_seeds(L, nm, q_len, t_len, k, &mapQ);
+	if(mapQ < (unsigned) mq || MEMA(L, 5, start) < k) return FAIL;
+
+	// leading tail (leadTailAln, align.c:53-131)
+	Aln S = {0, 0, 0, 0, 0, 0};
+	{
+		const int t_e = MEMA(L, 0, start) - 1, q_e = MEMA(L, 2, start);
+		S.pos = t_e;
+		if(q_e) {
+			int t_s = 0, q_s = 0;
+			if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+			else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+			if(t_e - t_s > 0 && q_e - q_s > 0) {
+				const int band = abs(t_e - t_s - q_e + q_s) + bw;
+				const Aln r = nw_auto(L, ts, t_len, q, -1 - (t_s == 0), t_s, t_e, q_s, q_e, t_e - t_s, band);
+				S.pos -= r.len - r.tGaps;
+				S.score = r.score; S.len = r.len; S.match = r.match; S.tGaps = r.tGaps; S.qGaps = r.qGaps;
+			}
+		}
+	}
+	for(;;) {
+		const int qS = MEMA(L, 2, start), qE = MEMA(L, 3, start);
+		S.len += qE - qS; S.match += qE - qS;
+		for(int i = qS; i < qE; ++i) { const int b = qn(q, i); S.score += L.d[6 * b]; }
+		const int nxt = MEMA(L, 6, start);
+		if(!nxt) break;
+		const int q_s = qE, t_s = MEMA(L, 1, start) - 1;
+		start = nxt;
+		int qSn = MEMA(L, 2, start), tSn = MEMA(L, 0, start);
+		if(qSn < q_s) { tSn += q_s - qSn; qSn = q_s; }
+		int t_e = tSn - 1, t_l;
+		if(t_e < t_s) {
+			if(t_s <= MEMA(L, 1, start)) { qSn += t_s - t_e; t_e = t_s; t_l = 0; }
+			else t_l = t_len - t_s + t_e;
+		} else t_l = t_e - t_s;
+		MEMA(L, 2, start) = qSn; MEMA(L, 0, start) = tSn;
+		const int q_e = qSn;
+		if(abs(t_l - q_e + q_s) * L.U > q_len * L.M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+		if(t_l > 0 || q_e - q_s > 0) {
+			const int band = abs(t_l - q_e + q_s) + bw;
+			const Aln r = nw_auto(L, ts, t_len, q, 0, t_s, t_e, q_s, q_e, t_l, band);
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+	}
+	{	// trailing tail (trailTailAln, align.c:140-212)
+		const int t_s = MEMA(L, 1, start) - 1, q_s = MEMA(L, 3, start);
+		int q_e = q_len, t_e = t_len;
+		if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+			t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+		} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+			q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+		}
+		if(t_e - t_s > 0 && q_e - q_s > 0) {
+			const int band = abs(t_e - t_s - q_e + q_s) + bw;
+			const Aln r = nw_auto(L, ts, t_len, q, 1 + (t_e == t_len), t_s, t_e, q_s, q_e, t_e - t_s, band);
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+	}
+	return S;
+}
+
+__global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A) {
+	__shared__ int s_d[25];
+	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
+	__syncthreads();
+	const int64_t gtid = (int64_t) blockIdx.x * ATHREADS + threadIdx.x;
+	if(gtid >= A.lanes) return;
+	Lane L;
+	L.s32 = A.s32 + gtid; L.s64 = A.s64 + gtid; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
+	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
+	const int64_t n_tasks = A.T_off[A.n_reads];
+	const int k = (int) A.db.kmersize;
+	for(int64_t task = gtid; task < n_tasks; task += A.lanes) {
+		// read owning this task: last r with T_off[r] <= task
+		int64_t lo = 0, hi = A.n_reads;
+		while(hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if(A.T_off[mid] <= task) lo = mid; else hi = mid; }
+		const int64_t r = lo;
+		int rs = 0, alen = 0, start = 0, end = 0;
+		double norm = 0.0;
+		const int rcf = A.rc_flag[r];
+		const int q_len = A.len[r];
+		if(rcf > 0 && q_len >= k) {
+			QView q;
+			q.w = A.seq + A.seq_off[r]; q.L = q_len; q.rc = (A.flag[r] & 16) ? 1 : 0;
+			q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+			const int tmpl = A.T[task], at = abs(tmpl);
+			const int t_len = A.db.tlen[at];
+			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+			int status = 0;
+			const Aln st = kma_score(L, A.db, at, ts, t_len, q, A.mq, &status);
+			if(status) atomicMax(&A.counters[1], 3ull);
+			// alnFragsSE, alnfrags.c:1127-1168
+			alen = st.len; start = st.pos;
+			end = start + alen - st.tGaps;
+			if(t_len < end) end -= t_len;
+			const double denom = (q_len <= alen || t_len <= alen) ? (double) alen : (double) min(q_len, t_len);
+			rs = st.score;
+			if(A.minlen <= alen && ((A.mrc * q_len <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) norm = rs / denom;
+			else { rs = 0; norm = 0.0; }
+		}
+		A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
+	}
+}
+
+struct ReduceArgs {
+	int64_t n_reads;
+	const int32_t *rc_flag, *flag;
+	const int64_t *T_off;
+	const int32_t *T;
+	const int32_t *t_score, *t_alen, *t_start, *t_end;
+	const double *t_norm;
+	int k;
+	double scoreT;
+	int32_t *n_hits, *best_score, *out_flag, *h_tmpl, *h_score, *h_start, *h_end;
+	unsigned long long *alignment_scores, *uniq_alignment_scores;
+};
+
+// per read: hit filter of alnFragsSE (alnfrags.c:1165-1215) + update_Scores with
+// minFrac == 1.0 (updatescores.c:217-234, :275-277)
+__global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= R.n_reads) return;
+	const int64_t o = R.T_off[r], e = R.T_off[r + 1];
+	int nh = 0, bestRead = 0, fl = R.flag[r];
+	if(e > o) {
+		if(R.rc_flag[r] < 0) {
+			nh = -1;   // strand tie (anker_rc_comp path) not implemented on device yet
+		} else {
+			double bestScore = 0.0;
+			for(int64_t t = o; t < e; ++t) {
+				const int rs = R.t_score[t];
+				const double sc = R.t_norm[t];
+				if(R.k < rs && R.scoreT <= sc) {
+					if(bestScore < sc) bestScore = sc;
+					if(bestRead < rs) bestRead = rs;
+				}
+			}
+			if(bestRead > R.k) {
+				for(int64_t t = o; t < e; ++t) {
+					const int rs = R.t_score[t];
+					if(!(R.k < rs && R.scoreT <= R.t_norm[t])) continue;
+					const double ms = (double) (rs / R.t_alen[t]);
+					if(ms == bestScore || rs == bestRead) {
+						const int64_t w = o + nh;
+						const int tm = R.T[t];
+						R.h_tmpl[w] = tm; R.h_score[w] = rs; R.h_start[w] = R.t_start[t]; R.h_end[w] = R.t_end[t];
+						if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) rs);
+						++nh;
+					}
+				}
+				if(nh == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o])], (unsigned long long) bestRead);
+			} else {
+				fl |= 4;
+				bestRead = 0;
+			}
+		}
+	}
+	R.n_hits[r] = nh; R.best_score[r] = (nh > 0) ? bestRead : 0; R.out_flag[r] = fl;
+}
+
+} // namespace
+
+int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                           const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	if(n < 0 || !cands || !out || !p) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
+	if(!db->dev.tpos_slots) { kmahip_set_error("index has no .length.b/.seq.b: stage 3a unavailable"); return KMAHIP_EINVAL; }
+	if(p->minFrac != 1.0) { kmahip_set_error("minFrac != 1.0 not supported"); return KMAHIP_EINVAL; }
+	if(n == 0) return KMAHIP_OK;
+	int max_len = reads->max_len;
+	if(max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set for the align stage"); return KMAHIP_EINVAL; }
+	if(max_len > (1 << 20)) { kmahip_set_error("reads longer than 2^20 bases not supported"); return KMAHIP_EINVAL; }
+	// scratch geometry
+	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
+	const int ncols = max_len + 72;
+	const int64_t tasks_cap = cands->T_cap > 0 ? cands->T_cap : 1;
+	int64_t lanes = 256ll * 1024;
+	const size_t per_lane32 = (size_t) (7 * (mem_cap + 1) + 2 * ncols) * 4, per_lane64 = (size_t) 2 * ncols * 8;
+	while(lanes > 4096 && (size_t) lanes * (per_lane32 + per_lane64) > (6ull << 30)) lanes >>= 1;
+	if(ws->a_lanes != lanes || ws->a_mem_cap != mem_cap || ws->a_ncols != ncols) {
+		(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64);
+		ws->a_s32 = nullptr; ws->a_s64 = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->a_s32, (size_t) lanes * per_lane32));
+		HIP_TRY(hipMalloc((void **) &ws->a_s64, (size_t) lanes * per_lane64));
+		ws->a_lanes = lanes; ws->a_mem_cap = mem_cap; ws->a_ncols = ncols;
+	}
+	if(ws->a_task_cap < tasks_cap) {
+		(void) hipFree(ws->a_task);
+		ws->a_task = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (4 * 4 + 8)));
+		ws->a_task_cap = tasks_cap;
+	}
+	if(!ws->counters) HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, 8 * sizeof(unsigned long long), stream));
+
+	AlignArgs A;
+	A.db = db->dev;
+	A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.rc_flag = cands->rc_flag; A.flag = cands->flag; A.T_off = cands->T_off; A.T = cands->T;
+	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1;
+	for(int i = 0; i < 5; ++i) for(int j = 0; j < 5; ++j) A.d[i * 5 + j] = p->rw.d[i][j];
+	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
+	double *norm = (double *) ws->a_task;
+	int32_t *ti = (int32_t *) (norm + tasks_cap);
+	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap;
+	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
+	A.counters = ws->counters;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if(ws->timing_on) {
+		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+		HIP_TRY(hipEventRecord(ev0, stream));
+	}
+	hipLaunchKernelGGL(align_tasks_kernel, dim3((unsigned) (lanes / ATHREADS)), dim3(ATHREADS), 0, stream, A);
+	if(ws->timing_on) {
+		HIP_TRY(hipEventRecord(ev1, stream));
+		if(!ws->events2) ws->events2 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+		ws->events2->push_back({ev0, ev1});
+	}
+	ReduceArgs R;
+	R.n_reads = n; R.rc_flag = cands->rc_flag; R.flag = cands->flag; R.T_off = cands->T_off; R.T = cands->T;
+	R.t_score = A.t_score; R.t_alen = A.t_alen; R.t_start = A.t_start; R.t_end = A.t_end; R.t_norm = A.t_norm;
+	R.k = (int) db->dev.kmersize; R.scoreT = p->scoreT;
+	R.n_hits = out->n_hits; R.best_score = out->best_score; R.out_flag = out->flag;
+	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;
+	R.alignment_scores = (unsigned long long *) out->alignment_scores;
+	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
+	hipLaunchKernelGGL(reduce_reads_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, R);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}

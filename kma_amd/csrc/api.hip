@@ -1,6 +1,7 @@
 // api.hip -- extern "C" entry points of libkmahip.so (see include/kmahip.h).
 #include "kmahip_internal.h"
 #include <cstring>
+#include <vector>
 
 extern "C" int kmahip_ws_create(kmahip_db *db, kmahip_ws **out) {
 	if(!db || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
@@ -17,10 +18,12 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->pool); (void) hipFree(ws->counters); (void) hipFree(ws->overflow_items);
 	(void) hipFree(ws->dense); (void) hipFree(ws->blk_sums);
 	for(int i = 0; i < 8; ++i) (void) hipFree(ws->stage[i]);
-	if(ws->events) {
-		for(auto &e : *ws->events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
-		delete ws->events;
+	for(auto *ev : {ws->events, ws->events2}) {
+		if(!ev) continue;
+		for(auto &e : *ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+		delete ev;
 	}
+	(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64); (void) hipFree(ws->a_task);
 	delete ws;
 }
 
@@ -65,9 +68,9 @@ static int stage_reserve(kmahip_ws *ws, int slot, size_t bytes) {
 	return KMAHIP_OK;
 }
 
-extern "C" int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
-                              const kmahip_params *p, kmahip_cands *out) {
-	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+// host buffers in / out: reads are staged once; stage 3a optionally follows on the same staged batch
+static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                    kmahip_cands *out, kmahip_hits *hits) {
 	const int64_t n = reads->n_reads;
 	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
 	int rc;
@@ -108,7 +111,61 @@ extern "C" int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	const int64_t total = out->T_off[n];
 	if(total > out->T_cap) { kmahip_set_error("T_cap %lld too small, need %lld", (long long) out->T_cap, (long long) total); return KMAHIP_EOVERFLOW; }
 	if(total) HIP_TRY(hipMemcpy(out->T, o.T, (size_t) total * 4, hipMemcpyDeviceToHost));
-	return KMAHIP_OK;
+	if(!hits || n == 0) return KMAHIP_OK;
+
+	// stage 3a on the staged batch; device outputs in one block
+	const size_t D = db->info.DB_size;
+	const size_t hb = (size_t) n * 12 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
+	void *dh = nullptr;
+	HIP_TRY(hipMalloc(&dh, hb));
+	HIP_TRY(hipMemsetAsync(dh, 0, hb, s));
+	kmahip_hits h;
+	uint64_t *u = (uint64_t *) dh;
+	h.alignment_scores = u; h.uniq_alignment_scores = u + D;
+	int32_t *ip = (int32_t *) (u + 2 * D);
+	h.n_hits = ip; h.best_score = ip + n; h.flag = ip + 2 * n;
+	h.tmpl = ip + 3 * n; h.score = h.tmpl + total + 1; h.start = h.score + total + 1; h.end = h.start + total + 1;
+	rc = kmahip_launch_align_se(db, ws, &d, &o, p, &h, s);
+	if(!rc) {
+		hipError_t e = hipStreamSynchronize(s);
+		if(e != hipSuccess) { kmahip_set_error("align kernels failed: %s", hipGetErrorString(e)); rc = KMAHIP_EDEVICE; }
+	}
+	if(!rc) {
+		(void) hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost);
+		if(c[1] == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); rc = KMAHIP_EOVERFLOW; }
+	}
+	if(!rc) {
+		(void) hipMemcpy(hits->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(hits->best_score, h.best_score, (size_t) n * 4, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(hits->flag, h.flag, (size_t) n * 4, hipMemcpyDeviceToHost);
+		if(total) {
+			(void) hipMemcpy(hits->tmpl, h.tmpl, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->score, h.score, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->start, h.start, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->end, h.end, (size_t) total * 4, hipMemcpyDeviceToHost);
+		}
+		// ADD into the caller's accumulators
+		std::vector<uint64_t> acc(2 * D);
+		(void) hipMemcpy(acc.data(), u, 2 * D * 8, hipMemcpyDeviceToHost);
+		if(hits->alignment_scores) for(size_t i = 0; i < D; ++i) hits->alignment_scores[i] += acc[i];
+		if(hits->uniq_alignment_scores) for(size_t i = 0; i < D; ++i) hits->uniq_alignment_scores[i] += acc[D + i];
+		hipError_t e = hipGetLastError();
+		if(e != hipSuccess) { kmahip_set_error("copy back failed: %s", hipGetErrorString(e)); rc = KMAHIP_EDEVICE; }
+	}
+	(void) hipFree(dh);
+	return rc;
+}
+
+extern "C" int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
+                              const kmahip_params *p, kmahip_cands *out) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return run_host(db, ws, reads, p, out, nullptr);
+}
+
+extern "C" int kmahip_map_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                             kmahip_cands *cands_out, kmahip_hits *hits_out) {
+	if(!db || !ws || !reads || !p || !cands_out || !hits_out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return run_host(db, ws, reads, p, cands_out, hits_out);
 }
 
 extern "C" int kmahip_ws_set_timing(kmahip_ws *ws, int on) {
@@ -117,17 +174,24 @@ extern "C" int kmahip_ws_set_timing(kmahip_ws *ws, int on) {
 	return KMAHIP_OK;
 }
 
-extern "C" int kmahip_ws_get_timing(kmahip_ws *ws, double *total_ms, int64_t *launches) {
-	if(!ws || !total_ms || !launches) return KMAHIP_EINVAL;
+extern "C" int kmahip_ws_get_timing(kmahip_ws *ws, int kernel, double *total_ms, int64_t *launches) {
+	if(!ws || !total_ms || !launches || kernel < 0 || kernel > 1) return KMAHIP_EINVAL;
 	*total_ms = 0.0; *launches = 0;
-	if(!ws->events) return KMAHIP_OK;
-	for(auto &e : *ws->events) {
+	auto *ev = kernel ? ws->events2 : ws->events;
+	if(!ev) return KMAHIP_OK;
+	for(auto &e : *ev) {
 		float ms = 0.f;
 		HIP_TRY(hipEventSynchronize(e.second));
 		HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
 		*total_ms += ms; *launches += 1;
 		(void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second);
 	}
-	ws->events->clear();
+	ev->clear();
 	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_align_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                                   const kmahip_params *p, kmahip_hits *out, void *stream) {
+	if(!db || !ws || !reads || !cands || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_launch_align_se(db, ws, reads, cands, p, out, (hipStream_t) stream);
 }

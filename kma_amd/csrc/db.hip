@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -145,6 +146,58 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		if((rc = upload(db, db->h_tlen.data(), db->h_tlen.size(), &d.tlen)) ||
 		   (rc = upload(db, tseq.data(), tseq.size(), &d.tseq)) ||
 		   (rc = upload(db, off.data(), off.size(), &d.tseq_off))) { kmahip_db_close(db); return rc; }
+
+		// per-template k-mer position index
+		const int k = (int) tail[0];
+		std::vector<int64_t> poff(DB_size + 1, 0);
+		std::vector<uint32_t> pshift(DB_size, 31);
+		for(uint32_t t = 1; t < DB_size; ++t) {
+			const int64_t nk = std::max<int64_t>(0, (int64_t) db->h_tlen[t] - k + 1);
+			uint32_t lg = 4;
+			while((1ull << lg) * 2 < (uint64_t) nk * 3) ++lg;   // load <= 2/3
+			pshift[t] = 32 - lg;
+			poff[t + 1] = poff[t] + (1ll << lg);
+		}
+		poff[1] = poff[0] = 0;
+		for(uint32_t t = 1; t < DB_size; ++t) poff[t + 1] = poff[t] + (1ll << (32 - pshift[t]));
+		std::vector<uint2> pslots((size_t) poff[DB_size] + 1, make_uint2(0u, 0u));
+		std::vector<int32_t> dups(1, 0);
+		std::vector<std::pair<uint32_t, int32_t>> kp;
+		for(uint32_t t = 1; t < DB_size; ++t) {
+			const int tl = db->h_tlen[t];
+			const uint64_t *ts = tseq.data() + off[t];
+			kp.clear();
+			for(int i = 0; i + k <= tl; ++i) {
+				const int ip = (i & 31) << 1, w = i >> 5;
+				uint64_t x = ts[w] << ip;
+				if(ip) x |= ts[w + 1] >> (64 - ip);
+				const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
+				if(km) kp.push_back({km, i + 1});
+			}
+			std::sort(kp.begin(), kp.end());
+			const uint32_t sh = pshift[t];
+			const uint64_t msk = (1ull << (32 - sh)) - 1;
+			uint2 *tab = pslots.data() + poff[t];
+			for(size_t a = 0; a < kp.size();) {
+				size_t b = a;
+				while(b < kp.size() && kp[b].first == kp[a].first) ++b;
+				int32_t val;
+				if(b - a == 1) val = kp[a].second;
+				else {
+					val = -((int32_t) dups.size() + 1);
+					dups.push_back((int32_t) (b - a));
+					for(size_t c = a; c < b; ++c) dups.push_back(kp[c].second);
+				}
+				uint64_t sl = (uint32_t) (kp[a].first * 0x9E3779B1u) >> sh;
+				while(tab[sl].y != 0) sl = (sl + 1) & msk;
+				tab[sl] = make_uint2(kp[a].first, (uint32_t) val);
+				a = b;
+			}
+		}
+		if((rc = upload(db, pslots.data(), pslots.size(), &d.tpos_slots)) ||
+		   (rc = upload(db, poff.data(), poff.size(), &d.tpos_off)) ||
+		   (rc = upload(db, pshift.data(), pshift.size(), &d.tpos_shift)) ||
+		   (rc = upload(db, dups.data(), dups.size(), &d.tpos_dups))) { kmahip_db_close(db); return rc; }
 	}
 	*out = db;
 	return KMAHIP_OK;

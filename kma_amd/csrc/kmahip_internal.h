@@ -29,6 +29,15 @@ struct DevDB {
 	const int32_t *tlen;          // DB_size, tlen[0] = kmerindex
 	const uint64_t *tseq;         // 2-bit template store (.seq.b image + pad)
 	const int64_t *tseq_off;      // DB_size + 1 word offsets
+	// per-template position index (replaces the lazily built HashMapCCI,
+	// hashmapcci.c:470-505): linear-probing table of (kmer, val) per template;
+	// val > 0: the single 1-based position of the k-mer; val < 0: -(o + 1) where
+	// tpos_dups[o] = count followed by the ascending 1-based positions; val == 0
+	// empty. The poly-A k-mer 0 is never indexed (hashmapcci.c:414-417).
+	const uint2 *tpos_slots;
+	const int64_t *tpos_off;      // DB_size + 1 slot offsets
+	const uint32_t *tpos_shift;   // DB_size: 32 - log2(table size)
+	const int32_t *tpos_dups;
 };
 
 struct kmahip_db {
@@ -57,6 +66,14 @@ struct kmahip_ws {
 	int stats_on;
 	int timing_on;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events2;
+	// align stage
+	int32_t *a_s32;
+	uint64_t *a_s64;
+	int64_t a_lanes;
+	int a_mem_cap, a_ncols;
+	void *a_task;
+	int64_t a_task_cap;
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;
@@ -74,3 +91,5 @@ void kmahip_set_error(const char *fmt, ...);
 
 int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
                           const kmahip_params *p, kmahip_cands *out, hipStream_t stream);
+int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                           const kmahip_params *p, kmahip_hits *out, hipStream_t stream);

@@ -1,0 +1,77 @@
+"""Stage-3a parity on the GPU: HIP path (through the C-ABI) vs the reference frag_raw taps and the CPU oracle."""
+import numpy as np
+import pytest
+
+import golden_util
+from kma_amd import formats, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(g):
+    from kma_amd import binding
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        return db.map_se(g["batch"])
+    finally:
+        db.close()
+
+
+def test_align_matches_reference_frag_raw_tap(golden_se):
+    (rc_flag, flag, T_off, T), h = _run(golden_se)
+    golden_util.check_scan_against_s2(golden_se["s1"], golden_se["s2"], rc_flag, flag, T_off, T)
+    n = golden_util.check_align_against_frag_raw(golden_se["s1"], golden_util.load_frag_raw("se"), T_off, h)
+    assert n > 900
+
+
+def test_align_long_reads_banded_matches_reference_frag_raw_tap(golden_long):
+    (rc_flag, flag, T_off, T), h = _run(golden_long)
+    golden_util.check_scan_against_s2(golden_long["s1"], golden_long["s2"], rc_flag, flag, T_off, T)
+    n = golden_util.check_align_against_frag_raw(golden_long["s1"], golden_util.load_frag_raw("long"), T_off, h)
+    assert n > 200
+
+
+def _vs_oracle(prefix, batch):
+    import oracle
+    from kma_amd import binding
+    db = binding.KmaHipDB(prefix)
+    try:
+        (rc_flag, flag, T_off, T), h = db.map_se(batch)
+    finally:
+        db.close()
+    odb = oracle.OracleDB(prefix)
+    e = odb.scan_se(batch)
+    for a, b in zip(e, (rc_flag, flag, T_off, T)):
+        assert np.array_equal(a, b)
+    o = odb.align_se(batch, rc_flag, flag, T_off, T)
+    assert np.array_equal(o["n_hits"], h["n_hits"])
+    assert np.array_equal(o["best_score"], h["best_score"])
+    assert np.array_equal(o["out_flag"], h["flag"])
+    for i in np.nonzero(o["n_hits"] > 0)[0]:
+        s, c = int(T_off[i]), int(o["n_hits"][i])
+        for key in ("tmpl", "start", "end", "score"):
+            assert np.array_equal(o[key][s:s + c], h[key][s:s + c]), (i, key)
+    assert np.array_equal(o["alignment_scores"], h["alignment_scores"])
+    assert np.array_equal(o["uniq_alignment_scores"], h["uniq_alignment_scores"])
+    return o
+
+
+def test_align_vs_oracle_5variant_db(tmp_path):
+    names, seqs = synth.make_gene_db(n_families=40, variants=5, seed=17)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads, *_ = synth.make_reads(seqs, 6000, read_len=150, sub_rate=0.01, random_frac=0.03, n_rate=0.001, seed=9)
+    o = _vs_oracle(prefix, formats.pack_fixed(reads))
+    assert (o["n_hits"] > 0).sum() > 5000
+    assert o["alignment_scores"].sum() > 0 and o["uniq_alignment_scores"].sum() > 0
+
+
+def test_align_vs_oracle_indels_and_ragged(tmp_path):
+    names, seqs = synth.make_gene_db(n_families=12, variants=4, len_lo=800, len_hi=2500, seed=23)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    cat = np.concatenate(seqs)
+    reads = synth.make_long_reads(cat, 300, read_len=400, sub=0.03, dele=0.02, ins=0.02, seed=4)
+    short, *_ = synth.make_reads(seqs, 500, read_len=75, sub_rate=0.03, seed=6)
+    reads = reads + list(short)
+    _vs_oracle(prefix, formats.pack_ragged(reads))
