@@ -61,41 +61,60 @@ def write_fastq_fixed(path, codes):
 
 
 def cpu_baseline(prefix, codes, tmp):
-    """Reference KMA (oracle/_ref/kma, stage 1 + stage 2 via its -s2 tap) or, if the
-    binary is absent, the C oracle port, timed on a bounded sample of the same reads."""
+    """Reference KMA (oracle/_ref/kma) on a bounded sample of the step's reads, using the
+    reference's own per-stage CPU timers (-status): stage 2 "ankering" + stage 3a "KMA mapping".
+    Falls back to the C oracle port when the binary is absent."""
+    import re
     n = len(codes)
     ref = os.path.join(ROOT, "oracle", "_ref", "kma")
     if os.path.exists(ref):
         fq = os.path.join(tmp, "sample.fq")
         write_fastq_fixed(fq, codes)
-        cmd = [ref, "-i", fq, "-o", os.path.join(tmp, "cpu"), "-t_db", prefix, "-1t1", "-t", "1", "-s2"]
+        cmd = [ref, "-i", fq, "-o", os.path.join(tmp, "cpu"), "-t_db", prefix, "-1t1", "-t", "1", "-status",
+               "-nc", "-na", "-nf"]
         t0 = time.time()
-        with open(os.devnull, "wb") as dn:
-            subprocess.run(cmd, stdout=dn, stderr=dn, check=True)
-        dt = time.time() - t0
-        return dict(value=n / dt, unit="reads/s", cores=2, kind="reference",
-                    sample=f"{n} of the step's reads; reference kma -1t1 -t 1 -s2 (stage-1 FASTQ parse thread + "
-                           f"one stage-2 scan thread), {dt:.1f} s wall")
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True)
+        wall = time.time() - t0
+        err = r.stderr.decode()
+        m2 = re.search(r"ankering query:\s*([0-9.]+) s", err)
+        m3 = re.search(r"KMA mapping time\s*([0-9.]+) s", err)
+        if m2 and m3:
+            s2, s3 = float(m2.group(1)), float(m3.group(1))
+            return dict(value=n / (s2 + s3), unit="reads/s", cores=1, kind="reference",
+                        sample=f"{n} of the step's reads; reference kma -1t1 -t 1 -status: its own stage timers give "
+                               f"stage 2 (ankering) {s2:.2f} s + stage 3a (mapping) {s3:.2f} s of CPU time, one thread "
+                               f"each (whole pipeline incl. parse/ConClave/assembly: {wall:.1f} s wall)",
+                        stage2_s=s2, stage3a_s=s3, whole_pipeline_wall_s=wall)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from kma_amd import formats
     batch = formats.pack_fixed(codes)
     odb = oracle.OracleDB(prefix)
     t0 = time.time()
-    odb.scan_se(batch)
+    e = odb.scan_se(batch)
+    odb.align_se(batch, *e)
     dt = time.time() - t0
     return dict(value=n / dt, unit="reads/s", cores=1, kind="port",
-                sample=f"{n} of the step's reads; oracle/scan.c scalar port, {dt:.1f} s")
+                sample=f"{n} of the step's reads; oracle/scan.c + oracle/align.c scalar port, {dt:.1f} s")
 
 
-def parity_sample(prefix, codes, got):
-    """Checker leg: the first reads of the step vs the CPU oracle (bit-exact)."""
+def parity_sample(prefix, codes, got_scan, got_hits):
+    """Checker leg: the first reads of the step vs the CPU oracle (bit-exact), stages 2 and 3a."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     from kma_amd import formats
     batch = formats.pack_fixed(codes)
-    e = oracle.OracleDB(prefix).scan_se(batch)
-    return all(np.array_equal(a, b) for a, b in zip(e, got))
+    odb = oracle.OracleDB(prefix)
+    e = odb.scan_se(batch)
+    ok = all(np.array_equal(a, b) for a, b in zip(e, got_scan))
+    o = odb.align_se(batch, *e)
+    ok = ok and np.array_equal(o["n_hits"], got_hits["n_hits"]) and np.array_equal(o["best_score"], got_hits["best_score"])
+    T_off = e[2]
+    for i in np.nonzero(o["n_hits"] > 0)[0]:
+        a, c = int(T_off[i]), int(o["n_hits"][i])
+        for key in ("tmpl", "start", "end", "score"):
+            ok = ok and np.array_equal(o[key][a:a + c], got_hits[key][a:a + c])
+    return bool(ok)
 
 
 def main():
@@ -124,12 +143,27 @@ def main():
         rc_flag = torch.empty(n, dtype=torch.int32, device=dev)
         flag = torch.empty(n, dtype=torch.int32, device=dev)
         T_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        T = torch.empty(8 * n, dtype=torch.int32, device=dev)
+        tcap = 8 * n
+        T = torch.empty(tcap, dtype=torch.int32, device=dev)
+        n_hits = torch.empty(n, dtype=torch.int32, device=dev)
+        best = torch.empty(n, dtype=torch.int32, device=dev)
+        oflag = torch.empty(n, dtype=torch.int32, device=dev)
+        h_t, h_sc, h_s, h_e = (torch.empty(tcap, dtype=torch.int32, device=dev) for _ in range(4))
+        D = int(db.info.DB_size)
+        aln = torch.zeros(D, dtype=torch.int64, device=dev)
+        uniq = torch.zeros(D, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
 
         def step():
+            aln.zero_(); uniq.zero_()
             db.scan_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], rc_flag, flag, T_off, T,
                            stream=stream)
+            db.align_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, rc_flag, flag, T_off, T,
+                            n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
+            if world > 1:
+                # the path's only exchange: SUM of the two ConClave score vectors over the read shards
+                dist.all_reduce(aln, op=dist.ReduceOp.SUM)
+                dist.all_reduce(uniq, op=dist.ReduceOp.SUM)
 
         def fence():
             torch.cuda.synchronize()
@@ -147,7 +181,8 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
-        kern_ms, launches = db.get_timing()
+        scan_ms, scan_n = db.get_timing(0)
+        aln_ms, aln_n = db.get_timing(1)
         db.set_timing(False)
         db.status(stream)
         if world > 1:
@@ -155,19 +190,33 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
-        # algorithmic work of one launch (separate, untimed, counter-enabled launch)
+        # algorithmic work of one launch (separate, untimed, counter-enabled launches)
         db.set_stats(True)
-        step()
+        db.scan_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], rc_flag, flag, T_off, T, stream=stream)
         st = db.get_stats(stream)
+        db.align_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, rc_flag, flag, T_off, T,
+                        n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
+        ast = db.get_align_stats(stream)
         db.set_stats(False)
-        mapped = int((T_off[1:] > T_off[:-1]).sum().item())
+        cand = int((T_off[1:] > T_off[:-1]).sum().item())
+        mapped = int((n_hits > 0).sum().item())
+        ties = int((n_hits < 0).sum().item())
         total_T = int(T_off[-1].item())
         W = (150 + 31) // 32
-        # 12 B per probe (4 B bucket directory + 4 B key + 4 B value index in the
-        # reference layout), 2 B per value-list element read, packed read in, S2 fields out
-        alg_bytes = 12 * st.probes + 2 * st.value_elems + n * (8 * W + 4 + 8) + n * (4 + 4 + 8) + 4 * total_T
-        kern_s = kern_ms / 1e3 / max(1, launches)
-        achieved = alg_bytes / kern_s / 1e9
+        scan_s = scan_ms / 1e3 / max(1, scan_n)
+        aln_s = aln_ms / 1e3 / max(1, aln_n)
+        # SURVEY §8(d) algorithmic bytes.  scan: 12 B per probe (4 B directory + 4 B key + 4 B value index in the
+        # reference layout) + 2 B per value-list element + packed read in + S2 fields out.
+        scan_bytes = 12 * st.probes + 2 * st.value_elems + n * (8 * W + 4 + 8) + n * (4 + 4 + 8) + 4 * total_T
+        # align: 12 B per position-index lookup (4 B index + 8 B template word), 2 bits per MEM base on both
+        # sequences, packed read in per task, 24 B out per task; DP cells move no HBM bytes (no E matrix)
+        aln_bytes = 12 * ast.lookups + ast.mem_bases // 2 + ast.tasks * (8 * W + 24) + n * 12
+        if aln_s >= scan_s:
+            dom = dict(kernel="align_tasks_kernel", kernel_ms=aln_s * 1e3, achieved=aln_bytes / aln_s / 1e9,
+                       algorithmic_bytes_per_launch=aln_bytes)
+        else:
+            dom = dict(kernel="scan_se_kernel", kernel_ms=scan_s * 1e3, achieved=scan_bytes / scan_s / 1e9,
+                       algorithmic_bytes_per_launch=scan_bytes)
 
         out = {
             "metric": "mapped reads/sec (whole node), 10M×150bp vs 5k-gene DB, 1/2/4/8 GPU",
@@ -183,27 +232,35 @@ def main():
             "dtype": "i32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n} x 150 bp SE reads per GPU vs {5 * a.families}-gene DB (k=16), -1t1; "
-                            "hot path covered: stage 2 (k-mer probe + candidate-template scoring, "
-                            "save_kmers/hashMap_get); stage 3a not yet on device",
+                "workload": f"{n} x 150 bp SE reads per GPU vs {5 * a.families}-gene DB (k=16), -1t1; one step = "
+                            "stage 2 (k-mer probe + candidate-template scoring) + stage 3a (MEM seeding, chaining, "
+                            "NW extension, per-read hit selection, ConClave score vectors) on reads resident in HBM",
                 "reads_per_gpu": n, "genes": 5 * a.families, "db_kmers": int(db.info.n_kmers),
-                "probe_table_MB": round(db.info.hash_bytes / 1e6, 1),
-                "mapped_fraction": mapped / n, "parallelism": f"read-shard x{world}",
+                "probe_table_MB": round(db.info.hash_bytes / 1e6, 1), "db_total_MB": round(db.info.total_bytes / 1e6, 1),
+                "stage2_candidate_fraction": cand / n, "mapped_fraction": mapped / n, "strand_tie_reads": ties,
+                "align_tasks": total_T, "parallelism": f"read-shard x{world}",
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "scan_se_kernel", "kernel_ms": kern_s * 1e3,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "probes_per_launch": int(st.probes), "probes_per_s": st.probes / kern_s,
+                "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": None,
+                "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes), "GB/s": scan_bytes / scan_s / 1e9,
+                         "probes_per_s": st.probes / scan_s},
+                "align": {"kernel_ms": aln_s * 1e3, "lookups": int(ast.lookups), "dp_cells": int(ast.dp_cells),
+                          "GCUPS": ast.dp_cells / aln_s / 1e9, "GB/s": aln_bytes / aln_s / 1e9,
+                          "tasks_per_s": ast.tasks / aln_s},
             },
         }
         if rank == 0 and world == 1 and not a.no_cpu and keep:
             codes = rd["codes"][:keep]
             k = min(50_000, keep)
             got = [x.cpu().numpy() for x in (rc_flag[:k], flag[:k], T_off[:k + 1])]
-            got.append(T[: int(got[2][-1])].cpu().numpy())
-            out["config"]["parity_first_reads_vs_oracle"] = bool(parity_sample(prefix, codes[:k], got))
+            nt = int(got[2][-1])
+            got.append(T[:nt].cpu().numpy())
+            hits = dict(n_hits=n_hits[:k].cpu().numpy(), best_score=best[:k].cpu().numpy(), tmpl=h_t[:nt].cpu().numpy(),
+                        score=h_sc[:nt].cpu().numpy(), start=h_s[:nt].cpu().numpy(), end=h_e[:nt].cpu().numpy())
+            out["config"]["parity_first_reads_vs_oracle"] = parity_sample(prefix, codes[:k], got, hits)
             out["cpu_baseline"] = cpu_baseline(prefix, codes, tmp)
         elif rank == 0:
             out["cpu_baseline"] = None

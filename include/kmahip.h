@@ -171,6 +171,15 @@ typedef struct kmahip_scan_stats {
 	uint64_t value_elems;
 	uint64_t active_strands;
 } kmahip_scan_stats;
+/* same for the last align call: template-index lookups, bases inside MEMs,
+ * DP cells filled, (read, candidate) tasks aligned */
+typedef struct kmahip_align_stats {
+	uint64_t lookups;
+	uint64_t mem_bases;
+	uint64_t dp_cells;
+	uint64_t tasks;
+} kmahip_align_stats;
+int kmahip_align_get_stats(kmahip_ws *ws, kmahip_align_stats *st, void *stream);
 /* counting costs atomics in the kernel: off by default */
 int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);

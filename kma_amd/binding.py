@@ -50,6 +50,10 @@ class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64)]
 
 
+class AlignStats(C.Structure):
+    _fields_ = [("lookups", C.c_uint64), ("mem_bases", C.c_uint64), ("dp_cells", C.c_uint64), ("tasks", C.c_uint64)]
+
+
 class KmaHipError(RuntimeError):
     pass
 
@@ -83,6 +87,7 @@ def lib():
         L.kmahip_ws_get_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.kmahip_align_se_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Cands), C.POINTER(Params),
                                           C.POINTER(Hits), C.c_void_p]
+        L.kmahip_align_get_stats.argtypes = [C.c_void_p, C.POINTER(AlignStats), C.c_void_p]
         L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
         _lib = L
     return _lib
@@ -175,6 +180,11 @@ class KmaHipDB:
     def get_stats(self, stream=None) -> ScanStats:
         st = ScanStats()
         _check(lib().kmahip_scan_get_stats(self.ws, C.byref(st), C.c_void_p(stream or 0)))
+        return st
+
+    def get_align_stats(self, stream=None) -> AlignStats:
+        st = AlignStats()
+        _check(lib().kmahip_align_get_stats(self.ws, C.byref(st), C.c_void_p(stream or 0)))
         return st
 
     def set_timing(self, on: bool):

@@ -52,6 +52,7 @@ struct AlignArgs {
 	int mem_cap;     // MEM slots per lane (arrays hold mem_cap + 1)
 	int ncols;       // DP columns per lane
 	unsigned long long *counters;   // [1] status
+	int stats;
 };
 
 struct Aln { int score, len, pos, match, tGaps, qGaps; };
@@ -127,6 +128,7 @@ struct Lane {
 	int ncols;
 	const int *d;   // 25 ints in LDS
 	int M, MM, U, W1;
+	unsigned long long *cnt;   // work counters (stats launches only): [3] lookups [4] MEM bases [5] DP cells [6] tasks
 };
 
 // MEM arrays: 0 tS, 1 tE, 2 qS, 3 qE, 4 weight, 5 score, 6 next
@@ -161,6 +163,7 @@ __device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const 
 	if(t_len < 0) t_len += tlen_total;
 	if(t_len == 0 || q_len == 0) return nw_degenerate(t_len, q_len, U, W1);
 	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
 	if(k == 2) {
 		for(int n = 0; n <= q_len; ++n) { ROWD(L, n) = 0; ROWP(L, n) = low; ROWTD(L, n) = 0; ROWTP(L, n) = 0; }
 	} else {
@@ -226,6 +229,7 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 	if(band & 1) ++band;
 	const int half = band >> 1, bq = band + 1;
 	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len * bq);
 	int c = (t_len + q_len) >> 1;
 	int sn = q_len - 1 - (c - half);
 	// rows are never read outside what the previous row wrote, except for cells the
@@ -395,6 +399,7 @@ __device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, cons
 	while(l < segstop && value < t_len && qn(q, l) == tn(ts, value)) { ++l; ++value; }
 	MEMA(L, 3, m) = l; MEMA(L, 1, m) = value + 1;
 	MEMA(L, 4, m) = l - (kk + 1);
+	if(L.cnt) atomicAdd(&L.cnt[4], (unsigned long long) (l - (kk + 1)));
 	return l;
 }
 
@@ -409,6 +414,7 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 		const int segstop = end + k - 1;
 		while(j < end) {
 			const int v = tpos_get(db, t, q_kmer(q, j, k));
+			if(L.cnt) atomicAdd(&L.cnt[3], 1ull);
 			if(v == 0) { ++j; continue; }
 			if(v > 0) {
 				if(nm >= cap) { *status = 1; return FAIL; }
@@ -501,6 +507,7 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 	Lane L;
 	L.s32 = A.s32 + gtid; L.s64 = A.s64 + gtid; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
+	L.cnt = A.stats ? A.counters : nullptr;
 	const int64_t n_tasks = A.T_off[A.n_reads];
 	const int k = (int) A.db.kmersize;
 	for(int64_t task = gtid; task < n_tasks; task += A.lanes) {
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 			const int t_len = A.db.tlen[at];
 			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
 			int status = 0;
+			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
 			const Aln st = kma_score(L, A.db, at, ts, t_len, q, A.mq, &status);
 			if(status) atomicMax(&A.counters[1], 3ull);
 			// alnFragsSE, alnfrags.c:1127-1168
@@ -623,8 +631,8 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (4 * 4 + 8)));
 		ws->a_task_cap = tasks_cap;
 	}
-	if(!ws->counters) HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long)));
-	HIP_TRY(hipMemsetAsync(ws->counters, 0, 8 * sizeof(unsigned long long), stream));
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
 
 	AlignArgs A;
 	A.db = db->dev;
@@ -638,6 +646,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap;
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
 	A.counters = ws->counters;
+	A.stats = ws->stats_on;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(ws->timing_on) {
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));

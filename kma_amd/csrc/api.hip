@@ -38,7 +38,11 @@ extern "C" int kmahip_ws_status(kmahip_ws *ws, void *stream) {
 	unsigned long long c[8];
 	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
-	if(c[1]) { kmahip_set_error("output capacity too small (status %llu)", c[1]); return KMAHIP_EOVERFLOW; }
+	if(c[1]) {
+		HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
+		kmahip_set_error(c[1] == 3 ? "seed (MEM) capacity per read/template pair exceeded" : "output capacity too small (status %llu)", c[1]);
+		return KMAHIP_EOVERFLOW;
+	}
 	return KMAHIP_OK;
 }
 
@@ -54,6 +58,15 @@ extern "C" int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void 
 	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
 	st->probes = c[3]; st->value_elems = c[4]; st->active_strands = c[5];
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_align_get_stats(kmahip_ws *ws, kmahip_align_stats *st, void *stream) {
+	if(!ws || !st || !ws->counters) return KMAHIP_EINVAL;
+	unsigned long long c[8];
+	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
+	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+	st->lookups = c[3]; st->mem_bases = c[4]; st->dp_cells = c[5]; st->tasks = c[6];
 	return KMAHIP_OK;
 }
 
@@ -102,6 +115,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 	HIP_TRY(hipStreamSynchronize(s));
 	unsigned long long c[8];
 	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	if(c[1]) HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
 	if(c[1] == 1) {
 		// internal candidate pool too small: grow and let the caller retry
 		ws->cap_reads = 0;
@@ -132,6 +146,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 	}
 	if(!rc) {
 		(void) hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost);
+		if(c[1]) (void) hipMemset(ws->counters + 1, 0, sizeof(unsigned long long));
 		if(c[1] == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); rc = KMAHIP_EOVERFLOW; }
 	}
 	if(!rc) {

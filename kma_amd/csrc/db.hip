@@ -85,10 +85,12 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	// exist[] is only the reference's bucket directory: skipped
 	if(fseek(f, (long) (size * 4), SEEK_CUR)) { fclose(f); return KMAHIP_EIO; }
 	const bool u16 = DB_size < 65535; // hashmapkma.c:340-348
-	std::vector<uint8_t> values(v_index * (u16 ? 2 : 4));
+	// 8 zero elements of slack: the scan kernel fetches a list head as count + 7 ids
+	const size_t vbytes = v_index * (u16 ? 2 : 4);
+	std::vector<uint8_t> values(vbytes + 8 * 4, 0);
 	std::vector<uint32_t> keys(n + 1), vidx(n);
 	uint32_t tail[2] = {mlen, 0};
-	bool ok = read_exact(f, values.data(), values.size()) && read_exact(f, keys.data(), (n + 1) * 4) && read_exact(f, vidx.data(), n * 4);
+	bool ok = read_exact(f, values.data(), vbytes) && read_exact(f, keys.data(), (n + 1) * 4) && read_exact(f, vidx.data(), n * 4);
 	if(ok && read_exact(f, &tail[0], 4)) ok = read_exact(f, &tail[1], 4);
 	fclose(f);
 	if(!ok) { kmahip_set_error("truncated %s.comp.b", prefix); return KMAHIP_EIO; }
@@ -123,8 +125,8 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	memset(&d, 0, sizeof d);
 	d.DB_size = DB_size; d.kmersize = tail[0]; d.mlen = mlen; d.nb_log2 = nb_log2; d.values_u16 = u16;
 	if((rc = upload(db, slots.data(), slots.size(), &d.slots))) { kmahip_db_close(db); return rc; }
-	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index, &d.values16);
-	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index, &d.values32);
+	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index + 8, &d.values16);
+	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index + 8, &d.values32);
 	if(rc) { kmahip_db_close(db); return rc; }
 
 	// template lengths + 2-bit template store (needed by stage 3a)

@@ -199,11 +199,35 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 	const uint64_t active = ((uint64_t) s_active[1] << 32) | s_active[0];
 	const int maxnpos = s_maxnpos;
 
-	// ---- per-item machine state (wave 0, lane = item) ------------------------
+	// ---- per-item machine state: 16 items per wave, lanes 0-15 of each of the 4 waves --
+	// (the other lanes only probe). Spreading the 64 machines over all four waves lets
+	// their value-list loads overlap; inside a wave the lanes advance in "rounds": every
+	// lane first walks its LDS column (no global access) up to its next value-set change,
+	// then all lanes handle one change each, so the serial depth is the number of set
+	// changes per item (~30 for a 150 bp read), not the number of k-mer positions.
 	uint32_t last = NONE;
 	int gaps = 0, HIT = 0, acc = 0, nlist = 0, ncur = 0, hits = 0;
 	bool overflow = false;
-	const bool my_active = tid < ITEMS && ((active >> tid) & 1ull);
+	const int lane = tid & 63;
+	const int a_own = ((tid >> 6) << 4) | (lane & 15);
+	const bool owner = lane < 16;
+	const bool my_active = owner && ((active >> a_own) & 1ull);
+
+	// one template of a newly opened value set (savekmers.c:2584-2655)
+	auto open_template = [&](const int a, const uint32_t t) {
+		int e = -1;
+		for(int x = 0; x < nlist; ++x) if(t_id[x * ITEMS + a] == t) { e = x; break; }
+		if(e >= 0) {
+			t_score[e * ITEMS + a] += bridge(HIT - t_ext[e * ITEMS + a], k, A.M, A.MM, A.U, A.W1);
+		} else {
+			if(nlist == TCAP) { overflow = true; return; }
+			e = nlist++;
+			t_id[e * ITEMS + a] = t;
+			t_score[e * ITEMS + a] = k * A.M;
+		}
+		t_cur[ncur * ITEMS + a] = (uint8_t) e;
+		++ncur;
+	};
 
 	for(int c0 = 0; c0 < maxnpos; c0 += CHUNK) {
 		// stage forward words covering this pass
@@ -244,59 +268,61 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 		}
 		if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
 		__syncthreads();
-		// sequential score machine
-		if(my_active && !overflow) {
-			const int a = tid;
-			const int npos = s_len[a] - k + 1;
-			const int jend = min(CHUNK, npos - c0);
-			for(int jj = 0; jj < jend; ++jj) {
-				const uint32_t vi = vi_buf[jj * ITEMS + a];
-				if(vi == MISS) { ++gaps; continue; }
-				const int p = c0 + jj;
-				if(vi == last) {
-					acc += bridge(gaps, k, A.M, A.MM, A.U, A.W1);
-				} else {
-					if(last != NONE) {
-						for(int c = 0; c < ncur; ++c) {
-							const int e = t_cur[c * ITEMS + a];
-							t_score[e * ITEMS + a] += acc;
-							t_ext[e * ITEMS + a] = HIT;
-						}
+		// score machines, in rounds of one value-set change per lane
+		{
+			const int a = a_own;
+			const bool run = my_active && !overflow;
+			const int jend = run ? min(CHUNK, s_len[a] - k + 1 - c0) : 0;
+			int jj = 0;
+			for(;;) {
+				uint32_t vi = MISS;
+				bool pending = false;
+				while(jj < jend) {
+					vi = vi_buf[jj * ITEMS + a];
+					if(vi == MISS) { ++gaps; ++jj; continue; }
+					if(vi == last) { acc += bridge(gaps, k, A.M, A.MM, A.U, A.W1); HIT = c0 + jj; gaps = 0; ++hits; ++jj; continue; }
+					pending = true;
+					break;
+				}
+				if(!__any(pending)) break;
+				if(pending) {
+					const int p = c0 + jj;
+					// fetch the new list first: count + up to 7 ids in flight together
+					uint32_t cnt, el[7];
+					if(db.values_u16) {
+						const uint16_t *vp = db.values16 + vi;
+						cnt = vp[0];
+#pragma unroll
+						for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+					} else {
+						const uint32_t *vp = db.values32 + vi;
+						cnt = vp[0];
+#pragma unroll
+						for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+					}
+					// close the old set (savekmers.c:2575-2582)
+					for(int c = 0; c < ncur; ++c) {
+						const int e = t_cur[c * ITEMS + a];
+						t_score[e * ITEMS + a] += acc;
+						t_ext[e * ITEMS + a] = HIT;
 					}
 					HIT = p - 1;
-					const int cnt = (int) value_at(db, vi, 0);
-					if(STATS) atomicAdd(&s_stats[1], (uint32_t) cnt + 1u);
 					ncur = 0;
-					for(int i = 1; i <= cnt; ++i) {
-						const uint32_t t = value_at(db, vi, i);
-						int e = -1;
-						for(int x = 0; x < nlist; ++x) if(t_id[x * ITEMS + a] == t) { e = x; break; }
-						if(e >= 0) {
-							t_score[e * ITEMS + a] += bridge(HIT - t_ext[e * ITEMS + a], k, A.M, A.MM, A.U, A.W1);
-						} else {
-							if(nlist == TCAP) { overflow = true; break; }
-							e = nlist++;
-							t_id[e * ITEMS + a] = t;
-							t_score[e * ITEMS + a] = k * A.M;
-						}
-						t_cur[ncur * ITEMS + a] = (uint8_t) e;
-						++ncur;
-					}
-					if(overflow) break;
-					last = vi;
-					acc = 0;
+					if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
+#pragma unroll
+					for(int i = 0; i < 7; ++i) if((uint32_t) i < cnt && !overflow) open_template(a, el[i]);
+					for(uint32_t i = 8; i <= cnt && !overflow; ++i) open_template(a, value_at(db, vi, (int) i));
+					if(overflow) { jj = jend; }
+					else { last = vi; acc = 0; HIT = p; gaps = 0; ++hits; ++jj; }
 				}
-				HIT = p;
-				gaps = 0;
-				++hits;
 			}
 		}
 		__syncthreads();
 	}
 
 	// ---- finish items -------------------------------------------------------
-	if(tid < ITEMS) {
-		const int a = tid;
+	if(owner) {
+		const int a = a_own;
 		const int64_t item = item0 + a;
 		if((item >> 1) < A.n_reads) {
 			int best = 0, nb = 0;
@@ -539,7 +565,7 @@ static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 		HIP_TRY(hipMalloc((void **) &ws->blk_sums, ws->blk_cap * sizeof(int64_t)));
 		ws->cap_reads = cap;
 	}
-	if(!ws->counters) HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long)));
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
 	if(!ws->dense) {
 		// overflow scratch: up to 4096 concurrent items, bounded to 1 GiB
 		int64_t slots = 4096;
@@ -566,7 +592,9 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
-	HIP_TRY(hipMemsetAsync(ws->counters, 0, 8 * sizeof(unsigned long long), stream));
+	// word 1 (status) is sticky until kmahip_ws_status reads it
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
 	if(n == 0) {
 		HIP_TRY(hipMemsetAsync(out->T_off, 0, sizeof(int64_t), stream));
 		return KMAHIP_OK;
