@@ -131,6 +131,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from kma_amd import binding, formats, synth, synth_dev
+    from kma_amd.dist import allreduce_scores
     tmp = tempfile.mkdtemp(prefix=f"kmabench{rank}_")
     try:
         names, seqs = synth.make_gene_db(a.families, 5, 600, 1500, 0.04, seed=12345)
@@ -160,10 +161,8 @@ def main():
                            stream=stream)
             db.align_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, rc_flag, flag, T_off, T,
                             n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
-            if world > 1:
-                # the path's only exchange: SUM of the two ConClave score vectors over the read shards
-                dist.all_reduce(aln, op=dist.ReduceOp.SUM)
-                dist.all_reduce(uniq, op=dist.ReduceOp.SUM)
+            # the path's only exchange: SUM of the two ConClave score vectors over the read shards (no-op at N=1)
+            allreduce_scores(aln, uniq)
 
         def fence():
             torch.cuda.synchronize()

@@ -22,6 +22,7 @@
  *                             (chain.h:39, chain.c:79-260), NW_score /
  *                             NW_band_score (nw.h:62-63, nw.c:642-1188),
  *                             update_Scores (updatescores.c:203-298)
+ *   kmahip_map_se             both of the above on one staged batch (host buffers)
  *   kmahip_allreduce_scores   (new) SUM of alignment_scores/uniq_alignment_scores
  *                             across read shards before runConClave
  *                             (runkma.c:563-594); see INTEGRATION.md
@@ -159,6 +160,13 @@ int kmahip_align_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 /* Stages 2 + 3a with host buffers in and out (reads staged once). */
 int kmahip_map_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                   kmahip_cands *cands_out, kmahip_hits *hits_out);
+
+/* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
+ * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
+ * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);
+ * librccl is resolved at run time, the library does not link against it. */
+int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scores, uint64_t *uniq_alignment_scores,
+                            size_t DB_size, void *stream);
 
 /* status of the last *_dev call on this workspace after the stream has been
  * synchronised: 0 or KMAHIP_EOVERFLOW */

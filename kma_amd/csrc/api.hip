@@ -1,6 +1,7 @@
 // api.hip -- extern "C" entry points of libkmahip.so (see include/kmahip.h).
 #include "kmahip_internal.h"
 #include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 extern "C" int kmahip_ws_create(kmahip_db *db, kmahip_ws **out) {
@@ -209,4 +210,27 @@ extern "C" int kmahip_align_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_re
                                    const kmahip_params *p, kmahip_hits *out, void *stream) {
 	if(!db || !ws || !reads || !cands || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	return kmahip_launch_align_se(db, ws, reads, cands, p, out, (hipStream_t) stream);
+}
+
+// RCCL is bound lazily so that a single-GPU host never needs librccl and a host that
+// already loaded one (e.g. through PyTorch) keeps using that copy.
+extern "C" int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scores, uint64_t *uniq_alignment_scores,
+                                       size_t DB_size, void *stream) {
+	typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+	static allreduce_fn fn = nullptr;
+	if(!nccl_comm || !alignment_scores || !uniq_alignment_scores) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(!fn) {
+		fn = (allreduce_fn) dlsym(RTLD_DEFAULT, "ncclAllReduce");
+		if(!fn) {
+			void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+			if(!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+			if(h) fn = (allreduce_fn) dlsym(h, "ncclAllReduce");
+		}
+		if(!fn) { kmahip_set_error("RCCL (librccl.so) not found"); return KMAHIP_EDEVICE; }
+	}
+	const int ncclUint64 = 5, ncclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+	int rc = fn(alignment_scores, alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
+	if(!rc) rc = fn(uniq_alignment_scores, uniq_alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
+	if(rc) { kmahip_set_error("ncclAllReduce failed with code %d", rc); return KMAHIP_EDEVICE; }
+	return KMAHIP_OK;
 }
