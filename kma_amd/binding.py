@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmahip.so")
+LIB_PATH = os.environ.get("KMAHIP_LIB") or os.path.join(_HERE, "libkmahip.so")
 
 
 class Rewards(C.Structure):

@@ -17,6 +17,11 @@
 // D/P/Q as three packed 21-bit counters ("count-carrying DP"), including the
 // walk's quirk that a gap run ends on the first cell with EITHER may-open bit.
 #include "kmahip_internal.h"
+#include <cstdlib>
+
+#ifdef KMAHIP_DIAG
+__device__ unsigned long long *g_diag_hist = nullptr;
+#endif
 
 namespace {
 
@@ -24,7 +29,6 @@ constexpr int ATHREADS = 256;
 constexpr uint64_t MA = 1ull;             // one diagonal step
 constexpr uint64_t TG = 1ull << 21;       // one gap-in-template step (query consumed)
 constexpr uint64_t QG = 1ull << 42;       // one gap-in-query step (template consumed)
-constexpr uint64_t FMASK = (1ull << 21) - 1;
 
 struct AlignArgs {
 	DevDB db;
@@ -53,6 +57,7 @@ struct AlignArgs {
 	int ncols;       // DP columns per lane
 	unsigned long long *counters;   // [1] status
 	int stats;
+	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
 };
 
 struct Aln { int score, len, pos, match, tGaps, qGaps; };
@@ -105,6 +110,41 @@ __device__ __forceinline__ int tn(const uint64_t *ts, int pos) {
 	return (int) ((ts[pos >> 5] >> (62 - ((pos & 31) << 1))) & 3ull);
 }
 
+__device__ __forceinline__ uint64_t revcomp64(uint64_t x) {
+	x = __brevll(~x);
+	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+
+// 32 bases starting at base `pos` of a 2-bit word array (MSB first); reads word+1
+__device__ __forceinline__ uint64_t win2(const uint64_t *w, int pos) {
+	const int ip = (pos & 31) << 1, i = pos >> 5;
+	uint64_t x = w[i] << ip;
+	if(ip) x |= w[i + 1] >> (64 - ip);
+	return x;
+}
+
+// 32 bases of the ORIENTED read starting at oriented position i (N packed as A;
+// bases past the read end are garbage)
+__device__ __forceinline__ uint64_t qwin(const QView &q, int i) {
+	if(!q.rc) return win2(q.w, i);
+	const int s = q.L - 32 - i;           // forward window that mirrors [i, i+32)
+	if(s >= 0) return revcomp64(win2(q.w, s));
+	return revcomp64(q.w[0] >> ((-s) << 1));
+}
+
+// Query codes of a DP problem without a global load per cell: a cached 32-base window of the oriented
+// read, reloaded when the column index leaves it (columns are walked in descending order).
+struct QCursor {
+	uint64_t w;
+	int blk;      // window covers problem columns [32*blk, 32*blk + 32)
+	__device__ __forceinline__ int code(const QView &q, int q_s, int n) {
+		const int b = n >> 5;
+		if(b != blk) { blk = b; w = qwin(q, q_s + (b << 5)); }
+		if(q.nN && q_is_N(q, q_s + n)) return 4;
+		return (int) ((w >> (62 - ((n & 31) << 1))) & 3ull);
+	}
+};
+
 // hashMapCCI_get semantics (hashmapcci.c:95-124): 0 absent, +pos unique, negative = duplicated
 __device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
 	if(km == 0) return 0;
@@ -128,6 +168,9 @@ struct Lane {
 	int ncols;
 	const int *d;   // 25 ints in LDS
 	int M, MM, U, W1;
+	uint32_t *wide;            // this wave's LDS row slots (WSLOTS x 4 planes x WCOLS words)
+	int ablate;
+	int diag_uniform;          // d[0][0] == d[1][1] == d[2][2] == d[3][3]: a MEM (never holds an N) scores span * d[0][0]
 	unsigned long long *cnt;   // work counters (stats launches only): [3] lookups [4] MEM bases [5] DP cells [6] tasks
 };
 
@@ -138,10 +181,37 @@ struct Lane {
 #define ROWTD(L, n) (L).s64[((int64_t) (n)) * (L).lanes]
 #define ROWTP(L, n) (L).s64[((int64_t) ((L).ncols + (n))) * (L).lanes]
 
+constexpr int WCOLS = 64;           // LDS row slots for "wide" problems: 17..63 query columns
+constexpr int WSLOTS = 2;           // slots per wave
+
+struct GRows {
+	typedef uint64_t ST;
+	static constexpr int SH = 21;
+	int32_t *d, *p;
+	uint64_t *td, *tp;
+	int64_t stride;
+	__device__ __forceinline__ int32_t &D(int n) const { return d[(int64_t) n * stride]; }
+	__device__ __forceinline__ int32_t &P(int n) const { return p[(int64_t) n * stride]; }
+	__device__ __forceinline__ uint64_t &TD(int n) const { return td[(int64_t) n * stride]; }
+	__device__ __forceinline__ uint64_t &TP(int n) const { return tp[(int64_t) n * stride]; }
+};
+
+struct LRows {
+	typedef uint32_t ST;
+	static constexpr int SH = 10;
+	uint32_t *base;   // planes D, P, TD, TP of WCOLS words each, one lane at a time
+	__device__ __forceinline__ int32_t &D(int n) const { return ((int32_t *) base)[n]; }
+	__device__ __forceinline__ int32_t &P(int n) const { return ((int32_t *) base)[WCOLS + n]; }
+	__device__ __forceinline__ uint32_t &TD(int n) const { return base[2 * WCOLS + n]; }
+	__device__ __forceinline__ uint32_t &TP(int n) const { return base[3 * WCOLS + n]; }
+};
+
+template <int SH>
 __device__ __forceinline__ Aln aln_from(int score, uint64_t st) {
 	Aln a;
+	const uint64_t fm = (1ull << SH) - 1;
 	a.score = score; a.pos = 0;
-	a.match = (int) (st & FMASK); a.tGaps = (int) ((st >> 21) & FMASK); a.qGaps = (int) ((st >> 42) & FMASK);
+	a.match = (int) (st & fm); a.tGaps = (int) ((st >> SH) & fm); a.qGaps = (int) ((st >> (2 * SH)) & fm);
 	a.len = a.match + a.tGaps + a.qGaps;
 	return a;
 }
@@ -155,8 +225,12 @@ __device__ Aln nw_degenerate(int t_len, int q_len, int U, int W1) {
 }
 
 // NW_score, nw.c:642-890 (mode k: 0 global, -1/-2 free leading template / both, +1/+2 free trailing)
-__device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
+// R = where the single DP row lives (GRows: HBM scratch, 21-bit walk counters).
+template <class R>
+__device__ Aln nw_full(const R r, const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
                        int t_s, int t_e, int q_s, int q_e) {
+	typedef typename R::ST ST;
+	const ST MA = 1, TG = (ST) 1 << R::SH, QG = (ST) 1 << (2 * R::SH);
 	const int U = L.U, W1 = L.W1;
 	int t_len = t_e - t_s;
 	const int q_len = q_e - q_s;
@@ -165,30 +239,31 @@ __device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const 
 	const int low = (t_len + q_len) * (L.MM + U + W1);
 	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
 	if(k == 2) {
-		for(int n = 0; n <= q_len; ++n) { ROWD(L, n) = 0; ROWP(L, n) = low; ROWTD(L, n) = 0; ROWTP(L, n) = 0; }
+		for(int n = 0; n <= q_len; ++n) { r.D(n) = 0; r.P(n) = low; r.TD(n) = 0; r.TP(n) = 0; }
 	} else {
 		for(int n = 0; n < q_len; ++n) {
-			ROWD(L, n) = W1 + (q_len - 1 - n) * U; ROWP(L, n) = low;
-			ROWTD(L, n) = TG * (uint64_t) (q_len - n); ROWTP(L, n) = 0;
+			r.D(n) = W1 + (q_len - 1 - n) * U; r.P(n) = low;
+			r.TD(n) = TG * (ST) (q_len - n); r.TP(n) = 0;
 		}
-		ROWD(L, q_len) = 0; ROWP(L, q_len) = 0; ROWTD(L, q_len) = 0; ROWTP(L, q_len) = 0;
+		r.D(q_len) = 0; r.P(q_len) = 0; r.TD(q_len) = 0; r.TP(q_len) = 0;
 	}
 	int best = low;
-	uint64_t bestTD = 0;
+	ST bestTD = 0;
+	QCursor qc; qc.blk = -1; qc.w = 0;
 	int npos = t_e - 1;
 	for(int m = t_len - 1; m >= 0; --m, --npos) {
 		if(npos < 0) npos = tlen_total - 1;
-		int diagD = ROWD(L, q_len);
-		uint64_t diagTD = ROWTD(L, q_len);
+		int diagD = r.D(q_len);
+		ST diagTD = r.TD(q_len);
 		int Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
-		uint64_t TDright = (0 < k) ? 0ull : QG * (uint64_t) (t_len - m);
-		uint64_t TQright = 0;
-		ROWD(L, q_len) = Dright; ROWTD(L, q_len) = TDright;
+		ST TDright = (0 < k) ? (ST) 0 : QG * (ST) (t_len - m);
+		ST TQright = 0;
+		r.D(q_len) = Dright; r.TD(q_len) = TDright;
 		int Qprev = low;
 		const int *drow = L.d + 5 * tn(ts, npos);
 		for(int n = q_len - 1; n >= 0; --n) {
-			const int Dp = ROWD(L, n), Pp = ROWP(L, n);
-			const uint64_t TDp = ROWTD(L, n), TPp = ROWTP(L, n);
+			const int Dp = r.D(n), Pp = r.P(n);
+			const ST TDp = r.TD(n), TPp = r.TP(n);
 			int Q = Dright + W1, P = Dp + W1, D, mv;
 			bool ob = false;
 			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
@@ -196,12 +271,12 @@ __device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const 
 			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
 			x = Pp + U;
 			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
-			x = diagD + drow[qn(q, q_s + n)];
+			x = diagD + drow[qc.code(q, q_s, n)];
 			if(D <= x) { D = x; mv = 1; }
-			const uint64_t TQ = TG + (ob ? TDright : TQright);
-			const uint64_t TP = QG + (ob ? TDp : TPp);
-			const uint64_t TD = (mv == 1) ? (MA + diagTD) : (mv >= 4 ? TP : TQ);
-			ROWD(L, n) = D; ROWP(L, n) = P; ROWTD(L, n) = TD; ROWTP(L, n) = TP;
+			const ST TQ = TG + (ob ? TDright : TQright);
+			const ST TP = QG + (ob ? TDp : TPp);
+			const ST TD = (mv == 1) ? (MA + diagTD) : (mv >= 4 ? TP : TQ);
+			r.D(n) = D; r.P(n) = P; r.TD(n) = TD; r.TP(n) = TP;
 			diagD = Dp; diagTD = TDp; Dright = D; TDright = TD; TQright = TQ; Qprev = Q;
 		}
 		if(k < 0 && best < Dright) { best = Dright; bestTD = TDright; }
@@ -209,13 +284,88 @@ __device__ Aln nw_full(const Lane &L, const uint64_t *ts, int tlen_total, const 
 	if(k < 0) {
 		if(k == -2) {
 			for(int n = 0; n < q_len; ++n) {
-				const int D = ROWD(L, n);
-				if(best <= D) { best = D; bestTD = ROWTD(L, n); }
+				const int D = r.D(n);
+				if(best <= D) { best = D; bestTD = r.TD(n); }
 			}
 		}
-		return aln_from(best, bestTD);
+		return aln_from<R::SH>(best, (uint64_t) bestTD);
 	}
-	return aln_from(ROWD(L, 0), ROWTD(L, 0));
+	return aln_from<R::SH>(r.D(0), (uint64_t) r.TD(0));
+}
+
+// NW_score for narrow problems (q_len <= NC, t_len + q_len < 1000): the whole DP row lives in registers
+// (static indices after full unrolling), the query codes in one 64-bit window, walk counters in 10-bit fields.
+// No memory traffic inside the cell loop except the per-row d[][] reads from LDS.
+template <int NC>
+__device__ Aln nw_full_reg(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
+                           int t_s, int t_e, int q_s, int q_e) {
+	const int U = L.U, W1 = L.W1;
+	int t_len = t_e - t_s;
+	const int q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	if(t_len == 0 || q_len == 0) return nw_degenerate(t_len, q_len, U, W1);
+	const uint32_t MA = 1u, TG = 1u << 10, QG = 1u << 20;
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
+	// query codes of columns 0..q_len-1: 2-bit window + N mask
+	const uint64_t qw = qwin(q, q_s);
+	uint32_t nmask = 0;
+	for(int i = 1; i <= q.nN; ++i) { const int p = qN_at(q, i) - q_s; if(0 <= p && p < NC) nmask |= 1u << p; }
+	int D[NC], P[NC];
+	uint32_t TD[NC], TP[NC];
+#pragma unroll
+	for(int c = 0; c < NC; ++c) {
+		if(k == 2) { D[c] = 0; TD[c] = 0; }
+		else { D[c] = W1 + (q_len - 1 - c) * U; TD[c] = TG * (uint32_t) max(0, q_len - c); }
+		P[c] = low; TP[c] = 0;
+	}
+	int best = low, Db_prev = 0;
+	uint32_t bestTD = 0, TDb_prev = 0;
+	int npos = t_e - 1;
+	if(npos < 0) npos = tlen_total - 1;
+	int tcode = tn(ts, npos);
+	for(int m = t_len - 1; m >= 0; --m) {
+		const int *drow = L.d + 5 * tcode;
+		// next row's template base: issue the load now, consume after this row
+		--npos;
+		if(npos < 0) npos = tlen_total - 1;
+		const int tnext = (m > 0) ? tn(ts, npos) : 0;
+		int diagD = Db_prev, Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U), Qprev = low;
+		uint32_t diagTD = TDb_prev, TDright = (0 < k) ? 0u : QG * (uint32_t) (t_len - m), TQright = 0;
+		Db_prev = Dright; TDb_prev = TDright;
+#pragma unroll
+		for(int c = NC - 1; c >= 0; --c) {
+			if(c < q_len) {
+				const int qc = ((nmask >> c) & 1u) ? 4 : (int) ((qw >> (62 - 2 * c)) & 3ull);
+				const int Dp = D[c], Pp = P[c];
+				const uint32_t TDp = TD[c], TPp = TP[c];
+				int Q = Dright + W1, Pn = Dp + W1, Dn, mv;
+				bool ob = false;
+				if(Q < Pn) { Dn = Pn; mv = 4; } else { Dn = Q; mv = 2; }
+				int x = Qprev + U;
+				if(Q < x) { Q = x; if(Dn <= x) { Dn = x; mv = 3; } } else ob = true;
+				x = Pp + U;
+				if(Pn < x) { Pn = x; if(Dn <= x) { Dn = x; mv = 5; } } else ob = true;
+				x = diagD + drow[qc];
+				if(Dn <= x) { Dn = x; mv = 1; }
+				const uint32_t TQ = TG + (ob ? TDright : TQright);
+				const uint32_t TPn = QG + (ob ? TDp : TPp);
+				const uint32_t TDn = (mv == 1) ? (MA + diagTD) : (mv >= 4 ? TPn : TQ);
+				D[c] = Dn; P[c] = Pn; TD[c] = TDn; TP[c] = TPn;
+				diagD = Dp; diagTD = TDp; Dright = Dn; TDright = TDn; TQright = TQ; Qprev = Q;
+			}
+		}
+		if(k < 0 && best < Dright) { best = Dright; bestTD = TDright; }
+		tcode = tnext;
+	}
+	if(k < 0) {
+		if(k == -2) {
+#pragma unroll
+			for(int c = 0; c < NC; ++c) if(c < q_len && best <= D[c]) { best = D[c]; bestTD = TD[c]; }
+		}
+		return aln_from<10>(best, (uint64_t) bestTD);
+	}
+	return aln_from<10>(D[0], (uint64_t) TD[0]);
 }
 
 // NW_band_score, nw.c:892-1188. Column n of row m is column n-1 of row m+1.
@@ -242,6 +392,7 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 		for(int n = sn; n >= 0; --n) { ROWD(L, n) = 0; ROWP(L, n) = low; ROWTD(L, n) = 0; }
 	}
 	int best = low, bm = 0, en = 0, n = 0;
+	QCursor qc; qc.blk = -1; qc.w = 0;
 	uint64_t bestTD = 0;
 	int npos = t_e - 1;
 	for(int m = t_len - 1; m >= 0; --m, --npos, --c) {
@@ -276,7 +427,7 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
 			x = Pp1 + U;
 			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
-			x = Dp + drow[qn(q, q_s + qp)];
+			x = Dp + drow[qc.code(q, q_s, qp)];
 			if(D <= x) { D = x; mv = 1; }
 			const uint64_t TQ = TG + (ob ? TDright : TQright);
 			const uint64_t TP = QG + (ob ? TDp1 : TPp1);
@@ -291,7 +442,7 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 			bool ob = false;
 			const int x = Qprev + U;
 			if(Q < x) { Q = x; mv = 3; } else { mv = 2; ob = true; }
-			int D = Dp + drow[qn(q, q_s + qp)];
+			int D = Dp + drow[qc.code(q, q_s, qp)];
 			if(Q <= D) mv = 1; else D = Q;
 			const uint64_t TQ = TG + (ob ? TDright : TQright);
 			const uint64_t TD = (mv == 1) ? (MA + TDp) : TQ;
@@ -306,12 +457,46 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 			if(best <= D) { best = D; bestTD = ROWTD(L, n); }
 		}
 	}
-	return aln_from(best, bestTD);
+	return aln_from<21>(best, bestTD);
 }
 
 __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
                                        int t_s, int t_e, int q_s, int q_e, int tspan, int band) {
-	if(q_e - q_s <= band || tspan <= band) return nw_full(L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+#ifdef KMAHIP_DIAG
+	if(L.ablate & 1) return nw_degenerate(tspan, 0, L.U, L.W1);
+	if((L.ablate & 8) && q_e - q_s > 16) return nw_degenerate(tspan, 0, L.U, L.W1);
+	if((L.ablate & 16) && q_e - q_s == 1) return nw_degenerate(tspan, 0, L.U, L.W1);
+	if((L.ablate & 32) && q_e - q_s > 1 && q_e - q_s <= 16) return nw_degenerate(tspan, 0, L.U, L.W1);
+	if(L.cnt && g_diag_hist) {
+		const int ql = q_e - q_s, b = min(63, ql);
+		atomicAdd(&g_diag_hist[b], 1ull);
+		atomicAdd(&g_diag_hist[64 + b], (unsigned long long) max(0, tspan) * ql);
+		atomicAdd(&g_diag_hist[128 + (k + 2)], 1ull);
+		atomicAdd(&g_diag_hist[136 + min(63, max(0, tspan) >> 2)], 1ull);
+	}
+#endif
+	if(q_e - q_s <= band || tspan <= band) {
+		if(q_e - q_s <= 16 && tspan + (q_e - q_s) < 1000) return nw_full_reg<16>(L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+		if(q_e - q_s < WCOLS && tspan + (q_e - q_s) < 1000) {
+			// ~1 % of the tasks: the row goes to one of the wave's LDS slots; the lanes of this wave that
+			// are here together take turns, WSLOTS at a time (they run in lock step anyway)
+			const unsigned long long here = __ballot(1);
+			const int rank = __popcll(here & ((1ull << (threadIdx.x & 63)) - 1ull));
+			const int total = __popcll(here);
+			Aln res = {0, 0, 0, 0, 0, 0};
+			for(int round = 0; round * WSLOTS < total; ++round) {
+				if(rank / WSLOTS == round) {
+					LRows lr;
+					lr.base = L.wide + (rank % WSLOTS) * 4 * WCOLS;
+					res = nw_full(lr, L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+				}
+			}
+			return res;
+		}
+		GRows gr;
+		gr.d = &ROWD(L, 0); gr.p = &ROWP(L, 0); gr.td = &ROWTD(L, 0); gr.tp = &ROWTP(L, 0); gr.stride = L.lanes;
+		return nw_full(gr, L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+	}
 	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
 }
 
@@ -390,13 +575,36 @@ __device__ int chain_seeds(const Lane &L, int n, int q_len, int t_len, int k, un
 	return bestPos;
 }
 
-// one maximal exact match through k-mer hit (q pos j, template 1-based pos1); returns its query end
-__device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, const QView &q, int j, int pos1, int k, int segstop) {
-	int prev = pos1 - 2, kk;
-	for(kk = j - 1; 0 <= kk && 0 <= prev && qn(q, kk) == tn(ts, prev); --kk) --prev;
+// one maximal exact match through k-mer hit (q pos j, template 1-based pos1); returns its query end.
+// Same result as the reference's base-by-base loops (align.c:548-575), done 32 bases per step on the
+// 2-bit words: lowq = first query position after the previous N (an N never matches, so the backward
+// walk cannot cross it), segstop = end of the N-free segment.
+__device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, const QView &q, int j, int pos1, int k, int lowq, int segstop) {
+	// backward
+	int kk = j - 1, prev = pos1 - 2;
+	for(;;) {
+		const int room = min(kk - lowq + 1, prev + 1);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t xq = qwin(q, kk - step + 1) >> (64 - 2 * step);
+		const uint64_t xt = win2(ts, prev - step + 1) >> (64 - 2 * step);
+		const uint64_t x = xq ^ xt;
+		const int same = x ? (__ffsll((long long) x) - 1) >> 1 : step;
+		kk -= same; prev -= same;
+		if(same < step) break;
+	}
 	MEMA(L, 2, m) = kk + 1; MEMA(L, 0, m) = prev + 2;
+	// forward
 	int value = pos1 + k - 1, l = j + k;
-	while(l < segstop && value < t_len && qn(q, l) == tn(ts, value)) { ++l; ++value; }
+	for(;;) {
+		const int room = min(segstop - l, t_len - value);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t x = (qwin(q, l) ^ win2(ts, value)) >> (64 - 2 * step);
+		const int same = x ? (__clzll((long long) x) - (64 - 2 * step)) >> 1 : step;
+		l += same; value += same;
+		if(same < step) break;
+	}
 	MEMA(L, 3, m) = l; MEMA(L, 1, m) = value + 1;
 	MEMA(L, 4, m) = l - (kk + 1);
 	if(L.cnt) atomicAdd(&L.cnt[4], (unsigned long long) (l - (kk + 1)));
@@ -407,7 +615,10 @@ __device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, cons
 __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq, int *status) {
 	const Aln FAIL = {0, 1, 0, 0, 0, 0};
 	const int k = (int) db.kmersize, q_len = q.L, bw = 64, cap = L.cap1 - 1;
-	int nm = 0, j = 0;
+	int nm = 0, j = 0, lowq = 0;
+#ifdef KMAHIP_DIAG
+	if(L.ablate & 2) return FAIL;
+#endif
 	for(int i = 1; i <= q.nN + 1; ++i) {
 		const int Ni = qN_at(q, i);
 		const int end = (i != q.nN + 1) ? Ni - k + 1 : q_len - k + 1;
@@ -418,7 +629,7 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 			if(v == 0) { ++j; continue; }
 			if(v > 0) {
 				if(nm >= cap) { *status = 1; return FAIL; }
-				j = add_mem(L, nm, ts, t_len, q, j, v, k, segstop);
+				j = add_mem(L, nm, ts, t_len, q, j, v, k, lowq, segstop);
 				++nm;
 			} else {
 				const int32_t *dl = db.tpos_dups + (-v - 1);
@@ -426,7 +637,7 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 				int bias = j;
 				for(int c = 1; c <= cnt; ++c) {
 					if(nm >= cap) { *status = 1; return FAIL; }
-					const int qe = add_mem(L, nm, ts, t_len, q, j, dl[c], k, segstop);
+					const int qe = add_mem(L, nm, ts, t_len, q, j, dl[c], k, lowq, segstop);
 					++nm;
 					bias = max(bias, qe);
 				}
@@ -434,9 +645,13 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 			}
 		}
 		j = Ni + 1;
+		lowq = Ni + 1;
 	}
 	if(!nm) return FAIL;
 	unsigned mapQ = 0;
+#ifdef KMAHIP_DIAG
+	if(L.ablate & 4) return FAIL;
+#endif
 	int start = chain_seeds(L, nm, q_len, t_len, k, &mapQ);
 	if(mapQ < (unsigned) mq || MEMA(L, 5, start) < k) return FAIL;
 
@@ -460,7 +675,8 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 	for(;;) {
 		const int qS = MEMA(L, 2, start), qE = MEMA(L, 3, start);
 		S.len += qE - qS; S.match += qE - qS;
-		for(int i = qS; i < qE; ++i) { const int b = qn(q, i); S.score += L.d[6 * b]; }
+		if(L.diag_uniform) S.score += (qE - qS) * L.d[0];
+		else for(int i = qS; i < qE; ++i) { const int b = qn(q, i); S.score += L.d[6 * b]; }
 		const int nxt = MEMA(L, 6, start);
 		if(!nxt) break;
 		const int q_s = qE, t_s = MEMA(L, 1, start) - 1;
@@ -500,6 +716,7 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 
 __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
+	__shared__ uint32_t s_wide[(ATHREADS / 64) * WSLOTS * 4 * WCOLS];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
 	__syncthreads();
 	const int64_t gtid = (int64_t) blockIdx.x * ATHREADS + threadIdx.x;
@@ -508,6 +725,9 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 	L.s32 = A.s32 + gtid; L.s64 = A.s64 + gtid; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = A.stats ? A.counters : nullptr;
+	L.wide = s_wide + (threadIdx.x >> 6) * WSLOTS * 4 * WCOLS;
+	L.ablate = A.ablate;
+	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
 	const int64_t n_tasks = A.T_off[A.n_reads];
 	const int k = (int) A.db.kmersize;
 	for(int64_t task = gtid; task < n_tasks; task += A.lanes) {
@@ -647,6 +867,10 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
 	A.counters = ws->counters;
 	A.stats = ws->stats_on;
+	A.ablate = 0;
+#ifdef KMAHIP_DIAG
+	if(const char *e = getenv("KMAHIP_ABLATE_ALIGN")) A.ablate = atoi(e);
+#endif
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(ws->timing_on) {
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
@@ -670,3 +894,20 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
 }
+
+#ifdef KMAHIP_DIAG
+// diagnostic build only: histogram of DP problems ([0..63] calls by q_len, [64..127] cells by q_len,
+// [128..132] calls by mode k+2, [136..199] calls by t_len/4)
+extern "C" int kmahip_diag_hist(unsigned long long *out256, int reset) {
+	static unsigned long long *buf = nullptr;
+	if(!buf) {
+		if(hipMalloc((void **) &buf, 256 * 8) != hipSuccess) return -1;
+		(void) hipMemset(buf, 0, 256 * 8);
+		(void) hipMemcpyToSymbol(HIP_SYMBOL(g_diag_hist), &buf, sizeof buf);
+	}
+	(void) hipDeviceSynchronize();
+	if(out256) (void) hipMemcpy(out256, buf, 256 * 8, hipMemcpyDeviceToHost);
+	if(reset) (void) hipMemset(buf, 0, 256 * 8);
+	return 0;
+}
+#endif

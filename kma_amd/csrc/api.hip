@@ -35,7 +35,8 @@ extern "C" int kmahip_scan_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_rea
 }
 
 extern "C" int kmahip_ws_status(kmahip_ws *ws, void *stream) {
-	if(!ws || !ws->counters) return KMAHIP_EINVAL;
+	if(!ws) return KMAHIP_EINVAL;
+	if(!ws->counters) return KMAHIP_OK;   // nothing launched yet
 	unsigned long long c[8];
 	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));

@@ -20,6 +20,7 @@
 // Reverse strand k-mers are the reverse complement of forward k-mers read at the
 // mirrored position, so only the forward 2-bit words are ever staged.
 #include "kmahip_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -40,6 +41,7 @@ struct ScanArgs {
 	const int32_t *N;
 	const int64_t *N_off;
 	int M, MM, U, W1, exhaustive;
+	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip score machines, 2 skip phase-1 probes, 4 skip prefilter probes
 	int32_t *item_score;
 	int32_t *item_n;
 	int64_t *item_off;
@@ -160,8 +162,12 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 		uint32_t nprobe = 0;
 		if(npos > 0) {
 			const uint64_t *rs = A.seq + s_soff[a];
+#ifdef KMAHIP_DIAG
+			if(A.exhaustive || (A.ablate & 4)) {
+#else
 			if(A.exhaustive) {
-				hit = true;
+#endif
+				hit = (a & 1) == 0 || A.exhaustive;
 			} else if(nN == 0) {
 				for(int j = slot * k; j < npos; j += 4 * k) {
 					const int q = strand ? (L - k - j) : j;
@@ -261,6 +267,9 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 				const int w = (q >> 5) - s_wbase[a];
 				uint64_t km = kmer_from(w_lds[a * SW + w], w_lds[a * SW + w + 1], q, k);
 				if(a & 1) km = revcomp_kmer(km, k);
+#ifdef KMAHIP_DIAG
+				if(A.ablate & 2) vi = (uint32_t) (km & 1023u); else
+#endif
 				vi = probe(db, (uint32_t) km);
 				++nprobe;
 			}
@@ -271,7 +280,11 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 		// score machines, in rounds of one value-set change per lane
 		{
 			const int a = a_own;
+#ifdef KMAHIP_DIAG
+			const bool run = my_active && !overflow && !(A.ablate & 1);
+#else
 			const bool run = my_active && !overflow;
+#endif
 			const int jend = run ? min(CHUNK, s_len[a] - k + 1 - c0) : 0;
 			int jj = 0;
 			for(;;) {
@@ -592,6 +605,10 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
+	A.ablate = 0;
+#ifdef KMAHIP_DIAG
+	if(const char *e = getenv("KMAHIP_ABLATE_SCAN")) A.ablate = atoi(e);
+#endif
 	// word 1 (status) is sticky until kmahip_ws_status reads it
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
