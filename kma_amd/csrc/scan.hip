@@ -21,14 +21,19 @@
 // mirrored position, so only the forward 2-bit words are ever staged.
 #include "kmahip_internal.h"
 #include <cstdlib>
+#include <climits>
 
 namespace {
 
-constexpr int ITEMS = 64;
+constexpr int ITEMS = 32;             // (read, strand) items per workgroup
+constexpr int GROUP = 16;             // active items scored together
 constexpr int THREADS = 256;
-constexpr int CHUNK = 136;
+constexpr int CHUNK = 136;            // k-mer start positions per pass
+constexpr int MW = 5;                 // hit-mask words per candidate (>= CHUNK / 32)
 constexpr int SW = 7;                 // staged u64 words per item and pass
-constexpr int TCAP = 24;              // LDS candidate-table capacity per item
+constexpr int TSLOTS = 16;            // hashed candidate slots per item in LDS
+constexpr int TMAX = 14;              // ... of which at most this many occupied
+constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFEu;
 
@@ -123,18 +128,33 @@ __device__ __forceinline__ int n_strand(const int32_t *Nl, int nN, int L, int st
 	return strand ? (L - 1 - Nl[nN - i]) : Nl[i - 1];
 }
 
+// first set bit at or after `from` in an MW-word mask laid out with stride `st`; MW*32 if none
+__device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bool want_set) {
+	int w = from >> 5;
+	if(w >= MW) return MW * 32;
+	uint32_t x = want_set ? m[w * st] : ~m[w * st];
+	x &= 0xFFFFFFFFu << (from & 31);
+	for(;;) {
+		if(x) return (w << 5) + __ffs((int) x) - 1;
+		if(++w >= MW) return MW * 32;
+		x = want_set ? m[w * st] : ~m[w * st];
+	}
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
-	__shared__ uint32_t vi_buf[CHUNK * ITEMS];
-	__shared__ uint64_t w_lds[ITEMS * SW];
-	__shared__ uint32_t t_id[TCAP * ITEMS];
-	__shared__ int32_t t_score[TCAP * ITEMS];
-	__shared__ int32_t t_ext[TCAP * ITEMS];
-	__shared__ uint8_t t_cur[TCAP * ITEMS];
-	__shared__ int32_t s_len[ITEMS], s_nN[ITEMS], s_wbase[ITEMS];
+	__shared__ uint32_t vi_buf[CHUNK * GROUP];
+	__shared__ uint64_t w_lds[GROUP * SW];
+	__shared__ uint32_t t_id[TSLOTS * GROUP];
+	__shared__ uint32_t t_mask[MW * TSLOTS * GROUP];
+	__shared__ int32_t t_score[TSLOTS * GROUP];
+	__shared__ int32_t t_last[TSLOTS * GROUP];
+	__shared__ int32_t t_first[TSLOTS * GROUP];
+	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_wbase[GROUP];
+	__shared__ int32_t s_len[ITEMS], s_nN[ITEMS], s_alist[ITEMS];
 	__shared__ int64_t s_soff[ITEMS], s_noff[ITEMS];
 	__shared__ uint32_t s_active[2];
-	__shared__ int32_t s_maxnpos;
+	__shared__ int32_t s_nact, s_gmax;
 	__shared__ uint32_t s_stats[2];
 
 	const DevDB &db = A.db;
@@ -151,12 +171,12 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no;
 	}
 	if(tid < 2) { s_active[tid] = 0; s_stats[tid] = 0; }
-	if(tid == 0) s_maxnpos = 0;
 	__syncthreads();
 
-	// ---- phase 0: prefilter --------------------------------------------
+	// ---- phase 0: prefilter (savekmers.c:2477-2495) -------------------------------
 	{
-		const int a = tid & 63, slot = tid >> 6;
+		constexpr int PLANES = THREADS / ITEMS;     // lanes sharing one item's prefilter probes
+		const int a = tid & (ITEMS - 1), slot = tid / ITEMS;
 		const int L = s_len[a], nN = s_nN[a], strand = a & 1, npos = L - k + 1;
 		bool hit = false;
 		uint32_t nprobe = 0;
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 #endif
 				hit = (a & 1) == 0 || A.exhaustive;
 			} else if(nN == 0) {
-				for(int j = slot * k; j < npos; j += 4 * k) {
+				for(int j = slot * k; j < npos; j += PLANES * k) {
 					const int q = strand ? (L - k - j) : j;
 					const int w = q >> 5;
 					uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
@@ -195,167 +215,206 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 				}
 			}
 		}
-		if(hit) {
-			atomicOr(&s_active[a >> 5], 1u << (a & 31));
-			atomicMax(&s_maxnpos, npos);
-		}
+		if(hit) atomicOr(&s_active[a >> 5], 1u << (a & 31));
 		if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
 	}
 	__syncthreads();
 	const uint64_t active = ((uint64_t) s_active[1] << 32) | s_active[0];
-	const int maxnpos = s_maxnpos;
-
-	// ---- per-item machine state: 16 items per wave, lanes 0-15 of each of the 4 waves --
-	// (the other lanes only probe). Spreading the 64 machines over all four waves lets
-	// their value-list loads overlap; inside a wave the lanes advance in "rounds": every
-	// lane first walks its LDS column (no global access) up to its next value-set change,
-	// then all lanes handle one change each, so the serial depth is the number of set
-	// changes per item (~30 for a 150 bp read), not the number of k-mer positions.
-	uint32_t last = NONE;
-	int gaps = 0, HIT = 0, acc = 0, nlist = 0, ncur = 0, hits = 0;
-	bool overflow = false;
-	const int lane = tid & 63;
-	const int a_own = ((tid >> 6) << 4) | (lane & 15);
-	const bool owner = lane < 16;
-	const bool my_active = owner && ((active >> a_own) & 1ull);
-
-	// one template of a newly opened value set (savekmers.c:2584-2655)
-	auto open_template = [&](const int a, const uint32_t t) {
-		int e = -1;
-		for(int x = 0; x < nlist; ++x) if(t_id[x * ITEMS + a] == t) { e = x; break; }
-		if(e >= 0) {
-			t_score[e * ITEMS + a] += bridge(HIT - t_ext[e * ITEMS + a], k, A.M, A.MM, A.U, A.W1);
-		} else {
-			if(nlist == TCAP) { overflow = true; return; }
-			e = nlist++;
-			t_id[e * ITEMS + a] = t;
-			t_score[e * ITEMS + a] = k * A.M;
+	// compact the active items; inactive ones are finished (no candidates)
+	if(tid < ITEMS) {
+		const bool act = (active >> tid) & 1ull;
+		if(act) s_alist[__popcll(active & ((1ull << tid) - 1ull))] = tid;
+		else if(((item0 + tid) >> 1) < A.n_reads) {
+			A.item_score[item0 + tid] = 0; A.item_n[item0 + tid] = 0; A.item_off[item0 + tid] = 0;
 		}
-		t_cur[ncur * ITEMS + a] = (uint8_t) e;
-		++ncur;
-	};
-
-	for(int c0 = 0; c0 < maxnpos; c0 += CHUNK) {
-		// stage forward words covering this pass
-		for(int idx = tid; idx < ITEMS * SW; idx += THREADS) {
-			const int a = idx / SW, w = idx - a * SW;
-			uint64_t v = 0;
-			if((active >> a) & 1ull) {
-				const int L = s_len[a], npos = L - k + 1;
-				int lo = c0;
-				if(a & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
-				if(lo < 0) lo = 0;
-				const int wb = lo >> 5;
-				if(w == 0) s_wbase[a] = wb;
-				const int words = (L + 31) >> 5;
-				if(wb + w < words) v = A.seq[s_soff[a] + wb + w];
-			}
-			w_lds[idx] = v;
-		}
-		__syncthreads();
-		// probe every k-mer start of the pass
-		uint32_t nprobe = 0;
-		for(int idx = tid; idx < ITEMS * CHUNK; idx += THREADS) {
-			const int a = idx & 63, jj = idx >> 6;
-			if(!((active >> a) & 1ull)) continue;
-			const int L = s_len[a], p = c0 + jj;
-			if(p >= L - k + 1) continue;
-			const int q = (a & 1) ? (L - k - p) : p;
-			uint32_t vi = MISS;
-			const int nN = s_nN[a];
-			if(nN == 0 || !window_has_N(A.N + s_noff[a], nN, q, k)) {
-				const int w = (q >> 5) - s_wbase[a];
-				uint64_t km = kmer_from(w_lds[a * SW + w], w_lds[a * SW + w + 1], q, k);
-				if(a & 1) km = revcomp_kmer(km, k);
-#ifdef KMAHIP_DIAG
-				if(A.ablate & 2) vi = (uint32_t) (km & 1023u); else
-#endif
-				vi = probe(db, (uint32_t) km);
-				++nprobe;
-			}
-			vi_buf[jj * ITEMS + a] = vi;
-		}
-		if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
-		__syncthreads();
-		// score machines, in rounds of one value-set change per lane
-		{
-			const int a = a_own;
-#ifdef KMAHIP_DIAG
-			const bool run = my_active && !overflow && !(A.ablate & 1);
-#else
-			const bool run = my_active && !overflow;
-#endif
-			const int jend = run ? min(CHUNK, s_len[a] - k + 1 - c0) : 0;
-			int jj = 0;
-			for(;;) {
-				uint32_t vi = MISS;
-				bool pending = false;
-				while(jj < jend) {
-					vi = vi_buf[jj * ITEMS + a];
-					if(vi == MISS) { ++gaps; ++jj; continue; }
-					if(vi == last) { acc += bridge(gaps, k, A.M, A.MM, A.U, A.W1); HIT = c0 + jj; gaps = 0; ++hits; ++jj; continue; }
-					pending = true;
-					break;
-				}
-				if(!__any(pending)) break;
-				if(pending) {
-					const int p = c0 + jj;
-					// fetch the new list first: count + up to 7 ids in flight together
-					uint32_t cnt, el[7];
-					if(db.values_u16) {
-						const uint16_t *vp = db.values16 + vi;
-						cnt = vp[0];
-#pragma unroll
-						for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
-					} else {
-						const uint32_t *vp = db.values32 + vi;
-						cnt = vp[0];
-#pragma unroll
-						for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
-					}
-					// close the old set (savekmers.c:2575-2582)
-					for(int c = 0; c < ncur; ++c) {
-						const int e = t_cur[c * ITEMS + a];
-						t_score[e * ITEMS + a] += acc;
-						t_ext[e * ITEMS + a] = HIT;
-					}
-					HIT = p - 1;
-					ncur = 0;
-					if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
-#pragma unroll
-					for(int i = 0; i < 7; ++i) if((uint32_t) i < cnt && !overflow) open_template(a, el[i]);
-					for(uint32_t i = 8; i <= cnt && !overflow; ++i) open_template(a, value_at(db, vi, (int) i));
-					if(overflow) { jj = jend; }
-					else { last = vi; acc = 0; HIT = p; gaps = 0; ++hits; ++jj; }
-				}
-			}
-		}
-		__syncthreads();
+		if(tid == 0) s_nact = __popcll(active);
 	}
+	__syncthreads();
+	const int nact = s_nact;
 
-	// ---- finish items -------------------------------------------------------
-	if(owner) {
-		const int a = a_own;
-		const int64_t item = item0 + a;
-		if((item >> 1) < A.n_reads) {
+	// Scores are computed per template, not per position: the score machine of save_kmers
+	// (savekmers.c:2511-2706) gives template t   k*M  at its first hit and  bridge(p - 1 - last_t)
+	// at every later hit p (a hit = the value set of the k-mer at p holds t); runs of equal sets and
+	// set changes are only how the reference walks that sum. So every (item, run of equal sets)
+	// ORs its position range into the bitmask of each template of the set, and every
+	// (item, template) then folds its own bitmask -- no serial walk over the positions.
+	for(int g0 = 0; g0 < nact; g0 += GROUP) {
+		const int ng = min(GROUP, nact - g0);
+		for(int idx = tid; idx < TSLOTS * GROUP; idx += THREADS) {
+			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN; t_last[idx] = 0; t_first[idx] = 0;
+#pragma unroll
+			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+		}
+		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; }
+		if(tid == 0) s_gmax = 0;
+		__syncthreads();
+		if(tid < ng) atomicMax(&s_gmax, s_len[s_alist[g0 + tid]] - k + 1);
+		__syncthreads();
+		const int gmax = s_gmax;
+
+		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
+			// stage the forward words of this pass
+			for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
+				const int g = idx / SW, w = idx - g * SW;
+				uint64_t v = 0;
+				if(g < ng) {
+					const int a = s_alist[g0 + g];
+					const int L = s_len[a], npos = L - k + 1;
+					int lo = c0;
+					if(a & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
+					if(lo < 0) lo = 0;
+					const int wb = lo >> 5;
+					if(w == 0) s_wbase[g] = wb;
+					const int words = (L + 31) >> 5;
+					if(wb + w < words) v = A.seq[s_soff[a] + wb + w];
+				}
+				w_lds[idx] = v;
+			}
+			__syncthreads();
+			// phase 1: probe every k-mer start of the pass
+			uint32_t nprobe = 0;
+			for(int idx = tid; idx < GROUP * CHUNK; idx += THREADS) {
+				const int g = idx & (GROUP - 1), jj = idx / GROUP;
+				uint32_t vi = MISS;
+				if(g < ng) {
+					const int a = s_alist[g0 + g];
+					const int L = s_len[a], p = c0 + jj;
+					if(p < L - k + 1) {
+						const int q = (a & 1) ? (L - k - p) : p;
+						const int nN = s_nN[a];
+						if(nN == 0 || !window_has_N(A.N + s_noff[a], nN, q, k)) {
+							const int w = (q >> 5) - s_wbase[g];
+							uint64_t km = kmer_from(w_lds[g * SW + w], w_lds[g * SW + w + 1], q, k);
+							if(a & 1) km = revcomp_kmer(km, k);
+#ifdef KMAHIP_DIAG
+							if(A.ablate & 2) vi = (uint32_t) (km & 1023u); else
+#endif
+							vi = probe(db, (uint32_t) km);
+							++nprobe;
+						}
+					}
+				}
+				vi_buf[idx] = vi;    // == [jj * GROUP + g]
+			}
+			if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
+			__syncthreads();
+			// phase 2a: one thread per run of equal value sets
+#ifdef KMAHIP_DIAG
+			if(!(A.ablate & 1))
+#endif
+			for(int idx = tid; idx < GROUP * CHUNK; idx += THREADS) {
+				const int g = idx & (GROUP - 1), jj = idx / GROUP;
+				if(g >= ng || s_over[g]) continue;
+				const uint32_t vi = vi_buf[idx];
+				if(vi == MISS) continue;
+				if(jj > 0 && vi_buf[idx - GROUP] == vi) continue;
+				int e = jj + 1;
+				while(e < CHUNK && vi_buf[e * GROUP + g] == vi) ++e;
+				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
+				uint32_t cnt, el[7];
+				if(db.values_u16) {
+					const uint16_t *vp = db.values16 + vi;
+					cnt = vp[0];
+#pragma unroll
+					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+				} else {
+					const uint32_t *vp = db.values32 + vi;
+					cnt = vp[0];
+#pragma unroll
+					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+				}
+				if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
+				auto add_template = [&](const uint32_t t) -> bool {
+					// claim / find the template's slot
+					int slot = -1;
+					const uint32_t h = (t * 0x9E3779B1u) >> 28;
+					for(int x = 0; x < TSLOTS; ++x) {
+						const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
+						const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
+						if(old == T_EMPTY) {
+							if(atomicAdd(&t_cnt[g], 1) >= TMAX) break;
+							slot = sidx; break;
+						}
+						if(old == t) { slot = sidx; break; }
+					}
+					if(slot < 0) { s_over[g] = 1; return false; }
+					for(int w = jj >> 5; w <= (e - 1) >> 5; ++w) {
+						const int lo = max(jj, w << 5) & 31, hi = min(e, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
+						const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
+						atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
+					}
+					return true;
+				};
+				bool ok = true;
+#ifdef KMAHIP_DIAG
+				if(A.ablate & 32) { if(cnt + el[0] + el[6] == 0xFFFFFFF0u) s_over[g] = 1; continue; }
+#endif
+#pragma unroll
+				for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
+				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+			}
+			__syncthreads();
+			// phase 2b: one thread per (item, template): fold the hit mask into the score
+#ifdef KMAHIP_DIAG
+			if(!(A.ablate & 8))
+#endif
+			for(int idx = tid; idx < TSLOTS * GROUP; idx += THREADS) {
+				const int g = idx & (GROUP - 1);
+				if(g >= ng || t_id[idx] == T_EMPTY) continue;
+				int score = t_score[idx], last = t_last[idx], first = t_first[idx];
+				const uint32_t *m = t_mask + idx;
+				int cur = 0;
+				for(;;) {
+					const int b0 = mask_next(m, TSLOTS * GROUP, cur, true);
+					if(b0 >= MW * 32) break;
+					const int b1 = mask_next(m, TSLOTS * GROUP, b0, false);
+					const int pa = c0 + b0, len = b1 - b0;
+					if(score == INT_MIN) { score = k * A.M + (len - 1) * A.M; first = pa; }
+					else score += bridge(pa - 1 - last, k, A.M, A.MM, A.U, A.W1) + (len - 1) * A.M;
+					last = c0 + b1 - 1;
+					cur = b1;
+				}
+				t_score[idx] = score; t_last[idx] = last; t_first[idx] = first;
+#pragma unroll
+				for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+			}
+			__syncthreads();
+		}
+
+		// ---- finish the items of this group: getBestMatch (savekmers.c:273-294) ---------
+		if(tid < ng) {
+			const int g = tid, a = s_alist[g0 + g];
+			const int64_t item = item0 + a;
 			int best = 0, nb = 0;
 			int64_t off = 0;
-			if(my_active && overflow) {
+#ifdef KMAHIP_DIAG
+			if(A.ablate & 16) { nb = 0; } else
+#endif
+			if(s_over[g]) {
 				const unsigned long long slot = atomicAdd(&A.counters[C_NOVER], 1ull);
 				A.overflow_items[slot] = item;
 				nb = -1;
-			} else if(my_active && hits) {
-				for(int c = 0; c < ncur; ++c) t_score[t_cur[c * ITEMS + a] * ITEMS + a] += acc;
-				for(int e = 0; e < nlist; ++e) {
-					const int s = max(0, t_score[e * ITEMS + a]);
-					if(s > best) { best = s; nb = 1; } else if(s == best) ++nb;
+			} else {
+				for(int x = 0; x < TSLOTS; ++x) {
+					if(t_id[x * GROUP + g] == T_EMPTY) continue;
+					const int sc = max(0, t_score[x * GROUP + g]);
+					if(sc > best) { best = sc; nb = 1; } else if(sc == best) ++nb;
 				}
 				if(best > 0) {
 					off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
 					if(off + nb <= A.pool_cap) {
-						int w = 0;
-						for(int e = 0; e < nlist; ++e) {
-							if(max(0, t_score[e * ITEMS + a]) == best) A.pool[off + w++] = (int32_t) t_id[e * ITEMS + a];
+						// first-seen order = ascending (first hit position, template id)
+						long long prevkey = -1;
+						for(int w = 0; w < nb; ++w) {
+							long long bk = 0x7FFFFFFFFFFFFFFFll;
+							for(int x = 0; x < TSLOTS; ++x) {
+								const uint32_t id = t_id[x * GROUP + g];
+								if(id == T_EMPTY || max(0, t_score[x * GROUP + g]) != best) continue;
+								const long long key = ((long long) t_first[x * GROUP + g] << 32) | id;
+								if(key > prevkey && key < bk) bk = key;
+							}
+							A.pool[off + w] = (int32_t) (bk & 0xFFFFFFFFll);
+							prevkey = bk;
 						}
 					} else {
 						atomicMax(&A.counters[C_STATUS], 1ull);
@@ -368,9 +427,9 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 			A.item_n[item] = nb;
 			A.item_off[item] = off;
 		}
+		__syncthreads();
 	}
 	if(STATS) {
-		__syncthreads();
 		if(tid == 0) {
 			atomicAdd(&A.counters[C_PROBES], (unsigned long long) s_stats[0]);
 			atomicAdd(&A.counters[C_VALS], (unsigned long long) s_stats[1]);

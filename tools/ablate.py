@@ -47,7 +47,8 @@ def run(scan_abl, align_abl, reps=3):
 
 print(f"reads {n}")
 for name, sa in (("scan full", 0), ("scan no-machines", 1), ("scan no-probe(phase1)", 2), ("scan no-prefilter-probe", 4),
-                 ("scan no-probe no-machines", 3), ("scan nothing", 7)):
+                 ("scan no-probe no-machines", 3), ("scan nothing", 7), ("scan no-2b", 8), ("scan no-finish", 16),
+                 ("scan 2a loads only", 32), ("scan no-2b no-finish", 24), ("scan 2a-loads-only no-2b no-finish", 56)):
     print(f"{name:32s} {run(sa, -1)[0]:8.2f} ms")
 run(0, -1)  # restore real candidates
 for name, aa in (("align full", 0), ("align no-DP", 1), ("align no-wide(q>16)", 8), ("align no-1x1", 16), ("align no-2..16", 32),
