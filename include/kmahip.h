@@ -113,9 +113,9 @@ typedef struct kmahip_cands {
 /* Stage-3a result (what update_Scores keeps, updatescores.c:203-298 = one
  * frag_raw record per read).  Hits of read i are stored at
  * [T_off[i], T_off[i] + n_hits[i]) of tmpl/score/start/end, in candidate order,
- * so these arrays need the same capacity as kmahip_cands.T.  n_hits[i] == -1
- * marks a read whose two strands tied in stage 2 (rc_flag < 0): that path
- * (anker_rc_comp, align.c:993-1176) is not on the device yet.
+ * so these arrays need the same capacity as kmahip_cands.T.  Reads whose two
+ * strands tied in stage 2 (rc_flag < 0) get their strand per template from MEM
+ * coverage (anker_rc_comp, align.c:993-1176); a negative tmpl = reverse strand.
  * alignment_scores / uniq_alignment_scores are the two u64[DB_size] ConClave
  * vectors (updatescores.c:228,276); the call ADDS into them (caller zeroes). */
 typedef struct kmahip_hits {

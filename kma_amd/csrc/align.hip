@@ -47,7 +47,7 @@ struct AlignArgs {
 	int minlen, mq;
 	double scoreT, mrc;
 	// per task
-	int32_t *t_score, *t_alen, *t_start, *t_end;
+	int32_t *t_score, *t_alen, *t_start, *t_end, *t_tmpl;
 	double *t_norm;
 	// scratch
 	int32_t *s32;
@@ -611,15 +611,90 @@ __device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, cons
 	return l;
 }
 
+// anker_rc_comp, align.c:993-1176: a read whose two strands tied in stage 2 is seeded on both strands of
+// the template; the strand with the larger MEM coverage wins (forward on equality) and its MEMs are
+// handed to KMA_score. Returns +n (forward, n MEMs at [0,n)), -n (reverse) or 0. Rare path: base by base.
+__device__ int anker_rc_comp(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &qf, int *status) {
+	const int k = (int) db.kmersize, q_len = qf.L, cap = L.cap1 - 1;
+	QView qr = qf; qr.rc = 1;
+	int bestScore = 0, score = 0, score_r = 0, mem_count = 0, tot = 0, plen = 0;
+	for(int rc = 0; rc < 2; ++rc) {
+		const QView &q = rc ? qr : qf;
+		int i = 0;
+		if(rc) { score = score_r; plen = mem_count; }
+		else {
+			// preseed (align.c:750-768): every k-th k-mer, built from byte codes (N = 4), past-the-end bytes = 0
+			bool hit = false;
+			for(i = 0; i < q_len && !hit; i += k) {
+				uint64_t key = 0;
+				for(int x = 0; x < k; ++x) key = (x ? (key << 2) : 0ull) | (uint64_t) ((i + x < q_len) ? qn(q, i + x) : 0);
+				if(key <= 0xFFFFFFFFull && tpos_get(db, t, (uint32_t) key) != 0) hit = true;
+			}
+			if(hit) i = 0;
+		}
+		score_r = 0; mem_count = 0;
+		int ni = 0;
+		while(i < q_len) {
+			const int end = qN_at(q, ++ni) - k + 1;
+			while(i < end) {
+				const int v = tpos_get(db, t, q_kmer(q, i, k));
+				if(v == 0) { ++i; continue; }
+				if(v > 0) {
+					if(tot >= cap) { *status = 1; return 0; }
+					int value = v, prev = value - 2, j;
+					for(j = i - 1; 0 <= j && 0 <= prev && qn(q, j) == tn(ts, prev); --j) { --prev; ++score_r; }
+					MEMA(L, 2, tot) = j + 1; MEMA(L, 0, tot) = prev + 2;
+					value += k - 1; i += k; score_r += k;
+					while(i < end && value < t_len && qn(q, i) == tn(ts, value)) { ++i; ++value; ++score_r; }
+					MEMA(L, 3, tot) = i; MEMA(L, 1, tot) = value + 1;
+					MEMA(L, 4, tot) = (value + 1) - (prev + 2);
+					++mem_count; ++tot;
+					++i;
+				} else {
+					score_r += k;
+					const int32_t *dl = db.tpos_dups + (-v - 1);
+					const int cnt = dl[0];
+					int bias = i;
+					for(int c = 1; c <= cnt; ++c) {
+						if(tot >= cap) { *status = 1; return 0; }
+						int value = dl[c], prev = value - 2, j, kk = i;
+						for(j = kk - 1; 0 <= j && 0 <= prev && qn(q, j) == tn(ts, prev); --j) --prev;
+						MEMA(L, 2, tot) = j + 1; MEMA(L, 0, tot) = prev + 2;
+						value += k - 1; kk += k;
+						while(kk < end && value < t_len && qn(q, kk) == tn(ts, value)) { ++kk; ++value; }
+						MEMA(L, 3, tot) = kk; MEMA(L, 1, tot) = value + 1;
+						MEMA(L, 4, tot) = kk - (j + 1);
+						++mem_count; ++tot;
+						bias = max(bias, kk);
+					}
+					score_r += bias - i;
+					i = bias + 1;
+				}
+			}
+			i = end + k;
+		}
+		bestScore = max(bestScore, score_r);
+	}
+	// one2one is set under -1t1 (kma.c:686-688, 1429)
+	if(bestScore < k && bestScore * k < (q_len - k - bestScore)) return 0;
+	if(bestScore == score) return plen;          // forward (also on equality); plen > 0 whenever bestScore > 0
+	for(int x = 0; x < mem_count; ++x) {
+		for(int a = 0; a < 5; ++a) MEMA(L, a, x) = MEMA(L, a, plen + x);
+	}
+	return -mem_count;
+}
+
 // KMA_score, align.c:509-748. status: 0 ok, 1 = MEM capacity exceeded
-__device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq, int *status) {
+__device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq, int preseeded, int *status) {
 	const Aln FAIL = {0, 1, 0, 0, 0, 0};
 	const int k = (int) db.kmersize, q_len = q.L, bw = 64, cap = L.cap1 - 1;
 	int nm = 0, j = 0, lowq = 0;
 #ifdef KMAHIP_DIAG
 	if(L.ablate & 2) return FAIL;
 #endif
-	for(int i = 1; i <= q.nN + 1; ++i) {
+	// MEMs left by anker_rc_comp are used as they are (align.c:530-532)
+	if(preseeded > 0) nm = preseeded;
+	for(int i = 1; preseeded <= 0 && i <= q.nN + 1; ++i) {
 		const int Ni = qN_at(q, i);
 		const int end = (i != q.nN + 1) ? Ni - k + 1 : q_len - k + 1;
 		const int segstop = end + k - 1;
@@ -739,16 +814,25 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 		double norm = 0.0;
 		const int rcf = A.rc_flag[r];
 		const int q_len = A.len[r];
-		if(rcf > 0 && q_len >= k) {
+		int tmpl_out = A.T[task];
+		if(rcf != 0 && q_len >= k) {
 			QView q;
 			q.w = A.seq + A.seq_off[r]; q.L = q_len; q.rc = (A.flag[r] & 16) ? 1 : 0;
 			q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-			const int tmpl = A.T[task], at = abs(tmpl);
+			const int at = abs(tmpl_out);
 			const int t_len = A.db.tlen[at];
 			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
 			int status = 0;
 			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
-			const Aln st = kma_score(L, A.db, at, ts, t_len, q, A.mq, &status);
+			Aln st = {0, 0, 0, 0, 0, 0};
+			if(rcf > 0) {
+				st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+			} else {
+				// strand tie: per template strand decision (alnfrags.c:1101-1124)
+				const int side = anker_rc_comp(L, A.db, at, ts, t_len, q, &status);
+				if(side < 0) { q.rc = 1; tmpl_out = -at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, -side, &status); }
+				else if(side > 0) { tmpl_out = at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, side, &status); }
+			}
 			if(status) atomicMax(&A.counters[1], 3ull);
 			// alnFragsSE, alnfrags.c:1127-1168
 			alen = st.len; start = st.pos;
@@ -759,6 +843,7 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 			if(A.minlen <= alen && ((A.mrc * q_len <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) norm = rs / denom;
 			else { rs = 0; norm = 0.0; }
 		}
+		A.t_tmpl[task] = tmpl_out;
 		A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
 	}
 }
@@ -768,7 +853,7 @@ struct ReduceArgs {
 	const int32_t *rc_flag, *flag;
 	const int64_t *T_off;
 	const int32_t *T;
-	const int32_t *t_score, *t_alen, *t_start, *t_end;
+	const int32_t *t_score, *t_alen, *t_start, *t_end, *t_tmpl;
 	const double *t_norm;
 	int k;
 	double scoreT;
@@ -784,9 +869,7 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 	const int64_t o = R.T_off[r], e = R.T_off[r + 1];
 	int nh = 0, bestRead = 0, fl = R.flag[r];
 	if(e > o) {
-		if(R.rc_flag[r] < 0) {
-			nh = -1;   // strand tie (anker_rc_comp path) not implemented on device yet
-		} else {
+		{
 			double bestScore = 0.0;
 			for(int64_t t = o; t < e; ++t) {
 				const int rs = R.t_score[t];
@@ -803,7 +886,7 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 					const double ms = (double) (rs / R.t_alen[t]);
 					if(ms == bestScore || rs == bestRead) {
 						const int64_t w = o + nh;
-						const int tm = R.T[t];
+						const int tm = R.t_tmpl[t];
 						R.h_tmpl[w] = tm; R.h_score[w] = rs; R.h_start[w] = R.t_start[t]; R.h_end[w] = R.t_end[t];
 						if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) rs);
 						++nh;
@@ -848,7 +931,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (4 * 4 + 8)));
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (5 * 4 + 8)));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
@@ -863,7 +946,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
 	double *norm = (double *) ws->a_task;
 	int32_t *ti = (int32_t *) (norm + tasks_cap);
-	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap;
+	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
 	A.counters = ws->counters;
 	A.stats = ws->stats_on;
@@ -884,7 +967,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	}
 	ReduceArgs R;
 	R.n_reads = n; R.rc_flag = cands->rc_flag; R.flag = cands->flag; R.T_off = cands->T_off; R.T = cands->T;
-	R.t_score = A.t_score; R.t_alen = A.t_alen; R.t_start = A.t_start; R.t_end = A.t_end; R.t_norm = A.t_norm;
+	R.t_score = A.t_score; R.t_alen = A.t_alen; R.t_start = A.t_start; R.t_end = A.t_end; R.t_norm = A.t_norm; R.t_tmpl = A.t_tmpl;
 	R.k = (int) db->dev.kmersize; R.scoreT = p->scoreT;
 	R.n_hits = out->n_hits; R.best_score = out->best_score; R.out_flag = out->flag;
 	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;

@@ -392,11 +392,13 @@ static const aln FAIL = {0, 1, 0, 0, 0, 0};
 
 static aln kma_score(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k, const uint8_t *qseq, int q_len,
                      int q_start, int q_end, const uint64_t *qcomp, const int *N /* N[0] = count incl. sentinel */,
-                     int mq, const orc_rewards *rw) {
+                     int mq, const orc_rewards *rw, int preseeded) {
 	const int bw = 64;
-	w->plen = 0;
+	/* align.c:530-532: MEMs left in `points` by anker_rc_comp are used as they are */
+	const int use_pre = preseeded && w->plen > 0;
+	if(!use_pre) w->plen = 0;
 	int j = q_start;
-	for(int i = 1; i <= N[0]; ++i) {
+	for(int i = 1; !use_pre && i <= N[0]; ++i) {
 		int end = (i != N[0]) ? N[i] - k + 1 : q_end - k + 1;
 		while(j < end) {
 			int cnt;
@@ -453,6 +455,85 @@ static aln kma_score(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, 
 	return S;
 }
 
+/* ---- anker_rc_comp, align.c:993-1176 (strand decision of a stage-2 strand tie) ---- */
+static int tindex_has(const tindex *ix, uint64_t key) { int c; if(!key) return 0; tindex_find(ix, key, &c); return c > 0; }
+
+static int anker_rc_comp(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k,
+                         const uint8_t *qseq_f, const uint8_t *qseq_r, int q_len,
+                         const uint64_t *comp_f, const int *N_f, const uint64_t *comp_r, const int *N_r, int one2one) {
+	int bestScore = 0, score = 0, score_r = 0, mem_count = 0, tot = 0, plen = 0;
+	for(int rc = 0; rc < 2; ++rc) {
+		const uint8_t *qseq = rc ? qseq_r : qseq_f;
+		const uint64_t *seq = rc ? comp_r : comp_f;
+		const int *N = rc ? N_r : N_f;       /* N[0] = count incl. the q_len sentinel */
+		int i = 0;
+		if(rc) { score = score_r; plen = mem_count; }
+		else {
+			/* preseed, align.c:750-768: every k-th k-mer built from the byte codes; bytes past the read
+			 * end are whatever the reference's buffer held -- taken as 0 here */
+			int hit = 0;
+			for(i = 0; i < q_len && !hit; i += k) {
+				uint64_t key = 0;
+				for(int x = 0; x < k; ++x) key = (x ? (key << 2) : 0) | (uint64_t) ((i + x < q_len) ? qseq[i + x] : 0);
+				if(tindex_has(ix, key)) hit = 1;
+			}
+			i = hit ? 0 : i;
+		}
+		score_r = 0; mem_count = 0;
+		int ni = 0;
+		while(i < q_len) {
+			const int end = N[++ni] - k + 1;
+			while(i < end) {
+				int cnt;
+				const uint64_t key = kmer_at(seq, i, k);
+				const int first = key ? tindex_find(ix, key, &cnt) : (cnt = 0, 0);
+				if(cnt == 0) { ++i; continue; }
+				if(cnt == 1) {
+					aws_points(w, tot + 2);
+					int value = ix->o[first].pos, prev = value - 2, j;
+					for(j = i - 1; 0 <= j && 0 <= prev && qseq[j] == tnuc(tseq, prev); --j) { --prev; ++score_r; }
+					w->qS[tot] = j + 1; w->tS[tot] = prev + 2;
+					value += k - 1; i += k; score_r += k;
+					while(i < end && value < t_len && qseq[i] == tnuc(tseq, value)) { ++i; ++value; ++score_r; }
+					w->qE[tot] = i; w->tE[tot] = value + 1;
+					w->w[tot] = w->tE[tot] - w->tS[tot];
+					++mem_count; ++tot;
+					++i;
+				} else {
+					score_r += k;
+					int bias = i;
+					for(int c = 0; c < cnt; ++c) {
+						aws_points(w, tot + 2);
+						int value = ix->o[first + c].pos, prev = value - 2, j, kk = i;
+						for(j = kk - 1; 0 <= j && 0 <= prev && qseq[j] == tnuc(tseq, prev); --j) --prev;
+						w->qS[tot] = j + 1; w->tS[tot] = prev + 2;
+						value += k - 1; kk += k;
+						while(kk < end && value < t_len && qseq[kk] == tnuc(tseq, value)) { ++kk; ++value; }
+						w->qE[tot] = kk; w->tE[tot] = value + 1;
+						w->w[tot] = w->qE[tot] - w->qS[tot];
+						++mem_count; ++tot;
+						if(bias < kk) bias = kk;
+					}
+					score_r += bias - i;
+					i = bias + 1;
+				}
+			}
+			i = end + k;
+		}
+		if(bestScore < score_r) bestScore = score_r;
+	}
+	if(one2one && bestScore < k && bestScore * k < (q_len - k - bestScore)) { w->plen = 0; return 0; }
+	if(bestScore == score) { w->plen = plen; return bestScore; }
+	if(plen) {
+		for(int x = 0; x < mem_count; ++x) {
+			w->tS[x] = w->tS[plen + x]; w->tE[x] = w->tE[plen + x]; w->qS[x] = w->qS[plen + x];
+			w->qE[x] = w->qE[plen + x]; w->w[x] = w->w[plen + x];
+		}
+	}
+	w->plen = mem_count;
+	return -bestScore;
+}
+
 /* ---- alnFragsSE + update_Scores ----------------------------------------- */
 struct orc_aligner {
 	const orc_db *db;
@@ -495,7 +576,6 @@ int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 	const int k = db->kmersize, q_len = seqlen;
 	*n_hits = 0; *best_score = 0; *out_flag = flag;
 	if(nT == 0 || q_len < k) return 0;
-	if(rc_flag < 0) { *n_hits = -1; return 0; }   /* strand tie (anker_rc_comp path): not restated */
 	const int words = (seqlen + 31) >> 5;
 	if(a->qcap < seqlen + 2) {
 		a->qcap = 2 * seqlen + 66;
@@ -518,6 +598,13 @@ int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 		qcomp = a->rc; Nq = a->Nr;
 	}
 	unpack_bytes(qcomp, seqlen, Nq, a->q);
+	if(rc_flag < 0) {
+		/* both orientations are needed (alnfrags.c:1061-1069); flag is 0 for ties so qcomp == seq */
+		orc_rc(seq, seqlen, a->Nf, a->rc, a->Nr);
+		a->rc[words] = 0;
+		unpack_bytes(a->rc, seqlen, a->Nr, a->qr);
+		a->Nr[0] += 1; a->Nr[a->Nr[0]] = q_len;
+	}
 	Nq[0] += 1; Nq[Nq[0]] = q_len;        /* sentinel, alnfrags.c:1071-1072 */
 
 	double bestScore = 0; int bestRead = 0, hits = 0;
@@ -526,7 +613,17 @@ int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 		const int t_len = db->tlen[at];
 		const uint64_t *tseq = db->tseq + db->tseq_off[at];
 		if(!a->ix[at].o) tindex_build(&a->ix[at], tseq, t_len, k);
-		aln st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, a->q, q_len, 0, q_len, qcomp, Nq, ap->mq, rw);
+		aln st;
+		int tmpl_out = tmpl;
+		if(rc_flag < 0) {
+			/* strand tie: decide per template by MEM coverage (alnfrags.c:1101-1124) */
+			const int rcv = anker_rc_comp(&a->w, &a->ix[at], tseq, t_len, k, a->q, a->qr, q_len, qcomp, Nq, a->rc, a->Nr, 1);
+			if(rcv < 0) { tmpl_out = -at; st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, a->qr, q_len, 0, q_len, a->rc, a->Nr, ap->mq, rw, 1); }
+			else if(rcv) { tmpl_out = at; st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, a->q, q_len, 0, q_len, qcomp, Nq, ap->mq, rw, 1); }
+			else { st.score = 0; st.pos = 0; st.len = 0; st.match = 0; st.tGaps = 0; st.qGaps = 0; a->w.plen = 0; }
+		} else {
+			st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, a->q, q_len, 0, q_len, qcomp, Nq, ap->mq, rw, 0);
+		}
 		const int aln_len = st.len, start = st.pos;
 		int end = start + aln_len - st.tGaps;
 		if(t_len < end) end -= t_len;
@@ -536,7 +633,7 @@ int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 		if(ap->minlen <= aln_len && ((ap->mrc * q_len <= st.len - st.qGaps) || (ap->mrc * t_len <= st.len - st.tGaps))) score = read_score / denom;
 		else { read_score = 0; score = 0; }
 		if(k < read_score && ap->scoreT <= score) {
-			a->bt[hits] = tmpl; a->bs[hits] = start; a->be[hits] = end; a->bsc[hits] = read_score; a->bl[hits] = aln_len; ++hits;
+			a->bt[hits] = tmpl_out; a->bs[hits] = start; a->be[hits] = end; a->bsc[hits] = read_score; a->bl[hits] = aln_len; ++hits;
 			if(bestScore < score) bestScore = score;
 			if(bestRead < read_score) bestRead = read_score;
 		}

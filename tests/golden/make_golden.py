@@ -47,6 +47,11 @@ def tricky_db(seed):
     names.append("short_template"); seqs.append(rng.integers(0, 4, 120, dtype=np.uint8))
     # chimera of two families (a read can bridge value sets)
     names.append("chimera_f1_f7"); seqs.append(np.concatenate([seqs[5][:300], seqs[35][100:420]]))
+    # the same gene indexed on both strands, and an inverted repeat: reads from these tie between
+    # the forward and reverse strand in stage 2 (rc_flag < 0 -> anker_rc_comp path in stage 3a)
+    names.append("rc_of_fam00002_v0"); seqs.append(synth.revcomp_codes(seqs[10]).copy())
+    x = rng.integers(0, 4, 320, dtype=np.uint8)
+    names.append("inverted_repeat"); seqs.append(np.concatenate([x, rng.integers(0, 4, 25, dtype=np.uint8), synth.revcomp_codes(x)]))
     return names, seqs
 
 

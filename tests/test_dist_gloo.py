@@ -61,4 +61,4 @@ def test_two_rank_read_shards_allreduce_matches_single_process(tmp_path):
     res = db.align_se(g["batch"], *sc)
     assert np.array_equal(got[0], res["alignment_scores"].astype(np.int64))
     assert np.array_equal(got[1], res["uniq_alignment_scores"].astype(np.int64))
-    assert int(open(out + ".mapped").read()) == int((res["n_hits"] > 0).sum()) == 954
+    assert int(open(out + ".mapped").read()) == int((res["n_hits"] > 0).sum()) == 966
