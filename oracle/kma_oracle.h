@@ -70,6 +70,16 @@ int64_t orc_scan_se_batch(const orc_db *db, const orc_rewards *rw, int exhaustiv
                           int32_t *rc_flag, int32_t *flag, int64_t *T_off,
                           int32_t *T, int64_t T_cap);
 
+/* stage 2, paired end `-apm p`: save_kmers_penaltyPair (savekmers.c:3572-3777). out[0], out[1] are the
+ * S2 records in stream order (present = 0: not written). mate = which input read the record carries,
+ * rc = 1 when its reverse complement is the sequence written. T1/T2: caller buffers of 2*DB_size ints the
+ * record lists point into. Returns the reference's unmapped mask (0 both written ... 3 none). */
+typedef struct { int present, mate, rc, rc_flag, flag, nT; const int *T; } orc_pe_rec;
+int orc_scan_pe(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                const uint64_t *seq1, int len1, const int *N1, int nN1,
+                const uint64_t *seq2, int len2, const int *N2, int nN2,
+                orc_pe_rec out[2], int *T1, int *T2);
+
 /* ---- stage 3a (oracle/align.c) ------------------------------------------ */
 typedef struct orc_aligner orc_aligner;
 typedef struct { int minlen, mq; double scoreT, mrc, minFrac; } orc_align_params;

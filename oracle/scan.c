@@ -121,9 +121,9 @@ static inline int vcount(const orc_db *db, int64_t v) { return db->values16 ? db
 static inline int vat(const orc_db *db, int64_t v, int i) { return db->values16 ? db->values16[v + i] : (int) db->values32[v + i]; }
 
 /* one strand: returns best score, best[] = tied templates in first-seen order */
-static int scan_strand(const orc_db *db, const orc_rewards *rw, int exhaustive, int is_rc,
-                       const uint64_t *seq, int seqlen, const int *N /* N[0]=count, list, no sentinel */,
-                       dense_state *st, int *list, int *nbest) {
+static int scan_strand_x(const orc_db *db, const orc_rewards *rw, int exhaustive, int is_rc,
+                         const uint64_t *seq, int seqlen, const int *N /* N[0]=count, list, no sentinel */,
+                         dense_state *st, int *list, int *nbest, int *full_scores, int *hit_count) {
 	const int k = db->kmersize, mlen = db->mlen;
 	const int npos = seqlen - k + 1;
 	int nN = N[0];
@@ -142,7 +142,7 @@ static int scan_strand(const orc_db *db, const orc_rewards *rw, int exhaustive, 
 			j = segend + 1;
 		}
 	}
-	if(!hit) return 0;
+	if(!hit) { if(hit_count) *hit_count = 0; return 0; }
 
 	int nlist = 0, hitCounter = 0, gaps = 0, HIT = 0;
 	int64_t last = -1;
@@ -196,6 +196,17 @@ static int scan_strand(const orc_db *db, const orc_rewards *rw, int exhaustive, 
 		int c = vcount(db, last);
 		for(int i = 1; i <= c; ++i) st->score[vat(db, last, i)] += sc;
 	}
+	if(hit_count) *hit_count = hitCounter;
+	if(full_scores) {
+		/* get_kmers_for_pair (savekmers.c:655-677): every candidate with its clamped score, first-seen order */
+		for(int i = 0; i < nlist; ++i) {
+			int t = list[i];
+			full_scores[i] = st->score[t] < 0 ? 0 : st->score[t];
+			st->score[t] = 0; st->ext[t] = 0; st->incl[t] = 0;
+		}
+		*nbest = nlist;
+		return hitCounter;
+	}
 	/* clean-up + clamp (savekmers.c:2744-2753) and getBestMatch (:273-294) */
 	int best = 0, nb = 0;
 	for(int i = 0; i < nlist; ++i) {
@@ -208,6 +219,11 @@ static int scan_strand(const orc_db *db, const orc_rewards *rw, int exhaustive, 
 	}
 	*nbest = nb;
 	return best;
+}
+
+static int scan_strand(const orc_db *db, const orc_rewards *rw, int exhaustive, int is_rc,
+                       const uint64_t *seq, int seqlen, const int *N, dense_state *st, int *list, int *nbest) {
+	return scan_strand_x(db, rw, exhaustive, is_rc, seq, seqlen, N, st, list, nbest, 0, 0);
 }
 
 typedef struct {
@@ -302,4 +318,143 @@ int64_t orc_scan_se_batch(const orc_db *db, const orc_rewards *rw, int exhaustiv
 	free(tmp);
 	ws_free(w);
 	return overflow ? -total : total;
+}
+
+/* ---- paired end, `-apm p`: save_kmers_penaltyPair (savekmers.c:3572-3777) -------------------
+ * per mate: get_kmers_for_pair (:427-688) = both strands scored like save_kmers, ALL candidates kept;
+ * getFirstPen (:1383), getSecondBestPen (:1415), getF_Best (:1648). `rev` = 1 (no prefix index). */
+typedef struct { int n; int *t; int *s; } plist;
+
+static int plist_find(const plist *l, int t) { for(int i = 0; i < l->n; ++i) if(l->t[i] == t) return l->s[i]; return 0; }
+
+int orc_scan_pe(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                const uint64_t *seq1, int len1, const int *N1, int nN1,
+                const uint64_t *seq2, int len2, const int *N2, int nN2,
+                orc_pe_rec out[2], int *T1, int *T2) {
+	const int k = db->kmersize, D = db->DB_size;
+	scan_ws *w = ws_new(db);
+	int *buf = malloc(sizeof(int) * (size_t) (8 * D + 32));
+	plist F1 = {0, buf, buf + D}, R1 = {0, buf + 2 * D, buf + 3 * D}, F2 = {0, buf + 4 * D, buf + 5 * D}, R2 = {0, buf + 6 * D, buf + 7 * D};
+	int hc1 = 0, hc2 = 0;
+	for(int m = 0; m < 2; ++m) {
+		const uint64_t *seq = m ? seq2 : seq1; const int len = m ? len2 : len1; const int *N = m ? N2 : N1; const int nN = m ? nN2 : nN1;
+		plist *F = m ? &F2 : &F1, *R = m ? &R2 : &R1;
+		if(len < k) continue;
+		const int words = (len + 31) >> 5;
+		uint64_t *rs = calloc((size_t) words + 2, 8);
+		int *fN = malloc(sizeof(int) * (size_t) (2 * nN + 4)), *rN = fN + nN + 2;
+		fN[0] = nN; memcpy(fN + 1, N, sizeof(int) * (size_t) nN);
+		orc_rc(seq, len, fN, rs, rN);
+		int hf = 0, hr = 0;
+		scan_strand_x(db, rw, exhaustive, 0, seq, len, fN, &w->st, F->t, &F->n, F->s, &hf);
+		scan_strand_x(db, rw, exhaustive, 1, rs, len, rN, &w->st, R->t, &R->n, R->s, &hr);
+		if(m) hc2 = hf > hr ? hf : hr; else hc1 = hf > hr ? hf : hr;
+		free(rs); free(fN);
+	}
+	/* mate 1: getFirstPen -> region = [F1 (+), R1 (-)] with scores */
+	int nreg = 0, *regT = T1, *regS = malloc(sizeof(int) * (size_t) (2 * D + 4));
+	int best1 = 0;
+	if(hc1) {
+		for(int i = 0; i < F1.n; ++i) { if(best1 < F1.s[i]) best1 = F1.s[i]; regT[nreg] = F1.t[i]; regS[nreg++] = F1.s[i]; }
+		for(int i = 0; i < R1.n; ++i) { if(best1 < R1.s[i]) best1 = R1.s[i]; regT[nreg] = -R1.t[i]; regS[nreg++] = R1.s[i]; }
+	}
+	int paired = 0, best2 = 0, nb2 = 0, *bT = T2;
+	if(hc2) {
+		if(0 < best1) {
+			/* getSecondBestPen */
+			for(int i = 0; i < F2.n; ++i) { if(best2 < F2.s[i]) best2 = F2.s[i]; bT[nb2++] = F2.t[i]; }
+			for(int i = 0; i < R2.n; ++i) { if(best2 < R2.s[i]) best2 = R2.s[i]; bT[nb2++] = -R2.t[i]; }
+			int hits = 0;
+			if(best2) {
+				int comp = best1 + best2 - rw->PE; if(comp < 0) comp = 0;
+				for(int i = 0; i < nreg; ++i) {
+					int sc = regT[i] > 0 ? plist_find(&R2, regT[i]) : plist_find(&F2, -regT[i]);
+					if(0 < sc) {
+						sc += regS[i];
+						if(comp < sc) { comp = sc; hits = 1; regT[0] = regT[i]; }
+						else if(comp == sc) { regT[hits++] = regT[i]; }
+					}
+				}
+			}
+			if(hits) { paired = 1; nreg = hits; }
+			else {
+				int c = 0;
+				for(int i = 0; i < nreg; ++i) if(best1 == regS[i]) regT[c++] = regT[i];
+				nreg = c; c = 0;
+				for(int i = 0; i < nb2; ++i) {
+					int t = bT[i];
+					if(0 < t) { if(best2 == plist_find(&F2, t)) bT[c++] = t; }
+					else { if(best2 <= plist_find(&R2, -t)) bT[c++] = t; }
+				}
+				nb2 = c;
+			}
+		} else {
+			/* getF_Best on mate 2 -> region */
+			nreg = 0;
+			for(int i = 0; i < F2.n; ++i) { int sc = F2.s[i]; if(best2 < sc) { best2 = sc; nreg = 0; regT[nreg++] = F2.t[i]; } else if(best2 == sc) regT[nreg++] = F2.t[i]; }
+			for(int i = 0; i < R2.n; ++i) { int sc = R2.s[i]; if(best2 < sc) { best2 = sc; nreg = 0; regT[nreg++] = -R2.t[i]; } else if(best2 == sc) regT[nreg++] = -R2.t[i]; }
+		}
+	}
+	/* both mates are left reverse-complemented by get_kmers_for_pair when they were scanned */
+	int o1 = len1 >= k, o2 = len2 >= k;
+	int flag = 65, flag_r = 129, ret = 3;
+	memset(out, 0, 2 * sizeof(orc_pe_rec));
+	#define EMIT(slot, MATE, RC, SCORE, FLAG, TP, NT) do { out[slot].present = 1; out[slot].mate = MATE; out[slot].rc = RC; \
+		out[slot].rc_flag = SCORE; out[slot].flag = FLAG; out[slot].nT = NT; out[slot].T = TP; } while(0)
+	if(0 < best1 && 0 < best2) {
+		if(paired) {
+			flag |= 2; flag_r |= 2;
+			int comp = (hc1 + hc2) < (best1 + best2) ? (hc1 + hc2) : (best1 + best2);
+			if(k <= comp || (unsigned) (len1 + len2 - comp - (k << 1)) < (unsigned) (comp * k)) {   /* CompDNA.seqlen is unsigned: the difference wraps */
+				if(0 < regT[0]) {
+					flag |= 32; flag_r |= 16; o1 ^= 1;
+					EMIT(0, 0, o1, best1, flag, regT, 0);
+					EMIT(1, 1, o2, best2, flag_r, regT, nreg);
+				} else {
+					flag |= 16; flag_r |= 32; o2 ^= 1;
+					for(int i = 0; i < nreg; ++i) regT[i] = -regT[i];
+					EMIT(0, 1, o2, best2, flag_r, regT, 0);
+					EMIT(1, 0, o1, best1, flag, regT, nreg);
+				}
+				ret = 0;
+			}
+		} else {
+			int h1 = hc1 < best1 ? hc1 : best1, h2 = hc2 < best2 ? hc2 : best2;
+			int ok1 = k <= h1 || (unsigned) (len1 - h1 - k) < (unsigned) (h1 * k), ok2 = k <= h2 || (unsigned) (len2 - h2 - k) < (unsigned) (h2 * k);
+			int s1 = best1, s2 = best2;
+			if(ok1) {
+				if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+				else { flag |= 16; flag_r |= 32; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			}
+			if(ok2) {
+				if(0 < bT[0]) { o2 ^= 1; if(bT[nb2 - 1] < 0) s2 = -s2; }
+				else { flag |= 32; flag_r |= 16; for(int i = 0; i < nb2; ++i) bT[i] = -bT[i]; }
+			}
+			if(ok1) EMIT(0, 0, o1, s1, flag, regT, nreg);
+			if(ok2) EMIT(1, 1, o2, s2, flag_r, bT, nb2);
+			ret = (ok1 ? 0 : 1) + (ok2 ? 0 : 2);
+		}
+	} else if(0 < best1) {
+		int h1 = hc1 < best1 ? hc1 : best1, s1 = best1;
+		if(k <= h1 || (unsigned) (len1 - h1 - k) < (unsigned) (h1 * k)) {
+			flag |= 8; flag |= 32;
+			if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+			else { flag |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			EMIT(0, 0, o1, s1, flag, regT, nreg);
+			ret = 2;
+		}
+	} else if(0 < best2) {
+		int h2 = hc2 < best2 ? hc2 : best2, s2 = best2;
+		if(k <= h2 || (unsigned) (len2 - h2 - k) < (unsigned) (h2 * k)) {
+			flag_r |= 8; flag_r |= 32;
+			if(0 < regT[0]) { o2 ^= 1; if(regT[nreg - 1] < 0) s2 = -s2; }
+			else { flag_r |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			EMIT(1, 1, o2, s2, flag_r, regT, nreg);
+			ret = 1;
+		}
+	}
+	#undef EMIT
+	free(regS); free(buf);
+	ws_free(w);
+	return ret;
 }

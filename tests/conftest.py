@@ -23,3 +23,9 @@ def golden_se(tmp_path_factory):
 def golden_long(tmp_path_factory):
     import golden_util
     return golden_util.load_se(tmp_path_factory.mktemp("golden_long"), "long")
+
+
+@pytest.fixture(scope="session")
+def golden_pe(tmp_path_factory):
+    import golden_util
+    return golden_util.load_pe(tmp_path_factory.mktemp("golden_pe"))

@@ -221,9 +221,83 @@ def make_long(outdir, seed=21):
         shutil.copy(os.path.join(tmp, "out.frag_raw.gz"), os.path.join(outdir, "out.frag_raw.gz"))
 
 
+def tricky_pairs(seqs, n, seed):
+    """Read pairs: proper pairs (either orientation), mates on different templates, one mate random,
+    short / N-containing mates, overlapping mates."""
+    rng = np.random.default_rng(seed)
+    m1, m2 = [], []
+    for i in range(n):
+        kind = rng.random()
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.choice([150, 150, 100, 75, 40]))
+        ins = int(rng.integers(max(L, 60), 500))
+        ins = min(ins, len(s))
+        L = min(L, ins)
+        st = int(rng.integers(0, len(s) - ins + 1))
+        frag = s[st:st + ins]
+        a = frag[:L].copy()
+        b = synth.revcomp_codes(frag[-L:]).copy()
+        if kind < 0.12:       # second mate from another template
+            s2 = seqs[int(rng.integers(0, len(seqs)))]
+            st2 = int(rng.integers(0, max(1, len(s2) - L)))
+            b = s2[st2:st2 + L].copy()
+            if rng.random() < 0.5:
+                b = synth.revcomp_codes(b)
+        elif kind < 0.20:     # one mate random
+            if rng.random() < 0.5:
+                a = rng.integers(0, 4, L, dtype=np.uint8)
+            else:
+                b = rng.integers(0, 4, L, dtype=np.uint8)
+        elif kind < 0.25:     # same strand (improper orientation)
+            b = frag[-L:].copy()
+        for r in (a, b):
+            rate = float(rng.choice([0.0, 0.005, 0.02, 0.05]))
+            m = rng.random(len(r)) < rate
+            r[m] = (r[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            if rng.random() < 0.1:
+                m = rng.random(len(r)) < 0.02
+                r[m] = 4
+        if rng.random() < 0.08:
+            a = a[: int(rng.integers(10, 30))]
+        if rng.random() < 0.5:
+            a, b = b, a
+        m1.append(np.ascontiguousarray(a)); m2.append(np.ascontiguousarray(b))
+    return m1, m2
+
+
+def make_pe(outdir, seed=33):
+    os.makedirs(outdir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        names, seqs = tricky_db(seed)
+        fa = os.path.join(tmp, "db.fsa")
+        synth.write_fasta(fa, names, seqs)
+        m1, m2 = tricky_pairs(seqs, 900, seed + 1)
+        fq1, fq2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+        synth.write_fastq(fq1, m1, prefix="p")
+        synth.write_fastq(fq2, m2, prefix="p")
+        db = os.path.join(tmp, "db")
+        run([KMA, "index", "-i", fa, "-o", db])
+        base = [KMA, "-ipe", fq1, fq2, "-o", os.path.join(tmp, "out"), "-t_db", db, "-1t1", "-apm", "p", "-t", "1"]
+        with open(os.path.join(tmp, "s1.bin"), "wb") as f:
+            run(base + ["-s1"], stdout=f)
+        with open(os.path.join(tmp, "s2.bin"), "wb") as f:
+            run(base + ["-s2"], stdout=f)
+        run(base + ["-a"])
+        gz(fa, os.path.join(outdir, "db.fsa.gz"))
+        gz(fq1, os.path.join(outdir, "r1.fq.gz")); gz(fq2, os.path.join(outdir, "r2.fq.gz"))
+        xz(db + ".comp.b", os.path.join(outdir, "db.comp.b.xz"))
+        for ext in (".length.b", ".seq.b", ".name"):
+            shutil.copy(db + ext, os.path.join(outdir, "db" + ext))
+        for b in ("s1.bin", "s2.bin"):
+            gz(os.path.join(tmp, b), os.path.join(outdir, b + ".gz"))
+        shutil.copy(os.path.join(tmp, "out.res"), os.path.join(outdir, "out.res"))
+        shutil.copy(os.path.join(tmp, "out.frag_raw.gz"), os.path.join(outdir, "out.frag_raw.gz"))
+
+
 if __name__ == "__main__":
     if not os.path.exists(KMA):
         sys.exit("oracle/_ref/kma missing: run `make -C oracle ref` first")
     make_se(os.path.join(HERE, "se"))
     make_long(os.path.join(HERE, "long"))
+    make_pe(os.path.join(HERE, "pe"))
     print("golden fixtures written")

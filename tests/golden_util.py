@@ -91,3 +91,58 @@ def check_align_against_frag_raw(s1, frag, T_off, res):
         n_ok += got is not None
     assert n_ok == len(frag)
     return n_ok
+
+
+def s2_record_bytes(seqlen, words, N, rc_flag, T, hdr, flag):
+    """One S2 record exactly as print_ankers writes it (ankers.c:30-50)."""
+    import struct
+    b = struct.pack("<7i", seqlen, len(words), len(N), rc_flag, len(T), len(hdr), flag)
+    return b + np.asarray(words, np.uint64).tobytes() + np.asarray(N, np.int32).tobytes() + \
+        np.asarray(T, np.int32).tobytes() + hdr
+
+
+def load_pe(tmp, name="pe"):
+    src = os.path.join(GOLD, name)
+    tmp = str(tmp)
+    prefix = os.path.join(tmp, "db")
+    with lzma.open(os.path.join(src, "db.comp.b.xz"), "rb") as f, open(prefix + ".comp.b", "wb") as g:
+        shutil.copyfileobj(f, g)
+    for ext in (".length.b", ".seq.b", ".name"):
+        shutil.copy(os.path.join(src, "db" + ext), prefix + ext)
+    s1 = formats.parse_s1(_gunzip(os.path.join(src, "s1.bin.gz")))
+    s2_bytes = _gunzip(os.path.join(src, "s2.bin.gz"))
+    # units: ("pe", i, i+1) or ("se", i)
+    units, i = [], 0
+    while i < len(s1):
+        if s1[i]["pair"]:
+            units.append(("pe", i, i + 1)); i += 2
+        else:
+            units.append(("se", i)); i += 1
+    return dict(dir=src, prefix=prefix, s1=s1, s2_bytes=s2_bytes, units=units)
+
+
+def pe_stream_from(g, scan_pair, scan_single, rc_packed):
+    """Rebuild the S2 byte stream of a mixed PE/SE S1 input from per-unit results.
+    scan_pair(a, b) -> list of record dicts (mate, rc, rc_flag, flag, T) in stream order;
+    scan_single(r) -> None or (rc_flag, flag, T)."""
+    import struct
+    out = b""
+    for u in g["units"]:
+        if u[0] == "se":
+            r = g["s1"][u[1]]
+            res = scan_single(r)
+            if res is not None:
+                rf, fl, T = res
+                words, N = r["seq"], r["N"]
+                if fl & 16:
+                    words, N = rc_packed(r["seq"], r["seqlen"], r["N"])
+                out += s2_record_bytes(r["seqlen"], words, N, rf, T, r["hdr"], fl)
+        else:
+            a, b = g["s1"][u[1]], g["s1"][u[2]]
+            for rec in scan_pair(a, b):
+                r = (a, b)[rec["mate"]]
+                words, N = r["seq"], r["N"]
+                if rec["rc"]:
+                    words, N = rc_packed(r["seq"], r["seqlen"], r["N"])
+                out += s2_record_bytes(r["seqlen"], words, N, int(rec["rc_flag"]), rec["T"], r["hdr"], int(rec["flag"]))
+    return out + struct.pack("<i", -len(g["units"]))

@@ -25,6 +25,11 @@ class AlignParams(C.Structure):
     _fields_ = [("minlen", C.c_int), ("mq", C.c_int), ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double)]
 
 
+class PeRec(C.Structure):
+    _fields_ = [("present", C.c_int), ("mate", C.c_int), ("rc", C.c_int), ("rc_flag", C.c_int), ("flag", C.c_int),
+                ("nT", C.c_int), ("T", C.POINTER(C.c_int))]
+
+
 def _build():
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
@@ -52,6 +57,11 @@ def lib():
         L.orc_align_se_batch.argtypes = [C.c_void_p, C.POINTER(Rewards), C.POINTER(AlignParams), C.c_int64] + [C.c_void_p] * 18
         L.orc_nw_tap.restype = None
         L.orc_nw_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.POINTER(Rewards), C.c_void_p]
+        L.orc_scan_pe.restype = C.c_int
+        L.orc_scan_pe.argtypes = [C.c_void_p, C.POINTER(Rewards), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PeRec * 2), C.c_void_p, C.c_void_p]
+        L.orc_rc.restype = None
+        L.orc_rc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -120,3 +130,33 @@ class OracleDB:
                                  _p(out["start"]), _p(out["end"]), _p(out["score"]),
                                  _p(out["alignment_scores"]), _p(out["uniq_alignment_scores"]))
         return out
+
+    def scan_pe(self, seq1, len1, N1, seq2, len2, N2, exhaustive=0):
+        """One pair (padded u64 word arrays + N position arrays) -> list of up to two record dicts in stream order."""
+        import struct
+        D = struct.unpack("<I", open(self.prefix + ".comp.b", "rb").read(4))[0]
+        T1 = np.zeros(2 * D + 8, np.int32); T2 = np.zeros(2 * D + 8, np.int32)
+        recs = (PeRec * 2)()
+        s1 = np.ascontiguousarray(np.concatenate([seq1, np.zeros(2, np.uint64)]))
+        s2 = np.ascontiguousarray(np.concatenate([seq2, np.zeros(2, np.uint64)]))
+        n1 = np.ascontiguousarray(N1 if len(N1) else np.zeros(1, np.int32), np.int32)
+        n2 = np.ascontiguousarray(N2 if len(N2) else np.zeros(1, np.int32), np.int32)
+        ret = lib().orc_scan_pe(self.h, C.byref(self.rw), exhaustive, _p(s1), len1, _p(n1), len(N1),
+                                _p(s2), len2, _p(n2), len(N2), C.byref(recs), _p(T1), _p(T2))
+        out = []
+        for r in recs:
+            if r.present:
+                out.append(dict(mate=r.mate, rc=r.rc, rc_flag=r.rc_flag, flag=r.flag,
+                                T=np.array([r.T[i] for i in range(r.nT)], np.int32)))
+        return ret, out
+
+
+def rc_packed(seq, length, N):
+    """compdna.c:228-256 on numpy arrays -> (rc words, rc N positions)."""
+    words = (length + 31) // 32
+    s = np.ascontiguousarray(np.concatenate([seq[:words], np.zeros(2, np.uint64)]))
+    fN = np.ascontiguousarray(np.concatenate([[len(N)], N]).astype(np.int32))
+    rs = np.zeros(words + 2, np.uint64)
+    rN = np.zeros(len(N) + 2, np.int32)
+    lib().orc_rc(_p(s), length, _p(fN), _p(rs), _p(rN))
+    return rs[:words], rN[1:1 + len(N)]

@@ -113,3 +113,21 @@ def test_reference_binary_accepts_our_index(golden_se, tmp_path):
     assert s2 == gzip.open(golden_se["dir"] + "/s2.bin.gz", "rb").read()
     subprocess.run(base, capture_output=True, check=True)
     assert open(str(tmp_path / "o.res")).read() == open(golden_se["dir"] + "/out.res").read()
+
+
+def test_oracle_pe_scan_matches_s2_tap_bytes(golden_pe):
+    # paired end `-apm p`: get_kmers_for_pair + getFirstPen/getSecondBestPen/getF_Best +
+    # save_kmers_penaltyPair; the rebuilt S2 stream must equal the reference's byte for byte
+    db = oracle.OracleDB(golden_pe["prefix"])
+
+    def single(r):
+        codes = formats.unpack_words(r["seq"], r["seqlen"]).copy()
+        codes[r["N"]] = 4
+        rf, fl, To, T = db.scan_se(formats.pack_ragged([codes]))
+        return (int(rf[0]), int(fl[0]), T) if To[1] > To[0] else None
+
+    def pair(a, b):
+        return db.scan_pe(a["seq"], a["seqlen"], a["N"], b["seq"], b["seqlen"], b["N"])[1]
+
+    got = golden_util.pe_stream_from(golden_pe, pair, single, oracle.rc_packed)
+    assert got == golden_pe["s2_bytes"]
