@@ -130,6 +130,21 @@ typedef struct kmahip_hits {
 	uint64_t *uniq_alignment_scores;  /* DB_size, may be NULL */
 } kmahip_hits;
 
+/* Stage-2 result for paired reads (`-ipe ... -apm p`): two record slots per pair, in the order the
+ * reference writes them to the S2 stream (printPair / deConPrintPtr, savekmers.c:3609-3737, ankers.c:150-160).
+ * mate[r] = -1: slot not written; else 0/1 = which mate of the pair the record carries. rc[r] = 1: its
+ * reverse complement is the sequence passed on. rc_flag / flag / T as in kmahip_cands; a properly paired
+ * couple is "first record with an empty list (flag & 2), second record with the shared list". */
+typedef struct kmahip_pe_recs {
+	int32_t *mate;        /* 2 * n_pairs */
+	int32_t *rc;
+	int32_t *rc_flag;
+	int32_t *flag;
+	int64_t *R_off;       /* 2 * n_pairs + 1 */
+	int32_t *T;
+	int64_t T_cap;
+} kmahip_pe_recs;
+
 void kmahip_default_params(kmahip_params *p);
 const char *kmahip_last_error(void);
 
@@ -152,6 +167,13 @@ int kmahip_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
  * (a hipStream_t, NULL = default stream). */
 int kmahip_scan_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
                        const kmahip_params *p, kmahip_cands *out, void *stream);
+/* Stage 2, paired end with pairing penalty (`-apm p`): save_kmers_pair = save_kmers_penaltyPair
+ * (savekmers.h:51, savekmers.c:3572-3777) with get_kmers_for_pair (:427-688). reads = mates interleaved
+ * (read 2i = mate 1, 2i+1 = mate 2 of pair i). *_dev: device pointers, asynchronous on `stream`. */
+int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, kmahip_pe_recs *out);
+int kmahip_scan_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                       kmahip_pe_recs *out, void *stream);
+
 /* Stage 3a, single end: alignment score of every (read, candidate) pair,
  * per-read hit selection and ConClave accumulators.  `cands` is the output of
  * kmahip_scan_se_dev on the same `reads` (device pointers). */

@@ -46,6 +46,11 @@ class Hits(C.Structure):
                 ("alignment_scores", C.c_void_p), ("uniq_alignment_scores", C.c_void_p)]
 
 
+class PeRecs(C.Structure):
+    _fields_ = [("mate", C.c_void_p), ("rc", C.c_void_p), ("rc_flag", C.c_void_p), ("flag", C.c_void_p),
+                ("R_off", C.c_void_p), ("T", C.c_void_p), ("T_cap", C.c_int64)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64)]
 
@@ -88,6 +93,8 @@ def lib():
         L.kmahip_align_se_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Cands), C.POINTER(Params),
                                           C.POINTER(Hits), C.c_void_p]
         L.kmahip_align_get_stats.argtypes = [C.c_void_p, C.POINTER(AlignStats), C.c_void_p]
+        L.kmahip_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs)]
+        L.kmahip_scan_pe_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs), C.c_void_p]
         L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
         _lib = L
     return _lib
@@ -243,3 +250,28 @@ class KmaHipDB:
         p = Params.from_buffer_copy(self.params)
         _check(lib().kmahip_align_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(p), C.byref(h),
                                          C.c_void_p(stream or 0)))
+
+    # -- paired end stage 2 (-apm p), host buffers ------------------------------------
+    def scan_pe(self, batch, exhaustive=0, t_cap=None):
+        """batch = mates interleaved (read 2i, 2i+1 = pair i) -> mate, rc, rc_flag, flag [2*pairs], R_off, T"""
+        n = batch.n
+        assert n % 2 == 0
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        mate, rc, rc_flag, flag = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+        R_off = np.zeros(n + 1, np.int64)
+        cap = t_cap or max(1024, 16 * n)
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        for _ in range(6):
+            T = np.zeros(cap, np.int32)
+            out = PeRecs(_p(mate), _p(rc), _p(rc_flag), _p(flag), _p(R_off), _p(T), cap)
+            rcode = lib().kmahip_scan_pe(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out))
+            if rcode == -6:
+                cap = max(cap * 2, int(R_off[n]) + 16)
+                continue
+            _check(rcode)
+            return mate[:n], rc[:n], rc_flag[:n], flag[:n], R_off, T[:R_off[n]]
+        raise KmaHipError("scan_pe: output capacity kept overflowing")

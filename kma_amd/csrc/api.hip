@@ -25,6 +25,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 		delete ev;
 	}
 	(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64); (void) hipFree(ws->a_task);
+	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
 	delete ws;
 }
 
@@ -120,8 +121,8 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 	if(c[1]) HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
 	if(c[1] == 1) {
 		// internal candidate pool too small: grow and let the caller retry
-		ws->cap_reads = 0;
-		kmahip_set_error("internal candidate pool exhausted");
+		ws->pool_scale *= 2; ws->cap_reads = 0;
+		kmahip_set_error("internal candidate pool exhausted (retry grows it)");
 		return KMAHIP_EOVERFLOW;
 	}
 	const int64_t total = out->T_off[n];
@@ -233,5 +234,53 @@ extern "C" int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scor
 	int rc = fn(alignment_scores, alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
 	if(!rc) rc = fn(uniq_alignment_scores, uniq_alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
 	if(rc) { kmahip_set_error("ncclAllReduce failed with code %d", rc); return KMAHIP_EDEVICE; }
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_scan_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                                  kmahip_pe_recs *out, void *stream) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_launch_scan_pe(db, ws, reads, p, out, (hipStream_t) stream);
+}
+
+extern "C" int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, kmahip_pe_recs *out) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	int rc;
+	if((rc = stage_reserve(ws, 0, (size_t) (reads->seq_words + 1) * 8)) || (rc = stage_reserve(ws, 1, (size_t) (n + 1) * 8)) ||
+	   (rc = stage_reserve(ws, 2, (size_t) n * 4)) || (rc = stage_reserve(ws, 3, (size_t) reads->N_total * 4)) ||
+	   (rc = stage_reserve(ws, 4, (size_t) (n + 1) * 8)) || (rc = stage_reserve(ws, 5, (size_t) n * 16)) ||
+	   (rc = stage_reserve(ws, 6, (size_t) (n + 1) * 8)) || (rc = stage_reserve(ws, 7, (size_t) out->T_cap * 4))) return rc;
+	hipStream_t s = 0;
+	HIP_TRY(hipMemsetAsync((char *) ws->stage[0] + (size_t) reads->seq_words * 8, 0, 8, s));
+	if(reads->seq_words) HIP_TRY(hipMemcpyAsync(ws->stage[0], reads->seq, (size_t) reads->seq_words * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[1], reads->seq_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	if(n) HIP_TRY(hipMemcpyAsync(ws->stage[2], reads->len, (size_t) n * 4, hipMemcpyHostToDevice, s));
+	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	kmahip_reads d = *reads;
+	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
+	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
+	kmahip_pe_recs o;
+	int32_t *ip = (int32_t *) ws->stage[5];
+	o.mate = ip; o.rc = ip + n; o.rc_flag = ip + 2 * n; o.flag = ip + 3 * n;
+	o.R_off = (int64_t *) ws->stage[6]; o.T = (int32_t *) ws->stage[7]; o.T_cap = out->T_cap;
+	if((rc = kmahip_launch_scan_pe(db, ws, &d, p, &o, s))) return rc;
+	if(n) {
+		HIP_TRY(hipMemcpyAsync(out->mate, o.mate, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(out->rc, o.rc, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(out->rc_flag, o.rc_flag, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(out->flag, o.flag, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+	}
+	HIP_TRY(hipMemcpyAsync(out->R_off, o.R_off, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned long long c[8];
+	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	if(c[1]) HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
+	if(c[1] == 1) { ws->pool_scale *= 2; ws->cap_reads = 0; kmahip_set_error("internal candidate pool exhausted (retry grows it)"); return KMAHIP_EOVERFLOW; }
+	const int64_t total = out->R_off[n];
+	if(total > out->T_cap) { kmahip_set_error("T_cap %lld too small, need %lld", (long long) out->T_cap, (long long) total); return KMAHIP_EOVERFLOW; }
+	if(total) HIP_TRY(hipMemcpy(out->T, o.T, (size_t) total * 4, hipMemcpyDeviceToHost));
 	return KMAHIP_OK;
 }

@@ -60,6 +60,7 @@ struct kmahip_ws {
 	// candidate pool
 	int32_t *pool;
 	int64_t pool_cap;
+	int64_t pool_scale;       // pool = cap_reads * 16 * pool_scale ints; doubled after an overflow
 	// counters: [0] pool top, [1] status, [2] n_overflow, [3] probes, [4] value elems, [5] active strands
 	unsigned long long *counters;
 	int64_t *overflow_items;
@@ -67,6 +68,10 @@ struct kmahip_ws {
 	int timing_on;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events2;
+	// paired-end stage 2
+	int32_t *pool_sc, *ppool;
+	void *pe_rec;
+	int64_t pe_cap;
 	// align stage
 	int32_t *a_s32;
 	uint64_t *a_s64;
@@ -93,3 +98,5 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
                           const kmahip_params *p, kmahip_cands *out, hipStream_t stream);
 int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
                            const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
+int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                          kmahip_pe_recs *out, hipStream_t stream);

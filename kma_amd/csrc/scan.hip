@@ -56,6 +56,8 @@ struct ScanArgs {
 	int64_t *overflow_items;
 	int32_t *dense;
 	int64_t dense_slots;
+	int mode;            // 0: best templates per strand (save_kmers); 1: every candidate + score + hit count (get_kmers_for_pair)
+	int32_t *pool_sc;    // mode 1: scores parallel to pool
 };
 
 enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5 };
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 	__shared__ int32_t t_score[TSLOTS * GROUP];
 	__shared__ int32_t t_last[TSLOTS * GROUP];
 	__shared__ int32_t t_first[TSLOTS * GROUP];
-	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_wbase[GROUP];
+	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_wbase[GROUP], s_hits[GROUP];
 	__shared__ int32_t s_len[ITEMS], s_nN[ITEMS], s_alist[ITEMS];
 	__shared__ int64_t s_soff[ITEMS], s_noff[ITEMS];
 	__shared__ uint32_t s_active[2];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 #pragma unroll
 			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
 		}
-		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; }
+		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; }
 		if(tid == 0) s_gmax = 0;
 		__syncthreads();
 		if(tid < ng) atomicMax(&s_gmax, s_len[s_alist[g0 + tid]] - k + 1);
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 					}
 				}
 				vi_buf[idx] = vi;    // == [jj * GROUP + g]
+				if(A.mode && vi != MISS) atomicAdd(&s_hits[g], 1);
 			}
 			if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
 			__syncthreads();
@@ -394,6 +397,31 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 				const unsigned long long slot = atomicAdd(&A.counters[C_NOVER], 1ull);
 				A.overflow_items[slot] = item;
 				nb = -1;
+			} else if(A.mode) {
+				// get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores
+				for(int x = 0; x < TSLOTS; ++x) if(t_id[x * GROUP + g] != T_EMPTY) ++nb;
+				best = s_hits[g];
+				if(nb) {
+					off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+					if(off + nb <= A.pool_cap) {
+						long long prevkey = -1;
+						for(int w = 0; w < nb; ++w) {
+							long long bk = 0x7FFFFFFFFFFFFFFFll;
+							int bx = 0;
+							for(int x = 0; x < TSLOTS; ++x) {
+								const uint32_t id = t_id[x * GROUP + g];
+								if(id == T_EMPTY) continue;
+								const long long key = ((long long) t_first[x * GROUP + g] << 32) | id;
+								if(key > prevkey && key < bk) { bk = key; bx = x; }
+							}
+							A.pool[off + w] = (int32_t) (bk & 0xFFFFFFFFll);
+							A.pool_sc[off + w] = max(0, t_score[bx * GROUP + g]);
+							prevkey = bk;
+						}
+					} else {
+						atomicMax(&A.counters[C_STATUS], 1ull);
+					}
+				}
 			} else {
 				for(int x = 0; x < TSLOTS; ++x) {
 					if(t_id[x * GROUP + g] == T_EMPTY) continue;
@@ -497,7 +525,16 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 		}
 		int best = 0, nb = 0;
 		int64_t off = 0;
-		if(hits) {
+		if(hits && A.mode) {
+			const int c = (int) value_at(db, last, 0);
+			for(int i = 1; i <= c; ++i) score[value_at(db, last, i)] += acc;
+			best = hits; nb = nlist;
+			off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+			if(off + nb <= A.pool_cap) {
+				for(int e = 0; e < nlist; ++e) { A.pool[off + e] = list[e]; A.pool_sc[off + e] = max(0, score[list[e]]); }
+			} else atomicMax(&A.counters[C_STATUS], 1ull);
+			for(int e = 0; e < nlist; ++e) { score[list[e]] = 0; ext[list[e]] = -1; }
+		} else if(hits) {
 			const int c = (int) value_at(db, last, 0);
 			for(int i = 1; i <= c; ++i) score[value_at(db, last, i)] += acc;
 			for(int e = 0; e < nlist; ++e) {
@@ -617,6 +654,195 @@ __global__ void dense_init_kernel(int32_t *p, int64_t n, int64_t D) {
 	for(; i < n; i += stride) p[i] = ((i / D) % 3 == 1) ? -1 : 0;
 }
 
+// ---- paired end, `-apm p` ------------------------------------------------------------------
+// save_kmers_penaltyPair (savekmers.c:3572-3777) over the four strand items of a pair
+// (mate1 fwd/rc = items 4p, 4p+1; mate2 = 4p+2, 4p+3): getFirstPen (:1383), getSecondBestPen (:1415),
+// getF_Best (:1648). One lane per pair; lists live in the item pool, results in the pair pool.
+struct PList { const int32_t *t, *s; int n; };
+
+__device__ __forceinline__ int plist_find(const PList &l, int t) {
+	for(int i = 0; i < l.n; ++i) if(l.t[i] == t) return l.s[i];
+	return 0;
+}
+
+struct PairArgs {
+	ScanArgs S;
+	int64_t n_pairs;
+	int PE;
+	int32_t *ppool;          // pair pool: record template lists
+	int64_t ppool_cap;
+	// per record (2 per pair, stream order)
+	int32_t *r_mate, *r_rc, *r_score, *r_flag, *r_n;
+	int64_t *r_off;
+};
+
+__global__ __launch_bounds__(256) void pair_penalty_kernel(const PairArgs P) {
+	const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(p >= P.n_pairs) return;
+	const ScanArgs &A = P.S;
+	const int k = (int) A.db.kmersize;
+	PList L[4];
+	int hc[4];
+	for(int x = 0; x < 4; ++x) {
+		const int64_t it = 4 * p + x;
+		L[x].n = max(0, A.item_n[it]); L[x].t = A.pool + A.item_off[it]; L[x].s = A.pool_sc + A.item_off[it];
+		hc[x] = A.item_score[it];
+	}
+	const PList &F1 = L[0], &R1 = L[1], &F2 = L[2], &R2 = L[3];
+	const int hc1 = max(hc[0], hc[1]), hc2 = max(hc[2], hc[3]);
+	const int len1 = A.len[2 * p], len2 = A.len[2 * p + 1];
+	// working lists in the pair pool
+	const int n1 = F1.n + R1.n, n2 = F2.n + R2.n;
+	const int64_t need = (int64_t) max(n1, n2) + n2;
+	int64_t base = 0;
+	if(need) {
+		base = (int64_t) atomicAdd(&A.counters[7], (unsigned long long) need);
+		if(base + need > P.ppool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); return; }
+	}
+	int32_t *regT = P.ppool + base, *bT = regT + max(n1, n2);
+	auto regS = [&](int i) { return i < F1.n ? F1.s[i] : R1.s[i - F1.n]; };
+	int nreg = 0, best1 = 0;
+	if(hc1) {
+		for(int i = 0; i < F1.n; ++i) { best1 = max(best1, F1.s[i]); regT[nreg++] = F1.t[i]; }
+		for(int i = 0; i < R1.n; ++i) { best1 = max(best1, R1.s[i]); regT[nreg++] = -R1.t[i]; }
+	}
+	int paired = 0, best2 = 0, nb2 = 0;
+	if(hc2) {
+		if(0 < best1) {
+			for(int i = 0; i < F2.n; ++i) { best2 = max(best2, F2.s[i]); bT[nb2++] = F2.t[i]; }
+			for(int i = 0; i < R2.n; ++i) { best2 = max(best2, R2.s[i]); bT[nb2++] = -R2.t[i]; }
+			int hits = 0;
+			if(best2) {
+				int comp = max(0, best1 + best2 - P.PE);
+				for(int i = 0; i < nreg; ++i) {
+					const int rt = regT[i];
+					int sc = rt > 0 ? plist_find(R2, rt) : plist_find(F2, -rt);
+					if(0 < sc) {
+						sc += regS(i);
+						if(comp < sc) { comp = sc; hits = 1; regT[0] = rt; }
+						else if(comp == sc) { regT[hits++] = rt; }
+					}
+				}
+			}
+			if(hits) { paired = 1; nreg = hits; }
+			else {
+				int c = 0;
+				for(int i = 0; i < nreg; ++i) if(best1 == regS(i)) regT[c++] = regT[i];
+				nreg = c; c = 0;
+				for(int i = 0; i < nb2; ++i) {
+					const int t = bT[i];
+					if(0 < t) { if(best2 == plist_find(F2, t)) bT[c++] = t; }
+					else { if(best2 <= plist_find(R2, -t)) bT[c++] = t; }
+				}
+				nb2 = c;
+			}
+		} else {
+			nreg = 0;
+			for(int i = 0; i < F2.n; ++i) { const int sc = F2.s[i]; if(best2 < sc) { best2 = sc; nreg = 0; regT[nreg++] = F2.t[i]; } else if(best2 == sc) regT[nreg++] = F2.t[i]; }
+			for(int i = 0; i < R2.n; ++i) { const int sc = R2.s[i]; if(best2 < sc) { best2 = sc; nreg = 0; regT[nreg++] = -R2.t[i]; } else if(best2 == sc) regT[nreg++] = -R2.t[i]; }
+		}
+	}
+	int o1 = len1 >= k, o2 = len2 >= k;      // get_kmers_for_pair leaves a scanned mate reverse-complemented
+	int flag = 65, flag_r = 129;
+	int m[2] = {-1, -1}, rcv[2] = {0, 0}, sc[2] = {0, 0}, fl[2] = {0, 0}, nn[2] = {0, 0};
+	int64_t of[2] = {0, 0};
+	// CompDNA.seqlen is unsigned, so the coverage tests below wrap like the reference's
+	if(0 < best1 && 0 < best2) {
+		if(paired) {
+			flag |= 2; flag_r |= 2;
+			const int comp = min(hc1 + hc2, best1 + best2);
+			if(k <= comp || (unsigned) (len1 + len2 - comp - (k << 1)) < (unsigned) (comp * k)) {
+				if(0 < regT[0]) {
+					flag |= 32; flag_r |= 16; o1 ^= 1;
+					m[0] = 0; rcv[0] = o1; sc[0] = best1; fl[0] = flag; nn[0] = 0;
+					m[1] = 1; rcv[1] = o2; sc[1] = best2; fl[1] = flag_r; nn[1] = nreg; of[1] = base;
+				} else {
+					flag |= 16; flag_r |= 32; o2 ^= 1;
+					for(int i = 0; i < nreg; ++i) regT[i] = -regT[i];
+					m[0] = 1; rcv[0] = o2; sc[0] = best2; fl[0] = flag_r; nn[0] = 0;
+					m[1] = 0; rcv[1] = o1; sc[1] = best1; fl[1] = flag; nn[1] = nreg; of[1] = base;
+				}
+			}
+		} else {
+			const int h1 = min(hc1, best1), h2 = min(hc2, best2);
+			const bool ok1 = k <= h1 || (unsigned) (len1 - h1 - k) < (unsigned) (h1 * k);
+			const bool ok2 = k <= h2 || (unsigned) (len2 - h2 - k) < (unsigned) (h2 * k);
+			int s1 = best1, s2 = best2;
+			if(ok1) {
+				if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+				else { flag |= 16; flag_r |= 32; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			}
+			if(ok2) {
+				if(0 < bT[0]) { o2 ^= 1; if(bT[nb2 - 1] < 0) s2 = -s2; }
+				else { flag |= 32; flag_r |= 16; for(int i = 0; i < nb2; ++i) bT[i] = -bT[i]; }
+			}
+			if(ok1) { m[0] = 0; rcv[0] = o1; sc[0] = s1; fl[0] = flag; nn[0] = nreg; of[0] = base; }
+			if(ok2) { m[1] = 1; rcv[1] = o2; sc[1] = s2; fl[1] = flag_r; nn[1] = nb2; of[1] = base + max(n1, n2); }
+		}
+	} else if(0 < best1) {
+		const int h1 = min(hc1, best1);
+		int s1 = best1;
+		if(k <= h1 || (unsigned) (len1 - h1 - k) < (unsigned) (h1 * k)) {
+			flag |= 8; flag |= 32;
+			if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+			else { flag |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			m[0] = 0; rcv[0] = o1; sc[0] = s1; fl[0] = flag; nn[0] = nreg; of[0] = base;
+		}
+	} else if(0 < best2) {
+		const int h2 = min(hc2, best2);
+		int s2 = best2;
+		if(k <= h2 || (unsigned) (len2 - h2 - k) < (unsigned) (h2 * k)) {
+			flag_r |= 8; flag_r |= 32;
+			if(0 < regT[0]) { o2 ^= 1; if(regT[nreg - 1] < 0) s2 = -s2; }
+			else { flag_r |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			m[1] = 1; rcv[1] = o2; sc[1] = s2; fl[1] = flag_r; nn[1] = nreg; of[1] = base;
+		}
+	}
+	for(int x = 0; x < 2; ++x) {
+		const int64_t r = 2 * p + x;
+		P.r_mate[r] = m[x]; P.r_rc[r] = rcv[x]; P.r_score[r] = sc[x]; P.r_flag[r] = fl[x];
+		P.r_n[r] = (m[x] >= 0) ? nn[x] : 0; P.r_off[r] = of[x];
+	}
+}
+
+// generic CSR compaction of per-record lists: counts -> offsets (3 kernels)
+__global__ __launch_bounds__(CB) void rec_count_kernel(const int32_t *cnt, int64_t n, int64_t *blk_sums) {
+	__shared__ int64_t red[CB];
+	const int64_t r = (int64_t) blockIdx.x * CB + threadIdx.x;
+	red[threadIdx.x] = (r < n) ? cnt[r] : 0;
+	__syncthreads();
+	for(int s = CB / 2; s > 0; s >>= 1) {
+		if(threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+		__syncthreads();
+	}
+	if(threadIdx.x == 0) blk_sums[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(CB) void rec_write_kernel(const int32_t *cnt, const int64_t *src_off, const int32_t *src, int64_t n,
+                                                        const int64_t *blk_sums, int64_t *out_off, int32_t *out, int64_t out_cap,
+                                                        unsigned long long *counters) {
+	__shared__ int64_t sc[CB];
+	const int t = threadIdx.x;
+	const int64_t r = (int64_t) blockIdx.x * CB + t;
+	const int64_t c = (r < n) ? cnt[r] : 0;
+	sc[t] = c;
+	__syncthreads();
+	for(int d = 1; d < CB; d <<= 1) {
+		int64_t v = (t >= d) ? sc[t - d] : 0;
+		__syncthreads();
+		sc[t] += v;
+		__syncthreads();
+	}
+	if(r >= n) return;
+	const int64_t end = blk_sums[blockIdx.x] + sc[t], beg = end - c;
+	out_off[r + 1] = end;
+	if(r == 0) out_off[0] = 0;
+	if(c == 0) return;
+	if(end > out_cap) { atomicMax(&counters[C_STATUS], 2ull); return; }
+	const int64_t so = src_off[r];
+	for(int64_t i = 0; i < c; ++i) out[beg + i] = src[so + i];
+}
+
 } // namespace
 
 static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
@@ -630,7 +856,8 @@ static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 		HIP_TRY(hipMalloc((void **) &ws->item_score, cap * 2 * sizeof(int32_t)));
 		HIP_TRY(hipMalloc((void **) &ws->item_n, cap * 2 * sizeof(int32_t)));
 		HIP_TRY(hipMalloc((void **) &ws->item_off, cap * 2 * sizeof(int64_t)));
-		ws->pool_cap = cap * 16;
+		if(ws->pool_scale < 1) ws->pool_scale = 1;
+		ws->pool_cap = cap * 16 * ws->pool_scale;
 		HIP_TRY(hipMalloc((void **) &ws->pool, ws->pool_cap * sizeof(int32_t)));
 		HIP_TRY(hipMalloc((void **) &ws->overflow_items, cap * 2 * sizeof(int64_t)));
 		ws->blk_cap = (cap + CB - 1) / CB + 1;
@@ -664,6 +891,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
+	A.mode = 0; A.pool_sc = nullptr;
 	A.ablate = 0;
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_SCAN")) A.ablate = atoi(e);
@@ -697,6 +925,50 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	hipLaunchKernelGGL(combine_count_kernel, dim3(cgrid), dim3(CB), 0, stream, A, out->rc_flag, out->flag, out->T_off, ws->blk_sums);
 	hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, ws->blk_sums, (int64_t) cgrid);
 	hipLaunchKernelGGL(combine_write_kernel, dim3(cgrid), dim3(CB), 0, stream, A, out->rc_flag, out->flag, out->T_off, ws->blk_sums, out->T, out->T_cap);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}
+
+int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                          kmahip_pe_recs *out, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	if(n < 0 || (n & 1) || !out || !p) { kmahip_set_error("paired scan needs an even number of reads (mates interleaved)"); return KMAHIP_EINVAL; }
+	const int64_t np = n / 2;
+	int rc = ws_reserve(ws, n > 0 ? n : 1);
+	if(rc) return rc;
+	if(ws->pe_cap < ws->pool_cap) {
+		(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
+		ws->pool_sc = nullptr; ws->ppool = nullptr; ws->pe_rec = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->pool_sc, ws->pool_cap * sizeof(int32_t)));
+		HIP_TRY(hipMalloc((void **) &ws->ppool, 2 * ws->pool_cap * sizeof(int32_t)));
+		HIP_TRY(hipMalloc((void **) &ws->pe_rec, (size_t) (ws->cap_reads + 2) * (sizeof(int32_t) + sizeof(int64_t))));
+		ws->pe_cap = ws->pool_cap;
+	}
+	ScanArgs A;
+	A.db = db->dev;
+	A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.exhaustive = p->exhaustive;
+	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
+	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
+	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
+	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc;
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
+	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
+	const unsigned grid = (unsigned) ((2 * n + ITEMS - 1) / ITEMS);
+	hipLaunchKernelGGL(scan_se_kernel<false>, dim3(grid), dim3(THREADS), 0, stream, A);
+	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ((ws->dense_slots + 63) / 64)), dim3(64), 0, stream, A);
+	PairArgs P;
+	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
+	P.ppool = ws->ppool; P.ppool_cap = 2 * ws->pool_cap;
+	P.r_mate = out->mate; P.r_rc = out->rc; P.r_score = out->rc_flag; P.r_flag = out->flag;
+	P.r_off = (int64_t *) ws->pe_rec; P.r_n = (int32_t *) (P.r_off + ws->cap_reads + 2);
+	hipLaunchKernelGGL(pair_penalty_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
+	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
+	hipLaunchKernelGGL(rec_count_kernel, dim3(cgrid), dim3(CB), 0, stream, P.r_n, n, ws->blk_sums);
+	hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, ws->blk_sums, (int64_t) cgrid);
+	hipLaunchKernelGGL(rec_write_kernel, dim3(cgrid), dim3(CB), 0, stream, P.r_n, P.r_off, ws->ppool, n, ws->blk_sums,
+	                   out->R_off, out->T, out->T_cap, ws->counters);
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
 }

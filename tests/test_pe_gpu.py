@@ -1,0 +1,87 @@
+"""Paired-end stage 2 (-apm p) on the GPU: rebuilt S2 byte stream vs the reference tap, and vs the oracle."""
+import numpy as np
+import pytest
+
+import golden_util
+from kma_amd import formats
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(r):
+    c = formats.unpack_words(r["seq"], r["seqlen"]).copy()
+    if len(r["N"]):
+        c[r["N"]] = 4
+    return c
+
+
+def _device_results(g, db):
+    pairs = [u for u in g["units"] if u[0] == "pe"]
+    singles = [u for u in g["units"] if u[0] == "se"]
+    pb = formats.pack_ragged([_codes(g["s1"][i]) for u in pairs for i in (u[1], u[2])])
+    mate, rc, rc_flag, flag, R_off, T = db.scan_pe(pb)
+    pair_res = {}
+    for j, u in enumerate(pairs):
+        recs = []
+        for x in (2 * j, 2 * j + 1):
+            if mate[x] >= 0:
+                recs.append(dict(mate=int(mate[x]), rc=int(rc[x]), rc_flag=int(rc_flag[x]), flag=int(flag[x]),
+                                 T=T[R_off[x]:R_off[x + 1]]))
+        pair_res[u[1]] = recs
+    single_res = {}
+    if singles:
+        sb = formats.pack_ragged([_codes(g["s1"][u[1]]) for u in singles])
+        rf, fl, To, Ts = db.scan_se(sb)
+        for j, u in enumerate(singles):
+            single_res[u[1]] = (int(rf[j]), int(fl[j]), Ts[To[j]:To[j + 1]]) if To[j + 1] > To[j] else None
+    return pair_res, single_res
+
+
+def test_pe_scan_matches_reference_s2_stream(golden_pe):
+    import oracle
+    from kma_amd import binding
+    db = binding.KmaHipDB(golden_pe["prefix"])
+    try:
+        pair_res, single_res = _device_results(golden_pe, db)
+    finally:
+        db.close()
+    s1 = golden_pe["s1"]
+    idx = {id(r): i for i, r in enumerate(s1)}
+    got = golden_util.pe_stream_from(golden_pe, lambda a, b: pair_res[idx[id(a)]], lambda r: single_res[idx[id(r)]],
+                                     oracle.rc_packed)
+    assert got == golden_pe["s2_bytes"]
+
+
+def test_pe_scan_vs_oracle_redundant_db(tmp_path):
+    """Wide candidate lists (overflow path) and short mates."""
+    import oracle
+    from kma_amd import binding, synth
+    names, seqs = synth.make_gene_db(n_families=5, variants=30, len_lo=500, len_hi=900, max_div=0.03, seed=77)
+    prefix = str(tmp_path / "red")
+    formats.write_index(prefix, names, seqs)
+    m1, m2, _ = synth.make_pairs(seqs, 1500, read_len=100, sub_rate=0.01, seed=3)
+    rng = np.random.default_rng(5)
+    reads = []
+    for a, b in zip(m1, m2):
+        if rng.random() < 0.1:
+            a = a[: int(rng.integers(12, 40))]
+        if rng.random() < 0.1:
+            b = rng.integers(0, 4, len(b), dtype=np.uint8)
+        reads += [a, b]
+    batch = formats.pack_ragged(reads)
+    db = binding.KmaHipDB(prefix)
+    try:
+        mate, rc, rc_flag, flag, R_off, T = db.scan_pe(batch)
+    finally:
+        db.close()
+    odb = oracle.OracleDB(prefix)
+    for j in range(len(reads) // 2):
+        w = lambda i: batch.seq[batch.seq_off[i]:batch.seq_off[i + 1] - 1]
+        Nn = lambda i: batch.N[batch.N_off[i]:batch.N_off[i + 1]]
+        _, recs = odb.scan_pe(w(2 * j), int(batch.length[2 * j]), Nn(2 * j), w(2 * j + 1), int(batch.length[2 * j + 1]), Nn(2 * j + 1))
+        got = []
+        for x in (2 * j, 2 * j + 1):
+            if mate[x] >= 0:
+                got.append((int(mate[x]), int(rc[x]), int(rc_flag[x]), int(flag[x]), T[R_off[x]:R_off[x + 1]].tolist()))
+        exp = [(r["mate"], r["rc"], r["rc_flag"], r["flag"], r["T"].tolist()) for r in recs]
+        assert got == exp, (j, got, exp)
