@@ -691,3 +691,170 @@ int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_al
 	orc_aligner_free(a);
 	return mapped;
 }
+
+/* ---- paired end: alnFragsPenaltyPE (alnfrags.c:1596-1972), update_Scores_pe (updatescores.c:390-488),
+ * update_Scores_se (:300-388). seqA/seqB are the two S2 records AS WRITTEN to the stream (first record with
+ * the empty list, second with the candidates T). No strand-tie (arc) handling: save_kmers_penaltyPair never
+ * writes a negative score on the first record of a proper pair. */
+static void orient(orc_aligner *a, const uint64_t *seq, int len, const int *N, int nN, int rc,
+                   uint8_t *bytes, uint64_t *comp, int *Nout) {
+	int *tmp = malloc(sizeof(int) * (size_t) (nN + 3));
+	tmp[0] = nN; memcpy(tmp + 1, N, sizeof(int) * (size_t) nN);
+	const int words = (len + 31) >> 5;
+	if(rc) { orc_rc(seq, len, tmp, comp, Nout); }
+	else { memcpy(comp, seq, sizeof(uint64_t) * (size_t) words); memcpy(Nout, tmp, sizeof(int) * (size_t) (nN + 1)); }
+	comp[words] = 0; comp[words + 1] = 0;
+	unpack_bytes(comp, len, Nout, bytes);
+	Nout[0] += 1; Nout[Nout[0]] = len;
+	free(tmp);
+	(void) a;
+}
+
+int orc_align_pe(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap,
+                 const uint64_t *seqA, int lenA, const int *NA, int nNA, int flagA,
+                 const uint64_t *seqB, int lenB, const int *NB, int nNB, int flagB,
+                 const int *T, int nT, orc_pe_out *out,
+                 uint64_t *alignment_scores, uint64_t *uniq_alignment_scores) {
+	const orc_db *db = a->db;
+	const int k = db->kmersize, Wl = -rw->Wl, PE = rw->PE;
+	{ int *t = out->tmpl, *sc = out->score, *st = out->start, *en = out->end; memset(out, 0, sizeof *out); out->tmpl = t; out->score = sc; out->start = st; out->end = en; }
+	out->flagA = flagA; out->flagB = flagB;
+	uint8_t *qa = malloc((size_t) lenA + 2), *qb = malloc((size_t) lenB + 2);
+	uint64_t *ca = calloc((size_t) ((lenA + 31) >> 5) + 3, 8), *cb = calloc((size_t) ((lenB + 31) >> 5) + 3, 8);
+	int *Na = malloc(sizeof(int) * (size_t) (nNA + 4)), *Nb = malloc(sizeof(int) * (size_t) (nNB + 4));
+	int *bt = calloc((size_t) nT + 2, sizeof(int)), *btr = calloc((size_t) nT + 2, sizeof(int));
+	int *bs = calloc((size_t) nT + 2, sizeof(int)), *be = calloc((size_t) nT + 2, sizeof(int));
+	int rcstate = 0, best = 0, best_r = 0, comp = 0;
+	orient(a, seqA, lenA, NA, nNA, 0, qa, ca, Na);
+	orient(a, seqB, lenB, NB, nNB, 0, qb, cb, Nb);
+	for(int i = 0; i < nT; ++i) {
+		const int tmpl = T[i], at = abs(tmpl);
+		if(tmpl < 0 && !rcstate) {   /* alnfrags.c:1633-1647: both mates are flipped once and stay flipped */
+			orient(a, seqA, lenA, NA, nNA, 1, qa, ca, Na);
+			orient(a, seqB, lenB, NB, nNB, 1, qb, cb, Nb);
+			rcstate = 1;
+		}
+		const int t_len = db->tlen[at];
+		const uint64_t *tseq = db->tseq + db->tseq_off[at];
+		if(!a->ix[at].o) tindex_build(&a->ix[at], tseq, t_len, k);
+		int start = 0, end = 0;
+		for(int m = 0; m < 2; ++m) {
+			const int qlen = m ? lenB : lenA;
+			aln st = kma_score(&a->w, &a->ix[at], tseq, t_len, k, m ? qb : qa, qlen, 0, qlen, m ? cb : ca, m ? Nb : Na, ap->mq, rw, 0);
+			int rs = st.score; double score = 0;
+			if(ap->minlen <= st.len && 0 < rs && ((ap->mrc * qlen <= st.len - st.qGaps) || (ap->mrc * t_len <= st.len - st.tGaps))) {
+				start = st.pos; end = st.pos + st.len - st.tGaps;
+				if(start == 0) rs += Wl;
+				if(end == t_len) rs += Wl;
+				score = 1.0 * rs / st.len;
+			} else rs = 0;
+			const int ok = rs > k && score >= ap->scoreT;
+			if(m == 0) {
+				if(ok) { bt[i] = rs; bs[i] = start; be[i] = end; if(best < rs) best = rs; }
+				else { bt[i] = 0; bs[i] = -1; be[i] = -1; }
+			} else {
+				if(ok) {
+					btr[i] = rs;
+					if(bt[i]) { if(start < bs[i]) bs[i] = start; else be[i] = end; }
+					else { bs[i] = start; be[i] = end; }
+					if(best_r < rs) best_r = rs;
+				} else btr[i] = 0;
+				/* alnfrags.c:1771: the raw second-mate score (0 if its own test failed) joins the first mate's */
+				const int both = rs + bt[i];
+				if(comp < both) comp = both;
+			}
+		}
+	}
+	int ret = 3;
+	if(best || best_r) {
+		const double need = 1.0 * (best + best_r);   /* minFrac == 1 */
+		if(comp && need <= comp + PE) {
+			/* proper pair */
+			const int bestScore = comp + PE;
+			int h = 0;
+			for(int i = 0; i < nT; ++i) if(bt[i] && btr[i]) { out->score[h] = bt[i] + btr[i] + PE; out->tmpl[h] = T[i]; out->start[h] = bs[i]; out->end[h] = be[i]; ++h; }
+			int swapped = 0;
+			if(h && out->tmpl[0] < 0) { for(int i = 0; i < h; ++i) out->tmpl[i] = -out->tmpl[i]; swapped = 1; }
+			else if(rcstate) { out->flagA ^= 48; out->flagB ^= 48; }
+			/* update_Scores_pe, minFrac == 1 */
+			int c = 0;
+			for(int i = 0; i < h; ++i) if(out->score[i] == bestScore) {
+				out->tmpl[c] = out->tmpl[i]; out->start[c] = out->start[i]; out->end[c] = out->end[i]; ++c;
+				if(alignment_scores) alignment_scores[abs(out->tmpl[c - 1])] += (uint64_t) bestScore;
+			}
+			if(c == 1 && uniq_alignment_scores) uniq_alignment_scores[abs(out->tmpl[0])] += (uint64_t) bestScore;
+			out->kind = 1; out->swapped = swapped; out->n_hits = c; out->best = bestScore; out->best_r = bestScore;
+			/* orientation of the two sequences as stored in the frag record */
+			out->rcA = swapped ? rcstate : 0; out->rcB = swapped ? rcstate : 0;
+			ret = 0;
+		} else if(best && best_r) {
+			/* unmated pair (alnfrags.c:1820-1891), restated literally on 1-based arrays incl. the
+			 * `+ end` pointer shift; hits of the first record go to [0, n_hits), of the second after them */
+			int *mt = malloc(sizeof(int) * (size_t) (nT + 2));
+			int *b1 = malloc(sizeof(int) * (size_t) (nT + 2)), *b2 = malloc(sizeof(int) * (size_t) (nT + 2));
+			int *s1 = malloc(sizeof(int) * (size_t) (nT + 2)), *e1 = malloc(sizeof(int) * (size_t) (nT + 2));
+			for(int i = 0; i < nT; ++i) { mt[i + 1] = T[i]; b1[i + 1] = bt[i]; b2[i + 1] = btr[i]; s1[i + 1] = bs[i]; e1[i + 1] = be[i]; }
+			mt[0] = nT; b1[0] = b2[0] = s1[0] = e1[0] = 0;
+			int h = 0, hr = 0, ti = 1, endp = nT, x;
+			const double sc1 = best, sc2 = best_r;
+			while(ti <= endp) {
+				if(sc1 <= b1[ti]) { mt[h] = mt[ti]; b1[h] = b1[ti]; s1[h] = s1[ti]; e1[h] = e1[ti]; ++h; ++ti; }
+				else if(sc2 <= b2[ti]) {
+					x = mt[ti]; mt[ti] = mt[endp]; mt[endp] = x; x = b2[ti]; b2[ti] = b2[endp]; b2[endp] = x;
+					x = s1[ti]; s1[ti] = s1[endp]; s1[endp] = x; x = e1[ti]; e1[ti] = e1[endp]; e1[endp] = x;
+					++hr; --endp;
+				} else ++ti;
+			}
+			int fA = flagA, fB = flagB;
+			if(b1[0] < 0) { for(int i = 0; i < h; ++i) b1[i] = -b1[i]; }
+			else if(rcstate) { fA ^= 16; fB ^= 32; }
+			if(b2[endp] < 0) { for(int i = 0; i < hr; ++i) b2[endp + i] = -b2[endp + i]; }
+			else if(rcstate) { fA ^= 32; fB ^= 16; }
+			if(fA & 2) { fA ^= 2; fB ^= 2; }
+			int c = 0;
+			for(int i = 0; i < h; ++i) if(b1[i] == best) {
+				out->tmpl[c] = mt[i]; out->start[c] = s1[i]; out->end[c] = e1[i]; out->score[c] = best; ++c;
+				if(alignment_scores) alignment_scores[abs(mt[i])] += (uint64_t) best;
+			}
+			if(c == 1 && uniq_alignment_scores) uniq_alignment_scores[abs(out->tmpl[0])] += (uint64_t) best;
+			int c2 = 0;
+			for(int i = 0; i < hr; ++i) if(b2[endp + i] == best_r) {
+				out->tmpl[c + c2] = mt[endp + i]; out->start[c + c2] = s1[endp + i]; out->end[c + c2] = e1[endp + i]; out->score[c + c2] = best_r; ++c2;
+				if(alignment_scores) alignment_scores[abs(mt[endp + i])] += (uint64_t) best_r;
+			}
+			if(c2 == 1 && uniq_alignment_scores) uniq_alignment_scores[abs(out->tmpl[c])] += (uint64_t) best_r;
+			out->kind = 2; out->n_hits = c; out->n_hits_r = c2; out->best = best; out->best_r = best_r; out->flagA = fA; out->flagB = fB;
+			free(mt); free(b1); free(b2); free(s1); free(e1);
+			ret = 0;
+		} else {
+			/* only one record aligned (alnfrags.c:1892-1966) */
+			const int first = best != 0;
+			const int *sc = first ? bt : btr;
+			const int bscore = first ? best : best_r;
+			int h = 0;
+			for(int i = 0; i < nT; ++i) if(sc[i]) { out->score[h] = sc[i]; out->tmpl[h] = T[i]; out->start[h] = bs[i]; out->end[h] = be[i]; ++h; }
+			int fA = flagA, fB = flagB;
+			if(first) {
+				if(h && out->tmpl[0] < 0) { for(int i = 0; i < h; ++i) out->tmpl[i] = -out->tmpl[i]; }
+				else if(rcstate) { fA ^= 16; fB ^= 32; }
+				fA |= 8; fB ^= 4;
+				if(fA & 2) { fA ^= 2; fB ^= 2; }
+			} else {
+				/* the reference tests the sign of a SCORE here (never negative): templates keep their sign */
+				if(rcstate) { fA ^= 32; fB ^= 16; }
+				fB |= 8; fA ^= 4;
+				if(fB & 2) { fA ^= 2; fB ^= 2; }
+			}
+			int c = 0;
+			for(int i = 0; i < h; ++i) if(out->score[i] == bscore) {
+				out->tmpl[c] = out->tmpl[i]; out->start[c] = out->start[i]; out->end[c] = out->end[i]; ++c;
+				if(alignment_scores) alignment_scores[abs(out->tmpl[c - 1])] += (uint64_t) bscore;
+			}
+			if(c == 1 && uniq_alignment_scores) uniq_alignment_scores[abs(out->tmpl[0])] += (uint64_t) bscore;
+			out->kind = first ? 3 : 4; out->n_hits = c; out->best = best; out->best_r = best_r; out->flagA = fA; out->flagB = fB;
+			ret = first ? 2 : 1;
+		}
+	}
+	free(qa); free(qb); free(ca); free(cb); free(Na); free(Nb); free(bt); free(btr); free(bs); free(be);
+	return ret;
+}

@@ -101,6 +101,18 @@ int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_al
                            int32_t *n_hits, int32_t *best_score, int32_t *out_flag,
                            int32_t *ht, int32_t *hs, int32_t *he, int32_t *hscore,
                            uint64_t *alignment_scores, uint64_t *uniq_alignment_scores);
+/* paired end stage 3a (alnFragsPenaltyPE). kind: 0 unmapped, 1 proper pair (hits shared by both mates),
+ * 2 unmated pair, 3 first record only, 4 second record only. Arrays hold nT entries (caller-owned). */
+typedef struct {
+	int kind, swapped, n_hits, best, best_r, flagA, flagB, rcA, rcB;
+	int n_hits_r;              /* kind 2: hits of the second record follow the first record's in the arrays */
+	int *tmpl, *score, *start, *end;
+} orc_pe_out;
+int orc_align_pe(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap,
+                 const uint64_t *seqA, int lenA, const int *NA, int nNA, int flagA,
+                 const uint64_t *seqB, int lenB, const int *NB, int nNB, int flagB,
+                 const int *T, int nT, orc_pe_out *out,
+                 uint64_t *alignment_scores, uint64_t *uniq_alignment_scores);
 void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
                 int band, const orc_rewards *rw, int out[6]);
 

@@ -30,6 +30,12 @@ class PeRec(C.Structure):
                 ("nT", C.c_int), ("T", C.POINTER(C.c_int))]
 
 
+class PeOut(C.Structure):
+    _fields_ = [("kind", C.c_int), ("swapped", C.c_int), ("n_hits", C.c_int), ("best", C.c_int), ("best_r", C.c_int),
+                ("flagA", C.c_int), ("flagB", C.c_int), ("rcA", C.c_int), ("rcB", C.c_int), ("n_hits_r", C.c_int),
+                ("tmpl", C.c_void_p), ("score", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p)]
+
+
 def _build():
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
@@ -60,6 +66,14 @@ def lib():
         L.orc_scan_pe.restype = C.c_int
         L.orc_scan_pe.argtypes = [C.c_void_p, C.POINTER(Rewards), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PeRec * 2), C.c_void_p, C.c_void_p]
+        L.orc_aligner_new.restype = C.c_void_p
+        L.orc_aligner_new.argtypes = [C.c_void_p]
+        L.orc_aligner_free.argtypes = [C.c_void_p]
+        L.orc_align_pe.restype = C.c_int
+        L.orc_align_pe.argtypes = [C.c_void_p, C.POINTER(Rewards), C.POINTER(AlignParams),
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.POINTER(PeOut), C.c_void_p, C.c_void_p]
         L.orc_rc.restype = None
         L.orc_rc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -160,3 +174,39 @@ def rc_packed(seq, length, N):
     rN = np.zeros(len(N) + 2, np.int32)
     lib().orc_rc(_p(s), length, _p(fN), _p(rs), _p(rN))
     return rs[:words], rN[1:1 + len(N)]
+
+
+class OracleAligner:
+    """Stateful aligner (per-template indexes are built lazily and kept)."""
+
+    def __init__(self, odb, minlen=16, mq=0, scoreT=0.5, mrc=0.0):
+        import struct
+        self.odb = odb
+        self.h = lib().orc_aligner_new(odb.h)
+        self.ap = AlignParams(minlen, mq, scoreT, mrc, 1.0)
+        D = struct.unpack("<I", open(odb.prefix + ".comp.b", "rb").read(4))[0]
+        self.alignment_scores = np.zeros(D, np.uint64)
+        self.uniq_alignment_scores = np.zeros(D, np.uint64)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_aligner_free(self.h)
+            self.h = None
+
+    def align_pe(self, seqA, lenA, NA, flagA, seqB, lenB, NB, flagB, T):
+        nT = len(T)
+        arr = [np.zeros(nT + 2, np.int32) for _ in range(4)]
+        out = PeOut()
+        out.tmpl, out.score, out.start, out.end = (a.ctypes.data for a in arr)
+        pad = lambda s: np.ascontiguousarray(np.concatenate([s, np.zeros(2, np.uint64)]))
+        nn = lambda N: np.ascontiguousarray(N if len(N) else np.zeros(1, np.int32), np.int32)
+        sA, sB, nA, nB = pad(seqA), pad(seqB), nn(NA), nn(NB)
+        Tn = np.ascontiguousarray(T, np.int32)
+        ret = lib().orc_align_pe(self.h, C.byref(self.odb.rw), C.byref(self.ap), _p(sA), lenA, _p(nA), len(NA), flagA,
+                                 _p(sB), lenB, _p(nB), len(NB), flagB, _p(Tn), nT, C.byref(out),
+                                 _p(self.alignment_scores), _p(self.uniq_alignment_scores))
+        n = out.n_hits
+        return ret, dict(kind=out.kind, swapped=out.swapped, n_hits=n, best=out.best, best_r=out.best_r,
+                         flagA=out.flagA, flagB=out.flagB, n_hits_r=out.n_hits_r,
+                         tmpl=arr[0][:n + out.n_hits_r].copy(), score=arr[1][:n + out.n_hits_r].copy(),
+                         start=arr[2][:n + out.n_hits_r].copy(), end=arr[3][:n + out.n_hits_r].copy())

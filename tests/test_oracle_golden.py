@@ -131,3 +131,14 @@ def test_oracle_pe_scan_matches_s2_tap_bytes(golden_pe):
 
     got = golden_util.pe_stream_from(golden_pe, pair, single, oracle.rc_packed)
     assert got == golden_pe["s2_bytes"]
+
+
+def test_oracle_pe_align_matches_frag_raw_tap(golden_pe):
+    # stage 3a for `-ipe ... -apm p`: alnFragsPenaltyPE + update_Scores_pe (proper pairs) and alnFragsSE for
+    # the records stage 2 wrote singly; compared line by line with the reference's `-a` tap.
+    import pe_util
+    exp, kinds = pe_util.oracle_pe_lines(golden_pe)
+    tap = pe_util.load_frag_raw_lines("pe")
+    assert len(exp) == len(tap)
+    assert kinds[1] > 500
+    pe_util.compare_lines(exp, tap)
