@@ -174,6 +174,19 @@ int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, cons
 int kmahip_scan_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                        kmahip_pe_recs *out, void *stream);
 
+/* Stage 3a for the records of kmahip_scan_pe_dev (device pointers): alnFragsPE = alnFragsPenaltyPE
+ * (alnfrags.h:68, alnfrags.c:1596-1972) for proper couples (first record with an empty list, second with the
+ * shared candidates), alnFragsSE for records written singly; update_Scores_pe / update_Scores_se
+ * (updatescores.c:300-488). The per-record arrays of `out` have 2 * n_pairs entries; pe_kind[pair] = 0 records
+ * handled singly / nothing, 1 proper pair, 2 unmated pair, 3 first record only, 4 second record only. Hits of a
+ * couple are stored in the SECOND record's slice [R_off[2p+1], ...): kind 1: n_hits shared by both records;
+ * kind 2: the first record's n_hits[2p] hits followed by the second's n_hits[2p+1]; kind 3/4: that record's. */
+int kmahip_align_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                        const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, void *stream);
+/* Stages 2 + 3a for paired reads with host buffers in and out. */
+int kmahip_map_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                  kmahip_pe_recs *recs_out, kmahip_hits *hits_out, int32_t *pe_kind);
+
 /* Stage 3a, single end: alignment score of every (read, candidate) pair,
  * per-read hit selection and ConClave accumulators.  `cands` is the output of
  * kmahip_scan_se_dev on the same `reads` (device pointers). */

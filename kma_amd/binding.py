@@ -95,6 +95,8 @@ def lib():
         L.kmahip_align_get_stats.argtypes = [C.c_void_p, C.POINTER(AlignStats), C.c_void_p]
         L.kmahip_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs)]
         L.kmahip_scan_pe_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs), C.c_void_p]
+        L.kmahip_map_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs),
+                                    C.POINTER(Hits), C.c_void_p]
         L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
         _lib = L
     return _lib
@@ -275,3 +277,34 @@ class KmaHipDB:
             _check(rcode)
             return mate[:n], rc[:n], rc_flag[:n], flag[:n], R_off, T[:R_off[n]]
         raise KmaHipError("scan_pe: output capacity kept overflowing")
+
+    def map_pe(self, batch, exhaustive=0, t_cap=None):
+        """Stages 2 + 3a for interleaved mates -> (mate, rc, rc_flag, flag, R_off, T), hits dict (+ "kind" per pair)"""
+        n = batch.n
+        assert n % 2 == 0
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        mate, rc, rc_flag, flag = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+        R_off = np.zeros(n + 1, np.int64)
+        cap = t_cap or max(1024, 16 * n)
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        D = int(self.info.DB_size)
+        for _ in range(6):
+            T = np.zeros(cap, np.int32)
+            h = dict(n_hits=np.zeros(max(n, 1), np.int32), best_score=np.zeros(max(n, 1), np.int32),
+                     flag=np.zeros(max(n, 1), np.int32), tmpl=np.zeros(cap, np.int32), score=np.zeros(cap, np.int32),
+                     start=np.zeros(cap, np.int32), end=np.zeros(cap, np.int32), kind=np.zeros(max(n // 2, 1), np.int32),
+                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64))
+            out = PeRecs(_p(mate), _p(rc), _p(rc_flag), _p(flag), _p(R_off), _p(T), cap)
+            hs = Hits(_p(h["n_hits"]), _p(h["best_score"]), _p(h["flag"]), _p(h["tmpl"]), _p(h["score"]), _p(h["start"]),
+                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]))
+            rcode = lib().kmahip_map_pe(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.byref(hs), _p(h["kind"]))
+            if rcode == -6:
+                cap = max(cap * 2, int(R_off[n]) + 16)
+                continue
+            _check(rcode)
+            return (mate[:n], rc[:n], rc_flag[:n], flag[:n], R_off, T[:R_off[n]]), h
+        raise KmaHipError("map_pe: output capacity kept overflowing")

@@ -55,6 +55,9 @@ struct AlignArgs {
 	int64_t lanes;
 	int mem_cap;     // MEM slots per lane (arrays hold mem_cap + 1)
 	int ncols;       // DP columns per lane
+	// paired-end mode: the 'reads' of the candidate CSR are stage-2 records (2 per pair)
+	const int32_t *rec_mate, *rec_rc;
+	int pe_mode, Wl, PE;
 	unsigned long long *counters;   // [1] status
 	int stats;
 	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
@@ -616,7 +619,7 @@ __device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, cons
 // handed to KMA_score. Returns +n (forward, n MEMs at [0,n)), -n (reverse) or 0. Rare path: base by base.
 __device__ int anker_rc_comp(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &qf, int *status) {
 	const int k = (int) db.kmersize, q_len = qf.L, cap = L.cap1 - 1;
-	QView qr = qf; qr.rc = 1;
+	QView qr = qf; qr.rc = qf.rc ^ 1;
 	int bestScore = 0, score = 0, score_r = 0, mem_count = 0, tot = 0, plen = 0;
 	for(int rc = 0; rc < 2; ++rc) {
 		const QView &q = rc ? qr : qf;
@@ -812,17 +815,67 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 		const int64_t r = lo;
 		int rs = 0, alen = 0, start = 0, end = 0;
 		double norm = 0.0;
-		const int rcf = A.rc_flag[r];
-		const int q_len = A.len[r];
 		int tmpl_out = A.T[task];
-		if(rcf != 0 && q_len >= k) {
+		// which read and which orientation does record r carry
+		int64_t rd = r;
+		int orient = (A.flag[r] & 16) ? 1 : 0;
+		bool couple = false;
+		if(A.pe_mode) {
+			const int64_t p0 = r & ~1ll;
+			rd = p0 + max(0, A.rec_mate[r]);
+			orient = A.rec_rc[r];
+			couple = (r & 1) && A.rec_mate[p0] >= 0 && A.rec_mate[r] >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
+		}
+		const int rcf = A.rc_flag[r];
+		const int q_len = A.len[rd];
+		const int at = abs(tmpl_out);
+		const int t_len = A.db.tlen[at];
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+		int status = 0;
+		if(couple) {
+			// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate. Both are
+			// flipped once the list reaches its first negative id and stay flipped (:1633-1647).
+			int rcstate = 0;
+			for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
+			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
+			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
+			for(int m = 0; m < 2; ++m) {
+				const int64_t rec = (r & ~1ll) + m;
+				const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
+				QView q;
+				q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
+				q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
+				Aln st = {0, 1, 0, 0, 0, 0};
+				if(q.L >= k) st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+				int sc = st.score, s0 = 0, e0 = 0;
+				double nrm = 0.0;
+				if(A.minlen <= st.len && 0 < sc && ((A.mrc * q.L <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) {
+					s0 = st.pos; e0 = st.pos + st.len - st.tGaps;
+					if(s0 == 0) sc += A.Wl;
+					if(e0 == t_len) sc += A.Wl;
+					nrm = 1.0 * sc / st.len;
+				} else sc = 0;
+				const bool ok = sc > k && nrm >= A.scoreT;
+				if(m == 0) {
+					if(ok) { bt = sc; bs = s0; be = e0; }
+				} else {
+					if(ok) {
+						btr = sc;
+						if(bt) { if(s0 < bs) bs = s0; else be = e0; }
+						else { bs = s0; be = e0; }
+					}
+					raw_b = sc;
+				}
+			}
+			if(status) atomicMax(&A.counters[1], 3ull);
+			A.t_tmpl[task] = raw_b;      // PE tasks: raw second-record score (joins the first in compScore, :1771)
+			A.t_score[task] = bt; A.t_alen[task] = btr; A.t_start[task] = bs; A.t_end[task] = be; A.t_norm[task] = 0.0;
+			continue;
+		}
+		if(rcf != 0 && q_len >= k && (!A.pe_mode || A.rec_mate[r] >= 0)) {
 			QView q;
-			q.w = A.seq + A.seq_off[r]; q.L = q_len; q.rc = (A.flag[r] & 16) ? 1 : 0;
-			q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-			const int at = abs(tmpl_out);
-			const int t_len = A.db.tlen[at];
-			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
-			int status = 0;
+			q.w = A.seq + A.seq_off[rd]; q.L = q_len; q.rc = orient;
+			q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
 			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
 			Aln st = {0, 0, 0, 0, 0, 0};
 			if(rcf > 0) {
@@ -830,7 +883,7 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 			} else {
 				// strand tie: per template strand decision (alnfrags.c:1101-1124)
 				const int side = anker_rc_comp(L, A.db, at, ts, t_len, q, &status);
-				if(side < 0) { q.rc = 1; tmpl_out = -at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, -side, &status); }
+				if(side < 0) { q.rc ^= 1; tmpl_out = -at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, -side, &status); }
 				else if(side > 0) { tmpl_out = at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, side, &status); }
 			}
 			if(status) atomicMax(&A.counters[1], 3ull);
@@ -859,7 +912,116 @@ struct ReduceArgs {
 	double scoreT;
 	int32_t *n_hits, *best_score, *out_flag, *h_tmpl, *h_score, *h_start, *h_end;
 	unsigned long long *alignment_scores, *uniq_alignment_scores;
+	// paired-end mode
+	const int32_t *rec_mate;
+	int pe_mode, PE;
+	int32_t *pe_kind;     // per pair: 0 none / records handled singly, 1 proper pair, 2 unmated, 3 first only, 4 second only
+	int32_t *t_score_w, *t_alen_w, *t_start_w, *t_end_w, *t_tmpl_w;   // writable views (unmated shuffle)
 };
+
+// per pair: the tail of alnFragsPenaltyPE (alnfrags.c:1777-1970) + update_Scores_pe / update_Scores_se with
+// minFrac == 1. Hits of the pair are written into the second record's slice [T_off[p0+1], ...): proper pair:
+// n shared hits; unmated: the first record's hits followed by the second's; single: that record's hits.
+__device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
+	const int64_t o = R.T_off[p0 + 1], nT = R.T_off[p0 + 2] - o;
+	int best = 0, best_r = 0, comp = 0, rcstate = 0;
+	for(int64_t i = 0; i < nT; ++i) {
+		best = max(best, R.t_score[o + i]); best_r = max(best_r, R.t_alen[o + i]);
+		comp = max(comp, R.t_tmpl[o + i] + R.t_score[o + i]);
+		if(R.T[o + i] < 0) rcstate = 1;
+	}
+	int fA = R.flag[p0], fB = R.flag[p0 + 1], kind = 0, nA = 0, nB = 0, sA = 0, sB = 0;
+	if(best || best_r) {
+		if(comp && 1.0 * (best + best_r) <= comp + R.PE) {
+			const int bestScore = comp + R.PE;
+			int first = 0, h = 0, c = 0;
+			for(int64_t i = 0; i < nT; ++i) if(R.t_score[o + i] && R.t_alen[o + i]) { if(!h) first = R.T[o + i]; ++h; }
+			const bool swapped = h && first < 0;
+			if(!swapped && rcstate) { fA ^= 48; fB ^= 48; }
+			for(int64_t i = 0; i < nT; ++i) {
+				const int bt = R.t_score[o + i], btr = R.t_alen[o + i];
+				if(bt && btr && bt + btr + R.PE == bestScore) {
+					const int tm = swapped ? -R.T[o + i] : R.T[o + i];
+					R.h_tmpl[o + c] = tm; R.h_score[o + c] = bestScore; R.h_start[o + c] = R.t_start[o + i]; R.h_end[o + c] = R.t_end[o + i];
+					if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) bestScore);
+					++c;
+				}
+			}
+			if(c == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o])], (unsigned long long) bestScore);
+			kind = 1; nA = nB = c; sA = sB = bestScore;
+		} else if(best && best_r) {
+			// unmated pair, alnfrags.c:1820-1891, restated literally (incl. that the first record's score array is
+			// not part of the exchange and the `+ end` pointer shift). Inputs are 1-based views X1(i) = X[o + i - 1]
+			// of the task arrays; outputs go to the hit arrays, which the reference overlays on the same memory
+			// without ever reading a slot it has overwritten.
+			int32_t *mt = R.t_tmpl_w + o, *b2 = R.t_alen_w + o, *s1 = R.t_start_w + o, *e1 = R.t_end_w + o;
+			const int32_t *b1 = R.t_score + o;
+			for(int64_t i = 0; i < nT; ++i) mt[i] = R.T[o + i];
+			int h = 0, hr = 0, ti = 1, endp = (int) nT;
+			while(ti <= endp) {
+				if(best <= b1[ti - 1]) {
+					R.h_tmpl[o + h] = mt[ti - 1]; R.h_score[o + h] = b1[ti - 1]; R.h_start[o + h] = s1[ti - 1]; R.h_end[o + h] = e1[ti - 1];
+					++h; ++ti;
+				} else if(best_r <= b2[ti - 1]) {
+					int x;
+					x = mt[ti - 1]; mt[ti - 1] = mt[endp - 1]; mt[endp - 1] = x;
+					x = b2[ti - 1]; b2[ti - 1] = b2[endp - 1]; b2[endp - 1] = x;
+					x = s1[ti - 1]; s1[ti - 1] = s1[endp - 1]; s1[endp - 1] = x;
+					x = e1[ti - 1]; e1[ti - 1] = e1[endp - 1]; e1[endp - 1] = x;
+					++hr; --endp;
+				} else ++ti;
+			}
+			if(rcstate) { fA ^= 48; fB ^= 48; }     // ^16 ^32 on both (:1863-1876; the sign tests there look at scores)
+			if(fA & 2) { fA ^= 2; fB ^= 2; }
+			int c = 0, c2 = 0;
+			for(int i = 0; i < h; ++i) if(R.h_score[o + i] == best) {
+				R.h_tmpl[o + c] = R.h_tmpl[o + i]; R.h_start[o + c] = R.h_start[o + i]; R.h_end[o + c] = R.h_end[o + i]; R.h_score[o + c] = best;
+				if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(R.h_tmpl[o + c])], (unsigned long long) best);
+				++c;
+			}
+			if(c == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o])], (unsigned long long) best);
+			for(int i = 0; i < hr; ++i) {
+				const int pos = endp + i;            // 1-based; position 0 is the reference's unused slot
+				if(pos < 1 || pos > nT || b2[pos - 1] != best_r) continue;
+				R.h_tmpl[o + c + c2] = mt[pos - 1]; R.h_start[o + c + c2] = s1[pos - 1]; R.h_end[o + c + c2] = e1[pos - 1]; R.h_score[o + c + c2] = best_r;
+				if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(mt[pos - 1])], (unsigned long long) best_r);
+				++c2;
+			}
+			if(c2 == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o + c])], (unsigned long long) best_r);
+			kind = 2; nA = c; nB = c2; sA = best; sB = best_r;
+		} else {
+			const bool first = best != 0;
+			const int bscore = first ? best : best_r;
+			int h = 0, c = 0, t0 = 0;
+			for(int64_t i = 0; i < nT; ++i) { const int sc = first ? R.t_score[o + i] : R.t_alen[o + i]; if(sc) { if(!h) t0 = R.T[o + i]; ++h; } }
+			bool neg = false;
+			if(first) {
+				if(h && t0 < 0) neg = true; else if(rcstate) { fA ^= 16; fB ^= 32; }
+				fA |= 8; fB ^= 4;
+				if(fA & 2) { fA ^= 2; fB ^= 2; }
+			} else {
+				if(rcstate) { fA ^= 32; fB ^= 16; }
+				fB |= 8; fA ^= 4;
+				if(fB & 2) { fA ^= 2; fB ^= 2; }
+			}
+			for(int64_t i = 0; i < nT; ++i) {
+				const int sc = first ? R.t_score[o + i] : R.t_alen[o + i];
+				if(sc && sc == bscore) {
+					const int tm = neg ? -R.T[o + i] : R.T[o + i];
+					R.h_tmpl[o + c] = tm; R.h_score[o + c] = bscore; R.h_start[o + c] = R.t_start[o + i]; R.h_end[o + c] = R.t_end[o + i];
+					if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) bscore);
+					++c;
+				}
+			}
+			if(c == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o])], (unsigned long long) bscore);
+			kind = first ? 3 : 4;
+			if(first) { nA = c; sA = best; } else { nB = c; sB = best_r; }
+		}
+	}
+	R.pe_kind[p0 >> 1] = kind;
+	R.n_hits[p0] = nA; R.n_hits[p0 + 1] = nB; R.best_score[p0] = sA; R.best_score[p0 + 1] = sB;
+	R.out_flag[p0] = fA; R.out_flag[p0 + 1] = fB;
+}
 
 // per read: hit filter of alnFragsSE (alnfrags.c:1165-1215) + update_Scores with
 // minFrac == 1.0 (updatescores.c:217-234, :275-277)
@@ -868,6 +1030,16 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 	if(r >= R.n_reads) return;
 	const int64_t o = R.T_off[r], e = R.T_off[r + 1];
 	int nh = 0, bestRead = 0, fl = R.flag[r];
+	if(R.pe_mode) {
+		const int64_t p0 = r & ~1ll;
+		const bool couple = R.rec_mate[p0] >= 0 && R.rec_mate[p0 + 1] >= 0 && R.T_off[p0 + 1] == R.T_off[p0];
+		if(couple) {
+			if(r & 1) reduce_couple(R, p0);
+			return;
+		}
+		if(!(r & 1)) R.pe_kind[r >> 1] = 0;
+		if(R.rec_mate[r] < 0) { R.n_hits[r] = 0; R.best_score[r] = 0; R.out_flag[r] = fl; return; }
+	}
 	if(e > o) {
 		{
 			double bestScore = 0.0;
@@ -904,8 +1076,10 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 
 } // namespace
 
-int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
-                           const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
+// common launcher. SE: one record per read. PE (rec_mate != null): two records per pair over interleaved mates.
+static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                        const int32_t *rec_mate, const int32_t *rec_rc, int32_t *pe_kind,
+                        const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
 	if(n < 0 || !cands || !out || !p) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
 	if(!db->dev.tpos_slots) { kmahip_set_error("index has no .length.b/.seq.b: stage 3a unavailable"); return KMAHIP_EINVAL; }
@@ -948,6 +1122,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	int32_t *ti = (int32_t *) (norm + tasks_cap);
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
+	A.rec_mate = rec_mate; A.rec_rc = rec_rc; A.pe_mode = rec_mate != nullptr; A.Wl = -p->rw.Wl; A.PE = p->rw.PE;
 	A.counters = ws->counters;
 	A.stats = ws->stats_on;
 	A.ablate = 0;
@@ -973,6 +1148,8 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
+	R.rec_mate = rec_mate; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
+	R.t_score_w = A.t_score; R.t_alen_w = A.t_alen; R.t_start_w = A.t_start; R.t_end_w = A.t_end; R.t_tmpl_w = A.t_tmpl;
 	hipLaunchKernelGGL(reduce_reads_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, R);
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
@@ -994,3 +1171,16 @@ extern "C" int kmahip_diag_hist(unsigned long long *out256, int reset) {
 	return 0;
 }
 #endif
+
+int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                           const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
+	return launch_align(db, ws, reads, cands, nullptr, nullptr, nullptr, p, out, stream);
+}
+
+int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                           const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, hipStream_t stream) {
+	if(!recs || !pe_kind || (reads->n_reads & 1)) { kmahip_set_error("paired align needs interleaved mates and a kind array"); return KMAHIP_EINVAL; }
+	kmahip_cands c;
+	c.rc_flag = recs->rc_flag; c.flag = recs->flag; c.T_off = recs->R_off; c.T = recs->T; c.T_cap = recs->T_cap;
+	return launch_align(db, ws, reads, &c, recs->mate, recs->rc, pe_kind, p, out, stream);
+}

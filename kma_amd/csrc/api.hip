@@ -243,8 +243,14 @@ extern "C" int kmahip_scan_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_rea
 	return kmahip_launch_scan_pe(db, ws, reads, p, out, (hipStream_t) stream);
 }
 
-extern "C" int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, kmahip_pe_recs *out) {
-	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+extern "C" int kmahip_align_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                                   const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, void *stream) {
+	if(!db || !ws || !reads || !recs || !p || !out || !pe_kind) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_launch_align_pe(db, ws, reads, recs, p, out, pe_kind, (hipStream_t) stream);
+}
+
+static int run_host_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, kmahip_pe_recs *out,
+                       kmahip_hits *hits, int32_t *pe_kind) {
 	const int64_t n = reads->n_reads;
 	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
 	int rc;
@@ -282,5 +288,61 @@ extern "C" int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	const int64_t total = out->R_off[n];
 	if(total > out->T_cap) { kmahip_set_error("T_cap %lld too small, need %lld", (long long) out->T_cap, (long long) total); return KMAHIP_EOVERFLOW; }
 	if(total) HIP_TRY(hipMemcpy(out->T, o.T, (size_t) total * 4, hipMemcpyDeviceToHost));
-	return KMAHIP_OK;
+	if(!hits || n == 0) return KMAHIP_OK;
+	// stage 3a on the staged batch
+	const size_t D = db->info.DB_size;
+	const size_t hb = (size_t) n * 16 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
+	void *dh = nullptr;
+	HIP_TRY(hipMalloc(&dh, hb));
+	HIP_TRY(hipMemsetAsync(dh, 0, hb, s));
+	kmahip_hits h;
+	uint64_t *u = (uint64_t *) dh;
+	h.alignment_scores = u; h.uniq_alignment_scores = u + D;
+	int32_t *hp = (int32_t *) (u + 2 * D);
+	h.n_hits = hp; h.best_score = hp + n; h.flag = hp + 2 * n;
+	int32_t *dkind = hp + 3 * n;
+	h.tmpl = hp + 4 * n; h.score = h.tmpl + total + 1; h.start = h.score + total + 1; h.end = h.start + total + 1;
+	kmahip_reads d2 = d;
+	rc = kmahip_launch_align_pe(db, ws, &d2, &o, p, &h, dkind, s);
+	if(!rc) {
+		hipError_t e = hipStreamSynchronize(s);
+		if(e != hipSuccess) { kmahip_set_error("align kernels failed: %s", hipGetErrorString(e)); rc = KMAHIP_EDEVICE; }
+	}
+	if(!rc) {
+		(void) hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost);
+		if(c[1]) (void) hipMemset(ws->counters + 1, 0, sizeof(unsigned long long));
+		if(c[1] == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); rc = KMAHIP_EOVERFLOW; }
+	}
+	if(!rc) {
+		(void) hipMemcpy(hits->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(hits->best_score, h.best_score, (size_t) n * 4, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(hits->flag, h.flag, (size_t) n * 4, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(pe_kind, dkind, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost);
+		if(total) {
+			(void) hipMemcpy(hits->tmpl, h.tmpl, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->score, h.score, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->start, h.start, (size_t) total * 4, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hits->end, h.end, (size_t) total * 4, hipMemcpyDeviceToHost);
+		}
+		std::vector<uint64_t> acc(2 * D);
+		(void) hipMemcpy(acc.data(), u, 2 * D * 8, hipMemcpyDeviceToHost);
+		if(hits->alignment_scores) for(size_t i = 0; i < D; ++i) hits->alignment_scores[i] += acc[i];
+		if(hits->uniq_alignment_scores) for(size_t i = 0; i < D; ++i) hits->uniq_alignment_scores[i] += acc[D + i];
+		hipError_t e = hipGetLastError();
+		if(e != hipSuccess) { kmahip_set_error("copy back failed: %s", hipGetErrorString(e)); rc = KMAHIP_EDEVICE; }
+	}
+	(void) hipFree(dh);
+	return rc;
+}
+
+extern "C" int kmahip_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, kmahip_pe_recs *out) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return run_host_pe(db, ws, reads, p, out, nullptr, nullptr);
+}
+
+extern "C" int kmahip_map_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                             kmahip_pe_recs *recs_out, kmahip_hits *hits_out, int32_t *pe_kind) {
+	if(!db || !ws || !reads || !p || !recs_out || !hits_out || !pe_kind) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(reads->max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set"); return KMAHIP_EINVAL; }
+	return run_host_pe(db, ws, reads, p, recs_out, hits_out, pe_kind);
 }

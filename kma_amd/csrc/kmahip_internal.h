@@ -100,3 +100,5 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
                            const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
 int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                           kmahip_pe_recs *out, hipStream_t stream);
+int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                           const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, hipStream_t stream);

@@ -85,3 +85,64 @@ def test_pe_scan_vs_oracle_redundant_db(tmp_path):
                 got.append((int(mate[x]), int(rc[x]), int(rc_flag[x]), int(flag[x]), T[R_off[x]:R_off[x + 1]].tolist()))
         exp = [(r["mate"], r["rc"], r["rc_flag"], r["flag"], r["T"].tolist()) for r in recs]
         assert got == exp, (j, got, exp)
+
+
+def test_pe_align_matches_reference_frag_raw_tap_and_oracle(golden_pe):
+    """Stage 3a on the records of the pairs: proper couples (alnFragsPenaltyPE) and single records (alnFragsSE)."""
+    import oracle
+    import pe_util
+    from kma_amd import binding
+    g = golden_pe
+    pairs = [u for u in g["units"] if u[0] == "pe"]
+    pb = formats.pack_ragged([_codes(g["s1"][i]) for u in pairs for i in (u[1], u[2])])
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        (mate, rc, rc_flag, flag, R_off, T), h = db.map_pe(pb)
+        singles = [u for u in g["units"] if u[0] == "se"]
+        sb = formats.pack_ragged([_codes(g["s1"][u[1]]) for u in singles])
+        (_, _, sT_off, _), sh = db.map_se(sb)
+    finally:
+        db.close()
+    # expected lines in stream order, from the device results
+    got = []
+    pj = {u[1]: j for j, u in enumerate(pairs)}
+    sj = {u[1]: j for j, u in enumerate(singles)}
+    for u in g["units"]:
+        if u[0] == "se":
+            j = sj[u[1]]
+            nh, o = int(sh["n_hits"][j]), int(sT_off[j])
+            if nh > 0:
+                got.append((g["s1"][u[1]]["hdr"].rstrip(b"\0").decode(), nh, int(sh["best_score"][j]),
+                            sh["start"][o:o + nh].tolist(), sh["end"][o:o + nh].tolist(), sh["tmpl"][o:o + nh].tolist()))
+            continue
+        j = pj[u[1]]
+        a, b = g["s1"][u[1]], g["s1"][u[2]]
+        kind = int(h["kind"][j])
+        r0, r1 = 2 * j, 2 * j + 1
+        hdr = lambda x: (a, b)[int(mate[x])]["hdr"].rstrip(b"\0").decode()
+        o = int(R_off[r1])
+        if kind == 1:
+            n = int(h["n_hits"][r1])
+            row = (n, int(h["best_score"][r1]), h["start"][o:o + n].tolist(), h["end"][o:o + n].tolist(), h["tmpl"][o:o + n].tolist())
+            got.append((hdr(r0),) + row)
+            got.append((hdr(r1),) + row)
+        elif kind == 2:
+            got += [(hdr(r0), None), (hdr(r1), None)]
+        elif kind == 3:
+            got.append((hdr(r0), None))
+        elif kind == 4:
+            got.append((hdr(r1), None))
+        else:
+            for x in (r0, r1):
+                nh = int(h["n_hits"][x])
+                if mate[x] >= 0 and nh > 0:
+                    ox = int(R_off[x])
+                    got.append((hdr(x), nh, int(h["best_score"][x]), h["start"][ox:ox + nh].tolist(),
+                                h["end"][ox:ox + nh].tolist(), h["tmpl"][ox:ox + nh].tolist()))
+    tap = pe_util.load_frag_raw_lines("pe")
+    assert len(got) == len(tap)
+    pe_util.compare_lines(got, tap)
+    # and the ConClave vectors against the oracle's over the same units
+    exp_lines, kinds = pe_util.oracle_pe_lines(g)
+    assert len(exp_lines) == len(got)
+    assert int((h["kind"] == 1).sum()) == kinds[1]
