@@ -18,6 +18,7 @@
 // walk's quirk that a gap run ends on the first cell with EITHER may-open bit.
 #include "kmahip_internal.h"
 #include <cstdlib>
+#include <climits>
 
 #ifdef KMAHIP_DIAG
 __device__ unsigned long long *g_diag_hist = nullptr;
@@ -172,6 +173,9 @@ struct Lane {
 	const int *d;   // 25 ints in LDS
 	int M, MM, U, W1;
 	uint32_t *wide;            // this wave's LDS row slots (WSLOTS x 4 planes x WCOLS words)
+	int *queue;                // this wave's deferred wide-DP queue in LDS: [0] = count, entries of QENT ints from [1]
+	int q_at, q_mate;          // context of the kma_score call being run (template id, mate slot) for queue entries
+	int64_t q_rd;              // read index of the query being aligned
 	int ablate;
 	int diag_uniform;          // d[0][0] == d[1][1] == d[2][2] == d[3][3]: a MEM (never holds an N) scores span * d[0][0]
 	unsigned long long *cnt;   // work counters (stats launches only): [3] lookups [4] MEM bases [5] DP cells [6] tasks
@@ -184,6 +188,10 @@ struct Lane {
 #define ROWTD(L, n) (L).s64[((int64_t) (n)) * (L).lanes]
 #define ROWTP(L, n) (L).s64[((int64_t) ((L).ncols + (n))) * (L).lanes]
 
+constexpr int QCAP = 8;             // deferred wide problems (17..63 columns) per wave and task round
+constexpr int QCAPN = 20;           // deferred narrow problems (2..16 columns)
+constexpr int QENT = 12;            // ints per queue entry
+constexpr int TBUF = 1024;          // staged template bases per cooperative problem
 constexpr int WCOLS = 64;           // LDS row slots for "wide" problems: 17..63 query columns
 constexpr int WSLOTS = 2;           // slots per wave
 
@@ -296,79 +304,48 @@ __device__ Aln nw_full(const R r, const Lane &L, const uint64_t *ts, int tlen_to
 	return aln_from<R::SH>(r.D(0), (uint64_t) r.TD(0));
 }
 
-// NW_score for narrow problems (q_len <= NC, t_len + q_len < 1000): the whole DP row lives in registers
-// (static indices after full unrolling), the query codes in one 64-bit window, walk counters in 10-bit fields.
-// No memory traffic inside the cell loop except the per-row d[][] reads from LDS.
-template <int NC>
-__device__ Aln nw_full_reg(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k,
-                           int t_s, int t_e, int q_s, int q_e) {
+// NW_score with a single query column (the 1 x 1 gap between two MEMs split by a mismatch is by far the most
+// common DP problem): same recurrences as nw_full, all state in scalars.
+__device__ Aln nw_col1(const Lane &L, const uint64_t *ts, int tlen_total, const QView &q, int k, int t_s, int t_e, int q_s) {
 	const int U = L.U, W1 = L.W1;
 	int t_len = t_e - t_s;
-	const int q_len = q_e - q_s;
 	if(t_len < 0) t_len += tlen_total;
-	if(t_len == 0 || q_len == 0) return nw_degenerate(t_len, q_len, U, W1);
 	const uint32_t MA = 1u, TG = 1u << 10, QG = 1u << 20;
-	const int low = (t_len + q_len) * (L.MM + U + W1);
-	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
-	// query codes of columns 0..q_len-1: 2-bit window + N mask
-	const uint64_t qw = qwin(q, q_s);
-	uint32_t nmask = 0;
-	for(int i = 1; i <= q.nN; ++i) { const int p = qN_at(q, i) - q_s; if(0 <= p && p < NC) nmask |= 1u << p; }
-	int D[NC], P[NC];
-	uint32_t TD[NC], TP[NC];
-#pragma unroll
-	for(int c = 0; c < NC; ++c) {
-		if(k == 2) { D[c] = 0; TD[c] = 0; }
-		else { D[c] = W1 + (q_len - 1 - c) * U; TD[c] = TG * (uint32_t) max(0, q_len - c); }
-		P[c] = low; TP[c] = 0;
-	}
-	int best = low, Db_prev = 0;
-	uint32_t bestTD = 0, TDb_prev = 0;
+	const int low = (t_len + 1) * (L.MM + U + W1);
+	if(L.cnt) atomicAdd(&L.cnt[5], (unsigned long long) t_len);
+	const int qc = qn(q, q_s);
+	// boundary row m = t_len: column 0 and the boundary column 1
+	int D = (k == 2) ? 0 : W1, P = low, Db = 0;
+	uint32_t TD = (k == 2) ? 0u : TG, TP = 0, TDb = 0;
+	int best = low;
+	uint32_t bestTD = 0;
 	int npos = t_e - 1;
-	if(npos < 0) npos = tlen_total - 1;
-	int tcode = tn(ts, npos);
-	for(int m = t_len - 1; m >= 0; --m) {
-		const int *drow = L.d + 5 * tcode;
-		// next row's template base: issue the load now, consume after this row
-		--npos;
+	for(int m = t_len - 1; m >= 0; --m, --npos) {
 		if(npos < 0) npos = tlen_total - 1;
-		const int tnext = (m > 0) ? tn(ts, npos) : 0;
-		int diagD = Db_prev, Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U), Qprev = low;
-		uint32_t diagTD = TDb_prev, TDright = (0 < k) ? 0u : QG * (uint32_t) (t_len - m), TQright = 0;
-		Db_prev = Dright; TDb_prev = TDright;
-#pragma unroll
-		for(int c = NC - 1; c >= 0; --c) {
-			if(c < q_len) {
-				const int qc = ((nmask >> c) & 1u) ? 4 : (int) ((qw >> (62 - 2 * c)) & 3ull);
-				const int Dp = D[c], Pp = P[c];
-				const uint32_t TDp = TD[c], TPp = TP[c];
-				int Q = Dright + W1, Pn = Dp + W1, Dn, mv;
-				bool ob = false;
-				if(Q < Pn) { Dn = Pn; mv = 4; } else { Dn = Q; mv = 2; }
-				int x = Qprev + U;
-				if(Q < x) { Q = x; if(Dn <= x) { Dn = x; mv = 3; } } else ob = true;
-				x = Pp + U;
-				if(Pn < x) { Pn = x; if(Dn <= x) { Dn = x; mv = 5; } } else ob = true;
-				x = diagD + drow[qc];
-				if(Dn <= x) { Dn = x; mv = 1; }
-				const uint32_t TQ = TG + (ob ? TDright : TQright);
-				const uint32_t TPn = QG + (ob ? TDp : TPp);
-				const uint32_t TDn = (mv == 1) ? (MA + diagTD) : (mv >= 4 ? TPn : TQ);
-				D[c] = Dn; P[c] = Pn; TD[c] = TDn; TP[c] = TPn;
-				diagD = Dp; diagTD = TDp; Dright = Dn; TDright = TDn; TQright = TQ; Qprev = Q;
-			}
-		}
-		if(k < 0 && best < Dright) { best = Dright; bestTD = TDright; }
-		tcode = tnext;
+		const int *drow = L.d + 5 * tn(ts, npos);
+		const int Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+		const uint32_t TDright = (0 < k) ? 0u : QG * (uint32_t) (t_len - m);
+		int Q = Dright + W1, Pn = D + W1, Dn, mv;
+		bool ob = false;
+		if(Q < Pn) { Dn = Pn; mv = 4; } else { Dn = Q; mv = 2; }
+		int x = low + U;
+		if(Q < x) { Q = x; if(Dn <= x) { Dn = x; mv = 3; } } else ob = true;
+		x = P + U;
+		if(Pn < x) { Pn = x; if(Dn <= x) { Dn = x; mv = 5; } } else ob = true;
+		x = Db + drow[qc];
+		if(Dn <= x) { Dn = x; mv = 1; }
+		const uint32_t TQ = TG + (ob ? TDright : 0u);
+		const uint32_t TPn = QG + (ob ? TD : TP);
+		const uint32_t TDn = (mv == 1) ? (MA + TDb) : (mv >= 4 ? TPn : TQ);
+		Db = Dright; TDb = TDright;
+		D = Dn; P = Pn; TD = TDn; TP = TPn;
+		if(k < 0 && best < D) { best = D; bestTD = TD; }
 	}
 	if(k < 0) {
-		if(k == -2) {
-#pragma unroll
-			for(int c = 0; c < NC; ++c) if(c < q_len && best <= D[c]) { best = D[c]; bestTD = TD[c]; }
-		}
+		if(k == -2 && best <= D) { best = D; bestTD = TD; }
 		return aln_from<10>(best, (uint64_t) bestTD);
 	}
-	return aln_from<10>(D[0], (uint64_t) TD[0]);
+	return aln_from<10>(D, (uint64_t) TD);
 }
 
 // NW_band_score, nw.c:892-1188. Column n of row m is column n-1 of row m+1.
@@ -479,9 +456,26 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 	}
 #endif
 	if(q_e - q_s <= band || tspan <= band) {
-		if(q_e - q_s <= 16 && tspan + (q_e - q_s) < 1000) return nw_full_reg<16>(L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
+		const int ql = q_e - q_s;
+		if(ql == 0 || tspan == 0) return nw_degenerate(tspan, ql, L.U, L.W1);      // nw.c:662-684
+		if(ql == 1 && tspan < 998) return nw_col1(L, ts, t_len, q, k, t_s, t_e, q_s);
+		if(L.queue && ql < WCOLS && tspan + ql < 1000) {
+			// The other small problems are handed to the whole wave (nw_coop, run after every lane has finished its
+			// own work): a lane walking a DP alone keeps 63 lanes idle at ~10^2 cycles per cell. Results are only
+			// ever summed into the alignment statistics, so the caller goes on with zeroes.
+			const bool narrow = ql <= 16 && tspan < TBUF / 4;
+			int *qu = narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
+			const int slot = atomicAdd(&qu[0], 1);
+			if(slot < (narrow ? QCAPN : QCAP)) {
+				int *e = qu + 1 + slot * QENT;
+				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
+				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = (k < 0) ? 1 : 0;
+				Aln z = {0, 0, 0, 0, 0, 0};
+				return z;
+			}
+		}
 		if(q_e - q_s < WCOLS && tspan + (q_e - q_s) < 1000) {
-			// ~1 % of the tasks: the row goes to one of the wave's LDS slots; the lanes of this wave that
+			// queue full (or deferral off): the row goes to one of the wave's LDS slots; the lanes of this wave that
 			// are here together take turns, WSLOTS at a time (they run in lock step anyway)
 			const unsigned long long here = __ballot(1);
 			const int rank = __popcll(here & ((1ull << (threadIdx.x & 63)) - 1ull));
@@ -501,6 +495,108 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 		return nw_full(gr, L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
 	}
 	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
+}
+
+// Wave-cooperative NW_score for deferred problems: lane n of a W-lane segment owns query column n and the segment
+// sweeps the anti-diagonals, so t_len * q_len cells cost t_len + q_len - 1 steps. W = 64: one problem of 17..63
+// columns per call; W = 16: four problems of 2..16 columns side by side. Same recurrences, tie rules and walk
+// counters as nw_full; neighbours come by shuffles (cell (m, n+1) from lane n+1's last step, (m+1, n+1) from the
+// step before that). All 64 lanes call this; segment g solves entry `first + g` (if < count) and its lane 0
+// overwrites the entry with the result: e[2..6] = score, len, match, tGaps, qGaps.
+template <int W>
+__device__ void nw_coop(const Lane &L, const DevDB &db, const AlignArgs &A, int *qu, int first, int count, uint8_t *tbuf_wave) {
+	constexpr int G = 64 / W;
+	const int lane = threadIdx.x & 63, n = lane & (W - 1), g = lane / W;
+	const bool live = first + g < count;
+	int *e = qu + 1 + (live ? first + g : first) * QENT;
+	uint8_t *tbuf = tbuf_wave + g * (TBUF / G);
+	const int k = e[2], t_s = e[3], t_e = e[4], q_s = e[5], q_e = e[6], at = e[7];
+	const int64_t rd = ((int64_t) e[9] << 32) | (uint32_t) e[8];
+	const int tlen_total = db.tlen[at];
+	const uint64_t *ts = db.tseq + db.tseq_off[at];
+	int t_len = t_e - t_s;
+	if(t_len < 0) t_len += tlen_total;
+	const int q_len = q_e - q_s;
+	const int U = L.U, W1 = L.W1;
+	const uint32_t MA = 1u, TG = 1u << 10, QG = 1u << 20;
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(L.cnt && live && n == 0) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
+	// template bases of rows 0..t_len-1 (row m = position t_s + m, circular)
+	if(live) for(int i = n; i < t_len; i += W) {
+		int pos = t_s + i;
+		if(pos >= tlen_total) pos -= tlen_total;
+		tbuf[i] = (uint8_t) tn(ts, pos);
+	}
+	QView q;
+	q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = e[10];
+	q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+	const bool col = live && n < q_len;
+	const int qc = col ? qn(q, q_s + n) : 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	// state: `last` = the row this lane computed most recently (start: boundary row m = t_len), `before` = the row before it
+	int lD, lP = low, lQ = low, bD = 0;
+	uint32_t lTD, lTP = 0, lTQ = 0, bTD = 0;
+	if(k == 2) { lD = 0; lTD = 0; } else { lD = W1 + (q_len - 1 - n) * U; lTD = TG * (uint32_t) max(0, q_len - n); }
+	int best = low;
+	uint32_t bestTD = 0;
+	int steps = live ? t_len + q_len - 1 : 0;
+	for(int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
+	for(int d = 0; d < steps; ++d) {
+		int rD = __shfl_down(lD, 1, W), rQ = __shfl_down(lQ, 1, W), dD = __shfl_down(bD, 1, W);
+		uint32_t rTD = __shfl_down(lTD, 1, W), rTQ = __shfl_down(lTQ, 1, W), dTD = __shfl_down(bTD, 1, W);
+		const int i = d - (q_len - 1 - n);
+		if(col && i >= 0 && i < t_len) {
+			const int m = t_len - 1 - i;
+			if(n == q_len - 1) {
+				// boundary column q_len (nw.c:703-750, :757)
+				rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+				rTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - m);
+				rTQ = 0; rQ = low;
+				if(m + 1 == t_len) { dD = 0; dTD = 0; }
+				else { dD = (0 < k) ? 0 : (W1 + (t_len - 2 - m) * U); dTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - 1 - m); }
+			}
+			const int *drow = L.d + 5 * (int) tbuf[m];
+			int Q = rD + W1, P = lD + W1, D, mv;
+			bool ob = false;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = rQ + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
+			x = lP + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
+			x = dD + drow[qc];
+			if(D <= x) { D = x; mv = 1; }
+			const uint32_t TQ = TG + (ob ? rTD : rTQ);
+			const uint32_t TP = QG + (ob ? lTD : lTP);
+			const uint32_t TD = (mv == 1) ? (MA + dTD) : (mv >= 4 ? TP : TQ);
+			bD = lD; bTD = lTD;
+			lD = D; lP = P; lTD = TD; lTP = TP; lQ = Q; lTQ = TQ;
+			if(n == 0 && k < 0 && best < D) { best = D; bestTD = TD; }
+		}
+	}
+	// result selection (nw.c:830-845), per segment
+	const int seg0 = g * W;
+	int score;
+	uint32_t st;
+	if(k < 0) {
+		score = __shfl(best, seg0); st = __shfl(bestTD, seg0);
+	} else {
+		score = __shfl(lD, seg0); st = __shfl(lTD, seg0);
+	}
+	{
+		// k == -2: for n ascending: if(score <= D[0][n]) take it -> the largest n holding the row maximum, if it is >= score
+		int mx = col ? lD : INT_MIN;
+		for(int o = W / 2; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, W));
+		const unsigned long long who = __ballot(col && lD == mx);
+		const unsigned long long mine = (W == 64) ? who : ((who >> seg0) & ((1ull << (W & 63)) - 1ull));
+		const int src = seg0 + (mine ? 63 - __clzll((long long) mine) : 0);
+		const uint32_t stn = __shfl(lTD, src);
+		if(k == -2 && mx >= score) { score = mx; st = stn; }
+	}
+	if(live && n == 0) {
+		const Aln r = aln_from<10>(score, (uint64_t) st);
+		e[2] = r.score; e[3] = r.len; e[4] = r.match; e[5] = r.tGaps; e[6] = r.qGaps;
+	}
 }
 
 // heuristic substitution model of chain.c (end / link / start terms)
@@ -792,64 +888,132 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 	return S;
 }
 
-__global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A) {
+__global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
 	__shared__ uint32_t s_wide[(ATHREADS / 64) * WSLOTS * 4 * WCOLS];
+	__shared__ int s_queue[(ATHREADS / 64) * (2 + (QCAP + QCAPN) * QENT)];
+	__shared__ uint8_t s_tbuf[(ATHREADS / 64) * TBUF];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
 	__syncthreads();
 	const int64_t gtid = (int64_t) blockIdx.x * ATHREADS + threadIdx.x;
-	if(gtid >= A.lanes) return;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	Lane L;
 	L.s32 = A.s32 + gtid; L.s64 = A.s64 + gtid; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = A.stats ? A.counters : nullptr;
-	L.wide = s_wide + (threadIdx.x >> 6) * WSLOTS * 4 * WCOLS;
+	L.wide = s_wide + wave * WSLOTS * 4 * WCOLS;
+	L.queue = s_queue + wave * (2 + (QCAP + QCAPN) * QENT);     // wide queue, then the narrow queue
+	L.q_at = 0; L.q_mate = 0; L.q_rd = 0;
 	L.ablate = A.ablate;
+#ifdef KMAHIP_DIAG
+	if(A.ablate & 64) L.queue = nullptr;      // ablation: no cooperative DP
+#endif
+	int *const queue = s_queue + wave * (2 + (QCAP + QCAPN) * QENT);
+	int *const queueN = queue + (1 + QCAP * QENT);
+	uint8_t *const tbuf = s_tbuf + wave * TBUF;
 	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
 	const int64_t n_tasks = A.T_off[A.n_reads];
 	const int k = (int) A.db.kmersize;
-	for(int64_t task = gtid; task < n_tasks; task += A.lanes) {
-		// read owning this task: last r with T_off[r] <= task
-		int64_t lo = 0, hi = A.n_reads;
-		while(hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if(A.T_off[mid] <= task) lo = mid; else hi = mid; }
-		const int64_t r = lo;
-		int rs = 0, alen = 0, start = 0, end = 0;
-		double norm = 0.0;
-		int tmpl_out = A.T[task];
-		// which read and which orientation does record r carry
-		int64_t rd = r;
-		int orient = (A.flag[r] & 16) ? 1 : 0;
-		bool couple = false;
-		if(A.pe_mode) {
-			const int64_t p0 = r & ~1ll;
-			rd = p0 + max(0, A.rec_mate[r]);
-			orient = A.rec_rc[r];
-			couple = (r & 1) && A.rec_mate[p0] >= 0 && A.rec_mate[r] >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
-		}
-		const int rcf = A.rc_flag[r];
-		const int q_len = A.len[rd];
-		const int at = abs(tmpl_out);
-		const int t_len = A.db.tlen[at];
-		const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
-		int status = 0;
-		if(couple) {
-			// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate. Both are
-			// flipped once the list reaches its first negative id and stay flipped (:1633-1647).
-			int rcstate = 0;
-			for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
-			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
-			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
-			for(int m = 0; m < 2; ++m) {
-				const int64_t rec = (r & ~1ll) + m;
-				const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
+	// the wave stays together: every round each lane does its own task up to the (deferred) wide DP problems,
+	// then all 64 lanes solve those, then each lane finishes its task
+	for(int64_t task = gtid; __any(task < n_tasks); task += A.lanes) {
+		const bool have = task < n_tasks && gtid < A.lanes;
+		if(lane == 0) { queue[0] = 0; queueN[0] = 0; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- phase A -------------------------------------------------------------------------------
+		int kind = 0;                  // 0 nothing, 1 single record, 2 couple
+		Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
+		int tmpl_out = 0, t_len = 0, qlen0 = 0, qlen1 = 0;
+		if(have) {
+			// record owning this task: last r with T_off[r] <= task
+			int64_t lo = 0, hi = A.n_reads;
+			while(hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if(A.T_off[mid] <= task) lo = mid; else hi = mid; }
+			const int64_t r = lo;
+			tmpl_out = A.T[task];
+			int64_t rd = r;
+			int orient = (A.flag[r] & 16) ? 1 : 0;
+			bool couple = false;
+			if(A.pe_mode) {
+				const int64_t p0 = r & ~1ll;
+				rd = p0 + max(0, A.rec_mate[r]);
+				orient = A.rec_rc[r];
+				couple = (r & 1) && A.rec_mate[p0] >= 0 && A.rec_mate[r] >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
+			}
+			const int rcf = A.rc_flag[r];
+			const int at = abs(tmpl_out);
+			t_len = A.db.tlen[at];
+			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+			int status = 0;
+			L.q_at = at;
+			if(couple) {
+				// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate. Both are
+				// flipped once the list reaches its first negative id and stay flipped (:1633-1647).
+				kind = 2;
+				int rcstate = 0;
+				for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
+				if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
+				for(int m = 0; m < 2; ++m) {
+					const int64_t rec = (r & ~1ll) + m;
+					const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
+					QView q;
+					q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
+					q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
+					L.q_mate = m; L.q_rd = rdm;
+					Aln st = {0, 1, 0, 0, 0, 0};
+					if(q.L >= k) st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+					if(m == 0) { S0 = st; qlen0 = q.L; } else { S1 = st; qlen1 = q.L; }
+				}
+			} else if(rcf != 0 && A.len[rd] >= k && (!A.pe_mode || A.rec_mate[r] >= 0)) {
+				kind = 1;
 				QView q;
-				q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
-				q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
-				Aln st = {0, 1, 0, 0, 0, 0};
-				if(q.L >= k) st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+				q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
+				q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+				qlen0 = q.L;
+				L.q_mate = 0; L.q_rd = rd;
+				if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
+				if(rcf > 0) {
+					S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+				} else {
+					// strand tie: per template strand decision (alnfrags.c:1101-1124)
+					const int side = anker_rc_comp(L, A.db, at, ts, t_len, q, &status);
+					if(side < 0) { q.rc ^= 1; tmpl_out = -at; S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, -side, &status); }
+					else if(side > 0) { tmpl_out = at; S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, side, &status); }
+				}
+			}
+			if(status) atomicMax(&A.counters[1], 3ull);
+		}
+		// ---- phase B: deferred wide DP problems, whole wave -----------------------------------------
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]);
+		for(int e = 0; e < nq; ++e) nw_coop<64>(L, A.db, A, queue, e, nq, tbuf);
+		for(int e = 0; e < nqn; e += 4) nw_coop<16>(L, A.db, A, queueN, e, nqn, tbuf);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		for(int pass = 0; pass < 2; ++pass) {
+			const int *qu = pass ? queueN : queue;
+			const int cnt = pass ? nqn : nq;
+			for(int e = 0; e < cnt; ++e) {
+				const int *ent = qu + 1 + e * QENT;
+				if(lane != ent[0]) continue;
+				Aln &S = ent[1] ? S1 : S0;
+				// a task that bailed out after queueing (gap too large, align.c:715) keeps its failure value
+				if(S.len == 1 && S.match == 0 && S.score == 0) continue;
+				S.score += ent[2]; S.len += ent[3]; S.match += ent[4]; S.tGaps += ent[5]; S.qGaps += ent[6];
+				if(ent[11]) S.pos -= ent[3] - ent[5];
+			}
+		}
+		// ---- phase C ---------------------------------------------------------------------------------
+		if(!have) continue;
+		if(kind == 2) {
+			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
+			for(int m = 0; m < 2; ++m) {
+				const Aln &st = m ? S1 : S0;
+				const int ql = m ? qlen1 : qlen0;
 				int sc = st.score, s0 = 0, e0 = 0;
 				double nrm = 0.0;
-				if(A.minlen <= st.len && 0 < sc && ((A.mrc * q.L <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) {
+				if(A.minlen <= st.len && 0 < sc && ((A.mrc * ql <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) {
 					s0 = st.pos; e0 = st.pos + st.len - st.tGaps;
 					if(s0 == 0) sc += A.Wl;
 					if(e0 == t_len) sc += A.Wl;
@@ -867,27 +1031,16 @@ __global__ __launch_bounds__(ATHREADS) void align_tasks_kernel(const AlignArgs A
 					raw_b = sc;
 				}
 			}
-			if(status) atomicMax(&A.counters[1], 3ull);
-			A.t_tmpl[task] = raw_b;      // PE tasks: raw second-record score (joins the first in compScore, :1771)
+			A.t_tmpl[task] = raw_b;      // couples: raw second-record score (joins the first in compScore, :1771)
 			A.t_score[task] = bt; A.t_alen[task] = btr; A.t_start[task] = bs; A.t_end[task] = be; A.t_norm[task] = 0.0;
 			continue;
 		}
-		if(rcf != 0 && q_len >= k && (!A.pe_mode || A.rec_mate[r] >= 0)) {
-			QView q;
-			q.w = A.seq + A.seq_off[rd]; q.L = q_len; q.rc = orient;
-			q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
-			if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
-			Aln st = {0, 0, 0, 0, 0, 0};
-			if(rcf > 0) {
-				st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
-			} else {
-				// strand tie: per template strand decision (alnfrags.c:1101-1124)
-				const int side = anker_rc_comp(L, A.db, at, ts, t_len, q, &status);
-				if(side < 0) { q.rc ^= 1; tmpl_out = -at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, -side, &status); }
-				else if(side > 0) { tmpl_out = at; st = kma_score(L, A.db, at, ts, t_len, q, A.mq, side, &status); }
-			}
-			if(status) atomicMax(&A.counters[1], 3ull);
+		int rs = 0, alen = 0, start = 0, end = 0;
+		double norm = 0.0;
+		if(kind == 1) {
 			// alnFragsSE, alnfrags.c:1127-1168
+			const Aln &st = S0;
+			const int q_len = qlen0;
 			alen = st.len; start = st.pos;
 			end = start + alen - st.tGaps;
 			if(t_len < end) end -= t_len;

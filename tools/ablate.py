@@ -52,7 +52,7 @@ for name, sa in (("scan full", 0), ("scan no-machines", 1), ("scan no-probe(phas
     print(f"{name:32s} {run(sa, -1)[0]:8.2f} ms")
 run(0, -1)  # restore real candidates
 for name, aa in (("align full", 0), ("align no-DP", 1), ("align no-wide(q>16)", 8), ("align no-1x1", 16), ("align no-2..16", 32),
-                 ("align only-1x1", 40), ("align only-2..16", 24), ("align only-wide", 48), ("align no-chain+", 4), ("align no-seed+", 2)):
+                 ("align only-1x1", 40), ("align only-2..16", 24), ("align only-wide", 48), ("align no-coop", 64), ("align no-chain+", 4), ("align no-seed+", 2)):
     print(f"{name:32s} {run(-1, aa)[1]:8.2f} ms")
 
 # DP problem histogram (stats launch)
