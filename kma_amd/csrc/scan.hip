@@ -143,8 +143,8 @@ __device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bo
 	}
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t vi_buf[CHUNK * GROUP];
 	__shared__ uint64_t w_lds[GROUP * SW];
 	__shared__ uint32_t t_id[TSLOTS * GROUP];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 					}
 				}
 				vi_buf[idx] = vi;    // == [jj * GROUP + g]
-				if(A.mode && vi != MISS) atomicAdd(&s_hits[g], 1);
+				if(MODE && vi != MISS) atomicAdd(&s_hits[g], 1);
 			}
 			if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
 			__syncthreads();
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(THREADS) void scan_se_kernel(const ScanArgs A) {
 				const unsigned long long slot = atomicAdd(&A.counters[C_NOVER], 1ull);
 				A.overflow_items[slot] = item;
 				nb = -1;
-			} else if(A.mode) {
+			} else if(MODE) {
 				// get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores
 				for(int x = 0; x < TSLOTS; ++x) if(t_id[x * GROUP + g] != T_EMPTY) ++nb;
 				best = s_hits[g];
@@ -910,8 +910,8 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
 		HIP_TRY(hipEventRecord(ev0, stream));
 	}
-	if(ws->stats_on) hipLaunchKernelGGL(scan_se_kernel<true>, dim3(grid), dim3(THREADS), 0, stream, A);
-	else hipLaunchKernelGGL(scan_se_kernel<false>, dim3(grid), dim3(THREADS), 0, stream, A);
+	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_se_kernel<false, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
@@ -956,7 +956,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
 	const unsigned grid = (unsigned) ((2 * n + ITEMS - 1) / ITEMS);
-	hipLaunchKernelGGL(scan_se_kernel<false>, dim3(grid), dim3(THREADS), 0, stream, A);
+	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(THREADS), 0, stream, A);
 	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ((ws->dense_slots + 63) / 64)), dim3(64), 0, stream, A);
 	PairArgs P;
 	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
