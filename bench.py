@@ -217,6 +217,17 @@ def main():
             dom = dict(kernel="scan_se_kernel", kernel_ms=scan_s * 1e3, achieved=scan_bytes / scan_s / 1e9,
                        algorithmic_bytes_per_launch=scan_bytes)
 
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+        # committed rocprofv3 --pmc summary of this same command (profiles/r1_pmc_traffic.json) supplies it
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if dom["kernel"] in pmc and n == 10_000_000 and a.families == 1000:
+                traffic = pmc[dom["kernel"]]["corrected_bytes"]
+                traffic_src = "profiles/r1_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes"
+        except (OSError, ValueError, KeyError):
+            pass
+
         out = {
             "metric": "mapped reads/sec (whole node), 10M×150bp vs 5k-gene DB, 1/2/4/8 GPU",
             "value": world * n * a.steps / dt,
@@ -241,7 +252,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": None,
+                "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes), "GB/s": scan_bytes / scan_s / 1e9,
