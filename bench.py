@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--families", type=int, default=1000, help="gene families (x5 variants = genes)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the host CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -124,9 +127,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.share_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -162,7 +170,12 @@ def main():
             db.align_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, rc_flag, flag, T_off, T,
                             n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
             # the path's only exchange: SUM of the two ConClave score vectors over the read shards (no-op at N=1)
-            allreduce_scores(aln, uniq)
+            if world > 1 and a.backend != "nccl":
+                ca, cu = aln.cpu(), uniq.cpu()
+                allreduce_scores(ca, cu)
+                aln.copy_(ca); uniq.copy_(cu)
+            else:
+                allreduce_scores(aln, uniq)
 
         def fence():
             torch.cuda.synchronize()
@@ -185,7 +198,7 @@ def main():
         db.set_timing(False)
         db.status(stream)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 

@@ -75,3 +75,48 @@ def test_align_vs_oracle_indels_and_ragged(tmp_path):
     short, *_ = synth.make_reads(seqs, 500, read_len=75, sub_rate=0.03, seed=6)
     reads = reads + list(short)
     _vs_oracle(prefix, formats.pack_ragged(reads))
+
+
+def test_shard_invariance_and_determinism_large_batch(tmp_path):
+    """Size-independent properties on a batch far larger than the oracle cases: the ConClave vectors of two
+    read shards add up to the whole batch's, per-read results do not depend on batching, and a second run is
+    bit-identical (atomics only feed exact integer sums)."""
+    from kma_amd import binding
+    names, seqs = synth.make_gene_db(n_families=200, variants=5, seed=5)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads, *_ = synth.make_reads(seqs, 300_000, read_len=150, sub_rate=0.005, random_frac=0.02, seed=21)
+    whole = formats.pack_fixed(reads)
+    half = len(reads) // 2 + 37
+    db = binding.KmaHipDB(prefix)
+    try:
+        (rc1, fl1, To1, T1), h1 = db.map_se(whole)
+        (rc2, fl2, To2, T2), h2 = db.map_se(whole)
+        (_, _, ToA, TA), hA = db.map_se(formats.pack_fixed(reads[:half]))
+        (_, _, ToB, TB), hB = db.map_se(formats.pack_fixed(reads[half:]))
+    finally:
+        db.close()
+    for a, b in ((rc1, rc2), (fl1, fl2), (To1, To2), (T1, T2), (h1["n_hits"], h2["n_hits"]), (h1["best_score"], h2["best_score"]),
+                 (h1["alignment_scores"], h2["alignment_scores"]), (h1["uniq_alignment_scores"], h2["uniq_alignment_scores"])):
+        assert np.array_equal(a, b)
+    assert np.array_equal(h1["alignment_scores"], hA["alignment_scores"] + hB["alignment_scores"])
+    assert np.array_equal(h1["uniq_alignment_scores"], hA["uniq_alignment_scores"] + hB["uniq_alignment_scores"])
+    assert np.array_equal(h1["n_hits"], np.concatenate([hA["n_hits"], hB["n_hits"]]))
+    assert np.array_equal(h1["best_score"], np.concatenate([hA["best_score"], hB["best_score"]]))
+    assert np.array_equal(T1, np.concatenate([TA, TB]))
+    # every kept hit carries the read's best score or the best score/length ratio; mapped fraction is sane
+    assert (h1["n_hits"] > 0).mean() > 0.95
+    assert int(h1["alignment_scores"].sum()) >= int(h1["best_score"].astype(np.int64).sum())
+
+
+def test_align_vs_oracle_long_noisy_reads(tmp_path):
+    """5-8 kb ONT-like reads against one 120 kb sequence: multi-pass scan, hundreds of MEMs per task, banded NW
+    with wide bands, DP rows in HBM scratch."""
+    rng = np.random.default_rng(8)
+    genome = rng.integers(0, 4, 120_000, dtype=np.uint8)
+    prefix = str(tmp_path / "g")
+    formats.write_index(prefix, ["genome"], [genome])
+    reads = []
+    for L in (5000, 6500, 8000):
+        reads += synth.make_long_reads(genome, 6, read_len=L, sub=0.03, dele=0.02, ins=0.02, seed=int(rng.integers(1 << 30)))
+    _vs_oracle(prefix, formats.pack_ragged(reads))
