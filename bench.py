@@ -268,8 +268,8 @@ def main():
                 "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes), "GB/s": scan_bytes / scan_s / 1e9,
-                         "probes_per_s": st.probes / scan_s},
+                "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes), "hash_probes": int(st.hash_probes),
+                         "GB/s": scan_bytes / scan_s / 1e9, "probes_per_s": st.probes / scan_s},
                 "align": {"kernel_ms": aln_s * 1e3, "lookups": int(ast.lookups), "dp_cells": int(ast.dp_cells),
                           "GCUPS": ast.dp_cells / aln_s / 1e9, "GB/s": aln_bytes / aln_s / 1e9,
                           "tasks_per_s": ast.tasks / aln_s},

@@ -207,12 +207,14 @@ int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scores, uint64_
  * synchronised: 0 or KMAHIP_EOVERFLOW */
 int kmahip_ws_status(kmahip_ws *ws, void *stream);
 
-/* Algorithmic work counters of the last scan on this workspace (read after a
- * sync): probes issued, probe-table bytes they touched, value-list bytes. */
+/* Algorithmic work counters of the last scan on this workspace (read after a sync): probes = k-mer starts
+ * whose value set was resolved (= hashMap_get calls of the reference), hash_probes = those that actually went
+ * to the probe table (the rest were read off the template store while walking a match). */
 typedef struct kmahip_scan_stats {
 	uint64_t probes;
 	uint64_t value_elems;
 	uint64_t active_strands;
+	uint64_t hash_probes;
 } kmahip_scan_stats;
 /* same for the last align call: template-index lookups, bases inside MEMs,
  * DP cells filled, (read, candidate) tasks aligned */

@@ -52,7 +52,8 @@ class PeRecs(C.Structure):
 
 
 class ScanStats(C.Structure):
-    _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64)]
+    _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
+                ("hash_probes", C.c_uint64)]
 
 
 class AlignStats(C.Structure):

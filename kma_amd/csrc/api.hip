@@ -60,7 +60,7 @@ extern "C" int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void 
 	unsigned long long c[8];
 	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
-	st->probes = c[3]; st->value_elems = c[4]; st->active_strands = c[5];
+	st->probes = c[3]; st->value_elems = c[4]; st->active_strands = c[5]; st->hash_probes = c[6];
 	return KMAHIP_OK;
 }
 

@@ -124,14 +124,15 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	DevDB &d = db->dev;
 	memset(&d, 0, sizeof d);
 	d.DB_size = DB_size; d.kmersize = tail[0]; d.mlen = mlen; d.nb_log2 = nb_log2; d.values_u16 = u16;
-	if((rc = upload(db, slots.data(), slots.size(), &d.slots))) { kmahip_db_close(db); return rc; }
+	// (slots are uploaded further down, once every key has been given a template position)
 	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index + 8, &d.values16);
 	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index + 8, &d.values32);
 	if(rc) { kmahip_db_close(db); return rc; }
 
-	// template lengths + 2-bit template store (needed by stage 3a)
+	// template lengths + 2-bit template store
 	f = fopen((base + ".length.b").c_str(), "rb");
-	if(f) {
+	if(!f) { kmahip_db_close(db); kmahip_set_error("cannot open %s.length.b", prefix); return KMAHIP_EIO; }
+	{
 		int32_t cnt = 0;
 		if(!read_exact(f, &cnt, 4) || (uint32_t) cnt != DB_size) { fclose(f); kmahip_db_close(db); kmahip_set_error("bad %s.length.b", prefix); return KMAHIP_EIO; }
 		db->h_tlen.resize(DB_size);
@@ -148,6 +149,55 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		if((rc = upload(db, db->h_tlen.data(), db->h_tlen.size(), &d.tlen)) ||
 		   (rc = upload(db, tseq.data(), tseq.size(), &d.tseq)) ||
 		   (rc = upload(db, off.data(), off.size(), &d.tseq_off))) { kmahip_db_close(db); return rc; }
+
+		// Concatenated template store + per-position value-list offsets: a read that matches a template keeps
+		// matching it, so after one hash hit the scan kernel walks along `cat` (sequential 4-byte reads of
+		// vs_id) instead of probing the table for every k-mer start.
+		{
+			const int kk = (int) tail[0];
+			int64_t total = 0;
+			for(uint32_t t = 1; t < DB_size; ++t) total += db->h_tlen[t];
+			if(total + 64 >= 0xFFFFFFFFll) { kmahip_db_close(db); kmahip_set_error("template store too large for 32-bit positions"); return KMAHIP_EFORMAT; }
+			std::vector<uint64_t> cat((size_t) (total >> 5) + 4, 0);
+			std::vector<uint32_t> vsid((size_t) total + 64, KMAHIP_EMPTY_VI);
+			std::vector<uint8_t> placed(slots.size(), 0);
+			int64_t g0 = 0;
+			uint64_t unplaced = n;
+			for(uint32_t t = 1; t < DB_size; ++t) {
+				const int tl = db->h_tlen[t];
+				const uint64_t *ts = tseq.data() + off[t];
+				for(int i = 0; i < tl; ++i) {
+					const uint64_t b = (ts[i >> 5] >> (62 - ((i & 31) << 1))) & 3ull;
+					const int64_t g = g0 + i;
+					cat[(size_t) (g >> 5)] |= b << (62 - ((g & 31) << 1));
+				}
+				for(int i = 0; i + kk <= tl; ++i) {
+					const int ip = (i & 31) << 1, w = i >> 5;
+					uint64_t x = ts[w] << ip;
+					if(ip) x |= ts[w + 1] >> (64 - ip);
+					const uint32_t km = (uint32_t) (x >> (64 - 2 * kk));
+					uint64_t b = home_bucket(km, nb_log2);
+					for(bool done = false; !done;) {
+						uint2 *sl = &slots[b * KMAHIP_BUCKET_SLOTS];
+						for(int j = 0; j < KMAHIP_BUCKET_SLOTS; ++j) {
+							const size_t si = b * KMAHIP_BUCKET_SLOTS + j;
+							if(sl[j].y == KMAHIP_EMPTY_VI && !placed[si]) { done = true; break; }   // k-mer not in the index
+							if(sl[j].x == km) {
+								// first sighting: remember the list offset at this position, then re-point the slot here
+								if(!placed[si]) { vsid[(size_t) (g0 + i)] = sl[j].y; sl[j].y = (uint32_t) (g0 + i); placed[si] = 1; --unplaced; }
+								else vsid[(size_t) (g0 + i)] = vsid[sl[j].y];
+								done = true; break;
+							}
+						}
+						if(!done) b = (b + 1) & (nb - 1);
+					}
+				}
+				g0 += tl;
+			}
+			if(unplaced) { kmahip_db_close(db); kmahip_set_error("%llu index k-mers do not occur in %s.seq.b", (unsigned long long) unplaced, prefix); return KMAHIP_EFORMAT; }
+			if((rc = upload(db, slots.data(), slots.size(), &d.slots)) || (rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
+			   (rc = upload(db, vsid.data(), vsid.size(), &d.vs_id))) { kmahip_db_close(db); return rc; }
+		}
 
 		// per-template k-mer position index
 		const int k = (int) tail[0];

@@ -10,7 +10,7 @@
 #define KMAHIP_EMPTY_VI 0xFFFFFFFFu
 #define KMAHIP_BUCKET_SLOTS 4
 
-// Probe table in HBM: open hashing over 32-byte buckets of 4 (key, value_offset)
+// Probe table in HBM: open hashing over 32-byte buckets of 4 (key, position)
 // slots. bucket(key) = (key * GOLD) >> (32 - nb_log2); a key lives in the first
 // bucket at or after its home bucket (cyclic) that had a free slot at build
 // time, so a lookup stops at the first bucket holding either the key (hit) or
@@ -23,7 +23,10 @@ struct DevDB {
 	uint32_t mlen;
 	uint32_t nb_log2;
 	uint32_t values_u16;          // 1: values16 valid, 0: values32
-	const uint2 *slots;           // (1 << nb_log2) * 4
+	const uint2 *slots;           // (1 << nb_log2) * 4 slots of (key, gpos): gpos = one position of the k-mer in `cat`
+	const uint64_t *cat;          // all templates back to back, 2 bit per base (+ pad words)
+	const uint32_t *vs_id;        // per position of `cat`: value-list offset of the k-mer starting there, or
+	                              // KMAHIP_EMPTY_VI where no k-mer of one template starts (its last k-1 bases)
 	const uint16_t *values16;     // [cnt, t1..tcnt] lists, offsets = value_index of the index file
 	const uint32_t *values32;
 	const int32_t *tlen;          // DB_size, tlen[0] = kmerindex

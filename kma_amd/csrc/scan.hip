@@ -60,7 +60,7 @@ struct ScanArgs {
 	int32_t *pool_sc;    // mode 1: scores parallel to pool
 };
 
-enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5 };
+enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6 };
 
 __device__ __forceinline__ uint32_t probe(const DevDB &db, uint32_t key) {
 	const uint32_t sh = 32u - db.nb_log2;
@@ -91,6 +91,25 @@ __device__ __forceinline__ uint64_t kmer_from(uint64_t lo, uint64_t hi, int q, i
 	uint64_t x = lo << ip;
 	if(ip) x |= hi >> (64 - ip);
 	return x >> (64 - 2 * k);
+}
+
+// 32 bases starting at base `pos` of a 2-bit word array (MSB first); reads word+1
+__device__ __forceinline__ uint64_t win2(const uint64_t *w, int64_t pos) {
+	const int ip = (int) (pos & 31) << 1;
+	const int64_t i = pos >> 5;
+	uint64_t x = w[i] << ip;
+	if(ip) x |= w[i + 1] >> (64 - ip);
+	return x;
+}
+
+// 32 bases of the read in STRAND orientation starting at strand position i (strand 1 = reverse complement of
+// the forward words `w` of a read of length L); bases past the read end are garbage
+__device__ __forceinline__ uint64_t strand_win(const uint64_t *w, int L, int strand, int i) {
+	if(!strand) return win2(w, i);
+	const int s0 = L - 32 - i;
+	uint64_t x = (s0 >= 0) ? win2(w, s0) : (w[0] >> ((-s0) << 1));
+	x = __brevll(~x);
+	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
 }
 
 // cost of bridging `gaps` missed k-mer starts between two hits of a template.
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ int64_t s_soff[ITEMS], s_noff[ITEMS];
 	__shared__ uint32_t s_active[2];
 	__shared__ int32_t s_nact, s_gmax;
-	__shared__ uint32_t s_stats[2];
+	__shared__ uint32_t s_stats[3];   // [0] k-mer starts resolved (= probes of the reference), [1] list elements, [2] hash probes
 
 	const DevDB &db = A.db;
 	const int tid = threadIdx.x;
@@ -172,7 +191,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 		}
 		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no;
 	}
-	if(tid < 2) { s_active[tid] = 0; s_stats[tid] = 0; }
+	if(tid < 2) s_active[tid] = 0;
+	if(tid < 3) s_stats[tid] = 0;
 	__syncthreads();
 
 	// ---- phase 0: prefilter (savekmers.c:2477-2495) -------------------------------
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			}
 		}
 		if(hit) atomicOr(&s_active[a >> 5], 1u << (a & 31));
-		if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
+		if(STATS && nprobe) { atomicAdd(&s_stats[0], nprobe); atomicAdd(&s_stats[2], nprobe); }
 	}
 	__syncthreads();
 	const uint64_t active = ((uint64_t) s_active[1] << 32) | s_active[0];
@@ -273,89 +293,134 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				w_lds[idx] = v;
 			}
 			__syncthreads();
-			// phase 1: probe every k-mer start of the pass
-			uint32_t nprobe = 0;
-			for(int idx = tid; idx < GROUP * CHUNK; idx += THREADS) {
-				const int g = idx & (GROUP - 1), jj = idx / GROUP;
-				uint32_t vi = MISS;
+			// phase 1: value set of every k-mer start of the pass. A read that matches a template keeps matching it, so
+			// each of the 16 lanes of an item anchors its 9-position segment with ONE hash probe and then walks along
+			// the concatenated template store: while the next read base equals the next template base, the next
+			// k-mer is the template's next k-mer and its value-list offset is a sequential 4-byte read of vs_id.
+			// Only anchors and the positions after a disagreement cost a random gather into the probe table.
+			uint32_t nprobe = 0, nres = 0;
+			{
+				constexpr int LPI = THREADS / GROUP;                 // lanes per item
+				constexpr int SEG = (CHUNK + LPI - 1) / LPI;         // positions per lane
+				const int g = tid & (GROUP - 1), sl = tid / GROUP;
+				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
 				if(g < ng) {
 					const int a = s_alist[g0 + g];
-					const int L = s_len[a], p = c0 + jj;
-					if(p < L - k + 1) {
-						const int q = (a & 1) ? (L - k - p) : p;
-						const int nN = s_nN[a];
-						if(nN == 0 || !window_has_N(A.N + s_noff[a], nN, q, k)) {
-							const int w = (q >> 5) - s_wbase[g];
-							uint64_t km = kmer_from(w_lds[g * SW + w], w_lds[g * SW + w + 1], q, k);
-							if(a & 1) km = revcomp_kmer(km, k);
+					const int L = s_len[a], npos = L - k + 1, strand = a & 1, nN = s_nN[a];
+					const uint64_t *rw = A.seq + s_soff[a];
+					const int32_t *Nl = A.N + s_noff[a];
+					int jj = j0;
+					while(jj < j1) {
+						const int p = c0 + jj;
+						if(p >= npos) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						const int q = strand ? (L - k - p) : p;
+						if(nN && window_has_N(Nl, nN, q, k)) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						const int w = (q >> 5) - s_wbase[g];
+						uint64_t km = kmer_from(w_lds[g * SW + w], w_lds[g * SW + w + 1], q, k);
+						if(strand) km = revcomp_kmer(km, k);
+						uint32_t gp;
 #ifdef KMAHIP_DIAG
-							if(A.ablate & 2) vi = (uint32_t) (km & 1023u); else
+						if(A.ablate & 2) gp = MISS; else
 #endif
-							vi = probe(db, (uint32_t) km);
-							++nprobe;
+						gp = probe(db, (uint32_t) km);
+						++nprobe; ++nres;
+						if(gp == MISS) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
+						constexpr int WALK = SEG - 1;
+						uint32_t vv[WALK + 1];
+#pragma unroll
+						for(int i = 0; i <= WALK; ++i) vv[i] = db.vs_id[gp + i];
+						const uint64_t tw = win2(db.cat, (int64_t) gp + k);
+						const uint64_t qw = strand_win(rw, L, strand, p + k);
+						vi_buf[jj * GROUP + g] = vv[0];
+						++jj;
+						// walk: how many more k-mer starts of this segment continue the same template diagonal
+						int room = min(j1 - jj, npos - (p + 1));
+						if(nN && room > 0) {
+							// the walk may not run into an N: strand position of the first N at or after p + k
+							int lo = 0, hi = nN;
+							if(!strand) { while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] < p + k) lo = mid + 1; else hi = mid; }
+								if(lo < nN) room = min(room, Nl[lo] - (p + k)); }
+							else { const int fq = L - 1 - (p + k);      // forward position of strand base p + k; bases go down from here
+								while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] <= fq) lo = mid + 1; else hi = mid; }
+								if(lo > 0) room = min(room, fq - Nl[lo - 1]); }
+						}
+						if(room > 0) {
+							const uint64_t x = qw ^ tw;
+							const int same = x ? (__clzll((long long) x) >> 1) : 32;
+							int run = min(room, same);
+							// the template ends where vs_id holds no k-mer: nothing after it continues the diagonal
+#pragma unroll
+							for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
+#pragma unroll
+							for(int i = 1; i <= WALK; ++i) {
+								if(i <= run) { vi_buf[jj * GROUP + g] = vv[i]; ++jj; ++nres; }
+							}
 						}
 					}
-				}
-				vi_buf[idx] = vi;    // == [jj * GROUP + g]
-				if(MODE && vi != MISS) atomicAdd(&s_hits[g], 1);
-			}
-			if(STATS && nprobe) atomicAdd(&s_stats[0], nprobe);
-			__syncthreads();
-			// phase 2a: one thread per run of equal value sets
+					// phase 2a, same lane, no barrier: every run of equal value sets inside this lane's segment ORs its
+					// position range into the hit mask of each listed template (runs are cut at segment borders,
+					// which leaves the union of ranges unchanged)
 #ifdef KMAHIP_DIAG
-			if(!(A.ablate & 1))
+					if(!(A.ablate & 1))
 #endif
-			for(int idx = tid; idx < GROUP * CHUNK; idx += THREADS) {
-				const int g = idx & (GROUP - 1), jj = idx / GROUP;
-				if(g >= ng || s_over[g]) continue;
-				const uint32_t vi = vi_buf[idx];
-				if(vi == MISS) continue;
-				if(jj > 0 && vi_buf[idx - GROUP] == vi) continue;
-				int e = jj + 1;
-				while(e < CHUNK && vi_buf[e * GROUP + g] == vi) ++e;
-				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
-				uint32_t cnt, el[7];
-				if(db.values_u16) {
-					const uint16_t *vp = db.values16 + vi;
-					cnt = vp[0];
+					for(int r0 = j0; r0 < j1 && !s_over[g];) {
+						const uint32_t vi = vi_buf[r0 * GROUP + g];
+						if(vi == MISS) { ++r0; continue; }
+						int e = r0 + 1;
+						while(e < j1 && vi_buf[e * GROUP + g] == vi) ++e;
+						const int jj = r0;
+						r0 = e;
+						// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
+						uint32_t cnt, el[7];
+						if(db.values_u16) {
+							const uint16_t *vp = db.values16 + vi;
+							cnt = vp[0];
 #pragma unroll
-					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+							for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+						} else {
+							const uint32_t *vp = db.values32 + vi;
+							cnt = vp[0];
+#pragma unroll
+							for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+						}
+						if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
+						auto add_template = [&](const uint32_t t) -> bool {
+							// claim / find the template's slot
+							int slot = -1;
+							const uint32_t h = (t * 0x9E3779B1u) >> 28;
+							for(int x = 0; x < TSLOTS; ++x) {
+								const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
+								const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
+								if(old == T_EMPTY) {
+									if(atomicAdd(&t_cnt[g], 1) >= TMAX) break;
+									slot = sidx; break;
+								}
+								if(old == t) { slot = sidx; break; }
+							}
+							if(slot < 0) { s_over[g] = 1; return false; }
+							for(int w = jj >> 5; w <= (e - 1) >> 5; ++w) {
+								const int lo = max(jj, w << 5) & 31, hi = min(e, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
+								const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
+								atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
+							}
+							return true;
+						};
+						bool ok = true;
+#pragma unroll
+						for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
+						for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+					}
 				} else {
-					const uint32_t *vp = db.values32 + vi;
-					cnt = vp[0];
-#pragma unroll
-					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+					for(int jj = j0; jj < j1; ++jj) vi_buf[jj * GROUP + g] = MISS;
 				}
-				if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
-				auto add_template = [&](const uint32_t t) -> bool {
-					// claim / find the template's slot
-					int slot = -1;
-					const uint32_t h = (t * 0x9E3779B1u) >> 28;
-					for(int x = 0; x < TSLOTS; ++x) {
-						const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
-						const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
-						if(old == T_EMPTY) {
-							if(atomicAdd(&t_cnt[g], 1) >= TMAX) break;
-							slot = sidx; break;
-						}
-						if(old == t) { slot = sidx; break; }
-					}
-					if(slot < 0) { s_over[g] = 1; return false; }
-					for(int w = jj >> 5; w <= (e - 1) >> 5; ++w) {
-						const int lo = max(jj, w << 5) & 31, hi = min(e, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
-						const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
-						atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
-					}
-					return true;
-				};
-				bool ok = true;
-#ifdef KMAHIP_DIAG
-				if(A.ablate & 32) { if(cnt + el[0] + el[6] == 0xFFFFFFF0u) s_over[g] = 1; continue; }
-#endif
-#pragma unroll
-				for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
-				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+				if(MODE && g < ng) {
+					int hc = 0;
+					for(int jj = j0; jj < j1; ++jj) hc += vi_buf[jj * GROUP + g] != MISS;
+					if(hc) atomicAdd(&s_hits[g], hc);
+				}
 			}
+			if(STATS && nres) { atomicAdd(&s_stats[0], nres); atomicAdd(&s_stats[2], nprobe); }
 			__syncthreads();
 			// phase 2b: one thread per (item, template): fold the hit mask into the score
 #ifdef KMAHIP_DIAG
@@ -462,6 +527,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			atomicAdd(&A.counters[C_PROBES], (unsigned long long) s_stats[0]);
 			atomicAdd(&A.counters[C_VALS], (unsigned long long) s_stats[1]);
 			atomicAdd(&A.counters[C_ACTIVE], (unsigned long long) __popcll(active));
+			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_stats[2]);
 		}
 	}
 }
@@ -497,6 +563,7 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 				uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
 				if(strand) km = revcomp_kmer(km, k);
 				vi = probe(db, (uint32_t) km);
+				if(vi != MISS) vi = db.vs_id[vi];
 			}
 			if(vi == MISS) { ++gaps; continue; }
 			if(vi == last) {
