@@ -70,6 +70,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "KMAHIP_LIB" not in os.environ:
+            # build on demand (same recipe as __graft_entry__.build()); there is no other implementation to fall back to
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+            except (OSError, subprocess.CalledProcessError) as e:
+                raise KmaHipError(f"{LIB_PATH} is not built and building it failed ({e}): run __graft_entry__.build()")
         if not os.path.exists(LIB_PATH):
             raise KmaHipError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
         L = C.CDLL(LIB_PATH)

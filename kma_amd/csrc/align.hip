@@ -50,6 +50,7 @@ struct AlignArgs {
 	// per task
 	int32_t *t_score, *t_alen, *t_start, *t_end, *t_tmpl;
 	double *t_norm;
+	const int32_t *t_rec;    // record owning each task (expanded from T_off by task_map_kernel)
 	// scratch
 	int32_t *s32;
 	uint64_t *s64;
@@ -929,10 +930,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
 		int tmpl_out = 0, t_len = 0, qlen0 = 0, qlen1 = 0;
 		if(have) {
-			// record owning this task: last r with T_off[r] <= task
-			int64_t lo = 0, hi = A.n_reads;
-			while(hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if(A.T_off[mid] <= task) lo = mid; else hi = mid; }
-			const int64_t r = lo;
+			const int64_t r = A.t_rec[task];
 			tmpl_out = A.T[task];
 			int64_t rd = r;
 			int orient = (A.flag[r] & 16) ? 1 : 0;
@@ -1055,6 +1053,14 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		A.t_tmpl[task] = tmpl_out;
 		A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
 	}
+}
+
+// task -> owning record, so that the task kernel needs one coalesced load instead of a 23-step binary search
+__global__ __launch_bounds__(256) void task_map_kernel(const int64_t *T_off, int64_t n, int32_t *t_rec) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= n) return;
+	const int64_t e = T_off[r + 1];
+	for(int64_t t = T_off[r]; t < e; ++t) t_rec[t] = (int32_t) r;
 }
 
 struct ReduceArgs {
@@ -1261,7 +1267,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (5 * 4 + 8)));
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (6 * 4 + 8)));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
@@ -1277,6 +1283,9 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	double *norm = (double *) ws->a_task;
 	int32_t *ti = (int32_t *) (norm + tasks_cap);
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
+	int32_t *t_rec = ti + 5 * tasks_cap;
+	A.t_rec = t_rec;
+	if(n >= 0x7FFFFFFF) { kmahip_set_error("too many records in one batch"); return KMAHIP_EINVAL; }
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
 	A.rec_mate = rec_mate; A.rec_rc = rec_rc; A.pe_mode = rec_mate != nullptr; A.Wl = -p->rw.Wl; A.PE = p->rw.PE;
 	A.counters = ws->counters;
@@ -1285,6 +1294,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_ALIGN")) A.ablate = atoi(e);
 #endif
+	hipLaunchKernelGGL(task_map_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, cands->T_off, n, t_rec);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(ws->timing_on) {
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
