@@ -34,6 +34,7 @@ constexpr int SW = 7;                 // staged u64 words per item and pass
 constexpr int TSLOTS = 16;            // hashed candidate slots per item in LDS
 constexpr int TMAX = 14;              // ... of which at most this many occupied
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
+constexpr int INL = 2;                // inline result slots per strand item (no allocation round trip for the usual 1-2 ties)
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFEu;
 
@@ -56,6 +57,7 @@ struct ScanArgs {
 	int64_t *overflow_items;
 	int32_t *dense;
 	int64_t dense_slots;
+	int64_t pool_tail0;  // pool[0 .. pool_tail0) = INL inline slots per strand item; longer lists are bump-allocated after it
 	int mode;            // 0: best templates per strand (save_kmers); 1: every candidate + score + hit count (get_kmers_for_pair)
 	int32_t *pool_sc;    // mode 1: scores parallel to pool
 };
@@ -165,7 +167,10 @@ __device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bo
 template <bool STATS, int MODE>
 __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t vi_buf[CHUNK * GROUP];
+	// forward words: if every read of the workgroup fits in SW-1 words they are staged ONCE per read (index = read)
+	// and serve the prefilter and all passes; otherwise (s_anylong) per pass and group item (index = group slot)
 	__shared__ uint64_t w_lds[GROUP * SW];
+	__shared__ int32_t s_anylong;
 	__shared__ uint32_t t_id[TSLOTS * GROUP];
 	__shared__ uint32_t t_mask[MW * TSLOTS * GROUP];
 	__shared__ int32_t t_score[TSLOTS * GROUP];
@@ -193,7 +198,19 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	}
 	if(tid < 2) s_active[tid] = 0;
 	if(tid < 3) s_stats[tid] = 0;
+	if(tid == 0) s_anylong = 0;
 	__syncthreads();
+	if(tid < ITEMS / 2 && s_len[2 * tid] > (SW - 1) * 32) s_anylong = 1;
+	__syncthreads();
+	const bool staged_once = !s_anylong;
+	if(staged_once) {
+		for(int idx = tid; idx < (ITEMS / 2) * SW; idx += THREADS) {
+			const int rr = idx / SW, w = idx - rr * SW;
+			const int L = s_len[2 * rr];
+			w_lds[idx] = (w < ((L + 31) >> 5)) ? A.seq[s_soff[2 * rr] + w] : 0ull;
+		}
+		__syncthreads();
+	}
 
 	// ---- phase 0: prefilter (savekmers.c:2477-2495) -------------------------------
 	{
@@ -211,10 +228,10 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 #endif
 				hit = (a & 1) == 0 || A.exhaustive;
 			} else if(nN == 0) {
+				const uint64_t *wsrc = staged_once ? &w_lds[(a >> 1) * SW] : rs;
 				for(int j = slot * k; j < npos; j += PLANES * k) {
 					const int q = strand ? (L - k - j) : j;
-					const int w = q >> 5;
-					uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
+					uint64_t km = kmer_from(wsrc[q >> 5], wsrc[(q >> 5) + 1], q, k);
 					if(strand) km = revcomp_kmer(km, k);
 					++nprobe;
 					if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
@@ -275,24 +292,26 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 		const int gmax = s_gmax;
 
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
-			// stage the forward words of this pass
-			for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
-				const int g = idx / SW, w = idx - g * SW;
-				uint64_t v = 0;
-				if(g < ng) {
-					const int a = s_alist[g0 + g];
-					const int L = s_len[a], npos = L - k + 1;
-					int lo = c0;
-					if(a & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
-					if(lo < 0) lo = 0;
-					const int wb = lo >> 5;
-					if(w == 0) s_wbase[g] = wb;
-					const int words = (L + 31) >> 5;
-					if(wb + w < words) v = A.seq[s_soff[a] + wb + w];
+			// stage the forward words of this pass (only workgroups holding a read too long to be staged once)
+			if(!staged_once) {
+				for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
+					const int g = idx / SW, w = idx - g * SW;
+					uint64_t v = 0;
+					if(g < ng) {
+						const int a = s_alist[g0 + g];
+						const int L = s_len[a], npos = L - k + 1;
+						int lo = c0;
+						if(a & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
+						if(lo < 0) lo = 0;
+						const int wb = lo >> 5;
+						if(w == 0) s_wbase[g] = wb;
+						const int words = (L + 31) >> 5;
+						if(wb + w < words) v = A.seq[s_soff[a] + wb + w];
+					}
+					w_lds[idx] = v;
 				}
-				w_lds[idx] = v;
+				__syncthreads();
 			}
-			__syncthreads();
 			// phase 1: value set of every k-mer start of the pass. A read that matches a template keeps matching it, so
 			// each of the 16 lanes of an item anchors its 9-position segment with ONE hash probe and then walks along
 			// the concatenated template store: while the next read base equals the next template base, the next
@@ -315,8 +334,9 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 						if(p >= npos) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
 						const int q = strand ? (L - k - p) : p;
 						if(nN && window_has_N(Nl, nN, q, k)) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
-						const int w = (q >> 5) - s_wbase[g];
-						uint64_t km = kmer_from(w_lds[g * SW + w], w_lds[g * SW + w + 1], q, k);
+						const uint64_t *wsrc = staged_once ? &w_lds[(a >> 1) * SW] : &w_lds[g * SW];
+						const int w = (q >> 5) - (staged_once ? 0 : s_wbase[g]);
+						uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], q, k);
 						if(strand) km = revcomp_kmer(km, k);
 						uint32_t gp;
 #ifdef KMAHIP_DIAG
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				for(int x = 0; x < TSLOTS; ++x) if(t_id[x * GROUP + g] != T_EMPTY) ++nb;
 				best = s_hits[g];
 				if(nb) {
-					off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+					off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
 					if(off + nb <= A.pool_cap) {
 						long long prevkey = -1;
 						for(int w = 0; w < nb; ++w) {
@@ -494,7 +514,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 					if(sc > best) { best = sc; nb = 1; } else if(sc == best) ++nb;
 				}
 				if(best > 0) {
-					off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+					off = (nb <= INL) ? item * INL : A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
 					if(off + nb <= A.pool_cap) {
 						// first-seen order = ascending (first hit position, template id)
 						long long prevkey = -1;
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 			const int c = (int) value_at(db, last, 0);
 			for(int i = 1; i <= c; ++i) score[value_at(db, last, i)] += acc;
 			best = hits; nb = nlist;
-			off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+			off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
 			if(off + nb <= A.pool_cap) {
 				for(int e = 0; e < nlist; ++e) { A.pool[off + e] = list[e]; A.pool_sc[off + e] = max(0, score[list[e]]); }
 			} else atomicMax(&A.counters[C_STATUS], 1ull);
@@ -609,7 +629,7 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 				if(s > best) { best = s; nb = 1; } else if(s == best) ++nb;
 			}
 			if(best > 0) {
-				off = (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+				off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
 				if(off + nb <= A.pool_cap) {
 					int w = 0;
 					for(int e = 0; e < nlist; ++e) if(max(0, score[list[e]]) == best) A.pool[off + w++] = list[e];
@@ -958,7 +978,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
-	A.mode = 0; A.pool_sc = nullptr;
+	A.mode = 0; A.pool_sc = nullptr; A.pool_tail0 = 2 * n * INL;
 	A.ablate = 0;
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_SCAN")) A.ablate = atoi(e);
@@ -1018,7 +1038,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
-	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc;
+	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc; A.pool_tail0 = 0;
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
