@@ -34,6 +34,8 @@ constexpr int SW = 7;                 // staged u64 words per item and pass
 constexpr int TSLOTS = 16;            // hashed candidate slots per item in LDS
 constexpr int TMAX = 14;              // ... of which at most this many occupied
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
+constexpr int VSLOTS = 16;            // hashed value-list slots per item in LDS (distinct lists seen in one pass); a list
+                                      // that finds all of them taken is expanded directly
 constexpr int INL = 2;                // inline result slots per strand item (no allocation round trip for the usual 1-2 ties)
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFEu;
@@ -164,9 +166,40 @@ __device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bo
 	}
 }
 
+// claim / find template t's slot in item g's candidate table; -1 when the table is full
+__device__ __forceinline__ int template_slot(uint32_t t, int g, uint32_t *t_id, int32_t *t_cnt) {
+	const uint32_t h = (t * 0x9E3779B1u) >> 28;
+	for(int x = 0; x < TSLOTS; ++x) {
+		const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
+		const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
+		if(old == T_EMPTY) {
+			if(atomicAdd(&t_cnt[g], 1) >= TMAX) return -1;
+			return sidx;
+		}
+		if(old == t) return sidx;
+	}
+	return -1;
+}
+
+// rare path: OR positions [rs, re) of the pass into the hit mask of every template of list vi
+__device__ __forceinline__ void expand_list(const DevDB &db, uint32_t vi, int rs, int re, int g,
+                                         uint32_t *t_id, int32_t *t_cnt, uint32_t *t_mask, int32_t *s_over) {
+	const uint32_t cnt = value_at(db, vi, 0);
+	for(uint32_t i = 1; i <= cnt; ++i) {
+		const int slot = template_slot(value_at(db, vi, (int) i), g, t_id, t_cnt);
+		if(slot < 0) { s_over[g] = 1; return; }
+		for(int w = rs >> 5; w <= (re - 1) >> 5; ++w) {
+			const int lo = max(rs, w << 5) & 31, hi = min(re, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
+			const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
+			atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
+		}
+	}
+}
+
 template <bool STATS, int MODE>
 __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
-	__shared__ uint32_t vi_buf[CHUNK * GROUP];
+	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
+	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
 	// forward words: if every read of the workgroup fits in SW-1 words they are staged ONCE per read (index = read)
 	// and serve the prefilter and all passes; otherwise (s_anylong) per pass and group item (index = group slot)
 	__shared__ uint64_t w_lds[GROUP * SW];
@@ -284,6 +317,11 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 #pragma unroll
 			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
 		}
+		for(int idx = tid; idx < VSLOTS * GROUP; idx += THREADS) {
+			v_id[idx] = MISS;
+#pragma unroll
+			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
+		}
 		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; }
 		if(tid == 0) s_gmax = 0;
 		__syncthreads();
@@ -317,6 +355,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			// the concatenated template store: while the next read base equals the next template base, the next
 			// k-mer is the template's next k-mer and its value-list offset is a sequential 4-byte read of vs_id.
 			// Only anchors and the positions after a disagreement cost a random gather into the probe table.
+			// Every run of equal value lists inside a walk ORs its position range into the mask of that LIST in the
+			// item's v-table -- no list is read here, and a list that recurs along the read is expanded once.
 			uint32_t nprobe = 0, nres = 0;
 			{
 				constexpr int LPI = THREADS / GROUP;                 // lanes per item
@@ -328,12 +368,12 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 					const int L = s_len[a], npos = L - k + 1, strand = a & 1, nN = s_nN[a];
 					const uint64_t *rw = A.seq + s_soff[a];
 					const int32_t *Nl = A.N + s_noff[a];
-					int jj = j0;
+					int jj = j0, hc = 0;
 					while(jj < j1) {
 						const int p = c0 + jj;
-						if(p >= npos) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						if(p >= npos) break;
 						const int q = strand ? (L - k - p) : p;
-						if(nN && window_has_N(Nl, nN, q, k)) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						if(nN && window_has_N(Nl, nN, q, k)) { ++jj; continue; }
 						const uint64_t *wsrc = staged_once ? &w_lds[(a >> 1) * SW] : &w_lds[g * SW];
 						const int w = (q >> 5) - (staged_once ? 0 : s_wbase[g]);
 						uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], q, k);
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 #endif
 						gp = probe(db, (uint32_t) km);
 						++nprobe; ++nres;
-						if(gp == MISS) { vi_buf[jj * GROUP + g] = MISS; ++jj; continue; }
+						if(gp == MISS) { ++jj; continue; }
 						// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
 						constexpr int WALK = SEG - 1;
 						uint32_t vv[WALK + 1];
@@ -352,10 +392,9 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 						for(int i = 0; i <= WALK; ++i) vv[i] = db.vs_id[gp + i];
 						const uint64_t tw = win2(db.cat, (int64_t) gp + k);
 						const uint64_t qw = strand_win(rw, L, strand, p + k);
-						vi_buf[jj * GROUP + g] = vv[0];
-						++jj;
 						// walk: how many more k-mer starts of this segment continue the same template diagonal
-						int room = min(j1 - jj, npos - (p + 1));
+						int run = 0;
+						int room = min(j1 - jj - 1, npos - (p + 1));
 						if(nN && room > 0) {
 							// the walk may not run into an N: strand position of the first N at or after p + k
 							int lo = 0, hi = nN;
@@ -368,79 +407,90 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 						if(room > 0) {
 							const uint64_t x = qw ^ tw;
 							const int same = x ? (__clzll((long long) x) >> 1) : 32;
-							int run = min(room, same);
+							run = min(room, same);
 							// the template ends where vs_id holds no k-mer: nothing after it continues the diagonal
 #pragma unroll
 							for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
-#pragma unroll
-							for(int i = 1; i <= WALK; ++i) {
-								if(i <= run) { vi_buf[jj * GROUP + g] = vv[i]; ++jj; ++nres; }
-							}
 						}
-					}
-					// phase 2a, same lane, no barrier: every run of equal value sets inside this lane's segment ORs its
-					// position range into the hit mask of each listed template (runs are cut at segment borders,
-					// which leaves the union of ranges unchanged)
+						// positions jj .. jj + run carry the lists vv[0 .. run]; bit i of bm: a run of equal lists starts at i
+						uint32_t bm = 1u;
+#pragma unroll
+						for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] != vv[i - 1]) bm |= 1u << i;
+						nres += run; hc += run + 1;
 #ifdef KMAHIP_DIAG
-					if(!(A.ablate & 1))
+						if(A.ablate & 1) bm = 0;
 #endif
-					for(int r0 = j0; r0 < j1 && !s_over[g];) {
-						const uint32_t vi = vi_buf[r0 * GROUP + g];
-						if(vi == MISS) { ++r0; continue; }
-						int e = r0 + 1;
-						while(e < j1 && vi_buf[e * GROUP + g] == vi) ++e;
-						const int jj = r0;
-						r0 = e;
-						// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
-						uint32_t cnt, el[7];
-						if(db.values_u16) {
-							const uint16_t *vp = db.values16 + vi;
-							cnt = vp[0];
+						while(bm && !s_over[g]) {
+							const int i0 = __ffs((int) bm) - 1;
+							bm &= bm - 1;
+							const int i1 = bm ? __ffs((int) bm) - 1 : run + 1;
+							uint32_t vi = vv[0];
 #pragma unroll
-							for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
-						} else {
-							const uint32_t *vp = db.values32 + vi;
-							cnt = vp[0];
-#pragma unroll
-							for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
-						}
-						if(STATS) atomicAdd(&s_stats[1], cnt + 1u);
-						auto add_template = [&](const uint32_t t) -> bool {
-							// claim / find the template's slot
+							for(int i = 1; i <= WALK; ++i) if(i0 == i) vi = vv[i];
+							const int rs = jj + i0, re = jj + i1;            // positions [rs, re) of the pass
+							if(STATS) atomicAdd(&s_stats[1], value_at(db, vi, 0) + 1u);
+							// claim / find the list's slot in the item's v-table
 							int slot = -1;
-							const uint32_t h = (t * 0x9E3779B1u) >> 28;
-							for(int x = 0; x < TSLOTS; ++x) {
-								const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
-								const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
-								if(old == T_EMPTY) {
-									if(atomicAdd(&t_cnt[g], 1) >= TMAX) break;
-									slot = sidx; break;
+							const uint32_t h = (vi * 0x9E3779B1u) >> 28;
+							for(int x = 0; x < VSLOTS; ++x) {
+								const int sidx = (int) ((h + x) & (VSLOTS - 1)) * GROUP + g;
+								const uint32_t old = atomicCAS(&v_id[sidx], MISS, vi);
+								if(old == MISS || old == vi) { slot = sidx; break; }
+							}
+							if(slot >= 0) {
+								for(int w = rs >> 5; w <= (re - 1) >> 5; ++w) {
+									const int lo = max(rs, w << 5) & 31, hi = min(re, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
+									const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
+									atomicOr(&v_mask[w * VSLOTS * GROUP + slot], m);
 								}
-								if(old == t) { slot = sidx; break; }
+							} else {
+								// more distinct lists in this pass than the v-table holds: expand this run directly
+								expand_list(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
 							}
-							if(slot < 0) { s_over[g] = 1; return false; }
-							for(int w = jj >> 5; w <= (e - 1) >> 5; ++w) {
-								const int lo = max(jj, w << 5) & 31, hi = min(e, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
-								const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
-								atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
-							}
-							return true;
-						};
-						bool ok = true;
-#pragma unroll
-						for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
-						for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+						}
+						jj += run + 1;
 					}
-				} else {
-					for(int jj = j0; jj < j1; ++jj) vi_buf[jj * GROUP + g] = MISS;
-				}
-				if(MODE && g < ng) {
-					int hc = 0;
-					for(int jj = j0; jj < j1; ++jj) hc += vi_buf[jj * GROUP + g] != MISS;
-					if(hc) atomicAdd(&s_hits[g], hc);
+					if(MODE && hc) atomicAdd(&s_hits[g], hc);
 				}
 			}
 			if(STATS && nres) { atomicAdd(&s_stats[0], nres); atomicAdd(&s_stats[2], nprobe); }
+			__syncthreads();
+			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
+			// flight together) and OR the list's position mask into the hit mask of each listed template
+			for(int idx = tid; idx < VSLOTS * GROUP; idx += THREADS) {
+				const int g = idx & (GROUP - 1);
+				const uint32_t vi = v_id[idx];
+				if(vi == MISS) continue;
+				v_id[idx] = MISS;
+				uint32_t mw[MW];
+#pragma unroll
+				for(int w = 0; w < MW; ++w) { mw[w] = v_mask[w * VSLOTS * GROUP + idx]; v_mask[w * VSLOTS * GROUP + idx] = 0; }
+				if(g >= ng || s_over[g]) continue;
+				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
+				uint32_t cnt, el[7];
+				if(db.values_u16) {
+					const uint16_t *vp = db.values16 + vi;
+					cnt = vp[0];
+#pragma unroll
+					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+				} else {
+					const uint32_t *vp = db.values32 + vi;
+					cnt = vp[0];
+#pragma unroll
+					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
+				}
+				auto add_template = [&](const uint32_t t) -> bool {
+					const int slot = template_slot(t, g, t_id, t_cnt);
+					if(slot < 0) { s_over[g] = 1; return false; }
+#pragma unroll
+					for(int w = 0; w < MW; ++w) if(mw[w]) atomicOr(&t_mask[w * TSLOTS * GROUP + slot], mw[w]);
+					return true;
+				};
+				bool ok = true;
+#pragma unroll
+				for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
+				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+			}
 			__syncthreads();
 			// phase 2b: one thread per (item, template): fold the hit mask into the score
 #ifdef KMAHIP_DIAG
