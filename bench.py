@@ -195,6 +195,7 @@ def main():
         dt = time.perf_counter() - t0
         scan_ms, scan_n = db.get_timing(0)
         aln_ms, aln_n = db.get_timing(1)
+        pre_ms, pre_n = db.get_timing(2)
         db.set_timing(False)
         db.status(stream)
         if world > 1:
@@ -217,9 +218,14 @@ def main():
         W = (150 + 31) // 32
         scan_s = scan_ms / 1e3 / max(1, scan_n)
         aln_s = aln_ms / 1e3 / max(1, aln_n)
+        pre_s = pre_ms / 1e3 / max(1, pre_n)
         # SURVEY §8(d) algorithmic bytes.  scan: 12 B per probe (4 B directory + 4 B key + 4 B value index in the
         # reference layout) + 2 B per value-list element + packed read in + S2 fields out.
-        scan_bytes = 12 * st.probes + 2 * st.value_elems + n * (8 * W + 4 + 8) + n * (4 + 4 + 8) + 4 * total_T
+        # Stage 2 runs as two kernels: scan_prefilter_kernel (every k-th k-mer of both strands; reads in, active list
+        # out) and scan_se_kernel (all k-mer starts of the surviving strands; the rest of the bytes).
+        pre_bytes = 12 * st.prefilter_probes + n * (8 * W + 4 + 8) + 8 * st.active_strands
+        scan_bytes = (12 * (st.probes - st.prefilter_probes) + 2 * st.value_elems + st.active_strands * (8 * W + 4 + 8 + 8)
+                      + n * (4 + 4 + 8) + 4 * total_T)
         # align: 12 B per position-index lookup (4 B index + 8 B template word), 2 bits per MEM base on both
         # sequences, packed read in per task, 24 B out per task; DP cells move no HBM bytes (no E matrix)
         aln_bytes = 12 * ast.lookups + ast.mem_bases // 2 + ast.tasks * (8 * W + 24) + n * 12
@@ -268,8 +274,11 @@ def main():
                 "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes), "hash_probes": int(st.hash_probes),
-                         "GB/s": scan_bytes / scan_s / 1e9, "probes_per_s": st.probes / scan_s},
+                "prefilter": {"kernel_ms": pre_s * 1e3, "probes": int(st.prefilter_probes), "GB/s": pre_bytes / pre_s / 1e9,
+                              "active_strands": int(st.active_strands)},
+                "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes - st.prefilter_probes),
+                         "hash_probes": int(st.hash_probes - st.prefilter_probes),
+                         "GB/s": scan_bytes / scan_s / 1e9, "probes_per_s": (st.probes - st.prefilter_probes) / scan_s},
                 "align": {"kernel_ms": aln_s * 1e3, "lookups": int(ast.lookups), "dp_cells": int(ast.dp_cells),
                           "GCUPS": ast.dp_cells / aln_s / 1e9, "GB/s": aln_bytes / aln_s / 1e9,
                           "tasks_per_s": ast.tasks / aln_s},

@@ -215,6 +215,7 @@ typedef struct kmahip_scan_stats {
 	uint64_t value_elems;
 	uint64_t active_strands;
 	uint64_t hash_probes;
+	uint64_t prefilter_probes;   /* of probes / hash_probes: those issued by scan_prefilter_kernel */
 } kmahip_scan_stats;
 /* same for the last align call: template-index lookups, bases inside MEMs,
  * DP cells filled, (read, candidate) tasks aligned */
@@ -230,10 +231,10 @@ int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
 
 /* Kernel timing: when on, every *_dev call records a HIP event pair around its
- * two main kernels (scan_se_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
+ * main kernels (scan_prefilter_kernel, scan_se_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
  * for them, returns the summed milliseconds and launch count, and resets. */
 int kmahip_ws_set_timing(kmahip_ws *ws, int on);
-int kmahip_ws_get_timing(kmahip_ws *ws, int kernel /* 0 scan_se_kernel, 1 align_tasks_kernel */,
+int kmahip_ws_get_timing(kmahip_ws *ws, int kernel /* 0 scan_se_kernel, 1 align_tasks_kernel, 2 scan_prefilter_kernel */,
                          double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus

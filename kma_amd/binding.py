@@ -53,7 +53,7 @@ class PeRecs(C.Structure):
 
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
-                ("hash_probes", C.c_uint64)]
+                ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
 
 
 class AlignStats(C.Structure):
@@ -208,7 +208,7 @@ class KmaHipDB:
         _check(lib().kmahip_ws_set_timing(self.ws, int(on)))
 
     def get_timing(self, kernel=0):
-        """kernel 0 = scan_se_kernel, 1 = align_tasks_kernel -> (summed ms, launches)"""
+        """kernel 0 = scan_se_kernel, 1 = align_tasks_kernel, 2 = scan_prefilter_kernel -> (summed ms, launches)"""
         ms, n = C.c_double(), C.c_int64()
         _check(lib().kmahip_ws_get_timing(self.ws, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value

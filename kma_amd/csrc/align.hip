@@ -1270,7 +1270,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (6 * 4 + 8)));
 		ws->a_task_cap = tasks_cap;
 	}
-	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
 
 	AlignArgs A;

@@ -16,10 +16,10 @@ extern "C" int kmahip_ws_create(kmahip_db *db, kmahip_ws **out) {
 extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	if(!ws) return;
 	(void) hipFree(ws->item_score); (void) hipFree(ws->item_n); (void) hipFree(ws->item_off);
-	(void) hipFree(ws->pool); (void) hipFree(ws->counters); (void) hipFree(ws->overflow_items);
+	(void) hipFree(ws->pool); (void) hipFree(ws->counters); (void) hipFree(ws->overflow_items); (void) hipFree(ws->active_items);
 	(void) hipFree(ws->dense); (void) hipFree(ws->blk_sums);
 	for(int i = 0; i < 8; ++i) (void) hipFree(ws->stage[i]);
-	for(auto *ev : {ws->events, ws->events2}) {
+	for(auto *ev : {ws->events, ws->events2, ws->events3}) {
 		if(!ev) continue;
 		for(auto &e : *ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
 		delete ev;
@@ -57,10 +57,10 @@ extern "C" int kmahip_scan_set_stats(kmahip_ws *ws, int on) {
 
 extern "C" int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream) {
 	if(!ws || !st || !ws->counters) return KMAHIP_EINVAL;
-	unsigned long long c[8];
+	unsigned long long c[KMAHIP_N_COUNTERS];
 	HIP_TRY(hipMemcpyAsync(c, ws->counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t) stream));
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
-	st->probes = c[3]; st->value_elems = c[4]; st->active_strands = c[5]; st->hash_probes = c[6];
+	st->probes = c[3]; st->value_elems = c[4]; st->active_strands = c[5]; st->hash_probes = c[6]; st->prefilter_probes = c[9];
 	return KMAHIP_OK;
 }
 
@@ -193,9 +193,9 @@ extern "C" int kmahip_ws_set_timing(kmahip_ws *ws, int on) {
 }
 
 extern "C" int kmahip_ws_get_timing(kmahip_ws *ws, int kernel, double *total_ms, int64_t *launches) {
-	if(!ws || !total_ms || !launches || kernel < 0 || kernel > 1) return KMAHIP_EINVAL;
+	if(!ws || !total_ms || !launches || kernel < 0 || kernel > 2) return KMAHIP_EINVAL;
 	*total_ms = 0.0; *launches = 0;
-	auto *ev = kernel ? ws->events2 : ws->events;
+	auto *ev = kernel == 0 ? ws->events : kernel == 1 ? ws->events2 : ws->events3;
 	if(!ev) return KMAHIP_OK;
 	for(auto &e : *ev) {
 		float ms = 0.f;

@@ -9,6 +9,7 @@
 
 #define KMAHIP_EMPTY_VI 0xFFFFFFFFu
 #define KMAHIP_BUCKET_SLOTS 4
+#define KMAHIP_N_COUNTERS 16      // device counter words per workspace
 
 // Probe table in HBM: open hashing over 32-byte buckets of 4 (key, position)
 // slots. bucket(key) = (key * GOLD) >> (32 - nb_log2); a key lives in the first
@@ -64,13 +65,16 @@ struct kmahip_ws {
 	int32_t *pool;
 	int64_t pool_cap;
 	int64_t pool_scale;       // pool = cap_reads * 16 * pool_scale ints; doubled after an overflow
-	// counters: [0] pool top, [1] status, [2] n_overflow, [3] probes, [4] value elems, [5] active strands
+	// counters (16): [0] pool top, [1] status, [2] n_overflow, [3] probes, [4] value elems, [5] active strands,
+	// [6] hash probes, [7] pair pool top, [8] active strand items, [9] prefilter probes
 	unsigned long long *counters;
 	int64_t *overflow_items;
+	int64_t *active_items;    // strand items that passed the prefilter (device-wide compaction)
 	int stats_on;
 	int timing_on;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events2;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events3;   // prefilter kernel
 	// paired-end stage 2
 	int32_t *pool_sc, *ppool;
 	void *pe_rec;

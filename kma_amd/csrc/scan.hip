@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int ITEMS = 32;             // (read, strand) items per workgroup
+
 constexpr int GROUP = 16;             // active items scored together
 constexpr int THREADS = 256;
 constexpr int CHUNK = 136;            // k-mer start positions per pass
@@ -59,12 +59,13 @@ struct ScanArgs {
 	int64_t *overflow_items;
 	int32_t *dense;
 	int64_t dense_slots;
+	int64_t *active_items; // strand items that passed the prefilter, in no particular order (counters[C_NACT] of them)
 	int64_t pool_tail0;  // pool[0 .. pool_tail0) = INL inline slots per strand item; longer lists are bump-allocated after it
 	int mode;            // 0: best templates per strand (save_kmers); 1: every candidate + score + hit count (get_kmers_for_pair)
 	int32_t *pool_sc;    // mode 1: scores parallel to pool
 };
 
-enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6 };
+enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6, C_PPOOL = 7, C_NACT = 8, C_PREF = 9, N_COUNTERS = KMAHIP_N_COUNTERS };
 
 __device__ __forceinline__ uint32_t probe(const DevDB &db, uint32_t key) {
 	const uint32_t sh = 32u - db.nb_log2;
@@ -196,12 +197,101 @@ __device__ __forceinline__ void expand_list(const DevDB &db, uint32_t vi, int rs
 	}
 }
 
+// ---- prefilter (savekmers.c:2477-2495): every k-th k-mer of every N-free segment of both strands is probed by
+// 8 adjacent lanes per strand item; a strand with no hit is finished (no candidates), the others are appended to
+// the device-wide list of active items, so that the scan kernel below only ever sees full groups of live items.
+// One workgroup filters PF_ITEMS items and appends its survivors with a single global atomic.
+constexpr int PF_PLANES = 8;                               // lanes sharing one item's probes
+constexpr int PF_BLOCK = THREADS / PF_PLANES;              // items per round
+constexpr int PF_ROUNDS = 16;
+constexpr int PF_ITEMS = PF_BLOCK * PF_ROUNDS;             // items per workgroup
+
+template <bool STATS>
+__global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs A) {
+	__shared__ int64_t s_list[PF_ITEMS];
+	__shared__ uint32_t s_n, s_np;
+	__shared__ unsigned long long s_base;
+	const DevDB &db = A.db;
+	const int tid = threadIdx.x;
+	const int k = (int) db.kmersize;
+	const int plane = tid & (PF_PLANES - 1);
+	if(tid == 0) { s_n = 0; s_np = 0; }
+	__syncthreads();
+	uint32_t nprobe = 0;
+	for(int rd = 0; rd < PF_ROUNDS; ++rd) {
+		const int64_t item = (int64_t) blockIdx.x * PF_ITEMS + rd * PF_BLOCK + (tid / PF_PLANES);
+		const int64_t r = item >> 1;
+		bool hit = false;
+		if(r < A.n_reads) {
+			const int L = A.len[r], strand = (int) (item & 1), npos = L - k + 1;
+			if(npos > 0) {
+				const uint64_t *rs = A.seq + A.seq_off[r];
+				const int64_t no = A.N_off[r];
+				const int nN = (int) (A.N_off[r + 1] - no);
+#ifdef KMAHIP_DIAG
+				if(A.exhaustive || (A.ablate & 4)) {
+#else
+				if(A.exhaustive) {
+#endif
+					hit = strand == 0 || A.exhaustive;
+				} else if(nN == 0) {
+					for(int j = plane * k; j < npos; j += PF_PLANES * k) {
+						const int q = strand ? (L - k - j) : j;
+						uint64_t km = kmer_from(rs[q >> 5], rs[(q >> 5) + 1], q, k);
+						if(strand) km = revcomp_kmer(km, k);
+						++nprobe;
+						if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
+					}
+				} else if(plane == 0) {
+					// rare: walk the N-free segments exactly like savekmers.c:2483-2495
+					const int32_t *Nl = A.N + no;
+					int j = 0;
+					for(int i = 1; i <= nN + 1 && !hit; ++i) {
+						const int segend = n_strand(Nl, nN, L, strand, i);
+						for(; j < segend - k + 1 && !hit; j += k) {
+							const int q = strand ? (L - k - j) : j;
+							const int w = q >> 5;
+							uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
+							if(strand) km = revcomp_kmer(km, k);
+							++nprobe;
+							if(probe(db, (uint32_t) km) != MISS) hit = true;
+						}
+						j = segend + 1;
+					}
+				}
+			}
+		}
+		// OR over the 8 lanes of the item (they sit next to each other in one wavefront)
+		const unsigned long long bal = __ballot(hit);
+		const bool any = ((bal >> ((tid & 63) & ~(PF_PLANES - 1))) & ((1ull << PF_PLANES) - 1ull)) != 0ull;
+		if(plane == 0 && r < A.n_reads) {
+			if(any) s_list[atomicAdd(&s_n, 1u)] = item;
+			else { A.item_score[item] = 0; A.item_n[item] = 0; A.item_off[item] = 0; }
+		}
+	}
+	if(STATS && nprobe) atomicAdd(&s_np, nprobe);
+	__syncthreads();
+	const uint32_t nact = s_n;
+	if(tid == 0) {
+		s_base = nact ? atomicAdd(&A.counters[C_NACT], (unsigned long long) nact) : 0ull;
+		if(STATS) {
+			atomicAdd(&A.counters[C_PROBES], (unsigned long long) s_np);
+			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_np);
+			atomicAdd(&A.counters[C_PREF], (unsigned long long) s_np);
+			atomicAdd(&A.counters[C_ACTIVE], (unsigned long long) nact);
+		}
+	}
+	__syncthreads();
+	for(uint32_t i = tid; i < nact; i += THREADS) A.active_items[s_base + i] = s_list[i];
+}
+
+// ---- scan: one workgroup = GROUP active strand items, 16 lanes each ----------------------------------------
 template <bool STATS, int MODE>
 __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
 	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
-	// forward words: if every read of the workgroup fits in SW-1 words they are staged ONCE per read (index = read)
-	// and serve the prefilter and all passes; otherwise (s_anylong) per pass and group item (index = group slot)
+	// forward words: if every read of the group fits in SW-1 words they are staged ONCE and serve all passes;
+	// otherwise (s_anylong) they are staged per pass
 	__shared__ uint64_t w_lds[GROUP * SW];
 	__shared__ int32_t s_anylong;
 	__shared__ uint32_t t_id[TSLOTS * GROUP];
@@ -210,99 +300,45 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ int32_t t_last[TSLOTS * GROUP];
 	__shared__ int32_t t_first[TSLOTS * GROUP];
 	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_wbase[GROUP], s_hits[GROUP];
-	__shared__ int32_t s_len[ITEMS], s_nN[ITEMS], s_alist[ITEMS];
-	__shared__ int64_t s_soff[ITEMS], s_noff[ITEMS];
-	__shared__ uint32_t s_active[2];
-	__shared__ int32_t s_nact, s_gmax;
+	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
+	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
+	__shared__ int32_t s_gmax;
 	__shared__ uint32_t s_stats[3];   // [0] k-mer starts resolved (= probes of the reference), [1] list elements, [2] hash probes
 
 	const DevDB &db = A.db;
 	const int tid = threadIdx.x;
 	const int k = (int) db.kmersize;
-	const int64_t item0 = (int64_t) blockIdx.x * ITEMS;
+	const int64_t n_active = (int64_t) A.counters[C_NACT];
+	const int64_t first = (int64_t) blockIdx.x * GROUP;
+	if(first >= n_active) return;
+	const int ng = (int) min((int64_t) GROUP, n_active - first);
 
-	if(tid < ITEMS) {
-		const int64_t r = (item0 + tid) >> 1;
-		int L = 0, nN = 0; int64_t so = 0, no = 0;
-		if(r < A.n_reads) {
+	if(tid < GROUP) {
+		int L = 0, nN = 0; int64_t so = 0, no = 0, it = 0;
+		if(tid < ng) {
+			it = A.active_items[first + tid];
+			const int64_t r = it >> 1;
 			L = A.len[r]; so = A.seq_off[r]; no = A.N_off[r]; nN = (int) (A.N_off[r + 1] - no);
 		}
-		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no;
+		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no; s_item[tid] = it;
 	}
-	if(tid < 2) s_active[tid] = 0;
 	if(tid < 3) s_stats[tid] = 0;
-	if(tid == 0) s_anylong = 0;
+	if(tid == 0) { s_anylong = 0; s_gmax = 0; }
 	__syncthreads();
-	if(tid < ITEMS / 2 && s_len[2 * tid] > (SW - 1) * 32) s_anylong = 1;
+	if(tid < ng) {
+		if(s_len[tid] > (SW - 1) * 32) s_anylong = 1;
+		atomicMax(&s_gmax, s_len[tid] - k + 1);
+	}
 	__syncthreads();
 	const bool staged_once = !s_anylong;
+	const int gmax = s_gmax;
 	if(staged_once) {
-		for(int idx = tid; idx < (ITEMS / 2) * SW; idx += THREADS) {
-			const int rr = idx / SW, w = idx - rr * SW;
-			const int L = s_len[2 * rr];
-			w_lds[idx] = (w < ((L + 31) >> 5)) ? A.seq[s_soff[2 * rr] + w] : 0ull;
+		for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
+			const int g = idx / SW, w = idx - g * SW;
+			const int L = s_len[g];
+			w_lds[idx] = (w < ((L + 31) >> 5)) ? A.seq[s_soff[g] + w] : 0ull;
 		}
-		__syncthreads();
 	}
-
-	// ---- phase 0: prefilter (savekmers.c:2477-2495) -------------------------------
-	{
-		constexpr int PLANES = THREADS / ITEMS;     // lanes sharing one item's prefilter probes
-		const int a = tid & (ITEMS - 1), slot = tid / ITEMS;
-		const int L = s_len[a], nN = s_nN[a], strand = a & 1, npos = L - k + 1;
-		bool hit = false;
-		uint32_t nprobe = 0;
-		if(npos > 0) {
-			const uint64_t *rs = A.seq + s_soff[a];
-#ifdef KMAHIP_DIAG
-			if(A.exhaustive || (A.ablate & 4)) {
-#else
-			if(A.exhaustive) {
-#endif
-				hit = (a & 1) == 0 || A.exhaustive;
-			} else if(nN == 0) {
-				const uint64_t *wsrc = staged_once ? &w_lds[(a >> 1) * SW] : rs;
-				for(int j = slot * k; j < npos; j += PLANES * k) {
-					const int q = strand ? (L - k - j) : j;
-					uint64_t km = kmer_from(wsrc[q >> 5], wsrc[(q >> 5) + 1], q, k);
-					if(strand) km = revcomp_kmer(km, k);
-					++nprobe;
-					if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
-				}
-			} else if(slot == 0) {
-				// rare: walk the N-free segments exactly like savekmers.c:2483-2495
-				const int32_t *Nl = A.N + s_noff[a];
-				int j = 0;
-				for(int i = 1; i <= nN + 1 && !hit; ++i) {
-					const int segend = n_strand(Nl, nN, L, strand, i);
-					for(; j < segend - k + 1 && !hit; j += k) {
-						const int q = strand ? (L - k - j) : j;
-						const int w = q >> 5;
-						uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
-						if(strand) km = revcomp_kmer(km, k);
-						++nprobe;
-						if(probe(db, (uint32_t) km) != MISS) hit = true;
-					}
-					j = segend + 1;
-				}
-			}
-		}
-		if(hit) atomicOr(&s_active[a >> 5], 1u << (a & 31));
-		if(STATS && nprobe) { atomicAdd(&s_stats[0], nprobe); atomicAdd(&s_stats[2], nprobe); }
-	}
-	__syncthreads();
-	const uint64_t active = ((uint64_t) s_active[1] << 32) | s_active[0];
-	// compact the active items; inactive ones are finished (no candidates)
-	if(tid < ITEMS) {
-		const bool act = (active >> tid) & 1ull;
-		if(act) s_alist[__popcll(active & ((1ull << tid) - 1ull))] = tid;
-		else if(((item0 + tid) >> 1) < A.n_reads) {
-			A.item_score[item0 + tid] = 0; A.item_n[item0 + tid] = 0; A.item_off[item0 + tid] = 0;
-		}
-		if(tid == 0) s_nact = __popcll(active);
-	}
-	__syncthreads();
-	const int nact = s_nact;
 
 	// Scores are computed per template, not per position: the score machine of save_kmers
 	// (savekmers.c:2511-2706) gives template t   k*M  at its first hit and  bridge(p - 1 - last_t)
@@ -310,8 +346,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	// set changes are only how the reference walks that sum. So every (item, run of equal sets)
 	// ORs its position range into the bitmask of each template of the set, and every
 	// (item, template) then folds its own bitmask -- no serial walk over the positions.
-	for(int g0 = 0; g0 < nact; g0 += GROUP) {
-		const int ng = min(GROUP, nact - g0);
+	{
 		for(int idx = tid; idx < TSLOTS * GROUP; idx += THREADS) {
 			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN; t_last[idx] = 0; t_first[idx] = 0;
 #pragma unroll
@@ -323,11 +358,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
 		}
 		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; }
-		if(tid == 0) s_gmax = 0;
 		__syncthreads();
-		if(tid < ng) atomicMax(&s_gmax, s_len[s_alist[g0 + tid]] - k + 1);
-		__syncthreads();
-		const int gmax = s_gmax;
 
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
 			// stage the forward words of this pass (only workgroups holding a read too long to be staged once)
@@ -336,15 +367,14 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 					const int g = idx / SW, w = idx - g * SW;
 					uint64_t v = 0;
 					if(g < ng) {
-						const int a = s_alist[g0 + g];
-						const int L = s_len[a], npos = L - k + 1;
+						const int L = s_len[g], npos = L - k + 1;
 						int lo = c0;
-						if(a & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
+						if(s_item[g] & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
 						if(lo < 0) lo = 0;
 						const int wb = lo >> 5;
 						if(w == 0) s_wbase[g] = wb;
 						const int words = (L + 31) >> 5;
-						if(wb + w < words) v = A.seq[s_soff[a] + wb + w];
+						if(wb + w < words) v = A.seq[s_soff[g] + wb + w];
 					}
 					w_lds[idx] = v;
 				}
@@ -364,17 +394,16 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				const int g = tid & (GROUP - 1), sl = tid / GROUP;
 				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
 				if(g < ng) {
-					const int a = s_alist[g0 + g];
-					const int L = s_len[a], npos = L - k + 1, strand = a & 1, nN = s_nN[a];
-					const uint64_t *rw = A.seq + s_soff[a];
-					const int32_t *Nl = A.N + s_noff[a];
+					const int L = s_len[g], npos = L - k + 1, strand = (int) (s_item[g] & 1), nN = s_nN[g];
+					const uint64_t *rw = A.seq + s_soff[g];
+					const int32_t *Nl = A.N + s_noff[g];
 					int jj = j0, hc = 0;
 					while(jj < j1) {
 						const int p = c0 + jj;
 						if(p >= npos) break;
 						const int q = strand ? (L - k - p) : p;
 						if(nN && window_has_N(Nl, nN, q, k)) { ++jj; continue; }
-						const uint64_t *wsrc = staged_once ? &w_lds[(a >> 1) * SW] : &w_lds[g * SW];
+						const uint64_t *wsrc = &w_lds[g * SW];
 						const int w = (q >> 5) - (staged_once ? 0 : s_wbase[g]);
 						uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], q, k);
 						if(strand) km = revcomp_kmer(km, k);
@@ -521,8 +550,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 
 		// ---- finish the items of this group: getBestMatch (savekmers.c:273-294) ---------
 		if(tid < ng) {
-			const int g = tid, a = s_alist[g0 + g];
-			const int64_t item = item0 + a;
+			const int g = tid;
+			const int64_t item = s_item[g];
 			int best = 0, nb = 0;
 			int64_t off = 0;
 #ifdef KMAHIP_DIAG
@@ -596,7 +625,6 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 		if(tid == 0) {
 			atomicAdd(&A.counters[C_PROBES], (unsigned long long) s_stats[0]);
 			atomicAdd(&A.counters[C_VALS], (unsigned long long) s_stats[1]);
-			atomicAdd(&A.counters[C_ACTIVE], (unsigned long long) __popcll(active));
 			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_stats[2]);
 		}
 	}
@@ -833,7 +861,7 @@ __global__ __launch_bounds__(256) void pair_penalty_kernel(const PairArgs P) {
 	const int64_t need = (int64_t) max(n1, n2) + n2;
 	int64_t base = 0;
 	if(need) {
-		base = (int64_t) atomicAdd(&A.counters[7], (unsigned long long) need);
+		base = (int64_t) atomicAdd(&A.counters[C_PPOOL], (unsigned long long) need);
 		if(base + need > P.ppool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); return; }
 	}
 	int32_t *regT = P.ppool + base, *bT = regT + max(n1, n2);
@@ -986,9 +1014,9 @@ static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 	kmahip_db *db = ws->db;
 	if(n_reads > ws->cap_reads) {
 		(void) hipFree(ws->item_score); (void) hipFree(ws->item_n); (void) hipFree(ws->item_off);
-		(void) hipFree(ws->pool); (void) hipFree(ws->overflow_items); (void) hipFree(ws->blk_sums);
+		(void) hipFree(ws->pool); (void) hipFree(ws->overflow_items); (void) hipFree(ws->blk_sums); (void) hipFree(ws->active_items);
 		ws->item_score = ws->item_n = nullptr; ws->item_off = nullptr; ws->pool = nullptr;
-		ws->overflow_items = nullptr; ws->blk_sums = nullptr;
+		ws->overflow_items = nullptr; ws->blk_sums = nullptr; ws->active_items = nullptr;
 		const int64_t cap = n_reads + n_reads / 8 + 1024;
 		HIP_TRY(hipMalloc((void **) &ws->item_score, cap * 2 * sizeof(int32_t)));
 		HIP_TRY(hipMalloc((void **) &ws->item_n, cap * 2 * sizeof(int32_t)));
@@ -997,11 +1025,12 @@ static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 		ws->pool_cap = cap * 16 * ws->pool_scale;
 		HIP_TRY(hipMalloc((void **) &ws->pool, ws->pool_cap * sizeof(int32_t)));
 		HIP_TRY(hipMalloc((void **) &ws->overflow_items, cap * 2 * sizeof(int64_t)));
+		HIP_TRY(hipMalloc((void **) &ws->active_items, cap * 2 * sizeof(int64_t)));
 		ws->blk_cap = (cap + CB - 1) / CB + 1;
 		HIP_TRY(hipMalloc((void **) &ws->blk_sums, ws->blk_cap * sizeof(int64_t)));
 		ws->cap_reads = cap;
 	}
-	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, 8 * sizeof(unsigned long long))); }
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, N_COUNTERS * sizeof(unsigned long long))); }
 	if(!ws->dense) {
 		// overflow scratch: up to 4096 concurrent items, bounded to 1 GiB
 		int64_t slots = 4096;
@@ -1027,7 +1056,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.exhaustive = p->exhaustive;
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
-	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
+	A.dense = ws->dense; A.dense_slots = ws->dense_slots; A.active_items = ws->active_items;
 	A.mode = 0; A.pool_sc = nullptr; A.pool_tail0 = 2 * n * INL;
 	A.ablate = 0;
 #ifdef KMAHIP_DIAG
@@ -1035,24 +1064,30 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 #endif
 	// word 1 (status) is sticky until kmahip_ws_status reads it
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
-	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
 	if(n == 0) {
 		HIP_TRY(hipMemsetAsync(out->T_off, 0, sizeof(int64_t), stream));
 		return KMAHIP_OK;
 	}
 	const int64_t items = 2 * n;
-	const unsigned grid = (unsigned) ((items + ITEMS - 1) / ITEMS);
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	const unsigned pgrid = (unsigned) ((items + PF_ITEMS - 1) / PF_ITEMS);
+	const unsigned grid = (unsigned) ((items + GROUP - 1) / GROUP);      // scan: upper bound; workgroups past the active count exit
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, evp = nullptr, evq = nullptr;
 	if(ws->timing_on) {
-		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
-		HIP_TRY(hipEventRecord(ev0, stream));
+		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventCreate(&evp)); HIP_TRY(hipEventCreate(&evq));
+		HIP_TRY(hipEventRecord(evp, stream));
 	}
+	if(ws->stats_on) hipLaunchKernelGGL((scan_prefilter_kernel<true>), dim3(pgrid), dim3(THREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3(pgrid), dim3(THREADS), 0, stream, A);
+	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
 	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
 	else hipLaunchKernelGGL((scan_se_kernel<false, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
 		ws->events->push_back({ev0, ev1});
+		if(!ws->events3) ws->events3 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+		ws->events3->push_back({evp, evq});
 	}
 	{
 		const unsigned dgrid = (unsigned) ((ws->dense_slots + 63) / 64);
@@ -1087,12 +1122,13 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.exhaustive = p->exhaustive;
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
-	A.dense = ws->dense; A.dense_slots = ws->dense_slots;
+	A.dense = ws->dense; A.dense_slots = ws->dense_slots; A.active_items = ws->active_items;
 	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc; A.pool_tail0 = 0;
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
-	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
-	const unsigned grid = (unsigned) ((2 * n + ITEMS - 1) / ITEMS);
+	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
+	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
 	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(THREADS), 0, stream, A);
 	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ((ws->dense_slots + 63) / 64)), dim3(64), 0, stream, A);
 	PairArgs P;

@@ -42,14 +42,16 @@ def run(scan_abl, align_abl, reps=3):
     torch.cuda.synchronize()
     s_ms, s_n = db.get_timing(0)
     a_ms, a_n = db.get_timing(1)
-    return (s_ms / max(1, s_n), a_ms / max(1, a_n))
+    p_ms, p_n = db.get_timing(2)
+    return (s_ms / max(1, s_n), a_ms / max(1, a_n), p_ms / max(1, p_n))
 
 
 print(f"reads {n}")
 for name, sa in (("scan full", 0), ("scan no-machines", 1), ("scan no-probe(phase1)", 2), ("scan no-prefilter-probe", 4),
                  ("scan no-probe no-machines", 3), ("scan nothing", 7), ("scan no-2b", 8), ("scan no-finish", 16),
                  ("scan 2a loads only", 32), ("scan no-2b no-finish", 24), ("scan 2a-loads-only no-2b no-finish", 56)):
-    print(f"{name:32s} {run(sa, -1)[0]:8.2f} ms")
+    t = run(sa, -1)
+    print(f"{name:32s} {t[0] + t[2]:8.2f} ms  (prefilter {t[2]:.2f} + scan {t[0]:.2f})")
 run(0, -1)  # restore real candidates
 for name, aa in (("align full", 0), ("align no-DP", 1), ("align no-wide(q>16)", 8), ("align no-1x1", 16), ("align no-2..16", 32),
                  ("align only-1x1", 40), ("align only-2..16", 24), ("align only-wide", 48), ("align no-coop", 64), ("align no-chain+", 4), ("align no-seed+", 2)):

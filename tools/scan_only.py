@@ -37,4 +37,5 @@ for _ in range(reps):
 torch.cuda.synchronize()
 s_ms, s_n = db.get_timing(0)
 a_ms, a_n = db.get_timing(1)
-print(f"reads {n}: scan {s_ms / max(1, s_n):.3f} ms x{s_n}, align {a_ms / max(1, a_n):.3f} ms x{a_n}")
+p_ms, p_n = db.get_timing(2)
+print(f"reads {n}: prefilter {p_ms / max(1, p_n):.3f} ms x{p_n}, scan {s_ms / max(1, s_n):.3f} ms x{s_n}, align {a_ms / max(1, a_n):.3f} ms x{a_n}")
