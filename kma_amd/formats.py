@@ -150,6 +150,12 @@ class CompDB:
     flag: int
 
 
+def read_lengths(prefix) -> np.ndarray:
+    """<prefix>.length.b -> template_lengths[DB_size] (int32; entry 0 = the index's k-mer count slot)."""
+    raw = np.fromfile(prefix + ".length.b", dtype=np.int32)
+    return raw[1:1 + int(raw[0])].copy()
+
+
 def read_comp_b(path) -> CompDB:
     b = open(path, "rb").read()
     DB_size, mlen, prefix_len = struct.unpack_from("<3I", b, 0)

@@ -116,6 +116,17 @@ int orc_align_pe(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
                 int band, const orc_rewards *rw, int out[6]);
 
+/* stage 3b: ConClave template choice per frag_raw record (runConClave, conclave.c:43-215) and the leading
+ * columns of the `.res` rows (runkma.c:608-613, 765-783; p_chisqr stdstat.c:136-147). See conclave.c. */
+int orc_conclave(int64_t n_rec, const int32_t *n_hits, const int32_t *read_score, const int32_t *q_len, const int32_t *q_len2,
+                 const int64_t *off, const int32_t *tmpl, const int32_t *start, const int32_t *end,
+                 const uint64_t *alignment_scores, const uint64_t *uniq_alignment_scores, const int32_t *template_lengths,
+                 int32_t *out_tmpl, int32_t *out_start, int32_t *out_end,
+                 uint64_t *w_scores, uint32_t *fragmentCounts, uint32_t *readCounts, uint64_t *depth);
+double orc_p_chisqr(long double q);
+int orc_res_stats(int DB_size, const uint64_t *w_scores, const int32_t *template_lengths, double evalue, double scoreT,
+                  double *expected, double *q_value, double *p_value, int32_t *significant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,3 +146,65 @@ def pe_stream_from(g, scan_pair, scan_single, rc_packed):
                     words, N = rc_packed(r["seq"], r["seqlen"], r["N"])
                 out += s2_record_bytes(r["seqlen"], words, N, int(rec["rc_flag"]), rec["T"], r["hdr"], int(rec["flag"]))
     return out + struct.pack("<i", -len(g["units"]))
+
+
+def load_res(name="se"):
+    """`.res` rows of the full reference run: template name -> (Score, Expected, Template_length, q_value, p_value) with
+    the last two kept as printed ("%8.2f", "%4.1e", runkma.c:809)."""
+    out = {}
+    with open(os.path.join(GOLD, name, "out.res")) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            c = [x.strip() for x in line.rstrip("\n").split("\t")]
+            out[c[0]] = (int(c[1]), int(c[2]), int(c[3]), c[9], c[10])
+    return out
+
+
+def load_frags(name="se"):
+    """`.frag.gz` rows: header -> (number of equally good templates, template name). Score / start / end of these rows come
+    from the stage-3c re-alignment (assembly.c:1940-1965), not from ConClave, and are not used."""
+    out = {}
+    if not os.path.exists(os.path.join(GOLD, name, "out.frag.gz")):
+        return None
+    with gzip.open(os.path.join(GOLD, name, "out.frag.gz"), "rt") as f:
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            out[c[6]] = (int(c[1]), c[5])
+    return out
+
+
+def template_names(name="se"):
+    with open(os.path.join(GOLD, name, "db.name")) as f:
+        return [l.rstrip("\n") for l in f]
+
+
+def check_conclave_against_outputs(name, headers, n_hits, picked, w_scores, stats, tlen):
+    """Stage 3b vs the reference's final files: every `.frag.gz` row names the template ConClave gave the read and the
+    number of templates it tied over; every `.res` row opens with Score (= w_scores), Expected, Template_length and
+    closes with q_value, p_value. Rows exist only for significant templates that also pass the consensus-identity gate of
+    stage 3c, so the `.res` templates must be a subset of ours."""
+    names = template_names(name)
+    frags = load_frags(name)
+    res = load_res(name)
+    seen = 0
+    for i, h in enumerate(headers if frags is not None else []):
+        e = frags.get(h)
+        if e is None:
+            continue
+        seen += 1
+        assert int(n_hits[i]) == e[0], (h, e, int(n_hits[i]))
+        assert names[abs(int(picked[i])) - 1] == e[1], (h, e, int(picked[i]))
+    assert frags is None or seen == len(frags)
+    rows = 0
+    for t in range(1, len(tlen)):
+        if w_scores[t] == 0:
+            continue
+        nm = names[t - 1]
+        if nm in res:
+            rows += 1
+            assert stats["significant"][t], nm
+            got = (int(w_scores[t]), int(stats["expected"][t]), int(tlen[t]), "%.2f" % stats["q_value"][t], "%4.1e" % stats["p_value"][t])
+            assert got == res[nm], (nm, got, res[nm])
+    assert rows == len(res)
+    return seen, rows

@@ -165,6 +165,38 @@ class OracleDB:
         return ret, out
 
 
+def conclave(n_hits, read_score, q_len, q_len2, off, tmpl, start, end, alignment_scores, uniq, tlen):
+    """Stage 3b on arrays -> dict(tmpl, start, end per record; w_scores, fragmentCounts, readCounts, depth per template)."""
+    n = len(n_hits)
+    D = len(tlen)
+    i32 = lambda x: np.ascontiguousarray(x, np.int32)
+    pad = lambda x: i32(x if len(x) else np.zeros(1, np.int32))
+    out = dict(tmpl=np.zeros(n, np.int32), start=np.zeros(n, np.int32), end=np.zeros(n, np.int32),
+               w_scores=np.zeros(D, np.uint64), fragmentCounts=np.zeros(D, np.uint32), readCounts=np.zeros(D, np.uint32),
+               depth=np.zeros(D, np.uint64))
+    L = lib()
+    L.orc_conclave.restype = C.c_int
+    L.orc_conclave.argtypes = [C.c_int64] + [C.c_void_p] * 18
+    a = [i32(n_hits), i32(read_score), i32(q_len), i32(q_len2), np.ascontiguousarray(off, np.int64), pad(tmpl), pad(start),
+         pad(end), np.ascontiguousarray(alignment_scores, np.uint64), np.ascontiguousarray(uniq, np.uint64), i32(tlen)]
+    rc = L.orc_conclave(n, *[_p(x) for x in a], _p(out["tmpl"]), _p(out["start"]), _p(out["end"]), _p(out["w_scores"]),
+                        _p(out["fragmentCounts"]), _p(out["readCounts"]), _p(out["depth"]))
+    assert rc == 0, "ConClave found no template for a multi-hit record"
+    return out
+
+
+def res_stats(w_scores, tlen, evalue=0.05, scoreT=0.5):
+    """-> dict(expected (as printed), q_value, p_value, significant) per template (runkma.c:765-783)."""
+    D = len(tlen)
+    out = dict(expected=np.zeros(D), q_value=np.zeros(D), p_value=np.zeros(D), significant=np.zeros(D, np.int32))
+    L = lib()
+    L.orc_res_stats.restype = C.c_int
+    L.orc_res_stats.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 4
+    L.orc_res_stats(D, _p(np.ascontiguousarray(w_scores, np.uint64)), _p(np.ascontiguousarray(tlen, np.int32)), evalue, scoreT,
+                    _p(out["expected"]), _p(out["q_value"]), _p(out["p_value"]), _p(out["significant"]))
+    return out
+
+
 def rc_packed(seq, length, N):
     """compdna.c:228-256 on numpy arrays -> (rc words, rc N positions)."""
     words = (length + 31) // 32

@@ -142,3 +142,42 @@ def test_oracle_pe_align_matches_frag_raw_tap(golden_pe):
     assert len(exp) == len(tap)
     assert kinds[1] > 500
     pe_util.compare_lines(exp, tap)
+
+
+def _oracle_conclave_se(g):
+    db = oracle.OracleDB(g["prefix"])
+    b = g["batch"]
+    rc_flag, flag, T_off, T = db.scan_se(b)
+    res = db.align_se(b, rc_flag, flag, T_off, T)
+    tlen = formats.read_lengths(g["prefix"])
+    cc = oracle.conclave(res["n_hits"], res["best_score"], b.length, np.zeros(b.n, np.int32), T_off[:-1], res["tmpl"],
+                         res["start"], res["end"], res["alignment_scores"], res["uniq_alignment_scores"], tlen)
+    st = oracle.res_stats(cc["w_scores"], tlen)
+    return res, cc, st, tlen
+
+
+def test_oracle_conclave_matches_res_and_frags(golden_se):
+    """Stage 3b restatement vs the reference's own `.res` and `.frag.gz` (full pipeline run, tests/golden/se)."""
+    res, cc, st, tlen = _oracle_conclave_se(golden_se)
+    hdrs = [r["hdr"].rstrip(b"\0").decode() for r in golden_se["s1"]]
+    seen, rows = golden_util.check_conclave_against_outputs("se", hdrs, res["n_hits"], cc["tmpl"], cc["w_scores"], st, tlen)
+    assert seen > 900 and rows > 50
+
+
+def test_oracle_conclave_matches_res_and_frags_long_reads(golden_long):
+    res, cc, st, tlen = _oracle_conclave_se(golden_long)
+    hdrs = [r["hdr"].rstrip(b"\0").decode() for r in golden_long["s1"]]
+    seen, rows = golden_util.check_conclave_against_outputs("long", hdrs, res["n_hits"], cc["tmpl"], cc["w_scores"], st, tlen)
+    assert rows > 0      # this fixture holds the `.res` only
+
+
+def test_oracle_conclave_matches_res_paired(golden_pe):
+    """`-ipe ... -apm p`: a proper pair is ONE ConClave record whose score counts once (conclave.c:147, 171-175)."""
+    import pe_util
+    r = pe_util.oracle_pe_conclave_records(golden_pe)
+    tlen = formats.read_lengths(golden_pe["prefix"])
+    cc = oracle.conclave(r["n_hits"], r["score"], r["q_len"], r["q_len2"], r["off"], r["tmpl"], r["start"], r["end"],
+                         r["alignment_scores"], r["uniq_alignment_scores"], tlen)
+    st = oracle.res_stats(cc["w_scores"], tlen)
+    seen, rows = golden_util.check_conclave_against_outputs("pe", [], r["n_hits"], cc["tmpl"], cc["w_scores"], st, tlen)
+    assert rows > 50
