@@ -196,6 +196,59 @@ int kmahip_align_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 int kmahip_map_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                   kmahip_cands *cands_out, kmahip_hits *hits_out);
 
+/* Stage 3b, ConClave (runConClave, conclave.c:43-215, `-ConClave 1`): ONE template per frag_raw record, chosen from the
+ * templates the read aligned equally well to by (alignment_scores, alignment_scores / template_length,
+ * uniq_alignment_scores, smaller id). Inputs are the outputs of kmahip_align_se_dev / kmahip_align_pe_dev (device
+ * pointers; with several GPUs AFTER kmahip_allreduce_scores). Per record slot (SE: read i; PE: record slot r, a proper
+ * pair being the record of its second slot): the chosen signed template (0 = nothing written for the slot), its start
+ * and end. Per template, ADDED into caller-zeroed vectors: w_scores (the Score column of `.res`, conclave.c:147),
+ * fragment / read counts (:148-151, 172-174) and the summed read lengths (Depth under `-sasm`, assembly.c:1280).
+ * With several GPUs these four are summed over ranks afterwards (kmahip_allreduce_scores takes any
+ * two u64 vectors). */
+typedef struct kmahip_conclave {
+	int32_t *tmpl;               /* n slots */
+	int32_t *start;
+	int32_t *end;
+	uint64_t *w_scores;          /* DB_size */
+	uint32_t *fragment_counts;   /* DB_size, may be NULL */
+	uint32_t *read_counts;       /* DB_size, may be NULL */
+	uint64_t *depth;             /* DB_size, may be NULL */
+} kmahip_conclave;
+int kmahip_conclave_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                           const kmahip_hits *hits, kmahip_conclave *out, void *stream);
+int kmahip_conclave_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                           const kmahip_hits *hits, const int32_t *pe_kind, kmahip_conclave *out, void *stream);
+/* the same with host buffers in and out (only reads->n_reads / len are used of `reads`; the per-template vectors of
+ * `out` are read, added to and written back) */
+int kmahip_conclave_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
+                       const kmahip_hits *hits, kmahip_conclave *out);
+int kmahip_conclave_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
+                       const kmahip_hits *hits, const int32_t *pe_kind, kmahip_conclave *out);
+/* The general form, host buffers: one entry per frag_raw record IN STREAM ORDER, exactly the fields runConClave reads
+ * (conclave.c:59-70): hits->n_hits[r] listed templates at off[r] of tmpl / start / end, hits->best_score[r] = stats[2]
+ * (negative: a pair record, the mate of length q_len2[r] follows), q_len[r]. off has n_records + 1 entries; q_len2 may be
+ * NULL. For glue that merges single and paired results of one input stream: a record whose list is empty takes the first
+ * listed hit of the record before it (the reference reads zero entries into buffers it does not clear). */
+int kmahip_conclave_records(kmahip_db *db, kmahip_ws *ws, int64_t n_records, const int32_t *q_len, const int32_t *q_len2,
+                            const int64_t *off, const kmahip_hits *hits, kmahip_conclave *out);
+
+/* The columns of a `.res` row that do not depend on the consensus (runkma.c:765-783, 809): Score, Expected (as printed,
+ * (unsigned) expected), Template_length, q_value, p_value, and whether the template passes the reference's gate for
+ * assembly / output (cmp_or(p <= evalue && score > expected, score >= scoreT * length), stdstat.c:23-27). One row per
+ * template with w_scores > 0, in template order; w_scores is a HOST vector (summed over ranks). kma.c:312,319:
+ * evalue = 0.05, scoreT = 0.5. Returns KMAHIP_EOVERFLOW with *n_rows = needed when cap is too small. */
+typedef struct kmahip_res_row {
+	int32_t template_id;
+	int32_t template_length;
+	uint64_t score;
+	uint32_t expected;
+	int32_t significant;
+	double q_value;
+	double p_value;
+} kmahip_res_row;
+int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
+                    kmahip_res_row *rows, int64_t cap, int64_t *n_rows);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

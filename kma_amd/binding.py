@@ -51,6 +51,16 @@ class PeRecs(C.Structure):
                 ("R_off", C.c_void_p), ("T", C.c_void_p), ("T_cap", C.c_int64)]
 
 
+class Conclave(C.Structure):
+    _fields_ = [("tmpl", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p), ("w_scores", C.c_void_p),
+                ("fragment_counts", C.c_void_p), ("read_counts", C.c_void_p), ("depth", C.c_void_p)]
+
+
+class ResRow(C.Structure):
+    _fields_ = [("template_id", C.c_int32), ("template_length", C.c_int32), ("score", C.c_uint64), ("expected", C.c_uint32),
+                ("significant", C.c_int32), ("q_value", C.c_double), ("p_value", C.c_double)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
                 ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
@@ -106,6 +116,14 @@ def lib():
         L.kmahip_map_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs),
                                     C.POINTER(Hits), C.c_void_p]
         L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
+        L.kmahip_conclave_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Cands), C.POINTER(Hits), C.POINTER(Conclave)]
+        L.kmahip_conclave_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(PeRecs), C.POINTER(Hits), C.c_void_p,
+                                         C.POINTER(Conclave)]
+        L.kmahip_conclave_se_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Cands), C.POINTER(Hits),
+                                             C.POINTER(Conclave), C.c_void_p]
+        L.kmahip_conclave_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hits),
+                                              C.POINTER(Conclave)]
+        L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -260,6 +278,89 @@ class KmaHipDB:
         p = Params.from_buffer_copy(self.params)
         _check(lib().kmahip_align_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(p), C.byref(h),
                                          C.c_void_p(stream or 0)))
+
+    # -- stage 3b (ConClave) -----------------------------------------------------------
+    def _conclave_out(self, n):
+        D = int(self.info.DB_size)
+        o = dict(tmpl=np.zeros(max(n, 1), np.int32), start=np.zeros(max(n, 1), np.int32), end=np.zeros(max(n, 1), np.int32),
+                 w_scores=np.zeros(D, np.uint64), fragment_counts=np.zeros(D, np.uint32), read_counts=np.zeros(D, np.uint32),
+                 depth=np.zeros(D, np.uint64))
+        return o, Conclave(_p(o["tmpl"]), _p(o["start"]), _p(o["end"]), _p(o["w_scores"]), _p(o["fragment_counts"]),
+                           _p(o["read_counts"]), _p(o["depth"]))
+
+    @staticmethod
+    def _hits_struct(h):
+        c = lambda a, t: np.ascontiguousarray(a if len(a) else np.zeros(1, t), t)
+        keep = [c(h["n_hits"], np.int32), c(h["best_score"], np.int32), c(h["tmpl"], np.int32), c(h["start"], np.int32),
+                c(h["end"], np.int32), c(h["alignment_scores"], np.uint64), c(h["uniq_alignment_scores"], np.uint64)]
+        return keep, Hits(_p(keep[0]), _p(keep[1]), None, _p(keep[2]), None, _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(keep[6]))
+
+    def conclave_se(self, length, T_off, hits):
+        """Stage 3b for the result of map_se (host arrays; `hits` may carry vectors summed over ranks) -> dict(tmpl, start,
+        end per read; w_scores, fragment_counts, read_counts, depth per template)"""
+        n = len(length)
+        ln = np.ascontiguousarray(length, np.int32)
+        to = np.ascontiguousarray(T_off, np.int64)
+        r = Reads(n, None, None, _p(ln), None, None, 0, 0, 0)
+        c = Cands(None, None, _p(to), None, 0)
+        keep, hs = self._hits_struct(hits)
+        o, oc = self._conclave_out(n)
+        _check(lib().kmahip_conclave_se(self.h, self.ws, C.byref(r), C.byref(c), C.byref(hs), C.byref(oc)))
+        for key in ("tmpl", "start", "end"):
+            o[key] = o[key][:n]
+        return o
+
+    def conclave_pe(self, length, mate, R_off, hits):
+        """Stage 3b for the result of map_pe (record slots; hits["kind"] per pair)"""
+        n = len(length)
+        ln = np.ascontiguousarray(length, np.int32)
+        ro = np.ascontiguousarray(R_off, np.int64)
+        mt = np.ascontiguousarray(mate if n else np.zeros(1, np.int32), np.int32)
+        kd = np.ascontiguousarray(hits["kind"], np.int32)
+        r = Reads(n, None, None, _p(ln), None, None, 0, 0, 0)
+        pr = PeRecs(_p(mt), None, None, None, _p(ro), None, 0)
+        keep, hs = self._hits_struct(hits)
+        o, oc = self._conclave_out(n)
+        _check(lib().kmahip_conclave_pe(self.h, self.ws, C.byref(r), C.byref(pr), C.byref(hs), _p(kd), C.byref(oc)))
+        for key in ("tmpl", "start", "end"):
+            o[key] = o[key][:n]
+        return o
+
+    def conclave_records(self, n_hits, score, q_len, q_len2, off, tmpl, start, end, alignment_scores, uniq_alignment_scores):
+        """Stage 3b over explicit frag_raw records in stream order (score < 0: pair record)"""
+        n = len(n_hits)
+        ql = np.ascontiguousarray(q_len if n else np.zeros(1, np.int32), np.int32)
+        ql2 = np.ascontiguousarray(q_len2 if n else np.zeros(1, np.int32), np.int32)
+        of = np.ascontiguousarray(off, np.int64)
+        assert len(of) == n + 1
+        keep, hs = self._hits_struct(dict(n_hits=n_hits, best_score=score, tmpl=tmpl, start=start, end=end,
+                                          alignment_scores=alignment_scores, uniq_alignment_scores=uniq_alignment_scores))
+        o, oc = self._conclave_out(n)
+        _check(lib().kmahip_conclave_records(self.h, self.ws, n, _p(ql), _p(ql2), _p(of), C.byref(hs), C.byref(oc)))
+        for key in ("tmpl", "start", "end"):
+            o[key] = o[key][:n]
+        return o
+
+    def conclave_se_dev(self, length, T_off, n_hits, best_score, h_tmpl, h_start, h_end, aln_scores, uniq_scores,
+                        o_tmpl, o_start, o_end, w_scores, fragment_counts=None, read_counts=None, depth=None, stream=None):
+        """Stage 3b on device tensors (outputs of align_se_dev); asynchronous on `stream`."""
+        dp = lambda t: t.data_ptr() if t is not None else None
+        r = Reads(length.numel(), None, None, length.data_ptr(), None, None, 0, 0, 0)
+        c = Cands(None, None, T_off.data_ptr(), None, 0)
+        h = Hits(n_hits.data_ptr(), best_score.data_ptr(), None, h_tmpl.data_ptr(), None, h_start.data_ptr(), h_end.data_ptr(),
+                 aln_scores.data_ptr(), uniq_scores.data_ptr())
+        o = Conclave(o_tmpl.data_ptr(), o_start.data_ptr(), o_end.data_ptr(), w_scores.data_ptr(), dp(fragment_counts),
+                     dp(read_counts), dp(depth))
+        _check(lib().kmahip_conclave_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(h), C.byref(o), C.c_void_p(stream or 0)))
+
+    def res_rows(self, w_scores, evalue=0.05, scoreT=0.5):
+        """Leading `.res` columns per template with a score -> list of ResRow (host arithmetic, runkma.c:765-783)"""
+        w = np.ascontiguousarray(w_scores, np.uint64)
+        cap = int((w[1:] > 0).sum()) + 1
+        rows = (ResRow * cap)()
+        n = C.c_int64()
+        _check(lib().kmahip_res_rows(self.h, _p(w), C.c_double(evalue), C.c_double(scoreT), rows, cap, C.byref(n)))
+        return [rows[i] for i in range(n.value)]
 
     # -- paired end stage 2 (-apm p), host buffers ------------------------------------
     def scan_pe(self, batch, exhaustive=0, t_cap=None):

@@ -152,3 +152,84 @@ def oracle_pe_conclave_records(g):
     col = lambda i: np.array([r[i] for r in rec], np.int32)
     return dict(n_hits=col(0), score=col(1), q_len=col(2), q_len2=col(3), off=off[:-1], tmpl=flat(4), start=flat(5), end=flat(6),
                 alignment_scores=vec[0], uniq_alignment_scores=vec[1])
+
+
+def hip_pe_conclave(db, g):
+    """Stages 2 + 3a on the device for the pairs (map_pe) and the singly emitted reads (map_se) of a paired fixture, the two
+    results merged into frag_raw records in stream order, then stage 3b over them (KmaHipDB.conclave_records)."""
+    codes = lambda r: codes_of(r["seq"], r["seqlen"], r["N"])
+    pairs = [u for u in g["units"] if u[0] == "pe"]
+    singles = [u for u in g["units"] if u[0] == "se"]
+    pb = formats.pack_ragged([codes(g["s1"][i]) for u in pairs for i in (u[1], u[2])])
+    (mate, rc, rc_flag, flag, R_off, T), h = db.map_pe(pb)
+    sb = formats.pack_ragged([codes(g["s1"][u[1]]) for u in singles])
+    (_, _, sT_off, _), sh = db.map_se(sb)
+    pj = {u[1]: j for j, u in enumerate(pairs)}
+    sj = {u[1]: j for j, u in enumerate(singles)}
+    rec = []
+
+    def add(n, score, ql, ql2, src, o):
+        rec.append((n, score, ql, ql2, src["tmpl"][o:o + n].tolist(), src["start"][o:o + n].tolist(), src["end"][o:o + n].tolist()))
+
+    for u in g["units"]:
+        if u[0] == "se":
+            j = sj[u[1]]
+            if sh["n_hits"][j] > 0:
+                add(int(sh["n_hits"][j]), int(sh["best_score"][j]), int(sb.length[j]), 0, sh, int(sT_off[j]))
+            continue
+        j = pj[u[1]]
+        r0, r1 = 2 * j, 2 * j + 1
+        kind = int(h["kind"][j])
+        ln = lambda x: int(pb.length[2 * j + int(mate[x])])
+        o = int(R_off[r1])
+        if kind == 1:
+            add(int(h["n_hits"][r1]), -int(h["best_score"][r1]), ln(r0), ln(r1), h, o)
+        elif kind == 2:
+            n0, n1 = int(h["n_hits"][r0]), int(h["n_hits"][r1])
+            add(n0, int(h["best_score"][r0]), ln(r0), 0, h, o)
+            add(n1, int(h["best_score"][r1]), ln(r1), 0, h, o + n0)
+        elif kind in (3, 4):
+            x = r0 if kind == 3 else r1
+            add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, o)
+        else:
+            for x in (r0, r1):
+                if mate[x] >= 0 and h["n_hits"][x] > 0:
+                    add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, int(R_off[x]))
+    off = np.concatenate([[0], np.cumsum([r[0] for r in rec])]).astype(np.int64)
+    flat = lambda i: np.array([x for r in rec for x in r[i]], np.int32)
+    col = lambda i: np.array([r[i] for r in rec], np.int32)
+    AS = h["alignment_scores"] + sh["alignment_scores"]
+    US = h["uniq_alignment_scores"] + sh["uniq_alignment_scores"]
+    out = db.conclave_records(col(0), col(1), col(2), col(3), off, flat(4), flat(5), flat(6), AS, US)
+    # the slot form on the pairs alone must agree with the records form over the same pairs
+    vec = dict(h); vec["alignment_scores"], vec["uniq_alignment_scores"] = AS, US
+    slot = db.conclave_pe(pb.length, mate, R_off, vec)
+    prec = [(n, sc, a, b2, t, s, e) for (n, sc, a, b2, t, s, e), is_pair in zip(rec, _pair_record_mask(g, pj, sj, h, sh, mate)) if is_pair]
+    poff = np.concatenate([[0], np.cumsum([r[0] for r in prec])]).astype(np.int64)
+    pflat = lambda i: np.array([x for r in prec for x in r[i]], np.int32)
+    pcol = lambda i: np.array([r[i] for r in prec], np.int32)
+    only = db.conclave_records(pcol(0), pcol(1), pcol(2), pcol(3), poff, pflat(4), pflat(5), pflat(6), AS, US)
+    assert np.array_equal(slot["w_scores"], only["w_scores"]) and np.array_equal(slot["depth"], only["depth"])
+    assert np.array_equal(slot["read_counts"], only["read_counts"])
+    return out
+
+
+def _pair_record_mask(g, pj, sj, h, sh, mate):
+    """For every record hip_pe_conclave builds (same order): does it come from a pair unit?"""
+    mask = []
+    for u in g["units"]:
+        if u[0] == "se":
+            if sh["n_hits"][sj[u[1]]] > 0:
+                mask.append(False)
+            continue
+        j = pj[u[1]]
+        kind = int(h["kind"][j])
+        if kind == 1:
+            mask.append(True)
+        elif kind == 2:
+            mask += [True, True]
+        elif kind in (3, 4):
+            mask.append(True)
+        else:
+            mask += [True for x in (2 * j, 2 * j + 1) if mate[x] >= 0 and h["n_hits"][x] > 0]
+    return mask
