@@ -120,14 +120,77 @@ static void walk(const uint8_t *E, long stride, int m, int n, int dn, aln *s) {
 	}
 }
 
+/* Frag_align of the traceback variants (nw.c:26-309, 310-640): aligned strings as codes 0-5 (5 = gap), the match
+ * line ('|' / '_'), and how many query bases the walk left out at either end (Aln.start / Aln.end). pos = the
+ * template length for circular joins (align.c:456). */
+typedef struct { uint8_t *t, *s, *q; long cap; int start, end, pos; } trace;
+
+static void trace_room(trace *tr, long need) {
+	if(tr->cap > need) return;
+	tr->cap = need * 2 + 64;
+	tr->t = realloc(tr->t, (size_t) tr->cap); tr->s = realloc(tr->s, (size_t) tr->cap); tr->q = realloc(tr->q, (size_t) tr->cap);
+}
+
+/* the same walk, writing the columns (nw.c:256-305 full matrix, :586-635 band): q_pos = query index of column n */
+static void walk_trace(const uint8_t *E, long stride, int m, int n, int dn, int q_pos, aln *s, trace *tr,
+                       const uint64_t *tseq, int nuc_pos, int tlen_total, const uint8_t *query, int q_len) {
+	const uint8_t *row = E + (long) m * stride;
+	s->len = s->match = s->tGaps = s->qGaps = 0;
+	while(row[n] != 0) {
+		if(nuc_pos == tlen_total) nuc_pos = 0;
+		const int mv = row[n] & 7;
+		if(mv == 1) {
+			tr->t[s->len] = (uint8_t) tnuc(tseq, nuc_pos); tr->q[s->len] = query[q_pos];
+			tr->s[s->len] = tr->t[s->len] == tr->q[s->len] ? '|' : '_';
+			++s->match; ++nuc_pos; row += stride; n += 1 + dn; ++q_pos;
+		} else if(mv >= 4) {
+			while(!(row[n] >> 4)) {
+				tr->t[s->len] = (uint8_t) tnuc(tseq, nuc_pos); tr->q[s->len] = 5; tr->s[s->len] = '_';
+				++nuc_pos; row += stride; n += dn; ++s->len; ++s->qGaps;
+			}
+			tr->t[s->len] = (uint8_t) tnuc(tseq, nuc_pos); tr->q[s->len] = 5; tr->s[s->len] = '_';
+			++nuc_pos; row += stride; n += dn; ++s->qGaps;
+		} else {
+			while(!(row[n] >> 3)) {
+				tr->t[s->len] = 5; tr->q[s->len] = query[q_pos]; tr->s[s->len] = '_';
+				++n; ++q_pos; ++s->len; ++s->tGaps;
+			}
+			tr->t[s->len] = 5; tr->q[s->len] = query[q_pos]; tr->s[s->len] = '_';
+			++n; ++q_pos; ++s->tGaps;
+		}
+		++s->len;
+	}
+	tr->end = q_len - q_pos;
+}
+
+/* nw.c:48-85: one side empty */
+static aln degenerate_trace(int t_len, int q_len, const orc_rewards *rw, trace *tr, const uint64_t *tseq, int t_e, const uint8_t *query) {
+	aln s = degenerate(t_len, q_len, rw);
+	tr->start = tr->end = 0;
+	if(t_len == q_len) return s;
+	if(t_len == 0) {
+		trace_room(tr, q_len + 2);
+		memset(tr->s, '_', (size_t) q_len); memset(tr->t, 5, (size_t) q_len); memcpy(tr->q, query, (size_t) q_len);
+	} else {
+		trace_room(tr, t_len + 2);
+		memset(tr->s, '_', (size_t) t_len); memset(tr->q, 5, (size_t) t_len);
+		int nuc_pos = (t_e ? t_e : tr->pos) - 1;
+		for(int m = t_len; m--;) {
+			tr->t[m] = (uint8_t) tnuc(tseq, nuc_pos);
+			if(--nuc_pos < 0) nuc_pos = tr->pos - 1;
+		}
+	}
+	return s;
+}
+
 static aln nw_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int k, int t_s, int t_e, int q_s, int q_e,
-                    const orc_rewards *rw, int tlen_total) {
-	/* nw.c:642-890 */
+                    const orc_rewards *rw, int tlen_total, trace *tr) {
+	/* nw.c:642-890; with tr: NW, nw.c:26-309 (same fill, the walk writes the columns) */
 	const int W1 = rw->W1, U = rw->U;
 	int t_len = t_e - t_s, q_len = q_e - q_s;
 	if(t_len < 0) t_len += tlen_total;
 	const uint8_t *q = qorg + q_s;
-	if(t_len == 0 || q_len == 0) return degenerate(t_len, q_len, rw);
+	if(t_len == 0 || q_len == 0) return tr ? degenerate_trace(t_len, q_len, rw, tr, tseq, t_e, q) : degenerate(t_len, q_len, rw);
 	orc_counters[0]++; orc_counters[2] += (int64_t) t_len * q_len;
 	aws_rows(w, q_len + 2);
 	aws_E(w, (long) (q_len + 2) * (t_len + 2));
@@ -179,12 +242,16 @@ static aln nw_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int k, in
 	} else {
 		s.score = Dp[0];
 	}
-	walk(E, pitch, sm, sn, 0, &s);
+	if(tr) {
+		trace_room(tr, (long) t_len + q_len + 2);
+		tr->start = sn;
+		walk_trace(E, pitch, sm, sn, 0, sn, &s, tr, tseq, sm + t_s, tlen_total, q, q_len);
+	} else walk(E, pitch, sm, sn, 0, &s);
 	return s;
 }
 
 static aln nw_band_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int k, int t_s, int t_e, int q_s, int q_e,
-                         int band, const orc_rewards *rw, int tlen_total) {
+                         int band, const orc_rewards *rw, int tlen_total, trace *tr) {
 	/* nw.c:892-1188. Band columns are indexed relative to a centre diagonal
 	 * that moves one query position per template row; column n of row m is
 	 * column n-1 of row m+1. */
@@ -192,7 +259,7 @@ static aln nw_band_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int 
 	int t_len = t_e - t_s, q_len = q_e - q_s;
 	if(t_len < 0) t_len += tlen_total;
 	const uint8_t *q = qorg + q_s;
-	if(t_len == 0 || q_len == 0) return degenerate(t_len, q_len, rw);
+	if(t_len == 0 || q_len == 0) return tr ? degenerate_trace(t_len, q_len, rw, tr, tseq, t_e, q) : degenerate(t_len, q_len, rw);
 	if(band & 1) ++band;
 	orc_counters[1]++; orc_counters[2] += (int64_t) t_len * (band + 1);
 	const int half = band >> 1, bq = band + 1;
@@ -256,11 +323,16 @@ static aln nw_band_score(aws *w, const uint64_t *tseq, const uint8_t *qorg, int 
 		if(eq == 0 && k < 0 && s.score < Dc[n]) { s.score = Dc[n]; bm = m; bn = n; }
 		int *t = Dc; Dc = Dp; Dp = t; t = Pc; Pc = Pp; Pp = t;
 	}
+	int q_pos = 0;
 	if(bm == 0) { bn = en; s.score = Dp[en]; }
 	if(k == -2) {
-		for(n = en; n < bq; ++n) if(s.score <= Dp[n]) { s.score = Dp[n]; bm = 0; bn = n; }
+		for(n = en; n < bq; ++n) if(s.score <= Dp[n]) { s.score = Dp[n]; bm = 0; bn = n; q_pos = n - en; }
 	}
-	walk(E, pitch, bm, bn, -1, &s);
+	if(tr) {
+		trace_room(tr, (long) t_len + q_len + 2);
+		tr->start = q_pos;
+		walk_trace(E, pitch, bm, bn, -1, q_pos, &s, tr, tseq, bm + t_s, tlen_total, q, q_len);
+	} else walk(E, pitch, bm, bn, -1, &s);
 	return s;
 }
 
@@ -348,8 +420,8 @@ static aln lead_tail(aws *w, const uint64_t *tseq, const uint8_t *qseq, int t_e,
 		const int band = abs(t_e - t_s - q_e + q_s) + bw;
 		const int mode = -1 - (t_s == 0);
 		aln r;
-		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len);
-		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len);
+		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len, NULL);
+		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len, NULL);
 		s.pos -= r.len - r.tGaps;
 		s.score = r.score; s.len = r.len; s.match = r.match; s.tGaps = r.tGaps; s.qGaps = r.qGaps;
 	}
@@ -367,8 +439,8 @@ static void trail_tail(aws *w, aln *s, const uint64_t *tseq, const uint8_t *qseq
 		const int band = abs(t_e - t_s - q_e + q_s) + bw;
 		const int mode = 1 + (t_e == t_len);
 		aln r;
-		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len);
-		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len);
+		if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len, NULL);
+		else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len, NULL);
 		s->score += r.score; s->len += r.len; s->match += r.match; s->tGaps += r.tGaps; s->qGaps += r.qGaps;
 	}
 }
@@ -446,12 +518,155 @@ static aln kma_score(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, 
 		if(t_l > 0 || q_e - q_s > 0) {
 			const int band = abs(t_l - q_e + q_s) + bw;
 			aln r;
-			if(q_e - q_s <= band || t_l <= band) r = nw_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, rw, t_len);
-			else r = nw_band_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, band, rw, t_len);
+			if(q_e - q_s <= band || t_l <= band) r = nw_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, rw, t_len, NULL);
+			else r = nw_band_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, band, rw, t_len, NULL);
 			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
 		}
 	}
 	trail_tail(w, &S, tseq, qseq, w->tE[start] - 1, t_len, w->qE[start], q_len, bw, rw);
+	return S;
+}
+
+/* ---- KMA, align.c:214-507: the stage-3c aligner. Same chain and joins as KMA_score, but (i) the seeding loop is the
+ * byte-wise one (a stretch must be LONGER than k to be probed, align.c:258,308,364), (ii) NW / NW_band write the aligned
+ * columns, (iii) gaps at the very start / end of the template are trimmed off the tails (align.c:97-112, 180-196).
+ * `al` receives the columns (codes 0-5), the number of columns is the returned len; al->start / al->end = read bases left
+ * unaligned before / after (soft clips of the SAM record). trimSeeds (chain.c:496) is a no-op at its default ts = 0. */
+static void al_put(trace *al, long at, const uint8_t *t, const uint8_t *ss, const uint8_t *q, long n) {
+	trace_room(al, at + n + 2);
+	memcpy(al->t + at, t, (size_t) n); memcpy(al->s + at, ss, (size_t) n); memcpy(al->q + at, q, (size_t) n);
+}
+
+static aln kma_trace(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k, const uint8_t *qseq, int q_len,
+                     int q_start, int q_end, int mq, const orc_rewards *rw, trace *al, trace *fr, unsigned *mapQ_out) {
+	const int bw = 64;
+	const uint64_t mask = (k < 32) ? ((1ull << (2 * k)) - 1) : ~0ull;
+	al->start = al->end = 0;
+	w->plen = 0;
+	int i = q_start;
+	while(i < q_end) {
+		int end = -1;
+		for(int x = i; x < q_len; ++x) if(qseq[x] == 4) { end = x; break; }     /* charpos(qseq, 4, i, q_len) */
+		if(end == -1) end = q_end;
+		uint64_t key = 0;
+#define RESTART_KEY() do { if(i < end - k) { key = 0; for(int x = 0; x < k - 1; ++x) key = (key << 2) | qseq[i + x]; i += k - 1; } else i = end + 1; } while(0)
+		RESTART_KEY();
+		while(i < end) {
+			key = ((key << 2) | qseq[i]) & mask;
+			int cnt = 0;
+			const int first = key ? tindex_find(ix, key, &cnt) : 0;
+			if(cnt == 0) { ++i; continue; }
+			i -= k - 1;
+			if(cnt == 1) {
+				int qe;
+				add_mem(w, tseq, t_len, qseq, i, ix->o[first].pos, k, end, &qe);
+				i = qe;
+			} else {
+				int bias = i;
+				for(int c = 0; c < cnt; ++c) {
+					int qe;
+					add_mem(w, tseq, t_len, qseq, i, ix->o[first + c].pos, k, end, &qe);
+					if(bias < qe) bias = qe;
+				}
+				i = bias + 1;
+			}
+			RESTART_KEY();
+		}
+#undef RESTART_KEY
+		i = end + 1;
+	}
+	if(!w->plen) return FAIL;
+	aws_points(w, w->plen + 2);
+	unsigned mapQ = 0;
+	int start = chain_seeds(w, q_len, t_len, k, rw, &mapQ);
+	*mapQ_out = mapQ;
+	if(mapQ < (unsigned) mq || w->sc[start] < k) return FAIL;
+	trace_room(al, (long) 2 * (q_len + t_len) + 64);
+
+	/* leading tail, leadTailAln with Frag_align (align.c:53-131) */
+	aln S = {0, 0, w->tS[start] - 1, 0, 0, 0};
+	{
+		const int t_e = w->tS[start] - 1, q_e = w->qS[start];
+		if(q_e) {
+			int t_s = 0, q_s = 0;
+			if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+			else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+			if(t_e - t_s > 0 && q_e - q_s > 0) {
+				const int band = abs(t_e - t_s - q_e + q_s) + bw, mode = -1 - (t_s == 0);
+				aln r;
+				fr->start = fr->end = 0;
+				if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len, fr);
+				else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len, fr);
+				int bias = 0;
+				if(t_s == 0) {
+					while(bias < r.len && (fr->t[bias] == 5 || fr->q[bias] == 5)) {
+						if(fr->t[bias] == 5) { --r.tGaps; ++fr->start; } else --r.qGaps;
+						++bias;
+					}
+					r.len -= bias;
+				}
+				al_put(al, 0, fr->t + bias, fr->s + bias, fr->q + bias, r.len);
+				al->start = q_s + fr->start;
+				S.pos -= r.len - r.tGaps;
+				S.score = r.score; S.len = r.len; S.match = r.match; S.tGaps = r.tGaps; S.qGaps = r.qGaps;
+			} else al->start = q_s;
+		}
+	}
+	for(;;) {
+		const int span = w->qE[start] - w->qS[start];
+		trace_room(al, (long) S.len + span + 2);
+		memcpy(al->t + S.len, qseq + w->qS[start], (size_t) span); memset(al->s + S.len, '|', (size_t) span);
+		memcpy(al->q + S.len, qseq + w->qS[start], (size_t) span);
+		S.len += span; S.match += span;
+		for(int x = w->qS[start]; x < w->qE[start]; ++x) S.score += rw->d[qseq[x]][qseq[x]];
+		if(!w->nx[start]) break;
+		int q_s = w->qE[start], t_s = w->tE[start] - 1, t_l;
+		start = w->nx[start];
+		if(w->qS[start] < q_s) { w->tS[start] += q_s - w->qS[start]; w->qS[start] = q_s; }
+		int t_e = w->tS[start] - 1;
+		if(t_e < t_s) {
+			if(t_s <= w->tE[start]) { w->qS[start] += t_s - t_e; t_e = t_s; t_l = 0; }
+			else { fr->pos = t_len; t_l = t_len - t_s + t_e; }
+		} else t_l = t_e - t_s;
+		const int q_e = w->qS[start];
+		if(abs(t_l - q_e + q_s) * rw->U > q_len * rw->M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+		if(t_l > 0 || q_e - q_s > 0) {
+			const int band = abs(t_l - q_e + q_s) + bw;
+			aln r;
+			if(q_e - q_s <= band || t_l <= band) r = nw_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, rw, t_len, fr);
+			else r = nw_band_score(w, tseq, qseq, 0, t_s, t_e, q_s, q_e, band, rw, t_len, fr);
+			al_put(al, S.len, fr->t, fr->s, fr->q, r.len);
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+	}
+	{	/* trailing tail, trailTailAln with Frag_align (align.c:140-212) */
+		const int t_s = w->tE[start] - 1, q_s = w->qE[start];
+		int q_e = q_len, t_e = t_len;
+		if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+			t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+		} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+			q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+		}
+		fr->end = 0;
+		if(t_e - t_s > 0 && q_e - q_s > 0) {
+			const int band = abs(t_e - t_s - q_e + q_s) + bw, mode = 1 + (t_e == t_len);
+			aln r;
+			if(q_e - q_s <= band || t_e - t_s <= band) r = nw_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, rw, t_len, fr);
+			else r = nw_band_score(w, tseq, qseq, mode, t_s, t_e, q_s, q_e, band, rw, t_len, fr);
+			if(t_e == t_len) {
+				int bias = r.len - 1;
+				while(bias && (fr->t[bias] == 5 || fr->q[bias] == 5)) {
+					if(fr->t[bias] == 5) { --r.tGaps; ++fr->end; } else --r.qGaps;
+					--bias;
+				}
+				++bias;
+				if(bias != r.len) r.len = bias;
+			}
+			al_put(al, S.len, fr->t, fr->s, fr->q, r.len);
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+		al->end = q_len - q_e + fr->end;
+	}
 	return S;
 }
 
@@ -658,11 +873,46 @@ int orc_align_se(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
 void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
                 int band /* < 0: full matrix */, const orc_rewards *rw, int out[6]) {
 	aws w; memset(&w, 0, sizeof w);
-	aln r = band < 0 ? nw_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, rw, tlen_total)
-	                 : nw_band_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, band, rw, tlen_total);
+	aln r = band < 0 ? nw_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, rw, tlen_total, NULL)
+	                 : nw_band_score(&w, tseq, q, k, t_s, t_e, q_s, q_e, band, rw, tlen_total, NULL);
 	out[0] = r.score; out[1] = r.len; out[2] = r.pos; out[3] = r.match; out[4] = r.tGaps; out[5] = r.qGaps;
 	for(int i = 0; i < 2; ++i) { free(w.D[i]); free(w.P[i]); }
 	free(w.E);
+}
+
+/* One read of stage 3c (assemble_KMA, assembly.c:1917-1965): the read as ConClave filed it under template t (bytes 0-4,
+ * already reverse-complemented if its hit was on the reverse strand, conclave.c:131-146), aligned with KMA(); +Wl for
+ * an alignment that starts at the first / ends at the last template base; kept if minlen <= aln_len, mrcheck, 0 < score
+ * and scoreT <= score / aln_len. Outputs: stats[10] = {score, start, end, aln_len, clip_start, clip_end, match, tGaps,
+ * qGaps, mapQ};
+ * cols (capacity cap) receives the columns as '=' 'X' 'I' (gap in template) 'D' (gap in read), the classes makeCigar
+ * uses (sam.c:57-78). Returns the number of columns if the read is kept, 0 if it is dropped, -needed if cap is too small. */
+int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, const uint8_t *read, int q_len, int t,
+                    int *stats, char *cols, int cap) {
+	static trace al, fr;              /* oracle = single-threaded test code */
+	const orc_db *db = a->db;
+	const int k = db->kmersize, t_len = db->tlen[t];
+	const uint64_t *tseq = db->tseq + db->tseq_off[t];
+	memset(stats, 0, 10 * sizeof(int));
+	unsigned mapQ = 0;
+	if(!a->ix[t].o) tindex_build(&a->ix[t], tseq, t_len, k);
+	fr.pos = 0;
+	aln S = kma_trace(&a->w, &a->ix[t], tseq, t_len, k, read, q_len, 0, q_len, ap->mq, rw, &al, &fr, &mapQ);
+	const int aln_len = S.len, start = S.pos;
+	int end = start + aln_len - S.tGaps;
+	if(t_len < end) end -= t_len;
+	int read_score = S.score;
+	if(start == 0) read_score += rw->Wl;
+	if(end == t_len) read_score += rw->Wl;
+	double score;
+	if(ap->minlen <= aln_len && ((ap->mrc * q_len <= S.len - S.qGaps) || (ap->mrc * t_len <= S.len - S.tGaps))) score = 1.0 * read_score / aln_len;
+	else { read_score = 0; score = 0; }
+	if(!(0 < read_score && ap->scoreT <= score)) return 0;
+	stats[0] = read_score; stats[1] = start; stats[2] = (t_len < end) ? end - t_len : end; stats[3] = aln_len;
+	stats[4] = al.start; stats[5] = al.end; stats[6] = S.match; stats[7] = S.tGaps; stats[8] = S.qGaps; stats[9] = (int) mapQ;
+	if(aln_len > cap) return -aln_len;
+	for(int i = 0; i < aln_len; ++i) cols[i] = al.s[i] == '|' ? '=' : al.t[i] == 5 ? 'I' : al.q[i] == 5 ? 'D' : 'X';
+	return aln_len;
 }
 
 int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_align_params *ap,

@@ -113,6 +113,10 @@ int orc_align_pe(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
                  const uint64_t *seqB, int lenB, const int *NB, int nNB, int flagB,
                  const int *T, int nT, orc_pe_out *out,
                  uint64_t *alignment_scores, uint64_t *uniq_alignment_scores);
+/* stage 3c, per read: KMA() with traceback (align.c:214-507) + the read filter of assemble_KMA (assembly.c:1917-1965).
+ * See align.c. */
+int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, const uint8_t *read, int q_len, int t,
+                    int *stats, char *cols, int cap);
 void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
                 int band, const orc_rewards *rw, int out[6]);
 

@@ -208,3 +208,14 @@ def check_conclave_against_outputs(name, headers, n_hits, picked, w_scores, stat
             assert got == res[nm], (nm, got, res[nm])
     assert rows == len(res)
     return seen, rows
+
+
+def load_sam(name="se"):
+    """Mapped SAM records of the reference run (tests/golden/make_golden_sam.py): qname -> list of
+    (flag, rname, pos, mapq, cigar, AS) in output order (a pair has two records under one name)."""
+    out = {}
+    with gzip.open(os.path.join(GOLD, name, "out.sam.tsv.gz"), "rt") as f:
+        for line in f:
+            c = line.rstrip("\n").split("\t")
+            out.setdefault(c[0], []).append((int(c[1]), c[2], int(c[3]), int(c[4]), c[5], int(c[6])))
+    return out

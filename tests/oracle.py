@@ -197,6 +197,21 @@ def res_stats(w_scores, tlen, evalue=0.05, scoreT=0.5):
     return out
 
 
+def cigar_of(cols, clip_start=0, clip_end=0):
+    """makeCigar (sam.c:30-98): run-length code of the column classes, soft clips around it"""
+    out = [f"{clip_start}S"] if clip_start else []
+    i = 0
+    while i < len(cols):
+        j = i
+        while j < len(cols) and cols[j] == cols[i]:
+            j += 1
+        out.append(f"{j - i}{cols[i]}")
+        i = j
+    if clip_end:
+        out.append(f"{clip_end}S")
+    return "".join(out)
+
+
 def rc_packed(seq, length, N):
     """compdna.c:228-256 on numpy arrays -> (rc words, rc N positions)."""
     words = (length + 31) // 32
@@ -224,6 +239,26 @@ class OracleAligner:
         if getattr(self, "h", None):
             lib().orc_aligner_free(self.h)
             self.h = None
+
+    def align_trace(self, read, t, minlen=None):
+        """Stage 3c for one read (uint8 codes 0-4, oriented like the template) -> None if dropped, else dict(score, start,
+        end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ, cigar)"""
+        rd = np.ascontiguousarray(read, np.uint8)
+        stats = np.zeros(10, np.int32)
+        cap = 4 * len(rd) + 4 * 4096
+        cols = C.create_string_buffer(cap)
+        L = lib()
+        L.orc_align_trace.restype = C.c_int
+        L.orc_align_trace.argtypes = [C.c_void_p, C.POINTER(Rewards), C.POINTER(AlignParams), C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_char_p, C.c_int]
+        n = L.orc_align_trace(self.h, C.byref(self.odb.rw), C.byref(self.ap), _p(rd), len(rd), int(t), _p(stats), cols, cap)
+        assert n >= 0
+        if n == 0:
+            return None
+        keys = ("score", "start", "end", "aln_len", "clip_start", "clip_end", "match", "tGaps", "qGaps", "mapQ")
+        out = dict(zip(keys, (int(x) for x in stats)))
+        out["cigar"] = cigar_of(cols.raw[:n].decode(), out["clip_start"], out["clip_end"])
+        return out
 
     def align_pe(self, seqA, lenA, NA, flagA, seqB, lenB, NB, flagB, T):
         nT = len(T)

@@ -181,3 +181,45 @@ def test_oracle_conclave_matches_res_paired(golden_pe):
     st = oracle.res_stats(cc["w_scores"], tlen)
     seen, rows = golden_util.check_conclave_against_outputs("pe", [], r["n_hits"], cc["tmpl"], cc["w_scores"], st, tlen)
     assert rows > 50
+
+
+def _oracle_trace_case(g, name):
+    """Stage 3c per read: every read ConClave filed under a template, re-aligned with the traceback aligner, must give the
+    POS / CIGAR / AS / MAPQ / FLAG of the reference's SAM record; reads the reference dropped in 3c must be dropped."""
+    from kma_amd import synth
+    res, cc, st, tlen = _oracle_conclave_se(g)
+    sam = golden_util.load_sam(name)
+    names = golden_util.template_names(name)
+    al = oracle.OracleAligner(oracle.OracleDB(g["prefix"]))
+    seen = 0
+    for i, r in enumerate(g["s1"]):
+        h = r["hdr"].rstrip(b"\0").decode()
+        tt = int(cc["tmpl"][i])
+        if tt == 0 or not st["significant"][abs(tt)]:
+            assert h not in sam, h
+            continue
+        read = g["reads"][i]
+        flag = int(res["out_flag"][i])
+        if flag & 16:
+            read = synth.revcomp_codes(read)
+        if tt < 0:
+            read = synth.revcomp_codes(read)
+            flag |= 16
+        o = al.align_trace(read, abs(tt))
+        if o is None:
+            assert h not in sam, h
+            continue
+        seen += 1
+        exp = sam[h][0]
+        got = (flag, names[abs(tt) - 1], o["start"] + 1, min(254, o["mapQ"]), o["cigar"], o["score"])
+        assert got == exp, (h, got, exp)
+    assert seen == len(sam)
+    return seen
+
+
+def test_oracle_traceback_matches_reference_sam(golden_se):
+    assert _oracle_trace_case(golden_se, "se") > 900
+
+
+def test_oracle_traceback_matches_reference_sam_long_reads(golden_long):
+    assert _oracle_trace_case(golden_long, "long") > 200
