@@ -249,6 +249,31 @@ typedef struct kmahip_res_row {
 int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
                     kmahip_res_row *rows, int64_t cap, int64_t *n_rows);
 
+/* Stage 3c, per read: the traceback aligner KMA() (align.c:214-507 with NW / NW_band, nw.c:26-640) for every read that
+ * ConClave filed under a template, followed by assemble_KMA's read filter (assembly.c:1931-1961: + Wl for an alignment
+ * that starts at the first / ends at the last template base, minlen, mrc, scoreT). This is what the reference prints per
+ * read in `.frag.gz` / SAM and feeds to alnToMat.
+ *   flag[i]   stage-3a flag of the read's record (bit 16: the record holds the reverse complement of reads[i])
+ *   tmpl[i]   kmahip_conclave.tmpl (signed; 0 = read has no template)
+ *   tmpl_ok   per template, 1 = assemble (kmahip_res_row.significant); NULL = all
+ * Out per read: stats[10 * i ..] = score, start, end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ (all 0: the
+ * read was dropped); the alignment columns as n_ops[i] runs at ops[ops_off[i] ..], each (length << 2) | class with class
+ * 0 '=' (match), 1 'X' (mismatch), 2 'I' (gap in template), 3 'D' (gap in read) -- the classes of makeCigar (sam.c:57-78).
+ * The SAM CIGAR is clip_start 'S' + runs + clip_end 'S'; POS = start + 1; AS = score. Runs are appended in no particular
+ * read order. KMAHIP_EOVERFLOW: ops_cap too small (kmahip_ws_status). Device pointers; asynchronous on `stream`. */
+typedef struct kmahip_traces {
+	int32_t *stats;     /* 10 * n_reads */
+	int64_t *ops_off;   /* n_reads */
+	int32_t *n_ops;     /* n_reads */
+	uint32_t *ops;      /* ops_cap */
+	int64_t ops_cap;
+} kmahip_traces;
+int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                           const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, void *stream);
+/* the same with host buffers in and out; returns KMAHIP_EOVERFLOW with the needed run count in *ops_needed */
+int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                       const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, int64_t *ops_needed);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

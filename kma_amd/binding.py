@@ -61,6 +61,10 @@ class ResRow(C.Structure):
                 ("significant", C.c_int32), ("q_value", C.c_double), ("p_value", C.c_double)]
 
 
+class Traces(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("ops_off", C.c_void_p), ("n_ops", C.c_void_p), ("ops", C.c_void_p), ("ops_cap", C.c_int64)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
                 ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
@@ -123,6 +127,8 @@ def lib():
                                              C.POINTER(Conclave), C.c_void_p]
         L.kmahip_conclave_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hits),
                                               C.POINTER(Conclave)]
+        L.kmahip_align_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params),
+                                         C.POINTER(Traces), C.POINTER(C.c_int64)]
         L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -135,6 +141,15 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def cigar_from_runs(runs, clip_start=0, clip_end=0):
+    """SAM CIGAR (makeCigar, sam.c:30-98) of one read's runs"""
+    out = [f"{clip_start}S"] if clip_start else []
+    out += [f"{int(x) >> 2}{'=XID'[int(x) & 3]}" for x in runs]
+    if clip_end:
+        out.append(f"{clip_end}S")
+    return "".join(out)
 
 
 def default_params() -> Params:
@@ -352,6 +367,36 @@ class KmaHipDB:
         o = Conclave(o_tmpl.data_ptr(), o_start.data_ptr(), o_end.data_ptr(), w_scores.data_ptr(), dp(fragment_counts),
                      dp(read_counts), dp(depth))
         _check(lib().kmahip_conclave_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(h), C.byref(o), C.c_void_p(stream or 0)))
+
+    def align_trace(self, batch, flag, tmpl, tmpl_ok=None):
+        """Stage 3c per read (host arrays): traceback alignment of every read against the template ConClave chose.
+        -> stats [n, 10] (score, start, end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ; zeros = dropped),
+        ops_off [n], n_ops [n], ops (runs (len << 2) | class, classes = X I D)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        fl = np.ascontiguousarray(flag if n else np.zeros(1, np.int32), np.int32)
+        tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
+        ok = None if tmpl_ok is None else np.ascontiguousarray(tmpl_ok, np.uint8)
+        stats = np.zeros((max(n, 1), 10), np.int32)
+        off = np.zeros(max(n, 1), np.int64)
+        nops = np.zeros(max(n, 1), np.int32)
+        cap = max(1024, 8 * n)
+        p = Params.from_buffer_copy(self.params)
+        need = C.c_int64()
+        for _ in range(3):
+            ops = np.zeros(cap, np.uint32)
+            o = Traces(_p(stats), _p(off), _p(nops), _p(ops), cap)
+            rc = lib().kmahip_align_trace(self.h, self.ws, C.byref(r), _p(fl), _p(tm), None if ok is None else _p(ok), C.byref(p),
+                                          C.byref(o), C.byref(need))
+            if rc == -6:
+                cap = need.value + 16
+                continue
+            _check(rc)
+            return stats[:n], off[:n], nops[:n], ops[:need.value]
+        raise KmaHipError("align_trace: output capacity kept overflowing")
 
     def res_rows(self, w_scores, evalue=0.05, scoreT=0.5):
         """Leading `.res` columns per template with a score -> list of ResRow (host arithmetic, runkma.c:765-783)"""

@@ -1236,6 +1236,414 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 	R.n_hits[r] = nh; R.best_score[r] = (nh > 0) ? bestRead : 0; R.out_flag[r] = fl;
 }
 
+// ---- stage 3c, per read: KMA() with traceback (align.c:214-507; NW nw.c:26-309, NW_band :310-640) ----------------
+// One lane per read that ConClave filed under a template. Same seeds / chain / joins as kma_score above, but the move
+// matrix E is kept (bytes, per-lane HBM scratch) and walked into alignment columns, which leave the kernel as a
+// run-length list of (=, X, I, D) -- the classes of makeCigar (sam.c:57-78) and everything alnToMat needs besides
+// the read itself (assembly.c:1317-1444).
+struct TraceArgs {
+	DevDB db;
+	int64_t n_reads;
+	const uint64_t *seq;
+	const int64_t *seq_off;
+	const int32_t *len;
+	const int32_t *N;
+	const int64_t *N_off;
+	const int32_t *flag;         // stage-3a flag of the read's record (16: its reverse complement is the stored read)
+	const int32_t *tmpl;         // ConClave's signed template per read (0: none)
+	const uint8_t *tmpl_ok;      // per template: assemble it? (NULL: all)
+	int M, MM, U, W1, Wl;
+	int d[25];
+	int minlen, mq;
+	double scoreT, mrc;
+	// scratch, lane-interleaved unless noted
+	int32_t *s32;                // MEM arrays (7 x cap1)
+	int32_t *rows;               // 4 DP rows of ncols ints
+	uint8_t *E;                  // e_cap bytes per lane, contiguous per lane
+	uint32_t *ops_s;             // ops_cap run slots
+	int64_t lanes, e_cap;
+	int mem_cap, ncols, ops_cap;
+	// out
+	int32_t *o_stats;            // 10 per read: score, start, end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ
+	int64_t *o_off;              // per read: first run in `ops`
+	int32_t *o_nops;
+	uint32_t *ops;               // runs: (length << 2) | class, class 0 '=' 1 'X' 2 'I' 3 'D'
+	int64_t ops_pool_cap;
+	unsigned long long *counters;   // [0] run pool top, [1] status
+};
+
+struct Emit {
+	uint32_t *ops; int64_t stride; int cap, n;
+	bool over;
+	__device__ __forceinline__ uint32_t &at(int i) const { return ops[(int64_t) i * stride]; }
+	__device__ void push(int cls, int len) {
+		if(len <= 0) return;
+		if(n && (int) (at(n - 1) & 3u) == cls) { at(n - 1) += (uint32_t) len << 2; return; }
+		if(n < cap) at(n++) = ((uint32_t) len << 2) | (uint32_t) cls; else over = true;
+	}
+	// drop the last `cols` columns
+	__device__ void pop(int cols) {
+		while(cols > 0 && n) {
+			const int have = (int) (at(n - 1) >> 2);
+			if(have <= cols) { cols -= have; --n; }
+			else { at(n - 1) -= (uint32_t) cols << 2; cols = 0; }
+		}
+	}
+	__device__ int last_cls() const { return n ? (int) (at(n - 1) & 3u) : -1; }
+	__device__ int last_len() const { return n ? (int) (at(n - 1) >> 2) : 0; }
+};
+
+struct TLane {
+	Lane L;
+	int32_t *rows; uint8_t *E; int64_t e_cap;
+	Emit em;
+	int status;     // 1: a DP problem did not fit the per-lane move matrix
+};
+
+#define TROW(T, r, n) (T).rows[((int64_t) ((r) * (T).L.ncols + (n))) * (T).L.lanes]
+
+// walk of the move matrix (nw.c:256-305 / :586-635), emitting columns. stride = bytes per template row, dn = column
+// change per template step (0 full, -1 band), q_pos = query index of the start column. lead_trim: gaps in front are
+// dropped (leadTailAln with t_s == 0, align.c:97-112): a dropped gap-in-template column leaves a read base unaligned.
+__device__ void trace_walk(TLane &T, const uint8_t *E, int stride, int m, int n, int dn, int q_pos, const uint64_t *ts,
+                           int nuc_pos, int tlen_total, const QView &q, int q_s, int q_len, bool lead_trim, Aln &s, int &clip_start, int &clip_end) {
+	const uint8_t *row = E + (int64_t) m * stride;
+	s.len = s.match = s.tGaps = s.qGaps = 0;
+	bool lead = lead_trim;
+	while(row[n] != 0) {
+		if(nuc_pos == tlen_total) nuc_pos = 0;
+		const int mv = row[n] & 7;
+		if(mv == 1) {
+			const int tb = tn(ts, nuc_pos), qb = qn(q, q_s + q_pos);
+			T.em.push(tb == qb ? 0 : 1, 1);
+			lead = false;
+			++s.match; ++s.len; ++nuc_pos; row += stride; n += 1 + dn; ++q_pos;
+		} else if(mv >= 4) {
+			// gap in the read: template bases consumed until a cell that may open the gap
+			int g = 1;
+			while(!(row[n] >> 4)) { row += stride; n += dn; ++g; }
+			row += stride; n += dn;
+			nuc_pos += g;        // like the reference, the wrap of a circular template is only taken on a column boundary
+			if(!lead) { T.em.push(3, g); s.qGaps += g; s.len += g; }
+		} else {
+			int g = 1;
+			while(!(row[n] >> 3)) { ++n; ++g; }
+			++n;
+			q_pos += g;
+			if(!lead) { T.em.push(2, g); s.tGaps += g; s.len += g; } else clip_start += g;
+		}
+	}
+	clip_end = q_len - q_pos;
+}
+
+// NW / NW_band with the move matrix (nw.c:26-309, 310-640; fill identical to NW_score / NW_band_score).
+// band < 0: full matrix. Returns false if E does not fit.
+__device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QView &q, int k, int t_s, int t_e, int q_s, int q_e,
+                         int band, bool lead_trim, int circ_pos, Aln &s, int &clip_start, int &clip_end) {
+	const Lane &L = T.L;
+	const int W1 = L.W1, U = L.U;
+	int t_len = t_e - t_s;
+	const int q_len = q_e - q_s;
+	if(t_len < 0) t_len += tlen_total;
+	s.pos = 0; clip_start = 0; clip_end = 0;
+	if(t_len == 0 || q_len == 0) {
+		s = nw_degenerate(t_len, q_len, U, W1);
+		if(t_len == 0) T.em.push(2, q_len); else T.em.push(3, t_len);
+		(void) circ_pos;
+		return true;
+	}
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(band < 0) {
+		const int pitch = q_len + 1;
+		if((int64_t) pitch * (t_len + 1) > T.e_cap || q_len + 2 > L.ncols) return false;
+		uint8_t *E = T.E, *Er = E + (int64_t) pitch * t_len;
+		int dc = 0, dp = 1, pc = 2, pp = 3;
+		s.score = low;
+		for(int m = 0; m < t_len; ++m) E[(int64_t) pitch * m + q_len] = (0 < k) ? 0 : 5;
+		if(!(0 < k)) E[(int64_t) pitch * (t_len - 1) + q_len] = 36;
+		if(k == 2) {
+			for(int n = q_len; n >= 0; --n) { TROW(T, dp, n) = 0; TROW(T, pp, n) = low; Er[n] = 0; }
+		} else {
+			for(int n = q_len - 1; n >= 0; --n) { TROW(T, dp, n) = W1 + (q_len - 1 - n) * U; TROW(T, pp, n) = low; Er[n] = 3; }
+			Er[q_len - 1] = 18; Er[q_len] = 0; TROW(T, dp, q_len) = 0; TROW(T, pp, q_len) = 0;
+		}
+		int best_m = 0, npos = t_e - 1;
+		for(int m = t_len - 1; m >= 0; --m, --npos) {
+			if(npos < 0) npos = tlen_total - 1;
+			uint8_t *e = E + (int64_t) pitch * m;
+			TROW(T, dc, q_len) = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			int Qprev = low;
+			const int tb = tn(ts, npos);
+			for(int n = q_len - 1; n >= 0; --n) {
+				uint8_t cell = 0, mv;
+				int Q = TROW(T, dc, n + 1) + W1;
+				int P = TROW(T, dp, n) + W1;
+				int D;
+				if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+				int x = Qprev + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				x = TROW(T, pp, n) + U;
+				if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+				x = TROW(T, dp, n + 1) + L.d[5 * tb + qn(q, q_s + n)];
+				if(D <= x) { D = x; cell |= 1; } else cell |= mv;
+				TROW(T, dc, n) = D; TROW(T, pc, n) = P; e[n] = cell; Qprev = Q;
+			}
+			if(k < 0 && s.score < TROW(T, dc, 0)) { s.score = TROW(T, dc, 0); best_m = m; }
+			int x = dc; dc = dp; dp = x; x = pc; pc = pp; pp = x;
+		}
+		int sm = 0, sn = 0;
+		if(k < 0) {
+			sm = best_m;
+			if(k == -2) for(int n = 0; n < q_len; ++n) if(s.score <= TROW(T, dp, n)) { s.score = TROW(T, dp, n); sm = 0; sn = n; }
+		} else s.score = TROW(T, dp, 0);
+		const int score = s.score;
+		clip_start = sn;
+		trace_walk(T, E, pitch, sm, sn, 0, sn, ts, sm + t_s, tlen_total, q, q_s, q_len, lead_trim, s, clip_start, clip_end);
+		s.score = score; s.pos = 0;
+		return true;
+	}
+	// banded (nw.c:310-640)
+	if(band & 1) ++band;
+	const int half = band >> 1, bq = band + 1, pitch = bq + 1;
+	if((int64_t) pitch * (t_len + 1) > T.e_cap || band + 4 > L.ncols) return false;
+	uint8_t *E = T.E, *Er = E + (int64_t) pitch * t_len;
+	int dc = 0, dp = 1, pc = 2, pp = 3;
+	s.score = low;
+	int c = (t_len + q_len) >> 1;
+	int sn = q_len - 1 - (c - half);
+	if(k != 2) {
+		for(int n = sn - 1; n >= 0; --n) { TROW(T, dp, n) = W1 + (sn - n - 1) * U; TROW(T, pp, n) = low; Er[n] = 3; }
+		Er[sn - 1] = 18; Er[sn] = 0; TROW(T, dp, sn) = 0; TROW(T, pp, sn) = 0;
+	} else {
+		for(int n = sn; n >= 0; --n) { TROW(T, dp, n) = 0; TROW(T, pp, n) = low; Er[n] = 0; }
+	}
+	int bm = 0, bn = 0, en = 0, n = 0, npos = t_e - 1;
+	for(int m = t_len - 1; m >= 0; --m, --npos, --c) {
+		if(npos < 0) npos = tlen_total - 1;
+		uint8_t *e = E + (int64_t) pitch * m;
+		int sq = c + half, eq = c - half;
+		if(eq < 0) { eq = 0; ++en; } else en = 0;
+		int Qprev = low;
+		if(sq < q_len - 1) {
+			sn = bq - 1; TROW(T, dc, bq) = low; e[bq] = 37;
+		} else {
+			sq = q_len - 1; sn = en + (q_len - eq);
+			TROW(T, dc, sn) = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			e[sn] = (0 < k) ? 0 : 37;
+			--sn;
+		}
+		const int tb = tn(ts, npos);
+		int qp = sq;
+		for(n = sn; n > en; --qp, --n) {
+			uint8_t cell = 0, mv;
+			int Q = TROW(T, dc, n + 1) + W1;
+			int P = TROW(T, dp, n - 1) + W1;
+			int D;
+			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+			x = TROW(T, pp, n - 1) + U;
+			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+			x = TROW(T, dp, n) + L.d[5 * tb + qn(q, q_s + qp)];
+			if(D <= x) { D = x; cell |= 1; } else cell |= mv;
+			TROW(T, dc, n) = D; TROW(T, pc, n) = P; e[n] = cell; Qprev = Q;
+		}
+		{	// band edge: no gap-in-query state (nw.c:1079-1105)
+			uint8_t cell = 0, mv;
+			int Q = TROW(T, dc, n + 1) + W1, x = Qprev + U;
+			if(Q < x) { Q = x; mv = 3; } else { mv = 2; cell |= 16; }
+			TROW(T, pc, n) = low;
+			int D = TROW(T, dp, n) + L.d[5 * tb + qn(q, q_s + qp)];
+			if(Q <= D) cell |= 1; else { D = Q; cell |= mv; }
+			TROW(T, dc, n) = D; e[n] = cell;
+		}
+		if(eq == 0 && k < 0 && s.score < TROW(T, dc, n)) { s.score = TROW(T, dc, n); bm = m; bn = n; }
+		int x = dc; dc = dp; dp = x; x = pc; pc = pp; pp = x;
+	}
+	int q_pos = 0;
+	if(bm == 0) { bn = en; s.score = TROW(T, dp, en); }
+	if(k == -2) for(n = en; n < bq; ++n) if(s.score <= TROW(T, dp, n)) { s.score = TROW(T, dp, n); bm = 0; bn = n; q_pos = n - en; }
+	const int score = s.score;
+	clip_start = q_pos;
+	trace_walk(T, E, pitch, bm, bn, -1, q_pos, ts, bm + t_s, tlen_total, q, q_s, q_len, lead_trim, s, clip_start, clip_end);
+	s.score = score; s.pos = 0;
+	return true;
+}
+
+// KMA(), align.c:214-507. Returns the alignment statistics (len == 1, score == 0: no alignment); columns go to T.em.
+__device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq,
+                         int &clip_start, int &clip_end, unsigned &mapQ) {
+	const Aln FAIL = {0, 1, 0, 0, 0, 0};
+	const Lane &L = T.L;
+	const int k = (int) db.kmersize, q_len = q.L, bw = 64, cap = L.cap1 - 1;
+	clip_start = clip_end = 0; mapQ = 0;
+	T.em.n = 0;
+	int nm = 0;
+	// seeds: the byte-wise loop of KMA() -- a stretch between Ns (or up to the read end) is probed only while MORE than
+	// k bases remain in it (align.c:258, 308, 364), unlike KMA_score
+	{
+		int i = 0, ni = 1;
+		while(i < q_len) {
+			while(ni <= q.nN && qN_at(q, ni) < i) ++ni;
+			const int end = (ni <= q.nN) ? qN_at(q, ni) : q_len;
+			const int lowq = (ni > 1) ? qN_at(q, ni - 1) + 1 : 0;
+			if(i < end - k) i += k - 1; else { i = end + 1; continue; }
+			while(i < end) {
+				const int v = tpos_get(db, t, q_kmer(q, i - (k - 1), k));
+				if(v == 0) { ++i; continue; }
+				i -= k - 1;
+				if(v > 0) {
+					if(nm >= cap) { T.status = 2; return FAIL; }
+					i = add_mem(L, nm, ts, t_len, q, i, v, k, lowq, end);
+					++nm;
+				} else {
+					const int32_t *dl = db.tpos_dups + (-v - 1);
+					const int cnt = dl[0];
+					int bias = i;
+					for(int c = 1; c <= cnt; ++c) {
+						if(nm >= cap) { T.status = 2; return FAIL; }
+						const int qe = add_mem(L, nm, ts, t_len, q, i, dl[c], k, lowq, end);
+						++nm;
+						bias = max(bias, qe);
+					}
+					i = bias + 1;
+				}
+				if(i < end - k) i += k - 1; else i = end + 1;
+			}
+			i = end + 1;
+		}
+	}
+	if(!nm) return FAIL;
+	int start = chain_seeds(L, nm, q_len, t_len, k, &mapQ);
+	if(mapQ < (unsigned) mq || MEMA(L, 5, start) < k) return FAIL;
+
+	Aln S = {0, 0, 0, 0, 0, 0};
+	{	// leading tail (leadTailAln with Frag_align, align.c:53-131)
+		const int t_e = MEMA(L, 0, start) - 1, q_e = MEMA(L, 2, start);
+		S.pos = t_e;
+		if(q_e) {
+			int t_s = 0, q_s = 0;
+			if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+			else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+			if(t_e - t_s > 0 && q_e - q_s > 0) {
+				const int band = abs(t_e - t_s - q_e + q_s) + bw;
+				const bool full = q_e - q_s <= band || t_e - t_s <= band;
+				Aln r; int cs, ce;
+				if(!nw_trace(T, ts, t_len, q, -1 - (t_s == 0), t_s, t_e, q_s, q_e, full ? -1 : band, t_s == 0, 0, r, cs, ce)) { T.status = 1; return FAIL; }
+				clip_start = q_s + cs;
+				S.pos -= r.len - r.tGaps;
+				S.score = r.score; S.len = r.len; S.match = r.match; S.tGaps = r.tGaps; S.qGaps = r.qGaps;
+			} else clip_start = q_s;
+		}
+	}
+	for(;;) {
+		const int qS = MEMA(L, 2, start), qE = MEMA(L, 3, start);
+		T.em.push(0, qE - qS);
+		S.len += qE - qS; S.match += qE - qS;
+		for(int i = qS; i < qE; ++i) { const int b = qn(q, i); S.score += L.d[6 * b]; }
+		const int nxt = MEMA(L, 6, start);
+		if(!nxt) break;
+		const int q_s = qE, t_s = MEMA(L, 1, start) - 1;
+		start = nxt;
+		int qSn = MEMA(L, 2, start), tSn = MEMA(L, 0, start);
+		if(qSn < q_s) { tSn += q_s - qSn; qSn = q_s; }
+		int t_e = tSn - 1, t_l;
+		if(t_e < t_s) {
+			if(t_s <= MEMA(L, 1, start)) { qSn += t_s - t_e; t_e = t_s; t_l = 0; }
+			else t_l = t_len - t_s + t_e;
+		} else t_l = t_e - t_s;
+		MEMA(L, 2, start) = qSn; MEMA(L, 0, start) = tSn;
+		const int q_e = qSn;
+		if(abs(t_l - q_e + q_s) * L.U > q_len * L.M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+		if(t_l > 0 || q_e - q_s > 0) {
+			const int band = abs(t_l - q_e + q_s) + bw;
+			const bool full = q_e - q_s <= band || t_l <= band;
+			Aln r; int cs, ce;
+			if(!nw_trace(T, ts, t_len, q, 0, t_s, t_e, q_s, q_e, full ? -1 : band, false, t_len, r, cs, ce)) { T.status = 1; return FAIL; }
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+	}
+	{	// trailing tail (trailTailAln with Frag_align, align.c:140-212)
+		const int t_s = MEMA(L, 1, start) - 1, q_s = MEMA(L, 3, start);
+		int q_e = q_len, t_e = t_len, fr_end = 0;
+		if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+			t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+		} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+			q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+		}
+		if(t_e - t_s > 0 && q_e - q_s > 0) {
+			const int band = abs(t_e - t_s - q_e + q_s) + bw;
+			const bool full = q_e - q_s <= band || t_e - t_s <= band;
+			Aln r; int cs, ce;
+			if(!nw_trace(T, ts, t_len, q, 1 + (t_e == t_len), t_s, t_e, q_s, q_e, full ? -1 : band, false, 0, r, cs, ce)) { T.status = 1; return FAIL; }
+			fr_end = ce;
+			if(t_e == t_len) {
+				// gaps at the very end of the template are trimmed; the first column of the tail always stays
+				int left = r.len - 1;
+				while(left > 0 && T.em.last_cls() >= 2) {
+					const int take = min(left, T.em.last_len()), cls = T.em.last_cls();
+					T.em.pop(take);
+					if(cls == 2) { r.tGaps -= take; fr_end += take; } else r.qGaps -= take;
+					r.len -= take; left -= take;
+				}
+			}
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+		clip_end = q_len - q_e + fr_end;
+	}
+	return S;
+}
+
+__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
+	__shared__ int s_d[25];
+	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
+	__syncthreads();
+	const int64_t gtid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(gtid >= A.lanes) return;
+	TLane T;
+	Lane &L = T.L;
+	L.s32 = A.s32 + gtid; L.s64 = nullptr; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
+	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
+	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0;
+	L.diag_uniform = 0;
+	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
+	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
+	for(int64_t r = gtid; r < A.n_reads; r += A.lanes) {
+		int32_t *st = A.o_stats + 10 * r;
+		for(int x = 0; x < 10; ++x) st[x] = 0;
+		A.o_off[r] = 0; A.o_nops[r] = 0;
+		const int tt = A.tmpl[r], t = abs(tt);
+		if(t == 0 || (A.tmpl_ok && !A.tmpl_ok[t])) continue;
+		QView q;
+		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+		q.rc = (((A.flag[r] & 16) != 0) != (tt < 0)) ? 1 : 0;
+		const int t_len = A.db.tlen[t];
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
+		T.em.n = 0; T.em.over = false; T.status = 0;
+		int cs = 0, ce = 0;
+		unsigned mapQ = 0;
+		const Aln S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
+		if(T.status || T.em.over) { atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16))); continue; }
+		// assemble_KMA, assembly.c:1931-1961
+		const int aln_len = S.len, start = S.pos;
+		int end = start + aln_len - S.tGaps;
+		if(t_len < end) end -= t_len;
+		int read_score = S.score;
+		if(start == 0) read_score += A.Wl;
+		if(end == t_len) read_score += A.Wl;
+		double score = 0;
+		if(A.minlen <= aln_len && ((A.mrc * q.L <= S.len - S.qGaps) || (A.mrc * t_len <= S.len - S.tGaps))) score = 1.0 * read_score / aln_len;
+		else read_score = 0;
+		if(!(0 < read_score && A.scoreT <= score)) continue;
+		const int64_t o = (int64_t) atomicAdd(&A.counters[0], (unsigned long long) T.em.n);
+		if(o + T.em.n > A.ops_pool_cap) { atomicMax(&A.counters[1], 2ull); continue; }
+		for(int x = 0; x < T.em.n; ++x) A.ops[o + x] = T.em.at(x);
+		st[0] = read_score; st[1] = start; st[2] = (t_len < end) ? end - t_len : end; st[3] = aln_len; st[4] = cs; st[5] = ce;
+		st[6] = S.match; st[7] = S.tGaps; st[8] = S.qGaps; st[9] = (int) mapQ;
+		A.o_off[r] = o; A.o_nops[r] = T.em.n;
+	}
+}
+
 } // namespace
 
 // common launcher. SE: one record per read. PE (rec_mate != null): two records per pair over interleaved mates.
@@ -1350,4 +1758,48 @@ int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 	kmahip_cands c;
 	c.rc_flag = recs->rc_flag; c.flag = recs->flag; c.T_off = recs->R_off; c.T = recs->T; c.T_cap = recs->T_cap;
 	return launch_align(db, ws, reads, &c, recs->mate, recs->rc, pe_kind, p, out, stream);
+}
+
+// stage 3c launcher: scratch lives in the workspace, sized by the longest read
+int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                        const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	if(n < 0 || !flag || !tmpl || !p || !out || !out->stats || !out->ops_off || !out->n_ops || (out->ops_cap > 0 && !out->ops)) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
+	if(!db->dev.tpos_slots) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
+	if(n == 0) return KMAHIP_OK;
+	const int max_len = reads->max_len;
+	if(max_len <= 0 || max_len > (1 << 20)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^20) for the trace stage"); return KMAHIP_EINVAL; }
+	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
+	const int ncols = max_len + 72;
+	const int ops_cap = 2 * max_len + 256;
+	// move matrix per lane: a banded tail (band 64 + 64) or a full join whose shorter side is within the band
+	int64_t e_cap = std::max<int64_t>((int64_t) 134 * (max_len + 68), (int64_t) (max_len / 2 + 4) * (max_len + 4));
+	e_cap = std::min<int64_t>(e_cap, 16ll << 20);
+	int64_t lanes = 65536;
+	const int64_t per_lane = e_cap + (int64_t) (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4;
+	while(lanes > 256 && lanes * per_lane > (6ll << 30)) lanes >>= 1;
+	lanes = std::min<int64_t>(lanes, ((n + 255) / 256) * 256);
+	if(ws->t_lanes != lanes || ws->t_max_len != max_len) {
+		(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
+		ws->t_s32 = nullptr; ws->t_E = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->t_s32, (size_t) lanes * (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4));
+		HIP_TRY(hipMalloc((void **) &ws->t_E, (size_t) lanes * e_cap));
+		ws->t_lanes = lanes; ws->t_max_len = max_len;
+	}
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	TraceArgs A;
+	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.flag = flag; A.tmpl = tmpl; A.tmpl_ok = tmpl_ok;
+	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
+	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
+	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
+	A.s32 = ws->t_s32; A.rows = ws->t_s32 + (size_t) lanes * 7 * (mem_cap + 1);
+	A.ops_s = (uint32_t *) (A.rows + (size_t) lanes * 4 * ncols);
+	A.E = ws->t_E; A.lanes = lanes; A.e_cap = e_cap; A.mem_cap = mem_cap; A.ncols = ncols; A.ops_cap = ops_cap;
+	A.o_stats = out->stats; A.o_off = out->ops_off; A.o_nops = out->n_ops; A.ops = out->ops; A.ops_pool_cap = out->ops_cap;
+	A.counters = ws->counters;
+	hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
 }

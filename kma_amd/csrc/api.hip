@@ -25,6 +25,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 		delete ev;
 	}
 	(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64); (void) hipFree(ws->a_task);
+	(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
 	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
 	delete ws;
 }
@@ -345,4 +346,56 @@ extern "C" int kmahip_map_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	if(!db || !ws || !reads || !p || !recs_out || !hits_out || !pe_kind) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	if(reads->max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set"); return KMAHIP_EINVAL; }
 	return run_host_pe(db, ws, reads, p, recs_out, hits_out, pe_kind);
+}
+
+extern "C" int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                                      const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, void *stream) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_launch_trace(db, ws, reads, flag, tmpl, tmpl_ok, p, out, (hipStream_t) stream);
+}
+
+extern "C" int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                                  const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, int64_t *ops_needed) {
+	if(!db || !ws || !reads || !flag || !tmpl || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0 || out->ops_cap < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(ops_needed) *ops_needed = 0;
+	if(n == 0) return KMAHIP_OK;
+	const size_t D = db->info.DB_size;
+	int rc;
+	if((rc = stage_reserve(ws, 0, (size_t) (reads->seq_words + 1) * 8)) || (rc = stage_reserve(ws, 1, (size_t) (n + 1) * 8)) ||
+	   (rc = stage_reserve(ws, 2, (size_t) n * 4)) || (rc = stage_reserve(ws, 3, (size_t) reads->N_total * 4)) ||
+	   (rc = stage_reserve(ws, 4, (size_t) (n + 1) * 8)) || (rc = stage_reserve(ws, 5, (size_t) n * 8 + D + 8)) ||
+	   (rc = stage_reserve(ws, 6, (size_t) n * (40 + 8 + 4) + 8)) || (rc = stage_reserve(ws, 7, (size_t) (out->ops_cap + 1) * 4))) return rc;
+	hipStream_t s = 0;
+	HIP_TRY(hipMemsetAsync((char *) ws->stage[0] + (size_t) reads->seq_words * 8, 0, 8, s));
+	if(reads->seq_words) HIP_TRY(hipMemcpyAsync(ws->stage[0], reads->seq, (size_t) reads->seq_words * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[1], reads->seq_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[2], reads->len, (size_t) n * 4, hipMemcpyHostToDevice, s));
+	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	int32_t *d_flag = (int32_t *) ws->stage[5], *d_tmpl = d_flag + n;
+	uint8_t *d_ok = tmpl_ok ? (uint8_t *) (d_tmpl + n) : nullptr;
+	HIP_TRY(hipMemcpyAsync(d_flag, flag, (size_t) n * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(d_tmpl, tmpl, (size_t) n * 4, hipMemcpyHostToDevice, s));
+	if(tmpl_ok) HIP_TRY(hipMemcpyAsync(d_ok, tmpl_ok, D, hipMemcpyHostToDevice, s));
+	kmahip_reads d = *reads;
+	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
+	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
+	kmahip_traces o;
+	o.ops_off = (int64_t *) ws->stage[6]; o.stats = (int32_t *) (o.ops_off + n); o.n_ops = o.stats + 10 * n;
+	o.ops = (uint32_t *) ws->stage[7]; o.ops_cap = out->ops_cap;
+	if((rc = kmahip_launch_trace(db, ws, &d, d_flag, d_tmpl, d_ok, p, &o, s))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned long long c[8];
+	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	if(c[1]) HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
+	if(ops_needed) *ops_needed = (int64_t) c[0];
+	if(c[1] == 2 || (int64_t) c[0] > out->ops_cap) { kmahip_set_error("ops_cap %lld too small, need %llu", (long long) out->ops_cap, c[0]); return KMAHIP_EOVERFLOW; }
+	if(c[1]) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %llu)", c[1]); return KMAHIP_EDEVICE; }
+	HIP_TRY(hipMemcpy(out->ops_off, o.ops_off, (size_t) n * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out->stats, o.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out->n_ops, o.n_ops, (size_t) n * 4, hipMemcpyDeviceToHost));
+	if(c[0]) HIP_TRY(hipMemcpy(out->ops, o.ops, (size_t) c[0] * 4, hipMemcpyDeviceToHost));
+	return KMAHIP_OK;
 }

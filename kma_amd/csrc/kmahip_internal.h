@@ -86,6 +86,11 @@ struct kmahip_ws {
 	int a_mem_cap, a_ncols;
 	void *a_task;
 	int64_t a_task_cap;
+	// trace stage (3c) scratch
+	int32_t *t_s32;
+	uint8_t *t_E;
+	int64_t t_lanes;
+	int t_max_len;
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;
@@ -105,6 +110,8 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
                           const kmahip_params *p, kmahip_cands *out, hipStream_t stream);
 int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
                            const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
+int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                        const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream);
 int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                           kmahip_pe_recs *out, hipStream_t stream);
 int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,

@@ -1,0 +1,64 @@
+"""Stage 3c per read on the GPU: KMA() with traceback vs the oracle and vs the reference's SAM records."""
+import numpy as np
+import pytest
+
+import golden_util
+import oracle
+from kma_amd import formats
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(g, name):
+    from kma_amd import binding, synth
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        b = g["batch"]
+        (rc_flag, flag, T_off, T), h = db.map_se(b)
+        cc = db.conclave_se(b.length, T_off, h)
+        rows = db.res_rows(cc["w_scores"])
+        ok = np.zeros(int(db.info.DB_size), np.uint8)
+        for r in rows:
+            ok[r.template_id] = r.significant
+        stats, off, nops, ops = db.align_trace(b, h["flag"], cc["tmpl"], ok)
+    finally:
+        db.close()
+    sam = golden_util.load_sam(name)
+    names = golden_util.template_names(name)
+    al = oracle.OracleAligner(oracle.OracleDB(g["prefix"]))
+    seen = 0
+    for i, r in enumerate(g["s1"]):
+        hd = r["hdr"].rstrip(b"\0").decode()
+        tt = int(cc["tmpl"][i])
+        st = stats[i]
+        if tt == 0 or not ok[abs(tt)]:
+            assert not st.any() and hd not in sam, hd
+            continue
+        # oracle on the same read
+        read = g["reads"][i]
+        fl = int(h["flag"][i])
+        if fl & 16:
+            read = synth.revcomp_codes(read)
+        if tt < 0:
+            read = synth.revcomp_codes(read)
+            fl |= 16
+        o = al.align_trace(read, abs(tt))
+        if o is None:
+            assert not st.any() and hd not in sam, hd
+            continue
+        cigar = binding.cigar_from_runs(ops[off[i]:off[i] + nops[i]], int(st[4]), int(st[5]))
+        got = dict(score=int(st[0]), start=int(st[1]), end=int(st[2]), aln_len=int(st[3]), clip_start=int(st[4]), clip_end=int(st[5]),
+                   match=int(st[6]), tGaps=int(st[7]), qGaps=int(st[8]), mapQ=int(st[9]), cigar=cigar)
+        assert got == o, (hd, got, o)
+        seen += 1
+        assert (fl, names[abs(tt) - 1], got["start"] + 1, min(254, got["mapQ"]), cigar, got["score"]) == sam[hd][0], hd
+    assert seen == len(sam)
+    return seen
+
+
+def test_trace_matches_reference_sam(golden_se):
+    assert _case(golden_se, "se") > 900
+
+
+def test_trace_matches_reference_sam_long_reads(golden_long):
+    assert _case(golden_long, "long") > 200
