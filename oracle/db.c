@@ -119,3 +119,5 @@ int64_t orc_hash_get(const orc_db *db, uint64_t key) {
 		if((k & db->size) != bucket) return -1;
 	}
 }
+
+const uint64_t *orc_db_template(const orc_db *db, int t) { return db->tseq + db->tseq_off[t]; }

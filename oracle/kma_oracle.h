@@ -131,6 +131,15 @@ double orc_p_chisqr(long double q);
 int orc_res_stats(int DB_size, const uint64_t *w_scores, const int32_t *template_lengths, double evalue, double scoreT,
                   double *expected, double *q_value, double *p_value, int32_t *significant);
 
+/* stage 3c per template: pile-up (alnToMat, assembly.c:1317-1444), consensus (callConsensus :1499-1631) -- see assembly.c */
+typedef struct orc_assembly orc_assembly;
+orc_assembly *orc_assembly_new(int t_len);
+void orc_assembly_free(orc_assembly *m);
+void orc_assembly_add(orc_assembly *m, const char *cols, int aln_len, const uint8_t *read, int start, int score);
+void orc_assembly_call(const orc_assembly *m, const uint64_t *tseq, int bcd, double evalue, int64_t *out, char *cons);
+int orc_assembly_has_reads(const orc_assembly *m);
+const uint64_t *orc_db_template(const orc_db *db, int t);
+
 #ifdef __cplusplus
 }
 #endif

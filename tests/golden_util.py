@@ -161,6 +161,18 @@ def load_res(name="se"):
     return out
 
 
+def load_res_identity(name="se"):
+    """template name -> (Template_Identity, Template_Coverage, Query_Identity, Query_Coverage, Depth) as printed"""
+    out = {}
+    with open(os.path.join(GOLD, name, "out.res")) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            c = [x.strip() for x in line.rstrip("\n").split("\t")]
+            out[c[0]] = tuple(c[4:9])
+    return out
+
+
 def load_frags(name="se"):
     """`.frag.gz` rows: header -> (number of equally good templates, template name). Score / start / end of these rows come
     from the stage-3c re-alignment (assembly.c:1940-1965), not from ConClave, and are not used."""

@@ -197,6 +197,56 @@ def res_stats(w_scores, tlen, evalue=0.05, scoreT=0.5):
     return out
 
 
+class Assembly:
+    """Pile-up + consensus of one template (oracle/assembly.c)."""
+
+    def __init__(self, odb, t, t_len):
+        L = lib()
+        L.orc_assembly_new.restype = C.c_void_p
+        L.orc_assembly_new.argtypes = [C.c_int]
+        L.orc_assembly_free.argtypes = [C.c_void_p]
+        L.orc_assembly_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_assembly_call.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_char_p]
+        L.orc_db_template.restype = C.c_void_p
+        L.orc_db_template.argtypes = [C.c_void_p, C.c_int]
+        self.h = L.orc_assembly_new(int(t_len))
+        self.tseq = L.orc_db_template(odb.h, int(t))
+        self.t_len = int(t_len)
+        self.n = 0
+
+    def add(self, trace, read):
+        """trace = OracleAligner.align_trace result; read = the oriented read it was computed from"""
+        rd = np.ascontiguousarray(read[trace["clip_start"]:], np.uint8)
+        lib().orc_assembly_add(self.h, trace["cols"], len(trace["cols"]), _p(rd), trace["start"], trace["score"])
+        self.n += 1
+
+    def call(self, bcd=1, evalue=0.05):
+        out = np.zeros(4, np.int64)
+        cons = C.create_string_buffer(int(2 * self.t_len + 64 + 2 * 1024 * 1024))
+        lib().orc_assembly_call(self.h, self.tseq, bcd, evalue, _p(out), cons)
+        return dict(cover=int(out[0]), aln_len=int(out[1]), depth=int(out[2]), asm_len=int(out[3]), consensus=cons.value.decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_assembly_free(self.h)
+            self.h = None
+
+
+def res_identity_columns(call, t_len):
+    """runkma.c:792-809: the five consensus columns of a `.res` row as printed, or None when the row is not written"""
+    if call["cover"] <= 0:
+        return None
+    import ctypes
+    ident = 100.0 * call["cover"] / t_len
+    cover = 100.0 * call["aln_len"] / t_len
+    q_id = 100.0 * call["cover"] / call["aln_len"]
+    q_cover = 100.0 * t_len / call["aln_len"]
+    depth = float(np.longdouble(call["depth"]) / np.longdouble(t_len))
+    if not (1.0 <= ident and 0 < ident):
+        return None
+    return tuple("%.2f" % x for x in (ident, cover, q_id, q_cover, depth))
+
+
 def cigar_of(cols, clip_start=0, clip_end=0):
     """makeCigar (sam.c:30-98): run-length code of the column classes, soft clips around it"""
     out = [f"{clip_start}S"] if clip_start else []
@@ -257,7 +307,8 @@ class OracleAligner:
             return None
         keys = ("score", "start", "end", "aln_len", "clip_start", "clip_end", "match", "tGaps", "qGaps", "mapQ")
         out = dict(zip(keys, (int(x) for x in stats)))
-        out["cigar"] = cigar_of(cols.raw[:n].decode(), out["clip_start"], out["clip_end"])
+        out["cols"] = cols.raw[:n]
+        out["cigar"] = cigar_of(out["cols"].decode(), out["clip_start"], out["clip_end"])
         return out
 
     def align_pe(self, seqA, lenA, NA, flagA, seqB, lenB, NB, flagB, T):

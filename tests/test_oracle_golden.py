@@ -223,3 +223,48 @@ def test_oracle_traceback_matches_reference_sam(golden_se):
 
 def test_oracle_traceback_matches_reference_sam_long_reads(golden_long):
     assert _oracle_trace_case(golden_long, "long") > 200
+
+
+def _oracle_assembly_case(g, name):
+    """Stage 3c per template: reads in the order the reference assembles them (reverse stream order: ConClave prepends to
+    the per-template list, conclave.c:164-165), piled up and called; the five consensus columns of every `.res` row must
+    come out as printed, and a template without a row must fail the row's own gate."""
+    from kma_amd import synth
+    res, cc, st, tlen = _oracle_conclave_se(g)
+    names = golden_util.template_names(name)
+    exp = golden_util.load_res_identity(name)
+    odb = oracle.OracleDB(g["prefix"])
+    al = oracle.OracleAligner(odb)
+    per_t = {}
+    for i in range(len(g["s1"]) - 1, -1, -1):
+        tt = int(cc["tmpl"][i])
+        if tt and st["significant"][abs(tt)]:
+            per_t.setdefault(abs(tt), []).append(i)
+    rows = 0
+    for t in range(1, len(tlen)):
+        if not (cc["w_scores"][t] > 0 and st["significant"][t]):
+            assert names[t - 1] not in exp
+            continue
+        asm = oracle.Assembly(odb, t, tlen[t])
+        for i in per_t.get(t, []):
+            read = g["reads"][i]
+            if int(res["out_flag"][i]) & 16:
+                read = synth.revcomp_codes(read)
+            if int(cc["tmpl"][i]) < 0:
+                read = synth.revcomp_codes(read)
+            o = al.align_trace(read, t)
+            if o is not None:
+                asm.add(o, read)
+        got = oracle.res_identity_columns(asm.call(), int(tlen[t])) if asm.n else None
+        assert got == exp.get(names[t - 1]), (names[t - 1], got, exp.get(names[t - 1]))
+        rows += got is not None
+    assert rows == len(exp)
+    return rows
+
+
+def test_oracle_assembly_matches_res_identity_columns(golden_se):
+    assert _oracle_assembly_case(golden_se, "se") > 50
+
+
+def test_oracle_assembly_matches_res_identity_columns_long_reads(golden_long):
+    assert _oracle_assembly_case(golden_long, "long") > 0
