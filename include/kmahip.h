@@ -274,6 +274,35 @@ int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                        const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, int64_t *ops_needed);
 
+/* Stage 3c per template: pile-up of the traced reads (alnToMat, assembly.c:1317-1444: per template position the counts of
+ * A C G T N and gap, insertion columns chained between positions) on the device, then callConsensus + baseCaller
+ * (assembly.c:1499-1631, 162-179) in host arithmetic. Inputs: the reads, the flag / tmpl arrays given to
+ * kmahip_align_trace and its output (all HOST buffers here). Reads of one template are piled up in the reference's order:
+ * reverse stream order inside every chunk of max_frag filed fragments (conclave.c:164-166, 194; kma.c default 1000000;
+ * <= 0 selects it) -- only the gap count a NEW insertion column starts with depends on it. bcd / evalue: `-bcd` (1) and
+ * `-e` (0.05). Out, per template (DB_size entries, zero where nothing was piled up): cover = called positions equal to the
+ * template base, aln_len = called columns, depth = summed depth of the called columns, asm_len = columns incl.
+ * insertion columns (runkma.c:792-800 turns these into Template_Identity / Template_Coverage / Query_Identity /
+ * Query_Coverage / Depth). Optionally the consensus line of every assembled template ("ACGTN-", lower case = call not
+ * significant, '-' = no call), 0-terminated, at consensus + consensus_off[t]. */
+typedef struct kmahip_assembly {
+	int64_t *cover;
+	int64_t *aln_len;
+	int64_t *depth;
+	int64_t *asm_len;
+	char *consensus;          /* may be NULL */
+	int64_t *consensus_off;   /* DB_size, may be NULL */
+	int64_t consensus_cap;
+	int64_t consensus_used;   /* in: 0; out: bytes written */
+} kmahip_assembly;
+int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                    const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out);
+/* One `.res` row exactly as runKMA prints it (runkma.c:809) from kmahip_res_rows + kmahip_assemble; returns the number of
+ * characters written, 0 when the reference prints no row for the template (nothing covered, identity below -ID (1.0) or
+ * depth below -md (0.0)). */
+int kmahip_res_line(const char *template_name, const kmahip_res_row *row, int64_t cover, int64_t aln_len, int64_t depth_sum,
+                    double ID_t, double Depth_t, char *line, int64_t cap);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

@@ -65,6 +65,11 @@ class Traces(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("ops_off", C.c_void_p), ("n_ops", C.c_void_p), ("ops", C.c_void_p), ("ops_cap", C.c_int64)]
 
 
+class Assembly(C.Structure):
+    _fields_ = [("cover", C.c_void_p), ("aln_len", C.c_void_p), ("depth", C.c_void_p), ("asm_len", C.c_void_p),
+                ("consensus", C.c_void_p), ("consensus_off", C.c_void_p), ("consensus_cap", C.c_int64), ("consensus_used", C.c_int64)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
                 ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
@@ -129,6 +134,10 @@ def lib():
                                               C.POINTER(Conclave)]
         L.kmahip_align_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params),
                                          C.POINTER(Traces), C.POINTER(C.c_int64)]
+        L.kmahip_assemble.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.POINTER(Traces), C.c_int64,
+                                      C.c_int, C.c_double, C.POINTER(Assembly)]
+        L.kmahip_res_line.argtypes = [C.c_char_p, C.POINTER(ResRow), C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                      C.c_char_p, C.c_int64]
         L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -164,6 +173,7 @@ class KmaHipDB:
     def __init__(self, prefix: str, device: int = 0):
         L = lib()
         _check(L.kmahip_init(device))
+        self.prefix = prefix
         self.h = C.c_void_p()
         _check(L.kmahip_db_open(prefix.encode(), C.byref(self.h)))
         self.ws = C.c_void_p()
@@ -397,6 +407,46 @@ class KmaHipDB:
             _check(rc)
             return stats[:n], off[:n], nops[:n], ops[:need.value]
         raise KmaHipError("align_trace: output capacity kept overflowing")
+
+    def assemble(self, batch, flag, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False):
+        """Stage 3c per template: pile-up of the traced reads + consensus -> dict(cover, aln_len, depth, asm_len [DB_size],
+        consensus {template: str} when asked). traces = the tuple align_trace returned."""
+        n = batch.n
+        stats, off, nops, ops = traces
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        fl = np.ascontiguousarray(flag if n else np.zeros(1, np.int32), np.int32)
+        tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
+        st = np.ascontiguousarray(stats if n else np.zeros((1, 10), np.int32), np.int32)
+        of = np.ascontiguousarray(off if n else np.zeros(1, np.int64), np.int64)
+        no = np.ascontiguousarray(nops if n else np.zeros(1, np.int32), np.int32)
+        op = np.ascontiguousarray(ops if len(ops) else np.zeros(1, np.uint32), np.uint32)
+        tr = Traces(_p(st), _p(of), _p(no), _p(op), len(op))
+        D = int(self.info.DB_size)
+        o = dict(cover=np.zeros(D, np.int64), aln_len=np.zeros(D, np.int64), depth=np.zeros(D, np.int64), asm_len=np.zeros(D, np.int64))
+        cap = 0
+        cbuf = coff = None
+        if consensus:
+            cap = int(2 * np.fromfile(self.prefix + ".length.b", dtype=np.int32)[1:].astype(np.int64).sum() + 4 * D + (1 << 20))
+            cbuf = np.zeros(cap, np.uint8)
+            coff = np.full(D, -1, np.int64)
+        a = Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), None if cbuf is None else _p(cbuf),
+                     None if coff is None else _p(coff), cap, 0)
+        _check(lib().kmahip_assemble(self.h, self.ws, C.byref(r), _p(fl), _p(tm), C.byref(tr), int(max_frag), int(bcd), float(evalue),
+                                     C.byref(a)))
+        if consensus:
+            raw = cbuf.tobytes()
+            o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
+        return o
+
+    @staticmethod
+    def res_line(name, row, cover, aln_len, depth, ID_t=1.0, Depth_t=0.0):
+        """The `.res` row as the reference prints it, or None when it prints none"""
+        buf = C.create_string_buffer(4096 + len(name))
+        n = lib().kmahip_res_line(name.encode(), C.byref(row), int(cover), int(aln_len), int(depth), ID_t, Depth_t, buf, len(buf))
+        return buf.raw[:n].decode() if n else None
 
     def res_rows(self, w_scores, evalue=0.05, scoreT=0.5):
         """Leading `.res` columns per template with a score -> list of ResRow (host arithmetic, runkma.c:765-783)"""

@@ -26,6 +26,8 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	}
 	(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64); (void) hipFree(ws->a_task);
 	(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
+	(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_seg); (void) hipFree(ws->p_vals);
+	(void) hipFree(ws->p_nodes); (void) hipFree(ws->p_keys); (void) hipFree(ws->p_rank);
 	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
 	delete ws;
 }

@@ -1,0 +1,492 @@
+// assemble.hip -- stage 3c per template on gfx950: the pile-up of the traced reads (alnToMat, assembly.c:1317-1444, the
+// default sparse matrix with insertion columns chained between template positions) on the device, and the consensus
+// call + `.res` columns (callConsensus assembly.c:1499-1631, baseCaller :162-179, runkma.c:792-809) in host arithmetic
+// (libm erf / tgamma exactly like the reference's p_chisqr).
+//
+// What makes the reference's pile-up sequential is only the insertion columns: a read that inserts bases the matrix has
+// no column for creates columns whose gap count starts at the depth seen SO FAR (myBias, :1377-1397). Everything else is
+// a commutative saturating increment. So: reads are sorted into the reference's order per template (ConClave prepends to
+// a per-template list, conclave.c:164-165 -> reverse stream order inside every chunk of maxFrag records); one wavefront
+// owns one template and goes through its reads 64 at a time: maximal stretches of reads without an insertion run are
+// piled up by all lanes at once (atomics), a read with an insertion run is piled up alone, in order.
+#include "kmahip_internal.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+
+namespace {
+
+struct InsNode { uint32_t c[6]; int32_t next; int32_t gaps; };   // next: following column of the chain (0 = none), gaps: template position after the chain
+
+struct PileArgs {
+	DevDB db;
+	int64_t n_reads;
+	const uint64_t *seq;
+	const int64_t *seq_off;
+	const int32_t *len;
+	const int32_t *N;
+	const int64_t *N_off;
+	const int32_t *flag, *tmpl;
+	const int32_t *stats;        // 10 per read (kmahip_traces)
+	const int64_t *ops_off;
+	const int32_t *n_ops;
+	const uint32_t *ops;
+	int64_t max_frag;
+	int64_t *rank;               // per read: number of filed fragments before it in the stream
+	// sorted work list
+	uint64_t *keys;
+	int32_t *vals;
+	unsigned long long *counters;   // [0] kept reads, [1] status, [2] node pool top
+	// output
+	uint32_t *counts;            // 6 per position of `cat`
+	int32_t *chain_head;         // per position of `cat`: first insertion column in front of it (0 = none), node ids are 1-based
+	InsNode *nodes;
+	int64_t node_cap;
+	int32_t *seg_start;          // per template: first entry of the sorted list (n_kept if none); DB_size + 1
+};
+
+// oriented read base (0-3, 4 = N): the read as ConClave filed it
+struct Q { const uint64_t *w; const int32_t *N; int L, nN, rc; };
+__device__ __forceinline__ int q_base(const Q &q, int i) {
+	const int p = q.rc ? q.L - 1 - i : i;
+	if(q.nN) {
+		int lo = 0, hi = q.nN;
+		while(lo < hi) { const int mid = (lo + hi) >> 1; if(q.N[mid] < p) lo = mid + 1; else hi = mid; }
+		if(lo < q.nN && q.N[lo] == p) return 4;
+	}
+	const int b = (int) ((q.w[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
+	return q.rc ? 3 - b : b;
+}
+
+__global__ __launch_bounds__(256) void pile_filed_kernel(const int32_t *tmpl, int64_t n, int64_t *filed) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r < n) filed[r] = tmpl[r] != 0;
+}
+
+// sort key: template, then the order the reference assembles the reads of a template in
+__global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= A.n_reads) return;
+	if(A.stats[10 * r + 3] == 0) return;          // dropped by the read filter (or no template)
+	const uint64_t t = (uint64_t) abs(A.tmpl[r]);
+	// rank among the fragments ConClave filed (conclave.c:166, 194) -> chunk of max_frag, reverse order inside the chunk
+	const int64_t rk = A.rank[r];
+	const uint64_t chunk = (uint64_t) (rk / A.max_frag), in = (uint64_t) (rk % A.max_frag);
+	const uint64_t ord = chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
+	const unsigned long long slot = atomicAdd(&A.counters[0], 1ull);
+	A.keys[slot] = (t << 40) | ord;
+	A.vals[slot] = (int32_t) r;
+}
+
+__global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_kept, int32_t *seg_start, int64_t DB_size) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n_kept) return;
+	const int64_t t = (int64_t) (keys[i] >> 40);
+	if(i == 0 || (int64_t) (keys[i - 1] >> 40) != t) seg_start[t] = (int32_t) i;
+}
+
+struct Walk {
+	const PileArgs &A;
+	int64_t tbase;
+	int t_len;
+	__device__ __forceinline__ bool is_node(int cur) const { return cur >= t_len; }
+	__device__ __forceinline__ InsNode &node(int cur) const { return A.nodes[cur - t_len - 1]; }    // 1-based ids: cur = t_len + id
+	// the column after `cur` in ring order
+	__device__ int next(int cur) const {
+		if(is_node(cur)) { const InsNode &n = node(cur); return n.next ? t_len + n.next : n.gaps; }
+		const int np = (cur + 1 == t_len) ? 0 : cur + 1;
+		const int h = A.chain_head[tbase + np];
+		return h ? t_len + h : np;
+	}
+	__device__ __forceinline__ uint32_t *counts(int cur) const { return is_node(cur) ? node(cur).c : A.counts + 6 * (tbase + cur); }
+	__device__ int depth16(int cur) const {
+		const uint32_t *c = counts(cur);
+		int s = 0;
+		for(int j = 0; j < 6; ++j) s += (int) min(c[j], 65535u);
+		return s;
+	}
+};
+
+// alnToMat for one read. EXACT: may create insertion columns (the lane runs alone); otherwise every update is an atomic
+// increment and any number of lanes may run side by side.
+template <bool EXACT>
+__device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has_ins_out) {
+	const int32_t *st = A.stats + 10 * r;
+	const int64_t o = A.ops_off[r];
+	int n = A.n_ops[r];
+	Q q;
+	q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+	q.rc = (((A.flag[r] & 16) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
+	int start = st[1], qp = st[4], first = 0;
+	// trim trailing / leading gap runs (assembly.c:1340-1354); column 0 is never trimmed from the back
+	while(n > 1 && (A.ops[o + n - 1] & 3u) >= 2u) --n;
+	while(first < n && (A.ops[o + first] & 3u) >= 2u) {
+		const uint32_t run = A.ops[o + first];
+		if((run & 3u) == 3u) start += (int) (run >> 2); else qp += (int) (run >> 2);
+		++first;
+	}
+	if(has_ins_out) {
+		bool ins = false;
+		for(int j = first; j < n; ++j) if((A.ops[o + j] & 3u) == 2u) ins = true;
+		*has_ins_out = ins;
+		return;
+	}
+	int cur = start;
+	for(int j = first; j < n; ++j) {
+		const uint32_t run = A.ops[o + j];
+		const int cls = (int) (run & 3u);
+		int left = (int) (run >> 2);
+		while(left > 0) {
+			if(cls == 2) {
+				if(!EXACT) return;                                  // cannot happen: such reads are piled up alone
+				if(W.is_node(cur)) {                                // an insertion column that already exists
+					atomicAdd(&W.counts(cur)[q_base(q, qp++)], 1u);
+					--left;
+					cur = W.next(cur);
+				} else {
+					// new columns in front of template position `gaps` (assembly.c:1368-1428)
+					const int gaps = cur;
+					int last = gaps ? gaps - 1 : W.t_len - 1;
+					for(int h = A.chain_head[W.tbase + gaps]; h; h = A.nodes[h - 1].next) last = W.t_len + h;
+					int myBias = W.depth16(last);
+					const int tmp = W.depth16(gaps);
+					myBias = (tmp < myBias) ? tmp : (myBias - 1);
+					if(65535 < myBias) myBias = 65535;
+					while(left > 0) {
+						const long long id = (long long) atomicAdd(&A.counters[2], 1ull) + 1;
+						if(id > A.node_cap) { atomicMax(&A.counters[1], 32ull); return; }
+						InsNode &nn = A.nodes[id - 1];
+						for(int x = 0; x < 6; ++x) nn.c[x] = 0;
+						nn.c[5] = (uint32_t) myBias; nn.c[q_base(q, qp++)] = 1; nn.next = 0; nn.gaps = gaps;
+						__threadfence();
+						if(W.is_node(last)) W.node(last).next = (int32_t) id; else A.chain_head[W.tbase + gaps] = (int32_t) id;
+						last = W.t_len + (int) id;
+						--left;
+					}
+					cur = gaps;
+				}
+			} else if(W.is_node(cur)) {                             // existing insertion column this read lacks
+				atomicAdd(&W.counts(cur)[5], 1u);
+				cur = W.next(cur);
+			} else {
+				const int b = cls == 3 ? 5 : q_base(q, qp++);
+				atomicAdd(&W.counts(cur)[b], 1u);
+				--left;
+				cur = W.next(cur);
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void pileup_kernel(const PileArgs A, int64_t n_kept) {
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int64_t n_waves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+	const int64_t D = A.db.DB_size;
+	for(int64_t t = 1 + wave; t < D; t += n_waves) {
+		const int64_t s0 = A.seg_start[t];
+		if(s0 >= n_kept) continue;
+		int64_t s1 = s0;
+		// end of the segment: next template that has reads (sorted list is template-major)
+		{
+			int64_t lo = s0, hi = n_kept;
+			while(lo < hi) { const int64_t mid = (lo + hi) >> 1; if((int64_t) (A.keys[mid] >> 40) <= t) lo = mid + 1; else hi = mid; }
+			s1 = lo;
+		}
+		Walk W{A, A.db.cat_off[t], A.db.tlen[t]};
+		for(int64_t b = s0; b < s1; b += 64) {
+			const bool valid = b + lane < s1;
+			const int64_t r = valid ? (int64_t) A.vals[b + lane] : 0;
+			bool ins = false;
+			if(valid) pile_read<false>(A, W, r, &ins);
+			const unsigned long long insmask = __ballot(valid && ins);
+			int cur = 0;
+			while(cur < 64) {
+				const unsigned long long rest = insmask >> cur;
+				const int nxt = rest ? cur + __ffsll((long long) rest) - 1 : 64;
+				if(valid && lane >= cur && lane < nxt) pile_read<false>(A, W, r, nullptr);
+				__threadfence();
+				__builtin_amdgcn_wave_barrier();
+				if(nxt < 64) {
+					if(lane == nxt) pile_read<true>(A, W, r, nullptr);
+					__threadfence();
+					__builtin_amdgcn_wave_barrier();
+				}
+				cur = nxt + 1;
+			}
+		}
+	}
+}
+
+} // namespace
+
+static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64_t node_cap) {
+	const int64_t total = db->h_cat_off.empty() ? 0 : db->h_cat_off.back();
+	if(ws->p_total != total || ws->p_node_cap < node_cap) {
+		(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_nodes); (void) hipFree(ws->p_seg);
+		ws->p_counts = nullptr; ws->p_chain = nullptr; ws->p_nodes = nullptr; ws->p_seg = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->p_counts, (size_t) (total + 1) * 6 * sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void **) &ws->p_chain, (size_t) (total + 1) * sizeof(int32_t)));
+		HIP_TRY(hipMalloc((void **) &ws->p_nodes, (size_t) node_cap * sizeof(InsNode)));
+		HIP_TRY(hipMalloc((void **) &ws->p_seg, (size_t) (db->info.DB_size + 1) * sizeof(int32_t)));
+		ws->p_total = total; ws->p_node_cap = node_cap;
+	}
+	if(ws->p_reads_cap < n_reads) {
+		(void) hipFree(ws->p_keys); (void) hipFree(ws->p_vals);
+		ws->p_keys = nullptr; ws->p_vals = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->p_keys, (size_t) n_reads * 2 * sizeof(uint64_t)));
+		HIP_TRY(hipMalloc((void **) &ws->p_vals, (size_t) n_reads * 2 * sizeof(int32_t)));
+		(void) hipFree(ws->p_rank);
+		ws->p_rank = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->p_rank, (size_t) n_reads * 2 * sizeof(int64_t)));
+		ws->p_reads_cap = n_reads;
+	}
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
+	return KMAHIP_OK;
+}
+
+// device part: counts / chains of every template with kept reads. All pointers are device pointers.
+static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                         const kmahip_traces *tr, int64_t max_frag, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	const int64_t node_cap = std::max<int64_t>(1 << 20, n);
+	int rc = assemble_scratch(db, ws, std::max<int64_t>(n, 1), node_cap);
+	if(rc) return rc;
+	const int64_t total = ws->p_total;
+	HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
+	HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, sizeof(unsigned long long), stream));
+	PileArgs A;
+	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.flag = flag; A.tmpl = tmpl; A.stats = tr->stats; A.ops_off = tr->ops_off; A.n_ops = tr->n_ops; A.ops = tr->ops;
+	A.max_frag = max_frag > 0 ? max_frag : 1000000;
+	A.keys = ws->p_keys; A.vals = ws->p_vals; A.counters = ws->counters;
+	A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.node_cap = node_cap; A.seg_start = ws->p_seg;
+	if(n == 0) return KMAHIP_OK;
+	void *tmp = nullptr;
+	size_t tmp_bytes = 0;
+	{
+		// rank of every read among the filed fragments: exclusive scan of (tmpl != 0)
+		int64_t *filed = ws->p_rank + n;
+		A.rank = ws->p_rank;
+		hipLaunchKernelGGL(pile_filed_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, tmpl, n, filed);
+		if(rocprim::exclusive_scan(nullptr, tmp_bytes, filed, A.rank, (int64_t) 0, (size_t) n, rocprim::plus<int64_t>(), stream) != hipSuccess) {
+			kmahip_set_error("rocprim::exclusive_scan (size query) failed"); return KMAHIP_EDEVICE;
+		}
+		HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+		const hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, filed, A.rank, (int64_t) 0, (size_t) n, rocprim::plus<int64_t>(), stream);
+		HIP_TRY(hipStreamSynchronize(stream));
+		(void) hipFree(tmp); tmp = nullptr;
+		if(e != hipSuccess) { kmahip_set_error("rocprim::exclusive_scan failed: %s", hipGetErrorString(e)); return KMAHIP_EDEVICE; }
+	}
+	hipLaunchKernelGGL(pile_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A);
+	unsigned long long kept = 0;
+	HIP_TRY(hipMemcpyAsync(&kept, ws->counters, sizeof kept, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipStreamSynchronize(stream));
+	ws->p_kept = (int64_t) kept;
+	if(!kept) return KMAHIP_OK;
+	// sort by (template, reference order)
+	uint64_t *keys_out = ws->p_keys + n;
+	int32_t *vals_out = ws->p_vals + n;
+	tmp_bytes = 0;
+	if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) kept, 0, 64, stream) != hipSuccess) {
+		kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE;
+	}
+	HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+	const hipError_t se = rocprim::radix_sort_pairs(tmp, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) kept, 0, 64, stream);
+	if(se != hipSuccess) { (void) hipFree(tmp); kmahip_set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(se)); return KMAHIP_EDEVICE; }
+	A.keys = keys_out; A.vals = vals_out;
+	// seg_start[t] = kept for templates without reads
+	{
+		std::vector<int32_t> init((size_t) db->info.DB_size + 1, (int32_t) kept);
+		HIP_TRY(hipMemcpyAsync(ws->p_seg, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+	}
+	hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((kept + 255) / 256)), dim3(256), 0, stream, keys_out, (int64_t) kept, ws->p_seg, (int64_t) db->info.DB_size);
+	const unsigned waves = (unsigned) std::min<int64_t>(std::max<int64_t>(db->info.DB_size, 1), 256 * 32);
+	hipLaunchKernelGGL(pileup_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, A, (int64_t) kept);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(stream));
+	(void) hipFree(tmp);
+	unsigned long long c[3];
+	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	if(c[1]) {
+		HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
+		kmahip_set_error("pile-up: insertion column pool exhausted (%lld columns)", (long long) node_cap);
+		return KMAHIP_EOVERFLOW;
+	}
+	ws->p_nodes_used = (int64_t) c[2];
+	return KMAHIP_OK;
+}
+
+// ---- consensus + `.res` columns, host arithmetic ----------------------------------------------------------------------
+static double asm_chi2_table(long double q) {
+	struct Step { double quantile, p; };
+	static const Step steps[] = {
+		{114.5242, 1e-26}, {109.9604, 1e-25}, {105.3969, 1e-24}, {100.8337, 1e-23}, {96.27476, 1e-22}, {91.71701, 1e-21},
+		{87.16164, 1e-20}, {82.60901, 1e-19}, {78.05917, 1e-18}, {73.51245, 1e-17}, {68.96954, 1e-16}, {64.43048, 1e-15},
+		{59.89615, 1e-14}, {55.36699, 1e-13}, {50.84417, 1e-12}, {46.32844, 1e-11}, {41.82144, 1e-10}, {37.32489, 1e-9},
+		{32.84127, 1e-8}, {28.37395, 1e-7}, {23.92814, 1e-6}, {19.51139, 1e-5}, {15.13671, 1e-4}, {10.82759, 1e-3},
+		{6.634897, 0.01}, {3.841443, 0.05}, {2.705532, 0.1}, {2.072251, 0.15}, {1.642374, 0.2}, {1.323304, 0.25},
+		{1.074194, 0.3}, {0.8734571, 0.35}, {0.7083263, 0.4}, {0.5706519, 0.45}, {0.4549364, 0.5}, {0.3573172, 0.55},
+		{0.2749959, 0.6}, {0.2059001, 0.65}, {0.1484719, 0.7}, {0.1015310, 0.75}, {0.06418475, 0.8}, {0.03576578, 0.85},
+		{0.01579077, 0.9}, {0.00393214, 0.95} };
+	for(const Step &st : steps) if(q > st.quantile) return st.p;
+	if(q >= 0.0) return 1.0;
+	return 1.00 - asm_chi2_table(-1 * q);
+}
+static double asm_p_chisqr(long double q) {      // stdstat.c:136-147
+	if(q < 0) return 1e-26;
+	if(q > 49) return asm_chi2_table(q);
+	return 1 - 1.772453850 * erf(sqrt((double) (0.5 * q))) / tgamma(0.5);
+}
+static int significant_nuc(int X, int Y, double evalue) {   // significantNuc, assembly.c:143-145
+	return (Y < X && asm_p_chisqr(pow(X - Y, 2) / (X + Y)) <= evalue);
+}
+
+// one column: callConsensus body + baseCaller (assembly.c:1543-1595, 162-179); counts already clamped to 16 bit
+static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, int bcd, double evalue, long *depth_out) {
+	static const char bases[] = "ACGTN-";
+	int bestNuc = tnuc;
+	const char tch = bases[tnuc];
+	int bestScore = (int) cnt[bestNuc];
+	long depthUpdate = 0;
+	for(int j = 0; j < 6; ++j) {
+		if(bestScore < (int) cnt[j]) { bestScore = (int) cnt[j]; bestNuc = j; }
+		depthUpdate += cnt[j];
+	}
+	unsigned char call = (unsigned char) bases[bestNuc];
+	if(!depthUpdate) call = '-';
+	else if(((long) bestScore << 1) < depthUpdate) {
+		if(call == '-') {
+			int bb = (int) cnt[4], b = 4;
+			for(int j = 0; j < 4; ++j) if(bb < (int) cnt[j]) { bb = (int) cnt[j]; b = j; }
+			call = (unsigned char) tolower(bases[b]);
+		} else call = (unsigned char) tolower(call);
+		bestScore = (int) (depthUpdate - cnt[5]);
+	} else if(depthUpdate < bcd) call = (unsigned char) tolower(call);
+	if(depthUpdate == 0) call = '-';
+	else if(significant_nuc(bestScore, (int) depthUpdate - bestScore, evalue) == 0) {
+		if(call == '-' && tch != '-' && bestScore != depthUpdate) call = 'n';
+		else call = (unsigned char) tolower(call);
+	}
+	*depth_out = depthUpdate;
+	return call;
+}
+
+extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                               const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
+	if(!db || !ws || !reads || !flag || !tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(db->h_cat_off.empty()) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
+	const int64_t D = db->info.DB_size;
+	for(int64_t t = 0; t < D; ++t) { out->cover[t] = 0; out->aln_len[t] = 0; out->depth[t] = 0; out->asm_len[t] = 0; }
+	if(n == 0) return KMAHIP_OK;
+	int64_t total_ops = 0;
+	for(int64_t i = 0; i < n; ++i) total_ops = std::max<int64_t>(total_ops, traces->ops_off[i] + traces->n_ops[i]);
+	// stage everything (host buffers in): reads, flags, templates, traces
+	std::vector<void *> owned;
+	struct Free { std::vector<void *> &v; ~Free() { for(void *p : v) (void) hipFree(p); } } guard{owned};
+	auto up = [&](const void *src, size_t bytes, void **dst) -> int {
+		void *d = nullptr;
+		if(hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) { kmahip_set_error("hipMalloc failed"); return KMAHIP_EDEVICE; }
+		owned.push_back(d);
+		if(bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { kmahip_set_error("hipMemcpy failed"); return KMAHIP_EDEVICE; }
+		*dst = d;
+		return KMAHIP_OK;
+	};
+	kmahip_reads d = *reads;
+	kmahip_traces dt = *traces;
+	int32_t *d_flag, *d_tmpl;
+	void *seq_d = nullptr;
+	int rc;
+	{
+		std::vector<uint64_t> seq((size_t) reads->seq_words + 2, 0);
+		if(reads->seq_words) memcpy(seq.data(), reads->seq, (size_t) reads->seq_words * 8);
+		if((rc = up(seq.data(), seq.size() * 8, &seq_d))) return rc;
+	}
+	d.seq = (const uint64_t *) seq_d;
+	if((rc = up(reads->seq_off, (size_t) (n + 1) * 8, (void **) &d.seq_off)) || (rc = up(reads->len, (size_t) n * 4, (void **) &d.len)) ||
+	   (rc = up(reads->N, (size_t) reads->N_total * 4, (void **) &d.N)) || (rc = up(reads->N_off, (size_t) (n + 1) * 8, (void **) &d.N_off)) ||
+	   (rc = up(flag, (size_t) n * 4, (void **) &d_flag)) || (rc = up(tmpl, (size_t) n * 4, (void **) &d_tmpl)) ||
+	   (rc = up(traces->stats, (size_t) n * 40, (void **) &dt.stats)) || (rc = up(traces->ops_off, (size_t) n * 8, (void **) &dt.ops_off)) ||
+	   (rc = up(traces->n_ops, (size_t) n * 4, (void **) &dt.n_ops)) || (rc = up(traces->ops, (size_t) total_ops * 4, (void **) &dt.ops))) return rc;
+	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, 0))) return rc;
+	if(!ws->p_kept) return KMAHIP_OK;
+
+	// consensus on the host
+	const int64_t total = ws->p_total;
+	std::vector<uint32_t> counts((size_t) total * 6);
+	std::vector<int32_t> chain((size_t) total);
+	std::vector<InsNode> nodes((size_t) ws->p_nodes_used);
+	std::vector<int32_t> seg((size_t) D + 1);
+	HIP_TRY(hipMemcpy(counts.data(), ws->p_counts, counts.size() * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(chain.data(), ws->p_chain, chain.size() * 4, hipMemcpyDeviceToHost));
+	if(!nodes.empty()) HIP_TRY(hipMemcpy(nodes.data(), ws->p_nodes, nodes.size() * sizeof(InsNode), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(seg.data(), ws->p_seg, seg.size() * 4, hipMemcpyDeviceToHost));
+	std::vector<uint64_t> tseq((size_t) db->info.tseq_words + 2);
+	HIP_TRY(hipMemcpy(tseq.data(), db->dev.tseq, (size_t) db->info.tseq_words * 8, hipMemcpyDeviceToHost));
+	std::vector<int64_t> toff((size_t) D + 1);
+	HIP_TRY(hipMemcpy(toff.data(), db->dev.tseq_off, toff.size() * 8, hipMemcpyDeviceToHost));
+	std::string cons;
+	for(int64_t t = 1; t < D; ++t) {
+		if(seg[t] >= ws->p_kept) continue;              // no read was piled up on this template
+		const int t_len = db->h_tlen[t];
+		const int64_t base = db->h_cat_off[t];
+		const uint64_t *ts = tseq.data() + toff[t];
+		int64_t cover = 0, aln_len = 0, depth = 0, asm_len = 0;
+		cons.clear();
+		auto column = [&](const uint32_t *c32, int tnuc, bool is_template) {
+			uint32_t c[6];
+			for(int j = 0; j < 6; ++j) c[j] = std::min<uint32_t>(c32[j], 65535u);
+			long dep = 0;
+			const unsigned char call = call_column(c, tnuc, bcd, evalue, &dep);
+			++asm_len;
+			if(out->consensus) cons.push_back((char) call);
+			if(call != '-') {
+				depth += dep; ++aln_len;
+				if(is_template && "ACGTN-"[tnuc] == toupper(call)) ++cover;
+			}
+		};
+		for(int p = 0; p < t_len; ++p) {
+			// ring order: template position p, then the insertion columns in front of position p + 1
+			column(counts.data() + (size_t) (base + p) * 6, (int) ((ts[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull), true);
+			const int np = (p + 1 == t_len) ? 0 : p + 1;
+			for(int h = chain[(size_t) (base + np)]; h; h = nodes[(size_t) h - 1].next) column(nodes[(size_t) h - 1].c, 5, false);
+		}
+		out->cover[t] = cover; out->aln_len[t] = aln_len; out->depth[t] = depth; out->asm_len[t] = asm_len;
+		if(out->consensus && out->consensus_off) {
+			if((int64_t) (out->consensus_used + cons.size() + 1) > out->consensus_cap) { kmahip_set_error("consensus_cap too small"); return KMAHIP_EOVERFLOW; }
+			out->consensus_off[t] = out->consensus_used;
+			memcpy(out->consensus + out->consensus_used, cons.data(), cons.size());
+			out->consensus[out->consensus_used + cons.size()] = 0;
+			out->consensus_used += (int64_t) cons.size() + 1;
+		}
+	}
+	return KMAHIP_OK;
+}
+
+// the `.res` row exactly as runKMA prints it (runkma.c:792-809); returns 0 when the reference prints no row
+// (no covered position, or identity / depth below the -ID / -md thresholds), else the number of characters written
+extern "C" int kmahip_res_line(const char *template_name, const kmahip_res_row *row, int64_t cover, int64_t aln_len, int64_t depth_sum,
+                               double ID_t, double Depth_t, char *line, int64_t cap) {
+	if(!template_name || !row || !line || cap <= 0) return 0;
+	if(!(cover > 0)) return 0;
+	const int t_len = row->template_length;
+	long double depth = depth_sum;
+	depth /= t_len;
+	const double id = 100.0 * cover / t_len;
+	const double q_id = 100.0 * cover / aln_len;
+	const double cov = 100.0 * aln_len / t_len;
+	const double q_cover = 100.0 * t_len / aln_len;
+	if(!(ID_t <= id && 0 < id && Depth_t <= depth)) return 0;
+	// runkma.c:141: expected / q_value are long double and printed as (unsigned) / (double)
+	const int w = snprintf(line, (size_t) cap, "%s\t%8ld\t%8u\t%8d\t%8.2f\t%8.2f\t%8.2f\t%8.2f\t%8.2f\t%8.2f\t%4.1e\n", template_name,
+	                       (long) row->score, row->expected, t_len, id, cov, q_id, q_cover, (double) depth, row->q_value, row->p_value);
+	return (w > 0 && w < cap) ? w : 0;
+}

@@ -163,6 +163,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 			std::vector<uint8_t> placed(slots.size(), 0);
 			int64_t g0 = 0;
 			uint64_t unplaced = n;
+			db->h_cat_off.assign((size_t) DB_size + 1, 0);
 			for(uint32_t t = 1; t < DB_size; ++t) {
 				const int tl = db->h_tlen[t];
 				const uint64_t *ts = tseq.data() + off[t];
@@ -193,10 +194,13 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 					}
 				}
 				g0 += tl;
+				db->h_cat_off[t + 1] = g0;
 			}
+			if(DB_size > 1) db->h_cat_off[1] = 0;
 			if(unplaced) { kmahip_db_close(db); kmahip_set_error("%llu index k-mers do not occur in %s.seq.b", (unsigned long long) unplaced, prefix); return KMAHIP_EFORMAT; }
 			if((rc = upload(db, slots.data(), slots.size(), &d.slots)) || (rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
-			   (rc = upload(db, vsid.data(), vsid.size(), &d.vs_id))) { kmahip_db_close(db); return rc; }
+			   (rc = upload(db, vsid.data(), vsid.size(), &d.vs_id)) ||
+			   (rc = upload(db, db->h_cat_off.data(), db->h_cat_off.size(), &d.cat_off))) { kmahip_db_close(db); return rc; }
 		}
 
 		// per-template k-mer position index

@@ -28,6 +28,7 @@ struct DevDB {
 	const uint64_t *cat;          // all templates back to back, 2 bit per base (+ pad words)
 	const uint32_t *vs_id;        // per position of `cat`: value-list offset of the k-mer starting there, or
 	                              // KMAHIP_EMPTY_VI where no k-mer of one template starts (its last k-1 bases)
+	const int64_t *cat_off;       // DB_size + 1: first position of template t in `cat` (cat_off[DB_size] = total bases)
 	const uint16_t *values16;     // [cnt, t1..tcnt] lists, offsets = value_index of the index file
 	const uint32_t *values32;
 	const int32_t *tlen;          // DB_size, tlen[0] = kmerindex
@@ -51,6 +52,7 @@ struct kmahip_db {
 	std::vector<void *> allocs;   // device allocations owned by the db
 	// host copies needed by host-side stages
 	std::vector<int32_t> h_tlen;
+	std::vector<int64_t> h_cat_off;
 };
 
 // per-call scratch, grown on demand
@@ -91,6 +93,13 @@ struct kmahip_ws {
 	uint8_t *t_E;
 	int64_t t_lanes;
 	int t_max_len;
+	// pile-up stage (3c) scratch and results
+	uint32_t *p_counts;
+	int32_t *p_chain, *p_seg, *p_vals;
+	void *p_nodes;
+	uint64_t *p_keys;
+	int64_t *p_rank;
+	int64_t p_total, p_node_cap, p_reads_cap, p_kept, p_nodes_used;
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;
