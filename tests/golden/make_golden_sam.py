@@ -3,7 +3,7 @@
 what KMA()'s traceback produced for every read that stage 3c kept: POS, the extended CIGAR (= X I D S) and AS (read score
 incl. the end bonus), plus the FLAG ConClave left. Runs oracle/_ref/kma on the inputs already committed next to this script
 (index files + FASTQ) and stores the columns qname, flag, rname, pos, mapq, cigar, AS of the mapped records as
-out.sam.tsv.gz. Only data is stored."""
+out.sam.tsv.gz, and the run's consensus FASTA as out.fsa.gz. Only data is stored."""
 import gzip
 import lzma
 import os
@@ -52,6 +52,9 @@ def make(name):
             rows.append("\t".join([c[0], c[1], c[2], c[3], c[4], c[5], AS]))
         with gzip.GzipFile(os.path.join(src, "out.sam.tsv.gz"), "wb", mtime=0) as g:
             g.write(("\n".join(rows) + "\n").encode())
+        # the consensus sequences of the same run (printConsensus, printconsensus.c:24-61)
+        with open(os.path.join(tmp, "out.fsa"), "rb") as f, gzip.GzipFile(os.path.join(src, "out.fsa.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
         print(name, len(rows), "mapped SAM records")
 
 

@@ -231,3 +231,18 @@ def load_sam(name="se"):
             c = line.rstrip("\n").split("\t")
             out.setdefault(c[0], []).append((int(c[1]), c[2], int(c[3]), int(c[4]), c[5], int(c[6])))
     return out
+
+
+def load_fsa(name="se"):
+    """consensus FASTA of the reference run as text"""
+    return _gunzip(os.path.join(GOLD, name, "out.fsa.gz")).decode()
+
+
+def fsa_text(entries):
+    """printConsensus (printconsensus.c:38-60, ref_fsa = 0): the consensus line without its '-' columns, 60 per line"""
+    out = []
+    for nm, cons in entries:
+        q = cons.replace("-", "")
+        out.append(">" + nm + "\n")
+        out += [q[i:i + 60] + "\n" for i in range(0, len(q), 60)]
+    return "".join(out)

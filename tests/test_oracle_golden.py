@@ -235,7 +235,7 @@ def _oracle_assembly_case(g, name):
     exp = golden_util.load_res_identity(name)
     odb = oracle.OracleDB(g["prefix"])
     al = oracle.OracleAligner(odb)
-    per_t = {}
+    per_t, fsa = {}, []
     for i in range(len(g["s1"]) - 1, -1, -1):
         tt = int(cc["tmpl"][i])
         if tt and st["significant"][abs(tt)]:
@@ -255,10 +255,14 @@ def _oracle_assembly_case(g, name):
             o = al.align_trace(read, t)
             if o is not None:
                 asm.add(o, read)
-        got = oracle.res_identity_columns(asm.call(), int(tlen[t])) if asm.n else None
+        call = asm.call() if asm.n else None
+        got = oracle.res_identity_columns(call, int(tlen[t])) if asm.n else None
         assert got == exp.get(names[t - 1]), (names[t - 1], got, exp.get(names[t - 1]))
         rows += got is not None
+        if got is not None:
+            fsa.append((names[t - 1], call["consensus"]))
     assert rows == len(exp)
+    assert golden_util.fsa_text(fsa) == golden_util.load_fsa(name)
     return rows
 
 

@@ -81,6 +81,7 @@ def _res_case(g, name):
         traces = db.align_trace(b, h["flag"], cc["tmpl"], ok)
         asm = db.assemble(b, h["flag"], cc["tmpl"], traces, consensus=True)
         names = golden_util.template_names(name)
+        fsa = []
         lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
         for r in rows:
             if not r.significant:
@@ -89,11 +90,13 @@ def _res_case(g, name):
             line = db.res_line(names[t - 1], r, asm["cover"][t], asm["aln_len"][t], asm["depth"][t])
             if line:
                 lines.append(line)
+                fsa.append((names[t - 1], asm["consensus"][t]))
     finally:
         db.close()
     with open(os.path.join(golden_util.GOLD, name, "out.res")) as f:
         exp = f.read()
     assert "".join(lines) == exp
+    assert golden_util.fsa_text(fsa) == golden_util.load_fsa(name)
     # the oracle's consensus lines (same columns, same order) for the templates it assembles
     return len(lines) - 1, asm
 
