@@ -128,6 +128,11 @@ typedef struct kmahip_hits {
 	int32_t *end;
 	uint64_t *alignment_scores;       /* DB_size, may be NULL */
 	uint64_t *uniq_alignment_scores;  /* DB_size, may be NULL */
+	int32_t *rc;          /* n_reads (records), may be NULL. bit 0: the fragment update_Scores* files for this record is the
+	                       * reverse complement of the ORIGINAL read (single end: stage 2's flag & 16; paired: a pair with a
+	                       * reverse-strand candidate is turned and only turned back, flag toggled, when its first kept template
+	                       * is positive, alnfrags.c:1629-1643, 1807-1822 -- the flag alone does not tell). bit 1 (proper pairs):
+	                       * the second slot's fragment is written first (alnfrags.c:1807-1812). Input of the stage-3c calls. */
 } kmahip_hits;
 
 /* Stage-2 result for paired reads (`-ipe ... -apm p`): two record slots per pair, in the order the
@@ -253,7 +258,7 @@ int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue
  * ConClave filed under a template, followed by assemble_KMA's read filter (assembly.c:1931-1961: + Wl for an alignment
  * that starts at the first / ends at the last template base, minlen, mrc, scoreT). This is what the reference prints per
  * read in `.frag.gz` / SAM and feeds to alnToMat.
- *   flag[i]   stage-3a flag of the read's record (bit 16: the record holds the reverse complement of reads[i])
+ *   rc[i]     kmahip_hits.rc of the read's record (bit 0: the filed fragment is the reverse complement of reads[i])
  *   tmpl[i]   kmahip_conclave.tmpl (signed; 0 = read has no template)
  *   tmpl_ok   per template, 1 = assemble (kmahip_res_row.significant); NULL = all
  * Out per read: stats[10 * i ..] = score, start, end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ (all 0: the
@@ -268,15 +273,15 @@ typedef struct kmahip_traces {
 	uint32_t *ops;      /* ops_cap */
 	int64_t ops_cap;
 } kmahip_traces;
-int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                            const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, void *stream);
 /* the same with host buffers in and out; returns KMAHIP_EOVERFLOW with the needed run count in *ops_needed */
-int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                        const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, int64_t *ops_needed);
 
 /* Stage 3c per template: pile-up of the traced reads (alnToMat, assembly.c:1317-1444: per template position the counts of
  * A C G T N and gap, insertion columns chained between positions) on the device, then callConsensus + baseCaller
- * (assembly.c:1499-1631, 162-179) in host arithmetic. Inputs: the reads, the flag / tmpl arrays given to
+ * (assembly.c:1499-1631, 162-179) in host arithmetic. Inputs: the reads, the rc / tmpl arrays given to
  * kmahip_align_trace and its output (all HOST buffers here). Reads of one template are piled up in the reference's order:
  * reverse stream order inside every chunk of max_frag filed fragments (conclave.c:164-166, 194; kma.c default 1000000;
  * <= 0 selects it) -- only the gap count a NEW insertion column starts with depends on it. bcd / evalue: `-bcd` (1) and
@@ -295,7 +300,7 @@ typedef struct kmahip_assembly {
 	int64_t consensus_cap;
 	int64_t consensus_used;   /* in: 0; out: bytes written */
 } kmahip_assembly;
-int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                     const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out);
 /* One `.res` row exactly as runKMA prints it (runkma.c:809) from kmahip_res_rows + kmahip_assemble; returns the number of
  * characters written, 0 when the reference prints no row for the template (nothing covered, identity below -ID (1.0) or

@@ -43,7 +43,7 @@ class Cands(C.Structure):
 class Hits(C.Structure):
     _fields_ = [("n_hits", C.c_void_p), ("best_score", C.c_void_p), ("flag", C.c_void_p), ("tmpl", C.c_void_p),
                 ("score", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p),
-                ("alignment_scores", C.c_void_p), ("uniq_alignment_scores", C.c_void_p)]
+                ("alignment_scores", C.c_void_p), ("uniq_alignment_scores", C.c_void_p), ("rc", C.c_void_p)]
 
 
 class PeRecs(C.Structure):
@@ -277,16 +277,17 @@ class KmaHipDB:
             h = dict(n_hits=np.zeros(max(n, 1), np.int32), best_score=np.zeros(max(n, 1), np.int32),
                      flag=np.zeros(max(n, 1), np.int32), tmpl=np.zeros(cap, np.int32), score=np.zeros(cap, np.int32),
                      start=np.zeros(cap, np.int32), end=np.zeros(cap, np.int32),
-                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64))
+                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64),
+                     rc=np.zeros(max(n, 1), np.int32))
             out = Cands(_p(rc_flag), _p(flag), _p(T_off), _p(T), cap)
             hs = Hits(_p(h["n_hits"]), _p(h["best_score"]), _p(h["flag"]), _p(h["tmpl"]), _p(h["score"]), _p(h["start"]),
-                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]))
+                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]), _p(h["rc"]))
             rc = lib().kmahip_map_se(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.byref(hs))
             if rc == -6 and int(T_off[n]) > cap:
                 cap = max(cap * 2, int(T_off[n]) + 16)
                 continue
             _check(rc)
-            for key in ("n_hits", "best_score", "flag"):
+            for key in ("n_hits", "best_score", "flag", "rc"):
                 h[key] = h[key][:n]
             return (rc_flag[:n], flag[:n], T_off, T[:T_off[n]]), h
         raise KmaHipError("map_se: output capacity kept overflowing")
@@ -299,7 +300,7 @@ class KmaHipDB:
                   seq.numel(), N.numel(), int(max_len))
         c = Cands(rc_flag.data_ptr(), flag.data_ptr(), T_off.data_ptr(), T.data_ptr(), T.numel())
         h = Hits(n_hits.data_ptr(), best_score.data_ptr(), out_flag.data_ptr(), h_tmpl.data_ptr(), h_score.data_ptr(),
-                 h_start.data_ptr(), h_end.data_ptr(), aln_scores.data_ptr(), uniq_scores.data_ptr())
+                 h_start.data_ptr(), h_end.data_ptr(), aln_scores.data_ptr(), uniq_scores.data_ptr(), None)
         p = Params.from_buffer_copy(self.params)
         _check(lib().kmahip_align_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(p), C.byref(h),
                                          C.c_void_p(stream or 0)))
@@ -318,7 +319,7 @@ class KmaHipDB:
         c = lambda a, t: np.ascontiguousarray(a if len(a) else np.zeros(1, t), t)
         keep = [c(h["n_hits"], np.int32), c(h["best_score"], np.int32), c(h["tmpl"], np.int32), c(h["start"], np.int32),
                 c(h["end"], np.int32), c(h["alignment_scores"], np.uint64), c(h["uniq_alignment_scores"], np.uint64)]
-        return keep, Hits(_p(keep[0]), _p(keep[1]), None, _p(keep[2]), None, _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(keep[6]))
+        return keep, Hits(_p(keep[0]), _p(keep[1]), None, _p(keep[2]), None, _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(keep[6]), None)
 
     def conclave_se(self, length, T_off, hits):
         """Stage 3b for the result of map_se (host arrays; `hits` may carry vectors summed over ranks) -> dict(tmpl, start,
@@ -373,12 +374,12 @@ class KmaHipDB:
         r = Reads(length.numel(), None, None, length.data_ptr(), None, None, 0, 0, 0)
         c = Cands(None, None, T_off.data_ptr(), None, 0)
         h = Hits(n_hits.data_ptr(), best_score.data_ptr(), None, h_tmpl.data_ptr(), None, h_start.data_ptr(), h_end.data_ptr(),
-                 aln_scores.data_ptr(), uniq_scores.data_ptr())
+                 aln_scores.data_ptr(), uniq_scores.data_ptr(), None)
         o = Conclave(o_tmpl.data_ptr(), o_start.data_ptr(), o_end.data_ptr(), w_scores.data_ptr(), dp(fragment_counts),
                      dp(read_counts), dp(depth))
         _check(lib().kmahip_conclave_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(h), C.byref(o), C.c_void_p(stream or 0)))
 
-    def align_trace(self, batch, flag, tmpl, tmpl_ok=None):
+    def align_trace(self, batch, rc, tmpl, tmpl_ok=None):
         """Stage 3c per read (host arrays): traceback alignment of every read against the template ConClave chose.
         -> stats [n, 10] (score, start, end, aln_len, clip_start, clip_end, match, tGaps, qGaps, mapQ; zeros = dropped),
         ops_off [n], n_ops [n], ops (runs (len << 2) | class, classes = X I D)"""
@@ -387,7 +388,7 @@ class KmaHipDB:
         Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
         r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
                   int(batch.length.max()) if n else 0)
-        fl = np.ascontiguousarray(flag if n else np.zeros(1, np.int32), np.int32)
+        fl = np.ascontiguousarray(rc if n else np.zeros(1, np.int32), np.int32)
         tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
         ok = None if tmpl_ok is None else np.ascontiguousarray(tmpl_ok, np.uint8)
         stats = np.zeros((max(n, 1), 10), np.int32)
@@ -408,7 +409,7 @@ class KmaHipDB:
             return stats[:n], off[:n], nops[:n], ops[:need.value]
         raise KmaHipError("align_trace: output capacity kept overflowing")
 
-    def assemble(self, batch, flag, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False):
+    def assemble(self, batch, rc, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False):
         """Stage 3c per template: pile-up of the traced reads + consensus -> dict(cover, aln_len, depth, asm_len [DB_size],
         consensus {template: str} when asked). traces = the tuple align_trace returned."""
         n = batch.n
@@ -417,7 +418,7 @@ class KmaHipDB:
         Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
         r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
                   int(batch.length.max()) if n else 0)
-        fl = np.ascontiguousarray(flag if n else np.zeros(1, np.int32), np.int32)
+        fl = np.ascontiguousarray(rc if n else np.zeros(1, np.int32), np.int32)
         tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
         st = np.ascontiguousarray(stats if n else np.zeros((1, 10), np.int32), np.int32)
         of = np.ascontiguousarray(off if n else np.zeros(1, np.int64), np.int64)
@@ -501,10 +502,11 @@ class KmaHipDB:
             h = dict(n_hits=np.zeros(max(n, 1), np.int32), best_score=np.zeros(max(n, 1), np.int32),
                      flag=np.zeros(max(n, 1), np.int32), tmpl=np.zeros(cap, np.int32), score=np.zeros(cap, np.int32),
                      start=np.zeros(cap, np.int32), end=np.zeros(cap, np.int32), kind=np.zeros(max(n // 2, 1), np.int32),
-                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64))
+                     alignment_scores=np.zeros(D, np.uint64), uniq_alignment_scores=np.zeros(D, np.uint64),
+                     rc=np.zeros(max(n, 1), np.int32))
             out = PeRecs(_p(mate), _p(rc), _p(rc_flag), _p(flag), _p(R_off), _p(T), cap)
             hs = Hits(_p(h["n_hits"]), _p(h["best_score"]), _p(h["flag"]), _p(h["tmpl"]), _p(h["score"]), _p(h["start"]),
-                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]))
+                      _p(h["end"]), _p(h["alignment_scores"]), _p(h["uniq_alignment_scores"]), _p(h["rc"]))
             rcode = lib().kmahip_map_pe(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.byref(hs), _p(h["kind"]))
             if rcode == -6:
                 cap = max(cap * 2, int(R_off[n]) + 16)

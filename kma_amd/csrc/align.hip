@@ -1075,7 +1075,9 @@ struct ReduceArgs {
 	int32_t *n_hits, *best_score, *out_flag, *h_tmpl, *h_score, *h_start, *h_end;
 	unsigned long long *alignment_scores, *uniq_alignment_scores;
 	// paired-end mode
-	const int32_t *rec_mate;
+	const int32_t *rec_mate, *rec_rc;
+	int32_t *out_rc;      // may be NULL. bit 0: the fragment filed for this record is the reverse complement of the original read;
+	                      // bit 1 (proper pair only): the pair's record is written second slot first (alnfrags.c:1807-1812)
 	int pe_mode, PE;
 	int32_t *pe_kind;     // per pair: 0 none / records handled singly, 1 proper pair, 2 unmated, 3 first only, 4 second only
 	int32_t *t_score_w, *t_alen_w, *t_start_w, *t_end_w, *t_tmpl_w;   // writable views (unmated shuffle)
@@ -1093,6 +1095,10 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 		if(R.T[o + i] < 0) rcstate = 1;
 	}
 	int fA = R.flag[p0], fB = R.flag[p0 + 1], kind = 0, nA = 0, nB = 0, sA = 0, sB = 0;
+	// Orientation of the two fragments as they end up in the frag record, relative to the S2 records: a negative candidate
+	// makes alnFragsPenaltyPE reverse-complement both mates (alnfrags.c:1629-1643); a mate whose first kept template is
+	// positive is turned back (with the flag toggled), one whose first kept template is negative stays turned.
+	int relA = 0, relB = 0, swap_rec = 0;
 	if(best || best_r) {
 		if(comp && 1.0 * (best + best_r) <= comp + R.PE) {
 			const int bestScore = comp + R.PE;
@@ -1100,6 +1106,7 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 			for(int64_t i = 0; i < nT; ++i) if(R.t_score[o + i] && R.t_alen[o + i]) { if(!h) first = R.T[o + i]; ++h; }
 			const bool swapped = h && first < 0;
 			if(!swapped && rcstate) { fA ^= 48; fB ^= 48; }
+			if(swapped) { relA = relB = 1; swap_rec = 2; }
 			for(int64_t i = 0; i < nT; ++i) {
 				const int bt = R.t_score[o + i], btr = R.t_alen[o + i];
 				if(bt && btr && bt + btr + R.PE == bestScore) {
@@ -1158,7 +1165,7 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 			for(int64_t i = 0; i < nT; ++i) { const int sc = first ? R.t_score[o + i] : R.t_alen[o + i]; if(sc) { if(!h) t0 = R.T[o + i]; ++h; } }
 			bool neg = false;
 			if(first) {
-				if(h && t0 < 0) neg = true; else if(rcstate) { fA ^= 16; fB ^= 32; }
+				if(h && t0 < 0) { neg = true; relA = 1; } else if(rcstate) { fA ^= 16; fB ^= 32; }
 				fA |= 8; fB ^= 4;
 				if(fA & 2) { fA ^= 2; fB ^= 2; }
 			} else {
@@ -1183,6 +1190,10 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 	R.pe_kind[p0 >> 1] = kind;
 	R.n_hits[p0] = nA; R.n_hits[p0 + 1] = nB; R.best_score[p0] = sA; R.best_score[p0 + 1] = sB;
 	R.out_flag[p0] = fA; R.out_flag[p0 + 1] = fB;
+	if(R.out_rc) {
+		R.out_rc[p0] = ((R.rec_rc[p0] != 0) != (relA != 0) ? 1 : 0) | swap_rec;
+		R.out_rc[p0 + 1] = ((R.rec_rc[p0 + 1] != 0) != (relB != 0) ? 1 : 0) | swap_rec;
+	}
 }
 
 // per read: hit filter of alnFragsSE (alnfrags.c:1165-1215) + update_Scores with
@@ -1200,7 +1211,7 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 			return;
 		}
 		if(!(r & 1)) R.pe_kind[r >> 1] = 0;
-		if(R.rec_mate[r] < 0) { R.n_hits[r] = 0; R.best_score[r] = 0; R.out_flag[r] = fl; return; }
+		if(R.rec_mate[r] < 0) { R.n_hits[r] = 0; R.best_score[r] = 0; R.out_flag[r] = fl; if(R.out_rc) R.out_rc[r] = 0; return; }
 	}
 	if(e > o) {
 		{
@@ -1234,6 +1245,8 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
 		}
 	}
 	R.n_hits[r] = nh; R.best_score[r] = (nh > 0) ? bestRead : 0; R.out_flag[r] = fl;
+	// single records are filed in the orientation stage 2 passed on (paired: rec_rc; single end: flag & 16)
+	if(R.out_rc) R.out_rc[r] = R.pe_mode ? (R.rec_rc[r] != 0) : ((R.flag[r] & 16) != 0);
 }
 
 // ---- stage 3c, per read: KMA() with traceback (align.c:214-507; NW nw.c:26-309, NW_band :310-640) ----------------
@@ -1249,7 +1262,7 @@ struct TraceArgs {
 	const int32_t *len;
 	const int32_t *N;
 	const int64_t *N_off;
-	const int32_t *flag;         // stage-3a flag of the read's record (16: its reverse complement is the stored read)
+	const int32_t *flag;         // kmahip_hits.rc: bit 0 = the filed fragment is the reverse complement of the read
 	const int32_t *tmpl;         // ConClave's signed template per read (0: none)
 	const uint8_t *tmpl_ok;      // per template: assemble it? (NULL: all)
 	int M, MM, U, W1, Wl;
@@ -1616,7 +1629,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 		if(t == 0 || (A.tmpl_ok && !A.tmpl_ok[t])) continue;
 		QView q;
 		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-		q.rc = (((A.flag[r] & 16) != 0) != (tt < 0)) ? 1 : 0;
+		q.rc = (((A.flag[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
 		const int t_len = A.db.tlen[t];
 		const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
 		T.em.n = 0; T.em.over = false; T.status = 0;
@@ -1723,7 +1736,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
-	R.rec_mate = rec_mate; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
+	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
 	R.t_score_w = A.t_score; R.t_alen_w = A.t_alen; R.t_start_w = A.t_start; R.t_end_w = A.t_end; R.t_tmpl_w = A.t_tmpl;
 	hipLaunchKernelGGL(reduce_reads_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, R);
 	HIP_TRY(hipGetLastError());

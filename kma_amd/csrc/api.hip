@@ -135,7 +135,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 
 	// stage 3a on the staged batch; device outputs in one block
 	const size_t D = db->info.DB_size;
-	const size_t hb = (size_t) n * 12 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
+	const size_t hb = (size_t) n * 16 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
 	void *dh = nullptr;
 	HIP_TRY(hipMalloc(&dh, hb));
 	HIP_TRY(hipMemsetAsync(dh, 0, hb, s));
@@ -145,6 +145,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 	int32_t *ip = (int32_t *) (u + 2 * D);
 	h.n_hits = ip; h.best_score = ip + n; h.flag = ip + 2 * n;
 	h.tmpl = ip + 3 * n; h.score = h.tmpl + total + 1; h.start = h.score + total + 1; h.end = h.start + total + 1;
+	h.rc = h.end + total + 1;
 	rc = kmahip_launch_align_se(db, ws, &d, &o, p, &h, s);
 	if(!rc) {
 		hipError_t e = hipStreamSynchronize(s);
@@ -159,6 +160,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 		(void) hipMemcpy(hits->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost);
 		(void) hipMemcpy(hits->best_score, h.best_score, (size_t) n * 4, hipMemcpyDeviceToHost);
 		(void) hipMemcpy(hits->flag, h.flag, (size_t) n * 4, hipMemcpyDeviceToHost);
+		if(hits->rc) (void) hipMemcpy(hits->rc, h.rc, (size_t) n * 4, hipMemcpyDeviceToHost);
 		if(total) {
 			(void) hipMemcpy(hits->tmpl, h.tmpl, (size_t) total * 4, hipMemcpyDeviceToHost);
 			(void) hipMemcpy(hits->score, h.score, (size_t) total * 4, hipMemcpyDeviceToHost);
@@ -294,7 +296,7 @@ static int run_host_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, 
 	if(!hits || n == 0) return KMAHIP_OK;
 	// stage 3a on the staged batch
 	const size_t D = db->info.DB_size;
-	const size_t hb = (size_t) n * 16 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
+	const size_t hb = (size_t) n * 20 + (size_t) (total + 1) * 16 + 2 * D * 8 + 64;
 	void *dh = nullptr;
 	HIP_TRY(hipMalloc(&dh, hb));
 	HIP_TRY(hipMemsetAsync(dh, 0, hb, s));
@@ -305,6 +307,7 @@ static int run_host_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, 
 	h.n_hits = hp; h.best_score = hp + n; h.flag = hp + 2 * n;
 	int32_t *dkind = hp + 3 * n;
 	h.tmpl = hp + 4 * n; h.score = h.tmpl + total + 1; h.start = h.score + total + 1; h.end = h.start + total + 1;
+	h.rc = h.end + total + 1;
 	kmahip_reads d2 = d;
 	rc = kmahip_launch_align_pe(db, ws, &d2, &o, p, &h, dkind, s);
 	if(!rc) {
@@ -320,6 +323,7 @@ static int run_host_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, 
 		(void) hipMemcpy(hits->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost);
 		(void) hipMemcpy(hits->best_score, h.best_score, (size_t) n * 4, hipMemcpyDeviceToHost);
 		(void) hipMemcpy(hits->flag, h.flag, (size_t) n * 4, hipMemcpyDeviceToHost);
+		if(hits->rc) (void) hipMemcpy(hits->rc, h.rc, (size_t) n * 4, hipMemcpyDeviceToHost);
 		(void) hipMemcpy(pe_kind, dkind, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost);
 		if(total) {
 			(void) hipMemcpy(hits->tmpl, h.tmpl, (size_t) total * 4, hipMemcpyDeviceToHost);

@@ -119,7 +119,7 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 	int n = A.n_ops[r];
 	Q q;
 	q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-	q.rc = (((A.flag[r] & 16) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
+	q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
 	int start = st[1], qp = st[4], first = 0;
 	// trim trailing / leading gap runs (assembly.c:1340-1354); column 0 is never trimmed from the back
 	while(n > 1 && (A.ops[o + n - 1] & 3u) >= 2u) --n;

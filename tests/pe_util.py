@@ -166,35 +166,39 @@ def hip_pe_conclave(db, g):
     (_, _, sT_off, _), sh = db.map_se(sb)
     pj = {u[1]: j for j, u in enumerate(pairs)}
     sj = {u[1]: j for j, u in enumerate(singles)}
-    rec = []
+    rec, frags = [], []      # frags[k] = fragments of record k in record order: (index into g["s1"], stage-3a flag, rc)
 
-    def add(n, score, ql, ql2, src, o):
+    def add(n, score, ql, ql2, src, o, fr):
         rec.append((n, score, ql, ql2, src["tmpl"][o:o + n].tolist(), src["start"][o:o + n].tolist(), src["end"][o:o + n].tolist()))
+        frags.append(fr)
 
     for u in g["units"]:
         if u[0] == "se":
             j = sj[u[1]]
             if sh["n_hits"][j] > 0:
-                add(int(sh["n_hits"][j]), int(sh["best_score"][j]), int(sb.length[j]), 0, sh, int(sT_off[j]))
+                add(int(sh["n_hits"][j]), int(sh["best_score"][j]), int(sb.length[j]), 0, sh, int(sT_off[j]), [(u[1], int(sh["flag"][j]), int(sh["rc"][j]))])
             continue
         j = pj[u[1]]
         r0, r1 = 2 * j, 2 * j + 1
         kind = int(h["kind"][j])
         ln = lambda x: int(pb.length[2 * j + int(mate[x])])
+        fg = lambda x: ((u[1], u[2])[int(mate[x])], int(h["flag"][x]), int(h["rc"][x]) & 1)
         o = int(R_off[r1])
         if kind == 1:
-            add(int(h["n_hits"][r1]), -int(h["best_score"][r1]), ln(r0), ln(r1), h, o)
+            swapped = int(h["rc"][r1]) & 2        # the second slot's fragment is written first (alnfrags.c:1807-1812)
+            add(int(h["n_hits"][r1]), -int(h["best_score"][r1]), ln(r1) if swapped else ln(r0), ln(r0) if swapped else ln(r1), h, o,
+                [fg(r1), fg(r0)] if swapped else [fg(r0), fg(r1)])
         elif kind == 2:
             n0, n1 = int(h["n_hits"][r0]), int(h["n_hits"][r1])
-            add(n0, int(h["best_score"][r0]), ln(r0), 0, h, o)
-            add(n1, int(h["best_score"][r1]), ln(r1), 0, h, o + n0)
+            add(n0, int(h["best_score"][r0]), ln(r0), 0, h, o, [fg(r0)])
+            add(n1, int(h["best_score"][r1]), ln(r1), 0, h, o + n0, [fg(r1)])
         elif kind in (3, 4):
             x = r0 if kind == 3 else r1
-            add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, o)
+            add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, o, [fg(x)])
         else:
             for x in (r0, r1):
                 if mate[x] >= 0 and h["n_hits"][x] > 0:
-                    add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, int(R_off[x]))
+                    add(int(h["n_hits"][x]), int(h["best_score"][x]), ln(x), 0, h, int(R_off[x]), [fg(x)])
     off = np.concatenate([[0], np.cumsum([r[0] for r in rec])]).astype(np.int64)
     flat = lambda i: np.array([x for r in rec for x in r[i]], np.int32)
     col = lambda i: np.array([r[i] for r in rec], np.int32)
@@ -211,6 +215,8 @@ def hip_pe_conclave(db, g):
     only = db.conclave_records(pcol(0), pcol(1), pcol(2), pcol(3), poff, pflat(4), pflat(5), pflat(6), AS, US)
     assert np.array_equal(slot["w_scores"], only["w_scores"]) and np.array_equal(slot["depth"], only["depth"])
     assert np.array_equal(slot["read_counts"], only["read_counts"])
+    out["frags"] = frags
+    out["n_hits"] = col(0)
     return out
 
 

@@ -20,7 +20,7 @@ def _case(g, name):
         ok = np.zeros(int(db.info.DB_size), np.uint8)
         for r in rows:
             ok[r.template_id] = r.significant
-        stats, off, nops, ops = db.align_trace(b, h["flag"], cc["tmpl"], ok)
+        stats, off, nops, ops = db.align_trace(b, h["rc"], cc["tmpl"], ok)
     finally:
         db.close()
     sam = golden_util.load_sam(name)
@@ -78,8 +78,8 @@ def _res_case(g, name):
         ok = np.zeros(int(db.info.DB_size), np.uint8)
         for r in rows:
             ok[r.template_id] = r.significant
-        traces = db.align_trace(b, h["flag"], cc["tmpl"], ok)
-        asm = db.assemble(b, h["flag"], cc["tmpl"], traces, consensus=True)
+        traces = db.align_trace(b, h["rc"], cc["tmpl"], ok)
+        asm = db.assemble(b, h["rc"], cc["tmpl"], traces, consensus=True)
         names = golden_util.template_names(name)
         fsa = []
         lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
@@ -110,3 +110,69 @@ def test_res_file_matches_reference_byte_for_byte_long_reads(golden_long):
     rows, asm = _res_case(golden_long, "long")
     assert rows > 0
     assert (asm["asm_len"] > 0).sum() >= rows
+
+
+def test_res_file_matches_reference_paired(golden_pe):
+    """`-ipe ... -apm p` end to end: pairs and singly emitted reads through stages 2 / 3a, their records merged in stream
+    order for ConClave, every fragment traced and piled up in the reference's order -> `.res`, consensus FASTA and the SAM
+    records (POS, CIGAR, AS, FLAG per fragment) of the reference run."""
+    import collections
+    import os
+    import pe_util
+    from kma_amd import binding
+    g = golden_pe
+    name = "pe"
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        cc = pe_util.hip_pe_conclave(db, g)
+        rows = db.res_rows(cc["w_scores"])
+        ok = np.zeros(int(db.info.DB_size), np.uint8)
+        for r in rows:
+            ok[r.template_id] = r.significant
+        # one batch of fragments in frag_raw stream order; the first fragment of a record carries the sign of the template
+        # (runConClave reverse-complements only it, conclave.c:131-146)
+        reads, flags, rcs, tmpls, hdrs = [], [], [], [], []
+        for k, fr in enumerate(cc["frags"]):
+            tt = int(cc["tmpl"][k])
+            for x, (i, fl, rcv) in enumerate(fr):
+                r = g["s1"][i]
+                reads.append(pe_util.codes_of(r["seq"], r["seqlen"], r["N"]))
+                flags.append(fl)
+                rcs.append(rcv)
+                tmpls.append(tt if x == 0 else abs(tt))
+                hdrs.append(r["hdr"].rstrip(b"\0").decode())
+        b = formats.pack_ragged(reads)
+        flags, rcs, tmpls = np.array(flags, np.int32), np.array(rcs, np.int32), np.array(tmpls, np.int32)
+        traces = db.align_trace(b, rcs, tmpls, ok)
+        asm = db.assemble(b, rcs, tmpls, traces, consensus=True)
+        names = golden_util.template_names(name)
+        lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
+        fsa = []
+        for r in rows:
+            if r.significant:
+                t = r.template_id
+                line = db.res_line(names[t - 1], r, asm["cover"][t], asm["aln_len"][t], asm["depth"][t])
+                if line:
+                    lines.append(line)
+                    fsa.append((names[t - 1], asm["consensus"][t]))
+    finally:
+        db.close()
+    # SAM records per fragment (a pair has two records under one name)
+    stats, off, nops, ops = traces
+    got = collections.Counter()
+    for i in range(b.n):
+        st = stats[i]
+        if not st[3]:
+            continue
+        tt = int(tmpls[i])
+        cigar = binding.cigar_from_runs(ops[off[i]:off[i] + nops[i]], int(st[4]), int(st[5]))
+        fl = int(flags[i]) | (16 if tt < 0 else 0)
+        got[(hdrs[i], fl, names[abs(tt) - 1], int(st[1]) + 1, min(254, int(st[9])), cigar, int(st[0]))] += 1
+    exp = collections.Counter()
+    for h, recs in golden_util.load_sam(name).items():
+        for rec in recs:
+            exp[(h,) + rec] += 1
+    assert got == exp
+    with open(os.path.join(golden_util.GOLD, name, "out.res")) as f:
+        assert "".join(lines) == f.read()
+    assert golden_util.fsa_text(fsa) == golden_util.load_fsa(name)
