@@ -176,3 +176,43 @@ def test_res_file_matches_reference_paired(golden_pe):
     with open(os.path.join(golden_util.GOLD, name, "out.res")) as f:
         assert "".join(lines) == f.read()
     assert golden_util.fsa_text(fsa) == golden_util.load_fsa(name)
+
+
+def test_c1_full_size_res_and_consensus_match_reference(tmp_path):
+    """BASELINE config C1 at full size (100 000 x 150 bp reads, 500 genes): the whole path -- stage 2, 3a, ConClave, the
+    traceback aligner, pile-up, consensus -- through the C-ABI must give the reference's `.res` and consensus FASTA byte for
+    byte. Inputs are regenerated from the seeds of tests/golden/make_golden_c1.py."""
+    import gzip
+    import os
+    import sys
+    from kma_amd import binding
+    sys.path.insert(0, os.path.join(golden_util.GOLD))
+    import make_golden_c1
+    prefix, names, reads = make_golden_c1.inputs(str(tmp_path))
+    b = formats.pack_fixed(reads)
+    db = binding.KmaHipDB(prefix)
+    try:
+        (rc_flag, flag, T_off, T), h = db.map_se(b)
+        cc = db.conclave_se(b.length, T_off, h)
+        rows = db.res_rows(cc["w_scores"])
+        ok = np.zeros(int(db.info.DB_size), np.uint8)
+        for r in rows:
+            ok[r.template_id] = r.significant
+        traces = db.align_trace(b, h["rc"], cc["tmpl"], ok)
+        asm = db.assemble(b, h["rc"], cc["tmpl"], traces, consensus=True)
+        lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
+        fsa = []
+        for r in rows:
+            if r.significant:
+                t = r.template_id
+                line = db.res_line(names[t - 1], r, asm["cover"][t], asm["aln_len"][t], asm["depth"][t])
+                if line:
+                    lines.append(line)
+                    fsa.append((names[t - 1], asm["consensus"][t]))
+    finally:
+        db.close()
+    with open(os.path.join(golden_util.GOLD, "c1", "out.res")) as f:
+        assert "".join(lines) == f.read()
+    with gzip.open(os.path.join(golden_util.GOLD, "c1", "out.fsa.gz"), "rt") as f:
+        assert golden_util.fsa_text(fsa) == f.read()
+    assert len(lines) == 501
