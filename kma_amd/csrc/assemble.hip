@@ -16,6 +16,8 @@
 #include <cctype>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 
 namespace {
 
@@ -345,7 +347,16 @@ static double asm_p_chisqr(long double q) {      // stdstat.c:136-147
 	return 1 - 1.772453850 * erf(sqrt((double) (0.5 * q))) / tgamma(0.5);
 }
 static int significant_nuc(int X, int Y, double evalue) {   // significantNuc, assembly.c:143-145
-	return (Y < X && asm_p_chisqr(pow(X - Y, 2) / (X + Y)) <= evalue);
+	if(!(Y < X)) return 0;
+	// a pure function of (X, Y, evalue): memoised, most columns of a pile-up repeat a handful of (X, Y) pairs
+	struct Slot { uint64_t key; double ev; int val; };
+	static thread_local std::vector<Slot> memo(1 << 16, Slot{~0ull, 0.0, 0});
+	const uint64_t key = ((uint64_t) (uint32_t) X << 32) | (uint32_t) Y;
+	Slot &m = memo[(size_t) ((key * 0x9E3779B97F4A7C15ull) >> 48)];
+	if(m.key == key && m.ev == evalue) return m.val;
+	const int v = asm_p_chisqr(pow(X - Y, 2) / (X + Y)) <= evalue;
+	m.key = key; m.ev = evalue; m.val = v;
+	return v;
 }
 
 // one column: callConsensus body + baseCaller (assembly.c:1543-1595, 162-179); counts already clamped to 16 bit
@@ -416,7 +427,13 @@ extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads 
 	   (rc = up(flag, (size_t) n * 4, (void **) &d_flag)) || (rc = up(tmpl, (size_t) n * 4, (void **) &d_tmpl)) ||
 	   (rc = up(traces->stats, (size_t) n * 40, (void **) &dt.stats)) || (rc = up(traces->ops_off, (size_t) n * 8, (void **) &dt.ops_off)) ||
 	   (rc = up(traces->n_ops, (size_t) n * 4, (void **) &dt.n_ops)) || (rc = up(traces->ops, (size_t) total_ops * 4, (void **) &dt.ops))) return rc;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	const auto t0 = now();
 	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, 0))) return rc;
+	const auto t1 = now();
+	if(dbg) fprintf(stderr, "[kmahip] assemble: pile-up on device %.1f ms\n", ms(t0, t1));
 	if(!ws->p_kept) return KMAHIP_OK;
 
 	// consensus on the host
@@ -434,6 +451,8 @@ extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads 
 	std::vector<int64_t> toff((size_t) D + 1);
 	HIP_TRY(hipMemcpy(toff.data(), db->dev.tseq_off, toff.size() * 8, hipMemcpyDeviceToHost));
 	std::string cons;
+	const auto t2 = now();
+	if(dbg) fprintf(stderr, "[kmahip] assemble: copy back %.1f ms\n", ms(t1, t2));
 	for(int64_t t = 1; t < D; ++t) {
 		if(seg[t] >= ws->p_kept) continue;              // no read was piled up on this template
 		const int t_len = db->h_tlen[t];
@@ -468,6 +487,7 @@ extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads 
 			out->consensus_used += (int64_t) cons.size() + 1;
 		}
 	}
+	if(dbg) fprintf(stderr, "[kmahip] assemble: consensus on host %.1f ms\n", ms(t2, now()));
 	return KMAHIP_OK;
 }
 
