@@ -1,5 +1,6 @@
 """N > 1 path on CPU: two gloo ranks map disjoint read shards (oracle as the compute stand-in),
-all-reduce the ConClave vectors, and must reproduce the single-process result exactly."""
+all-reduce the ConClave vectors, run ConClave per shard on the summed vectors, reduce its per-template outputs, and must
+reproduce the single-process result exactly."""
 import os
 import socket
 
@@ -38,7 +39,15 @@ def _worker(rank, world, port, tmpdir, out):
     mapped = torch.tensor([int((res["n_hits"] > 0).sum())])
     allreduce_scores(aln, uniq)
     dist.all_reduce(mapped)
+    # stage 3b on the shard with the GLOBAL vectors, then the second reduction: w_scores and depth
+    tlen = formats.read_lengths(g["prefix"])
+    cc = oracle.conclave(res["n_hits"], res["best_score"], batch.length, np.zeros(batch.n, np.int32), sc[2][:-1], res["tmpl"],
+                         res["start"], res["end"], aln.numpy().astype(np.uint64), uniq.numpy().astype(np.uint64), tlen)
+    w = torch.from_numpy(cc["w_scores"].astype(np.int64))
+    dp = torch.from_numpy(cc["depth"].astype(np.int64))
+    allreduce_scores(w, dp)
     if rank == 0:
+        np.save(out + ".w", np.stack([w.numpy(), dp.numpy()]))
         np.save(out, np.stack([aln.numpy(), uniq.numpy()]))
         open(out + ".mapped", "w").write(str(int(mapped)))
     dist.destroy_process_group()
@@ -62,3 +71,10 @@ def test_two_rank_read_shards_allreduce_matches_single_process(tmp_path):
     assert np.array_equal(got[0], res["alignment_scores"].astype(np.int64))
     assert np.array_equal(got[1], res["uniq_alignment_scores"].astype(np.int64))
     assert int(open(out + ".mapped").read()) == int((res["n_hits"] > 0).sum()) == 966
+    # ConClave per shard over the summed vectors + summed outputs == ConClave over the whole stream
+    tlen = formats.read_lengths(g["prefix"])
+    b = g["batch"]
+    cc = oracle.conclave(res["n_hits"], res["best_score"], b.length, np.zeros(b.n, np.int32), sc[2][:-1], res["tmpl"], res["start"],
+                         res["end"], res["alignment_scores"], res["uniq_alignment_scores"], tlen)
+    w = np.load(out + ".w.npy")
+    assert np.array_equal(w[0], cc["w_scores"].astype(np.int64)) and np.array_equal(w[1], cc["depth"].astype(np.int64))
