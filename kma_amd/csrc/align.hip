@@ -165,6 +165,26 @@ __device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
 	}
 }
 
+// two lookups whose first table gathers travel together
+__device__ __forceinline__ void tpos_get2(const DevDB &db, int t, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
+	const uint32_t sh = db.tpos_shift[t];
+	const uint2 *tab = db.tpos_slots + db.tpos_off[t];
+	const uint32_t msk = (1u << (32 - sh)) - 1u;
+	uint32_t s1 = (km1 * 0x9E3779B1u) >> sh, s2 = (km2 * 0x9E3779B1u) >> sh;
+	uint2 e1 = tab[s1], e2 = tab[want2 ? s2 : s1];
+	v1 = 0; v2 = 0;
+	if(km1) for(;;) {
+		if(e1.y == 0) break;
+		if(e1.x == km1) { v1 = (int) e1.y; break; }
+		s1 = (s1 + 1u) & msk; e1 = tab[s1];
+	}
+	if(want2 && km2) for(;;) {
+		if(e2.y == 0) break;
+		if(e2.x == km2) { v2 = (int) e2.y; break; }
+		s2 = (s2 + 1u) & msk; e2 = tab[s2];
+	}
+}
+
 struct Lane {
 	int32_t *s32;
 	uint64_t *s64;
@@ -799,9 +819,16 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 		const int end = (i != q.nN + 1) ? Ni - k + 1 : q_len - k + 1;
 		const int segstop = end + k - 1;
 		while(j < end) {
-			const int v = tpos_get(db, t, q_kmer(q, j, k));
+			// two k-mer starts per step, both gathers in flight together: the usual miss (the k-mer that starts on a
+			// mismatch) is followed by a hit one base later, and a wave waits for its slowest lane's step count
+			int v, v2;
+			tpos_get2(db, t, q_kmer(q, j, k), (j + 1 < end) ? q_kmer(q, j + 1, k) : 0u, j + 1 < end, v, v2);
 			if(L.cnt) atomicAdd(&L.cnt[3], 1ull);
-			if(v == 0) { ++j; continue; }
+			if(v == 0) {
+				if(j + 1 < end && L.cnt) atomicAdd(&L.cnt[3], 1ull);
+				if(v2 == 0) { j += 2; continue; }
+				++j; v = v2;
+			}
 			if(v > 0) {
 				if(nm >= cap) { *status = 1; return FAIL; }
 				j = add_mem(L, nm, ts, t_len, q, j, v, k, lowq, segstop);
