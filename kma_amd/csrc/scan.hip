@@ -529,17 +529,29 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				const int g = idx & (GROUP - 1);
 				if(g >= ng || t_id[idx] == T_EMPTY) continue;
 				int score = t_score[idx], last = t_last[idx], first = t_first[idx];
-				const uint32_t *m = t_mask + idx;
-				int cur = 0;
+				// the 136-bit mask as three 64-bit words; a run of ones starts where a one has a zero below it and ends
+				// (exclusively) where a zero has a one below it -- MW * 32 > CHUNK, so every run ends inside the words
+				static_assert(MW == 5 && CHUNK < MW * 32, "mask layout");
+				uint32_t mw[MW];
+#pragma unroll
+				for(int w = 0; w < MW; ++w) mw[w] = t_mask[w * TSLOTS * GROUP + idx];
+				const uint64_t M0 = (uint64_t) mw[0] | ((uint64_t) mw[1] << 32), M1 = (uint64_t) mw[2] | ((uint64_t) mw[3] << 32), M2 = mw[4];
+				const uint64_t X0 = M0 << 1, X1 = (M1 << 1) | (M0 >> 63), X2 = (M2 << 1) | (M1 >> 63);
+				uint64_t S0 = M0 & ~X0, S1 = M1 & ~X1, S2 = M2 & ~X2;
+				uint64_t E0 = ~M0 & X0, E1 = ~M1 & X1, E2 = ~M2 & X2;
 				for(;;) {
-					const int b0 = mask_next(m, TSLOTS * GROUP, cur, true);
-					if(b0 >= MW * 32) break;
-					const int b1 = mask_next(m, TSLOTS * GROUP, b0, false);
+					int b0, b1;
+					if(S0) { b0 = __ffsll((long long) S0) - 1; S0 &= S0 - 1; }
+					else if(S1) { b0 = 63 + __ffsll((long long) S1); S1 &= S1 - 1; }
+					else if(S2) { b0 = 127 + __ffsll((long long) S2); S2 &= S2 - 1; }
+					else break;
+					if(E0) { b1 = __ffsll((long long) E0) - 1; E0 &= E0 - 1; }
+					else if(E1) { b1 = 63 + __ffsll((long long) E1); E1 &= E1 - 1; }
+					else { b1 = 127 + __ffsll((long long) E2); E2 &= E2 - 1; }
 					const int pa = c0 + b0, len = b1 - b0;
 					if(score == INT_MIN) { score = k * A.M + (len - 1) * A.M; first = pa; }
 					else score += bridge(pa - 1 - last, k, A.M, A.MM, A.U, A.W1) + (len - 1) * A.M;
 					last = c0 + b1 - 1;
-					cur = b1;
 				}
 				t_score[idx] = score; t_last[idx] = last; t_first[idx] = first;
 #pragma unroll
