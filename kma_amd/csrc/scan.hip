@@ -67,6 +67,36 @@ struct ScanArgs {
 
 enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6, C_PPOOL = 7, C_NACT = 8, C_PREF = 9, N_COUNTERS = KMAHIP_N_COUNTERS };
 
+// two probes whose home buckets travel together (used after a miss: the k-mer starts behind a mismatch miss in a row)
+__device__ __forceinline__ void probe2(const DevDB &db, uint32_t key1, uint32_t key2, uint32_t &r1, uint32_t &r2) {
+	const uint32_t sh = 32u - db.nb_log2;
+	const uint32_t nbm = (1u << db.nb_log2) - 1u;
+	uint32_t b1 = (key1 * 0x9E3779B1u) >> sh, b2 = (key2 * 0x9E3779B1u) >> sh;
+	const uint4 *p1 = reinterpret_cast<const uint4 *>(db.slots + (size_t) b1 * KMAHIP_BUCKET_SLOTS);
+	const uint4 *p2 = reinterpret_cast<const uint4 *>(db.slots + (size_t) b2 * KMAHIP_BUCKET_SLOTS);
+	uint4 a1 = p1[0], c1 = p1[1], a2 = p2[0], c2 = p2[1];
+	for(;;) {
+		if(a1.x == key1 && a1.y != KMAHIP_EMPTY_VI) { r1 = a1.y; break; }
+		if(a1.z == key1 && a1.w != KMAHIP_EMPTY_VI) { r1 = a1.w; break; }
+		if(c1.x == key1 && c1.y != KMAHIP_EMPTY_VI) { r1 = c1.y; break; }
+		if(c1.z == key1 && c1.w != KMAHIP_EMPTY_VI) { r1 = c1.w; break; }
+		if(c1.w == KMAHIP_EMPTY_VI) { r1 = 0xFFFFFFFFu; break; }
+		b1 = (b1 + 1u) & nbm;
+		p1 = reinterpret_cast<const uint4 *>(db.slots + (size_t) b1 * KMAHIP_BUCKET_SLOTS);
+		a1 = p1[0]; c1 = p1[1];
+	}
+	for(;;) {
+		if(a2.x == key2 && a2.y != KMAHIP_EMPTY_VI) { r2 = a2.y; break; }
+		if(a2.z == key2 && a2.w != KMAHIP_EMPTY_VI) { r2 = a2.w; break; }
+		if(c2.x == key2 && c2.y != KMAHIP_EMPTY_VI) { r2 = c2.y; break; }
+		if(c2.z == key2 && c2.w != KMAHIP_EMPTY_VI) { r2 = c2.w; break; }
+		if(c2.w == KMAHIP_EMPTY_VI) { r2 = 0xFFFFFFFFu; break; }
+		b2 = (b2 + 1u) & nbm;
+		p2 = reinterpret_cast<const uint4 *>(db.slots + (size_t) b2 * KMAHIP_BUCKET_SLOTS);
+		a2 = p2[0]; c2 = p2[1];
+	}
+}
+
 __device__ __forceinline__ uint32_t probe(const DevDB &db, uint32_t key) {
 	const uint32_t sh = 32u - db.nb_log2;
 	const uint32_t nbm = (1u << db.nb_log2) - 1u;
@@ -398,22 +428,40 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 					const uint64_t *rw = A.seq + s_soff[g];
 					const int32_t *Nl = A.N + s_noff[g];
 					int jj = j0, hc = 0;
+					bool pairs = false;      // after a miss or a walk cut short: probe two k-mer starts per step
 					while(jj < j1) {
-						const int p = c0 + jj;
+						int p = c0 + jj;
 						if(p >= npos) break;
 						const int q = strand ? (L - k - p) : p;
 						if(nN && window_has_N(Nl, nN, q, k)) { ++jj; continue; }
 						const uint64_t *wsrc = &w_lds[g * SW];
-						const int w = (q >> 5) - (staged_once ? 0 : s_wbase[g]);
+						const int wb = staged_once ? 0 : s_wbase[g];
+						const int w = (q >> 5) - wb;
 						uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], q, k);
 						if(strand) km = revcomp_kmer(km, k);
 						uint32_t gp;
+						bool second = false;
+						if(pairs && jj + 1 < j1 && p + 1 < npos) {
+							const int q2 = strand ? q - 1 : q + 1;
+							second = !(nN && window_has_N(Nl, nN, q2, k));
+						}
 #ifdef KMAHIP_DIAG
 						if(A.ablate & 2) gp = MISS; else
 #endif
-						gp = probe(db, (uint32_t) km);
+						if(second) {
+							const int q2 = strand ? q - 1 : q + 1, w2 = (q2 >> 5) - wb;
+							uint64_t km2 = kmer_from(wsrc[w2], wsrc[w2 + 1], q2, k);
+							if(strand) km2 = revcomp_kmer(km2, k);
+							uint32_t gp2;
+							probe2(db, (uint32_t) km, (uint32_t) km2, gp, gp2);
+							if(gp == MISS) {
+								++nprobe; ++nres;
+								if(gp2 == MISS) { ++nprobe; ++nres; jj += 2; continue; }
+								gp = gp2; ++jj; ++p;
+							}
+						} else gp = probe(db, (uint32_t) km);
 						++nprobe; ++nres;
-						if(gp == MISS) { ++jj; continue; }
+						if(gp == MISS) { ++jj; pairs = true; continue; }
 						// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
 						constexpr int WALK = SEG - 1;
 						uint32_t vv[WALK + 1];
@@ -478,6 +526,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 							}
 						}
 						jj += run + 1;
+						pairs = true;        // whatever is left of the segment lies behind a mismatch
 					}
 					if(MODE && hc) atomicAdd(&s_hits[g], hc);
 				}
