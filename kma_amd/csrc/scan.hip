@@ -231,9 +231,9 @@ __device__ __forceinline__ void expand_list(const DevDB &db, uint32_t vi, int rs
 // 8 adjacent lanes per strand item; a strand with no hit is finished (no candidates), the others are appended to
 // the device-wide list of active items, so that the scan kernel below only ever sees full groups of live items.
 // One workgroup filters PF_ITEMS items and appends its survivors with a single global atomic.
-constexpr int PF_PLANES = 8;                               // lanes sharing one item's probes
+constexpr int PF_PLANES = 1;                               // lanes sharing one item's probes (8: 0.71 ms, 2: 0.51, 1 with paired probes: see DESIGN)
 constexpr int PF_BLOCK = THREADS / PF_PLANES;              // items per round
-constexpr int PF_ROUNDS = 16;
+constexpr int PF_ROUNDS = 512 / PF_BLOCK;
 constexpr int PF_ITEMS = PF_BLOCK * PF_ROUNDS;             // items per workgroup
 
 template <bool STATS>
@@ -265,12 +265,23 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 #endif
 					hit = strand == 0 || A.exhaustive;
 				} else if(nN == 0) {
-					for(int j = plane * k; j < npos; j += PF_PLANES * k) {
+					// two stride positions per step, their home buckets in flight together
+					for(int j = plane * k; j < npos; j += 2 * PF_PLANES * k) {
 						const int q = strand ? (L - k - j) : j;
 						uint64_t km = kmer_from(rs[q >> 5], rs[(q >> 5) + 1], q, k);
 						if(strand) km = revcomp_kmer(km, k);
 						++nprobe;
-						if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
+						const int j2 = j + PF_PLANES * k;
+						if(j2 < npos) {
+							const int q2 = strand ? (L - k - j2) : j2;
+							uint64_t km2 = kmer_from(rs[q2 >> 5], rs[(q2 >> 5) + 1], q2, k);
+							if(strand) km2 = revcomp_kmer(km2, k);
+							uint32_t r1, r2;
+							probe2(db, (uint32_t) km, (uint32_t) km2, r1, r2);
+							if(r1 != MISS) { hit = true; break; }
+							++nprobe;
+							if(r2 != MISS) { hit = true; break; }
+						} else if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
 					}
 				} else if(plane == 0) {
 					// rare: walk the N-free segments exactly like savekmers.c:2483-2495
