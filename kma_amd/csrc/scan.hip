@@ -702,21 +702,27 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	}
 }
 
-// Overflow path: one lane per item, DB_size-wide score / last-hit / list arrays
-// in HBM (the reference's own per-thread layout, savekmers.c:134-150).
+// Overflow path: items whose candidate set does not fit the LDS tables. The reference's own sequential formulation
+// (savekmers.c:2511-2706) on DB_size-wide score / last-hit / list arrays in HBM (its per-thread layout, :134-150), one
+// WAVEFRONT per item: the 64 lanes resolve 512 k-mer starts at a time side by side (the probes are what the old
+// one-lane version spent its time waiting for), then walk them in lockstep -- the walk itself is uniform, and the
+// templates of a value list are handled one per lane.
+constexpr int DCH = 512;
+
 __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
+	__shared__ uint32_t s_vi[DCH];
 	const DevDB &db = A.db;
-	const int k = (int) db.kmersize;
+	const int k = (int) db.kmersize, lane = threadIdx.x;
 	const int64_t n_over = (int64_t) A.counters[C_NOVER];
-	const int64_t slot = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t slot = blockIdx.x;
 	if(slot >= A.dense_slots) return;
 	const int64_t D = db.DB_size;
-	int32_t *score = A.dense + slot * 3 * D;
-	int32_t *ext = score + D;
-	int32_t *list = ext + D;   // list[0..nlist); membership: ext[t] high bit trick avoided -> score[t] = INT_MIN marks "absent"
-	const int64_t *items = A.overflow_items;
+	volatile int32_t *score = A.dense + slot * 3 * D;
+	volatile int32_t *ext = score + D;
+	volatile int32_t *list = ext + D;   // list[0..nlist): templates in first-seen order; ext[t] == -1 marks "absent"
+	const unsigned long long below = (1ull << lane) - 1ull;
 	for(int64_t oi = slot; oi < n_over; oi += A.dense_slots) {
-		const int64_t item = items[oi];
+		const int64_t item = A.overflow_items[oi];
 		const int64_t r = item >> 1;
 		const int strand = (int) (item & 1);
 		const int L = A.len[r], npos = L - k + 1;
@@ -725,75 +731,94 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 		const int nN = (int) (A.N_off[r + 1] - A.N_off[r]);
 		uint32_t last = NONE;
 		int gaps = 0, HIT = 0, acc = 0, nlist = 0, hits = 0;
-		for(int p = 0; p < npos; ++p) {
-			const int q = strand ? (L - k - p) : p;
-			uint32_t vi = MISS;
-			if(nN == 0 || !window_has_N(Nl, nN, q, k)) {
-				const int w = q >> 5;
-				uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
-				if(strand) km = revcomp_kmer(km, k);
-				vi = probe(db, (uint32_t) km);
-				if(vi != MISS) vi = db.vs_id[vi];
-			}
-			if(vi == MISS) { ++gaps; continue; }
-			if(vi == last) {
-				acc += bridge(gaps, k, A.M, A.MM, A.U, A.W1);
-			} else {
-				if(last != NONE) {
-					const int c = (int) value_at(db, last, 0);
-					for(int i = 1; i <= c; ++i) { const uint32_t t = value_at(db, last, i); score[t] += acc; ext[t] = HIT; }
+		// every template of list vl, one per lane: f(t, first-seen index or -1)
+		for(int base = 0; base < npos; base += DCH) {
+			const int n = min(DCH, npos - base);
+			for(int x = lane; x < n; x += 64) {
+				const int p = base + x, q = strand ? (L - k - p) : p;
+				uint32_t vi = MISS;
+				if(nN == 0 || !window_has_N(Nl, nN, q, k)) {
+					const int w = q >> 5;
+					uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
+					if(strand) km = revcomp_kmer(km, k);
+					vi = probe(db, (uint32_t) km);
+					if(vi != MISS) vi = db.vs_id[vi];
 				}
-				HIT = p - 1;
-				const int cnt = (int) value_at(db, vi, 0);
-				for(int i = 1; i <= cnt; ++i) {
-					const uint32_t t = value_at(db, vi, i);
-					if(ext[t] != -1) {
-						score[t] += bridge(HIT - ext[t], k, A.M, A.MM, A.U, A.W1);
-					} else {
-						score[t] = k * A.M;
-						ext[t] = 0;
-						list[nlist++] = (int32_t) t;
+				s_vi[x] = vi;
+			}
+			__syncthreads();
+			for(int x = 0; x < n; ++x) {
+				const int p = base + x;
+				const uint32_t vi = s_vi[x];
+				if(vi == MISS) { ++gaps; continue; }
+				if(vi == last) {
+					acc += bridge(gaps, k, A.M, A.MM, A.U, A.W1);
+				} else {
+					if(last != NONE) {
+						const int c = (int) value_at(db, last, 0);
+						for(int i = 1 + lane; i <= c; i += 64) { const uint32_t t = value_at(db, last, i); score[t] += acc; ext[t] = HIT; }
+						__threadfence();
 					}
+					HIT = p - 1;
+					const int cnt = (int) value_at(db, vi, 0);
+					for(int i0 = 1; i0 <= cnt; i0 += 64) {
+						const int i = i0 + lane;
+						bool fresh = false;
+						uint32_t t = 0;
+						if(i <= cnt) {
+							t = value_at(db, vi, i);
+							if(ext[t] != -1) score[t] += bridge(HIT - ext[t], k, A.M, A.MM, A.U, A.W1);
+							else { score[t] = k * A.M; ext[t] = 0; fresh = true; }
+						}
+						const unsigned long long fm = __ballot(fresh);
+						if(fresh) list[nlist + __popcll(fm & below)] = (int32_t) t;
+						nlist += __popcll(fm);
+					}
+					__threadfence();
+					last = vi;
+					acc = 0;
 				}
-				last = vi;
-				acc = 0;
+				HIT = p; gaps = 0; ++hits;
 			}
-			HIT = p; gaps = 0; ++hits;
+			__syncthreads();
 		}
 		int best = 0, nb = 0;
 		int64_t off = 0;
+		if(hits) {
+			const int c = (int) value_at(db, last, 0);
+			for(int i = 1 + lane; i <= c; i += 64) score[value_at(db, last, i)] += acc;
+			__threadfence();
+		}
 		if(hits && A.mode) {
-			const int c = (int) value_at(db, last, 0);
-			for(int i = 1; i <= c; ++i) score[value_at(db, last, i)] += acc;
 			best = hits; nb = nlist;
-			off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+			if(lane == 0) off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+			off = __shfl(off, 0);
 			if(off + nb <= A.pool_cap) {
-				for(int e = 0; e < nlist; ++e) { A.pool[off + e] = list[e]; A.pool_sc[off + e] = max(0, score[list[e]]); }
-			} else atomicMax(&A.counters[C_STATUS], 1ull);
-			for(int e = 0; e < nlist; ++e) { score[list[e]] = 0; ext[list[e]] = -1; }
+				for(int e = lane; e < nlist; e += 64) { A.pool[off + e] = list[e]; A.pool_sc[off + e] = max(0, (int) score[list[e]]); }
+			} else if(lane == 0) atomicMax(&A.counters[C_STATUS], 1ull);
 		} else if(hits) {
-			const int c = (int) value_at(db, last, 0);
-			for(int i = 1; i <= c; ++i) score[value_at(db, last, i)] += acc;
-			for(int e = 0; e < nlist; ++e) {
-				const int s = max(0, score[list[e]]);
-				if(s > best) { best = s; nb = 1; } else if(s == best) ++nb;
-			}
+			for(int e = lane; e < nlist; e += 64) best = max(best, max(0, (int) score[list[e]]));
+			for(int d = 32; d; d >>= 1) best = max(best, __shfl_xor(best, d));
 			if(best > 0) {
-				off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+				for(int e = lane; e < nlist; e += 64) nb += max(0, (int) score[list[e]]) == best;
+				for(int d = 32; d; d >>= 1) nb += __shfl_xor(nb, d);
+				if(lane == 0) off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+				off = __shfl(off, 0);
 				if(off + nb <= A.pool_cap) {
 					int w = 0;
-					for(int e = 0; e < nlist; ++e) if(max(0, score[list[e]]) == best) A.pool[off + w++] = list[e];
-				} else {
-					atomicMax(&A.counters[C_STATUS], 1ull);
-				}
-			} else {
-				nb = 0;
-			}
-			for(int e = 0; e < nlist; ++e) { score[list[e]] = 0; ext[list[e]] = -1; }
+					for(int e0 = 0; e0 < nlist; e0 += 64) {
+						const int e = e0 + lane;
+						const bool is = e < nlist && max(0, (int) score[list[e]]) == best;
+						const unsigned long long m = __ballot(is);
+						if(is) A.pool[off + w + __popcll(m & below)] = list[e];
+						w += __popcll(m);
+					}
+				} else if(lane == 0) atomicMax(&A.counters[C_STATUS], 1ull);
+			} else nb = 0;
 		}
-		A.item_score[item] = best;
-		A.item_n[item] = nb;
-		A.item_off[item] = off;
+		for(int e = lane; e < nlist; e += 64) { const int t = list[e]; score[t] = 0; ext[t] = -1; }
+		__threadfence();
+		if(lane == 0) { A.item_score[item] = best; A.item_n[item] = nb; A.item_off[item] = off; }
 	}
 }
 
@@ -1162,8 +1187,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 		ws->events3->push_back({evp, evq});
 	}
 	{
-		const unsigned dgrid = (unsigned) ((ws->dense_slots + 63) / 64);
-		hipLaunchKernelGGL(scan_dense_kernel, dim3(dgrid), dim3(64), 0, stream, A);
+		hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	}
 	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
 	hipLaunchKernelGGL(combine_count_kernel, dim3(cgrid), dim3(CB), 0, stream, A, out->rc_flag, out->flag, out->T_off, ws->blk_sums);
@@ -1202,7 +1226,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
 	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
 	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(THREADS), 0, stream, A);
-	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ((ws->dense_slots + 63) / 64)), dim3(64), 0, stream, A);
+	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	PairArgs P;
 	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
 	P.ppool = ws->ppool; P.ppool_cap = 2 * ws->pool_cap;
