@@ -31,3 +31,11 @@ def test_default_params_match_reference_defaults():
     d = [[p.rw.d[i][j] for j in range(5)] for i in range(5)]
     assert d[0] == [1, -2, -2, -2, 0] and d[4] == [0, 0, 0, 0, 0] and d[2][2] == 1
     assert (p.minlen, p.mq, p.scoreT, p.mrc, p.minFrac) == (16, 0, 0.5, 0.0, 1.0)
+
+
+def test_header_and_example_are_plain_c99():
+    """The boundary is a C ABI: the header and the example host program must compile as pedantic C99 (no GPU, no link)."""
+    import subprocess
+    for src in ("kmahip_s2.c", "kmahip_res.c"):
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src)])

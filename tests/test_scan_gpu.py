@@ -85,3 +85,18 @@ def test_scan_vs_oracle_ragged_lengths(tmp_path):
         _compare_with_oracle(prefix, batch, db, exhaustive=1)
     finally:
         db.close()
+
+
+def test_c_host_program_reproduces_reference_s2_stream(golden_se):
+    """examples/kmahip_s2.c (plain C99 over the C-ABI): the reference's S1 stream in, the reference's S2 stream out."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "examples", "kmahip_s2")
+    src = golden_se["dir"]
+    s1 = gzip.open(os.path.join(src, "s1.bin.gz"), "rb").read()
+    for extra, name in (([], "s2.bin.gz"), (["-ex_mode"], "s2_ex.bin.gz")):
+        out = subprocess.run([exe, "-t_db", golden_se["prefix"]] + extra, input=s1, stdout=subprocess.PIPE, check=True).stdout
+        assert out == gzip.open(os.path.join(src, name), "rb").read(), name

@@ -216,3 +216,17 @@ def test_c1_full_size_res_and_consensus_match_reference(tmp_path):
     with gzip.open(os.path.join(golden_util.GOLD, "c1", "out.fsa.gz"), "rt") as f:
         assert golden_util.fsa_text(fsa) == f.read()
     assert len(lines) == 501
+
+
+def test_c_host_program_reproduces_reference_res_file(golden_se, golden_long):
+    """examples/kmahip_res.c (plain C99 over the C-ABI): the reference's S1 stream in, the reference's `.res` out."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "examples", "kmahip_res")
+    for g in (golden_se, golden_long):
+        s1 = gzip.open(os.path.join(g["dir"], "s1.bin.gz"), "rb").read()
+        out = subprocess.run([exe, "-t_db", g["prefix"]], input=s1, stdout=subprocess.PIPE, check=True).stdout
+        assert out == open(os.path.join(g["dir"], "out.res"), "rb").read(), g["dir"]
