@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--families", type=int, default=1000, help="gene families (x5 variants = genes)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the host CPU baseline")
+    ap.add_argument("--parity-sample", type=int, default=50_000,
+                    help="reads of the step re-checked against the CPU oracle (bounded by --cpu-sample; the oracle does ~0.1 M reads/s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
@@ -286,13 +288,14 @@ def main():
         }
         if rank == 0 and world == 1 and not a.no_cpu and keep:
             codes = rd["codes"][:keep]
-            k = min(50_000, keep)
+            k = min(a.parity_sample, keep)
             got = [x.cpu().numpy() for x in (rc_flag[:k], flag[:k], T_off[:k + 1])]
             nt = int(got[2][-1])
             got.append(T[:nt].cpu().numpy())
             hits = dict(n_hits=n_hits[:k].cpu().numpy(), best_score=best[:k].cpu().numpy(), tmpl=h_t[:nt].cpu().numpy(),
                         score=h_sc[:nt].cpu().numpy(), start=h_s[:nt].cpu().numpy(), end=h_e[:nt].cpu().numpy())
             out["config"]["parity_first_reads_vs_oracle"] = parity_sample(prefix, codes[:k], got, hits)
+            out["config"]["parity_reads_checked"] = k
             out["cpu_baseline"] = cpu_baseline(prefix, codes, tmp)
         elif rank == 0:
             out["cpu_baseline"] = None
