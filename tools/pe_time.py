@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Paired-end path (`-ipe ... -apm p`, BASELINE config C3 shape) through the host-buffer calls, PCIe inclusive:
+stage 2 + 3a (map_pe), ConClave over the record slots.  usage (GPU box): python3 tools/pe_time.py [pairs]"""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from kma_amd import binding, formats, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+tmp = tempfile.mkdtemp()
+names, seqs = synth.make_gene_db(1000, 5, 600, 1500, 0.04, seed=12345)
+prefix = os.path.join(tmp, "db")
+formats.write_index(prefix, names, seqs)
+m1, m2, _ = synth.make_pairs(seqs, n, seed=11)
+inter = np.empty((2 * n, m1.shape[1]), np.uint8)
+inter[0::2] = m1
+inter[1::2] = m2
+b = formats.pack_fixed(inter)
+db = binding.KmaHipDB(prefix)
+for label in ("map_pe (stages 2 + 3a)", "map_pe again (warm)"):
+    t0 = time.perf_counter()
+    (mate, rc, rc_flag, flag, R_off, T), h = db.map_pe(b)
+    dt = time.perf_counter() - t0
+    print(f"{label:28s} {dt * 1e3:9.1f} ms  ({n / dt / 1e6:7.2f} M pairs/s)", flush=True)
+t0 = time.perf_counter()
+cc = db.conclave_pe(b.length, mate, R_off, h)
+dt = time.perf_counter() - t0
+print(f"{'conclave_pe':28s} {dt * 1e3:9.1f} ms")
+kinds = np.bincount(h["kind"], minlength=5)
+print("pair kinds (0 singly / none, 1 proper, 2 unmated, 3 first only, 4 second only):", kinds.tolist())
+print("templates with score:", int((cc["w_scores"] > 0).sum()))
