@@ -327,6 +327,22 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 }
 
 // ---- scan: one workgroup = GROUP active strand items, 16 lanes each ----------------------------------------
+// Workgroup-wide compaction of the threads whose `flag` is set: afterwards list[0 .. total) holds their thread ids, so the
+// first `total` threads can take one occupied table slot each -- the hashed tables are a third full, and a wavefront costs
+// the same whether 20 or 64 of its lanes have work. Two barriers inside.
+__device__ __forceinline__ int compact_threads(bool flag, int tid, int32_t *wcnt, uint16_t *list) {
+	const unsigned long long m = __ballot(flag);
+	const int wave = tid >> 6, lane = tid & 63;
+	if(lane == 0) wcnt[wave] = __popcll(m);
+	__syncthreads();
+	int before = 0, total = 0;
+#pragma unroll
+	for(int w = 0; w < THREADS / 64; ++w) { const int c = wcnt[w]; if(w < wave) before += c; total += c; }
+	if(flag) list[before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) tid;
+	__syncthreads();
+	return total;
+}
+
 template <bool STATS, int MODE>
 __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
@@ -344,6 +360,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
 	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
 	__shared__ int32_t s_gmax;
+	__shared__ int32_t s_wcnt[THREADS / 64];
+	__shared__ uint16_t s_list[THREADS];
 	__shared__ uint32_t s_stats[3];   // [0] k-mer starts resolved (= probes of the reference), [1] list elements, [2] hash probes
 
 	const DevDB &db = A.db;
@@ -546,15 +564,17 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			__syncthreads();
 			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
 			// flight together) and OR the list's position mask into the hit mask of each listed template
-			for(int idx = tid; idx < VSLOTS * GROUP; idx += THREADS) {
+			static_assert(VSLOTS * GROUP == THREADS && TSLOTS * GROUP == THREADS, "one thread per table slot");
+			const int n_lists = compact_threads(v_id[tid] != MISS, tid, s_wcnt, s_list);
+			if(tid < n_lists) {
+				const int idx = s_list[tid];
 				const int g = idx & (GROUP - 1);
 				const uint32_t vi = v_id[idx];
-				if(vi == MISS) continue;
 				v_id[idx] = MISS;
 				uint32_t mw[MW];
 #pragma unroll
 				for(int w = 0; w < MW; ++w) { mw[w] = v_mask[w * VSLOTS * GROUP + idx]; v_mask[w * VSLOTS * GROUP + idx] = 0; }
-				if(g >= ng || s_over[g]) continue;
+				if(g < ng && !s_over[g]) {
 				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
 				uint32_t cnt, el[7];
 				if(db.values_u16) {
@@ -579,15 +599,16 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 #pragma unroll
 				for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
 				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+				}
 			}
 			__syncthreads();
 			// phase 2b: one thread per (item, template): fold the hit mask into the score
+			const int n_tmpl = compact_threads((tid & (GROUP - 1)) < ng && t_id[tid] != T_EMPTY, tid, s_wcnt, s_list);
 #ifdef KMAHIP_DIAG
 			if(!(A.ablate & 8))
 #endif
-			for(int idx = tid; idx < TSLOTS * GROUP; idx += THREADS) {
-				const int g = idx & (GROUP - 1);
-				if(g >= ng || t_id[idx] == T_EMPTY) continue;
+			if(tid < n_tmpl) {
+				const int idx = s_list[tid];
 				int score = t_score[idx], last = t_last[idx], first = t_first[idx];
 				// the 136-bit mask as three 64-bit words; a run of ones starts where a one has a zero below it and ends
 				// (exclusively) where a zero has a one below it -- MW * 32 > CHUNK, so every run ends inside the words
