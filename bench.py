@@ -198,6 +198,7 @@ def main():
         scan_ms, scan_n = db.get_timing(0)
         aln_ms, aln_n = db.get_timing(1)
         pre_ms, pre_n = db.get_timing(2)
+        seed_ms, seed_n = db.get_timing(3)
         db.set_timing(False)
         db.status(stream)
         if world > 1:
@@ -221,6 +222,7 @@ def main():
         scan_s = scan_ms / 1e3 / max(1, scan_n)
         aln_s = aln_ms / 1e3 / max(1, aln_n)
         pre_s = pre_ms / 1e3 / max(1, pre_n)
+        seed_s = seed_ms / 1e3 / max(1, seed_n)
         # SURVEY §8(d) algorithmic bytes.  scan: 12 B per probe (4 B directory + 4 B key + 4 B value index in the
         # reference layout) + 2 B per value-list element + packed read in + S2 fields out.
         # Stage 2 runs as two kernels: scan_prefilter_kernel (every k-th k-mer of both strands; reads in, active list
@@ -230,7 +232,10 @@ def main():
                       + n * (4 + 4 + 8) + 4 * total_T)
         # align: 12 B per position-index lookup (4 B index + 8 B template word), 2 bits per MEM base on both
         # sequences, packed read in per task, 24 B out per task; DP cells move no HBM bytes (no E matrix)
-        aln_bytes = 12 * ast.lookups + ast.mem_bases // 2 + ast.tasks * (8 * W + 24) + n * 12
+        # Stage 3a runs as seed_tasks_kernel (the MEM search: lookups + MEM bases + packed read in, 4 + 32 B handed over per
+        # task) and align_tasks_kernel (chain, stitch, DP: hand-over + packed read in, 24 B out per task)
+        seed_bytes = 12 * ast.lookups + ast.mem_bases // 2 + ast.tasks * (8 * W + 36)
+        aln_bytes = ast.tasks * (8 * W + 36 + 24) + n * 12
         if aln_s >= scan_s:
             dom = dict(kernel="align_tasks_kernel", kernel_ms=aln_s * 1e3, achieved=aln_bytes / aln_s / 1e9,
                        algorithmic_bytes_per_launch=aln_bytes)
@@ -281,6 +286,7 @@ def main():
                 "scan": {"kernel_ms": scan_s * 1e3, "probes": int(st.probes - st.prefilter_probes),
                          "hash_probes": int(st.hash_probes - st.prefilter_probes),
                          "GB/s": scan_bytes / scan_s / 1e9, "probes_per_s": (st.probes - st.prefilter_probes) / scan_s},
+                "seed": {"kernel_ms": seed_s * 1e3, "lookups": int(ast.lookups), "GB/s": seed_bytes / seed_s / 1e9 if seed_s else None},
                 "align": {"kernel_ms": aln_s * 1e3, "lookups": int(ast.lookups), "dp_cells": int(ast.dp_cells),
                           "GCUPS": ast.dp_cells / aln_s / 1e9, "GB/s": aln_bytes / aln_s / 1e9,
                           "tasks_per_s": ast.tasks / aln_s},

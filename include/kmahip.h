@@ -343,10 +343,10 @@ int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
 
 /* Kernel timing: when on, every *_dev call records a HIP event pair around its
- * main kernels (scan_prefilter_kernel, scan_se_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
+ * main kernels (scan_prefilter_kernel, scan_se_kernel, seed_tasks_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
  * for them, returns the summed milliseconds and launch count, and resets. */
 int kmahip_ws_set_timing(kmahip_ws *ws, int on);
-int kmahip_ws_get_timing(kmahip_ws *ws, int kernel /* 0 scan_se_kernel, 1 align_tasks_kernel, 2 scan_prefilter_kernel */,
+int kmahip_ws_get_timing(kmahip_ws *ws, int kernel /* 0 scan_se_kernel, 1 align_tasks_kernel, 2 scan_prefilter_kernel, 3 seed_tasks_kernel */,
                          double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus

@@ -251,7 +251,7 @@ class KmaHipDB:
         _check(lib().kmahip_ws_set_timing(self.ws, int(on)))
 
     def get_timing(self, kernel=0):
-        """kernel 0 = scan_se_kernel, 1 = align_tasks_kernel, 2 = scan_prefilter_kernel -> (summed ms, launches)"""
+        """kernel 0 = scan_se_kernel, 1 = align_tasks_kernel, 2 = scan_prefilter_kernel, 3 = seed_tasks_kernel -> (summed ms, launches)"""
         ms, n = C.c_double(), C.c_int64()
         _check(lib().kmahip_ws_get_timing(self.ws, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value

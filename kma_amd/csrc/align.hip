@@ -51,6 +51,8 @@ struct AlignArgs {
 	int32_t *t_score, *t_alen, *t_start, *t_end, *t_tmpl;
 	double *t_norm;
 	const int32_t *t_rec;    // record owning each task (expanded from T_off by task_map_kernel)
+	int32_t *seed_n;         // per task, written by seed_tasks_kernel: number of MEMs found (0..SEEDS), -1: seed in the main kernel
+	uint2 *seed_mem;         // SEEDS per task: x = tS (1-based), y = qS | (length << 16)
 	// scratch
 	int32_t *s32;
 	uint64_t *s64;
@@ -66,6 +68,7 @@ struct AlignArgs {
 };
 
 struct Aln { int score, len, pos, match, tGaps, qGaps; };
+constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
 
 struct QView {
 	const uint64_t *w;
@@ -699,6 +702,34 @@ __device__ int chain_seeds(const Lane &L, int n, int q_len, int t_len, int k, un
 // Same result as the reference's base-by-base loops (align.c:548-575), done 32 bases per step on the
 // 2-bit words: lowq = first query position after the previous N (an N never matches, so the backward
 // walk cannot cross it), segstop = end of the N-free segment.
+__device__ __forceinline__ void mem_extend(const uint64_t *ts, int t_len, const QView &q, int j, int pos1, int k, int lowq, int segstop,
+                                           int &tS, int &tE, int &qS, int &qE) {
+	int kk = j - 1, prev = pos1 - 2;
+	for(;;) {
+		const int room = min(kk - lowq + 1, prev + 1);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t xq = qwin(q, kk - step + 1) >> (64 - 2 * step);
+		const uint64_t xt = win2(ts, prev - step + 1) >> (64 - 2 * step);
+		const uint64_t x = xq ^ xt;
+		const int same = x ? (__ffsll((long long) x) - 1) >> 1 : step;
+		kk -= same; prev -= same;
+		if(same < step) break;
+	}
+	qS = kk + 1; tS = prev + 2;
+	int value = pos1 + k - 1, l = j + k;
+	for(;;) {
+		const int room = min(segstop - l, t_len - value);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t x = (qwin(q, l) ^ win2(ts, value)) >> (64 - 2 * step);
+		const int same = x ? (__clzll((long long) x) - (64 - 2 * step)) >> 1 : step;
+		l += same; value += same;
+		if(same < step) break;
+	}
+	qE = l; tE = value + 1;
+}
+
 __device__ int add_mem(const Lane &L, int m, const uint64_t *ts, int t_len, const QView &q, int j, int pos1, int k, int lowq, int segstop) {
 	// backward
 	int kk = j - 1, prev = pos1 - 2;
@@ -918,6 +949,58 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 
 // STATS = work-counter launches (atomics in the hot loops; never timed) get their own symbol so that profiler
 // averages of the production kernel stay clean
+// ---- seeding on its own: the MEM search of KMA_score (align.c:534-638) needs a fraction of the registers of what follows
+// it, and all it does is wait for dependent gathers -- so it runs as its own kernel at 8 waves / SIMD (twice the gathers in
+// flight), one lane per single-end task, and hands up to SEEDS MEMs per task to the main kernel. Tasks it cannot serve
+// (strand ties, more MEMs, reads >= 64 k bases) are marked -1 and seeded by the main kernel as before.
+__global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
+	const int64_t n_tasks = A.T_off[A.n_reads];
+	const int k = (int) A.db.kmersize;
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	for(int64_t task = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; task < n_tasks; task += stride) {
+		const int64_t r = A.t_rec[task];
+		const int rcf = A.rc_flag[r], L = A.len[r];
+		if(rcf <= 0 || L < k || L > 0xFFFF) { A.seed_n[task] = -1; continue; }
+		const int t = abs(A.T[task]);
+		const int t_len = A.db.tlen[t];
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
+		QView q;
+		q.w = A.seq + A.seq_off[r]; q.L = L; q.rc = (A.flag[r] & 16) ? 1 : 0;
+		q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+		uint2 mem[SEEDS];
+		int nm = 0, j = 0, lowq = 0;
+		bool give_up = false;
+		for(int i = 1; i <= q.nN + 1 && !give_up; ++i) {
+			const int Ni = qN_at(q, i);
+			const int end = (i != q.nN + 1) ? Ni - k + 1 : L - k + 1;
+			const int segstop = end + k - 1;
+			while(j < end && !give_up) {
+				int v, v2;
+				tpos_get2(A.db, t, q_kmer(q, j, k), (j + 1 < end) ? q_kmer(q, j + 1, k) : 0u, j + 1 < end, v, v2);
+				if(v == 0) {
+					if(v2 == 0) { j += 2; continue; }
+					++j; v = v2;
+				}
+				if(v > 0) {
+					if(nm >= SEEDS) { give_up = true; break; }
+					int tS, tE, qS, qE;
+					mem_extend(ts, t_len, q, j, v, k, lowq, segstop, tS, tE, qS, qE);
+#pragma unroll
+					for(int x = 0; x < SEEDS; ++x) if(x == nm) mem[x] = make_uint2((uint32_t) tS, (uint32_t) qS | ((uint32_t) (qE - qS) << 16));
+					++nm;
+					j = qE;
+				} else give_up = true;       // duplicated k-mer: several MEMs per lookup, left to the main kernel
+			}
+			j = Ni + 1;
+			lowq = Ni + 1;
+		}
+		if(give_up) { A.seed_n[task] = -1; continue; }
+		A.seed_n[task] = nm;
+#pragma unroll
+		for(int x = 0; x < SEEDS; ++x) if(x < nm) A.seed_mem[task * SEEDS + x] = mem[x];
+	}
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
@@ -1001,7 +1084,17 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				L.q_mate = 0; L.q_rd = rd;
 				if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
 				if(rcf > 0) {
-					S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+					// MEMs found by seed_tasks_kernel (the work-counting launch seeds here so that its counters are complete)
+					const int pre = (!STATS && A.seed_n) ? A.seed_n[task] : -1;
+					if(pre > 0) {
+						for(int m = 0; m < pre; ++m) {
+							const uint2 e = A.seed_mem[task * SEEDS + m];
+							const int qS = (int) (e.y & 0xFFFFu), ln = (int) (e.y >> 16);
+							MEMA(L, 0, m) = (int) e.x; MEMA(L, 1, m) = (int) e.x + ln; MEMA(L, 2, m) = qS; MEMA(L, 3, m) = qS + ln; MEMA(L, 4, m) = ln;
+						}
+						S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, pre, &status);
+					} else if(pre == 0) S0 = Aln{0, 1, 0, 0, 0, 0};
+					else S0 = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
 				} else {
 					// strand tie: per template strand decision (alnfrags.c:1101-1124)
 					const int side = anker_rc_comp(L, A.db, at, ts, t_len, q, &status);
@@ -1715,7 +1808,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (6 * 4 + 8)));
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (7 * 4 + 8 + SEEDS * 8) + 16));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
@@ -1732,6 +1825,8 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	int32_t *ti = (int32_t *) (norm + tasks_cap);
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	int32_t *t_rec = ti + 5 * tasks_cap;
+	A.seed_n = nullptr; A.seed_mem = nullptr;
+	if(!rec_mate) { A.seed_n = ti + 6 * tasks_cap; A.seed_mem = (uint2 *) (ti + 7 * tasks_cap + (tasks_cap & 1)); }
 	A.t_rec = t_rec;
 	if(n >= 0x7FFFFFFF) { kmahip_set_error("too many records in one batch"); return KMAHIP_EINVAL; }
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
@@ -1744,6 +1839,16 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 #endif
 	hipLaunchKernelGGL(task_map_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, cands->T_off, n, t_rec);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if(A.seed_n && !A.stats) {
+		hipEvent_t es0 = nullptr, es1 = nullptr;
+		if(ws->timing_on) { HIP_TRY(hipEventCreate(&es0)); HIP_TRY(hipEventCreate(&es1)); HIP_TRY(hipEventRecord(es0, stream)); }
+		hipLaunchKernelGGL(seed_tasks_kernel, dim3(256 * 8), dim3(256), 0, stream, A);     // 8 waves / SIMD on 256 CUs
+		if(ws->timing_on) {
+			HIP_TRY(hipEventRecord(es1, stream));
+			if(!ws->events4) ws->events4 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+			ws->events4->push_back({es0, es1});
+		}
+	}
 	if(ws->timing_on) {
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
 		HIP_TRY(hipEventRecord(ev0, stream));

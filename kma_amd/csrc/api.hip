@@ -19,7 +19,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->pool); (void) hipFree(ws->counters); (void) hipFree(ws->overflow_items); (void) hipFree(ws->active_items);
 	(void) hipFree(ws->dense); (void) hipFree(ws->blk_sums);
 	for(int i = 0; i < 8; ++i) (void) hipFree(ws->stage[i]);
-	for(auto *ev : {ws->events, ws->events2, ws->events3}) {
+	for(auto *ev : {ws->events, ws->events2, ws->events3, ws->events4}) {
 		if(!ev) continue;
 		for(auto &e : *ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
 		delete ev;
@@ -198,9 +198,9 @@ extern "C" int kmahip_ws_set_timing(kmahip_ws *ws, int on) {
 }
 
 extern "C" int kmahip_ws_get_timing(kmahip_ws *ws, int kernel, double *total_ms, int64_t *launches) {
-	if(!ws || !total_ms || !launches || kernel < 0 || kernel > 2) return KMAHIP_EINVAL;
+	if(!ws || !total_ms || !launches || kernel < 0 || kernel > 3) return KMAHIP_EINVAL;
 	*total_ms = 0.0; *launches = 0;
-	auto *ev = kernel == 0 ? ws->events : kernel == 1 ? ws->events2 : ws->events3;
+	auto *ev = kernel == 0 ? ws->events : kernel == 1 ? ws->events2 : kernel == 2 ? ws->events3 : ws->events4;
 	if(!ev) return KMAHIP_OK;
 	for(auto &e : *ev) {
 		float ms = 0.f;

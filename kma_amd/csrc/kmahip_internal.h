@@ -77,6 +77,7 @@ struct kmahip_ws {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events2;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events3;   // prefilter kernel
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events4;   // seeding kernel
 	// paired-end stage 2
 	int32_t *pool_sc, *ppool;
 	void *pe_rec;

@@ -43,7 +43,8 @@ def run(scan_abl, align_abl, reps=3):
     s_ms, s_n = db.get_timing(0)
     a_ms, a_n = db.get_timing(1)
     p_ms, p_n = db.get_timing(2)
-    return (s_ms / max(1, s_n), a_ms / max(1, a_n), p_ms / max(1, p_n))
+    k_ms, k_n = db.get_timing(3)
+    return (s_ms / max(1, s_n), a_ms / max(1, a_n) + k_ms / max(1, k_n), p_ms / max(1, p_n))
 
 
 print(f"reads {n}")

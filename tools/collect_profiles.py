@@ -12,7 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("scan_prefilter_kernel", "scan_se_kernel", "align_tasks_kernel", "scan_dense_kernel", "task_map_kernel", "reduce_reads_kernel")
+KERNELS = ("scan_prefilter_kernel", "scan_se_kernel", "seed_tasks_kernel", "align_tasks_kernel", "scan_dense_kernel", "task_map_kernel", "reduce_reads_kernel")
 
 
 def one(pattern):

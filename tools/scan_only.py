@@ -38,4 +38,6 @@ torch.cuda.synchronize()
 s_ms, s_n = db.get_timing(0)
 a_ms, a_n = db.get_timing(1)
 p_ms, p_n = db.get_timing(2)
-print(f"reads {n}: prefilter {p_ms / max(1, p_n):.3f} ms x{p_n}, scan {s_ms / max(1, s_n):.3f} ms x{s_n}, align {a_ms / max(1, a_n):.3f} ms x{a_n}")
+k_ms, k_n = db.get_timing(3)
+print(f"reads {n}: prefilter {p_ms / max(1, p_n):.3f} ms x{p_n}, scan {s_ms / max(1, s_n):.3f} ms x{s_n}, "
+      f"seed {k_ms / max(1, k_n):.3f} ms x{k_n}, align {a_ms / max(1, a_n):.3f} ms x{a_n}")
