@@ -1194,6 +1194,11 @@ struct ReduceArgs {
 	double scoreT;
 	int32_t *n_hits, *best_score, *out_flag, *h_tmpl, *h_score, *h_start, *h_end;
 	unsigned long long *alignment_scores, *uniq_alignment_scores;
+	// private copies of the two vectors (copy c at priv + c * 2 * DB_size): every read adds into one of them, chosen by its
+	// workgroup -- 11 M u64 atomics on a few thousand addresses otherwise queue up on single L2 lines
+	unsigned long long *priv;
+	int priv_copies;
+	int64_t DB_size;
 	// paired-end mode
 	const int32_t *rec_mate, *rec_rc;
 	int32_t *out_rc;      // may be NULL. bit 0: the fragment filed for this record is the reverse complement of the original read;
@@ -1318,9 +1323,26 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 
 // per read: hit filter of alnFragsSE (alnfrags.c:1165-1215) + update_Scores with
 // minFrac == 1.0 (updatescores.c:217-234, :275-277)
-__global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R) {
+__global__ __launch_bounds__(256) void fold_scores_kernel(const unsigned long long *priv, int copies, int64_t D,
+                                                            unsigned long long *alignment_scores, unsigned long long *uniq_alignment_scores) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= 2 * D) return;
+	unsigned long long sum = 0;
+	for(int c = 0; c < copies; ++c) sum += priv[(int64_t) c * 2 * D + i];
+	if(!sum) return;
+	if(i < D) { if(alignment_scores) alignment_scores[i] += sum; }
+	else if(uniq_alignment_scores) uniq_alignment_scores[i - D] += sum;
+}
+
+__global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R0) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(r >= R.n_reads) return;
+	if(r >= R0.n_reads) return;
+	ReduceArgs R = R0;
+	if(R.priv_copies) {
+		unsigned long long *base = R.priv + (int64_t) (blockIdx.x % (unsigned) R.priv_copies) * 2 * R.DB_size;
+		if(R.alignment_scores) R.alignment_scores = base;
+		if(R.uniq_alignment_scores) R.uniq_alignment_scores = base + R.DB_size;
+	}
 	const int64_t o = R.T_off[r], e = R.T_off[r + 1];
 	int nh = 0, bestRead = 0, fl = R.flag[r];
 	if(R.pe_mode) {
@@ -1869,8 +1891,25 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
 	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
+	R.priv = nullptr; R.priv_copies = 0; R.DB_size = db->info.DB_size;
+	if(out->alignment_scores || out->uniq_alignment_scores) {
+		const int64_t D = db->info.DB_size;
+		int copies = (int) std::min<int64_t>(64, std::max<int64_t>(1, (256ll << 20) / (16 * D)));
+		if(copies > 1) {
+			if(ws->a_priv_cap < (int64_t) copies * 2 * D) {
+				(void) hipFree(ws->a_priv);
+				ws->a_priv = nullptr;
+				HIP_TRY(hipMalloc((void **) &ws->a_priv, (size_t) copies * 2 * D * 8));
+				ws->a_priv_cap = (int64_t) copies * 2 * D;
+			}
+			HIP_TRY(hipMemsetAsync(ws->a_priv, 0, (size_t) copies * 2 * D * 8, stream));
+			R.priv = (unsigned long long *) ws->a_priv; R.priv_copies = copies;
+		}
+	}
 	R.t_score_w = A.t_score; R.t_alen_w = A.t_alen; R.t_start_w = A.t_start; R.t_end_w = A.t_end; R.t_tmpl_w = A.t_tmpl;
 	hipLaunchKernelGGL(reduce_reads_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, R);
+	if(R.priv_copies) hipLaunchKernelGGL(fold_scores_kernel, dim3((unsigned) ((2 * R.DB_size + 255) / 256)), dim3(256), 0, stream, R.priv, R.priv_copies,
+	                                     R.DB_size, (unsigned long long *) out->alignment_scores, (unsigned long long *) out->uniq_alignment_scores);
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
 }

@@ -89,6 +89,8 @@ struct kmahip_ws {
 	int a_mem_cap, a_ncols;
 	void *a_task;
 	int64_t a_task_cap;
+	void *a_priv;             // private copies of the ConClave vectors (reduce_reads_kernel)
+	int64_t a_priv_cap;
 	// trace stage (3c) scratch
 	int32_t *t_s32;
 	uint8_t *t_E;
