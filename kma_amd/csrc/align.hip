@@ -213,8 +213,10 @@ struct Lane {
 #define ROWTP(L, n) (L).s64[((int64_t) ((L).ncols + (n))) * (L).lanes]
 
 constexpr int QCAP = 8;             // deferred wide problems (17..63 columns) per wave and task round
-constexpr int QCAPN = 20;           // deferred narrow problems (2..16 columns)
+constexpr int QCAPN = 20;           // deferred narrow problems (9..16 columns)
+constexpr int QCAPT = 32;           // deferred tiny problems (2..8 columns): eight side by side per cooperative call
 constexpr int QENT = 12;            // ints per queue entry
+constexpr int QINTS = 3 + (QCAP + QCAPN + QCAPT) * QENT;   // ints of one wave's three queues
 constexpr int TBUF = 1024;          // staged template bases per cooperative problem
 constexpr int WCOLS = 64;           // LDS row slots for "wide" problems: 17..63 query columns
 constexpr int WSLOTS = 2;           // slots per wave
@@ -487,10 +489,11 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			// The other small problems are handed to the whole wave (nw_coop, run after every lane has finished its
 			// own work): a lane walking a DP alone keeps 63 lanes idle at ~10^2 cycles per cell. Results are only
 			// ever summed into the alignment statistics, so the caller goes on with zeroes.
-			const bool narrow = ql <= 16 && tspan < TBUF / 4;
-			int *qu = narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
+			const bool tiny = ql <= 8 && tspan < TBUF / 8;
+			const bool narrow = !tiny && ql <= 16 && tspan < TBUF / 4;
+			int *qu = tiny ? L.queue + (2 + (QCAP + QCAPN) * QENT) : narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
 			const int slot = atomicAdd(&qu[0], 1);
-			if(slot < (narrow ? QCAPN : QCAP)) {
+			if(slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP)) {
 				int *e = qu + 1 + slot * QENT;
 				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
 				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = (k < 0) ? 1 : 0;
@@ -1005,7 +1008,7 @@ template <bool STATS>
 __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
 	__shared__ uint32_t s_wide[(ATHREADS / 64) * WSLOTS * 4 * WCOLS];
-	__shared__ int s_queue[(ATHREADS / 64) * (2 + (QCAP + QCAPN) * QENT)];
+	__shared__ int s_queue[(ATHREADS / 64) * QINTS];
 	__shared__ uint8_t s_tbuf[(ATHREADS / 64) * TBUF];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
 	__syncthreads();
@@ -1016,14 +1019,15 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = STATS ? A.counters : nullptr;
 	L.wide = s_wide + wave * WSLOTS * 4 * WCOLS;
-	L.queue = s_queue + wave * (2 + (QCAP + QCAPN) * QENT);     // wide queue, then the narrow queue
+	L.queue = s_queue + wave * QINTS;     // wide queue, then the narrow queue, then the tiny queue
 	L.q_at = 0; L.q_mate = 0; L.q_rd = 0;
 	L.ablate = A.ablate;
 #ifdef KMAHIP_DIAG
 	if(A.ablate & 64) L.queue = nullptr;      // ablation: no cooperative DP
 #endif
-	int *const queue = s_queue + wave * (2 + (QCAP + QCAPN) * QENT);
+	int *const queue = s_queue + wave * QINTS;
 	int *const queueN = queue + (1 + QCAP * QENT);
+	int *const queueT = queueN + (1 + QCAPN * QENT);
 	uint8_t *const tbuf = s_tbuf + wave * TBUF;
 	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
 	const int64_t n_tasks = A.T_off[A.n_reads];
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	// then all 64 lanes solve those, then each lane finishes its task
 	for(int64_t task = gtid; __any(task < n_tasks); task += A.lanes) {
 		const bool have = task < n_tasks && gtid < A.lanes;
-		if(lane == 0) { queue[0] = 0; queueN[0] = 0; }
+		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; }
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- phase A -------------------------------------------------------------------------------
@@ -1107,14 +1111,15 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		// ---- phase B: deferred wide DP problems, whole wave -----------------------------------------
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]);
+		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]);
 		for(int e = 0; e < nq; ++e) nw_coop<64>(L, A.db, A, queue, e, nq, tbuf);
 		for(int e = 0; e < nqn; e += 4) nw_coop<16>(L, A.db, A, queueN, e, nqn, tbuf);
+		for(int e = 0; e < nqt; e += 8) nw_coop<8>(L, A.db, A, queueT, e, nqt, tbuf);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		for(int pass = 0; pass < 2; ++pass) {
-			const int *qu = pass ? queueN : queue;
-			const int cnt = pass ? nqn : nq;
+		for(int pass = 0; pass < 3; ++pass) {
+			const int *qu = pass == 0 ? queue : pass == 1 ? queueN : queueT;
+			const int cnt = pass == 0 ? nq : pass == 1 ? nqn : nqt;
 			for(int e = 0; e < cnt; ++e) {
 				const int *ent = qu + 1 + e * QENT;
 				if(lane != ent[0]) continue;
