@@ -28,6 +28,10 @@ namespace {
 
 constexpr int GROUP = 16;             // active items scored together
 constexpr int THREADS = 256;
+#ifndef KMAHIP_STHREADS
+#define KMAHIP_STHREADS 256
+#endif
+constexpr int STHREADS = KMAHIP_STHREADS;   // threads of one scan workgroup: GROUP items x STHREADS / GROUP lanes
 constexpr int CHUNK = 136;            // k-mer start positions per pass
 constexpr int MW = 5;                 // hit-mask words per candidate (>= CHUNK / 32)
 constexpr int SW = 7;                 // staged u64 words per item and pass
@@ -337,14 +341,14 @@ __device__ __forceinline__ int compact_threads(bool flag, int tid, int32_t *wcnt
 	__syncthreads();
 	int before = 0, total = 0;
 #pragma unroll
-	for(int w = 0; w < THREADS / 64; ++w) { const int c = wcnt[w]; if(w < wave) before += c; total += c; }
+	for(int w = 0; w < STHREADS / 64; ++w) { const int c = wcnt[w]; if(w < wave) before += c; total += c; }
 	if(flag) list[before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) tid;
 	__syncthreads();
 	return total;
 }
 
 template <bool STATS, int MODE>
-__global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
+__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
 	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
 	// forward words: if every read of the group fits in SW-1 words they are staged ONCE and serve all passes;
@@ -360,8 +364,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
 	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
 	__shared__ int32_t s_gmax;
-	__shared__ int32_t s_wcnt[THREADS / 64];
-	__shared__ uint16_t s_list[THREADS];
+	__shared__ int32_t s_wcnt[STHREADS / 64];
+	__shared__ uint16_t s_list[STHREADS];
 	__shared__ uint32_t s_stats[3];   // [0] k-mer starts resolved (= probes of the reference), [1] list elements, [2] hash probes
 
 	const DevDB &db = A.db;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	const bool staged_once = !s_anylong;
 	const int gmax = s_gmax;
 	if(staged_once) {
-		for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
+		for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
 			const int g = idx / SW, w = idx - g * SW;
 			const int L = s_len[g];
 			w_lds[idx] = (w < ((L + 31) >> 5)) ? A.seq[s_soff[g] + w] : 0ull;
@@ -406,12 +410,12 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 	// ORs its position range into the bitmask of each template of the set, and every
 	// (item, template) then folds its own bitmask -- no serial walk over the positions.
 	{
-		for(int idx = tid; idx < TSLOTS * GROUP; idx += THREADS) {
+		for(int idx = tid; idx < TSLOTS * GROUP; idx += STHREADS) {
 			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN; t_last[idx] = 0; t_first[idx] = 0;
 #pragma unroll
 			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
 		}
-		for(int idx = tid; idx < VSLOTS * GROUP; idx += THREADS) {
+		for(int idx = tid; idx < VSLOTS * GROUP; idx += STHREADS) {
 			v_id[idx] = MISS;
 #pragma unroll
 			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
 			// stage the forward words of this pass (only workgroups holding a read too long to be staged once)
 			if(!staged_once) {
-				for(int idx = tid; idx < GROUP * SW; idx += THREADS) {
+				for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
 					const int g = idx / SW, w = idx - g * SW;
 					uint64_t v = 0;
 					if(g < ng) {
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			// item's v-table -- no list is read here, and a list that recurs along the read is expanded once.
 			uint32_t nprobe = 0, nres = 0;
 			{
-				constexpr int LPI = THREADS / GROUP;                 // lanes per item
+				constexpr int LPI = STHREADS / GROUP;                 // lanes per item
 				constexpr int SEG = (CHUNK + LPI - 1) / LPI;         // positions per lane
 				const int g = tid & (GROUP - 1), sl = tid / GROUP;
 				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
@@ -564,10 +568,11 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 			__syncthreads();
 			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
 			// flight together) and OR the list's position mask into the hit mask of each listed template
-			static_assert(VSLOTS * GROUP == THREADS && TSLOTS * GROUP == THREADS, "one thread per table slot");
-			const int n_lists = compact_threads(v_id[tid] != MISS, tid, s_wcnt, s_list);
+			static_assert(VSLOTS == TSLOTS && (VSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
+			for(int part = 0; part < VSLOTS * GROUP; part += STHREADS) {
+			const int n_lists = compact_threads(v_id[part + tid] != MISS, tid, s_wcnt, s_list);
 			if(tid < n_lists) {
-				const int idx = s_list[tid];
+				const int idx = part + s_list[tid];
 				const int g = idx & (GROUP - 1);
 				const uint32_t vi = v_id[idx];
 				v_id[idx] = MISS;
@@ -601,14 +606,16 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
 				}
 			}
+			}
 			__syncthreads();
 			// phase 2b: one thread per (item, template): fold the hit mask into the score
-			const int n_tmpl = compact_threads((tid & (GROUP - 1)) < ng && t_id[tid] != T_EMPTY, tid, s_wcnt, s_list);
+			for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
+			const int n_tmpl = compact_threads((tid & (GROUP - 1)) < ng && t_id[part + tid] != T_EMPTY, tid, s_wcnt, s_list);
 #ifdef KMAHIP_DIAG
 			if(!(A.ablate & 8))
 #endif
 			if(tid < n_tmpl) {
-				const int idx = s_list[tid];
+				const int idx = part + s_list[tid];
 				int score = t_score[idx], last = t_last[idx], first = t_first[idx];
 				// the 136-bit mask as three 64-bit words; a run of ones starts where a one has a zero below it and ends
 				// (exclusively) where a zero has a one below it -- MW * 32 > CHUNK, so every run ends inside the words
@@ -637,6 +644,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_se_kernel(const ScanArgs A) {
 				t_score[idx] = score; t_last[idx] = last; t_first[idx] = first;
 #pragma unroll
 				for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+			}
 			}
 			__syncthreads();
 		}
@@ -1198,8 +1206,8 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	if(ws->stats_on) hipLaunchKernelGGL((scan_prefilter_kernel<true>), dim3(pgrid), dim3(THREADS), 0, stream, A);
 	else hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3(pgrid), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
-	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
-	else hipLaunchKernelGGL((scan_se_kernel<false, 0>), dim3(grid), dim3(THREADS), 0, stream, A);
+	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_se_kernel<false, 0>), dim3(grid), dim3(STHREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
@@ -1246,7 +1254,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
 	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
-	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(THREADS), 0, stream, A);
+	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(STHREADS), 0, stream, A);
 	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	PairArgs P;
 	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
