@@ -6,9 +6,9 @@
 // What makes the reference's pile-up sequential is only the insertion columns: a read that inserts bases the matrix has
 // no column for creates columns whose gap count starts at the depth seen SO FAR (myBias, :1377-1397). Everything else is
 // a commutative saturating increment. So: reads are sorted into the reference's order per template (ConClave prepends to
-// a per-template list, conclave.c:164-165 -> reverse stream order inside every chunk of maxFrag records); one wavefront
-// owns one template and goes through its reads 64 at a time: maximal stretches of reads without an insertion run are
-// piled up by all lanes at once (atomics), a read with an insertion run is piled up alone, in order.
+// a per-template list, conclave.c:164-165 -> reverse stream order inside every chunk of maxFrag records); one workgroup
+// owns one template and goes through its reads 1024 at a time: maximal stretches of reads without an insertion run are
+// piled up by all threads at once (atomics), a read with an insertion run is piled up alone, in order.
 #include "kmahip_internal.h"
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -183,12 +183,13 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 	}
 }
 
-__global__ __launch_bounds__(256) void pileup_kernel(const PileArgs A, int64_t n_kept) {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const int64_t n_waves = ((int64_t) gridDim.x * blockDim.x) >> 6;
+constexpr int PILE_THREADS = 1024;     // one workgroup per template: reads are taken PILE_THREADS at a time
+
+__global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_kept) {
+	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int64_t D = A.db.DB_size;
-	for(int64_t t = 1 + wave; t < D; t += n_waves) {
+	for(int64_t t = 1 + blockIdx.x; t < D; t += gridDim.x) {
 		const int64_t s0 = A.seg_start[t];
 		if(s0 >= n_kept) continue;
 		int64_t s1 = s0;
@@ -199,26 +200,34 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileArgs A, int64_t n
 			s1 = lo;
 		}
 		Walk W{A, A.db.cat_off[t], A.db.tlen[t]};
-		for(int64_t b = s0; b < s1; b += 64) {
-			const bool valid = b + lane < s1;
-			const int64_t r = valid ? (int64_t) A.vals[b + lane] : 0;
+		for(int64_t b = s0; b < s1; b += PILE_THREADS) {
+			const bool valid = b + tid < s1;
+			const int64_t r = valid ? (int64_t) A.vals[b + tid] : 0;
 			bool ins = false;
 			if(valid) pile_read<false>(A, W, r, &ins);
-			const unsigned long long insmask = __ballot(valid && ins);
+			const unsigned long long m = __ballot(valid && ins);
+			if(lane == 0) s_ins[wave] = m;
+			__syncthreads();
+			// stretches of reads without an insertion run go side by side; a read with one goes alone, in order
 			int cur = 0;
-			while(cur < 64) {
-				const unsigned long long rest = insmask >> cur;
-				const int nxt = rest ? cur + __ffsll((long long) rest) - 1 : 64;
-				if(valid && lane >= cur && lane < nxt) pile_read<false>(A, W, r, nullptr);
+			while(cur < PILE_THREADS) {
+				int nxt = PILE_THREADS;
+				for(int w = cur >> 6; w < PILE_THREADS / 64; ++w) {
+					unsigned long long x = s_ins[w];
+					if(w == (cur >> 6)) x &= ~0ull << (cur & 63);
+					if(x) { nxt = (w << 6) + __ffsll((long long) x) - 1; break; }
+				}
+				if(valid && tid >= cur && tid < nxt) pile_read<false>(A, W, r, nullptr);
 				__threadfence();
-				__builtin_amdgcn_wave_barrier();
-				if(nxt < 64) {
-					if(lane == nxt) pile_read<true>(A, W, r, nullptr);
+				__syncthreads();
+				if(nxt < PILE_THREADS) {
+					if(tid == nxt) pile_read<true>(A, W, r, nullptr);
 					__threadfence();
-					__builtin_amdgcn_wave_barrier();
+					__syncthreads();
 				}
 				cur = nxt + 1;
 			}
+			__syncthreads();
 		}
 	}
 }
@@ -309,8 +318,8 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		HIP_TRY(hipStreamSynchronize(stream));
 	}
 	hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((kept + 255) / 256)), dim3(256), 0, stream, keys_out, (int64_t) kept, ws->p_seg, (int64_t) db->info.DB_size);
-	const unsigned waves = (unsigned) std::min<int64_t>(std::max<int64_t>(db->info.DB_size, 1), 256 * 32);
-	hipLaunchKernelGGL(pileup_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, A, (int64_t) kept);
+	const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(db->info.DB_size, 1), 256 * 8);
+	hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), 0, stream, A, (int64_t) kept);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(stream));
 	(void) hipFree(tmp);

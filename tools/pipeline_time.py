@@ -14,7 +14,8 @@ from kma_amd import binding, formats, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tmp = tempfile.mkdtemp()
-names, seqs = synth.make_gene_db(1000, 5, 600, 1500, 0.04, seed=12345)
+fam = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+names, seqs = synth.make_gene_db(fam, 5, 600, 1500, 0.04, seed=12345)
 prefix = os.path.join(tmp, "db")
 formats.write_index(prefix, names, seqs)
 reads, _, _, _ = synth.make_reads(seqs, n, seed=7)
