@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""One-off large validation on the GPU box: > maxFrag (1 M) reads incl. reads with indels against a 500-gene database, the
+compiled reference (oracle/_ref/kma -1t1 -t 1) and the library side by side; the two `.res` files and consensus FASTAs must be
+identical. Exercises the chunked read order of the pile-up (insertion columns) at scale.
+usage: python3 tools/validate_big.py [reads]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import golden_util  # noqa: E402
+from kma_amd import binding, formats, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_200_000
+KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+tmp = tempfile.mkdtemp()
+names, seqs = synth.make_gene_db(100, 5, 600, 1500, 0.04, seed=777)
+prefix = os.path.join(tmp, "db")
+formats.write_index(prefix, names, seqs)
+base, _, _, _ = synth.make_reads(seqs, n, seed=99)
+rng = np.random.default_rng(5)
+reads = [r for r in base]
+for i in rng.choice(n, size=n // 40, replace=False):          # 2.5 % of the reads get an indel or two
+    r = reads[i]
+    parts, j = [], 0
+    while j < len(r):
+        e = min(len(r), j + int(rng.integers(30, 120)))
+        parts.append(r[j:e])
+        u = rng.random()
+        if u < 0.45:
+            parts.append(rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8))
+        elif u < 0.9:
+            e = min(len(r), e + int(rng.integers(1, 4)))
+        j = e
+    reads[i] = np.concatenate(parts)
+fq = os.path.join(tmp, "reads.fq")
+synth.write_fastq(fq, reads, lens=None)
+t0 = time.perf_counter()
+subprocess.run([KMA, "-i", fq, "-o", os.path.join(tmp, "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+t_ref = time.perf_counter() - t0
+b = formats.pack_ragged(reads)
+db = binding.KmaHipDB(prefix)
+t0 = time.perf_counter()
+(rc_flag, flag, T_off, T), h = db.map_se(b)
+cc = db.conclave_se(b.length, T_off, h)
+rows = db.res_rows(cc["w_scores"])
+ok = np.zeros(int(db.info.DB_size), np.uint8)
+for r in rows:
+    ok[r.template_id] = r.significant
+traces = db.align_trace(b, h["rc"], cc["tmpl"], ok)
+asm = db.assemble(b, h["rc"], cc["tmpl"], traces, consensus=True)
+t_ours = time.perf_counter() - t0
+lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
+fsa = []
+for r in rows:
+    if r.significant:
+        t = r.template_id
+        line = db.res_line(names[t - 1], r, asm["cover"][t], asm["aln_len"][t], asm["depth"][t])
+        if line:
+            lines.append(line)
+            fsa.append((names[t - 1], asm["consensus"][t]))
+ref_res = open(os.path.join(tmp, "ref.res")).read()
+ref_fsa = open(os.path.join(tmp, "ref.fsa")).read()
+ins_reads = int(sum(1 for i in range(b.n) if traces[0][i, 7] > 0))
+print(f"reads {n}, reads aligned with an insertion {ins_reads}, .res rows {len(lines) - 1}")
+print(f"reference {t_ref:.1f} s (whole pipeline, 1 thread), library {t_ours:.2f} s (host-buffer calls incl. staging)")
+print("res identical:", "".join(lines) == ref_res, " consensus FASTA identical:", golden_util.fsa_text(fsa) == ref_fsa)
+if "".join(lines) != ref_res:
+    for a, c in zip("".join(lines).splitlines(), ref_res.splitlines()):
+        if a != c:
+            print("ours:", a)
+            print("ref :", c)
+            break
+    sys.exit(1)
