@@ -204,6 +204,8 @@ __device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bo
 // claim / find template t's slot in item g's candidate table; -1 when the table is full
 __device__ __forceinline__ int template_slot(uint32_t t, int g, uint32_t *t_id, int32_t *t_cnt) {
 	const uint32_t h = (t * 0x9E3779B1u) >> 28;
+	// rolled on purpose: unrolled, the 16 probes nest 16 exec masks (SGPR spills) and the body is inlined many times over
+#pragma unroll 1
 	for(int x = 0; x < TSLOTS; ++x) {
 		const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
 		const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 	__shared__ int32_t t_score[TSLOTS * GROUP];
 	__shared__ int32_t t_last[TSLOTS * GROUP];
 	__shared__ int32_t t_first[TSLOTS * GROUP];
-	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_wbase[GROUP], s_hits[GROUP];
+	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_hits[GROUP];
 	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
 	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
 	__shared__ int32_t s_gmax;
@@ -395,11 +397,15 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 	__syncthreads();
 	const bool staged_once = !s_anylong;
 	const int gmax = s_gmax;
+	// the words are staged in STRAND orientation (word w = strand bases 32w .. 32w+31: for the reverse strand the reverse
+	// complement of the forward words), so the passes below never reverse-complement a k-mer or a walk window
 	if(staged_once) {
 		for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
 			const int g = idx / SW, w = idx - g * SW;
 			const int L = s_len[g];
-			w_lds[idx] = (w < ((L + 31) >> 5)) ? A.seq[s_soff[g] + w] : 0ull;
+			uint64_t v = 0;
+			if(w < ((L + 31) >> 5)) v = (s_item[g] & 1) ? strand_win(A.seq + s_soff[g], L, 1, w << 5) : A.seq[s_soff[g] + w];
+			w_lds[idx] = v;
 		}
 	}
 
@@ -430,14 +436,9 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 					const int g = idx / SW, w = idx - g * SW;
 					uint64_t v = 0;
 					if(g < ng) {
-						const int L = s_len[g], npos = L - k + 1;
-						int lo = c0;
-						if(s_item[g] & 1) { const int jmax = min(c0 + CHUNK, npos) - 1; lo = L - k - jmax; }
-						if(lo < 0) lo = 0;
-						const int wb = lo >> 5;
-						if(w == 0) s_wbase[g] = wb;
-						const int words = (L + 31) >> 5;
-						if(wb + w < words) v = A.seq[s_soff[g] + wb + w];
+						const int L = s_len[g];
+						const int wb = c0 >> 5;
+						if(wb + w < ((L + 31) >> 5)) v = (s_item[g] & 1) ? strand_win(A.seq + s_soff[g], L, 1, (wb + w) << 5) : A.seq[s_soff[g] + wb + w];
 					}
 					w_lds[idx] = v;
 				}
@@ -458,20 +459,18 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
 				if(g < ng) {
 					const int L = s_len[g], npos = L - k + 1, strand = (int) (s_item[g] & 1), nN = s_nN[g];
-					const uint64_t *rw = A.seq + s_soff[g];
 					const int32_t *Nl = A.N + s_noff[g];
+					const uint64_t *wsrc = &w_lds[g * SW];
+					const int wb = staged_once ? 0 : (c0 >> 5);
 					int jj = j0, hc = 0;
 					bool pairs = false;      // after a miss or a walk cut short: probe two k-mer starts per step
 					while(jj < j1) {
 						int p = c0 + jj;
 						if(p >= npos) break;
-						const int q = strand ? (L - k - p) : p;
+						const int q = strand ? (L - k - p) : p;       // forward coordinate of the window (the N list is forward)
 						if(nN && window_has_N(Nl, nN, q, k)) { ++jj; continue; }
-						const uint64_t *wsrc = &w_lds[g * SW];
-						const int wb = staged_once ? 0 : s_wbase[g];
-						const int w = (q >> 5) - wb;
-						uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], q, k);
-						if(strand) km = revcomp_kmer(km, k);
+						const int w = (p >> 5) - wb;
+						const uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], p, k);
 						uint32_t gp;
 						bool second = false;
 						if(pairs && jj + 1 < j1 && p + 1 < npos) {
@@ -482,9 +481,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 						if(A.ablate & 2) gp = MISS; else
 #endif
 						if(second) {
-							const int q2 = strand ? q - 1 : q + 1, w2 = (q2 >> 5) - wb;
-							uint64_t km2 = kmer_from(wsrc[w2], wsrc[w2 + 1], q2, k);
-							if(strand) km2 = revcomp_kmer(km2, k);
+							const int w2 = ((p + 1) >> 5) - wb;
+							const uint64_t km2 = kmer_from(wsrc[w2], wsrc[w2 + 1], p + 1, k);
 							uint32_t gp2;
 							probe2(db, (uint32_t) km, (uint32_t) km2, gp, gp2);
 							if(gp == MISS) {
@@ -501,7 +499,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 #pragma unroll
 						for(int i = 0; i <= WALK; ++i) vv[i] = db.vs_id[gp + i];
 						const uint64_t tw = win2(db.cat, (int64_t) gp + k);
-						const uint64_t qw = strand_win(rw, L, strand, p + k);
+						const uint64_t qw = win2(wsrc, p + k - (wb << 5));
 						// walk: how many more k-mer starts of this segment continue the same template diagonal
 						int run = 0;
 						int room = min(j1 - jj - 1, npos - (p + 1));
@@ -542,6 +540,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 							// claim / find the list's slot in the item's v-table
 							int slot = -1;
 							const uint32_t h = (vi * 0x9E3779B1u) >> 28;
+#pragma unroll 1
 							for(int x = 0; x < VSLOTS; ++x) {
 								const int sidx = (int) ((h + x) & (VSLOTS - 1)) * GROUP + g;
 								const uint32_t old = atomicCAS(&v_id[sidx], MISS, vi);
@@ -601,9 +600,14 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 					return true;
 				};
 				bool ok = true;
+#pragma unroll 1
+				for(uint32_t i = 0; ok && i < cnt; ++i) {
+					uint32_t t = el[0];
 #pragma unroll
-				for(int i = 0; i < 7; ++i) if(ok && (uint32_t) i < cnt) ok = add_template(el[i]);
-				for(uint32_t i = 8; ok && i <= cnt; ++i) ok = add_template(value_at(db, vi, (int) i));
+					for(int e = 1; e < 7; ++e) if(i == (uint32_t) e) t = el[e];
+					if(i >= 7) t = value_at(db, vi, (int) i + 1);
+					ok = add_template(t);
+				}
 				}
 			}
 			}

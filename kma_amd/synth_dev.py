@@ -6,6 +6,8 @@ reads; packed into the kmahip_reads CSR layout (5 words + 1 pad per 150 bp read)
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -30,6 +32,9 @@ def make_packed_reads(seqs, n_reads, read_len=150, sub_rate=0.005, rc_frac=0.5, 
         m = min(chunk, n_reads - c0)
         gi = okt[torch.randint(0, len(ok), (m,), generator=g, device=device)]
         st = (torch.rand(m, generator=g, device=device, dtype=torch.float64) * (lens_t[gi] - read_len + 1).double()).long()
+        if os.environ.get("KMAHIP_SYNTH_SORTED"):          # locality experiment only: reads in template order
+            order = torch.argsort(offs[gi] + st)
+            gi, st = gi[order], st[order]
         idx = (offs[gi] + st)[:, None] + ar[None, :]
         r = cat[idx]
         if sub_rate > 0:

@@ -2,7 +2,7 @@
 """One-off large validation on the GPU box: > maxFrag (1 M) reads incl. reads with indels against a 500-gene database, the
 compiled reference (oracle/_ref/kma -1t1 -t 1) and the library side by side; the two `.res` files and consensus FASTAs must be
 identical. Exercises the chunked read order of the pile-up (insertion columns) at scale.
-usage: python3 tools/validate_big.py [reads]"""
+usage: python3 tools/validate_big.py [reads [families [variants [max_div]]]]   (C5-like: 2000000 5000 10 0.045)"""
 import os
 import subprocess
 import sys
@@ -20,7 +20,10 @@ from kma_amd import binding, formats, synth  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_200_000
 KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
 tmp = tempfile.mkdtemp()
-names, seqs = synth.make_gene_db(100, 5, 600, 1500, 0.04, seed=777)
+fam = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+var = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+div = float(sys.argv[4]) if len(sys.argv) > 4 else 0.04
+names, seqs = synth.make_gene_db(fam, var, 600, 1500, div, seed=777)
 prefix = os.path.join(tmp, "db")
 formats.write_index(prefix, names, seqs)
 base, _, _, _ = synth.make_reads(seqs, n, seed=99)
@@ -68,7 +71,7 @@ for r in rows:
 ref_res = open(os.path.join(tmp, "ref.res")).read()
 ref_fsa = open(os.path.join(tmp, "ref.fsa")).read()
 ins_reads = int(sum(1 for i in range(b.n) if traces[0][i, 7] > 0))
-print(f"reads {n}, reads aligned with an insertion {ins_reads}, .res rows {len(lines) - 1}")
+print(f"db {fam} families x {var} variants; reads {n}, reads aligned with an insertion {ins_reads}, .res rows {len(lines) - 1}")
 print(f"reference {t_ref:.1f} s (whole pipeline, 1 thread), library {t_ours:.2f} s (host-buffer calls incl. staging)")
 print("res identical:", "".join(lines) == ref_res, " consensus FASTA identical:", golden_util.fsa_text(fsa) == ref_fsa)
 if "".join(lines) != ref_res:
