@@ -123,12 +123,13 @@ __device__ __forceinline__ uint64_t revcomp64(uint64_t x) {
 	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
 }
 
-// 32 bases starting at base `pos` of a 2-bit word array (MSB first); reads word+1
+// 32 bases starting at base `pos` of a 2-bit word array (MSB first). Always reads word and word+1 (every array carries a
+// pad word), as one 16-byte access and without a branch: a conditional second load would wait for the first one.
 __device__ __forceinline__ uint64_t win2(const uint64_t *w, int pos) {
-	const int ip = (pos & 31) << 1, i = pos >> 5;
-	uint64_t x = w[i] << ip;
-	if(ip) x |= w[i + 1] >> (64 - ip);
-	return x;
+	const int ip = (pos & 31) << 1;
+	const uint64_t *p = w + (pos >> 5);
+	const uint64_t w0 = p[0], w1 = p[1];
+	return (w0 << ip) | ((w1 >> 1) >> (63 - ip));
 }
 
 // 32 bases of the ORIENTED read starting at oriented position i (N packed as A;

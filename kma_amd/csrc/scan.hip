@@ -127,18 +127,17 @@ __device__ __forceinline__ uint64_t revcomp_kmer(uint64_t x, int k) {
 
 __device__ __forceinline__ uint64_t kmer_from(uint64_t lo, uint64_t hi, int q, int k) {
 	const int ip = (q & 31) << 1;
-	uint64_t x = lo << ip;
-	if(ip) x |= hi >> (64 - ip);
+	const uint64_t x = (lo << ip) | ((hi >> 1) >> (63 - ip));      // branch-free: nothing of hi when ip == 0
 	return x >> (64 - 2 * k);
 }
 
-// 32 bases starting at base `pos` of a 2-bit word array (MSB first); reads word+1
+// 32 bases starting at base `pos` of a 2-bit word array (MSB first). Always reads word and word+1 (every array carries a
+// pad word), as ONE 16-byte access and without a branch: a conditional second load would wait for the first one.
 __device__ __forceinline__ uint64_t win2(const uint64_t *w, int64_t pos) {
 	const int ip = (int) (pos & 31) << 1;
-	const int64_t i = pos >> 5;
-	uint64_t x = w[i] << ip;
-	if(ip) x |= w[i + 1] >> (64 - ip);
-	return x;
+	const uint64_t *p = w + (pos >> 5);
+	const uint64_t w0 = p[0], w1 = p[1];
+	return (w0 << ip) | ((w1 >> 1) >> (63 - ip));
 }
 
 // 32 bases of the read in STRAND orientation starting at strand position i (strand 1 = reverse complement of
@@ -496,8 +495,9 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 						// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
 						constexpr int WALK = SEG - 1;
 						uint32_t vv[WALK + 1];
+						const uint32_t *vp = db.vs_id + gp;          // one address, immediate offsets: the loads merge
 #pragma unroll
-						for(int i = 0; i <= WALK; ++i) vv[i] = db.vs_id[gp + i];
+						for(int i = 0; i <= WALK; ++i) vv[i] = vp[i];
 						const uint64_t tw = win2(db.cat, (int64_t) gp + k);
 						const uint64_t qw = win2(wsrc, p + k - (wb << 5));
 						// walk: how many more k-mer starts of this segment continue the same template diagonal
