@@ -141,6 +141,14 @@ __device__ __forceinline__ uint64_t qwin(const QView &q, int i) {
 	return revcomp64(q.w[0] >> ((-s) << 1));
 }
 
+// the k-mers at oriented positions j and j + 1 from ONE 32-base window (k <= 16 here, so both fit): one 16-byte access
+// instead of up to four word loads and two reverse complements
+__device__ __forceinline__ void q_kmer2(const QView &q, int j, int k, uint32_t &km1, uint32_t &km2) {
+	const uint64_t w = qwin(q, j);
+	km1 = (uint32_t) (w >> (64 - 2 * k));
+	km2 = (uint32_t) ((w << 2) >> (64 - 2 * k));
+}
+
 // Query codes of a DP problem without a global load per cell: a cached 32-base window of the oriented
 // read, reloaded when the column index leaves it (columns are walked in descending order).
 struct QCursor {
@@ -857,7 +865,9 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 			// two k-mer starts per step, both gathers in flight together: the usual miss (the k-mer that starts on a
 			// mismatch) is followed by a hit one base later, and a wave waits for its slowest lane's step count
 			int v, v2;
-			tpos_get2(db, t, q_kmer(q, j, k), (j + 1 < end) ? q_kmer(q, j + 1, k) : 0u, j + 1 < end, v, v2);
+			uint32_t km1, km2;
+			q_kmer2(q, j, k, km1, km2);
+			tpos_get2(db, t, km1, km2, j + 1 < end, v, v2);
 			if(L.cnt) atomicAdd(&L.cnt[3], 1ull);
 			if(v == 0) {
 				if(j + 1 < end && L.cnt) atomicAdd(&L.cnt[3], 1ull);
@@ -980,7 +990,9 @@ __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 			const int segstop = end + k - 1;
 			while(j < end && !give_up) {
 				int v, v2;
-				tpos_get2(A.db, t, q_kmer(q, j, k), (j + 1 < end) ? q_kmer(q, j + 1, k) : 0u, j + 1 < end, v, v2);
+				uint32_t km1, km2;
+				q_kmer2(q, j, k, km1, km2);
+				tpos_get2(A.db, t, km1, km2, j + 1 < end, v, v2);
 				if(v == 0) {
 					if(v2 == 0) { j += 2; continue; }
 					++j; v = v2;
