@@ -1,6 +1,8 @@
-/* kmahip_res.c -- from stage 1's stream to the `.res` file on an MI355X, in plain C99 over the C-ABI of libkmahip.so.
+/* kmahip_res.c -- from the reads (or stage 1's stream) to the `.res` file on an MI355X, in plain C99 over the C-ABI of
+ * libkmahip.so.
  *
- *     kma -i reads.fq -o x -t_db db -1t1 -s1 | kmahip_res -t_db db  >  out.res
+ *     kmahip_res -t_db db -i reads.fq[.gz]  >  out.res                                  (stage 1 by kmahip_ingest_*)
+ *     kma -i reads.fq -o x -t_db db -1t1 -s1 | kmahip_res -t_db db  >  out.res          (stage 1 by the reference)
  *
  * Single-end `-1t1` with KMA's defaults: stage 2 + 3a (kmahip_map_se), ConClave (kmahip_conclave_se), the row statistics
  * (kmahip_res_rows), the per-read traceback aligner (kmahip_align_trace), pile-up + consensus (kmahip_assemble) and the row
@@ -18,10 +20,11 @@ static void *xrealloc(void *p, size_t n) { p = realloc(p, n ? n : 1); if(!p) { f
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) { fprintf(stderr, "kmahip_res: out of memory\n"); exit(1); } return p; }
 
 int main(int argc, char **argv) {
-	const char *prefix = NULL;
+	const char *prefix = NULL, *input = NULL;
 	for(int a = 1; a < argc; ++a) {
 		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
-		else { fprintf(stderr, "usage: kmahip_res -t_db <index prefix> < S1 stream > .res\n"); return 2; }
+		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
+		else { fprintf(stderr, "usage: kmahip_res -t_db <index prefix> [-i reads.fq[.gz]]  (without -i: S1 stream on stdin)  > .res\n"); return 2; }
 	}
 	if(!prefix) { fprintf(stderr, "kmahip_res: -t_db is required\n"); return 2; }
 
@@ -30,7 +33,17 @@ int main(int argc, char **argv) {
 	int max_len = 0;
 	uint64_t *seq = NULL; int64_t *seq_off = NULL, *N_off = NULL; int32_t *len = NULL, *Npos = NULL;
 	int32_t head[4];
-	while(fread(head, sizeof(int32_t), 4, stdin) == 4) {
+	kmahip_ingest *ing = NULL;
+	if(input) {
+		/* stage 1 inside the library: parse, trim (KMA's defaults) and pack the whole file as one batch; the arrays stay
+		 * owned by the reader, which is kept open until the end */
+		kmahip_read_batch b;
+		if(kmahip_ingest_open(input, NULL, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b)) die("ingest");
+		n = b.reads.n_reads; words = b.reads.seq_words; nN = b.reads.N_total; max_len = b.reads.max_len;
+		seq = (uint64_t *) b.reads.seq; seq_off = (int64_t *) b.reads.seq_off; N_off = (int64_t *) b.reads.N_off;
+		len = (int32_t *) b.reads.len; Npos = (int32_t *) b.reads.N;
+	}
+	while(!input && fread(head, sizeof(int32_t), 4, stdin) == 4) {
 		const int seqlen = head[0], complen = head[1], cnt = head[2], hl = abs(head[3]);
 		if(head[3] < 0) { fprintf(stderr, "kmahip_res: paired records: not handled by this example\n"); return 1; }
 		if(n + 2 > cap) { cap = cap ? 2 * cap : 1 << 16; seq_off = xrealloc(seq_off, (size_t) cap * 8); N_off = xrealloc(N_off, (size_t) cap * 8); len = xrealloc(len, (size_t) cap * 4); }
@@ -45,8 +58,10 @@ int main(int argc, char **argv) {
 		if(seqlen > max_len) max_len = seqlen;
 		++n;
 	}
-	if(!seq_off) { seq_off = xrealloc(NULL, 16); N_off = xrealloc(NULL, 16); }
-	seq_off[n] = words; N_off[n] = nN;
+	if(!input) {
+		if(!seq_off) { seq_off = xrealloc(NULL, 16); N_off = xrealloc(NULL, 16); }
+		seq_off[n] = words; N_off[n] = nN;
+	}
 
 	kmahip_db *db; kmahip_ws *ws; kmahip_params par; kmahip_db_info info;
 	if(kmahip_init(0) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
@@ -122,5 +137,6 @@ int main(int argc, char **argv) {
 	fflush(stdout);
 	kmahip_ws_destroy(ws);
 	kmahip_db_close(db);
+	kmahip_ingest_close(ing);
 	return 0;
 }

@@ -308,6 +308,45 @@ int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 int kmahip_res_line(const char *template_name, const kmahip_res_row *row, int64_t cover, int64_t aln_len, int64_t depth_sum,
                     double ID_t, double Depth_t, char *line, int64_t cap);
 
+/* ---- stage 1: FASTQ / FASTA ingest into packed read batches -------------------------------------------
+ * Host code (zlib for .gz, plain files read as they are): the record parser of FileBuffgetFq / FileBuffgetFsa
+ * (seqparse.c:241-403, 66-159) with the to2Bit table of kma.c:1440-1480 (IUPAC codes fold onto ACGT, N / X = 4), the
+ * phred-scale guess of getPhredFileBuff (seqparse.c:551-589), the quality trimming of phredStat (runinput.c:127-313;
+ * fsastat :315-368 for FASTA), the length gate of run_input / run_input_PE (runinput.c:370-606) and the 2-bit packing of
+ * compDNA (compdna.c:99-127). What it yields is what the reference's stage 1 writes into the S1 stream (printFsa /
+ * printFsa_pair, runinput.c:765-830), in the same order. */
+typedef struct kmahip_trim {
+	int32_t min_phred;    /* -mp  (20): 5' / 3' end bases below it are trimmed */
+	int32_t min_q;        /* -eq  (0): minimum average quality, bi-directional trimming towards it */
+	int32_t hardmask_q;   /* -mi  (0): bases below it become N */
+	int32_t min_len;      /* -ml  (16) */
+	int32_t max_len;      /* -xl  (2147483647) */
+} kmahip_trim;
+void kmahip_trim_default(kmahip_trim *t);
+
+typedef struct kmahip_ingest kmahip_ingest;
+
+/* One batch, owned by the reader and valid until the next call on it. `reads` holds HOST pointers in the layout every
+ * kmahip_*_se / _pe call takes (each read followed by one pad word). pair[i]: 0 = single record, 1 = first mate of a
+ * pair record (its second mate is read i + 1, pair 2). */
+typedef struct kmahip_read_batch {
+	kmahip_reads reads;
+	const char *names;        /* header lines without '@' / '>', chomped, each NUL-terminated */
+	const int64_t *name_off;  /* n_reads + 1 */
+	const uint8_t *pair;      /* n_reads */
+	int64_t records;          /* S1 records in the batch (a pair counts once) */
+} kmahip_read_batch;
+
+/* path2 == NULL: single end (run_input); otherwise the two mate files are read in lockstep (run_input_PE): both mates
+ * long enough -> a pair record, one of them -> a single record, none -> dropped. */
+int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *trim, kmahip_ingest **out);
+/* up to max_records further S1 records; batch->reads.n_reads == 0 at the end of the input */
+int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch);
+/* 33 or 64 (0: undeterminable, treated like the reference does); records read / kept so far */
+int kmahip_ingest_phred_scale(const kmahip_ingest *in);
+void kmahip_ingest_counts(const kmahip_ingest *in, int64_t *records_read, int64_t *records_kept);
+void kmahip_ingest_close(kmahip_ingest *in);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

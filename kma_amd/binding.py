@@ -70,6 +70,15 @@ class Assembly(C.Structure):
                 ("consensus", C.c_void_p), ("consensus_off", C.c_void_p), ("consensus_cap", C.c_int64), ("consensus_used", C.c_int64)]
 
 
+class Trim(C.Structure):
+    _fields_ = [("min_phred", C.c_int32), ("min_q", C.c_int32), ("hardmask_q", C.c_int32), ("min_len", C.c_int32),
+                ("max_len", C.c_int32)]
+
+
+class ReadBatchC(C.Structure):
+    _fields_ = [("reads", Reads), ("names", C.c_void_p), ("name_off", C.c_void_p), ("pair", C.c_void_p), ("records", C.c_int64)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
                 ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
@@ -139,6 +148,15 @@ def lib():
         L.kmahip_res_line.argtypes = [C.c_char_p, C.POINTER(ResRow), C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       C.c_char_p, C.c_int64]
         L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
+        L.kmahip_trim_default.restype = None
+        L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
+        L.kmahip_ingest_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ReadBatchC)]
+        L.kmahip_ingest_phred_scale.argtypes = [C.c_void_p]
+        L.kmahip_ingest_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.kmahip_ingest_counts.restype = None
+        L.kmahip_ingest_close.argtypes = [C.c_void_p]
+        L.kmahip_ingest_close.restype = None
         _lib = L
     return _lib
 
@@ -159,6 +177,56 @@ def cigar_from_runs(runs, clip_start=0, clip_end=0):
     if clip_end:
         out.append(f"{clip_end}S")
     return "".join(out)
+
+
+class Ingest:
+    """Stage 1 on the host (kmahip_ingest_*): FASTQ / FASTA(.gz) -> trimmed, packed formats.ReadBatch batches, the
+    records the reference's run_input / run_input_PE write into the S1 stream, in the same order."""
+
+    def __init__(self, path1, path2=None, min_phred=20, min_q=0, hardmask_q=0, min_len=16, max_len=2**31 - 1):
+        L = lib()
+        t = Trim(min_phred, min_q, hardmask_q, min_len, max_len)
+        self._h = C.c_void_p()
+        _check(L.kmahip_ingest_open(os.fsencode(path1), os.fsencode(path2) if path2 else None, C.byref(t), C.byref(self._h)))
+
+    @property
+    def phred_scale(self):
+        return lib().kmahip_ingest_phred_scale(self._h)
+
+    def counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        lib().kmahip_ingest_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def next(self, max_records=1 << 20):
+        """-> (ReadBatch, names list[bytes], pair u8[n]) or None at the end of the input (copies out of the reader's buffers)"""
+        from . import formats
+        b = ReadBatchC()
+        _check(lib().kmahip_ingest_next(self._h, max_records, C.byref(b)))
+        n = b.reads.n_reads
+        if n == 0:
+            return None
+
+        def arr(ptr, dt, m):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(m,)).copy() if m else np.zeros(0, dt)
+        batch = formats.ReadBatch(seq=arr(b.reads.seq, C.c_uint64, b.reads.seq_words), seq_off=arr(b.reads.seq_off, C.c_int64, n + 1),
+                                  length=arr(b.reads.len, C.c_int32, n), N=arr(b.reads.N, C.c_int32, max(1, b.reads.N_total)),
+                                  N_off=arr(b.reads.N_off, C.c_int64, n + 1))
+        noff = arr(b.name_off, C.c_int64, n + 1)
+        raw = C.string_at(b.names, int(noff[-1]))
+        names = [raw[noff[i]:noff[i + 1] - 1] for i in range(n)]
+        return batch, names, arr(b.pair, C.c_uint8, n)
+
+    def close(self):
+        if self._h:
+            lib().kmahip_ingest_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def default_params() -> Params:

@@ -1,0 +1,100 @@
+"""Stage-1 ingest (kmahip_ingest_*, host code in the C-ABI library) against the S1 streams the compiled reference wrote for
+the same inputs (tests/golden/ingest, made by tests/golden/make_golden_ingest.py) and against the S1 taps of the mapping
+fixtures. No GPU involved: FASTQ / FASTA parsing, phred-scale guess, quality trimming, length gate, 2-bit packing."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from kma_amd import binding, formats
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ING = os.path.join(GOLD, "ingest")
+SETTINGS = {
+    "default": {},
+    "mp25": dict(min_phred=25),
+    "eq15": dict(min_q=15),
+    "eq25ml40": dict(min_q=25, min_len=40),
+    "mi12": dict(hardmask_q=12),
+    "ml60xl130": dict(min_len=60, max_len=130),
+}
+CASES = {
+    "p33": ("p33.fq", None, 33),
+    "dos": ("dos.fq", None, 33),
+    "p64": ("p64.fq", None, 64),
+    "wrap": ("wrap.fa", None, None),
+    "pe": ("m1.fq", "m2.fq", 33),
+    "p33gz": ("p33gz.fq.gz", None, 33),
+}
+
+
+def _compare(batch, names, pair, s1):
+    assert batch.n == len(s1)
+    for i, r in enumerate(s1):
+        L = int(batch.length[i])
+        assert L == r["seqlen"], (i, L, r["seqlen"])
+        w = batch.seq[batch.seq_off[i]:batch.seq_off[i] + ((L + 31) >> 5)]
+        assert np.array_equal(w, r["seq"]), i
+        assert batch.seq[batch.seq_off[i] + ((L + 31) >> 5)] == 0                  # the pad word
+        assert np.array_equal(batch.N[batch.N_off[i]:batch.N_off[i + 1]], r["N"]), i
+        assert names[i] + b"\0" == r["hdr"], (i, names[i], r["hdr"])
+        assert (pair[i] == 1) == r["pair"], i
+        if pair[i] == 1:
+            assert pair[i + 1] == 2
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("setting", sorted(SETTINGS))
+def test_ingest_matches_reference_s1(case, setting):
+    f1, f2, phred = CASES[case]
+    s1 = formats.parse_s1(gzip.open(os.path.join(ING, f"{case}.{setting}.s1.gz")).read())
+    with binding.Ingest(os.path.join(ING, f1), os.path.join(ING, f2) if f2 else None, **SETTINGS[setting]) as ing:
+        if phred is not None:
+            assert ing.phred_scale == phred
+        got = ing.next(1 << 30)
+        assert got is not None
+        _compare(*got, s1)
+        assert ing.next(10) is None
+        read, kept = ing.counts()
+        assert kept == sum(1 for i in range(got[0].n) if got[2][i] != 2)
+
+
+def test_ingest_batches_are_a_partition():
+    """small batches concatenate to the one-shot result (records never split: a pair stays in one batch)"""
+    p1, p2 = os.path.join(ING, "m1.fq"), os.path.join(ING, "m2.fq")
+    with binding.Ingest(p1, p2) as a:
+        whole = a.next(1 << 30)
+    parts = []
+    with binding.Ingest(p1, p2) as b:
+        while True:
+            g = b.next(37)
+            if g is None:
+                break
+            assert g[2][-1] != 1
+            parts.append(g)
+    assert sum(p[0].n for p in parts) == whole[0].n
+    assert np.array_equal(np.concatenate([p[0].length for p in parts]), whole[0].length)
+    assert [n for p in parts for n in p[1]] == whole[1]
+    o = 0
+    for p in parts:
+        for i in range(p[0].n):
+            L = int(p[0].length[i])
+            a0, b0 = p[0].seq_off[i], whole[0].seq_off[o]
+            assert np.array_equal(p[0].seq[a0:a0 + ((L + 31) >> 5)], whole[0].seq[b0:b0 + ((L + 31) >> 5)])
+            o += 1
+
+
+@pytest.mark.parametrize("name,files", [("se", ("reads.fq.gz", None)), ("long", ("reads.fq.gz", None)), ("pe", ("r1.fq.gz", "r2.fq.gz"))])
+def test_ingest_matches_mapping_fixture_s1(name, files):
+    src = os.path.join(GOLD, name)
+    s1 = formats.parse_s1(gzip.open(os.path.join(src, "s1.bin.gz")).read())
+    with binding.Ingest(os.path.join(src, files[0]), os.path.join(src, files[1]) if files[1] else None) as ing:
+        _compare(*ing.next(1 << 30), s1)
+
+
+def test_ingest_errors():
+    with pytest.raises(binding.KmaHipError):
+        binding.Ingest(os.path.join(ING, "does_not_exist.fq"))
+    with pytest.raises(binding.KmaHipError):
+        binding.Ingest(os.path.join(ING, "p33.fq"), os.path.join(ING, "wrap.fa"))       # different formats

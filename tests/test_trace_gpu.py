@@ -230,3 +230,6 @@ def test_c_host_program_reproduces_reference_res_file(golden_se, golden_long):
         s1 = gzip.open(os.path.join(g["dir"], "s1.bin.gz"), "rb").read()
         out = subprocess.run([exe, "-t_db", g["prefix"]], input=s1, stdout=subprocess.PIPE, check=True).stdout
         assert out == open(os.path.join(g["dir"], "out.res"), "rb").read(), g["dir"]
+        # the same from the FASTQ file itself: stage 1 by kmahip_ingest_* instead of the reference's S1 stream
+        out = subprocess.run([exe, "-t_db", g["prefix"], "-i", os.path.join(g["dir"], "reads.fq.gz")], stdout=subprocess.PIPE, check=True).stdout
+        assert out == open(os.path.join(g["dir"], "out.res"), "rb").read(), g["dir"]

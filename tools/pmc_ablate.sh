@@ -16,7 +16,7 @@ import csv, glob, collections, os
 for d in sorted(glob.glob('gpurun_out/pa/v*'), key=lambda x: int(x.rsplit('v',1)[1])):
     f = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)
     if not f: continue
-    for kern in ('scan_prefilter_kernel<false', 'scan_se_kernel<false', 'align_tasks_kernel<false'):
+    for kern in ('scan_prefilter_kernel<false', 'scan_se_kernel<false', 'seed_tasks_kernel', 'align_tasks_kernel<false'):
         tot = collections.defaultdict(float); disp = set()
         for row in csv.DictReader(open(f[0])):
             if kern in row['Kernel_Name']:
