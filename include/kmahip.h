@@ -347,6 +347,16 @@ int kmahip_ingest_phred_scale(const kmahip_ingest *in);
 void kmahip_ingest_counts(const kmahip_ingest *in, int64_t *records_read, int64_t *records_kept);
 void kmahip_ingest_close(kmahip_ingest *in);
 
+/* `.frag.gz` (updateFrags, assembly.c:49-83): one row per read that passed the stage-3c filter -- the read as aligned, the
+ * number of equally good templates, score, start, end, template name (from <prefix>.name), read header -- in the order a
+ * single-threaded assemble_KMA writes them: templates ascending, inside a template the pile-up order (see kmahip_assemble).
+ * HOST buffers: the reads, kmahip_hits.rc, kmahip_conclave.tmpl, the per-read tie count (kmahip_hits.n_hits), the stats
+ * array of kmahip_align_trace and the read headers (kmahip_read_batch.names / name_off). A path ending in ".gz" is
+ * gzip-compressed (level 1 as filebuff.c:189), anything else plain text. */
+int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                      const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, const char *read_names,
+                      const int64_t *read_name_off, int64_t *rows);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

@@ -148,6 +148,8 @@ def lib():
         L.kmahip_res_line.argtypes = [C.c_char_p, C.POINTER(ResRow), C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       C.c_char_p, C.c_int64]
         L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.kmahip_frag_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
         L.kmahip_trim_default.restype = None
         L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
@@ -509,6 +511,26 @@ class KmaHipDB:
             raw = cbuf.tobytes()
             o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
         return o
+
+    def frag_write(self, path, batch, rc, tmpl, n_hits, stats, read_names, max_frag=0):
+        """`.frag.gz` of the traced reads (kmahip_frag_write); read_names = list[bytes] (Ingest.next) -> number of rows"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        fl = np.ascontiguousarray(rc if n else np.zeros(1, np.int32), np.int32)
+        tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
+        nh = np.ascontiguousarray(n_hits if n else np.zeros(1, np.int32), np.int32)
+        st = np.ascontiguousarray(stats if n else np.zeros((1, 10), np.int32), np.int32)
+        blob = b"".join(nm + b"\0" for nm in read_names) + b"\0"
+        noff = np.zeros(n + 1, np.int64)
+        if n:
+            noff[1:] = np.cumsum([len(nm) + 1 for nm in read_names])
+        rows = C.c_int64()
+        _check(lib().kmahip_frag_write(os.fsencode(path), self.h, C.byref(r), _p(fl), _p(tm), _p(nh), _p(st), int(max_frag), blob,
+                                       _p(noff), C.byref(rows)))
+        return rows.value
 
     @staticmethod
     def res_line(name, row, cover, aln_len, depth, ID_t=1.0, Depth_t=0.0):

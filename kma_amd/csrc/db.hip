@@ -98,6 +98,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(tail[0] != mlen) { kmahip_set_error("kmersize %u != mlen %u not supported", tail[0], mlen); return KMAHIP_EFORMAT; }
 
 	kmahip_db *db = new kmahip_db();
+	db->prefix = base;
 	memset(&db->info, 0, sizeof db->info);
 	db->device = g_device;
 	db->info.DB_size = DB_size; db->info.kmersize = tail[0]; db->info.n_kmers = n; db->info.n_values = v_index;

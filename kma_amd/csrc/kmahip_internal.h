@@ -53,6 +53,8 @@ struct kmahip_db {
 	// host copies needed by host-side stages
 	std::vector<int32_t> h_tlen;
 	std::vector<int64_t> h_cat_off;
+	std::string prefix;           // index prefix (the `.name` file is read on demand by the text writers)
+	std::vector<std::string> h_names;
 };
 
 // per-call scratch, grown on demand

@@ -91,6 +91,18 @@ def _res_case(g, name):
             if line:
                 lines.append(line)
                 fsa.append((names[t - 1], asm["consensus"][t]))
+        # `.frag.gz`: every row (read as aligned, ties, score, start, end, template, header) in the reference's order
+        if os.path.exists(os.path.join(golden_util.GOLD, name, "out.frag.gz")):
+            import gzip
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                hdrs = [r["hdr"].rstrip(b"\0") for r in g["s1"]]
+                for fn in ("x.frag.gz", "x.frag"):
+                    n_rows = db.frag_write(os.path.join(tmp, fn), b, h["rc"], cc["tmpl"], h["n_hits"], traces[0], hdrs)
+                    opener = gzip.open if fn.endswith(".gz") else open
+                    got = opener(os.path.join(tmp, fn), "rb").read()
+                    assert got == gzip.open(os.path.join(golden_util.GOLD, name, "out.frag.gz"), "rb").read()
+                    assert n_rows == got.count(b"\n") > 0
     finally:
         db.close()
     with open(os.path.join(golden_util.GOLD, name, "out.res")) as f:
