@@ -51,8 +51,9 @@ struct AlignArgs {
 	int32_t *t_score, *t_alen, *t_start, *t_end, *t_tmpl;
 	double *t_norm;
 	const int32_t *t_rec;    // record owning each task (expanded from T_off by task_map_kernel)
-	int32_t *seed_n;         // per task, written by seed_tasks_kernel: number of MEMs found (0..SEEDS), -1: seed in the main kernel
-	uint2 *seed_mem;         // SEEDS per task: x = tS (1-based), y = qS | (length << 16)
+	int32_t *seed_n;         // per seed slot, written by seed_tasks_kernel: number of MEMs found (0..SEEDS), -1: seed in the main kernel
+	uint2 *seed_mem;         // SEEDS per slot: x = tS (1-based), y = qS | (length << 16)
+	int seed_slots;          // seed slots per task: 1 (single end) or 2 (paired records: both mates of a couple)
 	// scratch
 	int32_t *s32;
 	uint64_t *s64;
@@ -200,6 +201,8 @@ __device__ __forceinline__ void tpos_get2(const DevDB &db, int t, uint32_t km1, 
 struct Lane {
 	int32_t *s32;
 	uint64_t *s64;
+	int32_t *r32;              // this lane's two int DP rows (2 * ncols) ...
+	uint64_t *r64;             // ... and its two counter rows
 	int64_t lanes;
 	int cap1;    // mem_cap + 1
 	int ncols;
@@ -216,16 +219,21 @@ struct Lane {
 
 // MEM arrays: 0 tS, 1 tE, 2 qS, 3 qE, 4 weight, 5 score, 6 next
 #define MEMA(L, a, m) (L).s32[((int64_t) ((a) * (L).cap1 + (m))) * (L).lanes]
-#define ROWD(L, n) (L).s32[((int64_t) (7 * (L).cap1 + (n))) * (L).lanes]
-#define ROWP(L, n) (L).s32[((int64_t) (7 * (L).cap1 + (L).ncols + (n))) * (L).lanes]
-#define ROWTD(L, n) (L).s64[((int64_t) (n)) * (L).lanes]
-#define ROWTP(L, n) (L).s64[((int64_t) ((L).ncols + (n))) * (L).lanes]
+// DP rows of the problems too wide for the cooperative queues: contiguous per lane (a lane that gets one walks it alone,
+// so neighbouring columns should share cache lines; strided by the lane count every cell was its own line and a single
+// 150 x 130 tail held its kernel for 5 ms)
+#define ROWD(L, n) (L).r32[(n)]
+#define ROWP(L, n) (L).r32[(L).ncols + (n)]
+#define ROWTD(L, n) (L).r64[(n)]
+#define ROWTP(L, n) (L).r64[(L).ncols + (n)]
 
 constexpr int QCAP = 8;             // deferred wide problems (17..63 columns) per wave and task round
 constexpr int QCAPN = 20;           // deferred narrow problems (9..16 columns)
 constexpr int QCAPT = 32;           // deferred tiny problems (2..8 columns): eight side by side per cooperative call
 constexpr int QENT = 12;            // ints per queue entry
-constexpr int QINTS = 3 + (QCAP + QCAPN + QCAPT) * QENT;   // ints of one wave's three queues
+constexpr int QCAPX = 4;            // deferred extra-wide problems (64..255 columns): one per cooperative call, XC columns per lane
+constexpr int XC = 4;
+constexpr int QINTS = 4 + (QCAP + QCAPN + QCAPT + QCAPX) * QENT;   // ints of one wave's four queues
 constexpr int TBUF = 1024;          // staged template bases per cooperative problem
 constexpr int WCOLS = 64;           // LDS row slots for "wide" problems: 17..63 query columns
 constexpr int WSLOTS = 2;           // slots per wave
@@ -494,6 +502,19 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 		const int ql = q_e - q_s;
 		if(ql == 0 || tspan == 0) return nw_degenerate(tspan, ql, L.U, L.W1);      // nw.c:662-684
 		if(ql == 1 && tspan < 998) return nw_col1(L, ts, t_len, q, k, t_s, t_e, q_s);
+		if(L.queue && ql >= WCOLS && ql < 64 * XC && tspan <= TBUF && tspan + ql < 1000) {
+			// long unaligned ends (a read that matches a template only in part): a lane walking those cells alone takes
+			// milliseconds and holds its whole wave
+			int *qu = L.queue + (3 + (QCAP + QCAPN + QCAPT) * QENT);
+			const int slot = atomicAdd(&qu[0], 1);
+			if(slot < QCAPX) {
+				int *e = qu + 1 + slot * QENT;
+				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
+				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = (k < 0) ? 1 : 0;
+				Aln z = {0, 0, 0, 0, 0, 0};
+				return z;
+			}
+		}
 		if(L.queue && ql < WCOLS && tspan + ql < 1000) {
 			// The other small problems are handed to the whole wave (nw_coop, run after every lane has finished its
 			// own work): a lane walking a DP alone keeps 63 lanes idle at ~10^2 cycles per cell. Results are only
@@ -502,6 +523,9 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			const bool narrow = !tiny && ql <= 16 && tspan < TBUF / 4;
 			int *qu = tiny ? L.queue + (2 + (QCAP + QCAPN) * QENT) : narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
 			const int slot = atomicAdd(&qu[0], 1);
+#ifdef KMAHIP_DIAG
+			if(g_diag_hist) atomicAdd(&g_diag_hist[200 + (tiny ? 0 : narrow ? 1 : 2) + (slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP) ? 0 : 4)], 1ull);
+#endif
 			if(slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP)) {
 				int *e = qu + 1 + slot * QENT;
 				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
@@ -510,6 +534,10 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 				return z;
 			}
 		}
+#ifdef KMAHIP_DIAG
+		if(g_diag_hist) { atomicAdd(&g_diag_hist[208], 1ull); atomicAdd(&g_diag_hist[209], (unsigned long long) max(0, tspan) * (q_e - q_s)); if(q_e - q_s >= WCOLS) atomicAdd(&g_diag_hist[210], 1ull); }
+		if(L.ablate & 128) return nw_degenerate(tspan, 0, L.U, L.W1);     // ablation: nothing that misses the queues
+#endif
 		if(q_e - q_s < WCOLS && tspan + (q_e - q_s) < 1000) {
 			// queue full (or deferral off): the row goes to one of the wave's LDS slots; the lanes of this wave that
 			// are here together take turns, WSLOTS at a time (they run in lock step anyway)
@@ -527,7 +555,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			return res;
 		}
 		GRows gr;
-		gr.d = &ROWD(L, 0); gr.p = &ROWP(L, 0); gr.td = &ROWTD(L, 0); gr.tp = &ROWTP(L, 0); gr.stride = L.lanes;
+		gr.d = &ROWD(L, 0); gr.p = &ROWP(L, 0); gr.td = &ROWTD(L, 0); gr.tp = &ROWTP(L, 0); gr.stride = 1;
 		return nw_full(gr, L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
 	}
 	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
@@ -630,6 +658,118 @@ __device__ void nw_coop(const Lane &L, const DevDB &db, const AlignArgs &A, int 
 		if(k == -2 && mx >= score) { score = mx; st = stn; }
 	}
 	if(live && n == 0) {
+		const Aln r = aln_from<10>(score, (uint64_t) st);
+		e[2] = r.score; e[3] = r.len; e[4] = r.match; e[5] = r.tGaps; e[6] = r.qGaps;
+	}
+}
+
+// The same for ONE problem of 64 .. 64 * XC - 1 columns: lane n owns XC neighbouring columns (aligned to the right end, so
+// only lane 0 can own fewer) and takes them right to left inside a step; between lanes the sweep is the anti-diagonal one
+// of nw_coop -- the right neighbour (m, c+1) and the diagonal (m+1, c+1) of a lane's last column come from the first
+// column of the lane to its right, one and two steps old.
+__device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, int *qu, int ent, uint8_t *tbuf) {
+	const int lane = threadIdx.x & 63;
+	int *e = qu + 1 + ent * QENT;
+	const int k = e[2], t_s = e[3], t_e = e[4], q_s = e[5], q_e = e[6], at = e[7];
+	const int64_t rd = ((int64_t) e[9] << 32) | (uint32_t) e[8];
+	const int tlen_total = db.tlen[at];
+	const uint64_t *ts = db.tseq + db.tseq_off[at];
+	int t_len = t_e - t_s;
+	if(t_len < 0) t_len += tlen_total;
+	const int q_len = q_e - q_s;
+	const int U = L.U, W1 = L.W1;
+	const uint32_t MA = 1u, TG = 1u << 10, QG = 1u << 20;
+	const int low = (t_len + q_len) * (L.MM + U + W1);
+	if(L.cnt && lane == 0) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
+	for(int i = lane; i < t_len; i += 64) {
+		int pos = t_s + i;
+		if(pos >= tlen_total) pos -= tlen_total;
+		tbuf[i] = (uint8_t) tn(ts, pos);
+	}
+	QView q;
+	q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = e[10];
+	q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+	const int nl = (q_len + XC - 1) / XC;              // lanes in use
+	const int c0 = q_len - (nl - lane) * XC;           // this lane's first column (negative: lane 0 owns fewer than XC)
+	const bool act = lane < nl;
+	int qc[XC], lD[XC], lP[XC], lQ[XC];
+	uint32_t lTD[XC], lTP[XC], lTQ[XC];
+#pragma unroll
+	for(int j = 0; j < XC; ++j) {
+		const int c = c0 + j;
+		qc[j] = (act && c >= 0) ? qn(q, q_s + c) : 0;
+		// boundary row m = t_len
+		if(k == 2) { lD[j] = 0; lTD[j] = 0; } else { lD[j] = W1 + (q_len - 1 - c) * U; lTD[j] = TG * (uint32_t) max(0, q_len - c); }
+		lP[j] = low; lQ[j] = low; lTP[j] = 0; lTQ[j] = 0;
+	}
+	int bD0 = 0;                                       // the row before `l` of this lane's first column, for the lane to the left
+	uint32_t bTD0 = 0;
+	int best = low;
+	uint32_t bestTD = 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const int steps = t_len + nl - 1;
+	for(int d = 0; d < steps; ++d) {
+		int rD = __shfl_down(lD[0], 1), rQ = __shfl_down(lQ[0], 1), dD = __shfl_down(bD0, 1);
+		uint32_t rTD = __shfl_down(lTD[0], 1), rTQ = __shfl_down(lTQ[0], 1), dTD = __shfl_down(bTD0, 1);
+		const int i = d - (nl - 1 - lane);
+		if(act && i >= 0 && i < t_len) {
+			const int m = t_len - 1 - i;
+			if(lane == nl - 1) {
+				// boundary column q_len (nw.c:703-750, :757)
+				rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+				rTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - m);
+				rTQ = 0; rQ = low;
+				if(m + 1 == t_len) { dD = 0; dTD = 0; }
+				else { dD = (0 < k) ? 0 : (W1 + (t_len - 2 - m) * U); dTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - 1 - m); }
+			}
+			const int *drow = L.d + 5 * (int) tbuf[m];
+#pragma unroll
+			for(int j = XC - 1; j >= 0; --j) {
+				if(c0 + j < 0) continue;
+				int Q = rD + W1, P = lD[j] + W1, D, mv;
+				bool ob = false;
+				if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+				int x = rQ + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
+				x = lP[j] + U;
+				if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
+				x = dD + drow[qc[j]];
+				if(D <= x) { D = x; mv = 1; }
+				const uint32_t TQ = TG + (ob ? rTD : rTQ);
+				const uint32_t TP = QG + (ob ? lTD[j] : lTP[j]);
+				const uint32_t TD = (mv == 1) ? (MA + dTD) : (mv >= 4 ? TP : TQ);
+				// what the column to the left needs: this cell as its right neighbour, the cell below it as its diagonal
+				dD = lD[j]; dTD = lTD[j];
+				if(j == 0) { bD0 = lD[0]; bTD0 = lTD[0]; }
+				lD[j] = D; lP[j] = P; lTD[j] = TD; lTP[j] = TP; lQ[j] = Q; lTQ[j] = TQ;
+				rD = D; rQ = Q; rTD = TD; rTQ = TQ;
+				if(c0 + j == 0 && k < 0 && best < D) { best = D; bestTD = TD; }
+			}
+		}
+	}
+	// result selection (nw.c:830-845). Column 0 lives in lane 0 at local index -c0.
+	const int j0 = nl * XC - q_len;
+	int D0 = lD[0];
+	uint32_t TD0 = lTD[0];
+#pragma unroll
+	for(int j = 1; j < XC; ++j) if(j == j0) { D0 = lD[j]; TD0 = lTD[j]; }
+	int score = (k < 0) ? __shfl(best, 0) : __shfl(D0, 0);
+	uint32_t st = (k < 0) ? __shfl(bestTD, 0) : __shfl(TD0, 0);
+	if(k == -2) {
+		// for n ascending: if(score <= D[0][n]) take it -> the largest column holding the row maximum, if it is >= score
+		int mx = INT_MIN, mc = -1;
+		uint32_t mtd = 0;
+#pragma unroll
+		for(int j = 0; j < XC; ++j) if(act && c0 + j >= 0 && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; mtd = lTD[j]; }
+		int wmx = mx;
+		for(int o = 32; o > 0; o >>= 1) wmx = max(wmx, __shfl_xor(wmx, o));
+		const unsigned long long who = __ballot(act && mc >= 0 && mx == wmx);
+		const int src = who ? 63 - __clzll((long long) who) : 0;
+		const uint32_t stn = __shfl(mtd, src);
+		if(wmx >= score) { score = wmx; st = stn; }
+	}
+	if(lane == 0) {
 		const Aln r = aln_from<10>(score, (uint64_t) st);
 		e[2] = r.score; e[3] = r.len; e[4] = r.match; e[5] = r.tGaps; e[6] = r.qGaps;
 	}
@@ -967,57 +1107,83 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 // it, and all it does is wait for dependent gathers -- so it runs as its own kernel at 8 waves / SIMD (twice the gathers in
 // flight), one lane per single-end task, and hands up to SEEDS MEMs per task to the main kernel. Tasks it cannot serve
 // (strand ties, more MEMs, reads >= 64 k bases) are marked -1 and seeded by the main kernel as before.
+// the MEM search of one oriented read against one template; returns the number of MEMs (0..SEEDS) or -1 (left to the main kernel)
+__device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView &q, int k, uint2 *mem) {
+	const int L = q.L;
+	if(L < k || L > 0xFFFF) return -1;
+	const int t_len = A.db.tlen[t];
+	const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
+	int nm = 0, j = 0, lowq = 0;
+	for(int i = 1; i <= q.nN + 1; ++i) {
+		const int Ni = qN_at(q, i);
+		const int end = (i != q.nN + 1) ? Ni - k + 1 : L - k + 1;
+		const int segstop = end + k - 1;
+		while(j < end) {
+			int v, v2;
+			uint32_t km1, km2;
+			q_kmer2(q, j, k, km1, km2);
+			tpos_get2(A.db, t, km1, km2, j + 1 < end, v, v2);
+			if(v == 0) {
+				if(v2 == 0) { j += 2; continue; }
+				++j; v = v2;
+			}
+			if(v < 0 || nm >= SEEDS) return -1;      // duplicated k-mer (several MEMs per lookup) or too many MEMs
+			int tS, tE, qS, qE;
+			mem_extend(ts, t_len, q, j, v, k, lowq, segstop, tS, tE, qS, qE);
+#pragma unroll
+			for(int x = 0; x < SEEDS; ++x) if(x == nm) mem[x] = make_uint2((uint32_t) tS, (uint32_t) qS | ((uint32_t) (qE - qS) << 16));
+			++nm;
+			j = qE;
+		}
+		j = Ni + 1;
+		lowq = Ni + 1;
+	}
+	return nm;
+}
+
 __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 	const int64_t n_tasks = A.T_off[A.n_reads];
 	const int k = (int) A.db.kmersize;
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	const int slots = A.seed_slots;
 	for(int64_t task = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; task < n_tasks; task += stride) {
 		const int64_t r = A.t_rec[task];
-		const int rcf = A.rc_flag[r], L = A.len[r];
-		if(rcf <= 0 || L < k || L > 0xFFFF) { A.seed_n[task] = -1; continue; }
 		const int t = abs(A.T[task]);
-		const int t_len = A.db.tlen[t];
-		const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
-		QView q;
-		q.w = A.seq + A.seq_off[r]; q.L = L; q.rc = (A.flag[r] & 16) ? 1 : 0;
-		q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-		uint2 mem[SEEDS];
-		int nm = 0, j = 0, lowq = 0;
-		bool give_up = false;
-		for(int i = 1; i <= q.nN + 1 && !give_up; ++i) {
-			const int Ni = qN_at(q, i);
-			const int end = (i != q.nN + 1) ? Ni - k + 1 : L - k + 1;
-			const int segstop = end + k - 1;
-			while(j < end && !give_up) {
-				int v, v2;
-				uint32_t km1, km2;
-				q_kmer2(q, j, k, km1, km2);
-				tpos_get2(A.db, t, km1, km2, j + 1 < end, v, v2);
-				if(v == 0) {
-					if(v2 == 0) { j += 2; continue; }
-					++j; v = v2;
-				}
-				if(v > 0) {
-					if(nm >= SEEDS) { give_up = true; break; }
-					int tS, tE, qS, qE;
-					mem_extend(ts, t_len, q, j, v, k, lowq, segstop, tS, tE, qS, qE);
-#pragma unroll
-					for(int x = 0; x < SEEDS; ++x) if(x == nm) mem[x] = make_uint2((uint32_t) tS, (uint32_t) qS | ((uint32_t) (qE - qS) << 16));
-					++nm;
-					j = qE;
-				} else give_up = true;       // duplicated k-mer: several MEMs per lookup, left to the main kernel
-			}
-			j = Ni + 1;
-			lowq = Ni + 1;
+		// the reads this task aligns and their orientation: exactly the choices of align_tasks_kernel's phase A
+		int views = 0, rcstate = 0;
+		int64_t rd0 = r;
+		int rc0 = 0;
+		if(!A.pe_mode) {
+			if(A.rc_flag[r] > 0) { views = 1; rc0 = (A.flag[r] & 16) ? 1 : 0; }
+		} else {
+			const int64_t p0 = r & ~1ll;
+			const bool couple = (r & 1) && A.rec_mate[p0] >= 0 && A.rec_mate[r] >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
+			if(couple) {
+				views = 2;
+				for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
+			} else if(A.rc_flag[r] > 0 && A.rec_mate[r] >= 0) { views = 1; rd0 = p0 + A.rec_mate[r]; rc0 = A.rec_rc[r]; }
 		}
-		if(give_up) { A.seed_n[task] = -1; continue; }
-		A.seed_n[task] = nm;
+		for(int m = 0; m < slots; ++m) {
+			int nm = -1;
+			uint2 mem[SEEDS];
+			if(m < views) {
+				int64_t rd = rd0;
+				int rc = rc0;
+				if(views == 2) { const int64_t rec = (r & ~1ll) + m; rd = (r & ~1ll) + A.rec_mate[rec]; rc = A.rec_rc[rec] ^ rcstate; }
+				QView q;
+				q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = rc;
+				q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+				nm = seed_view(A, t, q, k, mem);
+			}
+			A.seed_n[task * slots + m] = nm;
 #pragma unroll
-		for(int x = 0; x < SEEDS; ++x) if(x < nm) A.seed_mem[task * SEEDS + x] = mem[x];
+			for(int x = 0; x < SEEDS; ++x) if(x < nm) A.seed_mem[(task * slots + m) * SEEDS + x] = mem[x];
+		}
 	}
 }
 
-template <bool STATS>
+// PEM: paired records (couples, mate / orientation tables); the single-end instantiation carries none of that code
+template <bool STATS, bool PEM>
 __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
 	__shared__ uint32_t s_wide[(ATHREADS / 64) * WSLOTS * 4 * WCOLS];
@@ -1029,6 +1195,8 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	Lane L;
 	L.s32 = A.s32 + gtid; L.s64 = A.s64 + gtid; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
+	L.r32 = A.s32 + (int64_t) 7 * (A.mem_cap + 1) * A.lanes + gtid * (2 * (int64_t) A.ncols);
+	L.r64 = A.s64 + gtid * (2 * (int64_t) A.ncols);
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = STATS ? A.counters : nullptr;
 	L.wide = s_wide + wave * WSLOTS * 4 * WCOLS;
@@ -1041,15 +1209,23 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	int *const queue = s_queue + wave * QINTS;
 	int *const queueN = queue + (1 + QCAP * QENT);
 	int *const queueT = queueN + (1 + QCAPN * QENT);
+	int *const queueX = queueT + (1 + QCAPT * QENT);
 	uint8_t *const tbuf = s_tbuf + wave * TBUF;
 	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
 	const int64_t n_tasks = A.T_off[A.n_reads];
 	const int k = (int) A.db.kmersize;
 	// the wave stays together: every round each lane does its own task up to the (deferred) wide DP problems,
 	// then all 64 lanes solve those, then each lane finishes its task
-	for(int64_t task = gtid; __any(task < n_tasks); task += A.lanes) {
-		const bool have = task < n_tasks && gtid < A.lanes;
-		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; }
+	// Tasks are handed out 64 at a time from a device-wide counter: with a fixed stride the wave that meets a rare long DP
+	// (a 100-column tail walked by one lane takes milliseconds) would still own its share of the remaining tasks.
+	for(;;) {
+		unsigned long long base = 0;
+		if(lane == 0) base = atomicAdd(&A.counters[7], 64ull);
+		base = __shfl(base, 0);
+		if((int64_t) base >= n_tasks) break;
+		const int64_t task = (int64_t) base + lane;
+		const bool have = task < n_tasks;
+		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; queueX[0] = 0; }
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- phase A -------------------------------------------------------------------------------
@@ -1062,7 +1238,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 			int64_t rd = r;
 			int orient = (A.flag[r] & 16) ? 1 : 0;
 			bool couple = false;
-			if(A.pe_mode) {
+			if(PEM) {
 				const int64_t p0 = r & ~1ll;
 				rd = p0 + max(0, A.rec_mate[r]);
 				orient = A.rec_rc[r];
@@ -1074,7 +1250,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
 			int status = 0;
 			L.q_at = at;
-			if(couple) {
+			if(PEM && couple) {
 				// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate. Both are
 				// flipped once the list reaches its first negative id and stay flipped (:1633-1647).
 				kind = 2;
@@ -1089,10 +1265,20 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 					q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
 					L.q_mate = m; L.q_rd = rdm;
 					Aln st = {0, 1, 0, 0, 0, 0};
-					if(q.L >= k) st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+					if(q.L >= k) {
+						const int pre = (!STATS && A.seed_n) ? A.seed_n[task * 2 + m] : -1;
+						if(pre > 0) {
+							for(int x = 0; x < pre; ++x) {
+								const uint2 e = A.seed_mem[(task * 2 + m) * SEEDS + x];
+								const int qS = (int) (e.y & 0xFFFFu), ln = (int) (e.y >> 16);
+								MEMA(L, 0, x) = (int) e.x; MEMA(L, 1, x) = (int) e.x + ln; MEMA(L, 2, x) = qS; MEMA(L, 3, x) = qS + ln; MEMA(L, 4, x) = ln;
+							}
+							st = kma_score(L, A.db, at, ts, t_len, q, A.mq, pre, &status);
+						} else if(pre < 0) st = kma_score(L, A.db, at, ts, t_len, q, A.mq, 0, &status);
+					}
 					if(m == 0) { S0 = st; qlen0 = q.L; } else { S1 = st; qlen1 = q.L; }
 				}
-			} else if(rcf != 0 && A.len[rd] >= k && (!A.pe_mode || A.rec_mate[r] >= 0)) {
+			} else if(rcf != 0 && A.len[rd] >= k && (!PEM || A.rec_mate[r] >= 0)) {
 				kind = 1;
 				QView q;
 				q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
@@ -1102,10 +1288,10 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				if(L.cnt) atomicAdd(&L.cnt[6], 1ull);
 				if(rcf > 0) {
 					// MEMs found by seed_tasks_kernel (the work-counting launch seeds here so that its counters are complete)
-					const int pre = (!STATS && A.seed_n) ? A.seed_n[task] : -1;
+					const int pre = (!STATS && A.seed_n) ? A.seed_n[task * (PEM ? 2 : 1)] : -1;
 					if(pre > 0) {
 						for(int m = 0; m < pre; ++m) {
-							const uint2 e = A.seed_mem[task * SEEDS + m];
+							const uint2 e = A.seed_mem[task * (PEM ? 2 : 1) * SEEDS + m];
 							const int qS = (int) (e.y & 0xFFFFu), ln = (int) (e.y >> 16);
 							MEMA(L, 0, m) = (int) e.x; MEMA(L, 1, m) = (int) e.x + ln; MEMA(L, 2, m) = qS; MEMA(L, 3, m) = qS + ln; MEMA(L, 4, m) = ln;
 						}
@@ -1124,15 +1310,20 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		// ---- phase B: deferred wide DP problems, whole wave -----------------------------------------
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]);
+		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
+		for(int e = 0; e < nqx; ++e) {
+			nw_coop_x(L, A.db, A, queueX, e, tbuf);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
 		for(int e = 0; e < nq; ++e) nw_coop<64>(L, A.db, A, queue, e, nq, tbuf);
 		for(int e = 0; e < nqn; e += 4) nw_coop<16>(L, A.db, A, queueN, e, nqn, tbuf);
 		for(int e = 0; e < nqt; e += 8) nw_coop<8>(L, A.db, A, queueT, e, nqt, tbuf);
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
-		for(int pass = 0; pass < 3; ++pass) {
-			const int *qu = pass == 0 ? queue : pass == 1 ? queueN : queueT;
-			const int cnt = pass == 0 ? nq : pass == 1 ? nqn : nqt;
+		for(int pass = 0; pass < 4; ++pass) {
+			const int *qu = pass == 0 ? queue : pass == 1 ? queueN : pass == 2 ? queueT : queueX;
+			const int cnt = pass == 0 ? nq : pass == 1 ? nqn : pass == 2 ? nqt : nqx;
 			for(int e = 0; e < cnt; ++e) {
 				const int *ent = qu + 1 + e * QENT;
 				if(lane != ent[0]) continue;
@@ -1145,7 +1336,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		}
 		// ---- phase C ---------------------------------------------------------------------------------
 		if(!have) continue;
-		if(kind == 2) {
+		if(PEM && kind == 2) {
 			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
 			for(int m = 0; m < 2; ++m) {
 				const Aln &st = m ? S1 : S0;
@@ -1775,7 +1966,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	if(gtid >= A.lanes) return;
 	TLane T;
 	Lane &L = T.L;
-	L.s32 = A.s32 + gtid; L.s64 = nullptr; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
+	L.s32 = A.s32 + gtid; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0;
 	L.diag_uniform = 0;
@@ -1848,7 +2039,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (7 * 4 + 8 + SEEDS * 8) + 16));
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (8 * 4 + 8 + 2 * SEEDS * 8) + 16));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
@@ -1865,8 +2056,8 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	int32_t *ti = (int32_t *) (norm + tasks_cap);
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	int32_t *t_rec = ti + 5 * tasks_cap;
-	A.seed_n = nullptr; A.seed_mem = nullptr;
-	if(!rec_mate) { A.seed_n = ti + 6 * tasks_cap; A.seed_mem = (uint2 *) (ti + 7 * tasks_cap + (tasks_cap & 1)); }
+	A.seed_slots = rec_mate ? 2 : 1;
+	A.seed_n = ti + 6 * tasks_cap; A.seed_mem = (uint2 *) (ti + 8 * tasks_cap);
 	A.t_rec = t_rec;
 	if(n >= 0x7FFFFFFF) { kmahip_set_error("too many records in one batch"); return KMAHIP_EINVAL; }
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
@@ -1893,8 +2084,14 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
 		HIP_TRY(hipEventRecord(ev0, stream));
 	}
-	if(A.stats) hipLaunchKernelGGL(align_tasks_kernel<true>, dim3((unsigned) (lanes / ATHREADS)), dim3(ATHREADS), 0, stream, A);
-	else hipLaunchKernelGGL(align_tasks_kernel<false>, dim3((unsigned) (lanes / ATHREADS)), dim3(ATHREADS), 0, stream, A);
+	const dim3 agrid((unsigned) (lanes / ATHREADS));
+	if(A.stats) {
+		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<true, true>), agrid, dim3(ATHREADS), 0, stream, A);
+		else hipLaunchKernelGGL((align_tasks_kernel<true, false>), agrid, dim3(ATHREADS), 0, stream, A);
+	} else {
+		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<false, true>), agrid, dim3(ATHREADS), 0, stream, A);
+		else hipLaunchKernelGGL((align_tasks_kernel<false, false>), agrid, dim3(ATHREADS), 0, stream, A);
+	}
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events2) ws->events2 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();

@@ -120,3 +120,38 @@ def test_align_vs_oracle_long_noisy_reads(tmp_path):
     for L in (5000, 6500, 8000):
         reads += synth.make_long_reads(genome, 6, read_len=L, sub=0.03, dele=0.02, ins=0.02, seed=int(rng.integers(1 << 30)))
     _vs_oracle(prefix, formats.pack_ragged(reads))
+
+
+def test_align_vs_oracle_partially_matching_reads(tmp_path):
+    """Reads that match a template only in part (a gene segment followed or preceded by 60 ... 230 foreign bases, both
+    strands, some with a second segment further on): the unaligned ends are DP problems of 64 ... 255 query columns, solved
+    by the extra-wide cooperative path (nw_coop_x), up to the ones only a single lane or the banded DP can take."""
+    names, seqs = synth.make_gene_db(n_families=12, variants=3, len_lo=700, len_hi=1100, seed=23)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    rng = np.random.default_rng(99)
+    reads = []
+    for i in range(1500):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(250, 450))
+        a = int(rng.integers(0, len(s) - L))
+        core = s[a:a + L].copy()
+        junk = rng.integers(0, 4, int(rng.integers(64, 150)), dtype=np.uint8)
+        kind = i % 4
+        if kind == 0:
+            r = np.concatenate([core, junk])
+        elif kind == 1:
+            r = np.concatenate([junk, core])
+        elif kind == 2:
+            r = np.concatenate([junk[:len(junk) // 2], core, junk[len(junk) // 2:]])
+        else:                      # two segments of the same gene around the junk: a wide gap between two MEM chains
+            b = min(len(s) - 30, a + L + int(rng.integers(0, 80)))
+            r = np.concatenate([core, junk[:int(rng.integers(64, len(junk) + 1))], s[b:b + 30]])
+        if rng.random() < 0.01 * 30:
+            p = int(rng.integers(0, len(r)))
+            r[p] = (r[p] + 1) & 3
+        if rng.random() < 0.5:
+            r = synth.revcomp_codes(r)
+        reads.append(np.ascontiguousarray(r.astype(np.uint8)))
+    o = _vs_oracle(prefix, formats.pack_ragged(reads))
+    assert (o["n_hits"] > 0).sum() > 300, int((o["n_hits"] > 0).sum())
