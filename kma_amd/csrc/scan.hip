@@ -1256,9 +1256,22 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, evp = nullptr, evq = nullptr;
+	if(ws->timing_on) {
+		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventCreate(&evp)); HIP_TRY(hipEventCreate(&evq));
+		HIP_TRY(hipEventRecord(evp, stream));
+	}
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
+	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
 	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
 	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	if(ws->timing_on) {
+		HIP_TRY(hipEventRecord(ev1, stream));
+		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+		ws->events->push_back({ev0, ev1});
+		if(!ws->events3) ws->events3 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+		ws->events3->push_back({evp, evq});
+	}
 	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	PairArgs P;
 	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
