@@ -120,12 +120,28 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		}
 	}
 	db->info.hash_bytes = slots.size() * sizeof(uint2);
+	// presence bits: ~7 bits per k-mer (13 % false positives) as long as that fits 2 MiB
+	std::vector<uint32_t> kbits;
+	uint32_t kbits_log2 = 0;
+	if(n > 0 && 8 * n < (1ull << 25)) {
+		kbits_log2 = 16;
+		while((2ull << kbits_log2) <= 8 * n) ++kbits_log2;
+		kbits.assign((size_t) 1 << (kbits_log2 - 5), 0u);
+		for(uint64_t i = 0; i < n; ++i) {
+			const uint32_t h = (keys[i] * KMAHIP_KBITS_MUL) >> (32 - kbits_log2);
+			kbits[h >> 5] |= 1u << (h & 31);
+		}
+	}
 
 	int rc;
 	DevDB &d = db->dev;
 	memset(&d, 0, sizeof d);
 	d.DB_size = DB_size; d.kmersize = tail[0]; d.mlen = mlen; d.nb_log2 = nb_log2; d.values_u16 = u16;
 	// (slots are uploaded further down, once every key has been given a template position)
+	if(!kbits.empty()) {
+		if((rc = upload(db, kbits.data(), kbits.size(), &d.kbits))) { kmahip_db_close(db); return rc; }
+		d.kbits_shift = 32 - kbits_log2;
+	}
 	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index + 8, &d.values16);
 	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index + 8, &d.values32);
 	if(rc) { kmahip_db_close(db); return rc; }

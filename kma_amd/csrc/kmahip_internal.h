@@ -9,7 +9,8 @@
 
 #define KMAHIP_EMPTY_VI 0xFFFFFFFFu
 #define KMAHIP_BUCKET_SLOTS 4
-#define KMAHIP_N_COUNTERS 16      // device counter words per workspace
+#define KMAHIP_N_COUNTERS 16
+#define KMAHIP_KBITS_MUL 0x85EBCA6Bu      // device counter words per workspace
 
 // Probe table in HBM: open hashing over 32-byte buckets of 4 (key, position)
 // slots. bucket(key) = (key * GOLD) >> (32 - nb_log2); a key lives in the first
@@ -39,6 +40,11 @@ struct DevDB {
 	// val > 0: the single 1-based position of the k-mer; val < 0: -(o + 1) where
 	// tpos_dups[o] = count followed by the ascending 1-based positions; val == 0
 	// empty. The poly-A k-mer 0 is never indexed (hashmapcci.c:414-417).
+	// presence bits of the k-mers of the probe table (small databases only, else NULL): bit ((key * KBITS_MUL) >> kbits_shift).
+	// 2 MiB at most, so it stays in the 4 MiB L2 of every XCD, where a gather costs a quarter of one into the 67 MB table;
+	// consulted where a miss is the likely answer (wrong-strand prefilter probes)
+	const uint32_t *kbits;
+	uint32_t kbits_shift;
 	const uint2 *tpos_slots;
 	const int64_t *tpos_off;      // DB_size + 1 slot offsets
 	const uint32_t *tpos_shift;   // DB_size: 32 - log2(table size)

@@ -244,15 +244,15 @@ constexpr int PF_ITEMS = PF_BLOCK * PF_ROUNDS;             // items per workgrou
 template <bool STATS>
 __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs A) {
 	__shared__ int64_t s_list[PF_ITEMS];
-	__shared__ uint32_t s_n, s_np;
+	__shared__ uint32_t s_n, s_np, s_nt;
 	__shared__ unsigned long long s_base;
 	const DevDB &db = A.db;
 	const int tid = threadIdx.x;
 	const int k = (int) db.kmersize;
 	const int plane = tid & (PF_PLANES - 1);
-	if(tid == 0) { s_n = 0; s_np = 0; }
+	if(tid == 0) { s_n = 0; s_np = 0; s_nt = 0; }
 	__syncthreads();
-	uint32_t nprobe = 0;
+	uint32_t nprobe = 0, ntable = 0;      // k-mers resolved / of them by a gather into the probe table
 	for(int rd = 0; rd < PF_ROUNDS; ++rd) {
 		const int64_t item = (int64_t) blockIdx.x * PF_ITEMS + rd * PF_BLOCK + (tid / PF_PLANES);
 		const int64_t r = item >> 1;
@@ -269,13 +269,63 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 				if(A.exhaustive) {
 #endif
 					hit = strand == 0 || A.exhaustive;
+				} else if(nN == 0 && db.kbits) {
+					// small database: the first stride k-mer goes to the probe table (the right strand hits there); for the
+					// others the presence bits are fetched meanwhile (L2-resident, eight in flight), and only the few that
+					// pass -- false positives on the wrong strand -- are probed for real
+					const int nst = (npos + k - 1) / k;
+					auto stride_kmer = [&](int st) -> uint32_t {
+						const int q = strand ? (L - k - st * k) : st * k;
+						uint64_t km = kmer_from(rs[q >> 5], rs[(q >> 5) + 1], q, k);
+						if(strand) km = revcomp_kmer(km, k);
+						return (uint32_t) km;
+					};
+					const uint32_t km0 = stride_kmer(0);
+					const uint32_t sh = 32u - db.nb_log2;
+					const uint4 *p0 = reinterpret_cast<const uint4 *>(db.slots + (size_t) ((km0 * 0x9E3779B1u) >> sh) * KMAHIP_BUCKET_SLOTS);
+					const uint4 a0 = p0[0], c0 = p0[1];
+					int first_hit = -1;
+					for(int sb = 1; sb < nst || sb == 1; sb += 8) {
+						uint32_t kms[8], wd[8];
+#pragma unroll
+						for(int u = 0; u < 8; ++u) {
+							kms[u] = 0; wd[u] = 0;
+							if(sb + u < nst) {
+								kms[u] = stride_kmer(sb + u);
+								wd[u] = db.kbits[((kms[u] * KMAHIP_KBITS_MUL) >> db.kbits_shift) >> 5];
+							}
+						}
+						if(sb == 1) {
+							// the table answer for stride 0 (the usual linear probing if its bucket is full)
+							uint32_t g0;
+							if(a0.x == km0 && a0.y != KMAHIP_EMPTY_VI) g0 = a0.y;
+							else if(a0.z == km0 && a0.w != KMAHIP_EMPTY_VI) g0 = a0.w;
+							else if(c0.x == km0 && c0.y != KMAHIP_EMPTY_VI) g0 = c0.y;
+							else if(c0.z == km0 && c0.w != KMAHIP_EMPTY_VI) g0 = c0.w;
+							else if(c0.w == KMAHIP_EMPTY_VI) g0 = MISS;
+							else g0 = probe(db, km0);
+							++nprobe; ++ntable;
+							if(g0 != MISS) { first_hit = 0; break; }
+						}
+#pragma unroll
+						for(int u = 0; u < 8; ++u) {
+							if(first_hit >= 0 || sb + u >= nst) continue;
+							++nprobe;
+							const uint32_t h = (kms[u] * KMAHIP_KBITS_MUL) >> db.kbits_shift;
+							if(!((wd[u] >> (h & 31)) & 1u)) continue;
+							++ntable;
+							if(probe(db, kms[u]) != MISS) first_hit = sb + u;
+						}
+						if(first_hit >= 0) break;
+					}
+					hit = first_hit >= 0;
 				} else if(nN == 0) {
 					// two stride positions per step, their home buckets in flight together
 					for(int j = plane * k; j < npos; j += 2 * PF_PLANES * k) {
 						const int q = strand ? (L - k - j) : j;
 						uint64_t km = kmer_from(rs[q >> 5], rs[(q >> 5) + 1], q, k);
 						if(strand) km = revcomp_kmer(km, k);
-						++nprobe;
+						++nprobe; ++ntable;
 						const int j2 = j + PF_PLANES * k;
 						if(j2 < npos) {
 							const int q2 = strand ? (L - k - j2) : j2;
@@ -284,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 							uint32_t r1, r2;
 							probe2(db, (uint32_t) km, (uint32_t) km2, r1, r2);
 							if(r1 != MISS) { hit = true; break; }
-							++nprobe;
+							++nprobe; ++ntable;
 							if(r2 != MISS) { hit = true; break; }
 						} else if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
 					}
@@ -299,7 +349,7 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 							const int w = q >> 5;
 							uint64_t km = kmer_from(rs[w], rs[w + 1], q, k);
 							if(strand) km = revcomp_kmer(km, k);
-							++nprobe;
+							++nprobe; ++ntable;
 							if(probe(db, (uint32_t) km) != MISS) hit = true;
 						}
 						j = segend + 1;
@@ -315,14 +365,14 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 			else { A.item_score[item] = 0; A.item_n[item] = 0; A.item_off[item] = 0; }
 		}
 	}
-	if(STATS && nprobe) atomicAdd(&s_np, nprobe);
+	if(STATS && nprobe) { atomicAdd(&s_np, nprobe); atomicAdd(&s_nt, ntable); }
 	__syncthreads();
 	const uint32_t nact = s_n;
 	if(tid == 0) {
 		s_base = nact ? atomicAdd(&A.counters[C_NACT], (unsigned long long) nact) : 0ull;
 		if(STATS) {
 			atomicAdd(&A.counters[C_PROBES], (unsigned long long) s_np);
-			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_np);
+			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_nt);
 			atomicAdd(&A.counters[C_PREF], (unsigned long long) s_np);
 			atomicAdd(&A.counters[C_ACTIVE], (unsigned long long) nact);
 		}
