@@ -681,19 +681,29 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 				const uint64_t X0 = M0 << 1, X1 = (M1 << 1) | (M0 >> 63), X2 = (M2 << 1) | (M1 >> 63);
 				uint64_t S0 = M0 & ~X0, S1 = M1 & ~X1, S2 = M2 & ~X2;
 				uint64_t E0 = ~M0 & X0, E1 = ~M1 & X1, E2 = ~M2 & X2;
-				for(;;) {
-					int b0, b1;
-					if(S0) { b0 = __ffsll((long long) S0) - 1; S0 &= S0 - 1; }
-					else if(S1) { b0 = 63 + __ffsll((long long) S1); S1 &= S1 - 1; }
-					else if(S2) { b0 = 127 + __ffsll((long long) S2); S2 &= S2 - 1; }
-					else break;
-					if(E0) { b1 = __ffsll((long long) E0) - 1; E0 &= E0 - 1; }
-					else if(E1) { b1 = 63 + __ffsll((long long) E1); E1 &= E1 - 1; }
-					else { b1 = 127 + __ffsll((long long) E2); E2 &= E2 - 1; }
-					const int pa = c0 + b0, len = b1 - b0;
-					if(score == INT_MIN) { score = k * A.M + (len - 1) * A.M; first = pa; }
-					else score += bridge(pa - 1 - last, k, A.M, A.MM, A.U, A.W1) + (len - 1) * A.M;
-					last = c0 + b1 - 1;
+				if(M0 | M1 | M2) {
+					// every hit but the first of a run is worth M; the first one k*M (first hit ever) or the bridge over the
+					// zeros before it -- so only the zero runs BETWEEN runs are walked (none for the usual single run)
+					const int ones = __popcll(M0) + __popcll(M1) + __popcll(M2);
+					const int nruns = __popcll(S0) + __popcll(S1) + __popcll(S2);
+					const int fb = M0 ? __ffsll((long long) M0) - 1 : M1 ? 63 + __ffsll((long long) M1) : 127 + __ffsll((long long) M2);
+					const int lb = M2 ? 191 - __clzll((long long) M2) : M1 ? 127 - __clzll((long long) M1) : 63 - __clzll((long long) M0);
+					if(score == INT_MIN) { score = k * A.M; first = c0 + fb; }
+					else score += bridge(c0 + fb - 1 - last, k, A.M, A.MM, A.U, A.W1);
+					score += (ones - nruns) * A.M;
+					last = c0 + lb;
+					// drop the start of the first run; then the i-th end pairs with the start of run i + 1
+					if(S0) S0 &= S0 - 1; else if(S1) S1 &= S1 - 1; else S2 &= S2 - 1;
+					for(int r = 1; r < nruns; ++r) {
+						int b0, b1;
+						if(S0) { b0 = __ffsll((long long) S0) - 1; S0 &= S0 - 1; }
+						else if(S1) { b0 = 63 + __ffsll((long long) S1); S1 &= S1 - 1; }
+						else { b0 = 127 + __ffsll((long long) S2); S2 &= S2 - 1; }
+						if(E0) { b1 = __ffsll((long long) E0) - 1; E0 &= E0 - 1; }
+						else if(E1) { b1 = 63 + __ffsll((long long) E1); E1 &= E1 - 1; }
+						else { b1 = 127 + __ffsll((long long) E2); E2 &= E2 - 1; }
+						score += bridge(b0 - b1, k, A.M, A.MM, A.U, A.W1);      // b1 = first zero after a run, b0 = next run's start
+					}
 				}
 				t_score[idx] = score; t_last[idx] = last; t_first[idx] = first;
 #pragma unroll
