@@ -578,7 +578,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 #ifdef KMAHIP_DIAG
 						if(A.ablate & 1) bm = 0;
 #endif
-						while(bm && !s_over[g]) {
+						if(s_over[g]) bm = 0;                // the item goes to the overflow kernel anyway
+						while(bm) {
 							const int i0 = __ffs((int) bm) - 1;
 							bm &= bm - 1;
 							const int i1 = bm ? __ffs((int) bm) - 1 : run + 1;
@@ -597,11 +598,11 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 								if(old == MISS || old == vi) { slot = sidx; break; }
 							}
 							if(slot >= 0) {
-								for(int w = rs >> 5; w <= (re - 1) >> 5; ++w) {
-									const int lo = max(rs, w << 5) & 31, hi = min(re, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
-									const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
-									atomicOr(&v_mask[w * VSLOTS * GROUP + slot], m);
-								}
+								// a run inside one lane's segment is at most SEG (9) positions long: two mask words at most
+								const int w = rs >> 5;
+								const uint64_t m = ((1ull << (re - rs)) - 1ull) << (rs & 31);
+								atomicOr(&v_mask[w * VSLOTS * GROUP + slot], (uint32_t) m);
+								if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * GROUP + slot], (uint32_t) (m >> 32));
 							} else {
 								// more distinct lists in this pass than the v-table holds: expand this run directly
 								expand_list(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
