@@ -179,9 +179,11 @@ __device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
 }
 
 // two lookups whose first table gathers travel together
+__device__ __forceinline__ void tpos_get2(const uint2 *tab, uint32_t sh, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2);
 __device__ __forceinline__ void tpos_get2(const DevDB &db, int t, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
-	const uint32_t sh = db.tpos_shift[t];
-	const uint2 *tab = db.tpos_slots + db.tpos_off[t];
+	tpos_get2(db.tpos_slots + db.tpos_off[t], db.tpos_shift[t], km1, km2, want2, v1, v2);
+}
+__device__ __forceinline__ void tpos_get2(const uint2 *tab, uint32_t sh, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
 	const uint32_t msk = (1u << (32 - sh)) - 1u;
 	uint32_t s1 = (km1 * 0x9E3779B1u) >> sh, s2 = (km2 * 0x9E3779B1u) >> sh;
 	uint2 e1 = tab[s1], e2 = tab[want2 ? s2 : s1];
@@ -1111,8 +1113,11 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 __device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView &q, int k, uint2 *mem) {
 	const int L = q.L;
 	if(L < k || L > 0xFFFF) return -1;
-	const int t_len = A.db.tlen[t];
-	const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
+	const uint4 ma = A.db.tmeta[2 * (size_t) t], mb = A.db.tmeta[2 * (size_t) t + 1];
+	const int t_len = (int) mb.x;
+	const uint64_t *ts = A.db.tseq + (((uint64_t) ma.y << 32) | ma.x);
+	const uint2 *tab = A.db.tpos_slots + (((uint64_t) ma.w << 32) | ma.z);
+	const uint32_t tsh = mb.y;
 	int nm = 0, j = 0, lowq = 0;
 	for(int i = 1; i <= q.nN + 1; ++i) {
 		const int Ni = qN_at(q, i);
@@ -1122,7 +1127,7 @@ __device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView 
 			int v, v2;
 			uint32_t km1, km2;
 			q_kmer2(q, j, k, km1, km2);
-			tpos_get2(A.db, t, km1, km2, j + 1 < end, v, v2);
+			tpos_get2(tab, tsh, km1, km2, j + 1 < end, v, v2);
 			if(v == 0) {
 				if(v2 == 0) { j += 2; continue; }
 				++j; v = v2;

@@ -267,7 +267,14 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 				a = b;
 			}
 		}
-		if((rc = upload(db, pslots.data(), pslots.size(), &d.tpos_slots)) ||
+		std::vector<uint4> tmeta((size_t) 2 * DB_size, make_uint4(0u, 0u, 0u, 0u));
+		for(uint32_t t = 1; t < DB_size; ++t) {
+			const uint64_t so = (uint64_t) off[t], po = (uint64_t) poff[t];
+			tmeta[2 * (size_t) t] = make_uint4((uint32_t) so, (uint32_t) (so >> 32), (uint32_t) po, (uint32_t) (po >> 32));
+			tmeta[2 * (size_t) t + 1] = make_uint4((uint32_t) db->h_tlen[t], pshift[t], 0u, 0u);
+		}
+		if((rc = upload(db, tmeta.data(), tmeta.size(), &d.tmeta)) ||
+		   (rc = upload(db, pslots.data(), pslots.size(), &d.tpos_slots)) ||
 		   (rc = upload(db, poff.data(), poff.size(), &d.tpos_off)) ||
 		   (rc = upload(db, pshift.data(), pshift.size(), &d.tpos_shift)) ||
 		   (rc = upload(db, dups.data(), dups.size(), &d.tpos_dups))) { kmahip_db_close(db); return rc; }

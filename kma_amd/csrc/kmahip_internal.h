@@ -49,6 +49,9 @@ struct DevDB {
 	const int64_t *tpos_off;      // DB_size + 1 slot offsets
 	const uint32_t *tpos_shift;   // DB_size: 32 - log2(table size)
 	const int32_t *tpos_dups;
+	// everything the seeding kernel needs to know about a template in one 32-byte record (two 16-byte gathers instead of four
+	// scattered ones): x = {tseq_off lo, hi, tpos_off lo, hi}, y = {tlen, tpos_shift, 0, 0}
+	const uint4 *tmeta;           // 2 * DB_size
 };
 
 struct kmahip_db {
