@@ -302,6 +302,30 @@ typedef struct kmahip_assembly {
 } kmahip_assembly;
 int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                     const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out);
+/* kmahip_assemble with the per-read inputs already in HBM (reads, rc, tmpl and the traces are DEVICE pointers, e.g. the
+ * outputs of kmahip_align_trace_dev); `out` is filled on the host as above. */
+int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                        const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out);
+
+/* The whole single-end `-1t1` run on one batch, one call: reads uploaded ONCE, stage 2, stage 3a, ConClave, the `.res`
+ * statistics, the traceback aligner and the pile-up all on what is already in HBM; only the per-template results (and, if
+ * asked for, the per-read columns a `.frag.gz` / SAM writer needs) come back. Equivalent to kmahip_map_se +
+ * kmahip_conclave_se + kmahip_res_rows + kmahip_align_trace + kmahip_assemble, minus four uploads of the reads and the
+ * host round trips in between (runKMA, runkma.c:104-900, for one chunk of input). HOST buffers.
+ *   rows / rows_cap / n_rows   as kmahip_res_rows (KMAHIP_EOVERFLOW with n_rows = needed)
+ *   assembly                   as kmahip_assemble
+ *   tmpl, n_hits, rc, trace_stats   optional per-read outputs (n_reads, n_reads, n_reads, 10 * n_reads), NULL to skip
+ *   ms[6]                      wall time of: upload, stages 2 + 3a, ConClave + statistics, traceback, pile-up, consensus (host) */
+typedef struct kmahip_run {
+	kmahip_res_row *rows;
+	int64_t rows_cap, n_rows;
+	kmahip_assembly assembly;
+	int32_t *tmpl, *n_hits, *rc, *trace_stats;
+	double ms[6];
+} kmahip_run;
+int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
+                  int64_t max_frag, kmahip_run *out);
+
 /* One `.res` row exactly as runKMA prints it (runkma.c:809) from kmahip_res_rows + kmahip_assemble; returns the number of
  * characters written, 0 when the reference prints no row for the template (nothing covered, identity below -ID (1.0) or
  * depth below -md (0.0)). */

@@ -79,6 +79,11 @@ class ReadBatchC(C.Structure):
     _fields_ = [("reads", Reads), ("names", C.c_void_p), ("name_off", C.c_void_p), ("pair", C.c_void_p), ("records", C.c_int64)]
 
 
+class Run(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("rows_cap", C.c_int64), ("n_rows", C.c_int64), ("assembly", Assembly),
+                ("tmpl", C.c_void_p), ("n_hits", C.c_void_p), ("rc", C.c_void_p), ("trace_stats", C.c_void_p), ("ms", C.c_double * 6)]
+
+
 class ScanStats(C.Structure):
     _fields_ = [("probes", C.c_uint64), ("value_elems", C.c_uint64), ("active_strands", C.c_uint64),
                 ("hash_probes", C.c_uint64), ("prefilter_probes", C.c_uint64)]
@@ -150,6 +155,7 @@ def lib():
         L.kmahip_res_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.kmahip_frag_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.kmahip_run_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.POINTER(Run)]
         L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
         L.kmahip_trim_default.restype = None
         L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
@@ -510,6 +516,39 @@ class KmaHipDB:
         if consensus:
             raw = cbuf.tobytes()
             o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
+        return o
+
+    def run_se(self, batch, evalue=0.05, bcd=1, max_frag=0, consensus=True, per_read=True):
+        """The whole single-end run in one call (kmahip_run_se) -> dict(rows [ResRow], cover, aln_len, depth, asm_len, consensus,
+        tmpl, n_hits, rc, trace_stats, ms)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        D = int(self.info.DB_size)
+        o = dict(cover=np.zeros(D, np.int64), aln_len=np.zeros(D, np.int64), depth=np.zeros(D, np.int64), asm_len=np.zeros(D, np.int64))
+        cap = 0
+        cbuf = coff = None
+        if consensus:
+            cap = int(2 * np.fromfile(self.prefix + ".length.b", dtype=np.int32)[1:].astype(np.int64).sum() + 4 * D + (1 << 20))
+            cbuf = np.zeros(cap, np.uint8)
+            coff = np.full(D, -1, np.int64)
+        rows = (ResRow * D)()
+        pr = {k: np.zeros(max(1, n) * (10 if k == "trace_stats" else 1), np.int32) for k in ("tmpl", "n_hits", "rc", "trace_stats")} if per_read else {}
+        run = Run(C.cast(rows, C.c_void_p), D, 0,
+                  Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), None if cbuf is None else _p(cbuf),
+                           None if coff is None else _p(coff), cap, 0),
+                  *[(_p(pr[k]) if per_read else None) for k in ("tmpl", "n_hits", "rc", "trace_stats")])
+        p = Params.from_buffer_copy(self.params)
+        _check(lib().kmahip_run_se(self.h, self.ws, C.byref(r), C.byref(p), float(evalue), int(bcd), int(max_frag), C.byref(run)))
+        o["rows"] = [rows[i] for i in range(run.n_rows)]
+        if consensus:
+            raw = cbuf.tobytes()
+            o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
+        for k, v in pr.items():
+            o[k] = v[:n * 10].reshape(n, 10) if k == "trace_stats" else v[:n]
+        o["ms"] = list(run.ms)
         return o
 
     def frag_write(self, path, batch, rc, tmpl, n_hits, stats, read_names, max_frag=0):

@@ -436,6 +436,20 @@ extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads 
 	   (rc = up(flag, (size_t) n * 4, (void **) &d_flag)) || (rc = up(tmpl, (size_t) n * 4, (void **) &d_tmpl)) ||
 	   (rc = up(traces->stats, (size_t) n * 40, (void **) &dt.stats)) || (rc = up(traces->ops_off, (size_t) n * 8, (void **) &dt.ops_off)) ||
 	   (rc = up(traces->n_ops, (size_t) n * 4, (void **) &dt.n_ops)) || (rc = up(traces->ops, (size_t) total_ops * 4, (void **) &dt.ops))) return rc;
+	return kmahip_assemble_dev(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, bcd, evalue, out);
+}
+
+// the same with the per-read inputs already in HBM (reads, rc, tmpl, traces: DEVICE pointers; `out`: host)
+extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *d_flag, const int32_t *d_tmpl,
+                                   const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
+	if(!db || !ws || !reads || !d_flag || !d_tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(db->h_cat_off.empty()) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
+	const int64_t D = db->info.DB_size;
+	for(int64_t t = 0; t < D; ++t) { out->cover[t] = 0; out->aln_len[t] = 0; out->depth[t] = 0; out->asm_len[t] = 0; }
+	if(reads->n_reads == 0) return KMAHIP_OK;
+	int rc;
+	const kmahip_reads &d = *reads;
+	const kmahip_traces &dt = *traces;
 	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -245,3 +245,43 @@ def test_c_host_program_reproduces_reference_res_file(golden_se, golden_long):
         # the same from the FASTQ file itself: stage 1 by kmahip_ingest_* instead of the reference's S1 stream
         out = subprocess.run([exe, "-t_db", g["prefix"], "-i", os.path.join(g["dir"], "reads.fq.gz")], stdout=subprocess.PIPE, check=True).stdout
         assert out == open(os.path.join(g["dir"], "out.res"), "rb").read(), g["dir"]
+
+
+def _one_call_case(g, name):
+    """kmahip_run_se (reads uploaded once, everything else on the device) must give what the stage-wise calls give: the
+    reference's `.res`, consensus FASTA and `.frag.gz`."""
+    import gzip
+    import os
+    import tempfile
+    from kma_amd import binding
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        o = db.run_se(g["batch"])
+        names = golden_util.template_names(name)
+        lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
+        fsa = []
+        for r in o["rows"]:
+            if not r.significant:
+                continue
+            t = r.template_id
+            line = db.res_line(names[t - 1], r, o["cover"][t], o["aln_len"][t], o["depth"][t])
+            if line:
+                lines.append(line)
+                fsa.append((names[t - 1], o["consensus"][t]))
+        with open(os.path.join(golden_util.GOLD, name, "out.res")) as f:
+            assert "".join(lines) == f.read()
+        assert golden_util.fsa_text(fsa) == golden_util.load_fsa(name)
+        if os.path.exists(os.path.join(golden_util.GOLD, name, "out.frag.gz")):
+            with tempfile.TemporaryDirectory() as tmp:
+                hdrs = [r["hdr"].rstrip(b"\0") for r in g["s1"]]
+                db.frag_write(os.path.join(tmp, "x.frag.gz"), g["batch"], o["rc"], o["tmpl"], o["n_hits"], o["trace_stats"], hdrs)
+                assert gzip.open(os.path.join(tmp, "x.frag.gz"), "rb").read() == gzip.open(os.path.join(golden_util.GOLD, name, "out.frag.gz"), "rb").read()
+        assert len(o["ms"]) == 6 and all(m >= 0 for m in o["ms"])
+        return len(lines) - 1
+    finally:
+        db.close()
+
+
+def test_one_call_pipeline_matches_reference_files(golden_se, golden_long):
+    assert _one_call_case(golden_se, "se") > 50
+    assert _one_call_case(golden_long, "long") > 0

@@ -74,6 +74,22 @@ ins_reads = int(sum(1 for i in range(b.n) if traces[0][i, 7] > 0))
 print(f"db {fam} families x {var} variants; reads {n}, reads aligned with an insertion {ins_reads}, .res rows {len(lines) - 1}")
 print(f"reference {t_ref:.1f} s (whole pipeline, 1 thread), library {t_ours:.2f} s (host-buffer calls incl. staging)")
 print("res identical:", "".join(lines) == ref_res, " consensus FASTA identical:", golden_util.fsa_text(fsa) == ref_fsa)
+# the same through the one-call pipeline (reads uploaded once)
+t0 = time.perf_counter()
+o = db.run_se(b, per_read=False)
+t_one = time.perf_counter() - t0
+lines1, fsa1 = [lines[0]], []
+for r in o["rows"]:
+    if r.significant:
+        t = r.template_id
+        line = db.res_line(names[t - 1], r, o["cover"][t], o["aln_len"][t], o["depth"][t])
+        if line:
+            lines1.append(line)
+            fsa1.append((names[t - 1], o["consensus"][t]))
+print(f"kmahip_run_se: {t_one:.3f} s  (upload {o['ms'][0]:.0f} ms, stages 2+3a {o['ms'][1]:.0f}, ConClave+stats {o['ms'][2]:.0f}, traceback {o['ms'][3]:.0f}, "
+      f"pile-up+consensus {o['ms'][4]:.0f}, copies {o['ms'][5]:.0f});  res identical: {''.join(lines1) == ref_res}  consensus identical: {golden_util.fsa_text(fsa1) == ref_fsa}")
+if "".join(lines1) != ref_res:
+    sys.exit(1)
 if "".join(lines) != ref_res:
     for a, c in zip("".join(lines).splitlines(), ref_res.splitlines()):
         if a != c:
