@@ -51,15 +51,17 @@ struct PileArgs {
 };
 
 // oriented read base (0-3, 4 = N): the read as ConClave filed it
-struct Q { const uint64_t *w; const int32_t *N; int L, nN, rc; };
-__device__ __forceinline__ int q_base(const Q &q, int i) {
+struct Q { const uint64_t *w; const int32_t *N; int L, nN, rc; int cw; uint64_t cv; };     // cw / cv: the word read last
+__device__ __forceinline__ int q_base(Q &q, int i) {
 	const int p = q.rc ? q.L - 1 - i : i;
 	if(q.nN) {
 		int lo = 0, hi = q.nN;
 		while(lo < hi) { const int mid = (lo + hi) >> 1; if(q.N[mid] < p) lo = mid + 1; else hi = mid; }
 		if(lo < q.nN && q.N[lo] == p) return 4;
 	}
-	const int b = (int) ((q.w[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
+	// one load per 32 bases, not per base: the increments in between are atomics the compiler will not move a load across
+	if((p >> 5) != q.cw) { q.cw = p >> 5; q.cv = q.w[p >> 5]; }
+	const int b = (int) ((q.cv >> (62 - ((p & 31) << 1))) & 3ull);
 	return q.rc ? 3 - b : b;
 }
 
@@ -71,14 +73,22 @@ __global__ __launch_bounds__(256) void pile_filed_kernel(const int32_t *tmpl, in
 // sort key: template, then the order the reference assembles the reads of a template in
 __global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(r >= A.n_reads) return;
-	if(A.stats[10 * r + 3] == 0) return;          // dropped by the read filter (or no template)
+	// kept = has a template and passed the read filter; one atomic per wavefront (millions of single increments of one
+	// counter queue up on its L2 line: 250 ms for 4 M reads)
+	const bool keep = r < A.n_reads && A.stats[10 * r + 3] != 0;
+	const unsigned long long m = __ballot(keep);
+	if(!m) return;
+	const int lane = threadIdx.x & 63, leader = __ffsll((long long) m) - 1;
+	unsigned long long base = 0;
+	if(lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long) __popcll(m));
+	base = __shfl(base, leader);
+	if(!keep) return;
 	const uint64_t t = (uint64_t) abs(A.tmpl[r]);
 	// rank among the fragments ConClave filed (conclave.c:166, 194) -> chunk of max_frag, reverse order inside the chunk
 	const int64_t rk = A.rank[r];
 	const uint64_t chunk = (uint64_t) (rk / A.max_frag), in = (uint64_t) (rk % A.max_frag);
 	const uint64_t ord = chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
-	const unsigned long long slot = atomicAdd(&A.counters[0], 1ull);
+	const unsigned long long slot = base + (unsigned long long) __popcll(m & ((1ull << lane) - 1ull));
 	A.keys[slot] = (t << 40) | ord;
 	A.vals[slot] = (int32_t) r;
 }
@@ -90,6 +100,13 @@ __global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys
 	if(i == 0 || (int64_t) (keys[i - 1] >> 40) != t) seg_start[t] = (int32_t) i;
 }
 
+// Everything a template's workgroup shares lives in HBM and is read back by other threads of the SAME workgroup after a
+// barrier. The increments are atomics (performed in L2); the few plain loads that must see them -- chain links, column
+// depths -- go to L2 as well (agent-scope relaxed atomic loads) instead of invalidating the caches: a device-scope
+// __threadfence() per phase writes back and invalidates the XCD's whole L2 and cost 0.5 ms a piece.
+template <class T> __device__ __forceinline__ T ld_l2(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
 struct Walk {
 	const PileArgs &A;
 	int64_t tbase;
@@ -98,16 +115,16 @@ struct Walk {
 	__device__ __forceinline__ InsNode &node(int cur) const { return A.nodes[cur - t_len - 1]; }    // 1-based ids: cur = t_len + id
 	// the column after `cur` in ring order
 	__device__ int next(int cur) const {
-		if(is_node(cur)) { const InsNode &n = node(cur); return n.next ? t_len + n.next : n.gaps; }
+		if(is_node(cur)) { const InsNode &n = node(cur); const int nx = ld_l2(&n.next); return nx ? t_len + nx : ld_l2(&n.gaps); }
 		const int np = (cur + 1 == t_len) ? 0 : cur + 1;
-		const int h = A.chain_head[tbase + np];
+		const int h = ld_l2(&A.chain_head[tbase + np]);
 		return h ? t_len + h : np;
 	}
 	__device__ __forceinline__ uint32_t *counts(int cur) const { return is_node(cur) ? node(cur).c : A.counts + 6 * (tbase + cur); }
 	__device__ int depth16(int cur) const {
 		const uint32_t *c = counts(cur);
 		int s = 0;
-		for(int j = 0; j < 6; ++j) s += (int) min(c[j], 65535u);
+		for(int j = 0; j < 6; ++j) s += (int) min(ld_l2(&c[j]), 65535u);
 		return s;
 	}
 };
@@ -122,6 +139,7 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 	Q q;
 	q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
 	q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
+	q.cw = -1; q.cv = 0;
 	int start = st[1], qp = st[4], first = 0;
 	// trim trailing / leading gap runs (assembly.c:1340-1354); column 0 is never trimmed from the back
 	while(n > 1 && (A.ops[o + n - 1] & 3u) >= 2u) --n;
@@ -141,6 +159,9 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 		const uint32_t run = A.ops[o + j];
 		const int cls = (int) (run & 3u);
 		int left = (int) (run >> 2);
+		// '=' and 'X' runs are the same thing here (an aligned pair: the read's base is counted): taken as ONE stretch, so
+		// that the lanes of a wavefront -- reads with their mismatches in different places -- stay in step
+		if(cls < 2) while(j + 1 < n && (A.ops[o + j + 1] & 3u) < 2u) { ++j; left += (int) (A.ops[o + j] >> 2); }
 		while(left > 0) {
 			if(cls == 2) {
 				if(!EXACT) return;                                  // cannot happen: such reads are piled up alone
@@ -152,7 +173,7 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 					// new columns in front of template position `gaps` (assembly.c:1368-1428)
 					const int gaps = cur;
 					int last = gaps ? gaps - 1 : W.t_len - 1;
-					for(int h = A.chain_head[W.tbase + gaps]; h; h = A.nodes[h - 1].next) last = W.t_len + h;
+					for(int h = ld_l2(&A.chain_head[W.tbase + gaps]); h; h = ld_l2(&A.nodes[h - 1].next)) last = W.t_len + h;
 					int myBias = W.depth16(last);
 					const int tmp = W.depth16(gaps);
 					myBias = (tmp < myBias) ? tmp : (myBias - 1);
@@ -163,7 +184,7 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 						InsNode &nn = A.nodes[id - 1];
 						for(int x = 0; x < 6; ++x) nn.c[x] = 0;
 						nn.c[5] = (uint32_t) myBias; nn.c[q_base(q, qp++)] = 1; nn.next = 0; nn.gaps = gaps;
-						__threadfence();
+						wg_fence();
 						if(W.is_node(last)) W.node(last).next = (int32_t) id; else A.chain_head[W.tbase + gaps] = (int32_t) id;
 						last = W.t_len + (int) id;
 						--left;
@@ -173,6 +194,25 @@ __device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has
 			} else if(W.is_node(cur)) {                             // existing insertion column this read lacks
 				atomicAdd(&W.counts(cur)[5], 1u);
 				cur = W.next(cur);
+			} else if(cur + 1 < W.t_len) {
+				// plain template columns, up to eight at a time: the chain heads in front of the next positions are fetched
+				// together (one round trip instead of one per column); the walk stops behind the first position that has one
+				const int m = min(min(left, 8), W.t_len - 1 - cur);
+				int32_t hd[8];
+#pragma unroll
+				for(int i = 0; i < 8; ++i) hd[i] = i < m ? ld_l2(&A.chain_head[W.tbase + cur + 1 + i]) : 0;
+				int done = 0, to = 0;
+#pragma unroll
+				for(int i = 0; i < 8; ++i) {
+					if(i < m && !to) {
+						const int b = cls == 3 ? 5 : q_base(q, qp++);
+						atomicAdd(&A.counts[6 * (W.tbase + cur + i) + b], 1u);
+						++done;
+						if(hd[i]) to = W.t_len + hd[i];
+					}
+				}
+				left -= done;
+				cur = to ? to : cur + done;
 			} else {
 				const int b = cls == 3 ? 5 : q_base(q, qp++);
 				atomicAdd(&W.counts(cur)[b], 1u);
@@ -217,14 +257,23 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 					if(w == (cur >> 6)) x &= ~0ull << (cur & 63);
 					if(x) { nxt = (w << 6) + __ffsll((long long) x) - 1; break; }
 				}
+#ifdef KMAHIP_DIAG
+				const unsigned long long c0 = wall_clock64();
+#endif
 				if(valid && tid >= cur && tid < nxt) pile_read<false>(A, W, r, nullptr);
-				__threadfence();
+				wg_fence();
 				__syncthreads();
+#ifdef KMAHIP_DIAG
+				const unsigned long long c1 = wall_clock64();
+#endif
 				if(nxt < PILE_THREADS) {
 					if(tid == nxt) pile_read<true>(A, W, r, nullptr);
-					__threadfence();
+					wg_fence();
 					__syncthreads();
 				}
+#ifdef KMAHIP_DIAG
+				if(tid == 0 && blockIdx.x == 7) { atomicAdd(&A.counters[10], c1 - c0); atomicAdd(&A.counters[11], wall_clock64() - c1); atomicAdd(&A.counters[12], 1ull); }
+#endif
 				cur = nxt + 1;
 			}
 			__syncthreads();
@@ -331,6 +380,15 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		return KMAHIP_EOVERFLOW;
 	}
 	ws->p_nodes_used = (int64_t) c[2];
+#ifdef KMAHIP_DIAG
+	{
+		unsigned long long dbg[3];
+		HIP_TRY(hipMemcpy(dbg, ws->counters + 10, sizeof dbg, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemset(ws->counters + 10, 0, sizeof dbg));
+		fprintf(stderr, "[kmahip] pile-up workgroup 7: %llu phases, parallel part %.1f us, serial part %.1f us per phase (100 MHz clock)\n", dbg[2],
+		        dbg[2] ? dbg[0] / 100.0 / dbg[2] : 0.0, dbg[2] ? dbg[1] / 100.0 / dbg[2] : 0.0);
+	}
+#endif
 	return KMAHIP_OK;
 }
 

@@ -29,7 +29,8 @@ formats.write_index(prefix, names, seqs)
 base, _, _, _ = synth.make_reads(seqs, n, seed=99)
 rng = np.random.default_rng(5)
 reads = [r for r in base]
-for i in rng.choice(n, size=n // 40, replace=False):          # 2.5 % of the reads get an indel or two
+indel_div = int(os.environ.get("KMAHIP_VALIDATE_INDEL_DIV", "40"))     # every 40th read (2.5 %) gets an indel or two
+for i in rng.choice(n, size=(n // indel_div if indel_div > 0 else 0), replace=False):
     r = reads[i]
     parts, j = [], 0
     while j < len(r):
