@@ -2179,9 +2179,11 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	// move matrix per lane: a banded tail (band 64 + 64) or a full join whose shorter side is within the band
 	int64_t e_cap = std::max<int64_t>((int64_t) 134 * (max_len + 68), (int64_t) (max_len / 2 + 4) * (max_len + 4));
 	e_cap = std::min<int64_t>(e_cap, 16ll << 20);
-	int64_t lanes = 65536;
+	// one lane per read in flight; the kernel is bound by dependent loads, so it wants every wave slot of the chip (4 per SIMD
+	// at its register count = 262 144 lanes): 10 GB of scratch for 150-base reads, shrunk for longer ones to stay within 24 GB
+	int64_t lanes = 262144;
 	const int64_t per_lane = e_cap + (int64_t) (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4;
-	while(lanes > 256 && lanes * per_lane > (6ll << 30)) lanes >>= 1;
+	while(lanes > 256 && lanes * per_lane > (24ll << 30)) lanes >>= 1;
 	lanes = std::min<int64_t>(lanes, ((n + 255) / 256) * 256);
 	if(ws->t_lanes != lanes || ws->t_max_len != max_len) {
 		(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
