@@ -98,3 +98,16 @@ if "".join(lines) != ref_res:
             print("ref :", c)
             break
     sys.exit(1)
+
+# diagnostic build only (KMAHIP_LIB=kma_amd/libkmahip_diag.so): where the DP problems of stage 3a went
+import ctypes
+L = binding.lib()
+if hasattr(L, "kmahip_diag_hist"):
+    buf = (ctypes.c_uint64 * 256)()
+    L.kmahip_diag_hist(buf, 1)
+    db.set_timing(True)
+    db.map_se(b)
+    v = list(buf) if not L.kmahip_diag_hist(buf, 0) else list(buf)
+    print("stage 3a DP problems: queued tiny / narrow / wide:", v[200:203], " queue full:", v[204:207], " solved outside the queues:", v[208],
+          "cells there:", v[209], "of them >= 64 columns:", v[210])
+    print("kernel ms (scan, align, prefilter, seed):", [round(db.get_timing(i)[0], 2) for i in range(4)])
