@@ -526,7 +526,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			int *qu = tiny ? L.queue + (2 + (QCAP + QCAPN) * QENT) : narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
 			const int slot = atomicAdd(&qu[0], 1);
 #ifdef KMAHIP_DIAG
-			if(g_diag_hist) atomicAdd(&g_diag_hist[200 + (tiny ? 0 : narrow ? 1 : 2) + (slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP) ? 0 : 4)], 1ull);
+			if(L.cnt && g_diag_hist) atomicAdd(&g_diag_hist[200 + (tiny ? 0 : narrow ? 1 : 2) + (slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP) ? 0 : 4)], 1ull);
 #endif
 			if(slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP)) {
 				int *e = qu + 1 + slot * QENT;
@@ -537,7 +537,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			}
 		}
 #ifdef KMAHIP_DIAG
-		if(g_diag_hist) { atomicAdd(&g_diag_hist[208], 1ull); atomicAdd(&g_diag_hist[209], (unsigned long long) max(0, tspan) * (q_e - q_s)); if(q_e - q_s >= WCOLS) atomicAdd(&g_diag_hist[210], 1ull); }
+		if(L.cnt && g_diag_hist) { atomicAdd(&g_diag_hist[208], 1ull); atomicAdd(&g_diag_hist[209], (unsigned long long) max(0, tspan) * (q_e - q_s)); if(q_e - q_s >= WCOLS) atomicAdd(&g_diag_hist[210], 1ull); }
 		if(L.ablate & 128) return nw_degenerate(tspan, 0, L.U, L.W1);     // ablation: nothing that misses the queues
 #endif
 		if(q_e - q_s < WCOLS && tspan + (q_e - q_s) < 1000) {
@@ -727,8 +727,9 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 			}
 			const int *drow = L.d + 5 * (int) tbuf[m];
 #pragma unroll
-			for(int j = XC - 1; j >= 0; --j) {
-				if(c0 + j < 0) continue;
+			for(int jj = 0; jj < XC; ++jj) {
+				const int j = XC - 1 - jj;          // right to left; indices are compile-time after unrolling (arrays stay in registers)
+				if(c0 + j >= 0) {
 				int Q = rD + W1, P = lD[j] + W1, D, mv;
 				bool ob = false;
 				if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
@@ -747,6 +748,7 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 				lD[j] = D; lP[j] = P; lTD[j] = TD; lTP[j] = TP; lQ[j] = Q; lTQ[j] = TQ;
 				rD = D; rQ = Q; rTD = TD; rTQ = TQ;
 				if(c0 + j == 0 && k < 0 && best < D) { best = D; bestTD = TD; }
+				}
 			}
 		}
 	}
@@ -1234,6 +1236,9 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- phase A -------------------------------------------------------------------------------
+#ifdef KMAHIP_DIAG
+		const unsigned long long dbg_t0 = wall_clock64();
+#endif
 		int kind = 0;                  // 0 nothing, 1 single record, 2 couple
 		Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
 		int tmpl_out = 0, t_len = 0, qlen0 = 0, qlen1 = 0;
@@ -1312,9 +1317,15 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 			}
 			if(status) atomicMax(&A.counters[1], 3ull);
 		}
+#ifdef KMAHIP_DIAG
+		if(have) atomicMax(&A.counters[13], ((wall_clock64() - dbg_t0) << 32) | (unsigned long long) (task & 0xFFFFFFFFll));      // slowest phase A (10 ns ticks) and its task
+#endif
 		// ---- phase B: deferred wide DP problems, whole wave -----------------------------------------
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 		__builtin_amdgcn_wave_barrier();
+#ifdef KMAHIP_DIAG
+		const unsigned long long dbg_t1 = wall_clock64();
+#endif
 		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
 		for(int e = 0; e < nqx; ++e) {
 			nw_coop_x(L, A.db, A, queueX, e, tbuf);
@@ -1339,6 +1350,9 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				if(ent[11]) S.pos -= ent[3] - ent[5];
 			}
 		}
+#ifdef KMAHIP_DIAG
+		if(lane == 0) atomicMax(&A.counters[14], ((wall_clock64() - dbg_t1) << 32) | (unsigned long long) (task & 0xFFFFFFFFll));         // slowest phase B
+#endif
 		// ---- phase C ---------------------------------------------------------------------------------
 		if(!have) continue;
 		if(PEM && kind == 2) {
@@ -2102,6 +2116,16 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		if(!ws->events2) ws->events2 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
 		ws->events2->push_back({ev0, ev1});
 	}
+#ifdef KMAHIP_DIAG
+	if(getenv("KMAHIP_DEBUG_TIMING")) {
+		unsigned long long dbg[2];
+		HIP_TRY(hipStreamSynchronize(stream));
+		HIP_TRY(hipMemcpy(dbg, ws->counters + 13, sizeof dbg, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemset(ws->counters + 13, 0, sizeof dbg));
+		fprintf(stderr, "[kmahip] align: slowest phase A %.1f us (task %llu), slowest phase B %.1f us (round of task %llu)\n",
+		        (dbg[0] >> 32) / 100.0, dbg[0] & 0xFFFFFFFFull, (dbg[1] >> 32) / 100.0, dbg[1] & 0xFFFFFFFFull);
+	}
+#endif
 	ReduceArgs R;
 	R.n_reads = n; R.rc_flag = cands->rc_flag; R.flag = cands->flag; R.T_off = cands->T_off; R.T = cands->T;
 	R.t_score = A.t_score; R.t_alen = A.t_alen; R.t_start = A.t_start; R.t_end = A.t_end; R.t_norm = A.t_norm; R.t_tmpl = A.t_tmpl;

@@ -111,3 +111,45 @@ if hasattr(L, "kmahip_diag_hist"):
     print("stage 3a DP problems: queued tiny / narrow / wide:", v[200:203], " queue full:", v[204:207], " solved outside the queues:", v[208],
           "cells there:", v[209], "of them >= 64 columns:", v[210])
     print("kernel ms (scan, align, prefilter, seed):", [round(db.get_timing(i)[0], 2) for i in range(4)])
+    L.kmahip_diag_hist(buf, 1)
+    db.set_stats(True)
+    db.map_se(b)
+    db.set_stats(False)
+    L.kmahip_diag_hist(buf, 0)
+    v = list(buf)
+    print("DP calls by q_len :", {i: v[i] for i in range(64) if v[i]})
+    print("DP cells by q_len :", {i: v[64 + i] for i in range(64) if v[64 + i]})
+    print("DP calls by t_len/4:", {4 * i: v[136 + i] for i in range(64) if v[136 + i]})
+    t_id = int(os.environ.get("KMAHIP_TASK", "-1"))
+    if t_id >= 0:
+        (rc_flag2, flag2, T_off2, T2), h2 = db.map_se(b)
+        r_id = int(np.searchsorted(T_off2, t_id, side="right") - 1)
+        print(f"task {t_id}: read {r_id}, length {int(b.length[r_id])}, rc_flag {int(rc_flag2[r_id])}, flag {int(flag2[r_id])}, candidates "
+              f"{T2[T_off2[r_id]:T_off2[r_id + 1]].tolist()}, this one {int(T2[t_id])}, template length {int(formats.read_lengths(prefix)[abs(int(T2[t_id]))])}, "
+              f"hits {int(h2['n_hits'][r_id])}, best {int(h2['best_score'][r_id])}")
+        print("read:", "".join("ACGTN"[c] for c in reads[r_id]))
+        w0 = t_id & ~63
+        for tt in range(w0, w0 + 64):
+            rr = int(np.searchsorted(T_off2, tt, side="right") - 1)
+            if int(rc_flag2[rr]) < 140 or int(b.length[rr]) != 150:
+                print(f"  task {tt}: read {rr} len {int(b.length[rr])} rc_flag {int(rc_flag2[rr])} tmpl {int(T2[tt])} hits {int(h2['n_hits'][rr])} best {int(h2['best_score'][rr])}",
+                      "".join("ACGTN"[c] for c in reads[rr]))
+        # which read of that wavefront is the slow one: each alone, align kernel time
+        slow = []
+        for rr in sorted({int(np.searchsorted(T_off2, tt, side="right") - 1) for tt in range(w0, w0 + 64)}):
+            one = formats.pack_ragged([reads[rr]])
+            db.get_timing(1); db.get_timing(3)
+            db.map_se(one)
+            slow.append((round(db.get_timing(1)[0], 3), rr, len(reads[rr])))
+        slow.sort(reverse=True)
+        print("slowest single-read align kernels (ms, read, length):", slow[:6])
+        one = formats.pack_ragged([reads[slow[0][1]]])
+        L.kmahip_diag_hist(buf, 1)
+        db.set_stats(True)
+        db.map_se(one)
+        db.set_stats(False)
+        L.kmahip_diag_hist(buf, 0)
+        v = list(buf)
+        print("slowest read alone: DP calls by q_len", {i: v[i] for i in range(64) if v[i]}, "cells", {i: v[64 + i] for i in range(64) if v[64 + i]},
+              "by t_len/4", {4 * i: v[136 + i] for i in range(64) if v[136 + i]}, "mode", {i - 2: v[128 + i] for i in range(5) if v[128 + i]},
+              "queued", v[200:203], "full", v[204:207], "outside", v[208], v[209], v[210], "align stats", [getattr(db.get_align_stats(), f) for f in ("lookups", "mem_bases", "dp_cells", "tasks")])
