@@ -560,6 +560,25 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 		gr.d = &ROWD(L, 0); gr.p = &ROWP(L, 0); gr.td = &ROWTD(L, 0); gr.tp = &ROWTP(L, 0); gr.stride = 1;
 		return nw_full(gr, L, ts, t_len, q, k, t_s, t_e, q_s, q_e);
 	}
+	{
+		// banded problems of the same size go to the same queue (a read end that matches nothing: both sides beyond the band),
+		// unless the reference's last-row scan (k == -2) would read cells of its row buffer beyond the boundary column
+		const int ql = q_e - q_s;
+		int b2 = band + (band & 1);
+		const int cfin = ((tspan + ql) >> 1) - (tspan - 1);
+		const bool stale_scan = k == -2 && !(cfin + (b2 >> 1) < ql - 1);
+		if(L.queue && ql < 64 * XC && tspan <= TBUF && tspan + ql < 1000 && band < (1 << 20) && !stale_scan) {
+			int *qu = L.queue + (3 + (QCAP + QCAPN + QCAPT) * QENT);
+			const int slot = atomicAdd(&qu[0], 1);
+			if(slot < QCAPX) {
+				int *e = qu + 1 + slot * QENT;
+				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
+				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = ((k < 0) ? 1 : 0) | (band << 1);
+				Aln z = {0, 0, 0, 0, 0, 0};
+				return z;
+			}
+		}
+	}
 	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
 }
 
@@ -665,14 +684,22 @@ __device__ void nw_coop(const Lane &L, const DevDB &db, const AlignArgs &A, int 
 	}
 }
 
-// The same for ONE problem of 64 .. 64 * XC - 1 columns: lane n owns XC neighbouring columns (aligned to the right end, so
+// The same for ONE problem of up to 64 * XC - 1 columns: lane n owns XC neighbouring columns (aligned to the right end, so
 // only lane 0 can own fewer) and takes them right to left inside a step; between lanes the sweep is the anti-diagonal one
 // of nw_coop -- the right neighbour (m, c+1) and the diagonal (m+1, c+1) of a lane's last column come from the first
 // column of the lane to its right, one and two steps old.
+// band > 0: NW_band_score (nw.c:892-1188) on the same sweep. In query coordinates the banded recurrences are the full ones
+// restricted to the columns [c - band/2, c + band/2] of each row (c = (t_len + q_len)/2 at the last row, one less per row),
+// with three differences: the leftmost cell of a row has no template-gap state (nw.c:1079-1105); where the band ends before
+// the last column its right neighbour is a virtual cell (D = low, walk counter = one query gap more than the cell below
+// it); the result is read off the leftmost cells. A column outside the band simply keeps its last value, which is exactly
+// what the neighbouring column then needs (the cell below the virtual one, the diagonal of the band's last column).
+template <bool banded>
 __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, int *qu, int ent, uint8_t *tbuf) {
 	const int lane = threadIdx.x & 63;
 	int *e = qu + 1 + ent * QENT;
 	const int k = e[2], t_s = e[3], t_e = e[4], q_s = e[5], q_e = e[6], at = e[7];
+	int band = banded ? (e[11] >> 1) : 0;
 	const int64_t rd = ((int64_t) e[9] << 32) | (uint32_t) e[8];
 	const int tlen_total = db.tlen[at];
 	const uint64_t *ts = db.tseq + db.tseq_off[at];
@@ -682,7 +709,10 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 	const int U = L.U, W1 = L.W1;
 	const uint32_t MA = 1u, TG = 1u << 10, QG = 1u << 20;
 	const int low = (t_len + q_len) * (L.MM + U + W1);
-	if(L.cnt && lane == 0) atomicAdd(&L.cnt[5], (unsigned long long) t_len * q_len);
+	if(band & 1) ++band;
+	const int half = band >> 1;
+	const int cbot = (t_len + q_len) >> 1;             // band centre of the last row (m = t_len - 1)
+	if(L.cnt && lane == 0) atomicAdd(&L.cnt[5], (unsigned long long) t_len * (banded ? band + 1 : q_len));
 	for(int i = lane; i < t_len; i += 64) {
 		int pos = t_s + i;
 		if(pos >= tlen_total) pos -= tlen_total;
@@ -706,66 +736,109 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 	}
 	int bD0 = 0;                                       // the row before `l` of this lane's first column, for the lane to the left
 	uint32_t bTD0 = 0;
-	int best = low;
+	int best = low, bm = 0;
 	uint32_t bestTD = 0;
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const int steps = t_len + nl - 1;
 	for(int d = 0; d < steps; ++d) {
-		int rD = __shfl_down(lD[0], 1), rQ = __shfl_down(lQ[0], 1), dD = __shfl_down(bD0, 1);
-		uint32_t rTD = __shfl_down(lTD[0], 1), rTQ = __shfl_down(lTQ[0], 1), dTD = __shfl_down(bTD0, 1);
+		// the first column of the lane to the right: its newest row (l) and the one before (b)
+		const int nD = __shfl_down(lD[0], 1), nQ = __shfl_down(lQ[0], 1), nbD = __shfl_down(bD0, 1);
+		const uint32_t nTD = __shfl_down(lTD[0], 1), nTQ = __shfl_down(lTQ[0], 1), nbTD = __shfl_down(bTD0, 1);
 		const int i = d - (nl - 1 - lane);
 		if(act && i >= 0 && i < t_len) {
 			const int m = t_len - 1 - i;
-			if(lane == nl - 1) {
+			// columns of this row: [eq, sq]; `virt`: the band ends before the last column
+			const int c = cbot - i;
+			const int eq = banded ? max(c - half, 0) : -1;
+			const bool virt = banded && c + half < q_len - 1;
+			const int sq = virt ? c + half : q_len - 1;
+			int rD, rQ, dD;
+			uint32_t rTD, rTQ, dTD;
+			// what the lane's last column sees to its right
+			const int cr = c0 + XC;                         // first column of the lane to the right (q_len for the last lane)
+			if(cr >= q_len) {
 				// boundary column q_len (nw.c:703-750, :757)
 				rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
 				rTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - m);
 				rTQ = 0; rQ = low;
 				if(m + 1 == t_len) { dD = 0; dTD = 0; }
 				else { dD = (0 < k) ? 0 : (W1 + (t_len - 2 - m) * U); dTD = (0 < k) ? 0u : QG * (uint32_t) (t_len - 1 - m); }
-			}
+			} else if(cr <= sq) { rD = nD; rQ = nQ; rTD = nTD; rTQ = nTQ; dD = nbD; dTD = nbTD; }   // it has done this row already
+			else { rD = low; rQ = low; rTQ = 0; rTD = QG + nTD; dD = nD; dTD = nTD; }                    // outside the band: virtual cell, `l` is the row below
 			const int *drow = L.d + 5 * (int) tbuf[m];
 #pragma unroll
 			for(int jj = 0; jj < XC; ++jj) {
 				const int j = XC - 1 - jj;          // right to left; indices are compile-time after unrolling (arrays stay in registers)
-				if(c0 + j >= 0) {
-				int Q = rD + W1, P = lD[j] + W1, D, mv;
-				bool ob = false;
-				if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
-				int x = rQ + U;
-				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
-				x = lP[j] + U;
-				if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
-				x = dD + drow[qc[j]];
-				if(D <= x) { D = x; mv = 1; }
-				const uint32_t TQ = TG + (ob ? rTD : rTQ);
-				const uint32_t TP = QG + (ob ? lTD[j] : lTP[j]);
-				const uint32_t TD = (mv == 1) ? (MA + dTD) : (mv >= 4 ? TP : TQ);
-				// what the column to the left needs: this cell as its right neighbour, the cell below it as its diagonal
-				dD = lD[j]; dTD = lTD[j];
-				if(j == 0) { bD0 = lD[0]; bTD0 = lTD[0]; }
-				lD[j] = D; lP[j] = P; lTD[j] = TD; lTP[j] = TP; lQ[j] = Q; lTQ[j] = TQ;
-				rD = D; rQ = Q; rTD = TD; rTQ = TQ;
-				if(c0 + j == 0 && k < 0 && best < D) { best = D; bestTD = TD; }
+				const int col = c0 + j;
+				if(col >= 0 && col >= eq && col <= sq) {
+					const int oD = lD[j];
+					const uint32_t oTD = lTD[j];
+					int D, Q, P;
+					uint32_t TD, TQ, TP;
+					if(col == eq) {
+						// leftmost cell of the band (nw.c:1079-1105): no template-gap state
+						int mv;
+						bool ob = false;
+						Q = rD + W1;
+						const int x = rQ + U;
+						if(Q < x) { Q = x; mv = 3; } else { mv = 2; ob = true; }
+						D = dD + drow[qc[j]];
+						if(Q <= D) mv = 1; else D = Q;
+						TQ = TG + (ob ? rTD : rTQ);
+						TD = (mv == 1) ? (MA + dTD) : TQ;
+						P = low; TP = 0;
+						if(eq == 0 && k < 0 && best < D) { best = D; bestTD = TD; bm = m; }
+					} else {
+						int mv;
+						bool ob = false;
+						Q = rD + W1; P = oD + W1;
+						if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
+						int x = rQ + U;
+						if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else ob = true;
+						x = lP[j] + U;
+						if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else ob = true;
+						x = dD + drow[qc[j]];
+						if(D <= x) { D = x; mv = 1; }
+						TQ = TG + (ob ? rTD : rTQ);
+						TP = QG + (ob ? oTD : lTP[j]);
+						TD = (mv == 1) ? (MA + dTD) : (mv >= 4 ? TP : TQ);
+						if(!banded && col == 0 && k < 0 && best < D) { best = D; bestTD = TD; }
+					}
+					if(j == 0) { bD0 = oD; bTD0 = oTD; }
+					lD[j] = D; lP[j] = P; lTD[j] = TD; lTP[j] = TP; lQ[j] = Q; lTQ[j] = TQ;
+					// for the column to the left: this cell is its right neighbour, the cell below it its diagonal
+					rD = D; rQ = Q; rTD = TD; rTQ = TQ; dD = oD; dTD = oTD;
+				} else if(col >= 0 && col == sq + 1) {
+					// first column outside the band: the virtual cell for the band's last column
+					rD = low; rQ = low; rTQ = 0; rTD = QG + lTD[j]; dD = lD[j]; dTD = lTD[j];
 				}
 			}
 		}
 	}
-	// result selection (nw.c:830-845). Column 0 lives in lane 0 at local index -c0.
-	const int j0 = nl * XC - q_len;
-	int D0 = lD[0];
-	uint32_t TD0 = lTD[0];
+	// result selection. Full: nw.c:830-845, banded: nw.c:1148-1170. Column `cres` (0, or the leftmost column of the last
+	// row's band) holds the final value; lane 0 tracked the best leftmost cell for k < 0.
+	const int cfin = cbot - (t_len - 1);
+	const int cres = banded ? max(cfin - half, 0) : 0;
+	const int sfin = (banded && cfin + half < q_len - 1) ? cfin + half : q_len - 1;
+	const int owner = nl - 1 - (q_len - 1 - cres) / XC;
+	int Dres = 0;
+	uint32_t TDres = 0;
 #pragma unroll
-	for(int j = 1; j < XC; ++j) if(j == j0) { D0 = lD[j]; TD0 = lTD[j]; }
-	int score = (k < 0) ? __shfl(best, 0) : __shfl(D0, 0);
-	uint32_t st = (k < 0) ? __shfl(bestTD, 0) : __shfl(TD0, 0);
+	for(int j = 0; j < XC; ++j) if(c0 + j == cres) { Dres = lD[j]; TDres = lTD[j]; }
+	Dres = __shfl(Dres, owner); TDres = __shfl(TDres, owner);
+	// the best cell was tracked by the owner of column 0 (lane 0)
+	int score = __shfl(best, 0);
+	uint32_t st = __shfl(bestTD, 0);
+	const int bm0 = __shfl(bm, 0);
+	if(banded) { if(bm0 == 0) { score = Dres; st = TDres; } }
+	else if(!(k < 0)) { score = Dres; st = TDres; }
 	if(k == -2) {
 		// for n ascending: if(score <= D[0][n]) take it -> the largest column holding the row maximum, if it is >= score
 		int mx = INT_MIN, mc = -1;
 		uint32_t mtd = 0;
 #pragma unroll
-		for(int j = 0; j < XC; ++j) if(act && c0 + j >= 0 && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; mtd = lTD[j]; }
+		for(int j = 0; j < XC; ++j) if(act && c0 + j >= cres && c0 + j <= sfin && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; mtd = lTD[j]; }
 		int wmx = mx;
 		for(int o = 32; o > 0; o >>= 1) wmx = max(wmx, __shfl_xor(wmx, o));
 		const unsigned long long who = __ballot(act && mc >= 0 && mx == wmx);
@@ -1328,7 +1401,8 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 #endif
 		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
 		for(int e = 0; e < nqx; ++e) {
-			nw_coop_x(L, A.db, A, queueX, e, tbuf);
+			if(queueX[1 + e * QENT + 11] >> 1) nw_coop_x<true>(L, A.db, A, queueX, e, tbuf);
+			else nw_coop_x<false>(L, A.db, A, queueX, e, tbuf);
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 		}
@@ -1347,7 +1421,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				// a task that bailed out after queueing (gap too large, align.c:715) keeps its failure value
 				if(S.len == 1 && S.match == 0 && S.score == 0) continue;
 				S.score += ent[2]; S.len += ent[3]; S.match += ent[4]; S.tGaps += ent[5]; S.qGaps += ent[6];
-				if(ent[11]) S.pos -= ent[3] - ent[5];
+				if(ent[11] & 1) S.pos -= ent[3] - ent[5];
 			}
 		}
 #ifdef KMAHIP_DIAG

@@ -155,3 +155,29 @@ def test_align_vs_oracle_partially_matching_reads(tmp_path):
         reads.append(np.ascontiguousarray(r.astype(np.uint8)))
     o = _vs_oracle(prefix, formats.pack_ragged(reads))
     assert (o["n_hits"] > 0).sum() > 300, int((o["n_hits"] > 0).sum())
+
+
+def test_align_vs_oracle_long_unaligned_ends_banded(tmp_path):
+    """Ends of 129 ... 200 foreign bases next to 500 ... 750 matching ones: both sides of the end problem exceed the band
+    (|dt - dq| + 64), so it is NW_band_score's -- solved on the cooperative sweep in query coordinates (nw_coop_x, band > 0),
+    incl. free-end modes at template starts / ends. The reads keep enough score to be hits, so the DP results are observable."""
+    names, seqs = synth.make_gene_db(n_families=10, variants=2, len_lo=1400, len_hi=2000, seed=31)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    rng = np.random.default_rng(7)
+    reads = []
+    for i in range(1200):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(500, 750))
+        a = int(rng.integers(0, len(s) - L)) if i % 5 else (0 if i % 10 else len(s) - L)     # every fifth at a template end
+        core = s[a:a + L].copy()
+        junk = rng.integers(0, 4, int(rng.integers(129, 201)), dtype=np.uint8)
+        r = np.concatenate([core, junk]) if i % 2 else np.concatenate([junk, core])
+        for _ in range(int(rng.integers(0, 3))):
+            p = int(rng.integers(0, len(r)))
+            r[p] = (r[p] + 1) & 3
+        if rng.random() < 0.5:
+            r = synth.revcomp_codes(r)
+        reads.append(np.ascontiguousarray(r.astype(np.uint8)))
+    o = _vs_oracle(prefix, formats.pack_ragged(reads))
+    assert (o["n_hits"] > 0).sum() > 600, int((o["n_hits"] > 0).sum())
