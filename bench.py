@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--parity-sample", type=int, default=50_000,
                     help="reads of the step re-checked against the CPU oracle (bounded by --cpu-sample; the oracle does ~0.1 M reads/s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--hard", action="store_true", help="NOT the BASELINE workload: 2 %% unmappable reads and 2 %% reads whose last "
+                    "60-120 bases are foreign (stress of the prefilter rejection and of the unaligned-end DP); for DESIGN.md only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -150,7 +152,8 @@ def main():
         db = binding.KmaHipDB(prefix, device=local)
         n = a.reads
         keep = min(n, a.cpu_sample) if rank == 0 else 0
-        rd = synth_dev.make_packed_reads(seqs, n, seed=1000 + rank, device=dev, keep_codes=keep)
+        rd = synth_dev.make_packed_reads(seqs, n, seed=1000 + rank, device=dev, keep_codes=keep,
+                                         random_frac=0.02 if a.hard else 0.0, junk_frac=0.02 if a.hard else 0.0)
         rc_flag = torch.empty(n, dtype=torch.int32, device=dev)
         flag = torch.empty(n, dtype=torch.int32, device=dev)
         T_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
@@ -270,7 +273,8 @@ def main():
             "config": {
                 "workload": f"{n} x 150 bp SE reads per GPU vs {5 * a.families}-gene DB (k=16), -1t1; one step = "
                             "stage 2 (k-mer probe + candidate-template scoring) + stage 3a (MEM seeding, chaining, "
-                            "NW extension, per-read hit selection, ConClave score vectors) on reads resident in HBM",
+                            "NW extension, per-read hit selection, ConClave score vectors) on reads resident in HBM"
+                            + ("; HARD MIX (not the BASELINE workload): 2 % unmappable reads, 2 % with 60-120 foreign end bases" if a.hard else ""),
                 "reads_per_gpu": n, "genes": 5 * a.families, "db_kmers": int(db.info.n_kmers),
                 "probe_table_MB": round(db.info.hash_bytes / 1e6, 1), "db_total_MB": round(db.info.total_bytes / 1e6, 1),
                 "stage2_candidate_fraction": cand / n, "mapped_fraction": mapped / n, "strand_tie_reads": ties,

@@ -233,7 +233,7 @@ constexpr int QCAP = 8;             // deferred wide problems (17..63 columns) p
 constexpr int QCAPN = 20;           // deferred narrow problems (9..16 columns)
 constexpr int QCAPT = 32;           // deferred tiny problems (2..8 columns): eight side by side per cooperative call
 constexpr int QENT = 12;            // ints per queue entry
-constexpr int QCAPX = 4;            // deferred extra-wide problems (64..255 columns): one per cooperative call, XC columns per lane
+constexpr int QCAPX = 12;           // deferred extra-wide problems (64..255 columns): one per cooperative call, XC columns per lane
 constexpr int XC = 4;
 constexpr int QINTS = 4 + (QCAP + QCAPN + QCAPT + QCAPX) * QENT;   // ints of one wave's four queues
 constexpr int TBUF = 1024;          // staged template bases per cooperative problem
@@ -694,7 +694,7 @@ __device__ void nw_coop(const Lane &L, const DevDB &db, const AlignArgs &A, int 
 // the last column its right neighbour is a virtual cell (D = low, walk counter = one query gap more than the cell below
 // it); the result is read off the leftmost cells. A column outside the band simply keeps its last value, which is exactly
 // what the neighbouring column then needs (the cell below the virtual one, the diagonal of the band's last column).
-template <bool banded>
+template <int XW, bool banded>
 __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, int *qu, int ent, uint8_t *tbuf) {
 	const int lane = threadIdx.x & 63;
 	int *e = qu + 1 + ent * QENT;
@@ -721,13 +721,13 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 	QView q;
 	q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = e[10];
 	q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
-	const int nl = (q_len + XC - 1) / XC;              // lanes in use
-	const int c0 = q_len - (nl - lane) * XC;           // this lane's first column (negative: lane 0 owns fewer than XC)
+	const int nl = (q_len + XW - 1) / XW;              // lanes in use
+	const int c0 = q_len - (nl - lane) * XW;           // this lane's first column (negative: lane 0 owns fewer than XW)
 	const bool act = lane < nl;
-	int qc[XC], lD[XC], lP[XC], lQ[XC];
-	uint32_t lTD[XC], lTP[XC], lTQ[XC];
+	int qc[XW], lD[XW], lP[XW], lQ[XW];
+	uint32_t lTD[XW], lTP[XW], lTQ[XW];
 #pragma unroll
-	for(int j = 0; j < XC; ++j) {
+	for(int j = 0; j < XW; ++j) {
 		const int c = c0 + j;
 		qc[j] = (act && c >= 0) ? qn(q, q_s + c) : 0;
 		// boundary row m = t_len
@@ -756,7 +756,7 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 			int rD, rQ, dD;
 			uint32_t rTD, rTQ, dTD;
 			// what the lane's last column sees to its right
-			const int cr = c0 + XC;                         // first column of the lane to the right (q_len for the last lane)
+			const int cr = c0 + XW;                         // first column of the lane to the right (q_len for the last lane)
 			if(cr >= q_len) {
 				// boundary column q_len (nw.c:703-750, :757)
 				rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
@@ -768,8 +768,8 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 			else { rD = low; rQ = low; rTQ = 0; rTD = QG + nTD; dD = nD; dTD = nTD; }                    // outside the band: virtual cell, `l` is the row below
 			const int *drow = L.d + 5 * (int) tbuf[m];
 #pragma unroll
-			for(int jj = 0; jj < XC; ++jj) {
-				const int j = XC - 1 - jj;          // right to left; indices are compile-time after unrolling (arrays stay in registers)
+			for(int jj = 0; jj < XW; ++jj) {
+				const int j = XW - 1 - jj;          // right to left; indices are compile-time after unrolling (arrays stay in registers)
 				const int col = c0 + j;
 				if(col >= 0 && col >= eq && col <= sq) {
 					const int oD = lD[j];
@@ -821,11 +821,11 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 	const int cfin = cbot - (t_len - 1);
 	const int cres = banded ? max(cfin - half, 0) : 0;
 	const int sfin = (banded && cfin + half < q_len - 1) ? cfin + half : q_len - 1;
-	const int owner = nl - 1 - (q_len - 1 - cres) / XC;
+	const int owner = nl - 1 - (q_len - 1 - cres) / XW;
 	int Dres = 0;
 	uint32_t TDres = 0;
 #pragma unroll
-	for(int j = 0; j < XC; ++j) if(c0 + j == cres) { Dres = lD[j]; TDres = lTD[j]; }
+	for(int j = 0; j < XW; ++j) if(c0 + j == cres) { Dres = lD[j]; TDres = lTD[j]; }
 	Dres = __shfl(Dres, owner); TDres = __shfl(TDres, owner);
 	// the best cell was tracked by the owner of column 0 (lane 0)
 	int score = __shfl(best, 0);
@@ -838,7 +838,7 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 		int mx = INT_MIN, mc = -1;
 		uint32_t mtd = 0;
 #pragma unroll
-		for(int j = 0; j < XC; ++j) if(act && c0 + j >= cres && c0 + j <= sfin && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; mtd = lTD[j]; }
+		for(int j = 0; j < XW; ++j) if(act && c0 + j >= cres && c0 + j <= sfin && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; mtd = lTD[j]; }
 		int wmx = mx;
 		for(int o = 32; o > 0; o >>= 1) wmx = max(wmx, __shfl_xor(wmx, o));
 		const unsigned long long who = __ballot(act && mc >= 0 && mx == wmx);
@@ -1401,8 +1401,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 #endif
 		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
 		for(int e = 0; e < nqx; ++e) {
-			if(queueX[1 + e * QENT + 11] >> 1) nw_coop_x<true>(L, A.db, A, queueX, e, tbuf);
-			else nw_coop_x<false>(L, A.db, A, queueX, e, tbuf);
+			// two columns per lane up to 128 columns (half the cells per step), four beyond
+			const int *xe = queueX + 1 + e * QENT;
+			const bool bnd = (xe[11] >> 1) != 0, wide2 = xe[6] - xe[5] <= 128;
+			if(bnd) { if(wide2) nw_coop_x<2, true>(L, A.db, A, queueX, e, tbuf); else nw_coop_x<4, true>(L, A.db, A, queueX, e, tbuf); }
+			else { if(wide2) nw_coop_x<2, false>(L, A.db, A, queueX, e, tbuf); else nw_coop_x<4, false>(L, A.db, A, queueX, e, tbuf); }
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 		}

@@ -13,7 +13,7 @@ import torch
 
 
 def make_packed_reads(seqs, n_reads, read_len=150, sub_rate=0.005, rc_frac=0.5, random_frac=0.0,
-                      seed=1, device="cuda", chunk=1 << 20, keep_codes=0):
+                      seed=1, device="cuda", chunk=1 << 20, keep_codes=0, junk_frac=0.0):
     """-> dict(seq i64[n*(W+1)], seq_off i64[n+1], length i32[n], N i32[1], N_off i64[n+1], codes u8[keep_codes, L])"""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -43,6 +43,13 @@ def make_packed_reads(seqs, n_reads, read_len=150, sub_rate=0.005, rc_frac=0.5, 
             r = torch.where(mut, (r + add) & 3, r)
         rc = torch.rand(m, generator=g, device=device) < rc_frac
         r = torch.where(rc[:, None], 3 - r.flip(1), r)
+        if junk_frac > 0:
+            # reads that match their gene only in part: the last 60 ... 120 bases replaced by foreign sequence (adapters,
+            # chimeras) -- the unaligned-end DP problems of stage 3a
+            jk = torch.rand(m, generator=g, device=device) < junk_frac
+            cut = read_len - torch.randint(60, 121, (m,), generator=g, device=device)
+            rr = torch.randint(0, 4, r.shape, generator=g, device=device, dtype=torch.uint8)
+            r = torch.where(jk[:, None] & (ar[None, :] >= cut[:, None]), rr, r)
         if random_frac > 0:
             rnd = torch.rand(m, generator=g, device=device) < random_frac
             rr = torch.randint(0, 4, r.shape, generator=g, device=device, dtype=torch.uint8)

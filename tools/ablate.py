@@ -20,7 +20,8 @@ prefix = os.path.join(tmp, "db")
 formats.write_index(prefix, names, seqs)
 db = binding.KmaHipDB(prefix)
 dev = torch.device("cuda", 0)
-rd = synth_dev.make_packed_reads(seqs, n, seed=1000, device=dev)
+hard = bool(os.environ.get("KMAHIP_HARD"))          # 2 % unmappable reads + 2 % reads with 60-120 foreign end bases
+rd = synth_dev.make_packed_reads(seqs, n, seed=1000, device=dev, random_frac=0.02 if hard else 0.0, junk_frac=0.02 if hard else 0.0)
 i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
 rc_flag, flag, T_off, T = i32(n), i32(n), torch.empty(n + 1, dtype=torch.int64, device=dev), i32(8 * n)
 n_hits, best, oflag = i32(n), i32(n), i32(n)
@@ -55,7 +56,7 @@ for name, sa in (("scan full", 0), ("scan no-machines", 1), ("scan no-probe(phas
     print(f"{name:32s} {t[0] + t[2]:8.2f} ms  (prefilter {t[2]:.2f} + scan {t[0]:.2f})")
 run(0, -1)  # restore real candidates
 for name, aa in (("align full", 0), ("align no-DP", 1), ("align no-wide(q>16)", 8), ("align no-1x1", 16), ("align no-2..16", 32),
-                 ("align only-1x1", 40), ("align only-2..16", 24), ("align only-wide", 48), ("align no-coop", 64), ("align no-chain+", 4), ("align no-seed+", 2)):
+                 ("align only-1x1", 40), ("align only-2..16", 24), ("align only-wide", 48), ("align no-coop", 64), ("align no-chain+", 4), ("align no-seed+", 2), ("align nothing outside the queues", 128)):
     print(f"{name:32s} {run(-1, aa)[1]:8.2f} ms")
 
 # DP problem histogram (stats launch)
@@ -76,5 +77,7 @@ if hasattr(L, "kmahip_diag_hist"):
     print("tasks", int(T_off[-1].item()))
     print("calls by q_len :", {i: v[i] for i in range(64) if v[i]})
     print("cells by q_len :", {i: v[64 + i] for i in range(64) if v[64 + i]})
+    print("queued tiny / narrow / wide:", v[200:203], " queue full:", v[204:207], " solved outside the queues:", v[208], "cells there:", v[209],
+          "of them >= 64 columns:", v[210])
     print("calls by mode k:", {i - 2: v[128 + i] for i in range(5)})
     print("calls by t_len/4:", {4 * i: v[136 + i] for i in range(64) if v[136 + i]})
