@@ -7,10 +7,15 @@
 //   alnFragsSE       alnfrags.c:1052-1218 NW_band_score   nw.c:892-1188
 //   update_Scores    updatescores.c:203-298
 //
-// Structure (new): one lane per task, grid-stride over the CSR candidate list
-// written by the scan stage; all per-lane working arrays (MEMs, DP rows) live
-// in an HBM scratch laid out [index][lane] so lanes of a wave that walk in step
-// touch consecutive addresses.  The DP keeps ONE row in place and no traceback
+// Structure (new): seed_tasks_kernel finds the MEMs of every
+// task at 8 waves / SIMD (one lane per task, up to 4 MEMs handed over); the main
+// kernel takes tasks 64 at a time from a device-wide counter, one lane per task:
+// chaining and stitching per lane (MEM arrays in an HBM scratch laid out
+// [index][lane]), every DP problem wider than one column deferred into per-wave LDS
+// queues and solved by the whole wave on anti-diagonal sweeps (nw_coop<8|16|64>: up to
+// 63 query columns, nw_coop_x: up to 255 columns, full and banded), the results added
+// back per lane.  The trace kernel of stage 3c (KMA(), align.c:214-507) is further down.
+// The DP keeps ONE row in place and no traceback
 // matrix: the reference fills a byte matrix E and then walks it only to count
 // (len, match, tGaps, qGaps); because that walk from a cell visits only cells
 // filled earlier, the counts of the walk from every cell are carried beside

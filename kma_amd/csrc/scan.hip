@@ -1,24 +1,31 @@
 // scan.hip -- stage 2 of KMA on gfx950: k-mer extraction, probe of the template
 // k-mer table in HBM and per-read candidate-template scoring for `-1t1`
-// single-end reads.  Behaviour restated from save_kmers (savekmers.c:2442-3065),
-// getBestMatch (savekmers.c:273-294) and hashMap_getGlobal (hashmapkma.c:149-178);
-// the structure is new:
+// single-end reads and `-apm p` pairs.  Behaviour restated from save_kmers
+// (savekmers.c:2442-3065), get_kmers_for_pair / save_kmers_penaltyPair
+// (:427-688, :3572-3777), getBestMatch (:273-294) and hashMap_getGlobal
+// (hashmapkma.c:149-178); the structure is new:
 //
-//   work item  = one (read, strand); 64 items (32 reads) per 256-thread workgroup
-//   phase 0    = prefilter: every k-th k-mer of every N-free segment is probed by
-//                4 lanes per item; a strand with no hit is dropped (:2477-2495)
-//   phase 1    = all 256 lanes probe every k-mer start of the active items; the
-//                value-set offset (or MISS) of each position goes to an LDS tile
-//                laid out [position][item] (conflict-free for both phases)
-//   phase 2    = one wavefront walks the tile, lane = item, running the
-//                sequential run-length score machine (:2511-2706) against a small
-//                per-item candidate table in LDS (id, score, last-hit position)
-//   overflow   = items whose candidate set exceeds the LDS table are redone by
-//                scan_dense_kernel with DB_size-wide tables in HBM
-//   combine    = per read strand pick / tie merge (:3037-3062) and CSR output
+//   work item  = one (read, strand)
+//   prefilter  = scan_prefilter_kernel: one lane per item probes every k-th k-mer
+//                (:2477-2495; presence bits in L2 for small databases); survivors go
+//                to a device-wide list, one global atomic per 512 items
+//   scan       = scan_se_kernel: 16 live items x 16 lanes per workgroup. Phase 1: each
+//                lane anchors its 9 k-mer starts with one hash probe and walks along the
+//                concatenated templates (`cat` / `vs_id`); every run of equal value
+//                lists ORs its positions into the mask of that LIST (16-slot table per
+//                item in LDS). Phase 2a: one thread per (item, list) reads the list once
+//                and ORs the mask into each listed TEMPLATE's mask. Phase 2b: one thread
+//                per (item, template) folds its mask into the score (what the reference's
+//                run-length machine :2511-2706 computes, per template instead of per
+//                position). Finish: best score + tied templates in first-seen order.
+//   overflow   = items with more than 14 candidates: scan_dense_kernel, the reference's
+//                own sequential formulation on DB_size-wide tables in HBM, one wavefront
+//                per item
+//   combine    = per read strand pick / tie merge (:3037-3062), CSR output; for pairs
+//                pair_penalty_kernel (getFirstPen / getSecondBestPen / getF_Best)
 //
-// Reverse strand k-mers are the reverse complement of forward k-mers read at the
-// mirrored position, so only the forward 2-bit words are ever staged.
+// The words of a read are staged in LDS in STRAND orientation, so no k-mer or walk
+// window is reverse-complemented after staging.
 #include "kmahip_internal.h"
 #include <cstdlib>
 #include <climits>
