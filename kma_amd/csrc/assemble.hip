@@ -281,6 +281,134 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 	}
 }
 
+
+// ---- consensus on the device: callConsensus + baseCaller (assembly.c:1499-1631, 162-179) per column. The one piece of
+// floating point in it, significantNuc's p_chisqr((X-Y)^2 / (X+Y)) <= evalue, is a monotone function of the quotient; the host
+// finds the smallest double q* with p_chisqr(q*) <= evalue by bisection in its own libm arithmetic (and checks the
+// neighbourhood for monotonicity), so the device only compares an IEEE double quotient with q*.
+struct ConsArgs {
+	DevDB db;
+	const uint32_t *counts;
+	const int32_t *chain_head;
+	const InsNode *nodes;
+	const int32_t *seg_start;
+	int64_t n_kept;
+	int bcd;
+	double qstar;
+	unsigned long long *cover, *aln_len, *depth, *asm_len;      // per template
+	char *cons;                  // pass 2: consensus characters
+	const int64_t *cons_off;     // pass 2: per template offset into cons (-1: none)
+};
+
+__device__ __forceinline__ unsigned char dev_lower(unsigned char c) { return (c >= 'A' && c <= 'Z') ? (unsigned char) (c + 32) : c; }
+
+__device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd, double qstar, long long *depth_out) {
+	const char bases[7] = {'A', 'C', 'G', 'T', 'N', '-', 0};
+	int cnt[6];
+	for(int j = 0; j < 6; ++j) cnt[j] = (int) min(c32[j], 65535u);
+	int bestNuc = tnuc;
+	const char tch = bases[tnuc];
+	int bestScore = cnt[bestNuc];
+	long long depthUpdate = 0;
+	for(int j = 0; j < 6; ++j) {
+		if(bestScore < cnt[j]) { bestScore = cnt[j]; bestNuc = j; }
+		depthUpdate += cnt[j];
+	}
+	unsigned char call = (unsigned char) bases[bestNuc];
+	if(!depthUpdate) call = '-';
+	else if(((long long) bestScore << 1) < depthUpdate) {
+		if(call == '-') {
+			int bb = cnt[4], b = 4;
+			for(int j = 0; j < 4; ++j) if(bb < cnt[j]) { bb = cnt[j]; b = j; }
+			call = dev_lower((unsigned char) bases[b]);
+		} else call = dev_lower(call);
+		bestScore = (int) (depthUpdate - cnt[5]);
+	} else if(depthUpdate < bcd) call = dev_lower(call);
+	if(depthUpdate == 0) call = '-';
+	else {
+		const int X = bestScore, Y = (int) depthUpdate - bestScore;
+		const bool sig = Y < X && ((double) ((long long) (X - Y) * (X - Y)) / (double) (X + Y)) >= qstar;
+		if(!sig) {
+			if(call == '-' && tch != '-' && bestScore != depthUpdate) call = 'n';
+			else call = dev_lower(call);
+		}
+	}
+	*depth_out = depthUpdate;
+	return call;
+}
+
+constexpr int CONS_THREADS = 256;
+
+// one workgroup per template with reads; ring order = template position p, then the insertion columns in front of p + 1
+template <bool WRITE>
+__global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs C) {
+	__shared__ int s_scan[CONS_THREADS];
+	__shared__ unsigned long long s_cover, s_aln, s_depth;
+	const int tid = threadIdx.x;
+	const int64_t D = C.db.DB_size;
+	for(int64_t t = 1 + blockIdx.x; t < D; t += gridDim.x) {
+		if(C.seg_start[t] >= C.n_kept) continue;           // uniform per workgroup
+		const int t_len = C.db.tlen[t];
+		const int64_t base = C.db.cat_off[t];
+		const uint64_t *ts = C.db.tseq + C.db.tseq_off[t];
+		const int64_t coff = WRITE ? C.cons_off[t] : -1;
+		if(tid == 0) { s_cover = 0; s_aln = 0; s_depth = 0; }
+		__syncthreads();
+		unsigned long long cover = 0, aln = 0, depth = 0;
+		int64_t running = 0;
+		for(int b = 0; b < t_len; b += CONS_THREADS) {
+			const int p = b + tid;
+			const bool valid = p < t_len;
+			int items = 0;
+			if(valid) {
+				const int np = (p + 1 == t_len) ? 0 : p + 1;
+				items = 1;
+				for(int h = C.chain_head[base + np]; h; h = C.nodes[h - 1].next) ++items;
+			}
+			// exclusive scan of `items` over the workgroup
+			s_scan[tid] = items;
+			__syncthreads();
+			for(int o = 1; o < CONS_THREADS; o <<= 1) {
+				const int v = tid >= o ? s_scan[tid - o] : 0;
+				__syncthreads();
+				s_scan[tid] += v;
+				__syncthreads();
+			}
+			const int incl = s_scan[tid], tot = s_scan[CONS_THREADS - 1];
+			__syncthreads();
+			if(valid) {
+				int64_t o = running + incl - items;
+				const int tnuc = (int) ((ts[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
+				long long dep = 0;
+				unsigned char call = call_column_dev(C.counts + (size_t) (base + p) * 6, tnuc, C.bcd, C.qstar, &dep);
+				if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
+				++o;
+				if(call != '-') {
+					depth += (unsigned long long) dep; ++aln;
+					const char up = (call >= 'a' && call <= 'z') ? (char) (call - 32) : (char) call;
+					if("ACGTN-"[tnuc] == up) ++cover;
+				}
+				const int np = (p + 1 == t_len) ? 0 : p + 1;
+				for(int h = C.chain_head[base + np]; h; h = C.nodes[h - 1].next) {
+					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, &dep);
+					if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
+					++o;
+					if(call != '-') { depth += (unsigned long long) dep; ++aln; }
+				}
+			}
+			running += tot;
+		}
+		if(WRITE) {
+			if(tid == 0 && coff >= 0) C.cons[coff + running] = 0;
+		} else {
+			atomicAdd(&s_cover, cover); atomicAdd(&s_aln, aln); atomicAdd(&s_depth, depth);
+			__syncthreads();
+			if(tid == 0) { C.cover[t] = s_cover; C.aln_len[t] = s_aln; C.depth[t] = s_depth; C.asm_len[t] = (unsigned long long) running; }
+		}
+		__syncthreads();
+	}
+}
+
 } // namespace
 
 static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64_t node_cap) {
@@ -456,6 +584,8 @@ static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, i
 	return call;
 }
 
+namespace { struct DevGuard { std::vector<void *> v; ~DevGuard() { for(void *p : v) (void) hipFree(p); } }; }
+
 extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                                const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
 	if(!db || !ws || !reads || !flag || !tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
@@ -517,6 +647,75 @@ extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_re
 	if(dbg) fprintf(stderr, "[kmahip] assemble: pile-up on device %.1f ms\n", ms(t0, t1));
 	if(!ws->p_kept) return KMAHIP_OK;
 
+	// consensus on the device (two passes: figures + lengths, then the characters at their offsets); the host version below is
+	// kept as the arithmetic reference -- KMAHIP_HOST_CONSENSUS=1 selects it, and it takes over if p_chisqr is not monotone
+	// around the threshold in this libm
+	if(!getenv("KMAHIP_HOST_CONSENSUS")) {
+		double qstar = 0.0;
+		bool usable = true;
+		if(asm_p_chisqr(0.0L) <= evalue) qstar = 0.0;
+		else {
+			double lo = 0.0, hi = 200.0;                       // p(lo) > evalue >= p(hi)
+			if(!(asm_p_chisqr(hi) <= evalue)) usable = false;    // evalue below 1e-26: nothing is ever significant
+			while(usable) {
+				uint64_t a, b;
+				memcpy(&a, &lo, 8); memcpy(&b, &hi, 8);
+				if(b - a <= 1) break;
+				const uint64_t m = a + (b - a) / 2;
+				double mid;
+				memcpy(&mid, &m, 8);
+				if(asm_p_chisqr(mid) <= evalue) hi = mid; else lo = mid;
+			}
+			qstar = hi;
+			// monotone around the threshold? (a few thousand neighbouring doubles on each side)
+			uint64_t qb;
+			memcpy(&qb, &qstar, 8);
+			for(int i = 1; usable && i <= 4096; ++i) {
+				double above, below;
+				const uint64_t ua = qb + (uint64_t) i, ub = qb - (uint64_t) i;
+				memcpy(&above, &ua, 8); memcpy(&below, &ub, 8);
+				if(!(asm_p_chisqr(above) <= evalue) || (asm_p_chisqr(below) <= evalue)) usable = false;
+			}
+		}
+		if(usable) {
+			DevGuard G;
+			ConsArgs C;
+			C.db = db->dev; C.counts = ws->p_counts; C.chain_head = ws->p_chain; C.nodes = (const InsNode *) ws->p_nodes; C.seg_start = ws->p_seg;
+			C.n_kept = ws->p_kept; C.bcd = bcd; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
+			unsigned long long *fig = nullptr;
+			HIP_TRY(hipMalloc((void **) &fig, (size_t) 4 * D * sizeof(unsigned long long)));
+			G.v.push_back(fig);
+			HIP_TRY(hipMemset(fig, 0, (size_t) 4 * D * sizeof(unsigned long long)));
+			C.cover = fig; C.aln_len = fig + D; C.depth = fig + 2 * D; C.asm_len = fig + 3 * D;
+			const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(D, 1), 256 * 8);
+			hipLaunchKernelGGL((consensus_kernel<false>), dim3(blocks), dim3(CONS_THREADS), 0, 0, C);
+			std::vector<unsigned long long> hf((size_t) 4 * D);
+			HIP_TRY(hipMemcpy(hf.data(), fig, hf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+			for(int64_t t = 1; t < D; ++t) {
+				out->cover[t] = (int64_t) hf[(size_t) t]; out->aln_len[t] = (int64_t) hf[(size_t) (D + t)];
+				out->depth[t] = (int64_t) hf[(size_t) (2 * D + t)]; out->asm_len[t] = (int64_t) hf[(size_t) (3 * D + t)];
+			}
+			if(out->consensus && out->consensus_off) {
+				std::vector<int64_t> coff((size_t) D, -1);
+				int64_t used = 0;
+				for(int64_t t = 1; t < D; ++t) if(out->asm_len[t] > 0) { coff[(size_t) t] = used; used += out->asm_len[t] + 1; }
+				if(out->consensus_used + used > out->consensus_cap) { kmahip_set_error("consensus_cap too small"); return KMAHIP_EOVERFLOW; }
+				char *dc = nullptr;
+				int64_t *dco = nullptr;
+				HIP_TRY(hipMalloc((void **) &dc, (size_t) used + 16)); G.v.push_back(dc);
+				HIP_TRY(hipMalloc((void **) &dco, (size_t) D * 8)); G.v.push_back(dco);
+				HIP_TRY(hipMemcpy(dco, coff.data(), (size_t) D * 8, hipMemcpyHostToDevice));
+				C.cons = dc; C.cons_off = dco;
+				hipLaunchKernelGGL((consensus_kernel<true>), dim3(blocks), dim3(CONS_THREADS), 0, 0, C);
+				HIP_TRY(hipMemcpy(out->consensus + out->consensus_used, dc, (size_t) used, hipMemcpyDeviceToHost));
+				for(int64_t t = 1; t < D; ++t) if(coff[(size_t) t] >= 0) out->consensus_off[t] = out->consensus_used + coff[(size_t) t];
+				out->consensus_used += used;
+			}
+			HIP_TRY(hipGetLastError());
+			if(dbg) fprintf(stderr, "[kmahip] assemble: consensus on device %.1f ms (q* = %.17g)\n", ms(t1, now()), qstar);
+			return KMAHIP_OK;
+		}
+	}
 	// consensus on the host
 	const int64_t total = ws->p_total;
 	std::vector<uint32_t> counts((size_t) total * 6);
