@@ -56,6 +56,7 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
 	out->n_rows = 0;
 	hipStream_t s = 0;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 	DevBlock B;
 	int rc;
 	auto t = std::chrono::steady_clock::now();
@@ -84,9 +85,11 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 			continue;
 		}
 		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
+		if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: scan attempt %d: %.1f ms, %lld candidates (cap %lld)\n", attempt, since(t2), (long long) total, (long long) c.T_cap); }
 		if(total <= c.T_cap) break;
 		c.T_cap = total + 1024;
 	}
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 2 done after %.1f ms\n", since(t2)); }
 
 	// stage 3a
 	kmahip_hits h;

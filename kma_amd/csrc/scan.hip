@@ -42,8 +42,13 @@ constexpr int STHREADS = KMAHIP_STHREADS;   // threads of one scan workgroup: GR
 constexpr int CHUNK = 136;            // k-mer start positions per pass
 constexpr int MW = 5;                 // hit-mask words per candidate (>= CHUNK / 32)
 constexpr int SW = 7;                 // staged u64 words per item and pass
-constexpr int TSLOTS = 16;            // hashed candidate slots per item in LDS
-constexpr int TMAX = 14;              // ... of which at most this many occupied
+// hashed candidate slots per item in LDS (template parameter TS of the scan kernel; at most TS - 2 occupied): 16 in the
+// first tier (8 waves / SIMD), 64 in the second tier that re-does the items whose candidates did not fit -- a 50 k-gene
+// database with ten variants per family puts twenty and more templates on half of the reads (one chance k-mer hit in
+// another family brings all its variants), and the wavefront-per-item overflow kernel is 30x slower per item
+constexpr int TS1 = 16, TS2 = 64;
+constexpr unsigned TIER2_GRID = 256 * 3;        // second tier: three workgroups per CU fit its LDS
+__host__ __device__ constexpr int ilog2c(int x) { return x <= 1 ? 0 : 1 + ilog2c(x >> 1); }
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int VSLOTS = 16;            // hashed value-list slots per item in LDS (distinct lists seen in one pass); a list
                                       // that finds all of them taken is expanded directly
@@ -68,6 +73,11 @@ struct ScanArgs {
 	int64_t pool_cap;
 	unsigned long long *counters;
 	int64_t *overflow_items;
+	// what a launch of scan_se_kernel / scan_dense_kernel reads its items from and where it files what does not fit:
+	// in_items[0 .. counters[in_count]), out_over[counters[out_count]++]
+	const int64_t *in_items;
+	int64_t *out_over;
+	int in_count, out_count;
 	int32_t *dense;
 	int64_t dense_slots;
 	int64_t *active_items; // strand items that passed the prefilter, in no particular order (counters[C_NACT] of them)
@@ -76,7 +86,7 @@ struct ScanArgs {
 	int32_t *pool_sc;    // mode 1: scores parallel to pool
 };
 
-enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6, C_PPOOL = 7, C_NACT = 8, C_PREF = 9, N_COUNTERS = KMAHIP_N_COUNTERS };
+enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6, C_PPOOL = 7, C_NACT = 8, C_PREF = 9, C_NOVER2 = 10, N_COUNTERS = KMAHIP_N_COUNTERS };
 
 // two probes whose home buckets travel together (used after a miss: the k-mer starts behind a mismatch miss in a row)
 __device__ __forceinline__ void probe2(const DevDB &db, uint32_t key1, uint32_t key2, uint32_t &r1, uint32_t &r2) {
@@ -208,8 +218,10 @@ __device__ __forceinline__ int mask_next(const uint32_t *m, int st, int from, bo
 }
 
 // claim / find template t's slot in item g's candidate table; -1 when the table is full
+template <int TSLOTS>
 __device__ __forceinline__ int template_slot(uint32_t t, int g, uint32_t *t_id, int32_t *t_cnt) {
-	const uint32_t h = (t * 0x9E3779B1u) >> 28;
+	constexpr int TMAX = TSLOTS - 2;
+	const uint32_t h = (t * 0x9E3779B1u) >> (32 - ilog2c(TSLOTS));
 	// rolled on purpose: unrolled, the 16 probes nest 16 exec masks (SGPR spills) and the body is inlined many times over
 #pragma unroll 1
 	for(int x = 0; x < TSLOTS; ++x) {
@@ -225,11 +237,12 @@ __device__ __forceinline__ int template_slot(uint32_t t, int g, uint32_t *t_id, 
 }
 
 // rare path: OR positions [rs, re) of the pass into the hit mask of every template of list vi
+template <int TSLOTS>
 __device__ __forceinline__ void expand_list(const DevDB &db, uint32_t vi, int rs, int re, int g,
                                          uint32_t *t_id, int32_t *t_cnt, uint32_t *t_mask, int32_t *s_over) {
 	const uint32_t cnt = value_at(db, vi, 0);
 	for(uint32_t i = 1; i <= cnt; ++i) {
-		const int slot = template_slot(value_at(db, vi, (int) i), g, t_id, t_cnt);
+		const int slot = template_slot<TSLOTS>(value_at(db, vi, (int) i), g, t_id, t_cnt);
 		if(slot < 0) { s_over[g] = 1; return; }
 		for(int w = rs >> 5; w <= (re - 1) >> 5; ++w) {
 			const int lo = max(rs, w << 5) & 31, hi = min(re, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
@@ -405,8 +418,8 @@ __device__ __forceinline__ int compact_threads(bool flag, int tid, int32_t *wcnt
 	return total;
 }
 
-template <bool STATS, int MODE>
-__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_kernel(const ScanArgs A) {
+template <bool STATS, int MODE, int TSLOTS>
+__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2) : 4) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
 	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
 	// forward words: if every read of the group fits in SW-1 words they are staged ONCE and serve all passes;
@@ -429,15 +442,17 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 	const DevDB &db = A.db;
 	const int tid = threadIdx.x;
 	const int k = (int) db.kmersize;
-	const int64_t n_active = (int64_t) A.counters[C_NACT];
-	const int64_t first = (int64_t) blockIdx.x * GROUP;
+	const int64_t n_active = (int64_t) A.counters[A.in_count];
+	// first tier: one group of items per workgroup; second tier: a fixed grid that loops over the (usually few) groups
+	int64_t first = (int64_t) blockIdx.x * GROUP;
 	if(first >= n_active) return;
+	do {
 	const int ng = (int) min((int64_t) GROUP, n_active - first);
 
 	if(tid < GROUP) {
 		int L = 0, nN = 0; int64_t so = 0, no = 0, it = 0;
 		if(tid < ng) {
-			it = A.active_items[first + tid];
+			it = A.in_items[first + tid];
 			const int64_t r = it >> 1;
 			L = A.len[r]; so = A.seq_off[r]; no = A.N_off[r]; nN = (int) (A.N_off[r + 1] - no);
 		}
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 								if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * GROUP + slot], (uint32_t) (m >> 32));
 							} else {
 								// more distinct lists in this pass than the v-table holds: expand this run directly
-								expand_list(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
+								expand_list<TSLOTS>(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
 							}
 						}
 						jj += run + 1;
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 			__syncthreads();
 			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
 			// flight together) and OR the list's position mask into the hit mask of each listed template
-			static_assert(VSLOTS == TSLOTS && (VSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
+			static_assert((VSLOTS * GROUP) % STHREADS == 0 && (TSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
 			for(int part = 0; part < VSLOTS * GROUP; part += STHREADS) {
 			const int n_lists = compact_threads(v_id[part + tid] != MISS, tid, s_wcnt, s_list);
 			if(tid < n_lists) {
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 					for(int i = 0; i < 7; ++i) el[i] = vp[1 + i];
 				}
 				auto add_template = [&](const uint32_t t) -> bool {
-					const int slot = template_slot(t, g, t_id, t_cnt);
+					const int slot = template_slot<TSLOTS>(t, g, t_id, t_cnt);
 					if(slot < 0) { s_over[g] = 1; return false; }
 #pragma unroll
 					for(int w = 0; w < MW; ++w) if(mw[w]) atomicOr(&t_mask[w * TSLOTS * GROUP + slot], mw[w]);
@@ -731,8 +746,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 			if(A.ablate & 16) { nb = 0; } else
 #endif
 			if(s_over[g]) {
-				const unsigned long long slot = atomicAdd(&A.counters[C_NOVER], 1ull);
-				A.overflow_items[slot] = item;
+				const unsigned long long slot = atomicAdd(&A.counters[A.out_count], 1ull);
+				A.out_over[slot] = item;
 				nb = -1;
 			} else if(MODE) {
 				// get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores
@@ -800,7 +815,11 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? 8 : 4) void scan_se_ker
 			atomicAdd(&A.counters[C_VALS], (unsigned long long) s_stats[1]);
 			atomicAdd(&A.counters[C_HASH], (unsigned long long) s_stats[2]);
 		}
+		__syncthreads();
 	}
+	if(TSLOTS == TS1) break;          // (straight-line code in the first tier)
+	first += (int64_t) gridDim.x * GROUP;
+	} while(first < n_active);
 }
 
 // Overflow path: items whose candidate set does not fit the LDS tables. The reference's own sequential formulation
@@ -814,7 +833,7 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 	__shared__ uint32_t s_vi[DCH];
 	const DevDB &db = A.db;
 	const int k = (int) db.kmersize, lane = threadIdx.x;
-	const int64_t n_over = (int64_t) A.counters[C_NOVER];
+	const int64_t n_over = (int64_t) A.counters[A.in_count];
 	const int64_t slot = blockIdx.x;
 	if(slot >= A.dense_slots) return;
 	const int64_t D = db.DB_size;
@@ -823,7 +842,7 @@ __global__ __launch_bounds__(64) void scan_dense_kernel(const ScanArgs A) {
 	volatile int32_t *list = ext + D;   // list[0..nlist): templates in first-seen order; ext[t] == -1 marks "absent"
 	const unsigned long long below = (1ull << lane) - 1ull;
 	for(int64_t oi = slot; oi < n_over; oi += A.dense_slots) {
-		const int64_t item = A.overflow_items[oi];
+		const int64_t item = A.in_items[oi];
 		const int64_t r = item >> 1;
 		const int strand = (int) (item & 1);
 		const int L = A.len[r], npos = L - k + 1;
@@ -1222,7 +1241,7 @@ static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 		if(ws->pool_scale < 1) ws->pool_scale = 1;
 		ws->pool_cap = cap * 16 * ws->pool_scale;
 		HIP_TRY(hipMalloc((void **) &ws->pool, ws->pool_cap * sizeof(int32_t)));
-		HIP_TRY(hipMalloc((void **) &ws->overflow_items, cap * 2 * sizeof(int64_t)));
+		HIP_TRY(hipMalloc((void **) &ws->overflow_items, cap * 4 * sizeof(int64_t)));       // first-tier list + second-tier list
 		HIP_TRY(hipMalloc((void **) &ws->active_items, cap * 2 * sizeof(int64_t)));
 		ws->blk_cap = (cap + CB - 1) / CB + 1;
 		HIP_TRY(hipMalloc((void **) &ws->blk_sums, ws->blk_cap * sizeof(int64_t)));
@@ -1278,8 +1297,10 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	if(ws->stats_on) hipLaunchKernelGGL((scan_prefilter_kernel<true>), dim3(pgrid), dim3(THREADS), 0, stream, A);
 	else hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3(pgrid), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
-	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0>), dim3(grid), dim3(STHREADS), 0, stream, A);
-	else hipLaunchKernelGGL((scan_se_kernel<false, 0>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	int64_t *over1 = ws->overflow_items, *over2 = ws->overflow_items + 2 * ws->cap_reads;
+	A.in_items = ws->active_items; A.in_count = C_NACT; A.out_over = over1; A.out_count = C_NOVER;
+	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_se_kernel<false, 0, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
@@ -1288,6 +1309,11 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 		ws->events3->push_back({evp, evq});
 	}
 	{
+		// second tier (64-slot tables, a fixed grid looping over the groups), then whatever is left one wavefront per item
+		A.in_items = over1; A.in_count = C_NOVER; A.out_over = over2; A.out_count = C_NOVER2;
+		if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 0, TS2>), dim3(TIER2_GRID), dim3(STHREADS), 0, stream, A);
+		else hipLaunchKernelGGL((scan_se_kernel<false, 0, TS2>), dim3(TIER2_GRID), dim3(STHREADS), 0, stream, A);
+		A.in_items = over2; A.in_count = C_NOVER2;
 		hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	}
 	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
@@ -1332,7 +1358,9 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
 	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
-	hipLaunchKernelGGL((scan_se_kernel<false, 1>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	int64_t *over1 = ws->overflow_items, *over2 = ws->overflow_items + 2 * ws->cap_reads;
+	A.in_items = ws->active_items; A.in_count = C_NACT; A.out_over = over1; A.out_count = C_NOVER;
+	hipLaunchKernelGGL((scan_se_kernel<false, 1, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
@@ -1340,6 +1368,9 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 		if(!ws->events3) ws->events3 = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
 		ws->events3->push_back({evp, evq});
 	}
+	A.in_items = over1; A.in_count = C_NOVER; A.out_over = over2; A.out_count = C_NOVER2;
+	hipLaunchKernelGGL((scan_se_kernel<false, 1, TS2>), dim3(TIER2_GRID), dim3(STHREADS), 0, stream, A);
+	A.in_items = over2; A.in_count = C_NOVER2;
 	hipLaunchKernelGGL(scan_dense_kernel, dim3((unsigned) ws->dense_slots), dim3(64), 0, stream, A);
 	PairArgs P;
 	P.S = A; P.n_pairs = np; P.PE = p->rw.PE;
