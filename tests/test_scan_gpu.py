@@ -48,10 +48,12 @@ def _compare_with_oracle(prefix, batch, hipdb, exhaustive=0):
     return e
 
 
-def test_scan_vs_oracle_redundant_db(tmp_path):
-    """Wide candidate sets (40 variants per family) force the HBM overflow path."""
+@pytest.mark.parametrize("variants", [40, 90])
+def test_scan_vs_oracle_redundant_db(tmp_path, variants):
+    """Wide candidate sets: 40 variants per family do not fit the 16-slot candidate tables and go through the second tier
+    (64 slots); 90 variants do not fit those either and force the HBM overflow path (one wavefront per item)."""
     from kma_amd import binding
-    names, seqs = synth.make_gene_db(n_families=6, variants=40, len_lo=500, len_hi=900, max_div=0.03, seed=99)
+    names, seqs = synth.make_gene_db(n_families=6, variants=variants, len_lo=500, len_hi=900, max_div=0.03, seed=99)
     prefix = str(tmp_path / "red")
     formats.write_index(prefix, names, seqs)
     reads, *_ = synth.make_reads(seqs, 3000, read_len=150, sub_rate=0.01, random_frac=0.03, n_rate=0.002, seed=5)
