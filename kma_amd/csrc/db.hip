@@ -123,7 +123,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	// presence bits: ~7 bits per k-mer (13 % false positives) as long as that fits 2 MiB
 	std::vector<uint32_t> kbits;
 	uint32_t kbits_log2 = 0;
-	if(n > 0 && 8 * n < (1ull << 25)) {
+	if(n > 0 && 8 * n < (1ull << 25) && !getenv("KMAHIP_NO_KBITS")) {        // (the switch exists for the test that compares both paths)
 		kbits_log2 = 16;
 		while((2ull << kbits_log2) <= 8 * n) ++kbits_log2;
 		kbits.assign((size_t) 1 << (kbits_log2 - 5), 0u);

@@ -102,3 +102,19 @@ def test_c_host_program_reproduces_reference_s2_stream(golden_se):
     for extra, name in (([], "s2.bin.gz"), (["-ex_mode"], "s2_ex.bin.gz")):
         out = subprocess.run([exe, "-t_db", golden_se["prefix"]] + extra, input=s1, stdout=subprocess.PIPE, check=True).stdout
         assert out == gzip.open(os.path.join(src, name), "rb").read(), name
+
+
+def test_prefilter_with_and_without_presence_bits(golden_se, monkeypatch):
+    """Small databases get presence bits in front of the prefilter's probe-table gathers; the result may not depend on them."""
+    from kma_amd import binding
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("KMAHIP_NO_KBITS", "1")
+        db = binding.KmaHipDB(golden_se["prefix"])
+        try:
+            outs.append(db.scan_se(golden_se["batch"]))
+        finally:
+            db.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

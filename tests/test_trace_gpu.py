@@ -285,3 +285,26 @@ def _one_call_case(g, name):
 def test_one_call_pipeline_matches_reference_files(golden_se, golden_long):
     assert _one_call_case(golden_se, "se") > 50
     assert _one_call_case(golden_long, "long") > 0
+
+
+def test_device_consensus_equals_host_consensus(golden_se, golden_long, monkeypatch):
+    """callConsensus on the device (significance as a threshold on the IEEE quotient) against the host arithmetic
+    (KMAHIP_HOST_CONSENSUS=1: libm erf / tgamma per column) on the same pile-up: same figures, same consensus lines."""
+    from kma_amd import binding
+    for g in (golden_se, golden_long):
+        res = []
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("KMAHIP_HOST_CONSENSUS", "1")
+            else:
+                monkeypatch.delenv("KMAHIP_HOST_CONSENSUS", raising=False)
+            db = binding.KmaHipDB(g["prefix"])
+            try:
+                o = db.run_se(g["batch"], per_read=False)
+            finally:
+                db.close()
+            res.append(o)
+        for key in ("cover", "aln_len", "depth", "asm_len"):
+            assert np.array_equal(res[0][key], res[1][key]), key
+        assert res[0]["consensus"] == res[1]["consensus"]
+        assert (res[0]["asm_len"] > 0).sum() > 0

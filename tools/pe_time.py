@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Paired-end path (`-ipe ... -apm p`, BASELINE config C3 shape) through the host-buffer calls, PCIe inclusive:
-stage 2 + 3a (map_pe), ConClave over the record slots.  usage (GPU box): python3 tools/pe_time.py [pairs]"""
+stage 2 + 3a (map_pe), ConClave over the record slots.  usage (GPU box): python3 tools/pe_time.py [pairs [families [variants]]]"""
 import os
 import sys
 import tempfile
@@ -14,7 +14,9 @@ from kma_amd import binding, formats, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tmp = tempfile.mkdtemp()
-names, seqs = synth.make_gene_db(1000, 5, 600, 1500, 0.04, seed=12345)
+fam = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+var = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+names, seqs = synth.make_gene_db(fam, var, 600, 1500, 0.04, seed=12345)
 prefix = os.path.join(tmp, "db")
 formats.write_index(prefix, names, seqs)
 m1, m2, _ = synth.make_pairs(seqs, n, seed=11)
