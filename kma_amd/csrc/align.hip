@@ -59,6 +59,8 @@ struct AlignArgs {
 	int32_t *seed_n;         // per seed slot, written by seed_tasks_kernel: number of MEMs found (0..SEEDS), -1: seed in the main kernel
 	uint2 *seed_mem;         // SEEDS per slot: x = tS (1-based), y = qS | (length << 16)
 	int seed_slots;          // seed slots per task: 1 (single end) or 2 (paired records: both mates of a couple)
+	int *xq;                 // spill queues for deferred DP problems, per wavefront 4 classes x xq_cap entries of QENT ints (long reads)
+	int xq_cap;
 	// scratch
 	int32_t *s32;
 	uint64_t *s64;
@@ -217,6 +219,9 @@ struct Lane {
 	int M, MM, U, W1;
 	uint32_t *wide;            // this wave's LDS row slots (WSLOTS x 4 planes x WCOLS words)
 	int *queue;                // this wave's deferred wide-DP queue in LDS: [0] = count, entries of QENT ints from [1]
+	int *xq;                   // this wave's spill queues in HBM (long reads: hundreds of link problems per task), 4 classes x xq_cap entries
+	int *xq_cnt;               // their fill counts (LDS, 4 ints)
+	int xq_cap;
 	int q_at, q_mate;          // context of the kma_score call being run (template id, mate slot) for queue entries
 	int64_t q_rd;              // read index of the query being aligned
 	int ablate;
@@ -490,6 +495,27 @@ __device__ Aln nw_band(const Lane &L, const uint64_t *ts, int tlen_total, const 
 	return aln_from<21>(best, bestTD);
 }
 
+// hand a DP problem to the wave: class 0 wide (17..63 columns), 1 narrow (9..16), 2 tiny (2..8), 3 extra-wide / banded.
+// First the LDS queue of the class, then (long reads) its spill queue in HBM; false: the caller solves it in its lane.
+__device__ __forceinline__ bool dp_enqueue(const Lane &L, int cls, int k, int t_s, int t_e, int q_s, int q_e, int rc, int e11) {
+	int *qu = cls == 2 ? L.queue + (2 + (QCAP + QCAPN) * QENT) : cls == 1 ? L.queue + (1 + QCAP * QENT) : cls == 0 ? L.queue : L.queue + (3 + (QCAP + QCAPN + QCAPT) * QENT);
+	const int cap = cls == 2 ? QCAPT : cls == 1 ? QCAPN : cls == 0 ? QCAP : QCAPX;
+	int *e = nullptr;
+	const int slot = atomicAdd(&qu[0], 1);
+#ifdef KMAHIP_DIAG
+	if(L.cnt && g_diag_hist && cls < 3) atomicAdd(&g_diag_hist[200 + (cls == 2 ? 0 : cls == 1 ? 1 : 2) + (slot < cap ? 0 : 4)], 1ull);
+#endif
+	if(slot < cap) e = qu + 1 + slot * QENT;
+	else if(L.xq_cap > 0) {
+		const int s2 = atomicAdd(&L.xq_cnt[cls], 1);
+		if(s2 < L.xq_cap) e = L.xq + ((size_t) cls * L.xq_cap + s2) * QENT;
+	}
+	if(!e) return false;
+	e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
+	e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = rc; e[11] = e11;
+	return true;
+}
+
 __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
                                        int t_s, int t_e, int q_s, int q_e, int tspan, int band) {
 #ifdef KMAHIP_DIAG
@@ -512,15 +538,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 		if(L.queue && ql >= WCOLS && ql < 64 * XC && tspan <= TBUF && tspan + ql < 1000) {
 			// long unaligned ends (a read that matches a template only in part): a lane walking those cells alone takes
 			// milliseconds and holds its whole wave
-			int *qu = L.queue + (3 + (QCAP + QCAPN + QCAPT) * QENT);
-			const int slot = atomicAdd(&qu[0], 1);
-			if(slot < QCAPX) {
-				int *e = qu + 1 + slot * QENT;
-				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
-				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = (k < 0) ? 1 : 0;
-				Aln z = {0, 0, 0, 0, 0, 0};
-				return z;
-			}
+			if(dp_enqueue(L, 3, k, t_s, t_e, q_s, q_e, q.rc, (k < 0) ? 1 : 0)) { Aln z = {0, 0, 0, 0, 0, 0}; return z; }
 		}
 		if(L.queue && ql < WCOLS && tspan + ql < 1000) {
 			// The other small problems are handed to the whole wave (nw_coop, run after every lane has finished its
@@ -528,18 +546,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 			// ever summed into the alignment statistics, so the caller goes on with zeroes.
 			const bool tiny = ql <= 8 && tspan < TBUF / 8;
 			const bool narrow = !tiny && ql <= 16 && tspan < TBUF / 4;
-			int *qu = tiny ? L.queue + (2 + (QCAP + QCAPN) * QENT) : narrow ? L.queue + (1 + QCAP * QENT) : L.queue;
-			const int slot = atomicAdd(&qu[0], 1);
-#ifdef KMAHIP_DIAG
-			if(L.cnt && g_diag_hist) atomicAdd(&g_diag_hist[200 + (tiny ? 0 : narrow ? 1 : 2) + (slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP) ? 0 : 4)], 1ull);
-#endif
-			if(slot < (tiny ? QCAPT : narrow ? QCAPN : QCAP)) {
-				int *e = qu + 1 + slot * QENT;
-				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
-				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = (k < 0) ? 1 : 0;
-				Aln z = {0, 0, 0, 0, 0, 0};
-				return z;
-			}
+			if(dp_enqueue(L, tiny ? 2 : narrow ? 1 : 0, k, t_s, t_e, q_s, q_e, q.rc, (k < 0) ? 1 : 0)) { Aln z = {0, 0, 0, 0, 0, 0}; return z; }
 		}
 #ifdef KMAHIP_DIAG
 		if(L.cnt && g_diag_hist) { atomicAdd(&g_diag_hist[208], 1ull); atomicAdd(&g_diag_hist[209], (unsigned long long) max(0, tspan) * (q_e - q_s)); if(q_e - q_s >= WCOLS) atomicAdd(&g_diag_hist[210], 1ull); }
@@ -573,15 +580,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 		const int cfin = ((tspan + ql) >> 1) - (tspan - 1);
 		const bool stale_scan = k == -2 && !(cfin + (b2 >> 1) < ql - 1);
 		if(L.queue && ql < 64 * XC && tspan <= TBUF && tspan + ql < 1000 && band < (1 << 20) && !stale_scan) {
-			int *qu = L.queue + (3 + (QCAP + QCAPN + QCAPT) * QENT);
-			const int slot = atomicAdd(&qu[0], 1);
-			if(slot < QCAPX) {
-				int *e = qu + 1 + slot * QENT;
-				e[0] = (int) (threadIdx.x & 63); e[1] = L.q_mate; e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
-				e[7] = L.q_at; e[8] = (int) (L.q_rd & 0xFFFFFFFFll); e[9] = (int) (L.q_rd >> 32); e[10] = q.rc; e[11] = ((k < 0) ? 1 : 0) | (band << 1);
-				Aln z = {0, 0, 0, 0, 0, 0};
-				return z;
-			}
+			if(dp_enqueue(L, 3, k, t_s, t_e, q_s, q_e, q.rc, ((k < 0) ? 1 : 0) | (band << 1))) { Aln z = {0, 0, 0, 0, 0, 0}; return z; }
 		}
 	}
 	return nw_band(L, ts, t_len, q, k, t_s, t_e, q_s, q_e, band);
@@ -1273,6 +1272,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	__shared__ int s_d[25];
 	__shared__ uint32_t s_wide[(ATHREADS / 64) * WSLOTS * 4 * WCOLS];
 	__shared__ int s_queue[(ATHREADS / 64) * QINTS];
+	__shared__ int s_xcnt[(ATHREADS / 64) * 4];
 	__shared__ uint8_t s_tbuf[(ATHREADS / 64) * TBUF];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
 	__syncthreads();
@@ -1286,6 +1286,8 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	L.cnt = STATS ? A.counters : nullptr;
 	L.wide = s_wide + wave * WSLOTS * 4 * WCOLS;
 	L.queue = s_queue + wave * QINTS;     // wide queue, then the narrow queue, then the tiny queue
+	L.xq_cap = A.xq_cap; L.xq_cnt = s_xcnt + wave * 4;
+	L.xq = A.xq_cap ? A.xq + (size_t) (gtid >> 6) * 4 * A.xq_cap * QENT : nullptr;
 	L.q_at = 0; L.q_mate = 0; L.q_rd = 0;
 	L.ablate = A.ablate;
 #ifdef KMAHIP_DIAG
@@ -1311,6 +1313,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		const int64_t task = (int64_t) base + lane;
 		const bool have = task < n_tasks;
 		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; queueX[0] = 0; }
+		if(lane < 4) L.xq_cnt[lane] = 0;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- phase A -------------------------------------------------------------------------------
@@ -1404,24 +1407,23 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 #ifdef KMAHIP_DIAG
 		const unsigned long long dbg_t1 = wall_clock64();
 #endif
-		const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
-		for(int e = 0; e < nqx; ++e) {
-			// two columns per lane up to 128 columns (half the cells per step), four beyond
-			const int *xe = queueX + 1 + e * QENT;
-			const bool bnd = (xe[11] >> 1) != 0, wide2 = xe[6] - xe[5] <= 128;
-			if(bnd) { if(wide2) nw_coop_x<2, true>(L, A.db, A, queueX, e, tbuf); else nw_coop_x<4, true>(L, A.db, A, queueX, e, tbuf); }
-			else { if(wide2) nw_coop_x<2, false>(L, A.db, A, queueX, e, tbuf); else nw_coop_x<4, false>(L, A.db, A, queueX, e, tbuf); }
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-		}
-		for(int e = 0; e < nq; ++e) nw_coop<64>(L, A.db, A, queue, e, nq, tbuf);
-		for(int e = 0; e < nqn; e += 4) nw_coop<16>(L, A.db, A, queueN, e, nqn, tbuf);
-		for(int e = 0; e < nqt; e += 8) nw_coop<8>(L, A.db, A, queueT, e, nqt, tbuf);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		for(int pass = 0; pass < 4; ++pass) {
-			const int *qu = pass == 0 ? queue : pass == 1 ? queueN : pass == 2 ? queueT : queueX;
-			const int cnt = pass == 0 ? nq : pass == 1 ? nqn : pass == 2 ? nqt : nqx;
+		// the deferred problems of this round: the LDS queues, then (long reads only) what did not fit them, spilled to this
+		// wave's queues in HBM (written by single lanes, read by all: through L2)
+		auto solve = [&](int *p0, int *p1, int *p2, int *p3, const int nq, const int nqn, const int nqt, const int nqx) {
+			for(int e = 0; e < nqx; ++e) {
+				// two columns per lane up to 128 columns (half the cells per step), four beyond
+				const int *xe = p3 + 1 + e * QENT;
+				const bool bnd = (xe[11] >> 1) != 0, wide2 = xe[6] - xe[5] <= 128;
+				if(bnd) { if(wide2) nw_coop_x<2, true>(L, A.db, A, p3, e, tbuf); else nw_coop_x<4, true>(L, A.db, A, p3, e, tbuf); }
+				else { if(wide2) nw_coop_x<2, false>(L, A.db, A, p3, e, tbuf); else nw_coop_x<4, false>(L, A.db, A, p3, e, tbuf); }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			for(int e = 0; e < nq; ++e) nw_coop<64>(L, A.db, A, p0, e, nq, tbuf);
+			for(int e = 0; e < nqn; e += 4) nw_coop<16>(L, A.db, A, p1, e, nqn, tbuf);
+			for(int e = 0; e < nqt; e += 8) nw_coop<8>(L, A.db, A, p2, e, nqt, tbuf);
+		};
+		auto collect = [&](const int *qu, const int cnt) {
 			for(int e = 0; e < cnt; ++e) {
 				const int *ent = qu + 1 + e * QENT;
 				if(lane != ent[0]) continue;
@@ -1431,6 +1433,23 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				S.score += ent[2]; S.len += ent[3]; S.match += ent[4]; S.tGaps += ent[5]; S.qGaps += ent[6];
 				if(ent[11] & 1) S.pos -= ent[3] - ent[5];
 			}
+		};
+		{
+			const int nq = min(QCAP, queue[0]), nqn = min(QCAPN, queueN[0]), nqt = min(QCAPT, queueT[0]), nqx = min(QCAPX, queueX[0]);
+			solve(queue, queueN, queueT, queueX, nq, nqn, nqt, nqx);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			collect(queue, nq); collect(queueN, nqn); collect(queueT, nqt); collect(queueX, nqx);
+		}
+		if(L.xq_cap) {
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+			const size_t cs = (size_t) L.xq_cap * QENT;
+			int *p0 = L.xq - 1, *p1 = L.xq + cs - 1, *p2 = L.xq + 2 * cs - 1, *p3 = L.xq + 3 * cs - 1;
+			const int nq = min(L.xq_cap, L.xq_cnt[0]), nqn = min(L.xq_cap, L.xq_cnt[1]), nqt = min(L.xq_cap, L.xq_cnt[2]), nqx = min(L.xq_cap, L.xq_cnt[3]);
+			solve(p0, p1, p2, p3, nq, nqn, nqt, nqx);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+			__builtin_amdgcn_wave_barrier();
+			collect(p0, nq); collect(p1, nqn); collect(p2, nqt); collect(p3, nqx);
 		}
 #ifdef KMAHIP_DIAG
 		if(lane == 0) atomicMax(&A.counters[14], ((wall_clock64() - dbg_t1) << 32) | (unsigned long long) (task & 0xFFFFFFFFll));         // slowest phase B
@@ -2069,7 +2088,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	Lane &L = T.L;
 	L.s32 = A.s32 + gtid; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
-	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0;
+	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0;
 	L.diag_uniform = 0;
 	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
@@ -2163,6 +2182,20 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(n >= 0x7FFFFFFF) { kmahip_set_error("too many records in one batch"); return KMAHIP_EINVAL; }
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
 	A.rec_mate = rec_mate; A.rec_rc = rec_rc; A.pe_mode = rec_mate != nullptr; A.Wl = -p->rw.Wl; A.PE = p->rw.PE;
+	// long reads: a 10 kb read has hundreds of link problems per task; what the LDS queues cannot take is spilled per wave
+	A.xq = nullptr; A.xq_cap = 0;
+	if(max_len > 1024) {
+		const int64_t waves = lanes / 64;
+		int64_t cap = 16ll * (mem_cap + 2);
+		while(cap > 256 && waves * 4 * cap * QENT * 4 > (2ll << 30)) cap >>= 1;
+		const size_t bytes = (size_t) waves * 4 * cap * QENT * 4;
+		if(ws->a_xq_bytes < bytes) {
+			(void) hipFree(ws->a_xq); ws->a_xq = nullptr; ws->a_xq_bytes = 0;
+			HIP_TRY(hipMalloc((void **) &ws->a_xq, bytes));
+			ws->a_xq_bytes = bytes;
+		}
+		A.xq = ws->a_xq; A.xq_cap = (int) cap;
+	}
 	A.counters = ws->counters;
 	A.stats = ws->stats_on;
 	A.ablate = 0;

@@ -100,6 +100,8 @@ struct kmahip_ws {
 	int a_mem_cap, a_ncols;
 	void *a_task;
 	int64_t a_task_cap;
+	int *a_xq;                    // spill queues of deferred DP problems (long reads), see align.hip
+	size_t a_xq_bytes;
 	void *a_priv;             // private copies of the ConClave vectors (reduce_reads_kernel)
 	int64_t a_priv_cap;
 	// trace stage (3c) scratch
