@@ -1,0 +1,101 @@
+/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` on an MI355X without the reference: plain C99 over the C-ABI of
+ * libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte for byte what KMA 1.5.1 writes with one thread (the .gz
+ * after decompression).
+ *
+ *     kmahip_map -i reads.fq.gz -t_db db -o out
+ *
+ * Stage 1 (kmahip_ingest_*: parse, trim with KMA's defaults, pack), the whole device run in one call (kmahip_run_se: stage 2,
+ * 3a, ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kmahip.h"
+
+static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); exit(1); }
+static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) { fprintf(stderr, "kmahip_map: out of memory\n"); exit(1); } return p; }
+
+int main(int argc, char **argv) {
+	const char *prefix = NULL, *input = NULL, *out = NULL;
+	for(int a = 1; a < argc; ++a) {
+		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
+		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
+		else if(!strcmp(argv[a], "-o") && a + 1 < argc) out = argv[++a];
+		else { fprintf(stderr, "usage: kmahip_map -i reads.fq[.gz] -t_db <index prefix> -o <output prefix>\n"); return 2; }
+	}
+	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
+
+	/* stage 1: the whole file as one batch (the arrays stay owned by the reader) */
+	kmahip_ingest *ing;
+	kmahip_read_batch b;
+	if(kmahip_ingest_open(input, NULL, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b)) die("ingest");
+	const int64_t n = b.reads.n_reads;
+
+	kmahip_db *db; kmahip_ws *ws; kmahip_params par; kmahip_db_info info;
+	if(kmahip_init(0) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
+	kmahip_default_params(&par);
+	const int64_t D = info.DB_size;
+
+	/* everything on the device, one call */
+	int64_t tbases = 0;
+	{	/* consensus capacity: template bases (from <prefix>.length.b: DB_size ints, the first is the k-mer index size) + slack */
+		char path[4096];
+		snprintf(path, sizeof path, "%s.length.b", prefix);
+		FILE *f = fopen(path, "rb");
+		int32_t v, i = 0;
+		if(!f) { fprintf(stderr, "kmahip_map: cannot open %s\n", path); return 1; }
+		while(fread(&v, 4, 1, f) == 1) if(i++ > 0 && i <= D) tbases += v;
+		fclose(f);
+	}
+	kmahip_run run;
+	memset(&run, 0, sizeof run);
+	run.rows = xcalloc((size_t) D, sizeof *run.rows); run.rows_cap = D;
+	run.assembly.cover = xcalloc((size_t) D, 8); run.assembly.aln_len = xcalloc((size_t) D, 8);
+	run.assembly.depth = xcalloc((size_t) D, 8); run.assembly.asm_len = xcalloc((size_t) D, 8);
+	run.assembly.consensus_cap = 2 * tbases + 4 * D + (1 << 20);
+	run.assembly.consensus = xcalloc((size_t) run.assembly.consensus_cap, 1);
+	run.assembly.consensus_off = xcalloc((size_t) D, 8);
+	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
+	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
+	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
+	if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, 0, &run)) die("kmahip_run_se");
+
+	/* out.res + out.fsa: names from <prefix>.name, one per line, in template order */
+	char path[4096], *name = xcalloc(1 << 16, 1), *line = xcalloc((1 << 16) + 512, 1);
+	snprintf(path, sizeof path, "%s.name", prefix);
+	FILE *names = fopen(path, "r");
+	snprintf(path, sizeof path, "%s.res", out);
+	FILE *res = fopen(path, "w");
+	snprintf(path, sizeof path, "%s.fsa", out);
+	FILE *fsa = fopen(path, "w");
+	if(!names || !res || !fsa) { fprintf(stderr, "kmahip_map: cannot open the name file or the outputs\n"); return 1; }
+	fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
+	int64_t r = 0;
+	for(int64_t t = 1; t < D && fgets(name, 1 << 16, names); ++t) {
+		name[strcspn(name, "\n")] = 0;
+		while(r < run.n_rows && run.rows[r].template_id < t) ++r;
+		if(!(r < run.n_rows && run.rows[r].template_id == t && run.rows[r].significant)) continue;
+		if(!kmahip_res_line(name, &run.rows[r], run.assembly.cover[t], run.assembly.aln_len[t], run.assembly.depth[t], 1.0, 0.0, line, (1 << 16) + 512)) continue;
+		fputs(line, res);
+		/* printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line */
+		fprintf(fsa, ">%s\n", name);
+		const char *c = run.assembly.consensus + run.assembly.consensus_off[t];
+		int col = 0;
+		for(; *c; ++c) if(*c != '-') { fputc(*c, fsa); if(++col == 60) { fputc('\n', fsa); col = 0; } }
+		if(col) fputc('\n', fsa);
+	}
+	fclose(names); fclose(res); fclose(fsa);
+
+	/* out.frag.gz */
+	int64_t frag_rows = 0;
+	snprintf(path, sizeof path, "%s.frag.gz", out);
+	if(kmahip_frag_write(path, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
+	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f\n",
+	        (long long) n, (long long) frag_rows, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4]);
+	kmahip_ws_destroy(ws);
+	kmahip_db_close(db);
+	kmahip_ingest_close(ing);
+	return 0;
+}

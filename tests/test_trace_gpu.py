@@ -308,3 +308,20 @@ def test_device_consensus_equals_host_consensus(golden_se, golden_long, monkeypa
             assert np.array_equal(res[0][key], res[1][key]), key
         assert res[0]["consensus"] == res[1]["consensus"]
         assert (res[0]["asm_len"] > 0).sum() > 0
+
+
+def test_c_program_from_fastq_to_all_three_output_files(golden_se, tmp_path):
+    """examples/kmahip_map.c: reads.fq.gz + index in, out.res / out.fsa / out.frag.gz out -- the reference's files, with nothing of
+    the reference in between (kmahip_ingest_*, kmahip_run_se, kmahip_res_line, kmahip_frag_write)."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    g = golden_se
+    out = str(tmp_path / "out")
+    subprocess.run([os.path.join(root, "examples", "kmahip_map"), "-i", os.path.join(g["dir"], "reads.fq.gz"), "-t_db", g["prefix"], "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    assert open(out + ".res", "rb").read() == open(os.path.join(g["dir"], "out.res"), "rb").read()
+    assert open(out + ".fsa").read() == golden_util.load_fsa("se")
+    assert gzip.open(out + ".frag.gz", "rb").read() == gzip.open(os.path.join(g["dir"], "out.frag.gz"), "rb").read()
