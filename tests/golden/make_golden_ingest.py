@@ -39,10 +39,10 @@ def rand_read(rng, L):
         p = int(rng.integers(0, L))
         s[p] = rng.choice(list(b"NnRYSWKMBDHVXacgtrykm"))
     if rng.random() < 0.1:
-        k = int(rng.integers(1, 12))
+        k = min(L, int(rng.integers(1, 12)))
         s[:k] = b"N" * k
     if rng.random() < 0.1:
-        k = int(rng.integers(1, 12))
+        k = min(L, int(rng.integers(1, 12)))
         s[-k:] = b"N" * k
     return bytes(s)
 
