@@ -1,0 +1,73 @@
+"""End to end against the compiled reference itself (oracle/_ref/kma, which travels to the GPU box): a seeded read set with
+substitutions, indels, unmappable reads, partly foreign reads, N's and ragged lengths goes through `kma -1t1 -t 1` and through
+examples/kmahip_map (kmahip_ingest_*, kmahip_run_se, the writers); `.res`, `.fsa` and `.frag.gz` must be identical."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kma_amd import formats, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+
+
+def _reads(seqs, n, rng):
+    out = []
+    for i in range(n):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(60, 251))
+        a = int(rng.integers(0, max(1, len(s) - L)))
+        r = s[a:a + L].copy()
+        u = rng.random()
+        if u < 0.03:                                   # unmappable
+            r = rng.integers(0, 4, L, dtype=np.uint8)
+        elif u < 0.08:                                 # foreign end (either side)
+            j = rng.integers(0, 4, int(rng.integers(20, 140)), dtype=np.uint8)
+            r = np.concatenate([r, j]) if rng.random() < 0.5 else np.concatenate([j, r])
+        elif u < 0.16:                                 # an indel or two
+            parts, p = [], 0
+            while p < len(r):
+                e = min(len(r), p + int(rng.integers(25, 110)))
+                parts.append(r[p:e])
+                v = rng.random()
+                if v < 0.45:
+                    parts.append(rng.integers(0, 4, int(rng.integers(1, 5)), dtype=np.uint8))
+                elif v < 0.9:
+                    e = min(len(r), e + int(rng.integers(1, 5)))
+                p = e
+            r = np.concatenate(parts)
+        x = rng.random(len(r)) < 0.008
+        r = r.copy()
+        r[x] = (r[x] + rng.integers(1, 4, int(x.sum()), dtype=np.uint8)) & 3
+        if rng.random() < 0.03:
+            r[int(rng.integers(0, len(r)))] = 4        # an N
+        if rng.random() < 0.5:
+            r = synth.revcomp_codes(r)
+        out.append(np.ascontiguousarray(r.astype(np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("seed,families,variants", [(1, 40, 5), (2, 12, 12)])
+def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants):
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(seed)
+    names, seqs = synth.make_gene_db(families, variants, 500, 1300, 0.04, seed=100 + seed)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads = _reads(seqs, 60000, rng)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, reads, lens=None)
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
+    assert got.count(b"\n") > 40000
