@@ -381,6 +381,16 @@ int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads
                       const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, const char *read_names,
                       const int64_t *read_name_off, int64_t *rows);
 
+/* The paired run (`-ipe r1 r2 -apm p -1t1`) on one batch as kmahip_ingest_next hands it over for two mate files: reads in
+ * stream order, batch->pair[i] = 1 / 2 for the mates of a pair record, 0 for a record that lost its mate to the trimming.
+ * Pairs go through kmahip_map_pe, single records through kmahip_map_se; their results are merged into frag_raw records in
+ * stream order (alnFragsPenaltyPE's record forms: proper pair -- second slot first when the pair was swapped --, unmated,
+ * one mate only, alnfrags.c:1777-1970), ConClave over the records, the `.res` statistics, the traceback aligner over the
+ * fragments in record order and the pile-up. Fills out->rows / n_rows / assembly / ms (the per-read pointers of `out` are
+ * not used: fragments are not in read order); frag_path != NULL also writes the `.frag.gz`. HOST buffers. */
+int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
+                  int64_t max_frag, const char *frag_path, kmahip_run *out);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

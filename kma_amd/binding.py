@@ -156,6 +156,8 @@ def lib():
         L.kmahip_frag_write.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_run_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.POINTER(Run)]
+        L.kmahip_run_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.c_char_p,
+                                    C.POINTER(Run)]
         L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
         L.kmahip_trim_default.restype = None
         L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
@@ -548,6 +550,37 @@ class KmaHipDB:
             o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
         for k, v in pr.items():
             o[k] = v[:n * 10].reshape(n, 10) if k == "trace_stats" else v[:n]
+        o["ms"] = list(run.ms)
+        return o
+
+    def run_pe(self, batch, names, pair, evalue=0.05, bcd=1, max_frag=0, frag_path=None):
+        """The paired run in one call (kmahip_run_pe) on what Ingest.next returned for two mate files -> dict(rows, cover, aln_len,
+        depth, asm_len, consensus, ms)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        blob = b"".join(nm + b"\0" for nm in names) + b"\0"
+        blob_buf = C.create_string_buffer(blob, len(blob))
+        noff = np.zeros(n + 1, np.int64)
+        if n:
+            noff[1:] = np.cumsum([len(nm) + 1 for nm in names])
+        pr = np.ascontiguousarray(pair, np.uint8)
+        rb = ReadBatchC(Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                              int(batch.length.max()) if n else 0), C.cast(blob_buf, C.c_void_p), _p(noff), _p(pr), 0)
+        D = int(self.info.DB_size)
+        o = dict(cover=np.zeros(D, np.int64), aln_len=np.zeros(D, np.int64), depth=np.zeros(D, np.int64), asm_len=np.zeros(D, np.int64))
+        cap = int(2 * np.fromfile(self.prefix + ".length.b", dtype=np.int32)[1:].astype(np.int64).sum() + 4 * D + (1 << 20))
+        cbuf = np.zeros(cap, np.uint8)
+        coff = np.full(D, -1, np.int64)
+        rows = (ResRow * D)()
+        run = Run(C.cast(rows, C.c_void_p), D, 0, Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), _p(cbuf), _p(coff), cap, 0),
+                  None, None, None, None)
+        p = Params.from_buffer_copy(self.params)
+        _check(lib().kmahip_run_pe(self.h, self.ws, C.byref(rb), C.byref(p), float(evalue), int(bcd), int(max_frag),
+                                   os.fsencode(frag_path) if frag_path else None, C.byref(run)))
+        o["rows"] = [rows[i] for i in range(run.n_rows)]
+        raw = cbuf.tobytes()
+        o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
         o["ms"] = list(run.ms)
         return o
 

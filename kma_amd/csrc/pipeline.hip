@@ -2,7 +2,9 @@
 // out), built from the same launchers as the stage-wise entry points; what runKMA does between its input stream and the
 // `.res` / consensus output (runkma.c:104-900), minus the files.
 #include "kmahip_internal.h"
+#include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -149,6 +151,216 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 		if(out->n_hits) HIP_TRY(hipMemcpy(out->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost));
 		if(out->rc) HIP_TRY(hipMemcpy(out->rc, h.rc, (size_t) n * 4, hipMemcpyDeviceToHost));
 		if(out->trace_stats) HIP_TRY(hipMemcpy(out->trace_stats, tr.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
+	}
+	out->ms[5] = since(t);
+	return KMAHIP_OK;
+}
+
+// ---- paired run: host composition of the stage-wise calls (the record merge is the glue a host program would otherwise write) ----
+namespace {
+
+// a batch assembled on the host from reads of another batch
+struct HostBatch {
+	std::vector<uint64_t> seq;
+	std::vector<int64_t> seq_off{0}, N_off{0};
+	std::vector<int32_t> len, N;
+	std::vector<int64_t> src;          // index of each read in the source batch
+	int max_len = 0;
+	void add(const kmahip_reads &r, int64_t i) {
+		const int L = r.len[i];
+		const int64_t w = (L + 31) >> 5;
+		seq.insert(seq.end(), r.seq + r.seq_off[i], r.seq + r.seq_off[i] + w);
+		seq.push_back(0);
+		seq_off.push_back((int64_t) seq.size());
+		N.insert(N.end(), r.N + r.N_off[i], r.N + r.N_off[i + 1]);
+		N_off.push_back((int64_t) N.size());
+		len.push_back(L); src.push_back(i);
+		max_len = std::max(max_len, L);
+	}
+	kmahip_reads view() {
+		if(N.empty()) N.push_back(0);
+		kmahip_reads v;
+		v.n_reads = (int64_t) len.size(); v.seq = seq.data(); v.seq_off = seq_off.data(); v.len = len.data(); v.N = N.data(); v.N_off = N_off.data();
+		v.seq_words = (int64_t) seq.size(); v.N_total = N_off.back(); v.max_len = max_len;
+		return v;
+	}
+};
+
+struct HitBuf {
+	std::vector<int32_t> n_hits, best, flag, rc, tmpl, score, start, end;
+	kmahip_hits view(uint64_t *as, uint64_t *us) {
+		kmahip_hits h;
+		h.n_hits = n_hits.data(); h.best_score = best.data(); h.flag = flag.data(); h.tmpl = tmpl.data(); h.score = score.data();
+		h.start = start.data(); h.end = end.data(); h.alignment_scores = as; h.uniq_alignment_scores = us; h.rc = rc.data();
+		return h;
+	}
+	void size(int64_t n, int64_t cap) {
+		n_hits.assign((size_t) n + 1, 0); best.assign((size_t) n + 1, 0); flag.assign((size_t) n + 1, 0); rc.assign((size_t) n + 1, 0);
+		tmpl.assign((size_t) cap + 1, 0); score.assign((size_t) cap + 1, 0); start.assign((size_t) cap + 1, 0); end.assign((size_t) cap + 1, 0);
+	}
+};
+
+}  // namespace
+
+extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
+                             int64_t max_frag, const char *frag_path, kmahip_run *out) {
+	if(!db || !ws || !batch || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len || !batch->pair) {
+		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
+	}
+	const kmahip_reads &R = batch->reads;
+	const int64_t n = R.n_reads;
+	const size_t D = db->info.DB_size;
+	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
+	out->n_rows = 0;
+	auto t = std::chrono::steady_clock::now();
+	// units of the stream: a pair (two reads) or a single
+	HostBatch PB, SB;
+	std::vector<int64_t> unit_first;      // read index of each unit's first read
+	std::vector<int32_t> unit_idx;        // >= 0: pair number, < 0: -(single number) - 1
+	for(int64_t i = 0; i < n;) {
+		unit_first.push_back(i);
+		if(batch->pair[i] == 1 && i + 1 < n && batch->pair[i + 1] == 2) { unit_idx.push_back((int32_t) (PB.len.size() / 2)); PB.add(R, i); PB.add(R, i + 1); i += 2; }
+		else { unit_idx.push_back(-(int32_t) SB.len.size() - 1); SB.add(R, i); i += 1; }
+	}
+	const int64_t np = (int64_t) PB.len.size() / 2, ns = (int64_t) SB.len.size();
+	std::vector<uint64_t> AS(D, 0), US(D, 0);
+	int rc;
+	// stages 2 + 3a: pairs
+	kmahip_reads pr = PB.view(), sr = SB.view();
+	std::vector<int32_t> mate((size_t) 2 * np + 2), prc((size_t) 2 * np + 2), prcf((size_t) 2 * np + 2), pflag((size_t) 2 * np + 2), kind((size_t) np + 1, 0), pT;
+	std::vector<int64_t> R_off((size_t) 2 * np + 2, 0);
+	HitBuf ph, sh;
+	int64_t cap = 8 * np + 1024;
+	for(int tries = 0; np > 0; ++tries) {
+		pT.assign((size_t) cap + 1, 0);
+		ph.size(2 * np, cap);
+		std::fill(AS.begin(), AS.end(), 0); std::fill(US.begin(), US.end(), 0);
+		kmahip_pe_recs recs = { mate.data(), prc.data(), prcf.data(), pflag.data(), R_off.data(), pT.data(), cap };
+		kmahip_hits h = ph.view(AS.data(), US.data());
+		rc = kmahip_map_pe(db, ws, &pr, p, &recs, &h, kind.data());
+		if(rc == KMAHIP_OK) break;
+		if(rc != KMAHIP_EOVERFLOW || tries > 6) return rc;
+		cap = std::max<int64_t>(2 * cap, R_off[(size_t) 2 * np] + 16);
+	}
+	// ... and the single records (their scores add into the same two vectors)
+	std::vector<int32_t> srcf((size_t) ns + 1), sflag((size_t) ns + 1), sT;
+	std::vector<int64_t> sT_off((size_t) ns + 2, 0);
+	std::vector<uint64_t> AS2(D, 0), US2(D, 0);
+	cap = 8 * ns + 1024;
+	for(int tries = 0; ns > 0; ++tries) {
+		sT.assign((size_t) cap + 1, 0);
+		sh.size(ns, cap);
+		std::fill(AS2.begin(), AS2.end(), 0); std::fill(US2.begin(), US2.end(), 0);
+		kmahip_cands cd = { srcf.data(), sflag.data(), sT_off.data(), sT.data(), cap };
+		kmahip_hits h = sh.view(AS2.data(), US2.data());
+		rc = kmahip_map_se(db, ws, &sr, p, &cd, &h);
+		if(rc == KMAHIP_OK) break;
+		if(rc != KMAHIP_EOVERFLOW || tries > 6) return rc;
+		cap = std::max<int64_t>(2 * cap, sT_off[(size_t) ns] + 16);
+	}
+	for(size_t i = 0; i < D; ++i) { AS[i] += AS2[i]; US[i] += US2[i]; }
+	out->ms[1] = since(t);
+
+	// frag_raw records in stream order (update_Scores_pe / _se, updatescores.c:300-488)
+	struct Frag { int64_t read; int32_t flag, rc; };
+	std::vector<int32_t> r_n, r_score, r_ql, r_ql2, f_tmpl, f_start, f_end;
+	std::vector<int64_t> r_off{0};
+	std::vector<std::vector<Frag>> frags;
+	auto add = [&](int nh, int score, int ql, int ql2, const HitBuf &src, int64_t o, std::vector<Frag> fr) {
+		r_n.push_back(nh); r_score.push_back(score); r_ql.push_back(ql); r_ql2.push_back(ql2);
+		for(int x = 0; x < nh; ++x) { f_tmpl.push_back(src.tmpl[(size_t) (o + x)]); f_start.push_back(src.start[(size_t) (o + x)]); f_end.push_back(src.end[(size_t) (o + x)]); }
+		r_off.push_back((int64_t) f_tmpl.size());
+		frags.push_back(std::move(fr));
+	};
+	for(size_t u = 0; u < unit_idx.size(); ++u) {
+		if(unit_idx[u] < 0) {
+			const int64_t j = -(int64_t) unit_idx[u] - 1;
+			if(sh.n_hits[(size_t) j] > 0) add(sh.n_hits[(size_t) j], sh.best[(size_t) j], SB.len[(size_t) j], 0, sh, sT_off[(size_t) j], {Frag{unit_first[u], sh.flag[(size_t) j], sh.rc[(size_t) j]}});
+			continue;
+		}
+		const int64_t j = unit_idx[u], r0 = 2 * j, r1 = 2 * j + 1;
+		auto ln = [&](int64_t x) { return PB.len[(size_t) (2 * j + mate[(size_t) x])]; };
+		auto fg = [&](int64_t x) { return Frag{unit_first[u] + mate[(size_t) x], ph.flag[(size_t) x], ph.rc[(size_t) x] & 1}; };
+		const int64_t o = R_off[(size_t) r1];
+		const int kd = kind[(size_t) j];
+		if(kd == 1) {
+			const bool swapped = (ph.rc[(size_t) r1] & 2) != 0;       // the second slot's fragment is written first (alnfrags.c:1807-1812)
+			add(ph.n_hits[(size_t) r1], -ph.best[(size_t) r1], swapped ? ln(r1) : ln(r0), swapped ? ln(r0) : ln(r1), ph, o,
+			    swapped ? std::vector<Frag>{fg(r1), fg(r0)} : std::vector<Frag>{fg(r0), fg(r1)});
+		} else if(kd == 2) {
+			const int n0 = ph.n_hits[(size_t) r0], n1 = ph.n_hits[(size_t) r1];
+			add(n0, ph.best[(size_t) r0], ln(r0), 0, ph, o, {fg(r0)});
+			add(n1, ph.best[(size_t) r1], ln(r1), 0, ph, o + n0, {fg(r1)});
+		} else if(kd == 3 || kd == 4) {
+			const int64_t x = kd == 3 ? r0 : r1;
+			add(ph.n_hits[(size_t) x], ph.best[(size_t) x], ln(x), 0, ph, o, {fg(x)});
+		} else {
+			for(int64_t x : {r0, r1}) if(mate[(size_t) x] >= 0 && ph.n_hits[(size_t) x] > 0) add(ph.n_hits[(size_t) x], ph.best[(size_t) x], ln(x), 0, ph, R_off[(size_t) x], {fg(x)});
+		}
+	}
+	const int64_t nrec = (int64_t) r_n.size();
+	// stage 3b over the records + the `.res` statistics
+	std::vector<int32_t> c_tmpl((size_t) nrec + 1, 0), c_start((size_t) nrec + 1, 0), c_end((size_t) nrec + 1, 0);
+	std::vector<uint64_t> w(D, 0);
+	if(nrec) {
+		if(f_tmpl.empty()) { f_tmpl.push_back(0); f_start.push_back(0); f_end.push_back(0); }
+		kmahip_hits h;
+		memset(&h, 0, sizeof h);
+		h.n_hits = r_n.data(); h.best_score = r_score.data(); h.tmpl = f_tmpl.data(); h.start = f_start.data(); h.end = f_end.data();
+		h.alignment_scores = AS.data(); h.uniq_alignment_scores = US.data();
+		kmahip_conclave cc = { c_tmpl.data(), c_start.data(), c_end.data(), w.data(), nullptr, nullptr, nullptr };
+		if((rc = kmahip_conclave_records(db, ws, nrec, r_ql.data(), r_ql2.data(), r_off.data(), &h, &cc))) return rc;
+	}
+	if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
+	std::vector<uint8_t> ok(D + 8, 0);
+	for(int64_t r = 0; r < out->n_rows; ++r) ok[(size_t) out->rows[r].template_id] = (uint8_t) out->rows[r].significant;
+	out->ms[2] = since(t);
+
+	// the fragments in record order; the first fragment of a record carries the sign of the template (conclave.c:131-146)
+	HostBatch FB;
+	std::vector<int32_t> f_rc, f_t, f_nh;
+	for(int64_t k = 0; k < nrec; ++k) {
+		const int tt = c_tmpl[(size_t) k];
+		for(size_t x = 0; x < frags[(size_t) k].size(); ++x) {
+			FB.add(R, frags[(size_t) k][x].read);
+			f_rc.push_back(frags[(size_t) k][x].rc);
+			f_t.push_back(x == 0 ? tt : abs(tt));
+			f_nh.push_back(r_n[(size_t) k]);
+		}
+	}
+	const int64_t nf = (int64_t) FB.len.size();
+	kmahip_reads fr = FB.view();
+	std::vector<int32_t> stats((size_t) nf * 10 + 10, 0), n_ops((size_t) nf + 1, 0);
+	std::vector<int64_t> ops_off((size_t) nf + 1, 0);
+	std::vector<uint32_t> ops;
+	int64_t ops_cap = 8 * nf + 1024, need = 0;
+	kmahip_traces tr;
+	memset(&tr, 0, sizeof tr);
+	for(int tries = 0; nf > 0; ++tries) {
+		ops.assign((size_t) ops_cap + 1, 0);
+		tr.stats = stats.data(); tr.ops_off = ops_off.data(); tr.n_ops = n_ops.data(); tr.ops = ops.data(); tr.ops_cap = ops_cap;
+		rc = kmahip_align_trace(db, ws, &fr, f_rc.data(), f_t.data(), ok.data(), p, &tr, &need);
+		if(rc == KMAHIP_OK) break;
+		if(rc != KMAHIP_EOVERFLOW || tries > 3) return rc;
+		ops_cap = need + 16;
+	}
+	out->ms[3] = since(t);
+	if(nf > 0) {
+		if((rc = kmahip_assemble(db, ws, &fr, f_rc.data(), f_t.data(), &tr, max_frag, bcd, evalue, &out->assembly))) return rc;
+	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
+	out->ms[4] = since(t);
+	if(frag_path && nf > 0) {
+		if(!batch->names || !batch->name_off) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+		// names of the fragments, in fragment order
+		std::vector<char> names;
+		std::vector<int64_t> noff{0};
+		for(int64_t i = 0; i < nf; ++i) {
+			const char *nm = batch->names + batch->name_off[FB.src[(size_t) i]];
+			names.insert(names.end(), nm, nm + strlen(nm) + 1);
+			noff.push_back((int64_t) names.size());
+		}
+		int64_t rows = 0;
+		if((rc = kmahip_frag_write(frag_path, db, &fr, f_rc.data(), f_t.data(), f_nh.data(), stats.data(), max_frag, names.data(), noff.data(), &rows))) return rc;
 	}
 	out->ms[5] = since(t);
 	return KMAHIP_OK;

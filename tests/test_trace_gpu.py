@@ -325,3 +325,34 @@ def test_c_program_from_fastq_to_all_three_output_files(golden_se, tmp_path):
     assert open(out + ".res", "rb").read() == open(os.path.join(g["dir"], "out.res"), "rb").read()
     assert open(out + ".fsa").read() == golden_util.load_fsa("se")
     assert gzip.open(out + ".frag.gz", "rb").read() == gzip.open(os.path.join(g["dir"], "out.frag.gz"), "rb").read()
+
+
+def test_one_call_paired_run_matches_reference_files(golden_pe, tmp_path):
+    """kmahip_run_pe on the two mate files as kmahip_ingest_* reads them: the `.res` and consensus FASTA of `kma -ipe r1 r2 -apm p -1t1`."""
+    import gzip
+    import os
+    from kma_amd import binding
+    src = os.path.join(golden_util.GOLD, "pe")
+    with binding.Ingest(os.path.join(src, "r1.fq.gz"), os.path.join(src, "r2.fq.gz")) as ing:
+        batch, names, pair = ing.next(1 << 30)
+    db = binding.KmaHipDB(golden_pe["prefix"])
+    try:
+        o = db.run_pe(batch, names, pair, frag_path=str(tmp_path / "x.frag.gz"))
+        tn = golden_util.template_names("pe")
+        lines = ["#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n"]
+        fsa = []
+        for r in o["rows"]:
+            if r.significant:
+                t = r.template_id
+                line = db.res_line(tn[t - 1], r, o["cover"][t], o["aln_len"][t], o["depth"][t])
+                if line:
+                    lines.append(line)
+                    fsa.append((tn[t - 1], o["consensus"][t]))
+    finally:
+        db.close()
+    with open(os.path.join(src, "out.res")) as f:
+        assert "".join(lines) == f.read()
+    assert golden_util.fsa_text(fsa) == golden_util.load_fsa("pe")
+    rows = gzip.open(tmp_path / "x.frag.gz", "rt").read().splitlines()
+    sam = golden_util.load_sam("pe")
+    assert len(rows) == sum(len(v) for v in sam.values()) > 1000          # one row per SAM record of the reference run
