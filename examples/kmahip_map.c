@@ -1,8 +1,9 @@
-/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` on an MI355X without the reference: plain C99 over the C-ABI of
+/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` (or `-ipe r1.fq r2.fq ... -apm p -1t1`) on an MI355X without the reference: plain C99 over the C-ABI of
  * libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte for byte what KMA 1.5.1 writes with one thread (the .gz
  * after decompression).
  *
  *     kmahip_map -i reads.fq.gz -t_db db -o out
+ *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out
  *
  * Stage 1 (kmahip_ingest_*: parse, trim with KMA's defaults, pack), the whole device run in one call (kmahip_run_se: stage 2,
  * 3a, ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
@@ -18,19 +19,20 @@ static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) { fprintf(stderr, "kmahip_map: out of memory\n"); exit(1); } return p; }
 
 int main(int argc, char **argv) {
-	const char *prefix = NULL, *input = NULL, *out = NULL;
+	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	for(int a = 1; a < argc; ++a) {
 		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
 		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
+		else if(!strcmp(argv[a], "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
 		else if(!strcmp(argv[a], "-o") && a + 1 < argc) out = argv[++a];
-		else { fprintf(stderr, "usage: kmahip_map -i reads.fq[.gz] -t_db <index prefix> -o <output prefix>\n"); return 2; }
+		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix>\n"); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
 
 	/* stage 1: the whole file as one batch (the arrays stay owned by the reader) */
 	kmahip_ingest *ing;
 	kmahip_read_batch b;
-	if(kmahip_ingest_open(input, NULL, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b)) die("ingest");
+	if(kmahip_ingest_open(input, input2, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b)) die("ingest");
 	const int64_t n = b.reads.n_reads;
 
 	kmahip_db *db; kmahip_ws *ws; kmahip_params par; kmahip_db_info info;
@@ -60,7 +62,10 @@ int main(int argc, char **argv) {
 	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
-	if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, 0, &run)) die("kmahip_run_se");
+	char fpath[4096];
+	snprintf(fpath, sizeof fpath, "%s.frag.gz", out);
+	if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, 0, fpath, &run)) die("kmahip_run_pe"); }
+	else if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, 0, &run)) die("kmahip_run_se");
 
 	/* out.res + out.fsa: names from <prefix>.name, one per line, in template order */
 	char path[4096], *name = xcalloc(1 << 16, 1), *line = xcalloc((1 << 16) + 512, 1);
@@ -88,10 +93,9 @@ int main(int argc, char **argv) {
 	}
 	fclose(names); fclose(res); fclose(fsa);
 
-	/* out.frag.gz */
+	/* out.frag.gz (the paired run has written it itself: its fragments are in record order, not read order) */
 	int64_t frag_rows = 0;
-	snprintf(path, sizeof path, "%s.frag.gz", out);
-	if(kmahip_frag_write(path, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
+	if(!input2 && kmahip_frag_write(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f\n",
 	        (long long) n, (long long) frag_rows, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4]);
 	kmahip_ws_destroy(ws);

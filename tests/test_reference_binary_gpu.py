@@ -71,3 +71,41 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants):
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 40000
+
+
+def test_whole_paired_run_equals_reference_binary(tmp_path):
+    """`-ipe r1 r2 -apm p -1t1 -t 1`: pairs with substitutions, some mates foreign or too short after trimming (single records in the
+    pair stream), through the reference and through examples/kmahip_map -ipe."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(5)
+    names, seqs = synth.make_gene_db(30, 5, 700, 1400, 0.04, seed=77)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    m1, m2, _ = synth.make_pairs(seqs, 30000, seed=9)
+    r1, r2 = [r.copy() for r in m1], [r.copy() for r in m2]
+    q1, q2 = [b"I" * 150] * len(r1), [b"I" * 150] * len(r2)
+    for i in rng.choice(len(r1), 1500, replace=False):                   # a foreign mate
+        (r1 if rng.random() < 0.5 else r2)[i] = rng.integers(0, 4, 150, dtype=np.uint8)
+    for i in rng.choice(len(r1), 1500, replace=False):                   # a mate that the quality trim shortens below -ml
+        q = bytearray(b"I" * 150)
+        q[10:] = b"#" * 140
+        if rng.random() < 0.5:
+            q1[i] = bytes(q)
+        else:
+            q2[i] = bytes(q)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for path, rs, qs, tag in ((tmp_path / "r1.fq", r1, q1, b"/1"), (tmp_path / "r2.fq", r2, q2, b"/2")):
+        with open(path, "wb") as f:
+            for i, (r, q) in enumerate(zip(rs, qs)):
+                f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
+                   check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
+                   check=True, stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
+    assert got.count(b"\n") > 50000
