@@ -364,7 +364,9 @@ typedef struct kmahip_read_batch {
 /* path2 == NULL: single end (run_input); otherwise the two mate files are read in lockstep (run_input_PE): both mates
  * long enough -> a pair record, one of them -> a single record, none -> dropped. */
 int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *trim, kmahip_ingest **out);
-/* up to max_records further S1 records; batch->reads.n_reads == 0 at the end of the input */
+/* up to max_records further S1 records; batch->reads.n_reads == 0 at the end of the input. A record that does not start
+ * with '@' ends the input like in the reference ("Malformed input.", seqparse.c:256-260): the records before it are
+ * delivered, then one call returns KMAHIP_EFORMAT. */
 int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch);
 /* 33 or 64 (0: undeterminable, treated like the reference does); records read / kept so far */
 int kmahip_ingest_phred_scale(const kmahip_ingest *in);

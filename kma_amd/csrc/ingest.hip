@@ -128,6 +128,7 @@ struct kmahip_ingest {
 	kmahip_trim trim;
 	int phred = 33;
 	int threads = 1;
+	bool malformed = false, reported = false;      // a record that does not start with '@': everything before it is delivered, then KMAHIP_EFORMAT once
 	int64_t n_read = 0, n_kept = 0;
 	// current batch
 	std::vector<uint64_t> seq;
@@ -168,10 +169,10 @@ int guess_phred(const uint8_t *buff0, size_t bytes) {
 // FileBuffgetFq, seqparse.c:241-403: locate the next record. false at the end of the input (or on a truncated / malformed
 // record). Every byte of the sequence line counts, also the '\r' of a DOS file (code 8): the reference's chomp loop stops at
 // the newline code it has just stored (:322-326), so such a base is only lost later, to the quality trim ('\r' < '!').
-bool locate_fq(Stream &s, Span &r) {
+bool locate_fq(Stream &s, Span &r, bool *malformed) {
 	r = Span();
 	if(s.ensure(1) == 0) return false;
-	if(*s.at() != '@') return false;
+	if(*s.at() != '@') { *malformed = true; return false; }       // "Malformed input." (seqparse.c:256-260): the reference stops reading here
 	size_t n = s.line_len();
 	if(n == SIZE_MAX) return false;
 	{	// header: everything up to the newline, chomped of trailing white space; the '@' is not part of the name
@@ -471,7 +472,7 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 			for(; n < want; ++n) {
 				Span r[2];
 				bool any = false;
-				for(int m = 0; m < mates; ++m) any |= locate_fq(in->s[m], r[m]);
+				for(int m = 0; m < mates; ++m) any |= locate_fq(in->s[m], r[m], &in->malformed);
 				if(!any) break;
 				for(int m = 0; m < mates; ++m) spans[m].push_back(r[m]);
 			}
@@ -529,6 +530,12 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	batch->reads.max_len = max_len;
 	batch->names = in->names.data(); batch->name_off = in->name_off.data(); batch->pair = in->pair.data();
 	batch->records = records;
+	if(in->malformed && !in->reported && records == 0) {
+		// like the reference, which prints "Malformed input." and ends with a non-zero exit status after the good records
+		in->reported = true;
+		kmahip_set_error("malformed FASTQ input after %lld records", (long long) in->n_read);
+		return KMAHIP_EFORMAT;
+	}
 	return KMAHIP_OK;
 }
 

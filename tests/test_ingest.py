@@ -136,3 +136,14 @@ def test_ingest_differential_against_reference_binary(tmp_path):
                 _compare(*got, s1)
         except AssertionError as e:
             raise AssertionError(f"case {case} {kw}: {str(e)[:300]}")
+
+
+def test_ingest_reports_malformed_input_after_the_good_records(tmp_path):
+    fq = tmp_path / "bad.fq"
+    fq.write_bytes(b"@a\nACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIII\nthis is not a record\n@b\nACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIII\n")
+    with binding.Ingest(str(fq)) as ing:
+        got = ing.next(100)
+        assert got is not None and got[0].n == 1 and got[1] == [b"a"]
+        with pytest.raises(binding.KmaHipError):
+            ing.next(100)
+        assert ing.next(100) is None
