@@ -50,6 +50,8 @@ def main():
     res = {}
     for name in fetch:
         short = next((k for k in KERNELS if k in name), None)
+        if short == "scan_se_kernel" and ", 64>" in name:
+            short = "scan_se_kernel_tier2"                                # the 64-slot second tier (usually next to nothing to do)
         if short is None or name not in write or "<true" in name:     # <true...> = the stats-counting launches
             continue
         fk = fetch[name] / nf[name]
