@@ -1663,6 +1663,45 @@ __global__ __launch_bounds__(256) void fold_scores_kernel(const unsigned long lo
 	else if(uniq_alignment_scores) uniq_alignment_scores[i - D] += sum;
 }
 
+// one single-end record (alnFragsSE's tail + update_Scores with minFrac == 1, updatescores.c:203-298): keep the hits with the
+// best normalised score or the best read score, add their scores to the ConClave vectors through add_as / add_us
+template <class FA, class FU>
+__device__ __forceinline__ void reduce_single(const ReduceArgs &R, int64_t r, int64_t o, int64_t e, int fl, FA add_as, FU add_us) {
+	int nh = 0, bestRead = 0;
+	if(e > o) {
+		double bestScore = 0.0;
+		for(int64_t t = o; t < e; ++t) {
+			const int rs = R.t_score[t];
+			const double sc = R.t_norm[t];
+			if(R.k < rs && R.scoreT <= sc) {
+				if(bestScore < sc) bestScore = sc;
+				if(bestRead < rs) bestRead = rs;
+			}
+		}
+		if(bestRead > R.k) {
+			for(int64_t t = o; t < e; ++t) {
+				const int rs = R.t_score[t];
+				if(!(R.k < rs && R.scoreT <= R.t_norm[t])) continue;
+				const double ms = (double) (rs / R.t_alen[t]);
+				if(ms == bestScore || rs == bestRead) {
+					const int64_t w = o + nh;
+					const int tm = R.t_tmpl[t];
+					R.h_tmpl[w] = tm; R.h_score[w] = rs; R.h_start[w] = R.t_start[t]; R.h_end[w] = R.t_end[t];
+					add_as(abs(tm), rs);
+					++nh;
+				}
+			}
+			if(nh == 1) add_us(abs(R.h_tmpl[o]), bestRead);
+		} else {
+			fl |= 4;
+			bestRead = 0;
+		}
+	}
+	R.n_hits[r] = nh; R.best_score[r] = (nh > 0) ? bestRead : 0; R.out_flag[r] = fl;
+	// single records are filed in the orientation stage 2 passed on (paired: rec_rc; single end: flag & 16)
+	if(R.out_rc) R.out_rc[r] = R.pe_mode ? (R.rec_rc[r] != 0) : ((R.flag[r] & 16) != 0);
+}
+
 __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R0) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(r >= R0.n_reads) return;
@@ -1673,7 +1712,7 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R0) 
 		if(R.uniq_alignment_scores) R.uniq_alignment_scores = base + R.DB_size;
 	}
 	const int64_t o = R.T_off[r], e = R.T_off[r + 1];
-	int nh = 0, bestRead = 0, fl = R.flag[r];
+	const int fl = R.flag[r];
 	if(R.pe_mode) {
 		const int64_t p0 = r & ~1ll;
 		const bool couple = R.rec_mate[p0] >= 0 && R.rec_mate[p0 + 1] >= 0 && R.T_off[p0 + 1] == R.T_off[p0];
@@ -1684,40 +1723,31 @@ __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R0) 
 		if(!(r & 1)) R.pe_kind[r >> 1] = 0;
 		if(R.rec_mate[r] < 0) { R.n_hits[r] = 0; R.best_score[r] = 0; R.out_flag[r] = fl; if(R.out_rc) R.out_rc[r] = 0; return; }
 	}
-	if(e > o) {
-		{
-			double bestScore = 0.0;
-			for(int64_t t = o; t < e; ++t) {
-				const int rs = R.t_score[t];
-				const double sc = R.t_norm[t];
-				if(R.k < rs && R.scoreT <= sc) {
-					if(bestScore < sc) bestScore = sc;
-					if(bestRead < rs) bestRead = rs;
-				}
-			}
-			if(bestRead > R.k) {
-				for(int64_t t = o; t < e; ++t) {
-					const int rs = R.t_score[t];
-					if(!(R.k < rs && R.scoreT <= R.t_norm[t])) continue;
-					const double ms = (double) (rs / R.t_alen[t]);
-					if(ms == bestScore || rs == bestRead) {
-						const int64_t w = o + nh;
-						const int tm = R.t_tmpl[t];
-						R.h_tmpl[w] = tm; R.h_score[w] = rs; R.h_start[w] = R.t_start[t]; R.h_end[w] = R.t_end[t];
-						if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) rs);
-						++nh;
-					}
-				}
-				if(nh == 1 && R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[abs(R.h_tmpl[o])], (unsigned long long) bestRead);
-			} else {
-				fl |= 4;
-				bestRead = 0;
-			}
-		}
+	reduce_single(R, r, o, e, fl, [&](int t, int v) { if(R.alignment_scores) atomicAdd(&R.alignment_scores[t], (unsigned long long) v); },
+	              [&](int t, int v) { if(R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[t], (unsigned long long) v); });
+}
+
+// single-end batches against a database small enough for LDS (two u32 vectors of DB_size entries): every workgroup sums the
+// scores of its reads in LDS and flushes what is non-zero once -- the one-thread-per-read form above issues one or two u64
+// atomics per read and is bound by them (21 M for 10 M reads)
+constexpr int RL_THREADS = 1024;
+constexpr int RL_MAX_DB = 6144;
+__global__ __launch_bounds__(RL_THREADS) void reduce_reads_lds_kernel(const ReduceArgs R) {
+	__shared__ uint32_t s_acc[2 * RL_MAX_DB];
+	const int D = (int) R.DB_size;
+	for(int i = threadIdx.x; i < 2 * D; i += RL_THREADS) s_acc[i] = 0;
+	__syncthreads();
+	for(int64_t r = (int64_t) blockIdx.x * RL_THREADS + threadIdx.x; r < R.n_reads; r += (int64_t) gridDim.x * RL_THREADS) {
+		reduce_single(R, r, R.T_off[r], R.T_off[r + 1], R.flag[r], [&](int t, int v) { atomicAdd(&s_acc[t], (uint32_t) v); },
+		              [&](int t, int v) { atomicAdd(&s_acc[D + t], (uint32_t) v); });
 	}
-	R.n_hits[r] = nh; R.best_score[r] = (nh > 0) ? bestRead : 0; R.out_flag[r] = fl;
-	// single records are filed in the orientation stage 2 passed on (paired: rec_rc; single end: flag & 16)
-	if(R.out_rc) R.out_rc[r] = R.pe_mode ? (R.rec_rc[r] != 0) : ((R.flag[r] & 16) != 0);
+	__syncthreads();
+	for(int i = threadIdx.x; i < 2 * D; i += RL_THREADS) {
+		const uint32_t v = s_acc[i];
+		if(!v) continue;
+		if(i < D) { if(R.alignment_scores) atomicAdd(&R.alignment_scores[i], (unsigned long long) v); }
+		else if(R.uniq_alignment_scores) atomicAdd(&R.uniq_alignment_scores[i - D], (unsigned long long) v);
+	}
 }
 
 // ---- stage 3c, per read: KMA() with traceback (align.c:214-507; NW nw.c:26-309, NW_band :310-640) ----------------
@@ -2266,6 +2296,17 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		}
 	}
 	R.t_score_w = A.t_score; R.t_alen_w = A.t_alen; R.t_start_w = A.t_start; R.t_end_w = A.t_end; R.t_tmpl_w = A.t_tmpl;
+	const unsigned rl_grid = 512;
+	const bool lds_reduce = !R.pe_mode && R.DB_size <= RL_MAX_DB && (out->alignment_scores || out->uniq_alignment_scores) &&
+	                        (n / rl_grid + RL_THREADS) * (int64_t) max_len < (1ll << 31);       // a workgroup's u32 sums cannot overflow
+	if(lds_reduce) {
+		ReduceArgs RL = R;
+		RL.priv = nullptr; RL.priv_copies = 0;
+		RL.alignment_scores = (unsigned long long *) out->alignment_scores; RL.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
+		hipLaunchKernelGGL(reduce_reads_lds_kernel, dim3(rl_grid), dim3(RL_THREADS), 0, stream, RL);
+		HIP_TRY(hipGetLastError());
+		return KMAHIP_OK;
+	}
 	hipLaunchKernelGGL(reduce_reads_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, R);
 	if(R.priv_copies) hipLaunchKernelGGL(fold_scores_kernel, dim3((unsigned) ((2 * R.DB_size + 255) / 256)), dim3(256), 0, stream, R.priv, R.priv_copies,
 	                                     R.DB_size, (unsigned long long *) out->alignment_scores, (unsigned long long *) out->uniq_alignment_scores);
