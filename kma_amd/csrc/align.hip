@@ -2122,34 +2122,54 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	L.diag_uniform = 0;
 	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
-	for(int64_t r = gtid; r < A.n_reads; r += A.lanes) {
-		int32_t *st = A.o_stats + 10 * r;
-		for(int x = 0; x < 10; ++x) st[x] = 0;
-		A.o_off[r] = 0; A.o_nops[r] = 0;
-		const int tt = A.tmpl[r], t = abs(tt);
-		if(t == 0 || (A.tmpl_ok && !A.tmpl_ok[t])) continue;
-		QView q;
-		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-		q.rc = (((A.flag[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
-		const int t_len = A.db.tlen[t];
-		const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
-		T.em.n = 0; T.em.over = false; T.status = 0;
-		int cs = 0, ce = 0;
+	const int lane = threadIdx.x & 63;
+	for(int64_t r = gtid; __any(r < A.n_reads); r += A.lanes) {
+		// what the read contributes: nothing (keep = false) or its figures + T.em.n alignment runs
+		bool keep = false;
+		int32_t *st = nullptr;
+		int read_score = 0, start = 0, end = 0, aln_len = 0, cs = 0, ce = 0, t_len = 0;
 		unsigned mapQ = 0;
-		const Aln S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
-		if(T.status || T.em.over) { atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16))); continue; }
-		// assemble_KMA, assembly.c:1931-1961
-		const int aln_len = S.len, start = S.pos;
-		int end = start + aln_len - S.tGaps;
-		if(t_len < end) end -= t_len;
-		int read_score = S.score;
-		if(start == 0) read_score += A.Wl;
-		if(end == t_len) read_score += A.Wl;
-		double score = 0;
-		if(A.minlen <= aln_len && ((A.mrc * q.L <= S.len - S.qGaps) || (A.mrc * t_len <= S.len - S.tGaps))) score = 1.0 * read_score / aln_len;
-		else read_score = 0;
-		if(!(0 < read_score && A.scoreT <= score)) continue;
-		const int64_t o = (int64_t) atomicAdd(&A.counters[0], (unsigned long long) T.em.n);
+		Aln S = {0, 0, 0, 0, 0, 0};
+		if(r < A.n_reads) {
+			st = A.o_stats + 10 * r;
+			for(int x = 0; x < 10; ++x) st[x] = 0;
+			A.o_off[r] = 0; A.o_nops[r] = 0;
+			const int tt = A.tmpl[r], t = abs(tt);
+			if(!(t == 0 || (A.tmpl_ok && !A.tmpl_ok[t]))) {
+				QView q;
+				q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+				q.rc = (((A.flag[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
+				t_len = A.db.tlen[t];
+				const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
+				T.em.n = 0; T.em.over = false; T.status = 0;
+				S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
+				if(T.status || T.em.over) atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16)));
+				else {
+					// assemble_KMA, assembly.c:1931-1961
+					aln_len = S.len; start = S.pos;
+					end = start + aln_len - S.tGaps;
+					if(t_len < end) end -= t_len;
+					read_score = S.score;
+					if(start == 0) read_score += A.Wl;
+					if(end == t_len) read_score += A.Wl;
+					double score = 0;
+					if(A.minlen <= aln_len && ((A.mrc * q.L <= S.len - S.qGaps) || (A.mrc * t_len <= S.len - S.tGaps))) score = 1.0 * read_score / aln_len;
+					else read_score = 0;
+					keep = 0 < read_score && A.scoreT <= score;
+				}
+			}
+		}
+		// room in the run pool: one atomic per wavefront (a wave prefix sum of the run counts) instead of one per read on a
+		// single counter
+		const int need = keep ? T.em.n : 0;
+		int incl = need;
+		for(int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if(lane >= d) incl += v; }
+		const int total = __shfl(incl, 63);
+		unsigned long long base = 0;
+		if(lane == 63 && total) base = atomicAdd(&A.counters[0], (unsigned long long) total);
+		base = __shfl(base, 63);
+		if(!keep) continue;
+		const int64_t o = (int64_t) base + incl - need;
 		if(o + T.em.n > A.ops_pool_cap) { atomicMax(&A.counters[1], 2ull); continue; }
 		for(int x = 0; x < T.em.n; ++x) A.ops[o + x] = T.em.at(x);
 		st[0] = read_score; st[1] = start; st[2] = (t_len < end) ? end - t_len : end; st[3] = aln_len; st[4] = cs; st[5] = ce;
