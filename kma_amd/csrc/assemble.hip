@@ -48,6 +48,7 @@ struct PileArgs {
 	InsNode *nodes;
 	int64_t node_cap;
 	int32_t *seg_start;          // per template: first entry of the sorted list (n_kept if none); DB_size + 1
+	int lds_node_limit;          // test hook (KMAHIP_PILE_LDS_NODES): fewer insertion columns per template in LDS than fit
 };
 
 // oriented read base (0-3, 4 = N): the read as ConClave filed it
@@ -105,129 +106,227 @@ __global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys
 // depths -- go to L2 as well (agent-scope relaxed atomic loads) instead of invalidating the caches: a device-scope
 // __threadfence() per phase writes back and invalidates the XCD's whole L2 and cost 0.5 ms a piece.
 template <class T> __device__ __forceinline__ T ld_l2(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// chain links (plain stores by a thread of the same workgroup, read after a barrier): the CU's own L1 is coherent for them
+template <class T> __device__ __forceinline__ T ld_wg(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
+// A template whose columns fit keeps EVERYTHING its workgroup shares in LDS while the reads are piled up -- counts (6 words a
+// column), chain heads (1), and the insertion columns themselves (8 words each, numbered per template) -- and writes it out
+// once at the end (the insertion columns get a contiguous range of the HBM pool then). The pile-up is bound by the increments
+// (150 per read) and by walking the chains: L2 performs a few G atomics/s for the whole chip and a chain link read from it
+// takes a microsecond, where every CU's LDS does its own in tens of cycles. Templates too long for that (and a launch whose
+// insertion columns overflowed the LDS table, which is repeated) work on HBM as described above.
+extern __shared__ uint32_t pile_lds[];      // [6 * t_len] counts, [t_len] chain heads, [8 * lds_nodes] insertion columns
+constexpr int PILE_LDS_WORDS = (160 * 1024 - 1024) / 4;
+constexpr int PILE_LDS_MIN_NODES = 64;
+
+template <bool LDS>
 struct Walk {
 	const PileArgs &A;
 	int64_t tbase;
 	int t_len;
-	__device__ __forceinline__ bool is_node(int cur) const { return cur >= t_len; }
-	__device__ __forceinline__ InsNode &node(int cur) const { return A.nodes[cur - t_len - 1]; }    // 1-based ids: cur = t_len + id
-	// the column after `cur` in ring order
-	__device__ int next(int cur) const {
-		if(is_node(cur)) { const InsNode &n = node(cur); const int nx = ld_l2(&n.next); return nx ? t_len + nx : ld_l2(&n.gaps); }
-		const int np = (cur + 1 == t_len) ? 0 : cur + 1;
-		const int h = ld_l2(&A.chain_head[tbase + np]);
-		return h ? t_len + h : np;
+	unsigned *s_nodes;          // LDS mode: insertion columns in use
+	__device__ __forceinline__ int node_base() const { return 7 * t_len; }
+	__device__ __forceinline__ int node_cap() const { return min((PILE_LDS_WORDS - 7 * t_len) / 8, A.lds_node_limit); }
+	// the chain head in front of template position p (1-based column ids, 0 = none)
+	__device__ __forceinline__ int head(int p) const { return LDS ? (int) pile_lds[6 * t_len + p] : ld_wg(&A.chain_head[tbase + p]); }
+	__device__ __forceinline__ void set_head(int p, int id) const { if(LDS) pile_lds[6 * t_len + p] = (uint32_t) id; else A.chain_head[tbase + p] = id; }
+	// insertion column h
+	__device__ __forceinline__ int next(int h) const { return LDS ? (int) pile_lds[node_base() + 8 * (h - 1) + 6] : ld_wg(&A.nodes[h - 1].next); }
+	__device__ __forceinline__ void set_next(int h, int id) const { if(LDS) pile_lds[node_base() + 8 * (h - 1) + 6] = (uint32_t) id; else A.nodes[h - 1].next = id; }
+	__device__ __forceinline__ void add_node(int h, int b) const {
+		if(LDS) atomicAdd(&pile_lds[node_base() + 8 * (h - 1) + b], 1u); else atomicAdd(&A.nodes[h - 1].c[b], 1u);
 	}
-	__device__ __forceinline__ uint32_t *counts(int cur) const { return is_node(cur) ? node(cur).c : A.counts + 6 * (tbase + cur); }
-	__device__ int depth16(int cur) const {
-		const uint32_t *c = counts(cur);
+	__device__ __forceinline__ void add_col(int p, int b) const {      // template column p
+		if(LDS) atomicAdd(&pile_lds[6 * p + b], 1u); else atomicAdd(&A.counts[6 * (tbase + p) + b], 1u);
+	}
+	// depth as the reference's 16-bit counters hold it; h = 0: template column p
+	__device__ int depth16(int h, int p) const {
 		int s = 0;
-		for(int j = 0; j < 6; ++j) s += (int) min(ld_l2(&c[j]), 65535u);
+		if(LDS) { const uint32_t *c = h ? &pile_lds[node_base() + 8 * (h - 1)] : &pile_lds[6 * p]; for(int j = 0; j < 6; ++j) s += (int) min(c[j], 65535u); }
+		else { const uint32_t *c = h ? A.nodes[h - 1].c : A.counts + 6 * (tbase + p); for(int j = 0; j < 6; ++j) s += (int) min(ld_l2(&c[j]), 65535u); }
 		return s;
+	}
+	// a new insertion column (called by one thread at a time); 0: none left (status is set)
+	__device__ int new_node(int bias, int b, int gaps) const {
+		if(LDS) {
+			const int id = (int) ++*s_nodes;
+			if(id > node_cap()) { atomicMax(&A.counters[1], 16ull); return 0; }
+			uint32_t *c = &pile_lds[node_base() + 8 * (id - 1)];
+			for(int x = 0; x < 6; ++x) c[x] = 0;
+			c[5] = (uint32_t) bias; c[b] = 1; c[6] = 0; c[7] = (uint32_t) gaps;
+			return id;
+		}
+		const long long id = (long long) atomicAdd(&A.counters[2], 1ull) + 1;
+		if(id > A.node_cap) { atomicMax(&A.counters[1], 32ull); return 0; }
+		InsNode &nn = A.nodes[id - 1];
+		for(int x = 0; x < 6; ++x) nn.c[x] = 0;
+		nn.c[5] = (uint32_t) bias; nn.c[b] = 1; nn.next = 0; nn.gaps = gaps;
+		return (int) id;
 	}
 };
 
-// alnToMat for one read. EXACT: may create insertion columns (the lane runs alone); otherwise every update is an atomic
-// increment and any number of lanes may run side by side.
-template <bool EXACT>
-__device__ void pile_read(const PileArgs &A, const Walk &W, int64_t r, bool *has_ins_out) {
-	const int32_t *st = A.stats + 10 * r;
-	const int64_t o = A.ops_off[r];
-	int n = A.n_ops[r];
+// alnToMat for one read, split into what commutes and what does not (assembly.c:1317-1444). The runs of a kept read, after the
+// leading / trailing gap runs are trimmed (assembly.c:1340-1354), cover the template columns start .. start + span - 1 of the
+// ring: every column gets the read's base (or a gap), every insertion chain BETWEEN two covered columns a gap per column
+// ("this read lacks them"). Those are plain increments and any number of lanes may do them side by side: pile_cols gives
+// lane k of G a contiguous share of one read's columns. An insertion run -- bases for the chain in front of its column,
+// new columns when the chain is too short, whose gap count starts at the depth seen so far -- is order dependent: pile_ins
+// does these, one lane, after everything earlier in the order is in. To keep the depths it reads what the reference sees
+// (the column before the site counted, the column behind it not yet), pile_cols leaves the column behind an insertion run
+// and the chain in front of it to pile_ins.
+struct ReadRuns {
 	Q q;
-	q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
-	q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
-	q.cw = -1; q.cv = 0;
-	int start = st[1], qp = st[4], first = 0;
-	// trim trailing / leading gap runs (assembly.c:1340-1354); column 0 is never trimmed from the back
-	while(n > 1 && (A.ops[o + n - 1] & 3u) >= 2u) --n;
-	while(first < n && (A.ops[o + first] & 3u) >= 2u) {
-		const uint32_t run = A.ops[o + first];
-		if((run & 3u) == 3u) start += (int) (run >> 2); else qp += (int) (run >> 2);
-		++first;
+	int64_t o;
+	int n, first, start, qp;
+};
+__device__ __forceinline__ ReadRuns read_runs(const PileArgs &A, int64_t r) {
+	ReadRuns R;
+	const int32_t *st = A.stats + 10 * r;
+	R.o = A.ops_off[r];
+	R.n = A.n_ops[r];
+	R.q.w = A.seq + A.seq_off[r]; R.q.L = A.len[r]; R.q.N = A.N + A.N_off[r]; R.q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+	R.q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
+	R.q.cw = -1; R.q.cv = 0;
+	R.start = st[1]; R.qp = st[4]; R.first = 0;
+	// column 0 is never trimmed from the back
+	while(R.n > 1 && (A.ops[R.o + R.n - 1] & 3u) >= 2u) --R.n;
+	while(R.first < R.n && (A.ops[R.o + R.first] & 3u) >= 2u) {
+		const uint32_t run = A.ops[R.o + R.first];
+		if((run & 3u) == 3u) R.start += (int) (run >> 2); else R.qp += (int) (run >> 2);
+		++R.first;
 	}
-	if(has_ins_out) {
-		bool ins = false;
-		for(int j = first; j < n; ++j) if((A.ops[o + j] & 3u) == 2u) ins = true;
-		*has_ins_out = ins;
-		return;
+	return R;
+}
+
+__device__ bool read_has_ins(const PileArgs &A, int64_t r) {
+	const ReadRuns R = read_runs(A, r);
+	bool ins = false;
+	for(int j = R.first; j < R.n; ++j) if((A.ops[R.o + j] & 3u) == 2u) ins = true;
+	return ins;
+}
+
+template <bool LDS>
+__device__ void pile_cols(const PileArgs &A, const Walk<LDS> &W, int64_t r, int k, int G) {
+	ReadRuns R = read_runs(A, r);
+	int span = 0;
+	for(int j = R.first; j < R.n; ++j) { const uint32_t run = A.ops[R.o + j]; if((run & 3u) != 2u) span += (int) (run >> 2); }
+	const int chunk = (span + G - 1) / G, lo = k * chunk, hi = min(span, lo + chunk);
+	if(lo >= hi) return;
+	int i = 0, qpos = R.qp;
+	bool after_ins = false;
+	for(int j = R.first; j < R.n && i < hi; ++j) {
+		const uint32_t run = A.ops[R.o + j];
+		const int cls = (int) (run & 3u), len = (int) (run >> 2);
+		if(cls == 2) { qpos += len; after_ins = true; continue; }
+		for(int c = max(i, lo); c < min(i + len, hi); ++c) {
+			if(after_ins && c == i) continue;                       // pile_ins
+			int p = R.start + c;
+			if(p >= W.t_len) p -= W.t_len;
+			W.add_col(p, cls == 3 ? 5 : q_base(R.q, qpos + (c - i)));
+			if(c > 0) for(int h = W.head(p); h; h = W.next(h)) W.add_node(h, 5);
+		}
+		if(cls != 3) qpos += len;
+		i += len;
+		after_ins = false;
 	}
-	int cur = start;
-	for(int j = first; j < n; ++j) {
-		const uint32_t run = A.ops[o + j];
+}
+
+template <bool LDS>
+__device__ void pile_ins(const PileArgs &A, const Walk<LDS> &W, int64_t r) {
+	ReadRuns R = read_runs(A, r);
+	int i = 0, qpos = R.qp;
+	for(int j = R.first; j < R.n; ++j) {
+		const uint32_t run = A.ops[R.o + j];
 		const int cls = (int) (run & 3u);
 		int left = (int) (run >> 2);
-		// '=' and 'X' runs are the same thing here (an aligned pair: the read's base is counted): taken as ONE stretch, so
-		// that the lanes of a wavefront -- reads with their mismatches in different places -- stay in step
-		if(cls < 2) while(j + 1 < n && (A.ops[o + j + 1] & 3u) < 2u) { ++j; left += (int) (A.ops[o + j] >> 2); }
-		while(left > 0) {
-			if(cls == 2) {
-				if(!EXACT) return;                                  // cannot happen: such reads are piled up alone
-				if(W.is_node(cur)) {                                // an insertion column that already exists
-					atomicAdd(&W.counts(cur)[q_base(q, qp++)], 1u);
-					--left;
-					cur = W.next(cur);
-				} else {
-					// new columns in front of template position `gaps` (assembly.c:1368-1428)
-					const int gaps = cur;
-					int last = gaps ? gaps - 1 : W.t_len - 1;
-					for(int h = ld_l2(&A.chain_head[W.tbase + gaps]); h; h = ld_l2(&A.nodes[h - 1].next)) last = W.t_len + h;
-					int myBias = W.depth16(last);
-					const int tmp = W.depth16(gaps);
-					myBias = (tmp < myBias) ? tmp : (myBias - 1);
-					if(65535 < myBias) myBias = 65535;
-					while(left > 0) {
-						const long long id = (long long) atomicAdd(&A.counters[2], 1ull) + 1;
-						if(id > A.node_cap) { atomicMax(&A.counters[1], 32ull); return; }
-						InsNode &nn = A.nodes[id - 1];
-						for(int x = 0; x < 6; ++x) nn.c[x] = 0;
-						nn.c[5] = (uint32_t) myBias; nn.c[q_base(q, qp++)] = 1; nn.next = 0; nn.gaps = gaps;
-						wg_fence();
-						if(W.is_node(last)) W.node(last).next = (int32_t) id; else A.chain_head[W.tbase + gaps] = (int32_t) id;
-						last = W.t_len + (int) id;
-						--left;
-					}
-					cur = gaps;
-				}
-			} else if(W.is_node(cur)) {                             // existing insertion column this read lacks
-				atomicAdd(&W.counts(cur)[5], 1u);
-				cur = W.next(cur);
-			} else if(cur + 1 < W.t_len) {
-				// plain template columns, up to eight at a time: the chain heads in front of the next positions are fetched
-				// together (one round trip instead of one per column); the walk stops behind the first position that has one
-				const int m = min(min(left, 8), W.t_len - 1 - cur);
-				int32_t hd[8];
-#pragma unroll
-				for(int i = 0; i < 8; ++i) hd[i] = i < m ? ld_l2(&A.chain_head[W.tbase + cur + 1 + i]) : 0;
-				int done = 0, to = 0;
-#pragma unroll
-				for(int i = 0; i < 8; ++i) {
-					if(i < m && !to) {
-						const int b = cls == 3 ? 5 : q_base(q, qp++);
-						atomicAdd(&A.counts[6 * (W.tbase + cur + i) + b], 1u);
-						++done;
-						if(hd[i]) to = W.t_len + hd[i];
-					}
-				}
-				left -= done;
-				cur = to ? to : cur + done;
-			} else {
-				const int b = cls == 3 ? 5 : q_base(q, qp++);
-				atomicAdd(&W.counts(cur)[b], 1u);
-				--left;
-				cur = W.next(cur);
-			}
+		if(cls != 2) { if(cls != 3) qpos += left; i += left; continue; }
+		int gaps = R.start + i;                                     // the template column behind the insertion
+		if(gaps >= W.t_len) gaps -= W.t_len;
+		int last = 0;                                               // last column of the chain walked so far (0: none)
+		int h = W.head(gaps);
+		// insertion columns that already exist
+		while(h && left > 0) {
+			W.add_node(h, q_base(R.q, qpos++));
+			last = h;
+			h = W.next(h);
+			--left;
 		}
+		if(left > 0) {
+			// new columns in front of template position `gaps` (assembly.c:1368-1428)
+			int myBias = W.depth16(last, gaps ? gaps - 1 : W.t_len - 1);
+			const int tmp = W.depth16(0, gaps);
+			myBias = (tmp < myBias) ? tmp : (myBias - 1);
+			if(65535 < myBias) myBias = 65535;
+			while(left > 0) {
+				const int id = W.new_node(myBias, q_base(R.q, qpos++), gaps);
+				if(!id) return;
+				wg_fence();
+				if(last) W.set_next(last, id); else W.set_head(gaps, id);
+				last = id;
+				--left;
+			}
+		} else for(; h; h = W.next(h)) W.add_node(h, 5);            // the rest of the chain: columns this read lacks
+		// the column behind the insertion: first element of the next run (there is one: trailing gap runs are trimmed)
+		const int ncls = j + 1 < R.n ? (int) (A.ops[R.o + j + 1] & 3u) : 0;
+		W.add_col(gaps, ncls == 3 ? 5 : q_base(R.q, qpos));
 	}
 }
 
 constexpr int PILE_THREADS = 1024;     // one workgroup per template: reads are taken PILE_THREADS at a time
 
-__global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_kept) {
-	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
+// the reads [s0, s1) of the sorted list -- one template's -- PILE_THREADS at a time
+template <bool LDS>
+__device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0, int64_t s1, unsigned long long *s_ins) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for(int64_t b = s0; b < s1; b += PILE_THREADS) {
+		const bool valid = b + tid < s1;
+		const int64_t r = valid ? (int64_t) A.vals[b + tid] : 0;
+		const unsigned long long m = __ballot(valid && read_has_ins(A, r));
+		if(lane == 0) s_ins[wave] = m;
+		__syncthreads();
+		// a stretch of reads without an insertion run plus the aligned columns of the insertion-bearing read behind it go side
+		// by side, G lanes a read; then that read's insertion runs, alone
+		int cur = 0;
+		while(cur < PILE_THREADS) {
+			int nxt = PILE_THREADS;
+			for(int w = cur >> 6; w < PILE_THREADS / 64; ++w) {
+				unsigned long long x = s_ins[w];
+				if(w == (cur >> 6)) x &= ~0ull << (cur & 63);
+				if(x) { nxt = (w << 6) + __ffsll((long long) x) - 1; break; }
+			}
+#ifdef KMAHIP_DIAG
+			const unsigned long long c0 = wall_clock64();
+#endif
+			const int cnt = min(nxt + 1, PILE_THREADS) - cur;
+			int g_sh = 6;
+			while(g_sh > 0 && (cnt << g_sh) > PILE_THREADS) --g_sh;
+			const int idx = cur + (tid >> g_sh);
+			if(idx < cur + cnt && b + idx < s1) pile_cols(A, W, (int64_t) A.vals[b + idx], tid & ((1 << g_sh) - 1), 1 << g_sh);
+			wg_fence();
+			__syncthreads();
+#ifdef KMAHIP_DIAG
+			const unsigned long long c1 = wall_clock64();
+#endif
+			if(nxt < PILE_THREADS) {
+				if(tid == nxt) pile_ins(A, W, r);
+				wg_fence();
+				__syncthreads();
+			}
+#ifdef KMAHIP_DIAG
+			if(tid == 0 && blockIdx.x == 7) { atomicAdd(&A.counters[10], c1 - c0); atomicAdd(&A.counters[11], wall_clock64() - c1); atomicAdd(&A.counters[12], 1ull); }
+#endif
+			cur = nxt + 1;
+		}
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_kept, int lds_cols) {
+	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
+	__shared__ unsigned s_nodes;
+	__shared__ long long s_pool;
+	const int tid = threadIdx.x;
 	const int64_t D = A.db.DB_size;
 	for(int64_t t = 1 + blockIdx.x; t < D; t += gridDim.x) {
 		const int64_t s0 = A.seg_start[t];
@@ -239,45 +338,33 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			while(lo < hi) { const int64_t mid = (lo + hi) >> 1; if((int64_t) (A.keys[mid] >> 40) <= t) lo = mid + 1; else hi = mid; }
 			s1 = lo;
 		}
-		Walk W{A, A.db.cat_off[t], A.db.tlen[t]};
-		for(int64_t b = s0; b < s1; b += PILE_THREADS) {
-			const bool valid = b + tid < s1;
-			const int64_t r = valid ? (int64_t) A.vals[b + tid] : 0;
-			bool ins = false;
-			if(valid) pile_read<false>(A, W, r, &ins);
-			const unsigned long long m = __ballot(valid && ins);
-			if(lane == 0) s_ins[wave] = m;
+		const int64_t tbase = A.db.cat_off[t];
+		const int t_len = A.db.tlen[t];
+		if(t_len <= lds_cols) {
+			const Walk<true> W{A, tbase, t_len, &s_nodes};
+			for(int i = tid; i < 7 * t_len; i += PILE_THREADS) pile_lds[i] = 0;
+			if(tid == 0) s_nodes = 0;
 			__syncthreads();
-			// stretches of reads without an insertion run go side by side; a read with one goes alone, in order
-			int cur = 0;
-			while(cur < PILE_THREADS) {
-				int nxt = PILE_THREADS;
-				for(int w = cur >> 6; w < PILE_THREADS / 64; ++w) {
-					unsigned long long x = s_ins[w];
-					if(w == (cur >> 6)) x &= ~0ull << (cur & 63);
-					if(x) { nxt = (w << 6) + __ffsll((long long) x) - 1; break; }
+			pile_template(A, W, s0, s1, s_ins);
+			// out to HBM; the insertion columns get a contiguous range of the pool (ids base + 1 ...)
+			const int n_nodes = min((int) s_nodes, W.node_cap());
+			if(tid == 0) s_pool = n_nodes ? (long long) atomicAdd(&A.counters[2], (unsigned long long) n_nodes) : 0;
+			__syncthreads();
+			const long long base = s_pool;
+			if(base + n_nodes > A.node_cap) { if(tid == 0) atomicMax(&A.counters[1], 32ull); }
+			else {
+				for(int i = tid; i < 6 * t_len; i += PILE_THREADS) A.counts[6 * tbase + i] = pile_lds[i];
+				for(int i = tid; i < t_len; i += PILE_THREADS) { const int h = (int) pile_lds[6 * t_len + i]; A.chain_head[tbase + i] = h ? (int32_t) (base + h) : 0; }
+				for(int i = tid; i < n_nodes; i += PILE_THREADS) {
+					const uint32_t *c = &pile_lds[W.node_base() + 8 * i];
+					InsNode &nn = A.nodes[base + i];
+					for(int x = 0; x < 6; ++x) nn.c[x] = c[x];
+					nn.next = c[6] ? (int32_t) (base + c[6]) : 0;
+					nn.gaps = (int32_t) c[7];
 				}
-#ifdef KMAHIP_DIAG
-				const unsigned long long c0 = wall_clock64();
-#endif
-				if(valid && tid >= cur && tid < nxt) pile_read<false>(A, W, r, nullptr);
-				wg_fence();
-				__syncthreads();
-#ifdef KMAHIP_DIAG
-				const unsigned long long c1 = wall_clock64();
-#endif
-				if(nxt < PILE_THREADS) {
-					if(tid == nxt) pile_read<true>(A, W, r, nullptr);
-					wg_fence();
-					__syncthreads();
-				}
-#ifdef KMAHIP_DIAG
-				if(tid == 0 && blockIdx.x == 7) { atomicAdd(&A.counters[10], c1 - c0); atomicAdd(&A.counters[11], wall_clock64() - c1); atomicAdd(&A.counters[12], 1ull); }
-#endif
-				cur = nxt + 1;
 			}
 			__syncthreads();
-		}
+		} else pile_template(A, Walk<false>{A, tbase, t_len, nullptr}, s0, s1, s_ins);
 	}
 }
 
@@ -454,9 +541,20 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	A.max_frag = max_frag > 0 ? max_frag : 1000000;
 	A.keys = ws->p_keys; A.vals = ws->p_vals; A.counters = ws->counters;
 	A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.node_cap = node_cap; A.seg_start = ws->p_seg;
+	A.lds_node_limit = getenv("KMAHIP_PILE_LDS_NODES") ? atoi(getenv("KMAHIP_PILE_LDS_NODES")) : 1 << 30;
 	if(n == 0) return KMAHIP_OK;
 	void *tmp = nullptr;
 	size_t tmp_bytes = 0;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto t_prev = now();
+	auto lap = [&](const char *what) {
+		if(!dbg) return;
+		(void) hipStreamSynchronize(stream);
+		const auto t = now();
+		fprintf(stderr, "[kmahip] pile-up: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+		t_prev = t;
+	};
 	{
 		// rank of every read among the filed fragments: exclusive scan of (tmpl != 0)
 		int64_t *filed = ws->p_rank + n;
@@ -477,6 +575,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	HIP_TRY(hipStreamSynchronize(stream));
 	ws->p_kept = (int64_t) kept;
 	if(!kept) return KMAHIP_OK;
+	lap("ranks + keys");
 	// sort by (template, reference order)
 	uint64_t *keys_out = ws->p_keys + n;
 	int32_t *vals_out = ws->p_vals + n;
@@ -495,13 +594,29 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		HIP_TRY(hipStreamSynchronize(stream));
 	}
 	hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((kept + 255) / 256)), dim3(256), 0, stream, keys_out, (int64_t) kept, ws->p_seg, (int64_t) db->info.DB_size);
+	lap("sort + segments");
+#ifdef KMAHIP_DIAG
+	HIP_TRY(hipMemsetAsync(ws->counters + 10, 0, 6 * sizeof(unsigned long long), stream));
+#endif
 	const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(db->info.DB_size, 1), 256 * 8);
-	hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), 0, stream, A, (int64_t) kept);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(stream));
-	(void) hipFree(tmp);
+	// templates up to lds_cols columns are piled up in LDS (see Walk); if one of them ran out of room for its insertion columns
+	// there, the launch is repeated on HBM
+	int lds_cols = getenv("KMAHIP_PILE_NO_LDS") ? 0 : (PILE_LDS_WORDS - 8 * PILE_LDS_MIN_NODES) / 7;
+	HIP_TRY(hipFuncSetAttribute((const void *) pileup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PILE_LDS_WORDS * 4));
 	unsigned long long c[3];
-	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	for(;;) {
+		hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), lds_cols ? (size_t) PILE_LDS_WORDS * 4 : 0, stream, A, (int64_t) kept, lds_cols);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(stream));
+		lap("pileup_kernel");
+		HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+		if(c[1] != 16 || !lds_cols) break;
+		lds_cols = 0;
+		HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
+		HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
+		HIP_TRY(hipMemsetAsync(ws->counters + 1, 0, 2 * sizeof(unsigned long long), stream));
+	}
+	(void) hipFree(tmp);
 	if(c[1]) {
 		HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
 		kmahip_set_error("pile-up: insertion column pool exhausted (%lld columns)", (long long) node_cap);
@@ -510,10 +625,10 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	ws->p_nodes_used = (int64_t) c[2];
 #ifdef KMAHIP_DIAG
 	{
-		unsigned long long dbg[3];
+		unsigned long long dbg[6];
 		HIP_TRY(hipMemcpy(dbg, ws->counters + 10, sizeof dbg, hipMemcpyDeviceToHost));
 		HIP_TRY(hipMemset(ws->counters + 10, 0, sizeof dbg));
-		fprintf(stderr, "[kmahip] pile-up workgroup 7: %llu phases, parallel part %.1f us, serial part %.1f us per phase (100 MHz clock)\n", dbg[2],
+		fprintf(stderr, "[kmahip] pile-up workgroup 7: %llu phases, parallel part %.1f us, serial part %.1f us per phase; (100 MHz clock)\n", dbg[2],
 		        dbg[2] ? dbg[0] / 100.0 / dbg[2] : 0.0, dbg[2] ? dbg[1] / 100.0 / dbg[2] : 0.0);
 	}
 #endif
