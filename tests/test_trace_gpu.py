@@ -356,3 +356,25 @@ def test_one_call_paired_run_matches_reference_files(golden_pe, tmp_path):
     rows = gzip.open(tmp_path / "x.frag.gz", "rt").read().splitlines()
     sam = golden_util.load_sam("pe")
     assert len(rows) == sum(len(v) for v in sam.values()) > 1000          # one row per SAM record of the reference run
+
+def test_pileup_in_lds_equals_pileup_in_hbm(golden_se, golden_long, monkeypatch):
+    """The pile-up keeps a template's columns (and its insertion columns) in LDS when they fit; a template too long for it, or
+    a launch whose insertion columns overflowed the LDS table (repeated on HBM), works on HBM. Same result either way:
+    default; KMAHIP_PILE_NO_LDS=1 (HBM from the start); KMAHIP_PILE_LDS_NODES=1 (overflow after one insertion column)."""
+    from kma_amd import binding
+    for g in (golden_se, golden_long):
+        res = []
+        for env in ({}, {"KMAHIP_PILE_NO_LDS": "1"}, {"KMAHIP_PILE_LDS_NODES": "1"}):
+            for k in ("KMAHIP_PILE_NO_LDS", "KMAHIP_PILE_LDS_NODES"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            db = binding.KmaHipDB(g["prefix"])
+            try:
+                res.append(db.run_se(g["batch"], per_read=False))
+            finally:
+                db.close()
+        for o in res[1:]:
+            for key in ("cover", "aln_len", "depth", "asm_len"):
+                assert np.array_equal(res[0][key], o[key]), key
+            assert res[0]["consensus"] == o["consensus"]
