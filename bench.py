@@ -4,8 +4,14 @@
 One "step" = one pass of the HIP hot path over one batch of synthetic reads that
 is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
 10 M x 150 bp single-end reads against a 5 k-gene database, `-1t1`.  With N > 1
-every rank maps its own 10 M-read shard (weak scaling); reads are independent,
-so there is no data-path collective inside stage 2.
+every rank maps its own 10 M-read shard (weak scaling, the default) or its share
+of the fixed 10 M reads (`--scaling strong`; a weak run also reports the strong
+figure as the extra key `strong_scaling`); reads are independent, so the only
+data-path collective is the SUM of the two ConClave score vectors (RCCL).
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (a
+torch.distributed.run child, before this process touches the GPU); under a
+launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,7 +48,32 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --reads per rank; strong: --reads in total, sharded over the ranks")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`--gpus N` given to a plain python process: start the N ranks as a child launcher. Nothing in this process has touched
+    the GPU yet (no torch.cuda call, no HIP call), and the child is a new process, not an exec of this one."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def kernel_src_sha():
+    """hash of the kernel sources a PMC traffic figure belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("scan.hip", "align.hip", "kmahip_internal.h"):
+        h.update(open(os.path.join(ROOT, "kma_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def write_fastq_fixed(path, codes):
@@ -126,9 +157,13 @@ def parity_sample(prefix, codes, got_scan, got_hits):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.share_gpu:
@@ -141,6 +176,8 @@ def main():
             dist.init_process_group(a.backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # n_gpus is what the process group reports, not what was asked for
+    world = dist.get_world_size() if world > 1 else 1
 
     from kma_amd import binding, formats, synth, synth_dev
     from kma_amd.dist import allreduce_scores
@@ -151,6 +188,10 @@ def main():
         formats.write_index(prefix, names, seqs)
         db = binding.KmaHipDB(prefix, device=local)
         n = a.reads
+        if a.scaling == "strong":
+            from kma_amd.dist import shard_bounds
+            lo, hi = shard_bounds(a.reads, rank, world)
+            n = hi - lo
         keep = min(n, a.cpu_sample) if rank == 0 else 0
         rd = synth_dev.make_packed_reads(seqs, n, seed=1000 + rank, device=dev, keep_codes=keep,
                                          random_frac=0.02 if a.hard else 0.0, junk_frac=0.02 if a.hard else 0.0)
@@ -168,12 +209,13 @@ def main():
         uniq = torch.zeros(D, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
 
-        def step():
+        def step(m=n):
+            # m < n: the first m reads of this rank's batch (CSR prefix views) -- the strong-scaling leg
             aln.zero_(); uniq.zero_()
-            db.scan_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], rc_flag, flag, T_off, T,
-                           stream=stream)
-            db.align_se_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, rc_flag, flag, T_off, T,
-                            n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
+            db.scan_se_dev(rd["seq"], rd["seq_off"][:m + 1], rd["length"][:m], rd["N"], rd["N_off"][:m + 1], rc_flag[:m], flag[:m],
+                           T_off[:m + 1], T, stream=stream)
+            db.align_se_dev(rd["seq"], rd["seq_off"][:m + 1], rd["length"][:m], rd["N"], rd["N_off"][:m + 1], 150, rc_flag[:m], flag[:m],
+                            T_off[:m + 1], T, n_hits[:m], best[:m], oflag[:m], h_t, h_sc, h_s, h_e, aln, uniq, stream=stream)
             # the path's only exchange: SUM of the two ConClave score vectors over the read shards (no-op at N=1)
             if world > 1 and a.backend != "nccl":
                 ca, cu = aln.cpu(), uniq.cpu()
@@ -204,10 +246,29 @@ def main():
         seed_ms, seed_n = db.get_timing(3)
         db.set_timing(False)
         db.status(stream)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+
+        def max_over_ranks(x):
+            if world == 1:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            return float(t.item())
+        dt = max_over_ranks(dt)
+        # strong scaling beside the weak figure: the same K steps on this rank's share of ONE batch of a.reads reads
+        strong = None
+        if a.scaling == "weak" and world > 1:
+            from kma_amd.dist import shard_bounds
+            lo, hi = shard_bounds(a.reads, rank, world)
+            m = hi - lo
+            step(m)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step(m)
+            fence()
+            dts = max_over_ranks(time.perf_counter() - t0)
+            strong = {"reads_total": a.reads, "reads_per_gpu": m, "ms_per_step": dts / a.steps * 1e3, "value": a.reads * a.steps / dts,
+                      "unit": "reads/s", "note": "same timed loop with the fixed batch sharded over the ranks (max over ranks)"}
 
         # algorithmic work of one launch (separate, untimed, counter-enabled launches)
         db.set_stats(True)
@@ -246,32 +307,35 @@ def main():
             dom = dict(kernel="scan_se_kernel", kernel_ms=scan_s * 1e3, achieved=scan_bytes / scan_s / 1e9,
                        algorithmic_bytes_per_launch=scan_bytes)
 
-        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
-        # committed rocprofv3 --pmc summary of this same command (profiles/r1_pmc_traffic.json) supplies it
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
+        # --pmc summary of this same command supplies it -- but only while the kernel sources are the ones it was taken on
+        # (tools/collect_profiles.py stores their hash); a stale figure is dropped, not reported
         traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if dom["kernel"] in pmc and n == 10_000_000 and a.families == 1000:
-                traffic = pmc[dom["kernel"]]["corrected_bytes"]
-                traffic_src = "profiles/r1_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes"
-        except (OSError, ValueError, KeyError):
-            pass
+        for prof in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if dom["kernel"] in pmc and n == 10_000_000 and a.families == 1000 and pmc.get("_kernel_src_sha256") == kernel_src_sha():
+                    traffic = pmc[dom["kernel"]]["corrected_bytes"]
+                    traffic_src = f"profiles/{prof}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate --pmc passes, kernel sources {pmc['_kernel_src_sha256'][:12]}"
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
 
         out = {
             "metric": "mapped reads/sec (whole node), 10M×150bp vs 5k-gene DB, 1/2/4/8 GPU",
-            "value": world * n * a.steps / dt,
+            "value": (world * n if a.scaling == "weak" else a.reads) * a.steps / dt,
             "unit": "reads/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "i32",
             "data": "synthetic",
             "config": {
-                "workload": f"{n} x 150 bp SE reads per GPU vs {5 * a.families}-gene DB (k=16), -1t1; one step = "
+                "workload": f"{n} x 150 bp SE reads per GPU" + (f" ({a.reads} in total, sharded)" if a.scaling == "strong" else "") + f" vs {5 * a.families}-gene DB (k=16), -1t1; one step = "
                             "stage 2 (k-mer probe + candidate-template scoring) + stage 3a (MEM seeding, chaining, "
                             "NW extension, per-read hit selection, ConClave score vectors) on reads resident in HBM"
                             + ("; HARD MIX (not the BASELINE workload): 2 % unmappable reads, 2 % with 60-120 foreign end bases" if a.hard else ""),
@@ -283,6 +347,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "achieved_kind": "effective: SURVEY 8(d) algorithmic bytes of the REFERENCE layout (12 B per resolved k-mer start, ...) / "
+                                 "kernel time measured with HIP events in this run; the kernel resolves most k-mer starts by walking the "
+                                 "template store instead of probing (see scan.hash_probes), so this is not a DRAM bandwidth reading",
                 "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"],
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "prefilter": {"kernel_ms": pre_s * 1e3, "probes": int(st.prefilter_probes), "GB/s": pre_bytes / pre_s / 1e9,
@@ -326,6 +393,8 @@ def main():
                 out["whole_pipeline"] = {"error": str(e)}
         elif rank == 0:
             out["cpu_baseline"] = None
+        if strong is not None:
+            out["strong_scaling"] = strong
         if rank == 0:
             print(json.dumps(out), flush=True)
         db.close()

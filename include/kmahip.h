@@ -400,8 +400,15 @@ int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, 
 int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scores, uint64_t *uniq_alignment_scores,
                             size_t DB_size, void *stream);
 
-/* status of the last *_dev call on this workspace after the stream has been
- * synchronised: 0 or KMAHIP_EOVERFLOW */
+/* Status of the *_dev calls issued on this workspace since the last query; synchronises `stream`. 0, or KMAHIP_EOVERFLOW
+ * with kmahip_last_error() naming one of:
+ *   - the library's own candidate pool ran out (stage 2): the pool has been doubled, repeat the scan call (and what
+ *     followed it) -- no caller capacity is involved;
+ *   - T_cap (kmahip_cands / kmahip_pe_recs) or ops_cap (kmahip_traces) too small: T_off[n] / R_off[2n] holds the needed
+ *     size. A kmahip_align_*_dev call queued behind such a scan touches nothing beyond the capacities (it reports no hits),
+ *     so scan_dev + align_dev may be chained on a stream without a status check in between;
+ *   - more MEMs per (read, template) pair than the align scratch holds, or a DP problem beyond the trace scratch.
+ * The status word is sticky until read here. */
 int kmahip_ws_status(kmahip_ws *ws, void *stream);
 
 /* Algorithmic work counters of the last scan on this workspace (read after a sync): probes = k-mer starts

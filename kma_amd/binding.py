@@ -103,13 +103,21 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH) and "KMAHIP_LIB" not in os.environ:
-            # build on demand (same recipe as __graft_entry__.build()); there is no other implementation to fall back to
+        if "KMAHIP_LIB" not in os.environ:
+            # build on demand, also when a source is newer than the library (the .so is git-ignored but travels to the GPU box:
+            # a stale one must never be what gets tested or benchmarked). `make -q` costs milliseconds when everything is current;
+            # there is no other implementation to fall back to
+            import shutil
             import subprocess
-            try:
-                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=subprocess.DEVNULL)
-            except (OSError, subprocess.CalledProcessError) as e:
-                raise KmaHipError(f"{LIB_PATH} is not built and building it failed ({e}): run __graft_entry__.build()")
+            csrc = os.path.join(_HERE, "csrc")
+            stale = not os.path.exists(LIB_PATH)
+            if not stale and shutil.which("make"):
+                stale = subprocess.call(["make", "-q", "-C", csrc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0
+            if stale:
+                try:
+                    subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+                except (OSError, subprocess.CalledProcessError) as e:
+                    raise KmaHipError(f"{LIB_PATH} is missing or older than its sources and building it failed ({e}): run __graft_entry__.build()")
         if not os.path.exists(LIB_PATH):
             raise KmaHipError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
         L = C.CDLL(LIB_PATH)

@@ -61,6 +61,8 @@ struct AlignArgs {
 	int seed_slots;          // seed slots per task: 1 (single end) or 2 (paired records: both mates of a couple)
 	int *xq;                 // spill queues for deferred DP problems, per wavefront 4 classes x xq_cap entries of QENT ints (long reads)
 	int xq_cap;
+	int64_t tasks_cap;       // capacity of T / the task scratch / the caller's hit arrays: a candidate list that outgrew it (stage 2 set
+	                         // status 2 and still wrote the full offsets) is not touched, every kernel returns at once
 	// scratch
 	int32_t *s32;
 	uint64_t *s64;
@@ -1227,6 +1229,7 @@ __device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView 
 
 __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 	const int64_t n_tasks = A.T_off[A.n_reads];
+	if(n_tasks > A.tasks_cap) return;
 	const int k = (int) A.db.kmersize;
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
 	const int slots = A.seed_slots;
@@ -1300,6 +1303,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	uint8_t *const tbuf = s_tbuf + wave * TBUF;
 	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
 	const int64_t n_tasks = A.T_off[A.n_reads];
+	if(n_tasks > A.tasks_cap) return;
 	const int k = (int) A.db.kmersize;
 	// the wave stays together: every round each lane does its own task up to the (deferred) wide DP problems,
 	// then all 64 lanes solve those, then each lane finishes its task
@@ -1505,9 +1509,10 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 }
 
 // task -> owning record, so that the task kernel needs one coalesced load instead of a 23-step binary search
-__global__ __launch_bounds__(256) void task_map_kernel(const int64_t *T_off, int64_t n, int32_t *t_rec) {
+__global__ __launch_bounds__(256) void task_map_kernel(const int64_t *T_off, int64_t n, int32_t *t_rec, int64_t tasks_cap, unsigned long long *counters) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(r >= n) return;
+	if(T_off[n] > tasks_cap) { if(r == 0) atomicMax(&counters[1], 2ull); return; }
 	const int64_t e = T_off[r + 1];
 	for(int64_t t = T_off[r]; t < e; ++t) t_rec[t] = (int32_t) r;
 }
@@ -1533,6 +1538,7 @@ struct ReduceArgs {
 	int32_t *out_rc;      // may be NULL. bit 0: the fragment filed for this record is the reverse complement of the original read;
 	                      // bit 1 (proper pair only): the pair's record is written second slot first (alnfrags.c:1807-1812)
 	int pe_mode, PE;
+	int64_t tasks_cap;    // as AlignArgs.tasks_cap
 	int32_t *pe_kind;     // per pair: 0 none / records handled singly, 1 proper pair, 2 unmated, 3 first only, 4 second only
 	int32_t *t_score_w, *t_alen_w, *t_start_w, *t_end_w, *t_tmpl_w;   // writable views (unmated shuffle)
 };
@@ -1705,6 +1711,13 @@ __device__ __forceinline__ void reduce_single(const ReduceArgs &R, int64_t r, in
 __global__ __launch_bounds__(256) void reduce_reads_kernel(const ReduceArgs R0) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(r >= R0.n_reads) return;
+	if(R0.T_off[R0.n_reads] > R0.tasks_cap) {
+		// candidate list beyond the capacity (status 2 is set): no hits, so that whatever runs next on the stream stays in bounds
+		R0.n_hits[r] = 0; R0.best_score[r] = 0; R0.out_flag[r] = R0.flag[r];
+		if(R0.out_rc) R0.out_rc[r] = 0;
+		if(R0.pe_mode && !(r & 1)) R0.pe_kind[r >> 1] = 0;
+		return;
+	}
 	ReduceArgs R = R0;
 	if(R.priv_copies) {
 		unsigned long long *base = R.priv + (int64_t) (blockIdx.x % (unsigned) R.priv_copies) * 2 * R.DB_size;
@@ -1735,6 +1748,13 @@ constexpr int RL_MAX_DB = 6144;
 __global__ __launch_bounds__(RL_THREADS) void reduce_reads_lds_kernel(const ReduceArgs R) {
 	__shared__ uint32_t s_acc[2 * RL_MAX_DB];
 	const int D = (int) R.DB_size;
+	if(R.T_off[R.n_reads] > R.tasks_cap) {
+		for(int64_t r = (int64_t) blockIdx.x * RL_THREADS + threadIdx.x; r < R.n_reads; r += (int64_t) gridDim.x * RL_THREADS) {
+			R.n_hits[r] = 0; R.best_score[r] = 0; R.out_flag[r] = R.flag[r];
+			if(R.out_rc) R.out_rc[r] = 0;
+		}
+		return;
+	}
 	for(int i = threadIdx.x; i < 2 * D; i += RL_THREADS) s_acc[i] = 0;
 	__syncthreads();
 	for(int64_t r = (int64_t) blockIdx.x * RL_THREADS + threadIdx.x; r < R.n_reads; r += (int64_t) gridDim.x * RL_THREADS) {
@@ -2252,7 +2272,8 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_ALIGN")) A.ablate = atoi(e);
 #endif
-	hipLaunchKernelGGL(task_map_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, cands->T_off, n, t_rec);
+	A.tasks_cap = tasks_cap;
+	hipLaunchKernelGGL(task_map_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, cands->T_off, n, t_rec, tasks_cap, ws->counters);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(A.seed_n && !A.stats) {
 		hipEvent_t es0 = nullptr, es1 = nullptr;
@@ -2300,7 +2321,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
 	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
-	R.priv = nullptr; R.priv_copies = 0; R.DB_size = db->info.DB_size;
+	R.priv = nullptr; R.priv_copies = 0; R.DB_size = db->info.DB_size; R.tasks_cap = tasks_cap;
 	if(out->alignment_scores || out->uniq_alignment_scores) {
 		const int64_t D = db->info.DB_size;
 		int copies = (int) std::min<int64_t>(64, std::max<int64_t>(1, (256ll << 20) / (16 * D)));

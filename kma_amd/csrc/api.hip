@@ -46,7 +46,16 @@ extern "C" int kmahip_ws_status(kmahip_ws *ws, void *stream) {
 	HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
 	if(c[1]) {
 		HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
-		kmahip_set_error(c[1] == 3 ? "seed (MEM) capacity per read/template pair exceeded" : "output capacity too small (status %llu)", c[1]);
+		switch(c[1]) {
+			case 1:
+				// the library's own candidate pool (cap_reads * 16 * pool_scale ints), not a caller capacity: grown by the next launch
+				ws->pool_scale *= 2; ws->cap_reads = 0;
+				kmahip_set_error("internal candidate pool exhausted: the pool has been doubled, repeat the call");
+				break;
+			case 2: kmahip_set_error("output capacity (T_cap / ops_cap) too small: the offsets array holds the needed size; stage 3a was skipped"); break;
+			case 3: kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); break;
+			default: kmahip_set_error("a read needs more scratch than the workspace holds (status %llu)", c[1]); break;
+		}
 		return KMAHIP_EOVERFLOW;
 	}
 	return KMAHIP_OK;

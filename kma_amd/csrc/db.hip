@@ -77,6 +77,9 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(!read_exact(f, h32, 12) || !read_exact(f, h64, 40)) { fclose(f); kmahip_set_error("short header in %s.comp.b", prefix); return KMAHIP_EIO; }
 	const uint32_t DB_size = h32[0], mlen = h32[1];
 	const uint64_t size = h64[1], n = h64[2], v_index = h64[3];
+	// `kma index -Sparse`: only the k-mers behind a prefix are stored and the reference maps with save_kmers_sparse, without
+	// stage 3 (kma.c:1499-1501); the -1t1 scan over such a table would be wrong without any error
+	if(h32[2] != 0 || h64[0] != 0) { fclose(f); kmahip_set_error("sparse index (prefix length %u) not supported", h32[2]); return KMAHIP_EFORMAT; }
 	if(mlen == 0 || mlen > 16) { fclose(f); kmahip_set_error("k-mer length %u needs 64-bit keys: not supported", mlen); return KMAHIP_EFORMAT; }
 	const uint64_t kmask = (1ull << (2 * mlen)) - 1;
 	if(size - 1 == kmask) { fclose(f); kmahip_set_error("direct-address (megamap) index not supported"); return KMAHIP_EFORMAT; }

@@ -39,3 +39,38 @@ def test_header_and_example_are_plain_c99():
     for src in ("kmahip_s2.c", "kmahip_res.c"):
         subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
                                "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", src)])
+
+
+def test_sparse_index_is_rejected_loudly(tmp_path):
+    """`kma index -Sparse` output (prefix_len / prefix in the .comp.b header) must not be taken for a full index: the reference
+    maps against it with save_kmers_sparse and without stage 3 (kma.c:1499-1501). The check precedes every device call."""
+    import shutil
+    import struct
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util
+    from kma_amd import binding
+    os.makedirs(tmp_path / "g")
+    g = golden_util.load_se(tmp_path / "g")
+    L = binding.lib()
+    ref = os.path.join(ROOT, "oracle", "_ref", "kma")
+    prefixes = []
+    if os.path.exists(ref):
+        fsa = tmp_path / "db.fsa"
+        import gzip
+        fsa.write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "se", "db.fsa.gz")).read())
+        subprocess.check_call([ref, "index", "-i", str(fsa), "-o", str(tmp_path / "sp"), "-Sparse", "TG"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        prefixes.append(str(tmp_path / "sp"))
+    # and a header patched by hand (prefix_len = 2, prefix = 0b1110), for boxes without the reference binary
+    for ext in (".comp.b", ".length.b", ".seq.b", ".name"):
+        shutil.copy(g["prefix"] + ext, str(tmp_path / "patched") + ext)
+    with open(str(tmp_path / "patched") + ".comp.b", "r+b") as f:
+        f.seek(8)
+        f.write(struct.pack("<IQ", 2, 14))
+    prefixes.append(str(tmp_path / "patched"))
+    for p in prefixes:
+        h = ctypes.c_void_p()
+        rc = L.kmahip_db_open(p.encode(), ctypes.byref(h))
+        assert rc == -3 and h.value is None, (p, rc)
+        assert b"sparse" in L.kmahip_last_error()
