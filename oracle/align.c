@@ -538,12 +538,13 @@ static void al_put(trace *al, long at, const uint8_t *t, const uint8_t *ss, cons
 }
 
 static aln kma_trace(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k, const uint8_t *qseq, int q_len,
-                     int q_start, int q_end, int mq, const orc_rewards *rw, trace *al, trace *fr, unsigned *mapQ_out) {
+                     int q_start, int q_end, int mq, const orc_rewards *rw, trace *al, trace *fr, unsigned *mapQ_out, int preseeded) {
 	const int bw = 64;
 	const uint64_t mask = (k < 32) ? ((1ull << (2 * k)) - 1) : ~0ull;
 	al->start = al->end = 0;
-	w->plen = 0;
-	int i = q_start;
+	/* MEMs left by anker_rc are used as they are (align.c:245-247) */
+	if(!preseeded) w->plen = 0;
+	int i = preseeded ? q_end : q_start;
 	while(i < q_end) {
 		int end = -1;
 		for(int x = i; x < q_len; ++x) if(qseq[x] == 4) { end = x; break; }     /* charpos(qseq, 4, i, q_len) */
@@ -887,6 +888,9 @@ void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, i
  * qGaps, mapQ};
  * cols (capacity cap) receives the columns as '=' 'X' 'I' (gap in template) 'D' (gap in read), the classes makeCigar
  * uses (sam.c:57-78). Returns the number of columns if the read is kept, 0 if it is dropped, -needed if cap is too small. */
+static int trace_result(aln S, const orc_rewards *rw, const orc_align_params *ap, int q_len, int t_len, unsigned mapQ, const trace *alp,
+                        int *stats, char *cols, int cap);
+
 int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, const uint8_t *read, int q_len, int t,
                     int *stats, char *cols, int cap) {
 	static trace al, fr;              /* oracle = single-threaded test code */
@@ -897,7 +901,14 @@ int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_param
 	unsigned mapQ = 0;
 	if(!a->ix[t].o) tindex_build(&a->ix[t], tseq, t_len, k);
 	fr.pos = 0;
-	aln S = kma_trace(&a->w, &a->ix[t], tseq, t_len, k, read, q_len, 0, q_len, ap->mq, rw, &al, &fr, &mapQ);
+	aln S = kma_trace(&a->w, &a->ix[t], tseq, t_len, k, read, q_len, 0, q_len, ap->mq, rw, &al, &fr, &mapQ, 0);
+	return trace_result(S, rw, ap, q_len, t_len, mapQ, &al, stats, cols, cap);
+}
+
+/* the read filter of assemble_KMA (assembly.c:1931-1961) on KMA()'s result + the columns as classes */
+static int trace_result(aln S, const orc_rewards *rw, const orc_align_params *ap, int q_len, int t_len, unsigned mapQ, const trace *alp,
+                        int *stats, char *cols, int cap) {
+	const trace al = *alp;
 	const int aln_len = S.len, start = S.pos;
 	int end = start + aln_len - S.tGaps;
 	if(t_len < end) end -= t_len;
@@ -913,6 +924,120 @@ int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_param
 	if(aln_len > cap) return -aln_len;
 	for(int i = 0; i < aln_len; ++i) cols[i] = al.s[i] == '|' ? '=' : al.t[i] == 5 ? 'I' : al.q[i] == 5 ? 'D' : 'X';
 	return aln_len;
+}
+
+/* ---- `-Mt1`: anker_rc, align.c:780-991 -- both strands of a raw read are seeded against the one template, the strand
+ * with the larger MEM coverage wins (forward on equality) and its MEMs are left in the points for KMA(). Byte-wise like
+ * the reference: qseq is reverse-complemented in place (strrc, stdnuc.c:450-466) and stays that way when the reverse
+ * strand wins. preseed (align.c:750-768, unless -ex_mode): when none of the read's every-k-th k-mers is in the index
+ * the forward strand is not seeded at all. Returns bestScore; *is_rc = 1 when qseq is left reverse-complemented. */
+static void strrc_bytes(uint8_t *q, int n) {
+	static const uint8_t comp[6] = {3, 2, 1, 0, 4, 5};
+	for(int i = 0, j = n - 1; i < (n >> 1); ++i, --j) { const uint8_t c = comp[q[i]]; q[i] = comp[q[j]]; q[j] = c; }
+	if(n & 1) q[n >> 1] = comp[q[n >> 1]];
+}
+
+static int anker_rc_bytes(aws *w, const tindex *ix, const uint64_t *tseq, int t_len, int k, uint8_t *qseq, int q_len,
+                          int one2one, int exhaustive, int *is_rc) {
+	const uint64_t mask = (k < 32) ? ((1ull << (2 * k)) - 1) : ~0ull;
+	int bestScore = 0, score = 0, score_r = 0, mem_count = 0, tot = 0, plen = 0, q_start = 0, q_end = q_len;
+	*is_rc = 0;
+	for(int rc = 0; rc < 2; ++rc) {
+		int i;
+		if(rc) {
+			strrc_bytes(qseq, q_len);
+			score = score_r; plen = mem_count;
+			i = q_len - q_start; q_start = q_len - q_end; q_end = i; i = q_start;
+		} else if(exhaustive) i = 0;
+		else {
+			/* bytes past the read end are whatever the reference's buffer held -- taken as 0 here */
+			int hit = 0;
+			for(i = 0; i < q_end - q_start && !hit; i += k) {
+				uint64_t key = 0;
+				for(int x = 0; x < k; ++x) key = (x ? (key << 2) : 0) | (uint64_t) ((i + x < q_len) ? qseq[i + x] : 0);
+				if(tindex_has(ix, key)) hit = 1;
+			}
+			if(hit) i = 0;
+		}
+		score_r = 0; mem_count = 0;
+		while(i < q_end) {
+			int end = -1;
+			for(int x = i; x < q_len; ++x) if(qseq[x] == 4) { end = x; break; }
+			if(end == -1) end = q_end;
+			uint64_t key = 0;
+#define RESTART_KEY() do { if(i < end - k) { key = 0; for(int x = 0; x < k - 1; ++x) key = (key << 2) | qseq[i + x]; i += k - 1; } else i = end + 1; } while(0)
+			RESTART_KEY();
+			while(i < end) {
+				key = ((key << 2) | qseq[i]) & mask;
+				int cnt = 0;
+				const int first = key ? tindex_find(ix, key, &cnt) : 0;
+				if(cnt == 0) { ++i; continue; }
+				i -= k - 1;
+				if(cnt == 1) {
+					aws_points(w, tot + 2);
+					int value = ix->o[first].pos, prev = value - 2, j;
+					for(j = i - 1; 0 <= j && 0 <= prev && qseq[j] == tnuc(tseq, prev); --j) { --prev; ++score_r; }
+					w->qS[tot] = j + 1; w->tS[tot] = prev + 2;
+					value += k - 1; i += k; score_r += k;
+					while(i < end && value < t_len && qseq[i] == tnuc(tseq, value)) { ++i; ++value; ++score_r; }
+					w->qE[tot] = i; w->tE[tot] = value + 1;
+					w->w[tot] = w->tE[tot] - w->tS[tot];
+					++mem_count; ++tot;
+				} else {
+					score_r += k;
+					int bias = i;
+					for(int c = 0; c < cnt; ++c) {
+						aws_points(w, tot + 2);
+						int value = ix->o[first + c].pos, prev = value - 2, j, kk = i;
+						for(j = kk - 1; 0 <= j && 0 <= prev && qseq[j] == tnuc(tseq, prev); --j) --prev;
+						w->qS[tot] = j + 1; w->tS[tot] = prev + 2;
+						value += k - 1; kk += k;
+						while(kk < end && value < t_len && qseq[kk] == tnuc(tseq, value)) { ++kk; ++value; }
+						w->qE[tot] = kk; w->tE[tot] = value + 1;
+						w->w[tot] = w->qE[tot] - w->qS[tot];
+						++mem_count; ++tot;
+						if(bias < kk) bias = kk;
+					}
+					score_r += bias - i;
+					i = bias + 1;
+				}
+				RESTART_KEY();
+			}
+#undef RESTART_KEY
+			i = end + 1;
+		}
+		if(bestScore < score_r) bestScore = score_r;
+	}
+	if(one2one && bestScore < k && bestScore * k < (q_len - k - bestScore)) { w->plen = 0; *is_rc = 1; return 0; }
+	if(bestScore == score) { strrc_bytes(qseq, q_len); w->plen = plen; return bestScore; }
+	*is_rc = 1;
+	if(plen) {
+		for(int x = 0; x < mem_count; ++x) {
+			w->tS[x] = w->tS[plen + x]; w->tE[x] = w->tE[plen + x]; w->qS[x] = w->qS[plen + x];
+			w->qE[x] = w->qE[plen + x]; w->w[x] = w->w[plen + x];
+		}
+	}
+	w->plen = mem_count;
+	return bestScore;
+}
+
+/* One raw read of the `-Mt1 t` run (runKMA_Mt1, mt1.c:86-500 -> assemble_KMA, assembly.c:1917-1965 with read_score == 0):
+ * anker_rc picks the strand and leaves the MEMs, KMA() chains and joins them, then the read filter. `read` (codes 0-4,
+ * as stage 1 trimmed it) is overwritten with the orientation that was aligned; *is_rc says which. Other outputs as
+ * orc_align_trace. */
+int orc_align_trace_mt1(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, uint8_t *read, int q_len, int t,
+                        int one2one, int exhaustive, int *stats, char *cols, int cap, int *is_rc) {
+	static trace al, fr;
+	const orc_db *db = a->db;
+	const int k = db->kmersize, t_len = db->tlen[t];
+	const uint64_t *tseq = db->tseq + db->tseq_off[t];
+	memset(stats, 0, 10 * sizeof(int));
+	if(!a->ix[t].o) tindex_build(&a->ix[t], tseq, t_len, k);
+	if(!anker_rc_bytes(&a->w, &a->ix[t], tseq, t_len, k, read, q_len, one2one, exhaustive, is_rc)) return 0;
+	unsigned mapQ = 0;
+	fr.pos = 0;
+	aln S = kma_trace(&a->w, &a->ix[t], tseq, t_len, k, read, q_len, 0, q_len, ap->mq, rw, &al, &fr, &mapQ, 1);
+	return trace_result(S, rw, ap, q_len, t_len, mapQ, &al, stats, cols, cap);
 }
 
 int64_t orc_align_se_batch(const orc_db *db, const orc_rewards *rw, const orc_align_params *ap,

@@ -105,7 +105,16 @@ static int significant(int X, int Y, double evalue) {
  * out[0] = cover (consensus base == template base), out[1] = aln_len (called columns), out[2] = depth (sum of the column
  * depths of the called columns), out[3] = number of columns walked. cons (may be NULL, capacity >= len + 1) receives the
  * consensus line ("ACGTN-", lower case = not significant). */
+/* significantAnd90Nuc, assembly.c:147-149 */
+static int significant90(int X, int Y, double evalue) {
+	return (Y < X && (9 * (X + Y) <= 10 * X) && orc_p_chisqr(pow(X - Y, 2) / (X + Y)) <= evalue);
+}
+
 void orc_assembly_call(const orc_assembly *m, const uint64_t *tseq, int bcd, double evalue, int64_t *out, char *cons) {
+	orc_assembly_call2(m, tseq, bcd, evalue, 0, 0, out, cons);
+}
+
+void orc_assembly_call2(const orc_assembly *m, const uint64_t *tseq, int bcd, double evalue, int caller, int sig, int64_t *out, char *cons) {
 	static const char bases[] = "ACGTN-";
 	const node *A = m->a;
 	const int t_len = m->t_len, asm_len = m->len;
@@ -132,9 +141,15 @@ void orc_assembly_call(const orc_assembly *m, const uint64_t *tseq, int bcd, dou
 		} else if(depthUpdate < bcd) call = (unsigned char) tolower(call);
 		/* baseCaller */
 		if(depthUpdate == 0) call = '-';
-		else if(significant(bestScore, (int) depthUpdate - bestScore, evalue) == 0) {
-			if(call == '-' && tch != '-' && bestScore != depthUpdate) call = 'n';
-			else call = (unsigned char) tolower(call);
+		else if((sig ? significant90(bestScore, (int) depthUpdate - bestScore, evalue) : significant(bestScore, (int) depthUpdate - bestScore, evalue)) == 0) {
+			if(call == '-' && tch != '-' && bestScore != depthUpdate) {
+				if(caller == 1) {
+					/* nanoCaller, assembly.c:215-230: the best non-gap count decides */
+					int bestBaseScore = 0, b = -1;
+					for(int j = 0; j < 5; ++j) if(bestBaseScore < A[pos].counts[j]) { bestBaseScore = A[pos].counts[j]; b = j; }
+					call = bestBaseScore == 0 ? '-' : (unsigned char) tolower(bases[b]);
+				} else call = 'n';
+			} else call = (unsigned char) tolower(call);
 		}
 		if(cons) cons[i] = (char) call;
 		if(call != '-') {

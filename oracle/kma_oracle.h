@@ -117,6 +117,9 @@ int orc_align_pe(orc_aligner *a, const orc_rewards *rw, const orc_align_params *
  * See align.c. */
 int orc_align_trace(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, const uint8_t *read, int q_len, int t,
                     int *stats, char *cols, int cap);
+/* the `-Mt1 t` form of the same: raw read, strand picked by anker_rc (align.c:780-991). See align.c. */
+int orc_align_trace_mt1(orc_aligner *a, const orc_rewards *rw, const orc_align_params *ap, uint8_t *read, int q_len, int t,
+                        int one2one, int exhaustive, int *stats, char *cols, int cap, int *is_rc);
 void orc_nw_tap(const uint64_t *tseq, int tlen_total, const uint8_t *q, int k, int t_s, int t_e, int q_s, int q_e,
                 int band, const orc_rewards *rw, int out[6]);
 
@@ -137,6 +140,9 @@ orc_assembly *orc_assembly_new(int t_len);
 void orc_assembly_free(orc_assembly *m);
 void orc_assembly_add(orc_assembly *m, const char *cols, int aln_len, const uint8_t *read, int start, int score);
 void orc_assembly_call(const orc_assembly *m, const uint64_t *tseq, int bcd, double evalue, int64_t *out, char *cons);
+/* caller: 0 baseCaller (default), 1 nanoCaller (-bcNano, assembly.c:205-240); sig: 0 significantNuc, 1 significantAnd90Nuc
+ * (-bcNano, assembly.c:147-149, kma.c:762-766) */
+void orc_assembly_call2(const orc_assembly *m, const uint64_t *tseq, int bcd, double evalue, int caller, int sig, int64_t *out, char *cons);
 int orc_assembly_has_reads(const orc_assembly *m);
 const uint64_t *orc_db_template(const orc_db *db, int t);
 

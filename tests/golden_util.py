@@ -246,3 +246,33 @@ def fsa_text(entries):
         out.append(">" + nm + "\n")
         out += [q[i:i + 60] + "\n" for i in range(0, len(q), 60)]
     return "".join(out)
+
+
+def load_mt1(tmp):
+    """tests/golden/mt1 (make_golden_mt1.py): index unpacked into tmp, the raw reads (codes 0-4, file order) with their names"""
+    src = os.path.join(GOLD, "mt1")
+    tmp = str(tmp)
+    os.makedirs(tmp, exist_ok=True)
+    prefix = os.path.join(tmp, "db")
+    with lzma.open(os.path.join(src, "db.comp.b.xz"), "rb") as f, open(prefix + ".comp.b", "wb") as g:
+        shutil.copyfileobj(f, g)
+    for ext in (".length.b", ".seq.b", ".name"):
+        shutil.copy(os.path.join(src, "db" + ext), prefix + ext)
+    lut = np.full(256, 4, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    names, reads = [], []
+    lines = _gunzip(os.path.join(src, "reads.fq.gz")).split(b"\n")
+    for i in range(0, len(lines) - 3, 4):
+        names.append(lines[i][1:].decode())
+        reads.append(lut[np.frombuffer(lines[i + 1], np.uint8)])
+    fq = os.path.join(tmp, "reads.fq")
+    with open(fq, "wb") as f:
+        f.write(b"\n".join(lines))
+    return dict(dir=src, prefix=prefix, names=names, reads=reads, fastq=fq)
+
+
+def load_frag_rows(name):
+    """`.frag.gz` rows in file order: (sequence, n_templates, score, start, end, template name, header)"""
+    with gzip.open(os.path.join(GOLD, name, "out.frag.gz"), "rt") as f:
+        return [tuple(line.rstrip("\n").split("\t")) for line in f]

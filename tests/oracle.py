@@ -220,10 +220,13 @@ class Assembly:
         lib().orc_assembly_add(self.h, trace["cols"], len(trace["cols"]), _p(rd), trace["start"], trace["score"])
         self.n += 1
 
-    def call(self, bcd=1, evalue=0.05):
+    def call(self, bcd=1, evalue=0.05, caller=0, sig=0):
+        """caller 1 = nanoCaller, sig 1 = significantAnd90Nuc (both: -bcNano)"""
         out = np.zeros(4, np.int64)
         cons = C.create_string_buffer(int(2 * self.t_len + 64 + 2 * 1024 * 1024))
-        lib().orc_assembly_call(self.h, self.tseq, bcd, evalue, _p(out), cons)
+        L = lib()
+        L.orc_assembly_call2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_char_p]
+        L.orc_assembly_call2(self.h, self.tseq, bcd, evalue, caller, sig, _p(out), cons)
         return dict(cover=int(out[0]), aln_len=int(out[1]), depth=int(out[2]), asm_len=int(out[3]), consensus=cons.value.decode())
 
     def __del__(self):
@@ -310,6 +313,29 @@ class OracleAligner:
         out["cols"] = cols.raw[:n]
         out["cigar"] = cigar_of(out["cols"].decode(), out["clip_start"], out["clip_end"])
         return out
+
+    def align_trace_mt1(self, read, t, one2one=0, exhaustive=0):
+        """One raw read of a `-Mt1 t` run: anker_rc (strand) + KMA() + read filter -> (result dict as align_trace or None,
+        is_rc, the read as it was aligned)"""
+        rd = np.ascontiguousarray(read, np.uint8).copy()
+        stats = np.zeros(10, np.int32)
+        cap = 4 * len(rd) + 4 * 4096
+        cols = C.create_string_buffer(cap)
+        is_rc = C.c_int()
+        L = lib()
+        L.orc_align_trace_mt1.restype = C.c_int
+        L.orc_align_trace_mt1.argtypes = [C.c_void_p, C.POINTER(Rewards), C.POINTER(AlignParams), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        n = L.orc_align_trace_mt1(self.h, C.byref(self.odb.rw), C.byref(self.ap), _p(rd), len(rd), int(t), int(one2one), int(exhaustive),
+                                  _p(stats), cols, cap, C.byref(is_rc))
+        assert n >= 0
+        if n == 0:
+            return None, is_rc.value, rd
+        keys = ("score", "start", "end", "aln_len", "clip_start", "clip_end", "match", "tGaps", "qGaps", "mapQ")
+        out = dict(zip(keys, (int(x) for x in stats)))
+        out["cols"] = cols.raw[:n]
+        out["cigar"] = cigar_of(out["cols"].decode(), out["clip_start"], out["clip_end"])
+        return out, is_rc.value, rd
 
     def align_pe(self, seqA, lenA, NA, flagA, seqB, lenB, NB, flagB, T):
         nT = len(T)

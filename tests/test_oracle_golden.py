@@ -1,4 +1,6 @@
 """Pin the CPU oracle against the reference's own stream taps (not gpu)."""
+import os
+
 import numpy as np
 
 import golden_util
@@ -272,3 +274,54 @@ def test_oracle_assembly_matches_res_identity_columns(golden_se):
 
 def test_oracle_assembly_matches_res_identity_columns_long_reads(golden_long):
     assert _oracle_assembly_case(golden_long, "long") > 0
+
+
+# ---- BASELINE config C4 in small: `-Mt1 1 -bcNano` on ONT-like reads (tests/golden/mt1, make_golden_mt1.py) ----------------
+def _oracle_mt1(tmp_path):
+    """every raw read through the restated anker_rc + KMA() + read filter, in stream order"""
+    g = golden_util.load_mt1(tmp_path / "mt1")
+    odb = oracle.OracleDB(g["prefix"])
+    al = oracle.OracleAligner(odb)
+    out = [al.align_trace_mt1(rd, 1) for rd in g["reads"]]
+    return g, odb, out
+
+
+def test_oracle_mt1_traceback_matches_reference_sam(tmp_path):
+    """POS / CIGAR / AS / MAPQ of every read against the reference's SAM records: strand choice by MEM coverage, preseed,
+    chain over hundreds of MEMs, full and banded joins with traceback. The flag stays 0 on the reverse strand in this mode
+    (anker_rc leaves it alone, align.c:968-975), the sequence is what tells."""
+    g, odb, out = _oracle_mt1(tmp_path)
+    sam = golden_util.load_sam("mt1")
+    mapped = 0
+    for nm, (o, is_rc, rd) in zip(g["names"], out):
+        flag, rname, pos, mapq, cigar, AS = sam[nm][0]
+        if o is None:
+            assert cigar == "*" and flag == 4, nm
+            continue
+        mapped += 1
+        assert (0, "genome60k", o["start"] + 1, min(254, o["mapQ"]), o["cigar"], o["score"]) == (flag, rname, pos, mapq, cigar, AS), nm
+    assert mapped == 174 and sum(1 for o, r, _ in out if o is not None and r) > 50
+
+
+def test_oracle_mt1_pileup_and_nanocaller_match_res_fsa_frags(tmp_path):
+    """reads piled up in stream order (one thread reads the records one by one, assembly.c:1873-1965), consensus by nanoCaller
+    with significantAnd90Nuc: the `.res` row, the consensus FASTA and the `.frag.gz` rows of the reference."""
+    g, odb, out = _oracle_mt1(tmp_path)
+    tlen = formats.read_lengths(g["prefix"])
+    asm = oracle.Assembly(odb, 1, tlen[1])
+    rows = []
+    score = 0
+    for nm, (o, is_rc, rd) in zip(g["names"], out):
+        if o is None:
+            continue
+        asm.add(o, rd)
+        # alnToMat sums KMA()'s own score (assembly.c:1328-1334), i.e. without the end bonus Wl the read filter added
+        score += o["score"] - odb.rw.Wl * ((o["start"] == 0) + (o["end"] == tlen[1]))
+        rows.append(("".join("ACGTN"[c] for c in rd), "1", str(o["score"]), str(o["start"]), str(o["end"]), "genome60k", nm))
+    assert rows == golden_util.load_frag_rows("mt1")
+    call = asm.call(caller=1, sig=1)
+    assert golden_util.fsa_text([("genome60k", call["consensus"])]) == golden_util.load_fsa("mt1")
+    # the row as runKMA_Mt1 prints it (mt1.c:441-443): Score = summed read scores, Expected 0, q_value = score
+    exp = open(os.path.join(golden_util.GOLD, "mt1", "out.res")).read().splitlines()[1].split("\t")
+    assert int(exp[1]) == score and int(exp[3]) == tlen[1]
+    assert tuple(x.strip() for x in exp[4:9]) == oracle.res_identity_columns(call, int(tlen[1]))
