@@ -279,6 +279,20 @@ int kmahip_align_trace_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                        const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, int64_t *ops_needed);
 
+/* `-Mt1 t` (runKMA_Mt1, mt1.c:86-500 -> assemble_KMA with read_score == 0, assembly.c:1917-1965): raw reads go straight to
+ * stage 3c against ONE template, no stage 2 and no ConClave. Per read: anker_rc (align.c:780-991) seeds both strands against
+ * the template's position index and keeps the strand with the larger MEM coverage (forward on equality; the forward strand is
+ * only seeded when one of its every-k-th k-mers is in the index, preseed align.c:750-768, unless p->exhaustive), KMA() chains
+ * its MEMs and joins them with traceback, then the read filter as in kmahip_align_trace_dev. one2one: `-1t1` was given too
+ * (anker_rc's coverage gate, align.c:952). Out: kmahip_traces as above, and rc_out[i] (may be NULL) = 1 when the reverse
+ * complement of read i is what was aligned -- pass it as `rc` and a vector of `tmpl` to kmahip_assemble2. Built as a pipeline
+ * of kernels (seed + chain per read on a wavefront, DP problems batched by size); device pointers. */
+int kmahip_align_trace_mt1_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                               kmahip_traces *out, int32_t *rc_out, void *stream);
+/* the same with host buffers in and out; KMAHIP_EOVERFLOW with the needed run count in *ops_needed */
+int kmahip_align_trace_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                           kmahip_traces *out, int32_t *rc_out, int64_t *ops_needed);
+
 /* Stage 3c per template: pile-up of the traced reads (alnToMat, assembly.c:1317-1444: per template position the counts of
  * A C G T N and gap, insertion columns chained between positions) on the device, then callConsensus + baseCaller
  * (assembly.c:1499-1631, 162-179) in host arithmetic. Inputs: the reads, the rc / tmpl arrays given to

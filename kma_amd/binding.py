@@ -156,6 +156,8 @@ def lib():
                                               C.POINTER(Conclave)]
         L.kmahip_align_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params),
                                          C.POINTER(Traces), C.POINTER(C.c_int64)]
+        L.kmahip_align_trace_mt1.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_int, C.POINTER(Params), C.POINTER(Traces),
+                                             C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_assemble.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.POINTER(Traces), C.c_int64,
                                       C.c_int, C.c_double, C.POINTER(Assembly)]
         L.kmahip_res_line.argtypes = [C.c_char_p, C.POINTER(ResRow), C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
@@ -494,6 +496,31 @@ class KmaHipDB:
             _check(rc)
             return stats[:n], off[:n], nops[:n], ops[:need.value]
         raise KmaHipError("align_trace: output capacity kept overflowing")
+
+    def align_trace_mt1(self, batch, tmpl, one2one=0):
+        """`-Mt1 tmpl`: every raw read against one template, strand by anker_rc -> (stats, ops_off, n_ops, ops) as align_trace, rc [n]"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        stats = np.zeros((max(n, 1), 10), np.int32)
+        off = np.zeros(max(n, 1), np.int64)
+        nops = np.zeros(max(n, 1), np.int32)
+        rc_out = np.zeros(max(n, 1), np.int32)
+        cap = max(1024, int(batch.length.sum()) // 4)
+        p = Params.from_buffer_copy(self.params)
+        need = C.c_int64()
+        for _ in range(3):
+            ops = np.zeros(cap, np.uint32)
+            o = Traces(_p(stats), _p(off), _p(nops), _p(ops), cap)
+            rc = lib().kmahip_align_trace_mt1(self.h, self.ws, C.byref(r), int(tmpl), int(one2one), C.byref(p), C.byref(o), _p(rc_out), C.byref(need))
+            if rc == -6 and need.value > cap:
+                cap = need.value + 16
+                continue
+            _check(rc)
+            return (stats[:n], off[:n], nops[:n], ops[:need.value]), rc_out[:n]
+        raise KmaHipError("align_trace_mt1: output capacity kept overflowing")
 
     def assemble(self, batch, rc, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False):
         """Stage 3c per template: pile-up of the traced reads + consensus -> dict(cover, aln_len, depth, asm_len [DB_size],

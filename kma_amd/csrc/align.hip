@@ -22,6 +22,7 @@
 // D/P/Q as three packed 21-bit counters ("count-carrying DP"), including the
 // walk's quirk that a gap run ends on the first cell with EITHER may-open bit.
 #include "kmahip_internal.h"
+#include "dna_dev.h"
 #include <cstdlib>
 #include <climits>
 
@@ -77,137 +78,7 @@ struct AlignArgs {
 	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
 };
 
-struct Aln { int score, len, pos, match, tGaps, qGaps; };
 constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
-
-struct QView {
-	const uint64_t *w;
-	const int32_t *N;
-	int L, nN, rc;
-};
-
-__device__ __forceinline__ int q2(const QView &q, int i) {
-	const int p = q.rc ? q.L - 1 - i : i;
-	const int b = (int) ((q.w[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
-	return q.rc ? 3 - b : b;
-}
-
-__device__ __forceinline__ bool q_is_N(const QView &q, int i) {
-	if(q.nN == 0) return false;
-	const int p = q.rc ? q.L - 1 - i : i;
-	int lo = 0, hi = q.nN;
-	while(lo < hi) { const int mid = (lo + hi) >> 1; if(q.N[mid] < p) lo = mid + 1; else hi = mid; }
-	return lo < q.nN && q.N[lo] == p;
-}
-
-// byte code of the oriented query: 0-3, 4 = N (unCompDNA, compdna.c:178-203)
-__device__ __forceinline__ int qn(const QView &q, int i) { return q_is_N(q, i) ? 4 : q2(q, i); }
-
-// i-th (1-based) oriented N position; i > nN -> L (the sentinel alnFragsSE appends)
-__device__ __forceinline__ int qN_at(const QView &q, int i) {
-	if(i > q.nN) return q.L;
-	return q.rc ? (q.L - 1 - q.N[q.nN - i]) : q.N[i - 1];
-}
-
-__device__ __forceinline__ uint32_t q_kmer(const QView &q, int j, int k) {
-	const int p = q.rc ? q.L - k - j : j;
-	const int ip = (p & 31) << 1, w = p >> 5;
-	uint64_t x = q.w[w] << ip;
-	if(ip) x |= q.w[w + 1] >> (64 - ip);
-	x >>= (64 - 2 * k);
-	if(q.rc) {
-		x = ~x;
-		x = __brevll(x);
-		x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
-		x >>= (64 - 2 * k);
-	}
-	return (uint32_t) x;
-}
-
-__device__ __forceinline__ int tn(const uint64_t *ts, int pos) {
-	return (int) ((ts[pos >> 5] >> (62 - ((pos & 31) << 1))) & 3ull);
-}
-
-__device__ __forceinline__ uint64_t revcomp64(uint64_t x) {
-	x = __brevll(~x);
-	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
-}
-
-// 32 bases starting at base `pos` of a 2-bit word array (MSB first). Always reads word and word+1 (every array carries a
-// pad word), as one 16-byte access and without a branch: a conditional second load would wait for the first one.
-__device__ __forceinline__ uint64_t win2(const uint64_t *w, int pos) {
-	const int ip = (pos & 31) << 1;
-	const uint64_t *p = w + (pos >> 5);
-	const uint64_t w0 = p[0], w1 = p[1];
-	return (w0 << ip) | ((w1 >> 1) >> (63 - ip));
-}
-
-// 32 bases of the ORIENTED read starting at oriented position i (N packed as A;
-// bases past the read end are garbage)
-__device__ __forceinline__ uint64_t qwin(const QView &q, int i) {
-	if(!q.rc) return win2(q.w, i);
-	const int s = q.L - 32 - i;           // forward window that mirrors [i, i+32)
-	if(s >= 0) return revcomp64(win2(q.w, s));
-	return revcomp64(q.w[0] >> ((-s) << 1));
-}
-
-// the k-mers at oriented positions j and j + 1 from ONE 32-base window (k <= 16 here, so both fit): one 16-byte access
-// instead of up to four word loads and two reverse complements
-__device__ __forceinline__ void q_kmer2(const QView &q, int j, int k, uint32_t &km1, uint32_t &km2) {
-	const uint64_t w = qwin(q, j);
-	km1 = (uint32_t) (w >> (64 - 2 * k));
-	km2 = (uint32_t) ((w << 2) >> (64 - 2 * k));
-}
-
-// Query codes of a DP problem without a global load per cell: a cached 32-base window of the oriented
-// read, reloaded when the column index leaves it (columns are walked in descending order).
-struct QCursor {
-	uint64_t w;
-	int blk;      // window covers problem columns [32*blk, 32*blk + 32)
-	__device__ __forceinline__ int code(const QView &q, int q_s, int n) {
-		const int b = n >> 5;
-		if(b != blk) { blk = b; w = qwin(q, q_s + (b << 5)); }
-		if(q.nN && q_is_N(q, q_s + n)) return 4;
-		return (int) ((w >> (62 - ((n & 31) << 1))) & 3ull);
-	}
-};
-
-// hashMapCCI_get semantics (hashmapcci.c:95-124): 0 absent, +pos unique, negative = duplicated
-__device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
-	if(km == 0) return 0;
-	const uint32_t sh = db.tpos_shift[t];
-	const uint2 *tab = db.tpos_slots + db.tpos_off[t];
-	const uint32_t msk = (1u << (32 - sh)) - 1u;
-	uint32_t sl = (km * 0x9E3779B1u) >> sh;
-	for(;;) {
-		const uint2 e = tab[sl];
-		if(e.y == 0) return 0;
-		if(e.x == km) return (int) e.y;
-		sl = (sl + 1u) & msk;
-	}
-}
-
-// two lookups whose first table gathers travel together
-__device__ __forceinline__ void tpos_get2(const uint2 *tab, uint32_t sh, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2);
-__device__ __forceinline__ void tpos_get2(const DevDB &db, int t, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
-	tpos_get2(db.tpos_slots + db.tpos_off[t], db.tpos_shift[t], km1, km2, want2, v1, v2);
-}
-__device__ __forceinline__ void tpos_get2(const uint2 *tab, uint32_t sh, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
-	const uint32_t msk = (1u << (32 - sh)) - 1u;
-	uint32_t s1 = (km1 * 0x9E3779B1u) >> sh, s2 = (km2 * 0x9E3779B1u) >> sh;
-	uint2 e1 = tab[s1], e2 = tab[want2 ? s2 : s1];
-	v1 = 0; v2 = 0;
-	if(km1) for(;;) {
-		if(e1.y == 0) break;
-		if(e1.x == km1) { v1 = (int) e1.y; break; }
-		s1 = (s1 + 1u) & msk; e1 = tab[s1];
-	}
-	if(want2 && km2) for(;;) {
-		if(e2.y == 0) break;
-		if(e2.x == km2) { v2 = (int) e2.y; break; }
-		s2 = (s2 + 1u) & msk; e2 = tab[s2];
-	}
-}
 
 struct Lane {
 	int32_t *s32;
@@ -856,18 +727,6 @@ __device__ void nw_coop_x(const Lane &L, const DevDB &db, const AlignArgs &A, in
 		const Aln r = aln_from<10>(score, (uint64_t) st);
 		e[2] = r.score; e[3] = r.len; e[4] = r.match; e[5] = r.tGaps; e[6] = r.qGaps;
 	}
-}
-
-// heuristic substitution model of chain.c (end / link / start terms)
-__device__ __forceinline__ int mism_score(int span, int k, int M, int MM) {
-	int Ms, MMs;
-	if(span == 2) { MMs = 2; Ms = 0; }
-	else {
-		MMs = span / k + (span % k ? 1 : 0);
-		MMs = max(2, MMs);
-		Ms = min(min(span - MMs, k), MMs);
-	}
-	return Ms * M + MMs * MM;
 }
 
 // chainSeeds, chain.c:79-260; returns best start, *bestScore its score

@@ -29,6 +29,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_seg); (void) hipFree(ws->p_vals);
 	(void) hipFree(ws->p_nodes); (void) hipFree(ws->p_keys); (void) hipFree(ws->p_rank);
 	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
+	for(int i = 0; i < 8; ++i) (void) hipFree(ws->lt_buf[i]);
 	delete ws;
 }
 
@@ -411,6 +412,53 @@ extern "C" int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_rea
 	HIP_TRY(hipMemcpy(out->ops_off, o.ops_off, (size_t) n * 8, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(out->stats, o.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(out->n_ops, o.n_ops, (size_t) n * 4, hipMemcpyDeviceToHost));
+	if(c[0]) HIP_TRY(hipMemcpy(out->ops, o.ops, (size_t) c[0] * 4, hipMemcpyDeviceToHost));
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_align_trace_mt1_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                                          kmahip_traces *out, int32_t *rc_out, void *stream) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_launch_longtrace(db, ws, reads, nullptr, tmpl, nullptr, nullptr, one2one, p, out, rc_out, (hipStream_t) stream);
+}
+
+extern "C" int kmahip_align_trace_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                                      kmahip_traces *out, int32_t *rc_out, int64_t *ops_needed) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0 || out->ops_cap < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(ops_needed) *ops_needed = 0;
+	if(n == 0) return KMAHIP_OK;
+	int rc;
+	if((rc = stage_reserve(ws, 0, (size_t) (reads->seq_words + 2) * 8)) || (rc = stage_reserve(ws, 1, (size_t) (n + 1) * 8)) ||
+	   (rc = stage_reserve(ws, 2, (size_t) n * 4)) || (rc = stage_reserve(ws, 3, (size_t) reads->N_total * 4)) ||
+	   (rc = stage_reserve(ws, 4, (size_t) (n + 1) * 8)) || (rc = stage_reserve(ws, 5, (size_t) n * 4 + 8)) ||
+	   (rc = stage_reserve(ws, 6, (size_t) n * (40 + 8 + 4) + 8)) || (rc = stage_reserve(ws, 7, (size_t) (out->ops_cap + 1) * 4))) return rc;
+	hipStream_t s = 0;
+	HIP_TRY(hipMemsetAsync((char *) ws->stage[0] + (size_t) reads->seq_words * 8, 0, 16, s));
+	if(reads->seq_words) HIP_TRY(hipMemcpyAsync(ws->stage[0], reads->seq, (size_t) reads->seq_words * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[1], reads->seq_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[2], reads->len, (size_t) n * 4, hipMemcpyHostToDevice, s));
+	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
+	kmahip_reads d = *reads;
+	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
+	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
+	int32_t *d_rc = (int32_t *) ws->stage[5];
+	kmahip_traces o;
+	o.ops_off = (int64_t *) ws->stage[6]; o.stats = (int32_t *) (o.ops_off + n); o.n_ops = o.stats + 10 * n;
+	o.ops = (uint32_t *) ws->stage[7]; o.ops_cap = out->ops_cap;
+	if((rc = kmahip_launch_longtrace(db, ws, &d, nullptr, tmpl, nullptr, nullptr, one2one, p, &o, d_rc, s))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	unsigned long long c[2];
+	HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+	if(c[1]) HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
+	if(ops_needed) *ops_needed = (int64_t) c[0];
+	if(c[1] == 2 || (int64_t) c[0] > out->ops_cap) { kmahip_set_error("ops_cap %lld too small, need %llu", (long long) out->ops_cap, c[0]); return KMAHIP_EOVERFLOW; }
+	HIP_TRY(hipMemcpy(out->ops_off, o.ops_off, (size_t) n * 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out->stats, o.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out->n_ops, o.n_ops, (size_t) n * 4, hipMemcpyDeviceToHost));
+	if(rc_out) HIP_TRY(hipMemcpy(rc_out, d_rc, (size_t) n * 4, hipMemcpyDeviceToHost));
 	if(c[0]) HIP_TRY(hipMemcpy(out->ops, o.ops, (size_t) c[0] * 4, hipMemcpyDeviceToHost));
 	return KMAHIP_OK;
 }

@@ -116,6 +116,9 @@ struct kmahip_ws {
 	uint64_t *p_keys;
 	int64_t *p_rank;
 	int64_t p_total, p_node_cap, p_reads_cap, p_kept, p_nodes_used;
+	// long-read trace pipeline (longtrace.hip): per-wavefront MEM arrays, per-pass pools, queues, scratch, counters
+	void *lt_buf[8];
+	size_t lt_bytes[8];
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;
@@ -137,6 +140,8 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
                            const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
 int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                         const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream);
+int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *tmpl, int tmpl_all, const int32_t *rc_in,
+                            const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream);
 int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                           kmahip_pe_recs *out, hipStream_t stream);
 int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,

@@ -1,0 +1,1512 @@
+// longtrace.hip -- the traceback aligner as a pipeline of kernels with work compaction in between, built for reads that
+// carry hundreds of MEMs (BASELINE config C4: 10 kb Nanopore-style reads, `-Mt1 t -bcNano`), where one lane per read with
+// its move matrix in HBM (trace_kernel, align.hip) is structurally wrong. Behaviour restated from
+//   anker_rc     align.c:780-991    both strands of a raw read seeded against the template, strand by MEM coverage
+//   KMA          align.c:214-507    chain, leading / trailing tails, joins with traceback
+//   chainSeeds   chain.c:79-260     NW nw.c:26-309    NW_band nw.c:310-640
+//   assemble_KMA assembly.c:1917-1965 (read filter)
+//
+//   lt_seed_kernel    one WAVEFRONT per read: k-mer lookups 256 positions at a time (4 gathers per lane in flight), maximal
+//                     matches of all hits side by side, the reference's sequential walk over them out of LDS, chainSeeds with
+//                     the lanes over the 127 successors, the chain's joins -> one DP problem descriptor per join, appended
+//                     to a queue per size class
+//   lt_dp_kernel<W>   W = 8 / 16 / 32 / 64 lanes per problem: anti-diagonal sweep, lane n owns query column n, the move
+//                     matrix E (one byte per cell, the reference's encoding + a mismatch bit) in LDS, then one lane per
+//                     problem walks E and writes the alignment columns as runs
+//   lt_dpx_kernel     problems of 65..255 query columns and banded problems (several columns per lane, E in LDS or HBM);
+//                     whatever fits neither is solved by one lane with rows and E in HBM (same code path as the reference)
+//   lt_finish_kernel  per read: the runs of its problems and MEMs concatenated in chain order, read filter, output
+#include "kmahip_internal.h"
+#include "dna_dev.h"
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <unistd.h>
+
+namespace {
+
+constexpr int LT_TILE = 256;          // query positions looked up per round of the seeding wavefront
+constexpr int LT_NEXT_CAP = 2048;     // MEMs of the winning strand whose chain links / chain order stay in LDS
+constexpr int LT_NCLS = 9;            // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
+                                      // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one lane)
+constexpr int LT_E_WAVE = 8192;       // bytes of move matrix per wavefront in lt_dp_kernel (split between its problems)
+constexpr int LT_TMAX = 127;          // template rows of a problem in lt_dp_kernel
+constexpr int LT_XE_LDS = 32768;      // bytes of move matrix in LDS per workgroup of lt_dpx_kernel
+constexpr int LT_XT_LDS = 2048;       // template rows staged in LDS there
+
+enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_TRIM = 16 };
+// counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..12] class counts,
+// [23] output run pool top
+enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_OUT = 23, LC_N = 24 };
+
+struct LtRead {               // per read of the pass
+	int64_t first;            // first problem descriptor
+	int32_t status;           // 0: no alignment (unmapped, chain below the thresholds, join too large), 1: aligned
+	int32_t rc;               // 1: the reverse complement of the read is what was aligned
+	int32_t n_prob;           // chain length + 1 problem slots: leading tail, joins, trailing tail
+	int32_t mapQ;
+	int32_t pos0;             // template position in front of the first MEM (Stat.pos before the leading tail)
+	int32_t clip0;            // query bases in front of the leading tail's problem
+	int32_t qe_trail;         // query end of the trailing tail's problem
+	int32_t pad;
+};
+
+struct LtProb {               // one join / tail: 64 bytes
+	int64_t runs;             // word offset of its run slot in the run pool
+	int32_t read;             // read of the pass
+	int32_t t_s, t_l;         // template start (0-based) and rows (may wrap around a circular template)
+	int32_t q_s, q_l;         // oriented query start and columns
+	int32_t k;                // mode: 0 global, -1 / -2 free leading template / both, 1 / 2 free trailing
+	int32_t band;             // 0: full matrix, else NW_band with this band
+	int32_t flags;            // PF_*
+	int32_t body;             // '=' columns of the MEM that follows the problem
+	int32_t body_score;
+	// results
+	int32_t score;
+	int32_t n_runs;
+	int32_t clip;             // leading tail: query bases the walk left in front; trailing tail: behind
+	int32_t pad;
+};
+
+struct LtArgs {
+	DevDB db;
+	int64_t r0, n_reads;      // reads [r0, r0 + n_reads) of the batch form this pass
+	const uint64_t *seq;
+	const int64_t *seq_off;
+	const int32_t *len;
+	const int32_t *N;
+	const int64_t *N_off;
+	const int32_t *tmpl;      // per read (batch index): signed template, or NULL: tmpl_all
+	const int32_t *rc_in;     // per read: orientation to align (NULL: both strands are seeded, anker_rc decides)
+	const uint8_t *tmpl_ok;   // per template: align its reads? (NULL: all)
+	int tmpl_all;
+	int one2one, exhaustive;
+	int M, MM, U, W1, Wl;
+	int d[25];
+	int minlen, mq;
+	double scoreT, mrc;
+	// scratch of the pass
+	int32_t *mem;             // per seeding wavefront: 7 arrays of mcap ints (tS tE qS qE weight next chain)
+	int mcap;
+	LtRead *rd;
+	LtProb *prob;
+	int64_t prob_cap;
+	uint32_t *runs;           // run slots of the problems
+	int64_t runs_cap;
+	int32_t *queue;           // LT_NCLS x prob_cap problem indices
+	uint32_t *tmp;            // per finishing wavefront: tmp_cap words
+	int64_t tmp_cap;
+	uint8_t *xE;              // per lt_dpx workgroup: xe_cap bytes of move matrix + 4 rows of xrow ints
+	int64_t xe_cap;
+	int xrow;
+	unsigned long long *counters;
+	// output (kmahip_traces of the whole batch) + strand
+	int32_t *o_stats;
+	int64_t *o_off;
+	int32_t *o_nops;
+	uint32_t *ops;
+	int64_t ops_cap;
+	unsigned long long *ops_top;   // the batch's run pool top (shared by the passes)
+	int32_t *o_rc;
+	volatile uint32_t *rec;   // bring-up flight recorder in host memory (KMAHIP_DEBUG_TIMING): 16 words per workgroup, NULL = off
+};
+#define LT_REC(slot, val) do { if(A.rec) A.rec[(size_t) blockIdx.x * 16 + (slot)] = (uint32_t) (val); } while(0)
+
+__device__ __forceinline__ int wave_max(int x) {
+	for(int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o));
+	return x;
+}
+__device__ __forceinline__ int wave_sum(int x) {
+	for(int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+	return x;
+}
+__device__ __forceinline__ int wave_scan_incl(int x, int lane) {
+	for(int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(x, d); if(lane >= d) x += v; }
+	return x;
+}
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+}
+// the same when what one lane wrote to HBM is read by the others (their L1 may hold the line from an earlier read)
+__device__ __forceinline__ void wave_sync_hbm() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// position-index lookup of one template, table pointer and shift in registers
+__device__ __forceinline__ int lt_lookup(const uint2 *tab, uint32_t sh, uint32_t km) {
+	if(km == 0) return 0;
+	const uint32_t msk = (1u << (32 - sh)) - 1u;
+	uint32_t sl = (km * 0x9E3779B1u) >> sh;
+	for(;;) {
+		const uint2 e = tab[sl];
+		if(e.y == 0) return 0;
+		if(e.x == km) return (int) e.y;
+		sl = (sl + 1u) & msk;
+	}
+}
+
+// exact match lengths around the k-mer hit (query position s, template position pos1, 1-based): fwd = matching bases from s on
+// (>= k; bounded by the N-free stretch [lowq, segE) and the template end), bwd = matching bases in front of s
+__device__ __forceinline__ void lt_extend(const uint64_t *ts, int t_len, const QView &q, int s, int pos1, int k, int lowq, int segE, int &fwd, int &bwd) {
+	int kk = s - 1, prev = pos1 - 2;
+	for(;;) {
+		const int room = min(kk - lowq + 1, prev + 1);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t xq = qwin(q, kk - step + 1) >> (64 - 2 * step);
+		const uint64_t xt = win2(ts, prev - step + 1) >> (64 - 2 * step);
+		const uint64_t x = xq ^ xt;
+		const int same = x ? (__ffsll((long long) x) - 1) >> 1 : step;
+		kk -= same; prev -= same;
+		if(same < step) break;
+	}
+	bwd = s - 1 - kk;
+	int value = pos1 + k - 1, l = s + k;
+	for(;;) {
+		const int room = min(segE - l, t_len - value);
+		if(room <= 0) break;
+		const int step = min(32, room);
+		const uint64_t x = (qwin(q, l) ^ win2(ts, value)) >> (64 - 2 * step);
+		const int same = x ? (__clzll((long long) x) - (64 - 2 * step)) >> 1 : step;
+		l += same; value += same;
+		if(same < step) break;
+	}
+	fwd = l - s;
+}
+
+struct SeedLds {
+	int v[LT_TILE], F[LT_TILE], B[LT_TILE];
+	uint16_t next[LT_NEXT_CAP], chain[LT_NEXT_CAP];
+	int ring[6][128];
+	int stage[5][64];
+	int d[25];
+};
+
+// MEM arrays of a seeding wavefront in HBM
+struct MemArr {
+	int32_t *tS, *tE, *qS, *qE, *w, *nx, *ch;
+};
+
+// The seeding loop of anker_rc / KMA() for one orientation of the read (align.c:812-945): every k-mer start of an N-free
+// stretch is looked up -- a stretch is (re)entered only while MORE than k bases remain in it (`i < end - kmersize`), then
+// scanned up to its last k-mer; a unique hit gives one MEM and the scan resumes behind it, a duplicated k-mer one MEM per
+// occurrence and the scan resumes behind the longest. The lookups and the match lengths of all hits of 256 positions are
+// done side by side; the walk itself is the same for every lane (LDS broadcast reads), lane 0 writes the MEMs.
+// Returns false when the MEM arrays are full.
+__device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, const QView &q, const uint64_t *ts, int t_len,
+                               const uint2 *tab, uint32_t tsh, int k, int &tot, int &mem_count, int &score_r) {
+	const int lane = threadIdx.x & 63;
+	const int q_len = q.L;
+	int segS = 0;
+	for(int ni = 1; segS < q_len; ++ni) {
+		const int segE = qN_at(q, ni);              // next N (oriented), q_len behind the last one
+		int cur = segS;
+		bool scanning = false;
+		int carry_pos = -2, carry_v = 0, carry_F = 0, carry_B = 0;
+		for(int guard = 0;; ++guard) {
+			if(guard > q_len + 2) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }     // (cur advances every round)
+			if(!scanning) { if(!(cur < segE - k)) break; scanning = true; }
+			if(cur > segE - k) break;
+			const int p0 = cur;
+			// ---- lookups of the k-mer starts p0 .. p0 + 255 (position p0 + j * 64 + lane) ----
+			int v[4];
+			uint32_t km[4];
+#pragma unroll
+			for(int j = 0; j < 4; ++j) {
+				const int pos = p0 + j * 64 + lane;
+				km[j] = (pos <= segE - k) ? (uint32_t) (qwin(q, pos) >> (64 - 2 * k)) : 0u;
+			}
+			{
+				// first probes of the four lookups travel together
+				const uint32_t msk = (1u << (32 - tsh)) - 1u;
+				uint32_t sl[4];
+				uint2 e[4];
+#pragma unroll
+				for(int j = 0; j < 4; ++j) { sl[j] = (km[j] * 0x9E3779B1u) >> tsh; e[j] = tab[sl[j]]; }
+#pragma unroll
+				for(int j = 0; j < 4; ++j) {
+					v[j] = 0;
+					if(km[j]) for(;;) {
+						if(e[j].y == 0) break;
+						if(e[j].x == km[j]) { v[j] = (int) e[j].y; break; }
+						sl[j] = (sl[j] + 1u) & msk; e[j] = tab[sl[j]];
+					}
+				}
+			}
+			// ---- runs of hits on one diagonal: the first of a run extends, the others derive from it ----
+			int hd[4];
+			unsigned long long hitm[4];
+			int prev_last = (carry_pos == p0 - 1) ? carry_v : 0;
+#pragma unroll
+			for(int j = 0; j < 4; ++j) {
+				int pv = __shfl_up(v[j], 1);
+				if(lane == 0) pv = prev_last;
+				prev_last = __shfl(v[j], 63);
+				const int idx = j * 64 + lane;
+				const bool cont = v[j] > 0 && pv > 0 && pv + 1 == v[j];
+				int F = 0, B = 0;
+				hd[j] = -1;
+				if(v[j] > 0 && !cont) {
+					lt_extend(ts, t_len, q, p0 + idx, v[j], k, segS, segE, F, B);
+					hd[j] = idx;
+				} else if(cont && idx == 0) {
+					F = carry_F - 1; B = carry_B + 1;       // continues the last run of the round before
+					hd[j] = 0;
+				}
+				S.v[idx] = v[j];
+				if(hd[j] >= 0) { S.F[idx] = F; S.B[idx] = B; }
+				hitm[j] = __ballot(v[j] != 0);
+			}
+			wave_sync();
+			{
+				int carry = -1;
+#pragma unroll
+				for(int j = 0; j < 4; ++j) {
+					int x = hd[j];
+					for(int dd = 1; dd < 64; dd <<= 1) { const int y = __shfl_up(x, dd); if(lane >= dd) x = max(x, y); }
+					x = max(x, carry);
+					carry = __shfl(x, 63);
+					const int idx = j * 64 + lane;
+					if(v[j] > 0 && hd[j] < 0 && x >= 0) { S.F[idx] = S.F[x] - (idx - x); S.B[idx] = S.B[x] + (idx - x); }
+				}
+			}
+			wave_sync();
+			carry_pos = p0 + LT_TILE - 1; carry_v = S.v[LT_TILE - 1]; carry_F = S.F[LT_TILE - 1]; carry_B = S.B[LT_TILE - 1];
+			if(carry_v <= 0) carry_pos = -2;
+			// ---- the walk over this round's hits ----
+			for(;;) {
+				// first hit at or behind cur
+				const int off = cur - p0;
+				int s = -1;
+#pragma unroll
+				for(int j = 0; j < 4; ++j) {
+					if(s >= 0) continue;
+					unsigned long long m = hitm[j];
+					const int lo = off - j * 64;
+					if(lo >= 64) continue;
+					if(lo > 0) m &= ~0ull << lo;
+					if(m) s = j * 64 + __ffsll((long long) m) - 1;
+				}
+				if(s < 0) { cur = p0 + LT_TILE; break; }         // none left: the scan goes on in the next round
+				const int val = S.v[s];
+				const int qs = p0 + s;
+				if(val > 0) {
+					if(tot >= A.mcap) return false;
+					const int F = S.F[s], B = S.B[s];
+					if(lane == 0) { Mm.qS[tot] = qs - B; Mm.tS[tot] = val - B; Mm.qE[tot] = qs + F; Mm.tE[tot] = val + F; Mm.w[tot] = F + B; }
+					score_r += F + B;
+					++tot; ++mem_count;
+					cur = qs + F;
+				} else {
+					// duplicated k-mer: one MEM per occurrence (ascending positions), on behind the longest
+					const int32_t *dl = A.db.tpos_dups + (-val - 1);
+					const int cnt = dl[0];
+					int bias = qs;
+					for(int c = 1; c <= cnt; ++c) {
+						if(tot >= A.mcap) return false;
+						int F, B;
+						const int pos1 = dl[c];
+						lt_extend(ts, t_len, q, qs, pos1, k, segS, segE, F, B);
+						if(lane == 0) { Mm.qS[tot] = qs - B; Mm.tS[tot] = pos1 - B; Mm.qE[tot] = qs + F; Mm.tE[tot] = pos1 + F; Mm.w[tot] = F + B; }
+						++tot; ++mem_count;
+						bias = max(bias, qs + F);
+					}
+					score_r += k + (bias - qs);
+					cur = bias + 1;
+				}
+				scanning = false;
+				if(cur <= qs) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }
+				if(!(cur < segE - k)) break;
+				scanning = true;
+				if(cur >= p0 + LT_TILE) break;
+			}
+			if(!scanning) break;
+		}
+		segS = segE + 1;
+	}
+	return true;
+}
+
+// chainSeeds (chain.c:79-260) over the MEMs [base, base + n) of the wavefront: right to left, the 127 successors of a MEM
+// two per lane out of an LDS ring, the reference's left-to-right acceptance rule (`<=` for a free join, `<` for the
+// overlapping ones) resolved from the wave maximum: the later of the free joins that reach it, else the first join that does.
+// Returns the best start (relative to base); links in S.next (n <= LT_NEXT_CAP) or Mm.nx.
+__device__ int lt_chain(const LtArgs &A, SeedLds &S, const MemArr &Mm, int base, int n, int q_len, int t_len, int k, unsigned *mapQ, int *bestScore) {
+	const int lane = threadIdx.x & 63;
+	const int W1 = A.W1, U = A.U, M = A.M, MM = A.MM;
+	const bool lds_next = n <= LT_NEXT_CAP;
+	int best = 0, second = 0, bestPos = n - 1, bestW = 0;
+	for(int i = n - 1; i >= 0; --i) {
+		if((i & 63) == 63 || i == n - 1) {
+			// stage the MEMs of this block of 64
+			wave_sync();
+			const int b0 = i & ~63, m = b0 + lane;
+			if(m < n) {
+				S.stage[0][lane] = Mm.tS[base + m]; S.stage[1][lane] = Mm.tE[base + m]; S.stage[2][lane] = Mm.qS[base + m];
+				S.stage[3][lane] = Mm.qE[base + m]; S.stage[4][lane] = Mm.w[base + m];
+			}
+			wave_sync();
+		}
+		const int si = i & 63;
+		const int tSi = S.stage[0][si], tEnd = S.stage[1][si], qSi = S.stage[2][si], qEnd = S.stage[3][si], wi = S.stage[4][si];
+		const int weight = wi * M;
+		int span = min(t_len - tEnd, q_len - qEnd);
+		int gap = span - 1;
+		gap = gap ? gap * U + W1 : W1;
+		int sub = mism_score(span, k, M, MM);
+		const int score0 = weight + (sub < gap ? gap : sub);
+		// candidates
+		const int lim = min(n, i + 128);
+		int g[2];
+		bool ok[2], free_join[2];
+#pragma unroll
+		for(int h = 0; h < 2; ++h) {
+			const int j = i + 1 + h * 64 + lane;
+			ok[h] = false; free_join[h] = false; g[h] = INT_MIN;
+			if(j < lim) {
+				const int sl = j & 127;
+				const int tSj = S.ring[0][sl], tEj = S.ring[1][sl], qSj = S.ring[2][sl], qEj = S.ring[3][sl], scj = S.ring[4][sl];
+				if(qEnd < qSj) {
+					if(tEnd < tSj) {
+						const int tGap = tSj - tEnd, qGap = qSj - qEnd;
+						int x = abs(tGap - qGap);
+						if(x) x = (x - 1) * U + W1;
+						g[h] = x + weight + scj + mism_score(min(tGap, qGap), k, M, MM);
+						ok[h] = true; free_join[h] = true;
+					} else if(k <= tEj - tEnd) {
+						int x = qSj - qEnd;
+						if(x) x = (x - 1) * U + W1;
+						g[h] = x + weight + scj - (tSj - tEnd) * M;
+						ok[h] = true;
+					}
+				} else if(k <= qEj - qEnd) {
+					const int tStart = tSj + qEnd - qSj;
+					if(tEnd < tStart) {
+						int x = tStart - tEnd;
+						if(x) x = (x - 1) * U + W1;
+						g[h] = x + weight + scj - (tStart - tEnd) * M;
+						ok[h] = true;
+					}
+				}
+			}
+		}
+		const int G = wave_max(max(g[0], g[1]));
+		int nxt = 0, score = score0;
+		if(G >= score0) {
+			const unsigned long long e0 = __ballot(ok[0] && g[0] == G), e1 = __ballot(ok[1] && g[1] == G);
+			const unsigned long long a0 = __ballot(free_join[0] && g[0] == G), a1 = __ballot(free_join[1] && g[1] == G);
+			int lastA = -1;
+			if(a1) lastA = i + 65 + (63 - __clzll((long long) a1));
+			else if(a0) lastA = i + 1 + (63 - __clzll((long long) a0));
+			if(G > score0) {
+				const int first = e0 ? i + 1 + (__ffsll((long long) e0) - 1) : i + 65 + (__ffsll((long long) e1) - 1);
+				nxt = lastA >= 0 ? lastA : first;
+				score = G;
+			} else if(lastA >= 0) nxt = lastA;
+		}
+		const int wnew = nxt ? (wi + S.ring[5][nxt & 127] - k + 1) : (wi - (k - 1));
+		wave_sync();
+		if(lane == 0) {
+			const int sl = i & 127;
+			S.ring[0][sl] = tSi; S.ring[1][sl] = tEnd; S.ring[2][sl] = qSi; S.ring[3][sl] = qEnd; S.ring[4][sl] = score; S.ring[5][sl] = wnew;
+			if(lds_next) S.next[i] = (uint16_t) nxt; else Mm.nx[base + i] = nxt;
+		}
+		wave_sync();
+		span = min(tSi, qSi);
+		gap = span - 1;
+		if(0 < gap) gap = gap * U + W1; else if(gap == 0) gap = W1; else gap = 0;
+		sub = mism_score(span, k, M, MM);
+		score += sub < gap ? gap : sub;
+		if(best <= score) {
+			if(nxt != bestPos) second = best;
+			best = score; bestPos = i; bestW = wnew;
+		} else if(second <= score && nxt != bestPos) {
+			second = best;
+		}
+	}
+	if(0 < best) {
+		const double wq = fmin(1.0, bestW / 10.0);
+		*mapQ = (unsigned) ceil(40 * (1 - 1.0 * second / best) * wq * log((double) best));
+	} else *mapQ = 0;
+	*bestScore = best;
+	return bestPos;
+}
+
+// one join of the chain (KMA(), align.c:430-466): from the end of MEM a to the start of MEM b, which gives way where the
+// two overlap. l == 0: leading tail in front of b (leadTailAln, align.c:53-131); l == nc: trailing tail behind a
+// (trailTailAln, align.c:140-212).
+struct Join { int t_s, t_l, q_s, q_l, k, band, flags, body, bq, fail, clip0, qe; };
+__device__ Join lt_join(const LtArgs &A, const MemArr &Mm, int ia, int ib, int l, int nc, int q_len, int t_len) {
+	const int bw = 64;
+	Join J;
+	J.t_s = 0; J.t_l = 0; J.q_s = 0; J.q_l = 0; J.k = 0; J.band = 0; J.flags = PF_NONE; J.body = 0; J.bq = 0; J.fail = 0; J.clip0 = 0; J.qe = 0;
+	if(l == 0) {
+		const int t_e = Mm.tS[ib] - 1, q_e = Mm.qS[ib];
+		J.body = Mm.qE[ib] - Mm.qS[ib]; J.bq = q_e;
+		if(q_e) {
+			int t_s = 0, q_s = 0;
+			if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+			else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+			J.clip0 = q_s;
+			if(t_e - t_s > 0 && q_e - q_s > 0) {
+				const int band = abs(t_e - t_s - q_e + q_s) + bw;
+				J.t_s = t_s; J.t_l = t_e - t_s; J.q_s = q_s; J.q_l = q_e - q_s; J.k = -1 - (t_s == 0);
+				J.band = (q_e - q_s <= band || t_e - t_s <= band) ? 0 : band;
+				J.flags = (t_s == 0) ? PF_LEAD_TRIM : 0;
+			}
+		}
+		return J;
+	}
+	if(l == nc) {
+		const int t_s = Mm.tE[ia] - 1, q_s = Mm.qE[ia];
+		int q_e = q_len, t_e = t_len;
+		if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+			t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+		} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+			q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+		}
+		J.qe = q_e;
+		if(t_e - t_s > 0 && q_e - q_s > 0) {
+			const int band = abs(t_e - t_s - q_e + q_s) + bw;
+			J.t_s = t_s; J.t_l = t_e - t_s; J.q_s = q_s; J.q_l = q_e - q_s; J.k = 1 + (t_e == t_len);
+			J.band = (q_e - q_s <= band || t_e - t_s <= band) ? 0 : band;
+			J.flags = (t_e == t_len) ? PF_TRAIL_TRIM : 0;
+		}
+		return J;
+	}
+	const int q_s = Mm.qE[ia], t_s = Mm.tE[ia] - 1;
+	int qSn = Mm.qS[ib], tSn = Mm.tS[ib];
+	const int tEb = Mm.tE[ib], qEb = Mm.qE[ib];
+	if(qSn < q_s) { tSn += q_s - qSn; qSn = q_s; }
+	int t_e = tSn - 1, t_l;
+	if(t_e < t_s) {
+		if(t_s <= tEb) { qSn += t_s - t_e; t_e = t_s; t_l = 0; }
+		else t_l = t_len - t_s + t_e;
+	} else t_l = t_e - t_s;
+	const int q_e = qSn;
+	J.body = qEb - qSn; J.bq = qSn;
+	if(abs(t_l - q_e + q_s) * A.U > q_len * A.M || t_l > q_len || q_e - q_s > (q_len >> 1)) { J.fail = 1; return J; }
+	if(t_l > 0 || q_e - q_s > 0) {
+		J.t_s = t_s; J.t_l = t_l; J.q_s = q_s; J.q_l = q_e - q_s; J.k = 0;
+		if(t_l == 0) J.flags = PF_DEGEN_I;
+		else if(q_e - q_s == 0) J.flags = PF_DEGEN_D;
+		else {
+			const int band = abs(t_l - q_e + q_s) + bw;
+			J.band = (q_e - q_s <= band || t_l <= band) ? 0 : band;
+			J.flags = 0;
+		}
+	}
+	return J;
+}
+
+// size class of a DP problem
+__device__ __forceinline__ int lt_class(int q_l, int t_l, int band, int k, int64_t xe_cap) {
+	if(band == 0 && t_l <= LT_TMAX) {
+		const int cells = (q_l + 1) * (t_l + 1);
+		if(q_l <= 8 && cells <= LT_E_WAVE / 8) return 0;
+		if(q_l <= 16 && cells <= LT_E_WAVE / 4) return 1;
+		if(q_l <= 32 && cells <= LT_E_WAVE / 2) return 2;
+		if(q_l <= 64 && cells <= LT_E_WAVE) return 3;
+	}
+	if(band & 1) ++band;
+	const int pitch = band ? band + 2 : q_l + 1;
+	// the reference's last-row scan (k == -2) reads cells of its row buffer beyond the boundary column when the band is cut
+	// there: only the one-lane form reproduces that
+	const int cfin = ((t_l + q_l) >> 1) - (t_l - 1);
+	const bool stale_scan = band && k == -2 && !(cfin + (band >> 1) < q_l - 1);
+	// (the sweeps keep their move matrix in LDS; a problem beyond that is rare enough for the one-lane form)
+	if(q_l < 256 && !stale_scan && (int64_t) pitch * (t_l + 1) <= LT_XE_LDS) return 4 + (band ? 2 : 0) + (q_l <= 128 ? 0 : 1);
+	return 8;
+}
+
+__global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
+	__shared__ SeedLds S;
+	const int lane = threadIdx.x;
+	if(lane < 25) S.d[lane] = A.d[lane];
+	const int k = (int) A.db.kmersize;
+	MemArr Mm;
+	{
+		int32_t *m0 = A.mem + (size_t) blockIdx.x * 7 * A.mcap;
+		Mm.tS = m0; Mm.tE = m0 + A.mcap; Mm.qS = m0 + 2 * (size_t) A.mcap; Mm.qE = m0 + 3 * (size_t) A.mcap; Mm.w = m0 + 4 * (size_t) A.mcap;
+		Mm.nx = m0 + 5 * (size_t) A.mcap; Mm.ch = m0 + 6 * (size_t) A.mcap;
+	}
+	// reads are dealt out round robin (a work counter with `if(lane == 0) atomicAdd` + broadcast in these kernels was turned by
+	// the compiler into loops that drop lane 0 from EXEC on gfx950 -- plain strides are scalar loops and cannot go wrong that way)
+	for(int64_t rr = blockIdx.x; rr < A.n_reads; rr += gridDim.x) {
+		const int64_t r = A.r0 + rr;
+		LtRead H;
+		H.first = 0; H.status = 0; H.rc = 0; H.n_prob = 0; H.mapQ = 0; H.pos0 = 0; H.clip0 = 0; H.qe_trail = 0; H.pad = 0;
+		const int tt = A.tmpl ? A.tmpl[r] : A.tmpl_all;
+		const int t = abs(tt);
+		QView qf;
+		qf.w = A.seq + A.seq_off[r]; qf.L = A.len[r]; qf.N = A.N + A.N_off[r]; qf.nN = (int) (A.N_off[r + 1] - A.N_off[r]); qf.rc = 0;
+		const int q_len = qf.L;
+		bool go = t != 0 && !(A.tmpl_ok && !A.tmpl_ok[t]) && q_len > 0;
+		int t_len = 0, base = 0, n = 0;
+		const uint64_t *ts = nullptr;
+		if(go) {
+			const uint4 ma = A.db.tmeta[2 * (size_t) t], mb = A.db.tmeta[2 * (size_t) t + 1];
+			t_len = (int) mb.x;
+			ts = A.db.tseq + (((uint64_t) ma.y << 32) | ma.x);
+			const uint2 *tab = A.db.tpos_slots + (((uint64_t) ma.w << 32) | ma.z);
+			const uint32_t tsh = mb.y;
+			int tot = 0;
+			bool room = true;
+			if(A.rc_in) {
+				// orientation known (the read ConClave filed under a template): KMA()'s own seeding, one strand
+				qf.rc = (((A.rc_in[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
+				int mc = 0, sc = 0;
+				room = lt_seed_strand(A, S, Mm, qf, ts, t_len, tab, tsh, k, tot, mc, sc);
+				base = 0; n = mc; H.rc = qf.rc;
+			} else {
+				// anker_rc: forward strand (skipped when none of its every-k-th k-mers is in the index, preseed), then the reverse
+				bool fwd = true;
+				if(!A.exhaustive) {
+					bool hit = false;
+					for(int i0 = lane * k; i0 < q_len; i0 += 64 * k) {
+						uint64_t key = 0;
+						for(int x = 0; x < k; ++x) key = (x ? (key << 2) : 0ull) | (uint64_t) ((i0 + x < q_len) ? qn(qf, i0 + x) : 0);
+						if(key <= 0xFFFFFFFFull && lt_lookup(tab, tsh, (uint32_t) key) != 0) hit = true;
+					}
+					fwd = __any(hit);
+				}
+				int score = 0, plen = 0, mc = 0, sc = 0;
+				if(fwd) room = lt_seed_strand(A, S, Mm, qf, ts, t_len, tab, tsh, k, tot, mc, sc);
+				score = sc; plen = mc;
+				QView qr = qf; qr.rc = 1;
+				mc = 0; sc = 0;
+				if(room) room = lt_seed_strand(A, S, Mm, qr, ts, t_len, tab, tsh, k, tot, mc, sc);
+				const int bestScore = max(score, sc);
+				if(A.one2one && bestScore < k && bestScore * k < (q_len - k - bestScore)) n = 0;
+				else if(bestScore == 0) n = 0;
+				else if(bestScore == score) { base = 0; n = plen; H.rc = 0; }
+				else { base = plen; n = mc; H.rc = 1; qf.rc = 1; }
+			}
+			if(!room) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 3ull); n = 0; }
+			go = n > 0;
+		}
+		wave_sync_hbm();    // the MEMs written by lane 0 are read by all lanes from here on
+		unsigned mapQ = 0;
+		int start = 0, nc = 0;
+		if(go) {
+			int best = 0;
+			start = lt_chain(A, S, Mm, base, n, q_len, t_len, k, &mapQ, &best);
+			if(mapQ < (unsigned) A.mq || best < k) go = false;
+		}
+		if(go) {
+			// the chain in order
+			const bool lds_next = n <= LT_NEXT_CAP;
+			wave_sync();
+			if(lane == 0) {
+				int c = start;
+				for(;;) {
+					if(lds_next) S.chain[nc] = (uint16_t) c; else Mm.ch[base + nc] = c;
+					++nc;
+					const int nx = lds_next ? (int) S.next[c] : Mm.nx[base + c];
+					if(!nx || nx <= c || nx >= n || nc >= n) break;        // (links point to later MEMs)
+					c = nx;
+				}
+			}
+			nc = __shfl(nc, 0);
+			wave_sync_hbm();
+			// pass 1: a join too large to score positive fails the read (align.c:468-479)
+			bool fail = false;
+			for(int l = 1 + lane; l < nc; l += 64) {
+				const int ia = base + (lds_next ? (int) S.chain[l - 1] : Mm.ch[base + l - 1]), ib = base + (lds_next ? (int) S.chain[l] : Mm.ch[base + l]);
+				fail = fail || lt_join(A, Mm, ia, ib, l, nc, q_len, t_len).fail != 0;
+			}
+			if(__any(fail)) go = false;
+		}
+		if(go) {
+			const bool lds_next = n <= LT_NEXT_CAP;
+			const int np = nc + 1;
+			unsigned long long first = 0;
+			if(lane == 0) first = atomicAdd(&A.counters[LC_PROB], (unsigned long long) np);
+			first = __shfl(first, 0);
+			if((int64_t) first + np > A.prob_cap) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 5ull); go = false; }
+			else {
+				H.first = (int64_t) first; H.n_prob = np; H.mapQ = (int) mapQ; H.status = 1;
+				for(int l0 = 0; l0 < np; l0 += 64) {
+					const int l = l0 + lane;
+					Join J;
+					J.flags = PF_NONE; J.t_l = 0; J.q_l = 0; J.band = 0;
+					if(l < np) {
+						const int ca = l > 0 ? (lds_next ? (int) S.chain[l - 1] : Mm.ch[base + l - 1]) : 0;
+						const int cb = l < nc ? (lds_next ? (int) S.chain[l] : Mm.ch[base + l]) : 0;
+						J = lt_join(A, Mm, base + ca, base + cb, l, nc, q_len, t_len);
+					}
+					const bool dp = l < np && !(J.flags & (PF_NONE | PF_DEGEN_I | PF_DEGEN_D));
+					// run slots: one word per column at most
+					const int need = dp ? J.t_l + J.q_l + 1 : 0;
+					const int incl = wave_scan_incl(need, lane);
+					const int total = __shfl(incl, 63);
+					unsigned long long rbase = 0;
+					if(lane == 63 && total) rbase = atomicAdd(&A.counters[LC_RUNS], (unsigned long long) total);
+					rbase = __shfl(rbase, 63);
+					const bool rfit = (int64_t) rbase + total <= A.runs_cap;
+					if(!rfit && lane == 0) atomicMax(&A.counters[LC_STATUS], 6ull);
+					if(l < np) {
+						LtProb P;
+						P.runs = (int64_t) rbase + incl - need; P.read = (int32_t) rr; P.t_s = J.t_s; P.t_l = J.t_l; P.q_s = J.q_s; P.q_l = J.q_l;
+						P.k = J.k; P.band = J.band; P.flags = (dp && !rfit) ? PF_NONE : J.flags; P.body = J.body;
+						// MEM bases score d[b][b] each (a MEM never holds an N)
+						P.body_score = 0;
+						if(S.d[0] == S.d[6] && S.d[0] == S.d[12] && S.d[0] == S.d[18]) P.body_score = J.body * S.d[0];
+						else for(int x = 0; x < J.body; ++x) { const int b = q2(qf, J.bq + x); P.body_score += S.d[6 * b]; }
+						P.score = 0; P.n_runs = 0; P.clip = 0; P.pad = 0;
+						if(l == 0) { H.pos0 = Mm.tS[base + (lds_next ? (int) S.chain[0] : Mm.ch[base])] - 1; H.clip0 = J.clip0; }
+						if(l == nc) H.qe_trail = J.qe;
+						A.prob[first + l] = P;
+					}
+					// queues per class, one atomic per class and round
+					const int cls = dp && rfit ? lt_class(J.q_l, J.t_l, J.band, J.k, A.xe_cap) : -1;
+					for(int c = 0; c < LT_NCLS; ++c) {
+						const unsigned long long m = __ballot(cls == c);
+						if(!m) continue;
+						const int leader = __ffsll((long long) m) - 1;
+						unsigned long long qb = 0;
+						if(lane == leader) qb = atomicAdd(&A.counters[LC_CNT + c], (unsigned long long) __popcll(m));
+						qb = __shfl(qb, leader);
+						if(cls == c) A.queue[(size_t) c * A.prob_cap + qb + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t) (first + l);
+					}
+				}
+				// pos0 / clip0 live in lane 0 (l == 0), qe_trail in the lane that owned l == nc
+				const int own = nc & 63;
+				H.qe_trail = __shfl(H.qe_trail, own);
+				H.pos0 = __shfl(H.pos0, 0); H.clip0 = __shfl(H.clip0, 0);
+			}
+		}
+		if(!go) { H.status = 0; H.n_prob = 0; }
+		if(lane == 0) A.rd[rr] = H;
+		wave_sync();
+	}
+}
+
+// ---- the alignment columns of one problem as runs ((length << 2) | class: 0 '=', 1 'X', 2 'I' gap in the template, 3 'D' gap
+// in the read), written by the lane that walks the move matrix ---------------------------------------------------------------
+struct RunOut {
+	uint32_t *dst;
+	int cap;               // slot words
+	int n;                 // runs written
+	int cur_cls, cur_len;  // open run
+	int total;             // columns
+	int first_cls;
+	int n_diag;            // runs up to and including the last aligned pair (the open run counted)
+	int suf_I;             // 'I' columns behind the last aligned pair
+	bool writer;           // false: this lane only follows (a walk that every lane of the wavefront runs in step, lane 0 writing)
+	__device__ __forceinline__ void init(uint32_t *d, int c, bool w = true) { dst = d; cap = c; n = 0; cur_cls = -1; cur_len = 0; total = 0; first_cls = -1; n_diag = 0; suf_I = 0; writer = w; }
+	__device__ __forceinline__ void put(int cls, int len) {
+		if(len <= 0) return;
+		if(total == 0) first_cls = cls;
+		total += len;
+		if(cls == cur_cls) cur_len += len;
+		else {
+			if(cur_len && n < cap) { if(writer) dst[n] = ((uint32_t) cur_len << 2) | (uint32_t) cur_cls; ++n; }
+			cur_cls = cls; cur_len = len;
+		}
+		if(cls < 2) { n_diag = n + 1; suf_I = 0; }
+		else if(cls == 2) suf_I += len;
+	}
+	// gap columns at the very end of the template are trimmed, the first column always stays (trailTailAln, align.c:180-196);
+	// returns the number of trimmed 'I' columns (query bases that become a soft clip)
+	__device__ __forceinline__ int finish(bool trail_trim) {
+		if(cur_len && n < cap) { if(writer) dst[n] = ((uint32_t) cur_len << 2) | (uint32_t) cur_cls; ++n; }
+		cur_len = 0;
+		if(!trail_trim || n == n_diag) return 0;
+		if(n_diag > 0) { n = n_diag; return suf_I; }
+		// nothing but gaps: one column of the first run stays
+		if(writer) dst[0] = (1u << 2) | (uint32_t) first_cls;
+		n = 1;
+		return suf_I - (first_cls == 2 ? 1 : 0);
+	}
+};
+
+// the walk of the move matrix (nw.c:256-305 full, :586-635 band) from cell (m, n). pitch = bytes per template row, dn = column
+// change per template step (0 full matrix, -1 band). A gap run ends on the first cell with EITHER may-open bit (0x30); bit 6 of
+// a diagonal cell = the pair is a mismatch. lead: gaps in front are dropped (leadTailAln with t_s == 0, align.c:97-112), a
+// dropped 'I' column leaves a read base unaligned (-> clip). Returns the query columns consumed (from q_pos on).
+// Compiled as a function of its own (not inlined): inlined into the kernels' divergent regions (one lane per problem walks while
+// the others wait) the loop came out of the compiler as one that never ends on gfx950; as a separate function its control flow
+// is a single loop. E is a generic pointer (LDS or HBM).
+__attribute__((noinline)) __device__ int lt_walk(const uint8_t *E, int pitch, int m, int n, int dn, int q_pos, int lead, RunOut *Rp, int *clip, int64_t limit, int *bad) {
+	// one flat loop, one cell per iteration: mode 0 = at a cell whose move decides, 1 = inside a run of gaps in the read (template
+	// rows consumed), 2 = inside a run of gaps in the template (query columns consumed); a run counts its cells up to and including
+	// the first one that carries a may-open bit. A correct matrix is left through one of its zero cells; anything else (leaving the
+	// matrix, more iterations than cells) is a bug and must not hang the wavefront.
+	RunOut R = *Rp;
+	int64_t at = (int64_t) m * pitch + n;
+	int mode = 0, g = 0, cl = *clip, isbad = 0;
+	bool stop = false;
+	for(int64_t it = 0; !stop; ++it) {
+		if(at < 0 || at >= limit || it > limit) { isbad = 1; stop = true; }
+		else {
+			const int e = E[at];
+			if(mode == 0 && e == 0) stop = true;
+			else if(mode == 0 && (e & 7) == 1) {
+				R.put((e & 64) ? 1 : 0, 1);
+				lead = 0;
+				at += pitch + 1 + dn; ++q_pos;
+			} else {
+				if(mode == 0) { mode = ((e & 7) >= 4) ? 1 : 2; g = 0; }
+				++g;
+				const bool last = (e & 0x30) != 0;
+				if(mode == 1) {
+					at += pitch + dn;
+					if(last) { if(!lead) R.put(3, g); mode = 0; }
+				} else {
+					at += 1;
+					if(last) { q_pos += g; if(!lead) R.put(2, g); else cl += g; mode = 0; }
+				}
+			}
+		}
+	}
+	*Rp = R; *clip = cl; *bad = isbad;
+	return q_pos;
+}
+
+struct DpLds {
+	int d[25];
+	uint8_t E[4][LT_E_WAVE];
+	uint8_t t[4][8 * (LT_TMAX + 1)];
+};
+
+// NW / NW with free ends (nw.c:26-309; fill identical to NW_score, nw.c:642-890) for the problems of one size class: W lanes
+// per problem, lane n owns query column n, the segment sweeps the anti-diagonals (cell (m, n + 1) from the right neighbour's
+// last step, (m + 1, n + 1) from the step before), every cell's move byte goes to the problem's matrix in LDS, then lane 0 of
+// the segment walks it.
+template <int W>
+__global__ __launch_bounds__(256) void lt_dp_kernel(const LtArgs A, int cls) {
+	constexpr int G = 64 / W;
+	__shared__ DpLds S;
+	if(threadIdx.x < 25) S.d[threadIdx.x] = A.d[threadIdx.x];
+	__syncthreads();
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & (W - 1), g = lane / W;
+	uint8_t *const E = S.E[wave] + g * (LT_E_WAVE / G);
+	uint8_t *const tbuf = S.t[wave] + g * (LT_TMAX + 1);
+	const unsigned long long count = A.counters[LC_CNT + cls];
+	const int32_t *queue = A.queue + (size_t) cls * A.prob_cap;
+	const int U = A.U, W1 = A.W1;
+	for(unsigned long long base = ((unsigned long long) blockIdx.x * 4 + wave) * G; base < count; base += (unsigned long long) gridDim.x * 4 * G) {
+		const bool live = base + g < count;
+		LtProb *P = A.prob + queue[live ? base + g : base];
+		const int k = P->k, t_s = P->t_s, t_len = P->t_l, q_s = P->q_s, q_len = P->q_l, flags = P->flags;
+		const int64_t r = A.r0 + P->read;
+		const int tt = A.tmpl ? A.tmpl[r] : A.tmpl_all;
+		const int at = abs(tt);
+		const int tlen_total = A.db.tlen[at];
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+		QView q;
+		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.rc = A.rd[P->read].rc;
+		q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+		const int pitch = q_len + 1;
+		const int low = (t_len + q_len) * (A.MM + U + W1);
+		wave_sync();           // the walk of the round before is done with E
+		if(live) {
+			for(int i = n; i < t_len; i += W) {
+				int pos = t_s + i;
+				if(pos >= tlen_total) pos -= tlen_total;
+				tbuf[i] = (uint8_t) tn(ts, pos);
+			}
+			// boundary cells (nw.c:703-750): column q_len of every row, row t_len
+			for(int m = n; m < t_len; m += W) E[m * pitch + q_len] = (0 < k) ? 0 : ((m == t_len - 1) ? 36 : 5);
+			uint8_t *Er = E + t_len * pitch;
+			for(int c = n; c <= q_len; c += W) Er[c] = (k == 2 || c == q_len) ? 0 : ((c == q_len - 1) ? 18 : 3);
+		}
+		const bool col = live && n < q_len;
+		const int qc = col ? qn(q, q_s + n) : 0;
+		wave_sync();
+		// `l*` = the row this lane computed last (start: boundary row m = t_len), bD = D of the row before it
+		int lD, lP = low, lQ = low, bD = 0;
+		if(k == 2) lD = 0; else lD = W1 + (q_len - 1 - n) * U;
+		int best = low, best_m = 0;
+		int steps = live ? t_len + q_len - 1 : 0;
+		steps = wave_max(steps);
+		for(int dstep = 0; dstep < steps; ++dstep) {
+			int rD = __shfl_down(lD, 1, W), rQ = __shfl_down(lQ, 1, W), dD = __shfl_down(bD, 1, W);
+			const int i = dstep - (q_len - 1 - n);
+			if(col && i >= 0 && i < t_len) {
+				const int m = t_len - 1 - i;
+				if(n == q_len - 1) {
+					// boundary column q_len
+					rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+					rQ = low;
+					if(m + 1 == t_len) dD = 0;
+					else dD = (0 < k) ? 0 : (W1 + (t_len - 2 - m) * U);
+				}
+				const int tb = (int) tbuf[m];
+				const int *drow = S.d + 5 * tb;
+				int Q = rD + W1, Pn = lD + W1, D, mv, cell = 0;
+				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int x = rQ + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				x = lP + U;
+				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+				x = dD + drow[qc];
+				if(D <= x) { D = x; cell |= 1 | (tb != qc ? 64 : 0); } else cell |= mv;
+				E[m * pitch + n] = (uint8_t) cell;
+				bD = lD;
+				lD = D; lP = Pn; lQ = Q;
+				if(n == 0 && k < 0 && best < D) { best = D; best_m = m; }
+			}
+		}
+		wave_sync();
+		// result selection (nw.c:218-254): k < 0: best cell of column 0 (rows from the bottom up, strict); k == -2: then the
+		// cells of row 0, `<=`, so the largest column holding the row maximum if it reaches the score
+		int score, sm = 0, sn = 0;
+		const int seg0 = g * W;
+		if(k < 0) { score = __shfl(best, seg0); sm = __shfl(best_m, seg0); }
+		else score = __shfl(lD, seg0);
+		{
+			int mx = col ? lD : INT_MIN;
+			for(int o = W / 2; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, W));
+			const unsigned long long who = __ballot(col && lD == mx);
+			const unsigned long long mine = (W == 64) ? who : ((who >> seg0) & ((1ull << (W & 63)) - 1ull));
+			if(k == -2 && mx >= score && mine) { score = mx; sm = 0; sn = 63 - __clzll((long long) mine); }
+		}
+		if(live && n == 0) {
+			RunOut R;
+			R.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = sn, bad = 0;
+			const int q_pos = lt_walk((const uint8_t *) E, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : R.n;
+			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
+		}
+	}
+}
+
+// ---- problems of more than 64 query columns and banded problems --------------------------------------------------------------
+// One problem per wavefront, lane n owns XW neighbouring columns (aligned to the right end, so only lane 0 can own fewer) and
+// takes them right to left inside a step of the same anti-diagonal sweep. banded: NW_band (nw.c:310-640). In query coordinates
+// the banded recurrences are the full ones restricted to the columns [c - band/2, c + band/2] of each row (c = (t_len + q_len)/2
+// at the last row, one less per row), except that the leftmost cell of a row has no template-gap state (nw.c:505-531), that
+// the right neighbour of the band's last column is a virtual cell (D = low, move byte 37) and that the result is read off the
+// leftmost cells. The move matrix is stored as the reference stores it: row pitch band + 2, cell (m, column) at index
+// column - c_m + band/2, so the walk is the reference's (one column to the left per template row).
+template <int XW, bool banded>
+__device__ void lt_sweep_x(const LtArgs &A, const int *sd, const LtProb *P, const QView &q, uint8_t *E, const uint8_t *tbuf, const uint64_t *ts,
+                           int tlen_total, int &o_score, int &o_m, int &o_n, int &o_qpos) {
+	const int lane = threadIdx.x & 63;
+	const int k = P->k, t_s = P->t_s, t_len = P->t_l, q_s = P->q_s, q_len = P->q_l;
+	int band = banded ? P->band : 0;
+	const int U = A.U, W1 = A.W1;
+	const int low = (t_len + q_len) * (A.MM + U + W1);
+	if(band & 1) ++band;
+	const int half = band >> 1, bq = band + 1;
+	const int pitch = banded ? bq + 1 : q_len + 1;
+	const int cbot = (t_len + q_len) >> 1;             // band centre of the last row (m = t_len - 1)
+	// boundary cells: row t_len and, per row, the cell behind the last column
+	if(banded) {
+		const int sn0 = q_len - (cbot + 1) + half;
+		uint8_t *Er = E + (int64_t) t_len * pitch;
+		for(int c = lane; c <= sn0; c += 64) Er[c] = (k == 2 || c == sn0) ? 0 : ((c == sn0 - 1) ? 18 : 3);
+		for(int m = lane; m < t_len; m += 64) {
+			const int c = cbot - (t_len - 1 - m);
+			if(c + half < q_len - 1) E[(int64_t) m * pitch + bq] = 37;
+			else E[(int64_t) m * pitch + (q_len - c + half)] = (0 < k) ? 0 : 37;
+		}
+	} else {
+		for(int m = lane; m < t_len; m += 64) E[(int64_t) m * pitch + q_len] = (0 < k) ? 0 : ((m == t_len - 1) ? 36 : 5);
+		uint8_t *Er = E + (int64_t) t_len * pitch;
+		for(int c = lane; c <= q_len; c += 64) Er[c] = (k == 2 || c == q_len) ? 0 : ((c == q_len - 1) ? 18 : 3);
+	}
+	const int nl = (q_len + XW - 1) / XW;              // lanes in use
+	const int c0 = q_len - (nl - lane) * XW;           // this lane's first column (negative: lane 0 owns fewer than XW)
+	const bool act = lane < nl;
+	int qc[XW], lD[XW], lP[XW], lQ[XW];
+#pragma unroll
+	for(int j = 0; j < XW; ++j) {
+		const int c = c0 + j;
+		qc[j] = (act && c >= 0) ? qn(q, q_s + c) : 0;
+		if(k == 2) lD[j] = 0; else lD[j] = W1 + (q_len - 1 - c) * U;
+		lP[j] = low; lQ[j] = low;
+	}
+	int bD0 = 0;                                       // the row before `l` of this lane's first column, for the lane to the left
+	int best = low, bm = 0;
+	wave_sync();
+	const int steps = t_len + nl - 1;
+	for(int d = 0; d < steps; ++d) {
+		const int nD = __shfl_down(lD[0], 1), nQ = __shfl_down(lQ[0], 1), nbD = __shfl_down(bD0, 1);
+		const int i = d - (nl - 1 - lane);
+		if(act && i >= 0 && i < t_len) {
+			const int m = t_len - 1 - i;
+			const int c = cbot - i;
+			const int eq = banded ? max(c - half, 0) : -1;
+			const bool virt = banded && c + half < q_len - 1;
+			const int sq = virt ? c + half : q_len - 1;
+			int rD, rQ, dD;
+			const int cr = c0 + XW;                         // first column of the lane to the right (q_len for the last lane)
+			if(cr >= q_len) {
+				rD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+				rQ = low;
+				if(m + 1 == t_len) dD = 0;
+				else dD = (0 < k) ? 0 : (W1 + (t_len - 2 - m) * U);
+			} else if(cr <= sq) { rD = nD; rQ = nQ; dD = nbD; }      // it has done this row already
+			else { rD = low; rQ = low; dD = nD; }                      // outside the band: virtual cell, `l` is the row below
+			int tb;
+			if(m < LT_XT_LDS) tb = (int) tbuf[m];
+			else { int pos = t_s + m; if(pos >= tlen_total) pos -= tlen_total; tb = tn(ts, pos); }
+			const int *drow = sd + 5 * tb;
+			uint8_t *e = E + (int64_t) m * pitch + (banded ? half - c : 0);
+#pragma unroll
+			for(int jj = 0; jj < XW; ++jj) {
+				const int j = XW - 1 - jj;
+				const int col = c0 + j;
+				if(col >= 0 && col >= eq && col <= sq) {
+					const int oD = lD[j];
+					int D, Q, Pn, cell = 0;
+					if(col == eq) {
+						// leftmost cell of the band: no template-gap state
+						int mv;
+						Q = rD + W1;
+						const int x = rQ + U;
+						if(Q < x) { Q = x; mv = 3; } else { mv = 2; cell |= 16; }
+						D = dD + drow[qc[j]];
+						if(Q <= D) cell |= 1 | (tb != qc[j] ? 64 : 0); else { D = Q; cell |= mv; }
+						Pn = low;
+						if(eq == 0 && k < 0 && best < D) { best = D; bm = m; }
+					} else {
+						int mv;
+						Q = rD + W1; Pn = oD + W1;
+						if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+						int x = rQ + U;
+						if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+						x = lP[j] + U;
+						if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+						x = dD + drow[qc[j]];
+						if(D <= x) { D = x; cell |= 1 | (tb != qc[j] ? 64 : 0); } else cell |= mv;
+						if(!banded && col == 0 && k < 0 && best < D) { best = D; bm = m; }
+					}
+					e[col] = (uint8_t) cell;
+					if(j == 0) bD0 = oD;
+					lD[j] = D; lP[j] = Pn; lQ[j] = Q;
+					rD = D; rQ = Q; dD = oD;
+				} else if(col >= 0 && col == sq + 1) {
+					rD = low; rQ = low; dD = lD[j];
+				}
+			}
+		}
+	}
+	wave_sync();
+	// result selection. Full: nw.c:218-254, banded: nw.c:557-585. Column `cres` (0, or the leftmost column of the last row's
+	// band) holds the final value; lane 0 tracked the best leftmost cell for k < 0.
+	const int cfin = cbot - (t_len - 1);
+	const int cres = banded ? max(cfin - half, 0) : 0;
+	const int sfin = (banded && cfin + half < q_len - 1) ? cfin + half : q_len - 1;
+	const int owner = nl - 1 - (q_len - 1 - cres) / XW;
+	int Dres = 0;
+#pragma unroll
+	for(int j = 0; j < XW; ++j) if(c0 + j == cres) Dres = lD[j];
+	Dres = __shfl(Dres, owner);
+	int score = __shfl(best, 0), row = __shfl(bm, 0), colr = 0;
+	if(banded) { if(row == 0) { score = Dres; colr = cres; } }
+	else if(!(k < 0)) { score = Dres; row = 0; }
+	int q_pos = 0;
+	if(k == -2) {
+		int mx = INT_MIN, mc = -1;
+#pragma unroll
+		for(int j = 0; j < XW; ++j) if(act && c0 + j >= cres && c0 + j <= sfin && lD[j] >= mx) { mx = lD[j]; mc = c0 + j; }
+		const int wmx = wave_max(mx);
+		const unsigned long long who = __ballot(act && mc >= 0 && mx == wmx);
+		const int src = who ? 63 - __clzll((long long) who) : 0;
+		const int mcs = __shfl(mc, src);
+		if(wmx >= score) { score = wmx; row = 0; colr = mcs; q_pos = mcs - cres; }
+	}
+	o_score = score; o_m = row;
+	o_n = banded ? colr - (cbot - (t_len - 1 - row)) + half : colr;
+	o_qpos = q_pos;
+}
+
+// One lane, rows and move matrix in HBM: NW / NW_band as the reference runs them (nw.c:26-640), for what fits neither sweep
+// (more than 255 query columns, a banded problem whose last-row scan would read cells the band no longer covers).
+__device__ bool lt_serial(const LtArgs &A, const int *sd, const LtProb *P, const QView &q, const uint64_t *ts, int tlen_total,
+                          uint8_t *E, int64_t e_cap, int32_t *rows, int ncols, int &o_score, int &o_m, int &o_n, int &o_qpos, int &o_pitch, int &o_dn) {
+	const int k = P->k, t_s = P->t_s, t_len = P->t_l, q_s = P->q_s, q_len = P->q_l;
+	int band = P->band;
+	const int U = A.U, W1 = A.W1;
+	const int low = (t_len + q_len) * (A.MM + U + W1);
+	int32_t *Dr[2] = {rows, rows + ncols}, *Pr[2] = {rows + 2 * (int64_t) ncols, rows + 3 * (int64_t) ncols};
+	int dc = 0, dp = 1;
+	const int t_e = t_s + t_len;      // may exceed the template: positions are taken modulo its length
+	int score = low;
+	if(band == 0) {
+		const int pitch = q_len + 1;
+		if((int64_t) pitch * (t_len + 1) > e_cap || q_len + 2 > ncols) return false;
+		uint8_t *Er = E + (int64_t) pitch * t_len;
+		for(int m = 0; m < t_len; ++m) E[(int64_t) pitch * m + q_len] = (0 < k) ? 0 : 5;
+		if(!(0 < k)) E[(int64_t) pitch * (t_len - 1) + q_len] = 36;
+		if(k == 2) { for(int n = q_len; n >= 0; --n) { Dr[dp][n] = 0; Pr[dp][n] = low; Er[n] = 0; } }
+		else {
+			for(int n = q_len - 1; n >= 0; --n) { Dr[dp][n] = W1 + (q_len - 1 - n) * U; Pr[dp][n] = low; Er[n] = 3; }
+			Er[q_len - 1] = 18; Er[q_len] = 0; Dr[dp][q_len] = 0; Pr[dp][q_len] = 0;
+		}
+		int best_m = 0, npos = t_e - 1;
+		if(npos >= tlen_total) npos -= tlen_total;
+		for(int m = t_len - 1; m >= 0; --m, --npos) {
+			if(npos < 0) npos = tlen_total - 1;
+			uint8_t *e = E + (int64_t) pitch * m;
+			Dr[dc][q_len] = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			int Qprev = low;
+			const int tb = tn(ts, npos);
+			for(int n = q_len - 1; n >= 0; --n) {
+				int cell = 0, mv;
+				int Q = Dr[dc][n + 1] + W1, Pn = Dr[dp][n] + W1, D;
+				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int x = Qprev + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				x = Pr[dp][n] + U;
+				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+				const int qb = qn(q, q_s + n);
+				x = Dr[dp][n + 1] + sd[5 * tb + qb];
+				if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
+				Dr[dc][n] = D; Pr[dc][n] = Pn; e[n] = (uint8_t) cell; Qprev = Q;
+			}
+			if(k < 0 && score < Dr[dc][0]) { score = Dr[dc][0]; best_m = m; }
+			dc ^= 1; dp ^= 1;
+		}
+		int sm = 0, sn = 0;
+		if(k < 0) {
+			sm = best_m;
+			if(k == -2) for(int n = 0; n < q_len; ++n) if(score <= Dr[dp][n]) { score = Dr[dp][n]; sm = 0; sn = n; }
+		} else score = Dr[dp][0];
+		o_score = score; o_m = sm; o_n = sn; o_qpos = sn; o_pitch = pitch; o_dn = 0;
+		return true;
+	}
+	if(band & 1) ++band;
+	const int half = band >> 1, bq = band + 1, pitch = bq + 1;
+	if((int64_t) pitch * (t_len + 1) > e_cap || band + 4 > ncols) return false;
+	uint8_t *Er = E + (int64_t) pitch * t_len;
+	int c = (t_len + q_len) >> 1;
+	int sn = q_len - 1 - (c - half);
+	for(int n = 0; n <= bq; ++n) { Dr[0][n] = 0; Dr[1][n] = 0; Pr[0][n] = 0; Pr[1][n] = 0; }
+	if(k != 2) {
+		for(int n = sn - 1; n >= 0; --n) { Dr[dp][n] = W1 + (sn - n - 1) * U; Pr[dp][n] = low; Er[n] = 3; }
+		Er[sn - 1] = 18; Er[sn] = 0; Dr[dp][sn] = 0; Pr[dp][sn] = 0;
+	} else {
+		for(int n = sn; n >= 0; --n) { Dr[dp][n] = 0; Pr[dp][n] = low; Er[n] = 0; }
+	}
+	int bm = 0, bn = 0, en = 0, n = 0, npos = t_e - 1;
+	if(npos >= tlen_total) npos -= tlen_total;
+	for(int m = t_len - 1; m >= 0; --m, --npos, --c) {
+		if(npos < 0) npos = tlen_total - 1;
+		uint8_t *e = E + (int64_t) pitch * m;
+		int sq = c + half, eq = c - half;
+		if(eq < 0) { eq = 0; ++en; } else en = 0;
+		int Qprev = low;
+		if(sq < q_len - 1) { sn = bq - 1; Dr[dc][bq] = low; e[bq] = 37; }
+		else {
+			sq = q_len - 1; sn = en + (q_len - eq);
+			Dr[dc][sn] = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			e[sn] = (0 < k) ? 0 : 37;
+			--sn;
+		}
+		const int tb = tn(ts, npos);
+		int qp = sq;
+		for(n = sn; n > en; --qp, --n) {
+			int cell = 0, mv;
+			int Q = Dr[dc][n + 1] + W1, Pn = Dr[dp][n - 1] + W1, D;
+			if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+			int x = Qprev + U;
+			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+			x = Pr[dp][n - 1] + U;
+			if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+			const int qb = qn(q, q_s + qp);
+			x = Dr[dp][n] + sd[5 * tb + qb];
+			if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
+			Dr[dc][n] = D; Pr[dc][n] = Pn; e[n] = (uint8_t) cell; Qprev = Q;
+		}
+		{	// band edge: no template-gap state
+			int cell = 0, mv;
+			int Q = Dr[dc][n + 1] + W1, x = Qprev + U;
+			if(Q < x) { Q = x; mv = 3; } else { mv = 2; cell |= 16; }
+			Pr[dc][n] = low;
+			const int qb = qn(q, q_s + qp);
+			int D = Dr[dp][n] + sd[5 * tb + qb];
+			if(Q <= D) cell |= 1 | (tb != qb ? 64 : 0); else { D = Q; cell |= mv; }
+			Dr[dc][n] = D; e[n] = (uint8_t) cell;
+		}
+		if(eq == 0 && k < 0 && score < Dr[dc][n]) { score = Dr[dc][n]; bm = m; bn = n; }
+		dc ^= 1; dp ^= 1;
+	}
+	int q_pos = 0;
+	if(bm == 0) { bn = en; score = Dr[dp][en]; }
+	if(k == -2) for(n = en; n < bq; ++n) if(score <= Dr[dp][n]) { score = Dr[dp][n]; bm = 0; bn = n; q_pos = n - en; }
+	o_score = score; o_m = bm; o_n = bn; o_qpos = q_pos; o_pitch = pitch; o_dn = -1;
+	return true;
+}
+
+struct DpxLds {
+	int d[25];
+	uint8_t E[LT_XE_LDS];
+	uint8_t t[LT_XT_LDS];
+};
+
+#define LT_U(x) __builtin_amdgcn_readfirstlane(x)
+// the same value, but opaque to the compiler's uniformity analysis: what depends on it is kept in vector registers. These
+// kernels hold one problem per wavefront, so every problem field is wave-uniform and would be kept in scalar registers -- more of
+// them than there are, and the builds that spilled scalar registers (into lanes of a vector register) hung on gfx950.
+__device__ __forceinline__ int lt_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
+
+// one problem of class 4 + (banded ? 2 : 0) + (XW == 4) per wavefront. Everything outside the sweep is the same for every lane
+// (problem fields read wave-uniform, the walk run by all lanes in step): scalar branches only.
+template <int XW, bool banded>
+__global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
+	constexpr int cls = 4 + (banded ? 2 : 0) + (XW == 4 ? 1 : 0);
+	__shared__ DpxLds S;
+	const int lane = threadIdx.x;
+	if(lane < 25) S.d[lane] = A.d[lane];
+	wave_sync();
+	const unsigned long long count = A.counters[LC_CNT + cls];
+	const int32_t *queue = A.queue + (size_t) cls * A.prob_cap;
+	for(unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+		LtProb *P = A.prob + lt_vgpr(queue[idx]);
+		const int k = P->k, t_s = P->t_s, t_len = P->t_l, q_len = P->q_l, flags = P->flags;
+		int band = P->band;
+		if(lane == 0) { LT_REC(0, idx); LT_REC(1, 1); LT_REC(2, k); LT_REC(3, t_len); LT_REC(4, q_len); LT_REC(5, band); }
+		const int64_t r = A.r0 + P->read;
+		const int tt = A.tmpl ? A.tmpl[r] : lt_vgpr(A.tmpl_all);
+		const int at = abs(tt);
+		const int tlen_total = A.db.tlen[at];
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+		QView q;
+		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.rc = A.rd[P->read].rc;
+		q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+		if(band & 1) ++band;
+		const int pitch = banded ? band + 2 : q_len + 1;
+		const int64_t need = (int64_t) pitch * (t_len + 1);
+		int score = 0, sm = 0, sn = 0, q_pos = 0;
+		wave_sync();
+		for(int i = lane; i < t_len && i < LT_XT_LDS; i += 64) {
+			int pos = t_s + i;
+			if(pos >= tlen_total) pos -= tlen_total;
+			S.t[i] = (uint8_t) tn(ts, pos);
+		}
+		wave_sync();
+		lt_sweep_x<XW, banded>(A, S.d, P, q, S.E, S.t, ts, tlen_total, score, sm, sn, q_pos);
+		const uint8_t *E = (const uint8_t *) S.E;
+		if(lane == 0) {
+			LT_REC(1, 4);
+			RunOut R;
+			R.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = q_pos, bad = 0;
+			const int qend = lt_walk(E, pitch, sm, sn, banded ? -1 : 0, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, need, &bad);
+			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : R.n;
+			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
+			LT_REC(1, 5);
+		}
+	}
+	if(lane == 0) LT_REC(1, 99);
+}
+
+// class 8: what fits neither sweep, the reference's own formulation with rows and move matrix in the workgroup's HBM scratch. All
+// 64 lanes run the same instructions on the same addresses (uniform control flow; identical stores coalesce into one): it is one
+// lane's worth of work either way, and rare.
+__global__ __launch_bounds__(64) void lt_serial_kernel(const LtArgs A) {
+	__shared__ int s_d[25];
+	const int lane = threadIdx.x;
+	if(lane < 25) s_d[lane] = A.d[lane];
+	wave_sync();
+	const unsigned long long count = A.counters[LC_CNT + 8];
+	const int32_t *queue = A.queue + (size_t) 8 * A.prob_cap;
+	uint8_t *const xE = A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow);
+	int32_t *const xrows = (int32_t *) (xE + A.xe_cap);
+	for(unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
+		LtProb *P = A.prob + LT_U(queue[idx]);
+		LtProb Pu;      // the problem, wave-uniform
+		Pu.runs = P->runs; Pu.read = LT_U(P->read); Pu.t_s = LT_U(P->t_s); Pu.t_l = LT_U(P->t_l); Pu.q_s = LT_U(P->q_s); Pu.q_l = LT_U(P->q_l);
+		Pu.k = LT_U(P->k); Pu.band = LT_U(P->band); Pu.flags = LT_U(P->flags);
+		const int k = Pu.k, t_len = Pu.t_l, q_len = Pu.q_l, flags = Pu.flags;
+		const int64_t r = A.r0 + Pu.read;
+		const int tt = A.tmpl ? LT_U(A.tmpl[r]) : A.tmpl_all;
+		const int at = abs(tt);
+		const int tlen_total = LT_U(A.db.tlen[at]);
+		const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+		QView q;
+		q.w = A.seq + A.seq_off[r]; q.L = LT_U(A.len[r]); q.rc = LT_U(A.rd[Pu.read].rc);
+		q.N = A.N + A.N_off[r]; q.nN = LT_U((int) (A.N_off[r + 1] - A.N_off[r]));
+		int score = 0, sm = 0, sn = 0, q_pos = 0, wpitch = 0, dn = 0;
+		const bool ok = lt_serial(A, s_d, &Pu, q, ts, tlen_total, xE, A.xe_cap, xrows, A.xrow, score, sm, sn, q_pos, wpitch, dn);
+		wave_sync_hbm();
+		if(!LT_U((int) ok)) {
+			if(lane == 0) { atomicMax(&A.counters[LC_STATUS], 8ull); P->score = 0; P->n_runs = 0; P->clip = 0; P->flags |= PF_NONE; }
+		} else {
+			RunOut R;
+			R.init(A.runs + Pu.runs, t_len + q_len + 1, lane == 0);
+			int clip = q_pos, bad = 0;
+			const int qend = lt_walk((const uint8_t *) xE, wpitch, sm, sn, dn, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) wpitch * (t_len + 1), &bad);
+			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(lane == 0) {
+				if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+				P->score = score; P->n_runs = bad ? 0 : R.n;
+				P->clip = (k > 0) ? (q_len - qend + cut) : clip;
+			}
+		}
+	}
+}
+
+// ---- per read: the runs of its problems and MEMs in chain order, merged; alignment figures; the read filter of assemble_KMA
+// (assembly.c:1931-1961: + Wl for an alignment that starts at the first / ends at the last template base, minlen, mrc, scoreT)
+__global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
+	const int lane = threadIdx.x;
+	uint32_t *const tmp = A.tmp + (size_t) blockIdx.x * A.tmp_cap;
+	for(int64_t rr = blockIdx.x; rr < A.n_reads; rr += gridDim.x) {
+		const int64_t r = A.r0 + rr;
+		const LtRead H = A.rd[rr];
+		if(lane == 0) {
+			for(int x = 0; x < 10; ++x) A.o_stats[10 * r + x] = 0;
+			A.o_off[r] = 0; A.o_nops[r] = 0;
+			if(A.o_rc) A.o_rc[r] = H.rc;
+		}
+		if(!H.status) continue;
+		const int q_len = A.len[r];
+		const int tt = A.tmpl ? A.tmpl[r] : A.tmpl_all;
+		const int t_len = A.db.tlen[abs(tt)];
+		// ---- phase A: every problem's runs (+ the MEM behind it) into one list ----
+		int n_ent = 0, score = 0, lead_cols = 0, lead_clip = 0, trail_clip = 0;
+		bool over = false;
+		for(int b = 0; b < H.n_prob; b += 64) {
+			const int l = b + lane;
+			int cnt = 0, fl = PF_NONE, nr = 0, body = 0, deg_len = 0, sc = 0;
+			int64_t src = 0;
+			if(l < H.n_prob) {
+				const LtProb *P = A.prob + H.first + l;
+				fl = P->flags; body = P->body; src = P->runs;
+				sc = P->body_score;
+				if(fl & PF_NONE) nr = 0;
+				else if(fl & (PF_DEGEN_I | PF_DEGEN_D)) { nr = 1; deg_len = (fl & PF_DEGEN_I) ? P->q_l : P->t_l; sc += A.W1 + (deg_len - 1) * A.U; }
+				else {
+					nr = P->n_runs; sc += P->score;
+					if(l == 0) lead_clip = P->clip;
+					if(l == H.n_prob - 1) trail_clip = P->clip;
+				}
+				cnt = nr + (body > 0 ? 1 : 0);
+			}
+			const int incl = wave_scan_incl(cnt, lane);
+			const int tot = __shfl(incl, 63);
+			int o = n_ent + incl - cnt;
+			if((int64_t) n_ent + tot > A.tmp_cap) { over = true; break; }
+			if(fl & (PF_DEGEN_I | PF_DEGEN_D)) tmp[o++] = ((uint32_t) deg_len << 2) | ((fl & PF_DEGEN_I) ? 2u : 3u);
+			else for(int x = 0; x < nr; ++x) {
+				const uint32_t e = A.runs[src + x];
+				tmp[o++] = e;
+				if(l == 0 && (e & 3u) != 2u) lead_cols += (int) (e >> 2);
+			}
+			if(body > 0) tmp[o++] = (uint32_t) body << 2;
+			score += sc;
+			n_ent += tot;
+		}
+		if(over) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 9ull); continue; }
+		score = wave_sum(score);
+		lead_cols = __shfl(lead_cols, 0); lead_clip = __shfl(lead_clip, 0);
+		trail_clip = __shfl(trail_clip, (H.n_prob - 1) & 63);
+		wave_sync_hbm();
+		// ---- phase B: neighbours of one class merge; two passes (count, then write) ----
+		int n_merged = 0, cols[4] = {0, 0, 0, 0};
+		for(int c0 = 0; c0 < n_ent; c0 += 64) {
+			const bool valid = c0 + lane < n_ent;
+			const uint32_t e = valid ? tmp[c0 + lane] : 0u;
+			int pc = __shfl_up((int) (e & 3u), 1);
+			if(lane == 0) pc = c0 ? (int) (tmp[c0 - 1] & 3u) : -1;
+			n_merged += __popcll(__ballot(valid && (int) (e & 3u) != pc));
+			if(valid) cols[e & 3u] += (int) (e >> 2);
+		}
+		const int match = wave_sum(cols[0] + cols[1]), tGaps = wave_sum(cols[2]), qGaps = wave_sum(cols[3]);
+		const int aln_len = match + tGaps + qGaps;
+		// the filter
+		const int start = H.pos0 - lead_cols;
+		int end = start + aln_len - tGaps;
+		if(t_len < end) end -= t_len;
+		int read_score = score;
+		if(start == 0) read_score += A.Wl;
+		if(end == t_len) read_score += A.Wl;
+		double norm = 0;
+		if(A.minlen <= aln_len && ((A.mrc * q_len <= aln_len - qGaps) || (A.mrc * t_len <= aln_len - tGaps))) norm = 1.0 * read_score / aln_len;
+		else read_score = 0;
+		if(!(0 < read_score && A.scoreT <= norm)) continue;
+		unsigned long long ob = 0;
+		if(lane == 0) ob = atomicAdd(A.ops_top, (unsigned long long) n_merged);
+		ob = __shfl(ob, 0);
+		if((int64_t) ob + n_merged > A.ops_cap) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 2ull); continue; }
+		uint32_t *out = A.ops + ob;
+		int w = 0, carry_cls = -1, carry_len = 0;
+		for(int c0 = 0; c0 < n_ent; c0 += 64) {
+			const bool valid = c0 + lane < n_ent;
+			const uint32_t e = valid ? tmp[c0 + lane] : 0u;
+			const int cls = (int) (e & 3u), len = valid ? (int) (e >> 2) : 0;
+			int pc = __shfl_up(cls, 1);
+			if(lane == 0) pc = carry_cls;
+			const bool st = valid && cls != pc;
+			const unsigned long long sm = __ballot(st);
+			const int incl = wave_scan_incl(len, lane);
+			const int before = incl - len;                       // columns of this round in front of the lane
+			// a lane that opens a run closes the one before it (the shuffles are executed by all lanes)
+			const unsigned long long lower = sm & ((1ull << lane) - 1ull);
+			const int a = lower ? 63 - __clzll((long long) lower) : 0;
+			const int before_a = __shfl(before, a);
+			const int cls_a = __shfl(cls, a);
+			if(st) {
+				const int j = __popcll(lower);
+				if(lower) out[w + j - (carry_cls < 0 ? 1 : 0)] = ((uint32_t) (before - before_a) << 2) | (uint32_t) cls_a;
+				else if(carry_cls >= 0) out[w] = ((uint32_t) (carry_len + before) << 2) | (uint32_t) carry_cls;
+			}
+			const int total = __shfl(incl, 63);
+			if(sm) {
+				const int last = 63 - __clzll((long long) sm);
+				w += __popcll(sm) - (carry_cls < 0 ? 1 : 0);
+				carry_cls = __shfl(cls, last);
+				carry_len = total - __shfl(before, last);
+			} else carry_len += total;
+		}
+		if(lane == 0 && carry_cls >= 0) out[w] = ((uint32_t) carry_len << 2) | (uint32_t) carry_cls;
+		if(lane == 0) {
+			int32_t *st = A.o_stats + 10 * r;
+			st[0] = read_score; st[1] = start; st[2] = (t_len < end) ? end - t_len : end; st[3] = aln_len;
+			st[4] = H.clip0 + lead_clip; st[5] = q_len - H.qe_trail + trail_clip;
+			st[6] = match; st[7] = tGaps; st[8] = qGaps; st[9] = H.mapQ;
+			A.o_off[r] = (int64_t) ob; A.o_nops[r] = n_merged;
+		}
+	}
+}
+
+} // namespace
+
+static int lt_reserve(kmahip_ws *ws, int slot, size_t bytes) {
+	if(ws->lt_bytes[slot] >= bytes) return KMAHIP_OK;
+	(void) hipFree(ws->lt_buf[slot]);
+	ws->lt_buf[slot] = nullptr; ws->lt_bytes[slot] = 0;
+	if(hipMalloc(&ws->lt_buf[slot], bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes (long-read trace scratch) failed", bytes); return KMAHIP_ENOMEM; }
+	ws->lt_bytes[slot] = bytes;
+	return KMAHIP_OK;
+}
+
+// The pipeline over a device-resident batch, in passes of about 4e8 bases (the pools of a pass: one descriptor per chain join,
+// one run slot word per DP column at most). tmpl == NULL: every read against tmpl_all. rc_in == NULL: both strands are seeded
+// and anker_rc decides (`-Mt1`), else the orientation is given. rc_out (may be NULL): the strand that was aligned.
+int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *tmpl, int tmpl_all, const int32_t *rc_in,
+                            const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	if(n < 0 || !p || !out || !out->stats || !out->ops_off || !out->n_ops || (out->ops_cap > 0 && !out->ops)) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
+	if(!db->dev.tpos_slots) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
+	if(!tmpl && (tmpl_all < 1 || (uint32_t) tmpl_all >= db->info.DB_size)) { kmahip_set_error("template %d out of range", tmpl_all); return KMAHIP_EINVAL; }
+	if(n == 0) return KMAHIP_OK;
+	const int max_len = reads->max_len;
+	if(max_len <= 0 || max_len > (1 << 24)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^24) for the trace stage"); return KMAHIP_EINVAL; }
+	const int seed_wgs = 2048, fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
+	const int mcap = std::max(1024, max_len / 8 + 256);
+	const int64_t tmp_cap = 4ll * max_len + 1024;
+	const int64_t xe_cap = 2ll << 20;
+	const int xrow = max_len + 72;
+	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
+	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
+	int rc;
+	if((rc = lt_reserve(ws, 0, (size_t) seed_wgs * 7 * mcap * 4)) || (rc = lt_reserve(ws, 5, (size_t) fin_wgs * tmp_cap * 4)) ||
+	   (rc = lt_reserve(ws, 6, (size_t) dpx_wgs * ((size_t) xe_cap + 16 * (size_t) xrow))) || (rc = lt_reserve(ws, 7, (LC_N + 1) * 8))) return rc;
+	unsigned long long *counters = (unsigned long long *) ws->lt_buf[7];
+	HIP_TRY(hipMemsetAsync(counters, 0, (LC_N + 1) * 8, stream));
+	LtArgs A;
+	A.db = db->dev;
+	A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.tmpl = tmpl; A.rc_in = rc_in; A.tmpl_ok = tmpl_ok; A.tmpl_all = tmpl_all; A.one2one = one2one; A.exhaustive = p->exhaustive;
+	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
+	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
+	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
+	A.mem = (int32_t *) ws->lt_buf[0]; A.mcap = mcap;
+	A.tmp = (uint32_t *) ws->lt_buf[5]; A.tmp_cap = tmp_cap;
+	A.xE = (uint8_t *) ws->lt_buf[6]; A.xe_cap = xe_cap; A.xrow = xrow;
+	A.counters = counters;
+	A.o_stats = out->stats; A.o_off = out->ops_off; A.o_nops = out->n_ops; A.ops = out->ops; A.ops_cap = out->ops_cap;
+	A.ops_top = counters + LC_OUT; A.o_rc = rc_out;
+	A.rec = nullptr;
+	if(getenv("KMAHIP_DEBUG_TIMING")) {
+		static uint32_t *rec = nullptr;
+		if(!rec && hipHostMalloc((void **) &rec, 2048 * 16 * 4, hipHostMallocMapped) != hipSuccess) rec = nullptr;
+		if(rec) { memset(rec, 0, 2048 * 16 * 4); uint32_t *drec = nullptr; if(hipHostGetDevicePointer((void **) &drec, rec, 0) == hipSuccess) A.rec = drec; }
+	}
+	for(int64_t r0 = 0; r0 < n;) {
+		const int64_t nb = std::min<int64_t>(B, n - r0);
+		if((rc = lt_reserve(ws, 1, (size_t) B * sizeof(LtRead))) || (rc = lt_reserve(ws, 2, (size_t) prob_cap * sizeof(LtProb))) ||
+		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4))) return rc;
+		A.r0 = r0; A.n_reads = nb;
+		A.rd = (LtRead *) ws->lt_buf[1]; A.prob = (LtProb *) ws->lt_buf[2]; A.prob_cap = prob_cap;
+		A.runs = (uint32_t *) ws->lt_buf[3]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[4];
+		HIP_TRY(hipMemsetAsync(counters, 0, LC_OUT * 8, stream));
+		if(getenv("KMAHIP_DEBUG_TIMING")) { fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: seeding (prob_cap %lld, runs_cap %lld)\n", (long long) r0, (long long) nb, (long long) prob_cap, (long long) runs_cap); fflush(stderr); }
+		hipLaunchKernelGGL(lt_seed_kernel, dim3((unsigned) std::min<int64_t>(seed_wgs, nb)), dim3(64), 0, stream, A);
+		unsigned long long c[LC_N];
+		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		if(c[LC_STATUS] == 5 || c[LC_STATUS] == 6) {
+			// a pool of the pass ran out: larger pools (or a smaller pass), same reads again
+			if(c[LC_STATUS] == 5) prob_cap = std::max<int64_t>(2 * prob_cap, (int64_t) c[LC_PROB] + 1024);
+			else runs_cap = std::max<int64_t>(2 * runs_cap, (int64_t) c[LC_RUNS] + 1024);
+			if(prob_cap * (int64_t) sizeof(LtProb) > (48ll << 30) || runs_cap * 4 > (96ll << 30)) { kmahip_set_error("long-read trace: pools of a pass beyond 96 GB"); return KMAHIP_ENOMEM; }
+			continue;
+		}
+		if(c[LC_STATUS] == 3) { kmahip_set_error("seed (MEM) capacity per read exceeded (%d MEMs)", mcap); return KMAHIP_EOVERFLOW; }
+		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+		auto stage = [&](const char *what) {
+			if(!dbg) return;
+			if(A.rec) {
+				// a kernel that does not come back within 15 s: dump the recorder and give up (the process must not sit on a hung GPU)
+				for(int ms = 0; hipStreamQuery(stream) == hipErrorNotReady; ms += 10) {
+					struct timespec ts = {0, 10000000};
+					nanosleep(&ts, nullptr);
+					if(ms < 4000) continue;
+					fprintf(stderr, "[kmahip] longtrace: %s does not finish; recorder of the workgroups still busy:\n", what);
+					int shown = 0, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+					for(int wg = 0; wg < 1024; ++wg) { const volatile uint32_t *rr = A.rec + (size_t) wg * 16; hist[rr[1] == 99 ? 6 : (rr[1] < 6 ? rr[1] : 7)]++; }
+					fprintf(stderr, "  phase histogram (0 idle, 1 got problem, 2 coop, 3 serial, 4 swept, 5 walked, 99 exited, other): %d %d %d %d %d %d %d %d\n", hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+					for(int wg = 0; wg < 2048 && shown < 12; ++wg) {
+						const volatile uint32_t *rr = A.rec + (size_t) wg * 16;
+						if(rr[1] == 99 || (rr[1] == 0 && rr[11] == 0)) continue;
+						fprintf(stderr, "  wg %d:", wg);
+						for(int x = 0; x < 16; ++x) fprintf(stderr, " %d", (int) rr[x]);
+						fprintf(stderr, "\n");
+						++shown;
+					}
+					fflush(stderr);
+					_exit(3);
+				}
+			}
+			const hipError_t e = hipStreamSynchronize(stream);
+			fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: %s done (%s)\n", (long long) r0, (long long) nb, what, hipGetErrorString(e));
+			fflush(stderr);
+		};
+		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
+		                  c[LC_CNT], c[LC_CNT + 1], c[LC_CNT + 2], c[LC_CNT + 3], c[LC_CNT + 4], c[LC_CNT + 5], c[LC_CNT + 6], c[LC_CNT + 7], c[LC_CNT + 8]); fflush(stderr); }
+		// grids follow the queue lengths: 4 wavefronts per workgroup of lt_dp_kernel, 64 / W problems per wavefront round
+		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LC_CNT + cls] + per_wg - 1) / per_wg)); };
+		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
+		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
+		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
+		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
+		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full>"); }
+		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full>"); }
+		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded>"); }
+		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded>"); }
+		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, stream, A); stage("serial"); }
+		hipLaunchKernelGGL(lt_finish_kernel, dim3((unsigned) std::min<int64_t>(fin_wgs, nb)), dim3(64), 0, stream, A);
+		stage("finish");
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		if(c[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
+		if(c[LC_STATUS] == 8 || c[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", c[LC_STATUS]); return KMAHIP_EDEVICE; }
+		r0 += nb;
+	}
+	// the caller reads the pool top through the workspace counters like after trace_kernel: [0] = runs used, [1] = status
+	unsigned long long fin[2] = {0, 0};
+	HIP_TRY(hipMemcpy(&fin[0], counters + LC_OUT, 8, hipMemcpyDeviceToHost));
+	if((int64_t) fin[0] > out->ops_cap) fin[1] = 2;
+	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
+	HIP_TRY(hipMemcpy(ws->counters, fin, sizeof fin, hipMemcpyHostToDevice));
+	return KMAHIP_OK;
+}
