@@ -321,6 +321,22 @@ int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                         const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out);
 
+/* kmahip_assemble with the knobs of the other stage-3c flavours: order 1 = pile the reads up in stream order (what the single
+ * reading thread of `-Mt1` does, assembly.c:1873-1965) instead of ConClave's per-template order; caller 1 = nanoCaller
+ * (assembly.c:205-240) and sig90 1 = significantAnd90Nuc (assembly.c:147-149), the pair `-bcNano` selects (kma.c:762-766). */
+typedef struct kmahip_assemble_opts {
+	int64_t max_frag;   /* <= 0: 1000000 */
+	double evalue;      /* -e, 0.05 */
+	int32_t bcd;        /* -bcd, 1 */
+	int32_t order;      /* 0 ConClave's order, 1 stream order */
+	int32_t caller;     /* 0 baseCaller, 1 nanoCaller */
+	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc */
+} kmahip_assemble_opts;
+int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                     const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out);
+int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                         const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out);
+
 /* The whole single-end `-1t1` run on one batch, one call: reads uploaded ONCE, stage 2, stage 3a, ConClave, the `.res`
  * statistics, the traceback aligner and the pile-up all on what is already in HBM; only the per-template results (and, if
  * asked for, the per-read columns a `.frag.gz` / SAM writer needs) come back. Equivalent to kmahip_map_se +
@@ -339,6 +355,15 @@ typedef struct kmahip_run {
 } kmahip_run;
 int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
                   int64_t max_frag, kmahip_run *out);
+
+/* The `-Mt1 tmpl` run on one batch (runKMA_Mt1, mt1.c:86-500): raw reads uploaded once, kmahip_align_trace_mt1 per read, the
+ * pile-up in stream order and the consensus, all on the device. HOST buffers. aopts: evalue, bcd, caller / sig90 (`-bcNano` = 1, 1);
+ * order is stream order whatever aopts says. Out: rows[0] (n_rows = 1) = the `.res` figures of mt1.c:425-447: Score = summed KMA()
+ * scores of the kept reads, Expected 0, q_value = Score, p_value = p_chisqr(Score), significant = the reference's gate for printing
+ * the row with its identity columns; assembly as kmahip_assemble; tmpl[i] = tmpl for the reads that were kept, n_hits[i] = 1,
+ * rc[i] = strand, trace_stats as kmahip_traces.stats -- what kmahip_frag_write2 (order 1) takes. */
+int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                   const kmahip_assemble_opts *aopts, kmahip_run *out);
 
 /* One `.res` row exactly as runKMA prints it (runkma.c:809) from kmahip_res_rows + kmahip_assemble; returns the number of
  * characters written, 0 when the reference prints no row for the template (nothing covered, identity below -ID (1.0) or
@@ -396,6 +421,11 @@ void kmahip_ingest_close(kmahip_ingest *in);
 int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                       const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, const char *read_names,
                       const int64_t *read_name_off, int64_t *rows);
+
+/* kmahip_frag_write with the row order chosen: order 0 = as above, 1 = stream order inside a template (`-Mt1`) */
+int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                       const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const char *read_names,
+                       const int64_t *read_name_off, int64_t *rows);
 
 /* The paired run (`-ipe r1 r2 -apm p -1t1`) on one batch as kmahip_ingest_next hands it over for two mate files: reads in
  * stream order, batch->pair[i] = 1 / 2 for the mates of a pair record, 0 for a record that lost its mate to the trimming.

@@ -79,6 +79,10 @@ class ReadBatchC(C.Structure):
     _fields_ = [("reads", Reads), ("names", C.c_void_p), ("name_off", C.c_void_p), ("pair", C.c_void_p), ("records", C.c_int64)]
 
 
+class AssembleOpts(C.Structure):
+    _fields_ = [("max_frag", C.c_int64), ("evalue", C.c_double), ("bcd", C.c_int32), ("order", C.c_int32), ("caller", C.c_int32), ("sig90", C.c_int32)]
+
+
 class Run(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_cap", C.c_int64), ("n_rows", C.c_int64), ("assembly", Assembly),
                 ("tmpl", C.c_void_p), ("n_hits", C.c_void_p), ("rc", C.c_void_p), ("trace_stats", C.c_void_p), ("ms", C.c_double * 6)]
@@ -168,6 +172,11 @@ def lib():
         L.kmahip_run_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.POINTER(Run)]
         L.kmahip_run_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.c_char_p,
                                     C.POINTER(Run)]
+        L.kmahip_run_mt1.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_int, C.POINTER(Params), C.POINTER(AssembleOpts), C.POINTER(Run)]
+        L.kmahip_assemble2.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.POINTER(Traces), C.POINTER(AssembleOpts),
+                                       C.POINTER(Assembly)]
+        L.kmahip_frag_write2.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
         L.kmahip_trim_default.restype = None
         L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
@@ -587,6 +596,60 @@ class KmaHipDB:
             o[k] = v[:n * 10].reshape(n, 10) if k == "trace_stats" else v[:n]
         o["ms"] = list(run.ms)
         return o
+
+    def run_mt1(self, batch, tmpl, one2one=0, bc_nano=True, evalue=0.05, bcd=1, consensus=True):
+        """The `-Mt1 tmpl [-bcNano]` run in one call (kmahip_run_mt1) -> dict(row, cover, aln_len, depth, asm_len, consensus, tmpl, n_hits,
+        rc, trace_stats, ms)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        D = int(self.info.DB_size)
+        o = dict(cover=np.zeros(D, np.int64), aln_len=np.zeros(D, np.int64), depth=np.zeros(D, np.int64), asm_len=np.zeros(D, np.int64))
+        cap = 0
+        cbuf = coff = None
+        if consensus:
+            cap = int(2 * np.fromfile(self.prefix + ".length.b", dtype=np.int32)[1:].astype(np.int64).sum() + 4 * D + (1 << 20))
+            cbuf = np.zeros(cap, np.uint8)
+            coff = np.full(D, -1, np.int64)
+        rows = (ResRow * 1)()
+        pr = {k: np.zeros(max(1, n) * (10 if k == "trace_stats" else 1), np.int32) for k in ("tmpl", "n_hits", "rc", "trace_stats")}
+        run = Run(C.cast(rows, C.c_void_p), 1, 0,
+                  Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), None if cbuf is None else _p(cbuf),
+                           None if coff is None else _p(coff), cap, 0),
+                  *[_p(pr[k]) for k in ("tmpl", "n_hits", "rc", "trace_stats")])
+        p = Params.from_buffer_copy(self.params)
+        ao = AssembleOpts(0, float(evalue), int(bcd), 1, 1 if bc_nano else 0, 1 if bc_nano else 0)
+        _check(lib().kmahip_run_mt1(self.h, self.ws, C.byref(r), int(tmpl), int(one2one), C.byref(p), C.byref(ao), C.byref(run)))
+        o["row"] = rows[0]
+        if consensus:
+            raw = cbuf.tobytes()
+            o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
+        for k, v in pr.items():
+            o[k] = v[:n * 10].reshape(n, 10) if k == "trace_stats" else v[:n]
+        o["ms"] = list(run.ms)
+        return o
+
+    def frag_write2(self, path, batch, rc, tmpl, n_hits, stats, read_names, order=1, max_frag=0):
+        """kmahip_frag_write2: order 1 = stream order (`-Mt1`)"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        fl = np.ascontiguousarray(rc if n else np.zeros(1, np.int32), np.int32)
+        tm = np.ascontiguousarray(tmpl if n else np.zeros(1, np.int32), np.int32)
+        nh = np.ascontiguousarray(n_hits if n else np.zeros(1, np.int32), np.int32)
+        st = np.ascontiguousarray(stats if n else np.zeros((1, 10), np.int32), np.int32)
+        blob = b"".join(nm + b"\0" for nm in read_names) + b"\0"
+        noff = np.zeros(n + 1, np.int64)
+        if n:
+            noff[1:] = np.cumsum([len(nm) + 1 for nm in read_names])
+        rows = C.c_int64()
+        _check(lib().kmahip_frag_write2(os.fsencode(path), self.h, C.byref(r), _p(fl), _p(tm), _p(nh), _p(st), int(max_frag), int(order), blob,
+                                        _p(noff), C.byref(rows)))
+        return rows.value
 
     def run_pe(self, batch, names, pair, evalue=0.05, bcd=1, max_frag=0, frag_path=None):
         """The paired run in one call (kmahip_run_pe) on what Ingest.next returned for two mate files -> dict(rows, cover, aln_len,

@@ -37,6 +37,7 @@ struct PileArgs {
 	const int32_t *n_ops;
 	const uint32_t *ops;
 	int64_t max_frag;
+	int order;                   // 0: ConClave's order (chunks of max_frag, each back to front), 1: stream order (`-Mt1`)
 	int64_t *rank;               // per read: number of filed fragments before it in the stream
 	// sorted work list
 	uint64_t *keys;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
 	// rank among the fragments ConClave filed (conclave.c:166, 194) -> chunk of max_frag, reverse order inside the chunk
 	const int64_t rk = A.rank[r];
 	const uint64_t chunk = (uint64_t) (rk / A.max_frag), in = (uint64_t) (rk % A.max_frag);
-	const uint64_t ord = chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
+	const uint64_t ord = A.order ? (uint64_t) rk : chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
 	const unsigned long long slot = base + (unsigned long long) __popcll(m & ((1ull << lane) - 1ull));
 	A.keys[slot] = (t << 40) | ord;
 	A.vals[slot] = (int32_t) r;
@@ -381,6 +382,8 @@ struct ConsArgs {
 	const int32_t *seg_start;
 	int64_t n_kept;
 	int bcd;
+	int caller;                  // 0 baseCaller, 1 nanoCaller (-bcNano, assembly.c:205-240)
+	int sig90;                   // significantAnd90Nuc instead of significantNuc (-bcNano, assembly.c:147-149)
 	double qstar;
 	unsigned long long *cover, *aln_len, *depth, *asm_len;      // per template
 	char *cons;                  // pass 2: consensus characters
@@ -389,7 +392,7 @@ struct ConsArgs {
 
 __device__ __forceinline__ unsigned char dev_lower(unsigned char c) { return (c >= 'A' && c <= 'Z') ? (unsigned char) (c + 32) : c; }
 
-__device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd, double qstar, long long *depth_out) {
+__device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd, double qstar, int caller, int sig90, long long *depth_out) {
 	const char bases[7] = {'A', 'C', 'G', 'T', 'N', '-', 0};
 	int cnt[6];
 	for(int j = 0; j < 6; ++j) cnt[j] = (int) min(c32[j], 65535u);
@@ -414,10 +417,16 @@ __device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd,
 	if(depthUpdate == 0) call = '-';
 	else {
 		const int X = bestScore, Y = (int) depthUpdate - bestScore;
-		const bool sig = Y < X && ((double) ((long long) (X - Y) * (X - Y)) / (double) (X + Y)) >= qstar;
+		const bool sig = Y < X && (!sig90 || 9ll * (X + Y) <= 10ll * X) && ((double) ((long long) (X - Y) * (X - Y)) / (double) (X + Y)) >= qstar;
 		if(!sig) {
-			if(call == '-' && tch != '-' && bestScore != depthUpdate) call = 'n';
-			else call = dev_lower(call);
+			if(call == '-' && tch != '-' && bestScore != depthUpdate) {
+				if(caller == 1) {
+					// nanoCaller: the best base count (N included) decides; first of equals
+					int bb = 0, b = -1;
+					for(int j = 0; j < 5; ++j) if(bb < cnt[j]) { bb = cnt[j]; b = j; }
+					call = bb == 0 ? (unsigned char) '-' : dev_lower((unsigned char) bases[b]);
+				} else call = 'n';
+			} else call = dev_lower(call);
 		}
 	}
 	*depth_out = depthUpdate;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 				int64_t o = running + incl - items;
 				const int tnuc = (int) ((ts[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
 				long long dep = 0;
-				unsigned char call = call_column_dev(C.counts + (size_t) (base + p) * 6, tnuc, C.bcd, C.qstar, &dep);
+				unsigned char call = call_column_dev(C.counts + (size_t) (base + p) * 6, tnuc, C.bcd, C.qstar, C.caller, C.sig90, &dep);
 				if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
 				++o;
 				if(call != '-') {
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 				}
 				const int np = (p + 1 == t_len) ? 0 : p + 1;
 				for(int h = C.chain_head[base + np]; h; h = C.nodes[h - 1].next) {
-					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, &dep);
+					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, C.caller, C.sig90, &dep);
 					if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
 					++o;
 					if(call != '-') { depth += (unsigned long long) dep; ++aln; }
@@ -525,7 +534,7 @@ static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64
 
 // device part: counts / chains of every template with kept reads. All pointers are device pointers.
 static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
-                         const kmahip_traces *tr, int64_t max_frag, hipStream_t stream) {
+                         const kmahip_traces *tr, int64_t max_frag, int order, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
 	const int64_t node_cap = std::max<int64_t>(1 << 20, n);
 	int rc = assemble_scratch(db, ws, std::max<int64_t>(n, 1), node_cap);
@@ -539,6 +548,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.flag = flag; A.tmpl = tmpl; A.stats = tr->stats; A.ops_off = tr->ops_off; A.n_ops = tr->n_ops; A.ops = tr->ops;
 	A.max_frag = max_frag > 0 ? max_frag : 1000000;
+	A.order = order;
 	A.keys = ws->p_keys; A.vals = ws->p_vals; A.counters = ws->counters;
 	A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.node_cap = node_cap; A.seg_start = ws->p_seg;
 	A.lds_node_limit = getenv("KMAHIP_PILE_LDS_NODES") ? atoi(getenv("KMAHIP_PILE_LDS_NODES")) : 1 << 30;
@@ -656,8 +666,9 @@ static double asm_p_chisqr(long double q) {      // stdstat.c:136-147
 	if(q > 49) return asm_chi2_table(q);
 	return 1 - 1.772453850 * erf(sqrt((double) (0.5 * q))) / tgamma(0.5);
 }
-static int significant_nuc(int X, int Y, double evalue) {   // significantNuc, assembly.c:143-145
+static int significant_nuc(int X, int Y, double evalue, int sig90 = 0) {   // significantNuc / significantAnd90Nuc, assembly.c:143-149
 	if(!(Y < X)) return 0;
+	if(sig90 && !(9ll * (X + Y) <= 10ll * X)) return 0;
 	// a pure function of (X, Y, evalue): memoised, most columns of a pile-up repeat a handful of (X, Y) pairs
 	struct Slot { uint64_t key; double ev; int val; };
 	static thread_local std::vector<Slot> memo(1 << 16, Slot{~0ull, 0.0, 0});
@@ -670,7 +681,7 @@ static int significant_nuc(int X, int Y, double evalue) {   // significantNuc, a
 }
 
 // one column: callConsensus body + baseCaller (assembly.c:1543-1595, 162-179); counts already clamped to 16 bit
-static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, int bcd, double evalue, long *depth_out) {
+static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, int bcd, double evalue, int caller, int sig90, long *depth_out) {
 	static const char bases[] = "ACGTN-";
 	int bestNuc = tnuc;
 	const char tch = bases[tnuc];
@@ -691,9 +702,14 @@ static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, i
 		bestScore = (int) (depthUpdate - cnt[5]);
 	} else if(depthUpdate < bcd) call = (unsigned char) tolower(call);
 	if(depthUpdate == 0) call = '-';
-	else if(significant_nuc(bestScore, (int) depthUpdate - bestScore, evalue) == 0) {
-		if(call == '-' && tch != '-' && bestScore != depthUpdate) call = 'n';
-		else call = (unsigned char) tolower(call);
+	else if(significant_nuc(bestScore, (int) depthUpdate - bestScore, evalue, sig90) == 0) {
+		if(call == '-' && tch != '-' && bestScore != depthUpdate) {
+			if(caller == 1) {
+				int bb = 0, b = -1;
+				for(int j = 0; j < 5; ++j) if(bb < (int) cnt[j]) { bb = (int) cnt[j]; b = j; }
+				call = bb == 0 ? (unsigned char) '-' : (unsigned char) tolower(bases[b]);
+			} else call = 'n';
+		} else call = (unsigned char) tolower(call);
 	}
 	*depth_out = depthUpdate;
 	return call;
@@ -703,6 +719,19 @@ namespace { struct DevGuard { std::vector<void *> v; ~DevGuard() { for(void *p :
 
 extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                                const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
+	kmahip_assemble_opts o = {max_frag, evalue, bcd, 0, 0, 0};
+	return kmahip_assemble2(db, ws, reads, flag, tmpl, traces, &o, out);
+}
+
+extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *d_flag, const int32_t *d_tmpl,
+                                   const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
+	kmahip_assemble_opts o = {max_frag, evalue, bcd, 0, 0, 0};
+	return kmahip_assemble2_dev(db, ws, reads, d_flag, d_tmpl, traces, &o, out);
+}
+
+extern "C" int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
+                                const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out) {
+	if(!opts) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	if(!db || !ws || !reads || !flag || !tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	const int64_t n = reads->n_reads;
 	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
@@ -739,12 +768,16 @@ extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads 
 	   (rc = up(flag, (size_t) n * 4, (void **) &d_flag)) || (rc = up(tmpl, (size_t) n * 4, (void **) &d_tmpl)) ||
 	   (rc = up(traces->stats, (size_t) n * 40, (void **) &dt.stats)) || (rc = up(traces->ops_off, (size_t) n * 8, (void **) &dt.ops_off)) ||
 	   (rc = up(traces->n_ops, (size_t) n * 4, (void **) &dt.n_ops)) || (rc = up(traces->ops, (size_t) total_ops * 4, (void **) &dt.ops))) return rc;
-	return kmahip_assemble_dev(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, bcd, evalue, out);
+	return kmahip_assemble2_dev(db, ws, &d, d_flag, d_tmpl, &dt, opts, out);
 }
 
 // the same with the per-read inputs already in HBM (reads, rc, tmpl, traces: DEVICE pointers; `out`: host)
-extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *d_flag, const int32_t *d_tmpl,
-                                   const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {
+extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *d_flag, const int32_t *d_tmpl,
+                                    const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out) {
+	if(!opts) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t max_frag = opts->max_frag;
+	const int bcd = opts->bcd, caller = opts->caller, sig90 = opts->sig90;
+	const double evalue = opts->evalue;
 	if(!db || !ws || !reads || !d_flag || !d_tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	if(db->h_cat_off.empty()) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
 	const int64_t D = db->info.DB_size;
@@ -757,7 +790,7 @@ extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_re
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	const auto t0 = now();
-	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, 0))) return rc;
+	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, opts->order, 0))) return rc;
 	const auto t1 = now();
 	if(dbg) fprintf(stderr, "[kmahip] assemble: pile-up on device %.1f ms\n", ms(t0, t1));
 	if(!ws->p_kept) return KMAHIP_OK;
@@ -796,7 +829,7 @@ extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_re
 			DevGuard G;
 			ConsArgs C;
 			C.db = db->dev; C.counts = ws->p_counts; C.chain_head = ws->p_chain; C.nodes = (const InsNode *) ws->p_nodes; C.seg_start = ws->p_seg;
-			C.n_kept = ws->p_kept; C.bcd = bcd; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
+			C.n_kept = ws->p_kept; C.bcd = bcd; C.caller = caller; C.sig90 = sig90; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
 			unsigned long long *fig = nullptr;
 			HIP_TRY(hipMalloc((void **) &fig, (size_t) 4 * D * sizeof(unsigned long long)));
 			G.v.push_back(fig);
@@ -859,7 +892,7 @@ extern "C" int kmahip_assemble_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_re
 			uint32_t c[6];
 			for(int j = 0; j < 6; ++j) c[j] = std::min<uint32_t>(c32[j], 65535u);
 			long dep = 0;
-			const unsigned char call = call_column(c, tnuc, bcd, evalue, &dep);
+			const unsigned char call = call_column(c, tnuc, bcd, evalue, caller, sig90, &dep);
 			++asm_len;
 			if(out->consensus) cons.push_back((char) call);
 			if(call != '-') {

@@ -257,6 +257,8 @@ static double p_chisqr(long double q) {
 }
 
 // runkma.c:578-583, 608-613, 765-783 for every template with a ConClave score, in template order
+double kmahip_p_chisqr(long double q) { return p_chisqr(q); }
+
 extern "C" int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
                                kmahip_res_row *rows, int64_t cap, int64_t *n_rows) {
 	if(!db || !w_scores || !n_rows || (cap > 0 && !rows)) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }

@@ -31,6 +31,12 @@ int load_names(kmahip_db *db) {
 extern "C" int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                                  const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, const char *read_names,
                                  const int64_t *read_name_off, int64_t *rows) {
+	return kmahip_frag_write2(path, db, reads, rc, tmpl, n_hits, trace_stats, max_frag, 0, read_names, read_name_off, rows);
+}
+
+extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                                  const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const char *read_names,
+                                  const int64_t *read_name_off, int64_t *rows) {
 	if(!path || !db || !reads || !rc || !tmpl || !n_hits || !trace_stats || !read_names || !read_name_off) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	int e = load_names(db);
 	if(e) return e;
@@ -45,7 +51,7 @@ extern "C" int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_r
 		if(tmpl[i] == 0) continue;
 		const int64_t r = rank++;
 		if(trace_stats[10 * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
-		keys.push_back(Key{abs(tmpl[i]), r / max_frag, r, i});
+		keys.push_back(Key{abs(tmpl[i]), order ? 0 : r / max_frag, order ? -r : r, i});      // (order 1: the single thread of `-Mt1` writes them as they come)
 	}
 	std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
 		if(a.t != b.t) return a.t < b.t;

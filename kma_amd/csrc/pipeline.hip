@@ -365,3 +365,81 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	out->ms[5] = since(t);
 	return KMAHIP_OK;
 }
+
+// ---- `-Mt1 t`: raw reads straight to stage 3c against one template (runKMA_Mt1, mt1.c:86-500) ------------------------------
+extern "C" int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
+                              const kmahip_assemble_opts *aopts, kmahip_run *out) {
+	if(!db || !ws || !reads || !p || !aopts || !out || !out->rows || out->rows_cap < 1 || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) {
+		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
+	}
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	const size_t D = db->info.DB_size;
+	if(tmpl < 1 || (size_t) tmpl >= D) { kmahip_set_error("template %d out of range", tmpl); return KMAHIP_EINVAL; }
+	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
+	out->n_rows = 0;
+	hipStream_t s = 0;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	kmahip_reads d = *reads;
+	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &d.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &d.seq_off)) ||
+	   (rc = B.up(reads->len, (size_t) n, 1, &d.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &d.N)) ||
+	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	out->ms[0] = since(t);
+	// stage 3c per read: strand + traceback; the run pool grows on demand
+	kmahip_traces tr;
+	int32_t *d_rc = nullptr, *d_tmpl = nullptr;
+	if((rc = B.get((size_t) 10 * n + 10, &tr.stats)) || (rc = B.get((size_t) n + 1, &tr.ops_off)) || (rc = B.get((size_t) n + 1, &tr.n_ops)) ||
+	   (rc = B.get((size_t) n + 1, &d_rc)) || (rc = B.get((size_t) n + 1, &d_tmpl))) return rc;
+	int64_t total_bases = 0;
+	for(int64_t i = 0; i < n; ++i) total_bases += reads->len[i];
+	tr.ops_cap = total_bases / 3 + 8 * n + (1 << 16);
+	for(int attempt = 0; n; ++attempt) {
+		if((rc = B.get((size_t) tr.ops_cap, &tr.ops))) return rc;
+		if((rc = kmahip_launch_longtrace(db, ws, &d, nullptr, tmpl, nullptr, nullptr, one2one, p, &tr, d_rc, s))) return rc;
+		unsigned long long used = 0;
+		const int st = ws_status(ws, &used);
+		if(st == 2 || (int64_t) used > tr.ops_cap) {
+			if(attempt >= 2) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+			tr.ops_cap = (int64_t) used + (1 << 16);
+			continue;
+		}
+		break;
+	}
+	out->ms[3] = since(t);
+	// the per-read figures: Score of the `.res` row = sum of KMA()'s own scores of the kept reads (alnToMat, assembly.c:1328-1334),
+	// i.e. without the end bonus the read filter added
+	std::vector<int32_t> stats((size_t) 10 * n + 10, 0), h_tmpl((size_t) n + 1, 0);
+	if(n) HIP_TRY(hipMemcpy(stats.data(), tr.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
+	const int t_len = db->h_tlen[(size_t) tmpl];
+	uint64_t score = 0;
+	for(int64_t i = 0; i < n; ++i) {
+		const int32_t *st = &stats[(size_t) 10 * i];
+		if(st[3] == 0) continue;
+		h_tmpl[(size_t) i] = tmpl;
+		score += (uint64_t) (st[0] - p->rw.Wl * ((st[1] == 0) + (st[2] == t_len)));
+	}
+	if(n) HIP_TRY(hipMemcpy(d_tmpl, h_tmpl.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+	kmahip_res_row &row = out->rows[0];
+	row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
+	row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
+	row.significant = ((row.p_value <= aopts->evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+	out->n_rows = 1;
+	out->ms[2] = since(t);
+	kmahip_assemble_opts ao = *aopts;
+	ao.order = 1;
+	if(n && score) {
+		if((rc = kmahip_assemble2_dev(db, ws, &d, d_rc, d_tmpl, &tr, &ao, &out->assembly))) return rc;
+	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
+	out->ms[4] = since(t);
+	if(n) {
+		if(out->tmpl) memcpy(out->tmpl, h_tmpl.data(), (size_t) n * 4);
+		if(out->n_hits) for(int64_t i = 0; i < n; ++i) out->n_hits[i] = 1;
+		if(out->rc) HIP_TRY(hipMemcpy(out->rc, d_rc, (size_t) n * 4, hipMemcpyDeviceToHost));
+		if(out->trace_stats) memcpy(out->trace_stats, stats.data(), (size_t) n * 40);
+	}
+	out->ms[5] = since(t);
+	return KMAHIP_OK;
+}
