@@ -48,8 +48,17 @@ struct PileArgs {
 	int32_t *chain_head;         // per position of `cat`: first insertion column in front of it (0 = none), node ids are 1-based
 	InsNode *nodes;
 	int64_t node_cap;
-	int32_t *seg_start;          // per template: first entry of the sorted list (n_kept if none); DB_size + 1
+	int32_t *seg_start;          // per template: 0 if it has kept reads, INT32_MAX if none (the consensus kernels ask); DB_size + 1
 	int lds_node_limit;          // test hook (KMAHIP_PILE_LDS_NODES): fewer insertion columns per template in LDS than fit
+	// work units: a template that fits LDS is one unit; a longer one is cut into segments of seg_cols columns, each piled up by
+	// its own workgroup from the reads that cover it (a read visits every segment it touches)
+	const int32_t *unit_base;    // DB_size + 1: first unit of template t
+	const int32_t *unit_t;       // n_units: template of the unit
+	const int32_t *unit_lo;      // n_units: first column of the unit
+	int64_t n_units;
+	int seg_cols;
+	int64_t *vis_cnt, *vis_off;  // per read: number of units it visits, exclusive scan of that
+	int64_t *unit_start;         // n_units + 1: first entry of the sorted list per unit (n_entries if none)
 };
 
 // oriented read base (0-3, 4 = N): the read as ConClave filed it
@@ -72,36 +81,6 @@ __global__ __launch_bounds__(256) void pile_filed_kernel(const int32_t *tmpl, in
 	if(r < n) filed[r] = tmpl[r] != 0;
 }
 
-// sort key: template, then the order the reference assembles the reads of a template in
-__global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
-	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	// kept = has a template and passed the read filter; one atomic per wavefront (millions of single increments of one
-	// counter queue up on its L2 line: 250 ms for 4 M reads)
-	const bool keep = r < A.n_reads && A.stats[10 * r + 3] != 0;
-	const unsigned long long m = __ballot(keep);
-	if(!m) return;
-	const int lane = threadIdx.x & 63, leader = __ffsll((long long) m) - 1;
-	unsigned long long base = 0;
-	if(lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long) __popcll(m));
-	base = __shfl(base, leader);
-	if(!keep) return;
-	const uint64_t t = (uint64_t) abs(A.tmpl[r]);
-	// rank among the fragments ConClave filed (conclave.c:166, 194) -> chunk of max_frag, reverse order inside the chunk
-	const int64_t rk = A.rank[r];
-	const uint64_t chunk = (uint64_t) (rk / A.max_frag), in = (uint64_t) (rk % A.max_frag);
-	const uint64_t ord = A.order ? (uint64_t) rk : chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
-	const unsigned long long slot = base + (unsigned long long) __popcll(m & ((1ull << lane) - 1ull));
-	A.keys[slot] = (t << 40) | ord;
-	A.vals[slot] = (int32_t) r;
-}
-
-__global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_kept, int32_t *seg_start, int64_t DB_size) {
-	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(i >= n_kept) return;
-	const int64_t t = (int64_t) (keys[i] >> 40);
-	if(i == 0 || (int64_t) (keys[i - 1] >> 40) != t) seg_start[t] = (int32_t) i;
-}
-
 // Everything a template's workgroup shares lives in HBM and is read back by other threads of the SAME workgroup after a
 // barrier. The increments are atomics (performed in L2); the few plain loads that must see them -- chain links, column
 // depths -- go to L2 as well (agent-scope relaxed atomic loads) instead of invalidating the caches: a device-scope
@@ -120,6 +99,7 @@ __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ
 extern __shared__ uint32_t pile_lds[];      // [6 * t_len] counts, [t_len] chain heads, [8 * lds_nodes] insertion columns
 constexpr int PILE_LDS_WORDS = (160 * 1024 - 1024) / 4;
 constexpr int PILE_LDS_MIN_NODES = 64;
+constexpr int PILE_THREADS = 1024;     // one workgroup per unit: reads are taken PILE_THREADS at a time (short reads) or one by one (segments)
 
 template <bool LDS>
 struct Walk {
@@ -180,6 +160,7 @@ struct ReadRuns {
 	Q q;
 	int64_t o;
 	int n, first, start, qp;
+	int lead_d, trail_d;      // template columns of the gap runs trimmed in front / behind
 };
 __device__ __forceinline__ ReadRuns read_runs(const PileArgs &A, int64_t r) {
 	ReadRuns R;
@@ -189,12 +170,12 @@ __device__ __forceinline__ ReadRuns read_runs(const PileArgs &A, int64_t r) {
 	R.q.w = A.seq + A.seq_off[r]; R.q.L = A.len[r]; R.q.N = A.N + A.N_off[r]; R.q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
 	R.q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
 	R.q.cw = -1; R.q.cv = 0;
-	R.start = st[1]; R.qp = st[4]; R.first = 0;
+	R.start = st[1]; R.qp = st[4]; R.first = 0; R.lead_d = 0; R.trail_d = 0;
 	// column 0 is never trimmed from the back
-	while(R.n > 1 && (A.ops[R.o + R.n - 1] & 3u) >= 2u) --R.n;
+	while(R.n > 1 && (A.ops[R.o + R.n - 1] & 3u) >= 2u) { const uint32_t run = A.ops[R.o + R.n - 1]; if((run & 3u) == 3u) R.trail_d += (int) (run >> 2); --R.n; }
 	while(R.first < R.n && (A.ops[R.o + R.first] & 3u) >= 2u) {
 		const uint32_t run = A.ops[R.o + R.first];
-		if((run & 3u) == 3u) R.start += (int) (run >> 2); else R.qp += (int) (run >> 2);
+		if((run & 3u) == 3u) { R.start += (int) (run >> 2); R.lead_d += (int) (run >> 2); } else R.qp += (int) (run >> 2);
 		++R.first;
 	}
 	return R;
@@ -205,6 +186,216 @@ __device__ bool read_has_ins(const PileArgs &A, int64_t r) {
 	bool ins = false;
 	for(int j = R.first; j < R.n; ++j) if((A.ops[R.o + j] & 3u) == 2u) ins = true;
 	return ins;
+}
+
+// the units a kept read visits: [u0, u1] and, for an alignment that wraps around a circular template, [w0, w1] as well. A unit
+// [lo, hi) is visited when the read covers one of the columns lo - 1 .. hi - 1: the column in front of the unit is counted there
+// too (its depth is what a new insertion column in front of column lo starts from, assembly.c:1377-1397).
+struct Visits { int u0, u1, w0, w1; };
+__device__ Visits pile_visits(const PileArgs &A, int64_t r) {
+	Visits V = {0, -1, 0, -1};
+	const int t = abs(A.tmpl[r]);
+	const int ub = A.unit_base[t], nu = A.unit_base[t + 1] - ub;
+	if(nu == 1) { V.u0 = V.u1 = ub; return V; }
+	const ReadRuns R = read_runs(A, r);
+	const int32_t *st = A.stats + 10 * r;
+	const int t_len = A.db.tlen[t];
+	const int span = st[3] - st[7] - R.lead_d - R.trail_d;       // template columns the piled-up part covers
+	const int S = A.seg_cols;
+	int start = R.start;
+	if(start >= t_len) start -= t_len;
+	const int end = start + span;                                 // exclusive; > t_len: wraps
+	if(end <= t_len) {
+		V.u0 = ub + start / S; V.u1 = ub + min(nu - 1, end / S);
+		// (unit 0 also counts the last column of a circular template as the column in front of it)
+		if(end == t_len && V.u0 > ub) { V.w0 = V.w1 = ub; }
+	} else {
+		V.u0 = ub + start / S; V.u1 = ub + nu - 1;
+		V.w0 = ub; V.w1 = ub + min(nu - 1, (end - t_len) / S);
+		if(V.w1 >= V.u0) { V.u0 = ub; V.w1 = -1; V.w0 = 0; }     // covers everything
+	}
+	return V;
+}
+
+__global__ __launch_bounds__(256) void pile_count_kernel(const PileArgs A) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= A.n_reads) return;
+	int64_t c = 0;
+	if(A.stats[10 * r + 3] != 0) {
+		const Visits V = pile_visits(A, r);
+		c = (V.u1 - V.u0 + 1) + (V.w1 >= V.w0 ? V.w1 - V.w0 + 1 : 0);
+		A.seg_start[abs(A.tmpl[r])] = 0;
+	}
+	A.vis_cnt[r] = c;
+}
+
+// sort key: unit, then the order the reference assembles the reads of a template in
+__global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= A.n_reads || A.stats[10 * r + 3] == 0) return;
+	// rank among the fragments ConClave filed (conclave.c:166, 194) -> chunk of max_frag, reverse order inside the chunk
+	const int64_t rk = A.rank[r];
+	const uint64_t chunk = (uint64_t) (rk / A.max_frag), in = (uint64_t) (rk % A.max_frag);
+	const uint64_t ord = A.order ? (uint64_t) rk : chunk * (uint64_t) A.max_frag + ((uint64_t) A.max_frag - 1 - in);
+	const Visits V = pile_visits(A, r);
+	int64_t slot = A.vis_off[r];
+	for(int u = V.u0; u <= V.u1; ++u, ++slot) { A.keys[slot] = ((uint64_t) u << 28) | ord; A.vals[slot] = (int32_t) r; }
+	for(int u = V.w0; u <= V.w1; ++u, ++slot) { A.keys[slot] = ((uint64_t) u << 28) | ord; A.vals[slot] = (int32_t) r; }
+}
+
+__global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_ent, int64_t *unit_start) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n_ent) return;
+	const int64_t u = (int64_t) (keys[i] >> 28);
+	if(i == 0 || (int64_t) (keys[i - 1] >> 28) != u) unit_start[u] = i;
+}
+
+__global__ __launch_bounds__(256) void pile_fill_kernel(int64_t *p, int64_t n, int64_t v) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) p[i] = v;
+}
+
+// ---- a template too long for LDS: cut into units of seg_cols columns, one workgroup per unit, the reads that cover the unit in
+// the reference's order, ONE READ AT A TIME with all 1024 threads on it (long noisy reads all carry insertions, so there is no
+// stretch of insertion-free reads to pile up side by side; the parallelism is inside the read). Thread j takes run j of the read:
+//   scan     block prefix sums of the runs' template / query lengths -> where every run starts
+//   phase 1  runs of aligned pairs / gaps in the read: the columns they cover inside the unit (+ the column in front of it),
+//            a gap for every insertion column chained in front of a covered column -- except the first column behind an
+//            insertion run and its chain, which wait for ...
+//   phase 2a ... the insertion runs, each on the chain in front of its column: bases into the existing columns, new columns
+//            when the chain is too short, started from the depths the reference sees at that moment (the column in front of
+//            the site counted, the one behind it not yet; two insertion runs one aligned base apart read each other's column,
+//            hence the explicit `pending` base), then
+//   phase 2b the column behind each insertion run.
+struct SegWalk {
+	const PileArgs &A;
+	int lo, hi, t_len, ncol;        // columns [lo, hi) at index 1 .., index 0 = the column in front (lo - 1, or the last one of a ring)
+	unsigned *s_nodes;
+	__device__ __forceinline__ int ci(int p) const {
+		if(p >= lo && p < hi) return p - lo + 1;
+		return (p == (lo ? lo - 1 : t_len - 1)) ? 0 : -1;
+	}
+	__device__ __forceinline__ int node_base() const { return 7 * ncol; }
+	__device__ __forceinline__ int node_cap() const { return min((PILE_LDS_WORDS - 7 * ncol) / 8, A.lds_node_limit); }
+	__device__ __forceinline__ int head(int c) const { return (int) pile_lds[6 * ncol + c]; }
+	__device__ __forceinline__ void set_head(int c, int id) const { pile_lds[6 * ncol + c] = (uint32_t) id; }
+	__device__ __forceinline__ int next(int h) const { return (int) pile_lds[node_base() + 8 * (h - 1) + 6]; }
+	__device__ __forceinline__ void set_next(int h, int id) const { pile_lds[node_base() + 8 * (h - 1) + 6] = (uint32_t) id; }
+	__device__ __forceinline__ void add_node(int h, int b) const { atomicAdd(&pile_lds[node_base() + 8 * (h - 1) + b], 1u); }
+	__device__ __forceinline__ void add_col(int c, int b) const { atomicAdd(&pile_lds[6 * c + b], 1u); }
+	__device__ __forceinline__ int depth16_col(int c) const { int s = 0; for(int j = 0; j < 6; ++j) s += (int) min(pile_lds[6 * c + j], 65535u); return s; }
+	__device__ __forceinline__ int depth16_node(int h) const { int s = 0; for(int j = 0; j < 6; ++j) s += (int) min(pile_lds[node_base() + 8 * (h - 1) + j], 65535u); return s; }
+	__device__ int new_node(int bias, int b, int gaps) const {
+		const int id = (int) atomicAdd(s_nodes, 1u) + 1;
+		if(id > node_cap()) { atomicMax(&A.counters[1], 64ull); return 0; }
+		uint32_t *c = &pile_lds[node_base() + 8 * (id - 1)];
+		for(int x = 0; x < 6; ++x) c[x] = 0;
+		c[5] = (uint32_t) bias; c[b] = 1; c[6] = 0; c[7] = (uint32_t) gaps;
+		return id;
+	}
+};
+
+// exclusive prefix sums over the workgroup of two lengths packed into one word (template columns high, query bases low); *total
+// = their sums. s_w: one word per wavefront.
+__device__ uint64_t block_scan2(uint64_t v, unsigned long long *s_w, uint64_t *total) {
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint64_t x = v;
+	for(int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d); if(lane >= d) x += y; }
+	__syncthreads();
+	if(lane == 63) s_w[wave] = x;
+	__syncthreads();
+	uint64_t base = 0, tot = 0;
+	for(int w = 0; w < PILE_THREADS / 64; ++w) { const uint64_t t = s_w[w]; if(w < wave) base += t; tot += t; }
+	*total = tot;
+	return base + x - v;
+}
+
+__device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, unsigned long long *s_w) {
+	const int tid = threadIdx.x;
+	ReadRuns R = read_runs(A, r);
+	int start = R.start;
+	if(start >= W.t_len) start -= W.t_len;
+	int64_t col_carry = 0, q_carry = R.qp;
+	for(int j0 = R.first; j0 < R.n; j0 += PILE_THREADS) {
+		const int j = j0 + tid;
+		const bool valid = j < R.n;
+		const uint32_t run = valid ? A.ops[R.o + j] : 0u;
+		const int cls = (int) (run & 3u), len = (int) (run >> 2);
+		const uint64_t mine = valid ? (((uint64_t) (cls != 2 ? len : 0) << 32) | (uint64_t) (cls != 3 ? len : 0)) : 0ull;
+		uint64_t total;
+		const uint64_t ex = block_scan2(mine, s_w, &total);
+		const int64_t col0 = col_carry + (int64_t) (ex >> 32), q0 = q_carry + (int64_t) (ex & 0xFFFFFFFFull);
+		col_carry += (int64_t) (total >> 32); q_carry += (int64_t) (total & 0xFFFFFFFFull);
+		const uint32_t prun = (valid && j > R.first) ? A.ops[R.o + j - 1] : 0u;
+		const bool prevI = valid && j > R.first && (prun & 3u) == 2u;
+		// ---- phase 1: the columns of this run inside the unit. The run covers the positions p0 .. p0 + len - 1 (p0 < t_len, so it
+		// wraps at most once); the unit's interval [lo - 1, hi - 1] (without lo - 1 for the first unit) is met directly, after the
+		// wrap, and the first unit also counts the ring's last position
+		if(valid && cls != 2 && len > 0) {
+			const int64_t p0 = (start + col0) % W.t_len;
+			const int64_t ulo = W.lo ? W.lo - 1 : 0, uhi = W.hi - 1;
+			int64_t ia[3], ib[3];
+			ia[0] = ulo - p0; ib[0] = uhi - p0;
+			ia[1] = ulo + W.t_len - p0; ib[1] = uhi + W.t_len - p0;
+			ia[2] = 1; ib[2] = 0;
+			if(W.lo == 0 && W.hi < W.t_len) { ia[2] = ib[2] = W.t_len - 1 - p0; }
+			for(int x = 0; x < 3; ++x) {
+				const int64_t ca = ia[x] < 0 ? 0 : ia[x], cb = ib[x] >= len ? len - 1 : ib[x];
+				for(int64_t c = ca; c <= cb; ++c) {
+					if(c == 0 && prevI) continue;
+					const int64_t col = col0 + c;
+					const int ci = W.ci((int) ((p0 + c) % W.t_len));
+					if(ci < 0) continue;
+					W.add_col(ci, cls == 3 ? 5 : q_base(R.q, (int) (q0 + c)));
+					if(col > 0 && ci >= 1) for(int h = W.head(ci); h; h = W.next(h)) W.add_node(h, 5);
+				}
+			}
+		}
+		__syncthreads();
+		// ---- phase 2a: insertion runs whose column lies in the unit
+		int site = -1, qafter = 0;
+		if(valid && cls == 2) {
+			const int p = (int) ((start + col0) % W.t_len);
+			const int ci = W.ci(p);
+			if(ci >= 0) { site = ci; qafter = (int) (q0 + len); }      // (index 0, the column in front of the unit: counted, its chain is not ours)
+			if(ci >= 1) {
+				int left = len, qpos = (int) q0, last = 0;
+				int h = W.head(ci);
+				while(h && left > 0) { W.add_node(h, q_base(R.q, qpos++)); last = h; h = W.next(h); --left; }
+				if(left > 0) {
+					int myBias;
+					if(last) myBias = W.depth16_node(last);
+					else {
+						const int cprev = W.ci(p ? p - 1 : W.t_len - 1);
+						myBias = W.depth16_col(cprev);
+						// the column in front of the site is the single column between two insertion runs of this read: its own
+						// base is added in phase 2b of this round -- count it now (16-bit counters: only while below the ceiling)
+						if(j - 2 >= j0 && j - 2 >= R.first && (prun & 3u) != 2u && (prun >> 2) == 1u && (A.ops[R.o + j - 2] & 3u) == 2u) {
+							const int b = (prun & 3u) == 3u ? 5 : q_base(R.q, (int) q0 - 1);
+							if(pile_lds[6 * cprev + b] < 65535u) ++myBias;
+						}
+					}
+					const int tmp = W.depth16_col(ci);
+					myBias = (tmp < myBias) ? tmp : (myBias - 1);
+					if(65535 < myBias) myBias = 65535;
+					while(left > 0) {
+						const int id = W.new_node(myBias, q_base(R.q, qpos++), p);
+						if(!id) break;
+						if(last) W.set_next(last, id); else W.set_head(ci, id);
+						last = id;
+						--left;
+					}
+				} else for(; h; h = W.next(h)) W.add_node(h, 5);
+			}
+		}
+		__syncthreads();
+		// ---- phase 2b: the column behind the insertion (first element of the next run; there is one: trailing gap runs are trimmed)
+		if(site >= 0) {
+			const int ncls = j + 1 < R.n ? (int) (A.ops[R.o + j + 1] & 3u) : 0;
+			W.add_col(site, ncls == 3 ? 5 : q_base(R.q, qafter));
+		}
+		__syncthreads();
+	}
 }
 
 template <bool LDS>
@@ -274,7 +465,6 @@ __device__ void pile_ins(const PileArgs &A, const Walk<LDS> &W, int64_t r) {
 	}
 }
 
-constexpr int PILE_THREADS = 1024;     // one workgroup per template: reads are taken PILE_THREADS at a time
 
 // the reads [s0, s1) of the sorted list -- one template's -- PILE_THREADS at a time
 template <bool LDS>
@@ -323,24 +513,51 @@ __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0,
 	}
 }
 
-__global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_kept, int lds_cols) {
+__global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_ent, int lds_cols) {
 	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
 	__shared__ unsigned s_nodes;
 	__shared__ long long s_pool;
 	const int tid = threadIdx.x;
-	const int64_t D = A.db.DB_size;
-	for(int64_t t = 1 + blockIdx.x; t < D; t += gridDim.x) {
-		const int64_t s0 = A.seg_start[t];
-		if(s0 >= n_kept) continue;
+	for(int64_t u = blockIdx.x; u < A.n_units; u += gridDim.x) {
+		const int64_t s0 = A.unit_start[u];
+		if(s0 >= n_ent) continue;
 		int64_t s1 = s0;
-		// end of the segment: next template that has reads (sorted list is template-major)
+		// end of the unit's entries: first key of a later unit (the sorted list is unit-major)
 		{
-			int64_t lo = s0, hi = n_kept;
-			while(lo < hi) { const int64_t mid = (lo + hi) >> 1; if((int64_t) (A.keys[mid] >> 40) <= t) lo = mid + 1; else hi = mid; }
+			int64_t lo = s0, hi = n_ent;
+			while(lo < hi) { const int64_t mid = (lo + hi) >> 1; if((int64_t) (A.keys[mid] >> 28) <= u) lo = mid + 1; else hi = mid; }
 			s1 = lo;
 		}
+		const int t = A.unit_t[u];
 		const int64_t tbase = A.db.cat_off[t];
 		const int t_len = A.db.tlen[t];
+		if(A.unit_base[t + 1] - A.unit_base[t] > 1) {
+			// one segment of a long template
+			const int lo = A.unit_lo[u], hi = min(lo + A.seg_cols, t_len), ncol = hi - lo + 1;
+			const SegWalk W{A, lo, hi, t_len, ncol, &s_nodes};
+			for(int i = tid; i < 7 * ncol; i += PILE_THREADS) pile_lds[i] = 0;
+			if(tid == 0) s_nodes = 0;
+			__syncthreads();
+			for(int64_t e = s0; e < s1; ++e) pile_seg_read(A, W, (int64_t) A.vals[e], s_ins);
+			const int n_nodes = min((int) s_nodes, W.node_cap());
+			if(tid == 0) s_pool = n_nodes ? (long long) atomicAdd(&A.counters[2], (unsigned long long) n_nodes) : 0;
+			__syncthreads();
+			const long long base = s_pool;
+			if(base + n_nodes > A.node_cap) { if(tid == 0) atomicMax(&A.counters[1], 32ull); }
+			else {
+				for(int i = tid; i < 6 * (hi - lo); i += PILE_THREADS) A.counts[6 * (tbase + lo) + i] = pile_lds[6 + i];
+				for(int i = tid; i < hi - lo; i += PILE_THREADS) { const int h = (int) pile_lds[6 * ncol + 1 + i]; A.chain_head[tbase + lo + i] = h ? (int32_t) (base + h) : 0; }
+				for(int i = tid; i < n_nodes; i += PILE_THREADS) {
+					const uint32_t *c = &pile_lds[W.node_base() + 8 * i];
+					InsNode &nn = A.nodes[base + i];
+					for(int x = 0; x < 6; ++x) nn.c[x] = c[x];
+					nn.next = c[6] ? (int32_t) (base + c[6]) : 0;
+					nn.gaps = (int32_t) c[7];
+				}
+			}
+			__syncthreads();
+			continue;
+		}
 		if(t_len <= lds_cols) {
 			const Walk<true> W{A, tbase, t_len, &s_nodes};
 			for(int i = tid; i < 7 * t_len; i += PILE_THREADS) pile_lds[i] = 0;
@@ -507,6 +724,8 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 
 } // namespace
 
+namespace { struct DevGuard { std::vector<void *> v; ~DevGuard() { for(void *p : v) (void) hipFree(p); } }; }
+
 static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64_t node_cap) {
 	const int64_t total = db->h_cat_off.empty() ? 0 : db->h_cat_off.back();
 	if(ws->p_total != total || ws->p_node_cap < node_cap) {
@@ -519,10 +738,6 @@ static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64
 		ws->p_total = total; ws->p_node_cap = node_cap;
 	}
 	if(ws->p_reads_cap < n_reads) {
-		(void) hipFree(ws->p_keys); (void) hipFree(ws->p_vals);
-		ws->p_keys = nullptr; ws->p_vals = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->p_keys, (size_t) n_reads * 2 * sizeof(uint64_t)));
-		HIP_TRY(hipMalloc((void **) &ws->p_vals, (size_t) n_reads * 2 * sizeof(int32_t)));
 		(void) hipFree(ws->p_rank);
 		ws->p_rank = nullptr;
 		HIP_TRY(hipMalloc((void **) &ws->p_rank, (size_t) n_reads * 2 * sizeof(int64_t)));
@@ -536,23 +751,25 @@ static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64
 static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                          const kmahip_traces *tr, int64_t max_frag, int order, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
-	const int64_t node_cap = std::max<int64_t>(1 << 20, n);
+	// insertion columns: about one per 30 read bases of noisy long reads at most (every site of a deep pile-up has a few)
+	int64_t node_cap = std::max<int64_t>(1 << 20, n);
+	if(reads->max_len > 1000) node_cap = std::max<int64_t>(node_cap, std::min<int64_t>((int64_t) reads->max_len * n / 8, 4 * (db->h_cat_off.empty() ? 0 : db->h_cat_off.back()) + (1 << 20)));
 	int rc = assemble_scratch(db, ws, std::max<int64_t>(n, 1), node_cap);
 	if(rc) return rc;
 	const int64_t total = ws->p_total;
-	HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
-	HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
-	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
-	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, sizeof(unsigned long long), stream));
+	const int64_t D = db->info.DB_size;
 	PileArgs A;
 	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.flag = flag; A.tmpl = tmpl; A.stats = tr->stats; A.ops_off = tr->ops_off; A.n_ops = tr->n_ops; A.ops = tr->ops;
 	A.max_frag = max_frag > 0 ? max_frag : 1000000;
 	A.order = order;
-	A.keys = ws->p_keys; A.vals = ws->p_vals; A.counters = ws->counters;
-	A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.node_cap = node_cap; A.seg_start = ws->p_seg;
+	A.counters = ws->counters;
+	A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.node_cap = ws->p_node_cap; A.seg_start = ws->p_seg;
 	A.lds_node_limit = getenv("KMAHIP_PILE_LDS_NODES") ? atoi(getenv("KMAHIP_PILE_LDS_NODES")) : 1 << 30;
+	ws->p_kept = 0;
 	if(n == 0) return KMAHIP_OK;
+	if(n >= (1ll << 28)) { kmahip_set_error("pile-up: more than 2^28 reads in one batch"); return KMAHIP_EINVAL; }
+	DevGuard G;
 	void *tmp = nullptr;
 	size_t tmp_bytes = 0;
 	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
@@ -579,67 +796,118 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		(void) hipFree(tmp); tmp = nullptr;
 		if(e != hipSuccess) { kmahip_set_error("rocprim::exclusive_scan failed: %s", hipGetErrorString(e)); return KMAHIP_EDEVICE; }
 	}
-	hipLaunchKernelGGL(pile_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A);
-	unsigned long long kept = 0;
-	HIP_TRY(hipMemcpyAsync(&kept, ws->counters, sizeof kept, hipMemcpyDeviceToHost, stream));
-	HIP_TRY(hipStreamSynchronize(stream));
-	ws->p_kept = (int64_t) kept;
-	if(!kept) return KMAHIP_OK;
-	lap("ranks + keys");
-	// sort by (template, reference order)
-	uint64_t *keys_out = ws->p_keys + n;
-	int32_t *vals_out = ws->p_vals + n;
-	tmp_bytes = 0;
-	if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) kept, 0, 64, stream) != hipSuccess) {
-		kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE;
-	}
-	HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-	const hipError_t se = rocprim::radix_sort_pairs(tmp, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) kept, 0, 64, stream);
-	if(se != hipSuccess) { (void) hipFree(tmp); kmahip_set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(se)); return KMAHIP_EDEVICE; }
-	A.keys = keys_out; A.vals = vals_out;
-	// seg_start[t] = kept for templates without reads
-	{
-		std::vector<int32_t> init((size_t) db->info.DB_size + 1, (int32_t) kept);
-		HIP_TRY(hipMemcpyAsync(ws->p_seg, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
-	}
-	hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((kept + 255) / 256)), dim3(256), 0, stream, keys_out, (int64_t) kept, ws->p_seg, (int64_t) db->info.DB_size);
-	lap("sort + segments");
-#ifdef KMAHIP_DIAG
-	HIP_TRY(hipMemsetAsync(ws->counters + 10, 0, 6 * sizeof(unsigned long long), stream));
-#endif
-	const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(db->info.DB_size, 1), 256 * 8);
-	// templates up to lds_cols columns are piled up in LDS (see Walk); if one of them ran out of room for its insertion columns
-	// there, the launch is repeated on HBM
-	int lds_cols = getenv("KMAHIP_PILE_NO_LDS") ? 0 : (PILE_LDS_WORDS - 8 * PILE_LDS_MIN_NODES) / 7;
-	HIP_TRY(hipFuncSetAttribute((const void *) pileup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PILE_LDS_WORDS * 4));
-	unsigned long long c[3];
+	int64_t *vis = nullptr;
+	HIP_TRY(hipMalloc((void **) &vis, (size_t) (2 * n + 2) * sizeof(int64_t)));
+	G.v.push_back(vis);
+	A.vis_cnt = vis; A.vis_off = vis + n + 1;
+	// a template of up to split_cols columns is one unit (piled up in LDS as a whole, or on HBM if its insertion columns do not fit
+	// there); a longer one is cut into segments of seg_cols columns, halved when a segment runs out of LDS room
+	const int split_cols = (PILE_LDS_WORDS - 8 * PILE_LDS_MIN_NODES) / 7;
+	int lds_cols = getenv("KMAHIP_PILE_NO_LDS") ? 0 : split_cols;
+	int seg_cols = getenv("KMAHIP_PILE_SEG_COLS") ? atoi(getenv("KMAHIP_PILE_SEG_COLS")) : 1024;
+	unsigned long long c[3] = {0, 0, 0};
 	for(;;) {
-		hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), lds_cols ? (size_t) PILE_LDS_WORDS * 4 : 0, stream, A, (int64_t) kept, lds_cols);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(stream));
-		lap("pileup_kernel");
-		HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
-		if(c[1] != 16 || !lds_cols) break;
-		lds_cols = 0;
+		std::vector<int32_t> unit_base((size_t) D + 1, 0), unit_t, unit_lo;
+		for(int64_t t = 1; t < D; ++t) {
+			unit_base[(size_t) t] = (int32_t) unit_t.size();
+			const int tl = db->h_tlen[(size_t) t];
+			if(tl <= split_cols) { unit_t.push_back((int32_t) t); unit_lo.push_back(0); }
+			else for(int lo = 0; lo < tl; lo += seg_cols) { unit_t.push_back((int32_t) t); unit_lo.push_back(lo); }
+		}
+		unit_base[0] = 0; unit_base[(size_t) D] = (int32_t) unit_t.size();
+		if(D > 1) unit_base[1] = 0;
+		const int64_t n_units = (int64_t) unit_t.size();
+		int32_t *d_units = nullptr;
+		int64_t *d_ustart = nullptr;
+		HIP_TRY(hipMalloc((void **) &d_units, (size_t) (D + 1 + 2 * n_units + 2) * sizeof(int32_t)));
+		G.v.push_back(d_units);
+		HIP_TRY(hipMalloc((void **) &d_ustart, (size_t) (n_units + 2) * sizeof(int64_t)));
+		G.v.push_back(d_ustart);
+		HIP_TRY(hipMemcpyAsync(d_units, unit_base.data(), (size_t) (D + 1) * 4, hipMemcpyHostToDevice, stream));
+		if(n_units) {
+			HIP_TRY(hipMemcpyAsync(d_units + D + 1, unit_t.data(), (size_t) n_units * 4, hipMemcpyHostToDevice, stream));
+			HIP_TRY(hipMemcpyAsync(d_units + D + 1 + n_units, unit_lo.data(), (size_t) n_units * 4, hipMemcpyHostToDevice, stream));
+		}
+		A.unit_base = d_units; A.unit_t = d_units + D + 1; A.unit_lo = d_units + D + 1 + n_units; A.n_units = n_units; A.seg_cols = seg_cols;
+		A.unit_start = d_ustart;
 		HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
 		HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
-		HIP_TRY(hipMemsetAsync(ws->counters + 1, 0, 2 * sizeof(unsigned long long), stream));
+		HIP_TRY(hipMemsetAsync(ws->counters, 0, 3 * sizeof(unsigned long long), stream));
+		{
+			std::vector<int32_t> init((size_t) D + 1, INT32_MAX);
+			HIP_TRY(hipMemcpyAsync(ws->p_seg, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+		}
+		// visits per read -> entries (unit, order) -> sorted
+		hipLaunchKernelGGL(pile_count_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A);
+		tmp_bytes = 0;
+		if(rocprim::exclusive_scan(nullptr, tmp_bytes, A.vis_cnt, A.vis_off, (int64_t) 0, (size_t) n + 1, rocprim::plus<int64_t>(), stream) != hipSuccess) {
+			kmahip_set_error("rocprim::exclusive_scan (size query) failed"); return KMAHIP_EDEVICE;
+		}
+		HIP_TRY(hipMemsetAsync(A.vis_cnt + n, 0, sizeof(int64_t), stream));
+		HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+		{
+			const hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, A.vis_cnt, A.vis_off, (int64_t) 0, (size_t) n + 1, rocprim::plus<int64_t>(), stream);
+			int64_t n_ent = 0;
+			HIP_TRY(hipMemcpyAsync(&n_ent, A.vis_off + n, sizeof n_ent, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			(void) hipFree(tmp); tmp = nullptr;
+			if(e != hipSuccess) { kmahip_set_error("rocprim::exclusive_scan failed: %s", hipGetErrorString(e)); return KMAHIP_EDEVICE; }
+			ws->p_kept = n_ent;
+		}
+		const int64_t n_ent = ws->p_kept;
+		if(!n_ent) return KMAHIP_OK;
+		if(ws->p_ent_cap < n_ent) {
+			(void) hipFree(ws->p_keys); (void) hipFree(ws->p_vals);
+			ws->p_keys = nullptr; ws->p_vals = nullptr; ws->p_ent_cap = 0;
+			HIP_TRY(hipMalloc((void **) &ws->p_keys, (size_t) n_ent * 2 * sizeof(uint64_t)));
+			HIP_TRY(hipMalloc((void **) &ws->p_vals, (size_t) n_ent * 2 * sizeof(int32_t)));
+			ws->p_ent_cap = n_ent;
+		}
+		A.keys = ws->p_keys; A.vals = ws->p_vals;
+		hipLaunchKernelGGL(pile_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A);
+		lap("ranks + visits + keys");
+		uint64_t *keys_out = ws->p_keys + n_ent;
+		int32_t *vals_out = ws->p_vals + n_ent;
+		tmp_bytes = 0;
+		if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) n_ent, 0, 64, stream) != hipSuccess) {
+			kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE;
+		}
+		HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+		const hipError_t se = rocprim::radix_sort_pairs(tmp, tmp_bytes, ws->p_keys, keys_out, ws->p_vals, vals_out, (size_t) n_ent, 0, 64, stream);
+		if(se != hipSuccess) { (void) hipFree(tmp); kmahip_set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(se)); return KMAHIP_EDEVICE; }
+		A.keys = keys_out; A.vals = vals_out;
+		hipLaunchKernelGGL(pile_fill_kernel, dim3((unsigned) ((n_units + 1 + 255) / 256)), dim3(256), 0, stream, d_ustart, n_units + 1, n_ent);
+		hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((n_ent + 255) / 256)), dim3(256), 0, stream, keys_out, n_ent, d_ustart);
+		lap("sort + segments");
+#ifdef KMAHIP_DIAG
+		HIP_TRY(hipMemsetAsync(ws->counters + 10, 0, 6 * sizeof(unsigned long long), stream));
+#endif
+		const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(n_units, 1), 256 * 8);
+		HIP_TRY(hipFuncSetAttribute((const void *) pileup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PILE_LDS_WORDS * 4));
+		hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), (size_t) PILE_LDS_WORDS * 4, stream, A, n_ent, lds_cols);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(stream));
+		(void) hipFree(tmp); tmp = nullptr;
+		lap("pileup_kernel");
+		HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+		if(c[1] == 64 && seg_cols > 64) { seg_cols >>= 1; if(dbg) fprintf(stderr, "[kmahip] pile-up: a segment ran out of LDS room, again with %d columns per segment\n", seg_cols); continue; }
+		if(c[1] == 16 && lds_cols) { lds_cols = 0; continue; }      // a template's insertion columns did not fit LDS: those on HBM
+		break;
 	}
-	(void) hipFree(tmp);
 	if(c[1]) {
 		HIP_TRY(hipMemset(ws->counters + 1, 0, sizeof(unsigned long long)));
-		kmahip_set_error("pile-up: insertion column pool exhausted (%lld columns)", (long long) node_cap);
+		kmahip_set_error("pile-up: insertion column pool exhausted (%lld columns, status %llu)", (long long) ws->p_node_cap, c[1]);
 		return KMAHIP_EOVERFLOW;
 	}
 	ws->p_nodes_used = (int64_t) c[2];
 #ifdef KMAHIP_DIAG
 	{
-		unsigned long long dbg[6];
-		HIP_TRY(hipMemcpy(dbg, ws->counters + 10, sizeof dbg, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemset(ws->counters + 10, 0, sizeof dbg));
-		fprintf(stderr, "[kmahip] pile-up workgroup 7: %llu phases, parallel part %.1f us, serial part %.1f us per phase; (100 MHz clock)\n", dbg[2],
-		        dbg[2] ? dbg[0] / 100.0 / dbg[2] : 0.0, dbg[2] ? dbg[1] / 100.0 / dbg[2] : 0.0);
+		unsigned long long dbgc[6];
+		HIP_TRY(hipMemcpy(dbgc, ws->counters + 10, sizeof dbgc, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemset(ws->counters + 10, 0, sizeof dbgc));
+		fprintf(stderr, "[kmahip] pile-up workgroup 7: %llu phases, parallel part %.1f us, serial part %.1f us per phase; (100 MHz clock)\n", dbgc[2],
+		        dbgc[2] ? dbgc[0] / 100.0 / dbgc[2] : 0.0, dbgc[2] ? dbgc[1] / 100.0 / dbgc[2] : 0.0);
 	}
 #endif
 	return KMAHIP_OK;
@@ -715,7 +983,6 @@ static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, i
 	return call;
 }
 
-namespace { struct DevGuard { std::vector<void *> v; ~DevGuard() { for(void *p : v) (void) hipFree(p); } }; }
 
 extern "C" int kmahip_assemble(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                                const kmahip_traces *traces, int64_t max_frag, int bcd, double evalue, kmahip_assembly *out) {

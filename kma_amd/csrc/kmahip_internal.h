@@ -115,7 +115,7 @@ struct kmahip_ws {
 	void *p_nodes;
 	uint64_t *p_keys;
 	int64_t *p_rank;
-	int64_t p_total, p_node_cap, p_reads_cap, p_kept, p_nodes_used;
+	int64_t p_total, p_node_cap, p_reads_cap, p_kept, p_nodes_used, p_ent_cap;
 	// long-read trace pipeline (longtrace.hip): per-wavefront MEM arrays, per-pass pools, queues, scratch, counters
 	void *lt_buf[8];
 	size_t lt_bytes[8];

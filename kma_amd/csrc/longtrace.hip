@@ -113,7 +113,7 @@ struct LtArgs {
 	int32_t *o_rc;
 	volatile uint32_t *rec;   // bring-up flight recorder in host memory (KMAHIP_DEBUG_TIMING): 16 words per workgroup, NULL = off
 };
-#define LT_REC(slot, val) do { if(A.rec) A.rec[(size_t) blockIdx.x * 16 + (slot)] = (uint32_t) (val); } while(0)
+#define LT_REC(slot, val) do { if(A.rec && blockIdx.x < 2048) A.rec[(size_t) blockIdx.x * 16 + (slot)] = (uint32_t) (val); } while(0)
 
 __device__ __forceinline__ int wave_max(int x) {
 	for(int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o));
