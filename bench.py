@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--c4-reads", type=int, default=20000, help="reads of the extra BASELINE config C4 leg (10 kb ONT-like reads vs one 5 Mb "
+                    "genome, -Mt1 1 -bcNano, whole run incl. pile-up and consensus); 0 = skip")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --reads per rank; strong: --reads in total, sharded over the ranks")
     return ap.parse_args()
@@ -134,6 +136,67 @@ def cpu_baseline(prefix, codes, tmp):
     dt = time.time() - t0
     return dict(value=n / dt, unit="reads/s", cores=1, kind="port",
                 sample=f"{n} of the step's reads; oracle/scan.c + oracle/align.c scalar port, {dt:.1f} s")
+
+
+def c4_leg(tmp, n_reads, device):
+    """BASELINE config C4 beside the headline step (extra key, never `value`): n_reads ONT-like reads of 10 kb (4 % substitutions,
+    3 % deletions, 3 % insertions) against ONE random 5 Mb genome, `-Mt1 1 -bcNano`: per read strand choice (anker_rc), chaining and
+    traceback joins (longtrace.hip), pile-up in stream order and nanoCaller consensus, through kmahip_run_mt1 (host buffers in, so the
+    upload is inside). The reference binary runs the first 1000 reads on one host core for its rate and for the parity of
+    `.res` / consensus / fragment rows."""
+    import gzip
+    from kma_amd import binding, formats, synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    G, L = 5_000_000, 10_000
+    rng = np.random.default_rng(4)
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    prefix = os.path.join(tmp, "g5mb")
+    ref = os.path.join(ROOT, "oracle", "_ref", "kma")
+    if os.path.exists(ref):
+        synth.write_fasta(prefix + ".fsa", ["genome5Mb"], [genome])
+        subprocess.run([ref, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        formats.write_index(prefix, ["genome5Mb"], [genome])
+    reads = synth.make_long_reads(genome, n_reads, read_len=L, seed=8)
+    b = formats.pack_ragged(reads)
+    t0 = time.perf_counter()
+    db = binding.KmaHipDB(prefix, device=device)
+    t_open = time.perf_counter() - t0
+    try:
+        db.run_mt1(b, 1, consensus=False)           # scratch allocation
+        t0 = time.perf_counter()
+        o = db.run_mt1(b, 1, consensus=False)
+        dt = time.perf_counter() - t0
+        st = db.get_trace_stats()
+        bases = int(b.length.sum())
+        out = {"workload": f"{n_reads} x 10 kb ONT-like reads (4/3/3 % sub/del/ins) vs one 5 Mb genome, -Mt1 1 -bcNano: strand choice, chain, "
+                           "traceback joins, stream-order pile-up, nanoCaller consensus; kmahip_run_mt1, host buffers in",
+               "reads": n_reads, "reads_per_s": n_reads / dt, "gbases_per_s": bases / dt / 1e9, "call_ms": dt * 1e3, "db_open_s": round(t_open, 2),
+               "stage_ms": {k: round(v, 2) for k, v in zip(("upload", "-", "figures", "trace", "pileup+consensus", "copies"), o["ms"])},
+               "kept_reads": int((o["trace_stats"][:, 3] > 0).sum()), "dp_problems": int(st.problems), "dp_cells": int(st.dp_cells),
+               "mems_chained": int(st.mems), "trace_stage_GCUPS": st.dp_cells / (o["ms"][3] / 1e3) / 1e9 if o["ms"][3] else None}
+        if os.path.exists(ref):
+            import golden_util
+            m = min(1000, n_reads)
+            sub = formats.pack_ragged(reads[:m])
+            fq = os.path.join(tmp, "c4sub.fq")
+            synth.write_fastq(fq, reads[:m], prefix="r", qual=b"5")
+            t0 = time.perf_counter()
+            subprocess.run([ref, "-i", fq, "-o", os.path.join(tmp, "c4ref"), "-t_db", prefix, "-Mt1", "1", "-bcNano", "-t", "1"], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt_ref = time.perf_counter() - t0
+            os_ = db.run_mt1(sub, 1)
+            db.frag_write2(os.path.join(tmp, "c4our.frag.gz"), sub, os_["rc"], os_["tmpl"], os_["n_hits"], os_["trace_stats"], [f"r{i}".encode() for i in range(m)], order=1)
+            same = gzip.open(os.path.join(tmp, "c4our.frag.gz")).read() == gzip.open(os.path.join(tmp, "c4ref.frag.gz")).read()
+            same = same and golden_util.fsa_text([("genome5Mb", os_["consensus"][1])]) == open(os.path.join(tmp, "c4ref.fsa")).read()
+            line = binding.KmaHipDB.res_line("genome5Mb", os_["row"], os_["cover"][1], os_["aln_len"][1], os_["depth"][1])
+            ref_res = open(os.path.join(tmp, "c4ref.res")).read().splitlines()
+            same = same and len(ref_res) > 1 and line is not None and line.rstrip("\n") == ref_res[1]
+            out["cpu_reference"] = {"reads": m, "reads_per_s": m / dt_ref, "cores": 1, "what": "oracle/_ref/kma -Mt1 1 -bcNano -t 1, whole process wall clock"}
+            out["parity_subset_identical"] = bool(same)
+        return out
+    finally:
+        db.close()
 
 
 def parity_sample(prefix, codes, got_scan, got_hits):
@@ -391,6 +454,11 @@ def main():
                                                  "cpu_baseline.whole_pipeline_wall_s"}
             except Exception as e:  # noqa: BLE001  (informational leg only)
                 out["whole_pipeline"] = {"error": str(e)}
+            if a.c4_reads > 0 and not a.hard:
+                try:
+                    out["c4"] = c4_leg(tmp, a.c4_reads, local)
+                except Exception as e:  # noqa: BLE001  (extra leg only)
+                    out["c4"] = {"error": str(e)}
         elif rank == 0:
             out["cpu_baseline"] = None
         if strong is not None:

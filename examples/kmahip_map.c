@@ -1,9 +1,10 @@
-/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` (or `-ipe r1.fq r2.fq ... -apm p -1t1`) on an MI355X without the reference: plain C99 over the C-ABI of
- * libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte for byte what KMA 1.5.1 writes with one thread (the .gz
- * after decompression).
+/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` (or `-ipe r1.fq r2.fq ... -apm p -1t1`, or `-i reads.fq -Mt1 n [-bcNano]`)
+ * on an MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte
+ * for byte what KMA 1.5.1 writes with one thread (the .gz after decompression).
  *
  *     kmahip_map -i reads.fq.gz -t_db db -o out
  *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out
+ *     kmahip_map -i ont.fq.gz -t_db db -o out -Mt1 1 -bcNano        (every read against template 1, runKMA_Mt1 mt1.c:86-500)
  *
  * Stage 1 (kmahip_ingest_*: parse, trim with KMA's defaults, pack), the whole device run in one call (kmahip_run_se: stage 2,
  * 3a, ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
@@ -20,12 +21,16 @@ static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
+	int mt1 = 0, bc_nano = 0, one2one = 0;
 	for(int a = 1; a < argc; ++a) {
+		if(!strcmp(argv[a], "-Mt1") && a + 1 < argc) { mt1 = atoi(argv[++a]); continue; }
+		if(!strcmp(argv[a], "-bcNano")) { bc_nano = 1; continue; }
+		if(!strcmp(argv[a], "-1t1")) { one2one = 1; continue; }
 		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
 		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
 		else if(!strcmp(argv[a], "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
 		else if(!strcmp(argv[a], "-o") && a + 1 < argc) out = argv[++a];
-		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix>\n"); return 2; }
+		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template> [-bcNano]]\n"); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
 
@@ -64,7 +69,13 @@ int main(int argc, char **argv) {
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
 	char fpath[4096];
 	snprintf(fpath, sizeof fpath, "%s.frag.gz", out);
-	if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, 0, fpath, &run)) die("kmahip_run_pe"); }
+	if(mt1) {
+		kmahip_assemble_opts ao;
+		memset(&ao, 0, sizeof ao);
+		ao.evalue = 0.05; ao.bcd = 1; ao.order = 1; ao.caller = bc_nano; ao.sig90 = bc_nano;
+		if(input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
+		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
+	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, 0, fpath, &run)) die("kmahip_run_pe"); }
 	else if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, 0, &run)) die("kmahip_run_se");
 
 	/* out.res + out.fsa: names from <prefix>.name, one per line, in template order */
@@ -95,7 +106,7 @@ int main(int argc, char **argv) {
 
 	/* out.frag.gz (the paired run has written it itself: its fragments are in record order, not read order) */
 	int64_t frag_rows = 0;
-	if(!input2 && kmahip_frag_write(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
+	if(!input2 && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, 0, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f\n",
 	        (long long) n, (long long) frag_rows, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4]);
 	kmahip_ws_destroy(ws);

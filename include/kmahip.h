@@ -478,6 +478,14 @@ int kmahip_align_get_stats(kmahip_ws *ws, kmahip_align_stats *st, void *stream);
 int kmahip_scan_set_stats(kmahip_ws *ws, int on);
 int kmahip_scan_get_stats(kmahip_ws *ws, kmahip_scan_stats *st, void *stream);
 
+/* work figures of the last long-read trace call on this workspace (kmahip_align_trace_mt1*, kmahip_run_mt1, or the trace stage
+ * on reads over 1 kb): DP problems solved, their cells (rows x columns; rows x (band + 1) for banded ones), MEMs of the chained
+ * strands, reads */
+typedef struct kmahip_trace_stats {
+	uint64_t problems, dp_cells, mems, reads;
+} kmahip_trace_stats;
+int kmahip_trace_get_stats(kmahip_ws *ws, kmahip_trace_stats *st);
+
 /* Kernel timing: when on, every *_dev call records a HIP event pair around its
  * main kernels (scan_prefilter_kernel, scan_se_kernel, seed_tasks_kernel, align_tasks_kernel) on the caller's stream; get_timing waits
  * for them, returns the summed milliseconds and launch count, and resets. */

@@ -97,6 +97,10 @@ class AlignStats(C.Structure):
     _fields_ = [("lookups", C.c_uint64), ("mem_bases", C.c_uint64), ("dp_cells", C.c_uint64), ("tasks", C.c_uint64)]
 
 
+class TraceStats(C.Structure):
+    _fields_ = [("problems", C.c_uint64), ("dp_cells", C.c_uint64), ("mems", C.c_uint64), ("reads", C.c_uint64)]
+
+
 class KmaHipError(RuntimeError):
     pass
 
@@ -177,6 +181,7 @@ def lib():
                                        C.POINTER(Assembly)]
         L.kmahip_frag_write2.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.kmahip_trace_get_stats.argtypes = [C.c_void_p, C.POINTER(TraceStats)]
         L.kmahip_trim_default.argtypes = [C.POINTER(Trim)]
         L.kmahip_trim_default.restype = None
         L.kmahip_ingest_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Trim), C.POINTER(C.c_void_p)]
@@ -342,6 +347,11 @@ class KmaHipDB:
     def get_align_stats(self, stream=None) -> AlignStats:
         st = AlignStats()
         _check(lib().kmahip_align_get_stats(self.ws, C.byref(st), C.c_void_p(stream or 0)))
+        return st
+
+    def get_trace_stats(self) -> TraceStats:
+        st = TraceStats()
+        _check(lib().kmahip_trace_get_stats(self.ws, C.byref(st)))
         return st
 
     def set_timing(self, on: bool):

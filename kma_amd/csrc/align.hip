@@ -24,6 +24,7 @@
 #include "kmahip_internal.h"
 #include "dna_dev.h"
 #include <cstdlib>
+#include <cstring>
 #include <climits>
 
 #ifdef KMAHIP_DIAG
@@ -2253,6 +2254,13 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(n == 0) return KMAHIP_OK;
 	const int max_len = reads->max_len;
 	if(max_len <= 0 || max_len > (1 << 20)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^20) for the trace stage"); return KMAHIP_EINVAL; }
+	// the pipeline of longtrace.hip (a wavefront per read, DP problems batched by size) instead of one lane per read with its move
+	// matrix in HBM: for reads that carry hundreds of MEMs, or everything with KMAHIP_TRACE=pipeline (=lanes forces this kernel)
+	{
+		const char *mode = getenv("KMAHIP_TRACE");
+		const bool pipeline = mode ? !strcmp(mode, "pipeline") : max_len > 1024;
+		if(pipeline) return kmahip_launch_longtrace(db, ws, reads, tmpl, 0, flag, tmpl_ok, 0, p, out, nullptr, stream);
+	}
 	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
 	const int ncols = max_len + 72;
 	const int ops_cap = 2 * max_len + 256;

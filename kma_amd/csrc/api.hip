@@ -462,3 +462,9 @@ extern "C" int kmahip_align_trace_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip
 	if(c[0]) HIP_TRY(hipMemcpy(out->ops, o.ops, (size_t) c[0] * 4, hipMemcpyDeviceToHost));
 	return KMAHIP_OK;
 }
+
+extern "C" int kmahip_trace_get_stats(kmahip_ws *ws, kmahip_trace_stats *st) {
+	if(!ws || !st) return KMAHIP_EINVAL;
+	st->problems = ws->lt_stats[0]; st->dp_cells = ws->lt_stats[1]; st->mems = ws->lt_stats[2]; st->reads = ws->lt_stats[3];
+	return KMAHIP_OK;
+}

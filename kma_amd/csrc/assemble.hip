@@ -605,6 +605,12 @@ struct ConsArgs {
 	unsigned long long *cover, *aln_len, *depth, *asm_len;      // per template
 	char *cons;                  // pass 2: consensus characters
 	const int64_t *cons_off;     // pass 2: per template offset into cons (-1: none)
+	// the columns of a template are called in segments of CONS_SEG template positions, one workgroup each (a 5 Mb template by
+	// one workgroup took 85 ms)
+	const int32_t *cs_t, *cs_lo; // per segment: template, first position
+	int64_t n_cs;
+	unsigned long long *cs_items;   // pass 1 out: columns (template + insertion) of the segment
+	const int64_t *cs_off;       // pass 2 in: columns of the template in front of the segment
 };
 
 __device__ __forceinline__ unsigned char dev_lower(unsigned char c) { return (c >= 'A' && c <= 'Z') ? (unsigned char) (c + 32) : c; }
@@ -652,26 +658,29 @@ __device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd,
 
 constexpr int CONS_THREADS = 256;
 
-// one workgroup per template with reads; ring order = template position p, then the insertion columns in front of p + 1
+constexpr int CONS_SEG = 8192;
+
+// one workgroup per segment of a template with reads; ring order = template position p, then the insertion columns in front of p + 1
 template <bool WRITE>
 __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs C) {
 	__shared__ int s_scan[CONS_THREADS];
 	__shared__ unsigned long long s_cover, s_aln, s_depth;
 	const int tid = threadIdx.x;
-	const int64_t D = C.db.DB_size;
-	for(int64_t t = 1 + blockIdx.x; t < D; t += gridDim.x) {
+	for(int64_t g = blockIdx.x; g < C.n_cs; g += gridDim.x) {
+		const int t = C.cs_t[g];
 		if(C.seg_start[t] >= C.n_kept) continue;           // uniform per workgroup
 		const int t_len = C.db.tlen[t];
+		const int lo = C.cs_lo[g], hi = min(lo + CONS_SEG, t_len);
 		const int64_t base = C.db.cat_off[t];
 		const uint64_t *ts = C.db.tseq + C.db.tseq_off[t];
-		const int64_t coff = WRITE ? C.cons_off[t] : -1;
+		const int64_t coff = WRITE ? (C.cons_off[t] >= 0 ? C.cons_off[t] + C.cs_off[g] : -1) : -1;
 		if(tid == 0) { s_cover = 0; s_aln = 0; s_depth = 0; }
 		__syncthreads();
 		unsigned long long cover = 0, aln = 0, depth = 0;
 		int64_t running = 0;
-		for(int b = 0; b < t_len; b += CONS_THREADS) {
+		for(int b = lo; b < hi; b += CONS_THREADS) {
 			const int p = b + tid;
-			const bool valid = p < t_len;
+			const bool valid = p < hi;
 			int items = 0;
 			if(valid) {
 				const int np = (p + 1 == t_len) ? 0 : p + 1;
@@ -712,11 +721,14 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 			running += tot;
 		}
 		if(WRITE) {
-			if(tid == 0 && coff >= 0) C.cons[coff + running] = 0;
+			if(tid == 0 && coff >= 0 && hi == t_len) C.cons[coff + running] = 0;
 		} else {
 			atomicAdd(&s_cover, cover); atomicAdd(&s_aln, aln); atomicAdd(&s_depth, depth);
 			__syncthreads();
-			if(tid == 0) { C.cover[t] = s_cover; C.aln_len[t] = s_aln; C.depth[t] = s_depth; C.asm_len[t] = (unsigned long long) running; }
+			if(tid == 0) {
+				atomicAdd(&C.cover[t], s_cover); atomicAdd(&C.aln_len[t], s_aln); atomicAdd(&C.depth[t], s_depth); atomicAdd(&C.asm_len[t], (unsigned long long) running);
+				C.cs_items[g] = (unsigned long long) running;
+			}
 		}
 		__syncthreads();
 	}
@@ -1102,7 +1114,25 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 			G.v.push_back(fig);
 			HIP_TRY(hipMemset(fig, 0, (size_t) 4 * D * sizeof(unsigned long long)));
 			C.cover = fig; C.aln_len = fig + D; C.depth = fig + 2 * D; C.asm_len = fig + 3 * D;
-			const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(D, 1), 256 * 8);
+			std::vector<int32_t> cs_t, cs_lo;
+			std::vector<int64_t> cs_first((size_t) D + 1, 0);
+			for(int64_t t = 1; t < D; ++t) {
+				cs_first[(size_t) t] = (int64_t) cs_t.size();
+				for(int lo = 0; lo < db->h_tlen[(size_t) t]; lo += CONS_SEG) { cs_t.push_back((int32_t) t); cs_lo.push_back(lo); }
+			}
+			cs_first[(size_t) D] = (int64_t) cs_t.size();
+			const int64_t n_cs = (int64_t) cs_t.size();
+			int32_t *d_cs = nullptr;
+			unsigned long long *d_items = nullptr;
+			HIP_TRY(hipMalloc((void **) &d_cs, (size_t) (2 * n_cs + 2) * 4)); G.v.push_back(d_cs);
+			HIP_TRY(hipMalloc((void **) &d_items, (size_t) (2 * n_cs + 2) * 8)); G.v.push_back(d_items);
+			HIP_TRY(hipMemset(d_items, 0, (size_t) (2 * n_cs + 2) * 8));
+			if(n_cs) {
+				HIP_TRY(hipMemcpy(d_cs, cs_t.data(), (size_t) n_cs * 4, hipMemcpyHostToDevice));
+				HIP_TRY(hipMemcpy(d_cs + n_cs, cs_lo.data(), (size_t) n_cs * 4, hipMemcpyHostToDevice));
+			}
+			C.cs_t = d_cs; C.cs_lo = d_cs + n_cs; C.n_cs = n_cs; C.cs_items = d_items; C.cs_off = (const int64_t *) (d_items + n_cs + 1);
+			const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(n_cs, 1), 256 * 16);
 			hipLaunchKernelGGL((consensus_kernel<false>), dim3(blocks), dim3(CONS_THREADS), 0, 0, C);
 			std::vector<unsigned long long> hf((size_t) 4 * D);
 			HIP_TRY(hipMemcpy(hf.data(), fig, hf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1120,6 +1150,17 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 				HIP_TRY(hipMalloc((void **) &dc, (size_t) used + 16)); G.v.push_back(dc);
 				HIP_TRY(hipMalloc((void **) &dco, (size_t) D * 8)); G.v.push_back(dco);
 				HIP_TRY(hipMemcpy(dco, coff.data(), (size_t) D * 8, hipMemcpyHostToDevice));
+				{
+					// columns in front of every segment inside its template
+					std::vector<unsigned long long> items((size_t) n_cs + 1, 0);
+					std::vector<int64_t> soff((size_t) n_cs + 1, 0);
+					if(n_cs) HIP_TRY(hipMemcpy(items.data(), d_items, (size_t) n_cs * 8, hipMemcpyDeviceToHost));
+					for(int64_t t = 1; t < D; ++t) {
+						int64_t run = 0;
+						for(int64_t g = cs_first[(size_t) t]; g < cs_first[(size_t) t + 1]; ++g) { soff[(size_t) g] = run; run += (int64_t) items[(size_t) g]; }
+					}
+					if(n_cs) HIP_TRY(hipMemcpy(d_items + n_cs + 1, soff.data(), (size_t) n_cs * 8, hipMemcpyHostToDevice));
+				}
 				C.cons = dc; C.cons_off = dco;
 				hipLaunchKernelGGL((consensus_kernel<true>), dim3(blocks), dim3(CONS_THREADS), 0, 0, C);
 				HIP_TRY(hipMemcpy(out->consensus + out->consensus_used, dc, (size_t) used, hipMemcpyDeviceToHost));

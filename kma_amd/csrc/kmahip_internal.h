@@ -119,6 +119,7 @@ struct kmahip_ws {
 	// long-read trace pipeline (longtrace.hip): per-wavefront MEM arrays, per-pass pools, queues, scratch, counters
 	void *lt_buf[8];
 	size_t lt_bytes[8];
+	unsigned long long lt_stats[4];   // of the last call: DP problems, DP cells, MEMs chained, reads
 	// slow-path dense scratch
 	int32_t *dense;
 	int64_t dense_slots;

@@ -22,6 +22,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
 #include <unistd.h>
@@ -30,8 +31,9 @@ namespace {
 
 constexpr int LT_TILE = 256;          // query positions looked up per round of the seeding wavefront
 constexpr int LT_NEXT_CAP = 2048;     // MEMs of the winning strand whose chain links / chain order stay in LDS
-constexpr int LT_NCLS = 9;            // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
-                                      // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one lane)
+constexpr int LT_NCLS = 13;           // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
+                                      // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one
+                                      // lane); 9..12 = 4..7 with a move matrix too large for LDS (kept in the workgroup's HBM scratch)
 constexpr int LT_E_WAVE = 8192;       // bytes of move matrix per wavefront in lt_dp_kernel (split between its problems)
 constexpr int LT_TMAX = 127;          // template rows of a problem in lt_dp_kernel
 constexpr int LT_XE_LDS = 32768;      // bytes of move matrix in LDS per workgroup of lt_dpx_kernel
@@ -39,8 +41,8 @@ constexpr int LT_XT_LDS = 2048;       // template rows staged in LDS there
 
 enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_TRIM = 16 };
 // counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..12] class counts,
-// [23] output run pool top
-enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_OUT = 23, LC_N = 24 };
+// [21] DP cells, [22] MEMs of the chained strands (work figures), [23] output run pool top
+enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_OUT = 23, LC_N = 24 };
 
 struct LtRead {               // per read of the pass
 	int64_t first;            // first problem descriptor
@@ -519,8 +521,8 @@ __device__ __forceinline__ int lt_class(int q_l, int t_l, int band, int k, int64
 	// there: only the one-lane form reproduces that
 	const int cfin = ((t_l + q_l) >> 1) - (t_l - 1);
 	const bool stale_scan = band && k == -2 && !(cfin + (band >> 1) < q_l - 1);
-	// (the sweeps keep their move matrix in LDS; a problem beyond that is rare enough for the one-lane form)
-	if(q_l < 256 && !stale_scan && (int64_t) pitch * (t_l + 1) <= LT_XE_LDS) return 4 + (band ? 2 : 0) + (q_l <= 128 ? 0 : 1);
+	if(q_l < 256 && !stale_scan && (int64_t) pitch * (t_l + 1) <= xe_cap)
+		return ((int64_t) pitch * (t_l + 1) <= LT_XE_LDS ? 4 : 9) + (band ? 2 : 0) + (q_l <= 128 ? 0 : 1);
 	return 8;
 }
 
@@ -631,6 +633,7 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 			if((int64_t) first + np > A.prob_cap) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 5ull); go = false; }
 			else {
 				H.first = (int64_t) first; H.n_prob = np; H.mapQ = (int) mapQ; H.status = 1;
+				if(lane == 0) atomicAdd(&A.counters[LC_MEMS], (unsigned long long) n);
 				for(int l0 = 0; l0 < np; l0 += 64) {
 					const int l = l0 + lane;
 					Join J;
@@ -662,6 +665,13 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 						if(l == 0) { H.pos0 = Mm.tS[base + (lds_next ? (int) S.chain[0] : Mm.ch[base])] - 1; H.clip0 = J.clip0; }
 						if(l == nc) H.qe_trail = J.qe;
 						A.prob[first + l] = P;
+					}
+					{
+						// work figures: cells of the DP problems (rows x columns, rows x (band + 1) when banded)
+						const long long cells = dp ? (long long) J.t_l * (J.band ? (J.band | 1) + 1 : J.q_l) : 0;
+						long long tot = cells;
+						for(int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+						if(lane == 0 && tot) atomicAdd(&A.counters[LC_CELLS], (unsigned long long) tot);
 					}
 					// queues per class, one atomic per class and round
 					const int cls = dp && rfit ? lt_class(J.q_l, J.t_l, J.band, J.k, A.xe_cap) : -1;
@@ -1153,12 +1163,13 @@ struct DpxLds {
 // them than there are, and the builds that spilled scalar registers (into lanes of a vector register) hung on gfx950.
 __device__ __forceinline__ int lt_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
 
-// one problem of class 4 + (banded ? 2 : 0) + (XW == 4) per wavefront. Everything outside the sweep is the same for every lane
-// (problem fields read wave-uniform, the walk run by all lanes in step): scalar branches only.
-template <int XW, bool banded>
+// one problem of class (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4) per wavefront; EHBM: the move matrix in the workgroup's HBM
+// scratch instead of LDS (a kernel of its own, not a branch: see the note at lt_walk)
+template <int XW, bool banded, bool EHBM>
 __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
-	constexpr int cls = 4 + (banded ? 2 : 0) + (XW == 4 ? 1 : 0);
+	constexpr int cls = (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4 ? 1 : 0);
 	__shared__ DpxLds S;
+	uint8_t *const Ebuf = EHBM ? A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow) : (uint8_t *) S.E;
 	const int lane = threadIdx.x;
 	if(lane < 25) S.d[lane] = A.d[lane];
 	wave_sync();
@@ -1188,8 +1199,9 @@ __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
 			S.t[i] = (uint8_t) tn(ts, pos);
 		}
 		wave_sync();
-		lt_sweep_x<XW, banded>(A, S.d, P, q, S.E, S.t, ts, tlen_total, score, sm, sn, q_pos);
-		const uint8_t *E = (const uint8_t *) S.E;
+		lt_sweep_x<XW, banded>(A, S.d, P, q, Ebuf, S.t, ts, tlen_total, score, sm, sn, q_pos);
+		if(EHBM) wave_sync_hbm();
+		const uint8_t *E = (const uint8_t *) Ebuf;
 		if(lane == 0) {
 			LT_REC(1, 4);
 			RunOut R;
@@ -1411,6 +1423,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	   (rc = lt_reserve(ws, 6, (size_t) dpx_wgs * ((size_t) xe_cap + 16 * (size_t) xrow))) || (rc = lt_reserve(ws, 7, (LC_N + 1) * 8))) return rc;
 	unsigned long long *counters = (unsigned long long *) ws->lt_buf[7];
 	HIP_TRY(hipMemsetAsync(counters, 0, (LC_N + 1) * 8, stream));
+	for(int i = 0; i < 4; ++i) ws->lt_stats[i] = 0;
 	LtArgs A;
 	A.db = db->dev;
 	A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
@@ -1477,21 +1490,32 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				}
 			}
 			const hipError_t e = hipStreamSynchronize(stream);
-			fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: %s done (%s)\n", (long long) r0, (long long) nb, what, hipGetErrorString(e));
+			static auto t_last = std::chrono::steady_clock::now();
+			const auto t_now = std::chrono::steady_clock::now();
+			fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: %s done (%s), %.2f ms since the stage before\n", (long long) r0, (long long) nb, what, hipGetErrorString(e),
+			        std::chrono::duration<double, std::milli>(t_now - t_last).count());
+			t_last = t_now;
 			fflush(stderr);
 		};
-		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
-		                  c[LC_CNT], c[LC_CNT + 1], c[LC_CNT + 2], c[LC_CNT + 3], c[LC_CNT + 4], c[LC_CNT + 5], c[LC_CNT + 6], c[LC_CNT + 7], c[LC_CNT + 8]); fflush(stderr); }
+		stage("seed");
+		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu | %llu %llu %llu %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
+		                  c[LC_CNT], c[LC_CNT + 1], c[LC_CNT + 2], c[LC_CNT + 3], c[LC_CNT + 4], c[LC_CNT + 5], c[LC_CNT + 6], c[LC_CNT + 7], c[LC_CNT + 8],
+		                  c[LC_CNT + 9], c[LC_CNT + 10], c[LC_CNT + 11], c[LC_CNT + 12]); fflush(stderr); }
 		// grids follow the queue lengths: 4 wavefronts per workgroup of lt_dp_kernel, 64 / W problems per wavefront round
 		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LC_CNT + cls] + per_wg - 1) / per_wg)); };
 		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
 		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
 		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
 		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
-		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full>"); }
-		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full>"); }
-		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded>"); }
-		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded>"); }
+		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full>"); }
+		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full>"); }
+		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded>"); }
+		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded>"); }
+		// (the HBM variants share the per-workgroup scratch of dpx_wgs workgroups)
+		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full, HBM>"); }
+		if(c[LC_CNT + 10]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full, HBM>"); }
+		if(c[LC_CNT + 11]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded, HBM>"); }
+		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded, HBM>"); }
 		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, stream, A); stage("serial"); }
 		hipLaunchKernelGGL(lt_finish_kernel, dim3((unsigned) std::min<int64_t>(fin_wgs, nb)), dim3(64), 0, stream, A);
 		stage("finish");
@@ -1499,6 +1523,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		if(c[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
+		ws->lt_stats[0] += c[LC_PROB]; ws->lt_stats[1] += c[LC_CELLS]; ws->lt_stats[2] += c[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) nb;
 		if(c[LC_STATUS] == 8 || c[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", c[LC_STATUS]); return KMAHIP_EDEVICE; }
 		r0 += nb;
 	}

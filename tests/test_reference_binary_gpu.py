@@ -109,3 +109,54 @@ def test_whole_paired_run_equals_reference_binary(tmp_path):
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 50000
+
+
+def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
+    """BASELINE config C4 through the C host program: `kma -i ont.fq -t_db db -Mt1 1 -bcNano -t 1` vs `kmahip_map ... -Mt1 1 -bcNano`
+    on ONT-like reads (2-12 kb, 10 % errors, both strands, some with foreign chunks, N's, low-quality ends that the trim removes,
+    unmappable reads) against one 400 kb genome with a few repeats, indexed by the reference's own `kma index`."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(11)
+    G = 400000
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    for _ in range(6):                                   # repeats: direct and inverted copies of 300-1500 bases
+        L = int(rng.integers(300, 1500)); a = int(rng.integers(0, G - L)); b = int(rng.integers(0, G - L))
+        seg = genome[a:a + L].copy()
+        genome[b:b + L] = synth.revcomp_codes(seg) if rng.random() < 0.5 else seg
+    fsa = str(tmp_path / "g.fsa")
+    synth.write_fasta(fsa, ["chr test genome"], [genome])
+    prefix = str(tmp_path / "db")
+    subprocess.run([KMA, "index", "-i", fsa, "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = []
+    for L, n, seed in ((2000, 500, 1), (5000, 400, 2), (12000, 120, 3), (300, 200, 4)):
+        reads += synth.make_long_reads(genome, n, read_len=L, sub=0.04, dele=0.03, ins=0.03, seed=seed)
+    quals = []
+    for i, r in enumerate(reads):
+        u = rng.random()
+        if u < 0.03:
+            reads[i] = r = rng.integers(0, 4, len(r), dtype=np.uint8)
+        elif u < 0.08:
+            p = int(rng.integers(0, len(r)))
+            reads[i] = r = np.concatenate([r[:p], rng.integers(0, 4, int(rng.integers(40, 400)), dtype=np.uint8), r[p:]])
+        elif u < 0.12:
+            r = r.copy(); r[rng.integers(0, len(r), int(rng.integers(1, 6)))] = 4; reads[i] = r
+        q = bytearray(b"5" * len(r))
+        if rng.random() < 0.1:                           # a low-quality end: trimmed by stage 1 (-mp 20)
+            k = int(rng.integers(1, 60)); q[-k:] = b"#" * k
+        quals.append(bytes(q))
+    order = rng.permutation(len(reads))
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    fq = str(tmp_path / "ont.fq")
+    with open(fq, "wb") as f:
+        for j, i in enumerate(order):
+            f.write(b"@ont%d some comment\n" % j + lut[reads[i]].tobytes() + b"\n+\n" + quals[i] + b"\n")
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-Mt1", "1", "-bcNano", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-Mt1", "1", "-bcNano"], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
+    assert got.count(b"\n") > 1000
