@@ -1,0 +1,59 @@
+"""BASELINE configs C2 / C5 in small on indexes written by the REFERENCE's own `kma index` (bucket count, key order, value-list
+de-duplication as compress.c leaves them), file to file through examples/kmahip_map against the reference binary run beside it on
+the GPU box: DB-5k (1 000 families x 5 variants) and the per-GPU shape of C5, DB-50k (5 000 families x 10 variants up to 4.5 %
+apart -- a chance k-mer hit in another family brings all its variants: second scan tier, 16-bit value lists near their limit)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kma_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+
+
+def _indel_reads(reads, rng, every):
+    reads = [r for r in reads]
+    for i in rng.choice(len(reads), size=len(reads) // every, replace=False):
+        r = reads[i]
+        parts, j = [], 0
+        while j < len(r):
+            e = min(len(r), j + int(rng.integers(30, 120)))
+            parts.append(r[j:e])
+            u = rng.random()
+            if u < 0.45:
+                parts.append(rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8))
+            elif u < 0.9:
+                e = min(len(r), e + int(rng.integers(1, 4)))
+            j = e
+        reads[i] = np.concatenate(parts)
+    return reads
+
+
+@pytest.mark.parametrize("families,variants,div,n_reads", [(1000, 5, 0.04, 300000), (5000, 10, 0.045, 200000)])
+def test_reference_built_index_whole_run_equals_reference_binary(tmp_path, families, variants, div, n_reads):
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(families, variants, 600, 1500, div, seed=12345)
+    fsa, prefix = str(tmp_path / "db.fsa"), str(tmp_path / "db")
+    synth.write_fasta(fsa, names, seqs)
+    subprocess.run([KMA, "index", "-i", fsa, "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    base, _, _, _ = synth.make_reads(seqs, n_reads, seed=3, random_frac=0.01)
+    reads = _indel_reads(base, np.random.default_rng(5), 40)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, reads, lens=None)
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+                   stderr=subprocess.DEVNULL)
+    ref_res = open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.res", "rb").read() == ref_res
+    assert ref_res.count(b"\n") > min(families * variants * 0.8, n_reads / 10)
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
+    assert got.count(b"\n") > n_reads * 0.3

@@ -160,3 +160,83 @@ def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 1000
+
+
+def _pe_branch_db_and_pairs(rng, n_fam, n):
+    """A database and pairs built to leave the proper-pair branch of alnFragsPenaltyPE (alnfrags.c:1777-1970). Every family has two
+    templates, X and Y = X with a substitution every `gap` bases. A pair takes mate 1 from X and mate 2 from Y, placed so that the
+    substitutions fall mirror-symmetrically in the two mates: on X mate 1 is perfect and mate 2 carries c substitutions, on Y the other
+    way round -- the two templates tie in stage 2 (a couple with both in its list), and in stage 3a each mate scores best on its own
+    template: best + best_r exceeds every single template's joint score by 3 c, beyond PE = 7 once c >= 3 -> an unmated pair."""
+    names, seqs, pairs1, pairs2 = [], [], [], []
+    meta = []
+    for f in range(n_fam):
+        L = int(rng.integers(800, 1500))
+        gap = int(rng.choice([30, 40, 50]))
+        a = int(rng.integers(0, gap))
+        x = rng.integers(0, 4, L, dtype=np.uint8)
+        y = x.copy()
+        pos = np.arange(a, L, gap)
+        y[pos] = (y[pos] + rng.integers(1, 4, len(pos), dtype=np.uint8)) & 3
+        names += [f"fam{f}_X", f"fam{f}_Y"]
+        seqs += [x, y]
+        meta.append((L, gap, a))
+    for i in range(n):
+        f = int(rng.integers(0, n_fam))
+        L, gap, a = meta[f]
+        x, y = seqs[2 * f], seqs[2 * f + 1]
+        st = int(rng.integers(0, L - 400))
+        # mate 2 window [st2, st2 + 150): st + st2 = 2 a - 149 (mod gap) mirrors the substitution pattern
+        st2 = st + 100 + int(rng.integers(0, 150))
+        u = rng.random()
+        if u < 0.7:
+            st2 += (2 * a - 149 - st - st2) % gap
+        st2 = min(st2, L - 150)
+        m1, m2 = x[st:st + 150].copy(), synth.revcomp_codes(y[st2:st2 + 150])
+        if u >= 0.85:                                   # plain pairs, some with errors, to keep the other branches in the mix
+            m2 = synth.revcomp_codes(x[st2:st2 + 150])
+            e = rng.random(150) < 0.02
+            m2 = m2.copy(); m2[e] = (m2[e] + 1) & 3
+        if rng.random() < 0.5:
+            m1, m2 = m2, m1
+        pairs1.append(m1); pairs2.append(np.ascontiguousarray(m2))
+    return names, seqs, np.array(pairs1), np.array(pairs2)
+
+
+def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
+    """The branch of alnFragsPenaltyPE no earlier fixture reached: a couple whose mates score best on different templates (unmated
+    pair: update_Scores_se twice, alnfrags.c:1820-1891). The pairs are built for that; our own pe_kind says the branch is taken
+    by the hundred; `.res`, consensus and `.frag.gz` (every fragment's orientation, score, start, end and template) must equal the
+    reference's. The two single-record branches (:1892-1970) cannot be reached by any input: with one of best_read_score /
+    best_read_score_r zero, compScore (the maximum over templates of mate 1's kept score + mate 2's raw score, :1771-1775) is at
+    least the other one, so `score <= compScore + PE` (:1790) always takes the proper-pair branch first."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    from kma_amd import binding
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(21)
+    names, seqs, m1, m2 = _pe_branch_db_and_pairs(rng, 60, 30000)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    inter = np.empty((2 * len(m1), 150), np.uint8)
+    inter[0::2], inter[1::2] = m1, m2
+    db = binding.KmaHipDB(prefix)
+    try:
+        _, h = db.map_pe(formats.pack_fixed(inter))
+    finally:
+        db.close()
+    kinds = np.bincount(h["kind"], minlength=5)
+    assert kinds[1] > 1000 and kinds[2] > 100 and kinds[3] == 0 and kinds[4] == 0, kinds
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for path, rs, tag in ((tmp_path / "r1.fq", m1, b"/1"), (tmp_path / "r2.fq", m2, b"/2")):
+        with open(path, "wb") as f:
+            for i, r in enumerate(rs):
+                f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
+                   check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
+                   check=True, stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
