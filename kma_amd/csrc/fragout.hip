@@ -4,9 +4,14 @@
 // minus strand), the number of equally good templates, score, start, end, template name, read header.
 #include "kmahip_internal.h"
 #include <zlib.h>
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -26,6 +31,81 @@ int load_names(kmahip_db *db) {
 	return KMAHIP_OK;
 }
 
+// Rows [0, n_rows) written to `path` in order. The rows are cut into blocks; a few threads format blocks side by side and, for
+// a .gz, deflate each one as a gzip member of its own (level 1 like the reference's deflateInit2, filebuff.c:189); the caller's
+// thread writes the finished blocks in order. A file of concatenated members is a gzip file (RFC 1952 2.2): zcat, gzread and
+// the reference's own reader give back the same bytes as one stream would.
+struct RowBlock { std::string data; bool ready = false; };
+
+template <class Fmt>
+int write_rows(const char *path, size_t n_rows, Fmt fmt) {
+	const size_t plen = strlen(path);
+	const bool gz = plen > 3 && !strcmp(path + plen - 3, ".gz");
+	FILE *f = fopen(path, "wb");
+	if(!f) { kmahip_set_error("cannot create %s", path); return KMAHIP_EIO; }
+	const size_t BLOCK = 16384;
+	const size_t n_blocks = (n_rows + BLOCK - 1) / BLOCK;
+	const char *e = getenv("KMAHIP_IO_THREADS");
+	const int hw = (int) std::thread::hardware_concurrency();
+	int nt = e ? atoi(e) : std::min(16, hw > 0 ? hw : 1);
+	nt = (int) std::max<size_t>(1, std::min<size_t>((size_t) std::max(nt, 1), n_blocks));
+	const size_t WINDOW = (size_t) nt * 4;                // blocks in flight: bounds the memory held
+	std::vector<RowBlock> ring(WINDOW);
+	std::mutex mu;
+	std::condition_variable cv;
+	size_t written = 0;                                  // blocks [0, written) are on disk and their ring slots free
+	std::atomic<size_t> next{0};
+	std::atomic<int> failed{0};
+	auto worker = [&]() {
+		std::string raw;
+		for(;;) {
+			const size_t b = next.fetch_add(1);
+			if(b >= n_blocks || failed.load()) return;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return b < written + WINDOW || failed.load(); }); }
+			if(failed.load()) return;
+			raw.clear();
+			const size_t r1 = std::min(n_rows, (b + 1) * BLOCK);
+			for(size_t r = b * BLOCK; r < r1; ++r) fmt(r, raw);
+			RowBlock &B = ring[b % WINDOW];
+			if(gz) {
+				z_stream z;
+				memset(&z, 0, sizeof z);
+				if(deflateInit2(&z, 1, Z_DEFLATED, 31, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed.store(1); cv.notify_all(); return; }
+				B.data.resize(deflateBound(&z, (uLong) raw.size()));
+				z.next_in = (Bytef *) raw.data(); z.avail_in = (uInt) raw.size();
+				z.next_out = (Bytef *) &B.data[0]; z.avail_out = (uInt) B.data.size();
+				const int zr = deflate(&z, Z_FINISH);
+				B.data.resize(B.data.size() - z.avail_out);
+				deflateEnd(&z);
+				if(zr != Z_STREAM_END) { failed.store(1); cv.notify_all(); return; }
+			} else B.data.swap(raw);
+			{ std::lock_guard<std::mutex> lk(mu); B.ready = true; }
+			cv.notify_all();
+		}
+	};
+	std::vector<std::thread> pool;
+	for(int t = 0; t < nt; ++t) pool.emplace_back(worker);
+	int rc = KMAHIP_OK;
+	for(size_t b = 0; b < n_blocks; ++b) {
+		RowBlock &B = ring[b % WINDOW];
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return B.ready || failed.load(); }); }
+		if(failed.load()) { rc = KMAHIP_EIO; break; }
+		if(fwrite(B.data.data(), 1, B.data.size(), f) != B.data.size()) { failed.store(1); rc = KMAHIP_EIO; }
+		{ std::lock_guard<std::mutex> lk(mu); B.ready = false; written = b + 1; }
+		cv.notify_all();
+		if(rc) break;
+	}
+	cv.notify_all();
+	for(std::thread &th : pool) th.join();
+	if(n_blocks == 0 && gz) {                             // an empty .gz is still a gzip file
+		gzFile g = gzdopen(dup(fileno(f)), "wb1");
+		if(!g || gzclose(g) != Z_OK) rc = KMAHIP_EIO;
+	}
+	if(fclose(f) != 0) rc = KMAHIP_EIO;
+	if(rc) kmahip_set_error("write to %s failed", path);
+	return rc;
+}
+
 }  // namespace
 
 extern "C" int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
@@ -43,53 +123,70 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 	if(max_frag <= 0) max_frag = 1000000;
 	const int64_t n = reads->n_reads;
 	// the order assemble_KMA meets the fragments in: templates ascending; inside a template the chunks of max_frag filed
-	// fragments in stream order, each chunk back to front (conclave.c:164-166, 194)
-	struct Key { int32_t t; int64_t chunk, rank, read; };
-	std::vector<Key> keys;
-	int64_t rank = 0;
+	// fragments in stream order, each chunk back to front (conclave.c:164-166, 194). A counting sort over the templates keeps
+	// the stream order inside each one; the chunks are then turned round in place. (order 1: the single thread of `-Mt1`
+	// writes the rows as they come.)
+	const size_t n_t = db->h_names.size();
+	std::vector<int64_t> t_rows(n_t + 2, 0);
 	for(int64_t i = 0; i < n; ++i) {
 		if(tmpl[i] == 0) continue;
-		const int64_t r = rank++;
-		if(trace_stats[10 * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
-		keys.push_back(Key{abs(tmpl[i]), order ? 0 : r / max_frag, order ? -r : r, i});      // (order 1: the single thread of `-Mt1` writes them as they come)
+		const size_t t = (size_t) abs(tmpl[i]);
+		if(t > n_t) { kmahip_set_error("template %zu has no name in %s.name", t, db->prefix.c_str()); return KMAHIP_EFORMAT; }
+		if(trace_stats[10 * i + 3] != 0) ++t_rows[t + 1];
 	}
-	std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-		if(a.t != b.t) return a.t < b.t;
-		if(a.chunk != b.chunk) return a.chunk < b.chunk;
-		return a.rank > b.rank;
-	});
-	const size_t plen = strlen(path);
-	const bool gz = plen > 3 && !strcmp(path + plen - 3, ".gz");
-	gzFile g = gzopen(path, gz ? "wb1" : "wbT");            // level 1 like the reference's deflateInit2 (filebuff.c:189); T = plain
-	if(!g) { kmahip_set_error("cannot create %s", path); return KMAHIP_EIO; }
-	gzbuffer(g, 1 << 20);
-	static const char bases[] = "ACGTN";
-	std::string row;
-	for(const Key &k : keys) {
-		const int64_t i = k.read;
+	for(size_t t = 1; t < t_rows.size(); ++t) t_rows[t] += t_rows[t - 1];        // t_rows[t] = first row of template t
+	const size_t n_rows = (size_t) t_rows[n_t + 1];
+	std::vector<int64_t> row_read(n_rows), row_rank(order ? 0 : n_rows);
+	{
+		std::vector<int64_t> fill(t_rows.begin(), t_rows.end() - 1);
+		int64_t rank = 0;                                   // position among the filed reads of the whole run
+		for(int64_t i = 0; i < n; ++i) {
+			if(tmpl[i] == 0) continue;
+			const size_t t = (size_t) abs(tmpl[i]);
+			const int64_t r = rank++;
+			if(trace_stats[10 * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
+			const size_t at = (size_t) fill[t]++;
+			row_read[at] = i;
+			if(!order) row_rank[at] = r;
+		}
+	}
+	if(!order) {
+		for(size_t t = 1; t <= n_t; ++t) {
+			size_t a = (size_t) t_rows[t];
+			const size_t b = (size_t) t_rows[t + 1];
+			while(a < b) {
+				const int64_t chunk = row_rank[a] / max_frag;
+				size_t c = a + 1;
+				while(c < b && row_rank[c] / max_frag == chunk) ++c;
+				std::reverse(row_read.begin() + (ptrdiff_t) a, row_read.begin() + (ptrdiff_t) c);
+				a = c;
+			}
+		}
+	}
+	auto fmt = [&](size_t r, std::string &out) {
+		static const char bases[] = "ACGTN";
+		static const char comp[] = "TGCAN";
+		const int64_t i = row_read[r];
 		const int L = reads->len[i];
 		const uint64_t *w = reads->seq + reads->seq_off[i];
 		const int32_t *N = reads->N + reads->N_off[i];
 		const int nN = (int) (reads->N_off[i + 1] - reads->N_off[i]);
-		row.assign((size_t) L, 'A');
-		for(int p = 0; p < L; ++p) row[(size_t) p] = bases[(w[p >> 5] >> (62 - ((p & 31) << 1))) & 3];
-		for(int x = 0; x < nN; ++x) row[(size_t) N[x]] = 'N';
 		const bool flip = ((rc[i] & 1) != 0) != (tmpl[i] < 0);
-		if(flip) {
-			std::reverse(row.begin(), row.end());
-			for(char &c : row) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-		}
-		if((size_t) k.t > db->h_names.size()) { gzclose(g); kmahip_set_error("template %d has no name in %s.name", k.t, db->prefix.c_str()); return KMAHIP_EFORMAT; }
+		const size_t at = out.size();
+		out.resize(at + (size_t) L);
+		char *o = &out[at];
+		if(!flip) for(int p = 0; p < L; ++p) o[p] = bases[(w[p >> 5] >> (62 - ((p & 31) << 1))) & 3];
+		else for(int p = 0; p < L; ++p) o[L - 1 - p] = comp[(w[p >> 5] >> (62 - ((p & 31) << 1))) & 3];
+		for(int x = 0; x < nN; ++x) o[flip ? L - 1 - N[x] : N[x]] = 'N';
 		char num[96];
-		snprintf(num, sizeof num, "\t%d\t%d\t%d\t%d\t", n_hits[i], trace_stats[10 * i], trace_stats[10 * i + 1], trace_stats[10 * i + 2]);
-		row += num;
-		row += db->h_names[(size_t) k.t - 1];
-		row += '\t';
-		row.append(read_names + read_name_off[i]);              // NUL-terminated
-		row += '\n';
-		if(gzwrite(g, row.data(), (unsigned) row.size()) != (int) row.size()) { gzclose(g); kmahip_set_error("write to %s failed", path); return KMAHIP_EIO; }
-	}
-	if(gzclose(g) != Z_OK) { kmahip_set_error("closing %s failed", path); return KMAHIP_EIO; }
-	if(rows) *rows = (int64_t) keys.size();
+		const int m = snprintf(num, sizeof num, "\t%d\t%d\t%d\t%d\t", n_hits[i], trace_stats[10 * i], trace_stats[10 * i + 1], trace_stats[10 * i + 2]);
+		out.append(num, (size_t) m);
+		out += db->h_names[(size_t) abs(tmpl[i]) - 1];
+		out += '\t';
+		out.append(read_names + read_name_off[i]);              // NUL-terminated
+		out += '\n';
+	};
+	if((e = write_rows(path, n_rows, fmt))) return e;
+	if(rows) *rows = (int64_t) n_rows;
 	return KMAHIP_OK;
 }

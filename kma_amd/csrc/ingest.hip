@@ -8,10 +8,17 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -52,6 +59,7 @@ struct RawBuf {
 	uint8_t *data() const { return p; }
 	size_t size() const { return cap; }
 	void resize(size_t n) { if(n > cap) { p = (uint8_t *) realloc(p, n); cap = p ? n : 0; } }
+	void release() { free(p); p = nullptr; cap = 0; }
 };
 
 // A stream of decompressed bytes with byte-level access (zlib reads plain files as they are)
@@ -101,10 +109,31 @@ struct Rec {
 	std::vector<uint8_t> seq, qual;   // codes (0-4, 8 for bytes outside the table) and raw quality bytes
 };
 
-// one FASTQ record located in a stream buffer (offsets from the start of the buffer)
+// one FASTQ record located in the bytes of a chunk (which lives until the record has been packed)
 struct Span {
-	size_t name = 0, name_len = 0, seq = 0, seq_len = 0, qual = 0;
+	const uint8_t *name = nullptr, *seq = nullptr, *qual = nullptr;
+	uint32_t name_len = 0, seq_len = 0;
 	bool got = false;
+};
+
+// array that grows without being zero-filled and without a copy constructor in the way (mremap does the large moves)
+template <class T> struct Arr {
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	Arr() = default;
+	Arr(const Arr &) = delete;
+	Arr &operator=(const Arr &) = delete;
+	~Arr() { free(p); }
+	T *data() const { return p; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	void clear() { n = 0; }
+	void reserve(size_t m) { if(m > cap) { size_t c = std::max(m, cap + cap / 2); p = (T *) realloc(p, c * sizeof(T)); if(!p) abort(); cap = c; } }
+	void resize_raw(size_t m) { reserve(m); n = m; }
+	void push_back(const T &v) { if(n == cap) reserve(std::max<size_t>(1024, n + 1)); p[n++] = v; }
+	void append(const T *q, size_t m) { if(m) { reserve(n + m); memcpy(p + n, q, m * sizeof(T)); n += m; } }
+	T &operator[](size_t i) const { return p[i]; }
+	T &back() const { return p[n - 1]; }
 };
 
 // what one worker thread makes of its share of the records; appended to the batch in thread order
@@ -120,10 +149,118 @@ struct alignas(128) Part {      // own cache lines: neighbouring threads push in
 	void clear() { seq.clear(); len.clear(); N.clear(); nN.clear(); names.clear(); name_len.clear(); pair.clear(); records = 0; max_len = 0; }
 };
 
+// A piece of the decompressed input. The bytes [lo, hi) of base are data; a streamed chunk keeps room in front of lo for
+// the unfinished record of the chunk before it.
+struct Chunk {
+	uint8_t *base = nullptr;
+	size_t cap = 0, lo = 0, hi = 0;
+	bool mapped = false, last = false;
+	int64_t spans_end = 0;          // records located in it end here (position in the stream of records)
+	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else free(base); }
+};
+
+// The input file as chunks: a plain regular file is mapped whole (one chunk); anything else is read through zlib by a
+// thread of its own that stays a few chunks ahead of the parser (so inflating overlaps with everything after it).
+struct Feeder {
+	size_t CHUNK = 32u << 20, HEAD = 1u << 20;      // (KMAHIP_INGEST_CHUNK: smaller ones for the tests)
+	static constexpr size_t AHEAD = 4;
+	gzFile gz = nullptr;
+	Chunk *whole = nullptr;
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Chunk *> ready;
+	bool done = false, stop = false;
+
+	bool open(const char *path) {
+		const int fd = ::open(path, O_RDONLY);
+		if(fd < 0) return false;
+		if(const char *c = getenv("KMAHIP_INGEST_CHUNK")) { CHUNK = (size_t) std::max(64, atoi(c)); HEAD = std::max<size_t>(16, CHUNK / 32); }
+		struct stat sb;
+		uint8_t magic[2] = {0, 0};
+		const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+		if(regular && (sb.st_size < 2 || (pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)))) {
+			whole = new Chunk();
+			whole->last = true;
+			if(sb.st_size > 0) {
+				void *m = mmap(nullptr, (size_t) sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+				if(m == MAP_FAILED) { delete whole; whole = nullptr; }
+				else {
+					madvise(m, (size_t) sb.st_size, MADV_SEQUENTIAL);
+					whole->base = (uint8_t *) m; whole->cap = (size_t) sb.st_size; whole->hi = (size_t) sb.st_size; whole->mapped = true;
+				}
+			}
+			if(whole) { ::close(fd); return true; }
+		}
+		gz = gzdopen(fd, "rb");
+		if(!gz) { ::close(fd); return false; }
+		gzbuffer(gz, 1 << 20);
+		th = std::thread([this] { run(); });
+		return true;
+	}
+	void run() {
+		for(;;) {
+			Chunk *c = new Chunk();
+			c->cap = HEAD + CHUNK;
+			c->base = (uint8_t *) malloc(c->cap);
+			c->lo = c->hi = HEAD;
+			while(c->base && c->hi < c->cap) {
+				const int got = gzread(gz, c->base + c->hi, (unsigned) (c->cap - c->hi));
+				if(got <= 0) { c->last = true; break; }
+				c->hi += (size_t) got;
+			}
+			if(!c->base) c->last = true;
+			const bool last = c->last;
+			std::unique_lock<std::mutex> lk(mu);
+			ready.push_back(c);
+			if(last) done = true;
+			cv.notify_all();
+			if(last) return;
+			cv.wait(lk, [this] { return ready.size() < AHEAD || stop; });
+			if(stop) return;
+		}
+	}
+	// the next chunk, nullptr after the last one
+	Chunk *pop() {
+		if(whole) { Chunk *c = whole; whole = nullptr; return c; }
+		if(!gz) return nullptr;
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [this] { return !ready.empty() || done; });
+		if(ready.empty()) return nullptr;
+		Chunk *c = ready.front();
+		ready.pop_front();
+		cv.notify_all();
+		return c;
+	}
+	void close() {
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		cv.notify_all();
+		if(th.joinable()) th.join();
+		for(Chunk *c : ready) delete c;
+		ready.clear();
+		delete whole; whole = nullptr;
+		if(gz) gzclose(gz);
+		gz = nullptr;
+	}
+};
+
+// one mate file of a FASTQ input: its chunks, how far they have been cut into records, and the records waiting to be packed
+struct Mate {
+	Feeder feed;
+	std::deque<Chunk *> live;      // chunks that located records still point into; back() is the one being cut
+	size_t pos = 0;                 // offset in live.back(): everything before it has been located
+	bool eof = false;               // no further record will come
+	std::vector<Span> spans;        // located, not yet packed: [head, size)
+	size_t head = 0;
+	int64_t spans_base = 0;         // position of spans[0] in the stream of records
+	~Mate() { for(Chunk *c : live) delete c; }
+};
+
 }  // namespace
 
 struct kmahip_ingest {
-	Stream s[2];
+	Stream s[2];                // FASTA input, and the first bytes of any input (format, phred scale)
+	Mate m[2];                  // FASTQ input
 	bool paired = false, fastq = true;
 	kmahip_trim trim;
 	int phred = 33;
@@ -131,15 +268,14 @@ struct kmahip_ingest {
 	bool malformed = false, reported = false;      // a record that does not start with '@': everything before it is delivered, then KMAHIP_EFORMAT once
 	int64_t n_read = 0, n_kept = 0;
 	// current batch
-	std::vector<uint64_t> seq;
-	std::vector<int64_t> seq_off, N_off, name_off;
-	std::vector<int32_t> len, N;
-	std::vector<char> names;
-	std::vector<uint8_t> pair;
+	Arr<uint64_t> seq;
+	Arr<int64_t> seq_off, N_off, name_off;
+	Arr<int32_t> len, N;
+	Arr<char> names;
+	Arr<uint8_t> pair;
 	// kept between batches: the worker threads' parts and the located records (steady state allocates nothing -- eight
 	// threads growing fresh vectors every batch spent 6x the packing time inside the allocator)
 	std::vector<Part> parts;
-	std::vector<Span> spans[2];
 };
 
 namespace {
@@ -166,40 +302,86 @@ int guess_phred(const uint8_t *buff0, size_t bytes) {
 	return maxlen <= 301 ? scale : 33;
 }
 
-// FileBuffgetFq, seqparse.c:241-403: locate the next record. false at the end of the input (or on a truncated / malformed
-// record). Every byte of the sequence line counts, also the '\r' of a DOS file (code 8): the reference's chomp loop stops at
-// the newline code it has just stored (:322-326), so such a base is only lost later, to the quality trim ('\r' < '!').
-bool locate_fq(Stream &s, Span &r, bool *malformed) {
-	r = Span();
-	if(s.ensure(1) == 0) return false;
-	if(*s.at() != '@') { *malformed = true; return false; }       // "Malformed input." (seqparse.c:256-260): the reference stops reading here
-	size_t n = s.line_len();
-	if(n == SIZE_MAX) return false;
+// FileBuffgetFq, seqparse.c:241-403, over bytes in memory: the record at p. `final`: the input ends at e.
+//   LOC_REC        a record, *next = where the following one starts
+//   LOC_MORE       the record runs past e and the input goes on (never with final)
+//   LOC_END        the input ends here, or inside this record (which the reference drops)
+//   LOC_MALFORMED  the record does not start with '@' ("Malformed input.", seqparse.c:256-260): the reference stops reading
+// Every byte of the sequence line counts, also the '\r' of a DOS file (code 8): the reference's chomp loop stops at the newline
+// code it has just stored (:322-326), so such a base is only lost later, to the quality trim ('\r' < '!').
+enum { LOC_REC = 1, LOC_MORE = 0, LOC_END = 2, LOC_MALFORMED = -1 };
+int locate_mem(const uint8_t *p, const uint8_t *e, bool final, Span &r, const uint8_t **next) {
+	const int out = final ? LOC_END : LOC_MORE;
+	if(p == e) return out;
+	if(*p != '@') return LOC_MALFORMED;
+	const uint8_t *nl = (const uint8_t *) memchr(p, '\n', (size_t) (e - p));
+	if(!nl) return out;
 	{	// header: everything up to the newline, chomped of trailing white space; the '@' is not part of the name
-		size_t e = n;
-		while(e > 0 && isspace(s.at()[e - 1])) --e;
-		r.name = s.pos + 1; r.name_len = e > 0 ? e - 1 : 0;
-		s.pos += n + 1;
+		const uint8_t *h = nl;
+		while(h > p && isspace(h[-1])) --h;
+		r.name = p + 1; r.name_len = h > p ? (uint32_t) (h - p - 1) : 0;
 	}
-	s.ensure(1);
-	n = s.line_len();
-	if(n == SIZE_MAX) return false;
-	r.seq = s.pos; r.seq_len = n;
-	s.pos += n + 1;
-	s.ensure(1);
-	n = s.line_len();                                                   // the '+' line
-	if(n == SIZE_MAX) return false;
-	s.pos += n + 1;
+	const uint8_t *q = nl + 1;
+	nl = (const uint8_t *) memchr(q, '\n', (size_t) (e - q));
+	if(!nl) return out;
+	if((size_t) (nl - q) > (size_t) INT_MAX) return LOC_MALFORMED;
+	r.seq = q; r.seq_len = (uint32_t) (nl - q);
+	q = nl + 1;
+	nl = (const uint8_t *) memchr(q, '\n', (size_t) (e - q));            // the '+' line
+	if(!nl) return out;
+	q = nl + 1;
 	// quality: exactly as many raw bytes as the sequence line had, then on to the next newline
-	if(s.ensure(r.seq_len) < r.seq_len) return false;
-	r.qual = s.pos;
-	s.pos += r.seq_len;
-	s.ensure(1);
-	n = s.line_len();
+	if((size_t) (e - q) < r.seq_len) return out;
+	r.qual = q;
+	q += r.seq_len;
+	nl = (const uint8_t *) memchr(q, '\n', (size_t) (e - q));
 	r.got = true;
-	if(n == SIZE_MAX) { s.pos = s.end; return true; }                   // last record without a final newline
-	s.pos += n + 1;
-	return true;
+	if(!nl) {
+		if(!final) return LOC_MORE;
+		*next = e;                                                       // last record without a final newline
+		return LOC_REC;
+	}
+	*next = nl + 1;
+	return LOC_REC;
+}
+
+// records from p on until one starts at or after lim (or the bytes run out): appended to spans. Returns the status of the
+// locate that stopped the loop (LOC_REC: stopped at lim), *stop = where it stopped.
+int locate_range(const uint8_t *p, const uint8_t *lim, const uint8_t *e, bool final, std::vector<Span> &spans, const uint8_t **stop) {
+	int st = LOC_REC;
+	while(p < lim) {
+		Span r;
+		const uint8_t *next = nullptr;
+		st = locate_mem(p, e, final, r, &next);
+		if(st != LOC_REC) break;
+		spans.push_back(r);
+		p = next;
+	}
+	*stop = p;
+	return st;
+}
+
+// A guess at the first record starting in [c, lim): a line that begins with '@' whose next line but one begins with '+'.
+// (In a four-line FASTQ file only header lines are such lines; whether the guess was right is checked by the caller against
+// where the records before it really end, so a wrong one costs time, never a different result.)
+const uint8_t *guess_start(const uint8_t *lo, const uint8_t *c, const uint8_t *lim, const uint8_t *e) {
+	const uint8_t *q = c;
+	if(q > lo && q[-1] != '\n') {
+		const uint8_t *nl = (const uint8_t *) memchr(q, '\n', (size_t) (e - q));
+		if(!nl) return nullptr;
+		q = nl + 1;
+	}
+	while(q < lim) {
+		const uint8_t *l1 = (const uint8_t *) memchr(q, '\n', (size_t) (e - q));
+		if(!l1) return nullptr;
+		if(*q == '@') {
+			const uint8_t *l2 = (const uint8_t *) memchr(l1 + 1, '\n', (size_t) (e - l1 - 1));
+			if(!l2) return nullptr;
+			if(l2 + 1 < e && l2[1] == '+') return q;
+		}
+		q = l1 + 1;
+	}
+	return nullptr;
 }
 
 // FileBuffgetFsa, seqparse.c:66-159: header line, then every byte the table knows up to the next '>'
@@ -334,7 +516,7 @@ void append_raw(Part &P, const uint8_t *raw, int L, const char *name, size_t nam
 }
 
 // trim, gate and pack records [a, b) of a located batch (run_input / run_input_PE, runinput.c:404-424, 515-549)
-void pack_fastq(const kmahip_ingest *in, const std::vector<Span> *spans, size_t a, size_t b, Part &P) {
+void pack_fastq(const kmahip_ingest *in, const Span *const *spans, size_t a, size_t b, Part &P) {
 	P.clear();
 	const kmahip_trim &T = in->trim;
 	const double *prob = g_prob.p - in->phred;          // indexed by the raw quality byte
@@ -347,7 +529,7 @@ void pack_fastq(const kmahip_ingest *in, const std::vector<Span> *spans, size_t 
 			const int minPhred = in->phred + T.min_phred;
 			for(int m = 0; m < mates; ++m) {
 				const Span &r = spans[m][i];
-				const uint8_t *q = in->s[m].buf.data() + r.qual;
+				const uint8_t *q = r.qual;
 				const int L = r.got ? (int) r.seq_len : 0;
 				if(T.max_len < L) continue;
 				int s0 = 0, e0 = L;
@@ -358,8 +540,7 @@ void pack_fastq(const kmahip_ingest *in, const std::vector<Span> *spans, size_t 
 			const bool ok0 = T.min_len <= len[0], ok1 = in->paired && T.min_len <= len[1];
 			auto put = [&](int m, uint8_t pair) {
 				const Span &r = spans[m][i];
-				const uint8_t *base = in->s[m].buf.data();
-				append_raw(P, base + r.seq + st[m], en[m] - st[m], (const char *) base + r.name, r.got ? r.name_len : 0, pair);
+				append_raw(P, r.seq + st[m], en[m] - st[m], (const char *) r.name, r.got ? r.name_len : 0, pair);
 			};
 			if(ok0 && ok1) { put(0, 1); put(1, 2); }
 			else if(ok0) put(0, 0);
@@ -370,17 +551,16 @@ void pack_fastq(const kmahip_ingest *in, const std::vector<Span> *spans, size_t 
 		}
 		for(int m = 0; m < mates; ++m) {
 			const Span &r = spans[m][i];
-			const uint8_t *base = in->s[m].buf.data();
 			const int L = r.got ? (int) r.seq_len : 0;       // a mate file that ran out yields empty mates (the `|` at :516)
 			codes[m].resize((size_t) L);
-			for(int x = 0; x < L; ++x) codes[m][(size_t) x] = g_trans.t[base[r.seq + (size_t) x]];
-			len[m] = phred_stat(codes[m].data(), base + r.qual, L, prob, in->phred + T.min_phred, T.min_q, T.hardmask_q, T.min_len,
+			for(int x = 0; x < L; ++x) codes[m][(size_t) x] = g_trans.t[r.seq[x]];
+			len[m] = phred_stat(codes[m].data(), r.qual, L, prob, in->phred + T.min_phred, T.min_q, T.hardmask_q, T.min_len,
 			                    T.max_len, &st[m], &en[m]);
 		}
 		const bool ok0 = T.min_len <= len[0], ok1 = in->paired && T.min_len <= len[1];
 		auto put = [&](int m, uint8_t pair) {
 			const Span &r = spans[m][i];
-			append_read(P, codes[m].data() + st[m], en[m] - st[m], (const char *) in->s[m].buf.data() + r.name, r.got ? r.name_len : 0, pair);
+			append_read(P, codes[m].data() + st[m], en[m] - st[m], (const char *) r.name, r.got ? r.name_len : 0, pair);
 		};
 		if(ok0 && ok1) { put(0, 1); put(1, 2); }
 		else if(ok0) put(0, 0);
@@ -392,16 +572,160 @@ void pack_fastq(const kmahip_ingest *in, const std::vector<Span> *spans, size_t 
 
 void append_part(kmahip_ingest *in, const Part &P) {
 	const size_t r0 = in->len.size();
-	in->seq.insert(in->seq.end(), P.seq.begin(), P.seq.end());
-	in->len.insert(in->len.end(), P.len.begin(), P.len.end());
-	in->N.insert(in->N.end(), P.N.begin(), P.N.end());
-	in->names.insert(in->names.end(), P.names.begin(), P.names.end());
-	in->pair.insert(in->pair.end(), P.pair.begin(), P.pair.end());
+	in->seq.append(P.seq.data(), P.seq.size());
+	in->len.append(P.len.data(), P.len.size());
+	in->N.append(P.N.data(), P.N.size());
+	in->names.append(P.names.data(), P.names.size());
+	in->pair.append(P.pair.data(), P.pair.size());
 	for(size_t i = 0; i < P.len.size(); ++i) {
 		in->seq_off.push_back(in->seq_off[r0 + i] + ((P.len[i] + 31) >> 5) + 1);
 		in->N_off.push_back(in->N_off[r0 + i] + P.nN[i]);
 		in->name_off.push_back(in->name_off[r0 + i] + P.name_len[i]);
 	}
+}
+
+// the parts of one round of packing appended to the batch, each by the thread that made it
+void append_parts(kmahip_ingest *in, const std::vector<Part> &parts, int nt) {
+	std::vector<size_t> r0((size_t) nt + 1), w0((size_t) nt + 1), n0((size_t) nt + 1), c0((size_t) nt + 1);
+	r0[0] = in->len.size(); w0[0] = in->seq.size(); n0[0] = in->N.size(); c0[0] = in->names.size();
+	for(int t = 0; t < nt; ++t) {
+		const Part &P = parts[(size_t) t];
+		r0[(size_t) t + 1] = r0[(size_t) t] + P.len.size(); w0[(size_t) t + 1] = w0[(size_t) t] + P.seq.size();
+		n0[(size_t) t + 1] = n0[(size_t) t] + P.N.size(); c0[(size_t) t + 1] = c0[(size_t) t] + P.names.size();
+	}
+	in->len.resize_raw(r0[(size_t) nt]); in->pair.resize_raw(r0[(size_t) nt]);
+	in->seq_off.resize_raw(r0[(size_t) nt] + 1); in->N_off.resize_raw(r0[(size_t) nt] + 1); in->name_off.resize_raw(r0[(size_t) nt] + 1);
+	in->seq.resize_raw(w0[(size_t) nt]); in->N.resize_raw(n0[(size_t) nt]); in->names.resize_raw(c0[(size_t) nt]);
+	auto copy = [&](int t) {
+		const Part &P = parts[(size_t) t];
+		const size_t r = r0[(size_t) t];
+		if(!P.seq.empty()) memcpy(in->seq.data() + w0[(size_t) t], P.seq.data(), P.seq.size() * sizeof(uint64_t));
+		if(!P.len.empty()) memcpy(in->len.data() + r, P.len.data(), P.len.size() * sizeof(int32_t));
+		if(!P.N.empty()) memcpy(in->N.data() + n0[(size_t) t], P.N.data(), P.N.size() * sizeof(int32_t));
+		if(!P.names.empty()) memcpy(in->names.data() + c0[(size_t) t], P.names.data(), P.names.size());
+		if(!P.pair.empty()) memcpy(in->pair.data() + r, P.pair.data(), P.pair.size());
+		int64_t so = (int64_t) w0[(size_t) t], no = (int64_t) n0[(size_t) t], co = (int64_t) c0[(size_t) t];
+		for(size_t i = 0; i < P.len.size(); ++i) {
+			so += ((P.len[i] + 31) >> 5) + 1; no += P.nN[i]; co += P.name_len[i];
+			in->seq_off[r + i + 1] = so; in->N_off[r + i + 1] = no; in->name_off[r + i + 1] = co;
+		}
+	};
+	std::vector<std::thread> pool;
+	for(int t = 1; t < nt; ++t) pool.emplace_back(copy, t);
+	copy(0);
+	for(std::thread &th : pool) th.join();
+}
+
+// Cut more of a mate file into records: one wave of bytes, its regions located by `threads` threads side by side and
+// stitched together in order. A region's records are taken as they are when the region began exactly where the records
+// before it end; otherwise that stretch is located again from the true position, one record after the other -- the result is
+// always that of reading the file front to back. Returns false when nothing more will come.
+bool fill_wave(kmahip_ingest *in, Mate &M) {
+	// (KMAHIP_INGEST_REGION: the least bytes a region takes, 256 KiB; tiny ones make small test files take every path here)
+	const size_t region_min = getenv("KMAHIP_INGEST_REGION") ? (size_t) std::max(16, atoi(getenv("KMAHIP_INGEST_REGION"))) : (256u << 10);
+	size_t wave = (size_t) in->threads * std::min<size_t>(8u << 20, region_min * 32);
+	struct Region { const uint8_t *lim = nullptr, *start = nullptr, *stop = nullptr; int st = LOC_REC; std::vector<Span> spans; };
+	while(!M.eof) {
+		if(M.live.empty() || (M.live.back()->hi - M.pos < std::min<size_t>(64u << 10, region_min) && !M.live.back()->last)) {
+			// the next chunk, with what is left of this one (an unfinished record) in front of it
+			Chunk *c = M.feed.pop();
+			Chunk *old = M.live.empty() ? nullptr : M.live.back();
+			const size_t tail = old ? old->hi - M.pos : 0;
+			if(!c) {
+				if(!old) { M.eof = true; break; }
+				old->last = true;                              // (a stream that ended on a chunk boundary)
+			} else {
+				if(tail > c->lo) {                              // a record longer than the room kept for it
+					Chunk *big = new Chunk();
+					big->cap = tail + (c->hi - c->lo);
+					big->base = (uint8_t *) malloc(big->cap ? big->cap : 1);
+					if(!big->base) abort();
+					memcpy(big->base + tail, c->base + c->lo, c->hi - c->lo);
+					big->lo = tail; big->hi = big->cap; big->last = c->last;
+					delete c;
+					c = big;
+				}
+				if(tail) memcpy(c->base + c->lo - tail, old->base + M.pos, tail);
+				c->lo -= tail;
+				if(old) old->spans_end = M.spans_base + (int64_t) M.spans.size();
+				M.live.push_back(c);
+				M.pos = c->lo;
+			}
+		}
+		Chunk *c = M.live.back();
+		const uint8_t *lo = c->base + M.pos, *end = c->base + c->hi;
+		const uint8_t *e = (size_t) (end - lo) > wave ? lo + wave : end;
+		const bool final = e == end && c->last;
+		if(lo == e) { if(final) M.eof = true; continue; }
+		const int nr = (int) std::max<size_t>(1, std::min<size_t>((size_t) in->threads, (size_t) (e - lo) / region_min));
+		std::vector<Region> R((size_t) nr);
+		auto work = [&](int k) {
+			Region &r = R[(size_t) k];
+			const uint8_t *c0 = lo + (size_t) (e - lo) * (size_t) k / (size_t) nr;
+			r.lim = k + 1 == nr ? e : lo + (size_t) (e - lo) * (size_t) (k + 1) / (size_t) nr;
+			r.start = k == 0 ? lo : guess_start(lo, c0, r.lim, e);
+			if(r.start) r.st = locate_range(r.start, r.lim, e, final, r.spans, &r.stop);
+		};
+		{
+			std::vector<std::thread> pool;
+			for(int k = 1; k < nr; ++k) pool.emplace_back(work, k);
+			work(0);
+			for(std::thread &th : pool) th.join();
+		}
+		const uint8_t *cur = lo;
+		int st = LOC_REC;
+		const size_t before = M.spans.size();
+		for(int k = 0; k < nr && st == LOC_REC; ++k) {
+			Region &r = R[(size_t) k];
+			if(cur >= r.lim) continue;                          // a record before it reaches over the whole region
+			if(r.start != cur) {
+				// not where the guess was (or no guess): from the true position up to the guessed start, or through the region
+				const uint8_t *to = r.start && r.start > cur ? r.start : r.lim;
+				st = locate_range(cur, to, e, final, M.spans, &cur);
+				if(st != LOC_REC) break;
+				if(cur != r.start) {
+					if(cur < r.lim) st = locate_range(cur, r.lim, e, final, M.spans, &cur);
+					continue;
+				}
+			}
+			M.spans.insert(M.spans.end(), r.spans.begin(), r.spans.end());
+			cur = r.stop; st = r.st;
+		}
+		M.pos = (size_t) (cur - c->base);
+		if(st == LOC_MALFORMED) { in->malformed = true; M.eof = true; }
+		else if(st == LOC_END) M.eof = true;
+		else if(final && cur == e) M.eof = true;
+		if(M.spans.size() > before) return true;
+		if(M.eof) break;
+		// no record fits into the bytes looked at: look at more of the chunk, or go on to the next one
+		if(e < end) wave *= 2;
+		else if(c->last) M.eof = true;
+		else {
+			// force the next chunk in, whatever the size of the tail
+			Chunk *n = M.feed.pop();
+			const size_t tail = c->hi - M.pos;
+			if(!n) { c->last = true; continue; }
+			Chunk *big = new Chunk();
+			big->cap = tail + (n->hi - n->lo);
+			big->base = (uint8_t *) malloc(big->cap ? big->cap : 1);
+			if(!big->base) abort();
+			memcpy(big->base, c->base + M.pos, tail);
+			memcpy(big->base + tail, n->base + n->lo, n->hi - n->lo);
+			big->hi = big->cap; big->last = n->last;
+			delete n;
+			c->spans_end = M.spans_base + (int64_t) M.spans.size();
+			M.live.push_back(big);
+			M.pos = 0;
+		}
+	}
+	return false;
+}
+
+// chunks whose records have all been packed go
+void release_chunks(Mate &M) {
+	const int64_t done = M.spans_base + (int64_t) M.head;
+	while(M.live.size() > 1 && M.live.front()->spans_end <= done) { delete M.live.front(); M.live.pop_front(); }
+	if(M.head == M.spans.size()) { M.spans_base += (int64_t) M.head; M.spans.clear(); M.head = 0; }
 }
 
 }  // namespace
@@ -440,6 +764,14 @@ extern "C" int kmahip_ingest_open(const char *path1, const char *path2, const km
 		in->phred = guess_phred(in->s[0].at(), std::min(in->s[0].end - in->s[0].pos, FIRST_CHUNK));
 		if(in->paired && in->phred == 0) in->phred = guess_phred(in->s[1].at(), std::min(in->s[1].end - in->s[1].pos, FIRST_CHUNK));
 	}
+	if(in->fastq) {
+		// FASTQ is read again from the start, in chunks: a mapped file or a thread that inflates ahead of the parser
+		for(int i = 0; i < (in->paired ? 2 : 1); ++i) {
+			in->s[i].close();
+			in->s[i].buf.release();
+			if(!in->m[i].feed.open(paths[i])) { kmahip_set_error("cannot open %s", paths[i]); kmahip_ingest_close(in); return KMAHIP_EIO; }
+		}
+	}
 	*out = in;
 	return KMAHIP_OK;
 }
@@ -447,55 +779,62 @@ extern "C" int kmahip_ingest_open(const char *path1, const char *path2, const km
 extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch) {
 	if(!in || !batch || max_records < 0) { kmahip_set_error("bad argument"); return KMAHIP_EINVAL; }
 	in->seq.clear(); in->len.clear(); in->N.clear(); in->names.clear(); in->pair.clear();
-	in->seq_off.assign(1, 0); in->N_off.assign(1, 0); in->name_off.assign(1, 0);
+	in->seq_off.clear(); in->N_off.clear(); in->name_off.clear();
+	in->seq_off.push_back(0); in->N_off.push_back(0); in->name_off.push_back(0);
 	const kmahip_trim &T = in->trim;
 	const int mates = in->paired ? 2 : 1;
 	int64_t records = 0;
 	int max_len = 0;
 	if(in->fastq) {
-		// Records are located one after the other (memchr over the decompressed bytes), then trimmed and packed by a few
-		// threads side by side; a batch takes in `max_records` input records at a time until it holds that many kept ones
-		// or the input ends.
+		// Records are located a wave of bytes at a time (fill_wave), then trimmed and packed by the same few threads and
+		// appended to the batch; a batch takes in as many input records as it still has room for, until it holds
+		// `max_records` kept ones or the input ends.
+		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+		double ms_locate = 0, ms_pack = 0, ms_gather = 0;
+		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		while(records < max_records) {
-			const size_t want = (size_t) std::min<int64_t>(max_records - records, 1 << 20);
-			std::vector<Span> *spans = in->spans;
-			for(int m = 0; m < mates; ++m) {
-				spans[m].clear();
-				Stream &s = in->s[m];
-				if(s.pos) { memmove(s.buf.data(), s.buf.data() + s.pos, s.end - s.pos); s.end -= s.pos; s.pos = 0; }
-				s.pinned = true;
-				spans[m].reserve(want);
-			}
-			const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 			const auto t0 = std::chrono::steady_clock::now();
-			size_t n = 0;
-			for(; n < want; ++n) {
-				Span r[2];
-				bool any = false;
-				for(int m = 0; m < mates; ++m) any |= locate_fq(in->s[m], r[m], &in->malformed);
-				if(!any) break;
-				for(int m = 0; m < mates; ++m) spans[m].push_back(r[m]);
+			size_t avail = 0;
+			for(;;) {
+				for(int m = 0; m < mates; ++m) {
+					Mate &M = in->m[m], &O = in->m[mates - 1 - m];
+					// a mate file that has run out yields empty mates for what the other still holds (the `|` at runinput.c:516)
+					if(M.eof && M.spans.size() - M.head < O.spans.size() - O.head) M.spans.resize(M.head + (O.spans.size() - O.head));
+				}
+				avail = in->m[0].spans.size() - in->m[0].head;
+				if(mates == 2) avail = std::min(avail, in->m[1].spans.size() - in->m[1].head);
+				if(avail) break;
+				bool more = false;
+				for(int m = 0; m < mates; ++m) if(in->m[m].spans.size() == in->m[m].head) more |= fill_wave(in, in->m[m]);
+				if(!more) {
+					bool pending = false;
+					for(int m = 0; m < mates; ++m) pending |= in->m[m].spans.size() > in->m[m].head;
+					if(!pending) break;
+				}
 			}
-			for(int m = 0; m < mates; ++m) in->s[m].pinned = false;
-			if(n == 0) break;
+			if(!avail) break;
+			const size_t n = (size_t) std::min<int64_t>(max_records - records, (int64_t) avail);
 			in->n_read += (int64_t) n;
 			const auto t1 = std::chrono::steady_clock::now();
+			const Span *spans[2] = {in->m[0].spans.data() + in->m[0].head, mates == 2 ? in->m[1].spans.data() + in->m[1].head : nullptr};
 			const int nt = (int) std::max<size_t>(1, std::min<size_t>((size_t) in->threads, n / 2048));
 			if(in->parts.size() < (size_t) nt) in->parts.resize((size_t) nt);
 			std::vector<Part> &parts = in->parts;
-			std::vector<std::thread> pool;
-			for(int t = 1; t < nt; ++t) pool.emplace_back(pack_fastq, in, spans, n * (size_t) t / (size_t) nt, n * (size_t) (t + 1) / (size_t) nt, std::ref(parts[(size_t) t]));
-			pack_fastq(in, spans, 0, n / (size_t) nt, parts[0]);
-			for(std::thread &th : pool) th.join();
-			const auto t2 = std::chrono::steady_clock::now();
-			for(int t = 0; t < nt; ++t) { const Part &P = parts[(size_t) t]; append_part(in, P); records += P.records; max_len = std::max(max_len, P.max_len); }
-			if(dbg) {
-				const auto t3 = std::chrono::steady_clock::now();
-				auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-				fprintf(stderr, "[kmahip] ingest: %zu records: read + locate %.1f ms, trim + pack (%d threads) %.1f ms, gather %.1f ms\n", n, ms(t0, t1), nt, ms(t1, t2), ms(t2, t3));
+			{
+				std::vector<std::thread> pool;
+				for(int t = 1; t < nt; ++t) pool.emplace_back(pack_fastq, in, spans, n * (size_t) t / (size_t) nt, n * (size_t) (t + 1) / (size_t) nt, std::ref(parts[(size_t) t]));
+				pack_fastq(in, spans, 0, n / (size_t) nt, parts[0]);
+				for(std::thread &th : pool) th.join();
 			}
-			if(n < want) break;
+			const auto t2 = std::chrono::steady_clock::now();
+			append_parts(in, parts, nt);
+			for(int t = 0; t < nt; ++t) { records += parts[(size_t) t].records; max_len = std::max(max_len, parts[(size_t) t].max_len); }
+			for(int m = 0; m < mates; ++m) { in->m[m].head += n; release_chunks(in->m[m]); }
+			const auto t3 = std::chrono::steady_clock::now();
+			ms_locate += ms(t0, t1); ms_pack += ms(t1, t2); ms_gather += ms(t2, t3);
 		}
+		if(dbg) fprintf(stderr, "[kmahip] ingest: %lld records kept (%d threads): locate %.1f ms, trim + pack %.1f ms, gather %.1f ms\n",
+		                (long long) records, in->threads, ms_locate, ms_pack, ms_gather);
 	} else {
 		Rec r[2];
 		Part P;
@@ -549,5 +888,6 @@ extern "C" void kmahip_ingest_counts(const kmahip_ingest *in, int64_t *records_r
 extern "C" void kmahip_ingest_close(kmahip_ingest *in) {
 	if(!in) return;
 	in->s[0].close(); in->s[1].close();
+	in->m[0].feed.close(); in->m[1].feed.close();
 	delete in;
 }

@@ -147,3 +147,91 @@ def test_ingest_reports_malformed_input_after_the_good_records(tmp_path):
         with pytest.raises(binding.KmaHipError):
             ing.next(100)
         assert ing.next(100) is None
+
+
+def _all(path1, path2=None, step=1 << 30, **kw):
+    """every batch of a file concatenated: (lengths, names, pair flags, packed words per read)"""
+    out = ([], [], [], [])
+    with binding.Ingest(path1, path2, **kw) as ing:
+        err = None
+        while True:
+            try:
+                g = ing.next(step)
+            except binding.KmaHipError as e:
+                err = str(e)[:20]
+                continue
+            if g is None:
+                break
+            b, names, pair = g
+            out[0].extend(int(x) for x in b.length)
+            out[1].extend(names)
+            out[2].extend(int(x) for x in pair)
+            for i in range(b.n):
+                L = int(b.length[i])
+                out[3].append((bytes(b.seq[b.seq_off[i]:b.seq_off[i] + ((L + 31) >> 5)]), tuple(int(x) for x in b.N[b.N_off[i]:b.N_off[i + 1]])))
+    return out, err
+
+
+@pytest.fixture
+def tiny_chunks(monkeypatch):
+    """chunks of a few hundred bytes and regions of a few dozen: small files then run through every path of the chunked reader
+    (records cut by chunk and region boundaries, records longer than a chunk, regions without a record start, wrong guesses)"""
+    def set_(chunk, region, threads=4):
+        monkeypatch.setenv("KMAHIP_INGEST_CHUNK", str(chunk))
+        monkeypatch.setenv("KMAHIP_INGEST_REGION", str(region))
+        monkeypatch.setenv("KMAHIP_INGEST_THREADS", str(threads))
+    yield set_
+
+
+@pytest.mark.parametrize("chunk,region", [(64, 16), (300, 40), (1000, 100), (4096, 64), (100000, 200)])
+def test_ingest_chunked_reader_equals_one_pass(tmp_path, tiny_chunks, chunk, region):
+    """the same files read whole (default sizes: one region each) and in tiny chunks / regions, plain and gzip-compressed"""
+    import shutil
+    import subprocess
+    files = [("p33.fq", None), ("dos.fq", None), ("p64.fq", None), ("m1.fq", "m2.fq"), ("p33gz.fq.gz", None)]
+    # a file with hostile lines: qualities that begin with '@' and '+', a header that is only '@', long and empty reads
+    rng = np.random.default_rng(5)
+    rec = []
+    for i in range(300):
+        L = int(rng.choice([0, 1, 5, 30, 150, 700, 3000]))
+        seq = "".join(rng.choice(list("ACGTN"), L))
+        q = "".join(rng.choice(list("@+I5#"), L))
+        rec.append(f"@{'r%d some text' % i if i % 7 else ''}\n{seq}\n+{'x' * int(rng.integers(0, 3))}\n{q}\n")
+    hostile = tmp_path / "hostile.fq"
+    hostile.write_text("".join(rec))
+    nonl = tmp_path / "nonl.fq"
+    nonl.write_text("".join(rec)[:-1])                     # last record without its final newline
+    trunc = tmp_path / "trunc.fq"
+    trunc.write_text("".join(rec)[:-40])                   # last record cut short
+    files += [(str(hostile), None), (str(nonl), None), (str(trunc), None)]
+    for f in (hostile, nonl, trunc):
+        shutil.copy(f, str(f) + ".copy")
+        subprocess.run(["gzip", "-1", str(f) + ".copy"], check=True)
+        files.append((str(f) + ".copy.gz", None))
+    for f1, f2 in files:
+        p1 = f1 if os.path.isabs(f1) else os.path.join(ING, f1)
+        p2 = os.path.join(ING, f2) if f2 else None
+        want = _all(p1, p2, min_phred=0, min_len=0)
+        tiny_chunks(chunk, region)
+        assert _all(p1, p2, min_phred=0, min_len=0) == want, (f1, "one batch")
+        assert _all(p1, p2, step=7, min_phred=0, min_len=0) == want, (f1, "batches of 7")
+        for k in ("KMAHIP_INGEST_CHUNK", "KMAHIP_INGEST_REGION", "KMAHIP_INGEST_THREADS"):
+            os.environ.pop(k, None)
+
+
+def test_ingest_chunked_reader_malformed_and_short_mate(tmp_path, tiny_chunks):
+    good = b"".join(b"@r%d\nACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIII\n" % i for i in range(200))
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(good + b"this is not a record\n" + good)
+    short = tmp_path / "short.fq"
+    short.write_bytes(good[:len(good) // 3 - 5])
+    full = tmp_path / "full.fq"
+    full.write_bytes(good)
+    want_bad, want_pe = _all(str(bad)), _all(str(full), str(short))
+    assert len(want_bad[0][0]) == 200 and want_bad[1] is not None
+    assert len(want_pe[0][0]) > 200
+    tiny_chunks(200, 30)
+    assert _all(str(bad)) == want_bad
+    assert _all(str(bad), step=11) == want_bad
+    assert _all(str(full), str(short)) == want_pe
+    assert _all(str(short), str(full), step=13) == _all(str(short), str(full))
