@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--c4-reads", type=int, default=20000, help="reads of the extra BASELINE config C4 leg (10 kb ONT-like reads vs one 5 Mb "
                     "genome, -Mt1 1 -bcNano, whole run incl. pile-up and consensus); 0 = skip")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the file-to-file leg (FASTQ -> .res / .fsa / .frag.gz through "
+                    "examples/kmahip_map, whole-process wall clock); 0 = skip")
+    ap.add_argument("--e2e-sample", type=int, default=1_000_000, help="reads of it the reference binary is run on (parity of .res + its rates)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --reads per rank; strong: --reads in total, sharded over the ranks")
     return ap.parse_args()
@@ -197,6 +200,145 @@ def c4_leg(tmp, n_reads, device):
         return out
     finally:
         db.close()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
+    """File to file: a FASTQ of n reads -> .res / .fsa / .frag.gz through the C host program (examples/kmahip_map): whole-process
+    wall clock including HIP start-up, kmahip_db_open, ingest, the device run and the three writers, plain and gzip-compressed
+    input. The compiled reference on the first `sample` reads of the same file: -t 1, -t nproc, and independent -t 1 processes
+    over equal shards (16 = the CPU share of one GPU on the box, and nproc); its .res must be the one kmahip_map writes for
+    that sample."""
+    import re
+    from kma_amd import synth
+    say = log or (lambda *_: None)
+    kma = os.path.join(ROOT, "oracle", "_ref", "kma")
+    mapper = os.path.join(ROOT, "examples", "kmahip_map")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    fq = os.path.join(tmp, "e2e.fq")
+    t0 = time.perf_counter()
+    with open(fq, "wb") as f:
+        for a in range(0, n, 2_000_000):
+            m = min(2_000_000, n - a)
+            codes, _, _, _ = synth.make_reads(seqs, m, seed=1000 + a)
+            part = os.path.join(tmp, "part.fq")
+            write_fastq_fixed(part, codes)          # (names restart per part; nobody minds, and both sides see the same file)
+            with open(part, "rb") as g:
+                shutil.copyfileobj(g, f, 1 << 24)
+            os.unlink(part)
+    rec = os.path.getsize(fq) // n
+    say(f"e2e: FASTQ of {n} reads, {os.path.getsize(fq) / 1e9:.2f} GB, written in {time.perf_counter() - t0:.1f} s")
+    nproc = len(os.sched_getaffinity(0))
+    # the same file gzip-compressed (level 1), made by 16 gzip processes over slices (a multi-member .gz)
+    per = (n + 15) // 16
+    procs = []
+    with open(fq, "rb") as f:
+        for i in range(16):
+            sl = os.path.join(tmp, f"slice{i:02d}.fq")
+            with open(sl, "wb") as g:
+                g.write(f.read(rec * per))
+            procs.append(subprocess.Popen(["gzip", "-1", sl]))
+    for p_ in procs:
+        p_.wait()
+    gz = fq + ".gz"
+    with open(gz, "wb") as f:
+        for i in range(16):
+            with open(os.path.join(tmp, f"slice{i:02d}.fq.gz"), "rb") as g:
+                shutil.copyfileobj(g, f, 1 << 24)
+            os.unlink(os.path.join(tmp, f"slice{i:02d}.fq.gz"))
+
+    def run_map(inp, outp):
+        t0 = time.perf_counter()
+        r = subprocess.run([mapper, "-i", inp, "-t_db", prefix, "-o", outp], stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t0
+        err = r.stderr.decode().strip().splitlines()
+        if r.returncode:
+            raise RuntimeError(f"kmahip_map failed ({r.returncode}): {err[-1] if err else ''}")
+        return dt, err[-1] if err else ""
+
+    out = {"reads": n, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "fastq_gz_GB": round(os.path.getsize(gz) / 1e9, 2), "unit": "reads/s",
+           "host_threads": min(16, nproc),
+           "what": "examples/kmahip_map -i <fastq> -t_db <index> -o <out>: process start to exit, incl. HIP start-up, kmahip_db_open, ingest, "
+                   "kmahip_run_se (upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus), .res, .fsa and .frag.gz"}
+    got = os.path.join(tmp, "e2e_got")
+    walls = [run_map(fq, got) for _ in range(2)]
+    best = min(walls)
+    out["plain"] = {"wall_s": round(best[0], 3), "reads_per_s": n / best[0], "runs_s": [round(w[0], 3) for w in walls]}
+    m = re.search(r"wall: (.*?) \|", best[1])
+    if m:
+        out["plain"]["breakdown"] = m.group(1)
+    say(f"e2e: plain {best[0]:.2f} s | {best[1]}")
+    wz = run_map(gz, got + "_gz")
+    out["gz"] = {"wall_s": round(wz[0], 3), "reads_per_s": n / wz[0]}
+    m = re.search(r"wall: (.*?) \|", wz[1])
+    if m:
+        out["gz"]["breakdown"] = m.group(1)
+    out["gz"]["res_equals_plain"] = open(got + ".res", "rb").read() == open(got + "_gz.res", "rb").read()
+    say(f"e2e: gz {wz[0]:.2f} s | {wz[1]}")
+    ref = None
+    if os.path.exists(kma) and sample:
+        m_ = min(sample, n)
+        sfq = os.path.join(tmp, "e2e_sample.fq")
+        with open(fq, "rb") as f, open(sfq, "wb") as g:
+            g.write(f.read(rec * m_))
+        ws = run_map(sfq, got + "_sample")
+
+        def run_ref(threads, inp, outp):
+            return subprocess.Popen([kma, "-i", inp, "-o", outp, "-t_db", prefix, "-1t1", "-t", str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+        def shards(k):
+            per_ = (m_ + k - 1) // k
+            paths = []
+            with open(sfq, "rb") as f:
+                for i in range(k):
+                    p_ = os.path.join(tmp, f"shard{i}.fq")
+                    with open(p_, "wb") as g:
+                        g.write(f.read(rec * per_))
+                    paths.append(p_)
+            t0 = time.perf_counter()
+            ps = [run_ref(1, p_, os.path.join(tmp, f"shard_out{i}")) for i, p_ in enumerate(paths)]
+            bad = sum(1 for q in ps if q.wait() != 0)
+            dt = time.perf_counter() - t0
+            for p_ in paths:
+                os.unlink(p_)
+            if bad:
+                raise RuntimeError(f"{bad} of {k} reference processes failed")
+            return dt
+        t0 = time.perf_counter()
+        if run_ref(1, sfq, os.path.join(tmp, "e2e_ref")).wait():
+            raise RuntimeError("reference run failed")
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        run_ref(nproc, sfq, os.path.join(tmp, "e2e_reft")).wait()
+        tn = time.perf_counter() - t0
+        s16 = shards(min(16, nproc))
+        sn = shards(nproc) if nproc > 16 else s16
+        same = open(got + "_sample.res", "rb").read() == open(os.path.join(tmp, "e2e_ref.res"), "rb").read()
+        ref = {"sample_reads": m_, "cpu_model": cpu_model(), "nproc": nproc,
+               "t1": {"wall_s": round(t1, 2), "reads_per_s": m_ / t1},
+               "t_nproc": {"threads": nproc, "wall_s": round(tn, 2), "reads_per_s": m_ / tn},
+               "shards_16": {"processes": min(16, nproc), "wall_s": round(s16, 2), "reads_per_s": m_ / s16},
+               "shards_nproc": {"processes": nproc, "wall_s": round(sn, 2), "reads_per_s": m_ / sn},
+               "kmahip_map_on_sample": {"wall_s": round(ws[0], 3), "reads_per_s": m_ / ws[0]},
+               "res_identical_to_reference": same,
+               "note": "the reference binary (oracle/_ref/kma -1t1) file to file on the first sample_reads reads of the e2e FASTQ: one thread, "
+                       "-t nproc, and independent -t 1 processes over equal shards of the sample (wall = the slowest; every process "
+                       "loads the index itself, so short shards are start-up bound)"}
+        say(f"e2e: reference on {m_} reads: -t 1 {t1:.1f} s, -t {nproc} {tn:.1f} s, 16 shards {s16:.1f} s, {nproc} shards {sn:.1f} s; .res identical {same}")
+        out["vs_reference_t1"] = out["plain"]["reads_per_s"] / ref["t1"]["reads_per_s"]
+        out["vs_reference_best_shards"] = out["plain"]["reads_per_s"] / max(ref["shards_16"]["reads_per_s"], ref["shards_nproc"]["reads_per_s"], ref["t_nproc"]["reads_per_s"])
+    for f_ in (fq, gz):
+        os.unlink(f_)
+    return out, ref
 
 
 def parity_sample(prefix, codes, got_scan, got_hits):
@@ -459,6 +601,16 @@ def main():
                     out["c4"] = c4_leg(tmp, a.c4_reads, local)
                 except Exception as e:  # noqa: BLE001  (extra leg only)
                     out["c4"] = {"error": str(e)}
+            if a.e2e_reads > 0 and not a.hard:
+                try:
+                    db.close()            # the C host program opens the index itself; give it the card's memory back first
+                    torch.cuda.empty_cache()
+                    e2e, ref = e2e_leg(tmp, prefix, seqs, a.e2e_reads, a.e2e_sample)
+                    out["e2e"] = e2e
+                    if ref is not None and out.get("cpu_baseline"):
+                        out["cpu_baseline"].update(cpu_model=ref["cpu_model"], nproc=ref["nproc"], file_to_file=ref)
+                except Exception as e:  # noqa: BLE001  (extra leg only)
+                    out["e2e"] = {"error": str(e)}
         elif rank == 0:
             out["cpu_baseline"] = None
         if strong is not None:

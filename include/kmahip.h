@@ -427,6 +427,11 @@ int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_reads *read
                        const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const char *read_names,
                        const int64_t *read_name_off, int64_t *rows);
 
+/* One gzip member as kmahip_frag_write* makes them for a path ending in ".gz": Huffman coding only (the reference deflates
+ * at level 1, filebuff.c:189 -- what a reader inflates is the same). The writers compress blocks of rows on several threads
+ * and concatenate the members (RFC 1952 2.2). Exposed for tests. */
+int kmahip_gzip_member(const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes);
+
 /* The paired run (`-ipe r1 r2 -apm p -1t1`) on one batch as kmahip_ingest_next hands it over for two mate files: reads in
  * stream order, batch->pair[i] = 1 / 2 for the mates of a pair record, 0 for a record that lost its mate to the trimming.
  * Pairs go through kmahip_map_pe, single records through kmahip_map_se; their results are merged into frag_raw records in

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 static thread_local char g_err[512] = "";
 
@@ -70,6 +72,15 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(!prefix || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	*out = nullptr;
 	std::string base(prefix);
+	// KMAHIP_DEBUG_TIMING: where the time of opening an index goes
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto stamp = [&](const char *what) {
+		if(!dbg) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[kmahip] db_open: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 	FILE *f = fopen((base + ".comp.b").c_str(), "rb");
 	if(!f) { kmahip_set_error("cannot open %s.comp.b", prefix); return KMAHIP_EIO; }
 	uint32_t h32[3];
@@ -97,6 +108,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(ok && read_exact(f, &tail[0], 4)) ok = read_exact(f, &tail[1], 4);
 	fclose(f);
 	if(!ok) { kmahip_set_error("truncated %s.comp.b", prefix); return KMAHIP_EIO; }
+	stamp("read .comp.b");
 	if(tail[1] != 0) { kmahip_set_error("minimizer / homopolymer-compressed index (flag %u) not supported", tail[1]); return KMAHIP_EFORMAT; }
 	if(tail[0] != mlen) { kmahip_set_error("kmersize %u != mlen %u not supported", tail[0], mlen); return KMAHIP_EFORMAT; }
 
@@ -170,6 +182,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		   (rc = upload(db, tseq.data(), tseq.size(), &d.tseq)) ||
 		   (rc = upload(db, off.data(), off.size(), &d.tseq_off))) { kmahip_db_close(db); return rc; }
 
+		stamp("probe table, presence bits, value lists, template store (built + uploaded)");
 		// Concatenated template store + per-position value-list offsets: a read that matches a template keeps
 		// matching it, so after one hash hit the scan kernel walks along `cat` (sequential 4-byte reads of
 		// vs_id) instead of probing the table for every k-mer start.
@@ -223,6 +236,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 			   (rc = upload(db, db->h_cat_off.data(), db->h_cat_off.size(), &d.cat_off))) { kmahip_db_close(db); return rc; }
 		}
 
+		stamp("walkable template store (cat / vs_id)");
 		// per-template k-mer position index
 		const int k = (int) tail[0];
 		std::vector<int64_t> poff(DB_size + 1, 0);
@@ -237,37 +251,85 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		poff[1] = poff[0] = 0;
 		for(uint32_t t = 1; t < DB_size; ++t) poff[t + 1] = poff[t] + (1ll << (32 - pshift[t]));
 		std::vector<uint2> pslots((size_t) poff[DB_size] + 1, make_uint2(0u, 0u));
+		// built by a few threads, each over a stretch of templates with a duplicate list of its own; the lists are then put
+		// one after the other and the references into them moved by where each list landed
 		std::vector<int32_t> dups(1, 0);
-		std::vector<std::pair<uint32_t, int32_t>> kp;
-		for(uint32_t t = 1; t < DB_size; ++t) {
-			const int tl = db->h_tlen[t];
-			const uint64_t *ts = tseq.data() + off[t];
-			kp.clear();
-			for(int i = 0; i + k <= tl; ++i) {
-				const int ip = (i & 31) << 1, w = i >> 5;
-				uint64_t x = ts[w] << ip;
-				if(ip) x |= ts[w + 1] >> (64 - ip);
-				const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
-				if(km) kp.push_back({km, i + 1});
-			}
-			std::sort(kp.begin(), kp.end());
-			const uint32_t sh = pshift[t];
-			const uint64_t msk = (1ull << (32 - sh)) - 1;
-			uint2 *tab = pslots.data() + poff[t];
-			for(size_t a = 0; a < kp.size();) {
-				size_t b = a;
-				while(b < kp.size() && kp[b].first == kp[a].first) ++b;
-				int32_t val;
-				if(b - a == 1) val = kp[a].second;
-				else {
-					val = -((int32_t) dups.size() + 1);
-					dups.push_back((int32_t) (b - a));
-					for(size_t c = a; c < b; ++c) dups.push_back(kp[c].second);
+		{
+			const char *e = getenv("KMAHIP_IO_THREADS");
+			const int hw = (int) std::thread::hardware_concurrency();
+			int nt = e ? atoi(e) : std::min(16, hw > 0 ? hw : 1);
+			nt = std::max(1, std::min<int>(nt, (int) (DB_size / 64) + 1));
+			std::vector<std::vector<int32_t>> part((size_t) nt);
+			std::vector<uint32_t> cut((size_t) nt + 1, DB_size);
+			{	// equal shares of the template bases
+				int64_t total = 0, acc = 0;
+				for(uint32_t t = 1; t < DB_size; ++t) total += db->h_tlen[t];
+				cut[0] = 1;
+				int c = 1;
+				for(uint32_t t = 1; t < DB_size && c < nt; ++t) {
+					acc += db->h_tlen[t];
+					if(acc * nt >= total * c) cut[(size_t) c++] = t + 1;
 				}
-				uint64_t sl = (uint32_t) (kp[a].first * 0x9E3779B1u) >> sh;
-				while(tab[sl].y != 0) sl = (sl + 1) & msk;
-				tab[sl] = make_uint2(kp[a].first, (uint32_t) val);
-				a = b;
+			}
+			auto build = [&](int w) {
+				std::vector<std::pair<uint32_t, int32_t>> kp;
+				std::vector<int32_t> &dl = part[(size_t) w];
+				for(uint32_t t = cut[(size_t) w]; t < cut[(size_t) w + 1]; ++t) {
+					const int tl = db->h_tlen[t];
+					const uint64_t *ts = tseq.data() + off[t];
+					kp.clear();
+					for(int i = 0; i + k <= tl; ++i) {
+						const int ip = (i & 31) << 1, wd = i >> 5;
+						uint64_t x = ts[wd] << ip;
+						if(ip) x |= ts[wd + 1] >> (64 - ip);
+						const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
+						if(km) kp.push_back({km, i + 1});
+					}
+					std::sort(kp.begin(), kp.end());
+					const uint32_t sh = pshift[t];
+					const uint64_t msk = (1ull << (32 - sh)) - 1;
+					uint2 *tab = pslots.data() + poff[t];
+					for(size_t a = 0; a < kp.size();) {
+						size_t b = a;
+						while(b < kp.size() && kp[b].first == kp[a].first) ++b;
+						int32_t val;
+						if(b - a == 1) val = kp[a].second;
+						else {
+							val = -((int32_t) dl.size() + 1);         // (relative to this thread's list for now)
+							dl.push_back((int32_t) (b - a));
+							for(size_t c = a; c < b; ++c) dl.push_back(kp[c].second);
+						}
+						uint64_t sl = (uint32_t) (kp[a].first * 0x9E3779B1u) >> sh;
+						while(tab[sl].y != 0) sl = (sl + 1) & msk;
+						tab[sl] = make_uint2(kp[a].first, (uint32_t) val);
+						a = b;
+					}
+				}
+			};
+			{
+				std::vector<std::thread> pool;
+				for(int w = 1; w < nt; ++w) pool.emplace_back(build, w);
+				build(0);
+				for(std::thread &th : pool) th.join();
+			}
+			std::vector<int64_t> base((size_t) nt + 1, 1);
+			for(int w = 0; w < nt; ++w) base[(size_t) w + 1] = base[(size_t) w] + (int64_t) part[(size_t) w].size();
+			if(base[(size_t) nt] >= 0x7FFFFFFFll) { kmahip_db_close(db); kmahip_set_error("too many repeated k-mers inside templates"); return KMAHIP_EFORMAT; }
+			dups.resize((size_t) base[(size_t) nt]);
+			auto place = [&](int w) {
+				if(!part[(size_t) w].empty()) memcpy(dups.data() + base[(size_t) w], part[(size_t) w].data(), part[(size_t) w].size() * sizeof(int32_t));
+				const int32_t shift = (int32_t) base[(size_t) w];
+				if(!shift) return;
+				for(int64_t i = poff[cut[(size_t) w]]; i < poff[cut[(size_t) w + 1]]; ++i) {
+					const int32_t v = (int32_t) pslots[(size_t) i].y;
+					if(v < 0) pslots[(size_t) i].y = (uint32_t) (v - shift);
+				}
+			};
+			{
+				std::vector<std::thread> pool;
+				for(int w = 1; w < nt; ++w) pool.emplace_back(place, w);
+				place(0);
+				for(std::thread &th : pool) th.join();
 			}
 		}
 		std::vector<uint4> tmeta((size_t) 2 * DB_size, make_uint4(0u, 0u, 0u, 0u));
@@ -282,6 +344,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		   (rc = upload(db, pshift.data(), pshift.size(), &d.tpos_shift)) ||
 		   (rc = upload(db, dups.data(), dups.size(), &d.tpos_dups))) { kmahip_db_close(db); return rc; }
 	}
+	stamp("per-template position index");
 	*out = db;
 	return KMAHIP_OK;
 }

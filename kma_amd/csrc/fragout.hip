@@ -3,6 +3,7 @@
 // per read that passed the stage-3c filter -- the read as it was aligned (reverse complemented when it was filed on the
 // minus strand), the number of equally good templates, score, start, end, template name, read header.
 #include "kmahip_internal.h"
+#include "fastgz.h"
 #include <zlib.h>
 #include <unistd.h>
 #include <algorithm>
@@ -32,8 +33,8 @@ int load_names(kmahip_db *db) {
 }
 
 // Rows [0, n_rows) written to `path` in order. The rows are cut into blocks; a few threads format blocks side by side and, for
-// a .gz, deflate each one as a gzip member of its own (level 1 like the reference's deflateInit2, filebuff.c:189); the caller's
-// thread writes the finished blocks in order. A file of concatenated members is a gzip file (RFC 1952 2.2): zcat, gzread and
+// a .gz, compress each one as a gzip member of its own (fastgz.h: entropy coding only, where the reference runs zlib at level
+// 1, filebuff.c:189); the caller's thread writes the finished blocks in order. A file of concatenated members is a gzip file (RFC 1952 2.2): zcat, gzread and
 // the reference's own reader give back the same bytes as one stream would.
 struct RowBlock { std::string data; bool ready = false; };
 
@@ -58,6 +59,7 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 	std::atomic<int> failed{0};
 	auto worker = [&]() {
 		std::string raw;
+		std::vector<uint8_t> scratch;
 		for(;;) {
 			const size_t b = next.fetch_add(1);
 			if(b >= n_blocks || failed.load()) return;
@@ -68,16 +70,8 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 			for(size_t r = b * BLOCK; r < r1; ++r) fmt(r, raw);
 			RowBlock &B = ring[b % WINDOW];
 			if(gz) {
-				z_stream z;
-				memset(&z, 0, sizeof z);
-				if(deflateInit2(&z, 1, Z_DEFLATED, 31, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed.store(1); cv.notify_all(); return; }
-				B.data.resize(deflateBound(&z, (uLong) raw.size()));
-				z.next_in = (Bytef *) raw.data(); z.avail_in = (uInt) raw.size();
-				z.next_out = (Bytef *) &B.data[0]; z.avail_out = (uInt) B.data.size();
-				const int zr = deflate(&z, Z_FINISH);
-				B.data.resize(B.data.size() - z.avail_out);
-				deflateEnd(&z);
-				if(zr != Z_STREAM_END) { failed.store(1); cv.notify_all(); return; }
+				B.data.clear();
+				fastgz::gzip_member((const uint8_t *) raw.data(), raw.size(), B.data, scratch);
 			} else B.data.swap(raw);
 			{ std::lock_guard<std::mutex> lk(mu); B.ready = true; }
 			cv.notify_all();
@@ -188,5 +182,16 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 	};
 	if((e = write_rows(path, n_rows, fmt))) return e;
 	if(rows) *rows = (int64_t) n_rows;
+	return KMAHIP_OK;
+}
+
+// one gzip member as the writers above make them (for the tests of fastgz.h; KMAHIP_EINVAL when dst is too small)
+extern "C" int kmahip_gzip_member(const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes) {
+	if((!src && n) || !dst || !out_bytes || n < 0) { kmahip_set_error("bad argument"); return KMAHIP_EINVAL; }
+	std::string o;
+	fastgz::gzip_member((const uint8_t *) src, (size_t) n, o);
+	if((int64_t) o.size() > cap) { kmahip_set_error("destination too small: %zu bytes needed", o.size()); return KMAHIP_EINVAL; }
+	memcpy(dst, o.data(), o.size());
+	*out_bytes = (int64_t) o.size();
 	return KMAHIP_OK;
 }
