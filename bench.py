@@ -263,6 +263,9 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
         err = r.stderr.decode().strip().splitlines()
         if r.returncode:
             raise RuntimeError(f"kmahip_map failed ({r.returncode}): {err[-1] if err else ''}")
+        for line in err[:-1]:
+            if any(k in line for k in ("write_rows", "frag_write", "db_open", "ingest:")):
+                say("    " + line)
         return dt, err[-1] if err else ""
 
     out = {"reads": n, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "fastq_gz_GB": round(os.path.getsize(gz) / 1e9, 2), "unit": "reads/s",

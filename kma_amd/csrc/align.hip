@@ -1663,7 +1663,12 @@ struct TraceArgs {
 	int32_t *o_nops;
 	uint32_t *ops;               // runs: (length << 2) | class, class 0 '=' 1 'X' 2 'I' 3 'D'
 	int64_t ops_pool_cap;
-	unsigned long long *counters;   // [0] run pool top, [1] status
+	unsigned long long *counters;   // [0] run pool top, [1] status, [3] reads put off
+	// Two passes. fast != 0: a read whose DP problems all have a provably ungapped answer (see diag_proof) is finished without
+	// a move matrix; any other read is put off -- its index goes to q_out -- so that no lane of a wave sits through another
+	// lane's matrices. The second pass (q_in = that list, fast = 0) gives the reads put off the full treatment.
+	const int32_t *q_in; int32_t *q_out;
+	int fast, gap_m_max;
 };
 
 struct Emit {
@@ -1691,8 +1696,38 @@ struct TLane {
 	Lane L;
 	int32_t *rows; uint8_t *E; int64_t e_cap;
 	Emit em;
-	int status;     // 1: a DP problem did not fit the per-lane move matrix
+	int status;     // 1: a DP problem did not fit the per-lane move matrix; 32: put off to the second pass
+	int fast, gap_m_max;
 };
+
+// DP problems whose answer is known without the matrix. With match M > 0 > mismatch MM > gap open W1, extension U < 0 (checked
+// on the host before `fast` is set), an ungapped alignment of g read bases with m mismatches scores (g - m) M + m MM.
+//  * Between two seeds (NW with both ends fixed, t_l == q_l == g): any other alignment holds a gap in the read and a gap in the
+//    template and at most g - 1 pairs: <= (g - 1) M + 2 W1. The diagonal is the only optimum when m (M - MM) < M - 2 W1
+//    (m <= gap_m_max; 2 with the defaults).
+//  * A tail next to a seed (read end fixed, template end free, k = -1 / 1), m <= 1: the read base next to the seed is paired
+//    with its own template base (then a gap elsewhere: <= MM + (g - 1) M + W1), with a gap (<= W1 + (g - 1) M), or with an
+//    earlier template base after a gap of 1 (exactly the diagonal shifted by one: W1 + (g - x1) M + x1 MM for x1 mismatches on
+//    it, or <= 2 W1 + g M with a further gap) or of 2 and more (<= W1 + U + g M). With MM > W1, MM - M > 2 W1 and
+//    MM - M > W1 + U all of these are below (g - 1) M + MM unless x1 == 0.
+// Being the only optimum, the diagonal is what the reference's traceback yields whatever its tie rules.
+__device__ __forceinline__ int diag_mism(const uint64_t *ts, const QView &q, int tp, int qp, int g) {
+	int m = 0;
+	for(int i = 0; i < g; ++i) m += tn(ts, tp + i) != qn(q, qp + i);
+	return m;
+}
+__device__ __forceinline__ void diag_emit(TLane &T, const uint64_t *ts, const QView &q, int tp, int qp, int g, Aln &r) {
+	int score = 0, cls = -1, run = 0;
+	for(int i = 0; i < g; ++i) {
+		const int tb = tn(ts, tp + i), qb = qn(q, qp + i);
+		score += T.L.d[5 * tb + qb];
+		const int c = tb == qb ? 0 : 1;
+		if(c != cls) { T.em.push(cls, run); cls = c; run = 0; }
+		++run;
+	}
+	T.em.push(cls, run);
+	r.score = score; r.len = g; r.match = g; r.tGaps = 0; r.qGaps = 0; r.pos = 0;
+}
 
 #define TROW(T, r, n) (T).rows[((int64_t) ((r) * (T).L.ncols + (n))) * (T).L.lanes]
 
@@ -1922,8 +1957,14 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 			if(t_e - t_s > 0 && q_e - q_s > 0) {
 				const int band = abs(t_e - t_s - q_e + q_s) + bw;
 				const bool full = q_e - q_s <= band || t_e - t_s <= band;
-				Aln r; int cs, ce;
-				if(!nw_trace(T, ts, t_len, q, -1 - (t_s == 0), t_s, t_e, q_s, q_e, full ? -1 : band, t_s == 0, 0, r, cs, ce)) { T.status = 1; return FAIL; }
+				Aln r; int cs = 0, ce = 0;
+				if(T.fast) {
+					const int g = q_e - q_s;
+					if(t_s == 0 || !full || q.nN) { T.status = 32; return FAIL; }
+					const int m = diag_mism(ts, q, t_e - g, q_s, g);
+					if(m > 1 || (m == 1 && diag_mism(ts, q, t_e - 1 - g, q_s, g) == 0)) { T.status = 32; return FAIL; }
+					diag_emit(T, ts, q, t_e - g, q_s, g, r);
+				} else if(!nw_trace(T, ts, t_len, q, -1 - (t_s == 0), t_s, t_e, q_s, q_e, full ? -1 : band, t_s == 0, 0, r, cs, ce)) { T.status = 1; return FAIL; }
 				clip_start = q_s + cs;
 				S.pos -= r.len - r.tGaps;
 				S.score = r.score; S.len = r.len; S.match = r.match; S.tGaps = r.tGaps; S.qGaps = r.qGaps;
@@ -1953,7 +1994,10 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 			const int band = abs(t_l - q_e + q_s) + bw;
 			const bool full = q_e - q_s <= band || t_l <= band;
 			Aln r; int cs, ce;
-			if(!nw_trace(T, ts, t_len, q, 0, t_s, t_e, q_s, q_e, full ? -1 : band, false, t_len, r, cs, ce)) { T.status = 1; return FAIL; }
+			if(T.fast && t_l > 0 && q_e - q_s > 0) {
+				if(t_l != q_e - q_s || t_e < t_s || !full || q.nN || diag_mism(ts, q, t_s, q_s, t_l) > T.gap_m_max) { T.status = 32; return FAIL; }
+				diag_emit(T, ts, q, t_s, q_s, t_l, r);
+			} else if(!nw_trace(T, ts, t_len, q, 0, t_s, t_e, q_s, q_e, full ? -1 : band, false, t_len, r, cs, ce)) { T.status = 1; return FAIL; }
 			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
 		}
 	}
@@ -1968,8 +2012,14 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 		if(t_e - t_s > 0 && q_e - q_s > 0) {
 			const int band = abs(t_e - t_s - q_e + q_s) + bw;
 			const bool full = q_e - q_s <= band || t_e - t_s <= band;
-			Aln r; int cs, ce;
-			if(!nw_trace(T, ts, t_len, q, 1 + (t_e == t_len), t_s, t_e, q_s, q_e, full ? -1 : band, false, 0, r, cs, ce)) { T.status = 1; return FAIL; }
+			Aln r; int cs, ce = 0;
+			if(T.fast) {
+				const int g = q_e - q_s;
+				if(t_e == t_len || !full || q.nN) { T.status = 32; return FAIL; }
+				const int m = diag_mism(ts, q, t_s, q_s, g);
+				if(m > 1 || (m == 1 && diag_mism(ts, q, t_s + 1, q_s, g) == 0)) { T.status = 32; return FAIL; }
+				diag_emit(T, ts, q, t_s, q_s, g, r);
+			} else if(!nw_trace(T, ts, t_len, q, 1 + (t_e == t_len), t_s, t_e, q_s, q_e, full ? -1 : band, false, 0, r, cs, ce)) { T.status = 1; return FAIL; }
 			fr_end = ce;
 			if(t_e == t_len) {
 				// gaps at the very end of the template are trimmed; the first column of the tail always stays
@@ -2002,8 +2052,11 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	L.diag_uniform = 0;
 	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
+	T.fast = A.fast; T.gap_m_max = A.gap_m_max;
 	const int lane = threadIdx.x & 63;
-	for(int64_t r = gtid; __any(r < A.n_reads); r += A.lanes) {
+	const int64_t n_items = A.q_in ? (int64_t) A.counters[3] : A.n_reads;       // (the list was filled by the launch before this one)
+	for(int64_t it = gtid; __any(it < n_items); it += A.lanes) {
+		const int64_t r = it < n_items ? (A.q_in ? (int64_t) A.q_in[it] : it) : A.n_reads;
 		// what the read contributes: nothing (keep = false) or its figures + T.em.n alignment runs
 		bool keep = false;
 		int32_t *st = nullptr;
@@ -2023,7 +2076,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 				const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
 				T.em.n = 0; T.em.over = false; T.status = 0;
 				S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
-				if(T.status || T.em.over) atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16)));
+				if(T.status == 32) A.q_out[atomicAdd(&A.counters[3], 1ull)] = (int32_t) r;
+				else if(T.status || T.em.over) atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16)));
 				else {
 					// assemble_KMA, assembly.c:1931-1961
 					aln_len = S.len; start = S.pos;
@@ -2282,6 +2336,13 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 3, 0, sizeof(unsigned long long), stream));
+	if(ws->t_queue_cap < n) {
+		(void) hipFree(ws->t_queue);
+		ws->t_queue = nullptr; ws->t_queue_cap = 0;
+		HIP_TRY(hipMalloc((void **) &ws->t_queue, (size_t) n * sizeof(int32_t)));
+		ws->t_queue_cap = n;
+	}
 	TraceArgs A;
 	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.flag = flag; A.tmpl = tmpl; A.tmpl_ok = tmpl_ok;
@@ -2293,7 +2354,29 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.E = ws->t_E; A.lanes = lanes; A.e_cap = e_cap; A.mem_cap = mem_cap; A.ncols = ncols; A.ops_cap = ops_cap;
 	A.o_stats = out->stats; A.o_off = out->ops_off; A.o_nops = out->n_ops; A.ops = out->ops; A.ops_pool_cap = out->ops_cap;
 	A.counters = ws->counters;
+	// pass 1 settles every read whose DP problems are provably ungapped (diag_proof above) and lists the others; pass 2 runs
+	// the listed ones with their move matrices. KMAHIP_TRACE=lanes1: everything in one pass, as before.
+	const int M = p->rw.M, MM = p->rw.MM, W1 = p->rw.W1, U = p->rw.U;
+	bool plain = M > 0 && MM < 0 && W1 < 0 && U < 0 && MM > W1 && MM - M > 2 * W1 && MM - M > W1 + U;
+	for(int i = 0; i < 4 && plain; ++i) for(int j = 0; j < 4; ++j) plain = plain && p->rw.d[i][j] == (i == j ? M : MM);
+	{
+		const char *mode = getenv("KMAHIP_TRACE");
+		if(mode && !strcmp(mode, "lanes1")) plain = false;
+	}
+	A.q_in = nullptr; A.q_out = ws->t_queue; A.fast = plain ? 1 : 0;
+	A.gap_m_max = plain ? (M - 2 * W1 - 1) / (M - MM) : 0;
 	hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
 	HIP_TRY(hipGetLastError());
+	if(plain) {
+		A.q_in = ws->t_queue; A.fast = 0;
+		hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
+		HIP_TRY(hipGetLastError());
+		if(getenv("KMAHIP_DEBUG_TIMING")) {
+			unsigned long long put_off = 0;
+			HIP_TRY(hipStreamSynchronize(stream));
+			HIP_TRY(hipMemcpy(&put_off, ws->counters + 3, sizeof put_off, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the second pass\n", (long long) n, put_off);
+		}
+	}
 	return KMAHIP_OK;
 }

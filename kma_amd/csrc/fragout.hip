@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -57,6 +58,12 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 	size_t written = 0;                                  // blocks [0, written) are on disk and their ring slots free
 	std::atomic<size_t> next{0};
 	std::atomic<int> failed{0};
+	std::atomic<long long> us_fmt{0}, us_zip{0};
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto us = [](auto a, auto b) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+	const auto t_begin = now();
+	long long us_write = 0;
 	auto worker = [&]() {
 		std::string raw;
 		std::vector<uint8_t> scratch;
@@ -66,13 +73,16 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return b < written + WINDOW || failed.load(); }); }
 			if(failed.load()) return;
 			raw.clear();
+			const auto t0 = now();
 			const size_t r1 = std::min(n_rows, (b + 1) * BLOCK);
 			for(size_t r = b * BLOCK; r < r1; ++r) fmt(r, raw);
+			const auto t1 = now();
 			RowBlock &B = ring[b % WINDOW];
 			if(gz) {
 				B.data.clear();
 				fastgz::gzip_member((const uint8_t *) raw.data(), raw.size(), B.data, scratch);
 			} else B.data.swap(raw);
+			us_fmt += us(t0, t1); us_zip += us(t1, now());
 			{ std::lock_guard<std::mutex> lk(mu); B.ready = true; }
 			cv.notify_all();
 		}
@@ -84,7 +94,9 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 		RowBlock &B = ring[b % WINDOW];
 		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return B.ready || failed.load(); }); }
 		if(failed.load()) { rc = KMAHIP_EIO; break; }
+		const auto t0 = now();
 		if(fwrite(B.data.data(), 1, B.data.size(), f) != B.data.size()) { failed.store(1); rc = KMAHIP_EIO; }
+		us_write += us(t0, now());
 		{ std::lock_guard<std::mutex> lk(mu); B.ready = false; written = b + 1; }
 		cv.notify_all();
 		if(rc) break;
@@ -96,6 +108,8 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 		if(!g || gzclose(g) != Z_OK) rc = KMAHIP_EIO;
 	}
 	if(fclose(f) != 0) rc = KMAHIP_EIO;
+	if(dbg) fprintf(stderr, "[kmahip] write_rows: %zu rows, %d threads: wall %.1f ms; formatting %.1f ms and compressing %.1f ms summed over the threads, writing %.1f ms\n",
+	                n_rows, nt, us(t_begin, now()) / 1e3, us_fmt.load() / 1e3, us_zip.load() / 1e3, us_write / 1e3);
 	if(rc) kmahip_set_error("write to %s failed", path);
 	return rc;
 }
@@ -120,6 +134,7 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 	// fragments in stream order, each chunk back to front (conclave.c:164-166, 194). A counting sort over the templates keeps
 	// the stream order inside each one; the chunks are then turned round in place. (order 1: the single thread of `-Mt1`
 	// writes the rows as they come.)
+	const auto t_order = std::chrono::steady_clock::now();
 	const size_t n_t = db->h_names.size();
 	std::vector<int64_t> t_rows(n_t + 2, 0);
 	for(int64_t i = 0; i < n; ++i) {
@@ -157,28 +172,84 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 			}
 		}
 	}
+	if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] frag_write: row order %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_order).count());
+	// The rows come in template order, the reads lie in stream order: every row gathers from a dozen cache lines nobody has
+	// touched lately. The lines of the rows to come are asked for ahead of time: the per-read entries 16 rows ahead, what they
+	// point to (bases, header) 8 rows ahead.
+	auto ahead = [&](size_t r) {
+		if(r + 16 < n_rows) {
+			const int64_t i = row_read[r + 16];
+			__builtin_prefetch(reads->seq_off + i); __builtin_prefetch(reads->len + i); __builtin_prefetch(reads->N_off + i);
+			__builtin_prefetch(rc + i); __builtin_prefetch(tmpl + i); __builtin_prefetch(n_hits + i);
+			__builtin_prefetch(trace_stats + 10 * i); __builtin_prefetch(read_name_off + i);
+		}
+		if(r + 8 < n_rows) {
+			const int64_t i = row_read[r + 8];
+			const uint64_t *w = reads->seq + reads->seq_off[i];
+			__builtin_prefetch(w); __builtin_prefetch(w + 8);
+			__builtin_prefetch(read_names + read_name_off[i]);
+			__builtin_prefetch(db->h_names[(size_t) abs(tmpl[i]) - 1].data());
+		}
+	};
+	struct Four {
+		uint32_t t[256];
+		char c[256];
+		Four() {
+			for(int v = 0; v < 256; ++v) {
+				char b[4];
+				for(int j = 0; j < 4; ++j) b[j] = "ACGT"[(v >> (6 - 2 * j)) & 3];
+				memcpy(&t[v], b, 4);
+				c[v] = (char) v;
+			}
+			c[(int) 'A'] = 'T'; c[(int) 'C'] = 'G'; c[(int) 'G'] = 'C'; c[(int) 'T'] = 'A';
+		}
+	};
+	static const Four four;
+	auto put_int = [](char *o, int v) {          // "\t<v>", returns the end
+		*o++ = '\t';
+		unsigned u = v < 0 ? 0u - (unsigned) v : (unsigned) v;
+		if(v < 0) *o++ = '-';
+		char d[12];
+		int k = 0;
+		do { d[k++] = (char) ('0' + u % 10); u /= 10; } while(u);
+		while(k) *o++ = d[--k];
+		return o;
+	};
 	auto fmt = [&](size_t r, std::string &out) {
-		static const char bases[] = "ACGTN";
-		static const char comp[] = "TGCAN";
+		ahead(r);
 		const int64_t i = row_read[r];
 		const int L = reads->len[i];
 		const uint64_t *w = reads->seq + reads->seq_off[i];
 		const int32_t *N = reads->N + reads->N_off[i];
 		const int nN = (int) (reads->N_off[i + 1] - reads->N_off[i]);
 		const bool flip = ((rc[i] & 1) != 0) != (tmpl[i] < 0);
+		const std::string &tname = db->h_names[(size_t) abs(tmpl[i]) - 1];
+		const char *rname = read_names + read_name_off[i];            // NUL-terminated
+		const size_t rlen = strlen(rname);
 		const size_t at = out.size();
-		out.resize(at + (size_t) L);
+		out.resize(at + (size_t) (((L + 31) >> 5) << 5) + 4 * 12 + 2 + tname.size() + rlen + 1);
 		char *o = &out[at];
-		if(!flip) for(int p = 0; p < L; ++p) o[p] = bases[(w[p >> 5] >> (62 - ((p & 31) << 1))) & 3];
-		else for(int p = 0; p < L; ++p) o[L - 1 - p] = comp[(w[p >> 5] >> (62 - ((p & 31) << 1))) & 3];
+		{	// four bases per table look-up (the room behind the bases takes the overshoot of the last one)
+			const int words = (L + 31) >> 5;
+			char *d = o;
+			for(int x = 0; x < words; ++x) {
+				const uint64_t v = w[x];
+				for(int b = 56; b >= 0; b -= 8, d += 4) memcpy(d, &four.t[(v >> b) & 0xff], 4);
+			}
+			if(flip) {
+				for(int a = 0, b = L - 1; a < b; ++a, --b) { const char ca = o[a], cb = o[b]; o[a] = four.c[(unsigned char) cb]; o[b] = four.c[(unsigned char) ca]; }
+				if(L & 1) o[L >> 1] = four.c[(unsigned char) o[L >> 1]];
+			}
+		}
 		for(int x = 0; x < nN; ++x) o[flip ? L - 1 - N[x] : N[x]] = 'N';
-		char num[96];
-		const int m = snprintf(num, sizeof num, "\t%d\t%d\t%d\t%d\t", n_hits[i], trace_stats[10 * i], trace_stats[10 * i + 1], trace_stats[10 * i + 2]);
-		out.append(num, (size_t) m);
-		out += db->h_names[(size_t) abs(tmpl[i]) - 1];
-		out += '\t';
-		out.append(read_names + read_name_off[i]);              // NUL-terminated
-		out += '\n';
+		o += L;
+		o = put_int(o, n_hits[i]); o = put_int(o, trace_stats[10 * i]); o = put_int(o, trace_stats[10 * i + 1]); o = put_int(o, trace_stats[10 * i + 2]);
+		*o++ = '\t';
+		memcpy(o, tname.data(), tname.size()); o += tname.size();
+		*o++ = '\t';
+		memcpy(o, rname, rlen); o += rlen;
+		*o++ = '\n';
+		out.resize((size_t) (o - out.data()));
 	};
 	if((e = write_rows(path, n_rows, fmt))) return e;
 	if(rows) *rows = (int64_t) n_rows;

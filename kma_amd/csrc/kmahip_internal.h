@@ -108,6 +108,8 @@ struct kmahip_ws {
 	int32_t *t_s32;
 	uint8_t *t_E;
 	int64_t t_lanes;
+	int32_t *t_queue;            // reads the first trace pass put off
+	int64_t t_queue_cap;
 	int t_max_len;
 	// pile-up stage (3c) scratch and results
 	uint32_t *p_counts;
