@@ -331,6 +331,12 @@ typedef struct kmahip_assemble_opts {
 	int32_t order;      /* 0 ConClave's order, 1 stream order */
 	int32_t caller;     /* 0 baseCaller, 1 nanoCaller */
 	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc */
+	/* per read: how many filed fragments (ConClave template != 0) precede it in the WHOLE stream -- what the reference's
+	 * chunks of max_frag records are counted in (conclave.c:166, 194). NULL: the batch is the whole stream and the
+	 * positions are counted here. A rank that piles up the reads of its templates gathered from several read shards
+	 * (kma_amd/dist.py) passes the positions the reads had in the global stream. Host pointer for kmahip_assemble2,
+	 * device pointer for kmahip_assemble2_dev. */
+	const int64_t *frag_rank;
 } kmahip_assemble_opts;
 int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                      const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out);
@@ -426,6 +432,12 @@ int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads
 int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                        const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const char *read_names,
                        const int64_t *read_name_off, int64_t *rows);
+
+/* kmahip_frag_write2 for a batch that is not the whole stream: frag_rank[i] = number of filed fragments before read i in
+ * the whole stream (as kmahip_assemble_opts.frag_rank; NULL = count them in this batch). */
+int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                       const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const int64_t *frag_rank,
+                       const char *read_names, const int64_t *read_name_off, int64_t *rows);
 
 /* One gzip member as kmahip_frag_write* makes them for a path ending in ".gz": Huffman coding only (the reference deflates
  * at level 1, filebuff.c:189 -- what a reader inflates is the same). The writers compress blocks of rows on several threads

@@ -80,7 +80,8 @@ class ReadBatchC(C.Structure):
 
 
 class AssembleOpts(C.Structure):
-    _fields_ = [("max_frag", C.c_int64), ("evalue", C.c_double), ("bcd", C.c_int32), ("order", C.c_int32), ("caller", C.c_int32), ("sig90", C.c_int32)]
+    _fields_ = [("max_frag", C.c_int64), ("evalue", C.c_double), ("bcd", C.c_int32), ("order", C.c_int32), ("caller", C.c_int32), ("sig90", C.c_int32),
+                ("frag_rank", C.c_void_p)]
 
 
 class Run(C.Structure):
@@ -179,6 +180,8 @@ def lib():
         L.kmahip_run_mt1.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_int, C.POINTER(Params), C.POINTER(AssembleOpts), C.POINTER(Run)]
         L.kmahip_assemble2.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.POINTER(Traces), C.POINTER(AssembleOpts),
                                        C.POINTER(Assembly)]
+        L.kmahip_frag_write3.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_frag_write2.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.kmahip_trace_get_stats.argtypes = [C.c_void_p, C.POINTER(TraceStats)]
@@ -541,9 +544,10 @@ class KmaHipDB:
             return (stats[:n], off[:n], nops[:n], ops[:need.value]), rc_out[:n]
         raise KmaHipError("align_trace_mt1: output capacity kept overflowing")
 
-    def assemble(self, batch, rc, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False):
+    def assemble(self, batch, rc, tmpl, traces, max_frag=0, bcd=1, evalue=0.05, consensus=False, frag_rank=None):
         """Stage 3c per template: pile-up of the traced reads + consensus -> dict(cover, aln_len, depth, asm_len [DB_size],
-        consensus {template: str} when asked). traces = the tuple align_trace returned."""
+        consensus {template: str} when asked). traces = the tuple align_trace returned. frag_rank: positions of the reads among
+        the filed fragments of the whole stream, for a batch gathered from several read shards (kmahip_assemble_opts.frag_rank)."""
         n = batch.n
         stats, off, nops, ops = traces
         seq = np.ascontiguousarray(batch.seq, np.uint64)
@@ -567,8 +571,9 @@ class KmaHipDB:
             coff = np.full(D, -1, np.int64)
         a = Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), None if cbuf is None else _p(cbuf),
                      None if coff is None else _p(coff), cap, 0)
-        _check(lib().kmahip_assemble(self.h, self.ws, C.byref(r), _p(fl), _p(tm), C.byref(tr), int(max_frag), int(bcd), float(evalue),
-                                     C.byref(a)))
+        fr = None if frag_rank is None else np.ascontiguousarray(frag_rank if n else np.zeros(1, np.int64), np.int64)
+        ao = AssembleOpts(int(max_frag), float(evalue), int(bcd), 0, 0, 0, None if fr is None else _p(fr))
+        _check(lib().kmahip_assemble2(self.h, self.ws, C.byref(r), _p(fl), _p(tm), C.byref(tr), C.byref(ao), C.byref(a)))
         if consensus:
             raw = cbuf.tobytes()
             o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
@@ -641,8 +646,8 @@ class KmaHipDB:
         o["ms"] = list(run.ms)
         return o
 
-    def frag_write2(self, path, batch, rc, tmpl, n_hits, stats, read_names, order=1, max_frag=0):
-        """kmahip_frag_write2: order 1 = stream order (`-Mt1`)"""
+    def frag_write2(self, path, batch, rc, tmpl, n_hits, stats, read_names, order=1, max_frag=0, frag_rank=None):
+        """kmahip_frag_write3: order 1 = stream order (`-Mt1`); frag_rank as in assemble"""
         n = batch.n
         seq = np.ascontiguousarray(batch.seq, np.uint64)
         Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
@@ -657,8 +662,9 @@ class KmaHipDB:
         if n:
             noff[1:] = np.cumsum([len(nm) + 1 for nm in read_names])
         rows = C.c_int64()
-        _check(lib().kmahip_frag_write2(os.fsencode(path), self.h, C.byref(r), _p(fl), _p(tm), _p(nh), _p(st), int(max_frag), int(order), blob,
-                                        _p(noff), C.byref(rows)))
+        fr = None if frag_rank is None else np.ascontiguousarray(frag_rank if n else np.zeros(1, np.int64), np.int64)
+        _check(lib().kmahip_frag_write3(os.fsencode(path), self.h, C.byref(r), _p(fl), _p(tm), _p(nh), _p(st), int(max_frag), int(order),
+                                        None if fr is None else _p(fr), blob, _p(noff), C.byref(rows)))
         return rows.value
 
     def run_pe(self, batch, names, pair, evalue=0.05, bcd=1, max_frag=0, frag_path=None):

@@ -761,7 +761,7 @@ static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64
 
 // device part: counts / chains of every template with kept reads. All pointers are device pointers.
 static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
-                         const kmahip_traces *tr, int64_t max_frag, int order, hipStream_t stream) {
+                         const kmahip_traces *tr, int64_t max_frag, int order, const int64_t *frag_rank, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
 	// insertion columns: about one per 30 read bases of noisy long reads at most (every site of a deep pile-up has a few)
 	int64_t node_cap = std::max<int64_t>(1 << 20, n);
@@ -794,7 +794,8 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		fprintf(stderr, "[kmahip] pile-up: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
 		t_prev = t;
 	};
-	{
+	if(frag_rank) A.rank = const_cast<int64_t *>(frag_rank);       // the batch is a gathered part of the stream: positions given
+	else {
 		// rank of every read among the filed fragments: exclusive scan of (tmpl != 0)
 		int64_t *filed = ws->p_rank + n;
 		A.rank = ws->p_rank;
@@ -1047,7 +1048,9 @@ extern "C" int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	   (rc = up(flag, (size_t) n * 4, (void **) &d_flag)) || (rc = up(tmpl, (size_t) n * 4, (void **) &d_tmpl)) ||
 	   (rc = up(traces->stats, (size_t) n * 40, (void **) &dt.stats)) || (rc = up(traces->ops_off, (size_t) n * 8, (void **) &dt.ops_off)) ||
 	   (rc = up(traces->n_ops, (size_t) n * 4, (void **) &dt.n_ops)) || (rc = up(traces->ops, (size_t) total_ops * 4, (void **) &dt.ops))) return rc;
-	return kmahip_assemble2_dev(db, ws, &d, d_flag, d_tmpl, &dt, opts, out);
+	kmahip_assemble_opts od = *opts;
+	if(opts->frag_rank && (rc = up(opts->frag_rank, (size_t) n * 8, (void **) &od.frag_rank))) return rc;
+	return kmahip_assemble2_dev(db, ws, &d, d_flag, d_tmpl, &dt, &od, out);
 }
 
 // the same with the per-read inputs already in HBM (reads, rc, tmpl, traces: DEVICE pointers; `out`: host)
@@ -1069,7 +1072,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	const auto t0 = now();
-	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, opts->order, 0))) return rc;
+	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, opts->order, opts->frag_rank, 0))) return rc;
 	const auto t1 = now();
 	if(dbg) fprintf(stderr, "[kmahip] assemble: pile-up on device %.1f ms\n", ms(t0, t1));
 	if(!ws->p_kept) return KMAHIP_OK;

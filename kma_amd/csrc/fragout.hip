@@ -125,6 +125,12 @@ extern "C" int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_r
 extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                                   const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const char *read_names,
                                   const int64_t *read_name_off, int64_t *rows) {
+	return kmahip_frag_write3(path, db, reads, rc, tmpl, n_hits, trace_stats, max_frag, order, nullptr, read_names, read_name_off, rows);
+}
+
+extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
+                                  const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const int64_t *frag_rank,
+                                  const char *read_names, const int64_t *read_name_off, int64_t *rows) {
 	if(!path || !db || !reads || !rc || !tmpl || !n_hits || !trace_stats || !read_names || !read_name_off) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	int e = load_names(db);
 	if(e) return e;
@@ -152,7 +158,7 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 		for(int64_t i = 0; i < n; ++i) {
 			if(tmpl[i] == 0) continue;
 			const size_t t = (size_t) abs(tmpl[i]);
-			const int64_t r = rank++;
+			const int64_t r = frag_rank ? frag_rank[i] : rank++;
 			if(trace_stats[10 * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
 			const size_t at = (size_t) fill[t]++;
 			row_read[at] = i;

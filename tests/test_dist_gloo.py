@@ -78,3 +78,71 @@ def test_two_rank_read_shards_allreduce_matches_single_process(tmp_path):
                          res["end"], res["alignment_scores"], res["uniq_alignment_scores"], tlen)
     w = np.load(out + ".w.npy")
     assert np.array_equal(w[0], cc["w_scores"].astype(np.int64)) and np.array_equal(w[1], cc["depth"].astype(np.int64))
+
+
+def test_template_owners_are_contiguous_and_balanced():
+    from kma_amd.dist import template_owners
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        c = rng.integers(0, 50, 200)
+        c[rng.random(200) < 0.5] = 0
+        o = template_owners(c, world)
+        assert np.all(np.diff(o) >= 0) and o.min() == 0 and o.max() <= world - 1
+        per = np.bincount(o, weights=c, minlength=world)
+        assert per.max() <= c.sum() / world + c.max()
+    assert np.array_equal(template_owners(np.zeros(5, np.int64), 4), np.zeros(5, np.int64))
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kma_amd.dist import gather_filed_reads, shard_bounds as sb
+    reads, tmpl, stats, runs, names, nh, rc = _gather_case()
+    lo, hi = sb(len(reads), rank, world)
+    batch = formats.pack_ragged(reads[lo:hi])
+    n_ops = np.array([len(r) for r in runs[lo:hi]], np.int32)
+    ops_off = np.zeros(hi - lo, np.int64)
+    ops_off[1:] = np.cumsum(n_ops[:-1])
+    ops = np.concatenate(runs[lo:hi]).astype(np.uint32)
+    owner = np.array([0, 0, 0, 1, 1, 0, 1, 1], np.int64)              # (any map works for the exchange; contiguity is the caller's business)
+    got = gather_filed_reads(batch, rc[lo:hi], tmpl[lo:hi], nh[lo:hi], (stats[lo:hi], ops_off, n_ops, ops), owner, names[lo:hi])
+    b, rc2, tm2, nh2, tr2, rank2, names2 = got
+    np.savez(f"{out}.{rank}.npz", seq=b.seq, seq_off=b.seq_off, length=b.length, N=b.N, N_off=b.N_off, rc=rc2, tmpl=tm2, nh=nh2, stats=tr2[0],
+             ops_off=tr2[1], n_ops=tr2[2], ops=tr2[3], rank=rank2, names=np.array(names2, dtype=object))
+    dist.destroy_process_group()
+
+
+def _gather_case():
+    rng = np.random.default_rng(11)
+    n = 301
+    reads = [rng.integers(0, 5, int(rng.integers(20, 200)), dtype=np.uint8) for _ in range(n)]
+    tmpl = rng.integers(-7, 8, n).astype(np.int32)
+    stats = rng.integers(1, 100, (n, 10)).astype(np.int32)
+    stats[rng.random(n) < 0.2, 3] = 0                                   # dropped by the stage-3c filter: filed, but no pile-up and no row
+    runs = [rng.integers(1, 1 << 20, int(rng.integers(1, 6))).astype(np.uint32) for _ in range(n)]
+    names = [b"read%d/x" % i for i in range(n)]
+    return reads, tmpl, stats, runs, names, rng.integers(1, 4, n).astype(np.int32), rng.integers(0, 2, n).astype(np.int32)
+
+
+def test_filed_reads_reach_their_template_owner_in_stream_order(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "got")
+    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    reads, tmpl, stats, runs, names, nh, rc = _gather_case()
+    owner = np.array([0, 0, 0, 1, 1, 0, 1, 1], np.int64)
+    filed = tmpl != 0
+    frag_rank = np.cumsum(filed) - filed
+    for r in range(2):
+        g = np.load(f"{out}.{r}.npz", allow_pickle=True)
+        want = [i for i in range(len(reads)) if filed[i] and stats[i, 3] != 0 and owner[abs(tmpl[i])] == r]
+        assert len(g["length"]) == len(want) > 20
+        assert np.array_equal(g["rank"], frag_rank[want]) and np.array_equal(g["tmpl"], tmpl[want])
+        assert np.array_equal(g["rc"], rc[want]) and np.array_equal(g["nh"], nh[want]) and np.array_equal(g["stats"], stats[want])
+        assert list(g["names"]) == [names[i] for i in want]
+        ref = formats.pack_ragged([reads[i] for i in want])
+        for k in ("seq", "seq_off", "length", "N", "N_off"):
+            assert np.array_equal(g[k], getattr(ref, k)), k
+        for j, i in enumerate(want):
+            assert np.array_equal(g["ops"][g["ops_off"][j]:g["ops_off"][j] + g["n_ops"][j]], runs[i])
