@@ -87,24 +87,43 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	uint64_t h64[5];
 	if(!read_exact(f, h32, 12) || !read_exact(f, h64, 40)) { fclose(f); kmahip_set_error("short header in %s.comp.b", prefix); return KMAHIP_EIO; }
 	const uint32_t DB_size = h32[0], mlen = h32[1];
-	const uint64_t size = h64[1], n = h64[2], v_index = h64[3];
+	const uint64_t size = h64[1], n_hdr = h64[2], v_index = h64[3];
 	// `kma index -Sparse`: only the k-mers behind a prefix are stored and the reference maps with save_kmers_sparse, without
 	// stage 3 (kma.c:1499-1501); the -1t1 scan over such a table would be wrong without any error
 	if(h32[2] != 0 || h64[0] != 0) { fclose(f); kmahip_set_error("sparse index (prefix length %u) not supported", h32[2]); return KMAHIP_EFORMAT; }
 	if(mlen == 0 || mlen > 16) { fclose(f); kmahip_set_error("k-mer length %u needs 64-bit keys: not supported", mlen); return KMAHIP_EFORMAT; }
 	const uint64_t kmask = (1ull << (2 * mlen)) - 1;
-	if(size - 1 == kmask) { fclose(f); kmahip_set_error("direct-address (megamap) index not supported"); return KMAHIP_EFORMAT; }
-	if(size < n || n > 0xFFFFFFFFull || v_index >= 0xFFFFFFFFull || n == 0) { fclose(f); kmahip_set_error("index too large or old format"); return KMAHIP_EFORMAT; }
-
-	// exist[] is only the reference's bucket directory: skipped
-	if(fseek(f, (long) (size * 4), SEEK_CUR)) { fclose(f); return KMAHIP_EIO; }
+	// A direct-address index (`kma index -ME`, or any index whose table grew to 4^k slots, hashmap.c:204-209): exist[] holds one
+	// entry per possible k-mer, the offset of its value list or 1 for "none" (megaMap_getGlobal, hashmapkma.c:264-273), and
+	// there are no key / value-index arrays. The k-mers present are read out of it in ascending order; from there on the
+	// index is built like any other (the probe table below is what the kernels look k-mers up in).
+	const bool mega = size - 1 == kmask;
+	uint64_t n = n_hdr;
+	if(size < n_hdr || n_hdr > 0xFFFFFFFFull || v_index >= 0xFFFFFFFFull || (n_hdr == 0 && !mega)) { fclose(f); kmahip_set_error("index too large or old format"); return KMAHIP_EFORMAT; }
 	const bool u16 = DB_size < 65535; // hashmapkma.c:340-348
 	// 8 zero elements of slack: the scan kernel fetches a list head as count + 7 ids
 	const size_t vbytes = v_index * (u16 ? 2 : 4);
 	std::vector<uint8_t> values(vbytes + 8 * 4, 0);
-	std::vector<uint32_t> keys(n + 1), vidx(n);
+	std::vector<uint32_t> keys, vidx;
 	uint32_t tail[2] = {mlen, 0};
-	bool ok = read_exact(f, values.data(), vbytes) && read_exact(f, keys.data(), (n + 1) * 4) && read_exact(f, vidx.data(), n * 4);
+	bool ok = true;
+	if(mega) {
+		std::vector<uint32_t> chunk(1u << 22);
+		for(uint64_t at = 0; ok && at < size; at += chunk.size()) {
+			const size_t m = (size_t) std::min<uint64_t>(chunk.size(), size - at);
+			ok = read_exact(f, chunk.data(), m * 4);
+			for(size_t i = 0; ok && i < m; ++i) if(chunk[i] != 1u) { keys.push_back((uint32_t) (at + i)); vidx.push_back(chunk[i]); }
+		}
+		n = keys.size();
+		keys.push_back(0);
+		if(ok && (n == 0 || n > 0xFFFFFFFFull)) { fclose(f); kmahip_set_error("direct-address index holds no k-mers"); return KMAHIP_EFORMAT; }
+		ok = ok && read_exact(f, values.data(), vbytes);
+	} else {
+		// exist[] is only the reference's bucket directory: skipped
+		if(fseek(f, (long) (size * 4), SEEK_CUR)) { fclose(f); return KMAHIP_EIO; }
+		keys.resize(n + 1); vidx.resize(n);
+		ok = read_exact(f, values.data(), vbytes) && read_exact(f, keys.data(), (n + 1) * 4) && read_exact(f, vidx.data(), n * 4);
+	}
 	if(ok && read_exact(f, &tail[0], 4)) ok = read_exact(f, &tail[1], 4);
 	fclose(f);
 	if(!ok) { kmahip_set_error("truncated %s.comp.b", prefix); return KMAHIP_EIO; }

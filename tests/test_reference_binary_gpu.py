@@ -240,3 +240,31 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
+
+
+@pytest.mark.parametrize("k,flags", [(12, ["-ME"]), (9, [])])
+def test_direct_address_index_written_by_kma_index(tmp_path, k, flags):
+    """An index in the reference's direct-address form (`kma index -ME`, hashmapkma.c:264-273, 777-812; without the flag the
+    builder switches to it by itself once the table would be half of 4^k, hashmap.c:204-209 -- k = 9 here): exist[] holds a
+    value-list offset per possible k-mer and there are no key arrays. The whole run against it must equal the reference's."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(40 + k)
+    names, seqs = synth.make_gene_db(30, 4, 500, 1100, 0.04, seed=300 + k)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix, "-k", str(k)] + flags, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    hdr = np.fromfile(prefix + ".comp.b", dtype=np.uint8, count=52)
+    size = int(hdr[20:28].view(np.uint64)[0])
+    assert size == 4 ** k, "the index is not in direct-address form"
+    reads = _reads(seqs, 20000, rng)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, reads, lens=None)
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+                   stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref and got.count(b"\n") > 10000
