@@ -77,6 +77,7 @@ struct AlignArgs {
 	unsigned long long *counters;   // [1] status
 	int stats;
 	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
+	int gap_m_max;   // Lane::gap_m_max
 };
 
 constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
@@ -99,6 +100,7 @@ struct Lane {
 	int q_at, q_mate;          // context of the kma_score call being run (template id, mate slot) for queue entries
 	int64_t q_rd;              // read index of the query being aligned
 	int ablate;
+	int gap_m_max;             // >= 0: DP problems with a provably ungapped answer skip the matrix (nw_diagonal), up to this many mismatches between seeds
 	int diag_uniform;          // d[0][0] == d[1][1] == d[2][2] == d[3][3]: a MEM (never holds an N) scores span * d[0][0]
 	unsigned long long *cnt;   // work counters (stats launches only): [3] lookups [4] MEM bases [5] DP cells [6] tasks
 };
@@ -390,6 +392,42 @@ __device__ __forceinline__ bool dp_enqueue(const Lane &L, int cls, int k, int t_
 	return true;
 }
 
+// mismatches between g read bases from qp and g template bases from tp (neither side holds an N; both word arrays are padded)
+__device__ __forceinline__ int diag_mism(const uint64_t *ts, const QView &q, int tp, int qp, int g) {
+	int m = 0;
+	for(int o = 0; o < g; o += 32) {
+		const int step = min(32, g - o);
+		uint64_t x = (qwin(q, qp + o) ^ win2(ts, tp + o)) >> (64 - 2 * step);
+		x = (x | (x >> 1)) & 0x5555555555555555ull;
+		m += __popcll((long long) x);
+	}
+	return m;
+}
+
+// A DP problem whose only optimal alignment is the diagonal (see the proof at diag_emit below): score and counts without the
+// matrix. gap_m_max < 0: switched off (the score matrix is not plain match / mismatch).
+__device__ __forceinline__ bool nw_diagonal(const Lane &L, const uint64_t *ts, const QView &q, int k, int t_s, int t_e, int q_s, int q_e,
+                                            int tspan, Aln &out) {
+	const int g = q_e - q_s;
+	if(L.gap_m_max < 0 || q.nN || t_e - t_s != tspan || g <= 0) return false;
+	int m;
+	if(k == 0) {
+		if(tspan != g) return false;
+		m = diag_mism(ts, q, t_s, q_s, g);
+		if(m > L.gap_m_max) return false;
+	} else if(k == -1) {
+		if(tspan <= g) return false;
+		m = diag_mism(ts, q, t_e - g, q_s, g);
+		if(m > 1 || (m == 1 && diag_mism(ts, q, t_e - 1 - g, q_s, g) == 0)) return false;
+	} else if(k == 1) {
+		if(tspan <= g) return false;
+		m = diag_mism(ts, q, t_s, q_s, g);
+		if(m > 1 || (m == 1 && diag_mism(ts, q, t_s + 1, q_s, g) == 0)) return false;
+	} else return false;
+	out.score = (g - m) * L.M + m * L.MM; out.len = g; out.match = g; out.tGaps = 0; out.qGaps = 0; out.pos = 0;
+	return true;
+}
+
 __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
                                        int t_s, int t_e, int q_s, int q_e, int tspan, int band) {
 #ifdef KMAHIP_DIAG
@@ -408,6 +446,7 @@ __device__ __forceinline__ Aln nw_auto(const Lane &L, const uint64_t *ts, int t_
 	if(q_e - q_s <= band || tspan <= band) {
 		const int ql = q_e - q_s;
 		if(ql == 0 || tspan == 0) return nw_degenerate(tspan, ql, L.U, L.W1);      // nw.c:662-684
+		{ Aln dg; if(nw_diagonal(L, ts, q, k, t_s, t_e, q_s, q_e, tspan, dg)) return dg; }
 		if(ql == 1 && tspan < 998) return nw_col1(L, ts, t_len, q, k, t_s, t_e, q_s);
 		if(L.queue && ql >= WCOLS && ql < 64 * XC && tspan <= TBUF && tspan + ql < 1000) {
 			// long unaligned ends (a read that matches a template only in part): a lane walking those cells alone takes
@@ -1152,7 +1191,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	L.xq_cap = A.xq_cap; L.xq_cnt = s_xcnt + wave * 4;
 	L.xq = A.xq_cap ? A.xq + (size_t) (gtid >> 6) * 4 * A.xq_cap * QENT : nullptr;
 	L.q_at = 0; L.q_mate = 0; L.q_rd = 0;
-	L.ablate = A.ablate;
+	L.ablate = A.ablate; L.gap_m_max = A.gap_m_max;
 #ifdef KMAHIP_DIAG
 	if(A.ablate & 64) L.queue = nullptr;      // ablation: no cooperative DP
 #endif
@@ -1711,11 +1750,6 @@ struct TLane {
 //    it, or <= 2 W1 + g M with a further gap) or of 2 and more (<= W1 + U + g M). With MM > W1, MM - M > 2 W1 and
 //    MM - M > W1 + U all of these are below (g - 1) M + MM unless x1 == 0.
 // Being the only optimum, the diagonal is what the reference's traceback yields whatever its tie rules.
-__device__ __forceinline__ int diag_mism(const uint64_t *ts, const QView &q, int tp, int qp, int g) {
-	int m = 0;
-	for(int i = 0; i < g; ++i) m += tn(ts, tp + i) != qn(q, qp + i);
-	return m;
-}
 __device__ __forceinline__ void diag_emit(TLane &T, const uint64_t *ts, const QView &q, int tp, int qp, int g, Aln &r) {
 	int score = 0, cls = -1, run = 0;
 	for(int i = 0; i < g; ++i) {
@@ -2048,7 +2082,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	Lane &L = T.L;
 	L.s32 = A.s32 + gtid; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = A.lanes; L.cap1 = A.mem_cap + 1; L.ncols = A.ncols;
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
-	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0;
+	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0; L.gap_m_max = -1;
 	L.diag_uniform = 0;
 	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
@@ -2183,6 +2217,14 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.counters = ws->counters;
 	A.stats = ws->stats_on;
 	A.ablate = 0;
+	{	// nw_diagonal: only with a plain match / mismatch matrix and penalties ordered as its proof needs (KMAHIP_ALIGN_DIAG=0: off)
+		const int M = p->rw.M, MM = p->rw.MM, W1 = p->rw.W1, U = p->rw.U;
+		bool plain = M > 0 && MM < 0 && W1 < 0 && U < 0 && MM > W1 && MM - M > 2 * W1 && MM - M > W1 + U;
+		for(int i = 0; i < 4 && plain; ++i) for(int j = 0; j < 4; ++j) plain = plain && p->rw.d[i][j] == (i == j ? M : MM);
+		const char *e = getenv("KMAHIP_ALIGN_DIAG");
+		if(e && !atoi(e)) plain = false;
+		A.gap_m_max = plain ? (M - 2 * W1 - 1) / (M - MM) : -1;
+	}
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_ALIGN")) A.ablate = atoi(e);
 #endif
