@@ -1706,8 +1706,13 @@ struct TraceArgs {
 	// Two passes. fast != 0: a read whose DP problems all have a provably ungapped answer (see diag_proof) is finished without
 	// a move matrix; any other read is put off -- its index goes to q_out -- so that no lane of a wave sits through another
 	// lane's matrices. The second pass (q_in = that list, fast = 0) gives the reads put off the full treatment.
+	// Three passes in all: between the two, reads whose matrices are small get them in LDS (lds_bytes per lane: four rows of
+	// lds_ncols ints, the rest move bytes; 64 lanes per workgroup) -- a lane alone with its matrix in HBM waits a microsecond per
+	// cell, and the kernel lasts as long as its slowest lane. What does not fit LDS is put off once more.
 	const int32_t *q_in; int32_t *q_out;
+	int q_in_cnt, q_out_cnt;        // counter words holding the length of q_in / q_out
 	int fast, gap_m_max;
+	int lds_bytes, lds_ncols;
 };
 
 struct Emit {
@@ -1737,6 +1742,8 @@ struct TLane {
 	Emit em;
 	int status;     // 1: a DP problem did not fit the per-lane move matrix; 32: put off to the second pass
 	int fast, gap_m_max;
+	int ncols;                 // DP columns the rows hold
+	int64_t row_stride;        // distance between neighbouring row elements (the lane count in HBM, 1 in a lane's own LDS)
 };
 
 // DP problems whose answer is known without the matrix. With match M > 0 > mismatch MM > gap open W1, extension U < 0 (checked
@@ -1763,7 +1770,7 @@ __device__ __forceinline__ void diag_emit(TLane &T, const uint64_t *ts, const QV
 	r.score = score; r.len = g; r.match = g; r.tGaps = 0; r.qGaps = 0; r.pos = 0;
 }
 
-#define TROW(T, r, n) (T).rows[((int64_t) ((r) * (T).L.ncols + (n))) * (T).L.lanes]
+#define TROW(T, r, n) (T).rows[((int64_t) ((r) * (T).ncols + (n))) * (T).row_stride]
 
 // walk of the move matrix (nw.c:256-305 / :586-635), emitting columns. stride = bytes per template row, dn = column
 // change per template step (0 full, -1 band), q_pos = query index of the start column. lead_trim: gaps in front are
@@ -1818,7 +1825,7 @@ __device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QVi
 	const int low = (t_len + q_len) * (L.MM + U + W1);
 	if(band < 0) {
 		const int pitch = q_len + 1;
-		if((int64_t) pitch * (t_len + 1) > T.e_cap || q_len + 2 > L.ncols) return false;
+		if((int64_t) pitch * (t_len + 1) > T.e_cap || q_len + 2 > T.ncols) return false;
 		uint8_t *E = T.E, *Er = E + (int64_t) pitch * t_len;
 		int dc = 0, dp = 1, pc = 2, pp = 3;
 		s.score = low;
@@ -1868,7 +1875,7 @@ __device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QVi
 	// banded (nw.c:310-640)
 	if(band & 1) ++band;
 	const int half = band >> 1, bq = band + 1, pitch = bq + 1;
-	if((int64_t) pitch * (t_len + 1) > T.e_cap || band + 4 > L.ncols) return false;
+	if((int64_t) pitch * (t_len + 1) > T.e_cap || band + 4 > T.ncols) return false;
 	uint8_t *E = T.E, *Er = E + (int64_t) pitch * t_len;
 	int dc = 0, dp = 1, pc = 2, pp = 3;
 	s.score = low;
@@ -2072,7 +2079,7 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 	return S;
 }
 
-__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      // (64 threads in the LDS pass)
 	__shared__ int s_d[25];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
 	__syncthreads();
@@ -2084,12 +2091,19 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1;
 	L.cnt = nullptr; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0; L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0; L.gap_m_max = -1;
 	L.diag_uniform = 0;
-	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap;
+	T.rows = A.rows + gtid; T.E = A.E + gtid * A.e_cap; T.e_cap = A.e_cap; T.ncols = A.ncols; T.row_stride = A.lanes;
+	if(A.lds_bytes) {
+		extern __shared__ __align__(16) uint8_t t_lds[];
+		uint8_t *mine = t_lds + (size_t) threadIdx.x * A.lds_bytes;
+		T.rows = (int32_t *) mine; T.ncols = A.lds_ncols; T.row_stride = 1;
+		T.E = mine + 16 * A.lds_ncols; T.e_cap = A.lds_bytes - 16 * A.lds_ncols;
+	}
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
 	T.fast = A.fast; T.gap_m_max = A.gap_m_max;
 	const int lane = threadIdx.x & 63;
-	const int64_t n_items = A.q_in ? (int64_t) A.counters[3] : A.n_reads;       // (the list was filled by the launch before this one)
-	for(int64_t it = gtid; __any(it < n_items); it += A.lanes) {
+	const int64_t n_items = A.q_in ? (int64_t) A.counters[A.q_in_cnt] : A.n_reads;       // (the list was filled by the launch before this one)
+	const int64_t n_threads = (int64_t) gridDim.x * blockDim.x;
+	for(int64_t it = gtid; __any(it < n_items); it += n_threads) {
 		const int64_t r = it < n_items ? (A.q_in ? (int64_t) A.q_in[it] : it) : A.n_reads;
 		// what the read contributes: nothing (keep = false) or its figures + T.em.n alignment runs
 		bool keep = false;
@@ -2110,7 +2124,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {
 				const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
 				T.em.n = 0; T.em.over = false; T.status = 0;
 				S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
-				if(T.status == 32) A.q_out[atomicAdd(&A.counters[3], 1ull)] = (int32_t) r;
+				if(T.status == 32 || (T.status == 1 && A.lds_bytes)) A.q_out[atomicAdd(&A.counters[A.q_out_cnt], 1ull)] = (int32_t) r;
 				else if(T.status || T.em.over) atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16)));
 				else {
 					// assemble_KMA, assembly.c:1931-1961
@@ -2378,11 +2392,11 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
-	HIP_TRY(hipMemsetAsync(ws->counters + 3, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 3, 0, 2 * sizeof(unsigned long long), stream));
 	if(ws->t_queue_cap < n) {
 		(void) hipFree(ws->t_queue);
 		ws->t_queue = nullptr; ws->t_queue_cap = 0;
-		HIP_TRY(hipMalloc((void **) &ws->t_queue, (size_t) n * sizeof(int32_t)));
+		HIP_TRY(hipMalloc((void **) &ws->t_queue, (size_t) n * 2 * sizeof(int32_t)));
 		ws->t_queue_cap = n;
 	}
 	TraceArgs A;
@@ -2405,19 +2419,34 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		const char *mode = getenv("KMAHIP_TRACE");
 		if(mode && !strcmp(mode, "lanes1")) plain = false;
 	}
-	A.q_in = nullptr; A.q_out = ws->t_queue; A.fast = plain ? 1 : 0;
+	A.q_in = nullptr; A.q_out = ws->t_queue; A.q_in_cnt = 3; A.q_out_cnt = 3; A.fast = plain ? 1 : 0;
 	A.gap_m_max = plain ? (M - 2 * W1 - 1) / (M - MM) : 0;
+	A.lds_bytes = 0; A.lds_ncols = 0;
 	hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
 	HIP_TRY(hipGetLastError());
 	if(plain) {
-		A.q_in = ws->t_queue; A.fast = 0;
+		// pass 2: the reads put off, with their move matrices in HBM. (KMAHIP_TRACE_LDS=1 puts a pass with the matrices of small
+		// problems in LDS in between -- 1008 bytes per lane: rows of 24 columns + 624 move bytes; measured on the 10 M-read
+		// workload it takes a third of the put-off reads and the kernel time stays that of the slowest lane of the last pass:
+		// 27.9 ms for the three passes against 23.1 for two. Kept for workloads whose put-off problems are all small.)
+		const bool lds_pass = getenv("KMAHIP_TRACE_LDS") && atoi(getenv("KMAHIP_TRACE_LDS"));
+		A.q_in = ws->t_queue; A.q_out = ws->t_queue + n; A.q_in_cnt = 3; A.q_out_cnt = 4; A.fast = 0;
+		if(lds_pass) {
+			A.lds_bytes = 1008; A.lds_ncols = 24;
+			const unsigned g2 = (unsigned) std::min<int64_t>(lanes / 64, 256 * 2 * 8);
+			hipLaunchKernelGGL(trace_kernel, dim3(g2), dim3(64), 64 * 1008, stream, A);
+			HIP_TRY(hipGetLastError());
+			A.q_in = ws->t_queue + n; A.q_in_cnt = 4;
+		}
+		A.q_out = nullptr; A.lds_bytes = 0; A.lds_ncols = 0;
 		hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
 		HIP_TRY(hipGetLastError());
 		if(getenv("KMAHIP_DEBUG_TIMING")) {
-			unsigned long long put_off = 0;
+			unsigned long long put_off[2] = {0, 0};
 			HIP_TRY(hipStreamSynchronize(stream));
-			HIP_TRY(hipMemcpy(&put_off, ws->counters + 3, sizeof put_off, hipMemcpyDeviceToHost));
-			fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the second pass\n", (long long) n, put_off);
+			HIP_TRY(hipMemcpy(put_off, ws->counters + 3, sizeof put_off, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the pass with matrices in LDS, %llu of them to the pass with matrices in HBM\n",
+			        (long long) n, put_off[0], put_off[1]);
 		}
 	}
 	return KMAHIP_OK;

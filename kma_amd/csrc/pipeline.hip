@@ -9,14 +9,33 @@
 
 namespace {
 
+// Device buffers of one run, carved out of a few large allocations (a hipMalloc per array cost more than ConClave itself:
+// thirty of them per run). Everything is released when the run ends.
 struct DevBlock {
 	std::vector<void *> owned;
+	char *slab = nullptr;
+	size_t slab_left = 0, slab_bytes = 256u << 20;
 	~DevBlock() { for(void *p : owned) (void) hipFree(p); }
+	void expect(size_t bytes) { slab_bytes = std::max(slab_bytes, bytes); }
 	template <class T> int get(size_t n, T **dst, bool zero = false) {
-		void *d = nullptr;
-		if(hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", n * sizeof(T)); return KMAHIP_ENOMEM; }
-		owned.push_back(d);
-		if(zero && hipMemset(d, 0, (n ? n : 1) * sizeof(T)) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+		const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t) 255;
+		if(bytes > slab_left) {
+			const size_t want = std::max(bytes, slab_bytes);
+			void *d = nullptr;
+			if(hipMalloc(&d, want) != hipSuccess) {
+				// (a smaller slab may still fit)
+				if(want == bytes || hipMalloc(&d, bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+				owned.push_back(d);
+				if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+				*dst = (T *) d;
+				return KMAHIP_OK;
+			}
+			owned.push_back(d);
+			slab = (char *) d; slab_left = want;
+		}
+		void *d = slab;
+		slab += bytes; slab_left -= bytes;
+		if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
 		*dst = (T *) d;
 		return KMAHIP_OK;
 	}
@@ -24,7 +43,7 @@ struct DevBlock {
 		T *d = nullptr;
 		int rc = get(n + pad, &d);
 		if(rc) return rc;
-		if(pad && hipMemset(d + n, 0, pad * sizeof(T)) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+		if(pad && hipMemsetAsync(d + n, 0, pad * sizeof(T), 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
 		if(n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { kmahip_set_error("hipMemcpy failed"); return KMAHIP_EDEVICE; }
 		*dst = d;
 		return KMAHIP_OK;
@@ -63,7 +82,8 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	int rc;
 	auto t = std::chrono::steady_clock::now();
 
-	// the batch, once
+	// the batch, once (the slabs are sized for what a run of n reads usually needs: ~230 bytes per read next to the reads)
+	B.expect((size_t) reads->seq_words * 8 + (size_t) reads->N_total * 4 + (size_t) n * 280 + (64u << 20));
 	kmahip_reads d = *reads;
 	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &d.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &d.seq_off)) ||
 	   (rc = B.up(reads->len, (size_t) n, 1, &d.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &d.N)) ||
