@@ -119,7 +119,9 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	   (rc = B.get((size_t) n + 1, &h.rc, true)) || (rc = B.get((size_t) total + 1, &h.tmpl, true)) || (rc = B.get((size_t) total + 1, &h.score, true)) ||
 	   (rc = B.get((size_t) total + 1, &h.start, true)) || (rc = B.get((size_t) total + 1, &h.end, true)) ||
 	   (rc = B.get(D, &h.alignment_scores, true)) || (rc = B.get(D, &h.uniq_alignment_scores, true))) return rc;
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a buffers after %.2f ms\n", since(t2)); }
 	if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a launched after %.2f ms\n", since(t2)); }
 	HIP_TRY(hipStreamSynchronize(s));
 	if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
 	out->ms[1] = since(t);
@@ -129,10 +131,13 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	if((rc = B.get((size_t) n + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n + 1, &cc.start, true)) || (rc = B.get((size_t) n + 1, &cc.end, true)) ||
 	   (rc = B.get(D, &cc.w_scores, true))) return rc;
 	cc.fragment_counts = nullptr; cc.read_counts = nullptr; cc.depth = nullptr;
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: ConClave buffers after %.2f ms\n", since(t2)); }
 	if(n && (rc = kmahip_conclave_se_dev(db, ws, &d, &c, &h, &cc, s))) return rc;
 	std::vector<uint64_t> w(D);
 	HIP_TRY(hipMemcpy(w.data(), cc.w_scores, D * 8, hipMemcpyDeviceToHost));
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: ConClave kernel + scores back after %.2f ms\n", since(t2)); }
 	if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: .res statistics after %.2f ms\n", since(t2)); }
 	std::vector<uint8_t> ok(D + 8, 0);
 	for(int64_t r = 0; r < out->n_rows; ++r) ok[(size_t) out->rows[r].template_id] = (uint8_t) out->rows[r].significant;
 	const uint8_t *d_ok = nullptr;
