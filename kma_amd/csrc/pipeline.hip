@@ -342,8 +342,14 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	out->ms[2] = since(t);
 
 	// the fragments in record order; the first fragment of a record carries the sign of the template (conclave.c:131-146)
+	// runConClave closes a chunk of filed fragments when, AFTER a whole record, maxFrag or more have gone in (conclave.c:164-196):
+	// a couple that straddles the limit makes a chunk of maxFrag + 1. The chunks are counted here record by record and handed
+	// on as positions c (maxFrag + 1) + index, with maxFrag + 1 as the chunk length the pile-up and the writer divide by.
 	HostBatch FB;
 	std::vector<int32_t> f_rc, f_t, f_nh;
+	std::vector<int64_t> f_rank;
+	const int64_t mf = max_frag > 0 ? max_frag : 1000000;
+	int64_t chunk = 0, in_chunk = 0;
 	for(int64_t k = 0; k < nrec; ++k) {
 		const int tt = c_tmpl[(size_t) k];
 		for(size_t x = 0; x < frags[(size_t) k].size(); ++x) {
@@ -351,6 +357,11 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 			f_rc.push_back(frags[(size_t) k][x].rc);
 			f_t.push_back(x == 0 ? tt : abs(tt));
 			f_nh.push_back(r_n[(size_t) k]);
+			f_rank.push_back(tt ? chunk * (mf + 1) + in_chunk + (int64_t) x : 0);
+		}
+		if(tt) {
+			in_chunk += (int64_t) frags[(size_t) k].size();
+			if(in_chunk >= mf) { ++chunk; in_chunk = 0; }
 		}
 	}
 	const int64_t nf = (int64_t) FB.len.size();
@@ -371,7 +382,8 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	}
 	out->ms[3] = since(t);
 	if(nf > 0) {
-		if((rc = kmahip_assemble(db, ws, &fr, f_rc.data(), f_t.data(), &tr, max_frag, bcd, evalue, &out->assembly))) return rc;
+		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, 0, 0, f_rank.data()};
+		if((rc = kmahip_assemble2(db, ws, &fr, f_rc.data(), f_t.data(), &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);
 	if(frag_path && nf > 0) {
@@ -385,7 +397,7 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 			noff.push_back((int64_t) names.size());
 		}
 		int64_t rows = 0;
-		if((rc = kmahip_frag_write(frag_path, db, &fr, f_rc.data(), f_t.data(), f_nh.data(), stats.data(), max_frag, names.data(), noff.data(), &rows))) return rc;
+		if((rc = kmahip_frag_write3(frag_path, db, &fr, f_rc.data(), f_t.data(), f_nh.data(), stats.data(), mf + 1, 0, f_rank.data(), names.data(), noff.data(), &rows))) return rc;
 	}
 	out->ms[5] = since(t);
 	return KMAHIP_OK;

@@ -51,8 +51,8 @@ def _reads(seqs, n, rng):
     return out
 
 
-@pytest.mark.parametrize("seed,families,variants", [(1, 40, 5), (2, 12, 12)])
-def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants):
+@pytest.mark.parametrize("seed,families,variants,mf", [(1, 40, 5, None), (2, 12, 12, None), (3, 20, 5, 1000)])
+def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants, mf):
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -63,8 +63,9 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants):
     reads = _reads(seqs, 60000, rng)
     fq = str(tmp_path / "reads.fq")
     synth.write_fastq(fq, reads, lens=None)
-    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+    extra = ["-mf", str(mf)] if mf else []        # (-mf: fragments per assembly chunk, 60 chunks here instead of one)
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"] + extra, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")] + extra, check=True,
                    stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -73,9 +74,11 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants):
     assert got.count(b"\n") > 40000
 
 
-def test_whole_paired_run_equals_reference_binary(tmp_path):
+@pytest.mark.parametrize("mf", [None, 1001])
+def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
     """`-ipe r1 r2 -apm p -1t1 -t 1`: pairs with substitutions, some mates foreign or too short after trimming (single records in the
-    pair stream), through the reference and through examples/kmahip_map -ipe."""
+    pair stream), some with an insertion or deletion, through the reference and through examples/kmahip_map -ipe. With -mf 1001
+    the assembly chunks close after whole records: couples straddle the limit (chunks of 1002 fragments, conclave.c:164-196)."""
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -95,14 +98,19 @@ def test_whole_paired_run_equals_reference_binary(tmp_path):
             q1[i] = bytes(q)
         else:
             q2[i] = bytes(q)
+    for i in rng.choice(len(r1), 2500, replace=False):                   # an insertion or a deletion in a mate (the pile-up order matters)
+        r = r1 if rng.random() < 0.5 else r2
+        a = int(rng.integers(30, 120))
+        r[i] = np.concatenate([r[i][:a], rng.integers(0, 4, 2, dtype=np.uint8), r[i][a:148]]) if rng.random() < 0.5 else np.concatenate([r[i][:a], r[i][a + 2:], r[i][:2]])
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    extra = ["-mf", str(mf)] if mf else []
     for path, rs, qs, tag in ((tmp_path / "r1.fq", r1, q1, b"/1"), (tmp_path / "r2.fq", r2, q2, b"/2")):
         with open(path, "wb") as f:
             for i, (r, q) in enumerate(zip(rs, qs)):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
-    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")] + extra,
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -232,9 +240,9 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
         with open(path, "wb") as f:
             for i, r in enumerate(rs):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
-    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")] + extra,
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
