@@ -377,6 +377,17 @@ int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int3
 int kmahip_res_line(const char *template_name, const kmahip_res_row *row, int64_t cover, int64_t aln_len, int64_t depth_sum,
                     double ID_t, double Depth_t, char *line, int64_t cap);
 
+/* ---- index build: `kma index -i <fasta ...> -o <prefix> [-k k]` ------------------------------------------------
+ * Writes <prefix>.comp.b / .length.b / .seq.b / .name as the reference's index.c + makeindex.c:167-330 (makeDB) +
+ * compress.c:83-614 (compressKMA_DB) do for the default options: the hashed index form, k <= 16, templates trimmed of leading /
+ * trailing N's (their count goes into the name as " B<n>"), templates shorter than k skipped, k-mers that hold an N left out,
+ * equal template lists stored once. Every k-mer start becomes a 64-bit key on the device (k-mer << 32 | template), sorted and
+ * made unique there (rocPRIM); grouping, list sharing and the bucket directory are one pass on the host. The files hold the
+ * same k-mer -> template-list mapping as the reference's (tests compare the two) and the reference maps against them with
+ * identical results; bucket count, key order inside a bucket and list order are the builder's own. FASTA input, plain or .gz.
+ * Not covered: -Sparse / prefixes, minimizers (-m), homopolymer compression (-hc), -batch, -deCon, appending (-t_db). */
+int kmahip_index_build(const char *const *fasta_paths, int n_files, const char *out_prefix, int kmersize);
+
 /* ---- stage 1: FASTQ / FASTA ingest into packed read batches -------------------------------------------
  * Host code (zlib for .gz, plain files read as they are): the record parser of FileBuffgetFq / FileBuffgetFsa
  * (seqparse.c:241-403, 66-159) with the to2Bit table of kma.c:1440-1480 (IUPAC codes fold onto ACGT, N / X = 4), the

@@ -216,6 +216,16 @@ def cigar_from_runs(runs, clip_start=0, clip_end=0):
     return "".join(out)
 
 
+def index_build(fasta_paths, out_prefix, k=16):
+    """kmahip_index_build: the four index files from FASTA file(s) (needs a GPU: the k-mers are sorted on the device)"""
+    paths = [os.fsencode(p) for p in ([fasta_paths] if isinstance(fasta_paths, (str, bytes)) else fasta_paths)]
+    arr = (C.c_char_p * len(paths))(*paths)
+    L = lib()
+    L.kmahip_index_build.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int]
+    L.kmahip_index_build.restype = C.c_int
+    _check(L.kmahip_index_build(arr, len(paths), os.fsencode(out_prefix), int(k)))
+
+
 class Ingest:
     """Stage 1 on the host (kmahip_ingest_*): FASTQ / FASTA(.gz) -> trimmed, packed formats.ReadBatch batches, the
     records the reference's run_input / run_input_PE write into the S1 stream, in the same order."""
