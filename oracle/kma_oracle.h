@@ -74,6 +74,14 @@ int64_t orc_scan_se_batch(const orc_db *db, const orc_rewards *rw, int exhaustiv
  * S2 records in stream order (present = 0: not written). mate = which input read the record carries,
  * rc = 1 when its reverse complement is the sequence written. T1/T2: caller buffers of 2*DB_size ints the
  * record lists point into. Returns the reference's unmapped mask (0 both written ... 3 none). */
+/* stage 2, default mode (no -1t1): save_kmers_chain, savekmers.c:5127-5945. One read -> up to out_cap S2 records, one per
+ * accepted chain: rc_flag = the chain's score (negative when both strands carry it: the reverse strand's templates follow as
+ * negative ids), emit_rc = 1 when the reverse-complemented read is the one printed, [q_start, q_end) = the query bounds
+ * appended to the header (qseqs.c:41-56). T lists live in T_pool. Returns the number of records, -1 when a capacity ran out. */
+typedef struct { int rc_flag, emit_rc, nT, q_start, q_end; const int *T; } orc_chain_rec;
+int orc_scan_chain(const orc_db *db, const orc_rewards *rw, int exhaustive, int minlen, double coverT, double mrs,
+                   const uint64_t *seq, int seqlen, const int *N /* N[0] = count */, orc_chain_rec *out, int out_cap, int *T_pool, int T_cap);
+
 typedef struct { int present, mate, rc, rc_flag, flag, nT; const int *T; } orc_pe_rec;
 int orc_scan_pe(const orc_db *db, const orc_rewards *rw, int exhaustive,
                 const uint64_t *seq1, int len1, const int *N1, int nN1,

@@ -25,6 +25,10 @@ class AlignParams(C.Structure):
     _fields_ = [("minlen", C.c_int), ("mq", C.c_int), ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double)]
 
 
+class ChainRec(C.Structure):
+    _fields_ = [("rc_flag", C.c_int), ("emit_rc", C.c_int), ("nT", C.c_int), ("q_start", C.c_int), ("q_end", C.c_int), ("T", C.c_void_p)]
+
+
 class PeRec(C.Structure):
     _fields_ = [("present", C.c_int), ("mate", C.c_int), ("rc", C.c_int), ("rc_flag", C.c_int), ("flag", C.c_int),
                 ("nT", C.c_int), ("T", C.POINTER(C.c_int))]
@@ -121,6 +125,32 @@ class OracleDB:
             if r >= 0:
                 return rc_flag, flag, T_off, T[:r]
             cap = -r + 16
+
+    def scan_chain(self, batch, minlen=16, coverT=0.1, mrs=0.5, exhaustive=0):
+        """default template finder (no -1t1), read by read -> list per read of (rc_flag, emit_rc, q_start, q_end, T array)"""
+        L = lib()
+        L.orc_scan_chain.restype = C.c_int
+        L.orc_scan_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        out = []
+        rec = (ChainRec * 64)()
+        pool = np.zeros(1 << 20, np.int32)
+        seq = np.ascontiguousarray(batch.seq)
+        for i in range(batch.n):
+            Ln = int(batch.length[i])
+            words = np.zeros(((Ln + 31) >> 5) + 2, np.uint64)
+            w = seq[batch.seq_off[i]:batch.seq_off[i] + ((Ln + 31) >> 5)]
+            words[:len(w)] = w
+            Ni = batch.N[batch.N_off[i]:batch.N_off[i + 1]]
+            Nl = np.zeros(len(Ni) + 2, np.int32)
+            Nl[0] = len(Ni)
+            Nl[1:1 + len(Ni)] = Ni
+            r = L.orc_scan_chain(self.h, C.byref(self.rw), exhaustive, minlen, coverT, mrs, _p(words), Ln, _p(Nl), rec, 64, _p(pool), len(pool))
+            assert r >= 0, "oracle chain finder: capacity"
+            base = pool.ctypes.data
+            out.append([(rec[x].rc_flag, rec[x].emit_rc, rec[x].q_start, rec[x].q_end,
+                         pool[(rec[x].T - base) // 4:(rec[x].T - base) // 4 + rec[x].nT].copy()) for x in range(r)])
+        return out
 
     def align_se(self, batch, rc_flag, flag, T_off, T, minlen=16, mq=0, scoreT=0.5, mrc=0.0):
         """-> dict(n_hits, best_score, out_flag, tmpl, start, end, score (CSR at T_off), alignment_scores, uniq)"""

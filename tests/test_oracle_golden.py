@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 import golden_util
 import oracle
@@ -325,3 +326,106 @@ def test_oracle_mt1_pileup_and_nanocaller_match_res_fsa_frags(tmp_path):
     exp = open(os.path.join(golden_util.GOLD, "mt1", "out.res")).read().splitlines()[1].split("\t")
     assert int(exp[1]) == score and int(exp[3]) == tlen[1]
     assert tuple(x.strip() for x in exp[4:9]) == oracle.res_identity_columns(call, int(tlen[1]))
+
+
+@pytest.mark.parametrize("name", ["se", "long"])
+def test_chain_finder_oracle_matches_reference_s2_tap(tmp_path, name):
+    """KMA's default template finder (no -1t1), oracle/chain.c, against the reference's own `-s2` tap of the same reads
+    (tests/golden/make_golden_chain.py): the same records in the same order -- score / strand flag, template list, the read or
+    its reverse complement, and the query bounds behind the header. Left out: reads with an N among their first k - 1 bases --
+    behind an N the reference restarts its reverse-strand k-mer k bases too far on (savekmers.c:5447-5449; restated as it is),
+    and for those reads that lands beyond the end of its buffer, on whatever an earlier read left there."""
+    import gzip
+    import struct
+    g = golden_util.load_se(tmp_path, name)
+    tap, n_reads = formats.parse_s2(gzip.open(os.path.join(g["dir"], "s2_chain.bin.gz")).read())
+    by_read = {}
+    for w in tap:
+        by_read.setdefault(w["hdr"][:len(w["hdr"]) - 9], []).append(w)
+    db = oracle.OracleDB(g["prefix"])
+    got = db.scan_chain(g["batch"])
+    b = g["batch"]
+    n_rec = skipped = 0
+    for i, recs in enumerate(got):
+        hdr = g["s1"][i]["hdr"]
+        Ni = b.N[b.N_off[i]:b.N_off[i + 1]]
+        if len(Ni) and int(Ni[0]) < 15:
+            skipped += 1
+            continue
+        want = by_read.get(hdr, [])
+        assert len(want) == len(recs), (i, hdr, len(want), len(recs))
+        for w, (rc_flag, emit_rc, q_start, q_end, T) in zip(want, recs):
+            n_rec += 1
+            assert w["hdr"] == hdr + b"\x00" + struct.pack("<2i", q_start, q_end), (i, hdr, w["hdr"], q_start, q_end)
+            assert w["rc_flag"] == rc_flag and np.array_equal(w["T"], T), (i, hdr, w["rc_flag"], rc_flag, w["T"], T)
+            L = int(b.length[i])
+            seq = b.seq[b.seq_off[i]:b.seq_off[i] + ((L + 31) >> 5)]
+            if emit_rc:
+                seq, _ = oracle.rc_packed(seq, L, Ni)
+            assert np.array_equal(w["seq"], seq), (i, hdr, "sequence / strand")
+    assert n_rec > 200 and skipped < 100, (n_rec, skipped)
+
+
+def _chimeric_reads(seqs, n, rng, with_n=True):
+    """reads glued from 1-3 pieces of different genes and strands, with substitutions, small indels and (behind base 20) N's"""
+    from kma_amd import synth
+    out = []
+    for _ in range(n):
+        parts = []
+        for _p in range(int(rng.integers(1, 4))):
+            s = seqs[int(rng.integers(0, len(seqs)))]
+            L = int(rng.integers(40, 260))
+            a = int(rng.integers(0, max(1, len(s) - L)))
+            r = s[a:a + L].copy()
+            if rng.random() < 0.5:
+                r = synth.revcomp_codes(r)
+            parts.append(r)
+            if rng.random() < 0.3:
+                parts.append(rng.integers(0, 4, int(rng.integers(5, 60)), dtype=np.uint8))       # foreign stretch
+        r = np.concatenate(parts)
+        x = rng.random(len(r)) < 0.01
+        r[x] = (r[x] + rng.integers(1, 4, int(x.sum()), dtype=np.uint8)) & 3
+        if rng.random() < 0.2 and len(r) > 60:
+            p = int(rng.integers(30, len(r) - 20))
+            r = np.concatenate([r[:p], r[p + int(rng.integers(1, 4)):]]) if rng.random() < 0.5 else np.concatenate([r[:p], rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8), r[p:]])
+        if with_n and rng.random() < 0.15 and len(r) > 50:
+            r[int(rng.integers(20, len(r)))] = 4
+        out.append(np.ascontiguousarray(r.astype(np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_chain_finder_oracle_differential_against_reference_binary(tmp_path, seed):
+    """Chimeric reads (several chains per read: the extraction loop, tie anchors, the segment tree) through oracle/chain.c and
+    through the compiled reference (`kma -s2` without -1t1). Skipped where oracle/_ref/kma has not been built."""
+    import struct
+    import subprocess
+    from kma_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kma = os.path.join(root, "oracle", "_ref", "kma")
+    if not os.path.exists(kma):
+        pytest.skip("oracle/_ref/kma not built")
+    rng = np.random.default_rng(100 + seed)
+    names, seqs = synth.make_gene_db(25, 4, 300, 900, 0.05, seed=200 + seed)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([kma, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = _chimeric_reads(seqs, 3000, rng)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    tap = subprocess.run([kma, "-i", fq, "-o", str(tmp_path / "o"), "-t_db", prefix, "-t", "1", "-s2"], check=True, stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL).stdout
+    want, _ = formats.parse_s2(tap)
+    db = oracle.OracleDB(prefix)
+    b = formats.pack_ragged(reads)
+    got = db.scan_chain(b)
+    flat = []
+    for i, recs in enumerate(got):
+        for rc_flag, emit_rc, q_start, q_end, T in recs:
+            flat.append((b"r%d" % i + bytes(2) + struct.pack("<2i", q_start, q_end), rc_flag, tuple(int(x) for x in T)))
+    ref = [(w["hdr"], w["rc_flag"], tuple(int(x) for x in w["T"])) for w in want]
+    multi = sum(1 for recs in got if len(recs) > 1)
+    assert multi > 300, multi
+    for x, (a, c) in enumerate(zip(flat, ref)):
+        assert a == c, (x, a, c)
+    assert len(flat) == len(ref)
