@@ -377,6 +377,28 @@ int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int3
 int kmahip_res_line(const char *template_name, const kmahip_res_row *row, int64_t cover, int64_t aln_len, int64_t depth_sum,
                     double ID_t, double Depth_t, char *line, int64_t cap);
 
+/* ---- stage 2 of the DEFAULT mode (no -1t1) -------------------------------------------------------------------
+ * kmerScan = save_kmers_chain (savekmers.c:5127-5945, the reference's default, savekmers.c:40) with the default helpers of
+ * kmeranker.c:25-30. A read yields zero or more S2 records, one per accepted chain of anchors: rc_flag = the chain's score
+ * (negative: both strands carry it and the reverse strand's templates follow as negative ids), emit_rc = 1 when the record
+ * prints the reverse-complemented read (print_ankers with qseq_r), [q_start, q_end) = the query bounds insertKmerBound appends
+ * to the header behind a NUL (qseqs.c:41-56; read back at alnfrags.c:1092-1099, conclave.c:137-145, assembly.c:1926-1933).
+ * Records come back in stream order: reads ascending, the chains of a read in the order the reference prints them. HOST buffers;
+ * KMAHIP_EOVERFLOW with n_recs / n_T = what is needed when rec_cap / T_cap are too small. Parameters: minlen (-ml, 16),
+ * coverT (-mct, 0.1: how much of a chain may overlap what was taken before), mrs (-mrs, 0.5); NULL = those defaults.
+ * One lane per read on per-lane scratch in HBM: the anchor search is this round's correct-first form. */
+typedef struct kmahip_chain_params { int32_t minlen; int32_t pad_; double coverT, mrs; } kmahip_chain_params;
+typedef struct kmahip_chain_recs {
+	int64_t rec_cap, T_cap;   /* in: capacities of the arrays below (T_off: rec_cap + 1) */
+	int64_t n_recs, n_T;      /* out */
+	int64_t *read;            /* index of the read in the batch */
+	int32_t *rc_flag, *emit_rc, *q_start, *q_end;
+	int64_t *T_off;           /* templates of record i: T[T_off[i] .. T_off[i + 1]) */
+	int32_t *T;
+} kmahip_chain_recs;
+int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, const kmahip_chain_params *cp,
+                      kmahip_chain_recs *out);
+
 /* ---- index build: `kma index -i <fasta ...> -o <prefix> [-k k]` ------------------------------------------------
  * Writes <prefix>.comp.b / .length.b / .seq.b / .name as the reference's index.c + makeindex.c:167-330 (makeDB) +
  * compress.c:83-614 (compressKMA_DB) do for the default options: the hashed index form, k <= 16, templates trimmed of leading /

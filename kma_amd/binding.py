@@ -79,6 +79,16 @@ class ReadBatchC(C.Structure):
     _fields_ = [("reads", Reads), ("names", C.c_void_p), ("name_off", C.c_void_p), ("pair", C.c_void_p), ("records", C.c_int64)]
 
 
+class ChainParams(C.Structure):
+    _fields_ = [("minlen", C.c_int32), ("pad_", C.c_int32), ("coverT", C.c_double), ("mrs", C.c_double)]
+
+
+class ChainRecs(C.Structure):
+    _fields_ = [("rec_cap", C.c_int64), ("T_cap", C.c_int64), ("n_recs", C.c_int64), ("n_T", C.c_int64), ("read", C.c_void_p),
+                ("rc_flag", C.c_void_p), ("emit_rc", C.c_void_p), ("q_start", C.c_void_p), ("q_end", C.c_void_p), ("T_off", C.c_void_p),
+                ("T", C.c_void_p)]
+
+
 class AssembleOpts(C.Structure):
     _fields_ = [("max_frag", C.c_int64), ("evalue", C.c_double), ("bcd", C.c_int32), ("order", C.c_int32), ("caller", C.c_int32), ("sig90", C.c_int32),
                 ("frag_rank", C.c_void_p)]
@@ -336,6 +346,40 @@ class KmaHipDB:
         raise KmaHipError("scan_se: output capacity kept overflowing")
 
     # -- device resident (torch tensors) -----------------------------------------
+    def scan_chain(self, batch, minlen=16, coverT=0.1, mrs=0.5, exhaustive=0):
+        """Stage 2 of the default mode (kmahip_scan_chain, no -1t1) -> dict(read, rc_flag, emit_rc, q_start, q_end, T_off, T):
+        one entry per S2 record, in stream order"""
+        n = batch.n
+        seq = np.ascontiguousarray(batch.seq, np.uint64)
+        Nn = np.ascontiguousarray(batch.N if len(batch.N) else np.zeros(1, np.int32), np.int32)
+        r = Reads(n, _p(seq), _p(batch.seq_off), _p(batch.length), _p(Nn), _p(batch.N_off), len(seq), len(batch.N),
+                  int(batch.length.max()) if n else 0)
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        cp = ChainParams(int(minlen), 0, float(coverT), float(mrs))
+        L = lib()
+        L.kmahip_scan_chain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(ChainParams), C.POINTER(ChainRecs)]
+        L.kmahip_scan_chain.restype = C.c_int
+        rec_cap, T_cap = 2 * n + 1024, 16 * n + 4096
+        for _ in range(4):
+            o = dict(read=np.zeros(rec_cap, np.int64), rc_flag=np.zeros(rec_cap, np.int32), emit_rc=np.zeros(rec_cap, np.int32),
+                     q_start=np.zeros(rec_cap, np.int32), q_end=np.zeros(rec_cap, np.int32), T_off=np.zeros(rec_cap + 1, np.int64),
+                     T=np.zeros(T_cap, np.int32))
+            out = ChainRecs(rec_cap, T_cap, 0, 0, _p(o["read"]), _p(o["rc_flag"]), _p(o["emit_rc"]), _p(o["q_start"]), _p(o["q_end"]),
+                            _p(o["T_off"]), _p(o["T"]))
+            rc = L.kmahip_scan_chain(self.h, self.ws, C.byref(r), C.byref(p), C.byref(cp), C.byref(out))
+            if rc == -6 and (out.n_recs > rec_cap or out.n_T > T_cap):
+                rec_cap, T_cap = max(rec_cap, out.n_recs + 16), max(T_cap, out.n_T + 16)
+                continue
+            _check(rc)
+            m = out.n_recs
+            for key in ("read", "rc_flag", "emit_rc", "q_start", "q_end"):
+                o[key] = o[key][:m]
+            o["T_off"] = o["T_off"][:m + 1]
+            o["T"] = o["T"][:out.n_T]
+            return o
+        raise KmaHipError("scan_chain: output capacity kept overflowing")
+
     def scan_se_dev(self, seq, seq_off, length, N, N_off, rc_flag, flag, T_off, T, exhaustive=0, stream=None):
         """All arguments are CUDA(HIP) torch tensors; asynchronous on `stream`."""
         n = length.numel()

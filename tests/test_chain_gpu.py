@@ -1,0 +1,91 @@
+"""Stage 2 of KMA's default mode (no -1t1) on the HIP path, kmahip_scan_chain: the S2 records against the reference's own
+`-s2` tap of the committed fixtures, against the oracle, and against the compiled reference on chimeric reads (several chains per read)."""
+import gzip
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util
+import oracle
+from kma_amd import binding, formats, synth
+from test_oracle_golden import _chimeric_reads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+
+
+def _records(o):
+    return [(int(o["read"][x]), int(o["rc_flag"][x]), int(o["emit_rc"][x]), int(o["q_start"][x]), int(o["q_end"][x]),
+             tuple(int(t) for t in o["T"][o["T_off"][x]:o["T_off"][x + 1]])) for x in range(len(o["read"]))]
+
+
+@pytest.mark.parametrize("name", ["se", "long"])
+def test_chain_records_equal_reference_tap_and_oracle(tmp_path, name):
+    g = golden_util.load_se(tmp_path, name)
+    tap, _ = formats.parse_s2(gzip.open(os.path.join(g["dir"], "s2_chain.bin.gz")).read())
+    b = g["batch"]
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        got = _records(db.scan_chain(b))
+    finally:
+        db.close()
+    odb = oracle.OracleDB(g["prefix"])
+    want = [(i, rf, er, qs, qe, tuple(int(t) for t in T)) for i, recs in enumerate(odb.scan_chain(b)) for rf, er, qs, qe, T in recs]
+    assert got == want and len(got) > 200
+    # ... and the reference's tap, read by read (reads with an N among their first k - 1 bases left out: tests/test_oracle_golden.py)
+    by_read = {}
+    for w in tap:
+        by_read.setdefault(w["hdr"][:len(w["hdr"]) - 9], []).append(w)
+    mine = {}
+    for rec in got:
+        mine.setdefault(rec[0], []).append(rec)
+    checked = 0
+    for i in range(b.n):
+        Ni = b.N[b.N_off[i]:b.N_off[i + 1]]
+        if len(Ni) and int(Ni[0]) < 15:
+            continue
+        hdr = g["s1"][i]["hdr"]
+        ws, rs = by_read.get(hdr, []), mine.get(i, [])
+        assert len(ws) == len(rs), (i, hdr)
+        for w, (_, rf, er, qs, qe, T) in zip(ws, rs):
+            checked += 1
+            assert w["hdr"] == hdr + b"\x00" + struct.pack("<2i", qs, qe) and w["rc_flag"] == rf and tuple(int(t) for t in w["T"]) == T
+            L = int(b.length[i])
+            seq = b.seq[b.seq_off[i]:b.seq_off[i] + ((L + 31) >> 5)]
+            if er:
+                seq, _ = oracle.rc_packed(seq, L, Ni)
+            assert np.array_equal(w["seq"], seq)
+    assert checked > 200
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_chain_records_equal_reference_binary_on_chimeric_reads(tmp_path, seed):
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    rng = np.random.default_rng(300 + seed)
+    names, seqs = synth.make_gene_db(60, 5, 300, 900, 0.05, seed=400 + seed)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = _chimeric_reads(seqs, 20000, rng)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    tap = subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "o"), "-t_db", prefix, "-t", "1", "-s2"], check=True, stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL).stdout
+    want, _ = formats.parse_s2(tap)
+    b = formats.pack_ragged(reads)
+    db = binding.KmaHipDB(prefix)
+    try:
+        got = _records(db.scan_chain(b))
+    finally:
+        db.close()
+    flat = [(b"r%d" % r + bytes(2) + struct.pack("<2i", qs, qe), rf, T) for r, rf, er, qs, qe, T in got]
+    ref = [(w["hdr"], w["rc_flag"], tuple(int(x) for x in w["T"])) for w in want]
+    assert sum(1 for x in range(1, len(got)) if got[x][0] == got[x - 1][0]) > 2000          # many reads map in pieces
+    for x, (a, c) in enumerate(zip(flat, ref)):
+        assert a == c, (x, a, c)
+    assert len(flat) == len(ref)
