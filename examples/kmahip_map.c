@@ -38,18 +38,19 @@ static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
-	int mt1 = 0, bc_nano = 0, one2one = 0;
+	int mt1 = 0, bc_nano = 0, one2one = 0, chain = 0;
 	long long max_frag = 0;
 	for(int a = 1; a < argc; ++a) {
 		if(!strcmp(argv[a], "-Mt1") && a + 1 < argc) { mt1 = atoi(argv[++a]); continue; }
 		if(!strcmp(argv[a], "-bcNano")) { bc_nano = 1; continue; }
 		if(!strcmp(argv[a], "-1t1")) { one2one = 1; continue; }
+		if(!strcmp(argv[a], "-chain")) { chain = 1; continue; }      /* the reference's mode when -1t1 is absent: save_kmers_chain */
 		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
 		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
 		else if(!strcmp(argv[a], "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
 		else if(!strcmp(argv[a], "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(argv[a], "-mf") && a + 1 < argc) max_frag = atoll(argv[++a]);       /* fragments per assembly chunk (kma.c:1045) */
-		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix> [-1t1] [-mf <fragments per chunk>] [-Mt1 <template> [-bcNano]]\n"); return 2; }
+		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix> [-1t1 | -chain] [-mf <fragments per chunk>] [-Mt1 <template> [-bcNano]]\n"); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
 
@@ -103,6 +104,9 @@ int main(int argc, char **argv) {
 		ao.evalue = 0.05; ao.bcd = 1; ao.order = 1; ao.caller = bc_nano; ao.sig90 = bc_nano;
 		if(input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
+	} else if(chain) {
+		if(input2) { fprintf(stderr, "kmahip_map: -chain with -ipe is not supported\n"); return 2; }
+		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, NULL, 0.05, 1, max_frag, fpath, &run)) die("kmahip_run_chain");
 	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, max_frag, fpath, &run)) die("kmahip_run_pe"); }
 	else if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, max_frag, &run)) die("kmahip_run_se");
 
@@ -136,7 +140,7 @@ int main(int argc, char **argv) {
 	const double t_res = now_s();
 	/* out.frag.gz (the paired run has written it itself: its fragments are in record order, not read order) */
 	int64_t frag_rows = 0;
-	if(!input2 && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
+	if(!input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	const double t_frag = now_s();
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; wall: ingest %.2f s beside open %.2f (both done after %.2f), device run %.2f, .res + .fsa %.2f, .frag.gz %.2f | "
 	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f\n", (long long) n, (long long) frag_rows,

@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
 	const int64_t D = info.DB_size;
 
 	/* stages 2 + 3a */
-	kmahip_reads rd = { n, seq, seq_off, len, Npos, N_off, words, nN, max_len };
+	kmahip_reads rd = { n, seq, seq_off, len, Npos, N_off, words, nN, max_len, NULL, NULL };
 	int32_t *rc_flag = xcalloc((size_t) n + 1, 4), *flag = xcalloc((size_t) n + 1, 4);
 	int64_t *T_off = xcalloc((size_t) n + 1, 8), T_cap = 8 * n + 1024;
 	int32_t *T = NULL, *h_n = xcalloc((size_t) n + 1, 4), *h_best = xcalloc((size_t) n + 1, 4), *h_flag = xcalloc((size_t) n + 1, 4), *h_rc = xcalloc((size_t) n + 1, 4);

@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
 	kmahip_default_params(&par);
 	par.exhaustive = exhaustive;
 
-	kmahip_reads rd = { n, seq, seq_off, len, Npos, N_off, words, nN, max_len };
+	kmahip_reads rd = { n, seq, seq_off, len, Npos, N_off, words, nN, max_len, NULL, NULL };
 	int32_t *rc_flag = xrealloc(NULL, (size_t) (n + 1) * 4), *flag = xrealloc(NULL, (size_t) (n + 1) * 4), *T = NULL;
 	int64_t *T_off = xrealloc(NULL, (size_t) (n + 1) * 8), T_cap = 8 * n + 1024;
 	for(int tries = 0;; ++tries) {

@@ -95,6 +95,13 @@ typedef struct kmahip_reads {
 	int64_t seq_words;        /* total words in seq (host calls: bytes to stage) */
 	int64_t N_total;
 	int32_t max_len;          /* longest read in the batch (sizes the align scratch) */
+	/* optional (NULL: whole reads): query bounds per read, [q_start[i], q_end[i]) in the coordinates of the read as stored --
+	 * what a default-mode S2 record carries behind its header (qseqs.c:41-56). Stage 3a and the traceback look for seeds only
+	 * from q_start on and let the last N-free stretch end at q_end (KMA_score align.c:534-540, KMA :249-254, anker_rc_comp
+	 * :1029-1044; for a view of the reverse strand the bounds count from the other end, alnfrags.c:1113-1127). Same memory
+	 * space as the other arrays of the call. */
+	const int32_t *q_start;
+	const int32_t *q_end;
 } kmahip_reads;
 
 /* Stage-2 result, one entry per read = the S2 record fields (ankers.c:30-50):
@@ -476,6 +483,16 @@ int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_reads *read
  * at level 1, filebuff.c:189 -- what a reader inflates is the same). The writers compress blocks of rows on several threads
  * and concatenate the members (RFC 1952 2.2). Exposed for tests. */
 int kmahip_gzip_member(const void *src, int64_t n, void *dst, int64_t cap, int64_t *out_bytes);
+
+/* The single-end run in KMA's DEFAULT mode (no -1t1) on one batch: kmahip_scan_chain, then every S2 record -- a read, or its
+ * reverse complement where the record prints that, with its query bounds -- goes through stage 3a, ConClave, the `.res`
+ * statistics, the traceback and the pile-up like a read of kmahip_run_se (runKMA, runkma.c:104-900 with kmerScan =
+ * save_kmers_chain). A chimeric read therefore counts once per chain. `names` / `name_off`: read headers for the `.frag(.gz)`
+ * rows written to frag_path (both NULL to skip the file). out->tmpl / n_hits / rc / trace_stats are not filled (the records
+ * are not the caller's reads); rows, assembly and ms are as in kmahip_run_se. */
+int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
+                     const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
+                     const char *frag_path, kmahip_run *out);
 
 /* The paired run (`-ipe r1 r2 -apm p -1t1`) on one batch as kmahip_ingest_next hands it over for two mate files: reads in
  * stream order, batch->pair[i] = 1 / 2 for the mates of a pair record, 0 for a record that lost its mate to the trimming.

@@ -32,7 +32,7 @@ class DBInfo(C.Structure):
 class Reads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("len", C.c_void_p),
                 ("N", C.c_void_p), ("N_off", C.c_void_p), ("seq_words", C.c_int64), ("N_total", C.c_int64),
-                ("max_len", C.c_int32)]
+                ("max_len", C.c_int32), ("q_start", C.c_void_p), ("q_end", C.c_void_p)]
 
 
 class Cands(C.Structure):

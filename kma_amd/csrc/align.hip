@@ -50,6 +50,7 @@ struct AlignArgs {
 	const int32_t *flag;
 	const int64_t *T_off;
 	const int32_t *T;
+	const int32_t *q_start, *q_end;   // query bounds per read (default-mode records), NULL: whole reads
 	int M, MM, U, W1;
 	int d[25];
 	int minlen, mq;
@@ -903,14 +904,21 @@ __device__ int anker_rc_comp(const Lane &L, const DevDB &db, int t, const uint64
 	const int k = (int) db.kmersize, q_len = qf.L, cap = L.cap1 - 1;
 	QView qr = qf; qr.rc = qf.rc ^ 1;
 	int bestScore = 0, score = 0, score_r = 0, mem_count = 0, tot = 0, plen = 0;
+	// query bounds (align.c:1029-1044): the forward pass starts at q_start when there is one (no preseed then) and both passes
+	// stop looking for seeds at q_end -- the reverse pass with the bounds counted from the other end; the stretches themselves
+	// still end at the N's (or the read end), not at the bound
+	const int fb0 = qf.b0, fb1 = qb1(qf);
 	for(int rc = 0; rc < 2; ++rc) {
 		const QView &q = rc ? qr : qf;
 		int i = 0;
-		if(rc) { score = score_r; plen = mem_count; }
+		const int stop = rc ? q_len - fb0 : fb1;
+		if(rc) { score = score_r; plen = mem_count; i = q_len - fb1; }
+		else if(fb0) i = fb0;
 		else {
 			// preseed (align.c:750-768): every k-th k-mer, built from byte codes (N = 4), past-the-end bytes = 0
 			bool hit = false;
-			for(i = 0; i < q_len && !hit; i += k) {
+			const int span = fb1 - fb0;
+			for(i = 0; i < span && !hit; i += k) {
 				uint64_t key = 0;
 				for(int x = 0; x < k; ++x) key = (x ? (key << 2) : 0ull) | (uint64_t) ((i + x < q_len) ? qn(q, i + x) : 0);
 				if(key <= 0xFFFFFFFFull && tpos_get(db, t, (uint32_t) key) != 0) hit = true;
@@ -919,7 +927,7 @@ __device__ int anker_rc_comp(const Lane &L, const DevDB &db, int t, const uint64
 		}
 		score_r = 0; mem_count = 0;
 		int ni = 0;
-		while(i < q_len) {
+		while(i < stop) {
 			const int end = qN_at(q, ++ni) - k + 1;
 			while(i < end) {
 				const int v = tpos_get(db, t, q_kmer(q, i, k));
@@ -973,7 +981,7 @@ __device__ int anker_rc_comp(const Lane &L, const DevDB &db, int t, const uint64
 __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq, int preseeded, int *status) {
 	const Aln FAIL = {0, 1, 0, 0, 0, 0};
 	const int k = (int) db.kmersize, q_len = q.L, bw = 64, cap = L.cap1 - 1;
-	int nm = 0, j = 0, lowq = 0;
+	int nm = 0, j = q.b0, lowq = 0;
 #ifdef KMAHIP_DIAG
 	if(L.ablate & 2) return FAIL;
 #endif
@@ -981,7 +989,7 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 	if(preseeded > 0) nm = preseeded;
 	for(int i = 1; preseeded <= 0 && i <= q.nN + 1; ++i) {
 		const int Ni = qN_at(q, i);
-		const int end = (i != q.nN + 1) ? Ni - k + 1 : q_len - k + 1;
+		const int end = (i != q.nN + 1) ? Ni - k + 1 : qb1(q) - k + 1;
 		const int segstop = end + k - 1;
 		while(j < end) {
 			// two k-mer starts per step, both gathers in flight together: the usual miss (the k-mer that starts on a
@@ -1098,10 +1106,10 @@ __device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView 
 	const uint64_t *ts = A.db.tseq + (((uint64_t) ma.y << 32) | ma.x);
 	const uint2 *tab = A.db.tpos_slots + (((uint64_t) ma.w << 32) | ma.z);
 	const uint32_t tsh = mb.y;
-	int nm = 0, j = 0, lowq = 0;
+	int nm = 0, j = q.b0, lowq = 0;
 	for(int i = 1; i <= q.nN + 1; ++i) {
 		const int Ni = qN_at(q, i);
-		const int end = (i != q.nN + 1) ? Ni - k + 1 : L - k + 1;
+		const int end = (i != q.nN + 1) ? Ni - k + 1 : qb1(q) - k + 1;
 		const int segstop = end + k - 1;
 		while(j < end) {
 			int v, v2;
@@ -1158,6 +1166,7 @@ __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 				if(views == 2) { const int64_t rec = (r & ~1ll) + m; rd = (r & ~1ll) + A.rec_mate[rec]; rc = A.rec_rc[rec] ^ rcstate; }
 				QView q;
 				q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = rc;
+				q_set_bounds(q, A.q_start, A.q_end, rd);
 				q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
 				nm = seed_view(A, t, q, k, mem);
 			}
@@ -1276,6 +1285,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 				kind = 1;
 				QView q;
 				q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
+				q_set_bounds(q, A.q_start, A.q_end, rd);
 				q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
 				qlen0 = q.L;
 				L.q_mate = 0; L.q_rd = rd;
@@ -1685,6 +1695,8 @@ struct TraceArgs {
 	const int32_t *flag;         // kmahip_hits.rc: bit 0 = the filed fragment is the reverse complement of the read
 	const int32_t *tmpl;         // ConClave's signed template per read (0: none)
 	const uint8_t *tmpl_ok;      // per template: assemble it? (NULL: all)
+	const int32_t *q_start, *q_end;   // query bounds per read as ConClave left them (already counted from the end of the read where
+	                             // it filed the reverse complement, conclave.c:131-146), NULL: whole reads
 	int M, MM, U, W1, Wl;
 	int d[25];
 	int minlen, mq;
@@ -1952,10 +1964,11 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 	// seeds: the byte-wise loop of KMA() -- a stretch between Ns (or up to the read end) is probed only while MORE than
 	// k bases remain in it (align.c:258, 308, 364), unlike KMA_score
 	{
-		int i = 0, ni = 1;
-		while(i < q_len) {
+		int i = q.b0, ni = 1;
+		const int q_stop = qb1(q);           // query bounds: align.c:249-254
+		while(i < q_stop) {
 			while(ni <= q.nN && qN_at(q, ni) < i) ++ni;
-			const int end = (ni <= q.nN) ? qN_at(q, ni) : q_len;
+			const int end = (ni <= q.nN) ? qN_at(q, ni) : q_stop;
 			const int lowq = (ni > 1) ? qN_at(q, ni - 1) + 1 : 0;
 			if(i < end - k) i += k - 1; else { i = end + 1; continue; }
 			while(i < end) {
@@ -2120,6 +2133,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      //
 				QView q;
 				q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
 				q.rc = (((A.flag[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
+				q_set_bounds(q, A.q_start, A.q_end, r);
 				t_len = A.db.tlen[t];
 				const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
 				T.em.n = 0; T.em.over = false; T.status = 0;
@@ -2201,6 +2215,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.db = db->dev;
 	A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.rc_flag = cands->rc_flag; A.flag = cands->flag; A.T_off = cands->T_off; A.T = cands->T;
+	A.q_start = reads->q_start; A.q_end = reads->q_end;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1;
 	for(int i = 0; i < 5; ++i) for(int j = 0; j < 5; ++j) A.d[i * 5 + j] = p->rw.d[i][j];
 	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
@@ -2368,7 +2383,8 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	// matrix in HBM: for reads that carry hundreds of MEMs, or everything with KMAHIP_TRACE=pipeline (=lanes forces this kernel)
 	{
 		const char *mode = getenv("KMAHIP_TRACE");
-		const bool pipeline = mode ? !strcmp(mode, "pipeline") : max_len > 1024;
+		// (reads with query bounds -- default-mode records -- go through this kernel whatever their length: the pipeline has no bounds yet)
+		const bool pipeline = !reads->q_start && (mode ? !strcmp(mode, "pipeline") : max_len > 1024);
 		if(pipeline) return kmahip_launch_longtrace(db, ws, reads, tmpl, 0, flag, tmpl_ok, 0, p, out, nullptr, stream);
 	}
 	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
@@ -2402,6 +2418,7 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	TraceArgs A;
 	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.flag = flag; A.tmpl = tmpl; A.tmpl_ok = tmpl_ok;
+	A.q_start = reads->q_start; A.q_end = reads->q_end;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
 	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;

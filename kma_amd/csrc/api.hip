@@ -117,6 +117,7 @@ static int run_host(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, con
 	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
 	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
 	kmahip_cands o;
@@ -281,6 +282,7 @@ static int run_host_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, 
 	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
 	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
 	kmahip_pe_recs o;
@@ -396,6 +398,7 @@ extern "C" int kmahip_align_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_rea
 	HIP_TRY(hipMemcpyAsync(d_tmpl, tmpl, (size_t) n * 4, hipMemcpyHostToDevice, s));
 	if(tmpl_ok) HIP_TRY(hipMemcpyAsync(d_ok, tmpl_ok, D, hipMemcpyHostToDevice, s));
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
 	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
 	kmahip_traces o;
@@ -442,6 +445,7 @@ extern "C" int kmahip_align_trace_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip
 	if(reads->N_total) HIP_TRY(hipMemcpyAsync(ws->stage[3], reads->N, (size_t) reads->N_total * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(hipMemcpyAsync(ws->stage[4], reads->N_off, (size_t) (n + 1) * 8, hipMemcpyHostToDevice, s));
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	d.seq = (const uint64_t *) ws->stage[0]; d.seq_off = (const int64_t *) ws->stage[1]; d.len = (const int32_t *) ws->stage[2];
 	d.N = (const int32_t *) ws->stage[3]; d.N_off = (const int64_t *) ws->stage[4];
 	int32_t *d_rc = (int32_t *) ws->stage[5];

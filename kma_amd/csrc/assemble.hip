@@ -1033,6 +1033,7 @@ extern "C" int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 		return KMAHIP_OK;
 	};
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	kmahip_traces dt = *traces;
 	int32_t *d_flag, *d_tmpl;
 	void *seq_d = nullptr;

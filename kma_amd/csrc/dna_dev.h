@@ -12,7 +12,17 @@ struct QView {
 	const uint64_t *w;
 	const int32_t *N;
 	int L, nN, rc;
+	// seed bounds in the coordinates of this view (the query bounds a default-mode S2 record carries, qseqs.c:41-56): the seed
+	// search starts at b0 and the last N-free stretch ends at b1 (KMA_score align.c:534-540, KMA :249-254). Whole read by default.
+	int b0 = 0, b1 = 0x7fffffff;
 };
+__device__ __forceinline__ int qb1(const QView &q) { return q.b1 < q.L ? q.b1 : q.L; }
+// bounds given for the read as stored -> this view (reverse complemented views count from the other end, alnfrags.c:1113-1127)
+__device__ __forceinline__ void q_set_bounds(QView &q, const int32_t *q_start, const int32_t *q_end, int64_t rd) {
+	if(!q_start) return;
+	const int s = q_start[rd], e = q_end[rd];
+	if(q.rc) { q.b0 = q.L - e; q.b1 = q.L - s; } else { q.b0 = s; q.b1 = e; }
+}
 
 __device__ __forceinline__ int q2(const QView &q, int i) {
 	const int p = q.rc ? q.L - 1 - i : i;

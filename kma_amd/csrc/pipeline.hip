@@ -68,51 +68,17 @@ int ws_status(kmahip_ws *ws, unsigned long long *c0) {
 
 }  // namespace
 
-extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
-                             int64_t max_frag, kmahip_run *out) {
-	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	const int64_t n = reads->n_reads;
-	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+// everything behind stage 2 on a batch that is in HBM with its candidate lists: stage 3a, ConClave + the `.res` statistics, the
+// traceback, the pile-up. per_read: host arrays for the columns a `.frag` writer needs (any may be NULL).
+struct PerRead { int32_t *tmpl, *n_hits, *rc, *trace_stats; };
+
+static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_reads &d, kmahip_cands &c, int64_t total, const kmahip_params *p,
+                            double evalue, int bcd, int64_t max_frag, kmahip_run *out, const PerRead &per_read, std::chrono::steady_clock::time_point &t) {
+	const int64_t n = d.n_reads;
 	const size_t D = db->info.DB_size;
-	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
-	out->n_rows = 0;
 	hipStream_t s = 0;
 	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
-	DevBlock B;
 	int rc;
-	auto t = std::chrono::steady_clock::now();
-
-	// the batch, once (the slabs are sized for what a run of n reads usually needs: ~230 bytes per read next to the reads)
-	B.expect((size_t) reads->seq_words * 8 + (size_t) reads->N_total * 4 + (size_t) n * 280 + (64u << 20));
-	kmahip_reads d = *reads;
-	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &d.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &d.seq_off)) ||
-	   (rc = B.up(reads->len, (size_t) n, 1, &d.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &d.N)) ||
-	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
-	HIP_TRY(hipStreamSynchronize(s));
-	out->ms[0] = since(t);
-
-	// stage 2; the candidate lists have no bound known in advance: start at 2 per read and redo with the exact size if short
-	kmahip_cands c;
-	if((rc = B.get((size_t) n + 1, &c.rc_flag)) || (rc = B.get((size_t) n + 1, &c.flag)) || (rc = B.get((size_t) n + 1, &c.T_off))) return rc;
-	int64_t total = 0;
-	c.T_cap = 2 * n + 4096;
-	for(int attempt = 0;; ++attempt) {
-		if((rc = B.get((size_t) c.T_cap, &c.T))) return rc;
-		if((rc = kmahip_launch_scan_se(db, ws, &d, p, &c, s))) return rc;
-		HIP_TRY(hipStreamSynchronize(s));
-		const int st = ws_status(ws, nullptr);
-		if(st == 1) {
-			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
-			ws->pool_scale *= 2; ws->cap_reads = 0;     // grown by the next launch
-			continue;
-		}
-		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
-		if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: scan attempt %d: %.1f ms, %lld candidates (cap %lld)\n", attempt, since(t2), (long long) total, (long long) c.T_cap); }
-		if(total <= c.T_cap) break;
-		c.T_cap = total + 1024;
-	}
-	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 2 done after %.1f ms\n", since(t2)); }
-
 	// stage 3a
 	kmahip_hits h;
 	if((rc = B.get((size_t) n + 1, &h.n_hits, true)) || (rc = B.get((size_t) n + 1, &h.best_score, true)) || (rc = B.get((size_t) n + 1, &h.flag, true)) ||
@@ -172,13 +138,62 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 
 	// per-read columns for the text writers
 	if(n) {
-		if(out->tmpl) HIP_TRY(hipMemcpy(out->tmpl, cc.tmpl, (size_t) n * 4, hipMemcpyDeviceToHost));
-		if(out->n_hits) HIP_TRY(hipMemcpy(out->n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost));
-		if(out->rc) HIP_TRY(hipMemcpy(out->rc, h.rc, (size_t) n * 4, hipMemcpyDeviceToHost));
-		if(out->trace_stats) HIP_TRY(hipMemcpy(out->trace_stats, tr.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
+		if(per_read.tmpl) HIP_TRY(hipMemcpy(per_read.tmpl, cc.tmpl, (size_t) n * 4, hipMemcpyDeviceToHost));
+		if(per_read.n_hits) HIP_TRY(hipMemcpy(per_read.n_hits, h.n_hits, (size_t) n * 4, hipMemcpyDeviceToHost));
+		if(per_read.rc) HIP_TRY(hipMemcpy(per_read.rc, h.rc, (size_t) n * 4, hipMemcpyDeviceToHost));
+		if(per_read.trace_stats) HIP_TRY(hipMemcpy(per_read.trace_stats, tr.stats, (size_t) n * 40, hipMemcpyDeviceToHost));
 	}
 	out->ms[5] = since(t);
 	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
+                             int64_t max_frag, kmahip_run *out) {
+	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
+	out->n_rows = 0;
+	hipStream_t s = 0;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+
+	// the batch, once (the slabs are sized for what a run of n reads usually needs: ~230 bytes per read next to the reads)
+	B.expect((size_t) reads->seq_words * 8 + (size_t) reads->N_total * 4 + (size_t) n * 280 + (64u << 20));
+	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
+	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &d.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &d.seq_off)) ||
+	   (rc = B.up(reads->len, (size_t) n, 1, &d.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &d.N)) ||
+	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	out->ms[0] = since(t);
+
+	// stage 2; the candidate lists have no bound known in advance: start at 2 per read and redo with the exact size if short
+	kmahip_cands c;
+	if((rc = B.get((size_t) n + 1, &c.rc_flag)) || (rc = B.get((size_t) n + 1, &c.flag)) || (rc = B.get((size_t) n + 1, &c.T_off))) return rc;
+	int64_t total = 0;
+	c.T_cap = 2 * n + 4096;
+	for(int attempt = 0;; ++attempt) {
+		if((rc = B.get((size_t) c.T_cap, &c.T))) return rc;
+		if((rc = kmahip_launch_scan_se(db, ws, &d, p, &c, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		const int st = ws_status(ws, nullptr);
+		if(st == 1) {
+			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;     // grown by the next launch
+			continue;
+		}
+		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
+		if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: scan attempt %d: %.1f ms, %lld candidates (cap %lld)\n", attempt, since(t2), (long long) total, (long long) c.T_cap); }
+		if(total <= c.T_cap) break;
+		c.T_cap = total + 1024;
+	}
+	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 2 done after %.1f ms\n", since(t2)); }
+
+	PerRead pr = {out->tmpl, out->n_hits, out->rc, out->trace_stats};
+	return run_after_stage2(db, ws, B, d, c, total, p, evalue, bcd, max_frag, out, pr, t);
 }
 
 // ---- paired run: host composition of the stage-wise calls (the record merge is the glue a host program would otherwise write) ----
@@ -202,9 +217,28 @@ struct HostBatch {
 		len.push_back(L); src.push_back(i);
 		max_len = std::max(max_len, L);
 	}
+	// the reverse complement of read i (rc_comp, compdna.c:228-256: the bits complemented, an N keeps its place from the other end)
+	void add_rc(const kmahip_reads &r, int64_t i) {
+		const int L = r.len[i];
+		const int64_t w = (L + 31) >> 5;
+		const uint64_t *src = r.seq + r.seq_off[i];
+		const size_t at = seq.size();
+		seq.resize(at + (size_t) w + 1, 0);
+		for(int p = 0; p < L; ++p) {
+			const int q = L - 1 - p;
+			const uint64_t b = 3 - ((src[q >> 5] >> (62 - ((q & 31) << 1))) & 3);
+			seq[at + (size_t) (p >> 5)] |= b << (62 - ((p & 31) << 1));
+		}
+		seq_off.push_back((int64_t) seq.size());
+		for(int64_t x = r.N_off[i + 1] - 1; x >= r.N_off[i]; --x) N.push_back(L - 1 - r.N[x]);
+		N_off.push_back((int64_t) N.size());
+		len.push_back(L); src_read(i);
+		max_len = std::max(max_len, L);
+	}
+	void src_read(int64_t i) { src.push_back(i); }
 	kmahip_reads view() {
 		if(N.empty()) N.push_back(0);
-		kmahip_reads v;
+		kmahip_reads v = {};
 		v.n_reads = (int64_t) len.size(); v.seq = seq.data(); v.seq_off = seq_off.data(); v.len = len.data(); v.N = N.data(); v.N_off = N_off.data();
 		v.seq_words = (int64_t) seq.size(); v.N_total = N_off.back(); v.max_len = max_len;
 		return v;
@@ -403,6 +437,86 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	return KMAHIP_OK;
 }
 
+// ---- the default mode (no -1t1): kmahip_scan_chain, then every record through the stages of kmahip_run_se --------------------------
+extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
+                                const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
+                                const char *frag_path, kmahip_run *out) {
+	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(frag_path && (!names || !name_off)) { kmahip_set_error("the fragment file needs the read headers"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	const size_t D = db->info.DB_size;
+	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
+	out->n_rows = 0;
+	auto t = std::chrono::steady_clock::now();
+	int rc;
+	// stage 2: one record per accepted chain
+	std::vector<int64_t> r_read, r_Toff;
+	std::vector<int32_t> r_flag, r_emit, r_qs, r_qe, r_T;
+	kmahip_chain_recs R;
+	memset(&R, 0, sizeof R);
+	R.rec_cap = 2 * n + 1024; R.T_cap = 16 * n + 4096;
+	for(int attempt = 0;; ++attempt) {
+		r_read.assign((size_t) R.rec_cap, 0); r_Toff.assign((size_t) R.rec_cap + 1, 0);
+		r_flag.assign((size_t) R.rec_cap, 0); r_emit.assign((size_t) R.rec_cap, 0); r_qs.assign((size_t) R.rec_cap, 0); r_qe.assign((size_t) R.rec_cap, 0);
+		r_T.assign((size_t) R.T_cap, 0);
+		R.read = r_read.data(); R.rc_flag = r_flag.data(); R.emit_rc = r_emit.data(); R.q_start = r_qs.data(); R.q_end = r_qe.data();
+		R.T_off = r_Toff.data(); R.T = r_T.data();
+		rc = kmahip_scan_chain(db, ws, reads, p, cp, &R);
+		if(rc == KMAHIP_EOVERFLOW && attempt < 3 && (R.n_recs > R.rec_cap || R.n_T > R.T_cap)) {
+			R.rec_cap = std::max(R.rec_cap, R.n_recs + 16); R.T_cap = std::max(R.T_cap, R.n_T + 16);
+			continue;
+		}
+		if(rc) return rc;
+		break;
+	}
+	const int64_t m = R.n_recs;
+	out->ms[1] = since(t);
+	// the records as a batch of their own: the read, or its reverse complement where the record prints that, with its bounds
+	HostBatch RB;
+	for(int64_t x = 0; x < m; ++x) { if(r_emit[(size_t) x]) RB.add_rc(*reads, r_read[(size_t) x]); else RB.add(*reads, r_read[(size_t) x]); }
+	kmahip_reads rb = RB.view();
+	DevBlock B;
+	B.expect((size_t) rb.seq_words * 8 + (size_t) rb.N_total * 4 + (size_t) m * 300 + (64u << 20));
+	kmahip_reads d = rb;
+	std::vector<int32_t> zero((size_t) m + 1, 0);
+	kmahip_cands c;
+	const int32_t *d_rcflag = nullptr, *d_flag = nullptr, *d_T = nullptr;
+	const int64_t *d_Toff = nullptr;
+	const int64_t total = m ? r_Toff[(size_t) m] : 0;
+	if((rc = B.up(rb.seq, (size_t) rb.seq_words, 2, &d.seq)) || (rc = B.up(rb.seq_off, (size_t) m + 1, 0, &d.seq_off)) ||
+	   (rc = B.up(rb.len, (size_t) m, 1, &d.len)) || (rc = B.up(rb.N, (size_t) rb.N_total, 1, &d.N)) || (rc = B.up(rb.N_off, (size_t) m + 1, 0, &d.N_off)) ||
+	   (rc = B.up(r_qs.data(), (size_t) m, 1, &d.q_start)) || (rc = B.up(r_qe.data(), (size_t) m, 1, &d.q_end)) ||
+	   (rc = B.up(r_flag.data(), (size_t) m, 1, &d_rcflag)) || (rc = B.up(zero.data(), (size_t) m, 1, &d_flag)) ||
+	   (rc = B.up(r_Toff.data(), (size_t) m + 1, 0, &d_Toff)) || (rc = B.up(r_T.data(), (size_t) total, 1, &d_T))) return rc;
+	c.rc_flag = const_cast<int32_t *>(d_rcflag); c.flag = const_cast<int32_t *>(d_flag); c.T_off = const_cast<int64_t *>(d_Toff);
+	c.T = const_cast<int32_t *>(d_T); c.T_cap = total + 1;
+	HIP_TRY(hipStreamSynchronize(0));
+	out->ms[0] = since(t);
+	std::vector<int32_t> k_tmpl((size_t) m + 1, 0), k_nh((size_t) m + 1, 0), k_rc((size_t) m + 1, 0), k_stats((size_t) m * 10 + 10, 0);
+	PerRead pr = {k_tmpl.data(), k_nh.data(), k_rc.data(), k_stats.data()};
+	if(m) {
+		if((rc = run_after_stage2(db, ws, B, d, c, total, p, evalue, bcd, max_frag, out, pr, t))) return rc;
+	} else {
+		std::vector<uint64_t> w(D, 0);
+		if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
+		for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
+	}
+	if(frag_path && m) {
+		std::vector<char> nm;
+		std::vector<int64_t> noff{0};
+		for(int64_t x = 0; x < m; ++x) {
+			const char *h = names + name_off[r_read[(size_t) x]];
+			nm.insert(nm.end(), h, h + strlen(h) + 1);
+			noff.push_back((int64_t) nm.size());
+		}
+		int64_t rows = 0;
+		if((rc = kmahip_frag_write(frag_path, db, &rb, k_rc.data(), k_tmpl.data(), k_nh.data(), k_stats.data(), max_frag, nm.data(), noff.data(), &rows))) return rc;
+	}
+	out->ms[5] += since(t);
+	return KMAHIP_OK;
+}
+
 // ---- `-Mt1 t`: raw reads straight to stage 3c against one template (runKMA_Mt1, mt1.c:86-500) ------------------------------
 extern "C" int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, int32_t tmpl, int one2one, const kmahip_params *p,
                               const kmahip_assemble_opts *aopts, kmahip_run *out) {
@@ -420,6 +534,7 @@ extern "C" int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	int rc;
 	auto t = std::chrono::steady_clock::now();
 	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;       // (host pointers, if any: this entry point maps whole reads)
 	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &d.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &d.seq_off)) ||
 	   (rc = B.up(reads->len, (size_t) n, 1, &d.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &d.N)) ||
 	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &d.N_off))) return rc;

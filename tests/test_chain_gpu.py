@@ -89,3 +89,48 @@ def test_chain_records_equal_reference_binary_on_chimeric_reads(tmp_path, seed):
     for x, (a, c) in enumerate(zip(flat, ref)):
         assert a == c, (x, a, c)
     assert len(flat) == len(ref)
+
+
+def _run_both(tmp_path, prefix, fq):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-chain"], check=True,
+                   stderr=subprocess.DEVNULL)
+    return [open(tmp_path / "got.res", "rb").read(), open(tmp_path / "got.fsa", "rb").read(), gzip.open(tmp_path / "got.frag.gz").read()]
+
+
+@pytest.mark.parametrize("name", ["se", "long"])
+def test_whole_default_mode_run_equals_reference_files(tmp_path, name):
+    """examples/kmahip_map -chain (kmahip_run_chain: scan_chain, then stage 3a / ConClave / traceback / pile-up with the records' query
+    bounds) against the files the reference wrote without -1t1 for the same reads (tests/golden/make_golden_chain.py)."""
+    import shutil
+    g = golden_util.load_se(tmp_path, name)
+    fq = str(tmp_path / "reads.fq")
+    with gzip.open(os.path.join(g["dir"], "reads.fq.gz"), "rb") as f, open(fq, "wb") as o:
+        shutil.copyfileobj(f, o)
+    res, fsa, frag = _run_both(tmp_path, g["prefix"], fq)
+    assert res == open(os.path.join(g["dir"], "chain.res"), "rb").read()
+    assert fsa == gzip.open(os.path.join(g["dir"], "chain.fsa.gz")).read()
+    assert frag == gzip.open(os.path.join(g["dir"], "chain.frag.gz")).read()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_whole_default_mode_run_equals_reference_binary_on_chimeric_reads(tmp_path, seed):
+    """reads that map in pieces (several records per read, strand ties, bounds that cut the seed search) through `kma` without -1t1 and
+    through examples/kmahip_map -chain: .res, .fsa and .frag.gz"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    rng = np.random.default_rng(700 + seed)
+    names, seqs = synth.make_gene_db(50, 5, 300, 900, 0.05, seed=800 + seed)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = _chimeric_reads(seqs, 30000, rng, with_n=False)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    res, fsa, frag = _run_both(tmp_path, prefix, fq)
+    assert res == open(tmp_path / "ref.res", "rb").read() and res.count(b"\n") > 100
+    assert fsa == open(tmp_path / "ref.fsa", "rb").read()
+    ref_frag = gzip.open(tmp_path / "ref.frag.gz").read()
+    assert frag == ref_frag
+    assert frag.count(b"\n") > 10000

@@ -240,9 +240,9 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
         with open(path, "wb") as f:
             for i, r in enumerate(rs):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
-    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
