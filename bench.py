@@ -337,6 +337,28 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
                        "-t nproc, and independent -t 1 processes over equal shards of the sample (wall = the slowest; every process "
                        "loads the index itself, so short shards are start-up bound)"}
         say(f"e2e: reference on {m_} reads: -t 1 {t1:.1f} s, -t {nproc} {tn:.1f} s, 16 shards {s16:.1f} s, {nproc} shards {sn:.1f} s; .res identical {same}")
+        # the reference's DEFAULT mode (no -1t1: chain finder, reads mapping in pieces) on the same sample, both sides file to file
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run([mapper, "-i", sfq, "-t_db", prefix, "-o", got + "_chain", "-chain"], stderr=subprocess.PIPE)
+            tc = time.perf_counter() - t0
+            if r.returncode:
+                raise RuntimeError(r.stderr.decode().strip().splitlines()[-1] if r.stderr else "kmahip_map -chain failed")
+            k_ = min(m_, 200_000)
+            cfq = os.path.join(tmp, "e2e_chain_sample.fq")
+            with open(sfq, "rb") as f, open(cfq, "wb") as g:
+                g.write(f.read(rec * k_))
+            t0 = time.perf_counter()
+            subprocess.run([kma, "-i", cfq, "-o", os.path.join(tmp, "e2e_ref_chain"), "-t_db", prefix, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            trc = time.perf_counter() - t0
+            subprocess.run([mapper, "-i", cfq, "-t_db", prefix, "-o", got + "_chain_s", "-chain"], check=True, stderr=subprocess.DEVNULL)
+            ref["default_mode"] = {"what": "no -1t1 (save_kmers_chain): examples/kmahip_map -chain file to file on sample_reads reads; the reference -t 1 on the first reference_reads of them",
+                                   "kmahip_map_chain": {"wall_s": round(tc, 3), "reads_per_s": m_ / tc},
+                                   "reference_t1": {"reference_reads": k_, "wall_s": round(trc, 2), "reads_per_s": k_ / trc},
+                                   "res_identical_to_reference": open(got + "_chain_s.res", "rb").read() == open(os.path.join(tmp, "e2e_ref_chain.res"), "rb").read()}
+            say(f"e2e: default mode: kmahip_map -chain {tc:.2f} s on {m_} reads; reference {trc:.1f} s on {k_}; .res identical {ref['default_mode']['res_identical_to_reference']}")
+        except Exception as e:  # noqa: BLE001  (extra figure only)
+            ref["default_mode"] = {"error": str(e)}
         out["vs_reference_t1"] = out["plain"]["reads_per_s"] / ref["t1"]["reads_per_s"]
         out["vs_reference_best_shards"] = out["plain"]["reads_per_s"] / max(ref["shards_16"]["reads_per_s"], ref["shards_nproc"]["reads_per_s"], ref["t_nproc"]["reads_per_s"])
     for f_ in (fq, gz):
