@@ -16,6 +16,7 @@
 #include "kmahip_internal.h"
 #include "dna_dev.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -323,8 +324,27 @@ __device__ int build_ankers(CLane &L, const QView &qf, const QView &qr, int exha
 	int rcpos = seqlen - k;
 	for(int i = 1; i <= nN + 1 && j < seqend; ++i) {
 		const int segend = i <= nN ? qN_at(qf, i) : seqlen;
+		uint32_t gp = NOLIST;                  // where the k-mer of the step before lies in the template store
 		for(; j < segend - k + 1; ++j, --rcpos) {
-			const uint32_t values = list_of(db, is_rc ? rc_kmer(qr, rcpos, k) : q_kmer(qf, j, k));
+			// A read that matches a template keeps matching it: when the base that enters the window is the template's next base
+			// (the one in front of it on the reverse strand, whose windows move backwards), the k-mer is the template's
+			// neighbouring k-mer and its value list stands in vs_id -- no probe (the walk of scan.hip, one lane here)
+			uint32_t values;
+			bool walked = false;
+			if(gp != NOLIST) {
+				if(!is_rc) {
+					const uint32_t v = db.vs_id[gp + 1];
+					if(v != KMAHIP_EMPTY_VI && (int) ((db.cat[(gp + k) >> 5] >> (62 - (((gp + k) & 31) << 1))) & 3ull) == q2(qf, j + k - 1)) { ++gp; values = v; walked = true; }
+				} else if(gp > 0 && rcpos >= 0 && rcpos + k <= seqlen) {
+					const uint32_t v = db.vs_id[gp - 1];
+					if(v != KMAHIP_EMPTY_VI && (int) ((db.cat[(gp - 1) >> 5] >> (62 - (((gp - 1) & 31) << 1))) & 3ull) == q2(qr, rcpos)) { --gp; values = v; walked = true; }
+				}
+			}
+			if(!walked) {
+				gp = db_probe(db, is_rc ? rc_kmer(qr, rcpos, k) : q_kmer(qf, j, k));
+				values = gp == NOLIST ? NOLIST : db.vs_id[gp];
+				if(is_rc && (rcpos < 0 || rcpos + k > seqlen)) gp = NOLIST;       // (a window that hangs over the end: nothing to walk from)
+			}
 			if(values != NOLIST) {
 				bool open = true;
 				if(values == last) {
@@ -620,14 +640,25 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	const int max_len = reads->max_len;
 	if(max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set"); return KMAHIP_EINVAL; }
 	const int64_t D = db->info.DB_size;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto stamp = [&](const char *what) {
+		if(!dbg) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[kmahip] scan_chain: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
 	ChainArgs A;
 	A.db = db->dev; A.n_reads = n;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	A.exhaustive = p->exhaustive; A.minlen = cp ? cp->minlen : 16; A.coverT = cp ? cp->coverT : 0.1; A.mrs = cp ? cp->mrs : 0.5;
-	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 8192); A.s_cap = 256;
+	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 2048); A.s_cap = 128;
 	A.lane_bytes = ((int64_t) 2 * A.a_cap * (int64_t) sizeof(CAnk) + (D + 1) * 8 + (int64_t) 2 * A.b_cap * 4 + (int64_t) A.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;
+	// 254 VGPRs: one wave per SIMD = 65 536 lanes resident. (Capped at 128 VGPRs for four waves per SIMD the kernel spills 1 000
+	// registers and takes as long: 2 M reads in 62 vs 68 ms. At ~2 000 scattered accesses per read that is ~65 G lines/s, the
+	// gather ceiling of DESIGN 3.1 -- the way up is fewer scattered accesses, anchors and lists out of HBM scratch, not more lanes.)
 	int64_t lanes = 65536;
-	while(lanes > 64 && lanes * A.lane_bytes > (12ll << 30)) lanes >>= 1;
+	while(lanes > 64 && lanes * A.lane_bytes > (16ll << 30)) lanes >>= 1;
 	lanes = std::min<int64_t>(lanes, ((n + 63) / 64) * 64);
 	A.lanes = lanes;
 	// device buffers: staged reads, scratch, outputs
@@ -655,9 +686,12 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	if((rc = dev((size_t) std::max<int64_t>(A.rec_cap, 1) * 32, (void **) &A.rec, nullptr, false)) ||
 	   (rc = dev((size_t) std::max<int64_t>(A.rec_cap, 1) * 8, (void **) &A.rec_T, nullptr, false)) ||
 	   (rc = dev((size_t) std::max<int64_t>(A.T_cap, 1) * 4, (void **) &A.T, nullptr, false))) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	stamp("reads staged, scratch allocated and cleared");
 	hipLaunchKernelGGL(chain_kernel, dim3((unsigned) (lanes / 64)), dim3(64), 0, 0, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipDeviceSynchronize());
+	stamp("chain_kernel");
 	unsigned long long c[3] = {0, 0, 0};
 	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
 	out->n_recs = (int64_t) c[0]; out->n_T = (int64_t) c[2];
@@ -670,13 +704,15 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	std::vector<int32_t> T((size_t) c[2] + 1);
 	if(m) { HIP_TRY(hipMemcpy(rec.data(), A.rec, m * 32, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(rT.data(), A.rec_T, m * 8, hipMemcpyDeviceToHost)); }
 	if(c[2]) HIP_TRY(hipMemcpy(T.data(), A.T, (size_t) c[2] * 4, hipMemcpyDeviceToHost));
-	std::vector<size_t> order(m);
-	std::iota(order.begin(), order.end(), (size_t) 0);
+	// stream order: reads ascending, a read's chains by their ordinal (0, 1, ... per read) -- a counting sort
 	auto read_of = [&](size_t x) { return (int64_t) (uint32_t) rec[8 * x] | ((int64_t) rec[8 * x + 1] << 32); };
-	std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-		const int64_t ra = read_of(a), rb = read_of(b);
-		return ra != rb ? ra < rb : rec[8 * a + 2] < rec[8 * b + 2];
-	});
+	std::vector<size_t> order(m);
+	{
+		std::vector<int64_t> first((size_t) n + 1, 0);
+		for(size_t x = 0; x < m; ++x) ++first[(size_t) read_of(x) + 1];
+		for(int64_t r = 0; r < n; ++r) first[(size_t) r + 1] += first[(size_t) r];
+		for(size_t x = 0; x < m; ++x) order[(size_t) (first[(size_t) read_of(x)] + rec[8 * x + 2])] = x;
+	}
 	int64_t at = 0;
 	for(size_t x = 0; x < m; ++x) {
 		const size_t s = order[x];
@@ -688,5 +724,6 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 		at += nT;
 	}
 	out->T_off[m] = at;
+	stamp("records back and in stream order");
 	return KMAHIP_OK;
 }
