@@ -1503,25 +1503,47 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		                  c[LC_CNT + 9], c[LC_CNT + 10], c[LC_CNT + 11], c[LC_CNT + 12]); fflush(stderr); }
 		// grids follow the queue lengths: 4 wavefronts per workgroup of lt_dp_kernel, 64 / W problems per wavefront round
 		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LC_CNT + cls] + per_wg - 1) / per_wg)); };
+		// The size classes are independent of each other: the sweeps that live in LDS run side by side on three streams, the
+		// kernels that share the per-workgroup HBM scratch (classes 9-12 and the one-lane class 8: a few hundred big problems that
+		// take as long as the rest together when they run alone) one after the other on a fourth. With KMAHIP_DEBUG_TIMING
+		// everything stays on the caller's stream so that the stages can be timed.
+		static hipStream_t side[3] = {nullptr, nullptr, nullptr};
+		hipStream_t s1 = stream, s2 = stream, s3 = stream;
+		hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+		if(!dbg) {
+			for(int x = 0; x < 3; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+			HIP_TRY(hipEventRecord(fork, stream));
+			for(int x = 0; x < 3; ++x) HIP_TRY(hipStreamWaitEvent(side[x], fork, 0));
+			s1 = side[0]; s2 = side[1]; s3 = side[2];
+		}
 		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
 		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
 		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
 		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
-		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full>"); }
-		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full>"); }
-		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded>"); }
-		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded>"); }
-		// (the HBM variants share the per-workgroup scratch of dpx_wgs workgroups)
-		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, full, HBM>"); }
-		if(c[LC_CNT + 10]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, full, HBM>"); }
-		if(c[LC_CNT + 11]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<2, banded, HBM>"); }
-		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, stream, A); stage("dpx<4, banded, HBM>"); }
-		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, stream, A); stage("serial"); }
+		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, s1, A); stage("dpx<2, full>"); }
+		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, s1, A); stage("dpx<4, full>"); }
+		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, s2, A); stage("dpx<2, banded>"); }
+		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, s2, A); stage("dpx<4, banded>"); }
+		// (the HBM variants and the one-lane class share the per-workgroup scratch of dpx_wgs workgroups: one stream, in turn)
+		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, s3, A); stage("serial"); }
+		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, full, HBM>"); }
+		if(c[LC_CNT + 10]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, full, HBM>"); }
+		if(c[LC_CNT + 11]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, banded, HBM>"); }
+		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, banded, HBM>"); }
+		if(!dbg) {
+			for(int x = 0; x < 3; ++x) {
+				HIP_TRY(hipEventCreateWithFlags(&join[x], hipEventDisableTiming));
+				HIP_TRY(hipEventRecord(join[x], side[x]));
+				HIP_TRY(hipStreamWaitEvent(stream, join[x], 0));
+			}
+		}
 		hipLaunchKernelGGL(lt_finish_kernel, dim3((unsigned) std::min<int64_t>(fin_wgs, nb)), dim3(64), 0, stream, A);
 		stage("finish");
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
+		if(fork) { (void) hipEventDestroy(fork); for(int x = 0; x < 3; ++x) (void) hipEventDestroy(join[x]); }
 		if(c[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
 		ws->lt_stats[0] += c[LC_PROB]; ws->lt_stats[1] += c[LC_CELLS]; ws->lt_stats[2] += c[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) nb;
 		if(c[LC_STATUS] == 8 || c[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", c[LC_STATUS]); return KMAHIP_EDEVICE; }
