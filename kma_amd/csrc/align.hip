@@ -1853,23 +1853,36 @@ __device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QVi
 		for(int m = t_len - 1; m >= 0; --m, --npos) {
 			if(npos < 0) npos = tlen_total - 1;
 			uint8_t *e = E + (int64_t) pitch * m;
-			TROW(T, dc, q_len) = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			// (the cell to the right in this row and the cell below it stay in registers: a lane alone with its rows in HBM waited
+			// a memory round trip per cell for the value it had just stored)
+			int Dright = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+			TROW(T, dc, q_len) = Dright;
 			int Qprev = low;
+			int dp_right = TROW(T, dp, q_len);
 			const int tb = tn(ts, npos);
-			for(int n = q_len - 1; n >= 0; --n) {
+			auto one = [&](int n, int dp_n, int pp_n) {
 				uint8_t cell = 0, mv;
-				int Q = TROW(T, dc, n + 1) + W1;
-				int P = TROW(T, dp, n) + W1;
+				int Q = Dright + W1;
+				int P = dp_n + W1;
 				int D;
 				if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
 				int x = Qprev + U;
 				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
-				x = TROW(T, pp, n) + U;
+				x = pp_n + U;
 				if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
-				x = TROW(T, dp, n + 1) + L.d[5 * tb + qn(q, q_s + n)];
+				x = dp_right + L.d[5 * tb + qn(q, q_s + n)];
 				if(D <= x) { D = x; cell |= 1; } else cell |= mv;
 				TROW(T, dc, n) = D; TROW(T, pc, n) = P; e[n] = cell; Qprev = Q;
+				Dright = D; dp_right = dp_n;
+			};
+			int n = q_len - 1;
+			for(; n >= 3; n -= 4) {
+				// the row below, four cells at a time: eight loads in flight instead of two
+				const int a0 = TROW(T, dp, n), a1 = TROW(T, dp, n - 1), a2 = TROW(T, dp, n - 2), a3 = TROW(T, dp, n - 3);
+				const int b0 = TROW(T, pp, n), b1 = TROW(T, pp, n - 1), b2 = TROW(T, pp, n - 2), b3 = TROW(T, pp, n - 3);
+				one(n, a0, b0); one(n - 1, a1, b1); one(n - 2, a2, b2); one(n - 3, a3, b3);
 			}
+			for(; n >= 0; --n) one(n, TROW(T, dp, n), TROW(T, pp, n));
 			if(k < 0 && s.score < TROW(T, dc, 0)) { s.score = TROW(T, dc, 0); best_m = m; }
 			int x = dc; dc = dp; dp = x; x = pc; pc = pp; pp = x;
 		}
@@ -1916,26 +1929,29 @@ __device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QVi
 		}
 		const int tb = tn(ts, npos);
 		int qp = sq;
+		int Dright = TROW(T, dc, sn + 1), dp_here = TROW(T, dp, sn);      // (kept in registers from one cell to the next, as above)
 		for(n = sn; n > en; --qp, --n) {
 			uint8_t cell = 0, mv;
-			int Q = TROW(T, dc, n + 1) + W1;
-			int P = TROW(T, dp, n - 1) + W1;
+			const int dp_left = TROW(T, dp, n - 1), pp_left = TROW(T, pp, n - 1);
+			int Q = Dright + W1;
+			int P = dp_left + W1;
 			int D;
 			if(Q < P) { D = P; mv = 4; } else { D = Q; mv = 2; }
 			int x = Qprev + U;
 			if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
-			x = TROW(T, pp, n - 1) + U;
+			x = pp_left + U;
 			if(P < x) { P = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
-			x = TROW(T, dp, n) + L.d[5 * tb + qn(q, q_s + qp)];
+			x = dp_here + L.d[5 * tb + qn(q, q_s + qp)];
 			if(D <= x) { D = x; cell |= 1; } else cell |= mv;
 			TROW(T, dc, n) = D; TROW(T, pc, n) = P; e[n] = cell; Qprev = Q;
+			Dright = D; dp_here = dp_left;
 		}
 		{	// band edge: no gap-in-query state (nw.c:1079-1105)
 			uint8_t cell = 0, mv;
-			int Q = TROW(T, dc, n + 1) + W1, x = Qprev + U;
+			int Q = Dright + W1, x = Qprev + U;
 			if(Q < x) { Q = x; mv = 3; } else { mv = 2; cell |= 16; }
 			TROW(T, pc, n) = low;
-			int D = TROW(T, dp, n) + L.d[5 * tb + qn(q, q_s + qp)];
+			int D = dp_here + L.d[5 * tb + qn(q, q_s + qp)];
 			if(Q <= D) cell |= 1; else { D = Q; cell |= mv; }
 			TROW(T, dc, n) = D; e[n] = cell;
 		}
@@ -2462,8 +2478,9 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 			unsigned long long put_off[2] = {0, 0};
 			HIP_TRY(hipStreamSynchronize(stream));
 			HIP_TRY(hipMemcpy(put_off, ws->counters + 3, sizeof put_off, hipMemcpyDeviceToHost));
-			fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the pass with matrices in LDS, %llu of them to the pass with matrices in HBM\n",
-			        (long long) n, put_off[0], put_off[1]);
+			if(lds_pass) fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the pass with matrices in LDS, %llu of them to the pass with matrices in HBM\n",
+			                     (long long) n, put_off[0], put_off[1]);
+			else fprintf(stderr, "[kmahip] trace: %lld reads, %llu put off to the pass with move matrices\n", (long long) n, put_off[0]);
 		}
 	}
 	return KMAHIP_OK;
