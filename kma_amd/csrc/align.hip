@@ -1969,6 +1969,9 @@ __device__ bool nw_trace(TLane &T, const uint64_t *ts, int tlen_total, const QVi
 }
 
 // KMA(), align.c:214-507. Returns the alignment statistics (len == 1, score == 0: no alignment); columns go to T.em.
+// FAST (the first pass): problems are either settled on the diagonal or the read is put off -- no move matrix in this instantiation,
+// which is what lets it run at more waves per SIMD than the full one
+template <bool FAST>
 __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, int t_len, const QView &q, int mq,
                          int &clip_start, int &clip_end, unsigned &mapQ) {
 	const Aln FAIL = {0, 1, 0, 0, 0, 0};
@@ -2028,7 +2031,7 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 				const int band = abs(t_e - t_s - q_e + q_s) + bw;
 				const bool full = q_e - q_s <= band || t_e - t_s <= band;
 				Aln r; int cs = 0, ce = 0;
-				if(T.fast) {
+				if(FAST) {
 					const int g = q_e - q_s;
 					if(t_s == 0 || !full || q.nN) { T.status = 32; return FAIL; }
 					const int m = diag_mism(ts, q, t_e - g, q_s, g);
@@ -2064,9 +2067,14 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 			const int band = abs(t_l - q_e + q_s) + bw;
 			const bool full = q_e - q_s <= band || t_l <= band;
 			Aln r; int cs, ce;
-			if(T.fast && t_l > 0 && q_e - q_s > 0) {
+			if(FAST && t_l > 0 && q_e - q_s > 0) {
 				if(t_l != q_e - q_s || t_e < t_s || !full || q.nN || diag_mism(ts, q, t_s, q_s, t_l) > T.gap_m_max) { T.status = 32; return FAIL; }
 				diag_emit(T, ts, q, t_s, q_s, t_l, r);
+			} else if(FAST) {
+				// one side empty: a single gap run, no matrix (the head of NW, nw.c:37-60)
+				const int ql = q_e - q_s;
+				r = nw_degenerate(t_l, ql, L.U, L.W1);
+				if(t_l == 0) T.em.push(2, ql); else T.em.push(3, t_l);
 			} else if(!nw_trace(T, ts, t_len, q, 0, t_s, t_e, q_s, q_e, full ? -1 : band, false, t_len, r, cs, ce)) { T.status = 1; return FAIL; }
 			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
 		}
@@ -2083,7 +2091,7 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 			const int band = abs(t_e - t_s - q_e + q_s) + bw;
 			const bool full = q_e - q_s <= band || t_e - t_s <= band;
 			Aln r; int cs, ce = 0;
-			if(T.fast) {
+			if(FAST) {
 				const int g = q_e - q_s;
 				if(t_e == t_len || !full || q.nN) { T.status = 32; return FAIL; }
 				const int m = diag_mism(ts, q, t_s, q_s, g);
@@ -2108,6 +2116,7 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 	return S;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      // (64 threads in the LDS pass)
 	__shared__ int s_d[25];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
@@ -2153,7 +2162,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      //
 				t_len = A.db.tlen[t];
 				const uint64_t *ts = A.db.tseq + A.db.tseq_off[t];
 				T.em.n = 0; T.em.over = false; T.status = 0;
-				S = kma_trace(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
+				S = kma_trace<FAST>(T, A.db, t, ts, t_len, q, A.mq, cs, ce, mapQ);
 				if(T.status == 32 || (T.status == 1 && A.lds_bytes)) A.q_out[atomicAdd(&A.counters[A.q_out_cnt], 1ull)] = (int32_t) r;
 				else if(T.status || T.em.over) atomicMax(&A.counters[1], (unsigned long long) (T.em.over ? 4 : (T.status == 1 ? 8 : 16)));
 				else {
@@ -2455,7 +2464,17 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.q_in = nullptr; A.q_out = ws->t_queue; A.q_in_cnt = 3; A.q_out_cnt = 3; A.fast = plain ? 1 : 0;
 	A.gap_m_max = plain ? (M - 2 * W1 - 1) / (M - MM) : 0;
 	A.lds_bytes = 0; A.lds_ncols = 0;
-	hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
+	if(plain) {
+		// the first pass holds no move matrix and no DP rows: it fits five waves per SIMD where the full kernel fits four, and its
+		// lanes lay their MEM arrays and run slots over the room of the rows (same allocation, more lanes)
+		TraceArgs F = A;
+		int64_t lanes_fast = lanes / 4 * 5;
+		while(lanes_fast > lanes && lanes_fast * (int64_t) (7 * (mem_cap + 1) + ops_cap) > lanes * (int64_t) (7 * (mem_cap + 1) + 4 * ncols + ops_cap)) lanes_fast -= 256;
+		lanes_fast = std::min<int64_t>(lanes_fast, ((n + 255) / 256) * 256);
+		F.lanes = lanes_fast;
+		F.ops_s = (uint32_t *) (ws->t_s32 + (size_t) lanes_fast * 7 * (mem_cap + 1));
+		hipLaunchKernelGGL(trace_kernel<true>, dim3((unsigned) (lanes_fast / 256)), dim3(256), 0, stream, F);
+	} else hipLaunchKernelGGL(trace_kernel<false>, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
 	HIP_TRY(hipGetLastError());
 	if(plain) {
 		// pass 2: the reads put off, with their move matrices in HBM. (KMAHIP_TRACE_LDS=1 puts a pass with the matrices of small
@@ -2467,12 +2486,12 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		if(lds_pass) {
 			A.lds_bytes = 1008; A.lds_ncols = 24;
 			const unsigned g2 = (unsigned) std::min<int64_t>(lanes / 64, 256 * 2 * 8);
-			hipLaunchKernelGGL(trace_kernel, dim3(g2), dim3(64), 64 * 1008, stream, A);
+			hipLaunchKernelGGL(trace_kernel<false>, dim3(g2), dim3(64), 64 * 1008, stream, A);
 			HIP_TRY(hipGetLastError());
 			A.q_in = ws->t_queue + n; A.q_in_cnt = 4;
 		}
 		A.q_out = nullptr; A.lds_bytes = 0; A.lds_ncols = 0;
-		hipLaunchKernelGGL(trace_kernel, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
+		hipLaunchKernelGGL(trace_kernel<false>, dim3((unsigned) (lanes / 256)), dim3(256), 0, stream, A);
 		HIP_TRY(hipGetLastError());
 		if(getenv("KMAHIP_DEBUG_TIMING")) {
 			unsigned long long put_off[2] = {0, 0};
