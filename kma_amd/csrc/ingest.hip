@@ -155,6 +155,7 @@ struct Chunk {
 	uint8_t *base = nullptr;
 	size_t cap = 0, lo = 0, hi = 0;
 	bool mapped = false, last = false;
+	bool io_error = false;          // the stream ended on a read / inflate error, not at its end
 	int64_t spans_end = 0;          // records located in it end here (position in the stream of records)
 	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else free(base); }
 };
@@ -205,8 +206,9 @@ struct Feeder {
 			c->base = (uint8_t *) malloc(c->cap);
 			c->lo = c->hi = HEAD;
 			while(c->base && c->hi < c->cap) {
-				const int got = gzread(gz, c->base + c->hi, (unsigned) (c->cap - c->hi));
-				if(got <= 0) { c->last = true; break; }
+				// (in pieces: zlib drops what a call had inflated when the call ends in an error)
+				const int got = gzread(gz, c->base + c->hi, (unsigned) std::min<size_t>(c->cap - c->hi, 1u << 20));
+				if(got <= 0) { c->last = true; c->io_error = got < 0; break; }
 				c->hi += (size_t) got;
 			}
 			if(!c->base) c->last = true;
@@ -266,6 +268,7 @@ struct kmahip_ingest {
 	int phred = 33;
 	int threads = 1;
 	bool malformed = false, reported = false;      // a record that does not start with '@': everything before it is delivered, then KMAHIP_EFORMAT once
+	bool io_error = false, io_reported = false;     // a corrupt .gz (or a failing read): what came before it is delivered, then KMAHIP_EIO once
 	int64_t n_read = 0, n_kept = 0;
 	// current batch
 	Arr<uint64_t> seq;
@@ -631,6 +634,7 @@ bool fill_wave(kmahip_ingest *in, Mate &M) {
 			Chunk *c = M.feed.pop();
 			Chunk *old = M.live.empty() ? nullptr : M.live.back();
 			const size_t tail = old ? old->hi - M.pos : 0;
+			if(c && c->io_error) in->io_error = true;
 			if(!c) {
 				if(!old) { M.eof = true; break; }
 				old->last = true;                              // (a stream that ended on a chunk boundary)
@@ -704,6 +708,7 @@ bool fill_wave(kmahip_ingest *in, Mate &M) {
 			// force the next chunk in, whatever the size of the tail
 			Chunk *n = M.feed.pop();
 			const size_t tail = c->hi - M.pos;
+			if(n && n->io_error) in->io_error = true;
 			if(!n) { c->last = true; continue; }
 			Chunk *big = new Chunk();
 			big->cap = tail + (n->hi - n->lo);
@@ -869,6 +874,11 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	batch->reads.max_len = max_len;
 	batch->names = in->names.data(); batch->name_off = in->name_off.data(); batch->pair = in->pair.data();
 	batch->records = records;
+	if(in->io_error && !in->io_reported && records == 0) {
+		in->io_reported = true;
+		kmahip_set_error("read error (corrupt or truncated compressed input) after %lld records", (long long) in->n_read);
+		return KMAHIP_EIO;
+	}
 	if(in->malformed && !in->reported && records == 0) {
 		// like the reference, which prints "Malformed input." and ends with a non-zero exit status after the good records
 		in->reported = true;

@@ -235,3 +235,27 @@ def test_ingest_chunked_reader_malformed_and_short_mate(tmp_path, tiny_chunks):
     assert _all(str(bad), step=11) == want_bad
     assert _all(str(full), str(short)) == want_pe
     assert _all(str(short), str(full), step=13) == _all(str(short), str(full))
+
+
+def test_ingest_reports_a_corrupt_gzip_stream(tmp_path):
+    """the records before the damage are delivered, then one call fails with an I/O error (not a silent end of input)"""
+    import gzip as _gz
+    rng = np.random.default_rng(3)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    good = b"".join(b"@r%d\n" % i + lut[rng.integers(0, 4, 150)].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(20000))
+    z = bytearray(_gz.compress(good, 1))
+    z[len(z) // 2:len(z) // 2 + 64] = bytes(64)           # damage in the middle of the deflate stream
+    p = tmp_path / "bad.fq.gz"
+    p.write_bytes(bytes(z))
+    with binding.Ingest(str(p)) as ing:
+        n, err = 0, None
+        for _ in range(10):
+            try:
+                g = ing.next(1 << 30)
+            except binding.KmaHipError as e:
+                err = str(e)
+                break
+            if g is None:
+                break
+            n += g[0].n
+        assert err is not None and 0 < n < 20000, (n, err)
