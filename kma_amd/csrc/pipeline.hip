@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -472,10 +473,59 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	}
 	const int64_t m = R.n_recs;
 	out->ms[1] = since(t);
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_lap = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { if(dbg) fprintf(stderr, "[kmahip] run_chain: %s %.1f ms\n", what, since(t_lap)); };
+	lap("stage 2 (kmahip_scan_chain)");
 	// the records as a batch of their own: the read, or its reverse complement where the record prints that, with its bounds
-	HostBatch RB;
-	for(int64_t x = 0; x < m; ++x) { if(r_emit[(size_t) x]) RB.add_rc(*reads, r_read[(size_t) x]); else RB.add(*reads, r_read[(size_t) x]); }
-	kmahip_reads rb = RB.view();
+	// (laid out by a prefix sum, filled by a few threads: two million records one vector push at a time took longer than stage 2)
+	std::vector<int64_t> rb_seq_off((size_t) m + 1, 0), rb_N_off((size_t) m + 1, 0);
+	std::vector<int32_t> rb_len((size_t) m + 1, 0);
+	int rb_max_len = 0;
+	for(int64_t x = 0; x < m; ++x) {
+		const int64_t r = r_read[(size_t) x];
+		const int L = reads->len[r];
+		rb_len[(size_t) x] = L;
+		rb_seq_off[(size_t) x + 1] = rb_seq_off[(size_t) x] + ((L + 31) >> 5) + 1;
+		rb_N_off[(size_t) x + 1] = rb_N_off[(size_t) x] + (reads->N_off[r + 1] - reads->N_off[r]);
+		rb_max_len = std::max(rb_max_len, L);
+	}
+	std::vector<uint64_t> rb_seq((size_t) rb_seq_off[(size_t) m] + 2, 0);
+	std::vector<int32_t> rb_N((size_t) rb_N_off[(size_t) m] + 1, 0);
+	{
+		const int hw = (int) std::thread::hardware_concurrency();
+		const int nt = (int) std::max<int64_t>(1, std::min<int64_t>(std::min(16, hw > 0 ? hw : 1), m / 4096));
+		auto fill = [&](int w) {
+			for(int64_t x = m * w / nt; x < m * (w + 1) / nt; ++x) {
+				const int64_t r = r_read[(size_t) x];
+				const int L = rb_len[(size_t) x];
+				const uint64_t *src = reads->seq + reads->seq_off[r];
+				uint64_t *dst = rb_seq.data() + rb_seq_off[(size_t) x];
+				int32_t *nd = rb_N.data() + rb_N_off[(size_t) x];
+				const int64_t n0 = reads->N_off[r], n1 = reads->N_off[r + 1];
+				if(!r_emit[(size_t) x]) {
+					memcpy(dst, src, (size_t) ((L + 31) >> 5) * 8);
+					for(int64_t y = n0; y < n1; ++y) nd[y - n0] = reads->N[y];
+				} else {
+					// rc_comp, compdna.c:228-256: the bits complemented, an N keeps its place from the other end
+					for(int p = 0; p < L; ++p) {
+						const int q = L - 1 - p;
+						const uint64_t b = 3 - ((src[q >> 5] >> (62 - ((q & 31) << 1))) & 3);
+						dst[p >> 5] |= b << (62 - ((p & 31) << 1));
+					}
+					for(int64_t y = n1 - 1; y >= n0; --y) nd[n1 - 1 - y] = L - 1 - reads->N[y];
+				}
+			}
+		};
+		std::vector<std::thread> pool;
+		for(int w = 1; w < nt; ++w) pool.emplace_back(fill, w);
+		fill(0);
+		for(std::thread &th : pool) th.join();
+	}
+	kmahip_reads rb = {};
+	rb.n_reads = m; rb.seq = rb_seq.data(); rb.seq_off = rb_seq_off.data(); rb.len = rb_len.data(); rb.N = rb_N.data(); rb.N_off = rb_N_off.data();
+	rb.seq_words = rb_seq_off[(size_t) m]; rb.N_total = rb_N_off[(size_t) m]; rb.max_len = rb_max_len;
+	lap("record batch built");
 	DevBlock B;
 	B.expect((size_t) rb.seq_words * 8 + (size_t) rb.N_total * 4 + (size_t) m * 300 + (64u << 20));
 	kmahip_reads d = rb;
@@ -502,6 +552,7 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 		if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
 		for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	}
+	lap("stages 3a ... pile-up");
 	if(frag_path && m) {
 		std::vector<char> nm;
 		std::vector<int64_t> noff{0};
@@ -513,6 +564,7 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 		int64_t rows = 0;
 		if((rc = kmahip_frag_write(frag_path, db, &rb, k_rc.data(), k_tmpl.data(), k_nh.data(), k_stats.data(), max_frag, nm.data(), noff.data(), &rows))) return rc;
 	}
+	lap("fragment file");
 	out->ms[5] += since(t);
 	return KMAHIP_OK;
 }

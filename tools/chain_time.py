@@ -35,6 +35,9 @@ subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=sub
 t0 = time.perf_counter()
 r = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", os.path.join(tmp, "got"), "-chain"], stderr=subprocess.PIPE)
 dt = time.perf_counter() - t0
+for line in r.stderr.decode().splitlines():
+    if "run_chain" in line or "scan_chain" in line:
+        print("   ", line)
 print(f"kmahip_map -chain, file to file: {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stderr.decode().strip().splitlines()[-1] if r.stderr else ''}", flush=True)
 kma = os.path.join(ROOT, "oracle", "_ref", "kma")
 if os.path.exists(kma) and sample:
