@@ -178,6 +178,14 @@ def c4_leg(tmp, n_reads, device):
                "stage_ms": {k: round(v, 2) for k, v in zip(("upload", "-", "figures", "trace", "pileup+consensus", "copies"), o["ms"])},
                "kept_reads": int((o["trace_stats"][:, 3] > 0).sum()), "dp_problems": int(st.problems), "dp_cells": int(st.dp_cells),
                "mems_chained": int(st.mems), "trace_stage_GCUPS": st.dp_cells / (o["ms"][3] / 1e3) / 1e9 if o["ms"][3] else None}
+        # the contract's roofline view of this path: what it must move through HBM at the least (12 B per position-index
+        # lookup, one per base and strand; the packed reads; one move byte written and read per DP cell that leaves LDS -- here none
+        # of the common classes does; the runs and figures out) against what the stage takes. The DP lives in LDS and on the VALUs.
+        alg = 2 * bases * 12 + bases // 4 + int(st.mems) * 40 + n_reads * 64
+        out["roofline"] = {"bound": "valu + lds (integer DP, move matrices in LDS); HBM carries the index lookups", "algorithmic_bytes": alg,
+                           "achieved": alg / (o["ms"][3] / 1e3) / 1e9 if o["ms"][3] else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": alg / (o["ms"][3] / 1e3) / 1e9 / HBM_PEAK_GBS if o["ms"][3] else None,
+                           "GCUPS": out["trace_stage_GCUPS"]}
         if os.path.exists(ref):
             import golden_util
             m = min(1000, n_reads)
