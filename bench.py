@@ -266,7 +266,7 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
 
     def run_map(inp, outp):
         t0 = time.perf_counter()
-        r = subprocess.run([mapper, "-i", inp, "-t_db", prefix, "-o", outp], stderr=subprocess.PIPE)
+        r = subprocess.run([mapper, "-i", inp, "-t_db", prefix, "-o", outp, "-1t1"], stderr=subprocess.PIPE)
         dt = time.perf_counter() - t0
         err = r.stderr.decode().strip().splitlines()
         if r.returncode:
@@ -278,7 +278,7 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
 
     out = {"reads": n, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "fastq_gz_GB": round(os.path.getsize(gz) / 1e9, 2), "unit": "reads/s",
            "host_threads": min(16, nproc),
-           "what": "examples/kmahip_map -i <fastq> -t_db <index> -o <out>: process start to exit, incl. HIP start-up, kmahip_db_open, ingest, "
+           "what": "examples/kmahip_map -i <fastq> -t_db <index> -o <out> -1t1: process start to exit, incl. HIP start-up, kmahip_db_open, ingest, "
                    "kmahip_run_se (upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus), .res, .fsa and .frag.gz"}
     got = os.path.join(tmp, "e2e_got")
     walls = [run_map(fq, got) for _ in range(2)]

@@ -2,8 +2,9 @@
  * on an MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte
  * for byte what KMA 1.5.1 writes with one thread (the .gz after decompression).
  *
- *     kmahip_map -i reads.fq.gz -t_db db -o out
- *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out
+ *     kmahip_map -i reads.fq.gz -t_db db -o out                     (the reference's default mode: chain finder, reads may map in pieces)
+ *     kmahip_map -i reads.fq.gz -t_db db -o out -1t1
+ *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out -1t1
  *     kmahip_map -i ont.fq.gz -t_db db -o out -Mt1 1 -bcNano        (every read against template 1, runKMA_Mt1 mt1.c:86-500)
  *
  * Stage 1 (kmahip_ingest_*: parse, trim with KMA's defaults, pack), the whole device run in one call (kmahip_run_se: stage 2,
@@ -44,7 +45,7 @@ int main(int argc, char **argv) {
 		if(!strcmp(argv[a], "-Mt1") && a + 1 < argc) { mt1 = atoi(argv[++a]); continue; }
 		if(!strcmp(argv[a], "-bcNano")) { bc_nano = 1; continue; }
 		if(!strcmp(argv[a], "-1t1")) { one2one = 1; continue; }
-		if(!strcmp(argv[a], "-chain")) { chain = 1; continue; }      /* the reference's mode when -1t1 is absent: save_kmers_chain */
+		if(!strcmp(argv[a], "-chain")) { chain = 1; continue; }      /* (same as leaving -1t1 out) */
 		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
 		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
 		else if(!strcmp(argv[a], "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
@@ -53,6 +54,9 @@ int main(int argc, char **argv) {
 		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix> [-1t1 | -chain] [-mf <fragments per chunk>] [-Mt1 <template> [-bcNano]]\n"); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
+	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
+	if(!one2one && !mt1) chain = 1;
+	if(chain && input2) { fprintf(stderr, "kmahip_map: paired input needs -1t1 (the default mode is built for single-end input)\n"); return 2; }
 
 	const double t_start = now_s();
 	/* stage 1: the whole file as one batch (the arrays stay owned by the reader), while the device and the index come up */

@@ -39,6 +39,7 @@ struct ChainArgs {
 	const int64_t *N_off;
 	int M, MM, U, W1, Wl;
 	int exhaustive, minlen;
+	int stop_after;              // timing experiments only (KMAHIP_CHAIN_STOP): 1 = after the anchors, 2 = after the chaining
 	double coverT, mrs;
 	// scratch, one region per lane
 	uint8_t *scratch;
@@ -414,6 +415,7 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 	const unsigned hitF = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 0, VF);
 	const unsigned hitR = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 1, VR);
 	if(L.status || (!hitF && !hitR)) return;
+	if(A.stop_after == 1) return;
 
 	// chains left to right, per strand (savekmers.c:5466-5634)
 	CAnk *best = nullptr, *best_r = &VF[0];
@@ -478,6 +480,7 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 		}
 	}
 	if(best->score < k && best_r->score < k) return;
+	if(A.stop_after == 2) return;
 
 	const int VF_start = (int) VF[0].start, VR_start = (int) VR[0].start;
 	int headF = prune(VF, 0, k), headR = prune(VR, 0, k);
@@ -651,6 +654,7 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	ChainArgs A;
 	A.db = db->dev; A.n_reads = n;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
+	A.stop_after = getenv("KMAHIP_CHAIN_STOP") ? atoi(getenv("KMAHIP_CHAIN_STOP")) : 0;
 	A.exhaustive = p->exhaustive; A.minlen = cp ? cp->minlen : 16; A.coverT = cp ? cp->coverT : 0.1; A.mrs = cp ? cp->mrs : 0.5;
 	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 2048); A.s_cap = 128;
 	A.lane_bytes = ((int64_t) 2 * A.a_cap * (int64_t) sizeof(CAnk) + (D + 1) * 8 + (int64_t) 2 * A.b_cap * 4 + (int64_t) A.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;

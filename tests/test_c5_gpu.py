@@ -48,7 +48,7 @@ def test_reference_built_index_whole_run_equals_reference_binary(tmp_path, famil
     fq = str(tmp_path / "reads.fq")
     synth.write_fastq(fq, reads, lens=None)
     subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"], check=True,
                    stderr=subprocess.DEVNULL)
     ref_res = open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.res", "rb").read() == ref_res

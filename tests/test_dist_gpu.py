@@ -163,7 +163,7 @@ def test_multi_rank_host_program_writes_the_single_gpu_files(tmp_path):
     fq = str(tmp_path / "reads.fq")
     synth.write_fastq(fq, rag, prefix="q")
     subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one")], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one"), "-1t1"], check=True, stderr=subprocess.DEVNULL)
     e = dict(os.environ, PYTHONPATH=ROOT)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),

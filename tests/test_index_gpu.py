@@ -73,7 +73,7 @@ def test_index_build_equals_kma_index(tmp_path, k):
     outs = {}
     for tag, idx in (("ref", ref), ("got", got)):
         subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / f"kma_{tag}"), "-t_db", idx, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
-        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", idx, "-o", str(tmp_path / f"hip_{tag}")], check=True,
+        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", idx, "-o", str(tmp_path / f"hip_{tag}"), "-1t1"], check=True,
                        stderr=subprocess.DEVNULL)
         outs[tag] = [open(tmp_path / f"{p}_{tag}.res", "rb").read() for p in ("kma", "hip")] + \
                     [gzip.open(tmp_path / f"{p}_{tag}.frag.gz").read() for p in ("kma", "hip")]

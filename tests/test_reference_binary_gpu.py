@@ -65,7 +65,7 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants, m
     synth.write_fastq(fq, reads, lens=None)
     extra = ["-mf", str(mf)] if mf else []        # (-mf: fragments per assembly chunk, 60 chunks here instead of one)
     subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"] + extra, check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")] + extra, check=True,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + extra, check=True,
                    stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -110,7 +110,7 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
     subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -242,7 +242,7 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
     subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got")],
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"],
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -270,7 +270,7 @@ def test_direct_address_index_written_by_kma_index(tmp_path, k, flags):
     fq = str(tmp_path / "reads.fq")
     synth.write_fastq(fq, reads, lens=None)
     subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")], check=True,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"], check=True,
                    stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()

@@ -320,7 +320,7 @@ def test_c_program_from_fastq_to_all_three_output_files(golden_se, tmp_path):
     subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
     g = golden_se
     out = str(tmp_path / "out")
-    subprocess.run([os.path.join(root, "examples", "kmahip_map"), "-i", os.path.join(g["dir"], "reads.fq.gz"), "-t_db", g["prefix"], "-o", out],
+    subprocess.run([os.path.join(root, "examples", "kmahip_map"), "-i", os.path.join(g["dir"], "reads.fq.gz"), "-t_db", g["prefix"], "-o", out, "-1t1"],
                    check=True, stderr=subprocess.DEVNULL)
     assert open(out + ".res", "rb").read() == open(os.path.join(g["dir"], "out.res"), "rb").read()
     assert open(out + ".fsa").read() == golden_util.load_fsa("se")

@@ -19,5 +19,5 @@ with open(os.path.join(w, "reads.fq"), "wb") as f:
         f.write(open(os.path.join(w, "part.fq"), "rb").read())
 PY
 make -C examples >/dev/null
-examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out 2>&1 | tail -1; KMAHIP_DEBUG_TIMING=1 examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out 2>&1 | grep -v "^\[kmahip\] lt"
+examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out -1t1 2>&1 | tail -1; KMAHIP_DEBUG_TIMING=1 examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out -1t1 2>&1 | grep -v "^\[kmahip\] lt"
 rm -rf $W

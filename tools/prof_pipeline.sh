@@ -26,13 +26,13 @@ make -C examples >/dev/null
 export KMAHIP_MAP_TEARDOWN=1
 ROOT=$(pwd)
 cd /tmp
-CMD="$ROOT/examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out"
+CMD="$ROOT/examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out -1t1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o pipe -- $CMD > $ROOT/$OUT/run.log 2>&1
 # HBM traffic counters in passes of their own (never together with the traces gpurun refuses)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/fetch -o pipe -- $CMD > $ROOT/$OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/write -o pipe -- $CMD > $ROOT/$OUT/write.log 2>&1
 cd $ROOT
-echo "kmahip_map -i reads.fq ($N reads x 150 bp) -t_db db5k -o out" > $OUT/cmd.txt
+echo "kmahip_map -i reads.fq ($N reads x 150 bp) -t_db db5k -o out -1t1" > $OUT/cmd.txt
 grep "kmahip_map:" $OUT/run.log | tail -1 > $OUT/stages.txt
 python3 tools/collect_pipeline_profile.py $W $OUT
 rm -rf $W
