@@ -367,6 +367,45 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
             say(f"e2e: default mode: kmahip_map -chain {tc:.2f} s on {m_} reads; reference {trc:.1f} s on {k_}; .res identical {ref['default_mode']['res_identical_to_reference']}")
         except Exception as e:  # noqa: BLE001  (extra figure only)
             ref["default_mode"] = {"error": str(e)}
+        # paired end (`-ipe r1 r2 -apm p -1t1`, the shape of configs C3): both sides file to file
+        try:
+            n_pairs, k_ = min(n // 2, 1_000_000), min(m_ // 2, 100_000)
+            r1, r2 = os.path.join(tmp, "e2e_r1.fq"), os.path.join(tmp, "e2e_r2.fq")
+            with open(r1, "wb") as f1, open(r2, "wb") as f2:
+                for a_ in range(0, n_pairs, 250_000):
+                    m1, m2, _ = synth.make_pairs(seqs, min(250_000, n_pairs - a_), seed=500 + a_)
+                    for f_, mm in ((f1, m1), (f2, m2)):
+                        write_fastq_fixed(os.path.join(tmp, "part.fq"), mm)
+                        with open(os.path.join(tmp, "part.fq"), "rb") as g:
+                            shutil.copyfileobj(g, f_, 1 << 24)
+            walls = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([mapper, "-ipe", r1, r2, "-t_db", prefix, "-o", got + "_pe", "-1t1"], stderr=subprocess.PIPE)
+                walls.append(time.perf_counter() - t0)
+                if r.returncode:
+                    raise RuntimeError(r.stderr.decode().strip().splitlines()[-1] if r.stderr else "kmahip_map -ipe failed")
+            rec2 = os.path.getsize(r1) // n_pairs
+            subs = []
+            for p_ in (r1, r2):
+                with open(p_, "rb") as f, open(p_ + ".sample", "wb") as g:
+                    g.write(f.read(rec2 * k_))
+                subs.append(p_ + ".sample")
+            t0 = time.perf_counter()
+            subprocess.run([kma, "-ipe", subs[0], subs[1], "-o", os.path.join(tmp, "e2e_ref_pe"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            trp = time.perf_counter() - t0
+            subprocess.run([mapper, "-ipe", subs[0], subs[1], "-t_db", prefix, "-o", got + "_pe_s", "-1t1"], check=True, stderr=subprocess.DEVNULL)
+            ref["paired_end"] = {"what": "examples/kmahip_map -ipe r1 r2 -1t1 (kmahip_run_pe: pairing penalty as -apm p) file to file on `pairs` pairs of 2 x 150 nt; "
+                                         "the reference -ipe r1 r2 -apm p -1t1 -t 1 on the first reference_pairs of them",
+                                 "kmahip_map_ipe": {"pairs": n_pairs, "wall_s": round(min(walls), 3), "reads_per_s": 2 * n_pairs / min(walls)},
+                                 "reference_t1": {"reference_pairs": k_, "wall_s": round(trp, 2), "reads_per_s": 2 * k_ / trp},
+                                 "res_identical_to_reference": open(got + "_pe_s.res", "rb").read() == open(os.path.join(tmp, "e2e_ref_pe.res"), "rb").read()}
+            say(f"e2e: paired end: kmahip_map -ipe {min(walls):.2f} s on {n_pairs} pairs; reference {trp:.1f} s on {k_}; .res identical {ref['paired_end']['res_identical_to_reference']}")
+            for p_ in (r1, r2, *subs):
+                os.unlink(p_)
+        except Exception as e:  # noqa: BLE001  (extra figure only)
+            ref["paired_end"] = {"error": str(e)}
         out["vs_reference_t1"] = out["plain"]["reads_per_s"] / ref["t1"]["reads_per_s"]
         out["vs_reference_best_shards"] = out["plain"]["reads_per_s"] / max(ref["shards_16"]["reads_per_s"], ref["shards_nproc"]["reads_per_s"], ref["t_nproc"]["reads_per_s"])
     for f_ in (fq, gz):

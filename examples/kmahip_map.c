@@ -147,8 +147,9 @@ int main(int argc, char **argv) {
 	if(!input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	const double t_frag = now_s();
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; wall: ingest %.2f s beside open %.2f (both done after %.2f), device run %.2f, .res + .fsa %.2f, .frag.gz %.2f | "
-	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f\n", (long long) n, (long long) frag_rows,
-	        job.t_done - t_start, t_open - t_start, t_ingest - t_start, t_run - t_ingest, t_res - t_run, t_frag - t_res, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4]);
+	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f%s\n", (long long) n, (long long) frag_rows,
+	        job.t_done - t_start, t_open - t_start, t_ingest - t_start, t_run - t_ingest, t_res - t_run, t_frag - t_res, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4],
+	        input2 || chain ? " (the device run wrote the .frag.gz)" : "");
 	/* every output is closed; the process ends here instead of unmapping gigabytes of reads and scratch one by one
 	 * (KMAHIP_MAP_TEARDOWN=1: release everything in order, e.g. under a leak checker) */
 	if(getenv("KMAHIP_MAP_TEARDOWN")) {

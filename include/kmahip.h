@@ -243,6 +243,10 @@ int kmahip_conclave_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, 
  * listed hit of the record before it (the reference reads zero entries into buffers it does not clear). */
 int kmahip_conclave_records(kmahip_db *db, kmahip_ws *ws, int64_t n_records, const int32_t *q_len, const int32_t *q_len2,
                             const int64_t *off, const kmahip_hits *hits, kmahip_conclave *out);
+/* ... with DEVICE pointers, asynchronous on `stream`; `off` needs n_records entries only (a record with n_hits 0 and
+ * score 0 is an unused slot: ConClave passes over it) */
+int kmahip_conclave_records_dev(kmahip_db *db, kmahip_ws *ws, int64_t n_records, const int32_t *q_len, const int32_t *q_len2,
+                                const int64_t *off, const kmahip_hits *hits, kmahip_conclave *out, void *stream);
 
 /* The columns of a `.res` row that do not depend on the consensus (runkma.c:765-783, 809): Score, Expected (as printed,
  * (unsigned) expected), Template_length, q_value, p_value, and whether the template passes the reference's gate for

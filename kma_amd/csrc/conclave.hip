@@ -154,6 +154,17 @@ extern "C" int kmahip_conclave_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip
 	return launch_conclave(db, A, hits, out, (hipStream_t) stream);
 }
 
+// explicit records with everything in HBM (the paired run builds them on the device: two slots per unit of the stream, an
+// unused slot = a record with n_hits 0 and score 0, which ConClave passes over)
+extern "C" int kmahip_conclave_records_dev(kmahip_db *db, kmahip_ws *ws, int64_t n_records, const int32_t *q_len, const int32_t *q_len2,
+                                           const int64_t *off, const kmahip_hits *hits, kmahip_conclave *out, void *stream) {
+	(void) ws;
+	if(!db || !q_len || !off || !hits || !out || n_records < 0) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	CCArgs A{};
+	A.n_slots = n_records; A.pe = 2; A.len = q_len; A.len2 = q_len2; A.off = off;
+	return launch_conclave(db, A, hits, out, (hipStream_t) stream);
+}
+
 // ---- host-buffer forms: stage everything, run, copy back (PCIe inclusive; glue for callers that keep stage 3a's
 // results on the host) ------------------------------------------------------------------------------------------
 namespace {

@@ -116,6 +116,10 @@ int write_rows(const char *path, size_t n_rows, Fmt fmt) {
 
 }  // namespace
 
+int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *reads, int64_t n, const int64_t *src, const int32_t *rc,
+                          const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,
+                          const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows);
+
 extern "C" int kmahip_frag_write(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                                  const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, const char *read_names,
                                  const int64_t *read_name_off, int64_t *rows) {
@@ -131,11 +135,21 @@ extern "C" int kmahip_frag_write2(const char *path, kmahip_db *db, const kmahip_
 extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                                   const int32_t *n_hits, const int32_t *trace_stats, int64_t max_frag, int order, const int64_t *frag_rank,
                                   const char *read_names, const int64_t *read_name_off, int64_t *rows) {
+	if(!reads) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return kmahip_frag_write_src(path, db, reads, reads->n_reads, nullptr, rc, tmpl, n_hits, trace_stats, 10, max_frag, order, frag_rank, read_names, read_name_off, rows);
+}
+
+// the writer proper. src == NULL: fragment i is read i of `reads`; else fragment i (of n) is read src[i] of `reads` / `read_names`
+// (the paired run files its fragments in record order without copying the reads). rc, tmpl, n_hits, trace_stats, frag_rank: per fragment.
+int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *reads, int64_t n, const int64_t *src, const int32_t *rc,
+                          const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,
+                          const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows) {
+	const int64_t S = stats_stride;         // ints per fragment in trace_stats (score, start, end, kept first)
 	if(!path || !db || !reads || !rc || !tmpl || !n_hits || !trace_stats || !read_names || !read_name_off) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	int e = load_names(db);
 	if(e) return e;
 	if(max_frag <= 0) max_frag = 1000000;
-	const int64_t n = reads->n_reads;
+	auto rd = [src](int64_t i) { return src ? src[i] : i; };
 	// the order assemble_KMA meets the fragments in: templates ascending; inside a template the chunks of max_frag filed
 	// fragments in stream order, each chunk back to front (conclave.c:164-166, 194). A counting sort over the templates keeps
 	// the stream order inside each one; the chunks are then turned round in place. (order 1: the single thread of `-Mt1`
@@ -147,7 +161,7 @@ extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_
 		if(tmpl[i] == 0) continue;
 		const size_t t = (size_t) abs(tmpl[i]);
 		if(t > n_t) { kmahip_set_error("template %zu has no name in %s.name", t, db->prefix.c_str()); return KMAHIP_EFORMAT; }
-		if(trace_stats[10 * i + 3] != 0) ++t_rows[t + 1];
+		if(trace_stats[S * i + 3] != 0) ++t_rows[t + 1];
 	}
 	for(size_t t = 1; t < t_rows.size(); ++t) t_rows[t] += t_rows[t - 1];        // t_rows[t] = first row of template t
 	const size_t n_rows = (size_t) t_rows[n_t + 1];
@@ -159,7 +173,7 @@ extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_
 			if(tmpl[i] == 0) continue;
 			const size_t t = (size_t) abs(tmpl[i]);
 			const int64_t r = frag_rank ? frag_rank[i] : rank++;
-			if(trace_stats[10 * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
+			if(trace_stats[S * i + 3] == 0) continue;          // dropped by the stage-3c filter: no row
 			const size_t at = (size_t) fill[t]++;
 			row_read[at] = i;
 			if(!order) row_rank[at] = r;
@@ -184,16 +198,16 @@ extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_
 	// point to (bases, header) 8 rows ahead.
 	auto ahead = [&](size_t r) {
 		if(r + 16 < n_rows) {
-			const int64_t i = row_read[r + 16];
-			__builtin_prefetch(reads->seq_off + i); __builtin_prefetch(reads->len + i); __builtin_prefetch(reads->N_off + i);
+			const int64_t i = row_read[r + 16], j = rd(i);
+			__builtin_prefetch(reads->seq_off + j); __builtin_prefetch(reads->len + j); __builtin_prefetch(reads->N_off + j);
 			__builtin_prefetch(rc + i); __builtin_prefetch(tmpl + i); __builtin_prefetch(n_hits + i);
-			__builtin_prefetch(trace_stats + 10 * i); __builtin_prefetch(read_name_off + i);
+			__builtin_prefetch(trace_stats + S * i); __builtin_prefetch(read_name_off + j);
 		}
 		if(r + 8 < n_rows) {
-			const int64_t i = row_read[r + 8];
-			const uint64_t *w = reads->seq + reads->seq_off[i];
+			const int64_t i = row_read[r + 8], j = rd(i);
+			const uint64_t *w = reads->seq + reads->seq_off[j];
 			__builtin_prefetch(w); __builtin_prefetch(w + 8);
-			__builtin_prefetch(read_names + read_name_off[i]);
+			__builtin_prefetch(read_names + read_name_off[j]);
 			__builtin_prefetch(db->h_names[(size_t) abs(tmpl[i]) - 1].data());
 		}
 	};
@@ -223,14 +237,14 @@ extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_
 	};
 	auto fmt = [&](size_t r, std::string &out) {
 		ahead(r);
-		const int64_t i = row_read[r];
-		const int L = reads->len[i];
-		const uint64_t *w = reads->seq + reads->seq_off[i];
-		const int32_t *N = reads->N + reads->N_off[i];
-		const int nN = (int) (reads->N_off[i + 1] - reads->N_off[i]);
+		const int64_t i = row_read[r], j = rd(i);
+		const int L = reads->len[j];
+		const uint64_t *w = reads->seq + reads->seq_off[j];
+		const int32_t *N = reads->N + reads->N_off[j];
+		const int nN = (int) (reads->N_off[j + 1] - reads->N_off[j]);
 		const bool flip = ((rc[i] & 1) != 0) != (tmpl[i] < 0);
 		const std::string &tname = db->h_names[(size_t) abs(tmpl[i]) - 1];
-		const char *rname = read_names + read_name_off[i];            // NUL-terminated
+		const char *rname = read_names + read_name_off[j];            // NUL-terminated
 		const size_t rlen = strlen(rname);
 		const size_t at = out.size();
 		out.resize(at + (size_t) (((L + 31) >> 5) << 5) + 4 * 12 + 2 + tname.size() + rlen + 1);
@@ -249,7 +263,7 @@ extern "C" int kmahip_frag_write3(const char *path, kmahip_db *db, const kmahip_
 		}
 		for(int x = 0; x < nN; ++x) o[flip ? L - 1 - N[x] : N[x]] = 'N';
 		o += L;
-		o = put_int(o, n_hits[i]); o = put_int(o, trace_stats[10 * i]); o = put_int(o, trace_stats[10 * i + 1]); o = put_int(o, trace_stats[10 * i + 2]);
+		o = put_int(o, n_hits[i]); o = put_int(o, trace_stats[S * i]); o = put_int(o, trace_stats[S * i + 1]); o = put_int(o, trace_stats[S * i + 2]);
 		*o++ = '\t';
 		memcpy(o, tname.data(), tname.size()); o += tname.size();
 		*o++ = '\t';

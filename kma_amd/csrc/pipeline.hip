@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <memory>
+#include <rocprim/rocprim.hpp>
 #include <thread>
 #include <vector>
 
@@ -246,19 +248,180 @@ struct HostBatch {
 	}
 };
 
-struct HitBuf {
-	std::vector<int32_t> n_hits, best, flag, rc, tmpl, score, start, end;
-	kmahip_hits view(uint64_t *as, uint64_t *us) {
-		kmahip_hits h;
-		h.n_hits = n_hits.data(); h.best_score = best.data(); h.flag = flag.data(); h.tmpl = tmpl.data(); h.score = score.data();
-		h.start = start.data(); h.end = end.data(); h.alignment_scores = as; h.uniq_alignment_scores = us; h.rc = rc.data();
-		return h;
+}  // namespace
+
+// ---- paired run (`-ipe r1 r2 -apm p -1t1`): the batch goes up once; stages 2 and 3a of the pairs and of the reads filed singly, the
+// merge of their frag_raw records in stream order, ConClave, the fragments in record order, the traceback and the pile-up all work
+// on what is in HBM (runKMA + save_kmers_pair + alnFragsPE + runConClave + assemble_KMA for one chunk of input) ---------------------
+int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *reads, int64_t n, const int64_t *src, const int32_t *rc,
+                          const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,
+                          const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows);      // fragout.hip
+
+namespace {
+
+int scan_i64(DevBlock &B, const int64_t *in, int64_t *out, size_t n, hipStream_t s) {
+	size_t tmp_bytes = 0;
+	if(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
+		kmahip_set_error("rocprim::exclusive_scan (size query) failed"); return KMAHIP_EDEVICE;
 	}
-	void size(int64_t n, int64_t cap) {
-		n_hits.assign((size_t) n + 1, 0); best.assign((size_t) n + 1, 0); flag.assign((size_t) n + 1, 0); rc.assign((size_t) n + 1, 0);
-		tmpl.assign((size_t) cap + 1, 0); score.assign((size_t) cap + 1, 0); start.assign((size_t) cap + 1, 0); end.assign((size_t) cap + 1, 0);
+	char *tmp = nullptr;
+	int rc = B.get(tmp_bytes, &tmp);
+	if(rc) return rc;
+	if(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
+		kmahip_set_error("rocprim::exclusive_scan failed"); return KMAHIP_EDEVICE;
 	}
+	return KMAHIP_OK;
+}
+
+// reads idx[0 .. m) of a batch in HBM as a batch of its own (each read followed by one pad word, like the source)
+__global__ __launch_bounds__(256) void gather_sizes_kernel(int64_t m, const int64_t *idx, const int32_t *len, const int64_t *N_off, int64_t *words, int64_t *n_N) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > m) return;
+	if(i == m) { words[i] = 0; n_N[i] = 0; return; }
+	const int64_t r = idx[i];
+	words[i] = ((len[r] + 31) >> 5) + 1;
+	n_N[i] = N_off[r + 1] - N_off[r];
+}
+
+__global__ __launch_bounds__(256) void gather_copy_kernel(int64_t m, const int64_t *idx, const uint64_t *seq, const int64_t *seq_off, const int32_t *len,
+                                                          const int32_t *N, const int64_t *N_off, uint64_t *o_seq, const int64_t *o_seq_off, int32_t *o_len,
+                                                          int32_t *o_N, const int64_t *o_N_off) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= m) return;
+	const int64_t r = idx[i];
+	const int L = len[r], w = (L + 31) >> 5;
+	const uint64_t *a = seq + seq_off[r];
+	uint64_t *b = o_seq + o_seq_off[i];
+	for(int x = 0; x < w; ++x) b[x] = a[x];
+	b[w] = 0;
+	o_len[i] = L;
+	const int32_t *na = N + N_off[r];
+	int32_t *nb = o_N + o_N_off[i];
+	const int nn = (int) (N_off[r + 1] - N_off[r]);
+	for(int x = 0; x < nn; ++x) nb[x] = na[x];
+}
+
+int gather_batch(DevBlock &B, const kmahip_reads &src, const int64_t *d_idx, int64_t m, kmahip_reads *dst, hipStream_t s) {
+	int64_t *wc, *nc, *so, *no;
+	int rc;
+	if((rc = B.get((size_t) m + 1, &wc)) || (rc = B.get((size_t) m + 1, &nc)) || (rc = B.get((size_t) m + 1, &so)) || (rc = B.get((size_t) m + 1, &no))) return rc;
+	hipLaunchKernelGGL(gather_sizes_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, d_idx, src.len, src.N_off, wc, nc);
+	if((rc = scan_i64(B, wc, so, (size_t) m + 1, s)) || (rc = scan_i64(B, nc, no, (size_t) m + 1, s))) return rc;
+	int64_t tw = 0, tn = 0;
+	HIP_TRY(hipMemcpyAsync(&tw, so + m, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&tn, no + m, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	uint64_t *seq;
+	int32_t *len, *N;
+	if((rc = B.get((size_t) tw + 2, &seq)) || (rc = B.get((size_t) m + 1, &len)) || (rc = B.get((size_t) tn + 1, &N))) return rc;
+	HIP_TRY(hipMemsetAsync(seq + tw, 0, 16, s));
+	HIP_TRY(hipMemsetAsync(len + m, 0, 4, s));
+	if(m) hipLaunchKernelGGL(gather_copy_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, d_idx, src.seq, src.seq_off, src.len, src.N, src.N_off,
+	                         seq, so, len, N, no);
+	HIP_TRY(hipGetLastError());
+	*dst = kmahip_reads{};
+	dst->n_reads = m; dst->seq = seq; dst->seq_off = so; dst->len = len; dst->N = N; dst->N_off = no;
+	dst->seq_words = tw; dst->N_total = tn; dst->max_len = src.max_len;
+	return KMAHIP_OK;
+}
+
+// The frag_raw records of the stream (update_Scores_pe / _se, updatescores.c:300-488), two slots per unit in stream order: a slot
+// left at n = 0, score = 0 is no record. A record's hit list lies at r_off of the joint hit arrays (pairs first, the singles'
+// lists from s_base on); its one or two fragments are reads of the uploaded batch.
+struct RecArgs {
+	int64_t n_units;
+	const int32_t *u_first, *u_idx;      // first read of the unit; >= 0: pair number, < 0: -(single number) - 1
+	const int32_t *p_len, *s_len;        // lengths in the pair batch (mates interleaved) / the single batch
+	const int32_t *mate, *p_n, *p_best, *p_rc, *kind;
+	const int64_t *R_off;
+	const int32_t *s_n, *s_best, *s_rc;
+	const int64_t *T_off;
+	int64_t s_base;
+	int32_t *r_n, *r_score, *r_ql, *r_ql2;
+	int64_t *r_off;
+	int32_t *fr_read, *fr_rc;            // 2 per slot (-1: none)
 };
+
+__global__ __launch_bounds__(256) void pe_records_kernel(const RecArgs A) {
+	const int64_t u = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(u >= A.n_units) return;
+	const int64_t s0 = 2 * u;
+	for(int x = 0; x < 2; ++x) {
+		A.r_n[s0 + x] = 0; A.r_score[s0 + x] = 0; A.r_ql[s0 + x] = 0; A.r_ql2[s0 + x] = 0; A.r_off[s0 + x] = 0;
+		A.fr_read[2 * (s0 + x)] = -1; A.fr_read[2 * (s0 + x) + 1] = -1; A.fr_rc[2 * (s0 + x)] = 0; A.fr_rc[2 * (s0 + x) + 1] = 0;
+	}
+	auto rec = [&](int64_t slot, int n, int score, int ql, int ql2, int64_t off) {
+		A.r_n[slot] = n; A.r_score[slot] = score; A.r_ql[slot] = ql; A.r_ql2[slot] = ql2; A.r_off[slot] = off;
+	};
+	const int first = A.u_first[u];
+	if(A.u_idx[u] < 0) {
+		const int64_t j = -(int64_t) A.u_idx[u] - 1;
+		if(A.s_n[j] > 0) {
+			rec(s0, A.s_n[j], A.s_best[j], A.s_len[j], 0, A.s_base + A.T_off[j]);
+			A.fr_read[2 * s0] = first; A.fr_rc[2 * s0] = A.s_rc[j];
+		}
+		return;
+	}
+	const int64_t j = A.u_idx[u], r0 = 2 * j, r1 = 2 * j + 1;
+	auto ln = [&](int64_t x) { return A.p_len[2 * j + A.mate[x]]; };
+	auto frag = [&](int64_t slot, int at, int64_t x) { A.fr_read[2 * slot + at] = first + A.mate[x]; A.fr_rc[2 * slot + at] = A.p_rc[x] & 1; };
+	const int64_t o = A.R_off[r1];
+	const int kd = A.kind[j];
+	if(kd == 1) {
+		const bool swapped = (A.p_rc[r1] & 2) != 0;      // the second slot's fragment is written first (alnfrags.c:1807-1812)
+		rec(s0, A.p_n[r1], -A.p_best[r1], swapped ? ln(r1) : ln(r0), swapped ? ln(r0) : ln(r1), o);
+		frag(s0, 0, swapped ? r1 : r0); frag(s0, 1, swapped ? r0 : r1);
+	} else if(kd == 2) {
+		const int n0 = A.p_n[r0];
+		rec(s0, n0, A.p_best[r0], ln(r0), 0, o); frag(s0, 0, r0);
+		rec(s0 + 1, A.p_n[r1], A.p_best[r1], ln(r1), 0, o + n0); frag(s0 + 1, 0, r1);
+	} else if(kd == 3 || kd == 4) {
+		const int64_t x = kd == 3 ? r0 : r1;
+		rec(s0, A.p_n[x], A.p_best[x], ln(x), 0, o); frag(s0, 0, x);
+	} else {
+		for(int64_t x = r0; x <= r1; ++x) if(A.mate[x] >= 0 && A.p_n[x] > 0) { rec(s0 + (x - r0), A.p_n[x], A.p_best[x], ln(x), 0, A.R_off[x]); frag(s0 + (x - r0), 0, x); }
+	}
+}
+
+// fragments that ConClave filed (template != 0), per slot
+__global__ __launch_bounds__(256) void pe_frag_count_kernel(int64_t n_slots, const int32_t *c_tmpl, const int32_t *fr_read, int64_t *cnt, uint8_t *cnt8) {
+	const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(s > n_slots) return;
+	int c = 0;
+	if(s < n_slots && c_tmpl[s] != 0) c = (fr_read[2 * s] >= 0) + (fr_read[2 * s + 1] >= 0);
+	cnt[s] = c;
+	if(s < n_slots) cnt8[s] = (uint8_t) c;
+}
+
+// The filed fragments in record order. The first fragment of a record carries the sign of the template (conclave.c:131-146).
+// runConClave closes a chunk of filed fragments when, AFTER a whole record, maxFrag or more have gone in (conclave.c:164-196):
+// a couple that straddles the limit makes a chunk of maxFrag + 1. starts[c] = filed fragments before chunk c (counted record by
+// record on the host); a fragment is handed on as position c (maxFrag + 1) + index, with maxFrag + 1 as the chunk length the
+// pile-up and the writer divide by.
+__global__ __launch_bounds__(256) void pe_frag_fill_kernel(int64_t n_slots, const int32_t *c_tmpl, const int32_t *r_n, const int32_t *fr_read, const int32_t *fr_rc,
+                                                           const int64_t *f_off, const int64_t *starts, int n_starts, int64_t mf, int64_t *f_src, int32_t *f_rc,
+                                                           int32_t *f_t, int32_t *f_nh, int64_t *f_rank) {
+	const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(s >= n_slots) return;
+	const int tt = c_tmpl[s];
+	if(tt == 0) return;
+	int64_t g = f_off[s];
+	for(int x = 0; x < 2; ++x) {
+		if(fr_read[2 * s + x] < 0) continue;
+		int lo = 0, hi = n_starts;          // last chunk that starts at or before g
+		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(starts[mid] <= g) lo = mid; else hi = mid; }
+		f_src[g] = fr_read[2 * s + x]; f_rc[g] = fr_rc[2 * s + x]; f_t[g] = x == 0 ? tt : abs(tt); f_nh[g] = r_n[s];
+		f_rank[g] = (int64_t) lo * (mf + 1) + (g - starts[lo]);
+		++g;
+	}
+}
+
+// what a `.frag` row prints of a fragment's statistics: score, start, end, kept
+__global__ __launch_bounds__(256) void pe_stats4_kernel(int64_t n, const int32_t *stats, int32_t *out) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	for(int x = 0; x < 4; ++x) out[4 * i + x] = stats[10 * i + x];
+}
 
 }  // namespace
 
@@ -269,174 +432,242 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	}
 	const kmahip_reads &R = batch->reads;
 	const int64_t n = R.n_reads;
+	if(n < 0 || n > 0x7ffffff0ll || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("bad batch size"); return KMAHIP_EINVAL; }
+	if(frag_path && n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
 	const size_t D = db->info.DB_size;
 	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
 	out->n_rows = 0;
+	hipStream_t s = 0;
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 	auto t = std::chrono::steady_clock::now();
-	// units of the stream: a pair (two reads) or a single
-	HostBatch PB, SB;
-	std::vector<int64_t> unit_first;      // read index of each unit's first read
-	std::vector<int32_t> unit_idx;        // >= 0: pair number, < 0: -(single number) - 1
-	for(int64_t i = 0; i < n;) {
-		unit_first.push_back(i);
-		if(batch->pair[i] == 1 && i + 1 < n && batch->pair[i + 1] == 2) { unit_idx.push_back((int32_t) (PB.len.size() / 2)); PB.add(R, i); PB.add(R, i + 1); i += 2; }
-		else { unit_idx.push_back(-(int32_t) SB.len.size() - 1); SB.add(R, i); i += 1; }
-	}
-	const int64_t np = (int64_t) PB.len.size() / 2, ns = (int64_t) SB.len.size();
-	std::vector<uint64_t> AS(D, 0), US(D, 0);
+	auto stamp = [&](const char *what) { if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_pe: %s after %.2f ms\n", what, since(t2)); } };
 	int rc;
-	// stages 2 + 3a: pairs
-	kmahip_reads pr = PB.view(), sr = SB.view();
-	std::vector<int32_t> mate((size_t) 2 * np + 2), prc((size_t) 2 * np + 2), prcf((size_t) 2 * np + 2), pflag((size_t) 2 * np + 2), kind((size_t) np + 1, 0), pT;
-	std::vector<int64_t> R_off((size_t) 2 * np + 2, 0);
-	HitBuf ph, sh;
-	int64_t cap = 8 * np + 1024;
-	for(int tries = 0; np > 0; ++tries) {
-		pT.assign((size_t) cap + 1, 0);
-		ph.size(2 * np, cap);
-		std::fill(AS.begin(), AS.end(), 0); std::fill(US.begin(), US.end(), 0);
-		kmahip_pe_recs recs = { mate.data(), prc.data(), prcf.data(), pflag.data(), R_off.data(), pT.data(), cap };
-		kmahip_hits h = ph.view(AS.data(), US.data());
-		rc = kmahip_map_pe(db, ws, &pr, p, &recs, &h, kind.data());
-		if(rc == KMAHIP_OK) break;
-		if(rc != KMAHIP_EOVERFLOW || tries > 6) return rc;
-		cap = std::max<int64_t>(2 * cap, R_off[(size_t) 2 * np] + 16);
-	}
-	// ... and the single records (their scores add into the same two vectors)
-	std::vector<int32_t> srcf((size_t) ns + 1), sflag((size_t) ns + 1), sT;
-	std::vector<int64_t> sT_off((size_t) ns + 2, 0);
-	std::vector<uint64_t> AS2(D, 0), US2(D, 0);
-	cap = 8 * ns + 1024;
-	for(int tries = 0; ns > 0; ++tries) {
-		sT.assign((size_t) cap + 1, 0);
-		sh.size(ns, cap);
-		std::fill(AS2.begin(), AS2.end(), 0); std::fill(US2.begin(), US2.end(), 0);
-		kmahip_cands cd = { srcf.data(), sflag.data(), sT_off.data(), sT.data(), cap };
-		kmahip_hits h = sh.view(AS2.data(), US2.data());
-		rc = kmahip_map_se(db, ws, &sr, p, &cd, &h);
-		if(rc == KMAHIP_OK) break;
-		if(rc != KMAHIP_EOVERFLOW || tries > 6) return rc;
-		cap = std::max<int64_t>(2 * cap, sT_off[(size_t) ns] + 16);
-	}
-	for(size_t i = 0; i < D; ++i) { AS[i] += AS2[i]; US[i] += US2[i]; }
-	out->ms[1] = since(t);
 
-	// frag_raw records in stream order (update_Scores_pe / _se, updatescores.c:300-488)
-	struct Frag { int64_t read; int32_t flag, rc; };
-	std::vector<int32_t> r_n, r_score, r_ql, r_ql2, f_tmpl, f_start, f_end;
-	std::vector<int64_t> r_off{0};
-	std::vector<std::vector<Frag>> frags;
-	auto add = [&](int nh, int score, int ql, int ql2, const HitBuf &src, int64_t o, std::vector<Frag> fr) {
-		r_n.push_back(nh); r_score.push_back(score); r_ql.push_back(ql); r_ql2.push_back(ql2);
-		for(int x = 0; x < nh; ++x) { f_tmpl.push_back(src.tmpl[(size_t) (o + x)]); f_start.push_back(src.start[(size_t) (o + x)]); f_end.push_back(src.end[(size_t) (o + x)]); }
-		r_off.push_back((int64_t) f_tmpl.size());
-		frags.push_back(std::move(fr));
-	};
-	for(size_t u = 0; u < unit_idx.size(); ++u) {
-		if(unit_idx[u] < 0) {
-			const int64_t j = -(int64_t) unit_idx[u] - 1;
-			if(sh.n_hits[(size_t) j] > 0) add(sh.n_hits[(size_t) j], sh.best[(size_t) j], SB.len[(size_t) j], 0, sh, sT_off[(size_t) j], {Frag{unit_first[u], sh.flag[(size_t) j], sh.rc[(size_t) j]}});
+	// units of the stream: a pair (two reads) or a single
+	std::unique_ptr<int32_t[]> u_first(new int32_t[(size_t) n + 1]), u_idx(new int32_t[(size_t) n + 1]);
+	int64_t U = 0, np = 0, ns = 0;
+	for(int64_t i = 0; i < n; ++U) {
+		u_first[(size_t) U] = (int32_t) i;
+		if(batch->pair[i] == 1 && i + 1 < n && batch->pair[i + 1] == 2) { u_idx[(size_t) U] = (int32_t) np++; i += 2; }
+		else { u_idx[(size_t) U] = -(int32_t) (ns++) - 1; i += 1; }
+	}
+	const int64_t n_slots = 2 * U;
+
+	// the batch, once
+	DevBlock B;
+	B.expect((size_t) R.seq_words * 16 + (size_t) R.N_total * 8 + (size_t) n * 420 + (64u << 20));
+	kmahip_reads dR = R;
+	dR.q_start = nullptr; dR.q_end = nullptr;
+	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &dR.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
+	   (rc = B.up(R.len, (size_t) n, 1, &dR.len)) || (rc = B.up(R.N, (size_t) R.N_total, 1, &dR.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
+	const int32_t *d_first = nullptr, *d_uidx = nullptr;
+	if((rc = B.up(u_first.get(), (size_t) U, 1, &d_first)) || (rc = B.up(u_idx.get(), (size_t) U, 1, &d_uidx))) return rc;
+	kmahip_reads dP = dR, dS = dR;
+	dS.n_reads = 0;
+	if(ns > 0) {          // pairs and singles as batches of their own (all pairs: the batch as it is)
+		std::vector<int64_t> p_idx, s_idx;
+		p_idx.reserve((size_t) 2 * np); s_idx.reserve((size_t) ns);
+		for(int64_t u = 0; u < U; ++u) {
+			if(u_idx[(size_t) u] < 0) s_idx.push_back(u_first[(size_t) u]);
+			else { p_idx.push_back(u_first[(size_t) u]); p_idx.push_back(u_first[(size_t) u] + 1); }
+		}
+		const int64_t *d_pi = nullptr, *d_si = nullptr;
+		if((rc = B.up(p_idx.data(), (size_t) 2 * np, 1, &d_pi)) || (rc = B.up(s_idx.data(), (size_t) ns, 1, &d_si))) return rc;
+		if((rc = gather_batch(B, dR, d_pi, 2 * np, &dP, s)) || (rc = gather_batch(B, dR, d_si, ns, &dS, s))) return rc;
+	}
+	HIP_TRY(hipStreamSynchronize(s));
+	out->ms[0] = since(t);
+
+	// stage 2: pairs, then the singles
+	kmahip_pe_recs recs;
+	if((rc = B.get((size_t) 2 * np + 2, &recs.mate)) || (rc = B.get((size_t) 2 * np + 2, &recs.rc)) || (rc = B.get((size_t) 2 * np + 2, &recs.rc_flag)) ||
+	   (rc = B.get((size_t) 2 * np + 2, &recs.flag)) || (rc = B.get((size_t) 2 * np + 2, &recs.R_off, true))) return rc;
+	int64_t totP = 0, totS = 0;
+	recs.T_cap = 4 * np + 4096; recs.T = nullptr;
+	for(int attempt = 0; np > 0; ++attempt) {
+		if((rc = B.get((size_t) recs.T_cap, &recs.T))) return rc;
+		if((rc = kmahip_launch_scan_pe(db, ws, &dP, p, &recs, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 1) {
+			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;
 			continue;
 		}
-		const int64_t j = unit_idx[u], r0 = 2 * j, r1 = 2 * j + 1;
-		auto ln = [&](int64_t x) { return PB.len[(size_t) (2 * j + mate[(size_t) x])]; };
-		auto fg = [&](int64_t x) { return Frag{unit_first[u] + mate[(size_t) x], ph.flag[(size_t) x], ph.rc[(size_t) x] & 1}; };
-		const int64_t o = R_off[(size_t) r1];
-		const int kd = kind[(size_t) j];
-		if(kd == 1) {
-			const bool swapped = (ph.rc[(size_t) r1] & 2) != 0;       // the second slot's fragment is written first (alnfrags.c:1807-1812)
-			add(ph.n_hits[(size_t) r1], -ph.best[(size_t) r1], swapped ? ln(r1) : ln(r0), swapped ? ln(r0) : ln(r1), ph, o,
-			    swapped ? std::vector<Frag>{fg(r1), fg(r0)} : std::vector<Frag>{fg(r0), fg(r1)});
-		} else if(kd == 2) {
-			const int n0 = ph.n_hits[(size_t) r0], n1 = ph.n_hits[(size_t) r1];
-			add(n0, ph.best[(size_t) r0], ln(r0), 0, ph, o, {fg(r0)});
-			add(n1, ph.best[(size_t) r1], ln(r1), 0, ph, o + n0, {fg(r1)});
-		} else if(kd == 3 || kd == 4) {
-			const int64_t x = kd == 3 ? r0 : r1;
-			add(ph.n_hits[(size_t) x], ph.best[(size_t) x], ln(x), 0, ph, o, {fg(x)});
-		} else {
-			for(int64_t x : {r0, r1}) if(mate[(size_t) x] >= 0 && ph.n_hits[(size_t) x] > 0) add(ph.n_hits[(size_t) x], ph.best[(size_t) x], ln(x), 0, ph, R_off[(size_t) x], {fg(x)});
+		HIP_TRY(hipMemcpy(&totP, recs.R_off + 2 * np, sizeof totP, hipMemcpyDeviceToHost));
+		if(totP <= recs.T_cap) break;
+		if(attempt >= 6) { kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
+		recs.T_cap = totP + 1024;
+	}
+	stamp("stage 2 of the pairs");
+	kmahip_cands cd;
+	if((rc = B.get((size_t) ns + 1, &cd.rc_flag)) || (rc = B.get((size_t) ns + 1, &cd.flag)) || (rc = B.get((size_t) ns + 1, &cd.T_off, true))) return rc;
+	cd.T_cap = 2 * ns + 4096; cd.T = nullptr;
+	for(int attempt = 0; ns > 0; ++attempt) {
+		if((rc = B.get((size_t) cd.T_cap, &cd.T))) return rc;
+		if((rc = kmahip_launch_scan_se(db, ws, &dS, p, &cd, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 1) {
+			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;
+			continue;
 		}
+		HIP_TRY(hipMemcpy(&totS, cd.T_off + ns, sizeof totS, hipMemcpyDeviceToHost));
+		if(totS <= cd.T_cap) break;
+		if(attempt >= 6) { kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
+		cd.T_cap = totS + 1024;
 	}
-	const int64_t nrec = (int64_t) r_n.size();
-	// stage 3b over the records + the `.res` statistics
-	std::vector<int32_t> c_tmpl((size_t) nrec + 1, 0), c_start((size_t) nrec + 1, 0), c_end((size_t) nrec + 1, 0);
-	std::vector<uint64_t> w(D, 0);
-	if(nrec) {
-		if(f_tmpl.empty()) { f_tmpl.push_back(0); f_start.push_back(0); f_end.push_back(0); }
-		kmahip_hits h;
-		memset(&h, 0, sizeof h);
-		h.n_hits = r_n.data(); h.best_score = r_score.data(); h.tmpl = f_tmpl.data(); h.start = f_start.data(); h.end = f_end.data();
-		h.alignment_scores = AS.data(); h.uniq_alignment_scores = US.data();
-		kmahip_conclave cc = { c_tmpl.data(), c_start.data(), c_end.data(), w.data(), nullptr, nullptr, nullptr };
-		if((rc = kmahip_conclave_records(db, ws, nrec, r_ql.data(), r_ql2.data(), r_off.data(), &h, &cc))) return rc;
+
+	// stage 3a: one set of hit arrays (the pairs' lists first), one pair of ConClave vectors
+	const size_t H = (size_t) totP + (size_t) totS + 2;
+	const int64_t s_base = totP + 1;
+	kmahip_hits ph, sh;
+	int32_t *kind, *H_tmpl, *H_score, *H_start, *H_end;
+	uint64_t *AS, *US;
+	if((rc = B.get((size_t) 2 * np + 2, &ph.n_hits, true)) || (rc = B.get((size_t) 2 * np + 2, &ph.best_score, true)) || (rc = B.get((size_t) 2 * np + 2, &ph.flag, true)) ||
+	   (rc = B.get((size_t) 2 * np + 2, &ph.rc, true)) || (rc = B.get((size_t) np + 1, &kind, true)) ||
+	   (rc = B.get((size_t) ns + 1, &sh.n_hits, true)) || (rc = B.get((size_t) ns + 1, &sh.best_score, true)) || (rc = B.get((size_t) ns + 1, &sh.flag, true)) ||
+	   (rc = B.get((size_t) ns + 1, &sh.rc, true)) ||
+	   (rc = B.get(H, &H_tmpl, true)) || (rc = B.get(H, &H_score, true)) || (rc = B.get(H, &H_start, true)) || (rc = B.get(H, &H_end, true)) ||
+	   (rc = B.get(D, &AS, true)) || (rc = B.get(D, &US, true))) return rc;
+	ph.tmpl = H_tmpl; ph.score = H_score; ph.start = H_start; ph.end = H_end; ph.alignment_scores = AS; ph.uniq_alignment_scores = US;
+	sh.tmpl = H_tmpl + s_base; sh.score = H_score + s_base; sh.start = H_start + s_base; sh.end = H_end + s_base; sh.alignment_scores = AS; sh.uniq_alignment_scores = US;
+	if(np > 0) {
+		if((rc = kmahip_launch_align_pe(db, ws, &dP, &recs, p, &ph, kind, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
 	}
+	stamp("stage 3a of the pairs");
+	if(ns > 0) {
+		if((rc = kmahip_launch_align_se(db, ws, &dS, &cd, p, &sh, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	}
+	out->ms[1] = since(t);
+
+	// the records in stream order, stage 3b over them, the `.res` statistics
+	RecArgs A{};
+	A.n_units = U; A.u_first = d_first; A.u_idx = d_uidx; A.p_len = dP.len; A.s_len = dS.len;
+	A.mate = recs.mate; A.p_n = ph.n_hits; A.p_best = ph.best_score; A.p_rc = ph.rc; A.kind = kind; A.R_off = recs.R_off;
+	A.s_n = sh.n_hits; A.s_best = sh.best_score; A.s_rc = sh.rc; A.T_off = cd.T_off; A.s_base = s_base;
+	if((rc = B.get((size_t) n_slots + 1, &A.r_n)) || (rc = B.get((size_t) n_slots + 1, &A.r_score)) || (rc = B.get((size_t) n_slots + 1, &A.r_ql)) ||
+	   (rc = B.get((size_t) n_slots + 1, &A.r_ql2)) || (rc = B.get((size_t) n_slots + 1, &A.r_off)) || (rc = B.get((size_t) 2 * n_slots + 2, &A.fr_read)) ||
+	   (rc = B.get((size_t) 2 * n_slots + 2, &A.fr_rc))) return rc;
+	kmahip_conclave cc;
+	if((rc = B.get((size_t) n_slots + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n_slots + 1, &cc.start, true)) || (rc = B.get((size_t) n_slots + 1, &cc.end, true)) ||
+	   (rc = B.get(D, &cc.w_scores, true))) return rc;
+	cc.fragment_counts = nullptr; cc.read_counts = nullptr; cc.depth = nullptr;
+	if(U > 0) {
+		hipLaunchKernelGGL(pe_records_kernel, dim3((unsigned) ((U + 255) / 256)), dim3(256), 0, s, A);
+		HIP_TRY(hipGetLastError());
+		kmahip_hits h{};
+		h.n_hits = A.r_n; h.best_score = A.r_score; h.tmpl = H_tmpl; h.start = H_start; h.end = H_end; h.alignment_scores = AS; h.uniq_alignment_scores = US;
+		if((rc = kmahip_conclave_records_dev(db, ws, n_slots, A.r_ql, A.r_ql2, A.r_off, &h, &cc, s))) return rc;
+	}
+	std::vector<uint64_t> w(D);
+	HIP_TRY(hipMemcpy(w.data(), cc.w_scores, D * 8, hipMemcpyDeviceToHost));
 	if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
 	std::vector<uint8_t> ok(D + 8, 0);
 	for(int64_t r = 0; r < out->n_rows; ++r) ok[(size_t) out->rows[r].template_id] = (uint8_t) out->rows[r].significant;
+	const uint8_t *d_ok = nullptr;
+	if((rc = B.up(ok.data(), D + 8, 0, &d_ok))) return rc;
 	out->ms[2] = since(t);
 
-	// the fragments in record order; the first fragment of a record carries the sign of the template (conclave.c:131-146)
-	// runConClave closes a chunk of filed fragments when, AFTER a whole record, maxFrag or more have gone in (conclave.c:164-196):
-	// a couple that straddles the limit makes a chunk of maxFrag + 1. The chunks are counted here record by record and handed
-	// on as positions c (maxFrag + 1) + index, with maxFrag + 1 as the chunk length the pile-up and the writer divide by.
-	HostBatch FB;
-	std::vector<int32_t> f_rc, f_t, f_nh;
-	std::vector<int64_t> f_rank;
+	// the filed fragments in record order as a batch of their own
 	const int64_t mf = max_frag > 0 ? max_frag : 1000000;
-	int64_t chunk = 0, in_chunk = 0;
-	for(int64_t k = 0; k < nrec; ++k) {
-		const int tt = c_tmpl[(size_t) k];
-		for(size_t x = 0; x < frags[(size_t) k].size(); ++x) {
-			FB.add(R, frags[(size_t) k][x].read);
-			f_rc.push_back(frags[(size_t) k][x].rc);
-			f_t.push_back(x == 0 ? tt : abs(tt));
-			f_nh.push_back(r_n[(size_t) k]);
-			f_rank.push_back(tt ? chunk * (mf + 1) + in_chunk + (int64_t) x : 0);
-		}
-		if(tt) {
-			in_chunk += (int64_t) frags[(size_t) k].size();
-			if(in_chunk >= mf) { ++chunk; in_chunk = 0; }
+	int64_t *f_cnt, *f_off;
+	uint8_t *d_cnt8;
+	if((rc = B.get((size_t) n_slots + 1, &f_cnt)) || (rc = B.get((size_t) n_slots + 1, &f_off)) || (rc = B.get((size_t) n_slots + 1, &d_cnt8))) return rc;
+	hipLaunchKernelGGL(pe_frag_count_kernel, dim3((unsigned) ((n_slots + 256) / 256)), dim3(256), 0, s, n_slots, cc.tmpl, A.fr_read, f_cnt, d_cnt8);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, f_cnt, f_off, (size_t) n_slots + 1, s))) return rc;
+	int64_t nf = 0;
+	std::vector<uint8_t> cnt8((size_t) n_slots + 1);
+	HIP_TRY(hipMemcpyAsync(&nf, f_off + n_slots, 8, hipMemcpyDeviceToHost, s));
+	if(n_slots) HIP_TRY(hipMemcpyAsync(cnt8.data(), d_cnt8, (size_t) n_slots, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	std::vector<int64_t> starts{0};
+	{
+		int64_t filed = 0, in_chunk = 0;
+		for(int64_t k = 0; k < n_slots;) {
+			if(k + 8 <= n_slots) {          // eight slots at once while no chunk can close among them (a slot counts 2 at most)
+				uint64_t v;
+				memcpy(&v, &cnt8[(size_t) k], 8);
+				const int64_t sum = (int64_t) ((v * 0x0101010101010101ull) >> 56);
+				if(in_chunk + sum < mf) { filed += sum; in_chunk += sum; k += 8; continue; }
+			}
+			const int c = cnt8[(size_t) k++];
+			if(!c) continue;
+			filed += c; in_chunk += c;
+			if(in_chunk >= mf) { starts.push_back(filed); in_chunk = 0; }
 		}
 	}
-	const int64_t nf = (int64_t) FB.len.size();
-	kmahip_reads fr = FB.view();
-	std::vector<int32_t> stats((size_t) nf * 10 + 10, 0), n_ops((size_t) nf + 1, 0);
-	std::vector<int64_t> ops_off((size_t) nf + 1, 0);
-	std::vector<uint32_t> ops;
-	int64_t ops_cap = 8 * nf + 1024, need = 0;
+	stamp("fragment count + chunks");
+	const int64_t *d_starts = nullptr;
+	if((rc = B.up(starts.data(), starts.size(), 1, &d_starts))) return rc;
+	int64_t *f_src, *f_rank;
+	int32_t *f_rc, *f_t, *f_nh;
+	if((rc = B.get((size_t) nf + 1, &f_src)) || (rc = B.get((size_t) nf + 1, &f_rank)) || (rc = B.get((size_t) nf + 1, &f_rc)) || (rc = B.get((size_t) nf + 1, &f_t)) ||
+	   (rc = B.get((size_t) nf + 1, &f_nh))) return rc;
+	kmahip_reads dF{};
 	kmahip_traces tr;
 	memset(&tr, 0, sizeof tr);
-	for(int tries = 0; nf > 0; ++tries) {
-		ops.assign((size_t) ops_cap + 1, 0);
-		tr.stats = stats.data(); tr.ops_off = ops_off.data(); tr.n_ops = n_ops.data(); tr.ops = ops.data(); tr.ops_cap = ops_cap;
-		rc = kmahip_align_trace(db, ws, &fr, f_rc.data(), f_t.data(), ok.data(), p, &tr, &need);
-		if(rc == KMAHIP_OK) break;
-		if(rc != KMAHIP_EOVERFLOW || tries > 3) return rc;
-		ops_cap = need + 16;
+	if(nf > 0) {
+		hipLaunchKernelGGL(pe_frag_fill_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, s, n_slots, cc.tmpl, A.r_n, A.fr_read, A.fr_rc, f_off, d_starts,
+		                   (int) starts.size(), mf, f_src, f_rc, f_t, f_nh, f_rank);
+		HIP_TRY(hipGetLastError());
+		if((rc = gather_batch(B, dR, f_src, nf, &dF, s))) return rc;
+		stamp("fragment batch");
+		// stage 3c per fragment; the run pool is sized for a handful of runs per read and grown on demand
+		if((rc = B.get((size_t) 10 * nf + 10, &tr.stats)) || (rc = B.get((size_t) nf + 1, &tr.ops_off)) || (rc = B.get((size_t) nf + 1, &tr.n_ops))) return rc;
+		tr.ops_cap = 6 * nf + (1 << 20);
+		for(int attempt = 0;; ++attempt) {
+			if((rc = B.get((size_t) tr.ops_cap, &tr.ops))) return rc;
+			if((rc = kmahip_launch_trace(db, ws, &dF, f_rc, f_t, d_ok, p, &tr, s))) return rc;
+			HIP_TRY(hipStreamSynchronize(s));
+			unsigned long long used = 0;
+			const int st = ws_status(ws, &used);
+			if(st == 2 || (int64_t) used > tr.ops_cap) {
+				if(attempt >= 2) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+				tr.ops_cap = (int64_t) used + (1 << 20);
+				continue;
+			}
+			if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
+			break;
+		}
 	}
 	out->ms[3] = since(t);
+
+	// stage 3c per template
 	if(nf > 0) {
-		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, 0, 0, f_rank.data()};
-		if((rc = kmahip_assemble2(db, ws, &fr, f_rc.data(), f_t.data(), &tr, &ao, &out->assembly))) return rc;
+		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, 0, 0, f_rank};
+		if((rc = kmahip_assemble2_dev(db, ws, &dF, f_rc, f_t, &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);
+
+	// `.frag`: the per-fragment columns come back; the reads and their headers are the host batch's, through the fragments' read numbers
 	if(frag_path && nf > 0) {
-		if(!batch->names || !batch->name_off) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
-		// names of the fragments, in fragment order
-		std::vector<char> names;
-		std::vector<int64_t> noff{0};
-		for(int64_t i = 0; i < nf; ++i) {
-			const char *nm = batch->names + batch->name_off[FB.src[(size_t) i]];
-			names.insert(names.end(), nm, nm + strlen(nm) + 1);
-			noff.push_back((int64_t) names.size());
-		}
+		// (buffers nobody has touched: a vector would write every page once before the copy does)
+		int32_t *stats4 = nullptr;
+		if((rc = B.get((size_t) nf * 4 + 4, &stats4))) return rc;
+		hipLaunchKernelGGL(pe_stats4_kernel, dim3((unsigned) ((nf + 255) / 256)), dim3(256), 0, s, nf, tr.stats, stats4);
+		HIP_TRY(hipGetLastError());
+		std::unique_ptr<int64_t[]> h_src(new int64_t[(size_t) nf]), h_rank(new int64_t[(size_t) nf]);
+		std::unique_ptr<int32_t[]> h_rc(new int32_t[(size_t) nf]), h_t(new int32_t[(size_t) nf]), h_nh(new int32_t[(size_t) nf]), h_stats(new int32_t[(size_t) nf * 4]);
+		HIP_TRY(hipMemcpy(h_src.get(), f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_rank.get(), f_rank, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_rc.get(), f_rc, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_t.get(), f_t, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_nh.get(), f_nh, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_stats.get(), stats4, (size_t) nf * 16, hipMemcpyDeviceToHost));
+		stamp("fragment columns back");
 		int64_t rows = 0;
-		if((rc = kmahip_frag_write3(frag_path, db, &fr, f_rc.data(), f_t.data(), f_nh.data(), stats.data(), mf + 1, 0, f_rank.data(), names.data(), noff.data(), &rows))) return rc;
+		if((rc = kmahip_frag_write_src(frag_path, db, &R, nf, h_src.get(), h_rc.get(), h_t.get(), h_nh.get(), h_stats.get(), 4, mf + 1, 0, h_rank.get(),
+		                               batch->names, batch->name_off, &rows))) return rc;
 	}
 	out->ms[5] = since(t);
 	return KMAHIP_OK;
 }
+
 
 // ---- the default mode (no -1t1): kmahip_scan_chain, then every record through the stages of kmahip_run_se --------------------------
 extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
