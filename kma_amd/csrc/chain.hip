@@ -632,15 +632,16 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainArgs A) {
 
 }  // namespace
 
-// ---- C-ABI ------------------------------------------------------------------------------------------------------------------
-extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
-                                 const kmahip_chain_params *cp, kmahip_chain_recs *out) {
-	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	const int64_t n = reads->n_reads;
-	out->n_recs = 0; out->n_T = 0;
+// ---- the launch, everything in HBM: `d` holds DEVICE pointers; rec (8 ints per record: read lo, read hi, ordinal within the read,
+// rc_flag, emit_rc, q_start, q_end, number of templates), rec_T (first template of the record in T) and T are device buffers of
+// rec_cap / T_cap entries, filled in no particular order. n_recs / n_T: what the batch needs (KMAHIP_EOVERFLOW when that is more). -----
+int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec, int64_t *rec_T,
+                        int32_t *T, int64_t rec_cap, int64_t T_cap, int64_t *n_recs, int64_t *n_T) {
+	const int64_t n = d->n_reads;
+	*n_recs = 0; *n_T = 0;
 	if(n <= 0) return KMAHIP_OK;
 	if(!db->dev.tlen) { kmahip_set_error("index has no .length.b: the default template finder needs the template lengths"); return KMAHIP_EINVAL; }
-	const int max_len = reads->max_len;
+	const int max_len = d->max_len;
 	if(max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set"); return KMAHIP_EINVAL; }
 	const int64_t D = db->info.DB_size;
 	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
@@ -653,6 +654,7 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	};
 	ChainArgs A;
 	A.db = db->dev; A.n_reads = n;
+	A.seq = d->seq; A.seq_off = d->seq_off; A.len = d->len; A.N = d->N; A.N_off = d->N_off;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	A.stop_after = getenv("KMAHIP_CHAIN_STOP") ? atoi(getenv("KMAHIP_CHAIN_STOP")) : 0;
 	A.exhaustive = p->exhaustive; A.minlen = cp ? cp->minlen : 16; A.coverT = cp ? cp->coverT : 0.1; A.mrs = cp ? cp->mrs : 0.5;
@@ -665,7 +667,44 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	while(lanes > 64 && lanes * A.lane_bytes > (16ll << 30)) lanes >>= 1;
 	lanes = std::min<int64_t>(lanes, ((n + 63) / 64) * 64);
 	A.lanes = lanes;
-	// device buffers: staged reads, scratch, outputs
+	void *scratch = nullptr, *counters = nullptr;
+	struct Free { void *&a, *&b; ~Free() { if(a) (void) hipFree(a); if(b) (void) hipFree(b); } } guard{scratch, counters};
+	if(hipMalloc(&scratch, (size_t) (lanes * A.lane_bytes)) != hipSuccess) { scratch = nullptr; kmahip_set_error("hipMalloc of %lld bytes failed", (long long) (lanes * A.lane_bytes)); return KMAHIP_ENOMEM; }
+	if(hipMalloc(&counters, KMAHIP_N_COUNTERS * 8) != hipSuccess) { counters = nullptr; kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM; }
+	HIP_TRY(hipMemsetAsync(scratch, 0, (size_t) (lanes * A.lane_bytes), 0));
+	HIP_TRY(hipMemsetAsync(counters, 0, KMAHIP_N_COUNTERS * 8, 0));
+	A.scratch = (uint8_t *) scratch; A.counters = (unsigned long long *) counters;
+	A.rec = rec; A.rec_T = rec_T; A.T = T; A.rec_cap = rec_cap; A.T_cap = T_cap;
+	if(dbg) { HIP_TRY(hipDeviceSynchronize()); stamp("scratch allocated and cleared"); }
+	hipLaunchKernelGGL(chain_kernel, dim3((unsigned) (lanes / 64)), dim3(64), 0, 0, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	stamp("chain_kernel");
+	unsigned long long c[3] = {0, 0, 0};
+	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
+	*n_recs = (int64_t) c[0]; *n_T = (int64_t) c[2];
+	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (value lists of more than %d templates, or more than %d chains in a read)", A.b_cap / 2, A.s_cap / 2); return KMAHIP_EOVERFLOW; }
+	if(c[1] == 2 || (int64_t) c[0] > rec_cap || (int64_t) c[2] > T_cap) { kmahip_set_error("record capacity: %llu records with %llu templates", c[0], c[2]); return KMAHIP_EOVERFLOW; }
+	return KMAHIP_OK;
+}
+
+// ---- C-ABI ------------------------------------------------------------------------------------------------------------------
+extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
+                                 const kmahip_chain_params *cp, kmahip_chain_recs *out) {
+	if(!db || !ws || !reads || !p || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	out->n_recs = 0; out->n_T = 0;
+	if(n <= 0) return KMAHIP_OK;
+	if(reads->max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set"); return KMAHIP_EINVAL; }
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto stamp = [&](const char *what) {
+		if(!dbg) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[kmahip] scan_chain: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
+	// device buffers: staged reads, outputs
 	std::vector<void *> owned;
 	struct Free { std::vector<void *> &v; ~Free() { for(void *q : v) (void) hipFree(q); } } guard{owned};
 	auto dev = [&](size_t bytes, void **d, const void *src, bool zero) -> int {
@@ -676,31 +715,26 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 		return KMAHIP_OK;
 	};
 	int rc;
+	kmahip_reads d = *reads;
+	d.q_start = nullptr; d.q_end = nullptr;
 	{
 		std::vector<uint64_t> seq((size_t) reads->seq_words + 2, 0);
 		if(reads->seq_words) memcpy(seq.data(), reads->seq, (size_t) reads->seq_words * 8);
-		if((rc = dev(seq.size() * 8, (void **) &A.seq, seq.data(), false))) return rc;
+		if((rc = dev(seq.size() * 8, (void **) &d.seq, seq.data(), false))) return rc;
 	}
-	if((rc = dev((size_t) (n + 1) * 8, (void **) &A.seq_off, reads->seq_off, false)) || (rc = dev((size_t) n * 4, (void **) &A.len, reads->len, false)) ||
-	   (rc = dev((size_t) std::max<int64_t>(reads->N_total, 1) * 4, (void **) &A.N, reads->N_total ? reads->N : nullptr, !reads->N_total)) ||
-	   (rc = dev((size_t) (n + 1) * 8, (void **) &A.N_off, reads->N_off, false)) ||
-	   (rc = dev((size_t) (lanes * A.lane_bytes), (void **) &A.scratch, nullptr, true)) ||
-	   (rc = dev(KMAHIP_N_COUNTERS * 8, (void **) &A.counters, nullptr, true))) return rc;
-	A.rec_cap = out->rec_cap; A.T_cap = out->T_cap;
-	if((rc = dev((size_t) std::max<int64_t>(A.rec_cap, 1) * 32, (void **) &A.rec, nullptr, false)) ||
-	   (rc = dev((size_t) std::max<int64_t>(A.rec_cap, 1) * 8, (void **) &A.rec_T, nullptr, false)) ||
-	   (rc = dev((size_t) std::max<int64_t>(A.T_cap, 1) * 4, (void **) &A.T, nullptr, false))) return rc;
-	HIP_TRY(hipDeviceSynchronize());
-	stamp("reads staged, scratch allocated and cleared");
-	hipLaunchKernelGGL(chain_kernel, dim3((unsigned) (lanes / 64)), dim3(64), 0, 0, A);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipDeviceSynchronize());
-	stamp("chain_kernel");
-	unsigned long long c[3] = {0, 0, 0};
-	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
-	out->n_recs = (int64_t) c[0]; out->n_T = (int64_t) c[2];
-	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (value lists of more than %d templates, or more than %d chains in a read)", A.b_cap / 2, A.s_cap / 2); return KMAHIP_EOVERFLOW; }
-	if(c[1] == 2 || (int64_t) c[0] > out->rec_cap || (int64_t) c[2] > out->T_cap) { kmahip_set_error("record capacity: %llu records with %llu templates", c[0], c[2]); return KMAHIP_EOVERFLOW; }
+	int32_t *d_rec, *d_T;
+	int64_t *d_rec_T;
+	if((rc = dev((size_t) (n + 1) * 8, (void **) &d.seq_off, reads->seq_off, false)) || (rc = dev((size_t) n * 4, (void **) &d.len, reads->len, false)) ||
+	   (rc = dev((size_t) std::max<int64_t>(reads->N_total, 1) * 4, (void **) &d.N, reads->N_total ? reads->N : nullptr, !reads->N_total)) ||
+	   (rc = dev((size_t) (n + 1) * 8, (void **) &d.N_off, reads->N_off, false)) ||
+	   (rc = dev((size_t) std::max<int64_t>(out->rec_cap, 1) * 32, (void **) &d_rec, nullptr, false)) ||
+	   (rc = dev((size_t) std::max<int64_t>(out->rec_cap, 1) * 8, (void **) &d_rec_T, nullptr, false)) ||
+	   (rc = dev((size_t) std::max<int64_t>(out->T_cap, 1) * 4, (void **) &d_T, nullptr, false))) return rc;
+	stamp("reads staged");
+	if((rc = kmahip_chain_device(db, &d, p, cp, d_rec, d_rec_T, d_T, out->rec_cap, out->T_cap, &out->n_recs, &out->n_T))) return rc;
+	unsigned long long c[3] = {(unsigned long long) out->n_recs, 0, (unsigned long long) out->n_T};
+	struct { int32_t *rec; int64_t *rec_T; int32_t *T; } A = {d_rec, d_rec_T, d_T};
+	t_last = std::chrono::steady_clock::now();
 	// back to the host, in stream order (reads ascending, a read's chains in the order they were taken)
 	const size_t m = (size_t) c[0];
 	std::vector<int32_t> rec(m * 8 + 8);

@@ -199,57 +199,6 @@ extern "C" int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *r
 	return run_after_stage2(db, ws, B, d, c, total, p, evalue, bcd, max_frag, out, pr, t);
 }
 
-// ---- paired run: host composition of the stage-wise calls (the record merge is the glue a host program would otherwise write) ----
-namespace {
-
-// a batch assembled on the host from reads of another batch
-struct HostBatch {
-	std::vector<uint64_t> seq;
-	std::vector<int64_t> seq_off{0}, N_off{0};
-	std::vector<int32_t> len, N;
-	std::vector<int64_t> src;          // index of each read in the source batch
-	int max_len = 0;
-	void add(const kmahip_reads &r, int64_t i) {
-		const int L = r.len[i];
-		const int64_t w = (L + 31) >> 5;
-		seq.insert(seq.end(), r.seq + r.seq_off[i], r.seq + r.seq_off[i] + w);
-		seq.push_back(0);
-		seq_off.push_back((int64_t) seq.size());
-		N.insert(N.end(), r.N + r.N_off[i], r.N + r.N_off[i + 1]);
-		N_off.push_back((int64_t) N.size());
-		len.push_back(L); src.push_back(i);
-		max_len = std::max(max_len, L);
-	}
-	// the reverse complement of read i (rc_comp, compdna.c:228-256: the bits complemented, an N keeps its place from the other end)
-	void add_rc(const kmahip_reads &r, int64_t i) {
-		const int L = r.len[i];
-		const int64_t w = (L + 31) >> 5;
-		const uint64_t *src = r.seq + r.seq_off[i];
-		const size_t at = seq.size();
-		seq.resize(at + (size_t) w + 1, 0);
-		for(int p = 0; p < L; ++p) {
-			const int q = L - 1 - p;
-			const uint64_t b = 3 - ((src[q >> 5] >> (62 - ((q & 31) << 1))) & 3);
-			seq[at + (size_t) (p >> 5)] |= b << (62 - ((p & 31) << 1));
-		}
-		seq_off.push_back((int64_t) seq.size());
-		for(int64_t x = r.N_off[i + 1] - 1; x >= r.N_off[i]; --x) N.push_back(L - 1 - r.N[x]);
-		N_off.push_back((int64_t) N.size());
-		len.push_back(L); src_read(i);
-		max_len = std::max(max_len, L);
-	}
-	void src_read(int64_t i) { src.push_back(i); }
-	kmahip_reads view() {
-		if(N.empty()) N.push_back(0);
-		kmahip_reads v = {};
-		v.n_reads = (int64_t) len.size(); v.seq = seq.data(); v.seq_off = seq_off.data(); v.len = len.data(); v.N = N.data(); v.N_off = N_off.data();
-		v.seq_words = (int64_t) seq.size(); v.N_total = N_off.back(); v.max_len = max_len;
-		return v;
-	}
-};
-
-}  // namespace
-
 // ---- paired run (`-ipe r1 r2 -apm p -1t1`): the batch goes up once; stages 2 and 3a of the pairs and of the reads filed singly, the
 // merge of their frag_raw records in stream order, ConClave, the fragments in record order, the traceback and the pile-up all work
 // on what is in HBM (runKMA + save_kmers_pair + alnFragsPE + runConClave + assemble_KMA for one chunk of input) ---------------------
@@ -669,7 +618,82 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 }
 
 
-// ---- the default mode (no -1t1): kmahip_scan_chain, then every record through the stages of kmahip_run_se --------------------------
+// ---- the default mode (no -1t1): the chain finder's records, put in stream order and made a batch of their own on the device, then
+// every record through the stages of kmahip_run_se with its query bounds ------------------------------------------------------------
+int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec, int64_t *rec_T,
+                        int32_t *T, int64_t rec_cap, int64_t T_cap, int64_t *n_recs, int64_t *n_T);                            // chain.hip
+
+namespace {
+
+__device__ __forceinline__ int64_t crec_read(const int32_t *r) { return (int64_t) (uint32_t) r[0] | ((int64_t) r[1] << 32); }
+
+__global__ __launch_bounds__(256) void chain_count_kernel(int64_t m, const int32_t *rec, unsigned long long *cnt) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x < m) atomicAdd(&cnt[crec_read(rec + 8 * x)], 1ull);
+}
+
+// stream order: reads ascending, a read's chains by their ordinal (0, 1, ... per read)
+__global__ __launch_bounds__(256) void chain_place_kernel(int64_t m, const int32_t *rec, const int64_t *first, int64_t *o_read, int32_t *o_rcflag, int32_t *o_emit,
+                                                          int32_t *o_qs, int32_t *o_qe, int64_t *o_nT, int64_t *slot_of) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x > m) return;
+	if(x == m) { o_nT[m] = 0; return; }
+	const int32_t *r = rec + 8 * x;
+	const int64_t rd = crec_read(r), at = first[rd] + r[2];
+	o_read[at] = rd; o_rcflag[at] = r[3]; o_emit[at] = r[4]; o_qs[at] = r[5]; o_qe[at] = r[6]; o_nT[at] = r[7]; slot_of[at] = x;
+}
+
+__global__ __launch_bounds__(256) void chain_lists_kernel(int64_t m, const int64_t *slot_of, const int64_t *rec_T, const int32_t *T, const int64_t *T_off, int32_t *o_T) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x >= m) return;
+	const int32_t *src = T + rec_T[slot_of[x]];
+	int32_t *dst = o_T + T_off[x];
+	const int nT = (int) (T_off[x + 1] - T_off[x]);
+	for(int i = 0; i < nT; ++i) dst[i] = src[i];
+}
+
+// gather_copy_kernel where a record may print the reverse complement of its read (rc_comp, compdna.c:228-256: the bits complemented,
+// an N keeps its place from the other end)
+__global__ __launch_bounds__(256) void gather_copy_rc_kernel(int64_t m, const int64_t *idx, const int32_t *turn, const uint64_t *seq, const int64_t *seq_off,
+                                                             const int32_t *len, const int32_t *N, const int64_t *N_off, uint64_t *o_seq, const int64_t *o_seq_off,
+                                                             int32_t *o_len, int32_t *o_N, const int64_t *o_N_off) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= m) return;
+	const int64_t r = idx[i];
+	const int L = len[r], w = (L + 31) >> 5;
+	const uint64_t *a = seq + seq_off[r];
+	uint64_t *b = o_seq + o_seq_off[i];
+	const int32_t *na = N + N_off[r];
+	int32_t *nb = o_N + o_N_off[i];
+	const int nn = (int) (N_off[r + 1] - N_off[r]);
+	o_len[i] = L;
+	b[w] = 0;
+	if(!turn[i]) {
+		for(int x = 0; x < w; ++x) b[x] = a[x];
+		for(int x = 0; x < nn; ++x) nb[x] = na[x];
+		return;
+	}
+	// word x of the turned read = bases L-1-32x downwards; taken two source words at a time: the 64 bits that end at base q0 = L-1-32x,
+	// complemented, their 2-bit groups reversed
+	for(int x = 0; x < w; ++x) {
+		const int q0 = L - 1 - 32 * x;                 // last source base of this word (>= 0)
+		const int wi = q0 >> 5, sh = 2 * (31 - (q0 & 31));   // bits of word wi behind base q0
+		uint64_t v = a[wi] >> sh;                      // base q0 in the lowest two bits
+		if(sh && wi > 0) v |= a[wi - 1] << (64 - sh);
+		v = ~v;
+		// reverse the 2-bit groups
+		v = ((v >> 2) & 0x3333333333333333ull) | ((v & 0x3333333333333333ull) << 2);
+		v = ((v >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((v & 0x0F0F0F0F0F0F0F0Full) << 4);
+		v = __builtin_bswap64(v);
+		const int have = q0 + 1 < 32 ? q0 + 1 : 32;     // bases in this word
+		if(have < 32) v &= ~0ull << (2 * (32 - have));
+		b[x] = v;
+	}
+	for(int x = 0; x < nn; ++x) nb[x] = L - 1 - na[nn - 1 - x];
+}
+
+}  // namespace
+
 extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
                                 const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
                                 const char *frag_path, kmahip_run *out) {
@@ -680,104 +704,82 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	const size_t D = db->info.DB_size;
 	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
 	out->n_rows = 0;
+	hipStream_t s = 0;
 	auto t = std::chrono::steady_clock::now();
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_lap = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { if(dbg) fprintf(stderr, "[kmahip] run_chain: %s %.1f ms\n", what, since(t_lap)); };
 	int rc;
-	// stage 2: one record per accepted chain
-	std::vector<int64_t> r_read, r_Toff;
-	std::vector<int32_t> r_flag, r_emit, r_qs, r_qe, r_T;
-	kmahip_chain_recs R;
-	memset(&R, 0, sizeof R);
-	R.rec_cap = 2 * n + 1024; R.T_cap = 16 * n + 4096;
-	for(int attempt = 0;; ++attempt) {
-		r_read.assign((size_t) R.rec_cap, 0); r_Toff.assign((size_t) R.rec_cap + 1, 0);
-		r_flag.assign((size_t) R.rec_cap, 0); r_emit.assign((size_t) R.rec_cap, 0); r_qs.assign((size_t) R.rec_cap, 0); r_qe.assign((size_t) R.rec_cap, 0);
-		r_T.assign((size_t) R.T_cap, 0);
-		R.read = r_read.data(); R.rc_flag = r_flag.data(); R.emit_rc = r_emit.data(); R.q_start = r_qs.data(); R.q_end = r_qe.data();
-		R.T_off = r_Toff.data(); R.T = r_T.data();
-		rc = kmahip_scan_chain(db, ws, reads, p, cp, &R);
-		if(rc == KMAHIP_EOVERFLOW && attempt < 3 && (R.n_recs > R.rec_cap || R.n_T > R.T_cap)) {
-			R.rec_cap = std::max(R.rec_cap, R.n_recs + 16); R.T_cap = std::max(R.T_cap, R.n_T + 16);
+	// the batch, once
+	DevBlock B;
+	B.expect((size_t) reads->seq_words * 16 + (size_t) reads->N_total * 8 + (size_t) n * 480 + (64u << 20));
+	kmahip_reads dR = *reads;
+	dR.q_start = nullptr; dR.q_end = nullptr;
+	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &dR.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
+	   (rc = B.up(reads->len, (size_t) n, 1, &dR.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &dR.N)) ||
+	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	out->ms[0] = since(t);
+	lap("reads uploaded");
+	// stage 2: one record per accepted chain, in no particular order
+	int32_t *rec = nullptr, *T = nullptr;
+	int64_t *rec_T = nullptr;
+	int64_t rec_cap = 2 * n + 1024, T_cap = 16 * n + 4096, m = 0, n_T = 0;
+	for(int attempt = 0; n > 0; ++attempt) {
+		if((rc = B.get((size_t) rec_cap * 8, &rec)) || (rc = B.get((size_t) rec_cap, &rec_T)) || (rc = B.get((size_t) T_cap, &T))) return rc;
+		rc = kmahip_chain_device(db, &dR, p, cp, rec, rec_T, T, rec_cap, T_cap, &m, &n_T);
+		if(rc == KMAHIP_EOVERFLOW && attempt < 3 && (m > rec_cap || n_T > T_cap)) {
+			rec_cap = std::max(rec_cap, m + 16); T_cap = std::max(T_cap, n_T + 16);
 			continue;
 		}
 		if(rc) return rc;
 		break;
 	}
-	const int64_t m = R.n_recs;
-	out->ms[1] = since(t);
-	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
-	auto t_lap = std::chrono::steady_clock::now();
-	auto lap = [&](const char *what) { if(dbg) fprintf(stderr, "[kmahip] run_chain: %s %.1f ms\n", what, since(t_lap)); };
-	lap("stage 2 (kmahip_scan_chain)");
-	// the records as a batch of their own: the read, or its reverse complement where the record prints that, with its bounds
-	// (laid out by a prefix sum, filled by a few threads: two million records one vector push at a time took longer than stage 2)
-	std::vector<int64_t> rb_seq_off((size_t) m + 1, 0), rb_N_off((size_t) m + 1, 0);
-	std::vector<int32_t> rb_len((size_t) m + 1, 0);
-	int rb_max_len = 0;
-	for(int64_t x = 0; x < m; ++x) {
-		const int64_t r = r_read[(size_t) x];
-		const int L = reads->len[r];
-		rb_len[(size_t) x] = L;
-		rb_seq_off[(size_t) x + 1] = rb_seq_off[(size_t) x] + ((L + 31) >> 5) + 1;
-		rb_N_off[(size_t) x + 1] = rb_N_off[(size_t) x] + (reads->N_off[r + 1] - reads->N_off[r]);
-		rb_max_len = std::max(rb_max_len, L);
-	}
-	std::vector<uint64_t> rb_seq((size_t) rb_seq_off[(size_t) m] + 2, 0);
-	std::vector<int32_t> rb_N((size_t) rb_N_off[(size_t) m] + 1, 0);
-	{
-		const int hw = (int) std::thread::hardware_concurrency();
-		const int nt = (int) std::max<int64_t>(1, std::min<int64_t>(std::min(16, hw > 0 ? hw : 1), m / 4096));
-		auto fill = [&](int w) {
-			for(int64_t x = m * w / nt; x < m * (w + 1) / nt; ++x) {
-				const int64_t r = r_read[(size_t) x];
-				const int L = rb_len[(size_t) x];
-				const uint64_t *src = reads->seq + reads->seq_off[r];
-				uint64_t *dst = rb_seq.data() + rb_seq_off[(size_t) x];
-				int32_t *nd = rb_N.data() + rb_N_off[(size_t) x];
-				const int64_t n0 = reads->N_off[r], n1 = reads->N_off[r + 1];
-				if(!r_emit[(size_t) x]) {
-					memcpy(dst, src, (size_t) ((L + 31) >> 5) * 8);
-					for(int64_t y = n0; y < n1; ++y) nd[y - n0] = reads->N[y];
-				} else {
-					// rc_comp, compdna.c:228-256: the bits complemented, an N keeps its place from the other end
-					for(int p = 0; p < L; ++p) {
-						const int q = L - 1 - p;
-						const uint64_t b = 3 - ((src[q >> 5] >> (62 - ((q & 31) << 1))) & 3);
-						dst[p >> 5] |= b << (62 - ((p & 31) << 1));
-					}
-					for(int64_t y = n1 - 1; y >= n0; --y) nd[n1 - 1 - y] = L - 1 - reads->N[y];
-				}
-			}
-		};
-		std::vector<std::thread> pool;
-		for(int w = 1; w < nt; ++w) pool.emplace_back(fill, w);
-		fill(0);
-		for(std::thread &th : pool) th.join();
-	}
-	kmahip_reads rb = {};
-	rb.n_reads = m; rb.seq = rb_seq.data(); rb.seq_off = rb_seq_off.data(); rb.len = rb_len.data(); rb.N = rb_N.data(); rb.N_off = rb_N_off.data();
-	rb.seq_words = rb_seq_off[(size_t) m]; rb.N_total = rb_N_off[(size_t) m]; rb.max_len = rb_max_len;
-	lap("record batch built");
-	DevBlock B;
-	B.expect((size_t) rb.seq_words * 8 + (size_t) rb.N_total * 4 + (size_t) m * 300 + (64u << 20));
-	kmahip_reads d = rb;
-	std::vector<int32_t> zero((size_t) m + 1, 0);
-	kmahip_cands c;
-	const int32_t *d_rcflag = nullptr, *d_flag = nullptr, *d_T = nullptr;
-	const int64_t *d_Toff = nullptr;
-	const int64_t total = m ? r_Toff[(size_t) m] : 0;
-	if((rc = B.up(rb.seq, (size_t) rb.seq_words, 2, &d.seq)) || (rc = B.up(rb.seq_off, (size_t) m + 1, 0, &d.seq_off)) ||
-	   (rc = B.up(rb.len, (size_t) m, 1, &d.len)) || (rc = B.up(rb.N, (size_t) rb.N_total, 1, &d.N)) || (rc = B.up(rb.N_off, (size_t) m + 1, 0, &d.N_off)) ||
-	   (rc = B.up(r_qs.data(), (size_t) m, 1, &d.q_start)) || (rc = B.up(r_qe.data(), (size_t) m, 1, &d.q_end)) ||
-	   (rc = B.up(r_flag.data(), (size_t) m, 1, &d_rcflag)) || (rc = B.up(zero.data(), (size_t) m, 1, &d_flag)) ||
-	   (rc = B.up(r_Toff.data(), (size_t) m + 1, 0, &d_Toff)) || (rc = B.up(r_T.data(), (size_t) total, 1, &d_T))) return rc;
-	c.rc_flag = const_cast<int32_t *>(d_rcflag); c.flag = const_cast<int32_t *>(d_flag); c.T_off = const_cast<int64_t *>(d_Toff);
-	c.T = const_cast<int32_t *>(d_T); c.T_cap = total + 1;
-	HIP_TRY(hipStreamSynchronize(0));
-	out->ms[0] = since(t);
-	std::vector<int32_t> k_tmpl((size_t) m + 1, 0), k_nh((size_t) m + 1, 0), k_rc((size_t) m + 1, 0), k_stats((size_t) m * 10 + 10, 0);
-	PerRead pr = {k_tmpl.data(), k_nh.data(), k_rc.data(), k_stats.data()};
+	lap("stage 2 (chain_kernel)");
+	// the records in stream order
+	unsigned long long *cnt;
+	int64_t *first, *o_read, *o_nT, *slot_of, *T_off;
+	int32_t *o_rcflag, *o_emit, *o_qs, *o_qe, *o_T, *zero;
+	if((rc = B.get((size_t) n + 1, &cnt, true)) || (rc = B.get((size_t) n + 1, &first)) || (rc = B.get((size_t) m + 1, &o_read)) || (rc = B.get((size_t) m + 1, &o_nT)) ||
+	   (rc = B.get((size_t) m + 1, &slot_of)) || (rc = B.get((size_t) m + 1, &T_off, true)) || (rc = B.get((size_t) m + 1, &o_rcflag)) || (rc = B.get((size_t) m + 1, &o_emit)) ||
+	   (rc = B.get((size_t) m + 1, &o_qs)) || (rc = B.get((size_t) m + 1, &o_qe)) || (rc = B.get((size_t) n_T + 1, &o_T)) || (rc = B.get((size_t) m + 1, &zero, true))) return rc;
+	kmahip_reads d{};
 	if(m) {
-		if((rc = run_after_stage2(db, ws, B, d, c, total, p, evalue, bcd, max_frag, out, pr, t))) return rc;
+		hipLaunchKernelGGL(chain_count_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, rec, cnt);
+		if((rc = scan_i64(B, (const int64_t *) cnt, first, (size_t) n + 1, s))) return rc;
+		hipLaunchKernelGGL(chain_place_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, rec, first, o_read, o_rcflag, o_emit, o_qs, o_qe, o_nT, slot_of);
+		if((rc = scan_i64(B, o_nT, T_off, (size_t) m + 1, s))) return rc;
+		hipLaunchKernelGGL(chain_lists_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, slot_of, rec_T, T, T_off, o_T);
+		HIP_TRY(hipGetLastError());
+		// ... as a batch of their own: the read, or its reverse complement where the record prints that, with its bounds
+		int64_t *wc, *nc, *so, *no;
+		if((rc = B.get((size_t) m + 1, &wc)) || (rc = B.get((size_t) m + 1, &nc)) || (rc = B.get((size_t) m + 1, &so)) || (rc = B.get((size_t) m + 1, &no))) return rc;
+		hipLaunchKernelGGL(gather_sizes_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, o_read, dR.len, dR.N_off, wc, nc);
+		if((rc = scan_i64(B, wc, so, (size_t) m + 1, s)) || (rc = scan_i64(B, nc, no, (size_t) m + 1, s))) return rc;
+		int64_t tw = 0, tn = 0;
+		HIP_TRY(hipMemcpyAsync(&tw, so + m, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(&tn, no + m, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		uint64_t *seq;
+		int32_t *len, *N;
+		if((rc = B.get((size_t) tw + 2, &seq)) || (rc = B.get((size_t) m + 1, &len)) || (rc = B.get((size_t) tn + 1, &N))) return rc;
+		HIP_TRY(hipMemsetAsync(seq + tw, 0, 16, s));
+		HIP_TRY(hipMemsetAsync(len + m, 0, 4, s));
+		hipLaunchKernelGGL(gather_copy_rc_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, o_read, o_emit, dR.seq, dR.seq_off, dR.len, dR.N, dR.N_off,
+		                   seq, so, len, N, no);
+		HIP_TRY(hipGetLastError());
+		d.n_reads = m; d.seq = seq; d.seq_off = so; d.len = len; d.N = N; d.N_off = no; d.seq_words = tw; d.N_total = tn; d.max_len = reads->max_len;
+		d.q_start = o_qs; d.q_end = o_qe;
+		HIP_TRY(hipStreamSynchronize(s));
+	}
+	lap("records in stream order, record batch");
+	kmahip_cands c;
+	c.rc_flag = o_rcflag; c.flag = zero; c.T_off = T_off; c.T = o_T; c.T_cap = n_T + 1;
+	// (buffers nobody has touched: a vector would write every page once before the copy does)
+	std::unique_ptr<int32_t[]> k_tmpl(new int32_t[(size_t) m + 1]), k_nh(new int32_t[(size_t) m + 1]), k_rc(new int32_t[(size_t) m + 1]), k_stats(new int32_t[(size_t) m * 10 + 10]);
+	PerRead pr = {k_tmpl.get(), k_nh.get(), k_rc.get(), k_stats.get()};
+	if(m) {
+		if((rc = run_after_stage2(db, ws, B, d, c, n_T, p, evalue, bcd, max_frag, out, pr, t))) return rc;
 	} else {
 		std::vector<uint64_t> w(D, 0);
 		if((rc = kmahip_res_rows(db, w.data(), evalue, p->scoreT, out->rows, out->rows_cap, &out->n_rows))) return rc;
@@ -785,15 +787,15 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	}
 	lap("stages 3a ... pile-up");
 	if(frag_path && m) {
-		std::vector<char> nm;
-		std::vector<int64_t> noff{0};
-		for(int64_t x = 0; x < m; ++x) {
-			const char *h = names + name_off[r_read[(size_t) x]];
-			nm.insert(nm.end(), h, h + strlen(h) + 1);
-			noff.push_back((int64_t) nm.size());
-		}
+		// the rows are formatted from the reads as they came: a record that printed the reverse complement turns its row once more
+		std::unique_ptr<int64_t[]> h_read(new int64_t[(size_t) m]);
+		std::unique_ptr<int32_t[]> h_emit(new int32_t[(size_t) m]);
+		HIP_TRY(hipMemcpy(h_read.get(), o_read, (size_t) m * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_emit.get(), o_emit, (size_t) m * 4, hipMemcpyDeviceToHost));
+		for(int64_t x = 0; x < m; ++x) k_rc[(size_t) x] ^= h_emit[(size_t) x] & 1;
 		int64_t rows = 0;
-		if((rc = kmahip_frag_write(frag_path, db, &rb, k_rc.data(), k_tmpl.data(), k_nh.data(), k_stats.data(), max_frag, nm.data(), noff.data(), &rows))) return rc;
+		if((rc = kmahip_frag_write_src(frag_path, db, reads, m, h_read.get(), k_rc.get(), k_tmpl.get(), k_nh.get(), k_stats.get(), 10, max_frag, 0, nullptr,
+		                               names, name_off, &rows))) return rc;
 	}
 	lap("fragment file");
 	out->ms[5] += since(t);

@@ -1,7 +1,8 @@
 #!/bin/bash
-# the file-to-file run with every KMAHIP_DEBUG_TIMING line (10 M reads by default): gpurun -- 'tools/map_debug.sh [reads]'
+# the file-to-file run with every KMAHIP_DEBUG_TIMING line (10 M reads by default): gpurun -- 'tools/map_debug.sh [reads [mode]]', mode = -1t1 | -chain
 set -e
 N=${1:-10000000}
+MODE=${2:--1t1}
 W=$(mktemp -d /tmp/mapdbg.XXXX)
 python3 - "$N" "$W" <<'PY'
 import os, sys
@@ -19,5 +20,5 @@ with open(os.path.join(w, "reads.fq"), "wb") as f:
         f.write(open(os.path.join(w, "part.fq"), "rb").read())
 PY
 make -C examples >/dev/null
-examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out -1t1 2>&1 | tail -1; KMAHIP_DEBUG_TIMING=1 examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out -1t1 2>&1 | grep -v "^\[kmahip\] lt"
+examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out $MODE 2>&1 | tail -1; KMAHIP_DEBUG_TIMING=1 examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out $MODE 2>&1 | grep -v "^\[kmahip\] lt"
 rm -rf $W
