@@ -601,7 +601,10 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 	}
 }
 
-__global__ __launch_bounds__(64) void chain_kernel(const ChainArgs A) {
+#ifndef CHAIN_MIN_WAVES
+#define CHAIN_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainArgs A) {
 	const int64_t lane = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(lane >= A.lanes) return;
 	uint8_t *base = A.scratch + lane * A.lane_bytes;
@@ -663,7 +666,7 @@ int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_param
 	// 254 VGPRs: one wave per SIMD = 65 536 lanes resident. (Capped at 128 VGPRs for four waves per SIMD the kernel spills 1 000
 	// registers and takes as long: 2 M reads in 62 vs 68 ms. At ~2 000 scattered accesses per read that is ~65 G lines/s, the
 	// gather ceiling of DESIGN 3.1 -- the way up is fewer scattered accesses, anchors and lists out of HBM scratch, not more lanes.)
-	int64_t lanes = 65536;
+	int64_t lanes = getenv("KMAHIP_CHAIN_LANES") ? atoll(getenv("KMAHIP_CHAIN_LANES")) : 65536;
 	while(lanes > 64 && lanes * A.lane_bytes > (16ll << 30)) lanes >>= 1;
 	lanes = std::min<int64_t>(lanes, ((n + 63) / 64) * 64);
 	A.lanes = lanes;

@@ -612,6 +612,11 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 		int64_t rows = 0;
 		if((rc = kmahip_frag_write_src(frag_path, db, &R, nf, h_src.get(), h_rc.get(), h_t.get(), h_nh.get(), h_stats.get(), 4, mf + 1, 0, h_rank.get(),
 		                               batch->names, batch->name_off, &rows))) return rc;
+	} else if(frag_path) {          // nothing filed: the file is written all the same (an empty gzip stream)
+		const int64_t none64 = 0;
+		const int32_t none[4] = {0, 0, 0, 0};
+		int64_t rows = 0;
+		if((rc = kmahip_frag_write_src(frag_path, db, &R, 0, &none64, none, none, none, none, 4, mf + 1, 0, &none64, "", &none64, &rows))) return rc;
 	}
 	out->ms[5] = since(t);
 	return KMAHIP_OK;
@@ -796,6 +801,12 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 		int64_t rows = 0;
 		if((rc = kmahip_frag_write_src(frag_path, db, reads, m, h_read.get(), k_rc.get(), k_tmpl.get(), k_nh.get(), k_stats.get(), 10, max_frag, 0, nullptr,
 		                               names, name_off, &rows))) return rc;
+	}
+	else if(frag_path) {          // no record: the file is written all the same (an empty gzip stream)
+		const int64_t none64 = 0;
+		const int32_t none[10] = {0};
+		int64_t rows = 0;
+		if((rc = kmahip_frag_write_src(frag_path, db, reads, 0, &none64, none, none, none, none, 10, max_frag, 0, nullptr, names ? names : "", name_off ? name_off : &none64, &rows))) return rc;
 	}
 	lap("fragment file");
 	out->ms[5] += since(t);

@@ -74,11 +74,12 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants, m
     assert got.count(b"\n") > 40000
 
 
-@pytest.mark.parametrize("mf", [None, 1001])
+@pytest.mark.parametrize("mf", [None, 1001, 7])
 def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
     """`-ipe r1 r2 -apm p -1t1 -t 1`: pairs with substitutions, some mates foreign or too short after trimming (single records in the
     pair stream), some with an insertion or deletion, through the reference and through examples/kmahip_map -ipe. With -mf 1001
-    the assembly chunks close after whole records: couples straddle the limit (chunks of 1002 fragments, conclave.c:164-196)."""
+    the assembly chunks close after whole records: couples straddle the limit (chunks of 1002 fragments, conclave.c:164-196); -mf 7
+    makes eight thousand chunks, half of them closed by a couple."""
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -117,6 +118,64 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 50000
+
+
+def test_paired_stream_of_singles_equals_reference_binary(tmp_path):
+    """`-ipe` where one mate of EVERY pair falls to the quality trim: the pair stream holds single records only (no pair batch at all
+    in kmahip_run_pe), and a second run where both mates of every pair are foreign (nothing maps: empty .res, no rows)."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(15)
+    names, seqs = synth.make_gene_db(20, 5, 700, 1400, 0.04, seed=78)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    m1, m2, _ = synth.make_pairs(seqs, 4000, seed=19)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    bad = b"I" * 10 + b"#" * 140
+    for case in ("singles", "foreign"):
+        for path, ms, tag, other in ((tmp_path / "r1.fq", m1, b"/1", 0), (tmp_path / "r2.fq", m2, b"/2", 1)):
+            with open(path, "wb") as f:
+                for i, r in enumerate(ms):
+                    if case == "foreign":
+                        r = rng.integers(0, 4, 150, dtype=np.uint8)
+                    q = bad if case == "singles" and (i & 1) == other else b"I" * 150
+                    f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
+        subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
+                       check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"],
+                       check=True, stderr=subprocess.DEVNULL)
+        assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
+        assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), case
+        got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+        assert got == ref, case
+        assert (got.count(b"\n") > 3000) == (case == "singles")
+
+
+@pytest.mark.parametrize("mode", ["-1t1", "default"])
+def test_run_where_nothing_maps_equals_reference_binary(tmp_path, mode):
+    """reads foreign to the database: header-only .res, empty .fsa, a .frag.gz that inflates to nothing -- all three files written"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(16)
+    names, seqs = synth.make_gene_db(10, 5, 700, 1400, 0.04, seed=79)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    with open(tmp_path / "r.fq", "wb") as f:
+        for i in range(2000):
+            f.write(b"@r%d\n" % i + lut[rng.integers(0, 4, 150, dtype=np.uint8)].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
+    for o in ("got.frag.gz", "ref.frag.gz"):
+        with open(tmp_path / o, "wb") as f:
+            f.write(b"stale")
+    subprocess.run([KMA, "-i", str(tmp_path / "r.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"] + (["-1t1"] if mode == "-1t1" else []),
+                   check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", str(tmp_path / "r.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"),
+                    "-1t1" if mode == "-1t1" else "-chain"], check=True, stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read() == b""
 
 
 def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
