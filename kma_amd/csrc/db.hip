@@ -56,7 +56,7 @@ static int upload(kmahip_db *db, const T *src, size_t count, const T **dst) {
 	size_t bytes = (count ? count : 1) * sizeof(T);
 	HIP_TRY(hipMalloc(&d, bytes));
 	db->allocs.push_back(d);
-	if(count) HIP_TRY(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+	if(count && src) HIP_TRY(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));      // (src == NULL: room only)
 	*dst = (const T *) d;
 	db->info.total_bytes += bytes;
 	return KMAHIP_OK;
@@ -67,6 +67,52 @@ static bool read_exact(FILE *f, void *dst, size_t bytes) { return fread(dst, 1, 
 static inline uint32_t home_bucket(uint32_t key, uint32_t nb_log2) {
 	return (uint32_t) (key * 0x9E3779B1u) >> (32 - nb_log2);
 }
+
+// ---- the walkable template store on the device: vs_id[g] = value-list offset of the k-mer that starts at position g of `cat`, and every
+// slot of the probe table re-pointed from its list offset to the FIRST position of its k-mer (what a serial pass over the templates
+// gives; here an atomicMin per k-mer start) ---------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int find_slot(const uint2 *slots, uint32_t nb_log2, uint32_t km, int64_t *si_out) {
+	const uint32_t nbm = (1u << nb_log2) - 1u;
+	uint32_t b = (km * 0x9E3779B1u) >> (32u - nb_log2);
+	for(;;) {
+		const uint2 *sl = slots + (size_t) b * KMAHIP_BUCKET_SLOTS;
+		for(int j = 0; j < KMAHIP_BUCKET_SLOTS; ++j) {
+			if(sl[j].y == KMAHIP_EMPTY_VI) return 0;            // k-mer not in the index
+			if(sl[j].x == km) { *si_out = (int64_t) b * KMAHIP_BUCKET_SLOTS + j; return 1; }
+		}
+		b = (b + 1u) & nbm;
+	}
+}
+
+// one workgroup per template; slots[].y still holds the list offsets
+__global__ __launch_bounds__(256) void walk_vsid_kernel(const uint2 *slots, uint32_t nb_log2, const uint64_t *cat, const int64_t *cat_off, const int32_t *tlen,
+                                                        int k, uint32_t *vs_id, uint32_t *first) {
+	const uint32_t t = blockIdx.x + 1;
+	const int64_t g0 = cat_off[t];
+	const int tl = tlen[t];
+	for(int i = threadIdx.x; i + k <= tl; i += blockDim.x) {
+		const int64_t g = g0 + i;
+		const int ip = (int) (g & 31) << 1;
+		uint64_t x = cat[g >> 5] << ip;
+		if(ip) x |= cat[(g >> 5) + 1] >> (64 - ip);
+		const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
+		int64_t si;
+		if(!find_slot(slots, nb_log2, km, &si)) continue;
+		vs_id[g] = slots[si].y;
+		atomicMin(&first[si], (uint32_t) g);
+	}
+}
+
+__global__ __launch_bounds__(256) void walk_repoint_kernel(uint2 *slots, int64_t n_slots, const uint32_t *first, unsigned long long *unplaced) {
+	const int64_t si = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(si >= n_slots || slots[si].y == KMAHIP_EMPTY_VI) return;
+	if(first[si] == 0xFFFFFFFFu) { atomicAdd(unplaced, 1ull); return; }
+	slots[si].y = first[si];
+}
+
+}  // namespace
 
 extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(!prefix || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
@@ -211,48 +257,47 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 			for(uint32_t t = 1; t < DB_size; ++t) total += db->h_tlen[t];
 			if(total + 64 >= 0xFFFFFFFFll) { kmahip_db_close(db); kmahip_set_error("template store too large for 32-bit positions"); return KMAHIP_EFORMAT; }
 			std::vector<uint64_t> cat((size_t) (total >> 5) + 4, 0);
-			std::vector<uint32_t> vsid((size_t) total + 64, KMAHIP_EMPTY_VI);
-			std::vector<uint8_t> placed(slots.size(), 0);
 			int64_t g0 = 0;
-			uint64_t unplaced = n;
 			db->h_cat_off.assign((size_t) DB_size + 1, 0);
 			for(uint32_t t = 1; t < DB_size; ++t) {
 				const int tl = db->h_tlen[t];
 				const uint64_t *ts = tseq.data() + off[t];
-				for(int i = 0; i < tl; ++i) {
-					const uint64_t b = (ts[i >> 5] >> (62 - ((i & 31) << 1))) & 3ull;
-					const int64_t g = g0 + i;
-					cat[(size_t) (g >> 5)] |= b << (62 - ((g & 31) << 1));
-				}
-				for(int i = 0; i + kk <= tl; ++i) {
-					const int ip = (i & 31) << 1, w = i >> 5;
-					uint64_t x = ts[w] << ip;
-					if(ip) x |= ts[w + 1] >> (64 - ip);
-					const uint32_t km = (uint32_t) (x >> (64 - 2 * kk));
-					uint64_t b = home_bucket(km, nb_log2);
-					for(bool done = false; !done;) {
-						uint2 *sl = &slots[b * KMAHIP_BUCKET_SLOTS];
-						for(int j = 0; j < KMAHIP_BUCKET_SLOTS; ++j) {
-							const size_t si = b * KMAHIP_BUCKET_SLOTS + j;
-							if(sl[j].y == KMAHIP_EMPTY_VI && !placed[si]) { done = true; break; }   // k-mer not in the index
-							if(sl[j].x == km) {
-								// first sighting: remember the list offset at this position, then re-point the slot here
-								if(!placed[si]) { vsid[(size_t) (g0 + i)] = sl[j].y; sl[j].y = (uint32_t) (g0 + i); placed[si] = 1; --unplaced; }
-								else vsid[(size_t) (g0 + i)] = vsid[sl[j].y];
-								done = true; break;
-							}
-						}
-						if(!done) b = (b + 1) & (nb - 1);
-					}
+				// the template's words shifted into place, 32 bases at a time (what lies behind its last base is masked off)
+				const int sh = (int) (g0 & 31) << 1;
+				uint64_t *dst = cat.data() + (g0 >> 5);
+				const int words = (tl + 31) >> 5;
+				for(int w = 0; w < words; ++w) {
+					uint64_t v = ts[w];
+					const int have = tl - 32 * w;
+					if(have < 32) v &= ~0ull << (64 - 2 * have);
+					dst[w] |= v >> sh;
+					if(sh) dst[w + 1] |= v << (64 - sh);
 				}
 				g0 += tl;
 				db->h_cat_off[t + 1] = g0;
 			}
 			if(DB_size > 1) db->h_cat_off[1] = 0;
-			if(unplaced) { kmahip_db_close(db); kmahip_set_error("%llu index k-mers do not occur in %s.seq.b", (unsigned long long) unplaced, prefix); return KMAHIP_EFORMAT; }
-			if((rc = upload(db, slots.data(), slots.size(), &d.slots)) || (rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
-			   (rc = upload(db, vsid.data(), vsid.size(), &d.vs_id)) ||
-			   (rc = upload(db, db->h_cat_off.data(), db->h_cat_off.size(), &d.cat_off))) { kmahip_db_close(db); return rc; }
+			uint2 *d_slots = nullptr;
+			uint32_t *d_vsid = nullptr, *d_first = nullptr;
+			unsigned long long *d_unplaced = nullptr, unplaced = 0;
+			if((rc = upload(db, slots.data(), slots.size(), (const uint2 **) &d_slots)) || (rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
+			   (rc = upload(db, db->h_cat_off.data(), db->h_cat_off.size(), &d.cat_off)) ||
+			   (rc = upload(db, (const uint32_t *) nullptr, (size_t) total + 64, (const uint32_t **) &d_vsid))) { kmahip_db_close(db); return rc; }
+			d.slots = d_slots; d.vs_id = d_vsid;
+			bool bad = hipMalloc((void **) &d_first, slots.size() * 4 + 8) != hipSuccess;
+			if(!bad) {
+				d_unplaced = (unsigned long long *) (d_first + slots.size());
+				bad = hipMemsetAsync(d_first, 0xFF, slots.size() * 4, 0) != hipSuccess || hipMemsetAsync(d_unplaced, 0, 8, 0) != hipSuccess ||
+				      hipMemsetAsync(d_vsid, 0xFF, ((size_t) total + 64) * 4, 0) != hipSuccess;
+				if(!bad && DB_size > 1) {
+					hipLaunchKernelGGL(walk_vsid_kernel, dim3(DB_size - 1), dim3(256), 0, 0, d_slots, nb_log2, d.cat, d.cat_off, d.tlen, kk, d_vsid, d_first);
+					hipLaunchKernelGGL(walk_repoint_kernel, dim3((unsigned) ((slots.size() + 255) / 256)), dim3(256), 0, 0, d_slots, (int64_t) slots.size(), d_first, d_unplaced);
+				}
+				bad = bad || hipMemcpy(&unplaced, d_unplaced, 8, hipMemcpyDeviceToHost) != hipSuccess;
+				(void) hipFree(d_first);
+			}
+			if(bad) { kmahip_db_close(db); kmahip_set_error("building the walkable template store failed: %s", hipGetErrorString(hipGetLastError())); return KMAHIP_EDEVICE; }
+			if(unplaced) { kmahip_db_close(db); kmahip_set_error("%llu index k-mers do not occur in %s.seq.b", unplaced, prefix); return KMAHIP_EFORMAT; }
 		}
 
 		stamp("walkable template store (cat / vs_id)");
