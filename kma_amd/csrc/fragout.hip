@@ -156,20 +156,55 @@ int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *r
 	// writes the rows as they come.)
 	const auto t_order = std::chrono::steady_clock::now();
 	const size_t n_t = db->h_names.size();
-	std::vector<int64_t> t_rows(n_t + 2, 0);
-	for(int64_t i = 0; i < n; ++i) {
-		if(tmpl[i] == 0) continue;
-		const size_t t = (size_t) abs(tmpl[i]);
-		if(t > n_t) { kmahip_set_error("template %zu has no name in %s.name", t, db->prefix.c_str()); return KMAHIP_EFORMAT; }
-		if(trace_stats[S * i + 3] != 0) ++t_rows[t + 1];
+	// (the fragments are cut into one contiguous range per thread: counts per range and template, a prefix over (template, range),
+	// then every range drops its rows where they belong -- the stream order inside a template is kept)
+	int nt;
+	const int64_t grain = getenv("KMAHIP_ROW_GRAIN") ? std::max(1, atoi(getenv("KMAHIP_ROW_GRAIN"))) : 65536;      // fragments per thread at least (the tests lower it)
+	{
+		const char *e_ = getenv("KMAHIP_IO_THREADS");
+		const int hw = (int) std::thread::hardware_concurrency();
+		nt = e_ ? atoi(e_) : std::min(16, hw > 0 ? hw : 1);
+		nt = (int) std::max<int64_t>(1, std::min<int64_t>(std::max(nt, 1), n / grain));
 	}
-	for(size_t t = 1; t < t_rows.size(); ++t) t_rows[t] += t_rows[t - 1];        // t_rows[t] = first row of template t
+	auto lo = [&](int w) { return n * w / nt; };
+	auto in_threads = [&](auto fn) {
+		std::vector<std::thread> pool;
+		for(int w = 1; w < nt; ++w) pool.emplace_back(fn, w);
+		fn(0);
+		for(std::thread &th : pool) th.join();
+	};
+	std::vector<std::vector<int64_t>> cnt((size_t) nt, std::vector<int64_t>(n_t + 2, 0));
+	std::vector<int64_t> filed((size_t) nt + 1, 0);
+	std::atomic<size_t> bad_t{0};
+	in_threads([&](int w) {
+		std::vector<int64_t> &c = cnt[(size_t) w];
+		int64_t f = 0;
+		for(int64_t i = lo(w); i < lo(w + 1); ++i) {
+			if(tmpl[i] == 0) continue;
+			const size_t t = (size_t) abs(tmpl[i]);
+			if(t > n_t) { bad_t.store(t); return; }
+			++f;
+			if(trace_stats[S * i + 3] != 0) ++c[t];
+		}
+		filed[(size_t) w + 1] = f;
+	});
+	if(bad_t.load()) { kmahip_set_error("template %zu has no name in %s.name", bad_t.load(), db->prefix.c_str()); return KMAHIP_EFORMAT; }
+	std::vector<int64_t> t_rows(n_t + 2, 0);            // t_rows[t] = first row of template t
+	{
+		int64_t at = 0;
+		for(size_t t = 0; t <= n_t; ++t) {
+			t_rows[t] = at;
+			for(int w = 0; w < nt; ++w) { const int64_t c = cnt[(size_t) w][t]; cnt[(size_t) w][t] = at; at += c; }    // now: where range w starts filling t
+		}
+		t_rows[n_t + 1] = at;
+		for(int w = 0; w < nt; ++w) filed[(size_t) w + 1] += filed[(size_t) w];
+	}
 	const size_t n_rows = (size_t) t_rows[n_t + 1];
 	std::vector<int64_t> row_read(n_rows), row_rank(order ? 0 : n_rows);
-	{
-		std::vector<int64_t> fill(t_rows.begin(), t_rows.end() - 1);
-		int64_t rank = 0;                                   // position among the filed reads of the whole run
-		for(int64_t i = 0; i < n; ++i) {
+	in_threads([&](int w) {
+		std::vector<int64_t> &fill = cnt[(size_t) w];
+		int64_t rank = filed[(size_t) w];                  // position among the filed reads of the whole run
+		for(int64_t i = lo(w); i < lo(w + 1); ++i) {
 			if(tmpl[i] == 0) continue;
 			const size_t t = (size_t) abs(tmpl[i]);
 			const int64_t r = frag_rank ? frag_rank[i] : rank++;
@@ -178,19 +213,28 @@ int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *r
 			row_read[at] = i;
 			if(!order) row_rank[at] = r;
 		}
-	}
+	});
 	if(!order) {
-		for(size_t t = 1; t <= n_t; ++t) {
-			size_t a = (size_t) t_rows[t];
-			const size_t b = (size_t) t_rows[t + 1];
-			while(a < b) {
-				const int64_t chunk = row_rank[a] / max_frag;
-				size_t c = a + 1;
-				while(c < b && row_rank[c] / max_frag == chunk) ++c;
-				std::reverse(row_read.begin() + (ptrdiff_t) a, row_read.begin() + (ptrdiff_t) c);
-				a = c;
+		std::atomic<size_t> next_t{1};
+		const int nt0 = nt;
+		nt = (int) std::max<size_t>(1, std::min<size_t>((size_t) nt0, n_rows / (size_t) grain));
+		in_threads([&](int) {
+			for(;;) {
+				const size_t t0 = next_t.fetch_add(64);
+				if(t0 > n_t) return;
+				for(size_t t = t0; t <= std::min(n_t, t0 + 63); ++t) {
+					size_t a = (size_t) t_rows[t];
+					const size_t b = (size_t) t_rows[t + 1];
+					while(a < b) {
+						const int64_t chunk = row_rank[a] / max_frag;
+						size_t c = a + 1;
+						while(c < b && row_rank[c] / max_frag == chunk) ++c;
+						std::reverse(row_read.begin() + (ptrdiff_t) a, row_read.begin() + (ptrdiff_t) c);
+						a = c;
+					}
+				}
 			}
-		}
+		});
 	}
 	if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] frag_write: row order %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_order).count());
 	// The rows come in template order, the reads lie in stream order: every row gathers from a dozen cache lines nobody has
