@@ -126,6 +126,8 @@ int main(int argc, char **argv) {
 	if(!names || !res || !fsa) { fprintf(stderr, "kmahip_map: cannot open the name file or the outputs\n"); return 1; }
 	fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
 	int64_t r = 0;
+	size_t fsa_cap = 1 << 16;
+	char *fsa_buf = xcalloc(fsa_cap, 1);
 	for(int64_t t = 1; t < D && fgets(name, 1 << 16, names); ++t) {
 		name[strcspn(name, "\n")] = 0;
 		while(r < run.n_rows && run.rows[r].template_id < t) ++r;
@@ -135,9 +137,13 @@ int main(int argc, char **argv) {
 		/* printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line */
 		fprintf(fsa, ">%s\n", name);
 		const char *c = run.assembly.consensus + run.assembly.consensus_off[t];
+		const size_t clen = strlen(c);
+		if(clen + clen / 60 + 2 > fsa_cap) { fsa_cap = 2 * (clen + clen / 60 + 2); free(fsa_buf); fsa_buf = xcalloc(fsa_cap, 1); }
+		char *o = fsa_buf;
 		int col = 0;
-		for(; *c; ++c) if(*c != '-') { fputc(*c, fsa); if(++col == 60) { fputc('\n', fsa); col = 0; } }
-		if(col) fputc('\n', fsa);
+		for(; *c; ++c) if(*c != '-') { *o++ = *c; if(++col == 60) { *o++ = '\n'; col = 0; } }
+		if(col) *o++ = '\n';
+		fwrite(fsa_buf, 1, (size_t) (o - fsa_buf), fsa);
 	}
 	fclose(names); fclose(res); fclose(fsa);
 
