@@ -160,8 +160,18 @@ struct Chunk {
 	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else free(base); }
 };
 
-// The input file as chunks: a plain regular file is mapped whole (one chunk); anything else is read through zlib by a
+// The input file as chunks: a plain regular file is mapped whole (one chunk); a gzip file of several members (bgzip, concatenated
+// lanes, `cat a.gz b.gz`) is mapped compressed and its members inflated side by side; anything else is read through zlib by a
 // thread of its own that stays a few chunks ahead of the parser (so inflating overlaps with everything after it).
+//
+// Members in parallel: a gzip member carries no length, so where members start is guessed first -- every offset that looks
+// like a member header (1f 8b 08, reserved flag bits clear, a plausible XFL and OS byte) -- and settled while inflating: offset
+// 0 is a start; where the member that starts at a settled offset ENDS is the next settled start. A worker takes the candidates
+// in ascending order, one member each, and inflates into chunks of its own; the parser is handed the chunks of the settled
+// members in order and never sees what a worker made of a false candidate (which fails within bytes, being random data).
+// A worker that is not feeding the parser stops at 512 MB of unread output until it is its member's turn, so at most that much
+// per worker waits in memory. What the parser gets is byte for byte what gzread gives: members back to back, bytes behind the
+// last member that are no member ignored, a corrupt member ending the input with an error after what came before it.
 struct Feeder {
 	size_t CHUNK = 32u << 20, HEAD = 1u << 20;      // (KMAHIP_INGEST_CHUNK: smaller ones for the tests)
 	static constexpr size_t AHEAD = 4;
@@ -172,6 +182,102 @@ struct Feeder {
 	std::condition_variable cv;
 	std::deque<Chunk *> ready;
 	bool done = false, stop = false;
+	// members in parallel
+	struct Seg { std::deque<Chunk *> ready; size_t buffered = 0; bool done = false, error = false; int64_t next = -1; };   // next: candidate where the member ended, -1: end of input
+	const uint8_t *zmap = nullptr;
+	size_t zsize = 0, LIMIT = 512u << 20;
+	std::vector<size_t> cands;
+	std::vector<Seg> segs;
+	std::vector<std::thread> workers;
+	size_t claim = 0, cur = 0;
+	bool par = false, par_end = false;
+
+	static bool looks_like_member(const uint8_t *q, size_t left) {
+		return left >= 18 && q[0] == 0x1f && q[1] == 0x8b && q[2] == 8 && (q[3] & 0xe0) == 0 && (q[8] == 0 || q[8] == 2 || q[8] == 4) && (q[9] <= 13 || q[9] == 255);
+	}
+	void find_members(int nt) {
+		std::vector<std::vector<size_t>> found((size_t) nt);
+		auto scan = [&](int w) {
+			const size_t a = zsize * (size_t) w / (size_t) nt, b = zsize * (size_t) (w + 1) / (size_t) nt;
+			const uint8_t *q = zmap + a;
+			while(q < zmap + b) {
+				q = (const uint8_t *) memchr(q, 0x1f, (size_t) (zmap + b - q));
+				if(!q) break;
+				if(looks_like_member(q, (size_t) (zmap + zsize - q))) found[(size_t) w].push_back((size_t) (q - zmap));
+				++q;
+			}
+		};
+		std::vector<std::thread> pool;
+		for(int w = 1; w < nt; ++w) pool.emplace_back(scan, w);
+		scan(0);
+		for(std::thread &t : pool) t.join();
+		for(int w = 0; w < nt; ++w) cands.insert(cands.end(), found[(size_t) w].begin(), found[(size_t) w].end());
+	}
+	// one member, from candidate i
+	void inflate_member(size_t i) {
+		Seg &S = segs[i];
+		z_stream zs;
+		memset(&zs, 0, sizeof zs);
+		bool ok = inflateInit2(&zs, 15 + 16) == Z_OK, ended = false;
+		size_t in_at = cands[i];
+		Chunk *c = nullptr;
+		auto hand_over = [&](Chunk *full) {
+			std::unique_lock<std::mutex> lk(mu);
+			S.ready.push_back(full);
+			S.buffered += full->hi - full->lo;
+			cv.notify_all();
+			cv.wait(lk, [&] { return stop || i == cur || S.buffered < LIMIT; });
+		};
+		while(ok && !ended) {
+			{ std::lock_guard<std::mutex> lk(mu); if(stop) break; }
+			if(!c) {
+				c = new Chunk();
+				c->cap = HEAD + CHUNK;
+				c->base = (uint8_t *) malloc(c->cap);
+				if(!c->base) { ok = false; break; }
+				c->lo = c->hi = HEAD;
+			}
+			if(zs.avail_in == 0) {
+				zs.next_in = const_cast<Bytef *>(zmap + in_at);
+				zs.avail_in = (uInt) std::min<size_t>(zsize - in_at, 1u << 30);
+				in_at += zs.avail_in;
+			}
+			zs.next_out = c->base + c->hi;
+			zs.avail_out = (uInt) std::min<size_t>(c->cap - c->hi, 1u << 30);
+			const uInt out0 = zs.avail_out;
+			const int r = inflate(&zs, Z_NO_FLUSH);
+			c->hi += out0 - zs.avail_out;
+			if(r == Z_STREAM_END) ended = true;
+			else if(r == Z_BUF_ERROR && zs.avail_in == 0 && in_at == zsize) ok = false;      // the file ends inside the member
+			else if(r != Z_OK && r != Z_BUF_ERROR) ok = false;
+			if(c->hi == c->cap && !ended && ok) { hand_over(c); c = nullptr; }
+		}
+		const size_t end = in_at - zs.avail_in;
+		inflateEnd(&zs);
+		int64_t next = -1;
+		if(ok && ended && end < zsize) {
+			const auto it = std::lower_bound(cands.begin(), cands.end(), end);
+			if(it != cands.end() && *it == end) next = (int64_t) (it - cands.begin());      // (else: bytes that are no member -- ignored, like gzread does)
+		}
+		std::lock_guard<std::mutex> lk(mu);
+		// (what the chunk in hand holds of a member that failed is dropped, as gzread drops what a failing call had inflated: the
+		// bytes next to the damage are not to be parsed)
+		if(c && ok && ended) { S.ready.push_back(c); S.buffered += c->hi - c->lo; }
+		else delete c;
+		S.error = !(ok && ended); S.next = next; S.done = true;
+		cv.notify_all();
+	}
+	void work() {
+		for(;;) {
+			size_t i;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if(stop || claim >= cands.size()) return;
+				i = claim++;
+			}
+			inflate_member(i);
+		}
+	}
 
 	bool open(const char *path) {
 		const int fd = ::open(path, O_RDONLY);
@@ -193,6 +299,27 @@ struct Feeder {
 			}
 			if(whole) { ::close(fd); return true; }
 		}
+		if(regular && sb.st_size >= 36 && !getenv("KMAHIP_INGEST_SERIAL_GZ")) {
+			void *m = mmap(nullptr, (size_t) sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+			if(m != MAP_FAILED) {
+				zmap = (const uint8_t *) m; zsize = (size_t) sb.st_size;
+				const char *e = getenv("KMAHIP_INGEST_THREADS");
+				const int hw = (int) std::thread::hardware_concurrency();
+				int nt = e ? atoi(e) : std::min(16, hw > 0 ? hw : 1);
+				nt = std::max(nt, 1);
+				find_members((int) std::min<size_t>((size_t) nt, zsize / (1u << 20) + 1));
+				if(cands.size() >= 2 && cands[0] == 0) {
+					if(const char *l = getenv("KMAHIP_INGEST_GZ_LIMIT")) LIMIT = (size_t) std::max(1, atoi(l));
+					par = true;
+					segs.resize(cands.size());
+					::close(fd);
+					for(int w = 0; w < (int) std::min<size_t>((size_t) nt, cands.size()); ++w) workers.emplace_back([this] { work(); });
+					return true;
+				}
+				munmap(m, zsize);
+				zmap = nullptr; zsize = 0; cands.clear();
+			}
+		}
 		gz = gzdopen(fd, "rb");
 		if(!gz) { ::close(fd); return false; }
 		gzbuffer(gz, 1 << 20);
@@ -208,7 +335,13 @@ struct Feeder {
 			while(c->base && c->hi < c->cap) {
 				// (in pieces: zlib drops what a call had inflated when the call ends in an error)
 				const int got = gzread(gz, c->base + c->hi, (unsigned) std::min<size_t>(c->cap - c->hi, 1u << 20));
-				if(got <= 0) { c->last = true; c->io_error = got < 0; break; }
+				if(got <= 0) {
+					// (a file that ends inside a member reads as 0 bytes with Z_BUF_ERROR pending)
+					int zerr = Z_OK;
+					(void) gzerror(gz, &zerr);
+					c->last = true; c->io_error = got < 0 || zerr == Z_BUF_ERROR || zerr == Z_DATA_ERROR;
+					break;
+				}
 				c->hi += (size_t) got;
 			}
 			if(!c->base) c->last = true;
@@ -225,6 +358,30 @@ struct Feeder {
 	// the next chunk, nullptr after the last one
 	Chunk *pop() {
 		if(whole) { Chunk *c = whole; whole = nullptr; return c; }
+		if(par) {
+			std::unique_lock<std::mutex> lk(mu);
+			for(;;) {
+				if(par_end) return nullptr;
+				Seg &S = segs[cur];
+				cv.wait(lk, [&] { return !S.ready.empty() || S.done; });
+				if(!S.ready.empty()) {
+					Chunk *c = S.ready.front();
+					S.ready.pop_front();
+					S.buffered -= c->hi - c->lo;
+					cv.notify_all();
+					return c;
+				}
+				// the member is through: on to the one that starts where it ended, or the end of the input
+				if(S.error || S.next < 0) {
+					par_end = true;
+					Chunk *c = new Chunk();
+					c->last = true; c->io_error = S.error;
+					return c;
+				}
+				cur = (size_t) S.next;
+				cv.notify_all();
+			}
+		}
 		if(!gz) return nullptr;
 		std::unique_lock<std::mutex> lk(mu);
 		cv.wait(lk, [this] { return !ready.empty() || done; });
@@ -238,6 +395,11 @@ struct Feeder {
 		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
 		cv.notify_all();
 		if(th.joinable()) th.join();
+		for(std::thread &w : workers) if(w.joinable()) w.join();
+		workers.clear();
+		for(Seg &S : segs) { for(Chunk *c : S.ready) delete c; S.ready.clear(); }
+		if(zmap) munmap(const_cast<uint8_t *>(zmap), zsize);
+		zmap = nullptr; par = false;
 		for(Chunk *c : ready) delete c;
 		ready.clear();
 		delete whole; whole = nullptr;

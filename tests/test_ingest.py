@@ -158,7 +158,7 @@ def _all(path1, path2=None, step=1 << 30, **kw):
             try:
                 g = ing.next(step)
             except binding.KmaHipError as e:
-                err = str(e)[:20]
+                err = str(e)[:32]
                 continue
             if g is None:
                 break
@@ -259,3 +259,89 @@ def test_ingest_reports_a_corrupt_gzip_stream(tmp_path):
                 break
             n += g[0].n
         assert err is not None and 0 < n < 20000, (n, err)
+
+
+def _member(data, level=1, fname=None):
+    """one gzip member, hand-made so that the header can carry a file name"""
+    import struct
+    import zlib
+    z = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = z.compress(data) + z.flush()
+    head = b"\x1f\x8b\x08" + (b"\x08" if fname is not None else b"\x00") + b"\x00\x00\x00\x00" + (b"\x04" if level == 1 else b"\x00") + b"\x03"
+    if fname is not None:
+        head += fname + b"\x00"
+    return head + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data) & 0xffffffff)
+
+
+def _fastq(n, seed, L=150):
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGTN", np.uint8)
+    return b"".join(b"@r%d\n" % i + lut[rng.integers(0, 5, int(rng.integers(20, L)))].tobytes() + b"\n+\n" for i in range(0)) + \
+        b"".join(b"@r%d x\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in
+                 ((i, lut[rng.integers(0, 5, int(rng.integers(20, L)))].tobytes()) for i in range(n)))
+
+
+@pytest.mark.parametrize("chunk,limit", [(None, None), (500, 300), (4096, 1)])
+def test_ingest_gzip_members_in_parallel(tmp_path, monkeypatch, chunk, limit):
+    """a .gz of several members (cut anywhere, also inside records and lines) read member by member on several threads gives what the
+    plain file gives: two big members, hundreds of small ones (bgzip-like), an empty member, a member whose header holds bytes that
+    look like a member start, bytes behind the last member that are no member; with tiny chunks and a tiny read-ahead limit too"""
+    data = _fastq(3000, 11)
+    plain = tmp_path / "x.fq"
+    plain.write_bytes(data)
+    want = _all(str(plain), min_phred=0, min_len=0)
+    assert len(want[0][0]) == 3000 and want[1] is None
+    rng = np.random.default_rng(12)
+    cases = {}
+    cut = len(data) // 2 + 7
+    cases["two"] = _member(data[:cut]) + _member(data[cut:], level=6)
+    cuts = [0] + sorted(int(x) for x in rng.choice(len(data), 400, replace=False)) + [len(data)]
+    cases["many"] = b"".join(_member(data[a:b]) for a, b in zip(cuts[:-1], cuts[1:]))
+    cases["empty"] = _member(data[:1000]) + _member(b"") + _member(data[1000:])
+    cases["decoy"] = _member(data[:5000], fname=b"a\x1f\x8b\x08\x01AAAA\x02\x03decoy-in-the-name") + _member(data[5000:], fname=b"\x1f\x8b\x08\x01BBBB\x04\x03")
+    cases["garbage"] = _member(data[:cut]) + _member(data[cut:]) + b"\x00" * 100 + b"not a member"
+    if chunk:
+        monkeypatch.setenv("KMAHIP_INGEST_CHUNK", str(chunk))
+        monkeypatch.setenv("KMAHIP_INGEST_REGION", "64")
+        monkeypatch.setenv("KMAHIP_INGEST_GZ_LIMIT", str(limit))
+    monkeypatch.setenv("KMAHIP_INGEST_THREADS", "5")
+    for name, blob in cases.items():
+        p = tmp_path / f"{name}.fq.gz"
+        p.write_bytes(blob)
+        if name != "garbage":
+            assert gzip.open(p).read() == data, name          # (a well-formed multi-member file for any reader)
+        assert _all(str(p), min_phred=0, min_len=0) == want, name
+        assert _all(str(p), step=101, min_phred=0, min_len=0) == want, (name, "batches")
+        monkeypatch.setenv("KMAHIP_INGEST_SERIAL_GZ", "1")    # the one-thread reader agrees
+        assert _all(str(p), min_phred=0, min_len=0) == want, (name, "serial")
+        monkeypatch.delenv("KMAHIP_INGEST_SERIAL_GZ")
+    # pairs: both mate files multi-member, cut at different places
+    d2 = _fastq(3000, 13)
+    (tmp_path / "y.fq").write_bytes(d2)
+    want_pe = _all(str(plain), str(tmp_path / "y.fq"), min_phred=0, min_len=0)
+    (tmp_path / "y.fq.gz").write_bytes(_member(d2[:999]) + _member(d2[999:70000]) + _member(d2[70000:]))
+    assert _all(str(tmp_path / "many.fq.gz"), str(tmp_path / "y.fq.gz"), min_phred=0, min_len=0) == want_pe
+
+
+def test_ingest_gzip_members_damaged(tmp_path, monkeypatch):
+    """a damaged member in the middle, and a file that ends inside its last member: the records before are delivered, then one call
+    fails with an I/O error -- as the one-thread reader does"""
+    monkeypatch.setenv("KMAHIP_INGEST_THREADS", "4")
+    data = _fastq(6000, 21)
+    third = len(data) // 3
+    parts = [_member(data[:third]), bytearray(_member(data[third:2 * third])), _member(data[2 * third:])]
+    mid = len(parts[1]) // 2
+    parts[1][mid:mid + 64] = bytes(64)
+    (tmp_path / "bad.fq.gz").write_bytes(parts[0] + bytes(parts[1]) + parts[2])
+    whole = _member(data[:third]) + _member(data[third:])
+    (tmp_path / "cut.fq.gz").write_bytes(whole[:-len(whole) // 4])
+    first = data[:third].count(b"\n") // 4
+    for name in ("bad", "cut"):
+        got, err = _all(str(tmp_path / f"{name}.fq.gz"), min_phred=0, min_len=0)
+        assert err is not None and first - 1 <= len(got[0]) < 6000, (name, len(got[0]), err)
+        monkeypatch.setenv("KMAHIP_INGEST_SERIAL_GZ", "1")
+        got1, err1 = _all(str(tmp_path / f"{name}.fq.gz"), min_phred=0, min_len=0)
+        monkeypatch.delenv("KMAHIP_INGEST_SERIAL_GZ")
+        k = min(len(got1[0]), len(got[0]))                 # (each drops a piece of its own size next to the damage: one is a prefix of the other)
+        assert err1 is not None and got1[0][:k] == got[0][:k] and got1[1][:k] == got[1][:k], name
+        assert "read error" in err, (name, err)
