@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <rocprim/rocprim.hpp>
 
 static thread_local char g_err[512] = "";
 
@@ -86,6 +87,33 @@ __device__ __forceinline__ int find_slot(const uint2 *slots, uint32_t nb_log2, u
 	}
 }
 
+// the probe table and the presence bits from the index's (k-mer, list offset) pairs: a lane per k-mer takes the first free slot at
+// or behind its home bucket with a 64-bit compare-and-swap. Slots of a bucket are tried in order, so a bucket fills front to back
+// and "last slot empty" keeps meaning "a free slot" for the readers; which of several k-mers of one home bucket ends up in the
+// next bucket depends on who came first -- a lookup finds each of them either way.
+__global__ __launch_bounds__(256) void table_fill_kernel(unsigned long long *slots, int64_t n_slots) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n_slots) slots[i] = (unsigned long long) KMAHIP_EMPTY_VI << 32;
+}
+
+__global__ __launch_bounds__(256) void table_insert_kernel(const uint32_t *keys, const uint32_t *vidx, int64_t n, unsigned long long *slots, uint32_t nb_log2,
+                                                           uint32_t *kbits, uint32_t kbits_shift) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint32_t key = keys[i], nbm = (1u << nb_log2) - 1u;
+	const unsigned long long empty = (unsigned long long) KMAHIP_EMPTY_VI << 32, mine = ((unsigned long long) vidx[i] << 32) | key;
+	if(kbits) {
+		const uint32_t h = (key * KMAHIP_KBITS_MUL) >> kbits_shift;
+		atomicOr(&kbits[h >> 5], 1u << (h & 31));
+	}
+	uint32_t b = (key * 0x9E3779B1u) >> (32u - nb_log2);
+	for(;;) {
+		unsigned long long *s = slots + (size_t) b * KMAHIP_BUCKET_SLOTS;
+		for(int j = 0; j < KMAHIP_BUCKET_SLOTS; ++j) if(atomicCAS(&s[j], empty, mine) == empty) return;
+		b = (b + 1u) & nbm;
+	}
+}
+
 // one workgroup per template; slots[].y still holds the list offsets
 __global__ __launch_bounds__(256) void walk_vsid_kernel(const uint2 *slots, uint32_t nb_log2, const uint64_t *cat, const int64_t *cat_off, const int32_t *tlen,
                                                         int k, uint32_t *vs_id, uint32_t *first) {
@@ -110,6 +138,67 @@ __global__ __launch_bounds__(256) void walk_repoint_kernel(uint2 *slots, int64_t
 	if(si >= n_slots || slots[si].y == KMAHIP_EMPTY_VI) return;
 	if(first[si] == 0xFFFFFFFFu) { atomicAdd(unplaced, 1ull); return; }
 	slots[si].y = first[si];
+}
+
+
+// ---- the per-template position index on the device: every k-mer start as (template, k-mer) -> 1-based position, sorted (a stable
+// radix sort keeps the positions of a repeated k-mer ascending), one lane per distinct pair writes its entry -- the position, or a
+// reference to "count, positions ..." in the duplicate list, laid out in (template, k-mer) order by a prefix sum -- into the
+// template's linear-probing table with a compare-and-swap -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tpos_keys_kernel(const uint64_t *cat, const int64_t *cat_off, const int32_t *tlen, int k, unsigned long long *keys, int32_t *vals) {
+	const uint32_t t = blockIdx.x + 1;
+	const int64_t g0 = cat_off[t];
+	const int tl = tlen[t];
+	for(int i = threadIdx.x; i < tl; i += blockDim.x) {
+		const int64_t g = g0 + i;
+		unsigned long long key = ~0ull;
+		int32_t val = 0;
+		if(i + k <= tl) {
+			const int ip = (int) (g & 31) << 1;
+			uint64_t x = cat[g >> 5] << ip;
+			if(ip) x |= cat[(g >> 5) + 1] >> (64 - ip);
+			const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
+			if(km) { key = ((unsigned long long) t << 32) | km; val = i + 1; }      // (the poly-A k-mer is never indexed, hashmapcci.c:414-417)
+		}
+		keys[g] = key; vals[g] = val;
+	}
+}
+
+__global__ __launch_bounds__(256) void tpos_runs_kernel(const unsigned long long *ks, int64_t n, int64_t *need) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > n) return;
+	int64_t v = 0;
+	if(i < n) {
+		const unsigned long long key = ks[i];
+		if(key != ~0ull && (i == 0 || ks[i - 1] != key)) {
+			int64_t len = 1;
+			while(i + len < n && ks[i + len] == key) ++len;
+			if(len > 1) v = len + 1;
+		}
+	}
+	need[i] = v;
+}
+
+__global__ __launch_bounds__(256) void tpos_insert_kernel(const unsigned long long *ks, const int32_t *vs, int64_t n, const int64_t *need, const int64_t *doff,
+                                                          const int64_t *poff, const uint32_t *pshift, unsigned long long *slots, int32_t *dups) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const unsigned long long key = ks[i];
+	if(key == ~0ull || (i > 0 && ks[i - 1] == key)) return;
+	const uint32_t t = (uint32_t) (key >> 32), km = (uint32_t) key;
+	int32_t val;
+	if(need[i] == 0) val = vs[i];
+	else {
+		const int64_t G = 1 + doff[i], len = need[i] - 1;
+		dups[G] = (int32_t) len;
+		for(int64_t c = 0; c < len; ++c) dups[G + 1 + c] = vs[i + c];
+		val = -(int32_t) (G + 1);
+	}
+	const uint32_t sh = pshift[t], msk = (uint32_t) ((1ull << (32 - sh)) - 1);
+	unsigned long long *tab = slots + poff[t];
+	const unsigned long long mine = ((unsigned long long) (uint32_t) val << 32) | km;
+	uint32_t sl = (km * 0x9E3779B1u) >> sh;
+	while(atomicCAS(&tab[sl], 0ull, mine) != 0ull) sl = (sl + 1) & msk;
 }
 
 }  // namespace
@@ -188,39 +277,40 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	while(((uint64_t) KMAHIP_BUCKET_SLOTS << nb_log2) < 2 * n) ++nb_log2;
 	if(nb_log2 > 31) { delete db; kmahip_set_error("index too large"); return KMAHIP_EFORMAT; }
 	const uint64_t nb = 1ull << nb_log2;
-	std::vector<uint2> slots(nb * KMAHIP_BUCKET_SLOTS, make_uint2(0u, KMAHIP_EMPTY_VI));
-	for(uint64_t i = 0; i < n; ++i) {
-		uint64_t b = home_bucket(keys[i], nb_log2);
-		for(;;) {
-			uint2 *s = &slots[b * KMAHIP_BUCKET_SLOTS];
-			int j = 0;
-			while(j < KMAHIP_BUCKET_SLOTS && s[j].y != KMAHIP_EMPTY_VI) ++j;
-			if(j < KMAHIP_BUCKET_SLOTS) { s[j] = make_uint2(keys[i], vidx[i]); break; }
-			b = (b + 1) & (nb - 1);
-		}
-	}
-	db->info.hash_bytes = slots.size() * sizeof(uint2);
+	const size_t n_slots = (size_t) nb * KMAHIP_BUCKET_SLOTS;
+	db->info.hash_bytes = n_slots * sizeof(uint2);
 	// presence bits: ~7 bits per k-mer (13 % false positives) as long as that fits 2 MiB
-	std::vector<uint32_t> kbits;
 	uint32_t kbits_log2 = 0;
 	if(n > 0 && 8 * n < (1ull << 25) && !getenv("KMAHIP_NO_KBITS")) {        // (the switch exists for the test that compares both paths)
 		kbits_log2 = 16;
 		while((2ull << kbits_log2) <= 8 * n) ++kbits_log2;
-		kbits.assign((size_t) 1 << (kbits_log2 - 5), 0u);
-		for(uint64_t i = 0; i < n; ++i) {
-			const uint32_t h = (keys[i] * KMAHIP_KBITS_MUL) >> (32 - kbits_log2);
-			kbits[h >> 5] |= 1u << (h & 31);
-		}
 	}
 
 	int rc;
 	DevDB &d = db->dev;
 	memset(&d, 0, sizeof d);
 	d.DB_size = DB_size; d.kmersize = tail[0]; d.mlen = mlen; d.nb_log2 = nb_log2; d.values_u16 = u16;
-	// (slots are uploaded further down, once every key has been given a template position)
-	if(!kbits.empty()) {
-		if((rc = upload(db, kbits.data(), kbits.size(), &d.kbits))) { kmahip_db_close(db); return rc; }
-		d.kbits_shift = 32 - kbits_log2;
+	// the probe table and the presence bits, filled on the device from the k-mers and their list offsets
+	uint2 *d_slots = nullptr;
+	{
+		uint32_t *d_kbits = nullptr;
+		const uint32_t *d_keys = nullptr, *d_vidx = nullptr;
+		if((rc = upload(db, (const uint2 *) nullptr, n_slots, (const uint2 **) &d_slots))) { kmahip_db_close(db); return rc; }
+		if(kbits_log2 && (rc = upload(db, (const uint32_t *) nullptr, (size_t) 1 << (kbits_log2 - 5), (const uint32_t **) &d_kbits))) { kmahip_db_close(db); return rc; }
+		bool bad = hipMalloc((void **) &d_keys, (size_t) (n + 1) * 4) != hipSuccess || hipMalloc((void **) &d_vidx, (size_t) (n + 1) * 4) != hipSuccess;
+		bad = bad || hipMemcpy((void *) d_keys, keys.data(), (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		      hipMemcpy((void *) d_vidx, vidx.data(), (size_t) n * 4, hipMemcpyHostToDevice) != hipSuccess;
+		if(!bad && d_kbits) bad = hipMemsetAsync(d_kbits, 0, (size_t) 4 << (kbits_log2 - 5), 0) != hipSuccess;
+		if(!bad) {
+			hipLaunchKernelGGL(table_fill_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, 0, (unsigned long long *) d_slots, (int64_t) n_slots);
+			if(n) hipLaunchKernelGGL(table_insert_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, d_keys, d_vidx, (int64_t) n, (unsigned long long *) d_slots,
+			                         nb_log2, d_kbits, 32 - kbits_log2);
+			bad = hipDeviceSynchronize() != hipSuccess;
+		}
+		(void) hipFree((void *) d_keys); (void) hipFree((void *) d_vidx);
+		if(bad) { kmahip_db_close(db); kmahip_set_error("building the probe table failed: %s", hipGetErrorString(hipGetLastError())); return KMAHIP_EDEVICE; }
+		d.slots = d_slots;
+		if(d_kbits) { d.kbits = d_kbits; d.kbits_shift = 32 - kbits_log2; }
 	}
 	if(u16) rc = upload(db, (const uint16_t *) values.data(), (size_t) v_index + 8, &d.values16);
 	else rc = upload(db, (const uint32_t *) values.data(), (size_t) v_index + 8, &d.values32);
@@ -277,21 +367,20 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 				db->h_cat_off[t + 1] = g0;
 			}
 			if(DB_size > 1) db->h_cat_off[1] = 0;
-			uint2 *d_slots = nullptr;
 			uint32_t *d_vsid = nullptr, *d_first = nullptr;
 			unsigned long long *d_unplaced = nullptr, unplaced = 0;
-			if((rc = upload(db, slots.data(), slots.size(), (const uint2 **) &d_slots)) || (rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
+			if((rc = upload(db, cat.data(), cat.size(), &d.cat)) ||
 			   (rc = upload(db, db->h_cat_off.data(), db->h_cat_off.size(), &d.cat_off)) ||
 			   (rc = upload(db, (const uint32_t *) nullptr, (size_t) total + 64, (const uint32_t **) &d_vsid))) { kmahip_db_close(db); return rc; }
-			d.slots = d_slots; d.vs_id = d_vsid;
-			bool bad = hipMalloc((void **) &d_first, slots.size() * 4 + 8) != hipSuccess;
+			d.vs_id = d_vsid;
+			bool bad = hipMalloc((void **) &d_first, n_slots * 4 + 8) != hipSuccess;
 			if(!bad) {
-				d_unplaced = (unsigned long long *) (d_first + slots.size());
-				bad = hipMemsetAsync(d_first, 0xFF, slots.size() * 4, 0) != hipSuccess || hipMemsetAsync(d_unplaced, 0, 8, 0) != hipSuccess ||
+				d_unplaced = (unsigned long long *) (d_first + n_slots);
+				bad = hipMemsetAsync(d_first, 0xFF, n_slots * 4, 0) != hipSuccess || hipMemsetAsync(d_unplaced, 0, 8, 0) != hipSuccess ||
 				      hipMemsetAsync(d_vsid, 0xFF, ((size_t) total + 64) * 4, 0) != hipSuccess;
 				if(!bad && DB_size > 1) {
 					hipLaunchKernelGGL(walk_vsid_kernel, dim3(DB_size - 1), dim3(256), 0, 0, d_slots, nb_log2, d.cat, d.cat_off, d.tlen, kk, d_vsid, d_first);
-					hipLaunchKernelGGL(walk_repoint_kernel, dim3((unsigned) ((slots.size() + 255) / 256)), dim3(256), 0, 0, d_slots, (int64_t) slots.size(), d_first, d_unplaced);
+					hipLaunchKernelGGL(walk_repoint_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, 0, d_slots, (int64_t) n_slots, d_first, d_unplaced);
 				}
 				bad = bad || hipMemcpy(&unplaced, d_unplaced, 8, hipMemcpyDeviceToHost) != hipSuccess;
 				(void) hipFree(d_first);
@@ -314,87 +403,48 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		}
 		poff[1] = poff[0] = 0;
 		for(uint32_t t = 1; t < DB_size; ++t) poff[t + 1] = poff[t] + (1ll << (32 - pshift[t]));
-		std::vector<uint2> pslots((size_t) poff[DB_size] + 1, make_uint2(0u, 0u));
-		// built by a few threads, each over a stretch of templates with a duplicate list of its own; the lists are then put
-		// one after the other and the references into them moved by where each list landed
-		std::vector<int32_t> dups(1, 0);
 		{
-			const char *e = getenv("KMAHIP_IO_THREADS");
-			const int hw = (int) std::thread::hardware_concurrency();
-			int nt = e ? atoi(e) : std::min(16, hw > 0 ? hw : 1);
-			nt = std::max(1, std::min<int>(nt, (int) (DB_size / 64) + 1));
-			std::vector<std::vector<int32_t>> part((size_t) nt);
-			std::vector<uint32_t> cut((size_t) nt + 1, DB_size);
-			{	// equal shares of the template bases
-				int64_t total = 0, acc = 0;
-				for(uint32_t t = 1; t < DB_size; ++t) total += db->h_tlen[t];
-				cut[0] = 1;
-				int c = 1;
-				for(uint32_t t = 1; t < DB_size && c < nt; ++t) {
-					acc += db->h_tlen[t];
-					if(acc * nt >= total * c) cut[(size_t) c++] = t + 1;
+			int64_t total = db->h_cat_off[DB_size];
+			const size_t n_ps = (size_t) poff[DB_size] + 1;
+			unsigned long long *d_ps = nullptr, *d_k = nullptr, *d_ks = nullptr;
+			int32_t *d_v = nullptr, *d_vs = nullptr, *d_dups = nullptr;
+			int64_t *d_need = nullptr, *d_doff = nullptr, *d_poff = nullptr;
+			uint32_t *d_pshift = nullptr;
+			void *d_tmp = nullptr;
+			std::vector<void *> scratch;
+			auto room = [&](void **q, size_t bytes) { if(hipMalloc(q, bytes ? bytes : 16) != hipSuccess) return false; scratch.push_back(*q); return true; };
+			struct Free { std::vector<void *> &v; ~Free() { for(void *q : v) (void) hipFree(q); } } guard{scratch};
+			if((rc = upload(db, (const unsigned long long *) nullptr, n_ps, (const unsigned long long **) &d_ps)) ||
+			   (rc = upload(db, poff.data(), poff.size(), (const int64_t **) &d_poff)) || (rc = upload(db, pshift.data(), pshift.size(), (const uint32_t **) &d_pshift))) { kmahip_db_close(db); return rc; }
+			d.tpos_slots = (const uint2 *) d_ps; d.tpos_off = d_poff; d.tpos_shift = d_pshift;
+			const size_t T = (size_t) total;
+			bool bad = hipMemsetAsync(d_ps, 0, n_ps * 8, 0) != hipSuccess ||
+			           !room((void **) &d_k, (T + 1) * 8) || !room((void **) &d_ks, (T + 1) * 8) || !room((void **) &d_v, (T + 1) * 4) || !room((void **) &d_vs, (T + 1) * 4) ||
+			           !room((void **) &d_need, (T + 1) * 8) || !room((void **) &d_doff, (T + 1) * 8);
+			int64_t n_dups = 0;
+			if(!bad && total > 0) {
+				hipLaunchKernelGGL(tpos_keys_kernel, dim3(DB_size - 1), dim3(256), 0, 0, d.cat, d.cat_off, d.tlen, k, d_k, d_v);
+				size_t tmp_bytes = 0, tmp2 = 0;
+				bad = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k, d_ks, d_v, d_vs, T, 0, 64, 0) != hipSuccess ||
+				      rocprim::exclusive_scan(nullptr, tmp2, d_need, d_doff, (int64_t) 0, T + 1, rocprim::plus<int64_t>(), 0) != hipSuccess;
+				tmp_bytes = std::max(tmp_bytes, tmp2);
+				bad = bad || !room(&d_tmp, tmp_bytes);
+				bad = bad || rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_k, d_ks, d_v, d_vs, T, 0, 64, 0) != hipSuccess;
+				if(!bad) {
+					hipLaunchKernelGGL(tpos_runs_kernel, dim3((unsigned) ((T + 256) / 256)), dim3(256), 0, 0, d_ks, (int64_t) T, d_need);
+					bad = rocprim::exclusive_scan(d_tmp, tmp_bytes, d_need, d_doff, (int64_t) 0, T + 1, rocprim::plus<int64_t>(), 0) != hipSuccess ||
+					      hipMemcpy(&n_dups, d_doff + T, 8, hipMemcpyDeviceToHost) != hipSuccess;
 				}
 			}
-			auto build = [&](int w) {
-				std::vector<std::pair<uint32_t, int32_t>> kp;
-				std::vector<int32_t> &dl = part[(size_t) w];
-				for(uint32_t t = cut[(size_t) w]; t < cut[(size_t) w + 1]; ++t) {
-					const int tl = db->h_tlen[t];
-					const uint64_t *ts = tseq.data() + off[t];
-					kp.clear();
-					for(int i = 0; i + k <= tl; ++i) {
-						const int ip = (i & 31) << 1, wd = i >> 5;
-						uint64_t x = ts[wd] << ip;
-						if(ip) x |= ts[wd + 1] >> (64 - ip);
-						const uint32_t km = (uint32_t) (x >> (64 - 2 * k));
-						if(km) kp.push_back({km, i + 1});
-					}
-					std::sort(kp.begin(), kp.end());
-					const uint32_t sh = pshift[t];
-					const uint64_t msk = (1ull << (32 - sh)) - 1;
-					uint2 *tab = pslots.data() + poff[t];
-					for(size_t a = 0; a < kp.size();) {
-						size_t b = a;
-						while(b < kp.size() && kp[b].first == kp[a].first) ++b;
-						int32_t val;
-						if(b - a == 1) val = kp[a].second;
-						else {
-							val = -((int32_t) dl.size() + 1);         // (relative to this thread's list for now)
-							dl.push_back((int32_t) (b - a));
-							for(size_t c = a; c < b; ++c) dl.push_back(kp[c].second);
-						}
-						uint64_t sl = (uint32_t) (kp[a].first * 0x9E3779B1u) >> sh;
-						while(tab[sl].y != 0) sl = (sl + 1) & msk;
-						tab[sl] = make_uint2(kp[a].first, (uint32_t) val);
-						a = b;
-					}
-				}
-			};
-			{
-				std::vector<std::thread> pool;
-				for(int w = 1; w < nt; ++w) pool.emplace_back(build, w);
-				build(0);
-				for(std::thread &th : pool) th.join();
+			if(!bad && n_dups + 1 >= 0x7FFFFFFFll) { kmahip_db_close(db); kmahip_set_error("too many repeated k-mers inside templates"); return KMAHIP_EFORMAT; }
+			if(!bad && (rc = upload(db, (const int32_t *) nullptr, (size_t) n_dups + 1, (const int32_t **) &d_dups))) { kmahip_db_close(db); return rc; }
+			if(!bad) {
+				d.tpos_dups = d_dups;
+				bad = hipMemsetAsync(d_dups, 0, 4, 0) != hipSuccess;
+				if(!bad && total > 0) hipLaunchKernelGGL(tpos_insert_kernel, dim3((unsigned) ((T + 255) / 256)), dim3(256), 0, 0, d_ks, d_vs, (int64_t) T, d_need, d_doff, d_poff, d_pshift, d_ps, d_dups);
+				bad = bad || hipDeviceSynchronize() != hipSuccess;
 			}
-			std::vector<int64_t> base((size_t) nt + 1, 1);
-			for(int w = 0; w < nt; ++w) base[(size_t) w + 1] = base[(size_t) w] + (int64_t) part[(size_t) w].size();
-			if(base[(size_t) nt] >= 0x7FFFFFFFll) { kmahip_db_close(db); kmahip_set_error("too many repeated k-mers inside templates"); return KMAHIP_EFORMAT; }
-			dups.resize((size_t) base[(size_t) nt]);
-			auto place = [&](int w) {
-				if(!part[(size_t) w].empty()) memcpy(dups.data() + base[(size_t) w], part[(size_t) w].data(), part[(size_t) w].size() * sizeof(int32_t));
-				const int32_t shift = (int32_t) base[(size_t) w];
-				if(!shift) return;
-				for(int64_t i = poff[cut[(size_t) w]]; i < poff[cut[(size_t) w + 1]]; ++i) {
-					const int32_t v = (int32_t) pslots[(size_t) i].y;
-					if(v < 0) pslots[(size_t) i].y = (uint32_t) (v - shift);
-				}
-			};
-			{
-				std::vector<std::thread> pool;
-				for(int w = 1; w < nt; ++w) pool.emplace_back(place, w);
-				place(0);
-				for(std::thread &th : pool) th.join();
-			}
+			if(bad) { kmahip_db_close(db); kmahip_set_error("building the position index failed: %s", hipGetErrorString(hipGetLastError())); return KMAHIP_EDEVICE; }
 		}
 		std::vector<uint4> tmeta((size_t) 2 * DB_size, make_uint4(0u, 0u, 0u, 0u));
 		for(uint32_t t = 1; t < DB_size; ++t) {
@@ -402,11 +452,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 			tmeta[2 * (size_t) t] = make_uint4((uint32_t) so, (uint32_t) (so >> 32), (uint32_t) po, (uint32_t) (po >> 32));
 			tmeta[2 * (size_t) t + 1] = make_uint4((uint32_t) db->h_tlen[t], pshift[t], 0u, 0u);
 		}
-		if((rc = upload(db, tmeta.data(), tmeta.size(), &d.tmeta)) ||
-		   (rc = upload(db, pslots.data(), pslots.size(), &d.tpos_slots)) ||
-		   (rc = upload(db, poff.data(), poff.size(), &d.tpos_off)) ||
-		   (rc = upload(db, pshift.data(), pshift.size(), &d.tpos_shift)) ||
-		   (rc = upload(db, dups.data(), dups.size(), &d.tpos_dups))) { kmahip_db_close(db); return rc; }
+		if((rc = upload(db, tmeta.data(), tmeta.size(), &d.tmeta))) { kmahip_db_close(db); return rc; }
 	}
 	stamp("per-template position index");
 	*out = db;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of the whole device pipeline (stage 2 ... consensus) on the GPU box: a 10 M-read FASTQ against the 5k-gene
 # index through examples/kmahip_map. usage: tools/prof_pipeline.sh [reads [mode [name]]] ; mode = -1t1 (single end), -chain (the default
-# mode) or -ipe (reads / 2 pairs); summaries land in gpurun_out/<name> (prof_pipeline)
+# mode) or -ipe (reads / 2 pairs); PROF_DB=50k: against the 50 k-gene database of C5; summaries land in gpurun_out/<name> (prof_pipeline)
 set -e
 N=${1:-10000000}
 MODE=${2:--1t1}
@@ -15,8 +15,15 @@ sys.path.insert(0, os.getcwd())
 import bench
 from kma_amd import formats, synth
 n, w, mode = int(sys.argv[1]), sys.argv[2], sys.argv[3]
-names, seqs = synth.make_gene_db(1000, 5, 600, 1500, 0.04, seed=12345)
-formats.write_index(os.path.join(w, "db5k"), names, seqs)
+if os.environ.get("PROF_DB") == "50k":      # the database of config C5: 5 000 families x 10 variants, indexed by examples/kmahip_index
+    import subprocess
+    names, seqs = synth.make_gene_db(5000, 10, 600, 1500, 0.04, seed=4321)
+    synth.write_fasta(os.path.join(w, "db.fsa"), names, seqs)
+    subprocess.check_call(["make", "-C", "examples"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["examples/kmahip_index", "-i", os.path.join(w, "db.fsa"), "-o", os.path.join(w, "db5k")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+else:
+    names, seqs = synth.make_gene_db(1000, 5, 600, 1500, 0.04, seed=12345)
+    formats.write_index(os.path.join(w, "db5k"), names, seqs)
 if mode == "-ipe":
     with open(os.path.join(w, "r1.fq"), "wb") as f1, open(os.path.join(w, "r2.fq"), "wb") as f2:
         for a in range(0, n // 2, 250_000):
@@ -43,6 +50,7 @@ else
 	CMD="$ROOT/examples/kmahip_map -i $W/reads.fq -t_db $W/db5k -o $W/out $MODE"
 	SAY="kmahip_map -i reads.fq ($N reads x 150 bp) -t_db db5k -o out $MODE"
 fi
+if [ "$PROF_DB" = "50k" ]; then SAY="$SAY   (db5k here = the 50 k-gene database of config C5)"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o pipe -- $CMD > $ROOT/$OUT/run.log 2>&1
 # HBM traffic counters in passes of their own (never together with the traces gpurun refuses)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/fetch -o pipe -- $CMD > $ROOT/$OUT/fetch.log 2>&1
