@@ -59,6 +59,8 @@ struct PileArgs {
 	int seg_cols;
 	int64_t *vis_cnt, *vis_off;  // per read: number of units it visits, exclusive scan of that
 	int64_t *unit_start;         // n_units + 1: first entry of the sorted list per unit (n_entries if none)
+	int64_t *unit_end;           // n_units: one past its last entry (read only where unit_start < n_entries)
+	int lds_words;               // LDS words a workgroup has (PILE_LDS_WORDS, or half of it so that two workgroups share a CU)
 };
 
 // oriented read base (0-3, 4 = N): the read as ConClave filed it
@@ -99,7 +101,8 @@ __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ
 extern __shared__ uint32_t pile_lds[];      // [6 * t_len] counts, [t_len] chain heads, [8 * lds_nodes] insertion columns
 constexpr int PILE_LDS_WORDS = (160 * 1024 - 1024) / 4;
 constexpr int PILE_LDS_MIN_NODES = 64;
-constexpr int PILE_THREADS = 1024;     // one workgroup per unit: reads are taken PILE_THREADS at a time (short reads) or one by one (segments)
+constexpr int PILE_THREADS = 1024;     // one workgroup per unit: reads are taken a workgroup's threads at a time (short reads) or one by one
+                                       // (segments). Launched with PILE_THREADS threads and all of the LDS, or with half of both: two per CU
 
 template <bool LDS>
 struct Walk {
@@ -108,7 +111,7 @@ struct Walk {
 	int t_len;
 	unsigned *s_nodes;          // LDS mode: insertion columns in use
 	__device__ __forceinline__ int node_base() const { return 7 * t_len; }
-	__device__ __forceinline__ int node_cap() const { return min((PILE_LDS_WORDS - 7 * t_len) / 8, A.lds_node_limit); }
+	__device__ __forceinline__ int node_cap() const { return min((A.lds_words - 7 * t_len) / 8, A.lds_node_limit); }
 	// the chain head in front of template position p (1-based column ids, 0 = none)
 	__device__ __forceinline__ int head(int p) const { return LDS ? (int) pile_lds[6 * t_len + p] : ld_wg(&A.chain_head[tbase + p]); }
 	__device__ __forceinline__ void set_head(int p, int id) const { if(LDS) pile_lds[6 * t_len + p] = (uint32_t) id; else A.chain_head[tbase + p] = id; }
@@ -243,11 +246,12 @@ __global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
 	for(int u = V.w0; u <= V.w1; ++u, ++slot) { A.keys[slot] = ((uint64_t) u << 28) | ord; A.vals[slot] = (int32_t) r; }
 }
 
-__global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_ent, int64_t *unit_start) {
+__global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_ent, int64_t *unit_start, int64_t *unit_end) {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= n_ent) return;
 	const int64_t u = (int64_t) (keys[i] >> 28);
 	if(i == 0 || (int64_t) (keys[i - 1] >> 28) != u) unit_start[u] = i;
+	if(i + 1 == n_ent || (int64_t) (keys[i + 1] >> 28) != u) unit_end[u] = i + 1;
 }
 
 __global__ __launch_bounds__(256) void pile_fill_kernel(int64_t *p, int64_t n, int64_t v) {
@@ -276,7 +280,7 @@ struct SegWalk {
 		return (p == (lo ? lo - 1 : t_len - 1)) ? 0 : -1;
 	}
 	__device__ __forceinline__ int node_base() const { return 7 * ncol; }
-	__device__ __forceinline__ int node_cap() const { return min((PILE_LDS_WORDS - 7 * ncol) / 8, A.lds_node_limit); }
+	__device__ __forceinline__ int node_cap() const { return min((A.lds_words - 7 * ncol) / 8, A.lds_node_limit); }
 	__device__ __forceinline__ int head(int c) const { return (int) pile_lds[6 * ncol + c]; }
 	__device__ __forceinline__ void set_head(int c, int id) const { pile_lds[6 * ncol + c] = (uint32_t) id; }
 	__device__ __forceinline__ int next(int h) const { return (int) pile_lds[node_base() + 8 * (h - 1) + 6]; }
@@ -305,7 +309,7 @@ __device__ uint64_t block_scan2(uint64_t v, unsigned long long *s_w, uint64_t *t
 	if(lane == 63) s_w[wave] = x;
 	__syncthreads();
 	uint64_t base = 0, tot = 0;
-	for(int w = 0; w < PILE_THREADS / 64; ++w) { const uint64_t t = s_w[w]; if(w < wave) base += t; tot += t; }
+	for(int w = 0; w < (int) blockDim.x / 64; ++w) { const uint64_t t = s_w[w]; if(w < wave) base += t; tot += t; }
 	*total = tot;
 	return base + x - v;
 }
@@ -316,7 +320,7 @@ __device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, un
 	int start = R.start;
 	if(start >= W.t_len) start -= W.t_len;
 	int64_t col_carry = 0, q_carry = R.qp;
-	for(int j0 = R.first; j0 < R.n; j0 += PILE_THREADS) {
+	for(int j0 = R.first; j0 < R.n; j0 += (int) blockDim.x) {
 		const int j = j0 + tid;
 		const bool valid = j < R.n;
 		const uint32_t run = valid ? A.ops[R.o + j] : 0u;
@@ -470,7 +474,7 @@ __device__ void pile_ins(const PileArgs &A, const Walk<LDS> &W, int64_t r) {
 template <bool LDS>
 __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0, int64_t s1, unsigned long long *s_ins) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for(int64_t b = s0; b < s1; b += PILE_THREADS) {
+	for(int64_t b = s0; b < s1; b += (int) blockDim.x) {
 		const bool valid = b + tid < s1;
 		const int64_t r = valid ? (int64_t) A.vals[b + tid] : 0;
 		const unsigned long long m = __ballot(valid && read_has_ins(A, r));
@@ -479,9 +483,9 @@ __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0,
 		// a stretch of reads without an insertion run plus the aligned columns of the insertion-bearing read behind it go side
 		// by side, G lanes a read; then that read's insertion runs, alone
 		int cur = 0;
-		while(cur < PILE_THREADS) {
-			int nxt = PILE_THREADS;
-			for(int w = cur >> 6; w < PILE_THREADS / 64; ++w) {
+		while(cur < (int) blockDim.x) {
+			int nxt = (int) blockDim.x;
+			for(int w = cur >> 6; w < (int) blockDim.x / 64; ++w) {
 				unsigned long long x = s_ins[w];
 				if(w == (cur >> 6)) x &= ~0ull << (cur & 63);
 				if(x) { nxt = (w << 6) + __ffsll((long long) x) - 1; break; }
@@ -489,9 +493,9 @@ __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0,
 #ifdef KMAHIP_DIAG
 			const unsigned long long c0 = wall_clock64();
 #endif
-			const int cnt = min(nxt + 1, PILE_THREADS) - cur;
+			const int cnt = min(nxt + 1, (int) blockDim.x) - cur;
 			int g_sh = 6;
-			while(g_sh > 0 && (cnt << g_sh) > PILE_THREADS) --g_sh;
+			while(g_sh > 0 && (cnt << g_sh) > (int) blockDim.x) --g_sh;
 			const int idx = cur + (tid >> g_sh);
 			if(idx < cur + cnt && b + idx < s1) pile_cols(A, W, (int64_t) A.vals[b + idx], tid & ((1 << g_sh) - 1), 1 << g_sh);
 			wg_fence();
@@ -499,7 +503,7 @@ __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0,
 #ifdef KMAHIP_DIAG
 			const unsigned long long c1 = wall_clock64();
 #endif
-			if(nxt < PILE_THREADS) {
+			if(nxt < (int) blockDim.x) {
 				if(tid == nxt) pile_ins(A, W, r);
 				wg_fence();
 				__syncthreads();
@@ -521,13 +525,7 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 	for(int64_t u = blockIdx.x; u < A.n_units; u += gridDim.x) {
 		const int64_t s0 = A.unit_start[u];
 		if(s0 >= n_ent) continue;
-		int64_t s1 = s0;
-		// end of the unit's entries: first key of a later unit (the sorted list is unit-major)
-		{
-			int64_t lo = s0, hi = n_ent;
-			while(lo < hi) { const int64_t mid = (lo + hi) >> 1; if((int64_t) (A.keys[mid] >> 28) <= u) lo = mid + 1; else hi = mid; }
-			s1 = lo;
-		}
+		const int64_t s1 = A.unit_end[u];          // (the sorted list is unit-major)
 		const int t = A.unit_t[u];
 		const int64_t tbase = A.db.cat_off[t];
 		const int t_len = A.db.tlen[t];
@@ -535,7 +533,7 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			// one segment of a long template
 			const int lo = A.unit_lo[u], hi = min(lo + A.seg_cols, t_len), ncol = hi - lo + 1;
 			const SegWalk W{A, lo, hi, t_len, ncol, &s_nodes};
-			for(int i = tid; i < 7 * ncol; i += PILE_THREADS) pile_lds[i] = 0;
+			for(int i = tid; i < 7 * ncol; i += (int) blockDim.x) pile_lds[i] = 0;
 			if(tid == 0) s_nodes = 0;
 			__syncthreads();
 			for(int64_t e = s0; e < s1; ++e) pile_seg_read(A, W, (int64_t) A.vals[e], s_ins);
@@ -545,9 +543,9 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			const long long base = s_pool;
 			if(base + n_nodes > A.node_cap) { if(tid == 0) atomicMax(&A.counters[1], 32ull); }
 			else {
-				for(int i = tid; i < 6 * (hi - lo); i += PILE_THREADS) A.counts[6 * (tbase + lo) + i] = pile_lds[6 + i];
-				for(int i = tid; i < hi - lo; i += PILE_THREADS) { const int h = (int) pile_lds[6 * ncol + 1 + i]; A.chain_head[tbase + lo + i] = h ? (int32_t) (base + h) : 0; }
-				for(int i = tid; i < n_nodes; i += PILE_THREADS) {
+				for(int i = tid; i < 6 * (hi - lo); i += (int) blockDim.x) A.counts[6 * (tbase + lo) + i] = pile_lds[6 + i];
+				for(int i = tid; i < hi - lo; i += (int) blockDim.x) { const int h = (int) pile_lds[6 * ncol + 1 + i]; A.chain_head[tbase + lo + i] = h ? (int32_t) (base + h) : 0; }
+				for(int i = tid; i < n_nodes; i += (int) blockDim.x) {
 					const uint32_t *c = &pile_lds[W.node_base() + 8 * i];
 					InsNode &nn = A.nodes[base + i];
 					for(int x = 0; x < 6; ++x) nn.c[x] = c[x];
@@ -560,7 +558,7 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 		}
 		if(t_len <= lds_cols) {
 			const Walk<true> W{A, tbase, t_len, &s_nodes};
-			for(int i = tid; i < 7 * t_len; i += PILE_THREADS) pile_lds[i] = 0;
+			for(int i = tid; i < 7 * t_len; i += (int) blockDim.x) pile_lds[i] = 0;
 			if(tid == 0) s_nodes = 0;
 			__syncthreads();
 			pile_template(A, W, s0, s1, s_ins);
@@ -571,9 +569,9 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			const long long base = s_pool;
 			if(base + n_nodes > A.node_cap) { if(tid == 0) atomicMax(&A.counters[1], 32ull); }
 			else {
-				for(int i = tid; i < 6 * t_len; i += PILE_THREADS) A.counts[6 * tbase + i] = pile_lds[i];
-				for(int i = tid; i < t_len; i += PILE_THREADS) { const int h = (int) pile_lds[6 * t_len + i]; A.chain_head[tbase + i] = h ? (int32_t) (base + h) : 0; }
-				for(int i = tid; i < n_nodes; i += PILE_THREADS) {
+				for(int i = tid; i < 6 * t_len; i += (int) blockDim.x) A.counts[6 * tbase + i] = pile_lds[i];
+				for(int i = tid; i < t_len; i += (int) blockDim.x) { const int h = (int) pile_lds[6 * t_len + i]; A.chain_head[tbase + i] = h ? (int32_t) (base + h) : 0; }
+				for(int i = tid; i < n_nodes; i += (int) blockDim.x) {
 					const uint32_t *c = &pile_lds[W.node_base() + 8 * i];
 					InsNode &nn = A.nodes[base + i];
 					for(int x = 0; x < 6; ++x) nn.c[x] = c[x];
@@ -819,6 +817,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	int lds_cols = getenv("KMAHIP_PILE_NO_LDS") ? 0 : split_cols;
 	int seg_cols = getenv("KMAHIP_PILE_SEG_COLS") ? atoi(getenv("KMAHIP_PILE_SEG_COLS")) : 1024;
 	unsigned long long c[3] = {0, 0, 0};
+	bool lds_half = !getenv("KMAHIP_PILE_FULL_LDS");
 	for(;;) {
 		std::vector<int32_t> unit_base((size_t) D + 1, 0), unit_t, unit_lo;
 		for(int64_t t = 1; t < D; ++t) {
@@ -834,7 +833,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		int64_t *d_ustart = nullptr;
 		HIP_TRY(hipMalloc((void **) &d_units, (size_t) (D + 1 + 2 * n_units + 2) * sizeof(int32_t)));
 		G.v.push_back(d_units);
-		HIP_TRY(hipMalloc((void **) &d_ustart, (size_t) (n_units + 2) * sizeof(int64_t)));
+		HIP_TRY(hipMalloc((void **) &d_ustart, (size_t) (2 * n_units + 4) * sizeof(int64_t)));
 		G.v.push_back(d_ustart);
 		HIP_TRY(hipMemcpyAsync(d_units, unit_base.data(), (size_t) (D + 1) * 4, hipMemcpyHostToDevice, stream));
 		if(n_units) {
@@ -842,7 +841,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 			HIP_TRY(hipMemcpyAsync(d_units + D + 1 + n_units, unit_lo.data(), (size_t) n_units * 4, hipMemcpyHostToDevice, stream));
 		}
 		A.unit_base = d_units; A.unit_t = d_units + D + 1; A.unit_lo = d_units + D + 1 + n_units; A.n_units = n_units; A.seg_cols = seg_cols;
-		A.unit_start = d_ustart;
+		A.unit_start = d_ustart; A.unit_end = d_ustart + n_units + 2;
 		HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
 		HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
 		HIP_TRY(hipMemsetAsync(ws->counters, 0, 3 * sizeof(unsigned long long), stream));
@@ -891,19 +890,28 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		if(se != hipSuccess) { (void) hipFree(tmp); kmahip_set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(se)); return KMAHIP_EDEVICE; }
 		A.keys = keys_out; A.vals = vals_out;
 		hipLaunchKernelGGL(pile_fill_kernel, dim3((unsigned) ((n_units + 1 + 255) / 256)), dim3(256), 0, stream, d_ustart, n_units + 1, n_ent);
-		hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((n_ent + 255) / 256)), dim3(256), 0, stream, keys_out, n_ent, d_ustart);
+		hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((n_ent + 255) / 256)), dim3(256), 0, stream, keys_out, n_ent, d_ustart, d_ustart + n_units + 2);
 		lap("sort + segments");
 #ifdef KMAHIP_DIAG
 		HIP_TRY(hipMemsetAsync(ws->counters + 10, 0, 6 * sizeof(unsigned long long), stream));
 #endif
 		const unsigned blocks = (unsigned) std::min<int64_t>(std::max<int64_t>(n_units, 1), 256 * 8);
+		// A unit's time is a chain of dependent loads (its reads' runs, then the columns): with half the LDS each, two workgroups
+		// share a CU and one's waiting hides behind the other's -- when every unit's columns fit that with room for a few hundred
+		// insertion columns. (Status 16 below: a template needed more insertion columns -- again with all of the LDS, then on HBM.)
+		int unit_cols = 0;
+		for(int64_t t = 1; t < D; ++t) { const int tl = db->h_tlen[(size_t) t]; unit_cols = std::max(unit_cols, tl <= split_cols ? tl : std::min(seg_cols, tl) + 1); }
+		const int half_words = (80 * 1024 - 1024) / 4;
+		const bool half = lds_half && lds_cols && 7 * unit_cols + 8 * 512 <= half_words;
+		A.lds_words = half ? half_words : PILE_LDS_WORDS;
 		HIP_TRY(hipFuncSetAttribute((const void *) pileup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PILE_LDS_WORDS * 4));
-		hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(PILE_THREADS), (size_t) PILE_LDS_WORDS * 4, stream, A, n_ent, lds_cols);
+		hipLaunchKernelGGL(pileup_kernel, dim3(blocks), dim3(half ? PILE_THREADS / 2 : PILE_THREADS), (size_t) A.lds_words * 4, stream, A, n_ent, lds_cols);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(stream));
 		(void) hipFree(tmp); tmp = nullptr;
 		lap("pileup_kernel");
 		HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+		if((c[1] == 16 || c[1] == 64) && half) { lds_half = false; if(dbg) fprintf(stderr, "[kmahip] pile-up: half the LDS did not hold a unit's insertion columns, again with all of it\n"); continue; }
 		if(c[1] == 64 && seg_cols > 64) { seg_cols >>= 1; if(dbg) fprintf(stderr, "[kmahip] pile-up: a segment ran out of LDS room, again with %d columns per segment\n", seg_cols); continue; }
 		if(c[1] == 16 && lds_cols) { lds_cols = 0; continue; }      // a template's insertion columns did not fit LDS: those on HBM
 		break;
