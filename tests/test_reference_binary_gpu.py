@@ -122,6 +122,71 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
     assert got.count(b"\n") > 50000
 
 
+def _fuzz_seeds():
+    e = os.environ.get("KMA_PE_FUZZ_SEEDS")          # "a:b" = range(a, b); the suite runs three
+    if e:
+        a, b = e.split(":")
+        return list(range(int(a), int(b)))
+    return [1, 2, 3]
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
+def test_paired_fuzz_equals_reference_binary(tmp_path, seed):
+    """a random database and pair set per seed: mates of ragged lengths with indels, foreign ends, N's, unmappable mates, mates the
+    quality trim removes or shortens, mates drawn from different variants of a family or from different families; maxFrag drawn
+    too. `kma -ipe r1 r2 -apm p -1t1 -t 1` against examples/kmahip_map -ipe: .res, .fsa, .frag.gz."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(1000 + seed)
+    fam, var = int(rng.integers(3, 30)), int(rng.integers(2, 9))
+    names, seqs = synth.make_gene_db(fam, var, 400, 1600, float(rng.choice([0.01, 0.03, 0.06])), seed=2000 + seed)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    n = 6000
+    a, b = _reads(seqs, n, rng), _reads(seqs, n, rng)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    with open(tmp_path / "r1.fq", "wb") as f1, open(tmp_path / "r2.fq", "wb") as f2:
+        for i in range(n):
+            u = rng.random()
+            if u < 0.7:                                   # a proper couple: mate 2 from the same template as mate 1, other strand, nearby
+                s = seqs[int(rng.integers(0, len(seqs)))]
+                L1, L2 = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+                ins = int(rng.integers(max(L1, L2), max(L1, L2) + 300))
+                st = int(rng.integers(0, max(1, len(s) - ins)))
+                frag = s[st:st + ins]
+                m1, m2 = frag[:L1].copy(), synth.revcomp_codes(frag[-L2:]).copy()
+                for m in (m1, m2):
+                    x = rng.random(len(m)) < 0.01
+                    m[x] = (m[x] + rng.integers(1, 4, int(x.sum()), dtype=np.uint8)) & 3
+                if rng.random() < 0.5:
+                    m1, m2 = m2, m1
+            elif u < 0.85:
+                m1, m2 = a[i], b[i]                        # two unrelated reads (with all of _reads' oddities)
+            else:
+                m1, m2 = a[i], synth.revcomp_codes(a[i])[:max(20, len(a[i]) // 2)].copy()      # overlapping mates
+            q1, q2 = bytearray(b"I" * len(m1)), bytearray(b"I" * len(m2))
+            v = rng.random()
+            if v < 0.05:
+                q1[8:] = b"#" * (len(q1) - 8)             # trimmed below the minimum length: mate 2 goes on as a single
+            elif v < 0.1:
+                q2[8:] = b"#" * (len(q2) - 8)
+            elif v < 0.15:
+                q1[len(q1) // 2:] = b"#" * (len(q1) - len(q1) // 2)      # shortened
+            f1.write(b"@p%d/1\n" % i + lut[m1].tobytes() + b"\n+\n" + bytes(q1) + b"\n")
+            f2.write(b"@p%d/2\n" % i + lut[m2].tobytes() + b"\n+\n" + bytes(q2) + b"\n")
+    extra = [] if seed % 3 == 0 else ["-mf", str(int(rng.integers(2, 3000)))]
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
+                   check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + extra,
+                   check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="300"))
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
+    assert got == ref
+    assert got.count(b"\n") > 3000
+
+
 def test_paired_stream_of_singles_equals_reference_binary(tmp_path):
     """`-ipe` where one mate of EVERY pair falls to the quality trim: the pair stream holds single records only (no pair batch at all
     in kmahip_run_pe), and a second run where both mates of every pair are foreign (nothing maps: empty .res, no rows)."""
