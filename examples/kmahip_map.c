@@ -86,7 +86,7 @@ int main(int argc, char **argv) {
 		FILE *f = fopen(path, "rb");
 		int32_t v, i = 0;
 		if(!f) { fprintf(stderr, "kmahip_map: cannot open %s\n", path); return 1; }
-		while(fread(&v, 4, 1, f) == 1) if(i++ > 0 && i <= D) tbases += v;
+		while(fread(&v, 4, 1, f) == 1) { if(i >= 2 && i <= D) tbases += v; ++i; }      /* [count][length of entry 0 = k][template 1] ... [template D - 1] */
 		fclose(f);
 	}
 	kmahip_run run;
@@ -94,12 +94,13 @@ int main(int argc, char **argv) {
 	run.rows = xcalloc((size_t) D, sizeof *run.rows); run.rows_cap = D;
 	run.assembly.cover = xcalloc((size_t) D, 8); run.assembly.aln_len = xcalloc((size_t) D, 8);
 	run.assembly.depth = xcalloc((size_t) D, 8); run.assembly.asm_len = xcalloc((size_t) D, 8);
-	run.assembly.consensus_cap = 2 * tbases + 4 * D + (1 << 20);
+	run.assembly.consensus_cap = 4 * tbases + 4 * D + (1 << 20);      /* template columns + insertion columns + a NUL each */
 	run.assembly.consensus = xcalloc((size_t) run.assembly.consensus_cap, 1);
 	run.assembly.consensus_off = xcalloc((size_t) D, 8);
 	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
+	run.caller = bc_nano; run.sig90 = bc_nano;      /* -bcNano (kma.c:762-766) */
 	char fpath[4096];
 	snprintf(fpath, sizeof fpath, "%s.frag.gz", out);
 	if(mt1) {

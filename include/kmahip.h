@@ -362,13 +362,15 @@ int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
  *   rows / rows_cap / n_rows   as kmahip_res_rows (KMAHIP_EOVERFLOW with n_rows = needed)
  *   assembly                   as kmahip_assemble
  *   tmpl, n_hits, rc, trace_stats   optional per-read outputs (n_reads, n_reads, n_reads, 10 * n_reads), NULL to skip
- *   ms[6]                      wall time of: upload, stages 2 + 3a, ConClave + statistics, traceback, pile-up, consensus (host) */
+ *   ms[6]                      wall time of: upload, stages 2 + 3a, ConClave + statistics, traceback, pile-up, consensus (host)
+ *   caller, sig90              IN: nanoCaller / significantAnd90Nuc for the consensus (`-bcNano`, kma.c:762-766); zero = baseCaller */
 typedef struct kmahip_run {
 	kmahip_res_row *rows;
 	int64_t rows_cap, n_rows;
 	kmahip_assembly assembly;
 	int32_t *tmpl, *n_hits, *rc, *trace_stats;
 	double ms[6];
+	int32_t caller, sig90;      /* IN, kmahip_run_se / _pe / _chain: the base caller as in kmahip_assemble_opts (`-bcNano` = 1, 1; 0, 0 = baseCaller) */
 } kmahip_run;
 int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
                   int64_t max_frag, kmahip_run *out);

@@ -96,7 +96,8 @@ class AssembleOpts(C.Structure):
 
 class Run(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_cap", C.c_int64), ("n_rows", C.c_int64), ("assembly", Assembly),
-                ("tmpl", C.c_void_p), ("n_hits", C.c_void_p), ("rc", C.c_void_p), ("trace_stats", C.c_void_p), ("ms", C.c_double * 6)]
+                ("tmpl", C.c_void_p), ("n_hits", C.c_void_p), ("rc", C.c_void_p), ("trace_stats", C.c_void_p), ("ms", C.c_double * 6),
+                ("caller", C.c_int32), ("sig90", C.c_int32)]
 
 
 class ScanStats(C.Structure):
@@ -633,7 +634,7 @@ class KmaHipDB:
             o["consensus"] = {t: raw[coff[t]:raw.index(b"\0", coff[t])].decode() for t in range(D) if coff[t] >= 0}
         return o
 
-    def run_se(self, batch, evalue=0.05, bcd=1, max_frag=0, consensus=True, per_read=True):
+    def run_se(self, batch, evalue=0.05, bcd=1, max_frag=0, consensus=True, per_read=True, bc_nano=False):
         """The whole single-end run in one call (kmahip_run_se) -> dict(rows [ResRow], cover, aln_len, depth, asm_len, consensus,
         tmpl, n_hits, rc, trace_stats, ms)"""
         n = batch.n
@@ -655,6 +656,7 @@ class KmaHipDB:
                   Assembly(_p(o["cover"]), _p(o["aln_len"]), _p(o["depth"]), _p(o["asm_len"]), None if cbuf is None else _p(cbuf),
                            None if coff is None else _p(coff), cap, 0),
                   *[(_p(pr[k]) if per_read else None) for k in ("tmpl", "n_hits", "rc", "trace_stats")])
+        run.caller = run.sig90 = 1 if bc_nano else 0
         p = Params.from_buffer_copy(self.params)
         _check(lib().kmahip_run_se(self.h, self.ws, C.byref(r), C.byref(p), float(evalue), int(bcd), int(max_frag), C.byref(run)))
         o["rows"] = [rows[i] for i in range(run.n_rows)]

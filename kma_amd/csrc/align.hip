@@ -2408,8 +2408,7 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	// matrix in HBM: for reads that carry hundreds of MEMs, or everything with KMAHIP_TRACE=pipeline (=lanes forces this kernel)
 	{
 		const char *mode = getenv("KMAHIP_TRACE");
-		// (reads with query bounds -- default-mode records -- go through this kernel whatever their length: the pipeline has no bounds yet)
-		const bool pipeline = !reads->q_start && (mode ? !strcmp(mode, "pipeline") : max_len > 1024);
+		const bool pipeline = mode ? !strcmp(mode, "pipeline") : max_len > 1024;
 		if(pipeline) return kmahip_launch_longtrace(db, ws, reads, tmpl, 0, flag, tmpl_ok, 0, p, out, nullptr, stream);
 	}
 	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;

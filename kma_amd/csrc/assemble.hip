@@ -1156,7 +1156,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 				std::vector<int64_t> coff((size_t) D, -1);
 				int64_t used = 0;
 				for(int64_t t = 1; t < D; ++t) if(out->asm_len[t] > 0) { coff[(size_t) t] = used; used += out->asm_len[t] + 1; }
-				if(out->consensus_used + used > out->consensus_cap) { kmahip_set_error("consensus_cap too small"); return KMAHIP_EOVERFLOW; }
+				if(out->consensus_used + used > out->consensus_cap) { kmahip_set_error("consensus_cap too small: %lld bytes needed, %lld given", (long long) (out->consensus_used + used), (long long) out->consensus_cap); return KMAHIP_EOVERFLOW; }
 				char *dc = nullptr;
 				int64_t *dco = nullptr;
 				HIP_TRY(hipMalloc((void **) &dc, (size_t) used + 16)); G.v.push_back(dc);
@@ -1228,7 +1228,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 		}
 		out->cover[t] = cover; out->aln_len[t] = aln_len; out->depth[t] = depth; out->asm_len[t] = asm_len;
 		if(out->consensus && out->consensus_off) {
-			if((int64_t) (out->consensus_used + cons.size() + 1) > out->consensus_cap) { kmahip_set_error("consensus_cap too small"); return KMAHIP_EOVERFLOW; }
+			if((int64_t) (out->consensus_used + cons.size() + 1) > out->consensus_cap) { kmahip_set_error("consensus_cap too small: more than %lld bytes needed", (long long) out->consensus_cap); return KMAHIP_EOVERFLOW; }
 			out->consensus_off[t] = out->consensus_used;
 			memcpy(out->consensus + out->consensus_used, cons.data(), cons.size());
 			out->consensus[out->consensus_used + cons.size()] = 0;

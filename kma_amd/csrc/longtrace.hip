@@ -83,6 +83,7 @@ struct LtArgs {
 	const int64_t *N_off;
 	const int32_t *tmpl;      // per read (batch index): signed template, or NULL: tmpl_all
 	const int32_t *rc_in;     // per read: orientation to align (NULL: both strands are seeded, anker_rc decides)
+	const int32_t *q_start, *q_end;   // query bounds per read (records of the default mode; with rc_in only), NULL: whole reads
 	const uint8_t *tmpl_ok;   // per template: align its reads? (NULL: all)
 	int tmpl_all;
 	int one2one, exhaustive;
@@ -204,9 +205,14 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
                                const uint2 *tab, uint32_t tsh, int k, int &tot, int &mem_count, int &score_r) {
 	const int lane = threadIdx.x & 63;
 	const int q_len = q.L;
-	int segS = 0;
-	for(int ni = 1; segS < q_len; ++ni) {
-		const int segE = qN_at(q, ni);              // next N (oriented), q_len behind the last one
+	// query bounds (KMA(), align.c:249-270): the scan starts at q_start; a stretch ends at the next N, the last one at q_end; a MEM
+	// is extended backwards to the N before it (or the read's first base), whatever q_start says
+	const int q_stop = qb1(q);
+	int segS = q.b0, ni = 1;
+	while(segS < q_stop) {
+		while(ni <= q.nN && qN_at(q, ni) < segS) ++ni;
+		const int segE = ni <= q.nN ? qN_at(q, ni) : q_stop;      // next N (oriented)
+		const int lowq = ni > 1 ? qN_at(q, ni - 1) + 1 : 0;
 		int cur = segS;
 		bool scanning = false;
 		int carry_pos = -2, carry_v = 0, carry_F = 0, carry_B = 0;
@@ -254,7 +260,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				int F = 0, B = 0;
 				hd[j] = -1;
 				if(v[j] > 0 && !cont) {
-					lt_extend(ts, t_len, q, p0 + idx, v[j], k, segS, segE, F, B);
+					lt_extend(ts, t_len, q, p0 + idx, v[j], k, lowq, segE, F, B);
 					hd[j] = idx;
 				} else if(cont && idx == 0) {
 					F = carry_F - 1; B = carry_B + 1;       // continues the last run of the round before
@@ -313,7 +319,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 						if(tot >= A.mcap) return false;
 						int F, B;
 						const int pos1 = dl[c];
-						lt_extend(ts, t_len, q, qs, pos1, k, segS, segE, F, B);
+						lt_extend(ts, t_len, q, qs, pos1, k, lowq, segE, F, B);
 						if(lane == 0) { Mm.qS[tot] = qs - B; Mm.tS[tot] = pos1 - B; Mm.qE[tot] = qs + F; Mm.tE[tot] = pos1 + F; Mm.w[tot] = F + B; }
 						++tot; ++mem_count;
 						bias = max(bias, qs + F);
@@ -562,6 +568,7 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 			if(A.rc_in) {
 				// orientation known (the read ConClave filed under a template): KMA()'s own seeding, one strand
 				qf.rc = (((A.rc_in[r] & 1) != 0) != (tt < 0)) ? 1 : 0;
+				q_set_bounds(qf, A.q_start, A.q_end, r);
 				int mc = 0, sc = 0;
 				room = lt_seed_strand(A, S, Mm, qf, ts, t_len, tab, tsh, k, tot, mc, sc);
 				base = 0; n = mc; H.rc = qf.rc;
@@ -1428,6 +1435,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	A.db = db->dev;
 	A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.tmpl = tmpl; A.rc_in = rc_in; A.tmpl_ok = tmpl_ok; A.tmpl_all = tmpl_all; A.one2one = one2one; A.exhaustive = p->exhaustive;
+	A.q_start = rc_in ? reads->q_start : nullptr; A.q_end = rc_in ? reads->q_end : nullptr;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
 	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;

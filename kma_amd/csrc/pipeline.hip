@@ -135,7 +135,8 @@ static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kma
 
 	// stage 3c per template
 	if(n) {
-		if((rc = kmahip_assemble_dev(db, ws, &d, h.rc, cc.tmpl, &tr, max_frag, bcd, evalue, &out->assembly))) return rc;
+		kmahip_assemble_opts ao = {max_frag, evalue, bcd, 0, out->caller, out->sig90, nullptr};      // (caller / sig90: `-bcNano`)
+		if((rc = kmahip_assemble2_dev(db, ws, &d, h.rc, cc.tmpl, &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);     // (pile-up + copy-back + consensus: kmahip_assemble_dev prints the split with KMAHIP_DEBUG_TIMING)
 
@@ -588,7 +589,7 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 
 	// stage 3c per template
 	if(nf > 0) {
-		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, 0, 0, f_rank};
+		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, out->caller, out->sig90, f_rank};
 		if((rc = kmahip_assemble2_dev(db, ws, &dF, f_rc, f_t, &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);
