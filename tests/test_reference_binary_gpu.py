@@ -245,6 +245,44 @@ def test_run_where_nothing_maps_equals_reference_binary(tmp_path, mode):
     assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read() == b""
 
 
+@pytest.mark.parametrize("mode", ["default", "-1t1"])
+def test_bcnano_without_mt1_equals_reference_binary(tmp_path, mode):
+    """`-bcNano` without `-Mt1` (the common way to run ONT reads): nanoCaller + significantAnd90Nuc in the consensus of the default mode
+    and of `-1t1`; long reads (2-6 kb, 10 % errors) whose default-mode records carry query bounds through the long-read traceback."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(31)
+    genes = [rng.integers(0, 4, int(rng.integers(3000, 9000)), dtype=np.uint8) for _ in range(12)]
+    genes += [g.copy() for g in genes[:4]]
+    for g in genes[12:]:                                   # four near-copies: ties and template choice
+        x = rng.random(len(g)) < 0.02
+        g[x] = (g[x] + rng.integers(1, 4, int(x.sum()), dtype=np.uint8)) & 3
+    names = [f"g{i}" for i in range(len(genes))]
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, genes)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = []
+    for i in range(600):
+        g = genes[int(rng.integers(0, len(genes)))]
+        r = synth.make_long_reads(g, 1, read_len=int(rng.integers(2000, min(6000, len(g)))), seed=1000 + i)[0]
+        if i % 9 == 0:                                     # a chimera: two genes in one read
+            h = genes[int(rng.integers(0, len(genes)))]
+            r = np.concatenate([r, synth.make_long_reads(h, 1, read_len=2000, seed=5000 + i)[0]])
+        reads.append(r)
+    fq = str(tmp_path / "ont.fq")
+    synth.write_fastq(fq, reads, prefix="r", qual=b"5")
+    flags = ["-1t1"] if mode == "-1t1" else []
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-bcNano", "-t", "1"] + flags, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-bcNano"] + (flags or ["-chain"]),
+                   check=True, stderr=subprocess.DEVNULL)
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    fsa = open(tmp_path / "got.fsa", "rb").read()
+    assert fsa == open(tmp_path / "ref.fsa", "rb").read() and any(c in fsa for c in b"acgt")      # (lower case: what nanoCaller leaves where depth is thin)
+    got = gzip.open(tmp_path / "got.frag.gz").read()
+    assert got == gzip.open(tmp_path / "ref.frag.gz").read() and got.count(b"\n") > 500
+
+
 def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
     """BASELINE config C4 through the C host program: `kma -i ont.fq -t_db db -Mt1 1 -bcNano -t 1` vs `kmahip_map ... -Mt1 1 -bcNano`
     on ONT-like reads (2-12 kb, 10 % errors, both strands, some with foreign chunks, N's, low-quality ends that the trim removes,

@@ -40,4 +40,4 @@ for extra in ([], ["-bcNano"]):
     same = [open(os.path.join(tmp, f"ref.{e}"), "rb").read() == open(os.path.join(tmp, f"got.{e}"), "rb").read() for e in ("res", "fsa")]
     same.append(gzip.open(os.path.join(tmp, "ref.frag.gz")).read() == gzip.open(os.path.join(tmp, "got.frag.gz")).read())
     print(f"{n} x {L} nt, default mode {extra}: reference -t 1 {t1 - t0:.1f} s, kmahip_map {t2 - t1:.2f} s; .res / .fsa / .frag.gz identical: {same} | "
-          f"{r.stderr.decode().strip().splitlines()[-1][:300]}", flush=True)
+          f"{r.stderr.decode().strip().splitlines()[-1][:300]}" + ("\n" + r.stderr.decode() if os.environ.get("KMAHIP_DEBUG_TIMING") else ""), flush=True)
