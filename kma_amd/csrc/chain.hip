@@ -661,7 +661,8 @@ int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_param
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	A.stop_after = getenv("KMAHIP_CHAIN_STOP") ? atoi(getenv("KMAHIP_CHAIN_STOP")) : 0;
 	A.exhaustive = p->exhaustive; A.minlen = cp ? cp->minlen : 16; A.coverT = cp ? cp->coverT : 0.1; A.mrs = cp ? cp->mrs : 0.5;
-	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 2048); A.s_cap = 128;
+	// (tree nodes: two per accepted chain, and a chain is minlen bases at least; 128 = 63 chains cover every read up to 1 kb)
+	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 2048); A.s_cap = std::max(128, 2 * (max_len / std::max(A.minlen, 8)) + 8);
 	A.lane_bytes = ((int64_t) 2 * A.a_cap * (int64_t) sizeof(CAnk) + (D + 1) * 8 + (int64_t) 2 * A.b_cap * 4 + (int64_t) A.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;
 	// 254 VGPRs: one wave per SIMD = 65 536 lanes resident. (Capped at 128 VGPRs for four waves per SIMD the kernel spills 1 000
 	// registers and takes as long: 2 M reads in 62 vs 68 ms. At ~2 000 scattered accesses per read that is ~65 G lines/s, the
@@ -686,7 +687,7 @@ int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_param
 	unsigned long long c[3] = {0, 0, 0};
 	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
 	*n_recs = (int64_t) c[0]; *n_T = (int64_t) c[2];
-	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (value lists of more than %d templates, or more than %d chains in a read)", A.b_cap / 2, A.s_cap / 2); return KMAHIP_EOVERFLOW; }
+	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (value lists of more than %d templates, more than %d chains in a read, or chains nested deeper than %d in the tree of covered stretches)", A.b_cap / 2, A.s_cap / 2, SEG_DEPTH); return KMAHIP_EOVERFLOW; }
 	if(c[1] == 2 || (int64_t) c[0] > rec_cap || (int64_t) c[2] > T_cap) { kmahip_set_error("record capacity: %llu records with %llu templates", c[0], c[2]); return KMAHIP_EOVERFLOW; }
 	return KMAHIP_OK;
 }
