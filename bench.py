@@ -406,6 +406,29 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
                 os.unlink(p_)
         except Exception as e:  # noqa: BLE001  (extra figure only)
             ref["paired_end"] = {"error": str(e)}
+        # long reads in the default mode with -bcNano (no -Mt1: how ONT reads are commonly run), both sides file to file
+        try:
+            rng_ = np.random.default_rng(4)
+            genome = rng_.integers(0, 4, 2_000_000, dtype=np.uint8)
+            gp = os.path.join(tmp, "g2mb")
+            synth.write_fasta(gp + ".fsa", ["genome2Mb"], [genome])
+            subprocess.run([kma, "index", "-i", gp + ".fsa", "-o", gp], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            n_long = 2000
+            lfq = os.path.join(tmp, "ont.fq")
+            synth.write_fastq(lfq, synth.make_long_reads(genome, n_long, read_len=10000, seed=8), prefix="r", qual=b"5")
+            t0 = time.perf_counter()
+            subprocess.run([kma, "-i", lfq, "-o", os.path.join(tmp, "e2e_ref_long"), "-t_db", gp, "-bcNano", "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            trl = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            subprocess.run([mapper, "-i", lfq, "-t_db", gp, "-o", got + "_long", "-chain", "-bcNano"], check=True, stderr=subprocess.DEVNULL)
+            tl = time.perf_counter() - t0
+            ref["long_default_mode"] = {"what": "2 000 ONT-like reads of 10 kb (4/3/3 % sub/del/ins) against one 2 Mb genome, default mode with -bcNano: kmahip_map -chain -bcNano "
+                                                "and the reference -bcNano -t 1, file to file",
+                                        "kmahip_map": {"wall_s": round(tl, 3), "reads_per_s": n_long / tl}, "reference_t1": {"wall_s": round(trl, 2), "reads_per_s": n_long / trl},
+                                        "res_identical_to_reference": open(got + "_long.res", "rb").read() == open(os.path.join(tmp, "e2e_ref_long.res"), "rb").read()}
+            say(f"e2e: long reads, default mode -bcNano: kmahip_map {tl:.2f} s, reference {trl:.1f} s; .res identical {ref['long_default_mode']['res_identical_to_reference']}")
+        except Exception as e:  # noqa: BLE001  (extra figure only)
+            ref["long_default_mode"] = {"error": str(e)}
         out["vs_reference_t1"] = out["plain"]["reads_per_s"] / ref["t1"]["reads_per_s"]
         out["vs_reference_best_shards"] = out["plain"]["reads_per_s"] / max(ref["shards_16"]["reads_per_s"], ref["shards_nproc"]["reads_per_s"], ref["t_nproc"]["reads_per_s"])
     for f_ in (fq, gz):
