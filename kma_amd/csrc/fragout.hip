@@ -145,7 +145,7 @@ int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *r
                           const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,
                           const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows) {
 	const int64_t S = stats_stride;         // ints per fragment in trace_stats (score, start, end, kept first)
-	if(!path || !db || !reads || !rc || !tmpl || !n_hits || !trace_stats || !read_names || !read_name_off) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(!path || !db || !reads || n < 0 || (n > 0 && (!rc || !tmpl || !n_hits || !trace_stats || !read_names || !read_name_off))) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	int e = load_names(db);
 	if(e) return e;
 	if(max_frag <= 0) max_frag = 1000000;

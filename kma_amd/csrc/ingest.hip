@@ -1034,6 +1034,7 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	batch->reads.N = in->N.data(); batch->reads.N_off = in->N_off.data();
 	batch->reads.seq_words = (int64_t) in->seq.size(); batch->reads.N_total = in->N_off.back();
 	batch->reads.max_len = max_len;
+	in->names.reserve(1); in->pair.reserve(1);          // (an empty batch still hands out pointers)
 	batch->names = in->names.data(); batch->name_off = in->name_off.data(); batch->pair = in->pair.data();
 	batch->records = records;
 	if(in->io_error && !in->io_reported && records == 0) {

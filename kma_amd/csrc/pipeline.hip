@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void pe_stats4_kernel(int64_t n, const int32_t
 
 extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
                              int64_t max_frag, const char *frag_path, kmahip_run *out) {
-	if(!db || !ws || !batch || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len || !batch->pair) {
+	if(!db || !ws || !batch || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len ||
+	   (!batch->pair && batch->reads.n_reads > 0)) {
 		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
 	}
 	const kmahip_reads &R = batch->reads;
@@ -704,7 +705,7 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
                                 const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
                                 const char *frag_path, kmahip_run *out) {
 	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	if(frag_path && (!names || !name_off)) { kmahip_set_error("the fragment file needs the read headers"); return KMAHIP_EINVAL; }
+	if(frag_path && reads && reads->n_reads > 0 && (!names || !name_off)) { kmahip_set_error("the fragment file needs the read headers"); return KMAHIP_EINVAL; }
 	const int64_t n = reads->n_reads;
 	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
 	const size_t D = db->info.DB_size;

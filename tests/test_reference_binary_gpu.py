@@ -283,6 +283,36 @@ def test_bcnano_without_mt1_equals_reference_binary(tmp_path, mode):
     assert got == gzip.open(tmp_path / "ref.frag.gz").read() and got.count(b"\n") > 500
 
 
+@pytest.mark.parametrize("mode", ["-1t1", "default", "-ipe"])
+def test_empty_input_equals_reference_binary(tmp_path, mode):
+    """a FASTQ file without a record (and one whose only record is too short to keep): the three outputs as the reference writes them"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(5, 3, 700, 900, 0.04, seed=80)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    for case, text in (("empty", b""), ("short", b"@r0\nACGTACGT\n+\nIIIIIIII\n")):
+        for f in ("r1.fq", "r2.fq"):
+            (tmp_path / f).write_bytes(text)
+        if mode == "-ipe":
+            ra = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-apm", "p", "-1t1"]
+            ga = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-1t1"]
+        else:
+            ra = ["-i", str(tmp_path / "r1.fq")] + (["-1t1"] if mode == "-1t1" else [])
+            ga = ["-i", str(tmp_path / "r1.fq"), "-1t1" if mode == "-1t1" else "-chain"]
+        r = subprocess.run([KMA] + ra + ["-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        g = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map")] + ga + ["-t_db", prefix, "-o", str(tmp_path / "got")], stderr=subprocess.PIPE)
+        assert g.returncode == 0, (case, g.stderr.decode()[-300:])
+        if r.returncode == 0 and os.path.exists(tmp_path / "ref.res"):
+            assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
+            assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), case
+            assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read() == b"", case
+        for f in ("ref.res", "ref.fsa", "ref.frag.gz", "got.res", "got.fsa", "got.frag.gz"):
+            if os.path.exists(tmp_path / f):
+                os.unlink(tmp_path / f)
+
+
 def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
     """BASELINE config C4 through the C host program: `kma -i ont.fq -t_db db -Mt1 1 -bcNano -t 1` vs `kmahip_map ... -Mt1 1 -bcNano`
     on ONT-like reads (2-12 kb, 10 % errors, both strands, some with foreign chunks, N's, low-quality ends that the trim removes,
