@@ -40,12 +40,12 @@ int load_names(kmahip_db *db) {
 struct RowBlock { std::string data; bool ready = false; };
 
 template <class Fmt>
-int write_rows(const char *path, size_t n_rows, Fmt fmt) {
+int write_rows(const char *path, size_t n_rows, size_t block_rows, Fmt fmt) {
 	const size_t plen = strlen(path);
 	const bool gz = plen > 3 && !strcmp(path + plen - 3, ".gz");
 	FILE *f = fopen(path, "wb");
 	if(!f) { kmahip_set_error("cannot create %s", path); return KMAHIP_EIO; }
-	const size_t BLOCK = 16384;
+	const size_t BLOCK = std::max<size_t>(1, std::min<size_t>(16384, block_rows));      // rows per block: some megabytes of text
 	const size_t n_blocks = (n_rows + BLOCK - 1) / BLOCK;
 	const char *e = getenv("KMAHIP_IO_THREADS");
 	const int hw = (int) std::thread::hardware_concurrency();
@@ -315,7 +315,16 @@ int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *r
 		*o++ = '\n';
 		out.resize((size_t) (o - out.data()));
 	};
-	if((e = write_rows(path, n_rows, fmt))) return e;
+	// (16 384 rows of short reads are 5 MB of text; rows of long reads are cut into blocks of about that size too, so that a few
+	// thousand 10 kb rows still keep every thread busy)
+	size_t row_bytes = 64;
+	if(n_rows) {
+		const size_t step = std::max<size_t>(1, n_rows / 1024);
+		size_t sum = 0, cnt = 0;
+		for(size_t r = 0; r < n_rows; r += step, ++cnt) sum += (size_t) reads->len[rd(row_read[r])];
+		row_bytes += sum / cnt;
+	}
+	if((e = write_rows(path, n_rows, (5u << 20) / row_bytes, fmt))) return e;
 	if(rows) *rows = (int64_t) n_rows;
 	return KMAHIP_OK;
 }
