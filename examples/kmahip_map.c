@@ -34,6 +34,16 @@ static void *ingest_main(void *arg) {
 	return NULL;
 }
 
+/* The per-read result columns (half a gigabyte for 10 M reads) come from calloc: their pages do not exist until something writes
+ * them. A thread writes them -- an atomic OR of zero per page, which changes nothing whatever the run has already copied there --
+ * while the GPU is busy with stages 2 and 3a, so that the copy at the end of the run finds the pages in place. */
+typedef struct touch_job { char *p[4]; size_t n[4]; } touch_job;
+static void *touch_main(void *arg) {
+	touch_job *j = (touch_job *) arg;
+	for(int a = 0; a < 4; ++a) for(size_t i = 0; i < j->n[a]; i += 4096) __atomic_fetch_or(&j->p[a][i], 0, __ATOMIC_RELAXED);
+	return NULL;
+}
+
 static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); exit(1); }
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) { fprintf(stderr, "kmahip_map: out of memory\n"); exit(1); } return p; }
 
@@ -101,6 +111,10 @@ int main(int argc, char **argv) {
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
 	run.caller = bc_nano; run.sig90 = bc_nano;      /* -bcNano (kma.c:762-766) */
+	touch_job tj = { { (char *) run.tmpl, (char *) run.n_hits, (char *) run.rc, (char *) run.trace_stats },
+	                 { ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n * 10 + 10) * 4 } };
+	pthread_t touch_thread;
+	const int touching = !input2 && !chain && n > 100000 && !getenv("KMAHIP_MAP_NO_TOUCH") && !pthread_create(&touch_thread, NULL, touch_main, &tj);
 	char fpath[4096];
 	snprintf(fpath, sizeof fpath, "%s.frag.gz", out);
 	if(mt1) {
@@ -115,6 +129,7 @@ int main(int argc, char **argv) {
 	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, max_frag, fpath, &run)) die("kmahip_run_pe"); }
 	else if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, max_frag, &run)) die("kmahip_run_se");
 
+	if(touching) pthread_join(touch_thread, NULL);
 	const double t_run = now_s();
 	/* out.res + out.fsa: names from <prefix>.name, one per line, in template order */
 	char path[4096], *name = xcalloc(1 << 16, 1), *line = xcalloc((1 << 16) + 512, 1);
@@ -154,8 +169,9 @@ int main(int argc, char **argv) {
 	if(!input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	const double t_frag = now_s();
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; wall: ingest %.2f s beside open %.2f (both done after %.2f), device run %.2f, .res + .fsa %.2f, .frag.gz %.2f | "
-	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f%s\n", (long long) n, (long long) frag_rows,
+	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, columns back %.1f%s\n", (long long) n, (long long) frag_rows,
 	        job.t_done - t_start, t_open - t_start, t_ingest - t_start, t_run - t_ingest, t_res - t_run, t_frag - t_res, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4],
+	        input2 || chain ? 0.0 : run.ms[5],
 	        input2 || chain ? " (the device run wrote the .frag.gz)" : "");
 	/* every output is closed; the process ends here instead of unmapping gigabytes of reads and scratch one by one
 	 * (KMAHIP_MAP_TEARDOWN=1: release everything in order, e.g. under a leak checker) */
