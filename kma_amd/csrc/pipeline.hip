@@ -60,6 +60,24 @@ double since(std::chrono::steady_clock::time_point &t) {
 	return ms;
 }
 
+// Host buffers for the per-read / per-fragment columns a run brings back: fresh from malloc their pages do not exist yet, and a copy
+// that has to fault them in one by one runs at half speed. A thread writes every page once (an atomic OR of zero: it changes nothing,
+// whatever has been copied there already) while the device is busy with the stages before the copy.
+struct HostCols {
+	std::vector<std::pair<char *, size_t>> bufs;
+	std::thread th;
+	template <class T> T *get(size_t n) {
+		T *p = (T *) malloc((n ? n : 1) * sizeof(T));
+		if(p) bufs.push_back({(char *) p, n * sizeof(T)});
+		return p;
+	}
+	void start() {
+		th = std::thread([this] { for(auto &b : bufs) for(size_t i = 0; i < b.second; i += 4096) __atomic_fetch_or(&b.first[i], 0, __ATOMIC_RELAXED); });
+	}
+	void wait() { if(th.joinable()) th.join(); }
+	~HostCols() { wait(); for(auto &b : bufs) free(b.first); }
+};
+
 // status word of the workspace after a synchronised stage (and the first counter, the pool / run top)
 int ws_status(kmahip_ws *ws, unsigned long long *c0) {
 	unsigned long long c[2];
@@ -428,6 +446,16 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	}
 	HIP_TRY(hipStreamSynchronize(s));
 	out->ms[0] = since(t);
+	// (the columns of the `.frag` rows, at most one fragment per read)
+	HostCols HC;
+	int64_t *h_src = nullptr, *h_rank = nullptr;
+	int32_t *h_rc = nullptr, *h_t = nullptr, *h_nh = nullptr, *h_stats = nullptr;
+	if(frag_path && n) {
+		h_src = HC.get<int64_t>((size_t) n); h_rank = HC.get<int64_t>((size_t) n); h_rc = HC.get<int32_t>((size_t) n); h_t = HC.get<int32_t>((size_t) n);
+		h_nh = HC.get<int32_t>((size_t) n); h_stats = HC.get<int32_t>((size_t) n * 4);
+		if(!h_src || !h_rank || !h_rc || !h_t || !h_nh || !h_stats) { kmahip_set_error("out of host memory"); return KMAHIP_ENOMEM; }
+		HC.start();
+	}
 
 	// stage 2: pairs, then the singles
 	kmahip_pe_recs recs;
@@ -597,22 +625,21 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 
 	// `.frag`: the per-fragment columns come back; the reads and their headers are the host batch's, through the fragments' read numbers
 	if(frag_path && nf > 0) {
-		// (buffers nobody has touched: a vector would write every page once before the copy does)
 		int32_t *stats4 = nullptr;
 		if((rc = B.get((size_t) nf * 4 + 4, &stats4))) return rc;
 		hipLaunchKernelGGL(pe_stats4_kernel, dim3((unsigned) ((nf + 255) / 256)), dim3(256), 0, s, nf, tr.stats, stats4);
 		HIP_TRY(hipGetLastError());
-		std::unique_ptr<int64_t[]> h_src(new int64_t[(size_t) nf]), h_rank(new int64_t[(size_t) nf]);
-		std::unique_ptr<int32_t[]> h_rc(new int32_t[(size_t) nf]), h_t(new int32_t[(size_t) nf]), h_nh(new int32_t[(size_t) nf]), h_stats(new int32_t[(size_t) nf * 4]);
-		HIP_TRY(hipMemcpy(h_src.get(), f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_rank.get(), f_rank, (size_t) nf * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_rc.get(), f_rc, (size_t) nf * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_t.get(), f_t, (size_t) nf * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_nh.get(), f_nh, (size_t) nf * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_stats.get(), stats4, (size_t) nf * 16, hipMemcpyDeviceToHost));
+		if(nf > n) { kmahip_set_error("more fragments than reads"); return KMAHIP_EDEVICE; }
+		HC.wait();
+		HIP_TRY(hipMemcpy(h_src, f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_rank, f_rank, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_rc, f_rc, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_t, f_t, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_nh, f_nh, (size_t) nf * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_stats, stats4, (size_t) nf * 16, hipMemcpyDeviceToHost));
 		stamp("fragment columns back");
 		int64_t rows = 0;
-		if((rc = kmahip_frag_write_src(frag_path, db, &R, nf, h_src.get(), h_rc.get(), h_t.get(), h_nh.get(), h_stats.get(), 4, mf + 1, 0, h_rank.get(),
+		if((rc = kmahip_frag_write_src(frag_path, db, &R, nf, h_src, h_rc, h_t, h_nh, h_stats, 4, mf + 1, 0, h_rank,
 		                               batch->names, batch->name_off, &rows))) return rc;
 	} else if(frag_path) {          // nothing filed: the file is written all the same (an empty gzip stream)
 		const int64_t none64 = 0;
@@ -782,9 +809,13 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	lap("records in stream order, record batch");
 	kmahip_cands c;
 	c.rc_flag = o_rcflag; c.flag = zero; c.T_off = T_off; c.T = o_T; c.T_cap = n_T + 1;
-	// (buffers nobody has touched: a vector would write every page once before the copy does)
-	std::unique_ptr<int32_t[]> k_tmpl(new int32_t[(size_t) m + 1]), k_nh(new int32_t[(size_t) m + 1]), k_rc(new int32_t[(size_t) m + 1]), k_stats(new int32_t[(size_t) m * 10 + 10]);
-	PerRead pr = {k_tmpl.get(), k_nh.get(), k_rc.get(), k_stats.get()};
+	HostCols H;
+	int32_t *k_tmpl = H.get<int32_t>((size_t) m + 1), *k_nh = H.get<int32_t>((size_t) m + 1), *k_rc = H.get<int32_t>((size_t) m + 1), *k_stats = H.get<int32_t>((size_t) m * 10 + 10);
+	int64_t *h_read = H.get<int64_t>((size_t) m + 1);
+	int32_t *h_emit = H.get<int32_t>((size_t) m + 1);
+	if(!k_tmpl || !k_nh || !k_rc || !k_stats || !h_read || !h_emit) { kmahip_set_error("out of host memory"); return KMAHIP_ENOMEM; }
+	if(m > 100000) H.start();
+	PerRead pr = {k_tmpl, k_nh, k_rc, k_stats};
 	if(m) {
 		if((rc = run_after_stage2(db, ws, B, d, c, n_T, p, evalue, bcd, max_frag, out, pr, t))) return rc;
 	} else {
@@ -795,13 +826,11 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	lap("stages 3a ... pile-up");
 	if(frag_path && m) {
 		// the rows are formatted from the reads as they came: a record that printed the reverse complement turns its row once more
-		std::unique_ptr<int64_t[]> h_read(new int64_t[(size_t) m]);
-		std::unique_ptr<int32_t[]> h_emit(new int32_t[(size_t) m]);
-		HIP_TRY(hipMemcpy(h_read.get(), o_read, (size_t) m * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_emit.get(), o_emit, (size_t) m * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_read, o_read, (size_t) m * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_emit, o_emit, (size_t) m * 4, hipMemcpyDeviceToHost));
 		for(int64_t x = 0; x < m; ++x) k_rc[(size_t) x] ^= h_emit[(size_t) x] & 1;
 		int64_t rows = 0;
-		if((rc = kmahip_frag_write_src(frag_path, db, reads, m, h_read.get(), k_rc.get(), k_tmpl.get(), k_nh.get(), k_stats.get(), 10, max_frag, 0, nullptr,
+		if((rc = kmahip_frag_write_src(frag_path, db, reads, m, h_read, k_rc, k_tmpl, k_nh, k_stats, 10, max_frag, 0, nullptr,
 		                               names, name_off, &rows))) return rc;
 	}
 	else if(frag_path) {          // no record: the file is written all the same (an empty gzip stream)
