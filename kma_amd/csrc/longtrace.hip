@@ -31,16 +31,18 @@ namespace {
 
 constexpr int LT_TILE = 256;          // query positions looked up per round of the seeding wavefront
 constexpr int LT_NEXT_CAP = 2048;     // MEMs of the winning strand whose chain links / chain order stay in LDS
-constexpr int LT_NCLS = 13;           // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
+constexpr int LT_NCLS = 17;           // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
                                       // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one
-                                      // lane); 9..12 = 4..7 with a move matrix too large for LDS (kept in the workgroup's HBM scratch)
+                                      // lane); 9..12 = 4..7 with a move matrix too large for LDS (kept in the workgroup's HBM scratch);
+                                      // 15, 16 = banded matrix of up to 511 / 1023 columns (8 / 16 per lane, HBM): the tails of a gene
+                                      // found in the middle of a long read (13, 14: their full-matrix counterparts, not instantiated)
 constexpr int LT_E_WAVE = 8192;       // bytes of move matrix per wavefront in lt_dp_kernel (split between its problems)
 constexpr int LT_TMAX = 127;          // template rows of a problem in lt_dp_kernel
 constexpr int LT_XE_LDS = 32768;      // bytes of move matrix in LDS per workgroup of lt_dpx_kernel
 constexpr int LT_XT_LDS = 2048;       // template rows staged in LDS there
 
 enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_TRIM = 16 };
-// counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..12] class counts,
+// counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..20] class counts,
 // [21] DP cells, [22] MEMs of the chained strands (work figures), [23] output run pool top
 enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_OUT = 23, LC_N = 24 };
 
@@ -529,6 +531,8 @@ __device__ __forceinline__ int lt_class(int q_l, int t_l, int band, int k, int64
 	const bool stale_scan = band && k == -2 && !(cfin + (band >> 1) < q_l - 1);
 	if(q_l < 256 && !stale_scan && (int64_t) pitch * (t_l + 1) <= xe_cap)
 		return ((int64_t) pitch * (t_l + 1) <= LT_XE_LDS ? 4 : 9) + (band ? 2 : 0) + (q_l <= 128 ? 0 : 1);
+	// (banded only: the full-matrix instantiations of 8 and 16 columns per lane spill scalar registers by the dozen)
+	if(band && q_l < 1024 && !stale_scan && (int64_t) pitch * (t_l + 1) <= xe_cap) return 15 + (q_l < 512 ? 0 : 1);
 	return 8;
 }
 
@@ -1170,11 +1174,13 @@ struct DpxLds {
 // them than there are, and the builds that spilled scalar registers (into lanes of a vector register) hung on gfx950.
 __device__ __forceinline__ int lt_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
 
-// one problem of class (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4) per wavefront; EHBM: the move matrix in the workgroup's HBM
-// scratch instead of LDS (a kernel of its own, not a branch: see the note at lt_walk)
+// one problem of class (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4) per wavefront (XW 8 / 16: 13 + (banded ? 2 : 0) + (XW == 16),
+// always EHBM); EHBM: the move matrix in the workgroup's HBM scratch instead of LDS (a kernel of its own, not a branch: see the note
+// at lt_walk)
 template <int XW, bool banded, bool EHBM>
 __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
-	constexpr int cls = (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4 ? 1 : 0);
+	static_assert(XW <= 4 || EHBM, "the wide classes keep their move matrix in HBM");
+	constexpr int cls = XW <= 4 ? (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4 ? 1 : 0) : 13 + (banded ? 2 : 0) + (XW == 16 ? 1 : 0);
 	__shared__ DpxLds S;
 	uint8_t *const Ebuf = EHBM ? A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow) : (uint8_t *) S.E;
 	const int lane = threadIdx.x;
@@ -1506,9 +1512,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			fflush(stderr);
 		};
 		stage("seed");
-		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu | %llu %llu %llu %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
+		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu | %llu %llu %llu %llu | %llu %llu %llu %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
 		                  c[LC_CNT], c[LC_CNT + 1], c[LC_CNT + 2], c[LC_CNT + 3], c[LC_CNT + 4], c[LC_CNT + 5], c[LC_CNT + 6], c[LC_CNT + 7], c[LC_CNT + 8],
-		                  c[LC_CNT + 9], c[LC_CNT + 10], c[LC_CNT + 11], c[LC_CNT + 12]); fflush(stderr); }
+		                  c[LC_CNT + 9], c[LC_CNT + 10], c[LC_CNT + 11], c[LC_CNT + 12], c[LC_CNT + 13], c[LC_CNT + 14], c[LC_CNT + 15], c[LC_CNT + 16]); fflush(stderr); }
 		// grids follow the queue lengths: 4 wavefronts per workgroup of lt_dp_kernel, 64 / W problems per wavefront round
 		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LC_CNT + cls] + per_wg - 1) / per_wg)); };
 		// The size classes are independent of each other: the sweeps that live in LDS run side by side on three streams, the
@@ -1539,6 +1545,8 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(c[LC_CNT + 10]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, full, HBM>"); }
 		if(c[LC_CNT + 11]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, banded, HBM>"); }
 		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, banded, HBM>"); }
+		if(c[LC_CNT + 15]) { hipLaunchKernelGGL((lt_dpx_kernel<8, true, true>), wgs(15, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<8, banded, HBM>"); }
+		if(c[LC_CNT + 16]) { hipLaunchKernelGGL((lt_dpx_kernel<16, true, true>), wgs(16, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<16, banded, HBM>"); }
 		if(!dbg) {
 			for(int x = 0; x < 3; ++x) {
 				HIP_TRY(hipEventCreateWithFlags(&join[x], hipEventDisableTiming));
