@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void walk_vsid_kernel(const uint2 *slots, uint
 	const uint32_t t = blockIdx.x + 1;
 	const int64_t g0 = cat_off[t];
 	const int tl = tlen[t];
-	for(int i = threadIdx.x; i + k <= tl; i += blockDim.x) {
+	// (blockIdx.y: a long template -- a genome -- is shared by several workgroups)
+	for(int i = threadIdx.x + blockIdx.y * blockDim.x; i + k <= tl; i += blockDim.x * gridDim.y) {
 		const int64_t g = g0 + i;
 		const int ip = (int) (g & 31) << 1;
 		uint64_t x = cat[g >> 5] << ip;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void tpos_keys_kernel(const uint64_t *cat, con
 	const uint32_t t = blockIdx.x + 1;
 	const int64_t g0 = cat_off[t];
 	const int tl = tlen[t];
-	for(int i = threadIdx.x; i < tl; i += blockDim.x) {
+	for(int i = threadIdx.x + blockIdx.y * blockDim.x; i < tl; i += blockDim.x * gridDim.y) {
 		const int64_t g = g0 + i;
 		unsigned long long key = ~0ull;
 		int32_t val = 0;
@@ -338,6 +339,9 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		   (rc = upload(db, off.data(), off.size(), &d.tseq_off))) { kmahip_db_close(db); return rc; }
 
 		stamp("probe table, presence bits, value lists, template store (built + uploaded)");
+		int max_tlen = 0;
+		for(uint32_t t = 1; t < DB_size; ++t) max_tlen = std::max(max_tlen, db->h_tlen[t]);
+		const unsigned grid_y = (unsigned) std::max(1, std::min(1024, max_tlen / 4096));      // workgroups per template in the per-position kernels
 		// Concatenated template store + per-position value-list offsets: a read that matches a template keeps
 		// matching it, so after one hash hit the scan kernel walks along `cat` (sequential 4-byte reads of
 		// vs_id) instead of probing the table for every k-mer start.
@@ -379,7 +383,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 				bad = hipMemsetAsync(d_first, 0xFF, n_slots * 4, 0) != hipSuccess || hipMemsetAsync(d_unplaced, 0, 8, 0) != hipSuccess ||
 				      hipMemsetAsync(d_vsid, 0xFF, ((size_t) total + 64) * 4, 0) != hipSuccess;
 				if(!bad && DB_size > 1) {
-					hipLaunchKernelGGL(walk_vsid_kernel, dim3(DB_size - 1), dim3(256), 0, 0, d_slots, nb_log2, d.cat, d.cat_off, d.tlen, kk, d_vsid, d_first);
+					hipLaunchKernelGGL(walk_vsid_kernel, dim3(DB_size - 1, grid_y), dim3(256), 0, 0, d_slots, nb_log2, d.cat, d.cat_off, d.tlen, kk, d_vsid, d_first);
 					hipLaunchKernelGGL(walk_repoint_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, 0, d_slots, (int64_t) n_slots, d_first, d_unplaced);
 				}
 				bad = bad || hipMemcpy(&unplaced, d_unplaced, 8, hipMemcpyDeviceToHost) != hipSuccess;
@@ -423,7 +427,7 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 			           !room((void **) &d_need, (T + 1) * 8) || !room((void **) &d_doff, (T + 1) * 8);
 			int64_t n_dups = 0;
 			if(!bad && total > 0) {
-				hipLaunchKernelGGL(tpos_keys_kernel, dim3(DB_size - 1), dim3(256), 0, 0, d.cat, d.cat_off, d.tlen, k, d_k, d_v);
+				hipLaunchKernelGGL(tpos_keys_kernel, dim3(DB_size - 1, grid_y), dim3(256), 0, 0, d.cat, d.cat_off, d.tlen, k, d_k, d_v);
 				size_t tmp_bytes = 0, tmp2 = 0;
 				bad = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_k, d_ks, d_v, d_vs, T, 0, 64, 0) != hipSuccess ||
 				      rocprim::exclusive_scan(nullptr, tmp2, d_need, d_doff, (int64_t) 0, T + 1, rocprim::plus<int64_t>(), 0) != hipSuccess;
