@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 #include <pthread.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "kmahip.h"
@@ -125,7 +126,10 @@ int main(int argc, char **argv) {
 	kmahip_default_params(&par);
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
-	if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP")) warm_up(db, ws, prefix, D, &par);
+	{	/* (worth it when stage 1 has a few hundred milliseconds of reading in front of it: inputs of 64 MB and more) */
+		struct stat sb;
+		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (64 << 20)) warm_up(db, ws, prefix, D, &par);
+	}
 	pthread_join(ingest_thread, NULL);
 	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); return 1; }
 	kmahip_ingest *ing = job.ing;
