@@ -151,13 +151,40 @@ struct alignas(128) Part {      // own cache lines: neighbouring threads push in
 
 // A piece of the decompressed input. The bytes [lo, hi) of base are data; a streamed chunk keeps room in front of lo for
 // the unfinished record of the chunk before it.
+// Buffers of streamed chunks go round: the parser hands a chunk's buffer back when its records are packed, and the inflating threads
+// take it again -- gigabytes of input pass through a few dozen buffers whose pages exist already, instead of through fresh memory that
+// the kernel has to hand out page by page.
+struct ChunkPool {
+	std::mutex mu;
+	std::vector<std::pair<uint8_t *, size_t>> spare;
+	static constexpr size_t KEEP = 48;
+	uint8_t *take(size_t cap) {
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			for(size_t i = 0; i < spare.size(); ++i) if(spare[i].second == cap) { uint8_t *p = spare[i].first; spare[i] = spare.back(); spare.pop_back(); return p; }
+		}
+		return (uint8_t *) malloc(cap ? cap : 1);
+	}
+	void give(uint8_t *p, size_t cap) {
+		if(!p) return;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if(spare.size() < KEEP && cap >= (1u << 20)) { spare.push_back({p, cap}); return; }
+		}
+		free(p);
+	}
+	void clear() { std::lock_guard<std::mutex> lk(mu); for(auto &b : spare) free(b.first); spare.clear(); }
+	~ChunkPool() { for(auto &b : spare) free(b.first); }
+};
+ChunkPool g_chunk_pool;
+
 struct Chunk {
 	uint8_t *base = nullptr;
 	size_t cap = 0, lo = 0, hi = 0;
 	bool mapped = false, last = false;
 	bool io_error = false;          // the stream ended on a read / inflate error, not at its end
 	int64_t spans_end = 0;          // records located in it end here (position in the stream of records)
-	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else free(base); }
+	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else g_chunk_pool.give(base, cap); }
 };
 
 // The input file as chunks: a plain regular file is mapped whole (one chunk); a gzip file of several members (bgzip, concatenated
@@ -233,7 +260,7 @@ struct Feeder {
 			if(!c) {
 				c = new Chunk();
 				c->cap = HEAD + CHUNK;
-				c->base = (uint8_t *) malloc(c->cap);
+				c->base = g_chunk_pool.take(c->cap);
 				if(!c->base) { ok = false; break; }
 				c->lo = c->hi = HEAD;
 			}
@@ -330,7 +357,7 @@ struct Feeder {
 		for(;;) {
 			Chunk *c = new Chunk();
 			c->cap = HEAD + CHUNK;
-			c->base = (uint8_t *) malloc(c->cap);
+			c->base = g_chunk_pool.take(c->cap);
 			c->lo = c->hi = HEAD;
 			while(c->base && c->hi < c->cap) {
 				// (in pieces: zlib drops what a call had inflated when the call ends in an error)
@@ -1062,5 +1089,7 @@ extern "C" void kmahip_ingest_close(kmahip_ingest *in) {
 	if(!in) return;
 	in->s[0].close(); in->s[1].close();
 	in->m[0].feed.close(); in->m[1].feed.close();
+	for(int m = 0; m < 2; ++m) { for(Chunk *c : in->m[m].live) delete c; in->m[m].live.clear(); }
+	g_chunk_pool.clear();
 	delete in;
 }
