@@ -126,9 +126,12 @@ int main(int argc, char **argv) {
 	kmahip_default_params(&par);
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
-	{	/* (worth it when stage 1 has a few hundred milliseconds of reading in front of it: inputs of 64 MB and more) */
+	{	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
+		 * behind a shorter input the warm-up itself would be what the run waits for) */
 		struct stat sb;
-		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (64 << 20)) warm_up(db, ws, prefix, D, &par);
+		const size_t il = strlen(input);
+		const int gz = il > 3 && !strcmp(input + il - 3, ".gz");
+		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (gz ? (128ll << 20) : (1ll << 30))) warm_up(db, ws, prefix, D, &par);
 	}
 	pthread_join(ingest_thread, NULL);
 	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); return 1; }
