@@ -20,12 +20,42 @@ def shard_bounds(n_reads: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _device(group=None):
+    """Where a collective's tensors have to live for the backend of `group`: RCCL moves device memory only (a CPU tensor
+    under nccl raises "No backend type associated with device type cpu"), gloo host memory."""
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def _place(t: torch.Tensor, group=None) -> torch.Tensor:
+    """`t` where the backend of `group` can reach it. EVERY tensor handed to a collective in this module -- inputs and
+    receive buffers -- is made by this function (tests/test_dist_gloo.py wraps the collectives and rejects any other)."""
+    dev = _device(group)
+    return t if t.device == dev else t.to(dev)
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """SUM of `t` over the ranks of `group`, returned on the device `t` came from."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    x = _place(t, group)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+    return x.to(t.device)
+
+
+def all_gather_ints(value: int, group=None):
+    """[value of rank 0, value of rank 1, ...] (a tensor collective: no pickling, placed like the others)."""
+    world = dist.get_world_size(group)
+    mine = _place(torch.tensor([int(value)], dtype=torch.int64), group)
+    out = [_place(torch.empty(1, dtype=torch.int64), group) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [int(x.cpu()) for x in out]
+
+
 def allreduce_scores(alignment_scores: torch.Tensor, uniq_alignment_scores: torch.Tensor, group=None):
     """In-place SUM over ranks of the two score vectors (int64 view of the u64 sums: exact, order-free)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    both = torch.stack([alignment_scores, uniq_alignment_scores])
-    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    both = all_reduce_sum(torch.stack([alignment_scores, uniq_alignment_scores]), group)
     alignment_scores.copy_(both[0])
     uniq_alignment_scores.copy_(both[1])
 
@@ -56,24 +86,19 @@ def template_owners(fragment_counts: np.ndarray, world: int) -> np.ndarray:
     return np.minimum(before * world // total, world - 1).astype(np.int64)
 
 
-def _device(group=None):
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-
-
 def exchange(parts, dtype, group=None):
     """parts[d] = 1-D numpy array for rank d -> list over source ranks of what they sent here (all_to_all_single with the
     sizes exchanged first)."""
     world = dist.get_world_size(group)
-    dev = _device(group)
     send = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype).ravel() for p in parts]) if world else np.zeros(0, dtype), dtype)
-    n_in = torch.tensor([len(np.asarray(p).ravel()) for p in parts], dtype=torch.int64, device=dev)
-    n_out = torch.empty(world, dtype=torch.int64, device=dev)
+    n_in = _place(torch.tensor([len(np.asarray(p).ravel()) for p in parts], dtype=torch.int64), group)
+    n_out = _place(torch.empty(world, dtype=torch.int64), group)
     dist.all_to_all_single(n_out, n_in, group=group)
     n_out_l = [int(x) for x in n_out.cpu()]
     # (torch has no unsigned 64-bit collectives: the bytes travel as they are)
-    tsend = torch.from_numpy(send.view(np.uint8).copy()).to(dev)
+    tsend = _place(torch.from_numpy(send.view(np.uint8).copy()), group)
     item = np.dtype(dtype).itemsize
-    trecv = torch.empty(sum(n_out_l) * item, dtype=torch.uint8, device=dev)
+    trecv = _place(torch.empty(sum(n_out_l) * item, dtype=torch.uint8), group)
     dist.all_to_all_single(trecv, tsend, [x * item for x in n_out_l], [int(x) * item for x in n_in.cpu()], group=group)
     flat = trecv.cpu().numpy().view(dtype)
     out, at = [], 0
@@ -83,46 +108,76 @@ def exchange(parts, dtype, group=None):
     return out
 
 
+def _csr_take(data, starts, lens):
+    """The concatenation of data[starts[i] : starts[i] + lens[i]] over i, as ONE fancy-index gather (no per-read loop)."""
+    lens = np.asarray(lens, np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, np.asarray(data).dtype)
+    before = np.cumsum(lens) - lens
+    return np.asarray(data)[np.repeat(np.asarray(starts, np.int64) - before, lens) + np.arange(total)]
+
+
+def _names_blob(names):
+    """list[bytes] -> (u8 blob, int64 offsets[n + 1]); a (blob, offsets) pair passes through."""
+    if isinstance(names, tuple):
+        return np.asarray(names[0], np.uint8), np.asarray(names[1], np.int64)
+    off = np.zeros(len(names) + 1, np.int64)
+    if len(names):
+        off[1:] = np.cumsum(np.fromiter(map(len, names), np.int64, len(names)))
+    return np.frombuffer(b"".join(names), np.uint8), off
+
+
 def gather_filed_reads(batch: ReadBatch, rc, tmpl, n_hits, traces, owner, names=None, group=None):
     """Step 3 above. Every rank passes its shard (reads, strand flags, ConClave templates, tie counts, the tuple align_trace
     returned); returns what this rank owns: (ReadBatch, rc, tmpl, n_hits, traces, frag_rank, names) with the reads in the order
-    of the global stream."""
+    of the global stream. names: list[bytes] or (u8 blob, offsets[n + 1]); it comes back as a list. All gathers are array
+    operations -- the cost is a few passes over the kept reads' bytes, not interpreter time per read."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     stats, ops_off, n_ops, ops = traces
     n = batch.n
     tmpl = np.asarray(tmpl, np.int32)
     filed = tmpl != 0
     # position among the filed fragments of the whole stream: shards are contiguous in stream order
-    counts = [None] * world
-    dist.all_gather_object(counts, int(filed.sum()), group=group)
+    counts = all_gather_ints(int(filed.sum()), group)
     base = int(sum(counts[:rank]))
     frag_rank = base + np.cumsum(filed) - filed
     kept = np.nonzero(filed & (np.asarray(stats)[:, 3] != 0))[0] if n else np.zeros(0, np.int64)
     dest = owner[np.abs(tmpl[kept])] if len(kept) else np.zeros(0, np.int64)
-    fixed, words, npos, runs, nblob = [], [], [], [], []
+    # kept reads grouped by destination, stream order inside a group (a stable sort of a few small integers)
+    order = kept[np.argsort(dest, kind="stable")]
+    per_dest = np.bincount(dest, minlength=world)[:world] if len(kept) else np.zeros(world, np.int64)
+    cut = np.zeros(world + 1, np.int64)
+    cut[1:] = np.cumsum(per_dest)
     seq_off, N_off = np.asarray(batch.seq_off, np.int64), np.asarray(batch.N_off, np.int64)
-    for d in range(world):
-        idx = kept[dest == d]
-        L = np.asarray(batch.length, np.int64)[idx]
-        nw = ((L + 31) >> 5)
-        nN = N_off[idx + 1] - N_off[idx]
-        nm = [names[i] for i in idx] if names is not None else []
-        nlen = np.array([len(x) for x in nm], np.int64) if names is not None else np.zeros(len(idx), np.int64)
-        tab = np.zeros((len(idx), 18), np.int64)
-        if len(idx):
-            tab[:, 0] = frag_rank[idx]; tab[:, 1] = L; tab[:, 2] = np.asarray(rc)[idx]; tab[:, 3] = tmpl[idx]
-            tab[:, 4] = np.asarray(n_hits)[idx]; tab[:, 5] = nN; tab[:, 6] = np.asarray(n_ops)[idx]; tab[:, 7] = nlen
-            tab[:, 8:18] = np.asarray(stats)[idx]
-        fixed.append(tab.ravel())
-        words.append(np.concatenate([batch.seq[seq_off[i]:seq_off[i] + w] for i, w in zip(idx, nw)]) if len(idx) else np.zeros(0, np.uint64))
-        npos.append(np.concatenate([batch.N[N_off[i]:N_off[i + 1]] for i in idx]) if len(idx) and int(nN.sum()) else np.zeros(0, np.int32))
-        runs.append(np.concatenate([ops[ops_off[i]:ops_off[i] + n_ops[i]] for i in idx]) if len(idx) else np.zeros(0, np.uint32))
-        nblob.append(np.frombuffer(b"".join(nm), np.uint8) if nm else np.zeros(0, np.uint8))
-    got_fixed = exchange(fixed, np.int64, group)
-    got_words = exchange(words, np.uint64, group)
-    got_npos = exchange(npos, np.int32, group)
-    got_runs = exchange(runs, np.uint32, group)
-    got_names = exchange(nblob, np.uint8, group)
+    L = np.asarray(batch.length, np.int64)[order]
+    nw = (L + 31) >> 5
+    nN = N_off[order + 1] - N_off[order]
+    nops = np.asarray(n_ops, np.int64)[order]
+    if names is not None:
+        nblob, noff = _names_blob(names)
+        nlen = noff[order + 1] - noff[order]
+    else:
+        nlen = np.zeros(len(order), np.int64)
+    tab = np.zeros((len(order), 18), np.int64)
+    if len(order):
+        tab[:, 0] = frag_rank[order]; tab[:, 1] = L; tab[:, 2] = np.asarray(rc)[order]; tab[:, 3] = tmpl[order]
+        tab[:, 4] = np.asarray(n_hits)[order]; tab[:, 5] = nN; tab[:, 6] = nops; tab[:, 7] = nlen
+        tab[:, 8:18] = np.asarray(stats)[order]
+    words = _csr_take(batch.seq, seq_off[order], nw).astype(np.uint64, copy=False)
+    npos = _csr_take(batch.N, N_off[order], nN).astype(np.int32, copy=False)
+    runs = _csr_take(ops, np.asarray(ops_off, np.int64)[order], nops).astype(np.uint32, copy=False)
+    nbytes = _csr_take(nblob, noff[order], nlen) if names is not None else np.zeros(0, np.uint8)
+
+    def cuts(per_read):
+        c = np.zeros(len(order) + 1, np.int64)
+        c[1:] = np.cumsum(per_read)
+        return [slice(int(c[cut[d]]), int(c[cut[d + 1]])) for d in range(world)]
+    got_fixed = exchange([tab[cut[d]:cut[d + 1]].ravel() for d in range(world)], np.int64, group)
+    got_words = exchange([words[s] for s in cuts(nw)], np.uint64, group)
+    got_npos = exchange([npos[s] for s in cuts(nN)], np.int32, group)
+    got_runs = exchange([runs[s] for s in cuts(nops)], np.uint32, group)
+    got_names = exchange([nbytes[s] for s in cuts(nlen)], np.uint8, group)
     tab = np.concatenate(got_fixed).reshape(-1, 18) if got_fixed else np.zeros((0, 18), np.int64)
     m = len(tab)
     L = tab[:, 1].astype(np.int32)
@@ -148,8 +203,8 @@ def gather_filed_reads(batch: ReadBatch, rc, tmpl, n_hits, traces, owner, names=
     names2 = None
     if names is not None:
         blob = np.concatenate(got_names).tobytes() if m else b""
-        ends = np.cumsum(tab[:, 7])
-        names2 = [blob[int(e - l):int(e)] for e, l in zip(ends, tab[:, 7])]
+        ends = np.cumsum(tab[:, 7]).tolist()
+        names2 = [blob[a:b] for a, b in zip([0] + ends[:-1], ends)]
     b2 = ReadBatch(seq2, seq_off2, L, N2, N_off2)
     tr2 = (np.ascontiguousarray(tab[:, 8:18], dtype=np.int32), ops_off2, tab[:, 6].astype(np.int32), ops2)
     return b2, tab[:, 2].astype(np.int32), tab[:, 3].astype(np.int32), tab[:, 4].astype(np.int32), tr2, tab[:, 0].copy(), names2
@@ -170,8 +225,7 @@ def run_se_sharded(db, batch: ReadBatch, names=None, evalue=0.05, bcd=1, max_fra
     h["uniq_alignment_scores"] = uniq.numpy().astype(np.uint64)
     cc = db.conclave_se(batch.length, T_off, h)
     per_t = torch.from_numpy(np.stack([cc[k].astype(np.int64) for k in ("w_scores", "depth", "fragment_counts", "read_counts")]))
-    if world > 1:
-        dist.all_reduce(per_t, op=dist.ReduceOp.SUM, group=group)                          # exchange 2
+    per_t = all_reduce_sum(per_t, group)                                                   # exchange 2
     w_scores = per_t[0].numpy().astype(np.uint64)
     rows = db.res_rows(w_scores, evalue=evalue)
     D = int(db.info.DB_size)
@@ -186,8 +240,7 @@ def run_se_sharded(db, batch: ReadBatch, names=None, evalue=0.05, bcd=1, max_fra
     if frag_path is not None and names2 is not None:
         frag_rows = db.frag_write2(frag_path % dist.get_rank(group), b2, rc2, tm2, nh2, tr2[0], names2, order=0, max_frag=max_frag, frag_rank=rank2)
     figs = torch.from_numpy(np.stack([asm[k].astype(np.int64) for k in ("cover", "aln_len", "depth", "asm_len")]))
-    if world > 1:
-        dist.all_reduce(figs, op=dist.ReduceOp.SUM, group=group)                           # (owners are disjoint: a gather in template order)
+    figs = all_reduce_sum(figs, group)                                                     # (owners are disjoint: a gather in template order)
     out = dict(rows=rows, owner=owner, consensus=asm.get("consensus", {}), frag_rows=frag_rows, tmpl=cc["tmpl"], depth_sum=per_t[1].numpy(),
                fragment_counts=per_t[2].numpy(), read_counts=per_t[3].numpy())
     for i, k in enumerate(("cover", "aln_len", "depth", "asm_len")):

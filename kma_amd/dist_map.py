@@ -51,7 +51,7 @@ def main():
     frag = a.o + ".frag.%d.gz"
     o = run_se_sharded(db, batch, names=names, frag_path=frag)
     cons = [None] * world
-    dist.all_gather_object(cons, o["consensus"])
+    dist.all_gather_object(cons, o["consensus"])      # (pickled; torch stages it on the current device under nccl)
     if rank == 0:
         tn = [x.rstrip("\n") for x in open(a.t_db + ".name")]
         merged = {}

@@ -35,6 +35,8 @@ def main():
     dist.init_process_group("gloo")
     from kma_amd import binding, formats
     from kma_amd.dist import run_se_sharded, shard_bounds
+    from test_dist_gloo import _guard_collectives
+    _guard_collectives()          # every collective of run_se_sharded must take tensors placed for the group's backend
     names, seqs, rag, rnames = case()
     prefix = os.path.join(out_dir, "db")
     if rank == 0:

@@ -93,10 +93,50 @@ def test_template_owners_are_contiguous_and_balanced():
     assert np.array_equal(template_owners(np.zeros(5, np.int64), 4), np.zeros(5, np.int64))
 
 
+class _Placed(torch.Tensor):
+    """marks a tensor that kma_amd.dist._place made"""
+
+
+def _guard_collectives():
+    """Every tensor a collective of kma_amd.dist receives must have been placed for the group's backend by dist._place: under
+    nccl (= RCCL) a CPU tensor raises "No backend type associated with device type cpu", which no gloo run would ever show.
+    _place is made to tag what it returns and the collectives are wrapped to reject untagged tensors."""
+    import kma_amd.dist as kd
+    place = kd._place
+    kd._place = lambda t, group=None: place(t, group).as_subclass(_Placed)
+    seen = []
+
+    def wrap(name):
+        real = getattr(dist, name)
+
+        def checked(*a, **k):
+            flat = [x for arg in list(a) + list(k.values()) for x in (arg if isinstance(arg, (list, tuple)) else [arg])]
+            ts = [x for x in flat if isinstance(x, torch.Tensor)]
+            assert ts and all(isinstance(x, _Placed) for x in ts), f"dist.{name} received a tensor that did not come from dist._place"
+            seen.append(name)
+            return real(*[x.as_subclass(torch.Tensor) if isinstance(x, _Placed) else
+                          [y.as_subclass(torch.Tensor) for y in x] if isinstance(x, list) and x and isinstance(x[0], torch.Tensor) else x for x in a], **k)
+        setattr(dist, name, checked)
+    for name in ("all_reduce", "all_gather", "all_to_all_single", "all_gather_into_tensor", "broadcast", "reduce_scatter_tensor"):
+        wrap(name)
+    return seen
+
+
 def _gather_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from kma_amd.dist import gather_filed_reads, shard_bounds as sb
+    from kma_amd.dist import all_reduce_sum, gather_filed_reads, shard_bounds as sb
+    seen = _guard_collectives()
+    # the guard itself: an unplaced tensor is refused, the helpers pass
+    try:
+        dist.all_reduce(torch.zeros(2, dtype=torch.int64))
+        raise SystemExit("the guard let an unplaced tensor through")
+    except AssertionError:
+        pass
+    assert int(all_reduce_sum(torch.tensor([rank + 1]))[0]) == world * (world + 1) // 2
+    a, u = torch.tensor([1, 2 + rank]), torch.tensor([3, 4])
+    allreduce_scores(a, u)
+    assert a.tolist() == [world, sum(2 + r for r in range(world))] and u.tolist() == [3 * world, 4 * world]
     reads, tmpl, stats, runs, names, nh, rc = _gather_case()
     lo, hi = sb(len(reads), rank, world)
     batch = formats.pack_ragged(reads[lo:hi])
@@ -109,6 +149,7 @@ def _gather_worker(rank, world, port, out):
     b, rc2, tm2, nh2, tr2, rank2, names2 = got
     np.savez(f"{out}.{rank}.npz", seq=b.seq, seq_off=b.seq_off, length=b.length, N=b.N, N_off=b.N_off, rc=rc2, tmpl=tm2, nh=nh2, stats=tr2[0],
              ops_off=tr2[1], n_ops=tr2[2], ops=tr2[3], rank=rank2, names=np.array(names2, dtype=object))
+    assert {"all_reduce", "all_gather", "all_to_all_single"} <= set(seen)
     dist.destroy_process_group()
 
 

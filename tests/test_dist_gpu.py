@@ -173,3 +173,31 @@ def test_multi_rank_host_program_writes_the_single_gpu_files(tmp_path):
     assert open(tmp_path / "one.res").read() == open(tmp_path / "two.res").read() and open(tmp_path / "one.res").read().count("\n") > 30
     assert open(tmp_path / "one.fsa").read() == open(tmp_path / "two.fsa").read()
     assert gzip.open(tmp_path / "one.frag.gz").read() == gzip.open(tmp_path / "two.frag.gz").read()
+
+
+def test_multi_rank_host_program_over_rccl_when_two_devices_are_visible(tmp_path):
+    """the same program under --backend nccl (= RCCL), one rank per device: only where the box has two (the 1-GPU test boxes skip
+    it; the placement of every collective's tensors is checked on the CPU in tests/test_dist_gloo.py)"""
+    import gzip
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_pipeline_worker as W
+    from kma_amd import formats, synth
+    names, seqs, rag, rnames = W.case()
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, rag, prefix="q")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one"), "-1t1"], check=True, stderr=subprocess.DEVNULL)
+    e = dict(os.environ, PYTHONPATH=ROOT)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "-m", "kma_amd.dist_map", "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "two"), "--backend", "nccl"]
+    r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert open(tmp_path / "one.res").read() == open(tmp_path / "two.res").read()
+    assert open(tmp_path / "one.fsa").read() == open(tmp_path / "two.fsa").read()
+    assert gzip.open(tmp_path / "one.frag.gz").read() == gzip.open(tmp_path / "two.frag.gz").read()
