@@ -71,3 +71,61 @@ def make_packed_reads(seqs, n_reads, read_len=150, sub_rate=0.005, rc_frac=0.5, 
         N_off=torch.zeros(n + 1, dtype=torch.int64, device=device),
         codes=(torch.cat(codes_keep).numpy() if codes_keep else None),
     )
+
+
+def make_long_reads_packed(genome, n_reads, read_len=10000, sub=0.04, dele=0.03, ins=0.03, rc_frac=0.5, seed=8, device="cuda",
+                           chunk=2048, keep_codes=0):
+    """ONT-like reads of one genome (SURVEY.md §8d "ONT-10k": windows of read_len bases, substitutions / deletions / insertions,
+    half of them reverse-complemented), generated and 2-bit packed on the device, returned as HOST arrays in the kmahip_reads CSR
+    layout (each read followed by one pad word): dict(seq u64, seq_off i64[n+1], length i32[n], N i32[1], N_off i64[n+1],
+    codes = the first keep_codes reads as a list of uint8 arrays -- what the reference is given as FASTQ for the parity subset).
+    Same distribution as synth.make_long_reads, not the same random stream."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    G = len(genome)
+    gen = torch.from_numpy(np.ascontiguousarray(genome)).to(device)
+    ar = torch.arange(read_len, device=device)
+    seqs, lens, codes = [], [], []
+    for c0 in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - c0)
+        st = torch.randint(0, G - read_len + 1, (m,), generator=g, device=device)
+        w = gen[st[:, None] + ar[None, :]]
+        mut = torch.rand((m, read_len), generator=g, device=device) < sub
+        w = torch.where(mut, (w + torch.randint(1, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8)) & 3, w)
+        keep = torch.rand((m, read_len), generator=g, device=device) >= dele
+        insb = (torch.rand((m, read_len), generator=g, device=device) < ins) & keep     # a random base in front of a kept base
+        cnt = keep.to(torch.int32) + insb.to(torch.int32)
+        end = torch.cumsum(cnt, 1)
+        L = end[:, -1].to(torch.int64)                                                  # read lengths
+        off = (end - cnt).to(torch.int64)
+        rc = torch.rand(m, generator=g, device=device) < rc_frac
+        nw = ((L + 31) >> 5) + 1
+        woff = torch.cumsum(nw, 0) - nw
+        flat = torch.zeros(int(nw.sum()), dtype=torch.int64, device=device)
+        pad = torch.zeros((m, int(L.max()) if keep_codes > c0 else 1), dtype=torch.uint8, device=device)
+
+        def put(sel, pos, val):
+            # base `val` of read row at read position pos (before the strand turn)
+            rows = sel.nonzero(as_tuple=True)[0]
+            q = pos[sel]
+            v = val[sel].to(torch.int64)
+            turn = rc[rows]
+            q = torch.where(turn, L[rows] - 1 - q, q)
+            v = torch.where(turn, 3 - v, v)
+            flat.index_add_(0, woff[rows] + (q >> 5), v << (62 - 2 * (q & 31)))
+            if keep_codes > c0:
+                pad[rows, q] = v.to(torch.uint8)
+        put(insb, off, torch.randint(0, 4, (m, read_len), generator=g, device=device, dtype=torch.uint8))
+        put(keep, off + insb.to(torch.int64), w)
+        seqs.append(flat.cpu().numpy().view(np.uint64))
+        lens.append(L.cpu().numpy())
+        if keep_codes > c0:
+            hp, hl = pad.cpu().numpy(), lens[-1]
+            for i in range(min(m, keep_codes - c0)):
+                codes.append(hp[i, :hl[i]].copy())
+        del w, mut, keep, insb, cnt, end, off, flat, pad
+    length = np.concatenate(lens).astype(np.int32)
+    nw = ((length.astype(np.int64) + 31) >> 5) + 1
+    seq_off = np.zeros(n_reads + 1, np.int64)
+    seq_off[1:] = np.cumsum(nw)
+    return dict(seq=np.concatenate(seqs), seq_off=seq_off, length=length, N=np.zeros(1, np.int32), N_off=np.zeros(n_reads + 1, np.int64), codes=codes)
