@@ -26,8 +26,55 @@ namespace {
 
 constexpr uint32_t NOLIST = 0xFFFFFFFFu;
 
-struct CAnk { int score, weight, score_len, len_len; unsigned start, end; uint32_t values; int descend; };
+using CAnk = KmaAnk;      // (kmahip_internal.h: the anchors of short N-free reads come from chain_anchor_kernel, scan.hip)
 struct CSeg { unsigned start, end, covered; int b0, b1; };
+
+// The reference keeps three DB_size-wide arrays per thread (Score, extendScore, include; savekmers.c:5140-5160) of which a read
+// touches the entries of its few candidate templates. Two homes for them:
+//   DenseMap  the same arrays in the lane's HBM scratch (the lane-per-read kernel that takes every read);
+//   LdsMap    a hashed table of TS entries per lane in LDS (entry (slot, lane) at slot * 64 + lane): what the fast kernel uses.
+//             A template that finds the table full sets the lane's status and the read goes to the other kernel.
+// A handle is obtained once per (anchor, template) and used for the three fields.
+struct DenseMap {
+	int *Score, *extend;
+	int8_t *include;
+	const int32_t *tlen;
+	__device__ __forceinline__ int slot(int t, int &) const { return t; }
+	__device__ __forceinline__ int TL(int h) const { return tlen[h]; }
+	__device__ __forceinline__ int &S(int h) const { return Score[h]; }
+	__device__ __forceinline__ int &E(int h) const { return extend[h]; }
+	__device__ __forceinline__ int8_t &I(int h) const { return include[h]; }
+};
+#ifndef CHAIN_LDS_TS
+#define CHAIN_LDS_TS 16
+#endif
+constexpr int LDS_TS = CHAIN_LDS_TS;       // slots per lane
+constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
+struct LdsMap {
+	uint32_t *id;
+	int *sc, *tl;              // (tl: the template's length, fetched once per read instead of once per anchor it occurs in)
+	uint16_t *ex;              // (positions of reads the fast route takes fit 16 bits)
+	int8_t *inc;
+	const int32_t *tlen;
+	int lane;
+	__device__ __forceinline__ int slot(int t, int &status) const {
+		const uint32_t h = ((uint32_t) t * 0x9E3779B1u) >> (LDS_TS == 16 ? 28 : 29);
+#pragma unroll 1
+		for(int x = 0; x < LDS_TS; ++x) {
+			const int idx = (int) ((h + x) & (LDS_TS - 1)) * 64 + lane;
+			const uint32_t cur = id[idx];
+			if(cur == (uint32_t) t) return idx;
+			if(cur == LDS_EMPTY) { id[idx] = (uint32_t) t; sc[idx] = 0; ex[idx] = 0; inc[idx] = 0; tl[idx] = tlen[t]; return idx; }
+		}
+		status = 1;
+		return (int) (h & (LDS_TS - 1)) * 64 + lane;          // (any slot: the read is given up)
+	}
+	__device__ __forceinline__ int TL(int h) const { return tl[h]; }
+	__device__ __forceinline__ int &S(int h) const { return sc[h]; }
+	__device__ __forceinline__ uint16_t &E(int h) const { return ex[h]; }
+	__device__ __forceinline__ int8_t &I(int h) const { return inc[h]; }
+	__device__ __forceinline__ void reset() const { for(int x = 0; x < LDS_TS; ++x) id[x * 64 + lane] = LDS_EMPTY; }
+};
 
 struct ChainArgs {
 	DevDB db;
@@ -39,6 +86,7 @@ struct ChainArgs {
 	const int64_t *N_off;
 	int M, MM, U, W1, Wl;
 	int exhaustive, minlen;
+	int64_t read_base;           // number of the batch's first read in the stream the records count in (the fast route works in chunks)
 	int stop_after;              // timing experiments only (KMAHIP_CHAIN_STOP): 1 = after the anchors, 2 = after the chaining
 	double coverT, mrs;
 	// scratch, one region per lane
@@ -53,11 +101,11 @@ struct ChainArgs {
 	unsigned long long *counters;   // [0] records, [1] status, [2] templates
 };
 
-struct CLane {
+template <class TM>
+struct CLaneT {
 	const DevDB *db;
 	CAnk *VF, *VR;
-	int *Score, *extend;
-	int8_t *include;
+	TM tm;
 	int *bestT, *bestT_r;
 	CSeg *tree;
 	int tree_n;
@@ -99,7 +147,7 @@ __device__ __forceinline__ uint32_t rc_kmer(const QView &qr, int pos, int k) {
 
 // ---- segment tree (seqmenttree.c), recursion unrolled by depth -------------------------------------------------------------
 template <int D> struct SegOps {
-	__device__ static unsigned add(CLane &L, int root, int node) {
+	template <class CLane> __device__ __noinline__ static unsigned add(CLane &L, int root, int node) {
 		CSeg *v = L.tree;
 		CSeg &R = v[root], &Nn = v[node];
 		if(R.b0 >= 0) {
@@ -135,7 +183,7 @@ template <int D> struct SegOps {
 		}
 		return R.covered;
 	}
-	__device__ static unsigned que(const CLane &L, int i, unsigned start, unsigned end) {
+	template <class CLane> __device__ __noinline__ static unsigned que(const CLane &L, int i, unsigned start, unsigned end) {
 		const CSeg &s = L.tree[i];
 		if(end < s.start || s.end < start) return 0;
 		if(start <= s.start && s.end <= end) return s.covered;
@@ -147,12 +195,12 @@ template <int D> struct SegOps {
 	}
 };
 template <> struct SegOps<0> {
-	__device__ static unsigned add(CLane &L, int, int) { L.status = 1; return 0; }
-	__device__ static unsigned que(const CLane &, int, unsigned, unsigned) { return 0; }
+	template <class CLane> __device__ static unsigned add(CLane &L, int, int) { L.status = 1; return 0; }
+	template <class CLane> __device__ static unsigned que(const CLane &, int, unsigned, unsigned) { return 0; }
 };
 constexpr int SEG_DEPTH = 24;
 
-__device__ void seg_grow(CLane &L, unsigned start, unsigned end) {
+template <class CLane> __device__ void seg_grow(CLane &L, unsigned start, unsigned end) {
 	if(L.s_cap <= L.tree_n + 2) { L.status = 1; return; }
 	CSeg *v = L.tree;
 	if(L.tree_n == 0) {
@@ -167,7 +215,7 @@ __device__ void seg_grow(CLane &L, unsigned start, unsigned end) {
 }
 
 // ---- chaining helpers -------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int bridge(const CLane &L, int mlen, int weight, int gaps) {
+template <class CLane> __device__ __forceinline__ int bridge(const CLane &L, int mlen, int weight, int gaps) {
 	const int k = L.k, M = L.M, MM = L.MM, U = L.U, W1 = L.W1;
 	if(gaps == -k) return weight - (k - 1) * M;
 	if(gaps == 0) return weight + MM;
@@ -189,7 +237,7 @@ __device__ __forceinline__ int bridge(const CLane &L, int mlen, int weight, int 
 
 // getBestChainTemplates: templates of the chain that ends in V[src] into bests[0 .. ]; the anchors it passes are silenced.
 // Returns the anchor the chain starts at, -1 none. `room`: slots bests may use.
-__device__ int chain_templates(CLane &L, CAnk *V, int src, int *bests, int room) {
+template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src, int *bests, int room) {
 	const DevDB &db = *L.db;
 	if(src < 0) return -1;
 	int nextAnker = 0;
@@ -200,41 +248,50 @@ __device__ int chain_templates(CLane &L, CAnk *V, int src, int *bests, int room)
 		for(int i = n; i >= 1; --i) {
 			const int t = list_at(db, V[src].values, i);
 			bests[i] = t;
-			if(++L.include[t] == 1) nextAnker = 1;
+			if(++L.tm.I(L.tm.slot(t, L.status)) == 1) nextAnker = 1;
 		}
 	}
 	const int bestScore = V[src].score;
 	int prev = src;
+	// (the anchor in hand in registers, the one below it and the head of its list asked for ahead: see the chaining loop)
+	CAnk nxt = V[src];
+	int nxt_n = nextAnker ? list_n(db, nxt.values) : 0;
 	for(int node = src; nextAnker && node >= 0; --node) {
-		const int n = list_n(db, V[node].values);
-		const int start = (int) V[node].start, end = (int) V[node].end;
+		const CAnk cur = nxt;
+		const int n = nxt_n;
+		if(node > 0) { nxt = V[node - 1]; nxt_n = list_n(db, nxt.values); }
+		const int start = (int) cur.start, end = (int) cur.end;
+		bool silenced = false;
 		for(int i = n; i >= 1; --i) {
-			const int t = list_at(db, V[node].values, i);
-			if(!L.include[t]) continue;
-			int score = L.Score[t];
-			const int pos = L.extend[t];
-			if(pos == 0) score = V[node].weight;
+			const int t = list_at(db, cur.values, i);
+			const int th = L.tm.slot(t, L.status);
+			if(!L.tm.I(th)) continue;
+			int score = L.tm.S(th);
+			const int pos = L.tm.E(th);
+			if(pos == 0) score = cur.weight;
 			else {
-				score += bridge(L, (int) db.mlen, V[node].weight, pos - end);
-				V[node].score = 0;
+				score += bridge(L, (int) db.mlen, cur.weight, pos - end);
+				silenced = true;
 			}
 			if(bestScore <= score) {
 				int tmp;
-				if(V[node].start) {
-					tmp = L.W1 + ((int) V[node].start - 1) * L.U;
+				if(start) {
+					tmp = L.W1 + (start - 1) * L.U;
 					tmp = score + (L.Wl < tmp ? tmp : L.Wl);
 				} else tmp = score;
 				if(tmp == bestScore) { score = bestScore; nextAnker = 0; prev = node; }
 			}
-			L.extend[t] = start;
-			L.Score[t] = score;
+			L.tm.E(th) = start;
+			L.tm.S(th) = score;
 		}
+		if(silenced) V[node].score = 0;
 	}
 	int j = 0;
 	for(int i = 1; i <= bests[0]; ++i) {
 		const int t = bests[i];
-		if(L.include[t] == 1 && bestScore <= L.Score[t]) bests[++j] = t;
-		L.Score[t] = 0; L.include[t] = 0; L.extend[t] = 0;
+		const int th = L.tm.slot(t, L.status);
+		if(L.tm.I(th) == 1 && bestScore <= L.tm.S(th)) bests[++j] = t;
+		L.tm.S(th) = 0; L.tm.I(th) = 0; L.tm.E(th) = 0;
 	}
 	bests[0] = j;
 	return j ? prev : -1;
@@ -302,7 +359,7 @@ __device__ int choose_chain(const CAnk &b, const CAnk &r, int cStart, int cStart
 }
 
 // anchors of one strand in forward coordinates (savekmers.c:5208-5330, 5333-5452); returns their number
-__device__ int build_ankers(CLane &L, const QView &qf, const QView &qr, int exhaustive, int is_rc, CAnk *V) {
+template <class CLane> __device__ int build_ankers(CLane &L, const QView &qf, const QView &qr, int exhaustive, int is_rc, CAnk *V) {
 	const DevDB &db = *L.db;
 	const int k = L.k, seqlen = qf.L, nN = qf.nN;
 	V[0].start = 0; V[0].end = 0; V[0].values = NOLIST; V[0].descend = -1;
@@ -385,11 +442,32 @@ struct Emit {
 	int ordinal;
 };
 
-__device__ void emit_record(CLane &L, Emit &E, int rc_flag, int emit_rc, int q_start, int q_end, const int *bt) {
+// One S2 record. The lanes of a wavefront that emit at the same moment take their slots with ONE atomic per counter: two atomics
+// per record on two addresses, as first written, ran at 17 ns a record -- 35 of the 51 ms the kernel took for 2 M reads.
+template <class CLane> __device__ void emit_record(CLane &L, Emit &E, int rc_flag, int emit_rc, int q_start, int q_end, const int *bt) {
 	const ChainArgs &A = *E.A;
 	const int nT = bt[0];
-	const unsigned long long slot = atomicAdd(&A.counters[0], 1ull);
-	const unsigned long long toff = atomicAdd(&A.counters[2], (unsigned long long) nT);
+	const int lane = (int) (threadIdx.x & 63);
+	const unsigned long long act = __ballot(1);                       // the lanes that are here together
+	const unsigned long long below = act & ((1ull << lane) - 1ull);
+	const int leader = __ffsll((long long) act) - 1;
+	// exclusive prefix and total of nT over those lanes, one ballot per bit that any of them has set
+	unsigned pre = 0, tot = 0;
+	for(int b = 0; b < 31 && __ballot((nT >> b) != 0); ++b) {
+		const unsigned long long m = __ballot((nT >> b) & 1);
+		pre += (unsigned) __popcll(m & below) << b;
+		tot += (unsigned) __popcll(m) << b;
+	}
+	unsigned long long slot0 = 0, toff0 = 0;
+	if(lane == leader) {
+		slot0 = atomicAdd(&A.counters[0], (unsigned long long) __popcll(act));
+		toff0 = atomicAdd(&A.counters[2], (unsigned long long) tot);
+	}
+	// (the first active lane is the leader: a scalar broadcast, no lane index in the instruction stream)
+	const unsigned lo0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (slot0 & 0xFFFFFFFFull)), hi0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (slot0 >> 32));
+	const unsigned lo2 = (unsigned) __builtin_amdgcn_readfirstlane((int) (toff0 & 0xFFFFFFFFull)), hi2 = (unsigned) __builtin_amdgcn_readfirstlane((int) (toff0 >> 32));
+	const unsigned long long slot = (((unsigned long long) hi0 << 32) | lo0) + (unsigned long long) __popcll(below);
+	const unsigned long long toff = (((unsigned long long) hi2 << 32) | lo2) + pre;
 	if((int64_t) slot >= A.rec_cap || (int64_t) (toff + nT) > A.T_cap) { atomicMax(&A.counters[1], 2ull); ++E.ordinal; return; }
 	int32_t *r = A.rec + 8 * slot;
 	r[0] = (int32_t) (E.read & 0xFFFFFFFFll); r[1] = (int32_t) (E.read >> 32); r[2] = E.ordinal++; r[3] = rc_flag; r[4] = emit_rc;
@@ -398,8 +476,11 @@ __device__ void emit_record(CLane &L, Emit &E, int rc_flag, int emit_rc, int q_s
 	for(int i = 0; i < nT; ++i) A.T[toff + i] = bt[1 + i];
 }
 
-__device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
-	const DevDB &db = *L.db;
+// the read's anchors are in L.VF / L.VR (hitF / hitR of them; V[0] holds start 0, end 0, descend -1 when a strand has none):
+// chaining and extraction, savekmers.c:5466-5940
+template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs &A, int64_t r, int seqlen, unsigned hitF, unsigned hitR);
+
+template <class CLane> __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 	const int k = L.k;
 	QView qf;
 	qf.w = A.seq + A.seq_off[r]; qf.L = A.len[r]; qf.N = A.N + A.N_off[r]; qf.nN = (int) (A.N_off[r + 1] - A.N_off[r]); qf.rc = 0;
@@ -407,19 +488,25 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 	const int seqlen = qf.L;
 	if(seqlen < k) return;
 	if(seqlen + 2 > L.a_cap) { L.status = 1; return; }
+	const unsigned hitF = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 0, L.VF);
+	const unsigned hitR = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 1, L.VR);
+	if(L.status || (!hitF && !hitR)) return;
+	if(A.stop_after == 1) return;
+	chain_read_tail(L, A, r, seqlen, hitF, hitR);
+}
+
+template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs &A, int64_t r, int seqlen, unsigned hitF, unsigned hitR) {
+	const DevDB &db = *L.db;
+	const int k = L.k;
 	CAnk *VF = L.VF, *VR = L.VR;
 	int *bestT = L.bestT, *bestT_r = L.bestT_r;
 	L.tree_n = 0;
-	Emit E = {&A, r, 0};
-
-	const unsigned hitF = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 0, VF);
-	const unsigned hitR = (unsigned) build_ankers(L, qf, qr, A.exhaustive, 1, VR);
-	if(L.status || (!hitF && !hitR)) return;
-	if(A.stop_after == 1) return;
+	Emit E = {&A, A.read_base + r, 0};
 
 	// chains left to right, per strand (savekmers.c:5466-5634)
 	CAnk *best = nullptr, *best_r = &VF[0];
 	unsigned ties = 0;
+	int a_min = 0x7fffffff, a_max = 0;          // every anchor of either strand lies inside [a_min, a_max)
 	VF[0].score = 0;
 	{
 		int *bests = bestT;
@@ -435,48 +522,63 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 			}
 			bests[0] = 0;
 			int vi = 0;
+			// The anchor in hand is kept in registers (its fields would be re-read from HBM behind every store otherwise), and so is
+			// what the comparisons below read of the best anchor so far; best_r points at V[0] BEFORE that anchor is chained, so the
+			// first comparison of a strand compares the anchor with itself -- an equality, which counts a tie (kept, b_idx == vi).
+			// The next anchor and the head of its value list are asked for while this one is worked on.
+			int b_idx = 0, b_score = 0, b_sl = 0, n_bests = 0;
+			CAnk nxt = V[0];
+			int nxt_n = HIT > 1 ? list_n(db, nxt.values) : 0;
 			while(--HIT) {
-				CAnk &An = V[vi];
-				const int start = (int) An.start, end = (int) An.end;
-				An.score = 0; An.score_len = 0; An.len_len = 1;
-				const int n = list_n(db, An.values);
+				const CAnk cur = nxt;
+				const int n = nxt_n;
+				if(HIT > 1) { nxt = V[vi + 1]; nxt_n = list_n(db, nxt.values); }
+				const int start = (int) cur.start, end = (int) cur.end, weight = cur.weight;
+				a_min = start < a_min ? start : a_min; a_max = end > a_max ? end : a_max;
+				int a_score = 0, a_sl = 0, a_ll = 1;
 				for(int i = n; i >= 1; --i) {
-					const int t = list_at(db, An.values, i);
-					int score = L.Score[t];
-					const int pos = L.extend[t];
-					if(!L.include[t]) {
-						L.include[t] = 1;
-						if(bests[0] + 2 > L.b_cap) { L.status = 1; return; }
-						bests[++bests[0]] = t;
+					const int t = list_at(db, cur.values, i);
+					const int th = L.tm.slot(t, L.status);
+					if(L.status) return;
+					int score = L.tm.S(th);
+					const int pos = L.tm.E(th);
+					if(!L.tm.I(th)) {
+						L.tm.I(th) = 1;
+						if(n_bests + 2 > L.b_cap) { L.status = 1; return; }
+						bests[++n_bests] = t;
 						if(start) {
 							score = L.W1 + (start - 1) * L.U;
-							score = An.weight + (L.Wl < score ? score : L.Wl);
-						} else score = An.weight;
+							score = weight + (L.Wl < score ? score : L.Wl);
+						} else score = weight;
 					} else {
-						score += bridge(L, (int) db.mlen, An.weight, start - pos);
+						score += bridge(L, (int) db.mlen, weight, start - pos);
 						if(score < 0) {
 							int test = start ? L.W1 + (start - 1) * L.U : 0;
 							if(test < L.Wl) test = L.Wl;
-							if(score < test + An.weight) score = test + An.weight;
+							if(score < test + weight) score = test + weight;
 						}
 					}
-					if(An.score < score) An.score = score;
-					int len_len = db.tlen[t];
+					if(a_score < score) a_score = score;
+					int len_len = L.tm.TL(th);
 					if(seqlen < len_len) len_len = seqlen;
 					double score_len = score;
-					if(An.len_len != len_len) { score_len /= len_len; score_len *= An.len_len; }
-					if(An.score_len < score_len || (An.score_len == score_len && An.score_len < score)) { An.score_len = score; An.len_len = len_len; }
-					L.Score[t] = score;
-					L.extend[t] = end;
+					if(a_ll != len_len) { score_len /= len_len; score_len *= a_ll; }
+					if(a_sl < score_len || (a_sl == score_len && a_sl < score)) { a_sl = score; a_ll = len_len; }
+					L.tm.S(th) = score;
+					L.tm.E(th) = end;
 				}
-				if(best_r->score < An.score) { best_r = &An; ties = 0; }
-				else if(best_r->score == An.score) {
-					if(best_r->score_len < An.score_len) { best_r = &An; ties = 0; }
-					else { best_r = &An; ++ties; }
+				V[vi].score = a_score;
+				const int c_score = b_idx == vi ? a_score : b_score, c_sl = b_idx == vi ? a_sl : b_sl;
+				if(c_score < a_score) { best_r = &V[vi]; ties = 0; }
+				else if(c_score == a_score) {
+					if(c_sl < a_sl) { best_r = &V[vi]; ties = 0; }
+					else { best_r = &V[vi]; ++ties; }
 				}
+				if(best_r == &V[vi]) { b_idx = vi; b_score = a_score; b_sl = a_sl; }
 				++vi;
 			}
-			for(int i = 1; i <= bests[0]; ++i) { const int t = bests[i]; L.Score[t] = 0; L.extend[t] = 0; L.include[t] = 0; }
+			bests[0] = n_bests;
+			for(int i = 1; i <= bests[0]; ++i) { const int th = L.tm.slot(bests[i], L.status); L.tm.S(th) = 0; L.tm.E(th) = 0; L.tm.I(th) = 0; }
 		}
 	}
 	if(best->score < k && best_r->score < k) return;
@@ -512,6 +614,7 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 		const int score = VF[bi].score > VR[bri].score ? VF[bi].score : VR[bri].score;
 		if(len < A.minlen || score < k) return;
 	}
+	if(A.stop_after == 3) return;
 	while((bi >= 0 || bri >= 0) && !L.status) {
 		if(ties) {
 			for(int side = 0; side < 2; ++side) {
@@ -522,7 +625,7 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 				int v = bidx;
 				while((v = tie_anker(V, start < vstart ? vstart : start, v, bidx)) >= 0) {
 					if((double) (unsigned) (V[v].end - (unsigned) start) < A.coverT * len) break;      // (unsigned arithmetic in the reference)
-					for(int i = 1; i <= bt[0]; ++i) { const int t = bt[i]; L.include[t] = 1; L.Score[t] = 0; L.extend[t] = 0; }
+					for(int i = 1; i <= bt[0]; ++i) { const int th = L.tm.slot(bt[i], L.status); L.tm.I(th) = 1; L.tm.S(th) = 0; L.tm.E(th) = 0; }
 					int *tail = bt + bt[0];
 					const int keep = *tail;
 					*tail = 0;
@@ -531,7 +634,7 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 					*tail = keep;
 					if(L.status) return;
 				}
-				for(int i = 1; i <= bt[0]; ++i) { const int t = bt[i]; L.include[t] = 0; L.Score[t] = 0; L.extend[t] = 0; }
+				for(int i = 1; i <= bt[0]; ++i) { const int th = L.tm.slot(bt[i], L.status); L.tm.I(th) = 0; L.tm.S(th) = 0; L.tm.E(th) = 0; }
 			}
 		}
 		if(rc) {
@@ -554,6 +657,19 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 				emit_record(L, E, VR[bri].score, 1, seqlen - (int) VR[bri].end, seqlen - start, bestT_r);
 				VR[bri].score = 0;
 				bestT_r[0] = 0;
+			}
+			// Nothing more can come once the one stretch [S, E) taken so far holds (nearly) every anchor. A later chain [cs, end) is
+			// cut out of [a_min, a_max); with S <= a_min and d = a_max - E bases beyond the stretch (an anchor closed by the next
+			// one ends k + 1 behind its last hit, the read's last anchor at its last hit, so d is a few bases):
+			//   cs < E: the overlap is min(end, E) - cs >= 1 of at most (E - cs) + d bases; it is turned down when
+			//           overlap > coverT * length, which holds for every cs once 1 - coverT > coverT * d;
+			//   cs >= E: the chain is at most d bases long, below minlen.
+			// The reference goes through every remaining anchor, walks its chain back and turns it down (savekmers.c:5860-5925);
+			// the usual read ends here.
+			if(A.stop_after == 4) return;
+			if(L.tree_n == 1 && (int) L.tree[0].start <= a_min) {
+				const int d = a_max - (int) L.tree[0].end;
+				if(d <= 0 ? (A.coverT < 1.0 && A.minlen > 0) : (d < A.minlen && 1.0 - A.coverT > A.coverT * d + 1e-9)) break;
 			}
 		}
 		// next chain of either strand (savekmers.c:5827-5925)
@@ -604,42 +720,102 @@ __device__ void chain_read(CLane &L, const ChainArgs &A, int64_t r) {
 #ifndef CHAIN_MIN_WAVES
 #define CHAIN_MIN_WAVES 2
 #endif
-__global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainArgs A) {
+// The lane-per-read kernel: every read it is given (list == NULL: all of them), anchors included, on per-lane scratch in HBM.
+// Takes what the fast pair of kernels below leaves: reads with N's, long reads, reads with more anchors or candidate templates
+// than the fast kernels' LDS tables hold.
+__global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainArgs A, const int64_t *list, int64_t n_list) {
 	const int64_t lane = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(lane >= A.lanes) return;
 	uint8_t *base = A.scratch + lane * A.lane_bytes;
 	const int64_t D = A.db.DB_size;
-	CLane L;
+	CLaneT<DenseMap> L;
 	L.db = &A.db;
 	L.VF = (CAnk *) base; base += (size_t) A.a_cap * sizeof(CAnk);
 	L.VR = (CAnk *) base; base += (size_t) A.a_cap * sizeof(CAnk);
-	L.Score = (int *) base; base += (size_t) (D + 1) * 4;
-	L.extend = (int *) base; base += (size_t) (D + 1) * 4;
+	L.tm.Score = (int *) base; base += (size_t) (D + 1) * 4;
+	L.tm.extend = (int *) base; base += (size_t) (D + 1) * 4;
 	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
 	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
 	L.tree = (CSeg *) base; base += (size_t) A.s_cap * sizeof(CSeg);
-	L.include = (int8_t *) base;
+	L.tm.include = (int8_t *) base;
+	L.tm.tlen = A.db.tlen;
+	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
+	L.a_cap = A.a_cap; L.b_cap = A.b_cap; L.s_cap = A.s_cap;
+	L.status = 0; L.tree_n = 0;
+	const int64_t total = list ? n_list : A.n_reads;
+	for(int64_t x = lane; x < total; x += A.lanes) {
+		chain_read(L, A, list ? list[x] : x);
+		if(L.status) {
+			// leave the per-template arrays clean for the next read of this lane, and say so
+			atomicMax(&A.counters[1], 40ull);
+			for(int64_t t = 0; t <= D; ++t) { L.tm.Score[t] = 0; L.tm.extend[t] = 0; L.tm.include[t] = 0; }
+			L.status = 0;
+		}
+	}
+}
+
+// The fast path, second kernel: chaining and extraction for the reads whose anchors chain_anchor_kernel (scan.hip) has built -- a
+// lane per read like chain_kernel, but the anchors come ready from a compact pool and the per-template state lives in a hashed
+// table in LDS, so a read costs a few dozen scattered accesses instead of 1 600. Per lane in HBM: two dummy anchors (a strand
+// without hits), the two template lists and the tree of covered stretches. A read that overflows the LDS table (which can only
+// happen while its anchors are chained, before anything has been written for it) is put on the list of the lane-per-read kernel.
+struct FastArgs {
+	CAnk *pool;
+	const int64_t *a_off;
+	const int32_t *a_n;
+	uint8_t *slow;
+};
+#ifndef CHAIN_FAST_WAVES
+#define CHAIN_FAST_WAVES 8
+#endif
+__global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const ChainArgs A, const FastArgs F) {
+	__shared__ uint32_t t_id[LDS_TS * 64];
+	__shared__ int t_sc[LDS_TS * 64], t_tl[LDS_TS * 64];
+	__shared__ uint16_t t_ex[LDS_TS * 64];
+	__shared__ int8_t t_inc[LDS_TS * 64];
+	const int64_t lane = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	uint8_t *base = A.scratch + lane * A.lane_bytes;
+	CLaneT<LdsMap> L;
+	L.db = &A.db;
+	CAnk *dummy = (CAnk *) base; base += 2 * sizeof(CAnk);
+	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
+	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
+	L.tree = (CSeg *) base;
+	L.tm.id = t_id; L.tm.sc = t_sc; L.tm.tl = t_tl; L.tm.ex = t_ex; L.tm.inc = t_inc; L.tm.tlen = A.db.tlen; L.tm.lane = (int) threadIdx.x;
+	L.tm.reset();
 	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
 	L.a_cap = A.a_cap; L.b_cap = A.b_cap; L.s_cap = A.s_cap;
 	L.status = 0; L.tree_n = 0;
 	for(int64_t r = lane; r < A.n_reads; r += A.lanes) {
-		chain_read(L, A, r);
-		if(L.status) {
-			// leave the per-template arrays clean for the next read of this lane, and say so
-			atomicMax(&A.counters[1], 40ull);
-			for(int64_t t = 0; t <= D; ++t) { L.Score[t] = 0; L.extend[t] = 0; L.include[t] = 0; }
-			L.status = 0;
-		}
+		if(F.slow[r]) continue;
+		const int nF = F.a_n[2 * r], nR = F.a_n[2 * r + 1];
+		if(!nF && !nR) continue;
+		for(int x = 0; x < 2; ++x) { dummy[x].start = 0; dummy[x].end = 0; dummy[x].values = NOLIST; dummy[x].descend = -1; dummy[x].score = 0; }
+		L.VF = nF ? F.pool + F.a_off[2 * r] : &dummy[0];
+		L.VR = nR ? F.pool + F.a_off[2 * r + 1] : &dummy[1];
+		chain_read_tail(L, A, r, A.len[r], (unsigned) nF, (unsigned) nR);
+		if(L.status) { F.slow[r] = 2; L.status = 0; }
+		L.tm.reset();
 	}
+}
+
+__global__ __launch_bounds__(256) void slow_list_kernel(int64_t n, const uint8_t *slow, int64_t *list, unsigned long long *count) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r < n && slow[r]) list[atomicAdd(count, 1ull)] = r;
 }
 
 }  // namespace
 
 // ---- the launch, everything in HBM: `d` holds DEVICE pointers; rec (8 ints per record: read lo, read hi, ordinal within the read,
 // rc_flag, emit_rc, q_start, q_end, number of templates), rec_T (first template of the record in T) and T are device buffers of
-// rec_cap / T_cap entries, filled in no particular order. n_recs / n_T: what the batch needs (KMAHIP_EOVERFLOW when that is more). -----
-int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec, int64_t *rec_T,
-                        int32_t *T, int64_t rec_cap, int64_t T_cap, int64_t *n_recs, int64_t *n_T) {
+// rec_cap / T_cap entries, filled in no particular order. n_recs / n_T: what the batch needs (KMAHIP_EOVERFLOW when that is more).
+// Two routes (KMAHIP_CHAIN=slow forces the second for every read; the tests compare them):
+//   fast   prefilter + chain_anchor_kernel (scan.hip: the anchors of every live strand, 16 lanes per strand) -> chain_fast_kernel
+//          (a lane per read on ready anchors, per-template state in LDS), chunks of 2 M reads through one anchor pool;
+//   slow   chain_kernel, a lane per read on DB_size-wide scratch, for the reads the fast route does not take (N's, more than 288
+//          k-mer starts, more than 64 anchors on a strand, more candidate templates than the LDS table holds). -------------------
+int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec,
+                        int64_t *rec_T, int32_t *T, int64_t rec_cap, int64_t T_cap, int64_t *n_recs, int64_t *n_T) {
 	const int64_t n = d->n_reads;
 	*n_recs = 0; *n_T = 0;
 	if(n <= 0) return KMAHIP_OK;
@@ -651,43 +827,116 @@ int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_param
 	auto t_last = std::chrono::steady_clock::now();
 	auto stamp = [&](const char *what) {
 		if(!dbg) return;
+		(void) hipDeviceSynchronize();
 		const auto now = std::chrono::steady_clock::now();
 		fprintf(stderr, "[kmahip] scan_chain: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
 		t_last = now;
 	};
+	std::vector<void *> owned;
+	struct Free { std::vector<void *> &v; ~Free() { for(void *q : v) (void) hipFree(q); } } guard{owned};
+	auto dev = [&](size_t bytes, void **out) -> int {
+		if(hipMalloc(out, bytes ? bytes : 16) != hipSuccess) { *out = nullptr; kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+		owned.push_back(*out);
+		return KMAHIP_OK;
+	};
+	auto drop = [&](void *q) { for(size_t i = 0; i < owned.size(); ++i) if(owned[i] == q) { (void) hipFree(q); owned.erase(owned.begin() + (ptrdiff_t) i); return; } };
+	int rc;
 	ChainArgs A;
 	A.db = db->dev; A.n_reads = n;
 	A.seq = d->seq; A.seq_off = d->seq_off; A.len = d->len; A.N = d->N; A.N_off = d->N_off;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	A.stop_after = getenv("KMAHIP_CHAIN_STOP") ? atoi(getenv("KMAHIP_CHAIN_STOP")) : 0;
 	A.exhaustive = p->exhaustive; A.minlen = cp ? cp->minlen : 16; A.coverT = cp ? cp->coverT : 0.1; A.mrs = cp ? cp->mrs : 0.5;
-	// (tree nodes: two per accepted chain, and a chain is minlen bases at least; 128 = 63 chains cover every read up to 1 kb)
-	A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 2048); A.s_cap = std::max(128, 2 * (max_len / std::max(A.minlen, 8)) + 8);
-	A.lane_bytes = ((int64_t) 2 * A.a_cap * (int64_t) sizeof(CAnk) + (D + 1) * 8 + (int64_t) 2 * A.b_cap * 4 + (int64_t) A.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;
-	// 254 VGPRs: one wave per SIMD = 65 536 lanes resident. (Capped at 128 VGPRs for four waves per SIMD the kernel spills 1 000
-	// registers and takes as long: 2 M reads in 62 vs 68 ms. At ~2 000 scattered accesses per read that is ~65 G lines/s, the
-	// gather ceiling of DESIGN 3.1 -- the way up is fewer scattered accesses, anchors and lists out of HBM scratch, not more lanes.)
-	int64_t lanes = getenv("KMAHIP_CHAIN_LANES") ? atoll(getenv("KMAHIP_CHAIN_LANES")) : 65536;
-	while(lanes > 64 && lanes * A.lane_bytes > (16ll << 30)) lanes >>= 1;
-	lanes = std::min<int64_t>(lanes, ((n + 63) / 64) * 64);
-	A.lanes = lanes;
-	void *scratch = nullptr, *counters = nullptr;
-	struct Free { void *&a, *&b; ~Free() { if(a) (void) hipFree(a); if(b) (void) hipFree(b); } } guard{scratch, counters};
-	if(hipMalloc(&scratch, (size_t) (lanes * A.lane_bytes)) != hipSuccess) { scratch = nullptr; kmahip_set_error("hipMalloc of %lld bytes failed", (long long) (lanes * A.lane_bytes)); return KMAHIP_ENOMEM; }
-	if(hipMalloc(&counters, KMAHIP_N_COUNTERS * 8) != hipSuccess) { counters = nullptr; kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM; }
-	HIP_TRY(hipMemsetAsync(scratch, 0, (size_t) (lanes * A.lane_bytes), 0));
+	A.read_base = 0;
+	unsigned long long *counters = nullptr;
+	if((rc = dev(KMAHIP_N_COUNTERS * 8, (void **) &counters))) return rc;
 	HIP_TRY(hipMemsetAsync(counters, 0, KMAHIP_N_COUNTERS * 8, 0));
-	A.scratch = (uint8_t *) scratch; A.counters = (unsigned long long *) counters;
+	A.counters = counters;
 	A.rec = rec; A.rec_T = rec_T; A.T = T; A.rec_cap = rec_cap; A.T_cap = T_cap;
-	if(dbg) { HIP_TRY(hipDeviceSynchronize()); stamp("scratch allocated and cleared"); }
-	hipLaunchKernelGGL(chain_kernel, dim3((unsigned) (lanes / 64)), dim3(64), 0, 0, A);
-	HIP_TRY(hipGetLastError());
+	// (tree nodes: two per accepted chain, and a chain is minlen bases at least; 128 = 63 chains cover every read up to 1 kb)
+	const int s_cap_of_len = std::max(128, 2 * (max_len / std::max(A.minlen, 8)) + 8);
+
+	const char *route = getenv("KMAHIP_CHAIN");
+	const bool all_slow = route && !strcmp(route, "slow");
+	uint8_t *slow = nullptr;
+	int64_t *slow_list = nullptr;
+	int64_t n_slow = all_slow ? n : 0;
+	if(!all_slow) {
+		constexpr int64_t CHUNK = 2000000;
+		const int64_t m_max = std::min(n, CHUNK);
+		int64_t *a_off = nullptr;
+		int32_t *a_n = nullptr;
+		unsigned long long *cnt = nullptr;
+		CAnk *pool = nullptr;
+		int64_t pool_cap = m_max * 40 + 4096;
+		if((rc = dev((size_t) n, (void **) &slow)) || (rc = dev((size_t) m_max * 16, (void **) &a_off)) || (rc = dev((size_t) m_max * 8, (void **) &a_n)) ||
+		   (rc = dev(16, (void **) &cnt)) || (rc = dev((size_t) pool_cap * sizeof(CAnk), (void **) &pool))) return rc;
+		// per-lane scratch of the fast kernel: two dummy anchors, the two template lists, the tree
+		ChainArgs Af = A;
+		Af.a_cap = 0; Af.b_cap = 2 * LDS_TS + 8; Af.s_cap = 128;
+		Af.lane_bytes = ((int64_t) 2 * (int64_t) sizeof(CAnk) + (int64_t) 2 * Af.b_cap * 4 + (int64_t) Af.s_cap * (int64_t) sizeof(CSeg) + 63) & ~63ll;
+		Af.lanes = std::min<int64_t>(256 * 16 * 64, ((m_max + 63) / 64) * 64);
+		void *fscratch = nullptr;
+		if((rc = dev((size_t) (Af.lanes * Af.lane_bytes), &fscratch))) return rc;
+		Af.scratch = (uint8_t *) fscratch;
+		stamp("fast route: buffers");
+		for(int64_t r0 = 0; r0 < n; r0 += CHUNK) {
+			const int64_t m = std::min(CHUNK, n - r0);
+			kmahip_reads v = *d;
+			v.n_reads = m; v.seq_off = d->seq_off + r0; v.len = d->len + r0; v.N_off = d->N_off + r0;
+			for(int attempt = 0;; ++attempt) {
+				if((rc = kmahip_launch_chain_anchors(db, ws, &v, p, pool, pool_cap, a_off, a_n, slow + r0, cnt, 0))) return rc;
+				unsigned long long used = 0;
+				HIP_TRY(hipMemcpy(&used, cnt, 8, hipMemcpyDeviceToHost));
+				if((int64_t) used <= pool_cap) break;
+				if(attempt >= 2) { kmahip_set_error("anchor pool: %llu anchors for %lld reads", used, (long long) m); return KMAHIP_EOVERFLOW; }
+				drop(pool);
+				pool_cap = (int64_t) used + 4096;
+				if((rc = dev((size_t) pool_cap * sizeof(CAnk), (void **) &pool))) return rc;
+			}
+			stamp("fast route: prefilter + chain_anchor_kernel");
+			ChainArgs Ac = Af;
+			Ac.n_reads = m; Ac.seq_off = v.seq_off; Ac.len = v.len; Ac.N_off = v.N_off; Ac.read_base = r0;
+			FastArgs F = {pool, a_off, a_n, slow + r0};
+			hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned) (std::min<int64_t>(Af.lanes, ((m + 63) / 64) * 64) / 64)), dim3(64), 0, 0, Ac, F);
+			HIP_TRY(hipGetLastError());
+			stamp("fast route: chain_fast_kernel");
+		}
+		drop(pool); drop(fscratch); drop(a_off); drop(a_n);
+		// what is left for the lane-per-read kernel
+		unsigned long long *cnt2 = cnt;
+		if((rc = dev((size_t) n * 8, (void **) &slow_list))) return rc;
+		HIP_TRY(hipMemsetAsync(cnt2, 0, 8, 0));
+		hipLaunchKernelGGL(slow_list_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, n, slow, slow_list, cnt2);
+		unsigned long long ns = 0;
+		HIP_TRY(hipMemcpy(&ns, cnt2, 8, hipMemcpyDeviceToHost));
+		n_slow = (int64_t) ns;
+		if(dbg) fprintf(stderr, "[kmahip] scan_chain: %lld of %lld reads left to the lane-per-read kernel\n", (long long) n_slow, (long long) n);
+	}
+	if(n_slow > 0) {
+		// every list may name all templates of the database (redundant databases: thousands share a k-mer), on either strand
+		A.a_cap = max_len + 4; A.b_cap = (int) std::min<int64_t>(2 * D + 4, 1 << 22); A.s_cap = s_cap_of_len;
+		A.lane_bytes = ((int64_t) 2 * A.a_cap * (int64_t) sizeof(CAnk) + (D + 1) * 8 + (int64_t) 2 * A.b_cap * 4 + (int64_t) A.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;
+		// 254 VGPRs: one wave per SIMD = 65 536 lanes resident. (Capped at 128 VGPRs for four waves per SIMD the kernel spills 1 000
+		// registers and takes as long.)
+		int64_t lanes = getenv("KMAHIP_CHAIN_LANES") ? atoll(getenv("KMAHIP_CHAIN_LANES")) : 65536;
+		while(lanes > 64 && lanes * A.lane_bytes > (16ll << 30)) lanes >>= 1;
+		lanes = std::min<int64_t>(lanes, ((n_slow + 63) / 64) * 64);
+		A.lanes = lanes;
+		void *scratch = nullptr;
+		if((rc = dev((size_t) (lanes * A.lane_bytes), &scratch))) return rc;
+		HIP_TRY(hipMemsetAsync(scratch, 0, (size_t) (lanes * A.lane_bytes), 0));
+		A.scratch = (uint8_t *) scratch;
+		stamp("slow route: scratch allocated and cleared");
+		hipLaunchKernelGGL(chain_kernel, dim3((unsigned) (lanes / 64)), dim3(64), 0, 0, A, (const int64_t *) slow_list, n_slow);
+		HIP_TRY(hipGetLastError());
+		stamp("slow route: chain_kernel");
+	}
 	HIP_TRY(hipDeviceSynchronize());
-	stamp("chain_kernel");
 	unsigned long long c[3] = {0, 0, 0};
 	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
 	*n_recs = (int64_t) c[0]; *n_T = (int64_t) c[2];
-	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (value lists of more than %d templates, more than %d chains in a read, or chains nested deeper than %d in the tree of covered stretches)", A.b_cap / 2, A.s_cap / 2, SEG_DEPTH); return KMAHIP_EOVERFLOW; }
+	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (more than %d chains in a read, or chains nested deeper than %d in the tree of covered stretches)", s_cap_of_len / 2, SEG_DEPTH); return KMAHIP_EOVERFLOW; }
 	if(c[1] == 2 || (int64_t) c[0] > rec_cap || (int64_t) c[2] > T_cap) { kmahip_set_error("record capacity: %llu records with %llu templates", c[0], c[2]); return KMAHIP_EOVERFLOW; }
 	return KMAHIP_OK;
 }
@@ -735,7 +984,7 @@ extern "C" int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_read
 	   (rc = dev((size_t) std::max<int64_t>(out->rec_cap, 1) * 8, (void **) &d_rec_T, nullptr, false)) ||
 	   (rc = dev((size_t) std::max<int64_t>(out->T_cap, 1) * 4, (void **) &d_T, nullptr, false))) return rc;
 	stamp("reads staged");
-	if((rc = kmahip_chain_device(db, &d, p, cp, d_rec, d_rec_T, d_T, out->rec_cap, out->T_cap, &out->n_recs, &out->n_T))) return rc;
+	if((rc = kmahip_chain_device(db, ws, &d, p, cp, d_rec, d_rec_T, d_T, out->rec_cap, out->T_cap, &out->n_recs, &out->n_T))) return rc;
 	unsigned long long c[3] = {(unsigned long long) out->n_recs, 0, (unsigned long long) out->n_T};
 	struct { int32_t *rec; int64_t *rec_T; int32_t *T; } A = {d_rec, d_rec_T, d_T};
 	t_last = std::chrono::steady_clock::now();

@@ -133,6 +133,10 @@ struct kmahip_ws {
 	size_t stage_bytes[8];
 };
 
+// an anchor of the default mode's chain finder (KmerAnker, kmeranker.h:25-34): a maximal run of k-mer starts with one value list.
+// Built by chain_anchor_kernel (scan.hip) or by the lane-per-read kernel of chain.hip, chained and taken apart in chain.hip.
+struct KmaAnk { int score, weight, score_len, len_len; unsigned start, end; uint32_t values; int descend; };
+
 void kmahip_set_error(const char *fmt, ...);
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if(e__ != hipSuccess) { \
 	kmahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return KMAHIP_EDEVICE; } } while(0)
@@ -145,6 +149,10 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
                         const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream);
 int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *tmpl, int tmpl_all, const int32_t *rc_in,
                             const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream);
+// anchors of every strand that passes the prefilter, for reads without N's and up to 288 k-mer starts (the others get slow[read] = 1):
+// a_n[2 r + strand] anchors at pool + a_off[2 r + strand]; cnt[0] = anchors written (may exceed pool_cap: repeat with a larger pool)
+int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, KmaAnk *pool, int64_t pool_cap,
+                                int64_t *a_off, int32_t *a_n, uint8_t *slow, unsigned long long *cnt, hipStream_t stream);
 double kmahip_p_chisqr(long double q);      // stdstat.c:136-147 (conclave.hip)
 int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                           kmahip_pe_recs *out, hipStream_t stream);

@@ -654,7 +654,7 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 
 // ---- the default mode (no -1t1): the chain finder's records, put in stream order and made a batch of their own on the device, then
 // every record through the stages of kmahip_run_se with its query bounds ------------------------------------------------------------
-int kmahip_chain_device(kmahip_db *db, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec, int64_t *rec_T,
+int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, const kmahip_params *p, const kmahip_chain_params *cp, int32_t *rec, int64_t *rec_T,
                         int32_t *T, int64_t rec_cap, int64_t T_cap, int64_t *n_recs, int64_t *n_T);                            // chain.hip
 
 namespace {
@@ -761,7 +761,7 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	int64_t rec_cap = 2 * n + 1024, T_cap = 16 * n + 4096, m = 0, n_T = 0;
 	for(int attempt = 0; n > 0; ++attempt) {
 		if((rc = B.get((size_t) rec_cap * 8, &rec)) || (rc = B.get((size_t) rec_cap, &rec_T)) || (rc = B.get((size_t) T_cap, &T))) return rc;
-		rc = kmahip_chain_device(db, &dR, p, cp, rec, rec_T, T, rec_cap, T_cap, &m, &n_T);
+		rc = kmahip_chain_device(db, ws, &dR, p, cp, rec, rec_T, T, rec_cap, T_cap, &m, &n_T);
 		if(rc == KMAHIP_EOVERFLOW && attempt < 3 && (m > rec_cap || n_T > T_cap)) {
 			rec_cap = std::max(rec_cap, m + 16); T_cap = std::max(T_cap, n_T + 16);
 			continue;

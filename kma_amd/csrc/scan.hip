@@ -1208,6 +1208,207 @@ __global__ __launch_bounds__(CB) void rec_write_kernel(const int32_t *cnt, const
 	for(int64_t i = 0; i < c; ++i) out[beg + i] = src[so + i];
 }
 
+
+// ---- anchors of the default mode's chain finder, side by side (save_kmers_chain, savekmers.c:5208-5452; the sequential form is
+// build_ankers in chain.hip) ---------------------------------------------------------------------------------------------------
+// An anchor is a maximal run of k-mer starts whose value list is the same as that of the hit before them, at a distance of 0 or
+// exactly k missed starts. One workgroup = 16 strand items that passed the prefilter x 16 lanes:
+//   1. every lane resolves the value list of its 9 k-mer starts per pass with the anchor + walk of scan_se_kernel and leaves the
+//      list offsets in LDS, indexed by FORWARD read position (the reverse strand's anchors are counted in forward coordinates);
+//   2. the 16 lanes of an item (one DPP row now) turn them into anchors: the hit before a lane's segment by a "last non-empty"
+//      scan across the row, open / continue per hit, the anchor numbers by a prefix sum of the opens, weights and last hits by LDS
+//      atomics (a run may span several lanes);
+//   3. the anchors go to a device-wide pool, one allocation per workgroup.
+// Reads with N's (where the reference's reverse strand restarts k bases off, savekmers.c:5447-5449), with more than CA_NPMAX k-mer
+// starts or more than CA_AMAX anchors on a strand are left to the lane-per-read kernel of chain.hip (slow[read] = 1).
+constexpr int CA_SEG = 9, CA_PASS = GROUP * CA_SEG, CA_NPMAX = 2 * CA_PASS, CA_AMAX = 64, CA_WORDS = 12, CA_VSTRIDE = CA_NPMAX + 1;
+
+struct AnchorArgs {
+	ScanArgs S;
+	KmaAnk *pool;
+	int64_t pool_cap;
+	int64_t *a_off;
+	int32_t *a_n;
+	uint8_t *slow;
+	unsigned long long *cnt;      // [0] anchors allocated
+};
+
+__global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorArgs A) {
+	__shared__ uint32_t s_val[GROUP * CA_VSTRIDE];          // value list per forward k-mer start (MISS: none), row stride odd
+	__shared__ uint64_t s_w[GROUP * CA_WORDS];              // the read in strand orientation
+	__shared__ uint32_t a_val[CA_AMAX * GROUP], a_start[CA_AMAX * GROUP], a_last[CA_AMAX * GROUP];
+	__shared__ int32_t a_w[CA_AMAX * GROUP];
+	__shared__ int32_t s_npos[GROUP], s_cnt[GROUP], s_off[GROUP];
+	__shared__ int64_t s_item[GROUP];
+	__shared__ unsigned long long s_base;
+	const ScanArgs &S = A.S;
+	const DevDB &db = S.db;
+	const int tid = threadIdx.x, k = (int) db.kmersize;
+	const int64_t n_active = (int64_t) S.counters[C_NACT];
+	const int64_t first = (int64_t) blockIdx.x * GROUP;
+	if(first >= n_active) return;
+	const int ng = (int) min((int64_t) GROUP, n_active - first);
+	for(int i = tid; i < CA_AMAX * GROUP; i += THREADS) { a_w[i] = 0; a_last[i] = 0; }
+	{
+		// phase 1 layout: item g = tid & 15, lane sl = tid >> 4 (as in scan_se_kernel: a wave's gathers belong to 16 reads)
+		const int g = tid & (GROUP - 1), sl = tid / GROUP;
+		int64_t item = 0, r = 0, so = 0;
+		int L = 0, npos = 0, strand = 0;
+		bool live = g < ng;
+		if(live) {
+			item = S.in_items[first + g];
+			r = item >> 1; strand = (int) (item & 1);
+			L = S.len[r]; npos = L - k + 1; so = S.seq_off[r];
+			if(S.N_off[r + 1] != S.N_off[r] || npos > CA_NPMAX || npos <= 0) { if(sl == 0) A.slow[r] = 1; live = false; }
+		}
+		if(sl == 0) { s_npos[g] = live ? npos : 0; s_item[g] = item; }
+		if(sl < CA_WORDS) {
+			uint64_t v = 0;
+			if(live && sl < ((L + 31) >> 5)) v = strand ? strand_win(S.seq + so, L, 1, sl << 5) : S.seq[so + sl];
+			s_w[g * CA_WORDS + sl] = v;
+		}
+		__syncthreads();
+		const uint64_t *wsrc = &s_w[g * CA_WORDS];
+		uint32_t *vrow = &s_val[g * CA_VSTRIDE];
+		auto put = [&](int p, uint32_t vi) { vrow[strand ? npos - 1 - p : p] = vi; };
+		for(int c0 = 0; c0 < CA_NPMAX; c0 += CA_PASS) {
+			const int j0 = c0 + sl * CA_SEG, j1 = j0 + CA_SEG;
+			if(!live || j0 >= npos) continue;
+			int jj = j0;
+			bool pairs = false;
+			while(jj < j1 && jj < npos) {
+				int p = jj;
+				const uint64_t km = kmer_from(wsrc[p >> 5], wsrc[(p >> 5) + 1], p, k);
+				uint32_t gp;
+				if(pairs && jj + 1 < j1 && p + 1 < npos) {
+					const uint64_t km2 = kmer_from(wsrc[(p + 1) >> 5], wsrc[((p + 1) >> 5) + 1], p + 1, k);
+					uint32_t gp2;
+					probe2(db, (uint32_t) km, (uint32_t) km2, gp, gp2);
+					if(gp == MISS) {
+						put(p, MISS);
+						if(gp2 == MISS) { put(p + 1, MISS); jj += 2; continue; }
+						gp = gp2; ++jj; ++p;
+					}
+				} else gp = probe(db, (uint32_t) km);
+				if(gp == MISS) { put(p, MISS); ++jj; pairs = true; continue; }
+				constexpr int WALK = CA_SEG - 1;
+				uint32_t vv[WALK + 1];
+				const uint32_t *vp = db.vs_id + gp;
+#pragma unroll
+				for(int i = 0; i <= WALK; ++i) vv[i] = vp[i];
+				const uint64_t tw = win2(db.cat, (int64_t) gp + k);
+				const uint64_t qw = win2(wsrc, p + k);
+				int run = 0;
+				const int room = min(j1 - jj - 1, npos - (p + 1));
+				if(room > 0) {
+					const uint64_t x = qw ^ tw;
+					const int same = x ? (__clzll((long long) x) >> 1) : 32;
+					run = min(room, same);
+#pragma unroll
+					for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
+				}
+#pragma unroll
+				for(int i = 0; i <= WALK; ++i) if(i <= run) put(p + i, vv[i]);
+				jj += run + 1;
+				pairs = true;
+			}
+		}
+	}
+	__syncthreads();
+	// phase 2 layout: item gi = tid >> 4, lane ln = tid & 15 (the lanes of an item are one DPP row)
+	const int gi = tid >> 4, ln = tid & 15;
+	const int npos = s_npos[gi];              // 0: nothing to do for this item
+	const uint32_t *vrow = &s_val[gi * CA_VSTRIDE];
+	int carry_h = -1, carry_cnt = 0;
+	uint32_t carry_v = MISS;
+	for(int c0 = 0; c0 < CA_NPMAX; c0 += CA_PASS) {
+		const int j0 = c0 + ln * CA_SEG;
+		uint32_t v[CA_SEG];
+		int lh = -1;
+		uint32_t lv = MISS;
+#pragma unroll
+		for(int i = 0; i < CA_SEG; ++i) {
+			v[i] = (j0 + i < npos) ? vrow[j0 + i] : MISS;
+			if(v[i] != MISS) { lh = j0 + i; lv = v[i]; }
+		}
+		// the last hit at or before each lane's segment (inclusive scan of "last non-empty"), then the one before it
+		int h = lh;
+		uint32_t hv = lv;
+#pragma unroll
+		for(int d = 1; d < 16; d <<= 1) {
+			const int oh = __shfl_up(h, d, 16);
+			const uint32_t ov = __shfl_up(hv, d, 16);
+			if(ln >= d && h < 0) { h = oh; hv = ov; }
+		}
+		int ph = __shfl_up(h, 1, 16);
+		uint32_t pv = __shfl_up(hv, 1, 16);
+		if(ln == 0 || ph < 0) { ph = carry_h; pv = carry_v; }
+		// open / continue per hit (savekmers.c:5262-5300: the same list as the hit before, 0 or exactly k starts missed in between)
+		int opens = 0, th = ph;
+		uint32_t tv = pv, code = 0;
+#pragma unroll
+		for(int i = 0; i < CA_SEG; ++i) {
+			if(v[i] == MISS) continue;
+			const int j = j0 + i;
+			uint32_t c = 1;
+			if(th >= 0 && v[i] == tv) { const int gaps = j - th - 1; if(gaps == 0) c = 2; else if(gaps == k) c = 3; }
+			if(c == 1) ++opens;
+			code |= c << (2 * i);
+			th = j; tv = v[i];
+		}
+		int inc = opens;
+#pragma unroll
+		for(int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(inc, d, 16); if(ln >= d) inc += o; }
+		int idx = carry_cnt + inc - opens - 1;
+#pragma unroll
+		for(int i = 0; i < CA_SEG; ++i) {
+			const uint32_t c = (code >> (2 * i)) & 3u;
+			if(!c) continue;
+			const int j = j0 + i;
+			if(c == 1) {
+				++idx;
+				if(idx < CA_AMAX) { a_start[idx * GROUP + gi] = (uint32_t) j; a_val[idx * GROUP + gi] = v[i]; atomicAdd(&a_w[idx * GROUP + gi], k * S.M); atomicMax(&a_last[idx * GROUP + gi], (uint32_t) j); }
+			} else if(idx < CA_AMAX) {
+				atomicAdd(&a_w[idx * GROUP + gi], c == 2 ? S.M : k * S.M + S.MM);
+				atomicMax(&a_last[idx * GROUP + gi], (uint32_t) j);
+			}
+		}
+		carry_cnt += __shfl(inc, 15, 16);
+		const int eh = __shfl(h, 15, 16);
+		const uint32_t ev = __shfl(hv, 15, 16);
+		if(eh >= 0) { carry_h = eh; carry_v = ev; }
+	}
+	const int n = carry_cnt;
+	const bool over = n > CA_AMAX;
+	if(ln == 0) s_cnt[gi] = over ? 0 : n;
+	__syncthreads();
+	if(tid == 0) {
+		int tot = 0;
+		for(int x = 0; x < GROUP; ++x) { s_off[x] = tot; tot += s_cnt[x]; }
+		s_base = tot ? atomicAdd(&A.cnt[0], (unsigned long long) tot) : 0ull;
+	}
+	__syncthreads();
+	if(npos <= 0 || gi >= ng) return;
+	const int64_t item = s_item[gi];
+	if(over) { if(ln == 0) A.slow[item >> 1] = 1; return; }
+	const int64_t off = (int64_t) s_base + s_off[gi];
+	if(ln == 0) { A.a_off[item] = off; A.a_n[item] = n; }
+	if(off + n > A.pool_cap) return;          // (the host sees cnt[0] > pool_cap and repeats with a larger pool)
+	const int L = npos + k - 1;
+	(void) L;
+	for(int i = ln; i < n; i += 16) {
+		KmaAnk a;
+		const uint32_t last = a_last[i * GROUP + gi];
+		a.score = 0; a.weight = a_w[i * GROUP + gi]; a.score_len = 0; a.len_len = 0;
+		a.start = a_start[i * GROUP + gi];
+		// an anchor closed by the next one ends behind its last hit's k-mer + 1 (j - gaps + k at the opening hit j); the last one
+		// at seqlen - gaps with the k missed starts of the read's end counted in: its last hit (savekmers.c:5316-5330)
+		a.end = i < n - 1 ? last + 1u + (uint32_t) k : last;
+		a.values = a_val[i * GROUP + gi];
+		a.descend = i < n - 1 ? i + 1 : -1;
+		A.pool[off + i] = a;
+	}
+}
 } // namespace
 
 static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
@@ -1303,6 +1504,35 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	hipLaunchKernelGGL(combine_count_kernel, dim3(cgrid), dim3(CB), 0, stream, A, out->rc_flag, out->flag, out->T_off, ws->blk_sums);
 	hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, ws->blk_sums, (int64_t) cgrid);
 	hipLaunchKernelGGL(combine_write_kernel, dim3(cgrid), dim3(CB), 0, stream, A, out->rc_flag, out->flag, out->T_off, ws->blk_sums, out->T, out->T_cap);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}
+
+int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, KmaAnk *pool, int64_t pool_cap,
+                                int64_t *a_off, int32_t *a_n, uint8_t *slow, unsigned long long *cnt, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	if(n <= 0 || !p) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
+	int rc = ws_reserve(ws, n);
+	if(rc) return rc;
+	AnchorArgs A;
+	ScanArgs &S = A.S;
+	S.db = db->dev;
+	S.n_reads = n; S.seq = reads->seq; S.seq_off = reads->seq_off; S.len = reads->len; S.N = reads->N; S.N_off = reads->N_off;
+	S.M = p->rw.M; S.MM = p->rw.MM; S.U = p->rw.U; S.W1 = p->rw.W1; S.exhaustive = p->exhaustive;
+	S.item_score = ws->item_score; S.item_n = ws->item_n; S.item_off = ws->item_off;
+	S.pool = ws->pool; S.pool_cap = ws->pool_cap; S.counters = ws->counters; S.overflow_items = ws->overflow_items;
+	S.dense = ws->dense; S.dense_slots = ws->dense_slots; S.active_items = ws->active_items;
+	S.mode = 0; S.pool_sc = nullptr; S.pool_tail0 = 2 * n * INL; S.ablate = 0;
+	S.in_items = ws->active_items; S.in_count = C_NACT; S.out_over = ws->overflow_items; S.out_count = C_NOVER;
+	A.pool = pool; A.pool_cap = pool_cap; A.a_off = a_off; A.a_n = a_n; A.slow = slow; A.cnt = cnt;
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(a_n, 0, (size_t) n * 2 * sizeof(int32_t), stream));
+	HIP_TRY(hipMemsetAsync(slow, 0, (size_t) n, stream));
+	HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), stream));
+	const int64_t items = 2 * n;
+	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((items + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, S);
+	hipLaunchKernelGGL(chain_anchor_kernel, dim3((unsigned) ((items + GROUP - 1) / GROUP)), dim3(THREADS), 0, stream, A);
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
 }
