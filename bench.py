@@ -430,7 +430,7 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
             walls = []
             for _ in range(2):
                 t0 = time.perf_counter()
-                r = subprocess.run([mapper, "-ipe", r1, r2, "-t_db", prefix, "-o", got + "_pe", "-1t1"], stderr=subprocess.PIPE)
+                r = subprocess.run([mapper, "-ipe", r1, r2, "-t_db", prefix, "-o", got + "_pe", "-1t1", "-apm", "p"], stderr=subprocess.PIPE)
                 walls.append(time.perf_counter() - t0)
                 if r.returncode:
                     raise RuntimeError(r.stderr.decode().strip().splitlines()[-1] if r.stderr else "kmahip_map -ipe failed")
@@ -444,7 +444,7 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
             subprocess.run([kma, "-ipe", subs[0], subs[1], "-o", os.path.join(tmp, "e2e_ref_pe"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"], check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             trp = time.perf_counter() - t0
-            subprocess.run([mapper, "-ipe", subs[0], subs[1], "-t_db", prefix, "-o", got + "_pe_s", "-1t1"], check=True, stderr=subprocess.DEVNULL)
+            subprocess.run([mapper, "-ipe", subs[0], subs[1], "-t_db", prefix, "-o", got + "_pe_s", "-1t1", "-apm", "p"], check=True, stderr=subprocess.DEVNULL)
             ref["paired_end"] = {"what": "examples/kmahip_map -ipe r1 r2 -1t1 (kmahip_run_pe: pairing penalty as -apm p) file to file on `pairs` pairs of 2 x 150 nt; "
                                          "the reference -ipe r1 r2 -apm p -1t1 -t 1 on the first reference_pairs of them",
                                  "kmahip_map_ipe": {"pairs": n_pairs, "wall_s": round(min(walls), 3), "reads_per_s": 2 * n_pairs / min(walls)},

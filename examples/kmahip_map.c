@@ -1,16 +1,26 @@
-/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db -1t1` (or `-ipe r1.fq r2.fq ... -apm p -1t1`, or `-i reads.fq -Mt1 n [-bcNano]`)
- * on an MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte
- * for byte what KMA 1.5.1 writes with one thread (the .gz after decompression).
+/* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db [-1t1]` (or `-ipe r1.fq r2.fq ... -apm p -1t1`, or `-i reads.fq -Mt1 n [-bcNano]`)
+ * on MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte for
+ * byte what KMA 1.5.1 writes with one thread (the .gz after decompression).
  *
  *     kmahip_map -i reads.fq.gz -t_db db -o out                     (the reference's default mode: chain finder, reads may map in pieces)
  *     kmahip_map -i reads.fq.gz -t_db db -o out -1t1
- *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out -1t1
+ *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out -1t1 -apm p
  *     kmahip_map -i ont.fq.gz -t_db db -o out -Mt1 1 -bcNano        (every read against template 1, runKMA_Mt1 mt1.c:86-500)
+ *     kmahip_map -gpus 8 -i reads.fq -t_db db -o out -1t1           (one process per GPU, the reads sharded; see below)
  *
- * Stage 1 (kmahip_ingest_*: parse, trim with KMA's defaults, pack), the whole device run in one call (kmahip_run_se: stage 2,
- * 3a, ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
+ * The command line is the reference's (kma.c:351-1248) for the options this path implements; anything else is refused, loudly.
+ * Stage 1 (kmahip_ingest_*: parse, trim, pack), the whole device run in one call (kmahip_run_se / _pe / _chain / _mt1: stage 2, 3a,
+ * ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
+ *
+ * Several GPUs of one node (`-1t1`, single end): `-gpus N` starts N copies of this program, one per device, before anything
+ * touches a GPU; each copy is a rank (KMAHIP_RANK / KMAHIP_WORLD / KMAHIP_KEY in its environment; under another launcher RANK /
+ * WORLD_SIZE / LOCAL_RANK and MASTER_PORT are read instead). A rank parses its byte range of the FASTQ, maps its reads, and
+ * kmahip_run_se_sharded does the three exchanges (kmahip.h) -- over RCCL, or staged through shared memory with
+ * KMAHIP_COMM=shm (KMAHIP_SHARE_GPU=1 puts every rank on device 0: a rehearsal on a one-GPU box).
  */
 #define _POSIX_C_SOURCE 200809L
+#define _DEFAULT_SOURCE
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +28,7 @@
 #include <time.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "kmahip.h"
@@ -25,12 +36,20 @@
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 /* stage 1 on a thread of its own, beside HIP start-up and the loading of the index */
-typedef struct ingest_job { const char *in1, *in2; kmahip_ingest *ing; kmahip_read_batch b; int rc; char err[512]; double t_done; } ingest_job;
+typedef struct ingest_job {
+	const char *in1, *in2;
+	kmahip_trim trim;
+	int part, parts, whole_input;
+	kmahip_ingest *ing; kmahip_read_batch b; int rc; char err[512]; double t_done;
+} ingest_job;
 static void *ingest_main(void *arg) {
 	ingest_job *j = (ingest_job *) arg;
-	j->rc = kmahip_ingest_open(j->in1, j->in2, NULL, &j->ing);
+	j->rc = kmahip_ingest_open_part(j->in1, j->in2, &j->trim, j->part, j->parts, &j->ing, &j->whole_input);
 	if(!j->rc) j->rc = kmahip_ingest_next(j->ing, INT64_MAX, &j->b);
-	if(j->rc) { strncpy(j->err, kmahip_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
+	/* the whole input in one batch: an input that breaks off (a truncated .gz, a record that is no FASTQ) delivers what came before
+	 * it; whether it did has to be asked, or the run would end well on half the reads */
+	if(!j->rc) j->rc = kmahip_ingest_status(j->ing);
+	if(j->rc && !j->err[0]) { strncpy(j->err, kmahip_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
 	j->t_done = now_s();
 	return NULL;
 }
@@ -89,44 +108,157 @@ static void warm_up(kmahip_db *db, kmahip_ws *ws, const char *prefix, int64_t D,
 	free(run.assembly.cover); free(run.assembly.aln_len); free(run.assembly.depth); free(run.assembly.asm_len);
 }
 
-static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); exit(1); }
-static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) { fprintf(stderr, "kmahip_map: out of memory\n"); exit(1); } return p; }
+/* (a reader thread may be inflating, workers of the library may be running: no destructors, no atexit handlers on the way out) */
+static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); fflush(NULL); _exit(1); }
+static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fflush(NULL); _exit(1); }
+static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
+
+static void usage(void) {
+	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano]\n"
+	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-mrs f] [-mrc f] [-mct f]\n"
+	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
+	                "(the options of kma 1.5.1 this path implements; -apm takes p only, -ipe needs -1t1; everything else is refused)\n");
+}
+
+static long long need_int(int argc, char **argv, int *a, const char *what) {
+	char *end;
+	if(*a + 1 >= argc) { fprintf(stderr, "kmahip_map: %s needs a value\n", what); exit(2); }
+	const long long v = strtoll(argv[++*a], &end, 10);
+	if(*end) { fprintf(stderr, "kmahip_map: invalid argument at \"%s\"\n", what); exit(1); }
+	return v;
+}
+static double need_num(int argc, char **argv, int *a, const char *what) {
+	char *end;
+	if(*a + 1 >= argc) { fprintf(stderr, "kmahip_map: %s needs a value\n", what); exit(2); }
+	const double v = strtod(argv[++*a], &end);
+	if(*end) { fprintf(stderr, "kmahip_map: invalid argument at \"%s\"\n", what); exit(1); }
+	return v;
+}
+
+/* `-gpus N`: N copies of this program, one per device, started before this process has touched a GPU; the exit status is the
+ * first non-zero one of the copies. */
+static int launch_ranks(int gpus, char **argv) {
+	char key[64], val[32];
+	snprintf(key, sizeof key, "%ld_%ld", (long) getpid(), (long) time(NULL));
+	setenv("KMAHIP_KEY", key, 1);
+	snprintf(val, sizeof val, "%d", gpus);
+	setenv("KMAHIP_WORLD", val, 1);
+	pid_t *pid = calloc((size_t) gpus, sizeof *pid);
+	if(!pid) return 1;
+	for(int r = 0; r < gpus; ++r) {
+		pid[r] = fork();
+		if(pid[r] < 0) { perror("kmahip_map: fork"); return 1; }
+		if(pid[r] == 0) {
+			snprintf(val, sizeof val, "%d", r);
+			setenv("KMAHIP_RANK", val, 1);
+			execv("/proc/self/exe", argv);
+			perror("kmahip_map: exec");
+			_exit(127);
+		}
+	}
+	int status = 0;
+	for(int r = 0; r < gpus; ++r) {
+		int st = 0;
+		if(waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) { if(!status) status = WIFEXITED(st) && WEXITSTATUS(st) ? WEXITSTATUS(st) : 1; }
+	}
+	free(pid);
+	return status;
+}
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
-	int mt1 = 0, bc_nano = 0, one2one = 0, chain = 0;
+	int mt1 = 0, bc_nano = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, gpus = 0, threads = 0, bcd = 1;
 	long long max_frag = 0;
+	double evalue = 0.05, ID_t = 1.0, Depth_t = 0.0;
+	kmahip_params par;
+	kmahip_chain_params cp;
+	kmahip_trim trim;
+	kmahip_default_params(&par);
+	kmahip_trim_default(&trim);
+	cp.minlen = 16; cp.pad_ = 0; cp.coverT = 0.1; cp.mrs = 0.5;
 	for(int a = 1; a < argc; ++a) {
-		if(!strcmp(argv[a], "-Mt1") && a + 1 < argc) { mt1 = atoi(argv[++a]); continue; }
-		if(!strcmp(argv[a], "-bcNano")) { bc_nano = 1; continue; }
-		if(!strcmp(argv[a], "-1t1")) { one2one = 1; continue; }
-		if(!strcmp(argv[a], "-chain")) { chain = 1; continue; }      /* (same as leaving -1t1 out) */
-		if(!strcmp(argv[a], "-t_db") && a + 1 < argc) prefix = argv[++a];
-		else if(!strcmp(argv[a], "-i") && a + 1 < argc) input = argv[++a];
-		else if(!strcmp(argv[a], "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
-		else if(!strcmp(argv[a], "-o") && a + 1 < argc) out = argv[++a];
-		else if(!strcmp(argv[a], "-mf") && a + 1 < argc) max_frag = atoll(argv[++a]);       /* fragments per assembly chunk (kma.c:1045) */
-		else { fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz]) -t_db <index prefix> -o <output prefix> [-1t1 | -chain] [-mf <fragments per chunk>] [-Mt1 <template> [-bcNano]]\n"); return 2; }
+		const char *o = argv[a];
+		if(!strcmp(o, "-Mt1")) mt1 = (int) need_int(argc, argv, &a, o);                        /* kma.c:923 */
+		else if(!strcmp(o, "-bcNano")) bc_nano = 1;                                             /* kma.c:762 */
+		else if(!strcmp(o, "-1t1")) one2one = 1;                                                /* kma.c:686 */
+		else if(!strcmp(o, "-chain")) chain = 1;                                                /* (our own: the same as leaving -1t1 out) */
+		else if(!strcmp(o, "-t_db") && a + 1 < argc) prefix = argv[++a];
+		else if(!strcmp(o, "-i") && a + 1 < argc) input = argv[++a];
+		else if(!strcmp(o, "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
+		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
+		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
+			if(a + 1 >= argc || argv[a + 1][0] != 'p') { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) only; u and f are not built\n"); return 1; }
+			++a; apm = 1;
+		}
+		else if(!strcmp(o, "-t")) {                                                             /* kma.c:529: a value is optional */
+			if(a + 1 < argc && argv[a + 1][0] != '-') threads = (int) need_int(argc, argv, &a, o);
+			if(threads < 1) threads = 1;
+		}
+		else if(!strcmp(o, "-nc")) no_cons = 1;                                                 /* kma.c:1018-1022 */
+		else if(!strcmp(o, "-na")) { /* no .aln file: none is written */ }
+		else if(!strcmp(o, "-nf")) no_frag = 1;
+		else if(!strcmp(o, "-mf")) { max_frag = need_int(argc, argv, &a, o); if(max_frag < 0) { fprintf(stderr, "Invalid argument at \"-mf\".\n"); return 1; } }
+		else if(!strcmp(o, "-ml")) { const int v = (int) need_int(argc, argv, &a, o); trim.min_len = v; par.minlen = v; cp.minlen = v; }       /* kma.c:581: one variable */
+		else if(!strcmp(o, "-xl")) trim.max_len = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-mp")) trim.min_phred = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-mi")) trim.hardmask_q = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-eq")) trim.min_q = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-mq")) par.mq = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-mrs")) { par.scoreT = need_num(argc, argv, &a, o); cp.mrs = par.scoreT; }
+		else if(!strcmp(o, "-mrc")) par.mrc = need_num(argc, argv, &a, o);
+		else if(!strcmp(o, "-mct")) cp.coverT = need_num(argc, argv, &a, o);
+		else if(!strcmp(o, "-e") || !strcmp(o, "-p")) { evalue = need_num(argc, argv, &a, o); if(evalue < 0 || 1.0 < evalue) { fprintf(stderr, "Invalid argument at \"%s\".\n", o); return 1; } }
+		else if(!strcmp(o, "-bcd")) bcd = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-ID")) ID_t = need_num(argc, argv, &a, o);
+		else if(!strcmp(o, "-md")) Depth_t = need_num(argc, argv, &a, o);
+		else if(!strcmp(o, "-ex_mode")) par.exhaustive = 1;
+		else if(!strcmp(o, "-gpus")) gpus = (int) need_int(argc, argv, &a, o);
+		else { fprintf(stderr, "kmahip_map: option %s is not one this program implements\n", o); usage(); return 2; }
 	}
-	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i, -t_db and -o are required\n"); return 2; }
+	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe), -t_db and -o are required\n"); usage(); return 2; }
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
+	if(input2 && !apm) { fprintf(stderr, "kmahip_map: -ipe needs -apm p (the reference pairs by union without it, kma.c:206: not built)\n"); return 2; }
 	if(chain && input2) { fprintf(stderr, "kmahip_map: paired input needs -1t1 (the default mode is built for single-end input)\n"); return 2; }
+	if(chain && par.mrc != 0.0) { fprintf(stderr, "kmahip_map: -mrc needs -1t1 (the chain finder's query-coverage variant is not built)\n"); return 2; }
+	if(mt1 && input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
+	if(threads) {
+		char v[16];
+		snprintf(v, sizeof v, "%d", threads);
+		setenv("KMAHIP_INGEST_THREADS", v, 1); setenv("KMAHIP_IO_THREADS", v, 1);          /* host threads of stage 1 and of the writers */
+	}
+
+	/* ranks */
+	if(gpus > 1 && !getenv("KMAHIP_RANK")) return launch_ranks(gpus, argv);
+	int rank = 0, world = 1, local = 0;
+	const char *key = getenv("KMAHIP_KEY");
+	char keybuf[64];
+	if(getenv("KMAHIP_RANK") && getenv("KMAHIP_WORLD")) { rank = atoi(getenv("KMAHIP_RANK")); world = atoi(getenv("KMAHIP_WORLD")); local = rank; }
+	else if(getenv("RANK") && getenv("WORLD_SIZE")) {
+		rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE")); local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
+		if(!key) { snprintf(keybuf, sizeof keybuf, "port%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0"); key = keybuf; }
+	}
+	if(world > 1 && (!one2one || input2 || mt1)) { fprintf(stderr, "kmahip_map: several ranks are built for the single-end -1t1 run\n"); return 2; }
+	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s();
-	/* stage 1: the whole file as one batch (the arrays stay owned by the reader), while the device and the index come up */
+	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */
 	ingest_job job;
 	memset(&job, 0, sizeof job);
-	job.in1 = input; job.in2 = input2;
+	job.in1 = input; job.in2 = input2; job.trim = trim; job.part = rank; job.parts = world;
 	pthread_t ingest_thread;
-	if(pthread_create(&ingest_thread, NULL, ingest_main, &job)) { fprintf(stderr, "kmahip_map: cannot start a thread\n"); return 1; }
+	if(pthread_create(&ingest_thread, NULL, ingest_main, &job)) fail("cannot start a thread");
 
-	kmahip_db *db; kmahip_ws *ws; kmahip_params par; kmahip_db_info info;
-	if(kmahip_init(0) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
-	kmahip_default_params(&par);
+	kmahip_db *db; kmahip_ws *ws; kmahip_db_info info;
+	if(kmahip_init(local) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
+	kmahip_comm *comm = NULL;
+	if(world > 1) {
+		const char *backend = getenv("KMAHIP_COMM") ? getenv("KMAHIP_COMM") : "rccl";
+		if(kmahip_comm_init(rank, world, key ? key : "kmahip", backend, &comm)) die("communicator");
+	}
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
-	{	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
+	if(world == 1) {	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
 		 * behind a shorter input the warm-up itself would be what the run waits for) */
 		struct stat sb;
 		const size_t il = strlen(input);
@@ -134,11 +266,39 @@ int main(int argc, char **argv) {
 		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (gz ? (128ll << 20) : (1ll << 30))) warm_up(db, ws, prefix, D, &par);
 	}
 	pthread_join(ingest_thread, NULL);
-	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); return 1; }
+	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); fflush(NULL); _exit(1); }
 	kmahip_ingest *ing = job.ing;
-	const kmahip_read_batch b = job.b;
-	const int64_t n = b.reads.n_reads;
+	kmahip_read_batch b = job.b;
 	const double t_ingest = now_s();
+
+	if(world > 1) {
+		/* an input the reader could not cut by bytes was delivered whole: this rank keeps its share of the records */
+		if(job.whole_input) {
+			const int64_t n_all = b.reads.n_reads, lo = n_all * rank / world, hi = n_all * (rank + 1) / world;
+			const int64_t so = b.reads.seq_off[lo], no = b.reads.N_off[lo], co = b.name_off[lo];
+			int64_t *seq_off = xcalloc((size_t) (hi - lo) + 1, 8), *N_off = xcalloc((size_t) (hi - lo) + 1, 8), *name_off = xcalloc((size_t) (hi - lo) + 1, 8);
+			for(int64_t i = lo; i <= hi; ++i) { seq_off[i - lo] = b.reads.seq_off[i] - so; N_off[i - lo] = b.reads.N_off[i] - no; name_off[i - lo] = b.name_off[i] - co; }
+			b.reads.n_reads = hi - lo; b.reads.seq += so; b.reads.seq_off = seq_off; b.reads.len += lo; b.reads.N += no; b.reads.N_off = N_off;
+			b.reads.seq_words = seq_off[hi - lo]; b.reads.N_total = N_off[hi - lo];
+			b.names += co; b.name_off = name_off; b.pair += lo; b.records = hi - lo;
+		}
+		kmahip_shard_opts so;
+		memset(&so, 0, sizeof so);
+		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		double ms[8];
+		if(kmahip_run_se_sharded(db, ws, comm, &b, &par, &so, out, ms)) die("kmahip_run_se_sharded");
+		if(rank == 0) {
+			char path[4096];
+			if(no_cons) { snprintf(path, sizeof path, "%s.fsa", out); remove(path); }
+			if(no_frag) { snprintf(path, sizeof path, "%s.frag.gz", out); remove(path); }
+		}
+		fprintf(stderr, "# kmahip_map rank %d of %d: %lld reads; wall: ingest %.2f s beside open %.2f, run %.2f | upload %.1f ms, stages 2+3a %.1f, exchanges 1+2 + ConClave %.1f, "
+		        "traceback %.1f, gather by owner %.1f, pile-up + consensus %.1f, writers %.1f, merge %.1f\n", rank, world, (long long) b.reads.n_reads, job.t_done - t_start,
+		        t_open - t_start, now_s() - t_ingest, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
+		fflush(NULL);
+		_exit(0);
+	}
+	const int64_t n = b.reads.n_reads;
 
 	/* everything on the device, one call */
 	int64_t tbases = 0;
@@ -169,17 +329,16 @@ int main(int argc, char **argv) {
 	const int touching = !input2 && !chain && n > 100000 && !getenv("KMAHIP_MAP_NO_TOUCH") && !pthread_create(&touch_thread, NULL, touch_main, &tj);
 	char fpath[4096];
 	snprintf(fpath, sizeof fpath, "%s.frag.gz", out);
+	const char *dev_frag = no_frag ? NULL : fpath;        /* (the paired and the default-mode run write the fragment file themselves) */
 	if(mt1) {
 		kmahip_assemble_opts ao;
 		memset(&ao, 0, sizeof ao);
-		ao.evalue = 0.05; ao.bcd = 1; ao.order = 1; ao.caller = bc_nano; ao.sig90 = bc_nano;
-		if(input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
+		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = bc_nano; ao.sig90 = bc_nano;
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
 	} else if(chain) {
-		if(input2) { fprintf(stderr, "kmahip_map: -chain with -ipe is not supported\n"); return 2; }
-		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, NULL, 0.05, 1, max_frag, fpath, &run)) die("kmahip_run_chain");
-	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, 0.05, 1, max_frag, fpath, &run)) die("kmahip_run_pe"); }
-	else if(kmahip_run_se(db, ws, &b.reads, &par, 0.05, 1, max_frag, &run)) die("kmahip_run_se");
+		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, &cp, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_chain");
+	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_pe"); }
+	else if(kmahip_run_se(db, ws, &b.reads, &par, evalue, bcd, max_frag, &run)) die("kmahip_run_se");
 
 	if(touching) pthread_join(touch_thread, NULL);
 	const double t_run = now_s();
@@ -190,8 +349,8 @@ int main(int argc, char **argv) {
 	snprintf(path, sizeof path, "%s.res", out);
 	FILE *res = fopen(path, "w");
 	snprintf(path, sizeof path, "%s.fsa", out);
-	FILE *fsa = fopen(path, "w");
-	if(!names || !res || !fsa) { fprintf(stderr, "kmahip_map: cannot open the name file or the outputs\n"); return 1; }
+	FILE *fsa = no_cons ? NULL : fopen(path, "w");
+	if(!names || !res || (!fsa && !no_cons)) fail("cannot open the name file or the outputs");
 	fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
 	int64_t r = 0;
 	size_t fsa_cap = 1 << 16;
@@ -200,8 +359,9 @@ int main(int argc, char **argv) {
 		name[strcspn(name, "\n")] = 0;
 		while(r < run.n_rows && run.rows[r].template_id < t) ++r;
 		if(!(r < run.n_rows && run.rows[r].template_id == t && run.rows[r].significant)) continue;
-		if(!kmahip_res_line(name, &run.rows[r], run.assembly.cover[t], run.assembly.aln_len[t], run.assembly.depth[t], 1.0, 0.0, line, (1 << 16) + 512)) continue;
+		if(!kmahip_res_line(name, &run.rows[r], run.assembly.cover[t], run.assembly.aln_len[t], run.assembly.depth[t], ID_t, Depth_t, line, (1 << 16) + 512)) continue;
 		fputs(line, res);
+		if(!fsa) continue;
 		/* printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line */
 		fprintf(fsa, ">%s\n", name);
 		const char *c = run.assembly.consensus + run.assembly.consensus_off[t];
@@ -213,12 +373,13 @@ int main(int argc, char **argv) {
 		if(col) *o++ = '\n';
 		fwrite(fsa_buf, 1, (size_t) (o - fsa_buf), fsa);
 	}
-	fclose(names); fclose(res); fclose(fsa);
+	fclose(names); fclose(res);
+	if(fsa) fclose(fsa);
 
 	const double t_res = now_s();
-	/* out.frag.gz (the paired run has written it itself: its fragments are in record order, not read order) */
+	/* out.frag.gz (the paired and the default-mode run have written it themselves: their fragments are in record order, not read order) */
 	int64_t frag_rows = 0;
-	if(!input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
+	if(!no_frag && !input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	const double t_frag = now_s();
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; wall: ingest %.2f s beside open %.2f (both done after %.2f), device run %.2f, .res + .fsa %.2f, .frag.gz %.2f | "
 	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, columns back %.1f%s\n", (long long) n, (long long) frag_rows,

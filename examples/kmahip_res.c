@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
 		/* stage 1 inside the library: parse, trim (KMA's defaults) and pack the whole file as one batch; the arrays stay
 		 * owned by the reader, which is kept open until the end */
 		kmahip_read_batch b;
-		if(kmahip_ingest_open(input, NULL, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b)) die("ingest");
+		if(kmahip_ingest_open(input, NULL, NULL, &ing) || kmahip_ingest_next(ing, INT64_MAX, &b) || kmahip_ingest_status(ing)) die("ingest");
 		n = b.reads.n_reads; words = b.reads.seq_words; nN = b.reads.N_total; max_len = b.reads.max_len;
 		seq = (uint64_t *) b.reads.seq; seq_off = (int64_t *) b.reads.seq_off; N_off = (int64_t *) b.reads.N_off;
 		len = (int32_t *) b.reads.len; Npos = (int32_t *) b.reads.N;

@@ -459,6 +459,10 @@ int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *
  * with '@' ends the input like in the reference ("Malformed input.", seqparse.c:256-260): the records before it are
  * delivered, then one call returns KMAHIP_EFORMAT. */
 int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch);
+/* For a caller that took the whole input as one batch (max_records = INT64_MAX): KMAHIP_EIO / KMAHIP_EFORMAT when the input broke
+ * off behind the records delivered (a truncated or corrupt .gz, a record that does not start with '@'; the reference ends with a
+ * non-zero exit status there), 0 otherwise. Does not touch the batch -- another kmahip_ingest_next would, its arrays are reused. */
+int kmahip_ingest_status(kmahip_ingest *in);
 /* 33 or 64 (0: undeterminable, treated like the reference does); records read / kept so far */
 int kmahip_ingest_phred_scale(const kmahip_ingest *in);
 void kmahip_ingest_counts(const kmahip_ingest *in, int64_t *records_read, int64_t *records_kept);
@@ -516,6 +520,59 @@ int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, 
  * librccl is resolved at run time, the library does not link against it. */
 int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scores, uint64_t *uniq_alignment_scores,
                             size_t DB_size, void *stream);
+
+/* ---- several GPUs of one node: one process per GPU, the reads sharded over the ranks -----------------------------
+ * The reference is one process (threads over pipes, kmapipe.c:55-146); these entries are what a read-sharded host needs between
+ * its stages: the SUM of alignment_scores / uniq_alignment_scores before runConClave (runkma.c:563-594, updatescores.c:228,276),
+ * the SUM of ConClave's per-template outputs before the `.res` statistics (conclave.c:147-151, runkma.c:608-613, 770-783), and the
+ * exchange that brings every traced read to the rank that owns its template, in the order of the whole stream (the assembly
+ * order of conclave.c:164-196 and assembly.c:1377-1424 is made of it).
+ * A communicator is bootstrapped through a POSIX shared-memory segment named after `key` (every rank of one run passes the same
+ * key, no two runs at a time the same one); backend "rccl": device data moves with ncclAllReduce / ncclSend / ncclRecv over xGMI
+ * (one device per rank), "shm": staged through host memory (any number of ranks per device: rehearsals and tests). */
+typedef struct kmahip_comm kmahip_comm;
+int kmahip_comm_init(int rank, int world, const char *key, const char *backend, kmahip_comm **out);
+void kmahip_comm_destroy(kmahip_comm *c);
+int kmahip_comm_rank(const kmahip_comm *c);
+int kmahip_comm_world(const kmahip_comm *c);
+int kmahip_comm_is_rccl(const kmahip_comm *c);
+int kmahip_comm_barrier(kmahip_comm *c);
+/* every rank posts `bytes` (at most 64 KiB) of HOST memory and gets all ranks' back in rank order */
+int kmahip_comm_allgather(kmahip_comm *c, const void *mine, size_t bytes, void *all);
+/* in-place SUM over the ranks of n u64 values in DEVICE memory */
+int kmahip_comm_allreduce_u64(kmahip_comm *c, uint64_t *d_buf, size_t n, void *stream);
+/* all-to-all of byte blocks: send_bytes[d] bytes for rank d back to back in `send`; recv_bytes[s] from rank s land back to back
+ * in `recv` in rank order (the sizes are agreed on beforehand, e.g. through kmahip_comm_allgather). device != 0: DEVICE buffers. */
+int kmahip_comm_alltoallv(kmahip_comm *c, const void *send, const int64_t *send_bytes, void *recv, const int64_t *recv_bytes,
+                          int device, void *stream);
+
+/* Stage 1 for one rank of a sharded run: the part `part` of `parts` of the input. FASTQ in a plain file (single end): the rank
+ * parses only its byte range -- ranges are cut at record starts found by the reader's own guess (a line beginning with '@' whose
+ * next line but one begins with '+'), the same on every rank, so the parts tile the file; *whole_input = 0. Anything else (.gz,
+ * FASTA, two mate files): the reader delivers the whole input and *whole_input = 1 -- the caller keeps the records
+ * [n part / parts, n (part + 1) / parts) of it. */
+int kmahip_ingest_open_part(const char *path1, const char *path2, const kmahip_trim *trim, int part, int parts, kmahip_ingest **out,
+                            int *whole_input);
+
+/* The single-end `-1t1` run of kmahip_run_se + the three writers, with the reads sharded over the ranks of `comm` (NULL or a
+ * one-rank communicator: everything on this device). `batch`: this rank's contiguous part of the input stream, in stream order
+ * over the ranks. Each rank maps its reads (stages 2, 3a), the score vectors are summed, ConClave runs per shard on the global
+ * vectors, its per-template outputs are summed (every rank then computes the same `.res` statistics), the traceback runs on the
+ * rank's own reads, and every kept read travels to the owner of its template (contiguous template ranges, balanced by filed
+ * fragments) with its position among the filed fragments of the whole stream; the owners pile up, call the consensus and write
+ * the rows of their templates to <out_prefix>.part<rank>.res, .fsa and .frag.gz. Rank 0 then concatenates the parts in
+ * rank order (= template order; gzip members concatenate) into <out_prefix>.res / .fsa / .frag.gz -- byte for byte the files of
+ * the one-device run (tests/test_shard_gpu.py). ms[8]: upload, stages 2 + 3a, exchange 1 + ConClave + exchange 2, traceback,
+ * gather by owner, pile-up + consensus, writers, merge. */
+typedef struct kmahip_shard_opts {
+	double evalue;        /* -e, 0.05 */
+	int32_t bcd;          /* -bcd, 1 */
+	int32_t caller, sig90;/* -bcNano: 1, 1 */
+	int64_t max_frag;     /* -mf, <= 0: 1000000 */
+	double ID_t, Depth_t; /* -ID (1.0), -md (0.0) */
+} kmahip_shard_opts;
+int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                          const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 
 /* Status of the *_dev calls issued on this workspace since the last query; synchronises `stream`. 0, or KMAHIP_EOVERFLOW
  * with kmahip_last_error() naming one of:

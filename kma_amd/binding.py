@@ -204,6 +204,7 @@ def lib():
         L.kmahip_ingest_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.kmahip_ingest_counts.restype = None
         L.kmahip_ingest_close.argtypes = [C.c_void_p]
+        L.kmahip_ingest_status.argtypes = [C.c_void_p]
         L.kmahip_ingest_close.restype = None
         _lib = L
     return _lib
@@ -274,6 +275,10 @@ class Ingest:
         raw = C.string_at(b.names, int(noff[-1]))
         names = [raw[noff[i]:noff[i + 1] - 1] for i in range(n)]
         return batch, names, arr(b.pair, C.c_uint8, n)
+
+    def status(self):
+        """raises when the input broke off behind the records delivered so far (for callers that take everything as one batch)"""
+        _check(lib().kmahip_ingest_status(self._h))
 
     def close(self):
         if self._h:

@@ -116,6 +116,9 @@ int write_rows(const char *path, size_t n_rows, size_t block_rows, Fmt fmt) {
 
 }  // namespace
 
+// the template names of <prefix>.name, one per template in template order (read once)
+int kmahip_db_load_names(kmahip_db *db) { return load_names(db); }
+
 int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *reads, int64_t n, const int64_t *src, const int32_t *rc,
                           const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,
                           const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows);

@@ -970,6 +970,31 @@ extern "C" int kmahip_ingest_open(const char *path1, const char *path2, const km
 	return KMAHIP_OK;
 }
 
+// One rank's part of the input (see kmahip.h). Plain single-end FASTQ: the mapped file is cut at record starts -- the guess of
+// fill_wave's regions, taken from the byte part * size / parts onwards, the same on every rank -- and the reader is given
+// [start of this part, start of the next); everything else is delivered whole for the caller to slice by record number.
+extern "C" int kmahip_ingest_open_part(const char *path1, const char *path2, const kmahip_trim *trim, int part, int parts, kmahip_ingest **out,
+                                       int *whole_input) {
+	if(!whole_input || parts < 1 || part < 0 || part >= parts) { kmahip_set_error("bad part"); return KMAHIP_EINVAL; }
+	*whole_input = 1;
+	int rc = kmahip_ingest_open(path1, path2, trim, out);
+	if(rc || parts == 1) { if(!rc) *whole_input = 0; return rc; }
+	kmahip_ingest *in = *out;
+	Chunk *w = (in->fastq && !in->paired) ? in->m[0].feed.whole : nullptr;
+	if(!w || !w->mapped || !w->base || getenv("KMAHIP_INGEST_NO_RANGES")) return KMAHIP_OK;
+	const uint8_t *base = w->base, *end = w->base + w->hi;
+	auto cut = [&](int q) -> size_t {
+		if(q <= 0) return 0;
+		if(q >= parts) return w->hi;
+		const uint8_t *g = guess_start(base, base + (size_t) ((unsigned __int128) w->hi * (unsigned) q / (unsigned) parts), end, end);
+		return g ? (size_t) (g - base) : w->hi;
+	};
+	const size_t a = cut(part), b = cut(part + 1);
+	w->lo = a; w->hi = b < a ? a : b;
+	*whole_input = 0;
+	return KMAHIP_OK;
+}
+
 extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch) {
 	if(!in || !batch || max_records < 0) { kmahip_set_error("bad argument"); return KMAHIP_EINVAL; }
 	in->seq.clear(); in->len.clear(); in->N.clear(); in->names.clear(); in->pair.clear();
@@ -1071,6 +1096,24 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	}
 	if(in->malformed && !in->reported && records == 0) {
 		// like the reference, which prints "Malformed input." and ends with a non-zero exit status after the good records
+		in->reported = true;
+		kmahip_set_error("malformed FASTQ input after %lld records", (long long) in->n_read);
+		return KMAHIP_EFORMAT;
+	}
+	return KMAHIP_OK;
+}
+
+// what a caller that takes the whole input as ONE batch has to ask afterwards: did the input break off behind the records delivered?
+// (kmahip_ingest_next reports that with the call that delivers nothing -- which such a caller never makes, and must not make while
+// it still uses the batch: the next call reuses the batch's arrays.)
+extern "C" int kmahip_ingest_status(kmahip_ingest *in) {
+	if(!in) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(in->io_error && !in->io_reported) {
+		in->io_reported = true;
+		kmahip_set_error("read error (corrupt or truncated compressed input) after %lld records", (long long) in->n_read);
+		return KMAHIP_EIO;
+	}
+	if(in->malformed && !in->reported) {
 		in->reported = true;
 		kmahip_set_error("malformed FASTQ input after %lld records", (long long) in->n_read);
 		return KMAHIP_EFORMAT;

@@ -153,6 +153,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 // a_n[2 r + strand] anchors at pool + a_off[2 r + strand]; cnt[0] = anchors written (may exceed pool_cap: repeat with a larger pool)
 int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, KmaAnk *pool, int64_t pool_cap,
                                 int64_t *a_off, int32_t *a_n, uint8_t *slow, unsigned long long *cnt, hipStream_t stream);
+int kmahip_db_load_names(kmahip_db *db);       // fragout.hip: fills db->h_names from <prefix>.name
 double kmahip_p_chisqr(long double q);      // stdstat.c:136-147 (conclave.hip)
 int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p,
                           kmahip_pe_recs *out, hipStream_t stream);

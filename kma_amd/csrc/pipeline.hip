@@ -922,3 +922,416 @@ extern "C" int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	out->ms[5] = since(t);
 	return KMAHIP_OK;
 }
+
+
+// ---- the single-end run over read shards, one process per GPU (kmahip.h: kmahip_run_se_sharded) -----------------------
+namespace {
+
+constexpr int ROW = 20;        // int32 fields of a travelling read: frag_rank lo / hi, len, rc, tmpl, n_hits, nN, n_ops, stats[10], 2 spare
+
+// ConClave's per-template outputs side by side as u64, for ONE all-reduce: w_scores | depth | fragment counts | read counts
+__global__ __launch_bounds__(256) void shard_pack_kernel(int64_t D, const uint64_t *w, const uint64_t *depth, const uint32_t *frags, const uint32_t *reads, uint64_t *out) {
+	const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(t >= D) return;
+	out[t] = w[t]; out[D + t] = depth[t]; out[2 * D + t] = frags[t]; out[3 * D + t] = reads[t];
+}
+
+// filed flag per read (ConClave gave it a template) for the scan that numbers the filed fragments; destination of a kept read
+__global__ __launch_bounds__(256) void shard_dest_kernel(int64_t n, const int32_t *tmpl, const int32_t *stats, const int32_t *owner, int world, int64_t *filed,
+                                                         uint32_t *dest, int64_t *idx) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > n) return;
+	if(i == n) { filed[n] = 0; return; }
+	const int t = tmpl[i];
+	filed[i] = t != 0;
+	const int dd = (t != 0 && stats[10 * i + 3] != 0) ? owner[abs(t)] : world;
+	dest[i] = (uint32_t) dd; idx[i] = i;
+}
+
+// where each destination's stretch begins in the sorted order (written only at the boundaries: no contended counters)
+__global__ __launch_bounds__(256) void shard_bounds_kernel(int64_t n, const uint32_t *sorted, unsigned long long *first) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	if(i == 0 || sorted[i] != sorted[i - 1]) first[sorted[i]] = (unsigned long long) i;
+}
+
+__global__ __launch_bounds__(256) void shard_rows_kernel(int64_t m, const int64_t *idx, int64_t rank_base, const int64_t *filed_before, const int32_t *len, const int32_t *rc,
+                                                         const int32_t *tmpl, const int32_t *n_hits, const int64_t *N_off, const int32_t *n_ops, const int32_t *stats,
+                                                         int32_t *rows, int64_t *ops_cnt) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x > m) return;
+	if(x == m) { ops_cnt[m] = 0; return; }
+	const int64_t i = idx[x];
+	int32_t *r = rows + ROW * x;
+	const int64_t fr = rank_base + filed_before[i];
+	r[0] = (int32_t) (fr & 0xFFFFFFFFll); r[1] = (int32_t) (fr >> 32);
+	r[2] = len[i]; r[3] = rc[i]; r[4] = tmpl[i]; r[5] = n_hits[i]; r[6] = (int32_t) (N_off[i + 1] - N_off[i]); r[7] = n_ops[i];
+	for(int k = 0; k < 10; ++k) r[8 + k] = stats[10 * i + k];
+	r[18] = 0; r[19] = 0;
+	ops_cnt[x] = n_ops[i];
+}
+
+__global__ __launch_bounds__(256) void shard_ops_kernel(int64_t m, const int64_t *idx, const int64_t *ops_off, const int32_t *n_ops, const uint32_t *ops, const int64_t *o_off, uint32_t *o_ops) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x >= m) return;
+	const int64_t i = idx[x];
+	const uint32_t *src = ops + ops_off[i];
+	uint32_t *dst = o_ops + o_off[x];
+	for(int k = 0; k < n_ops[i]; ++k) dst[k] = src[k];
+}
+
+// what an owner received: the rows back into per-read columns, and the sizes the CSR offsets are scanned from
+__global__ __launch_bounds__(256) void shard_unpack_kernel(int64_t m, const int32_t *rows, int64_t *frag_rank, int32_t *len, int32_t *rc, int32_t *tmpl, int32_t *n_hits,
+                                                           int32_t *n_ops, int32_t *stats, int64_t *words, int64_t *n_N, int64_t *ops_cnt) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x > m) return;
+	if(x == m) { words[m] = 0; n_N[m] = 0; ops_cnt[m] = 0; return; }
+	const int32_t *r = rows + ROW * x;
+	frag_rank[x] = (int64_t) (uint32_t) r[0] | ((int64_t) r[1] << 32);
+	len[x] = r[2]; rc[x] = r[3]; tmpl[x] = r[4]; n_hits[x] = r[5]; n_ops[x] = r[7];
+	for(int k = 0; k < 10; ++k) stats[10 * x + k] = r[8 + k];
+	words[x] = ((r[2] + 31) >> 5) + 1; n_N[x] = r[6]; ops_cnt[x] = r[7];
+}
+
+// files <prefix>.part0<ext> .. <prefix>.part<world - 1><ext> back to back into <prefix><ext> (behind `head`), the parts removed
+int concat_parts(const std::string &prefix, const char *ext, int world, const char *head) {
+	const std::string path = prefix + ext;
+	FILE *o = fopen(path.c_str(), "wb");
+	if(!o) { kmahip_set_error("cannot create %s", path.c_str()); return KMAHIP_EIO; }
+	if(head) fputs(head, o);
+	std::vector<char> buf(4u << 20);
+	int rc = KMAHIP_OK;
+	for(int r = 0; r < world && !rc; ++r) {
+		const std::string part = prefix + ".part" + std::to_string(r) + ext;
+		FILE *f = fopen(part.c_str(), "rb");
+		if(!f) { kmahip_set_error("part %s is missing", part.c_str()); rc = KMAHIP_EIO; break; }
+		size_t got;
+		while((got = fread(buf.data(), 1, buf.size(), f)) > 0) if(fwrite(buf.data(), 1, got, o) != got) { kmahip_set_error("write to %s failed", path.c_str()); rc = KMAHIP_EIO; break; }
+		fclose(f);
+		remove(part.c_str());
+	}
+	if(fclose(o) != 0 && !rc) { kmahip_set_error("write to %s failed", path.c_str()); rc = KMAHIP_EIO; }
+	return rc;
+}
+
+}  // namespace
+
+extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                                     const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
+	if(!db || !ws || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int W = kmahip_comm_world(comm), rank = kmahip_comm_rank(comm);
+	const kmahip_reads &R = batch->reads;
+	const int64_t n = R.n_reads;
+	if(n < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	const size_t D = db->info.DB_size;
+	const int64_t mf = opts->max_frag > 0 ? opts->max_frag : 1000000;
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	hipStream_t s = 0;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	if((rc = kmahip_db_load_names(db))) return rc;
+
+	// the shard, once
+	B.expect((size_t) R.seq_words * 8 + (size_t) R.N_total * 4 + (size_t) n * 320 + (64u << 20));
+	kmahip_reads d = R;
+	d.q_start = nullptr; d.q_end = nullptr;
+	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &d.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &d.seq_off)) || (rc = B.up(R.len, (size_t) n, 1, &d.len)) ||
+	   (rc = B.up(R.N, (size_t) R.N_total, 1, &d.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	ms[0] = since(t);
+
+	// stages 2 and 3a on the shard (as kmahip_run_se)
+	kmahip_cands c;
+	if((rc = B.get((size_t) n + 1, &c.rc_flag)) || (rc = B.get((size_t) n + 1, &c.flag)) || (rc = B.get((size_t) n + 1, &c.T_off, true))) return rc;
+	int64_t total = 0;
+	c.T_cap = 2 * n + 4096; c.T = nullptr;
+	for(int attempt = 0; n > 0; ++attempt) {
+		if((rc = B.get((size_t) c.T_cap, &c.T))) return rc;
+		if((rc = kmahip_launch_scan_se(db, ws, &d, p, &c, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 1) {
+			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;
+			continue;
+		}
+		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
+		if(total <= c.T_cap) break;
+		if(attempt >= 6) { kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
+		c.T_cap = total + 1024;
+	}
+	if(!c.T && (rc = B.get(16, &c.T))) return rc;
+	kmahip_hits h;
+	uint64_t *AS = nullptr;
+	if((rc = B.get((size_t) n + 1, &h.n_hits, true)) || (rc = B.get((size_t) n + 1, &h.best_score, true)) || (rc = B.get((size_t) n + 1, &h.flag, true)) ||
+	   (rc = B.get((size_t) n + 1, &h.rc, true)) || (rc = B.get((size_t) total + 1, &h.tmpl, true)) || (rc = B.get((size_t) total + 1, &h.score, true)) ||
+	   (rc = B.get((size_t) total + 1, &h.start, true)) || (rc = B.get((size_t) total + 1, &h.end, true)) || (rc = B.get(2 * D, &AS, true))) return rc;
+	h.alignment_scores = AS; h.uniq_alignment_scores = AS + D;
+	if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	ms[1] = since(t);
+
+	// exchange 1: the two score vectors summed over the shards; ConClave on them; exchange 2: its per-template outputs summed
+	if((rc = kmahip_comm_allreduce_u64(comm, AS, 2 * D, s))) return rc;
+	kmahip_conclave cc;
+	uint64_t *X = nullptr;
+	if((rc = B.get((size_t) n + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n + 1, &cc.start, true)) || (rc = B.get((size_t) n + 1, &cc.end, true)) ||
+	   (rc = B.get(D, &cc.w_scores, true)) || (rc = B.get(D, &cc.fragment_counts, true)) || (rc = B.get(D, &cc.read_counts, true)) || (rc = B.get(D, &cc.depth, true)) ||
+	   (rc = B.get(4 * D, &X))) return rc;
+	if(n && (rc = kmahip_conclave_se_dev(db, ws, &d, &c, &h, &cc, s))) return rc;
+	hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned) ((D + 255) / 256)), dim3(256), 0, s, (int64_t) D, cc.w_scores, cc.depth, cc.fragment_counts, cc.read_counts, X);
+	HIP_TRY(hipGetLastError());
+	if((rc = kmahip_comm_allreduce_u64(comm, X, 4 * D, s))) return rc;
+	std::vector<uint64_t> hx(4 * D);
+	HIP_TRY(hipMemcpy(hx.data(), X, 4 * D * 8, hipMemcpyDeviceToHost));
+	std::vector<kmahip_res_row> rows(D);
+	int64_t n_rows = 0;
+	if((rc = kmahip_res_rows(db, hx.data(), opts->evalue, p->scoreT, rows.data(), (int64_t) D, &n_rows))) return rc;
+	std::vector<uint8_t> ok(D + 8, 0);
+	for(int64_t r = 0; r < n_rows; ++r) ok[(size_t) rows[(size_t) r].template_id] = (uint8_t) rows[(size_t) r].significant;
+	const uint8_t *d_ok = nullptr;
+	if((rc = B.up(ok.data(), D + 8, 0, &d_ok))) return rc;
+	ms[2] = since(t);
+
+	// the traceback on the rank's own reads
+	kmahip_traces tr;
+	if((rc = B.get((size_t) 10 * n + 10, &tr.stats, true)) || (rc = B.get((size_t) n + 1, &tr.ops_off, true)) || (rc = B.get((size_t) n + 1, &tr.n_ops, true))) return rc;
+	tr.ops_cap = 6 * n + (1 << 20); tr.ops = nullptr;
+	for(int attempt = 0; n; ++attempt) {
+		if((rc = B.get((size_t) tr.ops_cap, &tr.ops))) return rc;
+		if((rc = kmahip_launch_trace(db, ws, &d, h.rc, cc.tmpl, d_ok, p, &tr, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		unsigned long long used = 0;
+		const int st = ws_status(ws, &used);
+		if(st == 2 || (int64_t) used > tr.ops_cap) {
+			if(attempt >= 2) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+			tr.ops_cap = (int64_t) used + (1 << 20);
+			continue;
+		}
+		if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
+		break;
+	}
+	if(!tr.ops && (rc = B.get(16, &tr.ops))) return rc;
+	ms[3] = since(t);
+
+	// exchange 3: every kept read to the owner of its template. Owners: contiguous template ranges, cut where the filed fragments
+	// before a template reach the next 1 / W of all of them (the same on every rank: the counts are the summed ones).
+	std::vector<int32_t> owner(D, 0);
+	{
+		unsigned long long tot = 0, before = 0;
+		for(size_t tt = 0; tt < D; ++tt) tot += hx[2 * D + tt];
+		for(size_t tt = 0; tt < D; ++tt) {
+			owner[tt] = tot ? (int32_t) std::min<unsigned long long>((unsigned long long) (W - 1), (unsigned long long) ((unsigned __int128) before * (unsigned) W / tot)) : 0;
+			before += hx[2 * D + tt];
+		}
+	}
+	const int32_t *d_owner = nullptr;
+	if((rc = B.up(owner.data(), D, 0, &d_owner))) return rc;
+	int64_t *filed = nullptr, *filed_before = nullptr, *idx = nullptr, *idx2 = nullptr;
+	uint32_t *dest = nullptr, *dest2 = nullptr;
+	unsigned long long *d_cnt = nullptr;
+	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &filed_before)) || (rc = B.get((size_t) n + 1, &idx)) || (rc = B.get((size_t) n + 1, &idx2)) ||
+	   (rc = B.get((size_t) n + 1, &dest)) || (rc = B.get((size_t) n + 1, &dest2)) || (rc = B.get((size_t) W + 2, &d_cnt))) return rc;
+	hipLaunchKernelGGL(shard_dest_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, cc.tmpl, tr.stats, d_owner, W, filed, dest, idx);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, filed, filed_before, (size_t) n + 1, s))) return rc;
+	int64_t my_filed = 0;
+	HIP_TRY(hipMemcpy(&my_filed, filed_before + n, 8, hipMemcpyDeviceToHost));
+	// (position of this shard among the filed fragments of the whole stream; the longest read of the run)
+	std::vector<int64_t> all_meta((size_t) W * 2);
+	{
+		const int64_t mine[2] = {my_filed, (int64_t) R.max_len};
+		if((rc = kmahip_comm_allgather(comm, mine, sizeof mine, all_meta.data()))) return rc;
+	}
+	int64_t rank_base = 0;
+	int max_len = 0;
+	for(int r = 0; r < W; ++r) { if(r < rank) rank_base += all_meta[(size_t) 2 * r]; max_len = std::max(max_len, (int) all_meta[(size_t) 2 * r + 1]); }
+	// kept reads ordered by destination, stream order inside one (a stable sort on the few bits of the destination)
+	if(n) {
+		size_t tmp_bytes = 0;
+		int bits = 1;
+		while((1 << bits) <= W) ++bits;
+		if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
+		char *tmp = nullptr;
+		if((rc = B.get(tmp_bytes, &tmp))) return rc;
+		if(rocprim::radix_sort_pairs(tmp, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
+	}
+	std::vector<int64_t> seg((size_t) W + 1, 0);
+	std::vector<unsigned long long> cnt((size_t) W + 1, 0);
+	{
+		std::vector<unsigned long long> first((size_t) W + 2, ~0ull);
+		HIP_TRY(hipMemcpyAsync(d_cnt, first.data(), ((size_t) W + 2) * 8, hipMemcpyHostToDevice, s));
+		if(n) hipLaunchKernelGGL(shard_bounds_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, dest2, d_cnt);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(first.data(), d_cnt, ((size_t) W + 2) * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		first[(size_t) W + 1] = (unsigned long long) n;
+		for(int r = W; r >= 0; --r) if(first[(size_t) r] == ~0ull) first[(size_t) r] = first[(size_t) r + 1];       // (a destination nobody goes to)
+		for(int r = 0; r <= W; ++r) { if(r <= W) seg[(size_t) std::min(r, W)] = (int64_t) first[(size_t) r]; }
+		for(int r = 0; r < W; ++r) cnt[(size_t) r] = first[(size_t) r + 1] - first[(size_t) r];
+	}
+	const int64_t m = seg[(size_t) W];
+	kmahip_reads dK{};
+	int32_t *rows_d = nullptr;
+	int64_t *ops_cnt = nullptr, *ops_o = nullptr;
+	uint32_t *ops_k = nullptr;
+	if((rc = gather_batch(B, d, idx2, m, &dK, s))) return rc;
+	if((rc = B.get((size_t) ROW * m + ROW, &rows_d)) || (rc = B.get((size_t) m + 1, &ops_cnt)) || (rc = B.get((size_t) m + 1, &ops_o))) return rc;
+	hipLaunchKernelGGL(shard_rows_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, idx2, rank_base, filed_before, d.len, h.rc, cc.tmpl, h.n_hits, d.N_off, tr.n_ops,
+	                   tr.stats, rows_d, ops_cnt);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, ops_cnt, ops_o, (size_t) m + 1, s))) return rc;
+	int64_t ops_total = 0;
+	HIP_TRY(hipMemcpy(&ops_total, ops_o + m, 8, hipMemcpyDeviceToHost));
+	if((rc = B.get((size_t) ops_total + 1, &ops_k))) return rc;
+	if(m) hipLaunchKernelGGL(shard_ops_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, idx2, tr.ops_off, tr.n_ops, tr.ops, ops_o, ops_k);
+	HIP_TRY(hipGetLastError());
+	// block sizes per destination (rows, words, N positions, runs, name bytes), agreed on through the mailboxes
+	std::vector<int64_t> h_idx((size_t) m + 1), so_at((size_t) W + 1), no_at((size_t) W + 1), oo_at((size_t) W + 1);
+	if(m) HIP_TRY(hipMemcpy(h_idx.data(), idx2, (size_t) m * 8, hipMemcpyDeviceToHost));
+	for(int r = 0; r <= W; ++r) {
+		HIP_TRY(hipMemcpy(&so_at[(size_t) r], dK.seq_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&no_at[(size_t) r], dK.N_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&oo_at[(size_t) r], ops_o + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+	}
+	std::vector<char> name_send;
+	std::vector<int64_t> name_at((size_t) W + 1, 0);
+	for(int r = 0; r < W; ++r) {
+		int64_t bytes = 0;
+		for(int64_t x = seg[(size_t) r]; x < seg[(size_t) r + 1]; ++x) { const int64_t i = h_idx[(size_t) x]; bytes += batch->name_off[i + 1] - batch->name_off[i]; }
+		name_at[(size_t) r + 1] = name_at[(size_t) r] + bytes;
+	}
+	name_send.resize((size_t) name_at[(size_t) W] + 1);
+	{
+		char *o = name_send.data();
+		for(int64_t x = 0; x < m; ++x) { const int64_t i = h_idx[(size_t) x]; const int64_t l = batch->name_off[i + 1] - batch->name_off[i]; memcpy(o, batch->names + batch->name_off[i], (size_t) l); o += l; }
+	}
+	constexpr int NA = 5;          // arrays that travel
+	std::vector<int64_t> mine((size_t) NA * W), all((size_t) NA * W * W);
+	for(int r = 0; r < W; ++r) {
+		mine[(size_t) (0 * W + r)] = (int64_t) cnt[(size_t) r] * ROW * 4;
+		mine[(size_t) (1 * W + r)] = (so_at[(size_t) r + 1] - so_at[(size_t) r]) * 8;
+		mine[(size_t) (2 * W + r)] = (no_at[(size_t) r + 1] - no_at[(size_t) r]) * 4;
+		mine[(size_t) (3 * W + r)] = (oo_at[(size_t) r + 1] - oo_at[(size_t) r]) * 4;
+		mine[(size_t) (4 * W + r)] = name_at[(size_t) r + 1] - name_at[(size_t) r];
+	}
+	if((rc = kmahip_comm_allgather(comm, mine.data(), mine.size() * 8, all.data()))) return rc;
+	std::vector<int64_t> rb[NA];
+	int64_t rtot[NA];
+	for(int a = 0; a < NA; ++a) {
+		rb[a].assign((size_t) W, 0);
+		rtot[a] = 0;
+		for(int src = 0; src < W; ++src) { rb[a][(size_t) src] = all[(size_t) src * NA * W + (size_t) a * W + (size_t) rank]; rtot[a] += rb[a][(size_t) src]; }
+	}
+	const int64_t m2 = rtot[0] / (ROW * 4);
+	int32_t *rows_r = nullptr, *N_r = nullptr;
+	uint64_t *seq_r = nullptr;
+	uint32_t *ops_r = nullptr;
+	if((rc = B.get((size_t) rtot[0] / 4 + ROW, &rows_r)) || (rc = B.get((size_t) rtot[1] / 8 + 2, &seq_r, true)) || (rc = B.get((size_t) rtot[2] / 4 + 1, &N_r)) ||
+	   (rc = B.get((size_t) rtot[3] / 4 + 1, &ops_r))) return rc;
+	std::vector<char> name_recv((size_t) rtot[4] + 1);
+	HIP_TRY(hipStreamSynchronize(s));
+	if((rc = kmahip_comm_alltoallv(comm, rows_d, &mine[0], rows_r, rb[0].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, dK.seq, &mine[(size_t) W], seq_r, rb[1].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, dK.N, &mine[(size_t) 2 * W], N_r, rb[2].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, ops_k, &mine[(size_t) 3 * W], ops_r, rb[3].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, name_send.data(), &mine[(size_t) 4 * W], name_recv.data(), rb[4].data(), 0, s))) return rc;
+	ms[4] = since(t);
+
+	// the owner's batch: what arrived is in source-rank order = the order of the whole stream
+	kmahip_reads dO{};
+	kmahip_traces trO;
+	memset(&trO, 0, sizeof trO);
+	int64_t *fr2 = nullptr, *w_cnt = nullptr, *n_cnt = nullptr, *o_cnt = nullptr, *so2 = nullptr, *no2 = nullptr, *oo2 = nullptr;
+	int32_t *len2 = nullptr, *rc2 = nullptr, *tm2 = nullptr, *nh2 = nullptr, *nops2 = nullptr, *st2 = nullptr;
+	if((rc = B.get((size_t) m2 + 1, &fr2)) || (rc = B.get((size_t) m2 + 1, &w_cnt)) || (rc = B.get((size_t) m2 + 1, &n_cnt)) || (rc = B.get((size_t) m2 + 1, &o_cnt)) ||
+	   (rc = B.get((size_t) m2 + 1, &so2)) || (rc = B.get((size_t) m2 + 1, &no2)) || (rc = B.get((size_t) m2 + 1, &oo2)) || (rc = B.get((size_t) m2 + 1, &len2, true)) ||
+	   (rc = B.get((size_t) m2 + 1, &rc2)) || (rc = B.get((size_t) m2 + 1, &tm2)) || (rc = B.get((size_t) m2 + 1, &nh2)) || (rc = B.get((size_t) m2 + 1, &nops2)) ||
+	   (rc = B.get((size_t) 10 * m2 + 10, &st2))) return rc;
+	hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned) ((m2 + 256) / 256)), dim3(256), 0, s, m2, rows_r, fr2, len2, rc2, tm2, nh2, nops2, st2, w_cnt, n_cnt, o_cnt);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, w_cnt, so2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, n_cnt, no2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, o_cnt, oo2, (size_t) m2 + 1, s))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	dO.n_reads = m2; dO.seq = seq_r; dO.seq_off = so2; dO.len = len2; dO.N = N_r; dO.N_off = no2; dO.seq_words = rtot[1] / 8; dO.N_total = rtot[2] / 4; dO.max_len = max_len;
+	trO.stats = st2; trO.ops_off = oo2; trO.n_ops = nops2; trO.ops = ops_r; trO.ops_cap = rtot[3] / 4;
+	// pile-up + consensus of the owned templates
+	kmahip_assembly asmb;
+	memset(&asmb, 0, sizeof asmb);
+	std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
+	int64_t tbases = 0;
+	for(size_t tt = 1; tt < D; ++tt) tbases += db->h_tlen[tt];
+	std::vector<char> cons((size_t) (4 * tbases + 4 * (int64_t) D + (1 << 20)));
+	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
+	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
+	if(m2) {
+		kmahip_assemble_opts ao = {mf, opts->evalue, opts->bcd, 0, opts->caller, opts->sig90, fr2};
+		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
+	}
+	ms[5] = since(t);
+
+	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
+	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
+	{
+		FILE *res = fopen((part + ".res").c_str(), "w"), *fsa = fopen((part + ".fsa").c_str(), "w");
+		if(!res || !fsa) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create the output parts of %s", out_prefix); return KMAHIP_EIO; }
+		std::vector<char> line((1 << 16) + 512);
+		std::string entry;
+		for(int64_t r = 0; r < n_rows; ++r) {
+			const kmahip_res_row &row = rows[(size_t) r];
+			const size_t tt = (size_t) row.template_id;
+			if(owner[tt] != rank || !row.significant || tt - 1 >= db->h_names.size()) continue;
+			const std::string &name = db->h_names[tt - 1];
+			if(!kmahip_res_line(name.c_str(), &row, a_cover[tt], a_len[tt], a_depth[tt], opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, line.data(), (int64_t) line.size())) continue;
+			fputs(line.data(), res);
+			// printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line
+			entry.clear();
+			entry += ">"; entry += name; entry += "\n";
+			int col = 0;
+			for(const char *q = c_off[tt] >= 0 ? cons.data() + c_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
+			if(col) entry.push_back('\n');
+			fwrite(entry.data(), 1, entry.size(), fsa);
+		}
+		if(fclose(res) != 0 || fclose(fsa) != 0) { kmahip_set_error("write to the output parts of %s failed", out_prefix); return KMAHIP_EIO; }
+	}
+	{
+		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
+		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);
+		std::vector<int64_t> h_so((size_t) m2 + 1, 0), h_no((size_t) m2 + 1, 0), h_fr((size_t) m2 + 1, 0), h_name_off((size_t) m2 + 1, 0);
+		std::vector<int32_t> h_len((size_t) m2 + 1, 0), h_N((size_t) dO.N_total + 1, 0), h_rc((size_t) m2 + 1, 0), h_tm((size_t) m2 + 1, 0), h_nh((size_t) m2 + 1, 0), h_st((size_t) 10 * m2 + 10, 0);
+		if(dO.seq_words) HIP_TRY(hipMemcpy(hs.data(), seq_r, (size_t) dO.seq_words * 8, hipMemcpyDeviceToHost));
+		if(dO.N_total) HIP_TRY(hipMemcpy(h_N.data(), N_r, (size_t) dO.N_total * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_so.data(), so2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_no.data(), no2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
+		if(m2) {
+			HIP_TRY(hipMemcpy(h_fr.data(), fr2, (size_t) m2 * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_len.data(), len2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_rc.data(), rc2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_tm.data(), tm2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_nh.data(), nh2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_st.data(), st2, (size_t) m2 * 40, hipMemcpyDeviceToHost));
+		}
+		// names arrive NUL-terminated, back to back
+		{
+			int64_t at = 0;
+			for(int64_t x = 0; x < m2; ++x) { h_name_off[(size_t) x] = at; at += (int64_t) strlen(name_recv.data() + at) + 1; }
+			h_name_off[(size_t) m2] = at;
+		}
+		kmahip_reads hr{};
+		hr.n_reads = m2; hr.seq = hs.data(); hr.seq_off = h_so.data(); hr.len = h_len.data(); hr.N = h_N.data(); hr.N_off = h_no.data();
+		hr.seq_words = dO.seq_words; hr.N_total = dO.N_total; hr.max_len = max_len;
+		int64_t frag_rows = 0;
+		if((rc = kmahip_frag_write3((part + ".frag.gz").c_str(), db, &hr, h_rc.data(), h_tm.data(), h_nh.data(), h_st.data(), mf, 0, h_fr.data(),
+		                            name_recv.data(), h_name_off.data(), &frag_rows))) return rc;
+	}
+	ms[6] = since(t);
+	if((rc = kmahip_comm_barrier(comm))) return rc;
+	if(rank == 0) {
+		if((rc = concat_parts(prefix, ".res", W, "#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n")) ||
+		   (rc = concat_parts(prefix, ".fsa", W, nullptr)) || (rc = concat_parts(prefix, ".frag.gz", W, nullptr))) return rc;
+	}
+	if((rc = kmahip_comm_barrier(comm))) return rc;
+	ms[7] = since(t);
+	return KMAHIP_OK;
+}

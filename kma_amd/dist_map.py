@@ -37,6 +37,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     with binding.Ingest(a.i) as ing:
         got = ing.next(1 << 62)
+        ing.status()
     if got is None:
         batch, names = ReadBatch(np.zeros(1, np.uint64), np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.int64)), []
     else:

@@ -113,7 +113,7 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
     subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"] + extra,
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="700") if mf else None)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -178,7 +178,7 @@ def test_paired_fuzz_equals_reference_binary(tmp_path, seed):
     extra = [] if seed % 3 == 0 else ["-mf", str(int(rng.integers(2, 3000)))]
     subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"] + extra,
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="300"))
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -210,7 +210,7 @@ def test_paired_stream_of_singles_equals_reference_binary(tmp_path):
                     f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
         subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
                        check=True, stderr=subprocess.DEVNULL)
-        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"],
+        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"],
                        check=True, stderr=subprocess.DEVNULL)
         assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
         assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), case
@@ -297,7 +297,7 @@ def test_empty_input_equals_reference_binary(tmp_path, mode):
             (tmp_path / f).write_bytes(text)
         if mode == "-ipe":
             ra = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-apm", "p", "-1t1"]
-            ga = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-1t1"]
+            ga = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-1t1", "-apm", "p"]
         else:
             ra = ["-i", str(tmp_path / "r1.fq")] + (["-1t1"] if mode == "-1t1" else [])
             ga = ["-i", str(tmp_path / "r1.fq"), "-1t1" if mode == "-1t1" else "-chain"]
@@ -436,7 +436,7 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + b"I" * 150 + b"\n")
     subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"],
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"],
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"],
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()

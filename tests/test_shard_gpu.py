@@ -1,0 +1,159 @@
+"""The C host program over several ranks (examples/kmahip_map -gpus N: one process per rank, kmahip_run_se_sharded, the
+communicator of comm.hip) against the same program on one rank: `.res` and `.fsa` byte for byte, `.frag.gz` after inflating.
+On the one-GPU test box every rank uses device 0 and the exchanges are staged through shared memory (KMAHIP_COMM=shm); with two
+devices visible the RCCL backend runs as well. Also: the command lines BASELINE.json spells, given to the reference and to
+kmahip_map alike, and inputs that break off."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kma_amd import formats, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+MAP = os.path.join(ROOT, "examples", "kmahip_map")
+
+
+def _case(tmp_path, n=14000, gz=False):
+    """a 200-gene database and a stream of reads with substitutions, insertions and deletions (their pile-up depends on the order
+    of the reads), unmappable reads, ragged lengths and a few N's"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(n_families=40, variants=5, seed=77)
+    reads, *_ = synth.make_reads(seqs, n, read_len=150, sub_rate=0.01, random_frac=0.02, seed=78)
+    rag = [r for r in reads]
+    rng = np.random.default_rng(5)
+    for g in rng.integers(0, len(seqs), 60):
+        if len(seqs[g]) > 260:
+            rag += synth.make_long_reads(seqs[g], 40, read_len=250, sub=0.01, dele=0.012, ins=0.012, seed=int(g) + 1)
+    rag = [rag[i] for i in rng.permutation(len(rag))]
+    for i in rng.integers(0, len(rag), 40):
+        rag[i] = rag[i].copy()
+        rag[i][int(rng.integers(0, len(rag[i])))] = 4
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, rag, prefix="q")
+    if gz:
+        subprocess.check_call(["gzip", "-1", fq])
+        fq += ".gz"
+    return prefix, fq
+
+
+def _run(args, env=None, ok=True):
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.update(env or {})
+    r = subprocess.run([MAP] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if ok:
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return r
+
+
+def _same_files(a, b):
+    assert open(a + ".res", "rb").read() == open(b + ".res", "rb").read() and open(a + ".res").read().count("\n") > 30
+    assert open(a + ".fsa", "rb").read() == open(b + ".fsa", "rb").read()
+    assert gzip.open(a + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
+
+
+@pytest.mark.parametrize("world,mf,gz", [(2, None, False), (3, 1500, False), (2, 1700, True)])
+def test_ranks_of_the_c_host_program_write_the_single_rank_files(tmp_path, world, mf, gz):
+    prefix, fq = _case(tmp_path, gz=gz)
+    extra = ["-mf", str(mf)] if mf else []
+    _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one"), "-1t1"] + extra)
+    _run(["-gpus", str(world), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many"), "-1t1"] + extra, env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
+    _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("many.part")]      # the parts are gone
+
+
+def test_ranks_over_rccl_when_two_devices_are_visible(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices (the placement-independent logic is covered by the shm backend above)")
+    prefix, fq = _case(tmp_path)
+    _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one"), "-1t1"])
+    _run(["-gpus", "2", "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many"), "-1t1"])
+    _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
+
+
+def test_byte_ranges_of_the_readers_tile_the_file(tmp_path):
+    """kmahip_ingest_open_part: the parts of a plain FASTQ file, read one after the other, are the whole file's records in order"""
+    import ctypes as C
+    from kma_amd import binding
+    prefix, fq = _case(tmp_path, n=3000)
+    L = binding.lib()
+    L.kmahip_ingest_open_part.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+
+    def part(p, parts):
+        h, whole = C.c_void_p(), C.c_int(-1)
+        assert L.kmahip_ingest_open_part(fq.encode(), None, None, p, parts, C.byref(h), C.byref(whole)) == 0
+        assert whole.value == 0
+        b = binding.ReadBatchC()
+        assert L.kmahip_ingest_next(h, 1 << 62, C.byref(b)) == 0
+        n = b.reads.n_reads
+        off = np.ctypeslib.as_array(C.cast(b.name_off, C.POINTER(C.c_int64)), shape=(n + 1,)).copy() if n else np.zeros(1, np.int64)
+        names = C.string_at(b.names, int(off[-1])).split(b"\0")[:n] if n else []
+        lens = np.ctypeslib.as_array(C.cast(b.reads.len, C.POINTER(C.c_int32)), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        L.kmahip_ingest_close(h)
+        return names, lens
+    all_names, all_lens = part(0, 1)
+    assert len(all_names) > 3000
+    for parts in (2, 3, 7):
+        got = [part(p, parts) for p in range(parts)]
+        assert [x for g in got for x in g[0]] == all_names
+        assert np.array_equal(np.concatenate([g[1] for g in got]), all_lens)
+        assert all(len(g[0]) > 0 for g in got)
+
+
+def test_baseline_command_lines_give_the_reference_files(tmp_path):
+    """the literal command lines of BASELINE.json's configs (scaled down), with the thread and output switches scripts pass"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    prefix, fq = _case(tmp_path, n=5000)
+    names, seqs = synth.make_gene_db(n_families=40, variants=5, seed=77)
+    m1, m2, _ = synth.make_pairs(seqs, 2000, seed=9)
+    synth.write_fastq(str(tmp_path / "r1.fq"), list(m1), prefix="p")
+    synth.write_fastq(str(tmp_path / "r2.fq"), list(m2), prefix="p")
+    r1, r2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    cases = [
+        ["-i", fq, "-t_db", prefix, "-1t1"],                                        # C1 / C2
+        ["-i", fq, "-t_db", prefix, "-1t1", "-t", "4", "-nc", "-na", "-nf"],       # the output switches of BASELINE.md R2
+        ["-ipe", r1, r2, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],         # C3
+        ["-i", fq, "-t_db", prefix, "-1t1", "-mp", "30", "-ml", "40", "-eq", "25", "-mf", "900"],
+        ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-bcNano"],                       # C4's switches
+        ["-i", fq, "-t_db", prefix, "-t", "2"],                                    # the default mode
+    ]
+    for i, args in enumerate(cases):
+        ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
+        subprocess.run([KMA] + args + ["-o", ref] + ([] if "-t" in args else ["-t", "1"]), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _run(args + ["-o", got])
+        assert open(got + ".res", "rb").read() == open(ref + ".res", "rb").read(), args
+        for ext, opener in ((".fsa", open), (".frag.gz", gzip.open)):
+            assert os.path.exists(got + ext) == os.path.exists(ref + ext), (args, ext)
+            if os.path.exists(ref + ext):
+                a, b = opener(got + ext, "rb").read(), opener(ref + ext, "rb").read()
+                if ext == ".frag.gz" and "-t" in args and args[args.index("-t") + 1] != "1":
+                    a, b = sorted(a.splitlines()), sorted(b.splitlines())      # (the reference's row order depends on its threads' timing)
+                assert a == b, (args, ext)
+    # what is not built is refused, not ignored
+    for bad in (["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-apm", "u"], ["-ipe", r1, r2, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1"],
+                ["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-sam"]):
+        assert _run(bad, ok=False).returncode != 0
+
+
+def test_input_that_breaks_off_ends_the_run_with_an_error(tmp_path):
+    """a truncated .gz and a record that is no FASTQ: the reference exits non-zero; so must the one-batch host program (it asks
+    the reader once more behind the batch)"""
+    prefix, fq = _case(tmp_path, n=3000)
+    raw = open(fq, "rb").read()
+    z = gzip.compress(raw, 1)
+    (tmp_path / "cut.fq.gz").write_bytes(z[: len(z) // 2])
+    cut = raw.index(b"\n@q", len(raw) // 2) + 1                                   # between two records
+    (tmp_path / "bad.fq").write_bytes(raw[:cut] + b"this is no record\n" + raw[cut:])
+    for f in ("cut.fq.gz", "bad.fq"):
+        r = _run(["-i", str(tmp_path / f), "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1"], ok=False)
+        assert r.returncode != 0, f
+        assert b"ingest" in r.stderr
