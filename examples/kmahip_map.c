@@ -238,7 +238,7 @@ int main(int argc, char **argv) {
 		rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE")); local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
 		if(!key) { snprintf(keybuf, sizeof keybuf, "port%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0"); key = keybuf; }
 	}
-	if(world > 1 && (!one2one || input2 || mt1)) { fprintf(stderr, "kmahip_map: several ranks are built for the single-end -1t1 run\n"); return 2; }
+	if(world > 1 && (!one2one || mt1)) { fprintf(stderr, "kmahip_map: several ranks are built for the -1t1 runs (single end and -ipe ... -apm p)\n"); return 2; }
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s();
@@ -274,7 +274,10 @@ int main(int argc, char **argv) {
 	if(world > 1) {
 		/* an input the reader could not cut by bytes was delivered whole: this rank keeps its share of the records */
 		if(job.whole_input) {
-			const int64_t n_all = b.reads.n_reads, lo = n_all * rank / world, hi = n_all * (rank + 1) / world;
+			const int64_t n_all = b.reads.n_reads;
+			int64_t lo = n_all * rank / world, hi = n_all * (rank + 1) / world;
+			if(lo < n_all && b.pair[lo] == 2) ++lo;          /* (a pair is never cut: the second mate goes with the first) */
+			if(hi < n_all && b.pair[hi] == 2) ++hi;
 			const int64_t so = b.reads.seq_off[lo], no = b.reads.N_off[lo], co = b.name_off[lo];
 			int64_t *seq_off = xcalloc((size_t) (hi - lo) + 1, 8), *N_off = xcalloc((size_t) (hi - lo) + 1, 8), *name_off = xcalloc((size_t) (hi - lo) + 1, 8);
 			for(int64_t i = lo; i <= hi; ++i) { seq_off[i - lo] = b.reads.seq_off[i] - so; N_off[i - lo] = b.reads.N_off[i] - no; name_off[i - lo] = b.name_off[i] - co; }
@@ -286,7 +289,7 @@ int main(int argc, char **argv) {
 		memset(&so, 0, sizeof so);
 		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		double ms[8];
-		if(kmahip_run_se_sharded(db, ws, comm, &b, &par, &so, out, ms)) die("kmahip_run_se_sharded");
+		if(input2 ? kmahip_run_pe_sharded(db, ws, comm, &b, &par, &so, out, ms) : kmahip_run_se_sharded(db, ws, comm, &b, &par, &so, out, ms)) die("sharded run");
 		if(rank == 0) {
 			char path[4096];
 			if(no_cons) { snprintf(path, sizeof path, "%s.fsa", out); remove(path); }

@@ -573,6 +573,13 @@ typedef struct kmahip_shard_opts {
 } kmahip_shard_opts;
 int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
+/* The paired run (`-ipe r1 r2 -apm p -1t1`, kmahip_run_pe) the same way. `batch`: this rank's contiguous part of the stream of
+ * units (pairs and single records; a pair is never cut). On top of the three exchanges above, two things cross the shards because
+ * runConClave walks ONE stream: a record whose hit list came out empty takes the first listed hit of the last record before it
+ * that had one (conclave.c:123-127) -- the shards hand that hit on --, and the chunks of maxFrag filed fragments close one after
+ * the other (conclave.c:164-196) -- the ranks count theirs in turn. */
+int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                          const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 
 /* Status of the *_dev calls issued on this workspace since the last query; synchronises `stream`. 0, or KMAHIP_EOVERFLOW
  * with kmahip_last_error() naming one of:

@@ -24,6 +24,10 @@ struct CCArgs {
 	int32_t *o_tmpl, *o_start, *o_end;
 	unsigned long long *w_scores, *depth;
 	uint32_t *frag_counts, *read_counts;
+	// a record with an empty list takes the first listed hit of the last record BEFORE it that had any (below); for the first such
+	// records of a read shard that is a record of an earlier shard: what it left behind (0, 0, 0 at the start of the stream)
+	int carry_t, carry_s, carry_e;
+	int32_t *last_out;           // conclave_last_kernel: {valid, tmpl, start, end} of this shard's last record with a list
 };
 
 struct Rec { int n, score, q_len, q_len2; int64_t o; };
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256) void conclave_kernel(const CCArgs A) {
 			// empty list: runConClave reads zero entries and uses element 0 of its buffers (conclave.c:123-127) = the
 			// first listed hit of the last record in the stream that had any
 			Rec q;
+			tt = A.carry_t; st = A.carry_s; en = A.carry_e;
 			for(int64_t s2 = s - 1; s2 >= 0; --s2) {
 				if(record_at(A, s2, q) && q.n >= 1) { tt = A.h_tmpl[q.o]; st = A.h_start[q.o]; en = A.h_end[q.o]; break; }
 			}
@@ -112,6 +117,15 @@ __global__ __launch_bounds__(256) void conclave_kernel(const CCArgs A) {
 	if(A.frag_counts) atomicAdd(&A.frag_counts[t], 1u);
 	if(A.read_counts) atomicAdd(&A.read_counts[t], r.score < 0 ? 2u : 1u);
 	if(A.depth) atomicAdd(&A.depth[t], (unsigned long long) (r.q_len + (r.score < 0 ? r.q_len2 : 0)));
+}
+
+// what the records of the NEXT shard inherit: the first listed hit of this shard's last record that has a list
+__global__ void conclave_last_kernel(const CCArgs A) {
+	Rec q;
+	A.last_out[0] = 0;
+	for(int64_t s2 = A.n_slots - 1; s2 >= 0; --s2) {
+		if(record_at(A, s2, q) && q.n >= 1) { A.last_out[0] = 1; A.last_out[1] = A.h_tmpl[q.o]; A.last_out[2] = A.h_start[q.o]; A.last_out[3] = A.h_end[q.o]; return; }
+	}
 }
 
 } // namespace
@@ -156,6 +170,29 @@ extern "C" int kmahip_conclave_pe_dev(kmahip_db *db, kmahip_ws *ws, const kmahip
 
 // explicit records with everything in HBM (the paired run builds them on the device: two slots per unit of the stream, an
 // unused slot = a record with n_hits 0 and score 0, which ConClave passes over)
+// for a read-sharded paired run (pipeline.hip): the records of one shard with what the shard before left behind for records with
+// an empty list (carry: tmpl, start, end) ...
+int kmahip_conclave_records_carry(kmahip_db *db, int64_t n_records, const int32_t *q_len, const int32_t *q_len2, const int64_t *off, const kmahip_hits *hits,
+                                  kmahip_conclave *out, const int32_t carry[3], hipStream_t stream) {
+	if(!db || !q_len || !off || !hits || !out || n_records < 0 || !carry) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	CCArgs A{};
+	A.n_slots = n_records; A.pe = 2; A.len = q_len; A.len2 = q_len2; A.off = off;
+	A.carry_t = carry[0]; A.carry_s = carry[1]; A.carry_e = carry[2];
+	return launch_conclave(db, A, hits, out, stream);
+}
+// ... and what this shard leaves behind: d_last[4] (device) = {1, tmpl, start, end} of its last record with a list, {0, ...} if none
+int kmahip_conclave_records_last(kmahip_db *db, int64_t n_records, const int32_t *q_len, const int32_t *q_len2, const int64_t *off, const kmahip_hits *hits,
+                                 int32_t *d_last, hipStream_t stream) {
+	if(!db || !q_len || !off || !hits || !d_last || n_records < 0) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	CCArgs A{};
+	A.n_slots = n_records; A.pe = 2; A.len = q_len; A.len2 = q_len2; A.off = off;
+	A.n_hits = hits->n_hits; A.best_score = hits->best_score; A.h_tmpl = hits->tmpl; A.h_start = hits->start; A.h_end = hits->end;
+	A.last_out = d_last;
+	hipLaunchKernelGGL(conclave_last_kernel, dim3(1), dim3(1), 0, stream, A);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}
+
 extern "C" int kmahip_conclave_records_dev(kmahip_db *db, kmahip_ws *ws, int64_t n_records, const int32_t *q_len, const int32_t *q_len2,
                                            const int64_t *off, const kmahip_hits *hits, kmahip_conclave *out, void *stream) {
 	(void) ws;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void pe_frag_count_kernel(int64_t n_slots, con
 // record on the host); a fragment is handed on as position c (maxFrag + 1) + index, with maxFrag + 1 as the chunk length the
 // pile-up and the writer divide by.
 __global__ __launch_bounds__(256) void pe_frag_fill_kernel(int64_t n_slots, const int32_t *c_tmpl, const int32_t *r_n, const int32_t *fr_read, const int32_t *fr_rc,
-                                                           const int64_t *f_off, const int64_t *starts, int n_starts, int64_t mf, int64_t *f_src, int32_t *f_rc,
+                                                           const int64_t *f_off, const int64_t *starts, int n_starts, int64_t mf, int64_t chunk_base, int64_t *f_src, int32_t *f_rc,
                                                            int32_t *f_t, int32_t *f_nh, int64_t *f_rank) {
 	const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(s >= n_slots) return;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void pe_frag_fill_kernel(int64_t n_slots, cons
 		int lo = 0, hi = n_starts;          // last chunk that starts at or before g
 		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(starts[mid] <= g) lo = mid; else hi = mid; }
 		f_src[g] = fr_read[2 * s + x]; f_rc[g] = fr_rc[2 * s + x]; f_t[g] = x == 0 ? tt : abs(tt); f_nh[g] = r_n[s];
-		f_rank[g] = (int64_t) lo * (mf + 1) + (g - starts[lo]);
+		f_rank[g] = (chunk_base + lo) * (mf + 1) + (g - starts[lo]);
 		++g;
 	}
 }
@@ -393,8 +393,36 @@ __global__ __launch_bounds__(256) void pe_stats4_kernel(int64_t n, const int32_t
 
 }  // namespace
 
+int kmahip_conclave_records_carry(kmahip_db *db, int64_t n_records, const int32_t *q_len, const int32_t *q_len2, const int64_t *off, const kmahip_hits *hits,
+                                  kmahip_conclave *out, const int32_t carry[3], hipStream_t stream);                                    // conclave.hip
+int kmahip_conclave_records_last(kmahip_db *db, int64_t n_records, const int32_t *q_len, const int32_t *q_len2, const int64_t *off, const kmahip_hits *hits,
+                                 int32_t *d_last, hipStream_t stream);
+// what a read-sharded run adds to the paired run: the communicator and where the owners' results go
+struct ShardCtx {
+	kmahip_comm *comm;
+	const kmahip_shard_opts *opts;
+	const char *out_prefix;
+	double *ms;
+	std::vector<uint64_t> frag_counts;       // summed over the ranks: the owners' template ranges are cut by them
+};
+static int shard_pe_tail(ShardCtx *sc, kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_read_batch *batch, const kmahip_reads &dF, const int32_t *f_rc, const int32_t *f_t,
+                         const int32_t *f_nh, const int64_t *f_rank, const kmahip_traces &tr, const int64_t *h_src, const kmahip_res_row *rows, int64_t n_rows, int64_t chunk,
+                         std::chrono::steady_clock::time_point &t);
+static int shard_allreduce(ShardCtx *sc, uint64_t *d_buf, size_t n);
+static int shard_carry_in(ShardCtx *sc, const int32_t last[4], int32_t carry[3]);
+static int shard_chunk_token(ShardCtx *sc, bool receive, int64_t state[2]);
+static uint64_t *shard_frag_counts(ShardCtx *sc, size_t D);
+
+static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
+                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc);
+
 extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
                              int64_t max_frag, const char *frag_path, kmahip_run *out) {
+	return run_pe_impl(db, ws, batch, p, evalue, bcd, max_frag, frag_path, out, nullptr);
+}
+
+static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
+                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc) {
 	if(!db || !ws || !batch || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len ||
 	   (!batch->pair && batch->reads.n_reads > 0)) {
 		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
@@ -522,6 +550,7 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 		if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
 	}
 	out->ms[1] = since(t);
+	if(sc && ((rc = shard_allreduce(sc, AS, D)) || (rc = shard_allreduce(sc, US, D)))) return rc;          // exchange 1
 
 	// the records in stream order, stage 3b over them, the `.res` statistics
 	RecArgs A{};
@@ -535,12 +564,32 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	if((rc = B.get((size_t) n_slots + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n_slots + 1, &cc.start, true)) || (rc = B.get((size_t) n_slots + 1, &cc.end, true)) ||
 	   (rc = B.get(D, &cc.w_scores, true))) return rc;
 	cc.fragment_counts = nullptr; cc.read_counts = nullptr; cc.depth = nullptr;
-	if(U > 0) {
-		hipLaunchKernelGGL(pe_records_kernel, dim3((unsigned) ((U + 255) / 256)), dim3(256), 0, s, A);
+	if(sc && (rc = B.get(D, &cc.fragment_counts, true))) return rc;
+	{
+		if(U > 0) hipLaunchKernelGGL(pe_records_kernel, dim3((unsigned) ((U + 255) / 256)), dim3(256), 0, s, A);
 		HIP_TRY(hipGetLastError());
 		kmahip_hits h{};
 		h.n_hits = A.r_n; h.best_score = A.r_score; h.tmpl = H_tmpl; h.start = H_start; h.end = H_end; h.alignment_scores = AS; h.uniq_alignment_scores = US;
-		if((rc = kmahip_conclave_records_dev(db, ws, n_slots, A.r_ql, A.r_ql2, A.r_off, &h, &cc, s))) return rc;
+		if(sc) {
+			// a record with an empty list takes the first listed hit of the last record before it that had one -- for the first such
+			// records of this shard that is a record of an earlier shard (conclave.c:123-127)
+			int32_t *d_last = nullptr, last[4] = {0, 0, 0, 0}, carry[3] = {0, 0, 0};
+			if((rc = B.get(4, &d_last, true))) return rc;
+			if(U > 0 && (rc = kmahip_conclave_records_last(db, n_slots, A.r_ql, A.r_ql2, A.r_off, &h, d_last, s))) return rc;
+			HIP_TRY(hipMemcpy(last, d_last, sizeof last, hipMemcpyDeviceToHost));
+			if((rc = shard_carry_in(sc, last, carry))) return rc;
+			if(U > 0 && (rc = kmahip_conclave_records_carry(db, n_slots, A.r_ql, A.r_ql2, A.r_off, &h, &cc, carry, s))) return rc;
+		} else if(U > 0 && (rc = kmahip_conclave_records_dev(db, ws, n_slots, A.r_ql, A.r_ql2, A.r_off, &h, &cc, s))) return rc;
+	}
+	if(sc) {          // exchange 2: ConClave's per-template outputs summed (the fragment counts cut the owners' template ranges)
+		uint64_t *fc = shard_frag_counts(sc, D), *d_fc = nullptr;
+		std::vector<uint32_t> c32(D);
+		HIP_TRY(hipMemcpy(c32.data(), cc.fragment_counts, D * 4, hipMemcpyDeviceToHost));
+		for(size_t x = 0; x < D; ++x) fc[x] = c32[x];
+		if((rc = B.get(D, &d_fc))) return rc;
+		HIP_TRY(hipMemcpy(d_fc, fc, D * 8, hipMemcpyHostToDevice));
+		if((rc = shard_allreduce(sc, (uint64_t *) cc.w_scores, D)) || (rc = shard_allreduce(sc, d_fc, D))) return rc;
+		HIP_TRY(hipMemcpy(fc, d_fc, D * 8, hipMemcpyDeviceToHost));
 	}
 	std::vector<uint64_t> w(D);
 	HIP_TRY(hipMemcpy(w.data(), cc.w_scores, D * 8, hipMemcpyDeviceToHost));
@@ -564,9 +613,14 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	HIP_TRY(hipMemcpyAsync(&nf, f_off + n_slots, 8, hipMemcpyDeviceToHost, s));
 	if(n_slots) HIP_TRY(hipMemcpyAsync(cnt8.data(), d_cnt8, (size_t) n_slots, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	std::vector<int64_t> starts{0};
+	// (a read shard continues the chunk the shards before it left open: it starts `in_chunk` fragments before this shard's first
+	// one, and `chunk_base` chunks are closed already; the ranks take their turns in stream order)
+	int64_t token[2] = {0, 0};
+	if(sc && (rc = shard_chunk_token(sc, true, token))) return rc;
+	const int64_t chunk_base = token[1];
+	std::vector<int64_t> starts{-token[0]};
 	{
-		int64_t filed = 0, in_chunk = 0;
+		int64_t filed = 0, in_chunk = token[0];
 		for(int64_t k = 0; k < n_slots;) {
 			if(k + 8 <= n_slots) {          // eight slots at once while no chunk can close among them (a slot counts 2 at most)
 				uint64_t v;
@@ -579,7 +633,9 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 			filed += c; in_chunk += c;
 			if(in_chunk >= mf) { starts.push_back(filed); in_chunk = 0; }
 		}
+		token[0] = in_chunk; token[1] = chunk_base + (int64_t) starts.size() - 1;
 	}
+	if(sc && (rc = shard_chunk_token(sc, false, token))) return rc;
 	stamp("fragment count + chunks");
 	const int64_t *d_starts = nullptr;
 	if((rc = B.up(starts.data(), starts.size(), 1, &d_starts))) return rc;
@@ -592,7 +648,7 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 	memset(&tr, 0, sizeof tr);
 	if(nf > 0) {
 		hipLaunchKernelGGL(pe_frag_fill_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, s, n_slots, cc.tmpl, A.r_n, A.fr_read, A.fr_rc, f_off, d_starts,
-		                   (int) starts.size(), mf, f_src, f_rc, f_t, f_nh, f_rank);
+		                   (int) starts.size(), mf, chunk_base, f_src, f_rc, f_t, f_nh, f_rank);
 		HIP_TRY(hipGetLastError());
 		if((rc = gather_batch(B, dR, f_src, nf, &dF, s))) return rc;
 		stamp("fragment batch");
@@ -615,6 +671,18 @@ extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_bat
 		}
 	}
 	out->ms[3] = since(t);
+	if(sc) {
+		// exchange 3 and the owners' work: the filed fragments travel with their positions (shard_finish)
+		std::vector<int64_t> src((size_t) nf + 1);
+		if(nf) HIP_TRY(hipMemcpy(src.data(), f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		if(nf == 0) {          // (an empty fragment batch still takes part in the exchanges)
+			if((rc = B.get(1, const_cast<uint64_t **>(&dF.seq), true)) || (rc = B.get(2, const_cast<int64_t **>(&dF.seq_off), true)) || (rc = B.get(1, const_cast<int32_t **>(&dF.len), true)) ||
+			   (rc = B.get(1, const_cast<int32_t **>(&dF.N), true)) || (rc = B.get(2, const_cast<int64_t **>(&dF.N_off), true)) ||
+			   (rc = B.get(16, &tr.stats, true)) || (rc = B.get(2, &tr.ops_off, true)) || (rc = B.get(2, &tr.n_ops, true)) || (rc = B.get(2, &tr.ops, true))) return rc;
+			dF.n_reads = 0; dF.max_len = R.max_len;
+		}
+		return shard_pe_tail(sc, db, ws, B, batch, dF, f_rc, f_t, f_nh, f_rank, tr, src.data(), out->rows, out->n_rows, mf + 1, t);
+	}
 
 	// stage 3c per template
 	if(nf > 0) {
@@ -937,13 +1005,18 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(int64_t D, const uint64
 }
 
 // filed flag per read (ConClave gave it a template) for the scan that numbers the filed fragments; destination of a kept read
-__global__ __launch_bounds__(256) void shard_dest_kernel(int64_t n, const int32_t *tmpl, const int32_t *stats, const int32_t *owner, int world, int64_t *filed,
-                                                         uint32_t *dest, int64_t *idx) {
+__global__ __launch_bounds__(256) void shard_filed_kernel(int64_t n, const int32_t *tmpl, int64_t *filed) {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(i > n) return;
-	if(i == n) { filed[n] = 0; return; }
+	if(i <= n) filed[i] = i < n && tmpl[i] != 0;
+}
+__global__ __launch_bounds__(256) void shard_add_kernel(int64_t n, int64_t *v, int64_t base) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) v[i] += base;
+}
+__global__ __launch_bounds__(256) void shard_dest_kernel(int64_t n, const int32_t *tmpl, const int32_t *stats, const int32_t *owner, int world, uint32_t *dest, int64_t *idx) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
 	const int t = tmpl[i];
-	filed[i] = t != 0;
 	const int dd = (t != 0 && stats[10 * i + 3] != 0) ? owner[abs(t)] : world;
 	dest[i] = (uint32_t) dd; idx[i] = i;
 }
@@ -955,7 +1028,7 @@ __global__ __launch_bounds__(256) void shard_bounds_kernel(int64_t n, const uint
 	if(i == 0 || sorted[i] != sorted[i - 1]) first[sorted[i]] = (unsigned long long) i;
 }
 
-__global__ __launch_bounds__(256) void shard_rows_kernel(int64_t m, const int64_t *idx, int64_t rank_base, const int64_t *filed_before, const int32_t *len, const int32_t *rc,
+__global__ __launch_bounds__(256) void shard_rows_kernel(int64_t m, const int64_t *idx, const int64_t *frag_rank, const int32_t *len, const int32_t *rc,
                                                          const int32_t *tmpl, const int32_t *n_hits, const int64_t *N_off, const int32_t *n_ops, const int32_t *stats,
                                                          int32_t *rows, int64_t *ops_cnt) {
 	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,7 +1036,7 @@ __global__ __launch_bounds__(256) void shard_rows_kernel(int64_t m, const int64_
 	if(x == m) { ops_cnt[m] = 0; return; }
 	const int64_t i = idx[x];
 	int32_t *r = rows + ROW * x;
-	const int64_t fr = rank_base + filed_before[i];
+	const int64_t fr = frag_rank[i];
 	r[0] = (int32_t) (fr & 0xFFFFFFFFll); r[1] = (int32_t) (fr >> 32);
 	r[2] = len[i]; r[3] = rc[i]; r[4] = tmpl[i]; r[5] = n_hits[i]; r[6] = (int32_t) (N_off[i + 1] - N_off[i]); r[7] = n_ops[i];
 	for(int k = 0; k < 10; ++k) r[8 + k] = stats[10 * i + k];
@@ -1015,6 +1088,237 @@ int concat_parts(const std::string &prefix, const char *ext, int world, const ch
 }
 
 }  // namespace
+
+// Exchange 3 and everything behind it, for single-end and paired runs alike. `d`: the rank's n items in HBM (reads, or the filed
+// fragments of a paired run) in the order of its part of the stream; tmpl (0: not filed), rc, n_hits, frag_rank (position among the
+// filed fragments of the WHOLE stream, chunk arithmetic of the caller included) and the traces are per item, DEVICE pointers;
+// name_src: which read of `batch` an item is (NULL: item i is read i). frag_counts: a per-template vector that is the same on every
+// rank (the summed fragment counts), which the owners are cut by. chunk: the chunk length the pile-up and the writer divide
+// frag_rank by.
+static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBlock &B, const kmahip_read_batch *batch, const kmahip_reads &d, const int32_t *i_tmpl,
+                        const int32_t *i_rc, const int32_t *i_nhits, const int64_t *i_frag_rank, const kmahip_traces &tr, const int64_t *name_src,
+                        const uint64_t *frag_counts, const kmahip_res_row *rows, int64_t n_rows, int64_t chunk, const kmahip_shard_opts *opts,
+                        const char *out_prefix, double ms[8], std::chrono::steady_clock::time_point &t) {
+	const int W = kmahip_comm_world(comm), rank = kmahip_comm_rank(comm);
+	const int64_t n = d.n_reads;
+	const size_t D = db->info.DB_size;
+	hipStream_t s = 0;
+	int rc;
+	// exchange 3: every kept read to the owner of its template. Owners: contiguous template ranges, cut where the filed fragments
+	// before a template reach the next 1 / W of all of them (the same on every rank: the counts are the summed ones).
+	std::vector<int32_t> owner(D, 0);
+	{
+		unsigned long long tot = 0, before = 0;
+		for(size_t tt = 0; tt < D; ++tt) tot += frag_counts[tt];
+		for(size_t tt = 0; tt < D; ++tt) {
+			owner[tt] = tot ? (int32_t) std::min<unsigned long long>((unsigned long long) (W - 1), (unsigned long long) ((unsigned __int128) before * (unsigned) W / tot)) : 0;
+			before += frag_counts[tt];
+		}
+	}
+	const int32_t *d_owner = nullptr;
+	if((rc = B.up(owner.data(), D, 0, &d_owner))) return rc;
+	int64_t *idx = nullptr, *idx2 = nullptr;
+	uint32_t *dest = nullptr, *dest2 = nullptr;
+	unsigned long long *d_cnt = nullptr;
+	if((rc = B.get((size_t) n + 1, &idx)) || (rc = B.get((size_t) n + 1, &idx2)) || (rc = B.get((size_t) n + 1, &dest)) || (rc = B.get((size_t) n + 1, &dest2)) ||
+	   (rc = B.get((size_t) W + 2, &d_cnt))) return rc;
+	if(n) hipLaunchKernelGGL(shard_dest_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, i_tmpl, tr.stats, d_owner, W, dest, idx);
+	HIP_TRY(hipGetLastError());
+	// (the longest read of the run sizes the owners' scratch)
+	std::vector<int64_t> all_meta((size_t) W);
+	{
+		const int64_t mine = (int64_t) d.max_len;
+		if((rc = kmahip_comm_allgather(comm, &mine, sizeof mine, all_meta.data()))) return rc;
+	}
+	int max_len = 0;
+	for(int r = 0; r < W; ++r) max_len = std::max(max_len, (int) all_meta[(size_t) r]);
+	// kept reads ordered by destination, stream order inside one (a stable sort on the few bits of the destination)
+	if(n) {
+		size_t tmp_bytes = 0;
+		int bits = 1;
+		while((1 << bits) <= W) ++bits;
+		if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
+		char *tmp = nullptr;
+		if((rc = B.get(tmp_bytes, &tmp))) return rc;
+		if(rocprim::radix_sort_pairs(tmp, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
+	}
+	std::vector<int64_t> seg((size_t) W + 1, 0);
+	std::vector<unsigned long long> cnt((size_t) W + 1, 0);
+	{
+		std::vector<unsigned long long> first((size_t) W + 2, ~0ull);
+		HIP_TRY(hipMemcpyAsync(d_cnt, first.data(), ((size_t) W + 2) * 8, hipMemcpyHostToDevice, s));
+		if(n) hipLaunchKernelGGL(shard_bounds_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, dest2, d_cnt);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(first.data(), d_cnt, ((size_t) W + 2) * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		first[(size_t) W + 1] = (unsigned long long) n;
+		for(int r = W; r >= 0; --r) if(first[(size_t) r] == ~0ull) first[(size_t) r] = first[(size_t) r + 1];       // (a destination nobody goes to)
+		for(int r = 0; r <= W; ++r) { if(r <= W) seg[(size_t) std::min(r, W)] = (int64_t) first[(size_t) r]; }
+		for(int r = 0; r < W; ++r) cnt[(size_t) r] = first[(size_t) r + 1] - first[(size_t) r];
+	}
+	const int64_t m = seg[(size_t) W];
+	kmahip_reads dK{};
+	int32_t *rows_d = nullptr;
+	int64_t *ops_cnt = nullptr, *ops_o = nullptr;
+	uint32_t *ops_k = nullptr;
+	if((rc = gather_batch(B, d, idx2, m, &dK, s))) return rc;
+	if((rc = B.get((size_t) ROW * m + ROW, &rows_d)) || (rc = B.get((size_t) m + 1, &ops_cnt)) || (rc = B.get((size_t) m + 1, &ops_o))) return rc;
+	hipLaunchKernelGGL(shard_rows_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, idx2, i_frag_rank, d.len, i_rc, i_tmpl, i_nhits, d.N_off, tr.n_ops,
+	                   tr.stats, rows_d, ops_cnt);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, ops_cnt, ops_o, (size_t) m + 1, s))) return rc;
+	int64_t ops_total = 0;
+	HIP_TRY(hipMemcpy(&ops_total, ops_o + m, 8, hipMemcpyDeviceToHost));
+	if((rc = B.get((size_t) ops_total + 1, &ops_k))) return rc;
+	if(m) hipLaunchKernelGGL(shard_ops_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, idx2, tr.ops_off, tr.n_ops, tr.ops, ops_o, ops_k);
+	HIP_TRY(hipGetLastError());
+	// block sizes per destination (rows, words, N positions, runs, name bytes), agreed on through the mailboxes
+	std::vector<int64_t> h_idx((size_t) m + 1), so_at((size_t) W + 1), no_at((size_t) W + 1), oo_at((size_t) W + 1);
+	if(m) HIP_TRY(hipMemcpy(h_idx.data(), idx2, (size_t) m * 8, hipMemcpyDeviceToHost));
+	for(int r = 0; r <= W; ++r) {
+		HIP_TRY(hipMemcpy(&so_at[(size_t) r], dK.seq_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&no_at[(size_t) r], dK.N_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&oo_at[(size_t) r], ops_o + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
+	}
+	std::vector<char> name_send;
+	std::vector<int64_t> name_at((size_t) W + 1, 0);
+	for(int r = 0; r < W; ++r) {
+		int64_t bytes = 0;
+		for(int64_t x = seg[(size_t) r]; x < seg[(size_t) r + 1]; ++x) { const int64_t i = name_src ? name_src[h_idx[(size_t) x]] : h_idx[(size_t) x]; bytes += batch->name_off[i + 1] - batch->name_off[i]; }
+		name_at[(size_t) r + 1] = name_at[(size_t) r] + bytes;
+	}
+	name_send.resize((size_t) name_at[(size_t) W] + 1);
+	{
+		char *o = name_send.data();
+		for(int64_t x = 0; x < m; ++x) { const int64_t i = name_src ? name_src[h_idx[(size_t) x]] : h_idx[(size_t) x]; const int64_t l = batch->name_off[i + 1] - batch->name_off[i]; memcpy(o, batch->names + batch->name_off[i], (size_t) l); o += l; }
+	}
+	constexpr int NA = 5;          // arrays that travel
+	std::vector<int64_t> mine((size_t) NA * W), all((size_t) NA * W * W);
+	for(int r = 0; r < W; ++r) {
+		mine[(size_t) (0 * W + r)] = (int64_t) cnt[(size_t) r] * ROW * 4;
+		mine[(size_t) (1 * W + r)] = (so_at[(size_t) r + 1] - so_at[(size_t) r]) * 8;
+		mine[(size_t) (2 * W + r)] = (no_at[(size_t) r + 1] - no_at[(size_t) r]) * 4;
+		mine[(size_t) (3 * W + r)] = (oo_at[(size_t) r + 1] - oo_at[(size_t) r]) * 4;
+		mine[(size_t) (4 * W + r)] = name_at[(size_t) r + 1] - name_at[(size_t) r];
+	}
+	if((rc = kmahip_comm_allgather(comm, mine.data(), mine.size() * 8, all.data()))) return rc;
+	std::vector<int64_t> rb[NA];
+	int64_t rtot[NA];
+	for(int a = 0; a < NA; ++a) {
+		rb[a].assign((size_t) W, 0);
+		rtot[a] = 0;
+		for(int src = 0; src < W; ++src) { rb[a][(size_t) src] = all[(size_t) src * NA * W + (size_t) a * W + (size_t) rank]; rtot[a] += rb[a][(size_t) src]; }
+	}
+	const int64_t m2 = rtot[0] / (ROW * 4);
+	int32_t *rows_r = nullptr, *N_r = nullptr;
+	uint64_t *seq_r = nullptr;
+	uint32_t *ops_r = nullptr;
+	if((rc = B.get((size_t) rtot[0] / 4 + ROW, &rows_r)) || (rc = B.get((size_t) rtot[1] / 8 + 2, &seq_r, true)) || (rc = B.get((size_t) rtot[2] / 4 + 1, &N_r)) ||
+	   (rc = B.get((size_t) rtot[3] / 4 + 1, &ops_r))) return rc;
+	std::vector<char> name_recv((size_t) rtot[4] + 1);
+	HIP_TRY(hipStreamSynchronize(s));
+	if((rc = kmahip_comm_alltoallv(comm, rows_d, &mine[0], rows_r, rb[0].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, dK.seq, &mine[(size_t) W], seq_r, rb[1].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, dK.N, &mine[(size_t) 2 * W], N_r, rb[2].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, ops_k, &mine[(size_t) 3 * W], ops_r, rb[3].data(), 1, s)) ||
+	   (rc = kmahip_comm_alltoallv(comm, name_send.data(), &mine[(size_t) 4 * W], name_recv.data(), rb[4].data(), 0, s))) return rc;
+	ms[4] = since(t);
+
+	// the owner's batch: what arrived is in source-rank order = the order of the whole stream
+	kmahip_reads dO{};
+	kmahip_traces trO;
+	memset(&trO, 0, sizeof trO);
+	int64_t *fr2 = nullptr, *w_cnt = nullptr, *n_cnt = nullptr, *o_cnt = nullptr, *so2 = nullptr, *no2 = nullptr, *oo2 = nullptr;
+	int32_t *len2 = nullptr, *rc2 = nullptr, *tm2 = nullptr, *nh2 = nullptr, *nops2 = nullptr, *st2 = nullptr;
+	if((rc = B.get((size_t) m2 + 1, &fr2)) || (rc = B.get((size_t) m2 + 1, &w_cnt)) || (rc = B.get((size_t) m2 + 1, &n_cnt)) || (rc = B.get((size_t) m2 + 1, &o_cnt)) ||
+	   (rc = B.get((size_t) m2 + 1, &so2)) || (rc = B.get((size_t) m2 + 1, &no2)) || (rc = B.get((size_t) m2 + 1, &oo2)) || (rc = B.get((size_t) m2 + 1, &len2, true)) ||
+	   (rc = B.get((size_t) m2 + 1, &rc2)) || (rc = B.get((size_t) m2 + 1, &tm2)) || (rc = B.get((size_t) m2 + 1, &nh2)) || (rc = B.get((size_t) m2 + 1, &nops2)) ||
+	   (rc = B.get((size_t) 10 * m2 + 10, &st2))) return rc;
+	hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned) ((m2 + 256) / 256)), dim3(256), 0, s, m2, rows_r, fr2, len2, rc2, tm2, nh2, nops2, st2, w_cnt, n_cnt, o_cnt);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, w_cnt, so2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, n_cnt, no2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, o_cnt, oo2, (size_t) m2 + 1, s))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	dO.n_reads = m2; dO.seq = seq_r; dO.seq_off = so2; dO.len = len2; dO.N = N_r; dO.N_off = no2; dO.seq_words = rtot[1] / 8; dO.N_total = rtot[2] / 4; dO.max_len = max_len;
+	trO.stats = st2; trO.ops_off = oo2; trO.n_ops = nops2; trO.ops = ops_r; trO.ops_cap = rtot[3] / 4;
+	// pile-up + consensus of the owned templates
+	kmahip_assembly asmb;
+	memset(&asmb, 0, sizeof asmb);
+	std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
+	int64_t tbases = 0;
+	for(size_t tt = 1; tt < D; ++tt) tbases += db->h_tlen[tt];
+	std::vector<char> cons((size_t) (4 * tbases + 4 * (int64_t) D + (1 << 20)));
+	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
+	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
+	if(m2) {
+		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, 0, opts->caller, opts->sig90, fr2};
+		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
+	}
+	ms[5] = since(t);
+
+	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
+	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
+	{
+		FILE *res = fopen((part + ".res").c_str(), "w"), *fsa = fopen((part + ".fsa").c_str(), "w");
+		if(!res || !fsa) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create the output parts of %s", out_prefix); return KMAHIP_EIO; }
+		std::vector<char> line((1 << 16) + 512);
+		std::string entry;
+		for(int64_t r = 0; r < n_rows; ++r) {
+			const kmahip_res_row &row = rows[r];
+			const size_t tt = (size_t) row.template_id;
+			if(owner[tt] != rank || !row.significant || tt - 1 >= db->h_names.size()) continue;
+			const std::string &name = db->h_names[tt - 1];
+			if(!kmahip_res_line(name.c_str(), &row, a_cover[tt], a_len[tt], a_depth[tt], opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, line.data(), (int64_t) line.size())) continue;
+			fputs(line.data(), res);
+			// printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line
+			entry.clear();
+			entry += ">"; entry += name; entry += "\n";
+			int col = 0;
+			for(const char *q = c_off[tt] >= 0 ? cons.data() + c_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
+			if(col) entry.push_back('\n');
+			fwrite(entry.data(), 1, entry.size(), fsa);
+		}
+		if(fclose(res) != 0 || fclose(fsa) != 0) { kmahip_set_error("write to the output parts of %s failed", out_prefix); return KMAHIP_EIO; }
+	}
+	{
+		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
+		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);
+		std::vector<int64_t> h_so((size_t) m2 + 1, 0), h_no((size_t) m2 + 1, 0), h_fr((size_t) m2 + 1, 0), h_name_off((size_t) m2 + 1, 0);
+		std::vector<int32_t> h_len((size_t) m2 + 1, 0), h_N((size_t) dO.N_total + 1, 0), h_rc((size_t) m2 + 1, 0), h_tm((size_t) m2 + 1, 0), h_nh((size_t) m2 + 1, 0), h_st((size_t) 10 * m2 + 10, 0);
+		if(dO.seq_words) HIP_TRY(hipMemcpy(hs.data(), seq_r, (size_t) dO.seq_words * 8, hipMemcpyDeviceToHost));
+		if(dO.N_total) HIP_TRY(hipMemcpy(h_N.data(), N_r, (size_t) dO.N_total * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_so.data(), so2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(h_no.data(), no2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
+		if(m2) {
+			HIP_TRY(hipMemcpy(h_fr.data(), fr2, (size_t) m2 * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_len.data(), len2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_rc.data(), rc2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_tm.data(), tm2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_nh.data(), nh2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(h_st.data(), st2, (size_t) m2 * 40, hipMemcpyDeviceToHost));
+		}
+		// names arrive NUL-terminated, back to back
+		{
+			int64_t at = 0;
+			for(int64_t x = 0; x < m2; ++x) { h_name_off[(size_t) x] = at; at += (int64_t) strlen(name_recv.data() + at) + 1; }
+			h_name_off[(size_t) m2] = at;
+		}
+		kmahip_reads hr{};
+		hr.n_reads = m2; hr.seq = hs.data(); hr.seq_off = h_so.data(); hr.len = h_len.data(); hr.N = h_N.data(); hr.N_off = h_no.data();
+		hr.seq_words = dO.seq_words; hr.N_total = dO.N_total; hr.max_len = max_len;
+		int64_t frag_rows = 0;
+		if((rc = kmahip_frag_write3((part + ".frag.gz").c_str(), db, &hr, h_rc.data(), h_tm.data(), h_nh.data(), h_st.data(), chunk, 0, h_fr.data(),
+		                            name_recv.data(), h_name_off.data(), &frag_rows))) return rc;
+	}
+	ms[6] = since(t);
+	if((rc = kmahip_comm_barrier(comm))) return rc;
+	if(rank == 0) {
+		if((rc = concat_parts(prefix, ".res", W, "#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n")) ||
+		   (rc = concat_parts(prefix, ".fsa", W, nullptr)) || (rc = concat_parts(prefix, ".frag.gz", W, nullptr))) return rc;
+	}
+	if((rc = kmahip_comm_barrier(comm))) return rc;
+	ms[7] = since(t);
+	return KMAHIP_OK;
+}
 
 extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                                      const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
@@ -1116,222 +1420,85 @@ extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	if(!tr.ops && (rc = B.get(16, &tr.ops))) return rc;
 	ms[3] = since(t);
 
-	// exchange 3: every kept read to the owner of its template. Owners: contiguous template ranges, cut where the filed fragments
-	// before a template reach the next 1 / W of all of them (the same on every rank: the counts are the summed ones).
-	std::vector<int32_t> owner(D, 0);
-	{
-		unsigned long long tot = 0, before = 0;
-		for(size_t tt = 0; tt < D; ++tt) tot += hx[2 * D + tt];
-		for(size_t tt = 0; tt < D; ++tt) {
-			owner[tt] = tot ? (int32_t) std::min<unsigned long long>((unsigned long long) (W - 1), (unsigned long long) ((unsigned __int128) before * (unsigned) W / tot)) : 0;
-			before += hx[2 * D + tt];
-		}
-	}
-	const int32_t *d_owner = nullptr;
-	if((rc = B.up(owner.data(), D, 0, &d_owner))) return rc;
-	int64_t *filed = nullptr, *filed_before = nullptr, *idx = nullptr, *idx2 = nullptr;
-	uint32_t *dest = nullptr, *dest2 = nullptr;
-	unsigned long long *d_cnt = nullptr;
-	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &filed_before)) || (rc = B.get((size_t) n + 1, &idx)) || (rc = B.get((size_t) n + 1, &idx2)) ||
-	   (rc = B.get((size_t) n + 1, &dest)) || (rc = B.get((size_t) n + 1, &dest2)) || (rc = B.get((size_t) W + 2, &d_cnt))) return rc;
-	hipLaunchKernelGGL(shard_dest_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, cc.tmpl, tr.stats, d_owner, W, filed, dest, idx);
+	// position of every read among the filed fragments of the whole stream: the shards are contiguous in stream order
+	int64_t *filed = nullptr, *filed_before = nullptr;
+	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &filed_before))) return rc;
+	hipLaunchKernelGGL(shard_filed_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, cc.tmpl, filed);
 	HIP_TRY(hipGetLastError());
 	if((rc = scan_i64(B, filed, filed_before, (size_t) n + 1, s))) return rc;
 	int64_t my_filed = 0;
 	HIP_TRY(hipMemcpy(&my_filed, filed_before + n, 8, hipMemcpyDeviceToHost));
-	// (position of this shard among the filed fragments of the whole stream; the longest read of the run)
-	std::vector<int64_t> all_meta((size_t) W * 2);
-	{
-		const int64_t mine[2] = {my_filed, (int64_t) R.max_len};
-		if((rc = kmahip_comm_allgather(comm, mine, sizeof mine, all_meta.data()))) return rc;
-	}
+	std::vector<int64_t> all_filed((size_t) W);
+	if((rc = kmahip_comm_allgather(comm, &my_filed, sizeof my_filed, all_filed.data()))) return rc;
 	int64_t rank_base = 0;
-	int max_len = 0;
-	for(int r = 0; r < W; ++r) { if(r < rank) rank_base += all_meta[(size_t) 2 * r]; max_len = std::max(max_len, (int) all_meta[(size_t) 2 * r + 1]); }
-	// kept reads ordered by destination, stream order inside one (a stable sort on the few bits of the destination)
-	if(n) {
-		size_t tmp_bytes = 0;
-		int bits = 1;
-		while((1 << bits) <= W) ++bits;
-		if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
-		char *tmp = nullptr;
-		if((rc = B.get(tmp_bytes, &tmp))) return rc;
-		if(rocprim::radix_sort_pairs(tmp, tmp_bytes, dest, dest2, idx, idx2, (size_t) n, 0, (unsigned) bits, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
-	}
-	std::vector<int64_t> seg((size_t) W + 1, 0);
-	std::vector<unsigned long long> cnt((size_t) W + 1, 0);
-	{
-		std::vector<unsigned long long> first((size_t) W + 2, ~0ull);
-		HIP_TRY(hipMemcpyAsync(d_cnt, first.data(), ((size_t) W + 2) * 8, hipMemcpyHostToDevice, s));
-		if(n) hipLaunchKernelGGL(shard_bounds_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, dest2, d_cnt);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(first.data(), d_cnt, ((size_t) W + 2) * 8, hipMemcpyDeviceToHost, s));
-		HIP_TRY(hipStreamSynchronize(s));
-		first[(size_t) W + 1] = (unsigned long long) n;
-		for(int r = W; r >= 0; --r) if(first[(size_t) r] == ~0ull) first[(size_t) r] = first[(size_t) r + 1];       // (a destination nobody goes to)
-		for(int r = 0; r <= W; ++r) { if(r <= W) seg[(size_t) std::min(r, W)] = (int64_t) first[(size_t) r]; }
-		for(int r = 0; r < W; ++r) cnt[(size_t) r] = first[(size_t) r + 1] - first[(size_t) r];
-	}
-	const int64_t m = seg[(size_t) W];
-	kmahip_reads dK{};
-	int32_t *rows_d = nullptr;
-	int64_t *ops_cnt = nullptr, *ops_o = nullptr;
-	uint32_t *ops_k = nullptr;
-	if((rc = gather_batch(B, d, idx2, m, &dK, s))) return rc;
-	if((rc = B.get((size_t) ROW * m + ROW, &rows_d)) || (rc = B.get((size_t) m + 1, &ops_cnt)) || (rc = B.get((size_t) m + 1, &ops_o))) return rc;
-	hipLaunchKernelGGL(shard_rows_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, idx2, rank_base, filed_before, d.len, h.rc, cc.tmpl, h.n_hits, d.N_off, tr.n_ops,
-	                   tr.stats, rows_d, ops_cnt);
+	for(int r = 0; r < rank; ++r) rank_base += all_filed[(size_t) r];
+	if(n) hipLaunchKernelGGL(shard_add_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, filed_before, rank_base);
 	HIP_TRY(hipGetLastError());
-	if((rc = scan_i64(B, ops_cnt, ops_o, (size_t) m + 1, s))) return rc;
-	int64_t ops_total = 0;
-	HIP_TRY(hipMemcpy(&ops_total, ops_o + m, 8, hipMemcpyDeviceToHost));
-	if((rc = B.get((size_t) ops_total + 1, &ops_k))) return rc;
-	if(m) hipLaunchKernelGGL(shard_ops_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, idx2, tr.ops_off, tr.n_ops, tr.ops, ops_o, ops_k);
-	HIP_TRY(hipGetLastError());
-	// block sizes per destination (rows, words, N positions, runs, name bytes), agreed on through the mailboxes
-	std::vector<int64_t> h_idx((size_t) m + 1), so_at((size_t) W + 1), no_at((size_t) W + 1), oo_at((size_t) W + 1);
-	if(m) HIP_TRY(hipMemcpy(h_idx.data(), idx2, (size_t) m * 8, hipMemcpyDeviceToHost));
-	for(int r = 0; r <= W; ++r) {
-		HIP_TRY(hipMemcpy(&so_at[(size_t) r], dK.seq_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(&no_at[(size_t) r], dK.N_off + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(&oo_at[(size_t) r], ops_o + seg[(size_t) r], 8, hipMemcpyDeviceToHost));
-	}
-	std::vector<char> name_send;
-	std::vector<int64_t> name_at((size_t) W + 1, 0);
-	for(int r = 0; r < W; ++r) {
-		int64_t bytes = 0;
-		for(int64_t x = seg[(size_t) r]; x < seg[(size_t) r + 1]; ++x) { const int64_t i = h_idx[(size_t) x]; bytes += batch->name_off[i + 1] - batch->name_off[i]; }
-		name_at[(size_t) r + 1] = name_at[(size_t) r] + bytes;
-	}
-	name_send.resize((size_t) name_at[(size_t) W] + 1);
-	{
-		char *o = name_send.data();
-		for(int64_t x = 0; x < m; ++x) { const int64_t i = h_idx[(size_t) x]; const int64_t l = batch->name_off[i + 1] - batch->name_off[i]; memcpy(o, batch->names + batch->name_off[i], (size_t) l); o += l; }
-	}
-	constexpr int NA = 5;          // arrays that travel
-	std::vector<int64_t> mine((size_t) NA * W), all((size_t) NA * W * W);
-	for(int r = 0; r < W; ++r) {
-		mine[(size_t) (0 * W + r)] = (int64_t) cnt[(size_t) r] * ROW * 4;
-		mine[(size_t) (1 * W + r)] = (so_at[(size_t) r + 1] - so_at[(size_t) r]) * 8;
-		mine[(size_t) (2 * W + r)] = (no_at[(size_t) r + 1] - no_at[(size_t) r]) * 4;
-		mine[(size_t) (3 * W + r)] = (oo_at[(size_t) r + 1] - oo_at[(size_t) r]) * 4;
-		mine[(size_t) (4 * W + r)] = name_at[(size_t) r + 1] - name_at[(size_t) r];
-	}
-	if((rc = kmahip_comm_allgather(comm, mine.data(), mine.size() * 8, all.data()))) return rc;
-	std::vector<int64_t> rb[NA];
-	int64_t rtot[NA];
-	for(int a = 0; a < NA; ++a) {
-		rb[a].assign((size_t) W, 0);
-		rtot[a] = 0;
-		for(int src = 0; src < W; ++src) { rb[a][(size_t) src] = all[(size_t) src * NA * W + (size_t) a * W + (size_t) rank]; rtot[a] += rb[a][(size_t) src]; }
-	}
-	const int64_t m2 = rtot[0] / (ROW * 4);
-	int32_t *rows_r = nullptr, *N_r = nullptr;
-	uint64_t *seq_r = nullptr;
-	uint32_t *ops_r = nullptr;
-	if((rc = B.get((size_t) rtot[0] / 4 + ROW, &rows_r)) || (rc = B.get((size_t) rtot[1] / 8 + 2, &seq_r, true)) || (rc = B.get((size_t) rtot[2] / 4 + 1, &N_r)) ||
-	   (rc = B.get((size_t) rtot[3] / 4 + 1, &ops_r))) return rc;
-	std::vector<char> name_recv((size_t) rtot[4] + 1);
-	HIP_TRY(hipStreamSynchronize(s));
-	if((rc = kmahip_comm_alltoallv(comm, rows_d, &mine[0], rows_r, rb[0].data(), 1, s)) ||
-	   (rc = kmahip_comm_alltoallv(comm, dK.seq, &mine[(size_t) W], seq_r, rb[1].data(), 1, s)) ||
-	   (rc = kmahip_comm_alltoallv(comm, dK.N, &mine[(size_t) 2 * W], N_r, rb[2].data(), 1, s)) ||
-	   (rc = kmahip_comm_alltoallv(comm, ops_k, &mine[(size_t) 3 * W], ops_r, rb[3].data(), 1, s)) ||
-	   (rc = kmahip_comm_alltoallv(comm, name_send.data(), &mine[(size_t) 4 * W], name_recv.data(), rb[4].data(), 0, s))) return rc;
-	ms[4] = since(t);
+	return shard_finish(db, ws, comm, B, batch, d, cc.tmpl, h.rc, h.n_hits, filed_before, tr, nullptr, &hx[2 * D], rows.data(), n_rows, mf, opts, out_prefix, ms, t);
+}
 
-	// the owner's batch: what arrived is in source-rank order = the order of the whole stream
-	kmahip_reads dO{};
-	kmahip_traces trO;
-	memset(&trO, 0, sizeof trO);
-	int64_t *fr2 = nullptr, *w_cnt = nullptr, *n_cnt = nullptr, *o_cnt = nullptr, *so2 = nullptr, *no2 = nullptr, *oo2 = nullptr;
-	int32_t *len2 = nullptr, *rc2 = nullptr, *tm2 = nullptr, *nh2 = nullptr, *nops2 = nullptr, *st2 = nullptr;
-	if((rc = B.get((size_t) m2 + 1, &fr2)) || (rc = B.get((size_t) m2 + 1, &w_cnt)) || (rc = B.get((size_t) m2 + 1, &n_cnt)) || (rc = B.get((size_t) m2 + 1, &o_cnt)) ||
-	   (rc = B.get((size_t) m2 + 1, &so2)) || (rc = B.get((size_t) m2 + 1, &no2)) || (rc = B.get((size_t) m2 + 1, &oo2)) || (rc = B.get((size_t) m2 + 1, &len2, true)) ||
-	   (rc = B.get((size_t) m2 + 1, &rc2)) || (rc = B.get((size_t) m2 + 1, &tm2)) || (rc = B.get((size_t) m2 + 1, &nh2)) || (rc = B.get((size_t) m2 + 1, &nops2)) ||
-	   (rc = B.get((size_t) 10 * m2 + 10, &st2))) return rc;
-	hipLaunchKernelGGL(shard_unpack_kernel, dim3((unsigned) ((m2 + 256) / 256)), dim3(256), 0, s, m2, rows_r, fr2, len2, rc2, tm2, nh2, nops2, st2, w_cnt, n_cnt, o_cnt);
-	HIP_TRY(hipGetLastError());
-	if((rc = scan_i64(B, w_cnt, so2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, n_cnt, no2, (size_t) m2 + 1, s)) || (rc = scan_i64(B, o_cnt, oo2, (size_t) m2 + 1, s))) return rc;
-	HIP_TRY(hipStreamSynchronize(s));
-	dO.n_reads = m2; dO.seq = seq_r; dO.seq_off = so2; dO.len = len2; dO.N = N_r; dO.N_off = no2; dO.seq_words = rtot[1] / 8; dO.N_total = rtot[2] / 4; dO.max_len = max_len;
-	trO.stats = st2; trO.ops_off = oo2; trO.n_ops = nops2; trO.ops = ops_r; trO.ops_cap = rtot[3] / 4;
-	// pile-up + consensus of the owned templates
-	kmahip_assembly asmb;
-	memset(&asmb, 0, sizeof asmb);
-	std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
-	int64_t tbases = 0;
-	for(size_t tt = 1; tt < D; ++tt) tbases += db->h_tlen[tt];
-	std::vector<char> cons((size_t) (4 * tbases + 4 * (int64_t) D + (1 << 20)));
-	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
-	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
-	if(m2) {
-		kmahip_assemble_opts ao = {mf, opts->evalue, opts->bcd, 0, opts->caller, opts->sig90, fr2};
-		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
-	}
-	ms[5] = since(t);
 
-	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
-	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
-	{
-		FILE *res = fopen((part + ".res").c_str(), "w"), *fsa = fopen((part + ".fsa").c_str(), "w");
-		if(!res || !fsa) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create the output parts of %s", out_prefix); return KMAHIP_EIO; }
-		std::vector<char> line((1 << 16) + 512);
-		std::string entry;
-		for(int64_t r = 0; r < n_rows; ++r) {
-			const kmahip_res_row &row = rows[(size_t) r];
-			const size_t tt = (size_t) row.template_id;
-			if(owner[tt] != rank || !row.significant || tt - 1 >= db->h_names.size()) continue;
-			const std::string &name = db->h_names[tt - 1];
-			if(!kmahip_res_line(name.c_str(), &row, a_cover[tt], a_len[tt], a_depth[tt], opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, line.data(), (int64_t) line.size())) continue;
-			fputs(line.data(), res);
-			// printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line
-			entry.clear();
-			entry += ">"; entry += name; entry += "\n";
-			int col = 0;
-			for(const char *q = c_off[tt] >= 0 ? cons.data() + c_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
-			if(col) entry.push_back('\n');
-			fwrite(entry.data(), 1, entry.size(), fsa);
-		}
-		if(fclose(res) != 0 || fclose(fsa) != 0) { kmahip_set_error("write to the output parts of %s failed", out_prefix); return KMAHIP_EIO; }
-	}
-	{
-		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
-		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);
-		std::vector<int64_t> h_so((size_t) m2 + 1, 0), h_no((size_t) m2 + 1, 0), h_fr((size_t) m2 + 1, 0), h_name_off((size_t) m2 + 1, 0);
-		std::vector<int32_t> h_len((size_t) m2 + 1, 0), h_N((size_t) dO.N_total + 1, 0), h_rc((size_t) m2 + 1, 0), h_tm((size_t) m2 + 1, 0), h_nh((size_t) m2 + 1, 0), h_st((size_t) 10 * m2 + 10, 0);
-		if(dO.seq_words) HIP_TRY(hipMemcpy(hs.data(), seq_r, (size_t) dO.seq_words * 8, hipMemcpyDeviceToHost));
-		if(dO.N_total) HIP_TRY(hipMemcpy(h_N.data(), N_r, (size_t) dO.N_total * 4, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_so.data(), so2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(h_no.data(), no2, ((size_t) m2 + 1) * 8, hipMemcpyDeviceToHost));
-		if(m2) {
-			HIP_TRY(hipMemcpy(h_fr.data(), fr2, (size_t) m2 * 8, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_len.data(), len2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_rc.data(), rc2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_tm.data(), tm2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_nh.data(), nh2, (size_t) m2 * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(h_st.data(), st2, (size_t) m2 * 40, hipMemcpyDeviceToHost));
-		}
-		// names arrive NUL-terminated, back to back
-		{
-			int64_t at = 0;
-			for(int64_t x = 0; x < m2; ++x) { h_name_off[(size_t) x] = at; at += (int64_t) strlen(name_recv.data() + at) + 1; }
-			h_name_off[(size_t) m2] = at;
-		}
-		kmahip_reads hr{};
-		hr.n_reads = m2; hr.seq = hs.data(); hr.seq_off = h_so.data(); hr.len = h_len.data(); hr.N = h_N.data(); hr.N_off = h_no.data();
-		hr.seq_words = dO.seq_words; hr.N_total = dO.N_total; hr.max_len = max_len;
-		int64_t frag_rows = 0;
-		if((rc = kmahip_frag_write3((part + ".frag.gz").c_str(), db, &hr, h_rc.data(), h_tm.data(), h_nh.data(), h_st.data(), mf, 0, h_fr.data(),
-		                            name_recv.data(), h_name_off.data(), &frag_rows))) return rc;
-	}
-	ms[6] = since(t);
-	if((rc = kmahip_comm_barrier(comm))) return rc;
-	if(rank == 0) {
-		if((rc = concat_parts(prefix, ".res", W, "#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n")) ||
-		   (rc = concat_parts(prefix, ".fsa", W, nullptr)) || (rc = concat_parts(prefix, ".frag.gz", W, nullptr))) return rc;
-	}
-	if((rc = kmahip_comm_barrier(comm))) return rc;
-	ms[7] = since(t);
+// ---- the paired run over read shards: kmahip_run_pe's stages with the exchanges of kmahip_run_se_sharded in between -----------------
+static int shard_allreduce(ShardCtx *sc, uint64_t *d_buf, size_t n) { return kmahip_comm_allreduce_u64(sc->comm, d_buf, n, nullptr); }
+static uint64_t *shard_frag_counts(ShardCtx *sc, size_t D) { sc->frag_counts.assign(D, 0); return sc->frag_counts.data(); }
+
+// last[4] = {valid, tmpl, start, end}: the first listed hit of this shard's last record with a list; carry = that of the nearest
+// earlier shard that has one
+static int shard_carry_in(ShardCtx *sc, const int32_t last[4], int32_t carry[3]) {
+	const int W = kmahip_comm_world(sc->comm), rank = kmahip_comm_rank(sc->comm);
+	std::vector<int32_t> all((size_t) 4 * W);
+	int rc = kmahip_comm_allgather(sc->comm, last, 4 * sizeof(int32_t), all.data());
+	if(rc) return rc;
+	carry[0] = carry[1] = carry[2] = 0;
+	for(int r = rank - 1; r >= 0; --r) if(all[(size_t) 4 * r]) { carry[0] = all[(size_t) 4 * r + 1]; carry[1] = all[(size_t) 4 * r + 2]; carry[2] = all[(size_t) 4 * r + 3]; break; }
 	return KMAHIP_OK;
+}
+
+// The chunks of maxFrag filed fragments close one after the other along the stream (conclave.c:164-196), so the ranks count
+// theirs in turn: state = {fragments in the chunk that is open, chunks closed so far}. W rounds of the mailboxes; rank r listens
+// for r rounds (receive), then posts its state in the remaining W - r (send).
+static int shard_chunk_token(ShardCtx *sc, bool receive, int64_t state[2]) {
+	const int W = kmahip_comm_world(sc->comm), rank = kmahip_comm_rank(sc->comm);
+	std::vector<int64_t> all((size_t) 3 * W);
+	int64_t mine[3] = {receive ? 0 : 1, state[0], state[1]};
+	int rc;
+	if(receive) {
+		state[0] = 0; state[1] = 0;
+		for(int round = 0; round < rank; ++round) {
+			if((rc = kmahip_comm_allgather(sc->comm, mine, sizeof mine, all.data()))) return rc;
+			if(round == rank - 1) {
+				if(!all[(size_t) 3 * (rank - 1)]) { kmahip_set_error("chunk token: rank %d had not posted in its round", rank - 1); return KMAHIP_EDEVICE; }
+				state[0] = all[(size_t) 3 * (rank - 1) + 1]; state[1] = all[(size_t) 3 * (rank - 1) + 2];
+			}
+		}
+		return KMAHIP_OK;
+	}
+	for(int round = rank; round < W; ++round) if((rc = kmahip_comm_allgather(sc->comm, mine, sizeof mine, all.data()))) return rc;
+	return KMAHIP_OK;
+}
+
+static int shard_pe_tail(ShardCtx *sc, kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_read_batch *batch, const kmahip_reads &dF, const int32_t *f_rc, const int32_t *f_t,
+                         const int32_t *f_nh, const int64_t *f_rank, const kmahip_traces &tr, const int64_t *h_src, const kmahip_res_row *rows, int64_t n_rows, int64_t chunk,
+                         std::chrono::steady_clock::time_point &t) {
+	return shard_finish(db, ws, sc->comm, B, batch, dF, f_t, f_rc, f_nh, f_rank, tr, h_src, sc->frag_counts.data(), rows, n_rows, chunk, sc->opts, sc->out_prefix, sc->ms, t);
+}
+
+extern "C" int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                                     const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
+	if(!db || !ws || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	int rc = kmahip_db_load_names(db);
+	if(rc) return rc;
+	const size_t D = db->info.DB_size;
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	std::vector<kmahip_res_row> rows(D);
+	std::vector<int64_t> a0(D), a1(D), a2(D), a3(D);
+	kmahip_run run;
+	memset(&run, 0, sizeof run);
+	run.rows = rows.data(); run.rows_cap = (int64_t) D;
+	run.assembly.cover = a0.data(); run.assembly.aln_len = a1.data(); run.assembly.depth = a2.data(); run.assembly.asm_len = a3.data();
+	run.caller = opts->caller; run.sig90 = opts->sig90;
+	ShardCtx sc{comm, opts, out_prefix, ms, {}};
+	rc = run_pe_impl(db, ws, batch, p, opts->evalue, opts->bcd, opts->max_frag, nullptr, &run, &sc);
+	for(int i = 0; i < 4; ++i) ms[i] = run.ms[i];
+	return rc;
 }
