@@ -35,6 +35,24 @@
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+/* seconds since the kernel started this process (exec, loader and libraries included): /proc/self/stat field 22 against the boot clock */
+static double since_process_start(void) {
+	FILE *f = fopen("/proc/self/stat", "r");
+	char buf[2048];
+	if(!f) return -1;
+	const size_t got = fread(buf, 1, sizeof buf - 1, f);
+	fclose(f);
+	buf[got] = 0;
+	const char *p = strrchr(buf, ')');          /* behind the command name, which may hold anything */
+	if(!p) return -1;
+	unsigned long long start = 0;
+	int field = 2;
+	for(p += 1; *p && field < 22; ++p) if(*p == ' ') { ++field; if(field == 22) { start = strtoull(p + 1, NULL, 10); break; } }
+	struct timespec ts;
+	clock_gettime(CLOCK_BOOTTIME, &ts);
+	return ts.tv_sec + 1e-9 * ts.tv_nsec - (double) start / (double) sysconf(_SC_CLK_TCK);
+}
+
 /* stage 1 on a thread of its own, beside HIP start-up and the loading of the index */
 typedef struct ingest_job {
 	const char *in1, *in2;
@@ -108,9 +126,21 @@ static void warm_up(kmahip_db *db, kmahip_ws *ws, const char *prefix, int64_t D,
 	free(run.assembly.cover); free(run.assembly.aln_len); free(run.assembly.depth); free(run.assembly.asm_len);
 }
 
+/* the pipe to the waiting parent (see main): one byte = the exit status, written when the outputs are complete or the run has failed */
+static int g_done_fd = -1;
+static void finish(int status) {
+	fflush(NULL);
+	if(g_done_fd >= 0) {
+		const unsigned char st = (unsigned char) status;
+		if(write(g_done_fd, &st, 1) != 1) { /* the parent is gone */ }
+		close(g_done_fd); g_done_fd = -1;
+		close(STDOUT_FILENO); close(STDERR_FILENO);          /* (whoever reads our output through a pipe sees its end now, not after the teardown) */
+	}
+	_exit(status);
+}
 /* (a reader thread may be inflating, workers of the library may be running: no destructors, no atexit handlers on the way out) */
-static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); fflush(NULL); _exit(1); }
-static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fflush(NULL); _exit(1); }
+static void die(const char *what) { fprintf(stderr, "kmahip_map: %s: %s\n", what, kmahip_last_error()); finish(1); }
+static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); finish(1); }
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
 
 static void usage(void) {
@@ -230,6 +260,28 @@ int main(int argc, char **argv) {
 
 	/* ranks */
 	if(gpus > 1 && !getenv("KMAHIP_RANK")) return launch_ranks(gpus, argv);
+	/* The work is done by a child: when every output is closed it says so through a pipe and this process ends with its status;
+	 * the child then gives back what it holds (gigabytes of mapped input, host arrays, the device context: 0.2-0.3 s of kernel
+	 * work after a 10 M-read run) without anybody waiting for that. KMAHIP_MAP_NO_FORK=1: one process, as under a debugger. */
+	int done_fd = -1;
+	if(!getenv("KMAHIP_MAP_NO_FORK") && !getenv("KMAHIP_RANK") && !getenv("RANK")) {
+		int pfd[2];
+		if(pipe(pfd) == 0) {
+			const pid_t child = fork();
+			if(child > 0) {
+				unsigned char st = 0;
+				close(pfd[1]);
+				const ssize_t got = read(pfd[0], &st, 1);
+				if(got == 1) _exit(st);                       /* outputs complete (or the child reported its failure) */
+				int ws_ = 0;                                   /* the child ended without a word: its exit status tells */
+				if(waitpid(child, &ws_, 0) < 0 || !WIFEXITED(ws_)) _exit(1);
+				_exit(WEXITSTATUS(ws_));
+			}
+			if(child == 0) { close(pfd[0]); done_fd = pfd[1]; }
+			else { close(pfd[0]); close(pfd[1]); }               /* fork failed: carry on in this process */
+		}
+	}
+	g_done_fd = done_fd;
 	int rank = 0, world = 1, local = 0;
 	const char *key = getenv("KMAHIP_KEY");
 	char keybuf[64];
@@ -238,10 +290,10 @@ int main(int argc, char **argv) {
 		rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE")); local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
 		if(!key) { snprintf(keybuf, sizeof keybuf, "port%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0"); key = keybuf; }
 	}
-	if(world > 1 && (!one2one || mt1)) { fprintf(stderr, "kmahip_map: several ranks are built for the -1t1 runs (single end and -ipe ... -apm p)\n"); return 2; }
+	if(world > 1 && (!one2one || mt1)) { fprintf(stderr, "kmahip_map: several ranks are built for the -1t1 runs (single end and -ipe ... -apm p)\n"); finish(2); }
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
-	const double t_start = now_s();
+	const double t_start = now_s(), t_before_main = since_process_start();
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */
 	ingest_job job;
 	memset(&job, 0, sizeof job);
@@ -258,6 +310,7 @@ int main(int argc, char **argv) {
 	}
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
+	if(getenv("KMAHIP_MAP_STOP") && !strcmp(getenv("KMAHIP_MAP_STOP"), "open")) { fprintf(stderr, "# kmahip_map: stopped after open: %.3f s in main, entered %.2f s after process start\n", t_open - t_start, t_before_main); finish(0); }
 	if(world == 1) {	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
 		 * behind a shorter input the warm-up itself would be what the run waits for) */
 		struct stat sb;
@@ -266,7 +319,7 @@ int main(int argc, char **argv) {
 		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (gz ? (128ll << 20) : (1ll << 30))) warm_up(db, ws, prefix, D, &par);
 	}
 	pthread_join(ingest_thread, NULL);
-	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); fflush(NULL); _exit(1); }
+	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); finish(1); }
 	kmahip_ingest *ing = job.ing;
 	kmahip_read_batch b = job.b;
 	const double t_ingest = now_s();
@@ -298,8 +351,7 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "# kmahip_map rank %d of %d: %lld reads; wall: ingest %.2f s beside open %.2f, run %.2f | upload %.1f ms, stages 2+3a %.1f, exchanges 1+2 + ConClave %.1f, "
 		        "traceback %.1f, gather by owner %.1f, pile-up + consensus %.1f, writers %.1f, merge %.1f\n", rank, world, (long long) b.reads.n_reads, job.t_done - t_start,
 		        t_open - t_start, now_s() - t_ingest, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
-		fflush(NULL);
-		_exit(0);
+		finish(0);
 	}
 	const int64_t n = b.reads.n_reads;
 
@@ -310,7 +362,7 @@ int main(int argc, char **argv) {
 		snprintf(path, sizeof path, "%s.length.b", prefix);
 		FILE *f = fopen(path, "rb");
 		int32_t v, i = 0;
-		if(!f) { fprintf(stderr, "kmahip_map: cannot open %s\n", path); return 1; }
+		if(!f) { fprintf(stderr, "kmahip_map: cannot open %s\n", path); finish(1); }
 		while(fread(&v, 4, 1, f) == 1) { if(i >= 2 && i <= D) tbases += v; ++i; }      /* [count][length of entry 0 = k][template 1] ... [template D - 1] */
 		fclose(f);
 	}
@@ -345,6 +397,7 @@ int main(int argc, char **argv) {
 
 	if(touching) pthread_join(touch_thread, NULL);
 	const double t_run = now_s();
+	if(getenv("KMAHIP_MAP_STOP") && !strcmp(getenv("KMAHIP_MAP_STOP"), "run")) { fprintf(stderr, "# kmahip_map: stopped after the device run: %.3f s in main\n", t_run - t_start); finish(0); }
 	/* out.res + out.fsa: names from <prefix>.name, one per line, in template order */
 	char path[4096], *name = xcalloc(1 << 16, 1), *line = xcalloc((1 << 16) + 512, 1);
 	snprintf(path, sizeof path, "%s.name", prefix);
@@ -385,18 +438,17 @@ int main(int argc, char **argv) {
 	if(!no_frag && !input2 && !chain && kmahip_frag_write2(fpath, db, &b.reads, run.rc, run.tmpl, run.n_hits, run.trace_stats, max_frag, mt1 ? 1 : 0, b.names, b.name_off, &frag_rows)) die("kmahip_frag_write");
 	const double t_frag = now_s();
 	fprintf(stderr, "# kmahip_map: %lld reads, %lld fragment rows; wall: ingest %.2f s beside open %.2f (both done after %.2f), device run %.2f, .res + .fsa %.2f, .frag.gz %.2f | "
-	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, columns back %.1f%s\n", (long long) n, (long long) frag_rows,
+	        "upload %.1f ms, stages 2+3a %.1f, ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, columns back %.1f%s (main entered %.2f s after process start)\n", (long long) n, (long long) frag_rows,
 	        job.t_done - t_start, t_open - t_start, t_ingest - t_start, t_run - t_ingest, t_res - t_run, t_frag - t_res, run.ms[0], run.ms[1], run.ms[2], run.ms[3], run.ms[4],
 	        input2 || chain ? 0.0 : run.ms[5],
-	        input2 || chain ? " (the device run wrote the .frag.gz)" : "");
+	        input2 || chain ? " (the device run wrote the .frag.gz)" : "", t_before_main);
 	/* every output is closed; the process ends here instead of unmapping gigabytes of reads and scratch one by one
 	 * (KMAHIP_MAP_TEARDOWN=1: release everything in order, e.g. under a leak checker) */
 	if(getenv("KMAHIP_MAP_TEARDOWN")) {
 		kmahip_ws_destroy(ws);
 		kmahip_db_close(db);
 		kmahip_ingest_close(ing);
-		return 0;
+		finish(0);
 	}
-	fflush(NULL);
-	_exit(0);
+	finish(0);
 }
