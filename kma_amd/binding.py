@@ -134,10 +134,18 @@ def lib():
             if not stale and shutil.which("make"):
                 stale = subprocess.call(["make", "-q", "-C", csrc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0
             if stale:
-                try:
-                    subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
-                except (OSError, subprocess.CalledProcessError) as e:
-                    raise KmaHipError(f"{LIB_PATH} is missing or older than its sources and building it failed ({e}): run __graft_entry__.build()")
+                # several ranks import this at the same moment (bench.py --gpus N, the dist tests): one builds, the others wait
+                # for the lock and find the library current
+                import fcntl
+                with open(os.path.join(csrc, ".build.lock"), "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    try:
+                        if not os.path.exists(LIB_PATH) or subprocess.call(["make", "-q", "-C", csrc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0:
+                            subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+                    except (OSError, subprocess.CalledProcessError) as e:
+                        raise KmaHipError(f"{LIB_PATH} is missing or older than its sources and building it failed ({e}): run __graft_entry__.build()")
+                    finally:
+                        fcntl.flock(lock, fcntl.LOCK_UN)
         if not os.path.exists(LIB_PATH):
             raise KmaHipError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
         L = C.CDLL(LIB_PATH)

@@ -282,16 +282,21 @@ struct Feeder {
 		const size_t end = in_at - zs.avail_in;
 		inflateEnd(&zs);
 		int64_t next = -1;
+		bool tail_error = false;
 		if(ok && ended && end < zsize) {
 			const auto it = std::lower_bound(cands.begin(), cands.end(), end);
-			if(it != cands.end() && *it == end) next = (int64_t) (it - cands.begin());      // (else: bytes that are no member -- ignored, like gzread does)
+			if(it != cands.end() && *it == end) next = (int64_t) (it - cands.begin());
+			// else: bytes that are no member -- ignored, like gzread does. But bytes that begin like one (1f 8b) gzread would try
+			// to inflate: a member whose header this reader's stricter test did not take for one (an unusual XFL / OS byte, fewer
+			// than 18 bytes left) must not be dropped in silence -- the input ends here with a read error instead
+			else if(zsize - end >= 2 && zmap[end] == 0x1f && zmap[end + 1] == 0x8b) tail_error = true;
 		}
 		std::lock_guard<std::mutex> lk(mu);
 		// (what the chunk in hand holds of a member that failed is dropped, as gzread drops what a failing call had inflated: the
 		// bytes next to the damage are not to be parsed)
 		if(c && ok && ended) { S.ready.push_back(c); S.buffered += c->hi - c->lo; }
 		else delete c;
-		S.error = !(ok && ended); S.next = next; S.done = true;
+		S.error = !(ok && ended) || tail_error; S.next = next; S.done = true;
 		cv.notify_all();
 	}
 	void work() {

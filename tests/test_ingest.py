@@ -345,3 +345,20 @@ def test_ingest_gzip_members_damaged(tmp_path, monkeypatch):
         k = min(len(got1[0]), len(got[0]))                 # (each drops a piece of its own size next to the damage: one is a prefix of the other)
         assert err1 is not None and got1[0][:k] == got[0][:k] and got1[1][:k] == got[1][:k], name
         assert "read error" in err, (name, err)
+
+
+def test_ingest_gzip_member_the_scan_did_not_take_for_one(tmp_path, monkeypatch):
+    """behind the last member the parallel reader recognised come bytes that begin like a gzip member but fail its stricter header test
+    (an OS byte of 100; a member cut to under 18 bytes): gzread would inflate them or report the damage -- the reader must end with a
+    read error, not drop them in silence as it does bytes that are no member at all"""
+    monkeypatch.setenv("KMAHIP_INGEST_THREADS", "4")
+    data = _fastq(3000, 22)
+    cut = len(data) // 2
+    odd = bytearray(_member(data[cut:]))
+    odd[9] = 100                                           # OS byte: a valid member for zlib, not a candidate for the scan
+    (tmp_path / "odd.fq.gz").write_bytes(_member(data[:cut // 2]) + _member(data[cut // 2:cut]) + bytes(odd))
+    (tmp_path / "short.fq.gz").write_bytes(_member(data[:cut // 2]) + _member(data[cut // 2:cut]) + _member(data[cut:])[:12])
+    for name in ("odd", "short"):
+        got, err = _all(str(tmp_path / f"{name}.fq.gz"), min_phred=0, min_len=0)
+        assert err is not None and "read error" in err, (name, err)
+        assert len(got[0]) >= data[:cut].count(b"\n") // 4 - 1
