@@ -38,6 +38,9 @@ constexpr int THREADS = 256;
 #ifndef KMAHIP_STHREADS
 #define KMAHIP_STHREADS 256
 #endif
+#ifndef KMAHIP_SCAN_WAVES
+#define KMAHIP_SCAN_WAVES 7
+#endif
 constexpr int STHREADS = KMAHIP_STHREADS;   // threads of one scan workgroup: GROUP items x STHREADS / GROUP lanes
 constexpr int CHUNK = 136;            // k-mer start positions per pass
 constexpr int MW = 5;                 // hit-mask words per candidate (>= CHUNK / 32)
@@ -52,6 +55,7 @@ __host__ __device__ constexpr int ilog2c(int x) { return x <= 1 ? 0 : 1 + ilog2c
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int VSLOTS = 16;            // hashed value-list slots per item in LDS (distinct lists seen in one pass); a list
                                       // that finds all of them taken is expanded directly
+constexpr int QCAP = 1024;            // entries of a workgroup's queue of left-over k-mer starts (a fuller one is finished by a rescan)
 constexpr int INL = 2;                // inline result slots per strand item (no allocation round trip for the usual 1-2 ties)
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFEu;
@@ -402,7 +406,7 @@ __device__ __forceinline__ int compact_threads(bool flag, int tid, int32_t *wcnt
 }
 
 template <bool STATS, int MODE, int TSLOTS>
-__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2) : 4) void scan_se_kernel(const ScanArgs A) {
+__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP_SCAN_WAVES : 2) : 4) void scan_se_kernel(const ScanArgs A) {
 	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
 	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
 	// forward words: if every read of the group fits in SW-1 words they are staged ONCE and serve all passes;
@@ -414,13 +418,16 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2)
 	__shared__ int32_t t_score[TSLOTS * GROUP];
 	__shared__ int32_t t_last[TSLOTS * GROUP];
 	__shared__ int32_t t_first[TSLOTS * GROUP];
-	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_hits[GROUP];
+	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_hits[GROUP], s_best[GROUP], s_nb[GROUP];
+	__shared__ int64_t s_off[GROUP];
 	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
 	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
 	__shared__ int32_t s_gmax;
 	__shared__ int32_t s_wcnt[STHREADS / 64];
 	__shared__ uint16_t s_list[STHREADS];
 	__shared__ uint32_t s_stats[3];   // [0] k-mer starts resolved (= probes of the reference), [1] list elements, [2] hash probes
+	__shared__ uint16_t s_q[QCAP];    // k-mer starts the lanes' one anchor + walk left over: (item << 8) | position in the pass
+	__shared__ uint32_t s_qn;
 
 	const DevDB &db = A.db;
 	const int tid = threadIdx.x;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2)
 		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no; s_item[tid] = it;
 	}
 	if(tid < 3) s_stats[tid] = 0;
-	if(tid == 0) { s_anylong = 0; s_gmax = 0; }
+	if(tid == 0) { s_anylong = 0; s_gmax = 0; s_qn = 0; }
 	__syncthreads();
 	if(tid < ng) {
 		if(s_len[tid] > (SW - 1) * 32) s_anylong = 1;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2)
 #pragma unroll
 			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
 		}
-		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; }
+		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; s_best[tid] = 0; s_nb[tid] = 0; }
 		__syncthreads();
 
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
@@ -506,121 +513,164 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2)
 			// Every run of equal value lists inside a walk ORs its position range into the mask of that LIST in the
 			// item's v-table -- no list is read here, and a list that recurs along the read is expanded once.
 			uint32_t nprobe = 0, nres = 0;
+			// one run of equal value lists, positions [rs, re) of the pass (re - rs <= SEG): into the item's v-table
+			auto add_run = [&](int g, uint32_t vi, int rs, int re) {
+				if(STATS) atomicAdd(&s_stats[1], value_at(db, vi, 0) + 1u);
+				// claim / find the list's slot in the item's v-table
+				int slot = -1;
+				const uint32_t h = (vi * 0x9E3779B1u) >> 28;
+#pragma unroll 1
+				for(int x = 0; x < VSLOTS; ++x) {
+					const int sidx = (int) ((h + x) & (VSLOTS - 1)) * GROUP + g;
+					const uint32_t old = atomicCAS(&v_id[sidx], MISS, vi);
+					if(old == MISS || old == vi) { slot = sidx; break; }
+				}
+				if(slot >= 0) {
+					// a run inside one lane's segment is at most SEG (9) positions long: two mask words at most
+					const int w = rs >> 5;
+					const uint64_t m = ((1ull << (re - rs)) - 1ull) << (rs & 31);
+					atomicOr(&v_mask[w * VSLOTS * GROUP + slot], (uint32_t) m);
+					if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * GROUP + slot], (uint32_t) (m >> 32));
+				} else {
+					// more distinct lists in this pass than the v-table holds: expand this run directly
+					expand_list<TSLOTS>(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
+				}
+			};
+			// one k-mer start on its own (position jj of the pass, item g): probe, and a run of one position when it hits
+			auto resolve = [&](int g, int jj) {
+				const int L = s_len[g], strand = (int) (s_item[g] & 1), nN = s_nN[g];
+				const int p = c0 + jj;
+				const int q = strand ? (L - k - p) : p;
+				if(nN && window_has_N(A.N + s_noff[g], nN, q, k)) return;
+				const uint64_t *wsrc = &w_lds[g * SW];
+				const int w = (p >> 5) - (staged_once ? 0 : (c0 >> 5));
+				const uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], p, k);
+				uint32_t gp;
+#ifdef KMAHIP_DIAG
+				if(A.ablate & 2) gp = MISS; else
+#endif
+				gp = probe(db, (uint32_t) km);
+				++nprobe; ++nres;
+				if(gp == MISS) return;
+				const uint32_t vi = db.vs_id[gp];
+				if(MODE) atomicAdd(&s_hits[g], 1);
+#ifdef KMAHIP_DIAG
+				if(A.ablate & 1) return;
+#endif
+				if(!s_over[g]) add_run(g, vi, jj, jj + 1);
+			};
+			int own_lo = 0, own_n = 0;          // k-mer starts this lane could not queue
 			{
 				constexpr int LPI = STHREADS / GROUP;                 // lanes per item
 				constexpr int SEG = (CHUNK + LPI - 1) / LPI;         // positions per lane
 				const int g = tid & (GROUP - 1), sl = tid / GROUP;
 				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
-				if(g < ng) {
+				// ONE anchor probe and walk per lane, straight-line. What a lane has left afterwards -- the k-mer starts behind a
+				// miss or behind a walk that a mismatch cut short -- goes into a workgroup-wide queue and is resolved below by all
+				// threads side by side, one probe each: a lane that resolved them itself, two per round trip, kept its workgroup
+				// waiting for five dependent gathers (profiles/r3_scan_phase_counters.md: phase 1 was 28 % of the instructions
+				// and 47 % of the time).
+				if(g < ng && c0 + j0 < s_len[g] - k + 1) {
 					const int L = s_len[g], npos = L - k + 1, strand = (int) (s_item[g] & 1), nN = s_nN[g];
 					const int32_t *Nl = A.N + s_noff[g];
 					const uint64_t *wsrc = &w_lds[g * SW];
 					const int wb = staged_once ? 0 : (c0 >> 5);
 					int jj = j0, hc = 0;
-					bool pairs = false;      // after a miss or a walk cut short: probe two k-mer starts per step
-					while(jj < j1) {
-						int p = c0 + jj;
-						if(p >= npos) break;
-						const int q = strand ? (L - k - p) : p;       // forward coordinate of the window (the N list is forward)
-						if(nN && window_has_N(Nl, nN, q, k)) { ++jj; continue; }
+					const int p = c0 + jj;
+					const int q = strand ? (L - k - p) : p;       // forward coordinate of the window (the N list is forward)
+					bool hit = false;
+					if(!(nN && window_has_N(Nl, nN, q, k))) {
 						const int w = (p >> 5) - wb;
 						const uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], p, k);
 						uint32_t gp;
-						bool second = false;
-						if(pairs && jj + 1 < j1 && p + 1 < npos) {
-							const int q2 = strand ? q - 1 : q + 1;
-							second = !(nN && window_has_N(Nl, nN, q2, k));
-						}
 #ifdef KMAHIP_DIAG
 						if(A.ablate & 2) gp = MISS; else
 #endif
-						if(second) {
-							const int w2 = ((p + 1) >> 5) - wb;
-							const uint64_t km2 = kmer_from(wsrc[w2], wsrc[w2 + 1], p + 1, k);
-							uint32_t gp2;
-							probe2(db, (uint32_t) km, (uint32_t) km2, gp, gp2);
-							if(gp == MISS) {
-								++nprobe; ++nres;
-								if(gp2 == MISS) { ++nprobe; ++nres; jj += 2; continue; }
-								gp = gp2; ++jj; ++p;
-							}
-						} else gp = probe(db, (uint32_t) km);
+						gp = probe(db, (uint32_t) km);
 						++nprobe; ++nres;
-						if(gp == MISS) { ++jj; pairs = true; continue; }
-						// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
-						constexpr int WALK = SEG - 1;
-						uint32_t vv[WALK + 1];
-						const uint32_t *vp = db.vs_id + gp;          // one address, immediate offsets: the loads merge
+						if(gp != MISS) {
+							hit = true;
+							// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
+							constexpr int WALK = SEG - 1;
+							uint32_t vv[WALK + 1];
+							const uint32_t *vp = db.vs_id + gp;          // one address, immediate offsets: the loads merge
 #pragma unroll
-						for(int i = 0; i <= WALK; ++i) vv[i] = vp[i];
-						const uint64_t tw = win2(db.cat, (int64_t) gp + k);
-						const uint64_t qw = win2(wsrc, p + k - (wb << 5));
-						// walk: how many more k-mer starts of this segment continue the same template diagonal
-						int run = 0;
-						int room = min(j1 - jj - 1, npos - (p + 1));
-						if(nN && room > 0) {
-							// the walk may not run into an N: strand position of the first N at or after p + k
-							int lo = 0, hi = nN;
-							if(!strand) { while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] < p + k) lo = mid + 1; else hi = mid; }
-								if(lo < nN) room = min(room, Nl[lo] - (p + k)); }
-							else { const int fq = L - 1 - (p + k);      // forward position of strand base p + k; bases go down from here
-								while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] <= fq) lo = mid + 1; else hi = mid; }
-								if(lo > 0) room = min(room, fq - Nl[lo - 1]); }
-						}
-						if(room > 0) {
-							const uint64_t x = qw ^ tw;
-							const int same = x ? (__clzll((long long) x) >> 1) : 32;
-							run = min(room, same);
-							// the template ends where vs_id holds no k-mer: nothing after it continues the diagonal
+							for(int i = 0; i <= WALK; ++i) vv[i] = vp[i];
+							const uint64_t tw = win2(db.cat, (int64_t) gp + k);
+							const uint64_t qw = win2(wsrc, p + k - (wb << 5));
+							// walk: how many more k-mer starts of this segment continue the same template diagonal
+							int run = 0;
+							int room = min(j1 - jj - 1, npos - (p + 1));
+							if(nN && room > 0) {
+								// the walk may not run into an N: strand position of the first N at or after p + k
+								int lo = 0, hi = nN;
+								if(!strand) { while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] < p + k) lo = mid + 1; else hi = mid; }
+									if(lo < nN) room = min(room, Nl[lo] - (p + k)); }
+								else { const int fq = L - 1 - (p + k);      // forward position of strand base p + k; bases go down from here
+									while(lo < hi) { const int mid = (lo + hi) >> 1; if(Nl[mid] <= fq) lo = mid + 1; else hi = mid; }
+									if(lo > 0) room = min(room, fq - Nl[lo - 1]); }
+							}
+							if(room > 0) {
+								const uint64_t x = qw ^ tw;
+								const int same = x ? (__clzll((long long) x) >> 1) : 32;
+								run = min(room, same);
+								// the template ends where vs_id holds no k-mer: nothing after it continues the diagonal
 #pragma unroll
-							for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
-						}
-						// positions jj .. jj + run carry the lists vv[0 .. run]; bit i of bm: a run of equal lists starts at i
-						uint32_t bm = 1u;
+								for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
+							}
+							// positions jj .. jj + run carry the lists vv[0 .. run]; bit i of bm: a run of equal lists starts at i
+							uint32_t bm = 1u;
 #pragma unroll
-						for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] != vv[i - 1]) bm |= 1u << i;
-						nres += run; hc += run + 1;
+							for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] != vv[i - 1]) bm |= 1u << i;
+							nres += run; hc += run + 1;
 #ifdef KMAHIP_DIAG
-						if(A.ablate & 1) bm = 0;
+							if(A.ablate & 1) bm = 0;
 #endif
-						if(s_over[g]) bm = 0;                // the item goes to the overflow kernel anyway
-						while(bm) {
-							const int i0 = __ffs((int) bm) - 1;
-							bm &= bm - 1;
-							const int i1 = bm ? __ffs((int) bm) - 1 : run + 1;
-							uint32_t vi = vv[0];
+							if(s_over[g]) bm = 0;                // the item goes to the overflow kernel anyway
+							while(bm) {
+								const int i0 = __ffs((int) bm) - 1;
+								bm &= bm - 1;
+								const int i1 = bm ? __ffs((int) bm) - 1 : run + 1;
+								uint32_t vi = vv[0];
 #pragma unroll
-							for(int i = 1; i <= WALK; ++i) if(i0 == i) vi = vv[i];
-							const int rs = jj + i0, re = jj + i1;            // positions [rs, re) of the pass
-							if(STATS) atomicAdd(&s_stats[1], value_at(db, vi, 0) + 1u);
-							// claim / find the list's slot in the item's v-table
-							int slot = -1;
-							const uint32_t h = (vi * 0x9E3779B1u) >> 28;
-#pragma unroll 1
-							for(int x = 0; x < VSLOTS; ++x) {
-								const int sidx = (int) ((h + x) & (VSLOTS - 1)) * GROUP + g;
-								const uint32_t old = atomicCAS(&v_id[sidx], MISS, vi);
-								if(old == MISS || old == vi) { slot = sidx; break; }
+								for(int i = 1; i <= WALK; ++i) if(i0 == i) vi = vv[i];
+								add_run(g, vi, jj + i0, jj + i1);            // positions [rs, re) of the pass
 							}
-							if(slot >= 0) {
-								// a run inside one lane's segment is at most SEG (9) positions long: two mask words at most
-								const int w = rs >> 5;
-								const uint64_t m = ((1ull << (re - rs)) - 1ull) << (rs & 31);
-								atomicOr(&v_mask[w * VSLOTS * GROUP + slot], (uint32_t) m);
-								if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * GROUP + slot], (uint32_t) (m >> 32));
-							} else {
-								// more distinct lists in this pass than the v-table holds: expand this run directly
-								expand_list<TSLOTS>(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
-							}
+							jj += run;
 						}
-						jj += run + 1;
-						pairs = true;        // whatever is left of the segment lies behind a mismatch
+					}
+					(void) hit;
+					++jj;
+					// what is left of the segment: into the queue; when the queue is full (every read of the group riddled with
+					// mismatches) the lane keeps it and resolves it itself behind the queue round
+					const int left = min(j1, npos - c0) - jj;
+					if(left > 0) {
+						const uint32_t at = atomicAdd(&s_qn, (uint32_t) left);
+						if(at + (uint32_t) left <= (uint32_t) QCAP) for(int i = 0; i < left; ++i) s_q[at + i] = (uint16_t) ((g << 8) | (jj + i));
+						else {
+							for(int i = 0; i < left; ++i) if(at + i < (uint32_t) QCAP) s_q[at + i] = 0xFFFFu;
+							own_lo = jj; own_n = left;
+						}
 					}
 					if(MODE && hc) atomicAdd(&s_hits[g], hc);
 				}
 			}
+			__syncthreads();
+			{
+				// the queue: every entry one k-mer start (item, position in the pass), one probe each
+				const uint32_t qn = min(s_qn, (uint32_t) QCAP);
+				const int q_iters = (int) ((qn + STHREADS - 1) / STHREADS);
+				// (a lane that kept its k-mer starts takes them one by one behind the queue's rounds)
+				for(int it = 0; it < q_iters + own_n; ++it) {
+					uint32_t v = 0xFFFFu;
+					if(it < q_iters) { const uint32_t e = (uint32_t) it * STHREADS + tid; if(e < qn) v = s_q[e]; }
+					else v = (uint32_t) (((tid & (GROUP - 1)) << 8) | (own_lo + it - q_iters));
+					if(v != 0xFFFFu) resolve((int) (v >> 8), (int) (v & 255u));
+				}
+			}
 			if(STATS && nres) { atomicAdd(&s_stats[0], nres); atomicAdd(&s_stats[2], nprobe); }
 			__syncthreads();
+			if(tid == 0) s_qn = 0;          // (for the next pass / the next group: barriers lie in between)
 			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
 			// flight together) and OR the list's position mask into the hit mask of each listed template
 			static_assert((VSLOTS * GROUP) % STHREADS == 0 && (TSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
@@ -719,76 +769,70 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? 8 : 2)
 			__syncthreads();
 		}
 
-		// ---- finish the items of this group: getBestMatch (savekmers.c:273-294) ---------
+		// ---- finish the items of this group: getBestMatch (savekmers.c:273-294), all threads: the best score of an item by an LDS
+		// atomic over its occupied slots, the tied templates counted the same way, one thread per item takes the result slots, and
+		// every tied template finds its place among the others -- first-seen order = ascending (first hit position, template id) --
+		// by counting the smaller keys (one lane per item walking the 16 slots once per tie kept the other three waves waiting)
+		static_assert((TSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
+		for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
+			const int idx = part + tid, g = idx & (GROUP - 1);
+			if(g < ng && !s_over[g] && t_id[idx] != T_EMPTY) {
+				if(MODE) atomicAdd(&s_nb[g], 1);
+				else atomicMax(&s_best[g], max(0, t_score[idx]));
+			}
+		}
+		__syncthreads();
+		if(!MODE) {
+			for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
+				const int idx = part + tid, g = idx & (GROUP - 1);
+				if(g < ng && !s_over[g] && t_id[idx] != T_EMPTY) { const int sc = max(0, t_score[idx]); if(sc > 0 && sc == s_best[g]) atomicAdd(&s_nb[g], 1); }
+			}
+			__syncthreads();
+		}
 		if(tid < ng) {
 			const int g = tid;
 			const int64_t item = s_item[g];
 			int best = 0, nb = 0;
 			int64_t off = 0;
 #ifdef KMAHIP_DIAG
-			if(A.ablate & 16) { nb = 0; } else
+			if(A.ablate & 16) { nb = 0; s_off[g] = -1; } else
 #endif
 			if(s_over[g]) {
 				const unsigned long long slot = atomicAdd(&A.counters[A.out_count], 1ull);
 				A.out_over[slot] = item;
 				nb = -1;
-			} else if(MODE) {
-				// get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores
-				for(int x = 0; x < TSLOTS; ++x) if(t_id[x * GROUP + g] != T_EMPTY) ++nb;
-				best = s_hits[g];
-				if(nb) {
-					off = A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
-					if(off + nb <= A.pool_cap) {
-						long long prevkey = -1;
-						for(int w = 0; w < nb; ++w) {
-							long long bk = 0x7FFFFFFFFFFFFFFFll;
-							int bx = 0;
-							for(int x = 0; x < TSLOTS; ++x) {
-								const uint32_t id = t_id[x * GROUP + g];
-								if(id == T_EMPTY) continue;
-								const long long key = ((long long) t_first[x * GROUP + g] << 32) | id;
-								if(key > prevkey && key < bk) { bk = key; bx = x; }
-							}
-							A.pool[off + w] = (int32_t) (bk & 0xFFFFFFFFll);
-							A.pool_sc[off + w] = max(0, t_score[bx * GROUP + g]);
-							prevkey = bk;
-						}
-					} else {
-						atomicMax(&A.counters[C_STATUS], 1ull);
-					}
-				}
+				s_off[g] = -1;
 			} else {
-				for(int x = 0; x < TSLOTS; ++x) {
-					if(t_id[x * GROUP + g] == T_EMPTY) continue;
-					const int sc = max(0, t_score[x * GROUP + g]);
-					if(sc > best) { best = sc; nb = 1; } else if(sc == best) ++nb;
-				}
-				if(best > 0) {
-					off = (nb <= INL) ? item * INL : A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
-					if(off + nb <= A.pool_cap) {
-						// first-seen order = ascending (first hit position, template id)
-						long long prevkey = -1;
-						for(int w = 0; w < nb; ++w) {
-							long long bk = 0x7FFFFFFFFFFFFFFFll;
-							for(int x = 0; x < TSLOTS; ++x) {
-								const uint32_t id = t_id[x * GROUP + g];
-								if(id == T_EMPTY || max(0, t_score[x * GROUP + g]) != best) continue;
-								const long long key = ((long long) t_first[x * GROUP + g] << 32) | id;
-								if(key > prevkey && key < bk) bk = key;
-							}
-							A.pool[off + w] = (int32_t) (bk & 0xFFFFFFFFll);
-							prevkey = bk;
-						}
-					} else {
-						atomicMax(&A.counters[C_STATUS], 1ull);
-					}
-				} else {
-					nb = 0;
-				}
+				// MODE 1, get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores, the hit count
+				best = MODE ? s_hits[g] : s_best[g];
+				nb = (MODE || best > 0) ? s_nb[g] : 0;
+				if(nb) off = (!MODE && nb <= INL) ? item * INL : A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+				if(nb && off + nb > A.pool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); s_off[g] = -1; }
+				else s_off[g] = nb ? off : -1;
 			}
 			A.item_score[item] = best;
 			A.item_n[item] = nb;
 			A.item_off[item] = off;
+		}
+		__syncthreads();
+		for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
+			const int idx = part + tid, g = idx & (GROUP - 1);
+			if(g >= ng || s_off[g] < 0 || t_id[idx] == T_EMPTY) continue;
+			const int sc = max(0, t_score[idx]), best = s_best[g];
+			if(!MODE && sc != best) continue;
+			int rank = 0;
+			if(s_nb[g] > 1) {
+				const long long key = ((long long) t_first[idx] << 32) | t_id[idx];
+#pragma unroll 1
+				for(int x = 0; x < TSLOTS; ++x) {
+					const int j = x * GROUP + g;
+					const uint32_t id = t_id[j];
+					if(id == T_EMPTY || (!MODE && max(0, t_score[j]) != best)) continue;
+					rank += ((((long long) t_first[j] << 32) | id) < key);
+				}
+			}
+			A.pool[s_off[g] + rank] = (int32_t) t_id[idx];
+			if(MODE) A.pool_sc[s_off[g] + rank] = sc;
 		}
 		__syncthreads();
 	}
