@@ -447,14 +447,13 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 			L = A.len[r]; so = A.seq_off[r]; no = A.N_off[r]; nN = (int) (A.N_off[r + 1] - no);
 		}
 		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no; s_item[tid] = it;
+		// the longest read of the group, among the 16 lanes that hold the items (one DPP row: no LDS round, no barrier of its own)
+		int mx = L;
+#pragma unroll
+		for(int d = 8; d; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 16));
+		if(tid == 0) { s_gmax = mx - k + 1; s_anylong = mx > (SW - 1) * 32; s_qn = 0; }
 	}
 	if(tid < 3) s_stats[tid] = 0;
-	if(tid == 0) { s_anylong = 0; s_gmax = 0; s_qn = 0; }
-	__syncthreads();
-	if(tid < ng) {
-		if(s_len[tid] > (SW - 1) * 32) s_anylong = 1;
-		atomicMax(&s_gmax, s_len[tid] - k + 1);
-	}
 	__syncthreads();
 	const bool staged_once = !s_anylong;
 	const int gmax = s_gmax;
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 	// (item, template) then folds its own bitmask -- no serial walk over the positions.
 	{
 		for(int idx = tid; idx < TSLOTS * GROUP; idx += STHREADS) {
-			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN; t_last[idx] = 0; t_first[idx] = 0;
+			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN;          // (t_last / t_first are only read behind a score)
 #pragma unroll
 			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
 		}
@@ -491,6 +490,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 		__syncthreads();
 
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
+			const bool more_passes = c0 + CHUNK < gmax;      // (every group starts from cleared tables)
 			// stage the forward words of this pass (only workgroups holding a read too long to be staged once)
 			if(!staged_once) {
 				for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
@@ -680,10 +680,14 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				const int idx = part + s_list[tid];
 				const int g = idx & (GROUP - 1);
 				const uint32_t vi = v_id[idx];
-				v_id[idx] = MISS;
 				uint32_t mw[MW];
 #pragma unroll
-				for(int w = 0; w < MW; ++w) { mw[w] = v_mask[w * VSLOTS * GROUP + idx]; v_mask[w * VSLOTS * GROUP + idx] = 0; }
+				for(int w = 0; w < MW; ++w) mw[w] = v_mask[w * VSLOTS * GROUP + idx];
+				if(more_passes) {          // (the tables of the last pass of a first-tier workgroup are not looked at again)
+					v_id[idx] = MISS;
+#pragma unroll
+					for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
+				}
 				if(g < ng && !s_over[g]) {
 				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
 				uint32_t cnt, el[7];
@@ -726,7 +730,9 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 #endif
 			if(tid < n_tmpl) {
 				const int idx = part + s_list[tid];
-				int score = t_score[idx], last = t_last[idx], first = t_first[idx];
+				// (the first pass starts every slot afresh: nothing to read)
+				int score = INT_MIN, last = 0, first = 0;
+				if(c0) { score = t_score[idx]; last = t_last[idx]; first = t_first[idx]; }
 				// the 136-bit mask as three 64-bit words; a run of ones starts where a one has a zero below it and ends
 				// (exclusively) where a zero has a one below it -- MW * 32 > CHUNK, so every run ends inside the words
 				static_assert(MW == 5 && CHUNK < MW * 32, "mask layout");
@@ -761,9 +767,12 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 						score += bridge(b0 - b1, k, A.M, A.MM, A.U, A.W1);      // b1 = first zero after a run, b0 = next run's start
 					}
 				}
-				t_score[idx] = score; t_last[idx] = last; t_first[idx] = first;
+				t_score[idx] = score; t_first[idx] = first;
+				if(more_passes) {
+					t_last[idx] = last;
 #pragma unroll
-				for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+					for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+				}
 			}
 			}
 			__syncthreads();
