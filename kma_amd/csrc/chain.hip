@@ -36,6 +36,7 @@ struct CSeg { unsigned start, end, covered; int b0, b1; };
 //             A template that finds the table full sets the lane's status and the read goes to the other kernel.
 // A handle is obtained once per (anchor, template) and used for the three fields.
 struct DenseMap {
+	static constexpr bool cached_lists = false;      // (the lane-per-read kernel builds its anchors itself: their spare fields are its own)
 	int *Score, *extend;
 	int8_t *include;
 	const int32_t *tlen;
@@ -50,11 +51,15 @@ struct DenseMap {
 #endif
 constexpr int LDS_TS = CHAIN_LDS_TS;       // slots per lane
 constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
+// (pointers into LDS carry their address space: kept in a struct as plain pointers they were compiled to FLAT accesses -- 230 M
+// vector-memory instructions and not one LDS instruction per 2 M reads, SQ counters of tools/pmc_chain.sh)
+#define KMAHIP_LDS __attribute__((address_space(3)))
 struct LdsMap {
-	uint32_t *id;
-	int *sc, *tl;              // (tl: the template's length, fetched once per read instead of once per anchor it occurs in)
-	uint16_t *ex;              // (positions of reads the fast route takes fit 16 bits)
-	int8_t *inc;
+	static constexpr bool cached_lists = true;       // (anchors of chain_anchor_kernel carry the head of their value list)
+	KMAHIP_LDS uint32_t *id;
+	KMAHIP_LDS int *sc, *tl;   // (tl: the template's length, fetched once per read instead of once per anchor it occurs in)
+	KMAHIP_LDS uint16_t *ex;   // (positions of reads the fast route takes fit 16 bits)
+	KMAHIP_LDS int8_t *inc;
 	const int32_t *tlen;
 	int lane;
 	__device__ __forceinline__ int slot(int t, int &status) const {
@@ -70,9 +75,9 @@ struct LdsMap {
 		return (int) (h & (LDS_TS - 1)) * 64 + lane;          // (any slot: the read is given up)
 	}
 	__device__ __forceinline__ int TL(int h) const { return tl[h]; }
-	__device__ __forceinline__ int &S(int h) const { return sc[h]; }
-	__device__ __forceinline__ uint16_t &E(int h) const { return ex[h]; }
-	__device__ __forceinline__ int8_t &I(int h) const { return inc[h]; }
+	__device__ __forceinline__ KMAHIP_LDS int &S(int h) const { return sc[h]; }
+	__device__ __forceinline__ KMAHIP_LDS uint16_t &E(int h) const { return ex[h]; }
+	__device__ __forceinline__ KMAHIP_LDS int8_t &I(int h) const { return inc[h]; }
 	__device__ __forceinline__ void reset() const { for(int x = 0; x < LDS_TS; ++x) id[x * 64 + lane] = LDS_EMPTY; }
 };
 
@@ -101,8 +106,28 @@ struct ChainArgs {
 	unsigned long long *counters;   // [0] records, [1] status, [2] templates
 };
 
+__device__ __forceinline__ int list_n(const DevDB &db, uint32_t v);
+__device__ __forceinline__ int list_at(const DevDB &db, uint32_t v, int i);
+// length / i-th element (1-based) of an anchor's value list: from the head the anchor carries where it does (see
+// chain_anchor_kernel), else from the list itself
+template <class TM> __device__ __forceinline__ int ank_n(const DevDB &db, const CAnk &a) {
+	if(TM::cached_lists) return db.values_u16 ? (int) ((uint32_t) a.score_len & 0xFFFFu) : a.score_len;
+	return list_n(db, a.values);
+}
+template <class TM> __device__ __forceinline__ int ank_at(const DevDB &db, const CAnk &a, int i) {
+	if(TM::cached_lists) {
+		if(db.values_u16) {
+			if(i == 1) return (int) ((uint32_t) a.score_len >> 16);
+			if(i == 2) return (int) ((uint32_t) a.len_len & 0xFFFFu);
+			if(i == 3) return (int) ((uint32_t) a.len_len >> 16);
+		} else if(i == 1) return a.len_len;
+	}
+	return list_at(db, a.values, i);
+}
+
 template <class TM>
 struct CLaneT {
+	typedef TM Map;
 	const DevDB *db;
 	CAnk *VF, *VR;
 	TM tm;
@@ -241,12 +266,14 @@ template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src
 	const DevDB &db = *L.db;
 	if(src < 0) return -1;
 	int nextAnker = 0;
+	typedef typename CLane::Map Map;
 	{
-		const int n = list_n(db, V[src].values);
+		const CAnk a = V[src];
+		const int n = ank_n<Map>(db, a);
 		if(n + 1 > room) { L.status = 1; bests[0] = 0; return -1; }
 		bests[0] = n;
 		for(int i = n; i >= 1; --i) {
-			const int t = list_at(db, V[src].values, i);
+			const int t = ank_at<Map>(db, a, i);
 			bests[i] = t;
 			if(++L.tm.I(L.tm.slot(t, L.status)) == 1) nextAnker = 1;
 		}
@@ -255,15 +282,15 @@ template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src
 	int prev = src;
 	// (the anchor in hand in registers, the one below it and the head of its list asked for ahead: see the chaining loop)
 	CAnk nxt = V[src];
-	int nxt_n = nextAnker ? list_n(db, nxt.values) : 0;
+	int nxt_n = nextAnker ? ank_n<Map>(db, nxt) : 0;
 	for(int node = src; nextAnker && node >= 0; --node) {
 		const CAnk cur = nxt;
 		const int n = nxt_n;
-		if(node > 0) { nxt = V[node - 1]; nxt_n = list_n(db, nxt.values); }
+		if(node > 0) { nxt = V[node - 1]; nxt_n = ank_n<Map>(db, nxt); }
 		const int start = (int) cur.start, end = (int) cur.end;
 		bool silenced = false;
 		for(int i = n; i >= 1; --i) {
-			const int t = list_at(db, cur.values, i);
+			const int t = ank_at<Map>(db, cur, i);
 			const int th = L.tm.slot(t, L.status);
 			if(!L.tm.I(th)) continue;
 			int score = L.tm.S(th);
@@ -515,7 +542,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			CAnk *V = strand ? VR : VF;
 			unsigned HIT = (strand ? hitR : hitF) + 1;
 			if(strand) {
-				V[0].score = 0; V[0].score_len = 0; V[0].len_len = 1;
+				V[0].score = 0;          // (score_len / len_len of the anchor in hand live in registers below)
 				bests = bestT_r;
 				best = best_r;
 				best_r = &V[0];
@@ -527,17 +554,18 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			// first comparison of a strand compares the anchor with itself -- an equality, which counts a tie (kept, b_idx == vi).
 			// The next anchor and the head of its value list are asked for while this one is worked on.
 			int b_idx = 0, b_score = 0, b_sl = 0, n_bests = 0;
+			typedef typename CLane::Map Map;
 			CAnk nxt = V[0];
-			int nxt_n = HIT > 1 ? list_n(db, nxt.values) : 0;
+			int nxt_n = HIT > 1 ? ank_n<Map>(db, nxt) : 0;
 			while(--HIT) {
 				const CAnk cur = nxt;
 				const int n = nxt_n;
-				if(HIT > 1) { nxt = V[vi + 1]; nxt_n = list_n(db, nxt.values); }
+				if(HIT > 1) { nxt = V[vi + 1]; nxt_n = ank_n<Map>(db, nxt); }
 				const int start = (int) cur.start, end = (int) cur.end, weight = cur.weight;
 				a_min = start < a_min ? start : a_min; a_max = end > a_max ? end : a_max;
 				int a_score = 0, a_sl = 0, a_ll = 1;
 				for(int i = n; i >= 1; --i) {
-					const int t = list_at(db, cur.values, i);
+					const int t = ank_at<Map>(db, cur, i);
 					const int th = L.tm.slot(t, L.status);
 					if(L.status) return;
 					int score = L.tm.S(th);
@@ -781,7 +809,8 @@ __global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const 
 	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
 	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
 	L.tree = (CSeg *) base;
-	L.tm.id = t_id; L.tm.sc = t_sc; L.tm.tl = t_tl; L.tm.ex = t_ex; L.tm.inc = t_inc; L.tm.tlen = A.db.tlen; L.tm.lane = (int) threadIdx.x;
+	L.tm.id = (KMAHIP_LDS uint32_t *) t_id; L.tm.sc = (KMAHIP_LDS int *) t_sc; L.tm.tl = (KMAHIP_LDS int *) t_tl; L.tm.ex = (KMAHIP_LDS uint16_t *) t_ex;
+	L.tm.inc = (KMAHIP_LDS int8_t *) t_inc; L.tm.tlen = A.db.tlen; L.tm.lane = (int) threadIdx.x;
 	L.tm.reset();
 	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
 	L.a_cap = A.a_cap; L.b_cap = A.b_cap; L.s_cap = A.s_cap;

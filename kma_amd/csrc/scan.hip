@@ -1452,12 +1452,23 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 	for(int i = ln; i < n; i += 16) {
 		KmaAnk a;
 		const uint32_t last = a_last[i * GROUP + gi];
-		a.score = 0; a.weight = a_w[i * GROUP + gi]; a.score_len = 0; a.len_len = 0;
+		const uint32_t vi = a_val[i * GROUP + gi];
+		// the head of the anchor's value list rides in the two fields the chaining keeps in registers (score_len: the length,
+		// and with 16-bit lists the first element in its upper half; len_len: the next two, or the first 32-bit one): the lane
+		// that chains the read (chain_fast_kernel) then needs no gather per anchor and listed template for lists of up to three
+		if(db.values_u16) {
+			const uint16_t *vp = db.values16 + vi;          // (the value arrays carry 8 pad elements)
+			const uint32_t nl = vp[0], e1 = vp[1], e2 = vp[2], e3 = vp[3];
+			a.score_len = (int) (nl | (e1 << 16)); a.len_len = (int) (e2 | (e3 << 16));
+		} else {
+			a.score_len = (int) db.values32[vi]; a.len_len = (int) db.values32[vi + 1];
+		}
+		a.score = 0; a.weight = a_w[i * GROUP + gi];
 		a.start = a_start[i * GROUP + gi];
 		// an anchor closed by the next one ends behind its last hit's k-mer + 1 (j - gaps + k at the opening hit j); the last one
 		// at seqlen - gaps with the k missed starts of the read's end counted in: its last hit (savekmers.c:5316-5330)
 		a.end = i < n - 1 ? last + 1u + (uint32_t) k : last;
-		a.values = a_val[i * GROUP + gi];
+		a.values = vi;
 		a.descend = i < n - 1 ? i + 1 : -1;
 		A.pool[off + i] = a;
 	}
