@@ -58,6 +58,11 @@ struct PileArgs {
 	int64_t n_units;
 	int seg_cols;
 	int64_t *vis_cnt, *vis_off;  // per read: number of units it visits, exclusive scan of that
+	// per entry (in the order pile_keys_kernel lists them: vis_off[read] + unit - first unit visited): where in the read's runs a
+	// unit's workgroup may start -- the last run that begins at or before the column two in front of the unit -- with the template
+	// columns and read bases before that run (pile_ckpt_kernel). Without it every one of the ~10 units a 10 kb read touches scans
+	// all of its ~3 000 runs.
+	int32_t *ck_j, *ck_col, *ck_q;
 	int64_t *unit_start;         // n_units + 1: first entry of the sorted list per unit (n_entries if none)
 	int64_t *unit_end;           // n_units: one past its last entry (read only where unit_start < n_entries)
 	int lds_words;               // LDS words a workgroup has (PILE_LDS_WORDS, or half of it so that two workgroups share a CU)
@@ -246,6 +251,48 @@ __global__ __launch_bounds__(256) void pile_keys_kernel(const PileArgs A) {
 	for(int u = V.w0; u <= V.w1; ++u, ++slot) { A.keys[slot] = ((uint64_t) u << 28) | ord; A.vals[slot] = (int32_t) r; }
 }
 
+// checkpoints of the reads that lie on a template cut into units and do not wrap around its end: one wavefront per read, its runs
+// 64 at a time (prefix sums of template columns / read bases by wave shuffles)
+__global__ __launch_bounds__(64) void pile_ckpt_kernel(const PileArgs A) {
+	const int lane = threadIdx.x;
+	for(int64_t r = blockIdx.x; r < A.n_reads; r += gridDim.x) {
+		if(A.stats[10 * r + 3] == 0) continue;
+		const int t = abs(A.tmpl[r]);
+		const int ub = A.unit_base[t], nu = A.unit_base[t + 1] - ub;
+		if(nu <= 1) continue;
+		const Visits V = pile_visits(A, r);
+		const ReadRuns R = read_runs(A, r);
+		const int t_len = A.db.tlen[t];
+		int start = R.start;
+		if(start >= t_len) start -= t_len;
+		const int nvis = V.u1 - V.u0 + 1;
+		const int64_t slot0 = A.vis_off[r];
+		const int nslots = nvis + (V.w1 >= V.w0 ? V.w1 - V.w0 + 1 : 0);
+		for(int x = lane; x < nslots; x += 64) { A.ck_j[slot0 + x] = R.first; A.ck_col[slot0 + x] = 0; A.ck_q[slot0 + x] = R.qp; }
+		if(V.w1 >= V.w0 || V.u0 != ub + start / A.seg_cols) continue;          // (wraps, or covers everything: the units scan from the first run)
+		const int S = A.seg_cols, u0l = V.u0 - ub;
+		int col_carry = 0, q_carry = R.qp;
+		for(int j0 = R.first; j0 < R.n; j0 += 64) {
+			const int j = j0 + lane;
+			const bool valid = j < R.n;
+			const uint32_t run = valid ? A.ops[R.o + j] : 0u;
+			const int cls = (int) (run & 3u), len = (int) (run >> 2);
+			const int tl = valid && cls != 2 ? len : 0, ql = valid && cls != 3 ? len : 0;
+			int ct = tl, cq = ql;
+			for(int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ct, d), b = __shfl_up(cq, d); if(lane >= d) { ct += a; cq += b; } }
+			const int col0 = col_carry + ct - tl, q0 = q_carry + cq - ql;
+			// this run is the place to start for every unit whose column lo - 2 lies in [col0, col0 + tl - 1] (relative to the read's
+			// first column); a run without template columns (an insertion) is never one
+			if(tl > 0) {
+				const int a0 = col0 + start + 2, a1 = col0 + tl - 1 + start + 2;          // lo of the units: a0 <= lo <= a1, lo a multiple of S
+				for(int ui = (a0 + S - 1) / S - u0l; ui <= a1 / S - u0l && ui < nvis; ++ui)
+					if(ui >= 0) { A.ck_j[slot0 + ui] = j; A.ck_col[slot0 + ui] = col0; A.ck_q[slot0 + ui] = q0; }
+			}
+			col_carry += __shfl(ct, 63); q_carry += __shfl(cq, 63);
+		}
+	}
+}
+
 __global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys, int64_t n_ent, int64_t *unit_start, int64_t *unit_end) {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= n_ent) return;
@@ -314,13 +361,28 @@ __device__ uint64_t block_scan2(uint64_t v, unsigned long long *s_w, uint64_t *t
 	return base + x - v;
 }
 
-__device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, unsigned long long *s_w) {
+__device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, int unit, unsigned long long *s_w) {
 	const int tid = threadIdx.x;
 	ReadRuns R = read_runs(A, r);
 	int start = R.start;
 	if(start >= W.t_len) start -= W.t_len;
 	int64_t col_carry = 0, q_carry = R.qp;
-	for(int j0 = R.first; j0 < R.n; j0 += (int) blockDim.x) {
+	// where this unit's stretch of the read begins (pile_ckpt_kernel); a read that wraps round the template's end has no checkpoints
+	int j_begin = R.first;
+	bool ends_early = false;
+	{
+		const int ub = A.unit_base[abs(A.tmpl[r])];
+		const int u0 = ub + start / A.seg_cols;
+		const int32_t *st = A.stats + 10 * r;
+		const int span = st[3] - st[7] - R.lead_d - R.trail_d;
+		if(A.ck_j && start + span <= W.t_len && unit >= u0) {
+			const int64_t slot = A.vis_off[r] + (unit - u0);
+			j_begin = A.ck_j[slot]; col_carry = A.ck_col[slot]; q_carry = A.ck_q[slot];
+			ends_early = true;
+		}
+	}
+	for(int j0 = j_begin; j0 < R.n; j0 += (int) blockDim.x) {
+		if(ends_early && start + col_carry > (int64_t) W.hi) break;          // (every further run lies behind the unit)
 		const int j = j0 + tid;
 		const bool valid = j < R.n;
 		const uint32_t run = valid ? A.ops[R.o + j] : 0u;
@@ -536,7 +598,7 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			for(int i = tid; i < 7 * ncol; i += (int) blockDim.x) pile_lds[i] = 0;
 			if(tid == 0) s_nodes = 0;
 			__syncthreads();
-			for(int64_t e = s0; e < s1; ++e) pile_seg_read(A, W, (int64_t) A.vals[e], s_ins);
+			for(int64_t e = s0; e < s1; ++e) pile_seg_read(A, W, (int64_t) A.vals[e], (int) u, s_ins);
 			const int n_nodes = min((int) s_nodes, W.node_cap());
 			if(tid == 0) s_pool = n_nodes ? (long long) atomicAdd(&A.counters[2], (unsigned long long) n_nodes) : 0;
 			__syncthreads();
@@ -878,6 +940,14 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		}
 		A.keys = ws->p_keys; A.vals = ws->p_vals;
 		hipLaunchKernelGGL(pile_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A);
+		A.ck_j = nullptr; A.ck_col = nullptr; A.ck_q = nullptr;
+		if(n_units > (int64_t) D - 1 && !getenv("KMAHIP_PILE_NO_CKPT")) {          // some template is cut into units
+			int32_t *ck = nullptr;
+			HIP_TRY(hipMalloc((void **) &ck, (size_t) n_ent * 3 * sizeof(int32_t)));
+			G.v.push_back(ck);
+			A.ck_j = ck; A.ck_col = ck + n_ent; A.ck_q = ck + 2 * n_ent;
+			hipLaunchKernelGGL(pile_ckpt_kernel, dim3((unsigned) std::min<int64_t>(n, 256 * 32)), dim3(64), 0, stream, A);
+		}
 		lap("ranks + visits + keys");
 		uint64_t *keys_out = ws->p_keys + n_ent;
 		int32_t *vals_out = ws->p_vals + n_ent;
