@@ -588,7 +588,9 @@ int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const
  *   - T_cap (kmahip_cands / kmahip_pe_recs) or ops_cap (kmahip_traces) too small: T_off[n] / R_off[2n] holds the needed
  *     size. A kmahip_align_*_dev call queued behind such a scan touches nothing beyond the capacities (it reports no hits),
  *     so scan_dev + align_dev may be chained on a stream without a status check in between;
- *   - more MEMs per (read, template) pair than the align scratch holds, or a DP problem beyond the trace scratch.
+ *   - more MEMs per (read, template) pair than the align scratch holds (a read full of repeats): the capacity has been raised
+ *     fourfold, repeat the align (score vectors zeroed again) or trace call; the one-call runs (kmahip_run_*) do that themselves;
+ *   - a DP problem beyond the trace scratch.
  * The status word is sticky until read here. */
 int kmahip_ws_status(kmahip_ws *ws, void *stream);
 

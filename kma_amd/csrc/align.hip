@@ -2214,7 +2214,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(max_len <= 0) { kmahip_set_error("kmahip_reads.max_len must be set for the align stage"); return KMAHIP_EINVAL; }
 	if(max_len > (1 << 20)) { kmahip_set_error("reads longer than 2^20 bases not supported"); return KMAHIP_EINVAL; }
 	// scratch geometry
-	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
+	const int mem_cap = (max_len <= 1024 ? 64 : max_len / 8) * std::max(1, ws->mem_scale);
 	const int ncols = max_len + 72;
 	const int64_t tasks_cap = cands->T_cap > 0 ? cands->T_cap : 1;
 	int64_t lanes = 256ll * 1024;
@@ -2411,7 +2411,7 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		const bool pipeline = mode ? !strcmp(mode, "pipeline") : max_len > 1024;
 		if(pipeline) return kmahip_launch_longtrace(db, ws, reads, tmpl, 0, flag, tmpl_ok, 0, p, out, nullptr, stream);
 	}
-	const int mem_cap = max_len <= 1024 ? 64 : max_len / 8;
+	const int mem_cap = (max_len <= 1024 ? 64 : max_len / 8) * std::max(1, ws->mem_scale);
 	const int ncols = max_len + 72;
 	const int ops_cap = 2 * max_len + 256;
 	// move matrix per lane: a banded tail (band 64 + 64) or a full join whose shorter side is within the band
@@ -2423,12 +2423,12 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	const int64_t per_lane = e_cap + (int64_t) (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4;
 	while(lanes > 256 && lanes * per_lane > (24ll << 30)) lanes >>= 1;
 	lanes = std::min<int64_t>(lanes, ((n + 255) / 256) * 256);
-	if(ws->t_lanes != lanes || ws->t_max_len != max_len) {
+	if(ws->t_lanes != lanes || ws->t_max_len != max_len || ws->t_mem_cap != mem_cap) {
 		(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
 		ws->t_s32 = nullptr; ws->t_E = nullptr;
 		HIP_TRY(hipMalloc((void **) &ws->t_s32, (size_t) lanes * (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4));
 		HIP_TRY(hipMalloc((void **) &ws->t_E, (size_t) lanes * e_cap));
-		ws->t_lanes = lanes; ws->t_max_len = max_len;
+		ws->t_lanes = lanes; ws->t_max_len = max_len; ws->t_mem_cap = mem_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));

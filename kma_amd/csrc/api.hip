@@ -54,7 +54,14 @@ extern "C" int kmahip_ws_status(kmahip_ws *ws, void *stream) {
 				kmahip_set_error("internal candidate pool exhausted: the pool has been doubled, repeat the call");
 				break;
 			case 2: kmahip_set_error("output capacity (T_cap / ops_cap) too small: the offsets array holds the needed size; stage 3a was skipped"); break;
-			case 3: kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); break;
+			case 3: case 16: {
+				// more MEMs against one template than the scratch has slots per (read, template) pair (a read full of repeats): the
+				// capacity goes up fourfold with the next launch, like the candidate pool
+				const int cur = ws->mem_scale > 0 ? ws->mem_scale : 1;
+				if(cur < 64) { ws->mem_scale = cur * 4; kmahip_set_error("seed (MEM) capacity per read/template pair exceeded: it has been raised fourfold, repeat the %s call (with the score vectors zeroed again)", c[1] == 3 ? "align" : "trace"); }
+				else kmahip_set_error("seed (MEM) capacity per read/template pair exceeded");
+				break;
+			}
 			default: kmahip_set_error("a read needs more scratch than the workspace holds (status %llu)", c[1]); break;
 		}
 		return KMAHIP_EOVERFLOW;

@@ -78,6 +78,8 @@ struct kmahip_ws {
 	int32_t *pool;
 	int64_t pool_cap;
 	int64_t pool_scale;       // pool = cap_reads * 16 * pool_scale ints; doubled after an overflow
+	int mem_scale;            // MEM slots per (read, template) = the usual 64 (reads up to 1 kb) x this; raised by the runs when a read
+	                          // full of repeats carries more (status 3), 0 = 1
 	// counters (16): [0] pool top, [1] status, [2] n_overflow, [3] probes, [4] value elems, [5] active strands,
 	// [6] hash probes, [7] pair pool top, [8] active strand items, [9] prefilter probes
 	unsigned long long *counters;
@@ -110,7 +112,7 @@ struct kmahip_ws {
 	int64_t t_lanes;
 	int32_t *t_queue;            // reads the first trace pass put off
 	int64_t t_queue_cap;
-	int t_max_len;
+	int t_max_len, t_mem_cap;
 	// pile-up stage (3c) scratch and results
 	uint32_t *p_counts;
 	int32_t *p_chain, *p_seg, *p_vals;

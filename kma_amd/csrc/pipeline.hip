@@ -87,6 +87,16 @@ int ws_status(kmahip_ws *ws, unsigned long long *c0) {
 	return (int) c[1];
 }
 
+// a read full of repeats can carry more MEMs against a template than the scratch holds slots for (64 for reads up to 1 kb;
+// status 3 from stage 3a, 16 from the traceback): the capacity goes up fourfold and the stage is run again
+bool grow_mem_cap(kmahip_ws *ws) {
+	const int cur = ws->mem_scale > 0 ? ws->mem_scale : 1;
+	if(cur >= 64) return false;
+	ws->mem_scale = cur * 4;
+	if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] seed (MEM) capacity per read and template raised to %d x the usual\n", ws->mem_scale);
+	return true;
+}
+
 }  // namespace
 
 // everything behind stage 2 on a batch that is in HBM with its candidate lists: stage 3a, ConClave + the `.res` statistics, the
@@ -107,10 +117,14 @@ static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kma
 	   (rc = B.get((size_t) total + 1, &h.start, true)) || (rc = B.get((size_t) total + 1, &h.end, true)) ||
 	   (rc = B.get(D, &h.alignment_scores, true)) || (rc = B.get(D, &h.uniq_alignment_scores, true))) return rc;
 	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a buffers after %.2f ms\n", since(t2)); }
-	if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
-	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a launched after %.2f ms\n", since(t2)); }
-	HIP_TRY(hipStreamSynchronize(s));
-	if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	for(;;) {
+		if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+		if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a launched after %.2f ms\n", since(t2)); }
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) != 3) break;
+		if(!grow_mem_cap(ws)) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+		HIP_TRY(hipMemsetAsync(h.alignment_scores, 0, D * 8, s)); HIP_TRY(hipMemsetAsync(h.uniq_alignment_scores, 0, D * 8, s));
+	}
 	out->ms[1] = since(t);
 
 	// stage 3b + the `.res` statistics (host arithmetic on one u64 per template)
@@ -146,6 +160,7 @@ static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kma
 			tr.ops_cap = (int64_t) used + (1 << 20);
 			continue;
 		}
+		if(st == 16 && grow_mem_cap(ws)) { --attempt; continue; }
 		if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
 		break;
 	}
@@ -538,16 +553,22 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	   (rc = B.get(D, &AS, true)) || (rc = B.get(D, &US, true))) return rc;
 	ph.tmpl = H_tmpl; ph.score = H_score; ph.start = H_start; ph.end = H_end; ph.alignment_scores = AS; ph.uniq_alignment_scores = US;
 	sh.tmpl = H_tmpl + s_base; sh.score = H_score + s_base; sh.start = H_start + s_base; sh.end = H_end + s_base; sh.alignment_scores = AS; sh.uniq_alignment_scores = US;
-	if(np > 0) {
-		if((rc = kmahip_launch_align_pe(db, ws, &dP, &recs, p, &ph, kind, s))) return rc;
-		HIP_TRY(hipStreamSynchronize(s));
-		if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
-	}
-	stamp("stage 3a of the pairs");
-	if(ns > 0) {
-		if((rc = kmahip_launch_align_se(db, ws, &dS, &cd, p, &sh, s))) return rc;
-		HIP_TRY(hipStreamSynchronize(s));
-		if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	for(;;) {
+		bool again = false;
+		if(np > 0) {
+			if((rc = kmahip_launch_align_pe(db, ws, &dP, &recs, p, &ph, kind, s))) return rc;
+			HIP_TRY(hipStreamSynchronize(s));
+			again = ws_status(ws, nullptr) == 3;
+		}
+		stamp("stage 3a of the pairs");
+		if(ns > 0 && !again) {
+			if((rc = kmahip_launch_align_se(db, ws, &dS, &cd, p, &sh, s))) return rc;
+			HIP_TRY(hipStreamSynchronize(s));
+			again = ws_status(ws, nullptr) == 3;
+		}
+		if(!again) break;
+		if(!grow_mem_cap(ws)) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+		HIP_TRY(hipMemsetAsync(AS, 0, D * 8, s)); HIP_TRY(hipMemsetAsync(US, 0, D * 8, s));          // (both stages add into them)
 	}
 	out->ms[1] = since(t);
 	if(sc && ((rc = shard_allreduce(sc, AS, D)) || (rc = shard_allreduce(sc, US, D)))) return rc;          // exchange 1
@@ -666,6 +687,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 				tr.ops_cap = (int64_t) used + (1 << 20);
 				continue;
 			}
+			if(st == 16 && grow_mem_cap(ws)) { --attempt; continue; }
 			if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
 			break;
 		}
@@ -1372,9 +1394,13 @@ extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	   (rc = B.get((size_t) n + 1, &h.rc, true)) || (rc = B.get((size_t) total + 1, &h.tmpl, true)) || (rc = B.get((size_t) total + 1, &h.score, true)) ||
 	   (rc = B.get((size_t) total + 1, &h.start, true)) || (rc = B.get((size_t) total + 1, &h.end, true)) || (rc = B.get(2 * D, &AS, true))) return rc;
 	h.alignment_scores = AS; h.uniq_alignment_scores = AS + D;
-	if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
-	HIP_TRY(hipStreamSynchronize(s));
-	if(ws_status(ws, nullptr) == 3) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	for(;;) {
+		if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) != 3) break;
+		if(!grow_mem_cap(ws)) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+		HIP_TRY(hipMemsetAsync(AS, 0, 2 * D * 8, s));
+	}
 	ms[1] = since(t);
 
 	// exchange 1: the two score vectors summed over the shards; ConClave on them; exchange 2: its per-template outputs summed
@@ -1414,6 +1440,7 @@ extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 			tr.ops_cap = (int64_t) used + (1 << 20);
 			continue;
 		}
+		if(st == 16 && grow_mem_cap(ws)) { --attempt; continue; }
 		if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
 		break;
 	}

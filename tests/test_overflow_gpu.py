@@ -57,3 +57,49 @@ def test_scan_dev_then_align_dev_with_small_T_cap_reports_overflow_and_stays_in_
         assert int((n_hits[:n] > 0).sum().item()) > n * 0.9
     finally:
         db.close()
+
+
+def test_reads_full_of_repeats_grow_the_seed_capacity_and_equal_the_reference(tmp_path):
+    """a gene that is a tandem repeat of a 24-base unit: a read out of it meets every one of its k-mers dozens of times in the
+    template, i.e. hundreds of MEMs against one template -- more than the 64 slots per (read, template) the scratch starts with.
+    The run raises the capacity and goes on (it used to end with KMAHIP_EOVERFLOW); files as the reference's."""
+    import gzip
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(12)
+    names, seqs = synth.make_gene_db(n_families=6, variants=3, seed=31)
+    unit = rng.integers(0, 4, 24, dtype=np.uint8)
+    rep = np.tile(unit, 50)
+    rep[rng.integers(0, len(rep), 12)] = rng.integers(0, 4, 12, dtype=np.uint8)          # a few units differ
+    seqs = list(seqs) + [np.concatenate([rng.integers(0, 4, 200, dtype=np.uint8), rep, rng.integers(0, 4, 200, dtype=np.uint8)])]
+    names = list(names) + ["tandem"]
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads, *_ = synth.make_reads(seqs[:-1], 600, read_len=150, sub_rate=0.01, seed=5)
+    reads = [r for r in reads]
+    t = seqs[-1]
+    for i in range(120):
+        a = int(rng.integers(150, len(t) - 400))
+        r = t[a:a + int(rng.integers(120, 260))].copy()
+        r[rng.random(len(r)) < 0.01] = 0
+        reads.append(r)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, reads, prefix="q")
+    for mode in (["-1t1"], []):
+        ref, got = str(tmp_path / ("ref" + "".join(mode))), str(tmp_path / ("got" + "".join(mode)))
+        subprocess.run([KMA, "-i", fq, "-o", ref, "-t_db", prefix, "-t", "1"] + mode, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        g = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", got] + mode, stderr=subprocess.PIPE,
+                           env=dict(os.environ, KMAHIP_DEBUG_TIMING="1"))
+        assert g.returncode == 0, g.stderr.decode()[-500:]
+        assert b"capacity per read and template raised" in g.stderr, mode          # (the case is what it claims to be)
+        assert open(got + ".res", "rb").read() == open(ref + ".res", "rb").read(), mode
+        assert b"tandem" in open(got + ".res", "rb").read()
+        assert open(got + ".fsa", "rb").read() == open(ref + ".fsa", "rb").read(), mode
+        assert gzip.open(got + ".frag.gz").read() == gzip.open(ref + ".frag.gz").read(), mode
