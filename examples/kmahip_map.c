@@ -53,6 +53,17 @@ static double since_process_start(void) {
 	return ts.tv_sec + 1e-9 * ts.tv_nsec - (double) start / (double) sysconf(_SC_CLK_TCK);
 }
 
+/* peak resident set of this process so far, MB (VmHWM of /proc/self/status) */
+static double peak_rss_mb(void) {
+	FILE *f = fopen("/proc/self/status", "r");
+	char line[256];
+	double mb = -1;
+	if(!f) return mb;
+	while(fgets(line, sizeof line, f)) if(!strncmp(line, "VmHWM:", 6)) { mb = strtod(line + 6, NULL) / 1024.0; break; }
+	fclose(f);
+	return mb;
+}
+
 /* stage 1 on a thread of its own, beside HIP start-up and the loading of the index */
 typedef struct ingest_job {
 	const char *in1, *in2;
@@ -70,6 +81,41 @@ static void *ingest_main(void *arg) {
 	if(j->rc && !j->err[0]) { strncpy(j->err, kmahip_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
 	j->t_done = now_s();
 	return NULL;
+}
+
+/* stage 1 batch by batch for the session (single end, -1t1, one rank): the reader parses the next batch while the device works on the
+ * one before; a batch is handed over (state 1), uploaded by the main thread, and given back (state 0) */
+typedef struct stream_job {
+	const char *in1;
+	kmahip_trim trim;
+	int64_t batch_reads;
+	kmahip_ingest *ing; kmahip_read_batch b;
+	int state, rc; char err[512]; double t_done;
+	pthread_mutex_t mu; pthread_cond_t cv;
+} stream_job;
+static void *stream_main(void *arg) {
+	stream_job *j = (stream_job *) arg;
+	int whole = 0;
+	int rc = kmahip_ingest_open_part(j->in1, NULL, &j->trim, 0, 1, &j->ing, &whole);
+	for(;;) {
+		if(!rc) rc = kmahip_ingest_next(j->ing, j->batch_reads, &j->b);
+		const int end = rc || j->b.reads.n_reads == 0;
+		if(end && !rc) rc = kmahip_ingest_status(j->ing);
+		pthread_mutex_lock(&j->mu);
+		if(end) {
+			j->rc = rc;
+			if(rc) { strncpy(j->err, kmahip_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
+			j->t_done = now_s();
+			j->state = 2;
+			pthread_cond_broadcast(&j->cv);
+			pthread_mutex_unlock(&j->mu);
+			return NULL;
+		}
+		j->state = 1;
+		pthread_cond_broadcast(&j->cv);
+		while(j->state != 0) pthread_cond_wait(&j->cv, &j->mu);
+		pthread_mutex_unlock(&j->mu);
+	}
 }
 
 /* The per-read result columns (half a gigabyte for 10 M reads) come from calloc: their pages do not exist until something writes
@@ -294,6 +340,57 @@ int main(int argc, char **argv) {
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s(), t_before_main = since_process_start();
+	if(world == 1 && one2one && !input2 && !mt1 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
+		/* the single-end -1t1 run, batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on this
+		 * one, the host holding one batch at a time */
+		stream_job sj;
+		memset(&sj, 0, sizeof sj);
+		sj.in1 = input; sj.trim = trim;
+		sj.batch_reads = getenv("KMAHIP_MAP_BATCH") ? atoll(getenv("KMAHIP_MAP_BATCH")) : 1000000;
+		if(sj.batch_reads < 1) sj.batch_reads = 1;
+		pthread_mutex_init(&sj.mu, NULL); pthread_cond_init(&sj.cv, NULL);
+		pthread_t reader;
+		if(pthread_create(&reader, NULL, stream_main, &sj)) fail("cannot start a thread");
+		kmahip_db *db; kmahip_ws *ws;
+		if(kmahip_init(local) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws)) die("open");
+		const double t_open = now_s();
+		kmahip_shard_opts so;
+		memset(&so, 0, sizeof so);
+		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		int64_t hint = 0;
+		{	/* (a guess at the number of reads from the size of the input: it only sizes the first allocation) */
+			struct stat sb;
+			const size_t il = strlen(input);
+			if(stat(input, &sb) == 0) hint = (int64_t) (sb.st_size / (il > 3 && !strcmp(input + il - 3, ".gz") ? 60 : 300));
+		}
+		kmahip_session *ses;
+		if(kmahip_session_open(db, ws, &par, &so, hint, &ses)) die("session");
+		int batches = 0;
+		for(;;) {
+			pthread_mutex_lock(&sj.mu);
+			while(sj.state == 0) pthread_cond_wait(&sj.cv, &sj.mu);
+			const int st = sj.state;
+			pthread_mutex_unlock(&sj.mu);
+			if(st == 2) break;
+			if(kmahip_session_upload(ses, &sj.b)) die("upload");
+			pthread_mutex_lock(&sj.mu);
+			sj.state = 0;
+			pthread_cond_broadcast(&sj.cv);
+			pthread_mutex_unlock(&sj.mu);
+			if(kmahip_session_map(ses)) die("stages 2 + 3a");
+			++batches;
+		}
+		pthread_join(reader, NULL);
+		if(sj.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", sj.err); finish(1); }
+		const double t_mapped = now_s();
+		double ms[8];
+		int64_t n_reads = 0, n_rows = 0;
+		if(kmahip_session_finish(ses, out, !no_cons, !no_frag, &n_reads, &n_rows, ms)) die("finish");
+		fprintf(stderr, "# kmahip_map: %lld reads in %d batches, %lld fragment rows; wall: open %.2f s, ingest done after %.2f, mapped after %.2f, finish %.2f | uploads %.1f ms, stages 2+3a %.1f, "
+		        "ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, .res + .fsa %.1f, .frag.gz %.1f (main entered %.2f s after process start; peak RSS %.0f MB)\n", (long long) n_reads, batches,
+		        (long long) n_rows, t_open - t_start, sj.t_done - t_start, t_mapped - t_start, now_s() - t_mapped, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], t_before_main, peak_rss_mb());
+		finish(0);
+	}
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */
 	ingest_job job;
 	memset(&job, 0, sizeof job);

@@ -581,6 +581,28 @@ int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const
 int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 
+/* ---- the single-end `-1t1` run fed batch by batch: the host holds one batch at a time ------------------------------------------
+ * The reference streams its input through pipes and spills the frag_raw records of stage 3a to a temporary file that ConClave
+ * and the assembly read back once the input has ended (kmapipe.c:55-146, updatescores.c:283-295, runkma.c:563-594, 757-863). Here
+ * HBM is that temporary file: kmahip_session_add uploads a batch of kmahip_ingest_next (reads, N positions, headers) behind the
+ * batches before it, runs stages 2 and 3a on it and adds into the ConClave vectors -- the batch's host arrays may be reused when it
+ * returns; kmahip_session_finish runs ConClave and the traceback per batch, one pile-up + consensus over everything, and writes
+ * <out_prefix>.res, .fsa (write_fsa) and .frag.gz (write_frag) -- the fragment rows are ordered, measured and formatted on the
+ * device and come back as text a chunk at a time for the host's threads to compress. Files byte for byte those of kmahip_run_se +
+ * kmahip_frag_write (the .gz after inflating). opts: evalue, bcd, caller / sig90, max_frag, ID_t, Depth_t as in
+ * kmahip_run_se_sharded; reads_hint: an estimate of the number of reads (0: none), sizes the device arrays up front.
+ * ms[8]: uploads and stages 2 + 3a (each summed over the batches), ConClave + statistics, traceback, pile-up + consensus,
+ * .res + .fsa, fragment rows. */
+typedef struct kmahip_session kmahip_session;
+int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_params *p, const kmahip_shard_opts *opts, int64_t reads_hint, kmahip_session **out);
+int kmahip_session_add(kmahip_session *s, const kmahip_read_batch *batch);
+/* kmahip_session_add in two steps, for a caller whose reader thread is to go on while the device works: _upload returns when the
+ * batch's host arrays are free again, _map runs stages 2 and 3a on what has been uploaded since the last call */
+int kmahip_session_upload(kmahip_session *s, const kmahip_read_batch *batch);
+int kmahip_session_map(kmahip_session *s);
+int kmahip_session_finish(kmahip_session *s, const char *out_prefix, int write_fsa, int write_frag, int64_t *n_reads, int64_t *n_rows, double ms[8]);
+void kmahip_session_close(kmahip_session *s);
+
 /* Status of the *_dev calls issued on this workspace since the last query; synchronises `stream`. 0, or KMAHIP_EOVERFLOW
  * with kmahip_last_error() naming one of:
  *   - the library's own candidate pool ran out (stage 2): the pool has been doubled, repeat the scan call (and what

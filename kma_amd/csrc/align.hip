@@ -2396,6 +2396,38 @@ int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
 }
 
 // stage 3c launcher: scratch lives in the workspace, sized by the longest read
+// the scratch of the lane-per-read traceback, sized by the longest read: made (or made anew) here, so that a caller that knows what
+// is coming can have it made while something else is going on (kmahip_trace_reserve: the batched session does, beside stage 1)
+struct TraceGeom { int mem_cap, ncols, ops_cap; int64_t e_cap, lanes; };
+static int trace_reserve(kmahip_ws *ws, int max_len, int64_t n, TraceGeom &G) {
+	G.mem_cap = (max_len <= 1024 ? 64 : max_len / 8) * std::max(1, ws->mem_scale);
+	G.ncols = max_len + 72;
+	G.ops_cap = 2 * max_len + 256;
+	// move matrix per lane: a banded tail (band 64 + 64) or a full join whose shorter side is within the band
+	G.e_cap = std::max<int64_t>((int64_t) 134 * (max_len + 68), (int64_t) (max_len / 2 + 4) * (max_len + 4));
+	G.e_cap = std::min<int64_t>(G.e_cap, 16ll << 20);
+	// one lane per read in flight; the kernel is bound by dependent loads, so it wants every wave slot of the chip (4 per SIMD
+	// at its register count = 262 144 lanes): 10 GB of scratch for 150-base reads, shrunk for longer ones to stay within 24 GB
+	int64_t lanes = 262144;
+	const int64_t per_lane = G.e_cap + (int64_t) (7 * (G.mem_cap + 1) + 4 * G.ncols + G.ops_cap) * 4;
+	while(lanes > 256 && lanes * per_lane > (24ll << 30)) lanes >>= 1;
+	lanes = std::min<int64_t>(lanes, ((n + 255) / 256) * 256);
+	G.lanes = lanes;
+	if(ws->t_lanes != lanes || ws->t_max_len != max_len || ws->t_mem_cap != G.mem_cap) {
+		(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
+		ws->t_s32 = nullptr; ws->t_E = nullptr;
+		HIP_TRY(hipMalloc((void **) &ws->t_s32, (size_t) lanes * (7 * (G.mem_cap + 1) + 4 * G.ncols + G.ops_cap) * 4));
+		HIP_TRY(hipMalloc((void **) &ws->t_E, (size_t) lanes * G.e_cap));
+		ws->t_lanes = lanes; ws->t_max_len = max_len; ws->t_mem_cap = G.mem_cap;
+	}
+	return KMAHIP_OK;
+}
+int kmahip_trace_reserve(kmahip_ws *ws, int max_len, int64_t n) {
+	if(max_len <= 0 || max_len > 1024 || n <= 0) return KMAHIP_OK;          // (longer reads take the pipeline of longtrace.hip)
+	TraceGeom G;
+	return trace_reserve(ws, max_len, n, G);
+}
+
 int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                         const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
@@ -2411,25 +2443,13 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		const bool pipeline = mode ? !strcmp(mode, "pipeline") : max_len > 1024;
 		if(pipeline) return kmahip_launch_longtrace(db, ws, reads, tmpl, 0, flag, tmpl_ok, 0, p, out, nullptr, stream);
 	}
-	const int mem_cap = (max_len <= 1024 ? 64 : max_len / 8) * std::max(1, ws->mem_scale);
-	const int ncols = max_len + 72;
-	const int ops_cap = 2 * max_len + 256;
-	// move matrix per lane: a banded tail (band 64 + 64) or a full join whose shorter side is within the band
-	int64_t e_cap = std::max<int64_t>((int64_t) 134 * (max_len + 68), (int64_t) (max_len / 2 + 4) * (max_len + 4));
-	e_cap = std::min<int64_t>(e_cap, 16ll << 20);
-	// one lane per read in flight; the kernel is bound by dependent loads, so it wants every wave slot of the chip (4 per SIMD
-	// at its register count = 262 144 lanes): 10 GB of scratch for 150-base reads, shrunk for longer ones to stay within 24 GB
-	int64_t lanes = 262144;
-	const int64_t per_lane = e_cap + (int64_t) (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4;
-	while(lanes > 256 && lanes * per_lane > (24ll << 30)) lanes >>= 1;
-	lanes = std::min<int64_t>(lanes, ((n + 255) / 256) * 256);
-	if(ws->t_lanes != lanes || ws->t_max_len != max_len || ws->t_mem_cap != mem_cap) {
-		(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E);
-		ws->t_s32 = nullptr; ws->t_E = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->t_s32, (size_t) lanes * (7 * (mem_cap + 1) + 4 * ncols + ops_cap) * 4));
-		HIP_TRY(hipMalloc((void **) &ws->t_E, (size_t) lanes * e_cap));
-		ws->t_lanes = lanes; ws->t_max_len = max_len; ws->t_mem_cap = mem_cap;
+	TraceGeom G;
+	{
+		const int rc = trace_reserve(ws, max_len, n, G);
+		if(rc) return rc;
 	}
+	const int mem_cap = G.mem_cap, ncols = G.ncols, ops_cap = G.ops_cap;
+	const int64_t e_cap = G.e_cap, lanes = G.lanes;
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 3, 0, 2 * sizeof(unsigned long long), stream));

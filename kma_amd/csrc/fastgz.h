@@ -5,6 +5,7 @@
 // several times its speed, and it runs on as many threads as there are blocks of rows.
 #pragma once
 #include <zlib.h>       // crc32()
+#include <immintrin.h>  // the carry-less multiply CRC below (x86-64 hosts; zlib's table form is the fallback)
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -66,6 +67,80 @@ inline void canonical_codes(const uint8_t *len, int n, uint16_t *code) {
 	}
 }
 
+// CRC-32 (the gzip polynomial) by folding with carry-less multiplication: 64 bytes per turn of the loop, an order of magnitude
+// faster than the table form zlib 1.2 ships -- the checksum was a third of a member's cost. The constants are the usual ones for
+// this polynomial in bit-reflected form (x^(n) mod P for the fold distances; "Fast CRC Computation for Generic Polynomials Using
+// PCLMULQDQ", Gopal et al.). tests/test_fastgz.py compares it with zlib's crc32 on every length from 0 to 300 and on megabytes.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1")))
+inline uint32_t crc32_fold(uint32_t crc, const uint8_t *buf, size_t len) {
+	// (crc: the running value as zlib's crc32() takes and returns it)
+	if(len < 64) return (uint32_t) ::crc32(crc, buf, (uInt) len);
+	const size_t body = len & ~(size_t) 15;
+	alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+	alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+	alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+	alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+	__m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+	size_t left = body;
+	x1 = _mm_loadu_si128((const __m128i *) (buf + 0x00));
+	x2 = _mm_loadu_si128((const __m128i *) (buf + 0x10));
+	x3 = _mm_loadu_si128((const __m128i *) (buf + 0x20));
+	x4 = _mm_loadu_si128((const __m128i *) (buf + 0x30));
+	x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int) ~crc));
+	x0 = _mm_load_si128((const __m128i *) k1k2);
+	buf += 64; left -= 64;
+	while(left >= 64) {
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+		x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+		x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+		x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+		y5 = _mm_loadu_si128((const __m128i *) (buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *) (buf + 0x10));
+		y7 = _mm_loadu_si128((const __m128i *) (buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *) (buf + 0x30));
+		x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+		x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+		buf += 64; left -= 64;
+	}
+	// four accumulators into one
+	x0 = _mm_load_si128((const __m128i *) k3k4);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+	x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+	while(left >= 16) {
+		x2 = _mm_loadu_si128((const __m128i *) buf);
+		x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+		buf += 16; left -= 16;
+	}
+	// 128 -> 64 -> 32 bits, Barrett reduction
+	x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+	x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+	x1 = _mm_srli_si128(x1, 8);
+	x1 = _mm_xor_si128(x1, x2);
+	x0 = _mm_loadl_epi64((const __m128i *) k5k0);
+	x2 = _mm_srli_si128(x1, 4);
+	x1 = _mm_and_si128(x1, x3);
+	x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+	x1 = _mm_xor_si128(x1, x2);
+	x0 = _mm_load_si128((const __m128i *) poly);
+	x2 = _mm_and_si128(x1, x3);
+	x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+	x2 = _mm_and_si128(x2, x3);
+	x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+	x1 = _mm_xor_si128(x1, x2);
+	uint32_t c = ~(uint32_t) _mm_extract_epi32(x1, 1);
+	if(len > body) c = (uint32_t) ::crc32(c, buf, (uInt) (len - body));          // (buf stands behind the folded part)
+	return c;
+}
+inline bool have_clmul() { static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"); return ok; }
+#else
+inline uint32_t crc32_fold(uint32_t crc, const uint8_t *buf, size_t len) { return (uint32_t) ::crc32(crc, buf, (uInt) len); }
+inline bool have_clmul() { return false; }
+#endif
+inline uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len) {
+	if(!have_clmul()) { for(size_t a = 0; a < len; a += 1u << 30) crc = (uint32_t) ::crc32(crc, buf + a, (uInt) std::min<size_t>(1u << 30, len - a)); return crc; }
+	return crc32_fold(crc, buf, len);
+}
+
 // bits go straight into a buffer the caller has sized for the worst case (15 bits per literal + the block headers): eight
 // bytes are stored at every put and the write position moves on by the whole bytes among them
 struct BitSink {
@@ -77,6 +152,14 @@ struct BitSink {
 		acc |= (uint64_t) v << n;
 		n += bits;
 		memcpy(w, &acc, 8);                            // (little endian host)
+		w += n >> 3;
+		acc >>= n & ~7;
+		n &= 7;
+	}
+	inline void put64(uint64_t v, int bits) {         // bits <= 56, n < 8 on entry
+		acc |= v << n;
+		n += bits;
+		memcpy(w, &acc, 8);
 		w += n >> 3;
 		acc >>= n & ~7;
 		n &= 7;
@@ -98,7 +181,7 @@ inline void deflate_block(BitSink &bs, const uint8_t *p, size_t n, bool last) {
 	freq[256] = 1;                                   // end of block
 	uint8_t llen[257];
 	uint16_t lcode[257];
-	code_lengths(freq, 257, 15, llen);
+	code_lengths(freq, 257, 12, llen);               // (12 bits at most: four codes fit one put of the bit sink, below)
 	canonical_codes(llen, 257, lcode);
 	// the two code-length sequences (257 literal/length codes, then two distance codes of one bit that are never used: readers
 	// insist on a distance code, deflate.c of zlib sends the same), run-length coded with the code-length alphabet
@@ -142,16 +225,17 @@ inline void deflate_block(BitSink &bs, const uint8_t *p, size_t n, bool last) {
 		bs.put(ccode[tok[t].sym], clen[tok[t].sym]);
 		if(tok[t].extra_bits) bs.put(tok[t].extra, tok[t].extra_bits);
 	}
-	// the literals: code and length of a byte in one table entry, two bytes per turn of the loop
+	// the literals: code and length of a byte in one table entry, four bytes per turn of the loop (4 x 12 bits + the 7 that may
+	// be waiting in the sink fit its 64)
 	uint32_t tab[256];
 	for(int s = 0; s < 256; ++s) tab[s] = (uint32_t) lcode[s] | ((uint32_t) llen[s] << 16);
 	size_t i = 0;
-	for(; i + 2 <= n; i += 2) {
-		const uint32_t a = tab[p[i]], b = tab[p[i + 1]];
-		const int la = (int) (a >> 16), lb = (int) (b >> 16);
-		bs.put((a & 0xffff) | ((b & 0xffff) << la), la + lb);
+	for(; i + 4 <= n; i += 4) {
+		const uint32_t a = tab[p[i]], b = tab[p[i + 1]], c = tab[p[i + 2]], d = tab[p[i + 3]];
+		const int la = (int) (a >> 16), lb = (int) (b >> 16), lc = (int) (c >> 16), ld = (int) (d >> 16);
+		bs.put64((uint64_t) (a & 0xffff) | ((uint64_t) (b & 0xffff) << la) | ((uint64_t) (c & 0xffff) << (la + lb)) | ((uint64_t) (d & 0xffff) << (la + lb + lc)), la + lb + lc + ld);
 	}
-	if(i < n) bs.put(tab[p[i]] & 0xffff, (int) (tab[p[i]] >> 16));
+	for(; i < n; ++i) bs.put(tab[p[i]] & 0xffff, (int) (tab[p[i]] >> 16));
 	bs.put(lcode[256], llen[256]);
 }
 
@@ -165,8 +249,7 @@ inline void gzip_member(const uint8_t *p, size_t n, std::string &out, std::vecto
 	if(n == 0) deflate_block(bs, p, 0, true);
 	for(size_t a = 0; a < n; a += BLOCK) deflate_block(bs, p + a, std::min(BLOCK, n - a), a + BLOCK >= n);
 	const size_t bytes = (size_t) (bs.finish() - scratch.data());
-	uint32_t crc = (uint32_t) crc32(0L, Z_NULL, 0);
-	for(size_t a = 0; a < n; a += 1u << 30) crc = (uint32_t) crc32(crc, p + a, (uInt) std::min<size_t>(1u << 30, n - a));
+	const uint32_t crc = crc32_fast((uint32_t) crc32(0L, Z_NULL, 0), p, n);
 	const uint32_t tail[2] = {crc, (uint32_t) (n & 0xffffffffu)};
 	out.reserve(out.size() + bytes + 18);
 	out.append((const char *) head, 10);

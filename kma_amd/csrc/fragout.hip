@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -118,6 +119,110 @@ int write_rows(const char *path, size_t n_rows, size_t block_rows, Fmt fmt) {
 
 // the template names of <prefix>.name, one per template in template order (read once)
 int kmahip_db_load_names(kmahip_db *db) { return load_names(db); }
+
+// ---- text that is formatted elsewhere (the session's rows come off the device as text), handed over block by block IN ORDER:
+// a few threads compress the blocks, each a gzip member of its own (fastgz.h), a writer thread puts them into the file in order.
+// The text is not copied: `done` of a block is counted down when its bytes are no longer needed.
+struct kmahip_gzstream {
+	struct Blk { const char *text; size_t bytes; std::atomic<int> *done; std::string out; int state; };      // state 0 queued, 1 taken, 2 ready
+	FILE *f = nullptr;
+	bool gz = false;
+	std::deque<Blk> q;                  // blocks [base, base + q.size())
+	size_t base = 0, next_work = 0;     // next_work: absolute index of the first block no worker has taken
+	bool closing = false;
+	int rc = KMAHIP_OK;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<std::thread> workers;
+	std::thread writer;
+	size_t blocks = 0;
+};
+
+static void gzstream_work(kmahip_gzstream *g) {
+	std::vector<uint8_t> scratch;
+	std::string out;
+	for(;;) {
+		kmahip_gzstream::Blk *b = nullptr;
+		size_t idx = 0;
+		{
+			std::unique_lock<std::mutex> lk(g->mu);
+			g->cv.wait(lk, [&] { return g->next_work < g->base + g->q.size() || g->closing; });
+			if(g->next_work >= g->base + g->q.size()) return;
+			idx = g->next_work++;
+			b = &g->q[idx - g->base];
+			b->state = 1;
+		}
+		out.clear();
+		if(g->gz) fastgz::gzip_member((const uint8_t *) b->text, b->bytes, out, scratch);
+		else out.assign(b->text, b->bytes);
+		{
+			std::lock_guard<std::mutex> lk(g->mu);
+			kmahip_gzstream::Blk &bb = g->q[idx - g->base];          // (the deque may have grown: take the block again)
+			bb.out.swap(out);
+			bb.state = 2;
+			if(bb.done) bb.done->fetch_sub(1);
+		}
+		g->cv.notify_all();
+	}
+}
+
+static void gzstream_write(kmahip_gzstream *g) {
+	for(;;) {
+		std::string out;
+		{
+			std::unique_lock<std::mutex> lk(g->mu);
+			g->cv.wait(lk, [&] { return (!g->q.empty() && g->q.front().state == 2) || (g->closing && g->q.empty()); });
+			if(g->q.empty()) return;
+			out.swap(g->q.front().out);
+			g->q.pop_front();
+			++g->base;
+		}
+		g->cv.notify_all();
+		if(fwrite(out.data(), 1, out.size(), g->f) != out.size()) { std::lock_guard<std::mutex> lk(g->mu); g->rc = KMAHIP_EIO; }
+	}
+}
+
+kmahip_gzstream *kmahip_gzstream_open(const char *path) {
+	FILE *f = fopen(path, "wb");
+	if(!f) { kmahip_set_error("cannot create %s", path); return nullptr; }
+	kmahip_gzstream *g = new kmahip_gzstream();
+	g->f = f;
+	const size_t plen = strlen(path);
+	g->gz = plen > 3 && !strcmp(path + plen - 3, ".gz");
+	const char *e = getenv("KMAHIP_IO_THREADS");
+	const int hw = (int) std::thread::hardware_concurrency();
+	int nt = e ? atoi(e) : std::min(16, hw > 0 ? hw : 1);
+	nt = std::max(nt, 1);
+	for(int t = 0; t < nt; ++t) g->workers.emplace_back(gzstream_work, g);
+	g->writer = std::thread(gzstream_write, g);
+	return g;
+}
+
+// the next block of the file; `done` (may be NULL) is counted down by one when the block's text has been read for the last time
+void kmahip_gzstream_submit(kmahip_gzstream *g, const char *text, size_t bytes, std::atomic<int> *done) {
+	{
+		std::lock_guard<std::mutex> lk(g->mu);
+		g->q.push_back({text, bytes, done, std::string(), 0});
+		++g->blocks;
+	}
+	g->cv.notify_all();
+}
+
+int kmahip_gzstream_close(kmahip_gzstream *g) {
+	{ std::lock_guard<std::mutex> lk(g->mu); g->closing = true; }
+	g->cv.notify_all();
+	for(std::thread &t : g->workers) t.join();
+	g->writer.join();
+	int rc = g->rc;
+	if(g->blocks == 0 && g->gz) {                             // an empty .gz is still a gzip file
+		gzFile z = gzdopen(dup(fileno(g->f)), "wb1");
+		if(!z || gzclose(z) != Z_OK) rc = KMAHIP_EIO;
+	}
+	if(fclose(g->f) != 0) rc = KMAHIP_EIO;
+	if(rc) kmahip_set_error("write to the fragment file failed");
+	delete g;
+	return rc;
+}
 
 int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *reads, int64_t n, const int64_t *src, const int32_t *rc,
                           const int32_t *tmpl, const int32_t *n_hits, const int32_t *trace_stats, int stats_stride, int64_t max_frag, int order,

@@ -183,6 +183,7 @@ struct Chunk {
 	size_t cap = 0, lo = 0, hi = 0;
 	bool mapped = false, last = false;
 	bool io_error = false;          // the stream ended on a read / inflate error, not at its end
+	size_t released = 0;            // mapped file: pages before this offset have been given back
 	int64_t spans_end = 0;          // records located in it end here (position in the stream of records)
 	~Chunk() { if(mapped) { if(base) munmap(base, cap); } else g_chunk_pool.give(base, cap); }
 };
@@ -924,6 +925,15 @@ bool fill_wave(kmahip_ingest *in, Mate &M) {
 void release_chunks(Mate &M) {
 	const int64_t done = M.spans_base + (int64_t) M.head;
 	while(M.live.size() > 1 && M.live.front()->spans_end <= done) { delete M.live.front(); M.live.pop_front(); }
+	// a file that is mapped whole: the pages behind the records packed so far are given back, so that what the process holds of
+	// its input does not grow with the input (they stay in the page cache; nothing here reads them again)
+	if(M.live.size() == 1 && M.live.front()->mapped && M.live.front()->base) {
+		Chunk *c = M.live.front();
+		const uint8_t *upto = M.head < M.spans.size() && M.spans[M.head].name ? M.spans[M.head].name - 1 : c->base + M.pos;
+		const size_t page = 4096, from = (c->released + page - 1) & ~(page - 1);
+		const size_t to = ((size_t) (upto - c->base)) & ~(page - 1);
+		if(to > from + (8u << 20)) { madvise(c->base + from, to - from, MADV_DONTNEED); c->released = to; }
+	}
 	if(M.head == M.spans.size()) { M.spans_base += (int64_t) M.head; M.spans.clear(); M.head = 0; }
 }
 

@@ -149,6 +149,7 @@ int kmahip_launch_align_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *rea
                            const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
 int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                         const uint8_t *tmpl_ok, const kmahip_params *p, kmahip_traces *out, hipStream_t stream);
+int kmahip_trace_reserve(kmahip_ws *ws, int max_len, int64_t n);          // align.hip: the traceback scratch, ahead of time
 int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *tmpl, int tmpl_all, const int32_t *rc_in,
                             const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream);
 // anchors of every strand that passes the prefilter, for reads without N's and up to 288 k-mer starts (the others get slow[read] = 1):

@@ -1,103 +1,9 @@
 // pipeline.hip -- kmahip_run_se: the single-end `-1t1` run of one batch in one call (host buffers in, per-template results
 // out), built from the same launchers as the stage-wise entry points; what runKMA does between its input stream and the
 // `.res` / consensus output (runkma.c:104-900), minus the files.
-#include "kmahip_internal.h"
-#include <algorithm>
-#include <chrono>
-#include <cstring>
+#include "pipeline_util.h"
 #include <memory>
-#include <rocprim/rocprim.hpp>
-#include <thread>
-#include <vector>
 
-namespace {
-
-// Device buffers of one run, carved out of a few large allocations (a hipMalloc per array cost more than ConClave itself:
-// thirty of them per run). Everything is released when the run ends.
-struct DevBlock {
-	std::vector<void *> owned;
-	char *slab = nullptr;
-	size_t slab_left = 0, slab_bytes = 256u << 20;
-	~DevBlock() { for(void *p : owned) (void) hipFree(p); }
-	void expect(size_t bytes) { slab_bytes = std::max(slab_bytes, bytes); }
-	template <class T> int get(size_t n, T **dst, bool zero = false) {
-		const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t) 255;
-		if(bytes > slab_left) {
-			const size_t want = std::max(bytes, slab_bytes);
-			void *d = nullptr;
-			if(hipMalloc(&d, want) != hipSuccess) {
-				// (a smaller slab may still fit)
-				if(want == bytes || hipMalloc(&d, bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
-				owned.push_back(d);
-				if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
-				*dst = (T *) d;
-				return KMAHIP_OK;
-			}
-			owned.push_back(d);
-			slab = (char *) d; slab_left = want;
-		}
-		void *d = slab;
-		slab += bytes; slab_left -= bytes;
-		if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
-		*dst = (T *) d;
-		return KMAHIP_OK;
-	}
-	template <class T> int up(const T *src, size_t n, size_t pad, const T **dst) {
-		T *d = nullptr;
-		int rc = get(n + pad, &d);
-		if(rc) return rc;
-		if(pad && hipMemsetAsync(d + n, 0, pad * sizeof(T), 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
-		if(n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { kmahip_set_error("hipMemcpy failed"); return KMAHIP_EDEVICE; }
-		*dst = d;
-		return KMAHIP_OK;
-	}
-};
-
-double since(std::chrono::steady_clock::time_point &t) {
-	const auto now = std::chrono::steady_clock::now();
-	const double ms = std::chrono::duration<double, std::milli>(now - t).count();
-	t = now;
-	return ms;
-}
-
-// Host buffers for the per-read / per-fragment columns a run brings back: fresh from malloc their pages do not exist yet, and a copy
-// that has to fault them in one by one runs at half speed. A thread writes every page once (an atomic OR of zero: it changes nothing,
-// whatever has been copied there already) while the device is busy with the stages before the copy.
-struct HostCols {
-	std::vector<std::pair<char *, size_t>> bufs;
-	std::thread th;
-	template <class T> T *get(size_t n) {
-		T *p = (T *) malloc((n ? n : 1) * sizeof(T));
-		if(p) bufs.push_back({(char *) p, n * sizeof(T)});
-		return p;
-	}
-	void start() {
-		th = std::thread([this] { for(auto &b : bufs) for(size_t i = 0; i < b.second; i += 4096) __atomic_fetch_or(&b.first[i], 0, __ATOMIC_RELAXED); });
-	}
-	void wait() { if(th.joinable()) th.join(); }
-	~HostCols() { wait(); for(auto &b : bufs) free(b.first); }
-};
-
-// status word of the workspace after a synchronised stage (and the first counter, the pool / run top)
-int ws_status(kmahip_ws *ws, unsigned long long *c0) {
-	unsigned long long c[2];
-	if(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-	if(c[1]) (void) hipMemset(ws->counters + 1, 0, sizeof(unsigned long long));
-	if(c0) *c0 = c[0];
-	return (int) c[1];
-}
-
-// a read full of repeats can carry more MEMs against a template than the scratch holds slots for (64 for reads up to 1 kb;
-// status 3 from stage 3a, 16 from the traceback): the capacity goes up fourfold and the stage is run again
-bool grow_mem_cap(kmahip_ws *ws) {
-	const int cur = ws->mem_scale > 0 ? ws->mem_scale : 1;
-	if(cur >= 64) return false;
-	ws->mem_scale = cur * 4;
-	if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] seed (MEM) capacity per read and template raised to %d x the usual\n", ws->mem_scale);
-	return true;
-}
-
-}  // namespace
 
 // everything behind stage 2 on a batch that is in HBM with its candidate lists: stage 3a, ConClave + the `.res` statistics, the
 // traceback, the pile-up. per_read: host arrays for the columns a `.frag` writer needs (any may be NULL).
@@ -241,20 +147,6 @@ int kmahip_frag_write_src(const char *path, kmahip_db *db, const kmahip_reads *r
                           const int64_t *frag_rank, const char *read_names, const int64_t *read_name_off, int64_t *rows);      // fragout.hip
 
 namespace {
-
-int scan_i64(DevBlock &B, const int64_t *in, int64_t *out, size_t n, hipStream_t s) {
-	size_t tmp_bytes = 0;
-	if(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
-		kmahip_set_error("rocprim::exclusive_scan (size query) failed"); return KMAHIP_EDEVICE;
-	}
-	char *tmp = nullptr;
-	int rc = B.get(tmp_bytes, &tmp);
-	if(rc) return rc;
-	if(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
-		kmahip_set_error("rocprim::exclusive_scan failed"); return KMAHIP_EDEVICE;
-	}
-	return KMAHIP_OK;
-}
 
 // reads idx[0 .. m) of a batch in HBM as a batch of its own (each read followed by one pad word, like the source)
 __global__ __launch_bounds__(256) void gather_sizes_kernel(int64_t m, const int64_t *idx, const int32_t *len, const int64_t *N_off, int64_t *words, int64_t *n_N) {
@@ -1111,6 +1003,39 @@ int concat_parts(const std::string &prefix, const char *ext, int world, const ch
 
 }  // namespace
 
+// The rows of `.res` (runkma.c:792-809) and the entries of the consensus FASTA (printConsensus, printconsensus.c:38-60: the
+// consensus line without its '-' columns, 60 per line) for the significant templates -- all of them, or those `owner` gives to
+// `rank`. fsa_path NULL: no consensus file (-nc).
+int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_path, bool header, const kmahip_res_row *rows, int64_t n_rows,
+                         const int32_t *owner, int rank, const int64_t *cover, const int64_t *aln_len, const int64_t *depth, const char *cons,
+                         const int64_t *cons_off, double ID_t, double Depth_t) {
+	int rc = kmahip_db_load_names(db);
+	if(rc) return rc;
+	FILE *res = fopen(res_path, "w"), *fsa = fsa_path ? fopen(fsa_path, "w") : nullptr;
+	if(!res || (fsa_path && !fsa)) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create %s", res ? fsa_path : res_path); return KMAHIP_EIO; }
+	if(header) fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
+	std::vector<char> line((1 << 16) + 512);
+	std::string entry;
+	for(int64_t r = 0; r < n_rows; ++r) {
+		const kmahip_res_row &row = rows[r];
+		const size_t tt = (size_t) row.template_id;
+		if((owner && owner[tt] != rank) || !row.significant || tt - 1 >= db->h_names.size()) continue;
+		const std::string &name = db->h_names[tt - 1];
+		if(!kmahip_res_line(name.c_str(), &row, cover[tt], aln_len[tt], depth[tt], ID_t, Depth_t, line.data(), (int64_t) line.size())) continue;
+		fputs(line.data(), res);
+		if(!fsa) continue;
+		entry.clear();
+		entry += ">"; entry += name; entry += "\n";
+		int col = 0;
+		for(const char *q = cons_off[tt] >= 0 ? cons + cons_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
+		if(col) entry.push_back('\n');
+		fwrite(entry.data(), 1, entry.size(), fsa);
+	}
+	const bool bad = fclose(res) != 0;
+	if((fsa && fclose(fsa) != 0) || bad) { kmahip_set_error("write to %s failed", res_path); return KMAHIP_EIO; }
+	return KMAHIP_OK;
+}
+
 // Exchange 3 and everything behind it, for single-end and paired runs alike. `d`: the rank's n items in HBM (reads, or the filed
 // fragments of a paired run) in the order of its part of the stream; tmpl (0: not filed), rc, n_hits, frag_rank (position among the
 // filed fragments of the WHOLE stream, chunk arithmetic of the caller included) and the traces are per item, DEVICE pointers;
@@ -1279,28 +1204,8 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 
 	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
 	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
-	{
-		FILE *res = fopen((part + ".res").c_str(), "w"), *fsa = fopen((part + ".fsa").c_str(), "w");
-		if(!res || !fsa) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create the output parts of %s", out_prefix); return KMAHIP_EIO; }
-		std::vector<char> line((1 << 16) + 512);
-		std::string entry;
-		for(int64_t r = 0; r < n_rows; ++r) {
-			const kmahip_res_row &row = rows[r];
-			const size_t tt = (size_t) row.template_id;
-			if(owner[tt] != rank || !row.significant || tt - 1 >= db->h_names.size()) continue;
-			const std::string &name = db->h_names[tt - 1];
-			if(!kmahip_res_line(name.c_str(), &row, a_cover[tt], a_len[tt], a_depth[tt], opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, line.data(), (int64_t) line.size())) continue;
-			fputs(line.data(), res);
-			// printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line
-			entry.clear();
-			entry += ">"; entry += name; entry += "\n";
-			int col = 0;
-			for(const char *q = c_off[tt] >= 0 ? cons.data() + c_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
-			if(col) entry.push_back('\n');
-			fwrite(entry.data(), 1, entry.size(), fsa);
-		}
-		if(fclose(res) != 0 || fclose(fsa) != 0) { kmahip_set_error("write to the output parts of %s failed", out_prefix); return KMAHIP_EIO; }
-	}
+	if((rc = kmahip_write_res_fsa(db, (part + ".res").c_str(), (part + ".fsa").c_str(), false, rows, n_rows, owner.data(), rank, a_cover.data(), a_len.data(), a_depth.data(),
+	                              cons.data(), c_off.data(), opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t))) return rc;
 	{
 		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
 		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);

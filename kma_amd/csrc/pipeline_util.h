@@ -1,0 +1,115 @@
+// pipeline_util.h -- what the one-call runs (pipeline.hip) and the batched session (session.hip) share: device buffers carved out
+// of slabs, the workspace's status word, an exclusive scan, the seed capacity that grows on demand.
+#pragma once
+#include "kmahip_internal.h"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// Device buffers of one run, carved out of a few large allocations (a hipMalloc per array cost more than ConClave itself:
+// thirty of them per run). Everything is released when the run ends.
+struct DevBlock {
+	std::vector<void *> owned;
+	char *slab = nullptr;
+	size_t slab_left = 0, slab_bytes = 256u << 20;
+	~DevBlock() { for(void *p : owned) (void) hipFree(p); }
+	void expect(size_t bytes) { slab_bytes = std::max(slab_bytes, bytes); }
+	template <class T> int get(size_t n, T **dst, bool zero = false) {
+		const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t) 255;
+		if(bytes > slab_left) {
+			const size_t want = std::max(bytes, slab_bytes);
+			void *d = nullptr;
+			if(hipMalloc(&d, want) != hipSuccess) {
+				// (a smaller slab may still fit)
+				if(want == bytes || hipMalloc(&d, bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+				owned.push_back(d);
+				if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+				*dst = (T *) d;
+				return KMAHIP_OK;
+			}
+			owned.push_back(d);
+			slab = (char *) d; slab_left = want;
+		}
+		void *d = slab;
+		slab += bytes; slab_left -= bytes;
+		if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+		*dst = (T *) d;
+		return KMAHIP_OK;
+	}
+	template <class T> int up(const T *src, size_t n, size_t pad, const T **dst) {
+		T *d = nullptr;
+		int rc = get(n + pad, &d);
+		if(rc) return rc;
+		if(pad && hipMemsetAsync(d + n, 0, pad * sizeof(T), 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+		if(n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { kmahip_set_error("hipMemcpy failed"); return KMAHIP_EDEVICE; }
+		*dst = d;
+		return KMAHIP_OK;
+	}
+};
+
+double since(std::chrono::steady_clock::time_point &t) {
+	const auto now = std::chrono::steady_clock::now();
+	const double ms = std::chrono::duration<double, std::milli>(now - t).count();
+	t = now;
+	return ms;
+}
+
+// Host buffers for the per-read / per-fragment columns a run brings back: fresh from malloc their pages do not exist yet, and a copy
+// that has to fault them in one by one runs at half speed. A thread writes every page once (an atomic OR of zero: it changes nothing,
+// whatever has been copied there already) while the device is busy with the stages before the copy.
+struct HostCols {
+	std::vector<std::pair<char *, size_t>> bufs;
+	std::thread th;
+	template <class T> T *get(size_t n) {
+		T *p = (T *) malloc((n ? n : 1) * sizeof(T));
+		if(p) bufs.push_back({(char *) p, n * sizeof(T)});
+		return p;
+	}
+	void start() {
+		th = std::thread([this] { for(auto &b : bufs) for(size_t i = 0; i < b.second; i += 4096) __atomic_fetch_or(&b.first[i], 0, __ATOMIC_RELAXED); });
+	}
+	void wait() { if(th.joinable()) th.join(); }
+	~HostCols() { wait(); for(auto &b : bufs) free(b.first); }
+};
+
+// status word of the workspace after a synchronised stage (and the first counter, the pool / run top)
+int ws_status(kmahip_ws *ws, unsigned long long *c0) {
+	unsigned long long c[2];
+	if(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if(c[1]) (void) hipMemset(ws->counters + 1, 0, sizeof(unsigned long long));
+	if(c0) *c0 = c[0];
+	return (int) c[1];
+}
+
+// a read full of repeats can carry more MEMs against a template than the scratch holds slots for (64 for reads up to 1 kb;
+// status 3 from stage 3a, 16 from the traceback): the capacity goes up fourfold and the stage is run again
+bool grow_mem_cap(kmahip_ws *ws) {
+	const int cur = ws->mem_scale > 0 ? ws->mem_scale : 1;
+	if(cur >= 64) return false;
+	ws->mem_scale = cur * 4;
+	if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] seed (MEM) capacity per read and template raised to %d x the usual\n", ws->mem_scale);
+	return true;
+}
+
+
+int scan_i64(DevBlock &B, const int64_t *in, int64_t *out, size_t n, hipStream_t s) {
+	size_t tmp_bytes = 0;
+	if(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
+		kmahip_set_error("rocprim::exclusive_scan (size query) failed"); return KMAHIP_EDEVICE;
+	}
+	char *tmp = nullptr;
+	int rc = B.get(tmp_bytes, &tmp);
+	if(rc) return rc;
+	if(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t) 0, n, rocprim::plus<int64_t>(), s) != hipSuccess) {
+		kmahip_set_error("rocprim::exclusive_scan failed"); return KMAHIP_EDEVICE;
+	}
+	return KMAHIP_OK;
+}
+
+
+}  // namespace

@@ -1,0 +1,537 @@
+// session.hip -- the single-end `-1t1` run fed batch by batch (kmahip.h: kmahip_session_*): what runKMA does between its input stream
+// and its output files (runkma.c:104-900) for an input that arrives in pieces, with the host holding one piece at a time.
+//
+// The reference streams: stage 1 writes records into a pipe, stage 2 and 3a take them as they come and spill frag_raw records to a
+// temporary file (updatescores.c:283-295, tmp.c:27), ConClave and the assembly read that file back once the input has ended
+// (runkma.c:563-594, 757-863). Here HBM is the temporary file:
+//   add     a batch of stage-1 records goes up ONCE -- packed reads, N positions, headers -- behind what is there already (arrays
+//           that grow by doubling), stages 2 and 3a run on it and add into the two ConClave vectors; the host's copy can go;
+//   finish  ConClave per batch on the finished vectors, the `.res` statistics, the traceback per batch, one pile-up + consensus
+//           over everything, and the fragment rows: ordered, measured and FORMATTED on the device (the reads and headers are
+//           there), brought back as text a chunk at a time and compressed by the host's threads while the next chunk is made.
+// Host memory is bounded by a batch and a few text chunks whatever the input's size; stage 1 of the next batch runs beside the
+// device work of this one when the caller reads ahead on a thread of its own (examples/kmahip_map.c).
+#include "pipeline_util.h"
+#include <atomic>
+#include <string>
+
+struct kmahip_gzstream;
+kmahip_gzstream *kmahip_gzstream_open(const char *path);                                                        // fragout.hip
+void kmahip_gzstream_submit(kmahip_gzstream *g, const char *text, size_t bytes, std::atomic<int> *done);
+int kmahip_gzstream_close(kmahip_gzstream *g);
+int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_path, bool header, const kmahip_res_row *rows, int64_t n_rows,
+                         const int32_t *owner, int rank, const int64_t *cover, const int64_t *aln_len, const int64_t *depth, const char *cons,
+                         const int64_t *cons_off, double ID_t, double Depth_t);                                    // pipeline.hip
+
+namespace {
+
+// a device array that grows by doubling (what it holds is copied over)
+struct DevArr {
+	char *p = nullptr;
+	size_t cap = 0;
+	~DevArr() { if(p) (void) hipFree(p); }
+	int ensure(size_t need, size_t used, hipStream_t s) {
+		if(need <= cap) return KMAHIP_OK;
+		const size_t want = std::max(need, cap * 2);
+		char *q = nullptr;
+		if(hipMalloc((void **) &q, want) != hipSuccess && (want == need || hipMalloc((void **) &q, need) != hipSuccess)) { kmahip_set_error("hipMalloc of %zu bytes failed", need); return KMAHIP_ENOMEM; }
+		if(used && hipMemcpyAsync(q, p, used, hipMemcpyDeviceToDevice, s) != hipSuccess) { (void) hipFree(q); kmahip_set_error("device copy failed"); return KMAHIP_EDEVICE; }
+		if(hipStreamSynchronize(s) != hipSuccess) { (void) hipFree(q); kmahip_set_error("device copy failed"); return KMAHIP_EDEVICE; }
+		if(p) (void) hipFree(p);
+		p = q; cap = want;
+		return KMAHIP_OK;
+	}
+	template <class T> T *as() const { return (T *) p; }
+};
+
+struct Batch {
+	int64_t r0 = 0, n = 0, total = 0;
+	int max_len = 0;
+	kmahip_cands c{};
+	kmahip_hits h{};
+	std::vector<void *> owned;
+	void release() { for(void *q : owned) (void) hipFree(q); owned.clear(); }
+};
+
+template <class T> int dev_new(std::vector<void *> &owned, size_t n, T **out, bool zero, hipStream_t s) {
+	void *d = nullptr;
+	const size_t bytes = (n ? n : 1) * sizeof(T);
+	if(hipMalloc(&d, bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+	owned.push_back(d);
+	if(zero && hipMemsetAsync(d, 0, bytes, s) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
+	*out = (T *) d;
+	return KMAHIP_OK;
+}
+
+__global__ __launch_bounds__(256) void add_u64_kernel(int64_t n, const unsigned long long *a, unsigned long long *b) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n && a[i]) b[i] += a[i];
+}
+__global__ __launch_bounds__(256) void add_off_kernel(int64_t n, int64_t *v, int64_t base) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) v[i] += base;
+}
+
+// ---- the fragment rows on the device (updateFrags, assembly.c:49-83; the host form is fragout.hip) -------------------------------
+// filed: ConClave gave the read a template; kept: it also passed the stage-3c filter and gets a row
+__global__ __launch_bounds__(256) void row_flags_kernel(int64_t n, const int32_t *tmpl, const int32_t *stats, int64_t *filed, int64_t *kept) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > n) return;
+	const bool f = i < n && tmpl[i] != 0;
+	filed[i] = f; kept[i] = f && stats[10 * i + 3] != 0;
+}
+// the order assemble_KMA meets the fragments in: templates ascending; inside a template the chunks of max_frag filed fragments in
+// stream order, each chunk back to front (conclave.c:164-166, 194)
+__global__ __launch_bounds__(256) void row_keys_kernel(int64_t n, const int32_t *tmpl, const int64_t *kept, const int64_t *rank, int64_t max_frag, unsigned long long *keys, int64_t *vals) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	vals[i] = i;
+	if(!(kept[i + 1] - kept[i])) { keys[i] = ~0ull; return; }
+	const unsigned long long rk = (unsigned long long) rank[i], chunk = rk / (unsigned long long) max_frag, in = rk % (unsigned long long) max_frag;
+	keys[i] = ((unsigned long long) abs(tmpl[i]) << 40) | (chunk * (unsigned long long) max_frag + ((unsigned long long) max_frag - 1ull - in));
+}
+
+struct RowArgs {
+	const uint64_t *seq;
+	const int64_t *seq_off, *N_off, *name_off;
+	const int32_t *len, *N, *rc, *tmpl, *n_hits, *stats;
+	const char *names, *tnames;
+	const int64_t *tname_off;
+	const int64_t *row_read;
+	int64_t *row_off;
+};
+__device__ __forceinline__ int digits_of(int v) {
+	unsigned u = v < 0 ? 0u - (unsigned) v : (unsigned) v;
+	int d = v < 0 ? 2 : 1;
+	while(u >= 10u) { u /= 10u; ++d; }
+	return d;
+}
+__global__ __launch_bounds__(256) void row_len_kernel(const RowArgs A, int64_t n_rows) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r > n_rows) return;
+	if(r == n_rows) { A.row_off[r] = 0; return; }
+	const int64_t i = A.row_read[r];
+	const int t = abs(A.tmpl[i]);
+	const int32_t *st = A.stats + 10 * i;
+	// bases, "\t<ties>\t<score>\t<start>\t<end>\t<template>\t<header>\n"
+	A.row_off[r] = (int64_t) A.len[i] + 4 + digits_of(A.n_hits[i]) + digits_of(st[0]) + digits_of(st[1]) + digits_of(st[2]) + 1 + (A.tname_off[t] - A.tname_off[t - 1]) + 1 +
+	               (A.name_off[i + 1] - A.name_off[i] - 1) + 1;
+}
+__device__ __forceinline__ char *put_int_dev(char *o, int v) {
+	*o++ = '\t';
+	unsigned u = v < 0 ? 0u - (unsigned) v : (unsigned) v;
+	if(v < 0) *o++ = '-';
+	char d[12];
+	int k = 0;
+	do { d[k++] = (char) ('0' + u % 10u); u /= 10u; } while(u);
+	while(k) *o++ = d[--k];
+	return o;
+}
+// one thread per row: the read as it was aligned (reverse complemented when it was filed on the minus strand), four bases per
+// 32-bit store; N's; the figures; the two names
+__global__ __launch_bounds__(256) void row_format_kernel(const RowArgs A, int64_t r0, int64_t r1, int64_t text_base, char *text) {
+	const int64_t r = r0 + (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= r1) return;
+	const int64_t i = A.row_read[r];
+	char *o = text + (A.row_off[r] - text_base);
+	const int L = A.len[i];
+	const uint64_t *w = A.seq + A.seq_off[i];
+	const int tt = A.tmpl[i];
+	const bool flip = ((A.rc[i] & 1) != 0) != (tt < 0);
+	const uint32_t lut = 0x54474341u;          // 'A' 'C' 'G' 'T', low byte first
+	for(int b = 0; b < L; b += 4) {
+		uint32_t four = 0;
+#pragma unroll
+		for(int x = 0; x < 4; ++x) {
+			const int pos = b + x;
+			int code = 0;
+			if(pos < L) {
+				const int src = flip ? L - 1 - pos : pos;
+				code = (int) ((w[src >> 5] >> (62 - ((src & 31) << 1))) & 3ull);
+				if(flip) code = 3 - code;
+			}
+			four |= ((lut >> (8 * code)) & 0xFFu) << (8 * x);
+		}
+		if(b + 4 <= L) memcpy(o + b, &four, 4);          // (unaligned: rows begin anywhere)
+		else for(int x = 0; b + x < L; ++x) o[b + x] = (char) ((four >> (8 * x)) & 0xFFu);
+	}
+	const int32_t *Np = A.N + A.N_off[i];
+	const int nN = (int) (A.N_off[i + 1] - A.N_off[i]);
+	for(int x = 0; x < nN; ++x) o[flip ? L - 1 - Np[x] : Np[x]] = 'N';
+	o += L;
+	const int32_t *st = A.stats + 10 * i;
+	o = put_int_dev(o, A.n_hits[i]); o = put_int_dev(o, st[0]); o = put_int_dev(o, st[1]); o = put_int_dev(o, st[2]);
+	*o++ = '\t';
+	const int t = abs(tt);
+	for(int64_t x = A.tname_off[t - 1]; x < A.tname_off[t]; ++x) *o++ = A.tnames[x];
+	*o++ = '\t';
+	for(int64_t x = A.name_off[i]; x < A.name_off[i + 1] - 1; ++x) *o++ = A.names[x];
+	*o++ = '\n';
+}
+__global__ __launch_bounds__(256) void row_blocks_kernel(int64_t n_blocks, int64_t rows_per_block, int64_t n_rows, const int64_t *row_off, int64_t *block_off) {
+	const int64_t b = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(b <= n_blocks) block_off[b] = row_off[b * rows_per_block < n_rows ? b * rows_per_block : n_rows];
+}
+
+}  // namespace
+
+struct kmahip_session {
+	kmahip_db *db = nullptr;
+	kmahip_ws *ws = nullptr;
+	kmahip_params par{};
+	kmahip_shard_opts opts{};
+	DevArr seq, seq_off, len, N, N_off, names, name_off;
+	int64_t n = 0, words = 0, nN = 0, name_bytes = 0;
+	int max_len = 0;
+	uint64_t *AS = nullptr, *AS_batch = nullptr;          // 2 D each: alignment_scores | uniq_alignment_scores
+	std::vector<Batch> batches, uploaded;          // mapped / uploaded and waiting for kmahip_session_map
+	// the text chunks of the fragment rows: pinned host buffers, made when the session opens (pinning 64 MB takes ~10 ms: paid beside
+	// stage 1 instead of in front of the writer)
+	static constexpr int NBUF = 3;
+	char *h_text[NBUF] = {nullptr, nullptr, nullptr};
+	int64_t text_chunk = 0;
+	double ms_upload = 0, ms_map = 0;
+	~kmahip_session() {
+		for(Batch &b : batches) b.release();
+		for(Batch &b : uploaded) b.release();
+		if(AS) (void) hipFree(AS);
+		if(AS_batch) (void) hipFree(AS_batch);
+		for(int x = 0; x < NBUF; ++x) if(h_text[x]) (void) hipHostFree(h_text[x]);
+	}
+};
+
+extern "C" int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_params *p, const kmahip_shard_opts *opts, int64_t reads_hint, kmahip_session **out) {
+	if(!db || !ws || !p || !opts || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	kmahip_session *S = new kmahip_session();
+	S->db = db; S->ws = ws; S->par = *p; S->opts = *opts;
+	const size_t D = db->info.DB_size;
+	if(hipMalloc((void **) &S->AS, 2 * D * 8) != hipSuccess || hipMalloc((void **) &S->AS_batch, 2 * D * 8) != hipSuccess || hipMemset(S->AS, 0, 2 * D * 8) != hipSuccess) {
+		delete S; kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM;
+	}
+	// (room for the hinted number of reads of ~150 bases up front: no copies while the arrays grow)
+	if(reads_hint > 0) {
+		const size_t r = (size_t) reads_hint + (size_t) reads_hint / 16 + 1024;
+		int rc;
+		if((rc = S->seq.ensure(r * 6 * 8, 0, 0)) || (rc = S->seq_off.ensure((r + 1) * 8, 0, 0)) || (rc = S->len.ensure((r + 1) * 4, 0, 0)) || (rc = S->N_off.ensure((r + 1) * 8, 0, 0)) ||
+		   (rc = S->name_off.ensure((r + 1) * 8, 0, 0)) || (rc = S->names.ensure(r * 12, 0, 0))) { delete S; return rc; }
+	}
+	S->text_chunk = getenv("KMAHIP_FRAG_CHUNK") ? std::max<int64_t>(1024, atoll(getenv("KMAHIP_FRAG_CHUNK"))) : (64ll << 20);
+	for(int x = 0; x < kmahip_session::NBUF; ++x) if(hipHostMalloc((void **) &S->h_text[x], (size_t) S->text_chunk + 16, hipHostMallocDefault) != hipSuccess) { S->h_text[x] = nullptr; delete S; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
+	*out = S;
+	return KMAHIP_OK;
+}
+
+extern "C" void kmahip_session_close(kmahip_session *S) { delete S; }
+
+// One batch of stage-1 records, first half: uploaded behind the batches before it. The caller's arrays are free when this returns
+// (a reader thread may go on to the next batch while kmahip_session_map works on this one).
+extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch *batch) {
+	if(!S || !batch) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const kmahip_reads &R = batch->reads;
+	const int64_t nb = R.n_reads;
+	if(nb < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(nb == 0) return KMAHIP_OK;
+	if(!batch->names || !batch->name_off) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	hipStream_t s = 0;
+	kmahip_db *db = S->db;
+	kmahip_ws *ws = S->ws;
+	const size_t D = db->info.DB_size;
+	auto t = std::chrono::steady_clock::now();
+	int rc;
+	const int64_t nbytes = batch->name_off[nb];
+	if((rc = S->seq.ensure((size_t) (S->words + R.seq_words + 2) * 8, (size_t) S->words * 8, s)) || (rc = S->seq_off.ensure((size_t) (S->n + nb + 1) * 8, (size_t) (S->n + 1) * 8, s)) ||
+	   (rc = S->len.ensure((size_t) (S->n + nb + 1) * 4, (size_t) S->n * 4, s)) || (rc = S->N.ensure((size_t) (S->nN + R.N_total + 1) * 4, (size_t) S->nN * 4, s)) ||
+	   (rc = S->N_off.ensure((size_t) (S->n + nb + 1) * 8, (size_t) (S->n + 1) * 8, s)) || (rc = S->names.ensure((size_t) (S->name_bytes + nbytes + 1), (size_t) S->name_bytes, s)) ||
+	   (rc = S->name_off.ensure((size_t) (S->n + nb + 1) * 8, (size_t) (S->n + 1) * 8, s))) return rc;
+	if(R.seq_words) HIP_TRY(hipMemcpyAsync(S->seq.as<uint64_t>() + S->words, R.seq, (size_t) R.seq_words * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(S->seq.as<uint64_t>() + S->words + R.seq_words, 0, 16, s));
+	HIP_TRY(hipMemcpyAsync(S->len.as<int32_t>() + S->n, R.len, (size_t) nb * 4, hipMemcpyHostToDevice, s));
+	if(R.N_total) HIP_TRY(hipMemcpyAsync(S->N.as<int32_t>() + S->nN, R.N, (size_t) R.N_total * 4, hipMemcpyHostToDevice, s));
+	if(nbytes) HIP_TRY(hipMemcpyAsync(S->names.as<char>() + S->name_bytes, batch->names, (size_t) nbytes, hipMemcpyHostToDevice, s));
+	// the three offset arrays go up as they are and are moved behind what is there on the device
+	HIP_TRY(hipMemcpyAsync(S->seq_off.as<int64_t>() + S->n, R.seq_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(S->N_off.as<int64_t>() + S->n, R.N_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemcpyAsync(S->name_off.as<int64_t>() + S->n, batch->name_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+	const unsigned g1 = (unsigned) ((nb + 1 + 255) / 256);
+	if(S->words) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, nb + 1, S->seq_off.as<int64_t>() + S->n, S->words);
+	if(S->nN) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, nb + 1, S->N_off.as<int64_t>() + S->n, S->nN);
+	if(S->name_bytes) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, nb + 1, S->name_off.as<int64_t>() + S->n, S->name_bytes);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));          // (the host arrays are the caller's again)
+	S->ms_upload += since(t);
+	Batch U;
+	U.r0 = S->n; U.n = nb; U.max_len = R.max_len;
+	S->uploaded.push_back(std::move(U));
+	S->n += nb; S->words += R.seq_words; S->nN += R.N_total; S->name_bytes += nbytes;
+	S->max_len = std::max(S->max_len, R.max_len);
+	return KMAHIP_OK;
+}
+
+static int session_map_one(kmahip_session *S, Batch &B);
+
+// ... second half: stages 2 and 3a on every batch that has been uploaded and not mapped yet
+extern "C" int kmahip_session_map(kmahip_session *S) {
+	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	while(!S->uploaded.empty()) {
+		Batch B = std::move(S->uploaded.front());
+		S->uploaded.erase(S->uploaded.begin());
+		const int rc = session_map_one(S, B);
+		if(rc) return rc;
+	}
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_session_add(kmahip_session *S, const kmahip_read_batch *batch) {
+	const int rc = kmahip_session_upload(S, batch);
+	return rc ? rc : kmahip_session_map(S);
+}
+
+static int session_map_one(kmahip_session *S, Batch &B) {
+	hipStream_t s = 0;
+	kmahip_db *db = S->db;
+	kmahip_ws *ws = S->ws;
+	const size_t D = db->info.DB_size;
+	const int64_t nb = B.n;
+	auto t = std::chrono::steady_clock::now();
+	int rc;
+	kmahip_reads d{};
+	d.n_reads = nb; d.seq = S->seq.as<uint64_t>(); d.seq_off = S->seq_off.as<int64_t>() + B.r0; d.len = S->len.as<int32_t>() + B.r0; d.N = S->N.as<int32_t>();
+	d.N_off = S->N_off.as<int64_t>() + B.r0; d.seq_words = S->words; d.N_total = S->nN; d.max_len = B.max_len;
+	// stage 2 (the candidate lists have no bound known in advance: two per read, redone with the exact size if short)
+	if((rc = dev_new(B.owned, (size_t) nb + 1, &B.c.rc_flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.T_off, true, s))) { B.release(); return rc; }
+	B.c.T_cap = 2 * nb + 4096;
+	for(int attempt = 0;; ++attempt) {
+		if((rc = dev_new(B.owned, (size_t) B.c.T_cap, &B.c.T, false, s)) || (rc = kmahip_launch_scan_se(db, ws, &d, &S->par, &B.c, s))) { B.release(); return rc; }
+		if(hipStreamSynchronize(s) != hipSuccess) { B.release(); kmahip_set_error("stage 2 failed"); return KMAHIP_EDEVICE; }
+		if(ws_status(ws, nullptr) == 1) {
+			if(attempt >= 4) { B.release(); kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;
+			continue;
+		}
+		if(hipMemcpy(&B.total, B.c.T_off + nb, 8, hipMemcpyDeviceToHost) != hipSuccess) { B.release(); kmahip_set_error("hipMemcpy failed"); return KMAHIP_EDEVICE; }
+		if(B.total <= B.c.T_cap) break;
+		if(attempt >= 6) { B.release(); kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
+		B.c.T_cap = B.total + 1024;
+	}
+	// stage 3a into vectors of the batch's own (a run that has to be repeated with more room for seeds starts them afresh), then added
+	kmahip_hits &h = B.h;
+	if((rc = dev_new(B.owned, (size_t) nb + 1, &h.n_hits, true, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &h.best_score, true, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &h.flag, true, s)) ||
+	   (rc = dev_new(B.owned, (size_t) nb + 1, &h.rc, true, s)) || (rc = dev_new(B.owned, (size_t) B.total + 1, &h.tmpl, true, s)) || (rc = dev_new(B.owned, (size_t) B.total + 1, &h.score, true, s)) ||
+	   (rc = dev_new(B.owned, (size_t) B.total + 1, &h.start, true, s)) || (rc = dev_new(B.owned, (size_t) B.total + 1, &h.end, true, s))) { B.release(); return rc; }
+	h.alignment_scores = S->AS_batch; h.uniq_alignment_scores = S->AS_batch + D;
+	for(;;) {
+		if(hipMemsetAsync(S->AS_batch, 0, 2 * D * 8, s) != hipSuccess || (rc = kmahip_launch_align_se(db, ws, &d, &B.c, &S->par, &h, s))) { B.release(); return rc ? rc : KMAHIP_EDEVICE; }
+		if(hipStreamSynchronize(s) != hipSuccess) { B.release(); kmahip_set_error("stage 3a failed"); return KMAHIP_EDEVICE; }
+		if(ws_status(ws, nullptr) != 3) break;
+		if(!grow_mem_cap(ws)) { B.release(); kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }
+	}
+	hipLaunchKernelGGL(add_u64_kernel, dim3((unsigned) ((2 * D + 255) / 256)), dim3(256), 0, s, (int64_t) (2 * D), (const unsigned long long *) S->AS_batch, (unsigned long long *) S->AS);
+	if(hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { B.release(); kmahip_set_error("stage 3a failed"); return KMAHIP_EDEVICE; }
+	h.alignment_scores = S->AS; h.uniq_alignment_scores = S->AS + D;
+	const int64_t first_reads = S->batches.empty() ? B.n : 0;
+	const int first_len = B.max_len;
+	S->batches.push_back(std::move(B));
+	// (what the finish needs once per process -- the traceback's scratch: gigabytes -- is made now, beside stage 1 of the next batch)
+	if(first_reads && (rc = kmahip_trace_reserve(ws, first_len, std::max<int64_t>(first_reads, 262144)))) return rc;
+	S->ms_map += since(t);
+	return KMAHIP_OK;
+}
+
+// ConClave, statistics, traceback, pile-up, consensus and the three files. ms[8]: uploads (summed over the batches), stages 2 + 3a
+// (summed), ConClave + statistics, traceback, pile-up + consensus, .res + .fsa, fragment rows, (unused).
+extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, int write_fsa, int write_frag, int64_t *n_reads, int64_t *n_rows_out, double ms[8]) {
+	if(!S || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	kmahip_db *db = S->db;
+	kmahip_ws *ws = S->ws;
+	const kmahip_params *p = &S->par;
+	const size_t D = db->info.DB_size;
+	const int64_t n = S->n;
+	const int64_t mf = S->opts.max_frag > 0 ? S->opts.max_frag : 1000000;
+	hipStream_t s = 0;
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	ms[0] = S->ms_upload; ms[1] = S->ms_map;
+	if(n_reads) *n_reads = n;
+	if(n_rows_out) *n_rows_out = 0;
+	auto t = std::chrono::steady_clock::now();
+	int rc;
+	if((rc = kmahip_session_map(S))) return rc;
+	ms[1] = S->ms_map;
+	if((rc = kmahip_db_load_names(db))) return rc;
+	DevBlock B;
+	B.expect((size_t) n * 120 + (64u << 20));
+	// (the arrays are read one element past the end by some kernels: make sure those exist when nothing was ever added)
+	if((rc = S->seq.ensure(16, 0, s)) || (rc = S->seq_off.ensure(16, 0, s)) || (rc = S->len.ensure(8, 0, s)) || (rc = S->N.ensure(8, 0, s)) || (rc = S->N_off.ensure(16, 0, s)) ||
+	   (rc = S->names.ensure(8, 0, s)) || (rc = S->name_off.ensure(16, 0, s))) return rc;
+	if(n == 0) { HIP_TRY(hipMemsetAsync(S->seq_off.p, 0, 16, s)); HIP_TRY(hipMemsetAsync(S->N_off.p, 0, 16, s)); HIP_TRY(hipMemsetAsync(S->name_off.p, 0, 16, s)); }
+	kmahip_reads W{};
+	W.n_reads = n; W.seq = S->seq.as<uint64_t>(); W.seq_off = S->seq_off.as<int64_t>(); W.len = S->len.as<int32_t>(); W.N = S->N.as<int32_t>(); W.N_off = S->N_off.as<int64_t>();
+	W.seq_words = S->words; W.N_total = S->nN; W.max_len = S->max_len;
+
+	// stage 3b per batch on the finished vectors, the `.res` statistics
+	kmahip_conclave cc{};
+	int32_t *rc_all = nullptr, *nh_all = nullptr;
+	if((rc = B.get((size_t) n + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n + 1, &cc.start, true)) || (rc = B.get((size_t) n + 1, &cc.end, true)) || (rc = B.get(D, &cc.w_scores, true)) ||
+	   (rc = B.get((size_t) n + 1, &rc_all, true)) || (rc = B.get((size_t) n + 1, &nh_all, true))) return rc;
+	for(Batch &b : S->batches) {
+		kmahip_reads d = W;
+		d.n_reads = b.n; d.seq_off = W.seq_off + b.r0; d.len = W.len + b.r0; d.N_off = W.N_off + b.r0; d.max_len = b.max_len;
+		kmahip_conclave cb = cc;
+		cb.tmpl = cc.tmpl + b.r0; cb.start = cc.start + b.r0; cb.end = cc.end + b.r0;
+		if((rc = kmahip_conclave_se_dev(db, ws, &d, &b.c, &b.h, &cb, s))) return rc;
+		HIP_TRY(hipMemcpyAsync(rc_all + b.r0, b.h.rc, (size_t) b.n * 4, hipMemcpyDeviceToDevice, s));
+		HIP_TRY(hipMemcpyAsync(nh_all + b.r0, b.h.n_hits, (size_t) b.n * 4, hipMemcpyDeviceToDevice, s));
+	}
+	std::vector<uint64_t> w(D);
+	HIP_TRY(hipMemcpy(w.data(), cc.w_scores, D * 8, hipMemcpyDeviceToHost));
+	std::vector<kmahip_res_row> rows(D);
+	int64_t n_rows = 0;
+	if((rc = kmahip_res_rows(db, w.data(), S->opts.evalue, p->scoreT, rows.data(), (int64_t) D, &n_rows))) return rc;
+	std::vector<uint8_t> ok(D + 8, 0);
+	for(int64_t r = 0; r < n_rows; ++r) ok[(size_t) rows[(size_t) r].template_id] = (uint8_t) rows[(size_t) r].significant;
+	const uint8_t *d_ok = nullptr;
+	if((rc = B.up(ok.data(), D + 8, 0, &d_ok))) return rc;
+	ms[2] = since(t);
+
+	// the traceback over everything in one launch (its second pass lasts as long as its slowest lane: once, not once per batch)
+	kmahip_traces tr{};
+	if((rc = B.get((size_t) 10 * n + 10, &tr.stats, true)) || (rc = B.get((size_t) n + 1, &tr.ops_off, true)) || (rc = B.get((size_t) n + 1, &tr.n_ops, true))) return rc;
+	for(Batch &b : S->batches) b.release();
+	DevArr pool;
+	if((rc = pool.ensure((size_t) (6 * n + (1 << 20)) * 4, 0, s))) return rc;
+	for(int attempt = 0; n; ++attempt) {
+		tr.ops = pool.as<uint32_t>(); tr.ops_cap = (int64_t) (pool.cap / 4);
+		if((rc = kmahip_launch_trace(db, ws, &W, rc_all, cc.tmpl, d_ok, p, &tr, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		unsigned long long used = 0;
+		const int st = ws_status(ws, &used);
+		if(st == 2 || (int64_t) used > tr.ops_cap) {
+			if(attempt >= 3) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+			if((rc = pool.ensure((size_t) ((int64_t) used + (1 << 20)) * 4, 0, s))) return rc;
+			continue;
+		}
+		if(st == 16 && grow_mem_cap(ws)) { --attempt; continue; }
+		if(st) { kmahip_set_error("trace stage: a read needs more scratch than the workspace holds (status %d)", st); return KMAHIP_EDEVICE; }
+		break;
+	}
+	tr.ops = pool.as<uint32_t>(); tr.ops_cap = (int64_t) (pool.cap / 4);
+	ms[3] = since(t);
+
+	// stage 3c per template over everything
+	std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
+	int64_t tbases = 0;
+	for(size_t tt = 1; tt < D; ++tt) tbases += db->h_tlen[tt];
+	std::vector<char> cons((size_t) (4 * tbases + 4 * (int64_t) D + (1 << 20)));
+	kmahip_assembly asmb{};
+	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
+	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
+	if(n) {
+		kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 0, S->opts.caller, S->opts.sig90, nullptr};
+		if((rc = kmahip_assemble2_dev(db, ws, &W, rc_all, cc.tmpl, &tr, &ao, &asmb))) return rc;
+	}
+	ms[4] = since(t);
+	const std::string prefix(out_prefix);
+	if((rc = kmahip_write_res_fsa(db, (prefix + ".res").c_str(), write_fsa ? (prefix + ".fsa").c_str() : nullptr, true, rows.data(), n_rows, nullptr, 0, a_cover.data(), a_len.data(),
+	                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t))) return rc;
+	ms[5] = since(t);
+	if(!write_frag) return KMAHIP_OK;
+
+	// ---- the fragment rows: order, lengths and text on the device; the host compresses and writes
+	int64_t *filed = nullptr, *kept = nullptr, *frank = nullptr, *kscan = nullptr, *vals = nullptr, *vals2 = nullptr, *row_off = nullptr, *row_len = nullptr;
+	unsigned long long *keys = nullptr, *keys2 = nullptr;
+	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &kept)) || (rc = B.get((size_t) n + 1, &frank)) || (rc = B.get((size_t) n + 1, &kscan)) ||
+	   (rc = B.get((size_t) n + 1, &keys)) || (rc = B.get((size_t) n + 1, &keys2)) || (rc = B.get((size_t) n + 1, &vals)) || (rc = B.get((size_t) n + 1, &vals2))) return rc;
+	hipLaunchKernelGGL(row_flags_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, cc.tmpl, tr.stats, filed, kept);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, filed, frank, (size_t) n + 1, s)) || (rc = scan_i64(B, kept, kscan, (size_t) n + 1, s))) return rc;
+	int64_t n_frag_rows = 0;
+	HIP_TRY(hipMemcpy(&n_frag_rows, kscan + n, 8, hipMemcpyDeviceToHost));
+	if(n_rows_out) *n_rows_out = n_frag_rows;
+	kmahip_gzstream *gz = kmahip_gzstream_open((prefix + ".frag.gz").c_str());
+	if(!gz) return KMAHIP_EIO;
+	struct Closer { kmahip_gzstream *&g; ~Closer() { if(g) (void) kmahip_gzstream_close(g); } } closer{gz};
+	if(n_frag_rows > 0) {
+		hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, cc.tmpl, kscan, frank, mf, keys, vals);
+		HIP_TRY(hipGetLastError());
+		{
+			size_t tmp_bytes = 0;
+			if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
+			char *tmp = nullptr;
+			if((rc = B.get(tmp_bytes, &tmp))) return rc;
+			if(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
+		}
+		// template names on the device
+		std::vector<int64_t> tn_off(D + 1, 0);
+		std::string tn;
+		for(size_t tt = 1; tt < D; ++tt) { if(tt - 1 < db->h_names.size()) tn += db->h_names[tt - 1]; tn_off[tt] = (int64_t) tn.size(); }
+		tn_off[D] = (int64_t) tn.size();
+		const char *d_tn = nullptr;
+		const int64_t *d_tn_off = nullptr;
+		if((rc = B.up(tn.data(), tn.size(), 1, &d_tn)) || (rc = B.up(tn_off.data(), D + 1, 0, &d_tn_off))) return rc;
+		if((rc = B.get((size_t) n_frag_rows + 1, &row_len)) || (rc = B.get((size_t) n_frag_rows + 1, &row_off))) return rc;
+		RowArgs A{};
+		A.seq = W.seq; A.seq_off = W.seq_off; A.N_off = W.N_off; A.name_off = S->name_off.as<int64_t>(); A.len = W.len; A.N = W.N; A.rc = rc_all; A.tmpl = cc.tmpl; A.n_hits = nh_all;
+		A.stats = tr.stats; A.names = S->names.as<char>(); A.tnames = d_tn; A.tname_off = d_tn_off; A.row_read = vals2; A.row_off = row_len;
+		hipLaunchKernelGGL(row_len_kernel, dim3((unsigned) ((n_frag_rows + 256) / 256)), dim3(256), 0, s, A, n_frag_rows);
+		HIP_TRY(hipGetLastError());
+		if((rc = scan_i64(B, row_len, row_off, (size_t) n_frag_rows + 1, s))) return rc;
+		A.row_off = row_off;
+		int64_t text_bytes = 0;
+		HIP_TRY(hipMemcpy(&text_bytes, row_off + n_frag_rows, 8, hipMemcpyDeviceToHost));
+		// blocks of rows of about 4 MB of text (a gzip member each), chunks of blocks of at most CHUNK bytes through two text buffers
+		const int64_t avg = std::max<int64_t>(1, text_bytes / n_frag_rows);
+		const int64_t rows_per_block = std::max<int64_t>(16, std::min<int64_t>(1 << 16, (4 << 20) / avg));
+		const int64_t n_blocks = (n_frag_rows + rows_per_block - 1) / rows_per_block;
+		int64_t *d_boff = nullptr;
+		if((rc = B.get((size_t) n_blocks + 1, &d_boff))) return rc;
+		hipLaunchKernelGGL(row_blocks_kernel, dim3((unsigned) ((n_blocks + 256) / 256)), dim3(256), 0, s, n_blocks, rows_per_block, n_frag_rows, row_off, d_boff);
+		HIP_TRY(hipGetLastError());
+		std::vector<int64_t> boff((size_t) n_blocks + 1);
+		HIP_TRY(hipMemcpy(boff.data(), d_boff, ((size_t) n_blocks + 1) * 8, hipMemcpyDeviceToHost));
+		int64_t max_block = 0;
+		for(int64_t b = 0; b < n_blocks; ++b) max_block = std::max(max_block, boff[(size_t) b + 1] - boff[(size_t) b]);
+		const int64_t CHUNK = std::max<int64_t>(S->text_chunk, max_block);
+		constexpr int NBUF = kmahip_session::NBUF;
+		char *d_text[2] = {nullptr, nullptr};
+		char **h_text = S->h_text;
+		std::atomic<int> pending[NBUF];
+		for(int x = 0; x < NBUF; ++x) pending[x].store(0);
+		for(int x = 0; x < 2; ++x) if((rc = B.get((size_t) CHUNK + 16, &d_text[x]))) return rc;
+		if(CHUNK > S->text_chunk) {          // (a single block of rows longer than the buffers made at the start: rows of very long reads)
+			for(int x = 0; x < NBUF; ++x) { (void) hipHostFree(h_text[x]); h_text[x] = nullptr; HIP_TRY(hipHostMalloc((void **) &h_text[x], (size_t) CHUNK + 16, hipHostMallocDefault)); }
+			S->text_chunk = CHUNK;
+		}
+		int chunk_no = 0;
+		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+		double ms_prep = since(t), ms_fmt = 0, ms_wait = 0, ms_copy = 0;
+		auto lap = std::chrono::steady_clock::now();
+		for(int64_t b0 = 0; b0 < n_blocks; ++chunk_no) {
+			int64_t b1 = b0 + 1;
+			while(b1 < n_blocks && boff[(size_t) b1 + 1] - boff[(size_t) b0] <= CHUNK) ++b1;
+			const int64_t r0 = b0 * rows_per_block, r1 = std::min(n_frag_rows, b1 * rows_per_block), bytes = boff[(size_t) b1] - boff[(size_t) b0];
+			char *dt = d_text[chunk_no & 1];
+			const int hb = chunk_no % NBUF;
+			hipLaunchKernelGGL(row_format_kernel, dim3((unsigned) ((r1 - r0 + 255) / 256)), dim3(256), 0, s, A, r0, r1, boff[(size_t) b0], dt);
+			HIP_TRY(hipGetLastError());
+			if(dbg) { HIP_TRY(hipStreamSynchronize(s)); ms_fmt += since(lap); }
+			while(pending[hb].load() > 0) std::this_thread::yield();          // (the buffer's blocks of three chunks ago are still being compressed)
+			if(dbg) ms_wait += since(lap);
+			HIP_TRY(hipMemcpyAsync(h_text[hb], dt, (size_t) bytes, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if(dbg) ms_copy += since(lap);
+			pending[hb].store((int) (b1 - b0));
+			for(int64_t b = b0; b < b1; ++b) kmahip_gzstream_submit(gz, h_text[hb] + (boff[(size_t) b] - boff[(size_t) b0]), (size_t) (boff[(size_t) b + 1] - boff[(size_t) b]), &pending[hb]);
+			b0 = b1;
+		}
+		kmahip_gzstream *g = gz;
+		gz = nullptr;
+		if((rc = kmahip_gzstream_close(g))) return rc;          // (before the pinned buffers go)
+		if(dbg) fprintf(stderr, "[kmahip] session: fragment rows: %lld rows, %lld bytes of text in %d chunks of %lld blocks; order + lengths + buffers %.1f ms, formatting %.1f, waiting for a free buffer %.1f, copies %.1f, draining the writer %.1f\n",
+		                (long long) n_frag_rows, (long long) text_bytes, chunk_no, (long long) n_blocks, ms_prep, ms_fmt, ms_wait, ms_copy, since(lap));
+	} else {
+		kmahip_gzstream *g = gz;
+		gz = nullptr;
+		if((rc = kmahip_gzstream_close(g))) return rc;
+	}
+	ms[6] = since(t);
+	return KMAHIP_OK;
+}

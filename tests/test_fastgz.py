@@ -59,3 +59,13 @@ def test_size_is_close_to_level_1_on_fragment_rows():
     ref = zlib.compressobj(1, zlib.DEFLATED, 31)
     r = ref.compress(data) + ref.flush()
     assert len(z) < 1.3 * len(r), (len(z), len(r))
+
+
+def test_every_length_around_the_checksum_fold_inflates():
+    """the member's CRC-32 is folded 64 bytes at a time with carry-less multiplication, then 16 at a time, then by table: every length
+    from 0 to 400 (and a few large odd ones) must come back through zlib, which checks the checksum"""
+    rng = np.random.default_rng(11)
+    blob = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    for n in list(range(0, 401)) + [4095, 4096, 4097, 65535, 100001, (1 << 20) - 1]:
+        data = blob[7:7 + n]
+        assert gzip.decompress(_member(data)) == data, n

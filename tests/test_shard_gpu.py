@@ -220,3 +220,19 @@ def test_paired_fixture_with_empty_hit_lists_over_three_ranks(tmp_path):
         _run((["-gpus", str(world)] if world > 1 else []) + args + ["-o", out], env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
         assert open(out + ".res").read() == open(os.path.join(g["dir"], "out.res")).read(), world
         assert open(out + ".fsa").read() == gzip.open(os.path.join(g["dir"], "out.fsa.gz"), "rt").read(), world
+
+
+@pytest.mark.parametrize("batch,chunk,mf", [(1000, 20000, None), (777, 3000000, 1500), (1 << 20, None, None)])
+def test_batched_session_writes_the_one_batch_files(tmp_path, batch, chunk, mf):
+    """the single-end -1t1 run batch by batch (kmahip_session_*: reads and headers kept in HBM, fragment rows ordered and formatted
+    on the device, text back in chunks) against the same program taking the whole input as one batch (kmahip_run_se + the host's
+    writer): tiny batches, tiny text chunks, chunks of -mf fragments that straddle batches"""
+    prefix, fq = _case(tmp_path)
+    extra = ["-mf", str(mf)] if mf else []
+    _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one"), "-1t1"] + extra, env={"KMAHIP_MAP_ONE_BATCH": "1"})
+    env = {"KMAHIP_MAP_BATCH": str(batch)}
+    if chunk:
+        env["KMAHIP_FRAG_CHUNK"] = str(chunk)
+    r = _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many"), "-1t1"] + extra, env=env)
+    assert b"batches" in r.stderr
+    _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
