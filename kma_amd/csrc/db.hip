@@ -401,7 +401,10 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		for(uint32_t t = 1; t < DB_size; ++t) {
 			const int64_t nk = std::max<int64_t>(0, (int64_t) db->h_tlen[t] - k + 1);
 			uint32_t lg = 4;
-			while((1ull << lg) * 2 < (uint64_t) nk * 3) ++lg;   // load <= 2/3
+			// load <= 2/3; for long templates (genomes: what long reads are seeded against, 256 lookups side by side that wait for the
+			// longest of their probe chains) <= 1/3. The gene-sized tables stay as dense as they were: they are what the short-read
+			// kernels keep in cache
+			while((1ull << lg) * 2 < (uint64_t) nk * (nk >= 65536 ? 6 : 3)) ++lg;
 			pshift[t] = 32 - lg;
 			poff[t + 1] = poff[t] + (1ll << lg);
 		}

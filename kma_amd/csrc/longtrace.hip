@@ -17,6 +17,8 @@
 //                     whatever fits neither is solved by one lane with rows and E in HBM (same code path as the reference)
 //   lt_finish_kernel  per read: the runs of its problems and MEMs concatenated in chain order, read filter, output
 #include "kmahip_internal.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include "dna_dev.h"
 #include <algorithm>
 #include <climits>
@@ -30,7 +32,7 @@
 namespace {
 
 constexpr int LT_TILE = 256;          // query positions looked up per round of the seeding wavefront
-constexpr int LT_NEXT_CAP = 2048;     // MEMs of the winning strand whose chain links / chain order stay in LDS
+constexpr int LT_NEXT_CAP = 512;     // MEMs of the winning strand whose chain links / chain order stay in LDS
 constexpr int LT_NCLS = 17;           // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
                                       // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one
                                       // lane); 9..12 = 4..7 with a move matrix too large for LDS (kept in the workgroup's HBM scratch);
@@ -43,8 +45,11 @@ constexpr int LT_XT_LDS = 2048;       // template rows staged in LDS there
 
 enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_TRIM = 16 };
 // counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..20] class counts,
-// [21] DP cells, [22] MEMs of the chained strands (work figures), [23] output run pool top
-enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_OUT = 23, LC_N = 24 };
+// [21] DP cells, [22] MEMs of the chained strands (work figures), [23] problems in the lane queue, [24..30] of them per lane class,
+// [31] output run pool top
+constexpr int LT_LCLS = 7;            // lane classes (lt_lane_kernel): 0..4 full matrix with rows of up to 16 / 32 / 64 / 128 / 256 cells,
+                                      // 5, 6 banded with rows of up to 128 / 256
+enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_LANE = 23, LC_LCNT = 24, LC_OUT = 31, LC_N = 32 };
 
 struct LtRead {               // per read of the pass
 	int64_t first;            // first problem descriptor
@@ -102,6 +107,10 @@ struct LtArgs {
 	uint32_t *runs;           // run slots of the problems
 	int64_t runs_cap;
 	int32_t *queue;           // LT_NCLS x prob_cap problem indices
+	int32_t *lq;              // the lane queue: problem indices of all lane classes (prob_cap), sorted by lkey before the kernels run
+	uint32_t *lkey;           // (lane class << 24) | iterations of the problem's sweep
+	int stop;                 // diagnosis (KMAHIP_LT_STOP): 1 = reads end after their seeding, 2 = after the chain
+	int lane_tq;              // 0: no lane classes; else the largest rows + columns whose scores stay inside 16 bits
 	uint32_t *tmp;            // per finishing wavefront: tmp_cap words
 	int64_t tmp_cap;
 	uint8_t *xE;              // per lt_dpx workgroup: xe_cap bytes of move matrix + 4 rows of xrow ints
@@ -136,9 +145,12 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 }
-// the same when what one lane wrote to HBM is read by the others (their L1 may hold the line from an earlier read)
+// the same when what one lane wrote to HBM is read by the others. Workgroup scope is enough: a workgroup of these kernels is one
+// wavefront, its lanes share the CU's L1, which a store writes through and updates; the agent scope this was written with first
+// writes back and invalidates L2 on every call (buffer_wbl2 / buffer_inv on gfx950) -- per read and per problem that was the
+// larger part of the seeding kernel's time
 __device__ __forceinline__ void wave_sync_hbm() {
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 }
 
@@ -232,19 +244,25 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				km[j] = (pos <= segE - k) ? (uint32_t) (qwin(q, pos) >> (64 - 2 * k)) : 0u;
 			}
 			{
-				// first probes of the four lookups travel together
+				// first probes of the four lookups travel together; a probe takes the aligned pair of slots its slot lies in (16 bytes:
+				// the chain of a lookup is walked two slots per round trip, and with the table at most a third full (db.hip) the
+				// longest of a round's 256 chains is two or three round trips instead of fifteen)
 				const uint32_t msk = (1u << (32 - tsh)) - 1u;
 				uint32_t sl[4];
-				uint2 e[4];
+				uint4 e[4];
 #pragma unroll
-				for(int j = 0; j < 4; ++j) { sl[j] = (km[j] * 0x9E3779B1u) >> tsh; e[j] = tab[sl[j]]; }
+				for(int j = 0; j < 4; ++j) { sl[j] = (km[j] * 0x9E3779B1u) >> tsh; e[j] = *(const uint4 *) (tab + (sl[j] & ~1u)); }
 #pragma unroll
 				for(int j = 0; j < 4; ++j) {
 					v[j] = 0;
 					if(km[j]) for(;;) {
-						if(e[j].y == 0) break;
-						if(e[j].x == km[j]) { v[j] = (int) e[j].y; break; }
-						sl[j] = (sl[j] + 1u) & msk; e[j] = tab[sl[j]];
+						if(!(sl[j] & 1u)) {
+							if(e[j].y == 0) break;
+							if(e[j].x == km[j]) { v[j] = (int) e[j].y; break; }
+						}
+						if(e[j].w == 0) break;
+						if(e[j].z == km[j]) { v[j] = (int) e[j].w; break; }
+						sl[j] = ((sl[j] | 1u) + 1u) & msk; e[j] = *(const uint4 *) (tab + sl[j]);
 					}
 				}
 			}
@@ -536,7 +554,40 @@ __device__ __forceinline__ int lt_class(int q_l, int t_l, int band, int k, int64
 	return 8;
 }
 
-__global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
+// lane class of a DP problem (lt_lane_kernel: one LANE per problem, rows in LDS as 16-bit pairs, move matrix in HBM), -1: none.
+// Geometry of class j: rows of up to R = 16 << j cells (full matrix: q_l + 1 of them; banded: band + 3), a move matrix of up to
+// 4096 << j bytes, up to 255 (j <= 2) / 511 template rows. *iters = turns of the problem's sweep.
+struct LaneGeom { int R, RQ, TW, ecap; };   // cells per row, query columns, template words (16 rows each), bytes of move matrix
+__host__ __device__ __forceinline__ LaneGeom lt_lane_geom(int j) {
+	LaneGeom g;
+	if(j < 5) { g.R = 16 << j; g.RQ = g.R; g.TW = j < 3 ? 16 : 32; g.ecap = 4096 << j; }
+	else if(j == 5) { g.R = 80; g.RQ = 160; g.TW = 16; g.ecap = 20480; }
+	else { g.R = 144; g.RQ = 256; g.TW = 32; g.ecap = 65536; }
+	return g;
+}
+__device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, int tq_max, int *iters) {
+	if(!tq_max || t_l + q_l > tq_max || t_l < 1 || q_l < 1) return -1;
+	if(band == 0) {
+		const int64_t e = (int64_t) (q_l + 1) * (t_l + 1) + 4;
+		for(int j = 0; j < 5; ++j) {
+			const LaneGeom g = lt_lane_geom(j);
+			if(q_l + 1 <= g.R && e <= g.ecap && t_l < 16 * g.TW) { *iters = (q_l + 1) * t_l; return j; }
+		}
+		return -1;
+	}
+	if(band & 1) ++band;
+	// (the reference's last-row scan over cells the band no longer covers: see lt_class)
+	const int cfin = ((t_l + q_l) >> 1) - (t_l - 1);
+	if(k == -2 && !(cfin + (band >> 1) < q_l - 1)) return -1;
+	const int64_t e = (int64_t) (band + 2) * (t_l + 1) + 4;
+	for(int j = 5; j < LT_LCLS; ++j) {
+		const LaneGeom g = lt_lane_geom(j);
+		if(band + 3 <= g.R && q_l <= g.RQ && e <= g.ecap && t_l < 16 * g.TW) { *iters = (band + 2) * t_l; return j; }
+	}
+	return -1;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lt_seed_kernel(const LtArgs A) {
 	__shared__ SeedLds S;
 	const int lane = threadIdx.x;
 	if(lane < 25) S.d[lane] = A.d[lane];
@@ -601,7 +652,7 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 				else { base = plen; n = mc; H.rc = 1; qf.rc = 1; }
 			}
 			if(!room) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 3ull); n = 0; }
-			go = n > 0;
+			go = n > 0 && A.stop != 1;
 		}
 		wave_sync_hbm();    // the MEMs written by lane 0 are read by all lanes from here on
 		unsigned mapQ = 0;
@@ -609,7 +660,7 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 		if(go) {
 			int best = 0;
 			start = lt_chain(A, S, Mm, base, n, q_len, t_len, k, &mapQ, &best);
-			if(mapQ < (unsigned) A.mq || best < k) go = false;
+			if(mapQ < (unsigned) A.mq || best < k || A.stop == 2) go = false;
 		}
 		if(go) {
 			// the chain in order
@@ -685,7 +736,28 @@ __global__ __launch_bounds__(64) void lt_seed_kernel(const LtArgs A) {
 						if(lane == 0 && tot) atomicAdd(&A.counters[LC_CELLS], (unsigned long long) tot);
 					}
 					// queues per class, one atomic per class and round
-					const int cls = dp && rfit ? lt_class(J.q_l, J.t_l, J.band, J.k, A.xe_cap) : -1;
+					int l_iters = 0;
+					const int lcls = dp && rfit ? lt_lane_class(J.q_l, J.t_l, J.band, J.k, A.lane_tq, &l_iters) : -1;
+					{
+						// the lane classes share one queue (sorted by class and sweep length before their kernels run)
+						const unsigned long long m = __ballot(lcls >= 0);
+						if(m) {
+							const int leader = __ffsll((long long) m) - 1;
+							unsigned long long qb = 0;
+							if(lane == leader) qb = atomicAdd(&A.counters[LC_LANE], (unsigned long long) __popcll(m));
+							qb = __shfl(qb, leader);
+							if(lcls >= 0) {
+								const size_t at = (size_t) qb + __popcll(m & ((1ull << lane) - 1ull));
+								A.lq[at] = (int32_t) (first + l);
+								A.lkey[at] = ((uint32_t) lcls << 24) | (uint32_t) min(l_iters, 0xFFFFFF);
+							}
+							for(int c = 0; c < LT_LCLS; ++c) {
+								const unsigned long long mc = __ballot(lcls == c);
+								if(mc && lane == __ffsll((long long) mc) - 1) atomicAdd(&A.counters[LC_LCNT + c], (unsigned long long) __popcll(mc));
+							}
+						}
+					}
+					const int cls = dp && rfit && lcls < 0 ? lt_class(J.q_l, J.t_l, J.band, J.k, A.xe_cap) : -1;
 					for(int c = 0; c < LT_NCLS; ++c) {
 						const unsigned long long m = __ballot(cls == c);
 						if(!m) continue;
@@ -1277,6 +1349,292 @@ __global__ __launch_bounds__(64) void lt_serial_kernel(const LtArgs A) {
 	}
 }
 
+// ---- one LANE per problem --------------------------------------------------------------------------------------------------
+// The sweeps above give a problem 8 to 64 lanes and keep its move matrix in LDS; what the configuration's reads produce by the
+// hundred million are problems of a few hundred to a few thousand cells, for which the fill and drain of an anti-diagonal sweep,
+// the walk by one lane and the LDS the matrices take leave the chip mostly idle. Here a lane owns a problem and runs the
+// reference's own row-by-row recurrence (nw.c:26-309; banded: nw.c:310-640): the row below as (D, P) pairs of 16 bits in LDS
+// (column-major over the lanes: no bank conflicts), the query columns as bytes beside it, the template rows 16 per word, the move
+// matrix in the lane's own stretch of HBM scratch, four cells per store, and the walk by the same lane right behind (the matrix is
+// read back through L2). The problems of a class arrive sorted by the length of their sweep, so the 64 sweeps of a wavefront end
+// together; all lanes run ONE flat loop, a cell per turn, the boundary column being a cell like the others whose values are
+// replaced. 16 bits hold every value as long as (rows + columns) x the largest penalty stays below 2^15 (lane_tq).
+struct LaneArgs {
+	const int32_t *queue;        // the class's problems, longest sweep first
+	unsigned long long count;
+	int R, RQ, TW;               // cells per row, query columns, template words per lane: the LDS geometry
+	uint8_t *E;                  // per workgroup 64 x ecap bytes of move matrix
+	int ecap;
+	int ablate;                  // diagnosis (KMAHIP_LT_ABLATE): 1 no matrix stores, 2 no walk, 4 no sweep
+};
+
+__device__ __forceinline__ uint32_t lt_pack16(int D, int Pn) { return ((uint32_t) D & 0xffffu) | ((uint32_t) Pn << 16); }
+
+struct LaneProb { LtProb *P; int k, t_s, t_len, q_s, q_len, flags, band; bool live; };
+
+// a wavefront's next 64 problems: descriptors, the template rows into T (16 per word, first row in the top bits), the query
+// columns into QB (one byte each)
+__device__ __forceinline__ LaneProb lt_lane_stage(const LtArgs &A, const LaneArgs &L, unsigned long long base, int lane, uint32_t *T, uint8_t *QB) {
+	LaneProb X;
+	X.live = base + lane < L.count;
+	LtProb *P = A.prob + L.queue[X.live ? base + lane : base];
+	X.P = P;
+	X.k = P->k; X.t_s = P->t_s; X.t_len = P->t_l; X.q_s = P->q_s; X.q_len = P->q_l; X.flags = P->flags; X.band = P->band;
+	const bool live = X.live;
+	const int t_s = X.t_s, t_len = X.t_len, q_s = X.q_s, q_len = X.q_len;
+	const int64_t r = A.r0 + P->read;
+	const int tt = A.tmpl ? A.tmpl[r] : A.tmpl_all;
+	const int at = abs(tt);
+	const int tlen_total = A.db.tlen[at];
+	const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+	QView q;
+	q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.rc = A.rd[P->read].rc;
+	q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+	wave_sync();
+	const int tw_n = live ? (t_len + 15) >> 4 : 0;
+	const int tw_max = wave_max(tw_n);
+	for(int j = 0; j < tw_max; ++j) {
+		if(j < tw_n) {
+			int pos = t_s + 16 * j;
+			if(pos >= tlen_total) pos -= tlen_total;
+			uint32_t w = 0;
+			if(pos + 16 <= tlen_total) w = (uint32_t) (win2(ts, pos) >> 32);
+			else for(int x = 0; x < 16; ++x) { int p2 = pos + x; if(p2 >= tlen_total) p2 -= tlen_total; w |= (uint32_t) tn(ts, p2) << (30 - 2 * x); }
+			T[j * 64 + lane] = w;
+		}
+	}
+	const int q_max = wave_max(live ? q_len : 0);
+	for(int n0 = 0; n0 < q_max; n0 += 16) {
+		if(live && n0 < q_len) {
+			if(q.nN == 0 && !q.rc) {
+				const uint64_t w = win2(q.w, q_s + n0);
+				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) ((w >> (62 - 2 * x)) & 3ull);
+			} else if(q.nN == 0) {
+				// stored positions L - 1 - (q_s + n0 + x), complemented; the window starts at the lowest of them
+				int ps = q.L - 1 - (q_s + n0 + 15), sh = 0;
+				if(ps < 0) { sh = -ps; ps = 0; }
+				const uint64_t w = win2(q.w, ps);
+				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) (3 - (int) ((w >> (62 - 2 * (15 - x - sh))) & 3ull));
+			} else {
+				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) qn(q, q_s + n0 + x);
+			}
+		}
+	}
+	return X;
+}
+
+__global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneArgs L) {
+	extern __shared__ uint32_t lt_lane_lds[];
+	int *const sd = (int *) lt_lane_lds;                         // 32 ints
+	uint32_t *const DP = lt_lane_lds + 32;                      // R x 64
+	uint32_t *const T = DP + (size_t) L.R * 64;                 // TW x 64
+	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64
+	const int lane = threadIdx.x;
+	if(lane < 25) sd[lane] = A.d[lane];
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.ecap;
+	const int U = A.U, W1 = A.W1;
+	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
+		const LaneProb X = lt_lane_stage(A, L, base, lane, T, QB);
+		LtProb *P = X.P;
+		const bool live = X.live;
+		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
+		const int pitch = q_len + 1;
+		const int low = (t_len + q_len) * (A.MM + U + W1);
+		const int q_max = wave_max(live ? q_len : 0);
+		if(live) QB[q_len * 64 + lane] = 0;
+		// the boundary row (m = t_len) and its move bytes; cells go out in descending address order, four to a store
+		int ea = pitch * (t_len + 1) - 1;
+		uint32_t ew = 0;
+		for(int i = 0; i <= q_max; ++i) {
+			const int n = q_len - i;
+			if(live && n >= 0) {
+				int D = 0, code = 0;
+				if(n < q_len && k != 2) { D = W1 + (q_len - 1 - n) * U; code = (n == q_len - 1) ? 18 : 3; }
+				DP[n * 64 + lane] = lt_pack16(D, low);
+				ew |= (uint32_t) code << ((ea & 3) << 3);
+				if((ea & 3) == 0) { *(uint32_t *) (E + ea) = ew; ew = 0; }
+				--ea;
+			}
+		}
+		int m = t_len - 1, n = q_len, right = 0, diag = 0, Qprev = low, score = low, best_m = 0;
+		const int iters = live && !(L.ablate & 4) ? pitch * t_len : 0;
+		const int it_max = wave_max(iters);
+		for(int it = 0; it < it_max; ++it) {
+			if(it < iters) {
+				const int li = n * 64 + lane;
+				const uint32_t below = DP[li];
+				const int qb = (int) QB[li];
+				const uint32_t tword = T[((m >> 4) << 6) + lane];
+				const int tb = (int) ((tword >> (30 - ((m & 15) << 1))) & 3u);
+				const int Db = (int) (short) (below & 0xffffu), Pb = ((int) below) >> 16;
+				int Q = right + W1, Pn = Db + W1, D, mv, cell = 0;
+				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int x = Qprev + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				x = Pb + U;
+				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+				x = diag + sd[5 * tb + qb];
+				if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
+				if(n == q_len) {
+					// boundary column (nw.c:703-750)
+					D = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+					Q = low;
+					cell = (0 < k) ? 0 : ((m == t_len - 1) ? 36 : 5);
+				}
+				DP[li] = lt_pack16(D, Pn);
+				ew |= (uint32_t) cell << ((ea & 3) << 3);
+				if((ea & 3) == 0) { if(!(L.ablate & 1)) *(uint32_t *) (E + ea) = ew; ew = 0; }
+				--ea;
+				if(n == 0 && k < 0 && score < D) { score = D; best_m = m; }
+				diag = Db; right = D; Qprev = Q;
+				if(n == 0) { --m; n = q_len; } else --n;
+			}
+		}
+		// result selection (nw.c:218-254)
+		int sm = 0, sn = 0;
+		if(live) {
+			if(k < 0) {
+				sm = best_m;
+				if(k == -2) for(int n2 = 0; n2 < q_len; ++n2) {
+					const int Dn = (int) (short) (DP[n2 * 64 + lane] & 0xffffu);
+					if(score <= Dn) { score = Dn; sm = 0; sn = n2; }
+				}
+			} else score = right;
+		}
+		wave_sync_hbm();   // the matrix is read back by the lane that wrote it
+		if(live && !(L.ablate & 2)) {
+			RunOut R;
+			R.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = sn, bad = 0;
+			const int q_pos = lt_walk((const uint8_t *) E, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : R.n;
+			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
+		}
+	}
+}
+
+// the same for NW_band (nw.c:310-640): a row holds the band's cells, index n = column - (c - band / 2) with c the band's centre, which
+// moves one column to the left per row; the cell below index n is index n - 1 of the row before, so a row is still updated in
+// place. Per row: the cell to the right of the band (virtual, D = low; or the boundary column where the band reaches it), the
+// band's cells, and the leftmost one, which has no template-gap state. Rows are cut at the matrix' first and last column (`en`
+// leading indices unused once the band has reached column 0).
+__global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const LaneArgs L) {
+	extern __shared__ uint32_t lt_lane_lds[];
+	int *const sd = (int *) lt_lane_lds;
+	uint32_t *const DP = lt_lane_lds + 32;
+	uint32_t *const T = DP + (size_t) L.R * 64;
+	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);
+	const int lane = threadIdx.x;
+	if(lane < 25) sd[lane] = A.d[lane];
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.ecap;
+	const int U = A.U, W1 = A.W1;
+	constexpr int NEG = -(1 << 28);
+	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
+		const LaneProb X = lt_lane_stage(A, L, base, lane, T, QB);
+		LtProb *P = X.P;
+		const bool live = X.live;
+		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
+		int band = X.band;
+		if(band & 1) ++band;
+		const int half = band >> 1, bq = band + 1, pitch = bq + 1;
+		const int low = (t_len + q_len) * (A.MM + U + W1);
+		// the row below the last one (nw.c:386-420): index sn0 is the boundary column
+		int c = (t_len + q_len) >> 1;
+		const int sn0 = q_len - 1 - (c - half);
+		const int r_max = wave_max(live ? bq : 0);
+		for(int i = 0; i <= r_max; ++i) if(live && i <= bq) DP[i * 64 + lane] = 0;
+		// move bytes go out in descending address order, a word is stored when the next byte belongs to another one
+		int ea = -1;
+		uint32_t ew = 0;
+		auto emit = [&](int addr, int code) {
+			if((addr >> 2) != (ea >> 2)) { if(ea >= 0 && !(L.ablate & 1)) *(uint32_t *) (E + (ea & ~3)) = ew; ew = 0; }
+			ew |= (uint32_t) code << ((addr & 3) << 3);
+			ea = addr;
+		};
+		for(int i = 0; i <= r_max; ++i) {
+			const int n = sn0 - i;
+			if(live && n >= 0) {
+				int D = 0, code = 0;
+				if(n < sn0 && k != 2) { D = W1 + (sn0 - n - 1) * U; code = (n == sn0 - 1) ? 18 : 3; }
+				DP[n * 64 + lane] = lt_pack16(D, n == sn0 && k != 2 ? 0 : low);
+				emit(pitch * t_len + n, code);
+			}
+		}
+		// row state: en = first index in use, sn = last band cell, the cell at sn + 1 opens the row
+		int m = t_len - 1, en = 0, sn, n, qcol0;          // qcol0 = column of index 0 = c - half
+		bool clipped;                                      // the band reaches the last column: index sn + 1 is the boundary column
+		auto open_row = [&]() {
+			int sq = c + half, eq = c - half;
+			if(eq < 0) { eq = 0; ++en; } else en = 0;
+			if(sq < q_len - 1) { sn = bq - 1; clipped = false; }
+			else { sn = en + (q_len - eq) - 1; clipped = true; }
+			qcol0 = c - half;
+			n = sn + 1;
+		};
+		open_row();
+		int right = 0, diag = 0, Qprev = low, score = low, bm = 0, bn = 0;
+		const int it_max = wave_max(live && !(L.ablate & 4) ? pitch * t_len : 0);
+		for(int it = 0; it < it_max; ++it) {
+			if(live && m >= 0) {
+				const uint32_t below = DP[max(n - 1, 0) * 64 + lane];
+				const int qcol = min(max(qcol0 + n, 0), q_len - 1);
+				const int qb = (int) QB[qcol * 64 + lane];
+				const uint32_t tword = T[((m >> 4) << 6) + lane];
+				const int tb = (int) ((tword >> (30 - ((m & 15) << 1))) & 3u);
+				const bool edge = n == en, first = n == sn + 1;
+				const int Dbl = (int) (short) (below & 0xffffu);
+				const int Db = edge ? NEG : Dbl, Pb = edge ? NEG : ((int) below) >> 16;
+				int Q = right + W1, Pn = Db + W1, D, mv, cell = 0;
+				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int x = Qprev + U;
+				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				x = Pb + U;
+				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
+				x = diag + sd[5 * tb + qb];
+				if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
+				if(edge) { cell &= ~32; Pn = low; }
+				if(first) {
+					// to the right of the band: a virtual cell, or the boundary column (nw.c:470-500)
+					if(clipped) { D = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U); cell = (0 < k) ? 0 : 37; }
+					else { D = low; cell = 37; }
+					Q = low; Pn = low;
+				}
+				DP[n * 64 + lane] = lt_pack16(D, Pn);
+				emit(pitch * m + n, cell);
+				diag = Dbl; right = D; Qprev = Q;
+				if(edge) {
+					if(qcol0 + en == 0 && k < 0 && score < D) { score = D; bm = m; bn = n; }
+					--m; --c;
+					if(m >= 0) open_row();
+				} else --n;
+			}
+		}
+		if(ea >= 0 && !(L.ablate & 1)) *(uint32_t *) (E + (ea & ~3)) = ew;
+		// result selection (nw.c:557-585): the leftmost cell of the first row unless a row above scored higher in column 0
+		int q_pos = 0;
+		if(live) {
+			if(bm == 0) { bn = en; score = right; }
+			if(k == -2) for(int n2 = en; n2 < bq; ++n2) {
+				const int Dn = (int) (short) (DP[n2 * 64 + lane] & 0xffffu);
+				if(score <= Dn) { score = Dn; bm = 0; bn = n2; q_pos = n2 - en; }
+			}
+		}
+		wave_sync_hbm();
+		if(live && !(L.ablate & 2)) {
+			RunOut R;
+			R.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = q_pos, bad = 0;
+			const int qend = lt_walk((const uint8_t *) E, pitch, bm, bn, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : R.n;
+			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
+		}
+	}
+}
+
 // ---- per read: the runs of its problems and MEMs in chain order, merged; alignment figures; the read filter of assemble_KMA
 // (assembly.c:1931-1961: + Wl for an alignment that starts at the first / ends at the last template base, minlen, mrc, scoreT)
 __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
@@ -1424,11 +1782,31 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	if(n == 0) return KMAHIP_OK;
 	const int max_len = reads->max_len;
 	if(max_len <= 0 || max_len > (1 << 24)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^24) for the trace stage"); return KMAHIP_EINVAL; }
-	const int seed_wgs = 2048, fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
+	// (the seeding kernel waits for its index lookups: as many wavefronts as the registers allow, 16 per CU)
+	const int seed_wgs = (int) std::min<int64_t>(getenv("KMAHIP_LT_SEED_WGS") ? atoi(getenv("KMAHIP_LT_SEED_WGS")) : 4096, std::max<int64_t>(1024, 400000000ll / max_len));
+	const int fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
 	const int mcap = std::max(1024, max_len / 8 + 256);
 	const int64_t tmp_cap = 4ll * max_len + 1024;
 	const int64_t xe_cap = 2ll << 20;
 	const int xrow = max_len + 72;
+	// lane classes (lt_lane_kernel): as long as the scores of (rows + columns) cells fit 16 bits; KMAHIP_LT_LANE=0 switches them off
+	int lane_tq = 0;
+	{
+		int mx = std::max(std::max(abs(p->rw.M), abs(p->rw.MM)), std::max(abs(p->rw.U), abs(p->rw.W1)));
+		for(int i = 0; i < 25; ++i) mx = std::max(mx, abs(p->rw.d[i / 5][i % 5]));
+		const char *e = getenv("KMAHIP_LT_LANE");
+		if(!(e && e[0] == '0')) lane_tq = 32000 / (abs(p->rw.MM + p->rw.U + p->rw.W1) + 2 * mx + 1);
+	}
+	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
+	LaneLaunch lg[LT_LCLS];
+	size_t lane_e_bytes = 0;
+	for(int j = 0; j < LT_LCLS; ++j) {
+		lg[j].g = lt_lane_geom(j);
+		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 64;
+		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
+		lg[j].e_off = lane_e_bytes;
+		lane_e_bytes += (size_t) lg[j].wgs * 64 * (size_t) lg[j].g.ecap;
+	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
 	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
 	int rc;
@@ -1452,6 +1830,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	A.o_stats = out->stats; A.o_off = out->ops_off; A.o_nops = out->n_ops; A.ops = out->ops; A.ops_cap = out->ops_cap;
 	A.ops_top = counters + LC_OUT; A.o_rc = rc_out;
 	A.rec = nullptr;
+	A.stop = getenv("KMAHIP_LT_STOP") ? atoi(getenv("KMAHIP_LT_STOP")) : 0;
 	if(getenv("KMAHIP_DEBUG_TIMING")) {
 		static uint32_t *rec = nullptr;
 		if(!rec && hipHostMalloc((void **) &rec, 2048 * 16 * 4, hipHostMallocMapped) != hipSuccess) rec = nullptr;
@@ -1460,7 +1839,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	for(int64_t r0 = 0; r0 < n;) {
 		const int64_t nb = std::min<int64_t>(B, n - r0);
 		if((rc = lt_reserve(ws, 1, (size_t) B * sizeof(LtRead))) || (rc = lt_reserve(ws, 2, (size_t) prob_cap * sizeof(LtProb))) ||
-		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4))) return rc;
+		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4)) ||
+		   (lane_tq && (rc = lt_reserve(ws, 8, (size_t) 4 * prob_cap * 4)))) return rc;
+		A.lq = (int32_t *) ws->lt_buf[8]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[8] + prob_cap : nullptr; A.lane_tq = lane_tq;
 		A.r0 = r0; A.n_reads = nb;
 		A.rd = (LtRead *) ws->lt_buf[1]; A.prob = (LtProb *) ws->lt_buf[2]; A.prob_cap = prob_cap;
 		A.runs = (uint32_t *) ws->lt_buf[3]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[4];
@@ -1483,10 +1864,10 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			if(!dbg) return;
 			if(A.rec) {
 				// a kernel that does not come back within 15 s: dump the recorder and give up (the process must not sit on a hung GPU)
-				for(int ms = 0; hipStreamQuery(stream) == hipErrorNotReady; ms += 10) {
-					struct timespec ts = {0, 10000000};
+				for(int us = 0; hipStreamQuery(stream) == hipErrorNotReady; us += 100) {
+					struct timespec ts = {0, 100000};
 					nanosleep(&ts, nullptr);
-					if(ms < 4000) continue;
+					if(us < 4000000) continue;
 					fprintf(stderr, "[kmahip] longtrace: %s does not finish; recorder of the workgroups still busy:\n", what);
 					int shown = 0, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 					for(int wg = 0; wg < 1024; ++wg) { const volatile uint32_t *rr = A.rec + (size_t) wg * 16; hist[rr[1] == 99 ? 6 : (rr[1] < 6 ? rr[1] : 7)]++; }
@@ -1521,6 +1902,19 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		// kernels that share the per-workgroup HBM scratch (classes 9-12 and the one-lane class 8: a few hundred big problems that
 		// take as long as the rest together when they run alone) one after the other on a fourth. With KMAHIP_DEBUG_TIMING
 		// everything stays on the caller's stream so that the stages can be timed.
+		int32_t *vals_out = nullptr;
+		if(c[LC_LANE]) {
+			// the lane classes: one sort by (class, sweep length), longest first, then a kernel per class (below)
+			const size_t nl = (size_t) c[LC_LANE];
+			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) ws->lt_buf[8] + 3 * prob_cap;
+			int32_t *vals_in = A.lq;
+			vals_out = (int32_t *) ws->lt_buf[8] + 2 * prob_cap;
+			size_t tmp_bytes = 0;
+			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 27u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
+			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, lane_e_bytes))) return rc;
+			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 27u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
+			stage("lane sort");
+		}
 		static hipStream_t side[3] = {nullptr, nullptr, nullptr};
 		hipStream_t s1 = stream, s2 = stream, s3 = stream;
 		hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
@@ -1547,6 +1941,28 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, banded, HBM>"); }
 		if(c[LC_CNT + 15]) { hipLaunchKernelGGL((lt_dpx_kernel<8, true, true>), wgs(15, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<8, banded, HBM>"); }
 		if(c[LC_CNT + 16]) { hipLaunchKernelGGL((lt_dpx_kernel<16, true, true>), wgs(16, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<16, banded, HBM>"); }
+		if(c[LC_LANE]) {
+			size_t off = 0;
+			for(int j = LT_LCLS - 1; j >= 0; --j) {
+				const unsigned long long cnt = c[LC_LCNT + j];
+				if(!cnt) continue;
+				LaneArgs La;
+				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap;
+				La.E = (uint8_t *) ws->lt_buf[10] + lg[j].e_off;
+				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
+				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
+				if(j < 5) {
+					if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *) lt_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
+					hipLaunchKernelGGL(lt_lane_kernel, dim3(grid), dim3(64), lg[j].lds, j <= 2 ? stream : (j == 3 ? s2 : s3), A, La);
+				} else {
+					if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *) lt_lane_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
+					hipLaunchKernelGGL(lt_lane_band_kernel, dim3(grid), dim3(64), lg[j].lds, j == 5 ? s1 : s2, A, La);
+				}
+				if(dbg) fprintf(stderr, "[kmahip] longtrace: lane class %d: %llu problems\n", j, cnt);
+				stage("lane class");
+				off += (size_t) cnt;
+			}
+		}
 		if(!dbg) {
 			for(int x = 0; x < 3; ++x) {
 				HIP_TRY(hipEventCreateWithFlags(&join[x], hipEventDisableTiming));
