@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 #include "dna_dev.h"
 #include <algorithm>
+#include <vector>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -45,11 +46,11 @@ constexpr int LT_XT_LDS = 2048;       // template rows staged in LDS there
 
 enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_TRIM = 16 };
 // counters of a longtrace pass: [1] status, [2] problem pool top, [3] run pool top (words), [4..20] class counts,
-// [21] DP cells, [22] MEMs of the chained strands (work figures), [23] problems in the lane queue, [24..30] of them per lane class,
-// [31] output run pool top
-constexpr int LT_LCLS = 7;            // lane classes (lt_lane_kernel): 0..4 full matrix with rows of up to 16 / 32 / 64 / 128 / 256 cells,
-                                      // 5, 6 banded with rows of up to 128 / 256
-enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_LANE = 23, LC_LCNT = 24, LC_OUT = 31, LC_N = 32 };
+// [21] DP cells, [22] MEMs of the chained strands (work figures), [23] problems in the lane queue, [24..] of them per lane class,
+// [LC_OUT] output run pool top
+constexpr int LT_LFULL = 6, LT_LCLS = 9;   // lane classes (lt_lane_kernel / lt_lane_band_kernel): 0..5 full matrix with rows of up to
+                                      // 16 / 32 / 48 / 64 / 128 / 256 cells, 6..8 banded with rows of up to 72 / 96 / 144 (lt_lane_geom)
+enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_LANE = 23, LC_LCNT = 24, LC_OUT = 24 + LT_LCLS, LC_N = 25 + LT_LCLS };
 
 struct LtRead {               // per read of the pass
 	int64_t first;            // first problem descriptor
@@ -110,6 +111,7 @@ struct LtArgs {
 	int32_t *lq;              // the lane queue: problem indices of all lane classes (prob_cap), sorted by lkey before the kernels run
 	uint32_t *lkey;           // (lane class << 24) | iterations of the problem's sweep
 	int stop;                 // diagnosis (KMAHIP_LT_STOP): 1 = reads end after their seeding, 2 = after the chain
+	int lane_mask;            // diagnosis (KMAHIP_LT_LANE=f / b): 1 = full-matrix classes only, 2 = banded only, 3 = both
 	int lane_tq;              // 0: no lane classes; else the largest rows + columns whose scores stay inside 16 bits
 	uint32_t *tmp;            // per finishing wavefront: tmp_cap words
 	int64_t tmp_cap;
@@ -559,17 +561,25 @@ __device__ __forceinline__ int lt_class(int q_l, int t_l, int band, int k, int64
 // 4096 << j bytes, up to 255 (j <= 2) / 511 template rows. *iters = turns of the problem's sweep.
 struct LaneGeom { int R, RQ, TW, ecap; };   // cells per row, query columns, template words (16 rows each), bytes of move matrix
 __host__ __device__ __forceinline__ LaneGeom lt_lane_geom(int j) {
+	// LDS per wavefront = (32 + 64 R + 64 TW) x 4 + 64 RQ (full matrix) or + 32 RQ (banded: two columns per byte) bytes, and a CU has
+	// 160 KB: 16 / 11 / 8 / 6 / 3 / 1 wavefronts per CU for the full-matrix classes, 6 / 4 / 2 for the banded ones -- the sweeps wait
+	// for LDS and for their own instructions' results, so the wavefronts per CU are what they run at
 	LaneGeom g;
-	if(j < 5) { g.R = 16 << j; g.RQ = g.R; g.TW = j < 3 ? 16 : 32; g.ecap = 4096 << j; }
-	else if(j == 5) { g.R = 80; g.RQ = 160; g.TW = 16; g.ecap = 20480; }
+	if(j < LT_LFULL) {
+		const int R[LT_LFULL] = {16, 32, 48, 64, 128, 256};
+		g.R = R[j]; g.RQ = g.R; g.TW = j < 4 ? 16 : 32; g.ecap = g.R * 256;
+	}
+	else if(j == LT_LFULL) { g.R = 72; g.RQ = 144; g.TW = 12; g.ecap = 72 * 192; }
+	else if(j == LT_LFULL + 1) { g.R = 96; g.RQ = 192; g.TW = 16; g.ecap = 96 * 256; }
 	else { g.R = 144; g.RQ = 256; g.TW = 32; g.ecap = 65536; }
 	return g;
 }
-__device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, int tq_max, int *iters) {
+__device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, int tq_max, int mask, int *iters) {
 	if(!tq_max || t_l + q_l > tq_max || t_l < 1 || q_l < 1) return -1;
+	if(!(mask & (band ? 2 : 1))) return -1;
 	if(band == 0) {
 		const int64_t e = (int64_t) (q_l + 1) * (t_l + 1) + 4;
-		for(int j = 0; j < 5; ++j) {
+		for(int j = 0; j < LT_LFULL; ++j) {
 			const LaneGeom g = lt_lane_geom(j);
 			if(q_l + 1 <= g.R && e <= g.ecap && t_l < 16 * g.TW) { *iters = (q_l + 1) * t_l; return j; }
 		}
@@ -580,7 +590,7 @@ __device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, 
 	const int cfin = ((t_l + q_l) >> 1) - (t_l - 1);
 	if(k == -2 && !(cfin + (band >> 1) < q_l - 1)) return -1;
 	const int64_t e = (int64_t) (band + 2) * (t_l + 1) + 4;
-	for(int j = 5; j < LT_LCLS; ++j) {
+	for(int j = LT_LFULL; j < LT_LCLS; ++j) {
 		const LaneGeom g = lt_lane_geom(j);
 		if(band + 3 <= g.R && q_l <= g.RQ && e <= g.ecap && t_l < 16 * g.TW) { *iters = (band + 2) * t_l; return j; }
 	}
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					}
 					// queues per class, one atomic per class and round
 					int l_iters = 0;
-					const int lcls = dp && rfit ? lt_lane_class(J.q_l, J.t_l, J.band, J.k, A.lane_tq, &l_iters) : -1;
+					const int lcls = dp && rfit ? lt_lane_class(J.q_l, J.t_l, J.band, J.k, A.lane_tq, A.lane_mask, &l_iters) : -1;
 					{
 						// the lane classes share one queue (sorted by class and sweep length before their kernels run)
 						const unsigned long long m = __ballot(lcls >= 0);
@@ -1365,15 +1375,16 @@ struct LaneArgs {
 	int R, RQ, TW;               // cells per row, query columns, template words per lane: the LDS geometry
 	uint8_t *E;                  // per workgroup 64 x ecap bytes of move matrix
 	int ecap;
+	int estride;                 // bytes between the lanes' stretches of E (ecap + room for the padding of lt_lane_kernel)
 	int ablate;                  // diagnosis (KMAHIP_LT_ABLATE): 1 no matrix stores, 2 no walk, 4 no sweep
 };
 
 __device__ __forceinline__ uint32_t lt_pack16(int D, int Pn) { return ((uint32_t) D & 0xffffu) | ((uint32_t) Pn << 16); }
-
 struct LaneProb { LtProb *P; int k, t_s, t_len, q_s, q_len, flags, band; bool live; };
 
 // a wavefront's next 64 problems: descriptors, the template rows into T (16 per word, first row in the top bits), the query
 // columns into QB (one byte each)
+template <bool QB4>
 __device__ __forceinline__ LaneProb lt_lane_stage(const LtArgs &A, const LaneArgs &L, unsigned long long base, int lane, uint32_t *T, uint8_t *QB) {
 	LaneProb X;
 	X.live = base + lane < L.count;
@@ -1406,23 +1417,30 @@ __device__ __forceinline__ LaneProb lt_lane_stage(const LtArgs &A, const LaneArg
 	const int q_max = wave_max(live ? q_len : 0);
 	for(int n0 = 0; n0 < q_max; n0 += 16) {
 		if(live && n0 < q_len) {
+			// sixteen columns, four bits each
+			uint64_t cw = 0;
 			if(q.nN == 0 && !q.rc) {
 				const uint64_t w = win2(q.w, q_s + n0);
-				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) ((w >> (62 - 2 * x)) & 3ull);
+				for(int x = 0; x < 16; ++x) cw |= ((w >> (62 - 2 * x)) & 3ull) << (4 * x);
 			} else if(q.nN == 0) {
 				// stored positions L - 1 - (q_s + n0 + x), complemented; the window starts at the lowest of them
 				int ps = q.L - 1 - (q_s + n0 + 15), sh = 0;
 				if(ps < 0) { sh = -ps; ps = 0; }
 				const uint64_t w = win2(q.w, ps);
-				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) (3 - (int) ((w >> (62 - 2 * (15 - x - sh))) & 3ull));
+				for(int x = 0; x < 16; ++x) if(15 - x - sh >= 0) cw |= (3ull - ((w >> (62 - 2 * (15 - x - sh))) & 3ull)) << (4 * x);
 			} else {
-				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) qn(q, q_s + n0 + x);
+				for(int x = 0; x < 16; ++x) if(n0 + x < q_len) cw |= (uint64_t) qn(q, q_s + n0 + x) << (4 * x);
 			}
+			if(QB4) { for(int x = 0; x < 16; x += 2) if(n0 + x < q_len) QB[((n0 + x) >> 1) * 64 + lane] = (uint8_t) ((cw >> (4 * x)) & 255ull); }
+			else for(int x = 0; x < 16; ++x) if(n0 + x < q_len) QB[(n0 + x) * 64 + lane] = (uint8_t) ((cw >> (4 * x)) & 15ull);
 		}
 	}
 	return X;
 }
 
+// SIMPLE: the score of a pair is one of three values (match, mismatch, N in the read), as in every scheme the reference's options
+// produce -- then it is computed instead of looked up
+template <bool SIMPLE>
 __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneArgs L) {
 	extern __shared__ uint32_t lt_lane_lds[];
 	int *const sd = (int *) lt_lane_lds;                         // 32 ints
@@ -1431,10 +1449,11 @@ __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneA
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64
 	const int lane = threadIdx.x;
 	if(lane < 25) sd[lane] = A.d[lane];
-	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.ecap;
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
 	const int U = A.U, W1 = A.W1;
+	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
 	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
-		const LaneProb X = lt_lane_stage(A, L, base, lane, T, QB);
+		const LaneProb X = lt_lane_stage<false>(A, L, base, lane, T, QB);
 		LtProb *P = X.P;
 		const bool live = X.live;
 		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
@@ -1442,52 +1461,84 @@ __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneA
 		const int low = (t_len + q_len) * (A.MM + U + W1);
 		const int q_max = wave_max(live ? q_len : 0);
 		if(live) QB[q_len * 64 + lane] = 0;
-		// the boundary row (m = t_len) and its move bytes; cells go out in descending address order, four to a store
-		int ea = pitch * (t_len + 1) - 1;
+		// Move bytes go out in descending address order, four to a store. All lanes emit one byte per turn from the first turn of
+		// the boundary row on (a lane with fewer columns than the widest starts with padding above its matrix), and every lane's
+		// matrix is shifted by up to three bytes so that its first byte is the top byte of a word: the store is then every fourth
+		// turn for all lanes alike, a scalar branch.
+		const int pad = q_max - q_len;
+		int ea = pitch * (t_len + 1) - 1 + pad;            // next byte, before the shift
+		const int delta = (3 - ea) & 3;
+		uint8_t *const Em = E + delta;                      // the lane's matrix
+		ea += delta;                                        // now in the coordinates of E; (ea & 3) == 3
 		uint32_t ew = 0;
 		for(int i = 0; i <= q_max; ++i) {
-			const int n = q_len - i;
-			if(live && n >= 0) {
+			const int n = q_max - i;
+			if(live) {
 				int D = 0, code = 0;
 				if(n < q_len && k != 2) { D = W1 + (q_len - 1 - n) * U; code = (n == q_len - 1) ? 18 : 3; }
-				DP[n * 64 + lane] = lt_pack16(D, low);
-				ew |= (uint32_t) code << ((ea & 3) << 3);
-				if((ea & 3) == 0) { *(uint32_t *) (E + ea) = ew; ew = 0; }
+				if(n <= q_len) DP[n * 64 + lane] = lt_pack16(D, low);
+				ew |= (uint32_t) code << ((3 - (i & 3)) << 3);
+				if((i & 3) == 3) { *(uint32_t *) (E + ea) = ew; ew = 0; }
 				--ea;
 			}
 		}
+		// the sweep. Per row: the template base, its five scores as bytes of two registers, the boundary column's value and code
 		int m = t_len - 1, n = q_len, right = 0, diag = 0, Qprev = low, score = low, best_m = 0;
+		int tb = 0, bnd = (0 < k) ? 0 : W1, bcode = (0 < k) ? 0 : 36;
+		uint32_t tw1 = 0;                                   // the template word of the row after this one
+		if(live) {
+			tb = (int) ((T[((m >> 4) << 6) + lane] >> (30 - ((m & 15) << 1))) & 3u);
+			tw1 = T[((max(m - 1, 0) >> 4) << 6) + lane];
+		}
 		const int iters = live && !(L.ablate & 4) ? pitch * t_len : 0;
 		const int it_max = wave_max(iters);
+		const int e0 = __builtin_amdgcn_readfirstlane(q_max + 1);
+		uint32_t below = live ? DP[n * 64 + lane] : 0u;
+		int qb = 0;
 		for(int it = 0; it < it_max; ++it) {
 			if(it < iters) {
-				const int li = n * 64 + lane;
-				const uint32_t below = DP[li];
-				const int qb = (int) QB[li];
-				const uint32_t tword = T[((m >> 4) << 6) + lane];
-				const int tb = (int) ((tword >> (30 - ((m & 15) << 1))) & 3u);
+				// what the next turn needs is asked for first: its cell of the row below and its query base
+				const bool isz = n == 0;
+				const int n1 = isz ? q_len : n - 1;
+				const uint32_t below1 = DP[n1 * 64 + lane];
+				const int qb1 = (int) QB[n1 * 64 + lane];
+				int sc;
+				if(SIMPLE) sc = qb == 4 ? dN : (tb == qb ? dM : dX);
+				else sc = sd[5 * tb + qb];
 				const int Db = (int) (short) (below & 0xffffu), Pb = ((int) below) >> 16;
-				int Q = right + W1, Pn = Db + W1, D, mv, cell = 0;
-				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int Q = right + W1, Pn = Db + W1;
+				int mv = Q < Pn ? 4 : 2;
+				int D = max(Q, Pn);
 				int x = Qprev + U;
-				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				const bool c1 = Q < x;
+				mv = (c1 && D <= x) ? 3 : mv;
+				int cell = c1 ? 0 : 16;
+				Q = max(Q, x); D = max(D, x);
 				x = Pb + U;
-				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
-				x = diag + sd[5 * tb + qb];
-				if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
-				if(n == q_len) {
-					// boundary column (nw.c:703-750)
-					D = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
-					Q = low;
-					cell = (0 < k) ? 0 : ((m == t_len - 1) ? 36 : 5);
-				}
-				DP[li] = lt_pack16(D, Pn);
-				ew |= (uint32_t) cell << ((ea & 3) << 3);
-				if((ea & 3) == 0) { if(!(L.ablate & 1)) *(uint32_t *) (E + ea) = ew; ew = 0; }
+				const bool c2 = Pn < x;
+				mv = (c2 && D <= x) ? 5 : mv;
+				cell |= c2 ? 0 : 32;
+				Pn = max(Pn, x); D = max(D, x);
+				x = diag + sc;
+				cell |= (D <= x) ? (tb != qb ? 65 : 1) : mv;
+				D = max(D, x);
+				const bool isb = n == q_len;
+				D = isb ? bnd : D; Q = isb ? low : Q; cell = isb ? bcode : cell;
+				DP[n * 64 + lane] = lt_pack16(D, Pn);
+				const int pos = 3 - ((e0 + it) & 3);
+				ew |= (uint32_t) cell << (pos << 3);
+				if(pos == 0 || it == iters - 1) { if(!(L.ablate & 1)) *(uint32_t *) (E + (ea & ~3)) = ew; ew = 0; }
 				--ea;
-				if(n == 0 && k < 0 && score < D) { score = D; best_m = m; }
+				if(isz && k < 0 && score < D) { score = D; best_m = m; }
 				diag = Db; right = D; Qprev = Q;
-				if(n == 0) { --m; n = q_len; } else --n;
+				if(isz) {
+					--m;
+					tb = (int) ((tw1 >> (30 - ((m & 15) << 1))) & 3u);
+					tw1 = T[((max(m - 1, 0) >> 4) << 6) + lane];
+					bnd = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U);
+					bcode = (0 < k) ? 0 : 5;
+				}
+				n = n1; below = below1; qb = qb1;
 			}
 		}
 		// result selection (nw.c:218-254)
@@ -1506,7 +1557,7 @@ __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneA
 			RunOut R;
 			R.init(A.runs + P->runs, t_len + q_len + 1);
 			int clip = sn, bad = 0;
-			const int q_pos = lt_walk((const uint8_t *) E, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int q_pos = lt_walk((const uint8_t *) Em, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
 			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : R.n;
@@ -1520,6 +1571,7 @@ __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneA
 // place. Per row: the cell to the right of the band (virtual, D = low; or the boundary column where the band reaches it), the
 // band's cells, and the leftmost one, which has no template-gap state. Rows are cut at the matrix' first and last column (`en`
 // leading indices unused once the band has reached column 0).
+template <bool SIMPLE>
 __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const LaneArgs L) {
 	extern __shared__ uint32_t lt_lane_lds[];
 	int *const sd = (int *) lt_lane_lds;
@@ -1528,11 +1580,12 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);
 	const int lane = threadIdx.x;
 	if(lane < 25) sd[lane] = A.d[lane];
-	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.ecap;
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
 	const int U = A.U, W1 = A.W1;
+	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
 	constexpr int NEG = -(1 << 28);
 	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
-		const LaneProb X = lt_lane_stage(A, L, base, lane, T, QB);
+		const LaneProb X = lt_lane_stage<true>(A, L, base, lane, T, QB);
 		LtProb *P = X.P;
 		const bool live = X.live;
 		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
@@ -1562,53 +1615,76 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 				emit(pitch * t_len + n, code);
 			}
 		}
-		// row state: en = first index in use, sn = last band cell, the cell at sn + 1 opens the row
-		int m = t_len - 1, en = 0, sn, n, qcol0;          // qcol0 = column of index 0 = c - half
-		bool clipped;                                      // the band reaches the last column: index sn + 1 is the boundary column
-		auto open_row = [&]() {
-			int sq = c + half, eq = c - half;
-			if(eq < 0) { eq = 0; ++en; } else en = 0;
-			if(sq < q_len - 1) { sn = bq - 1; clipped = false; }
-			else { sn = en + (q_len - eq) - 1; clipped = true; }
-			qcol0 = c - half;
-			n = sn + 1;
+		// row state: en = first index in use, sn = last band cell, the cell at sn + 1 opens the row; qcol0 = column of index 0;
+		// clipped: the band reaches the last column, index sn + 1 is the boundary column
+		int m = t_len - 1, en = 0, sn = 0, n = 0, qcol0 = 0;
+		bool clipped = false;
+		auto open_row = [&](int cc, int &en_, int &sn_, int &n_, int &qcol0_, bool &clipped_) {
+			int sq = cc + half, eq = cc - half;
+			if(eq < 0) { eq = 0; ++en_; } else en_ = 0;
+			if(sq < q_len - 1) { sn_ = bq - 1; clipped_ = false; }
+			else { sn_ = en_ + (q_len - eq) - 1; clipped_ = true; }
+			qcol0_ = cc - half;
+			n_ = sn_ + 1;
 		};
-		open_row();
+		open_row(c, en, sn, n, qcol0, clipped);
 		int right = 0, diag = 0, Qprev = low, score = low, bm = 0, bn = 0;
+		// per row: the template base, what the cell to the right of the band holds
+		int tb = 0, fD = 0, fcode = 0;
+		uint32_t tw1 = 0;
+		if(live) {
+			tb = (int) ((T[((m >> 4) << 6) + lane] >> (30 - ((m & 15) << 1))) & 3u);
+			tw1 = T[((max(m - 1, 0) >> 4) << 6) + lane];
+			if(clipped) { fD = (0 < k) ? 0 : W1; fcode = (0 < k) ? 0 : 37; } else { fD = low; fcode = 37; }
+		}
 		const int it_max = wave_max(live && !(L.ablate & 4) ? pitch * t_len : 0);
+		uint32_t below = live ? DP[max(n - 1, 0) * 64 + lane] : 0u;
+		auto qcode = [&](int col) { col = min(max(col, 0), q_len - 1); return (int) ((QB[(col >> 1) * 64 + lane] >> ((col & 1) << 2)) & 15u); };
+		int qb = live ? qcode(qcol0 + n) : 0;
 		for(int it = 0; it < it_max; ++it) {
 			if(live && m >= 0) {
-				const uint32_t below = DP[max(n - 1, 0) * 64 + lane];
-				const int qcol = min(max(qcol0 + n, 0), q_len - 1);
-				const int qb = (int) QB[qcol * 64 + lane];
-				const uint32_t tword = T[((m >> 4) << 6) + lane];
-				const int tb = (int) ((tword >> (30 - ((m & 15) << 1))) & 3u);
+				// the next turn's place first (a new row behind the leftmost cell), then what it needs from LDS
 				const bool edge = n == en, first = n == sn + 1;
+				int en1 = en, sn1 = sn, n1 = n - 1, qcol01 = qcol0;
+				bool clipped1 = clipped;
+				if(edge && m > 0) open_row(c - 1, en1, sn1, n1, qcol01, clipped1);    // (behind the first row `en` stays: the result is read off it)
+				const uint32_t below1 = DP[max(n1 - 1, 0) * 64 + lane];
+				const int qb1 = qcode(qcol01 + n1);
+				int sc;
+				if(SIMPLE) sc = qb == 4 ? dN : (tb == qb ? dM : dX);
+				else sc = sd[5 * tb + qb];
 				const int Dbl = (int) (short) (below & 0xffffu);
 				const int Db = edge ? NEG : Dbl, Pb = edge ? NEG : ((int) below) >> 16;
-				int Q = right + W1, Pn = Db + W1, D, mv, cell = 0;
-				if(Q < Pn) { D = Pn; mv = 4; } else { D = Q; mv = 2; }
+				int Q = right + W1, Pn = Db + W1;
+				int mv = Q < Pn ? 4 : 2;
+				int D = max(Q, Pn);
 				int x = Qprev + U;
-				if(Q < x) { Q = x; if(D <= x) { D = x; mv = 3; } } else cell |= 16;
+				const bool c1 = Q < x;
+				mv = (c1 && D <= x) ? 3 : mv;
+				int cell = c1 ? 0 : 16;
+				Q = max(Q, x); D = max(D, x);
 				x = Pb + U;
-				if(Pn < x) { Pn = x; if(D <= x) { D = x; mv = 5; } } else cell |= 32;
-				x = diag + sd[5 * tb + qb];
-				if(D <= x) { D = x; cell |= 1 | (tb != qb ? 64 : 0); } else cell |= mv;
-				if(edge) { cell &= ~32; Pn = low; }
-				if(first) {
-					// to the right of the band: a virtual cell, or the boundary column (nw.c:470-500)
-					if(clipped) { D = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U); cell = (0 < k) ? 0 : 37; }
-					else { D = low; cell = 37; }
-					Q = low; Pn = low;
-				}
+				const bool c2 = Pn < x;
+				mv = (c2 && D <= x) ? 5 : mv;
+				cell |= (c2 || edge) ? 0 : 32;
+				Pn = edge ? low : max(Pn, x); D = max(D, x);
+				x = diag + sc;
+				cell |= (D <= x) ? (tb != qb ? 65 : 1) : mv;
+				D = max(D, x);
+				// to the right of the band: a virtual cell, or the boundary column (nw.c:470-500)
+				D = first ? fD : D; cell = first ? fcode : cell; Q = first ? low : Q; Pn = first ? low : Pn;
 				DP[n * 64 + lane] = lt_pack16(D, Pn);
 				emit(pitch * m + n, cell);
 				diag = Dbl; right = D; Qprev = Q;
 				if(edge) {
 					if(qcol0 + en == 0 && k < 0 && score < D) { score = D; bm = m; bn = n; }
 					--m; --c;
-					if(m >= 0) open_row();
-				} else --n;
+					tb = (int) ((tw1 >> (30 - ((m & 15) << 1))) & 3u);
+					tw1 = T[((max(m - 1, 0) >> 4) << 6) + lane];
+					if(clipped1) { fD = (0 < k) ? 0 : (W1 + (t_len - 1 - m) * U); fcode = (0 < k) ? 0 : 37; } else { fD = low; fcode = 37; }
+				}
+				en = en1; sn = sn1; n = n1; qcol0 = qcol01; clipped = clipped1;
+				below = below1; qb = qb1;
 			}
 		}
 		if(ea >= 0 && !(L.ablate & 1)) *(uint32_t *) (E + (ea & ~3)) = ew;
@@ -1797,15 +1873,22 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		const char *e = getenv("KMAHIP_LT_LANE");
 		if(!(e && e[0] == '0')) lane_tq = 32000 / (abs(p->rw.MM + p->rw.U + p->rw.W1) + 2 * mx + 1);
 	}
+	// three scores only (match, mismatch, N in the read)? Then the lane kernels compute the score of a pair
+	bool simple_sc = true;
+	for(int i = 0; i < 4; ++i) for(int j = 0; j < 5; ++j) {
+		const int want = j == 4 ? p->rw.d[0][4] : (i == j ? p->rw.d[0][0] : p->rw.d[0][1]);
+		if(p->rw.d[i][j] != want) simple_sc = false;
+	}
+	if(getenv("KMAHIP_LT_SCORE_TABLE")) simple_sc = false;
 	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
 	LaneLaunch lg[LT_LCLS];
 	size_t lane_e_bytes = 0;
 	for(int j = 0; j < LT_LCLS; ++j) {
 		lg[j].g = lt_lane_geom(j);
-		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 64;
+		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * (j < LT_LFULL ? 64 : 32);
 		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
 		lg[j].e_off = lane_e_bytes;
-		lane_e_bytes += (size_t) lg[j].wgs * 64 * (size_t) lg[j].g.ecap;
+		lane_e_bytes += (size_t) lg[j].wgs * 64 * (size_t) (lg[j].g.ecap + 288);
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
 	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
@@ -1841,7 +1924,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if((rc = lt_reserve(ws, 1, (size_t) B * sizeof(LtRead))) || (rc = lt_reserve(ws, 2, (size_t) prob_cap * sizeof(LtProb))) ||
 		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4)) ||
 		   (lane_tq && (rc = lt_reserve(ws, 8, (size_t) 4 * prob_cap * 4)))) return rc;
-		A.lq = (int32_t *) ws->lt_buf[8]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[8] + prob_cap : nullptr; A.lane_tq = lane_tq;
+		A.lq = (int32_t *) ws->lt_buf[8]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[8] + prob_cap : nullptr; A.lane_tq = lane_tq; A.lane_mask = getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'f' ? 1 : (getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'b' ? 2 : 3);
 		A.r0 = r0; A.n_reads = nb;
 		A.rd = (LtRead *) ws->lt_buf[1]; A.prob = (LtProb *) ws->lt_buf[2]; A.prob_cap = prob_cap;
 		A.runs = (uint32_t *) ws->lt_buf[3]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[4];
@@ -1910,9 +1993,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			int32_t *vals_in = A.lq;
 			vals_out = (int32_t *) ws->lt_buf[8] + 2 * prob_cap;
 			size_t tmp_bytes = 0;
-			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 27u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
+			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
 			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, lane_e_bytes))) return rc;
-			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 27u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
+			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 			stage("lane sort");
 		}
 		static hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -1947,18 +2030,24 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				const unsigned long long cnt = c[LC_LCNT + j];
 				if(!cnt) continue;
 				LaneArgs La;
-				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap;
+				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap; La.estride = lg[j].g.ecap + 288;
 				La.E = (uint8_t *) ws->lt_buf[10] + lg[j].e_off;
 				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
 				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
-				if(j < 5) {
-					if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *) lt_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
-					hipLaunchKernelGGL(lt_lane_kernel, dim3(grid), dim3(64), lg[j].lds, j <= 2 ? stream : (j == 3 ? s2 : s3), A, La);
-				} else {
-					if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *) lt_lane_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
-					hipLaunchKernelGGL(lt_lane_band_kernel, dim3(grid), dim3(64), lg[j].lds, j == 5 ? s1 : s2, A, La);
+				const hipStream_t ls = j <= 3 ? stream : (j == LT_LFULL ? s1 : ((j == 5 || j == LT_LCLS - 1) ? s3 : s2));
+				const void *fn = j < LT_LFULL ? (simple_sc ? (const void *) lt_lane_kernel<true> : (const void *) lt_lane_kernel<false>)
+				                       : (simple_sc ? (const void *) lt_lane_band_kernel<true> : (const void *) lt_lane_band_kernel<false>);
+				if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
+				if(j < LT_LFULL) { if(simple_sc) hipLaunchKernelGGL(lt_lane_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
+				else { if(simple_sc) hipLaunchKernelGGL(lt_lane_band_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_band_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
+				if(dbg) {
+					std::vector<uint32_t> hk((size_t) cnt);
+					(void) hipMemcpy(hk.data(), (uint32_t *) ws->lt_buf[8] + 3 * prob_cap + off, (size_t) cnt * 4, hipMemcpyDeviceToHost);
+					unsigned long long turns = 0, rounds = 0;
+					for(size_t x = 0; x < hk.size(); ++x) { turns += hk[x] & 0xFFFFFFu; if(x % 64 == 0) rounds += hk[x] & 0xFFFFFFu; }
+					fprintf(stderr, "[kmahip] longtrace: lane class %d: %llu problems, %llu turns of their sweeps, %llu turns of the wavefronts (x 64 = %.2f of them used), longest %u\n",
+					        j, cnt, turns, rounds, rounds ? (double) turns / (64.0 * rounds) : 0.0, hk.empty() ? 0u : hk[0] & 0xFFFFFFu);
 				}
-				if(dbg) fprintf(stderr, "[kmahip] longtrace: lane class %d: %llu problems\n", j, cnt);
 				stage("lane class");
 				off += (size_t) cnt;
 			}
