@@ -582,9 +582,14 @@ __device__ void pile_template(const PileArgs &A, const Walk<LDS> &W, int64_t s0,
 __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, int64_t n_ent, int lds_cols) {
 	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
 	__shared__ unsigned s_nodes;
+	__shared__ int s_abort;
 	__shared__ long long s_pool;
 	const int tid = threadIdx.x;
 	for(int64_t u = blockIdx.x; u < A.n_units; u += gridDim.x) {
+		// a unit ran out of room somewhere: the host starts again with other sizes (one thread looks, so that all leave together)
+		if(tid == 0) s_abort = ld_l2(&A.counters[1]) != 0 ? 1 : 0;
+		__syncthreads();
+		if(s_abort) break;
 		const int64_t s0 = A.unit_start[u];
 		if(s0 >= n_ent) continue;
 		const int64_t s1 = A.unit_end[u];          // (the sorted list is unit-major)
@@ -598,7 +603,14 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			for(int i = tid; i < 7 * ncol; i += (int) blockDim.x) pile_lds[i] = 0;
 			if(tid == 0) s_nodes = 0;
 			__syncthreads();
-			for(int64_t e = s0; e < s1; ++e) pile_seg_read(A, W, (int64_t) A.vals[e], (int) u, s_ins);
+			for(int64_t e = s0; e < s1; ++e) {
+				if(((e - s0) & 63) == 63) {
+					if(tid == 0) s_abort = ld_l2(&A.counters[1]) != 0 ? 1 : 0;
+					__syncthreads();
+					if(s_abort) break;
+				}
+				pile_seg_read(A, W, (int64_t) A.vals[e], (int) u, s_ins);
+			}
 			const int n_nodes = min((int) s_nodes, W.node_cap());
 			if(tid == 0) s_pool = n_nodes ? (long long) atomicAdd(&A.counters[2], (unsigned long long) n_nodes) : 0;
 			__syncthreads();
@@ -878,6 +890,16 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 	const int split_cols = (PILE_LDS_WORDS - 8 * PILE_LDS_MIN_NODES) / 7;
 	int lds_cols = getenv("KMAHIP_PILE_NO_LDS") ? 0 : split_cols;
 	int seg_cols = getenv("KMAHIP_PILE_SEG_COLS") ? atoi(getenv("KMAHIP_PILE_SEG_COLS")) : 1024;
+	if(!getenv("KMAHIP_PILE_SEG_COLS")) {
+		// a deep pile-up has a few insertion columns at every site, and they must fit beside the unit's columns in HALF the LDS (two
+		// workgroups per CU are worth more than long units): shorter units from the start where the depth can be that large
+		int64_t long_cols = 0;
+		for(int64_t t = 1; t < D; ++t) if(db->h_tlen[(size_t) t] > split_cols) long_cols += db->h_tlen[(size_t) t];
+		if(long_cols > 0) {
+			const double depth = (double) n * (double) std::max(reads->max_len, 1) / (double) long_cols;
+			while(seg_cols > 256 && depth * seg_cols > 1.2e6) seg_cols >>= 1;
+		}
+	}
 	unsigned long long c[3] = {0, 0, 0};
 	bool lds_half = !getenv("KMAHIP_PILE_FULL_LDS");
 	for(;;) {
@@ -981,6 +1003,7 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		(void) hipFree(tmp); tmp = nullptr;
 		lap("pileup_kernel");
 		HIP_TRY(hipMemcpy(c, ws->counters, sizeof c, hipMemcpyDeviceToHost));
+		if(c[1] == 64 && half && seg_cols > 256) { seg_cols >>= 1; if(dbg) fprintf(stderr, "[kmahip] pile-up: a segment ran out of its half of the LDS, again with %d columns per segment\n", seg_cols); continue; }
 		if((c[1] == 16 || c[1] == 64) && half) { lds_half = false; if(dbg) fprintf(stderr, "[kmahip] pile-up: half the LDS did not hold a unit's insertion columns, again with all of it\n"); continue; }
 		if(c[1] == 64 && seg_cols > 64) { seg_cols >>= 1; if(dbg) fprintf(stderr, "[kmahip] pile-up: a segment ran out of LDS room, again with %d columns per segment\n", seg_cols); continue; }
 		if(c[1] == 16 && lds_cols) { lds_cols = 0; continue; }      // a template's insertion columns did not fit LDS: those on HBM
