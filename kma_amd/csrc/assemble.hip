@@ -23,6 +23,24 @@ namespace {
 
 struct InsNode { uint32_t c[6]; int32_t next; int32_t gaps; };   // next: following column of the chain (0 = none), gaps: template position after the chain
 
+// a read's visit to a unit, ready to use: the unit's workgroups take their reads one after the other, and what a visit needs first --
+// the read's figures, its checkpoint, where its runs and bases lie: four levels of dependent loads -- is gathered for all visits at
+// once by pile_desc_kernel, a thread per visit; the workgroup then loads one record (the next visit's, while it works on this one)
+struct VisitDesc {
+	int64_t o;                   // first run of the read in `ops`
+	int64_t qw;                  // first word of the read in `seq`
+	int64_t Noff;                // first N position in `N`
+	int32_t n, first;            // runs [first, n) are piled up (gap runs at either end trimmed)
+	int32_t j_begin;             // run to start from, with the template columns / read bases in front of it:
+	int32_t col_carry, q_carry;
+	int32_t start;               // first template column of run `first`
+	int32_t L, nN;
+	int32_t flags;               // 1: reverse complement, 2: runs behind the unit need not be looked at
+	int32_t pad;
+};
+
+static_assert(sizeof(VisitDesc) == 64, "a visit record is sixteen words");
+
 struct PileArgs {
 	DevDB db;
 	int64_t n_reads;
@@ -63,6 +81,7 @@ struct PileArgs {
 	// columns and read bases before that run (pile_ckpt_kernel). Without it every one of the ~10 units a 10 kb read touches scans
 	// all of its ~3 000 runs.
 	int32_t *ck_j, *ck_col, *ck_q;
+	struct VisitDesc *desc;      // per sorted entry of a unit of a cut template: what its workgroup needs to start on the read (pile_desc_kernel)
 	int64_t *unit_start;         // n_units + 1: first entry of the sorted list per unit (n_entries if none)
 	int64_t *unit_end;           // n_units: one past its last entry (read only where unit_start < n_entries)
 	int lds_words;               // LDS words a workgroup has (PILE_LDS_WORDS, or half of it so that two workgroups share a CU)
@@ -301,6 +320,37 @@ __global__ __launch_bounds__(256) void pile_segments_kernel(const uint64_t *keys
 	if(i + 1 == n_ent || (int64_t) (keys[i + 1] >> 28) != u) unit_end[u] = i + 1;
 }
 
+// one thread per sorted entry: the visit's record (only for units of templates that are cut into units)
+__global__ __launch_bounds__(256) void pile_desc_kernel(const PileArgs A, int64_t n_ent) {
+	const int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(e >= n_ent) return;
+	const int64_t r = A.vals[e];
+	const int unit = (int) (A.keys[e] >> 28);
+	const int t = abs(A.tmpl[r]);
+	const int ub = A.unit_base[t];
+	if(A.unit_base[t + 1] - ub <= 1) return;
+	const ReadRuns R = read_runs(A, r);
+	const int t_len = A.db.tlen[t];
+	VisitDesc D;
+	D.o = R.o; D.qw = A.seq_off[r]; D.Noff = A.N_off[r];
+	D.n = R.n; D.first = R.first; D.L = R.q.L; D.nN = R.q.nN;
+	int start = R.start;
+	if(start >= t_len) start -= t_len;
+	D.start = start;
+	D.j_begin = R.first; D.col_carry = 0; D.q_carry = R.qp;
+	D.flags = R.q.rc ? 1 : 0; D.pad = 0;
+	// where this unit's stretch of the read begins (pile_ckpt_kernel); a read that wraps round the template's end has no checkpoints
+	const int u0 = ub + start / A.seg_cols;
+	const int32_t *st = A.stats + 10 * r;
+	const int span = st[3] - st[7] - R.lead_d - R.trail_d;
+	if(A.ck_j && start + span <= t_len && unit >= u0) {
+		const int64_t slot = A.vis_off[r] + (unit - u0);
+		D.j_begin = A.ck_j[slot]; D.col_carry = A.ck_col[slot]; D.q_carry = A.ck_q[slot];
+		D.flags |= 2;
+	}
+	A.desc[e] = D;
+}
+
 __global__ __launch_bounds__(256) void pile_fill_kernel(int64_t *p, int64_t n, int64_t v) {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(i < n) p[i] = v;
@@ -327,7 +377,9 @@ struct SegWalk {
 		return (p == (lo ? lo - 1 : t_len - 1)) ? 0 : -1;
 	}
 	__device__ __forceinline__ int node_base() const { return 7 * ncol; }
-	__device__ __forceinline__ int node_cap() const { return min((A.lds_words - 7 * ncol) / 8, A.lds_node_limit); }
+	// (the last 3 words per thread of the LDS hold the round's runs: first template column, first read base, the run itself)
+	__device__ __forceinline__ int run_base() const { return A.lds_words - 3 * (int) blockDim.x; }
+	__device__ __forceinline__ int node_cap() const { return min((run_base() - 7 * ncol) / 8, A.lds_node_limit); }
 	__device__ __forceinline__ int head(int c) const { return (int) pile_lds[6 * ncol + c]; }
 	__device__ __forceinline__ void set_head(int c, int id) const { pile_lds[6 * ncol + c] = (uint32_t) id; }
 	__device__ __forceinline__ int next(int h) const { return (int) pile_lds[node_base() + 8 * (h - 1) + 6]; }
@@ -361,60 +413,63 @@ __device__ uint64_t block_scan2(uint64_t v, unsigned long long *s_w, uint64_t *t
 	return base + x - v;
 }
 
-__device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, int unit, unsigned long long *s_w) {
+__device__ __forceinline__ void pile_seg_read(const PileArgs &A, const SegWalk &W, const VisitDesc &V, uint32_t pre_run, uint32_t pre_prun, uint32_t pre_nrun, unsigned long long *s_w) {
 	const int tid = threadIdx.x;
-	ReadRuns R = read_runs(A, r);
-	int start = R.start;
-	if(start >= W.t_len) start -= W.t_len;
-	int64_t col_carry = 0, q_carry = R.qp;
-	// where this unit's stretch of the read begins (pile_ckpt_kernel); a read that wraps round the template's end has no checkpoints
-	int j_begin = R.first;
-	bool ends_early = false;
-	{
-		const int ub = A.unit_base[abs(A.tmpl[r])];
-		const int u0 = ub + start / A.seg_cols;
-		const int32_t *st = A.stats + 10 * r;
-		const int span = st[3] - st[7] - R.lead_d - R.trail_d;
-		if(A.ck_j && start + span <= W.t_len && unit >= u0) {
-			const int64_t slot = A.vis_off[r] + (unit - u0);
-			j_begin = A.ck_j[slot]; col_carry = A.ck_col[slot]; q_carry = A.ck_q[slot];
-			ends_early = true;
-		}
-	}
+	ReadRuns R;
+	R.o = V.o; R.n = V.n; R.first = V.first;
+	R.q.w = A.seq + V.qw; R.q.L = V.L; R.q.N = A.N + V.Noff; R.q.nN = V.nN; R.q.rc = V.flags & 1; R.q.cw = -1; R.q.cv = 0;
+	const int start = V.start;
+	int64_t col_carry = V.col_carry, q_carry = V.q_carry;
+	const int j_begin = V.j_begin;
+	const bool ends_early = (V.flags & 2) != 0;
 	for(int j0 = j_begin; j0 < R.n; j0 += (int) blockDim.x) {
 		if(ends_early && start + col_carry > (int64_t) W.hi) break;          // (every further run lies behind the unit)
 		const int j = j0 + tid;
 		const bool valid = j < R.n;
-		const uint32_t run = valid ? A.ops[R.o + j] : 0u;
+		const bool pre = j0 == j_begin;                 // the first round's runs were asked for during the visit before
+		const uint32_t run = valid ? (pre ? pre_run : A.ops[R.o + j]) : 0u;
 		const int cls = (int) (run & 3u), len = (int) (run >> 2);
 		const uint64_t mine = valid ? (((uint64_t) (cls != 2 ? len : 0) << 32) | (uint64_t) (cls != 3 ? len : 0)) : 0ull;
 		uint64_t total;
 		const uint64_t ex = block_scan2(mine, s_w, &total);
 		const int64_t col0 = col_carry + (int64_t) (ex >> 32), q0 = q_carry + (int64_t) (ex & 0xFFFFFFFFull);
 		col_carry += (int64_t) (total >> 32); q_carry += (int64_t) (total & 0xFFFFFFFFull);
-		const uint32_t prun = (valid && j > R.first) ? A.ops[R.o + j - 1] : 0u;
-		const bool prevI = valid && j > R.first && (prun & 3u) == 2u;
-		// ---- phase 1: the columns of this run inside the unit. The run covers the positions p0 .. p0 + len - 1 (p0 < t_len, so it
-		// wraps at most once); the unit's interval [lo - 1, hi - 1] (without lo - 1 for the first unit) is met directly, after the
-		// wrap, and the first unit also counts the ring's last position
-		if(valid && cls != 2 && len > 0) {
-			const int64_t p0 = (start + col0) % W.t_len;
-			const int64_t ulo = W.lo ? W.lo - 1 : 0, uhi = W.hi - 1;
-			int64_t ia[3], ib[3];
-			ia[0] = ulo - p0; ib[0] = uhi - p0;
-			ia[1] = ulo + W.t_len - p0; ib[1] = uhi + W.t_len - p0;
-			ia[2] = 1; ib[2] = 0;
-			if(W.lo == 0 && W.hi < W.t_len) { ia[2] = ib[2] = W.t_len - 1 - p0; }
-			for(int x = 0; x < 3; ++x) {
-				const int64_t ca = ia[x] < 0 ? 0 : ia[x], cb = ib[x] >= len ? len - 1 : ib[x];
-				for(int64_t c = ca; c <= cb; ++c) {
-					if(c == 0 && prevI) continue;
-					const int64_t col = col0 + c;
-					const int ci = W.ci((int) ((p0 + c) % W.t_len));
-					if(ci < 0) continue;
-					W.add_col(ci, cls == 3 ? 5 : q_base(R.q, (int) (q0 + c)));
-					if(col > 0 && ci >= 1) for(int h = W.head(ci); h; h = W.next(h)) W.add_node(h, 5);
-				}
+		const uint32_t prun = (valid && j > R.first) ? (pre ? pre_prun : A.ops[R.o + j - 1]) : 0u;
+		// ---- phase 1: the unit's columns the round's runs cover, a thread per COLUMN (a thread per run waits for the longest run: sixty
+		// columns, each with its chain of insertion columns to walk). The runs' first columns / bases go to LDS, a column finds its run
+		// by bisection. Column index ci: 0 = the column in front of the unit (the ring's last one for the first unit of a template
+		// that is not one unit), 1 .. = lo ..
+		{
+			uint32_t *rc0 = pile_lds + W.run_base(), *rq0 = rc0 + blockDim.x, *rrun = rq0 + blockDim.x;
+			const int64_t colA = col_carry - (int64_t) (total >> 32);
+			rc0[tid] = valid ? (uint32_t) (col0 - colA) : 0xFFFFFFFFu;
+			rq0[tid] = (uint32_t) q0;
+			rrun[tid] = run;
+			__syncthreads();
+			const int nr = min((int) blockDim.x, R.n - j0);
+			const uint32_t prev0 = j0 > R.first ? A.ops[R.o + j0 - 1] : 0u;       // the run in front of the round's first
+			const int64_t span = col_carry - colA;
+			for(int ci = tid; ci < W.ncol; ci += (int) blockDim.x) {
+				int p;
+				if(ci >= 1) p = W.lo + ci - 1;
+				else if(W.lo) p = W.lo - 1;
+				else if(W.hi < W.t_len) p = W.t_len - 1;
+				else continue;
+				int64_t rel = (int64_t) p - start;
+				if(rel < 0) rel += W.t_len;
+				rel -= colA;
+				if(rel < 0 || rel >= span) continue;
+				// last run that begins at or before the column (a run without template columns shares its column with the run behind it)
+				int a = 0, bnd = nr;
+				while(bnd - a > 1) { const int mid = (a + bnd) >> 1; if((int64_t) rc0[mid] <= rel) a = mid; else bnd = mid; }
+				const uint32_t rj = rrun[a];
+				const int rcls = (int) (rj & 3u);
+				if(rcls == 2) continue;
+				const int c = (int) (rel - (int64_t) rc0[a]);
+				const uint32_t pj = a ? rrun[a - 1] : prev0;
+				if(c == 0 && (j0 + a) > R.first && (pj & 3u) == 2u) continue;      // the first column behind an insertion run: phase 2b
+				W.add_col(ci, rcls == 3 ? 5 : q_base(R.q, (int) ((int64_t) (int32_t) rq0[a] + c)));
+				if(rel + colA > 0 && ci >= 1) for(int h = W.head(ci); h; h = W.next(h)) W.add_node(h, 5);
 			}
 		}
 		__syncthreads();
@@ -457,7 +512,7 @@ __device__ void pile_seg_read(const PileArgs &A, const SegWalk &W, int64_t r, in
 		__syncthreads();
 		// ---- phase 2b: the column behind the insertion (first element of the next run; there is one: trailing gap runs are trimmed)
 		if(site >= 0) {
-			const int ncls = j + 1 < R.n ? (int) (A.ops[R.o + j + 1] & 3u) : 0;
+			const int ncls = j + 1 < R.n ? (int) ((pre ? pre_nrun : A.ops[R.o + j + 1]) & 3u) : 0;
 			W.add_col(site, ncls == 3 ? 5 : q_base(R.q, qafter));
 		}
 		__syncthreads();
@@ -583,6 +638,7 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 	__shared__ unsigned long long s_ins[PILE_THREADS / 64];
 	__shared__ unsigned s_nodes;
 	__shared__ int s_abort;
+	__shared__ VisitDesc s_desc[3];
 	__shared__ long long s_pool;
 	const int tid = threadIdx.x;
 	for(int64_t u = blockIdx.x; u < A.n_units; u += gridDim.x) {
@@ -603,13 +659,33 @@ __global__ __launch_bounds__(PILE_THREADS) void pileup_kernel(const PileArgs A, 
 			for(int i = tid; i < 7 * ncol; i += (int) blockDim.x) pile_lds[i] = 0;
 			if(tid == 0) s_nodes = 0;
 			__syncthreads();
+			// the visits in order. Three records in LDS: this visit's, the next one's (whose first runs every thread asks for now) and
+			// the one after that (on its way from HBM)
+			const uint32_t *dsrc = (const uint32_t *) (A.desc + s0);
+			uint32_t *dlds = (uint32_t *) s_desc;
+			if(tid < 32 && s0 + (tid >> 4) < s1) dlds[tid] = dsrc[tid];
+			__syncthreads();
+			uint32_t run0 = 0, prun0 = 0, nrun0 = 0;
+			{
+				const VisitDesc &V0 = s_desc[0];
+				const int j = V0.j_begin + tid;
+				if(j < V0.n) { run0 = A.ops[V0.o + j]; if(j > V0.first) prun0 = A.ops[V0.o + j - 1]; if(j + 1 < V0.n) nrun0 = A.ops[V0.o + j + 1]; }
+			}
 			for(int64_t e = s0; e < s1; ++e) {
-				if(((e - s0) & 63) == 63) {
-					if(tid == 0) s_abort = ld_l2(&A.counters[1]) != 0 ? 1 : 0;
-					__syncthreads();
-					if(s_abort) break;
+				const int cur = (int) ((e - s0) % 3), nxt = (cur + 1) % 3, aft = (cur + 2) % 3;
+				uint32_t dreg = 0, run1 = 0, prun1 = 0, nrun1 = 0;
+				if(tid < 16 && e + 2 < s1) dreg = dsrc[(e + 2 - s0) * 16 + tid];
+				if(e + 1 < s1) {
+					const VisitDesc &V1 = s_desc[nxt];
+					const int j = V1.j_begin + tid;
+					if(j < V1.n) { run1 = A.ops[V1.o + j]; if(j > V1.first) prun1 = A.ops[V1.o + j - 1]; if(j + 1 < V1.n) nrun1 = A.ops[V1.o + j + 1]; }
 				}
-				pile_seg_read(A, W, (int64_t) A.vals[e], (int) u, s_ins);
+				pile_seg_read(A, W, s_desc[cur], run0, prun0, nrun0, s_ins);
+				if(tid < 16 && e + 2 < s1) dlds[aft * 16 + tid] = dreg;
+				if(tid == 0 && ((e - s0) & 63) == 63) s_abort = ld_l2(&A.counters[1]) != 0 ? 1 : 0;
+				__syncthreads();
+				if(s_abort) break;
+				run0 = run1; prun0 = prun1; nrun0 = nrun1;
 			}
 			const int n_nodes = min((int) s_nodes, W.node_cap());
 			if(tid == 0) s_pool = n_nodes ? (long long) atomicAdd(&A.counters[2], (unsigned long long) n_nodes) : 0;
@@ -983,7 +1059,15 @@ static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads
 		A.keys = keys_out; A.vals = vals_out;
 		hipLaunchKernelGGL(pile_fill_kernel, dim3((unsigned) ((n_units + 1 + 255) / 256)), dim3(256), 0, stream, d_ustart, n_units + 1, n_ent);
 		hipLaunchKernelGGL(pile_segments_kernel, dim3((unsigned) ((n_ent + 255) / 256)), dim3(256), 0, stream, keys_out, n_ent, d_ustart, d_ustart + n_units + 2);
-		lap("sort + segments");
+		A.desc = nullptr;
+		if(n_units > (int64_t) D - 1) {
+			VisitDesc *dd = nullptr;
+			HIP_TRY(hipMalloc((void **) &dd, (size_t) (n_ent + 2) * sizeof(VisitDesc)));
+			G.v.push_back(dd);
+			A.desc = dd;
+			hipLaunchKernelGGL(pile_desc_kernel, dim3((unsigned) ((n_ent + 255) / 256)), dim3(256), 0, stream, A, n_ent);
+		}
+		lap("sort + segments + visit records");
 #ifdef KMAHIP_DIAG
 		HIP_TRY(hipMemsetAsync(ws->counters + 10, 0, 6 * sizeof(unsigned long long), stream));
 #endif
