@@ -1246,7 +1246,6 @@ __device__ bool lt_serial(const LtArgs &A, const int *sd, const LtProb *P, const
 
 struct DpxLds {
 	int d[25];
-	uint8_t E[LT_XE_LDS];
 	uint8_t t[LT_XT_LDS];
 };
 
@@ -1261,10 +1260,14 @@ __device__ __forceinline__ int lt_vgpr(int x) { asm volatile("" : "+v"(x)); retu
 // at lt_walk)
 template <int XW, bool banded, bool EHBM>
 __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
+	// (a class of its own with the matrix of the 256..511-column problems in 96 KB of LDS was tried: its 2.5 ms instead of the 12.8 ms
+	// of the HBM form cost the whole stage 10 ms -- a workgroup that takes most of a CU's LDS keeps the lane kernels off that CU, the
+	// HBM form runs beside them for nothing)
 	static_assert(XW <= 4 || EHBM, "the wide classes keep their move matrix in HBM");
 	constexpr int cls = XW <= 4 ? (EHBM ? 9 : 4) + (banded ? 2 : 0) + (XW == 4 ? 1 : 0) : 13 + (banded ? 2 : 0) + (XW == 16 ? 1 : 0);
 	__shared__ DpxLds S;
-	uint8_t *const Ebuf = EHBM ? A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow) : (uint8_t *) S.E;
+	extern __shared__ uint32_t lt_dpx_e[];      // the move matrix of the LDS forms: LT_XE_LDS bytes
+	uint8_t *const Ebuf = EHBM ? A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow) : (uint8_t *) lt_dpx_e;
 	const int lane = threadIdx.x;
 	if(lane < 25) S.d[lane] = A.d[lane];
 	wave_sync();
@@ -1998,24 +2001,25 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 			stage("lane sort");
 		}
-		static hipStream_t side[3] = {nullptr, nullptr, nullptr};
-		hipStream_t s1 = stream, s2 = stream, s3 = stream;
-		hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+		constexpr int NSIDE = 5;
+		static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+		hipStream_t s1 = stream, s2 = stream, s3 = stream, s4 = stream, s5 = stream;
+		hipEvent_t fork = nullptr, join[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 		if(!dbg) {
-			for(int x = 0; x < 3; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
+			for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
 			HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
 			HIP_TRY(hipEventRecord(fork, stream));
-			for(int x = 0; x < 3; ++x) HIP_TRY(hipStreamWaitEvent(side[x], fork, 0));
-			s1 = side[0]; s2 = side[1]; s3 = side[2];
+			for(int x = 0; x < NSIDE; ++x) HIP_TRY(hipStreamWaitEvent(side[x], fork, 0));
+			s1 = side[0]; s2 = side[1]; s3 = side[2]; s4 = side[3]; s5 = side[4];
 		}
 		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
 		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
 		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
 		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
-		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), 0, s1, A); stage("dpx<2, full>"); }
-		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), 0, s1, A); stage("dpx<4, full>"); }
-		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), 0, s2, A); stage("dpx<2, banded>"); }
-		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), 0, s2, A); stage("dpx<4, banded>"); }
+		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s1, A); stage("dpx<2, full>"); }
+		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s1, A); stage("dpx<4, full>"); }
+		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s2, A); stage("dpx<2, banded>"); }
+		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s2, A); stage("dpx<4, banded>"); }
 		// (the HBM variants and the one-lane class share the per-workgroup scratch of dpx_wgs workgroups: one stream, in turn)
 		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, s3, A); stage("serial"); }
 		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, full, HBM>"); }
@@ -2034,7 +2038,10 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				La.E = (uint8_t *) ws->lt_buf[10] + lg[j].e_off;
 				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
 				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
-				const hipStream_t ls = j <= 3 ? stream : (j == LT_LFULL ? s1 : ((j == 5 || j == LT_LCLS - 1) ? s3 : s2));
+				hipStream_t ls = j <= 3 ? stream : (j == LT_LFULL ? s1 : ((j == 5 || j == LT_LCLS - 1) ? s3 : s2));
+				if(const char *map = getenv("KMAHIP_LT_STREAMS")) {       // diagnosis: a digit per lane class, 0 = the caller's stream, 1-5 = side streams
+					if((int) strlen(map) > j && !dbg) { const int x = map[j] - '0'; const hipStream_t all[6] = {stream, s1, s2, s3, s4, s5}; if(x >= 0 && x < 6) ls = all[x]; }
+				}
 				const void *fn = j < LT_LFULL ? (simple_sc ? (const void *) lt_lane_kernel<true> : (const void *) lt_lane_kernel<false>)
 				                       : (simple_sc ? (const void *) lt_lane_band_kernel<true> : (const void *) lt_lane_band_kernel<false>);
 				if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
@@ -2053,7 +2060,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			}
 		}
 		if(!dbg) {
-			for(int x = 0; x < 3; ++x) {
+			for(int x = 0; x < NSIDE; ++x) {
 				HIP_TRY(hipEventCreateWithFlags(&join[x], hipEventDisableTiming));
 				HIP_TRY(hipEventRecord(join[x], side[x]));
 				HIP_TRY(hipStreamWaitEvent(stream, join[x], 0));
@@ -2064,7 +2071,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
-		if(fork) { (void) hipEventDestroy(fork); for(int x = 0; x < 3; ++x) (void) hipEventDestroy(join[x]); }
+		if(fork) { (void) hipEventDestroy(fork); for(int x = 0; x < NSIDE; ++x) (void) hipEventDestroy(join[x]); }
 		if(c[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
 		ws->lt_stats[0] += c[LC_PROB]; ws->lt_stats[1] += c[LC_CELLS]; ws->lt_stats[2] += c[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) nb;
 		if(c[LC_STATUS] == 8 || c[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", c[LC_STATUS]); return KMAHIP_EDEVICE; }
