@@ -401,10 +401,10 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 		for(uint32_t t = 1; t < DB_size; ++t) {
 			const int64_t nk = std::max<int64_t>(0, (int64_t) db->h_tlen[t] - k + 1);
 			uint32_t lg = 4;
-			// load <= 2/3; for long templates (genomes: what long reads are seeded against, 256 lookups side by side that wait for the
-			// longest of their probe chains) <= 1/3. The gene-sized tables stay as dense as they were: they are what the short-read
-			// kernels keep in cache
-			while((1ull << lg) * 2 < (uint64_t) nk * (nk >= 65536 ? 6 : 3)) ++lg;
+			// load <= 1/3: the kernels that look k-mers up wait for the longest of their probe chains (the long-read seeding 256 lookups side
+			// by side: fifteen round trips at 2/3, two or three now; the short-read seeding 2.96 -> 2.10 ms per 10 M reads), and a probe
+			// takes two slots at once. KMAHIP_TPOS_DENSE: 2/3 as in rounds 1 and 2
+			while((1ull << lg) * 2 < (uint64_t) nk * (getenv("KMAHIP_TPOS_DENSE") ? 3 : 6)) ++lg;
 			pshift[t] = 32 - lg;
 			poff[t + 1] = poff[t] + (1ll << lg);
 		}

@@ -110,7 +110,18 @@ struct QCursor {
 	}
 };
 
-// hashMapCCI_get semantics (hashmapcci.c:95-124): 0 absent, +pos unique, negative = duplicated
+// hashMapCCI_get semantics (hashmapcci.c:95-124): 0 absent, +pos unique, negative = duplicated. A probe takes the aligned PAIR of
+// slots its slot lies in (16 bytes: tables start at even slots and have an even number of them), so a chain of slots is walked two per
+// round trip; with the tables at most a third full (db.hip) few lookups need a second one.
+__device__ __forceinline__ bool tpos_probe(const uint4 &e, uint32_t sl, uint32_t km, int &v) {      // true: decided (v = value or 0)
+	if(!(sl & 1u)) {
+		if(e.y == 0) { v = 0; return true; }
+		if(e.x == km) { v = (int) e.y; return true; }
+	}
+	if(e.w == 0) { v = 0; return true; }
+	if(e.z == km) { v = (int) e.w; return true; }
+	return false;
+}
 __device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
 	if(km == 0) return 0;
 	const uint32_t sh = db.tpos_shift[t];
@@ -118,10 +129,10 @@ __device__ __forceinline__ int tpos_get(const DevDB &db, int t, uint32_t km) {
 	const uint32_t msk = (1u << (32 - sh)) - 1u;
 	uint32_t sl = (km * 0x9E3779B1u) >> sh;
 	for(;;) {
-		const uint2 e = tab[sl];
-		if(e.y == 0) return 0;
-		if(e.x == km) return (int) e.y;
-		sl = (sl + 1u) & msk;
+		const uint4 e = *(const uint4 *) (tab + (sl & ~1u));
+		int v;
+		if(tpos_probe(e, sl, km, v)) return v;
+		sl = ((sl | 1u) + 1u) & msk;
 	}
 }
 
@@ -133,18 +144,10 @@ __device__ __forceinline__ void tpos_get2(const DevDB &db, int t, uint32_t km1, 
 __device__ __forceinline__ void tpos_get2(const uint2 *tab, uint32_t sh, uint32_t km1, uint32_t km2, bool want2, int &v1, int &v2) {
 	const uint32_t msk = (1u << (32 - sh)) - 1u;
 	uint32_t s1 = (km1 * 0x9E3779B1u) >> sh, s2 = (km2 * 0x9E3779B1u) >> sh;
-	uint2 e1 = tab[s1], e2 = tab[want2 ? s2 : s1];
+	uint4 e1 = *(const uint4 *) (tab + (s1 & ~1u)), e2 = *(const uint4 *) (tab + ((want2 ? s2 : s1) & ~1u));
 	v1 = 0; v2 = 0;
-	if(km1) for(;;) {
-		if(e1.y == 0) break;
-		if(e1.x == km1) { v1 = (int) e1.y; break; }
-		s1 = (s1 + 1u) & msk; e1 = tab[s1];
-	}
-	if(want2 && km2) for(;;) {
-		if(e2.y == 0) break;
-		if(e2.x == km2) { v2 = (int) e2.y; break; }
-		s2 = (s2 + 1u) & msk; e2 = tab[s2];
-	}
+	if(km1) while(!tpos_probe(e1, s1, km1, v1)) { s1 = ((s1 | 1u) + 1u) & msk; e1 = *(const uint4 *) (tab + s1); }
+	if(want2 && km2) while(!tpos_probe(e2, s2, km2, v2)) { s2 = ((s2 | 1u) + 1u) & msk; e2 = *(const uint4 *) (tab + s2); }
 }
 
 // heuristic substitution model of chain.c (end / link / start terms)
