@@ -32,7 +32,11 @@
 
 namespace {
 
-constexpr int LT_TILE = 256;          // query positions looked up per round of the seeding wavefront
+#ifndef KMAHIP_LT_TILE
+#define KMAHIP_LT_TILE 256
+#endif
+constexpr int LT_TILE = KMAHIP_LT_TILE;   // query positions looked up per round of the seeding wavefront
+constexpr int LT_NJ = LT_TILE / 64;   // ... per lane
 constexpr int LT_NEXT_CAP = 512;     // MEMs of the winning strand whose chain links / chain order stay in LDS
 constexpr int LT_NCLS = 17;           // problem classes: 0..3 = 8 / 16 / 32 / 64 lanes per problem; 4, 5 = full matrix of up to 128 / 255
                                       // columns, 6, 7 = banded of up to 128 / 255 columns (several columns per lane); 8 = the rest (one
@@ -238,10 +242,10 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 			if(cur > segE - k) break;
 			const int p0 = cur;
 			// ---- lookups of the k-mer starts p0 .. p0 + 255 (position p0 + j * 64 + lane) ----
-			int v[4];
-			uint32_t km[4];
+			int v[LT_NJ];
+			uint32_t km[LT_NJ];
 #pragma unroll
-			for(int j = 0; j < 4; ++j) {
+			for(int j = 0; j < LT_NJ; ++j) {
 				const int pos = p0 + j * 64 + lane;
 				km[j] = (pos <= segE - k) ? (uint32_t) (qwin(q, pos) >> (64 - 2 * k)) : 0u;
 			}
@@ -250,12 +254,12 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				// the chain of a lookup is walked two slots per round trip, and with the table at most a third full (db.hip) the
 				// longest of a round's 256 chains is two or three round trips instead of fifteen)
 				const uint32_t msk = (1u << (32 - tsh)) - 1u;
-				uint32_t sl[4];
-				uint4 e[4];
+				uint32_t sl[LT_NJ];
+				uint4 e[LT_NJ];
 #pragma unroll
-				for(int j = 0; j < 4; ++j) { sl[j] = (km[j] * 0x9E3779B1u) >> tsh; e[j] = *(const uint4 *) (tab + (sl[j] & ~1u)); }
+				for(int j = 0; j < LT_NJ; ++j) { sl[j] = (km[j] * 0x9E3779B1u) >> tsh; e[j] = *(const uint4 *) (tab + (sl[j] & ~1u)); }
 #pragma unroll
-				for(int j = 0; j < 4; ++j) {
+				for(int j = 0; j < LT_NJ; ++j) {
 					v[j] = 0;
 					if(km[j]) for(;;) {
 						if(!(sl[j] & 1u)) {
@@ -269,11 +273,11 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				}
 			}
 			// ---- runs of hits on one diagonal: the first of a run extends, the others derive from it ----
-			int hd[4];
-			unsigned long long hitm[4];
+			int hd[LT_NJ];
+			unsigned long long hitm[LT_NJ];
 			int prev_last = (carry_pos == p0 - 1) ? carry_v : 0;
 #pragma unroll
-			for(int j = 0; j < 4; ++j) {
+			for(int j = 0; j < LT_NJ; ++j) {
 				int pv = __shfl_up(v[j], 1);
 				if(lane == 0) pv = prev_last;
 				prev_last = __shfl(v[j], 63);
@@ -296,7 +300,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 			{
 				int carry = -1;
 #pragma unroll
-				for(int j = 0; j < 4; ++j) {
+				for(int j = 0; j < LT_NJ; ++j) {
 					int x = hd[j];
 					for(int dd = 1; dd < 64; dd <<= 1) { const int y = __shfl_up(x, dd); if(lane >= dd) x = max(x, y); }
 					x = max(x, carry);
@@ -314,7 +318,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				const int off = cur - p0;
 				int s = -1;
 #pragma unroll
-				for(int j = 0; j < 4; ++j) {
+				for(int j = 0; j < LT_NJ; ++j) {
 					if(s >= 0) continue;
 					unsigned long long m = hitm[j];
 					const int lo = off - j * 64;
