@@ -1889,13 +1889,11 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	if(getenv("KMAHIP_LT_SCORE_TABLE")) simple_sc = false;
 	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
 	LaneLaunch lg[LT_LCLS];
-	size_t lane_e_bytes = 0;
 	for(int j = 0; j < LT_LCLS; ++j) {
 		lg[j].g = lt_lane_geom(j);
 		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * (j < LT_LFULL ? 64 : 32);
 		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
-		lg[j].e_off = lane_e_bytes;
-		lane_e_bytes += (size_t) lg[j].wgs * 64 * (size_t) (lg[j].g.ecap + 288);
+		lg[j].e_off = 0;
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
 	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
@@ -2001,7 +1999,13 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			vals_out = (int32_t *) ws->lt_buf[8] + 2 * prob_cap;
 			size_t tmp_bytes = 0;
 			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
-			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, lane_e_bytes))) return rc;
+			// the lanes' stretches of move matrix: as many workgroups per class as this pass has work for
+			size_t lane_e_bytes = 0;
+			for(int j = 0; j < LT_LCLS; ++j) {
+				lg[j].e_off = lane_e_bytes;
+				lane_e_bytes += (size_t) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (c[LC_LCNT + j] + 63) / 64) * 64 * (size_t) (lg[j].g.ecap + 288);
+			}
+			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, std::max<size_t>(lane_e_bytes, 16)))) return rc;
 			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 			stage("lane sort");
 		}
