@@ -489,6 +489,11 @@ int main(int argc, char **argv) {
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
 	} else if(chain) {
 		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, &cp, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_chain");
+		{	/* (kmahip.h: the one place where the reference reads memory it never cleared) */
+			int64_t unpinned = 0;
+			if(!kmahip_chain_unpinned_reads(b.reads.len, b.reads.N, b.reads.N_off, b.reads.n_reads, (int) info.kmersize, 0, NULL, &unpinned) && unpinned)
+				fprintf(stderr, "# kmahip_map: %lld reads carry an N among their first k - 1 bases behind a longer read: the reference's records for them depend on what its buffer held\n", (long long) unpinned);
+		}
 	} else if(input2) { if(kmahip_run_pe(db, ws, &b, &par, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_pe"); }
 	else if(kmahip_run_se(db, ws, &b.reads, &par, evalue, bcd, max_frag, &run)) die("kmahip_run_se");
 

@@ -411,6 +411,16 @@ typedef struct kmahip_chain_recs {
 } kmahip_chain_recs;
 int kmahip_scan_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, const kmahip_chain_params *cp,
                       kmahip_chain_recs *out);
+/* One place where the reference's own result is not a function of its input (savekmers.c:5447-5449): behind an N the chain finder
+ * restarts the reverse strand's rolling k-mer k bases too far on, which for a read with an N among its first k - 1 bases lies
+ * beyond the end of that read in a buffer the reference never clears -- zeros while no longer read came before it in the stream,
+ * otherwise what the longer read left there (and with -t > 1 whichever read the thread's buffer held last). This library reads
+ * zeros. kmahip_chain_unpinned_reads counts, on HOST arrays of a batch in stream order, the reads for which that matters: an N among
+ * the first k - 1 bases and a longer read somewhere before (longest_before: the longest read of the batches before this one, 0 for
+ * the first; *longest_after = what to pass with the next batch). Their records may differ from the reference's; a host that must
+ * know says so (examples/kmahip_map prints the count). */
+int kmahip_chain_unpinned_reads(const int32_t *len, const int32_t *N, const int64_t *N_off, int64_t n_reads, int k,
+                                int32_t longest_before, int32_t *longest_after, int64_t *count);
 
 /* ---- index build: `kma index -i <fasta ...> -o <prefix> [-k k]` ------------------------------------------------
  * Writes <prefix>.comp.b / .length.b / .seq.b / .name as the reference's index.c + makeindex.c:167-330 (makeDB) +

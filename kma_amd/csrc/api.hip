@@ -479,3 +479,18 @@ extern "C" int kmahip_trace_get_stats(kmahip_ws *ws, kmahip_trace_stats *st) {
 	st->problems = ws->lt_stats[0]; st->dp_cells = ws->lt_stats[1]; st->mems = ws->lt_stats[2]; st->reads = ws->lt_stats[3];
 	return KMAHIP_OK;
 }
+
+// kmahip.h: reads of the default mode whose result the reference takes from memory it never cleared
+extern "C" int kmahip_chain_unpinned_reads(const int32_t *len, const int32_t *N, const int64_t *N_off, int64_t n_reads, int k,
+                                           int32_t longest_before, int32_t *longest_after, int64_t *count) {
+	if(!len || !N_off || n_reads < 0 || k < 1 || !count) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
+	int32_t longest = longest_before;
+	int64_t c = 0;
+	for(int64_t r = 0; r < n_reads; ++r) {
+		if(N_off[r + 1] > N_off[r] && N && N[N_off[r]] < k - 1 && longest > len[r]) ++c;      // (a read's N positions ascend)
+		if(len[r] > longest) longest = len[r];
+	}
+	if(longest_after) *longest_after = longest;
+	*count = c;
+	return KMAHIP_OK;
+}

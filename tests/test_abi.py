@@ -74,3 +74,22 @@ def test_sparse_index_is_rejected_loudly(tmp_path):
         rc = L.kmahip_db_open(p.encode(), ctypes.byref(h))
         assert rc == -3 and h.value is None, (p, rc)
         assert b"sparse" in L.kmahip_last_error()
+
+
+def test_chain_unpinned_reads_counts_what_the_reference_reads_from_stale_memory():
+    """kmahip_chain_unpinned_reads (host arrays, no GPU): an N among the first k - 1 bases AND a longer read before it in the stream"""
+    import numpy as np
+    from kma_amd import binding
+    lib = ctypes.CDLL(binding.LIB_PATH)
+    lib.kmahip_chain_unpinned_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    length = np.array([100, 150, 120, 150, 90, 200], np.int32)
+    # read 0: N at 3 but nothing longer before; read 2: N at 5 behind the 150; read 3: N at 20 (not among the first 15); read 4: N at 0
+    Ns = np.array([3, 5, 20, 0, 40], np.int32)
+    N_off = np.array([0, 1, 1, 2, 3, 5, 5], np.int64)
+    longest, count = ctypes.c_int32(), ctypes.c_int64()
+    assert lib.kmahip_chain_unpinned_reads(length.ctypes.data, Ns.ctypes.data, N_off.ctypes.data, 6, 16, 0, ctypes.byref(longest), ctypes.byref(count)) == 0
+    assert (count.value, longest.value) == (2, 200)
+    # the same batch behind one that held a 300-base read: read 0 counts too
+    assert lib.kmahip_chain_unpinned_reads(length.ctypes.data, Ns.ctypes.data, N_off.ctypes.data, 6, 16, 300, ctypes.byref(longest), ctypes.byref(count)) == 0
+    assert (count.value, longest.value) == (3, 300)
