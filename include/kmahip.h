@@ -583,6 +583,12 @@ typedef struct kmahip_shard_opts {
 } kmahip_shard_opts;
 int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
+/* `-Mt1 tmpl [-bcNano]` (kmahip_run_mt1; runKMA_Mt1 mt1.c:86-500) over read shards: every rank traces its contiguous part of the stream
+ * against the one template (the traceback is four fifths of that run), the Score and the number of kept reads are summed, and the kept
+ * reads travel to the template's owner (rank 0) with their positions among the kept reads of the whole stream, where they are piled
+ * up in stream order. Files as kmahip_run_se_sharded leaves them, identical to the one-process run. */
+int kmahip_run_mt1_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, int32_t tmpl, int one2one,
+                           const kmahip_params *p, const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 /* The paired run (`-ipe r1 r2 -apm p -1t1`, kmahip_run_pe) the same way. `batch`: this rank's contiguous part of the stream of
  * units (pairs and single records; a pair is never cut). On top of the three exchanges above, two things cross the shards because
  * runConClave walks ONE stream: a record whose hit list came out empty takes the first listed hit of the last record before it

@@ -1045,7 +1045,7 @@ int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_pa
 static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBlock &B, const kmahip_read_batch *batch, const kmahip_reads &d, const int32_t *i_tmpl,
                         const int32_t *i_rc, const int32_t *i_nhits, const int64_t *i_frag_rank, const kmahip_traces &tr, const int64_t *name_src,
                         const uint64_t *frag_counts, const kmahip_res_row *rows, int64_t n_rows, int64_t chunk, const kmahip_shard_opts *opts,
-                        const char *out_prefix, double ms[8], std::chrono::steady_clock::time_point &t) {
+                        const char *out_prefix, double ms[8], std::chrono::steady_clock::time_point &t, int order = 0) {
 	const int W = kmahip_comm_world(comm), rank = kmahip_comm_rank(comm);
 	const int64_t n = d.n_reads;
 	const size_t D = db->info.DB_size;
@@ -1197,7 +1197,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
 	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
 	if(m2) {
-		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, 0, opts->caller, opts->sig90, fr2};
+		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, order, opts->caller, opts->sig90, fr2};
 		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
 	}
 	ms[5] = since(t);
@@ -1233,7 +1233,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 		hr.n_reads = m2; hr.seq = hs.data(); hr.seq_off = h_so.data(); hr.len = h_len.data(); hr.N = h_N.data(); hr.N_off = h_no.data();
 		hr.seq_words = dO.seq_words; hr.N_total = dO.N_total; hr.max_len = max_len;
 		int64_t frag_rows = 0;
-		if((rc = kmahip_frag_write3((part + ".frag.gz").c_str(), db, &hr, h_rc.data(), h_tm.data(), h_nh.data(), h_st.data(), chunk, 0, h_fr.data(),
+		if((rc = kmahip_frag_write3((part + ".frag.gz").c_str(), db, &hr, h_rc.data(), h_tm.data(), h_nh.data(), h_st.data(), chunk, order, h_fr.data(),
 		                            name_recv.data(), h_name_off.data(), &frag_rows))) return rc;
 	}
 	ms[6] = since(t);
@@ -1367,6 +1367,102 @@ extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	if(n) hipLaunchKernelGGL(shard_add_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, filed_before, rank_base);
 	HIP_TRY(hipGetLastError());
 	return shard_finish(db, ws, comm, B, batch, d, cc.tmpl, h.rc, h.n_hits, filed_before, tr, nullptr, &hx[2 * D], rows.data(), n_rows, mf, opts, out_prefix, ms, t);
+}
+
+
+// ---- `-Mt1 n` over read shards: every rank traces its part of the stream (the traceback is four fifths of the run), two sums make the
+// `.res` row the same everywhere, and the kept reads meet at the template's owner -- rank 0 -- with their positions in the whole stream
+// for the pile-up in stream order (kmahip_run_mt1; mt1.c:86-500) ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt1_kept_kernel(int64_t n, const int32_t *stats, int32_t tmpl, int t_len, int Wl, int32_t *o_tmpl, int32_t *o_nh, int64_t *o_kept,
+                                                       unsigned long long *sums) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > n) return;
+	if(i == n) { o_kept[i] = 0; return; }
+	const int32_t *st = stats + 10 * i;
+	const bool kept = st[3] != 0;
+	o_tmpl[i] = kept ? tmpl : 0;
+	o_nh[i] = 1;
+	o_kept[i] = kept ? 1 : 0;
+	// Score of the `.res` row = sum of KMA()'s own scores of the kept reads, without the end bonus the read filter added
+	if(kept) { atomicAdd(&sums[0], (unsigned long long) (st[0] - Wl * ((st[1] == 0) + (st[2] == t_len)))); atomicAdd(&sums[1], 1ull); }
+}
+
+extern "C" int kmahip_run_mt1_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, int32_t tmpl, int one2one,
+                                      const kmahip_params *p, const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
+	if(!db || !ws || !comm || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const int W = kmahip_comm_world(comm), rank = kmahip_comm_rank(comm);
+	const kmahip_reads &R = batch->reads;
+	const int64_t n = R.n_reads;
+	if(n < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	const size_t D = db->info.DB_size;
+	if(tmpl < 1 || (size_t) tmpl >= D) { kmahip_set_error("template %d out of range", tmpl); return KMAHIP_EINVAL; }
+	const int64_t mf = opts->max_frag > 0 ? opts->max_frag : 1000000;
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	hipStream_t s = 0;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	if((rc = kmahip_db_load_names(db))) return rc;
+	kmahip_reads d = R;
+	d.q_start = nullptr; d.q_end = nullptr;
+	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &d.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &d.seq_off)) || (rc = B.up(R.len, (size_t) n, 1, &d.len)) ||
+	   (rc = B.up(R.N, (size_t) R.N_total, 1, &d.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	ms[0] = since(t);
+	// the traceback on the rank's own reads: strand by anker_rc, runs; the run pool grows on demand
+	kmahip_traces tr;
+	int32_t *d_rc = nullptr, *d_tmpl = nullptr, *d_nh = nullptr;
+	int64_t *kept = nullptr, *kept_before = nullptr;
+	unsigned long long *sums = nullptr;
+	if((rc = B.get((size_t) 10 * n + 10, &tr.stats, true)) || (rc = B.get((size_t) n + 1, &tr.ops_off, true)) || (rc = B.get((size_t) n + 1, &tr.n_ops, true)) ||
+	   (rc = B.get((size_t) n + 1, &d_rc, true)) || (rc = B.get((size_t) n + 1, &d_tmpl, true)) || (rc = B.get((size_t) n + 1, &d_nh, true)) ||
+	   (rc = B.get((size_t) n + 1, &kept)) || (rc = B.get((size_t) n + 1, &kept_before)) || (rc = B.get(2, &sums, true))) return rc;
+	int64_t total_bases = 0;
+	for(int64_t i = 0; i < n; ++i) total_bases += R.len[i];
+	tr.ops_cap = total_bases / 3 + 8 * n + (1 << 16); tr.ops = nullptr;
+	for(int attempt = 0; n; ++attempt) {
+		if((rc = B.get((size_t) tr.ops_cap, &tr.ops))) return rc;
+		if((rc = kmahip_launch_longtrace(db, ws, &d, nullptr, tmpl, nullptr, nullptr, one2one, p, &tr, d_rc, s))) return rc;
+		unsigned long long used = 0;
+		const int st = ws_status(ws, &used);
+		if(st == 2 || (int64_t) used > tr.ops_cap) {
+			if(attempt >= 2) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+			tr.ops_cap = (int64_t) used + (1 << 16);
+			continue;
+		}
+		break;
+	}
+	if(!tr.ops && (rc = B.get(16, &tr.ops))) return rc;
+	ms[3] = since(t);
+	// the `.res` row: Score and the number of kept reads summed over the shards; a read's position among the kept reads of the stream
+	const int t_len = db->h_tlen[(size_t) tmpl];
+	hipLaunchKernelGGL(mt1_kept_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, tr.stats, tmpl, t_len, p->rw.Wl, d_tmpl, d_nh, kept, sums);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, kept, kept_before, (size_t) n + 1, s))) return rc;
+	int64_t my_kept = 0;
+	HIP_TRY(hipMemcpy(&my_kept, kept_before + n, 8, hipMemcpyDeviceToHost));
+	std::vector<int64_t> all_kept((size_t) W);
+	if((rc = kmahip_comm_allgather(comm, &my_kept, sizeof my_kept, all_kept.data()))) return rc;
+	int64_t rank_base = 0;
+	for(int r = 0; r < rank; ++r) rank_base += all_kept[(size_t) r];
+	if(n) hipLaunchKernelGGL(shard_add_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, kept_before, rank_base);
+	HIP_TRY(hipGetLastError());
+	if((rc = kmahip_comm_allreduce_u64(comm, (uint64_t *) sums, 2, s))) return rc;
+	unsigned long long h_sums[2] = {0, 0};
+	HIP_TRY(hipMemcpy(h_sums, sums, sizeof h_sums, hipMemcpyDeviceToHost));
+	const uint64_t score = h_sums[0];
+	kmahip_res_row row;
+	memset(&row, 0, sizeof row);
+	row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
+	row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
+	row.significant = ((row.p_value <= opts->evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+	std::vector<uint64_t> frag_counts(D, 0);
+	frag_counts[(size_t) tmpl] = h_sums[1];
+	ms[2] = since(t);
+	// a run without a kept read or without a score: nothing is piled up (kmahip_run_mt1) -- the reads then go nowhere
+	if(!score && n) HIP_TRY(hipMemsetAsync(d_tmpl, 0, (size_t) n * 4, s));
+	return shard_finish(db, ws, comm, B, batch, d, d_tmpl, d_rc, d_nh, kept_before, tr, nullptr, frag_counts.data(), &row, 1, mf, opts, out_prefix, ms, t, 1);
 }
 
 

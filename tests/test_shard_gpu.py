@@ -236,3 +236,37 @@ def test_batched_session_writes_the_one_batch_files(tmp_path, batch, chunk, mf):
     r = _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many"), "-1t1"] + extra, env=env)
     assert b"batches" in r.stderr
     _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
+
+
+@pytest.mark.parametrize("world,gz,bc", [(2, False, True), (3, True, True), (2, False, False)])
+def test_mt1_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, gz, bc):
+    """`-Mt1 1 [-bcNano]` (kmahip_run_mt1_sharded): every rank traces its part of the stream, the kept reads meet at rank 0 with
+    their positions in the whole stream and are piled up in stream order -- long noisy reads, whose insertion columns depend on it"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(31)
+    genome = rng.integers(0, 4, 60_000, dtype=np.uint8)
+    prefix = str(tmp_path / "g")
+    synth.write_fasta(prefix + ".fsa", ["genome"], [genome])
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = synth.make_long_reads(genome, 400, read_len=3000, seed=5)
+    reads += [rng.integers(0, 4, 800, dtype=np.uint8) for _ in range(7)]          # reads from elsewhere: not kept
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    fq = str(tmp_path / "ont.fq")
+    synth.write_fastq(fq, reads, prefix="r", qual=b"5")
+    if gz:
+        subprocess.check_call(["gzip", "-1", fq])
+        fq += ".gz"
+    opt = ["-Mt1", "1"] + (["-bcNano"] if bc else [])
+    _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one")] + opt)
+    _run(["-gpus", str(world), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many")] + opt, env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
+    a, b = str(tmp_path / "one"), str(tmp_path / "many")
+    assert open(a + ".res", "rb").read() == open(b + ".res", "rb").read() and open(a + ".res").read().count("\n") == 2
+    assert open(a + ".fsa", "rb").read() == open(b + ".fsa", "rb").read()
+    assert gzip.open(a + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("many.part")]
+    if os.path.exists(KMA):
+        subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"] + opt, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        r = str(tmp_path / "ref")
+        assert open(r + ".res").read() == open(b + ".res").read()
+        assert open(r + ".fsa").read() == open(b + ".fsa").read()
+        assert gzip.open(r + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
