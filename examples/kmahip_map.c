@@ -336,7 +336,6 @@ int main(int argc, char **argv) {
 		rank = atoi(getenv("RANK")); world = atoi(getenv("WORLD_SIZE")); local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
 		if(!key) { snprintf(keybuf, sizeof keybuf, "port%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0"); key = keybuf; }
 	}
-	if(world > 1 && !one2one && !mt1) { fprintf(stderr, "kmahip_map: several ranks are built for the -1t1 runs (single end and -ipe ... -apm p) and for -Mt1\n"); finish(2); }
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s(), t_before_main = since_process_start();
@@ -440,6 +439,7 @@ int main(int argc, char **argv) {
 		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		double ms[8];
 		if(mt1 ? kmahip_run_mt1_sharded(db, ws, comm, &b, mt1, one2one, &par, &so, out, ms)
+		       : chain ? kmahip_run_chain_sharded(db, ws, comm, &b, &par, &cp, &so, out, ms)
 		       : (input2 ? kmahip_run_pe_sharded(db, ws, comm, &b, &par, &so, out, ms) : kmahip_run_se_sharded(db, ws, comm, &b, &par, &so, out, ms))) die("sharded run");
 		if(rank == 0) {
 			char path[4096];

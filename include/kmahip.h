@@ -583,6 +583,11 @@ typedef struct kmahip_shard_opts {
 } kmahip_shard_opts;
 int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
+/* The default mode (no -1t1; kmahip_run_chain) over read shards: stage 2 -- save_kmers_chain -- on the rank's reads, its records (a
+ * read or its pieces with their query bounds) in stream order, and from there the stages and exchanges of kmahip_run_se_sharded on
+ * records instead of reads; a fragment row carries the header of the read its record came from. cp: NULL = the defaults. */
+int kmahip_run_chain_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                             const kmahip_chain_params *cp, const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 /* `-Mt1 tmpl [-bcNano]` (kmahip_run_mt1; runKMA_Mt1 mt1.c:86-500) over read shards: every rank traces its contiguous part of the stream
  * against the one template (the traceback is four fifths of that run), the Score and the number of kept reads are summed, and the kept
  * reads travel to the template's owner (rank 0) with their positions among the kept reads of the whole stream, where they are piled

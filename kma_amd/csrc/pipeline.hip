@@ -2,6 +2,7 @@
 // out), built from the same launchers as the stage-wise entry points; what runKMA does between its input stream and the
 // `.res` / consensus output (runkma.c:104-900), minus the files.
 #include "pipeline_util.h"
+#include <functional>
 #include <memory>
 
 
@@ -710,33 +711,20 @@ __global__ __launch_bounds__(256) void gather_copy_rc_kernel(int64_t m, const in
 
 }  // namespace
 
-extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
-                                const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
-                                const char *frag_path, kmahip_run *out) {
-	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	if(frag_path && reads && reads->n_reads > 0 && (!names || !name_off)) { kmahip_set_error("the fragment file needs the read headers"); return KMAHIP_EINVAL; }
-	const int64_t n = reads->n_reads;
-	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
-	const size_t D = db->info.DB_size;
-	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
-	out->n_rows = 0;
+// stage 2 of the default mode on an uploaded batch and its records as a batch of their own, in stream order: R.d = the read of a
+// record, or its reverse complement where the record prints that, with the record's query bounds; R.c = the template lists
+struct ChainRecs {
+	int64_t m = 0, n_T = 0;
+	kmahip_reads d{};
+	kmahip_cands c{};
+	int64_t *o_read = nullptr;     // device: the read a record comes from
+	int32_t *o_emit = nullptr;     // device: 1 = the record holds the reverse complement
+};
+static int chain_records(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_reads &dR, const kmahip_reads *reads, const kmahip_params *p,
+                         const kmahip_chain_params *cp, ChainRecs &R, const std::function<void(const char *)> &lap) {
+	const int64_t n = dR.n_reads;
 	hipStream_t s = 0;
-	auto t = std::chrono::steady_clock::now();
-	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
-	auto t_lap = std::chrono::steady_clock::now();
-	auto lap = [&](const char *what) { if(dbg) fprintf(stderr, "[kmahip] run_chain: %s %.1f ms\n", what, since(t_lap)); };
 	int rc;
-	// the batch, once
-	DevBlock B;
-	B.expect((size_t) reads->seq_words * 16 + (size_t) reads->N_total * 8 + (size_t) n * 480 + (64u << 20));
-	kmahip_reads dR = *reads;
-	dR.q_start = nullptr; dR.q_end = nullptr;
-	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &dR.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
-	   (rc = B.up(reads->len, (size_t) n, 1, &dR.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &dR.N)) ||
-	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
-	HIP_TRY(hipStreamSynchronize(s));
-	out->ms[0] = since(t);
-	lap("reads uploaded");
 	// stage 2: one record per accepted chain, in no particular order
 	int32_t *rec = nullptr, *T = nullptr;
 	int64_t *rec_T = nullptr;
@@ -789,8 +777,45 @@ extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 		HIP_TRY(hipStreamSynchronize(s));
 	}
 	lap("records in stream order, record batch");
-	kmahip_cands c;
-	c.rc_flag = o_rcflag; c.flag = zero; c.T_off = T_off; c.T = o_T; c.T_cap = n_T + 1;
+	R.m = m; R.n_T = n_T; R.d = d; R.o_read = o_read; R.o_emit = o_emit;
+	R.c.rc_flag = o_rcflag; R.c.flag = zero; R.c.T_off = T_off; R.c.T = o_T; R.c.T_cap = n_T + 1;
+	return KMAHIP_OK;
+}
+
+extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
+                                const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
+                                const char *frag_path, kmahip_run *out) {
+	if(!db || !ws || !reads || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(frag_path && reads && reads->n_reads > 0 && (!names || !name_off)) { kmahip_set_error("the fragment file needs the read headers"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	if(n < 0 || reads->seq_words < 0 || reads->N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	const size_t D = db->info.DB_size;
+	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
+	out->n_rows = 0;
+	hipStream_t s = 0;
+	auto t = std::chrono::steady_clock::now();
+	const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	auto t_lap = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { if(dbg) fprintf(stderr, "[kmahip] run_chain: %s %.1f ms\n", what, since(t_lap)); };
+	int rc;
+	// the batch, once
+	DevBlock B;
+	B.expect((size_t) reads->seq_words * 16 + (size_t) reads->N_total * 8 + (size_t) n * 480 + (64u << 20));
+	kmahip_reads dR = *reads;
+	dR.q_start = nullptr; dR.q_end = nullptr;
+	if((rc = B.up(reads->seq, (size_t) reads->seq_words, 2, &dR.seq)) || (rc = B.up(reads->seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
+	   (rc = B.up(reads->len, (size_t) n, 1, &dR.len)) || (rc = B.up(reads->N, (size_t) reads->N_total, 1, &dR.N)) ||
+	   (rc = B.up(reads->N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	out->ms[0] = since(t);
+	lap("reads uploaded");
+	ChainRecs CR;
+	if((rc = chain_records(db, ws, B, dR, reads, p, cp, CR, lap))) return rc;
+	const int64_t m = CR.m, n_T = CR.n_T;
+	kmahip_reads d = CR.d;
+	int64_t *o_read = CR.o_read;
+	int32_t *o_emit = CR.o_emit;
+	kmahip_cands c = CR.c;
 	HostCols H;
 	int32_t *k_tmpl = H.get<int32_t>((size_t) m + 1), *k_nh = H.get<int32_t>((size_t) m + 1), *k_rc = H.get<int32_t>((size_t) m + 1), *k_stats = H.get<int32_t>((size_t) m * 10 + 10);
 	int64_t *h_read = H.get<int64_t>((size_t) m + 1);
@@ -1247,51 +1272,18 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	return KMAHIP_OK;
 }
 
-extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
-                                     const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
-	if(!db || !ws || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+// what follows stage 2 in a sharded run, for a batch of reads (`-1t1`) or of the default mode's records alike: stage 3a, the two
+// exchanges around ConClave, the traceback, the positions among the filed fragments of the stream, the gather and the owners' work.
+// name_src (host, or NULL): the read of `batch` a record of `d` carries the header of.
+static int sharded_after_stage2(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBlock &B, const kmahip_read_batch *batch, const kmahip_reads &d, kmahip_cands &c,
+                                int64_t total, const int64_t *name_src, const kmahip_params *p, const kmahip_shard_opts *opts, const char *out_prefix, double ms[8],
+                                std::chrono::steady_clock::time_point &t) {
 	const int W = kmahip_comm_world(comm), rank = kmahip_comm_rank(comm);
-	const kmahip_reads &R = batch->reads;
-	const int64_t n = R.n_reads;
-	if(n < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
-	if(n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	const int64_t n = d.n_reads;
 	const size_t D = db->info.DB_size;
 	const int64_t mf = opts->max_frag > 0 ? opts->max_frag : 1000000;
-	for(int i = 0; i < 8; ++i) ms[i] = 0;
 	hipStream_t s = 0;
-	DevBlock B;
 	int rc;
-	auto t = std::chrono::steady_clock::now();
-	if((rc = kmahip_db_load_names(db))) return rc;
-
-	// the shard, once
-	B.expect((size_t) R.seq_words * 8 + (size_t) R.N_total * 4 + (size_t) n * 320 + (64u << 20));
-	kmahip_reads d = R;
-	d.q_start = nullptr; d.q_end = nullptr;
-	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &d.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &d.seq_off)) || (rc = B.up(R.len, (size_t) n, 1, &d.len)) ||
-	   (rc = B.up(R.N, (size_t) R.N_total, 1, &d.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
-	HIP_TRY(hipStreamSynchronize(s));
-	ms[0] = since(t);
-
-	// stages 2 and 3a on the shard (as kmahip_run_se)
-	kmahip_cands c;
-	if((rc = B.get((size_t) n + 1, &c.rc_flag)) || (rc = B.get((size_t) n + 1, &c.flag)) || (rc = B.get((size_t) n + 1, &c.T_off, true))) return rc;
-	int64_t total = 0;
-	c.T_cap = 2 * n + 4096; c.T = nullptr;
-	for(int attempt = 0; n > 0; ++attempt) {
-		if((rc = B.get((size_t) c.T_cap, &c.T))) return rc;
-		if((rc = kmahip_launch_scan_se(db, ws, &d, p, &c, s))) return rc;
-		HIP_TRY(hipStreamSynchronize(s));
-		if(ws_status(ws, nullptr) == 1) {
-			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
-			ws->pool_scale *= 2; ws->cap_reads = 0;
-			continue;
-		}
-		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
-		if(total <= c.T_cap) break;
-		if(attempt >= 6) { kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
-		c.T_cap = total + 1024;
-	}
 	if(!c.T && (rc = B.get(16, &c.T))) return rc;
 	kmahip_hits h;
 	uint64_t *AS = nullptr;
@@ -1366,9 +1358,95 @@ extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	for(int r = 0; r < rank; ++r) rank_base += all_filed[(size_t) r];
 	if(n) hipLaunchKernelGGL(shard_add_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, filed_before, rank_base);
 	HIP_TRY(hipGetLastError());
-	return shard_finish(db, ws, comm, B, batch, d, cc.tmpl, h.rc, h.n_hits, filed_before, tr, nullptr, &hx[2 * D], rows.data(), n_rows, mf, opts, out_prefix, ms, t);
+	return shard_finish(db, ws, comm, B, batch, d, cc.tmpl, h.rc, h.n_hits, filed_before, tr, name_src, &hx[2 * D], rows.data(), n_rows, mf, opts, out_prefix, ms, t);
 }
 
+extern "C" int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                                     const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
+	if(!db || !ws || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const kmahip_reads &R = batch->reads;
+	const int64_t n = R.n_reads;
+	if(n < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	hipStream_t s = 0;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	if((rc = kmahip_db_load_names(db))) return rc;
+
+	// the shard, once
+	B.expect((size_t) R.seq_words * 8 + (size_t) R.N_total * 4 + (size_t) n * 320 + (64u << 20));
+	kmahip_reads d = R;
+	d.q_start = nullptr; d.q_end = nullptr;
+	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &d.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &d.seq_off)) || (rc = B.up(R.len, (size_t) n, 1, &d.len)) ||
+	   (rc = B.up(R.N, (size_t) R.N_total, 1, &d.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &d.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	ms[0] = since(t);
+
+	// stages 2 and 3a on the shard (as kmahip_run_se)
+	kmahip_cands c;
+	if((rc = B.get((size_t) n + 1, &c.rc_flag)) || (rc = B.get((size_t) n + 1, &c.flag)) || (rc = B.get((size_t) n + 1, &c.T_off, true))) return rc;
+	int64_t total = 0;
+	c.T_cap = 2 * n + 4096; c.T = nullptr;
+	for(int attempt = 0; n > 0; ++attempt) {
+		if((rc = B.get((size_t) c.T_cap, &c.T))) return rc;
+		if((rc = kmahip_launch_scan_se(db, ws, &d, p, &c, s))) return rc;
+		HIP_TRY(hipStreamSynchronize(s));
+		if(ws_status(ws, nullptr) == 1) {
+			if(attempt >= 4) { kmahip_set_error("internal candidate pool exhausted"); return KMAHIP_EOVERFLOW; }
+			ws->pool_scale *= 2; ws->cap_reads = 0;
+			continue;
+		}
+		HIP_TRY(hipMemcpy(&total, c.T_off + n, sizeof total, hipMemcpyDeviceToHost));
+		if(total <= c.T_cap) break;
+		if(attempt >= 6) { kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
+		c.T_cap = total + 1024;
+	}
+	return sharded_after_stage2(db, ws, comm, B, batch, d, c, total, nullptr, p, opts, out_prefix, ms, t);
+}
+
+
+// ---- the default mode (no -1t1) over read shards: stage 2 (the chain finder) on the rank's reads, its records -- a read, or its pieces,
+// with their query bounds -- as a batch in stream order, and from there what a batch of reads goes through (sharded_after_stage2); a
+// record carries the header of the read it came from -------------------------------------------------------------------------------
+extern "C" int kmahip_run_chain_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
+                                        const kmahip_chain_params *cp, const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]) {
+	if(!db || !ws || !comm || !batch || !p || !opts || !out_prefix || !ms) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	const kmahip_reads &R = batch->reads;
+	const int64_t n = R.n_reads;
+	if(n < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
+	if(n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	for(int i = 0; i < 8; ++i) ms[i] = 0;
+	hipStream_t s = 0;
+	DevBlock B;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	if((rc = kmahip_db_load_names(db))) return rc;
+	B.expect((size_t) R.seq_words * 16 + (size_t) R.N_total * 8 + (size_t) n * 520 + (64u << 20));
+	kmahip_reads dR = R;
+	dR.q_start = nullptr; dR.q_end = nullptr;
+	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &dR.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &dR.seq_off)) || (rc = B.up(R.len, (size_t) n, 1, &dR.len)) ||
+	   (rc = B.up(R.N, (size_t) R.N_total, 1, &dR.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
+	HIP_TRY(hipStreamSynchronize(s));
+	ms[0] = since(t);
+	ChainRecs CR;
+	if((rc = chain_records(db, ws, B, dR, &R, p, cp, CR, [](const char *) {}))) return rc;
+	// (every rank's longest read sizes the owners' scratch: the record batch keeps the batch's)
+	std::vector<int64_t> h_read((size_t) CR.m + 1, 0);
+	if(CR.m) HIP_TRY(hipMemcpy(h_read.data(), CR.o_read, (size_t) CR.m * 8, hipMemcpyDeviceToHost));
+	if(!CR.m) {
+		// a shard without a record still takes part in every exchange: an empty batch with valid (zero) offsets
+		int64_t *zo = nullptr;
+		int32_t *zi = nullptr;
+		uint64_t *zw = nullptr;
+		if((rc = B.get(2, &zo, true)) || (rc = B.get(2, &zi, true)) || (rc = B.get(2, &zw, true))) return rc;
+		CR.d = kmahip_reads{};
+		CR.d.n_reads = 0; CR.d.seq = zw; CR.d.seq_off = zo; CR.d.len = zi; CR.d.N = zi; CR.d.N_off = zo; CR.d.max_len = R.max_len;
+		CR.c.rc_flag = zi; CR.c.flag = zi; CR.c.T_off = zo; CR.c.T = zi; CR.c.T_cap = 1;
+	}
+	return sharded_after_stage2(db, ws, comm, B, batch, CR.d, CR.c, CR.n_T, h_read.data(), p, opts, out_prefix, ms, t);
+}
 
 // ---- `-Mt1 n` over read shards: every rank traces its part of the stream (the traceback is four fifths of the run), two sums make the
 // `.res` row the same everywhere, and the kept reads meet at the template's owner -- rank 0 -- with their positions in the whole stream

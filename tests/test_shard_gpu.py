@@ -270,3 +270,36 @@ def test_mt1_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_pat
         assert open(r + ".res").read() == open(b + ".res").read()
         assert open(r + ".fsa").read() == open(b + ".fsa").read()
         assert gzip.open(r + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
+
+
+@pytest.mark.parametrize("world,mf,seed", [(2, None, 1), (3, 777, 2), (5, 60, 3)])
+def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, mf, seed):
+    """no -1t1 (kmahip_run_chain_sharded): reads that map in pieces -- several records per read, strand ties, query bounds -- with N's
+    and indels; the records of the shards must come out as the records of the one stream (their pile-up and fragment rows follow the
+    order of the whole stream, the chunks of -mf filed fragments straddle the shards)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import _chimeric_reads
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(900 + seed)
+    names, seqs = synth.make_gene_db(40, 5, 300, 900, 0.05, seed=910 + seed)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = _chimeric_reads(seqs, 9000, rng, with_n=seed > 1)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    extra = ["-mf", str(mf)] if mf else []
+    _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one")] + extra)
+    _run(["-gpus", str(world), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many")] + extra, env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
+    a, b = str(tmp_path / "one"), str(tmp_path / "many")
+    assert open(a + ".res", "rb").read() == open(b + ".res", "rb").read() and open(a + ".res").read().count("\n") > 30
+    assert open(a + ".fsa", "rb").read() == open(b + ".fsa", "rb").read()
+    fa, fb = gzip.open(a + ".frag.gz").read(), gzip.open(b + ".frag.gz").read()
+    assert fa == fb and fa.count(b"\n") > 3000
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("many.part")]
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"] + extra, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = str(tmp_path / "ref")
+    assert open(r + ".res").read() == open(b + ".res").read()
+    assert open(r + ".fsa").read() == open(b + ".fsa").read()
+    assert gzip.open(r + ".frag.gz").read() == fb
