@@ -12,10 +12,10 @@
  * Stage 1 (kmahip_ingest_*: parse, trim, pack), the whole device run in one call (kmahip_run_se / _pe / _chain / _mt1: stage 2, 3a,
  * ConClave, `.res` statistics, traceback, pile-up, consensus), then the three writers.
  *
- * Several GPUs of one node (`-1t1`, single end): `-gpus N` starts N copies of this program, one per device, before anything
+ * Several GPUs of one node (every mode above): `-gpus N` starts N copies of this program, one per device, before anything
  * touches a GPU; each copy is a rank (KMAHIP_RANK / KMAHIP_WORLD / KMAHIP_KEY in its environment; under another launcher RANK /
  * WORLD_SIZE / LOCAL_RANK and MASTER_PORT are read instead). A rank parses its byte range of the FASTQ, maps its reads, and
- * kmahip_run_se_sharded does the three exchanges (kmahip.h) -- over RCCL, or staged through shared memory with
+ * kmahip_run_se_sharded / _pe_sharded / _chain_sharded / _mt1_sharded do the exchanges (kmahip.h) -- over RCCL, or staged through shared memory with
  * KMAHIP_COMM=shm (KMAHIP_SHARE_GPU=1 puts every rank on device 0: a rehearsal on a one-GPU box).
  */
 #define _POSIX_C_SOURCE 200809L
