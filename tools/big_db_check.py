@@ -55,7 +55,7 @@ bench.write_fastq_fixed(r1, m1)
 bench.write_fastq_fixed(r2, m2)
 ok = all(same.values())
 for what, ref_args, got_args in (("-1t1", ["-i", fq, "-1t1"], ["-i", fq, "-1t1"]), ("default mode", ["-i", fq], ["-i", fq, "-chain"]),
-                                 ("-ipe -apm p -1t1", ["-ipe", r1, r2, "-apm", "p", "-1t1"], ["-ipe", r1, r2, "-1t1"])):
+                                 ("-ipe -apm p -1t1", ["-ipe", r1, r2, "-apm", "p", "-1t1"], ["-ipe", r1, r2, "-apm", "p", "-1t1"])):
     t0 = time.perf_counter()
     subprocess.run([KMA] + ref_args + ["-o", os.path.join(tmp, "ref_out"), "-t_db", ref_db, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     t1 = time.perf_counter()
