@@ -339,8 +339,8 @@ int main(int argc, char **argv) {
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s(), t_before_main = since_process_start();
-	if(world == 1 && one2one && !input2 && !mt1 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
-		/* the single-end -1t1 run, batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on this
+	if(world == 1 && !input2 && !mt1 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
+		/* the single-end run (-1t1 or the default mode), batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on this
 		 * one, the host holding one batch at a time */
 		stream_job sj;
 		memset(&sj, 0, sizeof sj);
@@ -363,14 +363,22 @@ int main(int argc, char **argv) {
 			if(stat(input, &sb) == 0) hint = (int64_t) (sb.st_size / (il > 3 && !strcmp(input + il - 3, ".gz") ? 60 : 300));
 		}
 		kmahip_session *ses;
-		if(kmahip_session_open(db, ws, &par, &so, hint, &ses)) die("session");
+		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp))) die("session");
 		int batches = 0;
+		kmahip_db_info sinfo;
+		int64_t unpinned = 0;
+		int32_t longest = 0;
+		if(kmahip_db_get_info(db, &sinfo)) die("open");
 		for(;;) {
 			pthread_mutex_lock(&sj.mu);
 			while(sj.state == 0) pthread_cond_wait(&sj.cv, &sj.mu);
 			const int st = sj.state;
 			pthread_mutex_unlock(&sj.mu);
 			if(st == 2) break;
+			if(chain) {	/* (kmahip.h: the one place where the reference reads memory it never cleared) */
+				int64_t c = 0;
+				if(!kmahip_chain_unpinned_reads(sj.b.reads.len, sj.b.reads.N, sj.b.reads.N_off, sj.b.reads.n_reads, (int) sinfo.kmersize, longest, &longest, &c)) unpinned += c;
+			}
 			if(kmahip_session_upload(ses, &sj.b)) die("upload");
 			pthread_mutex_lock(&sj.mu);
 			sj.state = 0;
@@ -385,6 +393,7 @@ int main(int argc, char **argv) {
 		double ms[8];
 		int64_t n_reads = 0, n_rows = 0;
 		if(kmahip_session_finish(ses, out, !no_cons, !no_frag, &n_reads, &n_rows, ms)) die("finish");
+		if(unpinned) fprintf(stderr, "# kmahip_map: %lld reads carry an N among their first k - 1 bases behind a longer read: the reference's records for them depend on what its buffer held\n", (long long) unpinned);
 		fprintf(stderr, "# kmahip_map: %lld reads in %d batches, %lld fragment rows; wall: open %.2f s, ingest done after %.2f, mapped after %.2f, finish %.2f | uploads %.1f ms, stages 2+3a %.1f, "
 		        "ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, .res + .fsa %.1f, .frag.gz %.1f (main entered %.2f s after process start; peak RSS %.0f MB)\n", (long long) n_reads, batches,
 		        (long long) n_rows, t_open - t_start, sj.t_done - t_start, t_mapped - t_start, now_s() - t_mapped, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], t_before_main, peak_rss_mb());

@@ -616,6 +616,10 @@ int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const
  * .res + .fsa, fragment rows. */
 typedef struct kmahip_session kmahip_session;
 int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_params *p, const kmahip_shard_opts *opts, int64_t reads_hint, kmahip_session **out);
+/* The reference's DEFAULT mode (no -1t1: kmahip_run_chain) through the same session: call once, before the first batch. A batch's
+ * reads then go through the chain finder, and what the session keeps and maps are its records (a read, or its pieces, with their query
+ * bounds); a fragment row carries the header of the read its record came from. cp: NULL = the defaults (kmahip_scan_chain). */
+int kmahip_session_set_chain(kmahip_session *s, const kmahip_chain_params *cp);
 int kmahip_session_add(kmahip_session *s, const kmahip_read_batch *batch);
 /* kmahip_session_add in two steps, for a caller whose reader thread is to go on while the device works: _upload returns when the
  * batch's host arrays are free again, _map runs stages 2 and 3a on what has been uploaded since the last call */

@@ -154,6 +154,19 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
                             const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream);
 // anchors of every strand that passes the prefilter, for reads without N's and up to 288 k-mer starts (the others get slow[read] = 1):
 // a_n[2 r + strand] anchors at pool + a_off[2 r + strand]; cnt[0] = anchors written (may exceed pool_cap: repeat with a larger pool)
+// stage 2 of the default mode on a batch that is in HBM, its records as a batch of their own in stream order (pipeline.hip). The
+// arrays live in a block of their own until kmahip_chain_records_free.
+struct KmaChainRecs {
+	int64_t m = 0, n_T = 0;
+	kmahip_reads d{};              // the records: the read, or its reverse complement where the record prints that; q_start / q_end set
+	kmahip_cands c{};              // their template lists
+	int64_t *o_read = nullptr;     // the read of the batch a record comes from
+	int32_t *o_emit = nullptr;     // 1 = the record holds the reverse complement
+	void *block = nullptr;
+};
+int kmahip_chain_records_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *dR, const kmahip_params *p, const kmahip_chain_params *cp, KmaChainRecs *out);
+void kmahip_chain_records_free(KmaChainRecs *r);
+
 int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, KmaAnk *pool, int64_t pool_cap,
                                 int64_t *a_off, int32_t *a_n, uint8_t *slow, unsigned long long *cnt, hipStream_t stream);
 int kmahip_db_load_names(kmahip_db *db);       // fragout.hip: fills db->h_names from <prefix>.name

@@ -782,6 +782,19 @@ static int chain_records(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip
 	return KMAHIP_OK;
 }
 
+int kmahip_chain_records_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *dR, const kmahip_params *p, const kmahip_chain_params *cp, KmaChainRecs *out) {
+	DevBlock *B = new DevBlock();
+	B->expect((size_t) dR->seq_words * 8 + (size_t) dR->N_total * 4 + (size_t) dR->n_reads * 200 + (16u << 20));
+	ChainRecs CR;
+	const int rc = chain_records(db, ws, *B, *dR, dR, p, cp, CR, [](const char *) {});
+	if(rc) { delete B; return rc; }
+	out->m = CR.m; out->n_T = CR.n_T; out->d = CR.d; out->c = CR.c; out->o_read = CR.o_read; out->o_emit = CR.o_emit; out->block = B;
+	return KMAHIP_OK;
+}
+void kmahip_chain_records_free(KmaChainRecs *r) {
+	if(r && r->block) { delete (DevBlock *) r->block; r->block = nullptr; }
+}
+
 extern "C" int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const char *names, const int64_t *name_off,
                                 const kmahip_params *p, const kmahip_chain_params *cp, double evalue, int bcd, int64_t max_frag,
                                 const char *frag_path, kmahip_run *out) {

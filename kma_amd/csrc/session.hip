@@ -50,7 +50,13 @@ struct Batch {
 	kmahip_cands c{};
 	kmahip_hits h{};
 	std::vector<void *> owned;
-	void release() { for(void *q : owned) (void) hipFree(q); owned.clear(); }
+	// the default mode: the batch's READS wait here (their own arrays) until kmahip_session_map has made the records out of them
+	kmahip_reads tmp{};
+	std::vector<void *> tmp_owned;
+	int64_t read0 = 0;             // first read of the batch among all reads (its headers' index)
+	KmaChainRecs cr;               // the records' template lists live in its block
+	void release_tmp() { for(void *q : tmp_owned) (void) hipFree(q); tmp_owned.clear(); }
+	void release() { for(void *q : owned) (void) hipFree(q); owned.clear(); release_tmp(); kmahip_chain_records_free(&cr); }
 };
 
 template <class T> int dev_new(std::vector<void *> &owned, size_t n, T **out, bool zero, hipStream_t s) {
@@ -98,6 +104,7 @@ struct RowArgs {
 	const char *names, *tnames;
 	const int64_t *tname_off;
 	const int64_t *row_read;
+	const int64_t *name_idx;     // the header a row carries (NULL: the read's own; the default mode: the read its record came from)
 	int64_t *row_off;
 };
 __device__ __forceinline__ int digits_of(int v) {
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void row_len_kernel(const RowArgs A, int64_t n
 	const int32_t *st = A.stats + 10 * i;
 	// bases, "\t<ties>\t<score>\t<start>\t<end>\t<template>\t<header>\n"
 	A.row_off[r] = (int64_t) A.len[i] + 4 + digits_of(A.n_hits[i]) + digits_of(st[0]) + digits_of(st[1]) + digits_of(st[2]) + 1 + (A.tname_off[t] - A.tname_off[t - 1]) + 1 +
-	               (A.name_off[i + 1] - A.name_off[i] - 1) + 1;
+	               (A.name_off[(A.name_idx ? A.name_idx[i] : i) + 1] - A.name_off[A.name_idx ? A.name_idx[i] : i] - 1) + 1;
 }
 __device__ __forceinline__ char *put_int_dev(char *o, int v) {
 	*o++ = '\t';
@@ -165,7 +172,8 @@ __global__ __launch_bounds__(256) void row_format_kernel(const RowArgs A, int64_
 	const int t = abs(tt);
 	for(int64_t x = A.tname_off[t - 1]; x < A.tname_off[t]; ++x) *o++ = A.tnames[x];
 	*o++ = '\t';
-	for(int64_t x = A.name_off[i]; x < A.name_off[i + 1] - 1; ++x) *o++ = A.names[x];
+	const int64_t ni = A.name_idx ? A.name_idx[i] : i;
+	for(int64_t x = A.name_off[ni]; x < A.name_off[ni + 1] - 1; ++x) *o++ = A.names[x];
 	*o++ = '\n';
 }
 __global__ __launch_bounds__(256) void row_blocks_kernel(int64_t n_blocks, int64_t rows_per_block, int64_t n_rows, const int64_t *row_off, int64_t *block_off) {
@@ -181,6 +189,12 @@ struct kmahip_session {
 	kmahip_params par{};
 	kmahip_shard_opts opts{};
 	DevArr seq, seq_off, len, N, N_off, names, name_off;
+	// the default mode (kmahip_session_set_chain): the arrays above hold RECORDS, with their query bounds and the read they came from;
+	// names / name_off stay per read
+	bool chain = false;
+	kmahip_chain_params cp{};
+	DevArr qs, qe, rread;
+	int64_t n_reads = 0;
 	int64_t n = 0, words = 0, nN = 0, name_bytes = 0;
 	int max_len = 0;
 	uint64_t *AS = nullptr, *AS_batch = nullptr;          // 2 D each: alignment_scores | uniq_alignment_scores
@@ -223,6 +237,14 @@ extern "C" int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_pa
 
 extern "C" void kmahip_session_close(kmahip_session *S) { delete S; }
 
+extern "C" int kmahip_session_set_chain(kmahip_session *S, const kmahip_chain_params *cp) {
+	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty()) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	S->chain = true;
+	if(cp) S->cp = *cp; else { S->cp.minlen = 16; S->cp.pad_ = 0; S->cp.coverT = 0.1; S->cp.mrs = 0.5; }
+	return KMAHIP_OK;
+}
+
 // One batch of stage-1 records, first half: uploaded behind the batches before it. The caller's arrays are free when this returns
 // (a reader thread may go on to the next batch while kmahip_session_map works on this one).
 extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch *batch) {
@@ -233,12 +255,41 @@ extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch 
 	if(nb == 0) return KMAHIP_OK;
 	if(!batch->names || !batch->name_off) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
 	hipStream_t s = 0;
-	kmahip_db *db = S->db;
-	kmahip_ws *ws = S->ws;
-	const size_t D = db->info.DB_size;
 	auto t = std::chrono::steady_clock::now();
 	int rc;
 	const int64_t nbytes = batch->name_off[nb];
+	if(S->chain) {
+		// the default mode: the headers behind those of the reads before, the reads into arrays of the batch's own (the records made of
+		// them are what goes behind the records before: kmahip_session_map)
+		if((rc = S->names.ensure((size_t) (S->name_bytes + nbytes + 1), (size_t) S->name_bytes, s)) ||
+		   (rc = S->name_off.ensure((size_t) (S->n_reads + nb + 1) * 8, (size_t) (S->n_reads + 1) * 8, s))) return rc;
+		if(nbytes) HIP_TRY(hipMemcpyAsync(S->names.as<char>() + S->name_bytes, batch->names, (size_t) nbytes, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(S->name_off.as<int64_t>() + S->n_reads, batch->name_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+		if(S->name_bytes) hipLaunchKernelGGL(add_off_kernel, dim3((unsigned) ((nb + 1 + 255) / 256)), dim3(256), 0, s, nb + 1, S->name_off.as<int64_t>() + S->n_reads, S->name_bytes);
+		Batch U;
+		uint64_t *d_seq = nullptr;
+		int64_t *d_so = nullptr, *d_no = nullptr;
+		int32_t *d_len = nullptr, *d_N = nullptr;
+		if((rc = dev_new(U.tmp_owned, (size_t) R.seq_words + 2, &d_seq, false, s)) || (rc = dev_new(U.tmp_owned, (size_t) nb + 1, &d_so, false, s)) || (rc = dev_new(U.tmp_owned, (size_t) nb + 1, &d_len, false, s)) ||
+		   (rc = dev_new(U.tmp_owned, (size_t) R.N_total + 1, &d_N, false, s)) || (rc = dev_new(U.tmp_owned, (size_t) nb + 1, &d_no, false, s))) { U.release(); return rc; }
+		if(R.seq_words) HIP_TRY(hipMemcpyAsync(d_seq, R.seq, (size_t) R.seq_words * 8, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemsetAsync(d_seq + R.seq_words, 0, 16, s));
+		HIP_TRY(hipMemcpyAsync(d_so, R.seq_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_len, R.len, (size_t) nb * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemsetAsync(d_len + nb, 0, 4, s));
+		if(R.N_total) HIP_TRY(hipMemcpyAsync(d_N, R.N, (size_t) R.N_total * 4, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(d_no, R.N_off, (size_t) (nb + 1) * 8, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(s));
+		U.tmp = R;
+		U.tmp.seq = d_seq; U.tmp.seq_off = d_so; U.tmp.len = d_len; U.tmp.N = d_N; U.tmp.N_off = d_no; U.tmp.q_start = nullptr; U.tmp.q_end = nullptr;
+		U.read0 = S->n_reads; U.max_len = R.max_len;
+		S->uploaded.push_back(std::move(U));
+		S->n_reads += nb; S->name_bytes += nbytes;
+		S->max_len = std::max(S->max_len, R.max_len);
+		S->ms_upload += since(t);
+		return KMAHIP_OK;
+	}
 	if((rc = S->seq.ensure((size_t) (S->words + R.seq_words + 2) * 8, (size_t) S->words * 8, s)) || (rc = S->seq_off.ensure((size_t) (S->n + nb + 1) * 8, (size_t) (S->n + 1) * 8, s)) ||
 	   (rc = S->len.ensure((size_t) (S->n + nb + 1) * 4, (size_t) S->n * 4, s)) || (rc = S->N.ensure((size_t) (S->nN + R.N_total + 1) * 4, (size_t) S->nN * 4, s)) ||
 	   (rc = S->N_off.ensure((size_t) (S->n + nb + 1) * 8, (size_t) (S->n + 1) * 8, s)) || (rc = S->names.ensure((size_t) (S->name_bytes + nbytes + 1), (size_t) S->name_bytes, s)) ||
@@ -262,7 +313,7 @@ extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch 
 	Batch U;
 	U.r0 = S->n; U.n = nb; U.max_len = R.max_len;
 	S->uploaded.push_back(std::move(U));
-	S->n += nb; S->words += R.seq_words; S->nN += R.N_total; S->name_bytes += nbytes;
+	S->n += nb; S->n_reads += nb; S->words += R.seq_words; S->nN += R.N_total; S->name_bytes += nbytes;
 	S->max_len = std::max(S->max_len, R.max_len);
 	return KMAHIP_OK;
 }
@@ -291,13 +342,49 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 	kmahip_db *db = S->db;
 	kmahip_ws *ws = S->ws;
 	const size_t D = db->info.DB_size;
-	const int64_t nb = B.n;
 	auto t = std::chrono::steady_clock::now();
 	int rc;
+	if(S->chain) {
+		// stage 2 of the default mode: the chain finder on the batch's reads; its records -- in stream order -- go behind the records
+		// of the batches before, with their bounds and the read whose header they carry
+		if((rc = kmahip_chain_records_dev(db, ws, &B.tmp, &S->par, &S->cp, &B.cr))) { B.release(); return rc; }
+		const int64_t m = B.cr.m;
+		B.r0 = S->n; B.n = m;
+		if(m) {
+			const kmahip_reads &c = B.cr.d;
+			if((rc = S->seq.ensure((size_t) (S->words + c.seq_words + 2) * 8, (size_t) S->words * 8, s)) || (rc = S->seq_off.ensure((size_t) (S->n + m + 1) * 8, (size_t) (S->n + 1) * 8, s)) ||
+			   (rc = S->len.ensure((size_t) (S->n + m + 1) * 4, (size_t) S->n * 4, s)) || (rc = S->N.ensure((size_t) (S->nN + c.N_total + 1) * 4, (size_t) S->nN * 4, s)) ||
+			   (rc = S->N_off.ensure((size_t) (S->n + m + 1) * 8, (size_t) (S->n + 1) * 8, s)) || (rc = S->qs.ensure((size_t) (S->n + m + 1) * 4, (size_t) S->n * 4, s)) ||
+			   (rc = S->qe.ensure((size_t) (S->n + m + 1) * 4, (size_t) S->n * 4, s)) || (rc = S->rread.ensure((size_t) (S->n + m + 1) * 8, (size_t) S->n * 8, s))) { B.release(); return rc; }
+			bool ok = true;
+			ok = ok && (!c.seq_words || hipMemcpyAsync(S->seq.as<uint64_t>() + S->words, c.seq, (size_t) c.seq_words * 8, hipMemcpyDeviceToDevice, s) == hipSuccess);
+			ok = ok && hipMemsetAsync(S->seq.as<uint64_t>() + S->words + c.seq_words, 0, 16, s) == hipSuccess;
+			ok = ok && hipMemcpyAsync(S->seq_off.as<int64_t>() + S->n, c.seq_off, (size_t) (m + 1) * 8, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			ok = ok && hipMemcpyAsync(S->len.as<int32_t>() + S->n, c.len, (size_t) m * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			ok = ok && (!c.N_total || hipMemcpyAsync(S->N.as<int32_t>() + S->nN, c.N, (size_t) c.N_total * 4, hipMemcpyDeviceToDevice, s) == hipSuccess);
+			ok = ok && hipMemcpyAsync(S->N_off.as<int64_t>() + S->n, c.N_off, (size_t) (m + 1) * 8, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			ok = ok && hipMemcpyAsync(S->qs.as<int32_t>() + S->n, c.q_start, (size_t) m * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			ok = ok && hipMemcpyAsync(S->qe.as<int32_t>() + S->n, c.q_end, (size_t) m * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			ok = ok && hipMemcpyAsync(S->rread.as<int64_t>() + S->n, B.cr.o_read, (size_t) m * 8, hipMemcpyDeviceToDevice, s) == hipSuccess;
+			if(!ok) { B.release(); kmahip_set_error("device copy failed"); return KMAHIP_EDEVICE; }
+			const unsigned g1 = (unsigned) ((m + 1 + 255) / 256);
+			if(S->words) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, m + 1, S->seq_off.as<int64_t>() + S->n, S->words);
+			if(S->nN) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, m + 1, S->N_off.as<int64_t>() + S->n, S->nN);
+			if(B.read0) hipLaunchKernelGGL(add_off_kernel, dim3(g1), dim3(256), 0, s, m, S->rread.as<int64_t>() + S->n, B.read0);
+			if(hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { B.release(); kmahip_set_error("device copy failed"); return KMAHIP_EDEVICE; }
+			B.c = B.cr.c; B.total = B.cr.n_T;
+			S->n += m; S->words += c.seq_words; S->nN += c.N_total;
+		}
+		B.release_tmp();
+	}
+	const int64_t nb = B.n;
 	kmahip_reads d{};
 	d.n_reads = nb; d.seq = S->seq.as<uint64_t>(); d.seq_off = S->seq_off.as<int64_t>() + B.r0; d.len = S->len.as<int32_t>() + B.r0; d.N = S->N.as<int32_t>();
 	d.N_off = S->N_off.as<int64_t>() + B.r0; d.seq_words = S->words; d.N_total = S->nN; d.max_len = B.max_len;
+	if(S->chain && nb) { d.q_start = S->qs.as<int32_t>() + B.r0; d.q_end = S->qe.as<int32_t>() + B.r0; }
+	if(S->chain && !nb) { S->batches.push_back(std::move(B)); S->ms_map += since(t); return KMAHIP_OK; }       // (a batch without a record)
 	// stage 2 (the candidate lists have no bound known in advance: two per read, redone with the exact size if short)
+	if(!S->chain) {
 	if((rc = dev_new(B.owned, (size_t) nb + 1, &B.c.rc_flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.T_off, true, s))) { B.release(); return rc; }
 	B.c.T_cap = 2 * nb + 4096;
 	for(int attempt = 0;; ++attempt) {
@@ -312,6 +399,7 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 		if(B.total <= B.c.T_cap) break;
 		if(attempt >= 6) { B.release(); kmahip_set_error("candidate lists keep growing"); return KMAHIP_EOVERFLOW; }
 		B.c.T_cap = B.total + 1024;
+	}
 	}
 	// stage 3a into vectors of the batch's own (a run that has to be repeated with more room for seeds starts them afresh), then added
 	kmahip_hits &h = B.h;
@@ -350,7 +438,7 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	hipStream_t s = 0;
 	for(int i = 0; i < 8; ++i) ms[i] = 0;
 	ms[0] = S->ms_upload; ms[1] = S->ms_map;
-	if(n_reads) *n_reads = n;
+	if(n_reads) *n_reads = S->n_reads;
 	if(n_rows_out) *n_rows_out = 0;
 	auto t = std::chrono::steady_clock::now();
 	int rc;
@@ -366,6 +454,7 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	kmahip_reads W{};
 	W.n_reads = n; W.seq = S->seq.as<uint64_t>(); W.seq_off = S->seq_off.as<int64_t>(); W.len = S->len.as<int32_t>(); W.N = S->N.as<int32_t>(); W.N_off = S->N_off.as<int64_t>();
 	W.seq_words = S->words; W.N_total = S->nN; W.max_len = S->max_len;
+	if(S->chain && n) { W.q_start = S->qs.as<int32_t>(); W.q_end = S->qe.as<int32_t>(); }
 
 	// stage 3b per batch on the finished vectors, the `.res` statistics
 	kmahip_conclave cc{};
@@ -373,8 +462,10 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	if((rc = B.get((size_t) n + 1, &cc.tmpl, true)) || (rc = B.get((size_t) n + 1, &cc.start, true)) || (rc = B.get((size_t) n + 1, &cc.end, true)) || (rc = B.get(D, &cc.w_scores, true)) ||
 	   (rc = B.get((size_t) n + 1, &rc_all, true)) || (rc = B.get((size_t) n + 1, &nh_all, true))) return rc;
 	for(Batch &b : S->batches) {
+		if(!b.n) continue;
 		kmahip_reads d = W;
 		d.n_reads = b.n; d.seq_off = W.seq_off + b.r0; d.len = W.len + b.r0; d.N_off = W.N_off + b.r0; d.max_len = b.max_len;
+		if(W.q_start) { d.q_start = W.q_start + b.r0; d.q_end = W.q_end + b.r0; }
 		kmahip_conclave cb = cc;
 		cb.tmpl = cc.tmpl + b.r0; cb.start = cc.start + b.r0; cb.end = cc.end + b.r0;
 		if((rc = kmahip_conclave_se_dev(db, ws, &d, &b.c, &b.h, &cb, s))) return rc;
@@ -471,6 +562,7 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 		RowArgs A{};
 		A.seq = W.seq; A.seq_off = W.seq_off; A.N_off = W.N_off; A.name_off = S->name_off.as<int64_t>(); A.len = W.len; A.N = W.N; A.rc = rc_all; A.tmpl = cc.tmpl; A.n_hits = nh_all;
 		A.stats = tr.stats; A.names = S->names.as<char>(); A.tnames = d_tn; A.tname_off = d_tn_off; A.row_read = vals2; A.row_off = row_len;
+		A.name_idx = S->chain ? S->rread.as<int64_t>() : nullptr;
 		hipLaunchKernelGGL(row_len_kernel, dim3((unsigned) ((n_frag_rows + 256) / 256)), dim3(256), 0, s, A, n_frag_rows);
 		HIP_TRY(hipGetLastError());
 		if((rc = scan_i64(B, row_len, row_off, (size_t) n_frag_rows + 1, s))) return rc;

@@ -91,10 +91,11 @@ def test_chain_records_equal_reference_binary_on_chimeric_reads(tmp_path, seed):
     assert len(flat) == len(ref)
 
 
-def _run_both(tmp_path, prefix, fq, extra=()):
+def _run_both(tmp_path, prefix, fq, extra=(), env=None):
+    """examples/kmahip_map in the default mode: through the batched session (kmahip_session_set_chain) unless env says otherwise"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
     subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-chain"] + list(extra), check=True,
-                   stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="700"))
+                   stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="700", **(env or {})))
     return [open(tmp_path / "got.res", "rb").read(), open(tmp_path / "got.fsa", "rb").read(), gzip.open(tmp_path / "got.frag.gz").read()]
 
 
@@ -152,3 +153,8 @@ def test_whole_default_mode_run_equals_reference_binary_on_chimeric_reads(tmp_pa
         d = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
         assert False, (len(a), len(b), len(d), a[d[0]][-120:] if d else None, b[d[0]][-120:] if d else None)
     assert frag.count(b"\n") > (10000 if seed <= 2 else 3000)
+    # the same through batches of 1 777 reads with text chunks of 30 kB (records of a read never straddle batches, chunks of -mf do),
+    # and through the one-batch call (kmahip_run_chain)
+    for env in ({"KMAHIP_MAP_BATCH": "1777", "KMAHIP_FRAG_CHUNK": "30000"}, {"KMAHIP_MAP_ONE_BATCH": "1"}):
+        assert _run_both(tmp_path, prefix, fq, extra, env) == [res, fsa, frag], env
+
