@@ -175,7 +175,8 @@ def c4_leg(tmp, n_reads, device, n_parity=5000):
     db = binding.KmaHipDB(prefix, device=device)
     t_open = time.perf_counter() - t0
     try:
-        first = formats.ReadBatch(b.seq[:b.seq_off[min(n_reads, 20000)]], b.seq_off[:min(n_reads, 20000) + 1], b.length[:min(n_reads, 20000)], b.N, b.N_off[:min(n_reads, 20000) + 1])
+        nw = min(n_reads, max(1024, 400_000_000 // L))       # one pass of the long-read traceback: every scratch array reaches its size
+        first = formats.ReadBatch(b.seq[:b.seq_off[nw]], b.seq_off[:nw + 1], b.length[:nw], b.N, b.N_off[:nw + 1])
         db.run_mt1(first, 1, consensus=False)       # scratch allocation, first launches
         t0 = time.perf_counter()
         o = db.run_mt1(b, 1, consensus=False)
