@@ -2009,16 +2009,19 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 			stage("lane sort");
 		}
-		constexpr int NSIDE = 5;
-		static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-		hipStream_t s1 = stream, s2 = stream, s3 = stream, s4 = stream, s5 = stream;
-		hipEvent_t fork = nullptr, join[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+		// (three side streams and the caller's: the runtime maps streams onto four hardware queues, and streams that share a queue
+		// run their kernels one after the other -- with five side streams the stage took 1.5 to 3.6 s for the same million reads,
+		// depending on which streams the process had made before)
+		constexpr int NSIDE = 3;
+		static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+		hipStream_t s1 = stream, s2 = stream, s3 = stream;
+		hipEvent_t fork = nullptr, join[NSIDE] = {nullptr, nullptr, nullptr};
 		if(!dbg) {
 			for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
 			HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
 			HIP_TRY(hipEventRecord(fork, stream));
 			for(int x = 0; x < NSIDE; ++x) HIP_TRY(hipStreamWaitEvent(side[x], fork, 0));
-			s1 = side[0]; s2 = side[1]; s3 = side[2]; s4 = side[3]; s5 = side[4];
+			s1 = side[0]; s2 = side[1]; s3 = side[2];
 		}
 		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
 		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
@@ -2047,8 +2050,8 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
 				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
 				hipStream_t ls = j <= 3 ? stream : (j == LT_LFULL ? s1 : ((j == 5 || j == LT_LCLS - 1) ? s3 : s2));
-				if(const char *map = getenv("KMAHIP_LT_STREAMS")) {       // diagnosis: a digit per lane class, 0 = the caller's stream, 1-5 = side streams
-					if((int) strlen(map) > j && !dbg) { const int x = map[j] - '0'; const hipStream_t all[6] = {stream, s1, s2, s3, s4, s5}; if(x >= 0 && x < 6) ls = all[x]; }
+				if(const char *map = getenv("KMAHIP_LT_STREAMS")) {       // diagnosis: a digit per lane class, 0 = the caller's stream, 1-3 = side streams
+					if((int) strlen(map) > j && !dbg) { const int x = map[j] - '0'; const hipStream_t all[4] = {stream, s1, s2, s3}; if(x >= 0 && x < 4) ls = all[x]; }
 				}
 				const void *fn = j < LT_LFULL ? (simple_sc ? (const void *) lt_lane_kernel<true> : (const void *) lt_lane_kernel<false>)
 				                       : (simple_sc ? (const void *) lt_lane_band_kernel<true> : (const void *) lt_lane_band_kernel<false>);
