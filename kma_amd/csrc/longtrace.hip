@@ -1848,6 +1848,10 @@ static int lt_reserve(kmahip_ws *ws, int slot, size_t bytes) {
 	if(ws->lt_bytes[slot] >= bytes) return KMAHIP_OK;
 	(void) hipFree(ws->lt_buf[slot]);
 	ws->lt_buf[slot] = nullptr; ws->lt_bytes[slot] = 0;
+	// (an eighth more than asked for: what is sized by a pass's own counts -- the lanes' matrices, the sort's scratch -- must not be
+	// freed and allocated again, gigabytes at a time, because the next pass needs a few bytes more)
+	const size_t want = bytes + bytes / 8;
+	if(hipMalloc(&ws->lt_buf[slot], want) == hipSuccess) { ws->lt_bytes[slot] = want; return KMAHIP_OK; }
 	if(hipMalloc(&ws->lt_buf[slot], bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes (long-read trace scratch) failed", bytes); return KMAHIP_ENOMEM; }
 	ws->lt_bytes[slot] = bytes;
 	return KMAHIP_OK;
