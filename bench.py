@@ -725,7 +725,8 @@ def main():
                         score=h_sc[:nt].cpu().numpy(), start=h_s[:nt].cpu().numpy(), end=h_e[:nt].cpu().numpy())
             out["config"]["parity_first_reads_vs_oracle"] = parity_sample(prefix, codes[:k], got, hits)
             out["config"]["parity_reads_checked"] = k
-            out["cpu_baseline"] = cpu_baseline(prefix, codes, tmp)
+            # (the device legs first, the reference's CPU runs after them: behind those, copies to the device and the long-read leg --
+            # hundreds of launches, host syncs between them -- came out up to twice as slow in some runs of this file and not in others)
             # beyond the benchmarked step (informational, never `value`): the same sample through kmahip_run_se -- host
             # buffers in, `.res` statistics + consensus out: upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus
             try:
@@ -750,6 +751,7 @@ def main():
                     out["c4"] = c4_leg(tmp, a.c4_reads, local, a.c4_parity)
                 except Exception as e:  # noqa: BLE001  (extra leg only)
                     out["c4"] = {"error": str(e)}
+            out["cpu_baseline"] = cpu_baseline(prefix, codes, tmp)
             if a.e2e_reads > 0 and not a.hard:
                 try:
                     db.close()            # the C host program opens the index itself; give it the card's memory back first
