@@ -158,3 +158,27 @@ def test_whole_default_mode_run_equals_reference_binary_on_chimeric_reads(tmp_pa
     for env in ({"KMAHIP_MAP_BATCH": "1777", "KMAHIP_FRAG_CHUNK": "30000"}, {"KMAHIP_MAP_ONE_BATCH": "1"}):
         assert _run_both(tmp_path, prefix, fq, extra, env) == [res, fsa, frag], env
 
+
+
+def test_default_mode_session_with_batches_that_hold_no_record_and_with_no_read_at_all(tmp_path):
+    """the batched default mode (kmahip_session_set_chain) when a whole batch maps nowhere, when the input ends in such a batch, and
+    when the input is empty: the files of the one-batch call"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    rng = np.random.default_rng(5)
+    names, seqs = synth.make_gene_db(20, 4, 300, 800, 0.05, seed=91)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    good = _chimeric_reads(seqs, 1500, rng)
+    junk = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(600)]
+    for label, reads in (("middle", good[:500] + junk + good[500:]), ("end", good + junk), ("only", junk), ("empty", [])):
+        fq = str(tmp_path / (label + ".fq"))
+        synth.write_fastq(fq, reads)
+        a = _run_both(tmp_path, prefix, fq, (), {"KMAHIP_MAP_BATCH": "500"})
+        b = _run_both(tmp_path, prefix, fq, (), {"KMAHIP_MAP_ONE_BATCH": "1"})
+        assert a == b, label
+        if label in ("middle", "end"):
+            subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            assert a[0] == open(tmp_path / "ref.res", "rb").read() and a[2] == gzip.open(tmp_path / "ref.frag.gz").read(), label
+            assert a[2].count(b"\n") > 500
