@@ -190,7 +190,7 @@ static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fi
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
 
 static void usage(void) {
-	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano]\n"
+	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
 	                "(the options of kma 1.5.1 this path implements; -apm takes p only, -ipe needs -1t1; everything else is refused)\n");
@@ -243,7 +243,9 @@ static int launch_ranks(int gpus, char **argv) {
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
-	int mt1 = 0, bc_nano = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, gpus = 0, threads = 0, bcd = 1;
+	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, gpus = 0, threads = 0, bcd = 1;
+	int base_call = 0, sig_mode = 0, ref_fsa = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
+	double support = 0;
 	long long max_frag = 0;
 	double evalue = 0.05, ID_t = 1.0, Depth_t = 0.0;
 	kmahip_params par;
@@ -255,7 +257,20 @@ int main(int argc, char **argv) {
 	for(int a = 1; a < argc; ++a) {
 		const char *o = argv[a];
 		if(!strcmp(o, "-Mt1")) mt1 = (int) need_int(argc, argv, &a, o);                        /* kma.c:923 */
-		else if(!strcmp(o, "-bcNano")) bc_nano = 1;                                             /* kma.c:762 */
+		else if(!strcmp(o, "-bcNano")) { if(sig_mode == 0) sig_mode = 1; base_call = 1; }   /* kma.c:762-766 */
+		else if(!strcmp(o, "-bc90")) sig_mode = 1;                                              /* kma.c:758 */
+		else if(!strcmp(o, "-bcg")) base_call = 2;                                              /* kma.c:760: orgBaseCaller */
+		else if(!strcmp(o, "-bc")) {                                                            /* kma.c:744-757: with a value the support a call needs, without one back to significantNuc */
+			if(a + 1 < argc && argv[a + 1][0] != '-') {
+				support = need_num(argc, argv, &a, o);
+				if(support < 0 || 1 < support) { fprintf(stderr, "kmahip_map: invalid argument at \"-bc\"\n"); return 1; }
+				sig_mode = 2;
+			} else sig_mode = 0;
+		}
+		else if(!strcmp(o, "-ref_fsa")) {                                                       /* kma.c:671-684 */
+			ref_fsa = 1;
+			if(a + 1 < argc && argv[a + 1][0] != '-') { ref_fsa = (int) need_int(argc, argv, &a, o); if(ref_fsa == 0) ref_fsa = 2; }
+		}
 		else if(!strcmp(o, "-1t1")) one2one = 1;                                                /* kma.c:686 */
 		else if(!strcmp(o, "-chain")) chain = 1;                                                /* (our own: the same as leaving -1t1 out) */
 		else if(!strcmp(o, "-t_db") && a + 1 < argc) prefix = argv[++a];
@@ -292,6 +307,7 @@ int main(int argc, char **argv) {
 		else { fprintf(stderr, "kmahip_map: option %s is not one this program implements\n", o); usage(); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe), -t_db and -o are required\n"); usage(); return 2; }
+	if(ref_fsa == 1) base_call = base_call == 1 ? 4 : 3;      /* kma.c:1278-1284: refNanoCaller / refCaller */
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
 	if(input2 && !apm) { fprintf(stderr, "kmahip_map: -ipe needs -apm p (the reference pairs by union without it, kma.c:206: not built)\n"); return 2; }
@@ -355,7 +371,7 @@ int main(int argc, char **argv) {
 		const double t_open = now_s();
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call; so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		int64_t hint = 0;
 		{	/* (a guess at the number of reads from the size of the input: it only sizes the first allocation) */
 			struct stat sb;
@@ -445,7 +461,7 @@ int main(int argc, char **argv) {
 		}
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = bc_nano; so.sig90 = bc_nano; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call; so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		double ms[8];
 		if(mt1 ? kmahip_run_mt1_sharded(db, ws, comm, &b, mt1, one2one, &par, &so, out, ms)
 		       : chain ? kmahip_run_chain_sharded(db, ws, comm, &b, &par, &cp, &so, out, ms)
@@ -484,7 +500,7 @@ int main(int argc, char **argv) {
 	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
-	run.caller = bc_nano; run.sig90 = bc_nano;      /* -bcNano (kma.c:762-766) */
+	run.caller = base_call | (ref_fsa == 2 ? 8 : 0); run.sig90 = sig_mode; run.support = support;      /* -bcNano, -bc90, -bc, -bcg, -ref_fsa (bit 3: mark the trimmed insertion columns) */
 	touch_job tj = { { (char *) run.tmpl, (char *) run.n_hits, (char *) run.rc, (char *) run.trace_stats },
 	                 { ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n * 10 + 10) * 4 } };
 	pthread_t touch_thread;
@@ -495,7 +511,7 @@ int main(int argc, char **argv) {
 	if(mt1) {
 		kmahip_assemble_opts ao;
 		memset(&ao, 0, sizeof ao);
-		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = bc_nano; ao.sig90 = bc_nano;
+		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = base_call | (ref_fsa == 2 ? 8 : 0); ao.sig90 = sig_mode; ao.support = support;
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
 	} else if(chain) {
 		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, &cp, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_chain");
@@ -537,7 +553,7 @@ int main(int argc, char **argv) {
 		if(clen + clen / 60 + 2 > fsa_cap) { fsa_cap = 2 * (clen + clen / 60 + 2); free(fsa_buf); fsa_buf = xcalloc(fsa_cap, 1); }
 		char *o = fsa_buf;
 		int col = 0;
-		for(; *c; ++c) if(*c != '-') { *o++ = *c; if(++col == 60) { *o++ = '\n'; col = 0; } }
+		for(; *c; ++c) if(*c != '_' && (*c != '-' || ref_fsa == 2)) { *o++ = *c; if(++col == 60) { *o++ = '\n'; col = 0; } }
 		if(col) *o++ = '\n';
 		fwrite(fsa_buf, 1, (size_t) (o - fsa_buf), fsa);
 	}

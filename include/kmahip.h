@@ -340,14 +340,18 @@ typedef struct kmahip_assemble_opts {
 	double evalue;      /* -e, 0.05 */
 	int32_t bcd;        /* -bcd, 1 */
 	int32_t order;      /* 0 ConClave's order, 1 stream order */
-	int32_t caller;     /* 0 baseCaller, 1 nanoCaller */
-	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc */
+	int32_t caller;     /* 0 baseCaller, 1 nanoCaller (-bcNano), 2 orgBaseCaller (-bcg), 3 refCaller (-ref_fsa), 4 refNanoCaller (-ref_fsa
+	                     * -bcNano): assembly.c:162-270. + 8: insertion columns called as gaps -- which the reference trims from its alignment,
+	                     * assembly.c:748-752 -- come out as '_' in the consensus string instead of '-' (for a writer that keeps the gaps of
+	                     * template positions: -ref_fsa 0) */
+	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc (-bc90, -bcNano), 2 significantAndSupport (-bc x): `support` below */
 	/* per read: how many filed fragments (ConClave template != 0) precede it in the WHOLE stream -- what the reference's
 	 * chunks of max_frag records are counted in (conclave.c:166, 194). NULL: the batch is the whole stream and the
 	 * positions are counted here. A rank that piles up the reads of its templates gathered from several read shards
 	 * (kma_amd/dist.py) passes the positions the reads had in the global stream. Host pointer for kmahip_assemble2,
 	 * device pointer for kmahip_assemble2_dev. */
 	const int64_t *frag_rank;
+	double support;     /* sig90 == 2: a base call needs support * depth of the column (assembly.c:151-160) */
 } kmahip_assemble_opts;
 int kmahip_assemble2(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *rc, const int32_t *tmpl,
                      const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out);
@@ -371,6 +375,7 @@ typedef struct kmahip_run {
 	int32_t *tmpl, *n_hits, *rc, *trace_stats;
 	double ms[6];
 	int32_t caller, sig90;      /* IN, kmahip_run_se / _pe / _chain: the base caller as in kmahip_assemble_opts (`-bcNano` = 1, 1; 0, 0 = baseCaller) */
+	double support;             /* IN: as kmahip_assemble_opts.support */
 } kmahip_run;
 int kmahip_run_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_params *p, double evalue, int bcd,
                   int64_t max_frag, kmahip_run *out);
@@ -580,6 +585,9 @@ typedef struct kmahip_shard_opts {
 	int32_t caller, sig90;/* -bcNano: 1, 1 */
 	int64_t max_frag;     /* -mf, <= 0: 1000000 */
 	double ID_t, Depth_t; /* -ID (1.0), -md (0.0) */
+	double support;       /* -bc x with sig90 == 2 */
+	int32_t ref_fsa;      /* the consensus file: 0 gap columns left out, 1 gaps as n (-ref_fsa), 2 as they are (-ref_fsa 0; printconsensus.c:38-60) */
+	int32_t pad_;
 } kmahip_shard_opts;
 int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);

@@ -91,13 +91,13 @@ class ChainRecs(C.Structure):
 
 class AssembleOpts(C.Structure):
     _fields_ = [("max_frag", C.c_int64), ("evalue", C.c_double), ("bcd", C.c_int32), ("order", C.c_int32), ("caller", C.c_int32), ("sig90", C.c_int32),
-                ("frag_rank", C.c_void_p)]
+                ("frag_rank", C.c_void_p), ("support", C.c_double)]
 
 
 class Run(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_cap", C.c_int64), ("n_rows", C.c_int64), ("assembly", Assembly),
                 ("tmpl", C.c_void_p), ("n_hits", C.c_void_p), ("rc", C.c_void_p), ("trace_stats", C.c_void_p), ("ms", C.c_double * 6),
-                ("caller", C.c_int32), ("sig90", C.c_int32)]
+                ("caller", C.c_int32), ("sig90", C.c_int32), ("support", C.c_double)]
 
 
 class ScanStats(C.Structure):

@@ -748,7 +748,9 @@ struct ConsArgs {
 	int64_t n_kept;
 	int bcd;
 	int caller;                  // 0 baseCaller, 1 nanoCaller (-bcNano, assembly.c:205-240)
-	int sig90;                   // significantAnd90Nuc instead of significantNuc (-bcNano, assembly.c:147-149)
+	int sig90;                   // 1: significantAnd90Nuc instead of significantNuc (-bcNano, -bc90; assembly.c:147-149), 2: significantAndSupport
+	double support;
+	int mark_ins;                // insertion columns called as gaps are written as '_' (kmahip_assemble_opts.caller bit 3)
 	double qstar;
 	unsigned long long *cover, *aln_len, *depth, *asm_len;      // per template
 	char *cons;                  // pass 2: consensus characters
@@ -763,7 +765,7 @@ struct ConsArgs {
 
 __device__ __forceinline__ unsigned char dev_lower(unsigned char c) { return (c >= 'A' && c <= 'Z') ? (unsigned char) (c + 32) : c; }
 
-__device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd, double qstar, int caller, int sig90, long long *depth_out) {
+__device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd, double qstar, int caller, int sig90, double support, long long *depth_out) {
 	const char bases[7] = {'A', 'C', 'G', 'T', 'N', '-', 0};
 	int cnt[6];
 	for(int j = 0; j < 6; ++j) cnt[j] = (int) min(c32[j], 65535u);
@@ -785,19 +787,32 @@ __device__ unsigned char call_column_dev(const uint32_t *c32, int tnuc, int bcd,
 		} else call = dev_lower(call);
 		bestScore = (int) (depthUpdate - cnt[5]);
 	} else if(depthUpdate < bcd) call = dev_lower(call);
-	if(depthUpdate == 0) call = '-';
-	else {
+	{
+		// the base callers (assembly.c:162-270): 0 baseCaller, 1 nanoCaller, 2 orgBaseCaller, 3 refCaller, 4 refNanoCaller
 		const int X = bestScore, Y = (int) depthUpdate - bestScore;
-		const bool sig = Y < X && (!sig90 || 9ll * (X + Y) <= 10ll * X) && ((double) ((long long) (X - Y) * (X - Y)) / (double) (X + Y)) >= qstar;
-		if(!sig) {
-			if(call == '-' && tch != '-' && bestScore != depthUpdate) {
-				if(caller == 1) {
-					// nanoCaller: the best base count (N included) decides; first of equals
-					int bb = 0, b = -1;
-					for(int j = 0; j < 5; ++j) if(bb < cnt[j]) { bb = cnt[j]; b = j; }
-					call = bb == 0 ? (unsigned char) '-' : dev_lower((unsigned char) bases[b]);
-				} else call = 'n';
-			} else call = dev_lower(call);
+		const bool sig = depthUpdate != 0 && Y < X && (sig90 != 1 || 9ll * (X + Y) <= 10ll * X) && (sig90 != 2 || support * (double) (X + Y) <= (double) X) &&
+		                 ((double) ((long long) (X - Y) * (X - Y)) / (double) (X + Y)) >= qstar;
+		auto best_base = [&](unsigned char none) {      // the best base count (N included) decides; first of equals
+			int bb = 0, b = -1;
+			for(int j = 0; j < 5; ++j) if(bb < cnt[j]) { bb = cnt[j]; b = j; }
+			return bb == 0 ? none : dev_lower((unsigned char) bases[b]);
+		};
+		if(caller == 2) {
+			if(depthUpdate == 0 || call == '-') call = '-';
+			else if(!sig) call = dev_lower(call);
+		} else if(caller == 3) {
+			if(depthUpdate == 0 || (call == '-' && tch != '-')) call = 'n';
+			else if(!sig) call = dev_lower(call);
+		} else if(caller == 4) {
+			if(depthUpdate == 0) call = 'n';
+			else if(!sig) call = call == '-' ? best_base((unsigned char) 'n') : dev_lower(call);
+			else if(call == '-') call = 'n';
+		} else {
+			if(depthUpdate == 0) call = '-';
+			else if(!sig) {
+				if(call == '-' && tch != '-' && bestScore != depthUpdate) call = caller == 1 ? best_base((unsigned char) '-') : (unsigned char) 'n';
+				else call = dev_lower(call);
+			}
 		}
 	}
 	*depth_out = depthUpdate;
@@ -850,7 +865,7 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 				int64_t o = running + incl - items;
 				const int tnuc = (int) ((ts[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull);
 				long long dep = 0;
-				unsigned char call = call_column_dev(C.counts + (size_t) (base + p) * 6, tnuc, C.bcd, C.qstar, C.caller, C.sig90, &dep);
+				unsigned char call = call_column_dev(C.counts + (size_t) (base + p) * 6, tnuc, C.bcd, C.qstar, C.caller, C.sig90, C.support, &dep);
 				if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
 				++o;
 				if(call != '-') {
@@ -860,8 +875,10 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 				}
 				const int np = (p + 1 == t_len) ? 0 : p + 1;
 				for(int h = C.chain_head[base + np]; h; h = C.nodes[h - 1].next) {
-					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, C.caller, C.sig90, &dep);
-					if(WRITE && coff >= 0) C.cons[coff + o] = (char) call;
+					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, C.caller, C.sig90, C.support, &dep);
+					// (an insertion column called as a gap is trimmed from the reference's alignment, assembly.c:748-752: marked where the
+					// writer keeps the gaps of template positions, `-ref_fsa 0`)
+					if(WRITE && coff >= 0) C.cons[coff + o] = (call == '-' && C.mark_ins) ? '_' : (char) call;
 					++o;
 					if(call != '-') { depth += (unsigned long long) dep; ++aln; }
 				}
@@ -1132,9 +1149,10 @@ static double asm_p_chisqr(long double q) {      // stdstat.c:136-147
 	if(q > 49) return asm_chi2_table(q);
 	return 1 - 1.772453850 * erf(sqrt((double) (0.5 * q))) / tgamma(0.5);
 }
-static int significant_nuc(int X, int Y, double evalue, int sig90 = 0) {   // significantNuc / significantAnd90Nuc, assembly.c:143-149
+static int significant_nuc(int X, int Y, double evalue, int sig90 = 0, double support = 0) {   // significantNuc / significantAnd90Nuc, assembly.c:143-149
 	if(!(Y < X)) return 0;
-	if(sig90 && !(9ll * (X + Y) <= 10ll * X)) return 0;
+	if(sig90 == 1 && !(9ll * (X + Y) <= 10ll * X)) return 0;
+	if(sig90 == 2 && !(support * (double) (X + Y) <= (double) X)) return 0;
 	// a pure function of (X, Y, evalue): memoised, most columns of a pile-up repeat a handful of (X, Y) pairs
 	struct Slot { uint64_t key; double ev; int val; };
 	static thread_local std::vector<Slot> memo(1 << 16, Slot{~0ull, 0.0, 0});
@@ -1147,7 +1165,7 @@ static int significant_nuc(int X, int Y, double evalue, int sig90 = 0) {   // si
 }
 
 // one column: callConsensus body + baseCaller (assembly.c:1543-1595, 162-179); counts already clamped to 16 bit
-static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, int bcd, double evalue, int caller, int sig90, long *depth_out) {
+static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, int bcd, double evalue, int caller, int sig90, double support, long *depth_out) {
 	static const char bases[] = "ACGTN-";
 	int bestNuc = tnuc;
 	const char tch = bases[tnuc];
@@ -1167,15 +1185,30 @@ static unsigned char call_column(const uint32_t *cnt, int tnuc /* 0-3 or 5 */, i
 		} else call = (unsigned char) tolower(call);
 		bestScore = (int) (depthUpdate - cnt[5]);
 	} else if(depthUpdate < bcd) call = (unsigned char) tolower(call);
-	if(depthUpdate == 0) call = '-';
-	else if(significant_nuc(bestScore, (int) depthUpdate - bestScore, evalue, sig90) == 0) {
-		if(call == '-' && tch != '-' && bestScore != depthUpdate) {
-			if(caller == 1) {
-				int bb = 0, b = -1;
-				for(int j = 0; j < 5; ++j) if(bb < (int) cnt[j]) { bb = (int) cnt[j]; b = j; }
-				call = bb == 0 ? (unsigned char) '-' : (unsigned char) tolower(bases[b]);
-			} else call = 'n';
-		} else call = (unsigned char) tolower(call);
+	{
+		const bool sig = depthUpdate != 0 && significant_nuc(bestScore, (int) depthUpdate - bestScore, evalue, sig90, support) != 0;
+		auto best_base = [&](unsigned char none) {
+			int bb = 0, b = -1;
+			for(int j = 0; j < 5; ++j) if(bb < (int) cnt[j]) { bb = (int) cnt[j]; b = j; }
+			return bb == 0 ? none : (unsigned char) tolower(bases[b]);
+		};
+		if(caller == 2) {
+			if(depthUpdate == 0 || call == '-') call = '-';
+			else if(!sig) call = (unsigned char) tolower(call);
+		} else if(caller == 3) {
+			if(depthUpdate == 0 || (call == '-' && tch != '-')) call = 'n';
+			else if(!sig) call = (unsigned char) tolower(call);
+		} else if(caller == 4) {
+			if(depthUpdate == 0) call = 'n';
+			else if(!sig) call = call == '-' ? best_base((unsigned char) 'n') : (unsigned char) tolower(call);
+			else if(call == '-') call = 'n';
+		} else {
+			if(depthUpdate == 0) call = '-';
+			else if(!sig) {
+				if(call == '-' && tch != '-' && bestScore != depthUpdate) call = caller == 1 ? best_base((unsigned char) '-') : (unsigned char) 'n';
+				else call = (unsigned char) tolower(call);
+			}
+		}
 	}
 	*depth_out = depthUpdate;
 	return call;
@@ -1244,7 +1277,8 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
                                     const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out) {
 	if(!opts) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	const int64_t max_frag = opts->max_frag;
-	const int bcd = opts->bcd, caller = opts->caller, sig90 = opts->sig90;
+	const int bcd = opts->bcd, caller = opts->caller & 7, sig90 = opts->sig90, mark_ins = (opts->caller >> 3) & 1;
+	const double support = opts->support;
 	const double evalue = opts->evalue;
 	if(!db || !ws || !reads || !d_flag || !d_tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	if(db->h_cat_off.empty()) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
@@ -1297,7 +1331,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 			DevGuard G;
 			ConsArgs C;
 			C.db = db->dev; C.counts = ws->p_counts; C.chain_head = ws->p_chain; C.nodes = (const InsNode *) ws->p_nodes; C.seg_start = ws->p_seg;
-			C.n_kept = ws->p_kept; C.bcd = bcd; C.caller = caller; C.sig90 = sig90; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
+			C.n_kept = ws->p_kept; C.bcd = bcd; C.caller = caller; C.sig90 = sig90; C.support = support; C.mark_ins = mark_ins; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
 			unsigned long long *fig = nullptr;
 			HIP_TRY(hipMalloc((void **) &fig, (size_t) 4 * D * sizeof(unsigned long long)));
 			G.v.push_back(fig);
@@ -1389,9 +1423,9 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 			uint32_t c[6];
 			for(int j = 0; j < 6; ++j) c[j] = std::min<uint32_t>(c32[j], 65535u);
 			long dep = 0;
-			const unsigned char call = call_column(c, tnuc, bcd, evalue, caller, sig90, &dep);
+			const unsigned char call = call_column(c, tnuc, bcd, evalue, caller, sig90, support, &dep);
 			++asm_len;
-			if(out->consensus) cons.push_back((char) call);
+			if(out->consensus) cons.push_back((call == '-' && !is_template && mark_ins) ? '_' : (char) call);
 			if(call != '-') {
 				depth += dep; ++aln_len;
 				if(is_template && "ACGTN-"[tnuc] == toupper(call)) ++cover;

@@ -75,7 +75,7 @@ static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kma
 
 	// stage 3c per template
 	if(n) {
-		kmahip_assemble_opts ao = {max_frag, evalue, bcd, 0, out->caller, out->sig90, nullptr};      // (caller / sig90: `-bcNano`)
+		kmahip_assemble_opts ao = {max_frag, evalue, bcd, 0, out->caller, out->sig90, nullptr, out->support};      // (caller / sig90: `-bcNano`)
 		if((rc = kmahip_assemble2_dev(db, ws, &d, h.rc, cc.tmpl, &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);     // (pile-up + copy-back + consensus: kmahip_assemble_dev prints the split with KMAHIP_DEBUG_TIMING)
@@ -601,7 +601,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 
 	// stage 3c per template
 	if(nf > 0) {
-		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, out->caller, out->sig90, f_rank};
+		kmahip_assemble_opts ao = {mf + 1, evalue, bcd, 0, out->caller, out->sig90, f_rank, out->support};
 		if((rc = kmahip_assemble2_dev(db, ws, &dF, f_rc, f_t, &tr, &ao, &out->assembly))) return rc;
 	} else for(size_t i = 0; i < D; ++i) { out->assembly.cover[i] = 0; out->assembly.aln_len[i] = 0; out->assembly.depth[i] = 0; out->assembly.asm_len[i] = 0; }
 	out->ms[4] = since(t);
@@ -1046,7 +1046,7 @@ int concat_parts(const std::string &prefix, const char *ext, int world, const ch
 // `rank`. fsa_path NULL: no consensus file (-nc).
 int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_path, bool header, const kmahip_res_row *rows, int64_t n_rows,
                          const int32_t *owner, int rank, const int64_t *cover, const int64_t *aln_len, const int64_t *depth, const char *cons,
-                         const int64_t *cons_off, double ID_t, double Depth_t) {
+                         const int64_t *cons_off, double ID_t, double Depth_t, int ref_fsa) {
 	int rc = kmahip_db_load_names(db);
 	if(rc) return rc;
 	FILE *res = fopen(res_path, "w"), *fsa = fsa_path ? fopen(fsa_path, "w") : nullptr;
@@ -1065,7 +1065,10 @@ int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_pa
 		entry.clear();
 		entry += ">"; entry += name; entry += "\n";
 		int col = 0;
-		for(const char *q = cons_off[tt] >= 0 ? cons + cons_off[tt] : ""; *q; ++q) if(*q != '-') { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
+		// printConsensus (printconsensus.c:38-60): gap columns left out;
+		// with -ref_fsa 0 (ref_fsa == 2) the gaps of template positions stay; insertion columns called as gaps ('_': the caller was asked to
+		// mark them) were trimmed from the alignment before (assembly.c:748-752). With -ref_fsa refCaller leaves no gap at a template position.
+		for(const char *q = cons_off[tt] >= 0 ? cons + cons_off[tt] : ""; *q; ++q) if(*q != '_' && (*q != '-' || ref_fsa == 2)) { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
 		if(col) entry.push_back('\n');
 		fwrite(entry.data(), 1, entry.size(), fsa);
 	}
@@ -1235,7 +1238,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
 	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
 	if(m2) {
-		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, order, opts->caller, opts->sig90, fr2};
+		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, order, opts->caller | (opts->ref_fsa == 2 ? 8 : 0), opts->sig90, fr2, opts->support};
 		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
 	}
 	ms[5] = since(t);
@@ -1243,7 +1246,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
 	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
 	if((rc = kmahip_write_res_fsa(db, (part + ".res").c_str(), (part + ".fsa").c_str(), false, rows, n_rows, owner.data(), rank, a_cover.data(), a_len.data(), a_depth.data(),
-	                              cons.data(), c_off.data(), opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t))) return rc;
+	                              cons.data(), c_off.data(), opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, opts->ref_fsa))) return rc;
 	{
 		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
 		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);
@@ -1615,7 +1618,7 @@ extern "C" int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	memset(&run, 0, sizeof run);
 	run.rows = rows.data(); run.rows_cap = (int64_t) D;
 	run.assembly.cover = a0.data(); run.assembly.aln_len = a1.data(); run.assembly.depth = a2.data(); run.assembly.asm_len = a3.data();
-	run.caller = opts->caller; run.sig90 = opts->sig90;
+	run.caller = opts->caller; run.sig90 = opts->sig90; run.support = opts->support;
 	ShardCtx sc{comm, opts, out_prefix, ms, {}};
 	rc = run_pe_impl(db, ws, batch, p, opts->evalue, opts->bcd, opts->max_frag, nullptr, &run, &sc);
 	for(int i = 0; i < 4; ++i) ms[i] = run.ms[i];

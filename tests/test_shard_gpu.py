@@ -303,3 +303,34 @@ def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_
     assert open(r + ".res").read() == open(b + ".res").read()
     assert open(r + ".fsa").read() == open(b + ".fsa").read()
     assert gzip.open(r + ".frag.gz").read() == fb
+
+
+@pytest.mark.parametrize("opts", [["-bc90"], ["-bcg"], ["-bc", "0.7"], ["-ref_fsa"], ["-ref_fsa", "0"], ["-bcNano", "-ref_fsa"], ["-bc", "0.6", "-bcNano"],
+                                  ["-bcNano", "-bcg"], ["-bcd", "12", "-bc90"]])
+def test_base_caller_options_equal_the_reference(tmp_path, opts):
+    """the consensus options of kma.c:671-770 (orgBaseCaller, refCaller, refNanoCaller, significantAnd90Nuc, significantAndSupport,
+    the three forms of the consensus file) through the batched -1t1 run, the one-batch default mode and three ranks: `.res` and `.fsa`
+    of the compiled reference with the same options"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(n_families=12, variants=4, seed=177)
+    rng = np.random.default_rng(9)
+    reads = []
+    # shallow and deep templates, noisy reads with indels: calls below the depth and support thresholds, gaps that are and are not significant
+    for g in range(len(seqs)):
+        depth = int(rng.choice([2, 6, 25, 80]))
+        reads += synth.make_long_reads(seqs[g], depth, read_len=min(220, len(seqs[g]) - 5), sub=0.04, dele=0.03, ins=0.03, seed=1000 + g)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    for mode, env, pre in ((["-1t1"], {}, []), ([], {"KMAHIP_MAP_ONE_BATCH": "1"}, []), (["-1t1"], {"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"}, ["-gpus", "3"])):
+        subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"] + mode + opts, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _run(pre + ["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got")] + mode + opts, env=env)
+        r, g = str(tmp_path / "ref"), str(tmp_path / "got")
+        assert open(r + ".res").read() == open(g + ".res").read(), (mode, pre)
+        assert open(r + ".fsa").read() == open(g + ".fsa").read(), (mode, pre)
+        assert open(r + ".res").read().count("\n") > 8
