@@ -190,7 +190,7 @@ static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fi
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
 
 static void usage(void) {
-	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]]\n"
+	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
 	                "(the options of kma 1.5.1 this path implements; -apm takes p only, -ipe needs -1t1; everything else is refused)\n");
@@ -244,7 +244,7 @@ static int launch_ranks(int gpus, char **argv) {
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, gpus = 0, threads = 0, bcd = 1;
-	int base_call = 0, sig_mode = 0, ref_fsa = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
+	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
 	double support = 0;
 	long long max_frag = 0;
 	double evalue = 0.05, ID_t = 1.0, Depth_t = 0.0;
@@ -258,6 +258,7 @@ int main(int argc, char **argv) {
 		const char *o = argv[a];
 		if(!strcmp(o, "-Mt1")) mt1 = (int) need_int(argc, argv, &a, o);                        /* kma.c:923 */
 		else if(!strcmp(o, "-bcNano")) { if(sig_mode == 0) sig_mode = 1; base_call = 1; }   /* kma.c:762-766 */
+		else if(!strcmp(o, "-dense")) dense = 1;                                               /* kma.c:662: alnToMatDense */
 		else if(!strcmp(o, "-bc90")) sig_mode = 1;                                              /* kma.c:758 */
 		else if(!strcmp(o, "-bcg")) base_call = 2;                                              /* kma.c:760: orgBaseCaller */
 		else if(!strcmp(o, "-bc")) {                                                            /* kma.c:744-757: with a value the support a call needs, without one back to significantNuc */
@@ -371,7 +372,7 @@ int main(int argc, char **argv) {
 		const double t_open = now_s();
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = base_call; so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		int64_t hint = 0;
 		{	/* (a guess at the number of reads from the size of the input: it only sizes the first allocation) */
 			struct stat sb;
@@ -461,7 +462,7 @@ int main(int argc, char **argv) {
 		}
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = base_call; so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		double ms[8];
 		if(mt1 ? kmahip_run_mt1_sharded(db, ws, comm, &b, mt1, one2one, &par, &so, out, ms)
 		       : chain ? kmahip_run_chain_sharded(db, ws, comm, &b, &par, &cp, &so, out, ms)
@@ -500,7 +501,7 @@ int main(int argc, char **argv) {
 	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
-	run.caller = base_call | (ref_fsa == 2 ? 8 : 0); run.sig90 = sig_mode; run.support = support;      /* -bcNano, -bc90, -bc, -bcg, -ref_fsa (bit 3: mark the trimmed insertion columns) */
+	run.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0); run.sig90 = sig_mode; run.support = support;      /* -bcNano, -bc90, -bc, -bcg, -ref_fsa (bit 3: mark the trimmed insertion columns) */
 	touch_job tj = { { (char *) run.tmpl, (char *) run.n_hits, (char *) run.rc, (char *) run.trace_stats },
 	                 { ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n * 10 + 10) * 4 } };
 	pthread_t touch_thread;
@@ -511,7 +512,7 @@ int main(int argc, char **argv) {
 	if(mt1) {
 		kmahip_assemble_opts ao;
 		memset(&ao, 0, sizeof ao);
-		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = base_call | (ref_fsa == 2 ? 8 : 0); ao.sig90 = sig_mode; ao.support = support;
+		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0); ao.sig90 = sig_mode; ao.support = support;
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
 	} else if(chain) {
 		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, &cp, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_chain");

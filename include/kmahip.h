@@ -343,7 +343,8 @@ typedef struct kmahip_assemble_opts {
 	int32_t caller;     /* 0 baseCaller, 1 nanoCaller (-bcNano), 2 orgBaseCaller (-bcg), 3 refCaller (-ref_fsa), 4 refNanoCaller (-ref_fsa
 	                     * -bcNano): assembly.c:162-270. + 8: insertion columns called as gaps -- which the reference trims from its alignment,
 	                     * assembly.c:748-752 -- come out as '_' in the consensus string instead of '-' (for a writer that keeps the gaps of
-	                     * template positions: -ref_fsa 0) */
+	                     * template positions: -ref_fsa 0). + 16: alnToMatDense (-dense, assembly.c:1446-1497): template positions only, no
+	                     * insertion columns */
 	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc (-bc90, -bcNano), 2 significantAndSupport (-bc x): `support` below */
 	/* per read: how many filed fragments (ConClave template != 0) precede it in the WHOLE stream -- what the reference's
 	 * chunks of max_frag records are counted in (conclave.c:166, 194). NULL: the batch is the whole stream and the

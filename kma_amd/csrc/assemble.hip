@@ -925,6 +925,80 @@ static int assemble_scratch(kmahip_db *db, kmahip_ws *ws, int64_t n_reads, int64
 }
 
 // device part: counts / chains of every template with kept reads. All pointers are device pointers.
+// ---- alnToMatDense (`-dense`, assembly.c:1446-1497): template positions only -- the bases and gaps the reads put on them, no insertion
+// columns -- so the order of the reads does not matter: a wavefront per read, its runs 64 at a time (prefix sums by shuffles), a lane
+// per run. As the reference does it: gap runs at the END of an alignment are trimmed, those at its start are not (its loop for them
+// never runs); a run of gaps in the template (an insertion) only moves on in the read.
+__global__ __launch_bounds__(64) void pile_dense_kernel(const PileArgs A, unsigned long long *kept) {
+	const int lane = threadIdx.x;
+	for(int64_t r = blockIdx.x; r < A.n_reads; r += gridDim.x) {
+		const int32_t *st = A.stats + 10 * r;
+		if(st[3] == 0 || A.tmpl[r] == 0) continue;
+		const int t = abs(A.tmpl[r]);
+		const int t_len = A.db.tlen[t];
+		const int64_t tbase = A.db.cat_off[t];
+		if(lane == 0) { A.seg_start[t] = 0; atomicAdd(kept, 1ull); }
+		const int64_t o = A.ops_off[r];
+		int n = A.n_ops[r];
+		while(n > 0 && (A.ops[o + n - 1] & 3u) >= 2u) --n;          // trailing gap runs
+		Q q;
+		q.w = A.seq + A.seq_off[r]; q.L = A.len[r]; q.N = A.N + A.N_off[r]; q.nN = (int) (A.N_off[r + 1] - A.N_off[r]);
+		q.rc = (((A.flag[r] & 1) != 0) != (A.tmpl[r] < 0)) ? 1 : 0;
+		q.cw = -1; q.cv = 0;
+		int col_carry = 0, q_carry = st[4];
+		const int start = st[1] >= t_len ? st[1] - t_len : st[1];
+		for(int j0 = 0; j0 < n; j0 += 64) {
+			const int j = j0 + lane;
+			const bool valid = j < n;
+			const uint32_t run = valid ? A.ops[o + j] : 0u;
+			const int cls = (int) (run & 3u), len = (int) (run >> 2);
+			const int tl = valid && cls != 2 ? len : 0, ql = valid && cls != 3 ? len : 0;
+			int ct = tl, cq = ql;
+			for(int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ct, d), b = __shfl_up(cq, d); if(lane >= d) { ct += a; cq += b; } }
+			const int col0 = col_carry + ct - tl, q0 = q_carry + cq - ql;
+			if(tl > 0) {
+				int p = (start + col0) % t_len;
+				for(int c = 0; c < len; ++c) {
+					const int b = cls == 3 ? 5 : q_base(q, q0 + c);
+					atomicAdd(&A.counts[6 * (tbase + p) + b], 1u);
+					if(++p == t_len) p = 0;
+				}
+			}
+			col_carry += __shfl(ct, 63); q_carry += __shfl(cq, 63);
+		}
+	}
+}
+
+static int pileup_dense_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl, const kmahip_traces *tr, hipStream_t stream) {
+	const int64_t n = reads->n_reads;
+	int rc = assemble_scratch(db, ws, std::max<int64_t>(n, 1), 1 << 20);
+	if(rc) return rc;
+	const int64_t total = ws->p_total;
+	const int64_t D = db->info.DB_size;
+	PileArgs A;
+	memset((void *) &A, 0, sizeof A);
+	A.db = db->dev; A.n_reads = n; A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
+	A.flag = flag; A.tmpl = tmpl; A.stats = tr->stats; A.ops_off = tr->ops_off; A.n_ops = tr->n_ops; A.ops = tr->ops;
+	A.counters = ws->counters; A.counts = ws->p_counts; A.chain_head = ws->p_chain; A.nodes = (InsNode *) ws->p_nodes; A.seg_start = ws->p_seg;
+	ws->p_kept = 0; ws->p_nodes_used = 0;
+	if(n == 0) return KMAHIP_OK;
+	HIP_TRY(hipMemsetAsync(ws->p_counts, 0, (size_t) (total + 1) * 6 * sizeof(uint32_t), stream));
+	HIP_TRY(hipMemsetAsync(ws->p_chain, 0, (size_t) (total + 1) * sizeof(int32_t), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, 3 * sizeof(unsigned long long), stream));
+	{
+		std::vector<int32_t> init((size_t) D + 1, INT32_MAX);
+		HIP_TRY(hipMemcpyAsync(ws->p_seg, init.data(), init.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+	}
+	hipLaunchKernelGGL(pile_dense_kernel, dim3((unsigned) std::min<int64_t>(n, 256 * 32)), dim3(64), 0, stream, A, ws->counters);
+	HIP_TRY(hipGetLastError());
+	unsigned long long kept = 0;
+	HIP_TRY(hipMemcpy(&kept, ws->counters, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemsetAsync(ws->counters, 0, 3 * sizeof(unsigned long long), stream));
+	ws->p_kept = (int64_t) kept;
+	return KMAHIP_OK;
+}
+
 static int pileup_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *flag, const int32_t *tmpl,
                          const kmahip_traces *tr, int64_t max_frag, int order, const int64_t *frag_rank, hipStream_t stream) {
 	const int64_t n = reads->n_reads;
@@ -1292,7 +1366,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	const auto t0 = now();
-	if((rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, opts->order, opts->frag_rank, 0))) return rc;
+	if((opts->caller & 16) ? (rc = pileup_dense_device(db, ws, &d, d_flag, d_tmpl, &dt, 0)) : (rc = pileup_device(db, ws, &d, d_flag, d_tmpl, &dt, max_frag, opts->order, opts->frag_rank, 0))) return rc;
 	const auto t1 = now();
 	if(dbg) fprintf(stderr, "[kmahip] assemble: pile-up on device %.1f ms\n", ms(t0, t1));
 	if(!ws->p_kept) return KMAHIP_OK;

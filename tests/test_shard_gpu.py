@@ -306,7 +306,7 @@ def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_
 
 
 @pytest.mark.parametrize("opts", [["-bc90"], ["-bcg"], ["-bc", "0.7"], ["-ref_fsa"], ["-ref_fsa", "0"], ["-bcNano", "-ref_fsa"], ["-bc", "0.6", "-bcNano"],
-                                  ["-bcNano", "-bcg"], ["-bcd", "12", "-bc90"]])
+                                  ["-bcNano", "-bcg"], ["-bcd", "12", "-bc90"], ["-dense"], ["-dense", "-bcNano", "-ref_fsa", "0"]])
 def test_base_caller_options_equal_the_reference(tmp_path, opts):
     """the consensus options of kma.c:671-770 (orgBaseCaller, refCaller, refNanoCaller, significantAnd90Nuc, significantAndSupport,
     the three forms of the consensus file) through the batched -1t1 run, the one-batch default mode and three ranks: `.res` and `.fsa`
