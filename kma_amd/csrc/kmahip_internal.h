@@ -154,6 +154,12 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
                             const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream);
 // anchors of every strand that passes the prefilter, for reads without N's and up to 288 k-mer starts (the others get slow[read] = 1):
 // a_n[2 r + strand] anchors at pool + a_off[2 r + strand]; cnt[0] = anchors written (may exceed pool_cap: repeat with a larger pool)
+// the fragment rows of a run whose items (reads, records, fragments) and headers are in HBM: ordered, measured and formatted on the
+// device, compressed and written by the host's threads (session.hip)
+int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_names, const int64_t *d_name_off, const int64_t *d_name_idx, const int32_t *d_rc,
+                          const int32_t *d_tmpl, const int32_t *d_nhits, const int32_t *d_stats, const int64_t *d_rank, int64_t max_frag, const char *path,
+                          int64_t text_chunk, char **pinned, int64_t *n_rows_out);
+
 // stage 2 of the default mode on a batch that is in HBM, its records as a batch of their own in stream order (pipeline.hip). The
 // arrays live in a block of their own until kmahip_chain_records_free.
 struct KmaChainRecs {

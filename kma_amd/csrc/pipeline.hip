@@ -360,6 +360,24 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 
 	// the batch, once
 	DevBlock B;
+	// the three pinned text buffers of the fragment writer: pinning 192 MB takes 30 to 150 ms -- on a thread of its own, beside the stages
+	struct Pinned {
+		char *buf[3] = {nullptr, nullptr, nullptr};
+		std::thread th;
+		bool ok = false;
+		~Pinned() { if(th.joinable()) th.join(); for(int x = 0; x < 3; ++x) if(buf[x]) (void) hipHostFree(buf[x]); }
+	} pinned;
+	const int64_t pin_chunk = 64ll << 20;
+	if(frag_path && !sc && n > 100000 && !getenv("KMAHIP_PE_HOST_FRAG")) {
+		int dev = 0;
+		(void) hipGetDevice(&dev);
+		pinned.th = std::thread([&pinned, dev, pin_chunk] {
+			(void) hipSetDevice(dev);
+			bool ok = true;
+			for(int x = 0; x < 3 && ok; ++x) ok = hipHostMalloc((void **) &pinned.buf[x], (size_t) pin_chunk + 16, hipHostMallocDefault) == hipSuccess;
+			pinned.ok = ok;
+		});
+	}
 	B.expect((size_t) R.seq_words * 16 + (size_t) R.N_total * 8 + (size_t) n * 420 + (64u << 20));
 	kmahip_reads dR = R;
 	dR.q_start = nullptr; dR.q_end = nullptr;
@@ -607,7 +625,16 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	out->ms[4] = since(t);
 
 	// `.frag`: the per-fragment columns come back; the reads and their headers are the host batch's, through the fragments' read numbers
-	if(frag_path && nf > 0) {
+	if(frag_path && nf > 0 && !getenv("KMAHIP_PE_HOST_FRAG")) {
+		// the fragments and their figures are in HBM: the headers go up, the rows are ordered and formatted there (session.hip); the host
+		// compresses. (KMAHIP_PE_HOST_FRAG: the columns back and the rows made on the host, as in round 2)
+		const char *d_names = nullptr;
+		const int64_t *d_name_off = nullptr;
+		if((rc = B.up(batch->names, (size_t) batch->name_off[n], 1, &d_names)) || (rc = B.up(batch->name_off, (size_t) n + 1, 0, &d_name_off))) return rc;
+		int64_t rows = 0;
+		if(pinned.th.joinable()) pinned.th.join();
+		if((rc = kmahip_frag_write_dev(db, &dF, d_names, d_name_off, f_src, f_rc, f_t, f_nh, tr.stats, f_rank, mf + 1, frag_path, pin_chunk, pinned.ok ? pinned.buf : nullptr, &rows))) return rc;
+	} else if(frag_path && nf > 0) {
 		int32_t *stats4 = nullptr;
 		if((rc = B.get((size_t) nf * 4 + 4, &stats4))) return rc;
 		hipLaunchKernelGGL(pe_stats4_kernel, dim3((unsigned) ((nf + 255) / 256)), dim3(256), 0, s, nf, tr.stats, stats4);

@@ -425,6 +425,132 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 	return KMAHIP_OK;
 }
 
+// ---- the fragment rows of a run whose reads (or records, or fragments) and headers are in HBM: order, lengths and text on the device;
+// the host compresses and writes. Items 0 .. n - 1 = the entries of W; d_name_idx (or NULL): the header an item carries; d_rank (or NULL:
+// counted here): an item's position among the filed ones of the whole stream. pinned: three host buffers of text_chunk + 16 bytes made
+// by the caller ahead of time, or NULL.
+int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_names, const int64_t *d_name_off, const int64_t *d_name_idx, const int32_t *d_rc,
+                          const int32_t *d_tmpl, const int32_t *d_nhits, const int32_t *d_stats, const int64_t *d_rank, int64_t mf, const char *path,
+                          int64_t text_chunk, char **pinned, int64_t *n_rows_out) {
+	const int64_t n = W->n_reads;
+	const size_t D = db->info.DB_size;
+	hipStream_t s = 0;
+	int rc;
+	auto t = std::chrono::steady_clock::now();
+	if((rc = kmahip_db_load_names(db))) return rc;
+	DevBlock B;
+	B.expect((size_t) n * 72 + (64u << 20));
+	char *own[3] = {nullptr, nullptr, nullptr};
+	struct Own { char **o; ~Own() { for(int x = 0; x < 3; ++x) if(o[x]) (void) hipHostFree(o[x]); } } own_guard{own};
+	char *h_text_arr[3] = {pinned ? pinned[0] : nullptr, pinned ? pinned[1] : nullptr, pinned ? pinned[2] : nullptr};
+	char **h_text_in = h_text_arr;
+	if(text_chunk <= 0) text_chunk = 64ll << 20;
+	if(!pinned) {
+		for(int x = 0; x < 3; ++x) { if(hipHostMalloc((void **) &own[x], (size_t) text_chunk + 16, hipHostMallocDefault) != hipSuccess) { own[x] = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; } h_text_arr[x] = own[x]; }
+	}
+	const std::string prefix_path(path);
+	int64_t *filed = nullptr, *kept = nullptr, *frank = nullptr, *kscan = nullptr, *vals = nullptr, *vals2 = nullptr, *row_off = nullptr, *row_len = nullptr;
+	unsigned long long *keys = nullptr, *keys2 = nullptr;
+	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &kept)) || (rc = B.get((size_t) n + 1, &frank)) || (rc = B.get((size_t) n + 1, &kscan)) ||
+	   (rc = B.get((size_t) n + 1, &keys)) || (rc = B.get((size_t) n + 1, &keys2)) || (rc = B.get((size_t) n + 1, &vals)) || (rc = B.get((size_t) n + 1, &vals2))) return rc;
+	hipLaunchKernelGGL(row_flags_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, d_tmpl, d_stats, filed, kept);
+	HIP_TRY(hipGetLastError());
+	if((rc = scan_i64(B, filed, frank, (size_t) n + 1, s)) || (rc = scan_i64(B, kept, kscan, (size_t) n + 1, s))) return rc;
+	const int64_t *use_rank = d_rank ? d_rank : frank;
+	int64_t n_frag_rows = 0;
+	HIP_TRY(hipMemcpy(&n_frag_rows, kscan + n, 8, hipMemcpyDeviceToHost));
+	if(n_rows_out) *n_rows_out = n_frag_rows;
+	kmahip_gzstream *gz = kmahip_gzstream_open(prefix_path.c_str());
+	if(!gz) return KMAHIP_EIO;
+	struct Closer { kmahip_gzstream *&g; ~Closer() { if(g) (void) kmahip_gzstream_close(g); } } closer{gz};
+	if(n_frag_rows > 0) {
+		hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, d_tmpl, kscan, use_rank, mf, keys, vals);
+		HIP_TRY(hipGetLastError());
+		{
+			size_t tmp_bytes = 0;
+			if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
+			char *tmp = nullptr;
+			if((rc = B.get(tmp_bytes, &tmp))) return rc;
+			if(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
+		}
+		// template names on the device
+		std::vector<int64_t> tn_off(D + 1, 0);
+		std::string tn;
+		for(size_t tt = 1; tt < D; ++tt) { if(tt - 1 < db->h_names.size()) tn += db->h_names[tt - 1]; tn_off[tt] = (int64_t) tn.size(); }
+		tn_off[D] = (int64_t) tn.size();
+		const char *d_tn = nullptr;
+		const int64_t *d_tn_off = nullptr;
+		if((rc = B.up(tn.data(), tn.size(), 1, &d_tn)) || (rc = B.up(tn_off.data(), D + 1, 0, &d_tn_off))) return rc;
+		if((rc = B.get((size_t) n_frag_rows + 1, &row_len)) || (rc = B.get((size_t) n_frag_rows + 1, &row_off))) return rc;
+		RowArgs A{};
+		A.seq = W->seq; A.seq_off = W->seq_off; A.N_off = W->N_off; A.name_off = d_name_off; A.len = W->len; A.N = W->N; A.rc = d_rc; A.tmpl = d_tmpl; A.n_hits = d_nhits;
+		A.stats = d_stats; A.names = d_names; A.tnames = d_tn; A.tname_off = d_tn_off; A.row_read = vals2; A.row_off = row_len;
+		A.name_idx = d_name_idx;
+		hipLaunchKernelGGL(row_len_kernel, dim3((unsigned) ((n_frag_rows + 256) / 256)), dim3(256), 0, s, A, n_frag_rows);
+		HIP_TRY(hipGetLastError());
+		if((rc = scan_i64(B, row_len, row_off, (size_t) n_frag_rows + 1, s))) return rc;
+		A.row_off = row_off;
+		int64_t text_bytes = 0;
+		HIP_TRY(hipMemcpy(&text_bytes, row_off + n_frag_rows, 8, hipMemcpyDeviceToHost));
+		// blocks of rows of about 4 MB of text (a gzip member each), chunks of blocks of at most CHUNK bytes through two text buffers
+		const int64_t avg = std::max<int64_t>(1, text_bytes / n_frag_rows);
+		const int64_t rows_per_block = std::max<int64_t>(16, std::min<int64_t>(1 << 16, (4 << 20) / avg));
+		const int64_t n_blocks = (n_frag_rows + rows_per_block - 1) / rows_per_block;
+		int64_t *d_boff = nullptr;
+		if((rc = B.get((size_t) n_blocks + 1, &d_boff))) return rc;
+		hipLaunchKernelGGL(row_blocks_kernel, dim3((unsigned) ((n_blocks + 256) / 256)), dim3(256), 0, s, n_blocks, rows_per_block, n_frag_rows, row_off, d_boff);
+		HIP_TRY(hipGetLastError());
+		std::vector<int64_t> boff((size_t) n_blocks + 1);
+		HIP_TRY(hipMemcpy(boff.data(), d_boff, ((size_t) n_blocks + 1) * 8, hipMemcpyDeviceToHost));
+		int64_t max_block = 0;
+		for(int64_t b = 0; b < n_blocks; ++b) max_block = std::max(max_block, boff[(size_t) b + 1] - boff[(size_t) b]);
+		const int64_t CHUNK = std::max<int64_t>(text_chunk, max_block);
+		constexpr int NBUF = 3;
+		char *d_text[2] = {nullptr, nullptr};
+		char **h_text = h_text_in;
+		std::atomic<int> pending[NBUF];
+		for(int x = 0; x < NBUF; ++x) pending[x].store(0);
+		for(int x = 0; x < 2; ++x) if((rc = B.get((size_t) CHUNK + 16, &d_text[x]))) return rc;
+		if(CHUNK > text_chunk) {          // (a single block of rows longer than the buffers made at the start: rows of very long reads)
+			// (the caller's buffers stay as they are: three larger ones of our own for this file)
+			for(int x = 0; x < NBUF; ++x) { if(own[x]) (void) hipHostFree(own[x]); own[x] = nullptr; HIP_TRY(hipHostMalloc((void **) &own[x], (size_t) CHUNK + 16, hipHostMallocDefault)); h_text[x] = own[x]; }
+		}
+		int chunk_no = 0;
+		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+		double ms_prep = since(t), ms_fmt = 0, ms_wait = 0, ms_copy = 0;
+		auto lap = std::chrono::steady_clock::now();
+		for(int64_t b0 = 0; b0 < n_blocks; ++chunk_no) {
+			int64_t b1 = b0 + 1;
+			while(b1 < n_blocks && boff[(size_t) b1 + 1] - boff[(size_t) b0] <= CHUNK) ++b1;
+			const int64_t r0 = b0 * rows_per_block, r1 = std::min(n_frag_rows, b1 * rows_per_block), bytes = boff[(size_t) b1] - boff[(size_t) b0];
+			char *dt = d_text[chunk_no & 1];
+			const int hb = chunk_no % NBUF;
+			hipLaunchKernelGGL(row_format_kernel, dim3((unsigned) ((r1 - r0 + 255) / 256)), dim3(256), 0, s, A, r0, r1, boff[(size_t) b0], dt);
+			HIP_TRY(hipGetLastError());
+			if(dbg) { HIP_TRY(hipStreamSynchronize(s)); ms_fmt += since(lap); }
+			while(pending[hb].load() > 0) std::this_thread::yield();          // (the buffer's blocks of three chunks ago are still being compressed)
+			if(dbg) ms_wait += since(lap);
+			HIP_TRY(hipMemcpyAsync(h_text[hb], dt, (size_t) bytes, hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if(dbg) ms_copy += since(lap);
+			pending[hb].store((int) (b1 - b0));
+			for(int64_t b = b0; b < b1; ++b) kmahip_gzstream_submit(gz, h_text[hb] + (boff[(size_t) b] - boff[(size_t) b0]), (size_t) (boff[(size_t) b + 1] - boff[(size_t) b]), &pending[hb]);
+			b0 = b1;
+		}
+		kmahip_gzstream *g = gz;
+		gz = nullptr;
+		if((rc = kmahip_gzstream_close(g))) return rc;          // (before the pinned buffers go)
+		if(dbg) fprintf(stderr, "[kmahip] session: fragment rows: %lld rows, %lld bytes of text in %d chunks of %lld blocks; order + lengths + buffers %.1f ms, formatting %.1f, waiting for a free buffer %.1f, copies %.1f, draining the writer %.1f\n",
+		                (long long) n_frag_rows, (long long) text_bytes, chunk_no, (long long) n_blocks, ms_prep, ms_fmt, ms_wait, ms_copy, since(lap));
+	} else {
+		kmahip_gzstream *g = gz;
+		gz = nullptr;
+		if((rc = kmahip_gzstream_close(g))) return rc;
+	}
+	(void) t;
+	return KMAHIP_OK;
+}
+
 // ConClave, statistics, traceback, pile-up, consensus and the three files. ms[8]: uploads (summed over the batches), stages 2 + 3a
 // (summed), ConClave + statistics, traceback, pile-up + consensus, .res + .fsa, fragment rows, (unused).
 extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, int write_fsa, int write_frag, int64_t *n_reads, int64_t *n_rows_out, double ms[8]) {
@@ -526,103 +652,12 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	ms[5] = since(t);
 	if(!write_frag) return KMAHIP_OK;
 
-	// ---- the fragment rows: order, lengths and text on the device; the host compresses and writes
-	int64_t *filed = nullptr, *kept = nullptr, *frank = nullptr, *kscan = nullptr, *vals = nullptr, *vals2 = nullptr, *row_off = nullptr, *row_len = nullptr;
-	unsigned long long *keys = nullptr, *keys2 = nullptr;
-	if((rc = B.get((size_t) n + 1, &filed)) || (rc = B.get((size_t) n + 1, &kept)) || (rc = B.get((size_t) n + 1, &frank)) || (rc = B.get((size_t) n + 1, &kscan)) ||
-	   (rc = B.get((size_t) n + 1, &keys)) || (rc = B.get((size_t) n + 1, &keys2)) || (rc = B.get((size_t) n + 1, &vals)) || (rc = B.get((size_t) n + 1, &vals2))) return rc;
-	hipLaunchKernelGGL(row_flags_kernel, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, n, cc.tmpl, tr.stats, filed, kept);
-	HIP_TRY(hipGetLastError());
-	if((rc = scan_i64(B, filed, frank, (size_t) n + 1, s)) || (rc = scan_i64(B, kept, kscan, (size_t) n + 1, s))) return rc;
-	int64_t n_frag_rows = 0;
-	HIP_TRY(hipMemcpy(&n_frag_rows, kscan + n, 8, hipMemcpyDeviceToHost));
-	if(n_rows_out) *n_rows_out = n_frag_rows;
-	kmahip_gzstream *gz = kmahip_gzstream_open((prefix + ".frag.gz").c_str());
-	if(!gz) return KMAHIP_EIO;
-	struct Closer { kmahip_gzstream *&g; ~Closer() { if(g) (void) kmahip_gzstream_close(g); } } closer{gz};
-	if(n_frag_rows > 0) {
-		hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, cc.tmpl, kscan, frank, mf, keys, vals);
-		HIP_TRY(hipGetLastError());
-		{
-			size_t tmp_bytes = 0;
-			if(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs (size query) failed"); return KMAHIP_EDEVICE; }
-			char *tmp = nullptr;
-			if((rc = B.get(tmp_bytes, &tmp))) return rc;
-			if(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
-		}
-		// template names on the device
-		std::vector<int64_t> tn_off(D + 1, 0);
-		std::string tn;
-		for(size_t tt = 1; tt < D; ++tt) { if(tt - 1 < db->h_names.size()) tn += db->h_names[tt - 1]; tn_off[tt] = (int64_t) tn.size(); }
-		tn_off[D] = (int64_t) tn.size();
-		const char *d_tn = nullptr;
-		const int64_t *d_tn_off = nullptr;
-		if((rc = B.up(tn.data(), tn.size(), 1, &d_tn)) || (rc = B.up(tn_off.data(), D + 1, 0, &d_tn_off))) return rc;
-		if((rc = B.get((size_t) n_frag_rows + 1, &row_len)) || (rc = B.get((size_t) n_frag_rows + 1, &row_off))) return rc;
-		RowArgs A{};
-		A.seq = W.seq; A.seq_off = W.seq_off; A.N_off = W.N_off; A.name_off = S->name_off.as<int64_t>(); A.len = W.len; A.N = W.N; A.rc = rc_all; A.tmpl = cc.tmpl; A.n_hits = nh_all;
-		A.stats = tr.stats; A.names = S->names.as<char>(); A.tnames = d_tn; A.tname_off = d_tn_off; A.row_read = vals2; A.row_off = row_len;
-		A.name_idx = S->chain ? S->rread.as<int64_t>() : nullptr;
-		hipLaunchKernelGGL(row_len_kernel, dim3((unsigned) ((n_frag_rows + 256) / 256)), dim3(256), 0, s, A, n_frag_rows);
-		HIP_TRY(hipGetLastError());
-		if((rc = scan_i64(B, row_len, row_off, (size_t) n_frag_rows + 1, s))) return rc;
-		A.row_off = row_off;
-		int64_t text_bytes = 0;
-		HIP_TRY(hipMemcpy(&text_bytes, row_off + n_frag_rows, 8, hipMemcpyDeviceToHost));
-		// blocks of rows of about 4 MB of text (a gzip member each), chunks of blocks of at most CHUNK bytes through two text buffers
-		const int64_t avg = std::max<int64_t>(1, text_bytes / n_frag_rows);
-		const int64_t rows_per_block = std::max<int64_t>(16, std::min<int64_t>(1 << 16, (4 << 20) / avg));
-		const int64_t n_blocks = (n_frag_rows + rows_per_block - 1) / rows_per_block;
-		int64_t *d_boff = nullptr;
-		if((rc = B.get((size_t) n_blocks + 1, &d_boff))) return rc;
-		hipLaunchKernelGGL(row_blocks_kernel, dim3((unsigned) ((n_blocks + 256) / 256)), dim3(256), 0, s, n_blocks, rows_per_block, n_frag_rows, row_off, d_boff);
-		HIP_TRY(hipGetLastError());
-		std::vector<int64_t> boff((size_t) n_blocks + 1);
-		HIP_TRY(hipMemcpy(boff.data(), d_boff, ((size_t) n_blocks + 1) * 8, hipMemcpyDeviceToHost));
-		int64_t max_block = 0;
-		for(int64_t b = 0; b < n_blocks; ++b) max_block = std::max(max_block, boff[(size_t) b + 1] - boff[(size_t) b]);
-		const int64_t CHUNK = std::max<int64_t>(S->text_chunk, max_block);
-		constexpr int NBUF = kmahip_session::NBUF;
-		char *d_text[2] = {nullptr, nullptr};
-		char **h_text = S->h_text;
-		std::atomic<int> pending[NBUF];
-		for(int x = 0; x < NBUF; ++x) pending[x].store(0);
-		for(int x = 0; x < 2; ++x) if((rc = B.get((size_t) CHUNK + 16, &d_text[x]))) return rc;
-		if(CHUNK > S->text_chunk) {          // (a single block of rows longer than the buffers made at the start: rows of very long reads)
-			for(int x = 0; x < NBUF; ++x) { (void) hipHostFree(h_text[x]); h_text[x] = nullptr; HIP_TRY(hipHostMalloc((void **) &h_text[x], (size_t) CHUNK + 16, hipHostMallocDefault)); }
-			S->text_chunk = CHUNK;
-		}
-		int chunk_no = 0;
-		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
-		double ms_prep = since(t), ms_fmt = 0, ms_wait = 0, ms_copy = 0;
-		auto lap = std::chrono::steady_clock::now();
-		for(int64_t b0 = 0; b0 < n_blocks; ++chunk_no) {
-			int64_t b1 = b0 + 1;
-			while(b1 < n_blocks && boff[(size_t) b1 + 1] - boff[(size_t) b0] <= CHUNK) ++b1;
-			const int64_t r0 = b0 * rows_per_block, r1 = std::min(n_frag_rows, b1 * rows_per_block), bytes = boff[(size_t) b1] - boff[(size_t) b0];
-			char *dt = d_text[chunk_no & 1];
-			const int hb = chunk_no % NBUF;
-			hipLaunchKernelGGL(row_format_kernel, dim3((unsigned) ((r1 - r0 + 255) / 256)), dim3(256), 0, s, A, r0, r1, boff[(size_t) b0], dt);
-			HIP_TRY(hipGetLastError());
-			if(dbg) { HIP_TRY(hipStreamSynchronize(s)); ms_fmt += since(lap); }
-			while(pending[hb].load() > 0) std::this_thread::yield();          // (the buffer's blocks of three chunks ago are still being compressed)
-			if(dbg) ms_wait += since(lap);
-			HIP_TRY(hipMemcpyAsync(h_text[hb], dt, (size_t) bytes, hipMemcpyDeviceToHost, s));
-			HIP_TRY(hipStreamSynchronize(s));
-			if(dbg) ms_copy += since(lap);
-			pending[hb].store((int) (b1 - b0));
-			for(int64_t b = b0; b < b1; ++b) kmahip_gzstream_submit(gz, h_text[hb] + (boff[(size_t) b] - boff[(size_t) b0]), (size_t) (boff[(size_t) b + 1] - boff[(size_t) b]), &pending[hb]);
-			b0 = b1;
-		}
-		kmahip_gzstream *g = gz;
-		gz = nullptr;
-		if((rc = kmahip_gzstream_close(g))) return rc;          // (before the pinned buffers go)
-		if(dbg) fprintf(stderr, "[kmahip] session: fragment rows: %lld rows, %lld bytes of text in %d chunks of %lld blocks; order + lengths + buffers %.1f ms, formatting %.1f, waiting for a free buffer %.1f, copies %.1f, draining the writer %.1f\n",
-		                (long long) n_frag_rows, (long long) text_bytes, chunk_no, (long long) n_blocks, ms_prep, ms_fmt, ms_wait, ms_copy, since(lap));
-	} else {
-		kmahip_gzstream *g = gz;
-		gz = nullptr;
-		if((rc = kmahip_gzstream_close(g))) return rc;
+	// ---- the fragment rows: order, lengths and text on the device; the host compresses and writes (kmahip_frag_write_dev)
+	{
+		int64_t n_frag_rows = 0;
+		if((rc = kmahip_frag_write_dev(db, &W, S->names.as<char>(), S->name_off.as<int64_t>(), S->chain ? S->rread.as<int64_t>() : nullptr, rc_all, cc.tmpl, nh_all, tr.stats, nullptr, mf,
+		                               (prefix + ".frag.gz").c_str(), S->text_chunk, S->h_text, &n_frag_rows))) return rc;
+		if(n_rows_out) *n_rows_out = n_frag_rows;
 	}
 	ms[6] = since(t);
 	return KMAHIP_OK;
