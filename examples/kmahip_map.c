@@ -88,7 +88,7 @@ static void *ingest_main(void *arg) {
 typedef struct stream_job {
 	const char *in1;
 	kmahip_trim trim;
-	int64_t batch_reads;
+	int64_t batch_reads, batch_bases;
 	kmahip_ingest *ing; kmahip_read_batch b;
 	int state, rc; char err[512]; double t_done;
 	pthread_mutex_t mu; pthread_cond_t cv;
@@ -97,6 +97,7 @@ static void *stream_main(void *arg) {
 	stream_job *j = (stream_job *) arg;
 	int whole = 0;
 	int rc = kmahip_ingest_open_part(j->in1, NULL, &j->trim, 0, 1, &j->ing, &whole);
+	if(!rc && j->batch_bases > 0) rc = kmahip_ingest_set_batch_bases(j->ing, j->batch_bases);
 	for(;;) {
 		if(!rc) rc = kmahip_ingest_next(j->ing, j->batch_reads, &j->b);
 		const int end = rc || j->b.reads.n_reads == 0;
@@ -356,14 +357,15 @@ int main(int argc, char **argv) {
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
 	const double t_start = now_s(), t_before_main = since_process_start();
-	if(world == 1 && !input2 && !mt1 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
-		/* the single-end run (-1t1 or the default mode), batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on this
-		 * one, the host holding one batch at a time */
+	if(world == 1 && !input2 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
+		/* the single-end run (-1t1, the default mode or -Mt1), batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on
+		 * this one, the host holding one batch at a time. A batch: a million reads or a quarter of a gigabase, whichever comes first */
 		stream_job sj;
 		memset(&sj, 0, sizeof sj);
 		sj.in1 = input; sj.trim = trim;
 		sj.batch_reads = getenv("KMAHIP_MAP_BATCH") ? atoll(getenv("KMAHIP_MAP_BATCH")) : 1000000;
 		if(sj.batch_reads < 1) sj.batch_reads = 1;
+		sj.batch_bases = getenv("KMAHIP_MAP_BATCH_BASES") ? atoll(getenv("KMAHIP_MAP_BATCH_BASES")) : (256ll << 20);
 		pthread_mutex_init(&sj.mu, NULL); pthread_cond_init(&sj.cv, NULL);
 		pthread_t reader;
 		if(pthread_create(&reader, NULL, stream_main, &sj)) fail("cannot start a thread");
@@ -380,7 +382,9 @@ int main(int argc, char **argv) {
 			if(stat(input, &sb) == 0) hint = (int64_t) (sb.st_size / (il > 3 && !strcmp(input + il - 3, ".gz") ? 60 : 300));
 		}
 		kmahip_session *ses;
-		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp))) die("session");
+		char mt1_frag[4096];
+		snprintf(mt1_frag, sizeof mt1_frag, "%s.frag.gz", out);
+		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp)) || (mt1 && kmahip_session_set_mt1(ses, mt1, one2one, no_frag ? NULL : mt1_frag))) die("session");
 		int batches = 0;
 		kmahip_db_info sinfo;
 		int64_t unpinned = 0;
@@ -412,8 +416,8 @@ int main(int argc, char **argv) {
 		if(kmahip_session_finish(ses, out, !no_cons, !no_frag, &n_reads, &n_rows, ms)) die("finish");
 		if(unpinned) fprintf(stderr, "# kmahip_map: %lld reads carry an N among their first k - 1 bases behind a longer read: the reference's records for them depend on what its buffer held\n", (long long) unpinned);
 		fprintf(stderr, "# kmahip_map: %lld reads in %d batches, %lld fragment rows; wall: open %.2f s, ingest done after %.2f, mapped after %.2f, finish %.2f | uploads %.1f ms, stages 2+3a %.1f, "
-		        "ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, .res + .fsa %.1f, .frag.gz %.1f (main entered %.2f s after process start; peak RSS %.0f MB)\n", (long long) n_reads, batches,
-		        (long long) n_rows, t_open - t_start, sj.t_done - t_start, t_mapped - t_start, now_s() - t_mapped, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], t_before_main, peak_rss_mb());
+		        "ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, .res + .fsa %.1f, .frag.gz %.1f (+ %.1f beside the batches) (main entered %.2f s after process start; peak RSS %.0f MB)\n", (long long) n_reads, batches,
+		        (long long) n_rows, t_open - t_start, sj.t_done - t_start, t_mapped - t_start, now_s() - t_mapped, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7], t_before_main, peak_rss_mb());
 		finish(0);
 	}
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */

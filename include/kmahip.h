@@ -475,6 +475,10 @@ int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *
  * with '@' ends the input like in the reference ("Malformed input.", seqparse.c:256-260): the records before it are
  * delivered, then one call returns KMAHIP_EFORMAT. */
 int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip_read_batch *batch);
+/* A second bound on the batches of kmahip_ingest_next, for inputs of long reads where a count of records says little about a batch's
+ * size: a batch also closes once it holds about max_bases bases (checked between the stretches of input the reader cuts into records:
+ * it may go over by one such stretch, tens of megabytes of text). 0 (the default): no such bound. */
+int kmahip_ingest_set_batch_bases(kmahip_ingest *in, int64_t max_bases);
 /* For a caller that took the whole input as one batch (max_records = INT64_MAX): KMAHIP_EIO / KMAHIP_EFORMAT when the input broke
  * off behind the records delivered (a truncated or corrupt .gz, a record that does not start with '@'; the reference ends with a
  * non-zero exit status there), 0 otherwise. Does not touch the batch -- another kmahip_ingest_next would, its arrays are reused. */
@@ -629,6 +633,16 @@ int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_params *p, co
  * reads then go through the chain finder, and what the session keeps and maps are its records (a read, or its pieces, with their query
  * bounds); a fragment row carries the header of the read its record came from. cp: NULL = the defaults (kmahip_scan_chain). */
 int kmahip_session_set_chain(kmahip_session *s, const kmahip_chain_params *cp);
+/* `-Mt1 tmpl` (kmahip_run_mt1; runKMA_Mt1, mt1.c:86-500) through the same session: call once, before the first batch. There is no
+ * stage 2 and no ConClave in this mode, and a read's traceback depends on nothing but the read: kmahip_session_map seeds and traces
+ * the batch's reads against the template right away -- beside stage 1 of the next batch -- and keeps their figures and alignment runs
+ * in HBM; kmahip_session_finish sums the `.res` row, piles everything up in stream order and writes the three files (those of
+ * kmahip_run_mt1 + kmahip_frag_write2 with order 1). frag_path (or NULL): the fragment file -- its rows depend on nothing but their
+ * reads either, so each batch's rows are formatted on the device and handed to the compressing threads as soon as the batch is traced;
+ * kmahip_session_finish then only ends the file (its write_frag is ignored; with NULL here and write_frag set, the file is written at
+ * the finish as <out_prefix>.frag.gz). ms[] of kmahip_session_finish: [1] the tracebacks, [3] nothing, [7] the fragment rows made
+ * beside the batches. */
+int kmahip_session_set_mt1(kmahip_session *s, int32_t tmpl, int one2one, const char *frag_path);
 int kmahip_session_add(kmahip_session *s, const kmahip_read_batch *batch);
 /* kmahip_session_add in two steps, for a caller whose reader thread is to go on while the device works: _upload returns when the
  * batch's host arrays are free again, _map runs stages 2 and 3a on what has been uploaded since the last call */

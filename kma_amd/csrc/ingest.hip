@@ -465,6 +465,7 @@ struct kmahip_ingest {
 	bool malformed = false, reported = false;      // a record that does not start with '@': everything before it is delivered, then KMAHIP_EFORMAT once
 	bool io_error = false, io_reported = false;     // a corrupt .gz (or a failing read): what came before it is delivered, then KMAHIP_EIO once
 	int64_t n_read = 0, n_kept = 0;
+	int64_t batch_bases = 0;            // kmahip_ingest_set_batch_bases: a batch also closes once it holds about this many bases (0: no such bound)
 	// current batch
 	Arr<uint64_t> seq;
 	Arr<int64_t> seq_off, N_off, name_off;
@@ -1026,7 +1027,7 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 		double ms_locate = 0, ms_pack = 0, ms_gather = 0;
 		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		while(records < max_records) {
+		while(records < max_records && (in->batch_bases <= 0 || (int64_t) in->seq.size() * 32 < in->batch_bases)) {
 			const auto t0 = std::chrono::steady_clock::now();
 			size_t avail = 0;
 			for(;;) {
@@ -1072,7 +1073,7 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	} else {
 		Rec r[2];
 		Part P;
-		while(records < max_records) {
+		while(records < max_records && (in->batch_bases <= 0 || (int64_t) P.seq.size() * 32 < in->batch_bases)) {
 			bool got[2] = {false, false};
 			for(int m = 0; m < mates; ++m) got[m] = next_fa(in->s[m], r[m]);
 			if(!got[0] && !got[1]) break;
@@ -1115,6 +1116,15 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 		kmahip_set_error("malformed FASTQ input after %lld records", (long long) in->n_read);
 		return KMAHIP_EFORMAT;
 	}
+	return KMAHIP_OK;
+}
+
+// A second bound on a batch beside kmahip_ingest_next's max_records: once the batch holds about max_bases bases (counted in packed
+// words, checked between the waves of located records: a batch may go over by one wave) it closes. For inputs of long reads, where a
+// count of reads says little about the size of a batch. 0: no such bound.
+extern "C" int kmahip_ingest_set_batch_bases(kmahip_ingest *in, int64_t max_bases) {
+	if(!in || max_bases < 0) { kmahip_set_error("bad argument"); return KMAHIP_EINVAL; }
+	in->batch_bases = max_bases;
 	return KMAHIP_OK;
 }
 

@@ -158,7 +158,13 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 // device, compressed and written by the host's threads (session.hip)
 int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_names, const int64_t *d_name_off, const int64_t *d_name_idx, const int32_t *d_rc,
                           const int32_t *d_tmpl, const int32_t *d_nhits, const int32_t *d_stats, const int64_t *d_rank, int64_t max_frag, const char *path,
-                          int64_t text_chunk, char **pinned, int64_t *n_rows_out);
+                          int64_t text_chunk, char **pinned, int64_t *n_rows_out, int order = 0, struct KmaFragSink *sink = nullptr);
+// a fragment file that stays open over several kmahip_frag_write_dev calls (each appends its rows; kmahip_frag_sink_close ends the file):
+// the compressing threads go on with a call's text after the call has returned, in the caller's three pinned buffers (`pinned` is then
+// required, and the same for every call)
+struct KmaFragSink;
+KmaFragSink *kmahip_frag_sink_open(const char *path);
+int kmahip_frag_sink_close(KmaFragSink *sink);
 
 // stage 2 of the default mode on a batch that is in HBM, its records as a batch of their own in stream order (pipeline.hip). The
 // arrays live in a block of their own until kmahip_chain_records_free.

@@ -13,6 +13,7 @@
 // device work of this one when the caller reads ahead on a thread of its own (examples/kmahip_map.c).
 #include "pipeline_util.h"
 #include <atomic>
+#include <thread>
 #include <string>
 
 struct kmahip_gzstream;
@@ -54,6 +55,7 @@ struct Batch {
 	kmahip_reads tmp{};
 	std::vector<void *> tmp_owned;
 	int64_t read0 = 0;             // first read of the batch among all reads (its headers' index)
+	int64_t words = 0;             // packed words of the batch's reads
 	KmaChainRecs cr;               // the records' template lists live in its block
 	void release_tmp() { for(void *q : tmp_owned) (void) hipFree(q); tmp_owned.clear(); }
 	void release() { for(void *q : owned) (void) hipFree(q); owned.clear(); release_tmp(); kmahip_chain_records_free(&cr); }
@@ -88,11 +90,12 @@ __global__ __launch_bounds__(256) void row_flags_kernel(int64_t n, const int32_t
 }
 // the order assemble_KMA meets the fragments in: templates ascending; inside a template the chunks of max_frag filed fragments in
 // stream order, each chunk back to front (conclave.c:164-166, 194)
-__global__ __launch_bounds__(256) void row_keys_kernel(int64_t n, const int32_t *tmpl, const int64_t *kept, const int64_t *rank, int64_t max_frag, unsigned long long *keys, int64_t *vals) {
+__global__ __launch_bounds__(256) void row_keys_kernel(int64_t n, const int32_t *tmpl, const int64_t *kept, const int64_t *rank, int64_t max_frag, int order, unsigned long long *keys, int64_t *vals) {
 	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= n) return;
 	vals[i] = i;
 	if(!(kept[i + 1] - kept[i])) { keys[i] = ~0ull; return; }
+	if(order == 1) { keys[i] = ((unsigned long long) abs(tmpl[i]) << 40) | (unsigned long long) rank[i]; return; }          // (`-Mt1`: as the stream has them)
 	const unsigned long long rk = (unsigned long long) rank[i], chunk = rk / (unsigned long long) max_frag, in = rk % (unsigned long long) max_frag;
 	keys[i] = ((unsigned long long) abs(tmpl[i]) << 40) | (chunk * (unsigned long long) max_frag + ((unsigned long long) max_frag - 1ull - in));
 }
@@ -181,6 +184,18 @@ __global__ __launch_bounds__(256) void row_blocks_kernel(int64_t n_blocks, int64
 	if(b <= n_blocks) block_off[b] = row_off[b * rows_per_block < n_rows ? b * rows_per_block : n_rows];
 }
 
+// `-Mt1`: a read is kept when its traceback gave an alignment; the `.res` row's Score = the sum of KMA()'s own scores of the kept reads,
+// without the end bonus the read filter added (alnToMat, assembly.c:1328-1334; kmahip_run_mt1)
+__global__ __launch_bounds__(256) void session_mt1_kept_kernel(int64_t n, const int32_t *stats, int32_t tmpl, int t_len, int Wl, int32_t *o_tmpl, int32_t *o_nh, unsigned long long *sum) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const int32_t *st = stats + 10 * i;
+	const bool kept = st[3] != 0;
+	o_tmpl[i] = kept ? tmpl : 0;
+	o_nh[i] = 1;
+	if(kept) atomicAdd(sum, (unsigned long long) (st[0] - Wl * ((st[1] == 0) + (st[2] == t_len))));
+}
+
 }  // namespace
 
 struct kmahip_session {
@@ -195,6 +210,20 @@ struct kmahip_session {
 	kmahip_chain_params cp{};
 	DevArr qs, qe, rread;
 	int64_t n_reads = 0;
+	// `-Mt1` (kmahip_session_set_mt1): the reads of every batch are traced as the batch comes; figures, strands and runs of all of them
+	int32_t mt1 = 0;
+	int mt1_one2one = 0;
+	DevArr t_stats, t_off, t_nops, t_rc, t_pool, t_tmpl, t_nh;
+	int64_t pool_used = 0;
+	unsigned long long *mt1_sum = nullptr;          // Score of the `.res` row so far
+	KmaFragSink *sink = nullptr;                    // the fragment file, written as the batches are traced (kmahip_session_set_mt1 with a path)
+	int64_t sink_rows = 0;
+	double ms_frag = 0;
+	// the batch whose rows are still to be made: a thread makes them while the next batch is traced (or while everything is piled up)
+	bool frag_have = false;
+	int64_t frag_r0 = 0, frag_n = 0;
+	int frag_max_len = 0, frag_rc = 0, device = 0;
+	std::thread frag_thread;
 	int64_t n = 0, words = 0, nN = 0, name_bytes = 0;
 	int max_len = 0;
 	uint64_t *AS = nullptr, *AS_batch = nullptr;          // 2 D each: alignment_scores | uniq_alignment_scores
@@ -210,6 +239,9 @@ struct kmahip_session {
 		for(Batch &b : uploaded) b.release();
 		if(AS) (void) hipFree(AS);
 		if(AS_batch) (void) hipFree(AS_batch);
+		if(frag_thread.joinable()) frag_thread.join();
+		if(mt1_sum) (void) hipFree(mt1_sum);
+		if(sink) (void) kmahip_frag_sink_close(sink);          // (before the pinned buffers go)
 		for(int x = 0; x < NBUF; ++x) if(h_text[x]) (void) hipHostFree(h_text[x]);
 	}
 };
@@ -237,9 +269,24 @@ extern "C" int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_pa
 
 extern "C" void kmahip_session_close(kmahip_session *S) { delete S; }
 
+extern "C" int kmahip_session_set_mt1(kmahip_session *S, int32_t tmpl, int one2one, const char *frag_path) {
+	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty() || S->chain || S->mt1) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	if(tmpl < 1 || (size_t) tmpl >= S->db->info.DB_size) { kmahip_set_error("template %d out of range", tmpl); return KMAHIP_EINVAL; }
+	if(hipMalloc((void **) &S->mt1_sum, 8) != hipSuccess || hipMemset(S->mt1_sum, 0, 8) != hipSuccess) { kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM; }
+	if(frag_path) {
+		int rc = kmahip_db_load_names(S->db);
+		if(rc) return rc;
+		if(!(S->sink = kmahip_frag_sink_open(frag_path))) return KMAHIP_EIO;
+	}
+	S->mt1 = tmpl; S->mt1_one2one = one2one;
+	(void) hipGetDevice(&S->device);
+	return KMAHIP_OK;
+}
+
 extern "C" int kmahip_session_set_chain(kmahip_session *S, const kmahip_chain_params *cp) {
 	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	if(S->n || S->n_reads || !S->uploaded.empty()) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty() || S->mt1) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
 	S->chain = true;
 	if(cp) S->cp = *cp; else { S->cp.minlen = 16; S->cp.pad_ = 0; S->cp.coverT = 0.1; S->cp.mrs = 0.5; }
 	return KMAHIP_OK;
@@ -311,7 +358,7 @@ extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch 
 	HIP_TRY(hipStreamSynchronize(s));          // (the host arrays are the caller's again)
 	S->ms_upload += since(t);
 	Batch U;
-	U.r0 = S->n; U.n = nb; U.max_len = R.max_len;
+	U.r0 = S->n; U.n = nb; U.max_len = R.max_len; U.words = R.seq_words;
 	S->uploaded.push_back(std::move(U));
 	S->n += nb; S->n_reads += nb; S->words += R.seq_words; S->nN += R.N_total; S->name_bytes += nbytes;
 	S->max_len = std::max(S->max_len, R.max_len);
@@ -335,6 +382,79 @@ extern "C" int kmahip_session_map(kmahip_session *S) {
 extern "C" int kmahip_session_add(kmahip_session *S, const kmahip_read_batch *batch) {
 	const int rc = kmahip_session_upload(S, batch);
 	return rc ? rc : kmahip_session_map(S);
+}
+
+// `-Mt1`, the fragment rows of one traced batch: one template, stream order -- they follow those of the batches before. Made by a thread
+// of their own on the file's stream while the main thread traces the next batch (kmahip_session_map) or piles everything up
+// (kmahip_session_finish): both only read what the rows are made of, and the arrays are not moved meanwhile.
+static void mt1_frag_start(kmahip_session *S) {
+	if(!S->frag_have || !S->sink) return;
+	S->frag_have = false;
+	S->frag_rc = 0;
+	S->frag_thread = std::thread([S]() {
+		(void) hipSetDevice(S->device);
+		auto tf = std::chrono::steady_clock::now();
+		const int64_t r0 = S->frag_r0;
+		kmahip_reads w{};
+		w.n_reads = S->frag_n; w.seq = S->seq.as<uint64_t>(); w.seq_off = S->seq_off.as<int64_t>() + r0; w.len = S->len.as<int32_t>() + r0; w.N = S->N.as<int32_t>();
+		w.N_off = S->N_off.as<int64_t>() + r0; w.seq_words = S->words; w.N_total = S->nN; w.max_len = S->frag_max_len;
+		int64_t rows = 0;
+		S->frag_rc = kmahip_frag_write_dev(S->db, &w, S->names.as<char>(), S->name_off.as<int64_t>() + r0, nullptr, S->t_rc.as<int32_t>() + r0, S->t_tmpl.as<int32_t>() + r0, S->t_nh.as<int32_t>() + r0,
+		                                   S->t_stats.as<int32_t>() + 10 * r0, nullptr, S->opts.max_frag > 0 ? S->opts.max_frag : 1000000, "", S->text_chunk, S->h_text, &rows, 1, S->sink);
+		S->sink_rows += rows;
+		S->ms_frag += since(tf);
+	});
+}
+static int mt1_frag_join(kmahip_session *S) {
+	if(S->frag_thread.joinable()) S->frag_thread.join();
+	const int rc = S->frag_rc;
+	S->frag_rc = 0;
+	return rc;
+}
+
+// `-Mt1`: seeds + traceback of the batch's reads against the one template, into the session's arrays behind the batches before
+static int session_map_mt1(kmahip_session *S, Batch &B, const kmahip_reads &d) {
+	hipStream_t s = 0;
+	const int64_t nb = B.n, r0 = B.r0, n1 = r0 + nb;
+	int rc;
+	if((rc = S->t_stats.ensure((size_t) (10 * n1 + 10) * 4, (size_t) r0 * 40, s)) || (rc = S->t_off.ensure((size_t) (n1 + 1) * 8, (size_t) r0 * 8, s)) ||
+	   (rc = S->t_nops.ensure((size_t) (n1 + 1) * 4, (size_t) r0 * 4, s)) || (rc = S->t_rc.ensure((size_t) (n1 + 1) * 4, (size_t) r0 * 4, s)) ||
+	   (rc = S->t_tmpl.ensure((size_t) (n1 + 1) * 4, (size_t) r0 * 4, s)) || (rc = S->t_nh.ensure((size_t) (n1 + 1) * 4, (size_t) r0 * 4, s))) return rc;
+	HIP_TRY(hipMemsetAsync(S->t_stats.as<int32_t>() + 10 * r0, 0, (size_t) nb * 40, s));
+	HIP_TRY(hipMemsetAsync(S->t_off.as<int64_t>() + r0, 0, (size_t) nb * 8, s));
+	HIP_TRY(hipMemsetAsync(S->t_nops.as<int32_t>() + r0, 0, (size_t) nb * 4, s));
+	HIP_TRY(hipMemsetAsync(S->t_rc.as<int32_t>() + r0, 0, (size_t) nb * 4, s));
+	mt1_frag_start(S);          // (the batch before: nothing it reads is moved or written from here on)
+	// (the run pool: a guess from the batch's bases, redone with the count the kernels report if short)
+	int64_t room = B.words * 32 / 3 + 8 * nb + (1 << 16);
+	unsigned long long used = 0;
+	for(int attempt = 0;; ++attempt) {
+		if((rc = S->t_pool.ensure((size_t) (S->pool_used + room) * 4, (size_t) S->pool_used * 4, s))) return rc;
+		kmahip_traces tr;
+		tr.stats = S->t_stats.as<int32_t>() + 10 * r0; tr.ops_off = S->t_off.as<int64_t>() + r0; tr.n_ops = S->t_nops.as<int32_t>() + r0;
+		tr.ops = S->t_pool.as<uint32_t>() + S->pool_used; tr.ops_cap = (int64_t) (S->t_pool.cap / 4) - S->pool_used;
+		if((rc = kmahip_launch_longtrace(S->db, S->ws, &d, nullptr, S->mt1, nullptr, nullptr, S->mt1_one2one, &S->par, &tr, S->t_rc.as<int32_t>() + r0, s))) return rc;
+		used = 0;
+		const int st = ws_status(S->ws, &used);
+		if(st == 2 || (int64_t) used > tr.ops_cap) {
+			if(attempt >= 2) { kmahip_set_error("alignment run pool: %llu runs needed", used); return KMAHIP_EOVERFLOW; }
+			room = (int64_t) used + (1 << 16);
+			continue;
+		}
+		break;
+	}
+	// (the runs of a read are addressed from the start of the pool)
+	if(S->pool_used) hipLaunchKernelGGL(add_off_kernel, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, s, nb, S->t_off.as<int64_t>() + r0, S->pool_used);
+	// the kept reads, their part of the `.res` row's Score
+	hipLaunchKernelGGL(session_mt1_kept_kernel, dim3((unsigned) ((nb + 255) / 256)), dim3(256), 0, s, nb, S->t_stats.as<int32_t>() + 10 * r0, S->mt1, S->db->h_tlen[(size_t) S->mt1], S->par.rw.Wl,
+	                   S->t_tmpl.as<int32_t>() + r0, S->t_nh.as<int32_t>() + r0, S->mt1_sum);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	S->pool_used += (int64_t) used;
+	// (their fragment rows are made beside the next batch)
+	if((rc = mt1_frag_join(S))) return rc;
+	S->frag_have = S->sink != nullptr; S->frag_r0 = r0; S->frag_n = nb; S->frag_max_len = B.max_len;
+	return KMAHIP_OK;
 }
 
 static int session_map_one(kmahip_session *S, Batch &B) {
@@ -383,6 +503,12 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 	d.N_off = S->N_off.as<int64_t>() + B.r0; d.seq_words = S->words; d.N_total = S->nN; d.max_len = B.max_len;
 	if(S->chain && nb) { d.q_start = S->qs.as<int32_t>() + B.r0; d.q_end = S->qe.as<int32_t>() + B.r0; }
 	if(S->chain && !nb) { S->batches.push_back(std::move(B)); S->ms_map += since(t); return KMAHIP_OK; }       // (a batch without a record)
+	if(S->mt1) {
+		rc = session_map_mt1(S, B, d);
+		if(!rc) S->batches.push_back(std::move(B));
+		S->ms_map += since(t);
+		return rc;
+	}
 	// stage 2 (the candidate lists have no bound known in advance: two per read, redone with the exact size if short)
 	if(!S->chain) {
 	if((rc = dev_new(B.owned, (size_t) nb + 1, &B.c.rc_flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.flag, false, s)) || (rc = dev_new(B.owned, (size_t) nb + 1, &B.c.T_off, true, s))) { B.release(); return rc; }
@@ -427,14 +553,42 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 
 // ---- the fragment rows of a run whose reads (or records, or fragments) and headers are in HBM: order, lengths and text on the device;
 // the host compresses and writes. Items 0 .. n - 1 = the entries of W; d_name_idx (or NULL): the header an item carries; d_rank (or NULL:
-// counted here): an item's position among the filed ones of the whole stream. pinned: three host buffers of text_chunk + 16 bytes made
+// counted here): an item's position among the filed ones of the whole stream. order: 0 ConClave's (assemble_KMA's), 1 the stream's. pinned: three host buffers of text_chunk + 16 bytes made
 // by the caller ahead of time, or NULL.
+struct KmaFragSink {
+	kmahip_gzstream *gz = nullptr;
+	std::atomic<int> pending[3];
+	int chunk_no = 0;
+	// a stream of its own (the rows of one batch are made while the next batch is traced on the others), the template names once
+	hipStream_t stream = nullptr;
+	char *d_tn = nullptr;
+	int64_t *d_tn_off = nullptr;
+};
+KmaFragSink *kmahip_frag_sink_open(const char *path) {
+	KmaFragSink *k = new KmaFragSink();
+	for(int x = 0; x < 3; ++x) k->pending[x].store(0);
+	if(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) { k->stream = nullptr; delete k; kmahip_set_error("hipStreamCreate failed"); return nullptr; }
+	k->gz = kmahip_gzstream_open(path);
+	if(!k->gz) { (void) hipStreamDestroy(k->stream); delete k; return nullptr; }
+	return k;
+}
+int kmahip_frag_sink_close(KmaFragSink *k) {
+	if(!k) return KMAHIP_OK;
+	const int rc = k->gz ? kmahip_gzstream_close(k->gz) : KMAHIP_OK;
+	if(k->stream) (void) hipStreamDestroy(k->stream);
+	if(k->d_tn) (void) hipFree(k->d_tn);
+	if(k->d_tn_off) (void) hipFree(k->d_tn_off);
+	delete k;
+	return rc;
+}
+
 int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_names, const int64_t *d_name_off, const int64_t *d_name_idx, const int32_t *d_rc,
                           const int32_t *d_tmpl, const int32_t *d_nhits, const int32_t *d_stats, const int64_t *d_rank, int64_t mf, const char *path,
-                          int64_t text_chunk, char **pinned, int64_t *n_rows_out) {
+                          int64_t text_chunk, char **pinned, int64_t *n_rows_out, int order, KmaFragSink *sink) {
+	if(sink && !pinned) { kmahip_set_error("a fragment file that stays open needs the caller's buffers"); return KMAHIP_EINVAL; }
 	const int64_t n = W->n_reads;
 	const size_t D = db->info.DB_size;
-	hipStream_t s = 0;
+	hipStream_t s = sink ? sink->stream : 0;
 	int rc;
 	auto t = std::chrono::steady_clock::now();
 	if((rc = kmahip_db_load_names(db))) return rc;
@@ -458,13 +612,14 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 	if((rc = scan_i64(B, filed, frank, (size_t) n + 1, s)) || (rc = scan_i64(B, kept, kscan, (size_t) n + 1, s))) return rc;
 	const int64_t *use_rank = d_rank ? d_rank : frank;
 	int64_t n_frag_rows = 0;
-	HIP_TRY(hipMemcpy(&n_frag_rows, kscan + n, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpyAsync(&n_frag_rows, kscan + n, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
 	if(n_rows_out) *n_rows_out = n_frag_rows;
-	kmahip_gzstream *gz = kmahip_gzstream_open(prefix_path.c_str());
+	kmahip_gzstream *gz = sink ? sink->gz : kmahip_gzstream_open(prefix_path.c_str());
 	if(!gz) return KMAHIP_EIO;
-	struct Closer { kmahip_gzstream *&g; ~Closer() { if(g) (void) kmahip_gzstream_close(g); } } closer{gz};
+	struct Closer { kmahip_gzstream *&g; bool own; ~Closer() { if(g && own) (void) kmahip_gzstream_close(g); } } closer{gz, sink == nullptr};
 	if(n_frag_rows > 0) {
-		hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, d_tmpl, kscan, use_rank, mf, keys, vals);
+		hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, n, d_tmpl, kscan, use_rank, mf, order, keys, vals);
 		HIP_TRY(hipGetLastError());
 		{
 			size_t tmp_bytes = 0;
@@ -474,13 +629,21 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 			if(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, 64, s) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs failed"); return KMAHIP_EDEVICE; }
 		}
 		// template names on the device
-		std::vector<int64_t> tn_off(D + 1, 0);
-		std::string tn;
-		for(size_t tt = 1; tt < D; ++tt) { if(tt - 1 < db->h_names.size()) tn += db->h_names[tt - 1]; tn_off[tt] = (int64_t) tn.size(); }
-		tn_off[D] = (int64_t) tn.size();
-		const char *d_tn = nullptr;
-		const int64_t *d_tn_off = nullptr;
-		if((rc = B.up(tn.data(), tn.size(), 1, &d_tn)) || (rc = B.up(tn_off.data(), D + 1, 0, &d_tn_off))) return rc;
+		const char *d_tn = sink ? sink->d_tn : nullptr;
+		const int64_t *d_tn_off = sink ? sink->d_tn_off : nullptr;
+		if(!d_tn) {
+			std::vector<int64_t> tn_off(D + 1, 0);
+			std::string tn;
+			for(size_t tt = 1; tt < D; ++tt) { if(tt - 1 < db->h_names.size()) tn += db->h_names[tt - 1]; tn_off[tt] = (int64_t) tn.size(); }
+			tn_off[D] = (int64_t) tn.size();
+			if(sink) {          // (kept with the file)
+				if(hipMalloc((void **) &sink->d_tn, tn.size() + 1) != hipSuccess || hipMalloc((void **) &sink->d_tn_off, (D + 1) * 8) != hipSuccess) { kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM; }
+				HIP_TRY(hipMemcpy(sink->d_tn, tn.data(), tn.size(), hipMemcpyHostToDevice));
+				HIP_TRY(hipMemcpy(sink->d_tn_off, tn_off.data(), (D + 1) * 8, hipMemcpyHostToDevice));
+				d_tn = sink->d_tn; d_tn_off = sink->d_tn_off;
+			}
+			else if((rc = B.up(tn.data(), tn.size(), 1, &d_tn)) || (rc = B.up(tn_off.data(), D + 1, 0, &d_tn_off))) return rc;
+		}
 		if((rc = B.get((size_t) n_frag_rows + 1, &row_len)) || (rc = B.get((size_t) n_frag_rows + 1, &row_off))) return rc;
 		RowArgs A{};
 		A.seq = W->seq; A.seq_off = W->seq_off; A.N_off = W->N_off; A.name_off = d_name_off; A.len = W->len; A.N = W->N; A.rc = d_rc; A.tmpl = d_tmpl; A.n_hits = d_nhits;
@@ -491,7 +654,8 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 		if((rc = scan_i64(B, row_len, row_off, (size_t) n_frag_rows + 1, s))) return rc;
 		A.row_off = row_off;
 		int64_t text_bytes = 0;
-		HIP_TRY(hipMemcpy(&text_bytes, row_off + n_frag_rows, 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpyAsync(&text_bytes, row_off + n_frag_rows, 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
 		// blocks of rows of about 4 MB of text (a gzip member each), chunks of blocks of at most CHUNK bytes through two text buffers
 		const int64_t avg = std::max<int64_t>(1, text_bytes / n_frag_rows);
 		const int64_t rows_per_block = std::max<int64_t>(16, std::min<int64_t>(1 << 16, (4 << 20) / avg));
@@ -501,21 +665,24 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 		hipLaunchKernelGGL(row_blocks_kernel, dim3((unsigned) ((n_blocks + 256) / 256)), dim3(256), 0, s, n_blocks, rows_per_block, n_frag_rows, row_off, d_boff);
 		HIP_TRY(hipGetLastError());
 		std::vector<int64_t> boff((size_t) n_blocks + 1);
-		HIP_TRY(hipMemcpy(boff.data(), d_boff, ((size_t) n_blocks + 1) * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpyAsync(boff.data(), d_boff, ((size_t) n_blocks + 1) * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
 		int64_t max_block = 0;
 		for(int64_t b = 0; b < n_blocks; ++b) max_block = std::max(max_block, boff[(size_t) b + 1] - boff[(size_t) b]);
 		const int64_t CHUNK = std::max<int64_t>(text_chunk, max_block);
 		constexpr int NBUF = 3;
 		char *d_text[2] = {nullptr, nullptr};
 		char **h_text = h_text_in;
-		std::atomic<int> pending[NBUF];
-		for(int x = 0; x < NBUF; ++x) pending[x].store(0);
+		std::atomic<int> pending_own[NBUF];
+		for(int x = 0; x < NBUF; ++x) pending_own[x].store(0);
+		std::atomic<int> *pending = sink ? sink->pending : pending_own;
 		for(int x = 0; x < 2; ++x) if((rc = B.get((size_t) CHUNK + 16, &d_text[x]))) return rc;
 		if(CHUNK > text_chunk) {          // (a single block of rows longer than the buffers made at the start: rows of very long reads)
 			// (the caller's buffers stay as they are: three larger ones of our own for this file)
 			for(int x = 0; x < NBUF; ++x) { if(own[x]) (void) hipHostFree(own[x]); own[x] = nullptr; HIP_TRY(hipHostMalloc((void **) &own[x], (size_t) CHUNK + 16, hipHostMallocDefault)); h_text[x] = own[x]; }
 		}
-		int chunk_no = 0;
+		int chunk_no = sink ? sink->chunk_no : 0;
+		const int chunk_first = chunk_no;
 		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 		double ms_prep = since(t), ms_fmt = 0, ms_wait = 0, ms_copy = 0;
 		auto lap = std::chrono::steady_clock::now();
@@ -523,7 +690,7 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 			int64_t b1 = b0 + 1;
 			while(b1 < n_blocks && boff[(size_t) b1 + 1] - boff[(size_t) b0] <= CHUNK) ++b1;
 			const int64_t r0 = b0 * rows_per_block, r1 = std::min(n_frag_rows, b1 * rows_per_block), bytes = boff[(size_t) b1] - boff[(size_t) b0];
-			char *dt = d_text[chunk_no & 1];
+			char *dt = d_text[(chunk_no - chunk_first) & 1];
 			const int hb = chunk_no % NBUF;
 			hipLaunchKernelGGL(row_format_kernel, dim3((unsigned) ((r1 - r0 + 255) / 256)), dim3(256), 0, s, A, r0, r1, boff[(size_t) b0], dt);
 			HIP_TRY(hipGetLastError());
@@ -537,12 +704,18 @@ int kmahip_frag_write_dev(kmahip_db *db, const kmahip_reads *W, const char *d_na
 			for(int64_t b = b0; b < b1; ++b) kmahip_gzstream_submit(gz, h_text[hb] + (boff[(size_t) b] - boff[(size_t) b0]), (size_t) (boff[(size_t) b + 1] - boff[(size_t) b]), &pending[hb]);
 			b0 = b1;
 		}
-		kmahip_gzstream *g = gz;
-		gz = nullptr;
-		if((rc = kmahip_gzstream_close(g))) return rc;          // (before the pinned buffers go)
+		if(sink) {
+			sink->chunk_no = chunk_no;
+			// (the file stays open and the threads go on compressing out of the caller's buffers; buffers of our own go with this call)
+			if(CHUNK > text_chunk) for(int x = 0; x < NBUF; ++x) while(pending[x].load() > 0) std::this_thread::yield();
+		} else {
+			kmahip_gzstream *g = gz;
+			gz = nullptr;
+			if((rc = kmahip_gzstream_close(g))) return rc;          // (before the pinned buffers go)
+		}
 		if(dbg) fprintf(stderr, "[kmahip] session: fragment rows: %lld rows, %lld bytes of text in %d chunks of %lld blocks; order + lengths + buffers %.1f ms, formatting %.1f, waiting for a free buffer %.1f, copies %.1f, draining the writer %.1f\n",
 		                (long long) n_frag_rows, (long long) text_bytes, chunk_no, (long long) n_blocks, ms_prep, ms_fmt, ms_wait, ms_copy, since(lap));
-	} else {
+	} else if(!sink) {
 		kmahip_gzstream *g = gz;
 		gz = nullptr;
 		if((rc = kmahip_gzstream_close(g))) return rc;
@@ -581,6 +754,58 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	W.n_reads = n; W.seq = S->seq.as<uint64_t>(); W.seq_off = S->seq_off.as<int64_t>(); W.len = S->len.as<int32_t>(); W.N = S->N.as<int32_t>(); W.N_off = S->N_off.as<int64_t>();
 	W.seq_words = S->words; W.N_total = S->nN; W.max_len = S->max_len;
 	if(S->chain && n) { W.q_start = S->qs.as<int32_t>(); W.q_end = S->qe.as<int32_t>(); }
+
+	if(S->mt1) {
+		// `-Mt1`: the tracebacks are there (kmahip_session_map); the `.res` row, the pile-up in stream order, the files
+		const int32_t tmpl = S->mt1;
+		const int t_len = db->h_tlen[(size_t) tmpl];
+		unsigned long long score = 0;
+		if((rc = S->t_stats.ensure(48, 0, s)) || (rc = S->t_off.ensure(16, 0, s)) || (rc = S->t_nops.ensure(8, 0, s)) || (rc = S->t_rc.ensure(8, 0, s)) || (rc = S->t_pool.ensure(64, 0, s)) ||
+		   (rc = S->t_tmpl.ensure(8, 0, s)) || (rc = S->t_nh.ensure(8, 0, s))) return rc;
+		const int32_t *d_tmpl = S->t_tmpl.as<int32_t>(), *d_nh = S->t_nh.as<int32_t>();
+		mt1_frag_start(S);          // (the last batch's rows, beside the pile-up)
+		struct Join { kmahip_session *S; ~Join() { (void) mt1_frag_join(S); } } join_guard{S};
+		HIP_TRY(hipMemcpy(&score, S->mt1_sum, 8, hipMemcpyDeviceToHost));
+		kmahip_res_row row;
+		memset(&row, 0, sizeof row);
+		row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
+		row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
+		row.significant = ((row.p_value <= S->opts.evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+		ms[2] = since(t);
+		kmahip_traces tr{};
+		tr.stats = S->t_stats.as<int32_t>(); tr.ops_off = S->t_off.as<int64_t>(); tr.n_ops = S->t_nops.as<int32_t>(); tr.ops = S->t_pool.as<uint32_t>(); tr.ops_cap = (int64_t) (S->t_pool.cap / 4);
+		std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
+		std::vector<char> cons((size_t) (4 * (int64_t) t_len + 4 * (int64_t) D + (1 << 20)));
+		kmahip_assembly asmb{};
+		asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
+		asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
+		if(n && score) {
+			kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 1, S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0), S->opts.sig90, nullptr, S->opts.support};
+			if((rc = kmahip_assemble2_dev(db, ws, &W, S->t_rc.as<int32_t>(), d_tmpl, &tr, &ao, &asmb))) return rc;
+		}
+		ms[4] = since(t);
+		const std::string prefix(out_prefix);
+		if((rc = kmahip_write_res_fsa(db, (prefix + ".res").c_str(), write_fsa ? (prefix + ".fsa").c_str() : nullptr, true, &row, 1, nullptr, 0, a_cover.data(), a_len.data(),
+		                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa))) return rc;
+		ms[5] = since(t);
+		if(S->sink) {          // (written batch by batch: what is left is the end of the file)
+			if((rc = mt1_frag_join(S))) return rc;
+			KmaFragSink *k = S->sink;
+			S->sink = nullptr;
+			if((rc = kmahip_frag_sink_close(k))) return rc;
+			if(n_rows_out) *n_rows_out = S->sink_rows;
+			ms[6] = since(t);
+			ms[7] = S->ms_frag;
+			return KMAHIP_OK;
+		}
+		if(!write_frag) return KMAHIP_OK;
+		int64_t n_frag_rows = 0;
+		if((rc = kmahip_frag_write_dev(db, &W, S->names.as<char>(), S->name_off.as<int64_t>(), nullptr, S->t_rc.as<int32_t>(), d_tmpl, d_nh, tr.stats, nullptr, mf,
+		                               (prefix + ".frag.gz").c_str(), S->text_chunk, S->h_text, &n_frag_rows, 1))) return rc;
+		if(n_rows_out) *n_rows_out = n_frag_rows;
+		ms[6] = since(t);
+		return KMAHIP_OK;
+	}
 
 	// stage 3b per batch on the finished vectors, the `.res` statistics
 	kmahip_conclave cc{};

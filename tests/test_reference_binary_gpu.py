@@ -313,10 +313,14 @@ def test_empty_input_equals_reference_binary(tmp_path, mode):
                 os.unlink(tmp_path / f)
 
 
-def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
+@pytest.mark.parametrize("env", [{}, {"KMAHIP_MAP_BATCH": "97"}, {"KMAHIP_MAP_BATCH_BASES": "300000", "KMAHIP_INGEST_REGION": "4096"}, {"KMAHIP_MAP_ONE_BATCH": "1"}],
+                         ids=["session", "batches_of_97_reads", "batches_by_bases", "one_batch"])
+def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path, env):
     """BASELINE config C4 through the C host program: `kma -i ont.fq -t_db db -Mt1 1 -bcNano -t 1` vs `kmahip_map ... -Mt1 1 -bcNano`
     on ONT-like reads (2-12 kb, 10 % errors, both strands, some with foreign chunks, N's, low-quality ends that the trim removes,
-    unmappable reads) against one 400 kb genome with a few repeats, indexed by the reference's own `kma index`."""
+    unmappable reads) against one 400 kb genome with a few repeats, indexed by the reference's own `kma index`. The host program feeds
+    the reads batch by batch (kmahip_session_set_mt1: every batch traced as it comes): in one batch, in batches of 97 reads, in batches
+    closed by their bases, and through the one-call path (kmahip_run_mt1)."""
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -355,8 +359,12 @@ def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path):
         for j, i in enumerate(order):
             f.write(b"@ont%d some comment\n" % j + lut[reads[i]].tobytes() + b"\n+\n" + quals[i] + b"\n")
     subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-Mt1", "1", "-bcNano", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-Mt1", "1", "-bcNano"], check=True,
-                   stderr=subprocess.DEVNULL)
+    run = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-Mt1", "1", "-bcNano"], check=True,
+                         stderr=subprocess.PIPE, env=dict(os.environ, **env))
+    if "KMAHIP_MAP_BATCH" in env or "KMAHIP_MAP_BATCH_BASES" in env:
+        import re
+        m = re.search(rb"in (\d+) batches", run.stderr)
+        assert m and int(m.group(1)) >= 4, run.stderr[-400:]
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
