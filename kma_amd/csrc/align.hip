@@ -23,6 +23,7 @@
 // walk's quirk that a gap run ends on the first cell with EITHER may-open bit.
 #include "kmahip_internal.h"
 #include "dna_dev.h"
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <climits>
@@ -79,6 +80,7 @@ struct AlignArgs {
 	int stats;
 	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
 	int gap_m_max;   // Lane::gap_m_max
+	int long_min;    // > 0: the tasks of reads this long (strand known, no N's) are left to the long-read pipeline (long_routed)
 };
 
 constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
@@ -1097,6 +1099,12 @@ __device__ Aln kma_score(const Lane &L, const DevDB &db, int t, const uint64_t *
 // it, and all it does is wait for dependent gathers -- so it runs as its own kernel at 8 waves / SIMD (twice the gathers in
 // flight), one lane per single-end task, and hands up to SEEDS MEMs per task to the main kernel. Tasks it cannot serve
 // (strand ties, more MEMs, reads >= 64 k bases) are marked -1 and seeded by the main kernel as before.
+// Long reads (single end, strand decided by stage 2, no N's): a lane would walk hundreds of MEMs and DP problems of such a read alone;
+// their tasks go through the wavefront-per-read pipeline of longtrace.hip in KMA_score mode instead (launch_align: long_tasks)
+__device__ __forceinline__ bool long_routed(const AlignArgs &A, int64_t r) {
+	return A.long_min > 0 && A.len[r] >= A.long_min && A.rc_flag[r] > 0 && A.N_off[r + 1] == A.N_off[r];
+}
+
 // the MEM search of one oriented read against one template; returns the number of MEMs (0..SEEDS) or -1 (left to the main kernel)
 __device__ __forceinline__ int seed_view(const AlignArgs &A, int t, const QView &q, int k, uint2 *mem) {
 	const int L = q.L;
@@ -1148,7 +1156,7 @@ __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 		int64_t rd0 = r;
 		int rc0 = 0;
 		if(!A.pe_mode) {
-			if(A.rc_flag[r] > 0) { views = 1; rc0 = (A.flag[r] & 16) ? 1 : 0; }
+			if(A.rc_flag[r] > 0 && !long_routed(A, r)) { views = 1; rc0 = (A.flag[r] & 16) ? 1 : 0; }
 		} else {
 			const int64_t p0 = r & ~1ll;
 			const bool couple = (r & 1) && A.rec_mate[p0] >= 0 && A.rec_mate[r] >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
@@ -1253,7 +1261,8 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
 			int status = 0;
 			L.q_at = at;
-			if(PEM && couple) {
+			if(!PEM && long_routed(A, r)) kind = 3;          // (scored by the long-read pipeline)
+			else if(PEM && couple) {
 				// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate. Both are
 				// flipped once the list reaches its first negative id and stay flipped (:1633-1647).
 				kind = 2;
@@ -1368,7 +1377,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 		if(lane == 0) atomicMax(&A.counters[14], ((wall_clock64() - dbg_t1) << 32) | (unsigned long long) (task & 0xFFFFFFFFll));         // slowest phase B
 #endif
 		// ---- phase C ---------------------------------------------------------------------------------
-		if(!have) continue;
+		if(!have || kind == 3) continue;
 		if(PEM && kind == 2) {
 			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
 			for(int m = 0; m < 2; ++m) {
@@ -2202,6 +2211,89 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      //
 } // namespace
 
 // common launcher. SE: one record per read. PE (rec_mate != null): two records per pair over interleaved mates.
+// ---- the tasks of long reads (long_routed) through the pipeline of longtrace.hip in KMA_score mode: a task = a read of its own there,
+// with its template and strand; what comes back are KMA_score's figures, filtered like alnFragsSE does (alnfrags.c:1127-1168) ----
+__global__ __launch_bounds__(256) void long_pick_kernel(const AlignArgs A, int64_t *list, unsigned long long *cnt) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= A.n_reads || A.T_off[A.n_reads] > A.tasks_cap || !long_routed(A, r)) return;
+	const int64_t a = A.T_off[r], m = A.T_off[r + 1] - a;
+	if(m <= 0) return;
+	const unsigned long long b = atomicAdd(cnt, (unsigned long long) m);
+	for(int64_t j = 0; j < m; ++j) list[b + j] = a + j;
+}
+__global__ __launch_bounds__(256) void long_gather_kernel(const AlignArgs A, const int64_t *list, int64_t n_l, int64_t *so, int32_t *len, int32_t *tmpl, int32_t *rc, int32_t *qs, int32_t *qe) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n_l) return;
+	const int64_t task = list[i], r = A.t_rec[task];
+	so[i] = A.seq_off[r]; len[i] = A.len[r]; tmpl[i] = abs(A.T[task]); rc[i] = (A.flag[r] & 16) ? 1 : 0;
+	if(qs) { qs[i] = A.q_start[r]; qe[i] = A.q_end[r]; }
+}
+__global__ __launch_bounds__(256) void long_result_kernel(const AlignArgs A, const int64_t *list, int64_t n_l, const int32_t *stats) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n_l) return;
+	const int64_t task = list[i], r = A.t_rec[task];
+	const int32_t *st = stats + 10 * i;
+	const int t_len = A.db.tlen[abs(A.T[task])], q_len = A.len[r];
+	const int alen = st[3], start = st[1], tG = st[7], qG = st[8];
+	int end = start + alen - tG;
+	if(t_len < end) end -= t_len;
+	const double denom = (q_len <= alen || t_len <= alen) ? (double) alen : (double) min(q_len, t_len);
+	int rs = st[0];
+	double norm = 0.0;
+	if(A.minlen <= alen && ((A.mrc * q_len <= alen - qG) || (A.mrc * t_len <= alen - tG))) norm = rs / denom;
+	else rs = 0;
+	A.t_tmpl[task] = A.T[task];
+	A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
+}
+
+static int long_tasks(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const AlignArgs &A, const kmahip_params *p, hipStream_t stream) {
+	const int64_t n = reads->n_reads, cap = A.tasks_cap;
+	auto t_in = std::chrono::steady_clock::now();
+	const int tim_mode = getenv("KMAHIP_ALIGN_LONG_TIMING") ? atoi(getenv("KMAHIP_ALIGN_LONG_TIMING")) : 0;
+	if(tim_mode) { if(tim_mode == 1) HIP_TRY(hipStreamSynchronize(stream)); fprintf(stderr, "[kmahip] stage 3a: the kernels before the long reads' tasks %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count()); }
+	struct Dev { void *p = nullptr; ~Dev() { if(p) (void) hipFree(p); } } d_list, d_arr;
+	HIP_TRY(hipMalloc(&d_list.p, (size_t) cap * 8 + 16));
+	int64_t *list = (int64_t *) d_list.p;
+	unsigned long long *cnt = (unsigned long long *) (list + cap);
+	HIP_TRY(hipMemsetAsync(cnt, 0, 8, stream));
+	hipLaunchKernelGGL(long_pick_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, A, list, cnt);
+	HIP_TRY(hipGetLastError());
+	unsigned long long n_l = 0;
+	HIP_TRY(hipMemcpyAsync(&n_l, cnt, 8, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(hipStreamSynchronize(stream));
+	if(n_l == 0) return KMAHIP_OK;
+	if((int64_t) n_l > cap) { kmahip_set_error("long-read tasks: %llu for %lld slots", n_l, (long long) cap); return KMAHIP_EDEVICE; }
+	// the batch of tasks: offsets into the same packed reads, no N's (long_routed)
+	const size_t m = (size_t) n_l + 1;
+	const size_t words = 2 * m /*seq_off*/ + 2 * m /*N_off*/ + 2 * m /*ops_off*/ + 6 * m /*len tmpl rc qs qe n_ops*/ + 10 * m /*stats*/;
+	HIP_TRY(hipMalloc(&d_arr.p, words * 4));
+	HIP_TRY(hipMemsetAsync(d_arr.p, 0, words * 4, stream));
+	int64_t *so = (int64_t *) d_arr.p, *no = so + m, *oo = no + m;
+	int32_t *len = (int32_t *) (oo + m), *tmpl = len + m, *rc = tmpl + m, *qs = rc + m, *qe = qs + m, *nops = qe + m, *stats = nops + m;
+	const bool bounds = A.q_start != nullptr && A.q_end != nullptr;
+	hipLaunchKernelGGL(long_gather_kernel, dim3((unsigned) ((n_l + 255) / 256)), dim3(256), 0, stream, A, list, (int64_t) n_l, so, len, tmpl, rc, bounds ? qs : nullptr, bounds ? qe : nullptr);
+	HIP_TRY(hipGetLastError());
+	kmahip_reads L{};
+	L.n_reads = (int64_t) n_l; L.seq = reads->seq; L.seq_off = so; L.len = len; L.N = reads->N; L.N_off = no; L.seq_words = reads->seq_words; L.N_total = 0; L.max_len = reads->max_len;
+	if(bounds) { L.q_start = qs; L.q_end = qe; }
+	kmahip_traces tr{};
+	tr.stats = stats; tr.ops_off = oo; tr.n_ops = nops; tr.ops = nullptr; tr.ops_cap = 0;
+	const bool tim = getenv("KMAHIP_ALIGN_LONG_TIMING") != nullptr;
+	auto t0 = t_in;
+	if(tim_mode == 1) HIP_TRY(hipStreamSynchronize(stream));
+	auto t1 = std::chrono::steady_clock::now();
+	const int rcl = kmahip_launch_longtrace(db, ws, &L, tmpl, 0, rc, nullptr, 0, p, &tr, nullptr, stream, 1);
+	if(rcl) return rcl;
+	if(tim) {
+		fprintf(stderr, "[kmahip] stage 3a: %llu tasks of long reads: lists %.1f ms, pipeline %.1f ms\n", n_l, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+		        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+	}
+	hipLaunchKernelGGL(long_result_kernel, dim3((unsigned) ((n_l + 255) / 256)), dim3(256), 0, stream, A, list, (int64_t) n_l, stats);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(stream));          // (the scratch goes with this call)
+	return KMAHIP_OK;
+}
+
 static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
                         const int32_t *rec_mate, const int32_t *rec_rc, int32_t *pe_kind,
                         const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
@@ -2283,6 +2375,12 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(const char *e = getenv("KMAHIP_ABLATE_ALIGN")) A.ablate = atoi(e);
 #endif
 	A.tasks_cap = tasks_cap;
+	// reads over 1 kb (single end, not the work-counting launch) go through the long-read pipeline (KMAHIP_ALIGN_LONG: another length, 0: never)
+	A.long_min = 0;
+	if(!rec_mate && !A.stats) {
+		const int lm = getenv("KMAHIP_ALIGN_LONG") ? atoi(getenv("KMAHIP_ALIGN_LONG")) : 1025;
+		if(lm > 0 && max_len >= lm) A.long_min = std::max(lm, (int) db->dev.kmersize + 1);
+	}
 	hipLaunchKernelGGL(task_map_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, cands->T_off, n, t_rec, tasks_cap, ws->counters);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(A.seed_n && !A.stats) {
@@ -2322,6 +2420,10 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		        (dbg[0] >> 32) / 100.0, dbg[0] & 0xFFFFFFFFull, (dbg[1] >> 32) / 100.0, dbg[1] & 0xFFFFFFFFull);
 	}
 #endif
+	if(A.long_min) {
+		const int rcl = long_tasks(db, ws, reads, A, p, stream);
+		if(rcl) return rcl;
+	}
 	ReduceArgs R;
 	R.n_reads = n; R.rc_flag = cands->rc_flag; R.flag = cands->flag; R.T_off = cands->T_off; R.T = cands->T;
 	R.t_score = A.t_score; R.t_alen = A.t_alen; R.t_start = A.t_start; R.t_end = A.t_end; R.t_norm = A.t_norm; R.t_tmpl = A.t_tmpl;

@@ -95,6 +95,7 @@ struct LtArgs {
 	const int64_t *N_off;
 	const int32_t *tmpl;      // per read (batch index): signed template, or NULL: tmpl_all
 	const int32_t *rc_in;     // per read: orientation to align (NULL: both strands are seeded, anker_rc decides)
+	int score_mode;           // 1: KMA_score (align.c:509-748) instead of KMA(): its seeding rule at the end of a stretch, raw figures out, no runs
 	const int32_t *q_start, *q_end;   // query bounds per read (records of the default mode; with rc_in only), NULL: whole reads
 	const uint8_t *tmpl_ok;   // per template: align its reads? (NULL: all)
 	int tmpl_all;
@@ -228,6 +229,9 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 	// query bounds (KMA(), align.c:249-270): the scan starts at q_start; a stretch ends at the next N, the last one at q_end; a MEM
 	// is extended backwards to the N before it (or the read's first base), whatever q_start says
 	const int q_stop = qb1(q);
+	// (where a scan starts or starts again -- at the head of a stretch, behind a MEM -- KMA() wants more than k bases in front of it,
+	// align.c:256, 306, 367; KMA_score is content with k, align.c:541)
+	const int kk = A.score_mode ? k - 1 : k;
 	int segS = q.b0, ni = 1;
 	while(segS < q_stop) {
 		while(ni <= q.nN && qN_at(q, ni) < segS) ++ni;
@@ -238,7 +242,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 		int carry_pos = -2, carry_v = 0, carry_F = 0, carry_B = 0;
 		for(int guard = 0;; ++guard) {
 			if(guard > q_len + 2) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }     // (cur advances every round)
-			if(!scanning) { if(!(cur < segE - k)) break; scanning = true; }
+			if(!scanning) { if(!(cur < segE - kk)) break; scanning = true; }
 			if(cur > segE - k) break;
 			const int p0 = cur;
 			// ---- lookups of the k-mer starts p0 .. p0 + 255 (position p0 + j * 64 + lane) ----
@@ -355,7 +359,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 				}
 				scanning = false;
 				if(cur <= qs) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }
-				if(!(cur < segE - k)) break;
+				if(!(cur < segE - kk)) break;
 				scanning = true;
 				if(cur >= p0 + LT_TILE) break;
 			}
@@ -1731,7 +1735,7 @@ __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
 			A.o_off[r] = 0; A.o_nops[r] = 0;
 			if(A.o_rc) A.o_rc[r] = H.rc;
 		}
-		if(!H.status) continue;
+		if(!H.status) { if(A.score_mode && lane == 0) A.o_stats[10 * r + 3] = 1; continue; }          // (KMA_score's failure value: len 1)
 		const int q_len = A.len[r];
 		const int tt = A.tmpl ? A.tmpl[r] : A.tmpl_all;
 		const int t_len = A.db.tlen[abs(tt)];
@@ -1788,6 +1792,11 @@ __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
 		const int aln_len = match + tGaps + qGaps;
 		// the filter
 		const int start = H.pos0 - lead_cols;
+		if(A.score_mode) {
+			// stage 3a: KMA_score's figures as they are (the caller applies alnFragsSE's filter)
+			if(lane == 0) { int32_t *st = A.o_stats + 10 * r; st[0] = score; st[1] = start; st[3] = aln_len; st[6] = match; st[7] = tGaps; st[8] = qGaps; st[9] = H.mapQ; }
+			continue;
+		}
 		int end = start + aln_len - tGaps;
 		if(t_len < end) end -= t_len;
 		int read_score = score;
@@ -1861,7 +1870,7 @@ static int lt_reserve(kmahip_ws *ws, int slot, size_t bytes) {
 // one run slot word per DP column at most). tmpl == NULL: every read against tmpl_all. rc_in == NULL: both strands are seeded
 // and anker_rc decides (`-Mt1`), else the orientation is given. rc_out (may be NULL): the strand that was aligned.
 int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const int32_t *tmpl, int tmpl_all, const int32_t *rc_in,
-                            const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream) {
+                            const uint8_t *tmpl_ok, int one2one, const kmahip_params *p, kmahip_traces *out, int32_t *rc_out, hipStream_t stream, int score_mode) {
 	const int64_t n = reads->n_reads;
 	if(n < 0 || !p || !out || !out->stats || !out->ops_off || !out->n_ops || (out->ops_cap > 0 && !out->ops)) { kmahip_set_error("bad arguments"); return KMAHIP_EINVAL; }
 	if(!db->dev.tpos_slots) { kmahip_set_error("index has no .length.b/.seq.b: stage 3c unavailable"); return KMAHIP_EINVAL; }
@@ -1911,6 +1920,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	A.db = db->dev;
 	A.seq = reads->seq; A.seq_off = reads->seq_off; A.len = reads->len; A.N = reads->N; A.N_off = reads->N_off;
 	A.tmpl = tmpl; A.rc_in = rc_in; A.tmpl_ok = tmpl_ok; A.tmpl_all = tmpl_all; A.one2one = one2one; A.exhaustive = p->exhaustive;
+	A.score_mode = score_mode;
 	A.q_start = rc_in ? reads->q_start : nullptr; A.q_end = rc_in ? reads->q_end : nullptr;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
@@ -2093,6 +2103,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		r0 += nb;
 	}
 	// the caller reads the pool top through the workspace counters like after trace_kernel: [0] = runs used, [1] = status
+	if(score_mode) return KMAHIP_OK;          // (no runs; the workspace's status word is stage 3a's)
 	unsigned long long fin[2] = {0, 0};
 	HIP_TRY(hipMemcpy(&fin[0], counters + LC_OUT, 8, hipMemcpyDeviceToHost));
 	if((int64_t) fin[0] > out->ops_cap) fin[1] = 2;

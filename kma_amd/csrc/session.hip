@@ -839,7 +839,8 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	if((rc = B.get((size_t) 10 * n + 10, &tr.stats, true)) || (rc = B.get((size_t) n + 1, &tr.ops_off, true)) || (rc = B.get((size_t) n + 1, &tr.n_ops, true))) return rc;
 	for(Batch &b : S->batches) b.release();
 	DevArr pool;
-	if((rc = pool.ensure((size_t) (6 * n + (1 << 20)) * 4, 0, s))) return rc;
+	// (runs: a handful per short read; long reads with their errors leave one every few bases)
+	if((rc = pool.ensure((size_t) (6 * n + (1 << 20) + (S->max_len > 1024 ? S->words * 32 / 3 : 0)) * 4, 0, s))) return rc;
 	for(int attempt = 0; n; ++attempt) {
 		tr.ops = pool.as<uint32_t>(); tr.ops_cap = (int64_t) (pool.cap / 4);
 		if((rc = kmahip_launch_trace(db, ws, &W, rc_all, cc.tmpl, d_ok, p, &tr, s))) return rc;

@@ -28,6 +28,23 @@ subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, 
 reads = synth.make_long_reads(genome, n, read_len=L, seed=8)
 fq = os.path.join(tmp, "ont.fq")
 synth.write_fastq(fq, reads, prefix="r", qual=b"5")
+if os.environ.get("LONG_AB"):
+    # (no reference run: the long-read route of stage 3a against the lane-per-task kernel, files compared with each other)
+    out = {}
+    for name, env in (("routed", {}), ("lanes", {"KMAHIP_ALIGN_LONG": "0"})):
+        for rep in range(2):
+            time.sleep(2)
+            t1 = time.perf_counter()
+            r = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", os.path.join(tmp, name), "-chain", "-bcNano"], stderr=subprocess.PIPE,
+                               env=dict(os.environ, **env))
+            t2 = time.perf_counter()
+            print(f"{n} x {L} nt, default mode -bcNano, stage 3a {name}: {t2 - t1:.2f} s (rc {r.returncode}) | {r.stderr.decode().strip().splitlines()[-1][:330]}", flush=True)
+            for line in r.stderr.decode().splitlines():
+                if "stage 3a" in line:
+                    print("   ", line)
+        out[name] = [open(os.path.join(tmp, f"{name}.{e}"), "rb").read() for e in ("res", "fsa")] + [gzip.open(os.path.join(tmp, f"{name}.frag.gz")).read()]
+    print("files identical:", [a == b for a, b in zip(out["routed"], out["lanes"])], "fragment rows:", out["routed"][2].count(b"\n"))
+    sys.exit(0)
 for extra in ([], ["-bcNano"]):
     t0 = time.perf_counter()
     subprocess.run([KMA, "-i", fq, "-o", os.path.join(tmp, "ref"), "-t_db", prefix, "-t", "1"] + extra, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
