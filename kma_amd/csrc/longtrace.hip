@@ -495,7 +495,7 @@ __device__ Join lt_join(const LtArgs &A, const MemArr &Mm, int ia, int ib, int l
 				const int band = abs(t_e - t_s - q_e + q_s) + bw;
 				J.t_s = t_s; J.t_l = t_e - t_s; J.q_s = q_s; J.q_l = q_e - q_s; J.k = -1 - (t_s == 0);
 				J.band = (q_e - q_s <= band || t_e - t_s <= band) ? 0 : band;
-				J.flags = (t_s == 0) ? PF_LEAD_TRIM : 0;
+				J.flags = (t_s == 0 && !A.score_mode) ? PF_LEAD_TRIM : 0;          // (KMA_score keeps the gap columns at the template's ends: no Frag_align, align.c:95, 174)
 			}
 		}
 		return J;
@@ -513,7 +513,7 @@ __device__ Join lt_join(const LtArgs &A, const MemArr &Mm, int ia, int ib, int l
 			const int band = abs(t_e - t_s - q_e + q_s) + bw;
 			J.t_s = t_s; J.t_l = t_e - t_s; J.q_s = q_s; J.q_l = q_e - q_s; J.k = 1 + (t_e == t_len);
 			J.band = (q_e - q_s <= band || t_e - t_s <= band) ? 0 : band;
-			J.flags = (t_e == t_len) ? PF_TRAIL_TRIM : 0;
+			J.flags = (t_e == t_len && !A.score_mode) ? PF_TRAIL_TRIM : 0;
 		}
 		return J;
 	}

@@ -15,7 +15,7 @@ prefix = os.path.join(tmp, "db")
 synth.write_fasta(prefix + ".fsa", names, seqs)
 subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
-for pieces in (20, 150, 400):
+for pieces in ([int(x) for x in os.environ["PIECES"].split(",")] if os.environ.get("PIECES") else (20, 150, 400)):
     reads = []
     for i in range(60):
         parts = []
@@ -40,4 +40,10 @@ for pieces in (20, 150, 400):
         print(pieces, "pieces: kmahip_map failed:", r.stderr.decode().strip().splitlines()[-1:], flush=True); continue
     same = [open(os.path.join(tmp, f"ref.{e}"), "rb").read() == open(os.path.join(tmp, f"got.{e}"), "rb").read() for e in ("res", "fsa")]
     same.append(gzip.open(os.path.join(tmp, "ref.frag.gz")).read() == gzip.open(os.path.join(tmp, "got.frag.gz")).read())
+    if not same[0]:
+        a = open(os.path.join(tmp, "ref.res")).read().splitlines(); b = open(os.path.join(tmp, "got.res")).read().splitlines()
+        print("  .res lines", len(a), len(b))
+        for x, y in list(zip(a, b)):
+            if x != y:
+                print("  ref:", x); print("  got:", y)
     print(pieces, "pieces per read (", max(len(x) for x in reads), "nt ): reference", round(t1 - t0, 2), "s, kmahip_map", round(t2 - t1, 2), "s; identical", same, "rows", gzip.open(os.path.join(tmp, "ref.frag.gz")).read().count(b"\n"), flush=True)
