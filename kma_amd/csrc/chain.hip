@@ -13,6 +13,8 @@
 // per-template arrays, template lists, tree nodes); reads are handed out by static strides. What is parallel is the reads.
 // Correct first (records identical to the reference's -s2 tap); the run-of-equal-lists walk of scan.hip is the obvious next step
 // for the anchor search, which is where the gathers are.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include "kmahip_internal.h"
 #include "dna_dev.h"
 #include <algorithm>
@@ -792,7 +794,16 @@ struct FastArgs {
 	const int64_t *a_off;
 	const int32_t *a_n;
 	uint8_t *slow;
+	const uint32_t *order;    // the chunk's reads by falling number of anchors (or NULL: as they come): the 64 lanes of a wavefront pay for
+	                          // the longest of their reads, so reads of a kind go together
 };
+// key = anchors on both strands (reads the kernel skips: 0, they end up together at the far end)
+__global__ __launch_bounds__(256) void chain_order_keys_kernel(int64_t m, const int32_t *a_n, const uint8_t *slow, uint32_t *keys, uint32_t *vals) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= m) return;
+	const int a = slow[r] ? 0 : a_n[2 * r] + a_n[2 * r + 1];
+	keys[r] = (uint32_t) min(a, 255); vals[r] = (uint32_t) r;
+}
 #ifndef CHAIN_FAST_WAVES
 #define CHAIN_FAST_WAVES 8
 #endif
@@ -815,7 +826,8 @@ __global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const 
 	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
 	L.a_cap = A.a_cap; L.b_cap = A.b_cap; L.s_cap = A.s_cap;
 	L.status = 0; L.tree_n = 0;
-	for(int64_t r = lane; r < A.n_reads; r += A.lanes) {
+	for(int64_t i = lane; i < A.n_reads; i += A.lanes) {
+		const int64_t r = F.order ? (int64_t) F.order[i] : i;
 		if(F.slow[r]) continue;
 		const int nF = F.a_n[2 * r], nR = F.a_n[2 * r + 1];
 		if(!nF && !nR) continue;
@@ -908,6 +920,16 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 		void *fscratch = nullptr;
 		if((rc = dev((size_t) (Af.lanes * Af.lane_bytes), &fscratch))) return rc;
 		Af.scratch = (uint8_t *) fscratch;
+		// (KMAHIP_CHAIN_ORDER=0: the reads as they come)
+		const bool order_on = !(getenv("KMAHIP_CHAIN_ORDER") && !atoi(getenv("KMAHIP_CHAIN_ORDER")));
+		uint32_t *o_keys = nullptr, *o_keys2 = nullptr, *o_vals = nullptr, *o_vals2 = nullptr;
+		void *o_tmp = nullptr;
+		size_t o_tmp_bytes = 0;
+		if(order_on) {
+			if(rocprim::radix_sort_pairs_desc((void *) nullptr, o_tmp_bytes, o_keys, o_keys2, o_vals, o_vals2, (size_t) m_max, 0u, 8u, (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
+			if((rc = dev((size_t) m_max * 4, (void **) &o_keys)) || (rc = dev((size_t) m_max * 4, (void **) &o_keys2)) || (rc = dev((size_t) m_max * 4, (void **) &o_vals)) ||
+			   (rc = dev((size_t) m_max * 4, (void **) &o_vals2)) || (rc = dev(std::max<size_t>(o_tmp_bytes, 16), &o_tmp))) return rc;
+		}
 		stamp("fast route: buffers");
 		for(int64_t r0 = 0; r0 < n; r0 += CHUNK) {
 			const int64_t m = std::min(CHUNK, n - r0);
@@ -926,7 +948,13 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 			stamp("fast route: prefilter + chain_anchor_kernel");
 			ChainArgs Ac = Af;
 			Ac.n_reads = m; Ac.seq_off = v.seq_off; Ac.len = v.len; Ac.N_off = v.N_off; Ac.read_base = r0;
-			FastArgs F = {pool, a_off, a_n, slow + r0};
+			FastArgs F = {pool, a_off, a_n, slow + r0, nullptr};
+			if(order_on) {
+				hipLaunchKernelGGL(chain_order_keys_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, 0, m, a_n, slow + r0, o_keys, o_vals);
+				if(rocprim::radix_sort_pairs_desc(o_tmp, o_tmp_bytes, o_keys, o_keys2, o_vals, o_vals2, (size_t) m, 0u, 8u, (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
+				F.order = o_vals2;
+				stamp("fast route: reads ordered by their anchors");
+			}
 			hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned) (std::min<int64_t>(Af.lanes, ((m + 63) / 64) * 64) / 64)), dim3(64), 0, 0, Ac, F);
 			HIP_TRY(hipGetLastError());
 			stamp("fast route: chain_fast_kernel");
