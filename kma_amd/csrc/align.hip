@@ -2421,7 +2421,16 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	}
 #endif
 	if(A.long_min) {
-		const int rcl = long_tasks(db, ws, reads, A, p, stream);
+		int rcl = long_tasks(db, ws, reads, A, p, stream);
+		if(rcl == KMAHIP_EOVERFLOW) {
+			// a read with more MEMs than the pipeline has slots for: the lane kernel once more, for every task (it seeds the tasks
+			// seed_tasks_kernel left out by itself, and reports its own lack of room as status 3: the caller raises mem_scale)
+			A.long_min = 0;
+			HIP_TRY(hipMemsetAsync(ws->counters + 7, 0, sizeof(unsigned long long), stream));
+			hipLaunchKernelGGL((align_tasks_kernel<false, false>), agrid, dim3(ATHREADS), 0, stream, A);
+			HIP_TRY(hipGetLastError());
+			rcl = KMAHIP_OK;
+		}
 		if(rcl) return rcl;
 	}
 	ReduceArgs R;

@@ -1881,7 +1881,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	// (the seeding kernel waits for its index lookups: as many wavefronts as the registers allow, 16 per CU)
 	const int seed_wgs = (int) std::min<int64_t>(getenv("KMAHIP_LT_SEED_WGS") ? atoi(getenv("KMAHIP_LT_SEED_WGS")) : 4096, std::max<int64_t>(1024, 400000000ll / max_len));
 	const int fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
-	const int mcap = std::max(1024, max_len / 8 + 256);
+	int mcap = std::max(1024, max_len / 8 + 256);          // (MEM slots per seeding wavefront: four times more whenever a read runs out, below)
 	const int64_t tmp_cap = 4ll * max_len + 1024;
 	const int64_t xe_cap = 2ll << 20;
 	const int xrow = max_len + 72;
@@ -1960,7 +1960,15 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			if(prob_cap * (int64_t) sizeof(LtProb) > (48ll << 30) || runs_cap * 4 > (96ll << 30)) { kmahip_set_error("long-read trace: pools of a pass beyond 96 GB"); return KMAHIP_ENOMEM; }
 			continue;
 		}
-		if(c[LC_STATUS] == 3) { kmahip_set_error("seed (MEM) capacity per read exceeded (%d MEMs)", mcap); return KMAHIP_EOVERFLOW; }
+		if(c[LC_STATUS] == 3) {
+			// a read full of repeats: more MEMs against its template than a wavefront has slots for -- more slots, same reads again
+			if(mcap >= (1 << 16)) { kmahip_set_error("seed (MEM) capacity per read exceeded (%d MEMs)", mcap); return KMAHIP_EOVERFLOW; }
+			mcap *= 4;
+			if((rc = lt_reserve(ws, 0, (size_t) seed_wgs * 7 * mcap * 4))) return rc;
+			A.mem = (int32_t *) ws->lt_buf[0]; A.mcap = mcap;
+			if(getenv("KMAHIP_DEBUG_TIMING")) fprintf(stderr, "[kmahip] longtrace: seed (MEM) capacity per read raised to %d\n", mcap);
+			continue;
+		}
 		const bool dbg = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 		auto stage = [&](const char *what) {
 			if(!dbg) return;

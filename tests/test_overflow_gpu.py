@@ -103,3 +103,52 @@ def test_reads_full_of_repeats_grow_the_seed_capacity_and_equal_the_reference(tm
         assert b"tandem" in open(got + ".res", "rb").read()
         assert open(got + ".fsa", "rb").read() == open(ref + ".fsa", "rb").read(), mode
         assert gzip.open(got + ".frag.gz").read() == gzip.open(ref + ".frag.gz").read(), mode
+
+
+def test_long_reads_full_of_repeats_grow_the_pipelines_seed_capacity_and_equal_the_reference(tmp_path):
+    """the same for reads over 1 kb, whose stage 3a and traceback go through the long-read pipeline (longtrace.hip): a wavefront there
+    starts with 1 024 MEM slots; reads of 1.2-2.5 kb out of a tandem repeat of 300 units carry thousands of MEMs. The pipeline raises
+    its capacity and seeds the pass again (it used to end the run with KMAHIP_EOVERFLOW)."""
+    import gzip
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    KMA = os.path.join(ROOT, "oracle", "_ref", "kma")
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(13)
+    names, seqs = synth.make_gene_db(n_families=6, variants=3, len_lo=1500, len_hi=3000, seed=32)
+    unit = rng.integers(0, 4, 24, dtype=np.uint8)
+    rep = np.tile(unit, 300)
+    rep[rng.integers(0, len(rep), 70)] = rng.integers(0, 4, 70, dtype=np.uint8)          # some units differ
+    seqs = list(seqs) + [np.concatenate([rng.integers(0, 4, 300, dtype=np.uint8), rep, rng.integers(0, 4, 300, dtype=np.uint8)])]
+    names = list(names) + ["tandem"]
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = []
+    for i in range(120):
+        g = seqs[int(rng.integers(0, len(seqs) - 1))]
+        reads.append(synth.make_long_reads(g, 1, read_len=int(rng.integers(1100, len(g))), seed=200 + i)[0])
+    t = seqs[-1]
+    for i in range(40):
+        a = int(rng.integers(100, len(t) - 2800))
+        r = t[a:a + int(rng.integers(1200, 2500))].copy()
+        x = rng.random(len(r)) < 0.01
+        r[x] = (r[x] + 1) & 3
+        reads.append(r)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, reads, prefix="q")
+    for mode in (["-1t1"], []):
+        ref, got = str(tmp_path / ("ref" + "".join(mode))), str(tmp_path / ("got" + "".join(mode)))
+        subprocess.run([KMA, "-i", fq, "-o", ref, "-t_db", prefix, "-t", "1"] + mode, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        g = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", got] + mode, stderr=subprocess.PIPE,
+                           env=dict(os.environ, KMAHIP_DEBUG_TIMING="1"))
+        assert g.returncode == 0, g.stderr.decode()[-500:]
+        assert b"longtrace: seed (MEM) capacity per read raised" in g.stderr, mode          # (the case is what it claims to be)
+        assert open(got + ".res", "rb").read() == open(ref + ".res", "rb").read(), mode
+        assert b"tandem" in open(got + ".res", "rb").read()
+        assert open(got + ".fsa", "rb").read() == open(ref + ".fsa", "rb").read(), mode
+        assert gzip.open(got + ".frag.gz").read() == gzip.open(ref + ".frag.gz").read(), mode
