@@ -213,6 +213,7 @@ def lib():
         L.kmahip_ingest_counts.restype = None
         L.kmahip_ingest_close.argtypes = [C.c_void_p]
         L.kmahip_ingest_status.argtypes = [C.c_void_p]
+        L.kmahip_ingest_set_batch_bases.argtypes = [C.c_void_p, C.c_int64]
         L.kmahip_ingest_close.restype = None
         _lib = L
     return _lib
@@ -283,6 +284,10 @@ class Ingest:
         raw = C.string_at(b.names, int(noff[-1]))
         names = [raw[noff[i]:noff[i + 1] - 1] for i in range(n)]
         return batch, names, arr(b.pair, C.c_uint8, n)
+
+    def set_batch_bases(self, max_bases):
+        """a batch of next() also closes once it holds about max_bases bases (0: no such bound)"""
+        _check(lib().kmahip_ingest_set_batch_bases(self._h, int(max_bases)))
 
     def status(self):
         """raises when the input broke off behind the records delivered so far (for callers that take everything as one batch)"""

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from kma_amd import binding, formats
+from kma_amd import binding, formats, synth
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ING = os.path.join(GOLD, "ingest")
@@ -83,6 +83,33 @@ def test_ingest_batches_are_a_partition():
             a0, b0 = p[0].seq_off[i], whole[0].seq_off[o]
             assert np.array_equal(p[0].seq[a0:a0 + ((L + 31) >> 5)], whole[0].seq[b0:b0 + ((L + 31) >> 5)])
             o += 1
+
+
+def test_ingest_batches_closed_by_their_bases(tmp_path, monkeypatch):
+    """kmahip_ingest_set_batch_bases: a batch closes once it holds about that many bases (checked between the stretches of input the
+    reader cuts into records); the batches still concatenate to the one-shot result"""
+    monkeypatch.setenv("KMAHIP_INGEST_REGION", "256")           # small stretches: the bound is met often
+    rng = np.random.default_rng(3)
+    reads = [rng.integers(0, 4, int(rng.integers(200, 3000)), dtype=np.uint8) for _ in range(400)]
+    fq = str(tmp_path / "long.fq")
+    synth.write_fastq(fq, reads, prefix="r", qual=b"5")
+    with binding.Ingest(fq) as a:
+        whole = a.next(1 << 30)
+    parts = []
+    with binding.Ingest(fq) as b:
+        b.set_batch_bases(50_000)
+        while True:
+            g = b.next(1 << 30)
+            if g is None:
+                break
+            parts.append(g)
+    assert len(parts) > 5
+    assert max(int(p[0].length.sum()) for p in parts) < 50_000 + 64 * 32 * 256         # (over by one stretch of input at most)
+    assert np.array_equal(np.concatenate([p[0].length for p in parts]), whole[0].length)
+    assert [n for p in parts for n in p[1]] == whole[1]
+    with binding.Ingest(fq) as c:
+        with pytest.raises(binding.KmaHipError):
+            c.set_batch_bases(-1)
 
 
 @pytest.mark.parametrize("name,files", [("se", ("reads.fq.gz", None)), ("long", ("reads.fq.gz", None)), ("pe", ("r1.fq.gz", "r2.fq.gz"))])
