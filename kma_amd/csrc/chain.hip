@@ -903,15 +903,26 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 	int64_t *slow_list = nullptr;
 	int64_t n_slow = all_slow ? n : 0;
 	if(!all_slow) {
-		constexpr int64_t CHUNK = 2000000;
-		const int64_t m_max = std::min(n, CHUNK);
-		int64_t *a_off = nullptr;
-		int32_t *a_n = nullptr;
-		unsigned long long *cnt = nullptr;
-		CAnk *pool = nullptr;
-		int64_t pool_cap = m_max * 40 + 4096;
-		if((rc = dev((size_t) n, (void **) &slow)) || (rc = dev((size_t) m_max * 16, (void **) &a_off)) || (rc = dev((size_t) m_max * 8, (void **) &a_n)) ||
-		   (rc = dev(16, (void **) &cnt)) || (rc = dev((size_t) pool_cap * sizeof(CAnk), (void **) &pool))) return rc;
+		// (KMAHIP_CHAIN_CHUNK: reads per chunk, for the tests: many chunks out of a few thousand reads)
+		const int64_t CHUNK = getenv("KMAHIP_CHAIN_CHUNK") ? std::max<int64_t>(64, atoll(getenv("KMAHIP_CHAIN_CHUNK"))) : 2000000;
+		const int64_t m_max = std::min(n, CHUNK), n_chunks = (n + CHUNK - 1) / CHUNK;
+		// The anchors of chunk i + 1 are made (on a stream of their own, into a second set of buffers) while chunk i is chained: the two
+		// kernels wait for different things -- index lookups there, a lane's serial walk here. KMAHIP_CHAIN_OVERLAP=0, one chunk or
+		// KMAHIP_DEBUG_TIMING (stamps per kernel): one set of buffers, one after the other.
+		const int nbuf = (n_chunks > 1 && !dbg && !(getenv("KMAHIP_CHAIN_OVERLAP") && !atoi(getenv("KMAHIP_CHAIN_OVERLAP")))) ? 2 : 1;
+		struct Buf { CAnk *pool = nullptr; int64_t pool_cap = 0; int64_t *a_off = nullptr; int32_t *a_n = nullptr; unsigned long long *cnt = nullptr; } buf[2];
+		struct Side {
+			hipStream_t s = nullptr; hipEvent_t e[2] = {nullptr, nullptr}; bool rec[2] = {false, false};
+			~Side() { if(s) { (void) hipStreamSynchronize(s); (void) hipStreamDestroy(s); } for(int x = 0; x < 2; ++x) if(e[x]) (void) hipEventDestroy(e[x]); }
+		} side;
+		HIP_TRY(hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+		for(int x = 0; x < 2; ++x) HIP_TRY(hipEventCreateWithFlags(&side.e[x], hipEventDisableTiming));
+		if((rc = dev((size_t) n, (void **) &slow))) return rc;
+		for(int x = 0; x < nbuf; ++x) {
+			buf[x].pool_cap = m_max * 40 + 4096;
+			if((rc = dev((size_t) m_max * 16, (void **) &buf[x].a_off)) || (rc = dev((size_t) m_max * 8, (void **) &buf[x].a_n)) || (rc = dev(16, (void **) &buf[x].cnt)) ||
+			   (rc = dev((size_t) buf[x].pool_cap * sizeof(CAnk), (void **) &buf[x].pool))) return rc;
+		}
 		// per-lane scratch of the fast kernel: two dummy anchors, the two template lists, the tree
 		ChainArgs Af = A;
 		Af.a_cap = 0; Af.b_cap = 2 * LDS_TS + 8; Af.s_cap = 128;
@@ -930,36 +941,58 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 			if((rc = dev((size_t) m_max * 4, (void **) &o_keys)) || (rc = dev((size_t) m_max * 4, (void **) &o_keys2)) || (rc = dev((size_t) m_max * 4, (void **) &o_vals)) ||
 			   (rc = dev((size_t) m_max * 4, (void **) &o_vals2)) || (rc = dev(std::max<size_t>(o_tmp_bytes, 16), &o_tmp))) return rc;
 		}
+		HIP_TRY(hipStreamSynchronize(0));          // (the counters are cleared before anything on the other stream starts)
 		stamp("fast route: buffers");
-		for(int64_t r0 = 0; r0 < n; r0 += CHUNK) {
-			const int64_t m = std::min(CHUNK, n - r0);
-			kmahip_reads v = *d;
-			v.n_reads = m; v.seq_off = d->seq_off + r0; v.len = d->len + r0; v.N_off = d->N_off + r0;
+		const auto t_route = std::chrono::steady_clock::now();
+		auto chunk_view = [&](int64_t i) { kmahip_reads v = *d; const int64_t r0 = i * CHUNK; v.n_reads = std::min(CHUNK, n - r0); v.seq_off = d->seq_off + r0; v.len = d->len + r0; v.N_off = d->N_off + r0; return v; };
+		// the anchors of chunk i into its set of buffers, once the chain kernel that read that set last is through
+		auto launch_anchors = [&](int64_t i) -> int {
+			const int x = (int) (i % nbuf);
+			if(side.rec[x] && hipStreamWaitEvent(side.s, side.e[x], 0) != hipSuccess) { kmahip_set_error("hipStreamWaitEvent failed"); return KMAHIP_EDEVICE; }
+			const kmahip_reads v = chunk_view(i);
+			return kmahip_launch_chain_anchors(db, ws, &v, p, buf[x].pool, buf[x].pool_cap, buf[x].a_off, buf[x].a_n, slow + i * CHUNK, buf[x].cnt, side.s);
+		};
+		if((rc = launch_anchors(0))) return rc;
+		for(int64_t i = 0; i < n_chunks; ++i) {
+			const int x = (int) (i % nbuf);
+			const int64_t r0 = i * CHUNK;
+			const kmahip_reads v = chunk_view(i);
+			const int64_t m = v.n_reads;
 			for(int attempt = 0;; ++attempt) {
-				if((rc = kmahip_launch_chain_anchors(db, ws, &v, p, pool, pool_cap, a_off, a_n, slow + r0, cnt, 0))) return rc;
 				unsigned long long used = 0;
-				HIP_TRY(hipMemcpy(&used, cnt, 8, hipMemcpyDeviceToHost));
-				if((int64_t) used <= pool_cap) break;
+				HIP_TRY(hipMemcpyAsync(&used, buf[x].cnt, 8, hipMemcpyDeviceToHost, side.s));
+				HIP_TRY(hipStreamSynchronize(side.s));
+				if((int64_t) used <= buf[x].pool_cap) break;
 				if(attempt >= 2) { kmahip_set_error("anchor pool: %llu anchors for %lld reads", used, (long long) m); return KMAHIP_EOVERFLOW; }
-				drop(pool);
-				pool_cap = (int64_t) used + 4096;
-				if((rc = dev((size_t) pool_cap * sizeof(CAnk), (void **) &pool))) return rc;
+				drop(buf[x].pool);          // (nothing reads it any more: launch_anchors waited for the chain kernel before this chunk's anchors)
+				buf[x].pool_cap = (int64_t) used + 4096;
+				if((rc = dev((size_t) buf[x].pool_cap * sizeof(CAnk), (void **) &buf[x].pool))) return rc;
+				if((rc = launch_anchors(i))) return rc;
 			}
 			stamp("fast route: prefilter + chain_anchor_kernel");
+			if(nbuf == 2 && i + 1 < n_chunks && (rc = launch_anchors(i + 1))) return rc;          // beside this chunk's chain kernel
 			ChainArgs Ac = Af;
 			Ac.n_reads = m; Ac.seq_off = v.seq_off; Ac.len = v.len; Ac.N_off = v.N_off; Ac.read_base = r0;
-			FastArgs F = {pool, a_off, a_n, slow + r0, nullptr};
+			FastArgs F = {buf[x].pool, buf[x].a_off, buf[x].a_n, slow + r0, nullptr};
 			if(order_on) {
-				hipLaunchKernelGGL(chain_order_keys_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, 0, m, a_n, slow + r0, o_keys, o_vals);
+				hipLaunchKernelGGL(chain_order_keys_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, 0, m, buf[x].a_n, slow + r0, o_keys, o_vals);
 				if(rocprim::radix_sort_pairs_desc(o_tmp, o_tmp_bytes, o_keys, o_keys2, o_vals, o_vals2, (size_t) m, 0u, 8u, (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 				F.order = o_vals2;
 				stamp("fast route: reads ordered by their anchors");
 			}
 			hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned) (std::min<int64_t>(Af.lanes, ((m + 63) / 64) * 64) / 64)), dim3(64), 0, 0, Ac, F);
 			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipEventRecord(side.e[x], 0));
+			side.rec[x] = true;
 			stamp("fast route: chain_fast_kernel");
+			if(nbuf == 1 && i + 1 < n_chunks && (rc = launch_anchors(i + 1))) return rc;
 		}
-		drop(pool); drop(fscratch); drop(a_off); drop(a_n);
+		HIP_TRY(hipStreamSynchronize(0));
+		if(getenv("KMAHIP_CHAIN_TIMING")) fprintf(stderr, "[kmahip] scan_chain: fast route, %lld reads in %lld chunks, %d set(s) of buffers: %.1f ms\n", (long long) n, (long long) n_chunks, nbuf,
+		                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_route).count());
+		unsigned long long *cnt = buf[0].cnt;
+		for(int x = 0; x < nbuf; ++x) { drop(buf[x].pool); drop(buf[x].a_off); drop(buf[x].a_n); }
+		drop(fscratch);
 		// what is left for the lane-per-read kernel
 		unsigned long long *cnt2 = cnt;
 		if((rc = dev((size_t) n * 8, (void **) &slow_list))) return rc;

@@ -154,8 +154,10 @@ def test_whole_default_mode_run_equals_reference_binary_on_chimeric_reads(tmp_pa
         assert False, (len(a), len(b), len(d), a[d[0]][-120:] if d else None, b[d[0]][-120:] if d else None)
     assert frag.count(b"\n") > (10000 if seed <= 2 else 3000)
     # the same through batches of 1 777 reads with text chunks of 30 kB (records of a read never straddle batches, chunks of -mf do),
-    # and through the one-batch call (kmahip_run_chain)
-    for env in ({"KMAHIP_MAP_BATCH": "1777", "KMAHIP_FRAG_CHUNK": "30000"}, {"KMAHIP_MAP_ONE_BATCH": "1"}):
+    # and through the one-batch call (kmahip_run_chain); the one batch with stage 2 in chunks of 3 001 reads (the anchors of a chunk made
+    # beside the chaining of the chunk before, on a second set of buffers), and with the chunks one after the other
+    for env in ({"KMAHIP_MAP_BATCH": "1777", "KMAHIP_FRAG_CHUNK": "30000"}, {"KMAHIP_MAP_ONE_BATCH": "1"}, {"KMAHIP_MAP_ONE_BATCH": "1", "KMAHIP_CHAIN_CHUNK": "3001"},
+                {"KMAHIP_MAP_ONE_BATCH": "1", "KMAHIP_CHAIN_CHUNK": "3001", "KMAHIP_CHAIN_OVERLAP": "0"}):
         assert _run_both(tmp_path, prefix, fq, extra, env) == [res, fsa, frag], env
 
 

@@ -9,7 +9,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["KMAHIP_DEBUG_TIMING"] = "1"
+if not os.environ.get("KMAHIP_CHAIN_TIMING"):
+    os.environ["KMAHIP_DEBUG_TIMING"] = "1"          # (KMAHIP_CHAIN_TIMING=1: the fast route as a whole, chunks overlapped, no stamps per kernel)
 from kma_amd import binding, formats, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
