@@ -283,7 +283,7 @@ def test_bcnano_without_mt1_equals_reference_binary(tmp_path, mode):
     assert got == gzip.open(tmp_path / "ref.frag.gz").read() and got.count(b"\n") > 500
 
 
-@pytest.mark.parametrize("mode", ["-1t1", "default", "-ipe"])
+@pytest.mark.parametrize("mode", ["-1t1", "default", "-ipe", "-Mt1", "-Mt1 in one call"])
 def test_empty_input_equals_reference_binary(tmp_path, mode):
     """a FASTQ file without a record (and one whose only record is too short to keep): the three outputs as the reference writes them"""
     if not os.path.exists(KMA):
@@ -298,11 +298,14 @@ def test_empty_input_equals_reference_binary(tmp_path, mode):
         if mode == "-ipe":
             ra = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-apm", "p", "-1t1"]
             ga = ["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-1t1", "-apm", "p"]
+        elif mode.startswith("-Mt1"):
+            ra = ga = ["-i", str(tmp_path / "r1.fq"), "-Mt1", "2", "-bcNano"]
         else:
             ra = ["-i", str(tmp_path / "r1.fq")] + (["-1t1"] if mode == "-1t1" else [])
             ga = ["-i", str(tmp_path / "r1.fq"), "-1t1" if mode == "-1t1" else "-chain"]
         r = subprocess.run([KMA] + ra + ["-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
-        g = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map")] + ga + ["-t_db", prefix, "-o", str(tmp_path / "got")], stderr=subprocess.PIPE)
+        g = subprocess.run([os.path.join(ROOT, "examples", "kmahip_map")] + ga + ["-t_db", prefix, "-o", str(tmp_path / "got")], stderr=subprocess.PIPE,
+                           env=dict(os.environ, **({"KMAHIP_MAP_ONE_BATCH": "1"} if mode.endswith("one call") else {})))
         assert g.returncode == 0, (case, g.stderr.decode()[-300:])
         if r.returncode == 0 and os.path.exists(tmp_path / "ref.res"):
             assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
