@@ -389,6 +389,7 @@ extern "C" int kmahip_session_add(kmahip_session *S, const kmahip_read_batch *ba
 // (kmahip_session_finish): both only read what the rows are made of, and the arrays are not moved meanwhile.
 static void mt1_frag_start(kmahip_session *S) {
 	if(!S->frag_have || !S->sink) return;
+	if(S->frag_thread.joinable()) S->frag_thread.join();          // (a call that ended early left it behind)
 	S->frag_have = false;
 	S->frag_rc = 0;
 	S->frag_thread = std::thread([S]() {
