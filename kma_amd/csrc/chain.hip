@@ -155,6 +155,45 @@ __device__ __forceinline__ uint32_t db_probe(const DevDB &db, uint32_t key) {
 		b = (b + 1u) & nbm;
 	}
 }
+// db_probe in two halves, for a lane that wants several probes in flight: the first bucket of a key (one round trip), and what it says --
+// the k-mer's place, NOLIST, or PROBE_MORE (the bucket is full of other keys: the probe goes on in the next one, db_probe_from)
+constexpr uint32_t PROBE_MORE = 0xFFFFFFFEu;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct Bucket { u32x4 a, c; };
+// (the pointers of a DevDB that a lane reads out of its CLane are generic to the compiler: FLAT loads, which count on two counters at once
+// and are therefore waited for one by one -- eight buckets fetched "together" came back in eight round trips. As pointers into HBM
+// (address space 1) they are GLOBAL loads and overlap.)
+#define KMAHIP_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ Bucket db_bucket(const DevDB &db, uint32_t key) {
+	const uint32_t b = (key * 0x9E3779B1u) >> (32u - db.nb_log2);
+	const KMAHIP_GLOBAL u32x4 *p = (const KMAHIP_GLOBAL u32x4 *) (db.slots + (size_t) b * KMAHIP_BUCKET_SLOTS);
+	Bucket B;
+	B.a = p[0]; B.c = p[1];
+	return B;
+}
+__device__ __forceinline__ uint32_t db_list_id(const DevDB &db, uint32_t gp) { return ((const KMAHIP_GLOBAL uint32_t *) db.vs_id)[gp]; }
+__device__ __forceinline__ uint32_t db_bucket_says(const Bucket &B, uint32_t key) {
+	if(B.a.x == key && B.a.y != KMAHIP_EMPTY_VI) return B.a.y;
+	if(B.a.z == key && B.a.w != KMAHIP_EMPTY_VI) return B.a.w;
+	if(B.c.x == key && B.c.y != KMAHIP_EMPTY_VI) return B.c.y;
+	if(B.c.z == key && B.c.w != KMAHIP_EMPTY_VI) return B.c.w;
+	return B.c.w == KMAHIP_EMPTY_VI ? NOLIST : PROBE_MORE;
+}
+// (a probe whose first bucket said PROBE_MORE: from the bucket behind it on)
+__device__ __forceinline__ uint32_t db_probe_from(const DevDB &db, uint32_t key) {
+	const uint32_t sh = 32u - db.nb_log2, nbm = (1u << db.nb_log2) - 1u;
+	uint32_t b = (((key * 0x9E3779B1u) >> sh) + 1u) & nbm;
+	for(;;) {
+		const uint4 *p = reinterpret_cast<const uint4 *>(db.slots + (size_t) b * KMAHIP_BUCKET_SLOTS);
+		const uint4 a = p[0], c = p[1];
+		if(a.x == key && a.y != KMAHIP_EMPTY_VI) return a.y;
+		if(a.z == key && a.w != KMAHIP_EMPTY_VI) return a.w;
+		if(c.x == key && c.y != KMAHIP_EMPTY_VI) return c.y;
+		if(c.z == key && c.w != KMAHIP_EMPTY_VI) return c.w;
+		if(c.w == KMAHIP_EMPTY_VI) return NOLIST;
+		b = (b + 1u) & nbm;
+	}
+}
 // value list of a k-mer: its offset, or NOLIST
 __device__ __forceinline__ uint32_t list_of(const DevDB &db, uint32_t key) {
 	const uint32_t gp = db_probe(db, key);
@@ -387,10 +426,23 @@ __device__ int choose_chain(const CAnk &b, const CAnk &r, int cStart, int cStart
 	return rc;
 }
 
+#ifndef CHAIN_PROBE_BLOCK
+#define CHAIN_PROBE_BLOCK 8
+#endif
+constexpr int PB = CHAIN_PROBE_BLOCK;         // probes a lane of the slow route keeps in flight (build_ankers)
+static_assert(PB >= 1 && PB + 15 <= 32, "a block's k-mers come out of one 32-base window");
 // anchors of one strand in forward coordinates (savekmers.c:5208-5330, 5333-5452); returns their number
-template <class CLane> __device__ int build_ankers(CLane &L, const QView &qf, const QView &qr, int exhaustive, int is_rc, CAnk *V) {
+// (a function of its own, not inlined into the kernel: there its loop shared 254 registers and 2 kB of scratch per lane with the chaining
+// and the extraction, and kept its counters in scratch -- a round trip per position; the views and the database come in by value for the
+// same reason)
+template <class CLane> __attribute__((noinline)) __device__ int build_ankers(CLane &L, const QView qf, const QView qr, int exhaustive, int is_rc, CAnk *V) {
 	const DevDB &db = *L.db;
 	const int k = L.k, seqlen = qf.L, nN = qf.nN;
+	const int M_ = L.M, MM_ = L.MM, a_cap_ = L.a_cap;
+	// (what the fetches of a block need of the database, once: pointers into HBM)
+	const KMAHIP_GLOBAL u32x4 *const g_slots = (const KMAHIP_GLOBAL u32x4 *) db.slots;
+	const KMAHIP_GLOBAL uint32_t *const g_vs_id = (const KMAHIP_GLOBAL uint32_t *) db.vs_id;
+	const uint32_t g_sh = 32u - db.nb_log2;
 	V[0].start = 0; V[0].end = 0; V[0].values = NOLIST; V[0].descend = -1;
 	bool HIT = exhaustive != 0;
 	{
@@ -412,13 +464,84 @@ template <class CLane> __device__ int build_ankers(CLane &L, const QView &qf, co
 	for(int i = 1; i <= nN + 1 && j < seqend; ++i) {
 		const int segend = i <= nN ? qN_at(qf, i) : seqlen;
 		uint32_t gp = NOLIST;                  // where the k-mer of the step before lies in the template store
+		// A lane walks its read alone: with a probe (or a step along the template store) per position, every position of every lane is a
+		// round trip to memory the whole wavefront waits for -- 20 000 of them for a 10 kb read. So the lists of the next PB positions are
+		// fetched together: one round trip for the read's window, one for the PB buckets, one for the lists of the k-mers that are there;
+		// the state machine below then runs on registers. (PB = 1: a probe or a step per position, as first written.)
+		uint32_t pre[PB];
+		int pre_at = 0, pre_n = 0;             // the block's answers: pre[pre_at .. pre_n) are still to come
 		for(; j < segend - k + 1; ++j, --rcpos) {
+			if(PB > 1 && pre_at == pre_n) {
+				pre_n = min(PB, segend - k + 1 - j); pre_at = 0;
+				// the block's k-mers out of ONE 32-base window of the read (PB + k - 1 <= 32 bases): a round trip for the window, one for
+				// the PB buckets. The reverse strand's windows move backwards: position rcpos - x lies pre_n - 1 - x bases into the
+				// window that starts at the block's last position; a block that hangs over an end of the read (the reference's buffer
+				// has zeros there, rc_kmer) takes its k-mers one by one.
+				uint32_t keys[PB];
+				const int p0 = rcpos - (pre_n - 1);
+				if(!is_rc || (p0 >= 0 && rcpos + k <= seqlen)) {
+					const uint64_t w = is_rc ? qwin(qr, p0) : qwin(qf, j);
+#pragma unroll
+					for(int x = 0; x < PB; ++x) {
+						const int y = is_rc ? max(pre_n - 1 - x, 0) : x;
+						keys[x] = (uint32_t) ((w << (2 * y)) >> (64 - 2 * k));
+					}
+				} else {
+#pragma unroll
+					for(int x = 0; x < PB; ++x) keys[x] = x < pre_n ? rc_kmer(qr, rcpos - x, k) : 0u;
+				}
+				// (a key whose bucket is full of other keys lives further on: the unresolved ones of the block go on together, a round trip
+				// per round for the block instead of one per position -- with 64 lanes some lane has such a key at nearly every position)
+				uint32_t bi[PB];
+				const uint32_t g_nbm = (1u << db.nb_log2) - 1u;
+#pragma unroll
+				for(int x = 0; x < PB; ++x) bi[x] = (keys[x] * 0x9E3779B1u) >> g_sh;
+				for(int round = 0; round < 32; ++round) {
+					Bucket bk[PB];
+#pragma unroll
+					for(int x = 0; x < PB; ++x) {          // (every lane loads for every position, beyond pre_n and where the answer is there too: no branches)
+						const KMAHIP_GLOBAL u32x4 *pb = g_slots + (size_t) bi[x] * (KMAHIP_BUCKET_SLOTS / 2);
+						bk[x].a = pb[0]; bk[x].c = pb[1];
+					}
+					bool more = false;
+#pragma unroll
+					for(int x = 0; x < PB; ++x) {
+						const uint32_t says = db_bucket_says(bk[x], keys[x]);
+						pre[x] = (round == 0 || pre[x] == PROBE_MORE) ? says : pre[x];
+						more = more || (x < pre_n && pre[x] == PROBE_MORE);
+						bi[x] = (bi[x] + 1u) & g_nbm;
+					}
+					if(!more) break;
+				}
+				// ... and a third for the value lists of the k-mers that are there: pre[] holds a position's list (NOLIST: none) from here on
+				// (every lane loads for every position -- entry 0 where there is nothing to look up --, so that the loads are not eight branches
+				// with a wait behind each)
+				uint32_t lid[PB];
+#pragma unroll
+				for(int x = 0; x < PB; ++x) lid[x] = g_vs_id[pre[x] < PROBE_MORE ? pre[x] : 0u];
+#pragma unroll
+				for(int x = 0; x < PB; ++x) pre[x] = pre[x] < PROBE_MORE ? lid[x] : pre[x];
+			}
+			uint32_t fetched = NOLIST;
+			if(PB > 1) {
+#pragma unroll
+				for(int x = 0; x < PB; ++x) if(x == pre_at) fetched = pre[x];
+				++pre_at;
+			}
 			// A read that matches a template keeps matching it: when the base that enters the window is the template's next base
 			// (the one in front of it on the reverse strand, whose windows move backwards), the k-mer is the template's
 			// neighbouring k-mer and its value list stands in vs_id -- no probe (the walk of scan.hip, one lane here)
 			uint32_t values;
 			bool walked = false;
-			if(gp != NOLIST) {
+			if(PB > 1) {
+				// (no walk here: what it saves is the probe, and the probes are there already; the list of a k-mer is the same either way)
+				values = fetched;
+				if(values == PROBE_MORE) {
+					const uint32_t g2 = db_probe_from(db, is_rc ? rc_kmer(qr, rcpos, k) : q_kmer(qf, j, k));
+					values = g2 == NOLIST ? NOLIST : db.vs_id[g2];
+				}
+				walked = true;
+			} else if(gp != NOLIST) {
 				if(!is_rc) {
 					const uint32_t v = db.vs_id[gp + 1];
 					if(v != KMAHIP_EMPTY_VI && (int) ((db.cat[(gp + k) >> 5] >> (62 - (((gp + k) & 31) << 1))) & 3ull) == q2(qf, j + k - 1)) { ++gp; values = v; walked = true; }
@@ -440,11 +563,11 @@ template <class CLane> __device__ int build_ankers(CLane &L, const QView &qf, co
 				}
 				if(open) {
 					if(last != NOLIST) {
-						V[v].weight = Ms * L.M + MMs * L.MM;
+						V[v].weight = Ms * M_ + MMs * MM_;
 						V[v].end = (unsigned) (j - gaps + k);
 						V[v].descend = v + 1;
 						++v;
-						if(v >= L.a_cap) { L.status = 1; return 0; }
+						if(v >= a_cap_) { L.status = 1; return 0; }
 					}
 					V[v].start = (unsigned) j; V[v].values = values; V[v].descend = -1;
 					last = values;
@@ -459,7 +582,7 @@ template <class CLane> __device__ int build_ankers(CLane &L, const QView &qf, co
 		rcpos = seqlen - j;
 	}
 	if(last != NOLIST) {
-		V[v].weight = Ms * L.M + MMs * L.MM;
+		V[v].weight = Ms * M_ + MMs * MM_;
 		V[v].end = (unsigned) (seqlen - gaps);
 	}
 	return hits;
