@@ -31,6 +31,26 @@ constexpr uint32_t NOLIST = 0xFFFFFFFFu;
 using CAnk = KmaAnk;      // (kmahip_internal.h: the anchors of short N-free reads come from chain_anchor_kernel, scan.hip)
 struct CSeg { unsigned start, end, covered; int b0, b1; };
 
+// What a lane keeps in HBM -- its anchors, its template lists, its tree of covered stretches, the database's arrays, the output columns --
+// is reached through pointers of address space 1. As generic pointers (what a pointer kept in a struct is to the compiler) every access
+// was a FLAT one: counted on two counters at once, so each was waited for before anything else went on, and a lane never had two loads
+// in flight; GLOBAL accesses overlap.
+#define KMAHIP_GLOBAL __attribute__((address_space(1)))
+typedef KMAHIP_GLOBAL CAnk GAnk;
+typedef KMAHIP_GLOBAL CSeg GSeg;
+typedef KMAHIP_GLOBAL int GInt;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+static_assert(sizeof(CAnk) == 32, "an anchor is loaded as two 16-byte words");
+// an anchor into registers: two 16-byte loads
+__device__ __forceinline__ CAnk ank_load(const GAnk *p) {
+	const KMAHIP_GLOBAL u32x4 *q = (const KMAHIP_GLOBAL u32x4 *) p;
+	const u32x4 a = q[0], b = q[1];
+	CAnk r;
+	__builtin_memcpy(&r, &a, 16);
+	__builtin_memcpy((char *) &r + 16, &b, 16);
+	return r;
+}
+
 // The reference keeps three DB_size-wide arrays per thread (Score, extendScore, include; savekmers.c:5140-5160) of which a read
 // touches the entries of its few candidate templates. Two homes for them:
 //   DenseMap  the same arrays in the lane's HBM scratch (the lane-per-read kernel that takes every read);
@@ -43,10 +63,10 @@ struct DenseMap {
 	int8_t *include;
 	const int32_t *tlen;
 	__device__ __forceinline__ int slot(int t, int &) const { return t; }
-	__device__ __forceinline__ int TL(int h) const { return tlen[h]; }
-	__device__ __forceinline__ int &S(int h) const { return Score[h]; }
-	__device__ __forceinline__ int &E(int h) const { return extend[h]; }
-	__device__ __forceinline__ int8_t &I(int h) const { return include[h]; }
+	__device__ __forceinline__ int TL(int h) const { return ((const KMAHIP_GLOBAL int32_t *) tlen)[h]; }
+	__device__ __forceinline__ KMAHIP_GLOBAL int &S(int h) const { return ((KMAHIP_GLOBAL int *) Score)[h]; }
+	__device__ __forceinline__ KMAHIP_GLOBAL int &E(int h) const { return ((KMAHIP_GLOBAL int *) extend)[h]; }
+	__device__ __forceinline__ KMAHIP_GLOBAL int8_t &I(int h) const { return ((KMAHIP_GLOBAL int8_t *) include)[h]; }
 };
 #ifndef CHAIN_LDS_TS
 #define CHAIN_LDS_TS 16
@@ -71,7 +91,7 @@ struct LdsMap {
 			const int idx = (int) ((h + x) & (LDS_TS - 1)) * 64 + lane;
 			const uint32_t cur = id[idx];
 			if(cur == (uint32_t) t) return idx;
-			if(cur == LDS_EMPTY) { id[idx] = (uint32_t) t; sc[idx] = 0; ex[idx] = 0; inc[idx] = 0; tl[idx] = tlen[t]; return idx; }
+			if(cur == LDS_EMPTY) { id[idx] = (uint32_t) t; sc[idx] = 0; ex[idx] = 0; inc[idx] = 0; tl[idx] = ((const KMAHIP_GLOBAL int32_t *) tlen)[t]; return idx; }
 		}
 		status = 1;
 		return (int) (h & (LDS_TS - 1)) * 64 + lane;          // (any slot: the read is given up)
@@ -108,15 +128,18 @@ struct ChainArgs {
 	unsigned long long *counters;   // [0] records, [1] status, [2] templates
 };
 
-__device__ __forceinline__ int list_n(const DevDB &db, uint32_t v);
-__device__ __forceinline__ int list_at(const DevDB &db, uint32_t v, int i);
+// what the chaining reads of the database's description, by value in the lane (read through the lane's pointer to the kernel's argument
+// every field was a FLAT load of its own)
+struct DbLite { uint32_t values_u16, mlen; const uint16_t *values16; const uint32_t *values32; };
+template <class DB> __device__ __forceinline__ int list_n(const DB &db, uint32_t v);
+template <class DB> __device__ __forceinline__ int list_at(const DB &db, uint32_t v, int i);
 // length / i-th element (1-based) of an anchor's value list: from the head the anchor carries where it does (see
 // chain_anchor_kernel), else from the list itself
-template <class TM> __device__ __forceinline__ int ank_n(const DevDB &db, const CAnk &a) {
+template <class TM, class DB> __device__ __forceinline__ int ank_n(const DB &db, const CAnk &a) {
 	if(TM::cached_lists) return db.values_u16 ? (int) ((uint32_t) a.score_len & 0xFFFFu) : a.score_len;
 	return list_n(db, a.values);
 }
-template <class TM> __device__ __forceinline__ int ank_at(const DevDB &db, const CAnk &a, int i) {
+template <class TM, class DB> __device__ __forceinline__ int ank_at(const DB &db, const CAnk &a, int i) {
 	if(TM::cached_lists) {
 		if(db.values_u16) {
 			if(i == 1) return (int) ((uint32_t) a.score_len >> 16);
@@ -131,6 +154,7 @@ template <class TM>
 struct CLaneT {
 	typedef TM Map;
 	const DevDB *db;
+	DbLite dbl;
 	CAnk *VF, *VR;
 	TM tm;
 	int *bestT, *bestT_r;
@@ -158,12 +182,10 @@ __device__ __forceinline__ uint32_t db_probe(const DevDB &db, uint32_t key) {
 // db_probe in two halves, for a lane that wants several probes in flight: the first bucket of a key (one round trip), and what it says --
 // the k-mer's place, NOLIST, or PROBE_MORE (the bucket is full of other keys: the probe goes on in the next one, db_probe_from)
 constexpr uint32_t PROBE_MORE = 0xFFFFFFFEu;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct Bucket { u32x4 a, c; };
 // (the pointers of a DevDB that a lane reads out of its CLane are generic to the compiler: FLAT loads, which count on two counters at once
 // and are therefore waited for one by one -- eight buckets fetched "together" came back in eight round trips. As pointers into HBM
 // (address space 1) they are GLOBAL loads and overlap.)
-#define KMAHIP_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ Bucket db_bucket(const DevDB &db, uint32_t key) {
 	const uint32_t b = (key * 0x9E3779B1u) >> (32u - db.nb_log2);
 	const KMAHIP_GLOBAL u32x4 *p = (const KMAHIP_GLOBAL u32x4 *) (db.slots + (size_t) b * KMAHIP_BUCKET_SLOTS);
@@ -199,8 +221,8 @@ __device__ __forceinline__ uint32_t list_of(const DevDB &db, uint32_t key) {
 	const uint32_t gp = db_probe(db, key);
 	return gp == NOLIST ? NOLIST : db.vs_id[gp];
 }
-__device__ __forceinline__ int list_n(const DevDB &db, uint32_t v) { return db.values_u16 ? (int) db.values16[v] : (int) db.values32[v]; }
-__device__ __forceinline__ int list_at(const DevDB &db, uint32_t v, int i) { return db.values_u16 ? (int) db.values16[v + i] : (int) db.values32[v + i]; }
+template <class DB> __device__ __forceinline__ int list_n(const DB &db, uint32_t v) { return db.values_u16 ? (int) ((const KMAHIP_GLOBAL uint16_t *) db.values16)[v] : (int) ((const KMAHIP_GLOBAL uint32_t *) db.values32)[v]; }
+template <class DB> __device__ __forceinline__ int list_at(const DB &db, uint32_t v, int i) { return db.values_u16 ? (int) ((const KMAHIP_GLOBAL uint16_t *) db.values16)[v + i] : (int) ((const KMAHIP_GLOBAL uint32_t *) db.values32)[v + i]; }
 
 // k bases of the reverse-complemented read from position pos, zeros behind its end (the reference's buffer, freshly cleared)
 __device__ __forceinline__ uint32_t rc_kmer(const QView &qr, int pos, int k) {
@@ -214,8 +236,8 @@ __device__ __forceinline__ uint32_t rc_kmer(const QView &qr, int pos, int k) {
 // ---- segment tree (seqmenttree.c), recursion unrolled by depth -------------------------------------------------------------
 template <int D> struct SegOps {
 	template <class CLane> __device__ __noinline__ static unsigned add(CLane &L, int root, int node) {
-		CSeg *v = L.tree;
-		CSeg &R = v[root], &Nn = v[node];
+		GSeg *v = (GSeg *) L.tree;
+		GSeg &R = v[root], &Nn = v[node];
 		if(R.b0 >= 0) {
 			if(Nn.start < R.start && R.end < Nn.end) {
 				R.start = Nn.start; R.end = Nn.end; R.covered = Nn.covered; Nn.covered = 0; R.b0 = -1;
@@ -250,7 +272,7 @@ template <int D> struct SegOps {
 		return R.covered;
 	}
 	template <class CLane> __device__ __noinline__ static unsigned que(const CLane &L, int i, unsigned start, unsigned end) {
-		const CSeg &s = L.tree[i];
+		const GSeg &s = ((const GSeg *) L.tree)[i];
 		if(end < s.start || s.end < start) return 0;
 		if(start <= s.start && s.end <= end) return s.covered;
 		if(s.b0 >= 0) return SegOps<D - 1>::que(L, s.b0, start, end) + SegOps<D - 1>::que(L, s.b1, start, end);
@@ -268,7 +290,7 @@ constexpr int SEG_DEPTH = 24;
 
 template <class CLane> __device__ void seg_grow(CLane &L, unsigned start, unsigned end) {
 	if(L.s_cap <= L.tree_n + 2) { L.status = 1; return; }
-	CSeg *v = L.tree;
+	GSeg *v = (GSeg *) L.tree;
 	if(L.tree_n == 0) {
 		L.tree_n = 1;
 		v[0].start = start; v[0].end = end; v[0].covered = end - start; v[0].b0 = v[0].b1 = -1;
@@ -303,13 +325,13 @@ template <class CLane> __device__ __forceinline__ int bridge(const CLane &L, int
 
 // getBestChainTemplates: templates of the chain that ends in V[src] into bests[0 .. ]; the anchors it passes are silenced.
 // Returns the anchor the chain starts at, -1 none. `room`: slots bests may use.
-template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src, int *bests, int room) {
-	const DevDB &db = *L.db;
+template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src, GInt *bests, int room) {
+	const DbLite db = L.dbl;
 	if(src < 0) return -1;
 	int nextAnker = 0;
 	typedef typename CLane::Map Map;
 	{
-		const CAnk a = V[src];
+		const CAnk a = ank_load(&V[src]);
 		const int n = ank_n<Map>(db, a);
 		if(n + 1 > room) { L.status = 1; bests[0] = 0; return -1; }
 		bests[0] = n;
@@ -322,12 +344,12 @@ template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src
 	const int bestScore = V[src].score;
 	int prev = src;
 	// (the anchor in hand in registers, the one below it and the head of its list asked for ahead: see the chaining loop)
-	CAnk nxt = V[src];
+	CAnk nxt = ank_load(&V[src]);
 	int nxt_n = nextAnker ? ank_n<Map>(db, nxt) : 0;
 	for(int node = src; nextAnker && node >= 0; --node) {
 		const CAnk cur = nxt;
 		const int n = nxt_n;
-		if(node > 0) { nxt = V[node - 1]; nxt_n = ank_n<Map>(db, nxt); }
+		if(node > 0) { nxt = ank_load(&V[node - 1]); nxt_n = ank_n<Map>(db, nxt); }
 		const int start = (int) cur.start, end = (int) cur.end;
 		bool silenced = false;
 		for(int i = n; i >= 1; --i) {
@@ -365,7 +387,7 @@ template <class CLane> __device__ int chain_templates(CLane &L, CAnk *V, int src
 	return j ? prev : -1;
 }
 
-__device__ int prune(CAnk *V, int head, int k) {
+__device__ int prune(GAnk *V, int head, int k) {
 	while(head >= 0 && V[head].score < k) head = V[head].descend;
 	if(head < 0) return -1;
 	int prev = head;
@@ -374,7 +396,7 @@ __device__ int prune(CAnk *V, int head, int k) {
 	return head;
 }
 
-__device__ int best_anker(CAnk *V, int *head, unsigned *ties) {
+__device__ int best_anker(GAnk *V, int *head, unsigned *ties) {
 	*ties = 0;
 	int prev = *head;
 	while(prev >= 0 && V[prev].score == 0) prev = V[prev].descend;
@@ -393,7 +415,7 @@ __device__ int best_anker(CAnk *V, int *head, unsigned *ties) {
 	return best;
 }
 
-__device__ int tie_anker(const CAnk *V, int stop, int src, int best) {
+__device__ int tie_anker(const GAnk *V, int stop, int src, int best) {
 	if(src < 0 || (int) V[src].start <= stop) return -1;
 	while(src > 0 && stop < (int) V[--src].start) if(V[src].score == V[best].score) return src;
 	return -1;
@@ -435,7 +457,8 @@ static_assert(PB >= 1 && PB + 15 <= 32, "a block's k-mers come out of one 32-bas
 // (a function of its own, not inlined into the kernel: there its loop shared 254 registers and 2 kB of scratch per lane with the chaining
 // and the extraction, and kept its counters in scratch -- a round trip per position; the views and the database come in by value for the
 // same reason)
-template <class CLane> __attribute__((noinline)) __device__ int build_ankers(CLane &L, const QView qf, const QView qr, int exhaustive, int is_rc, CAnk *V) {
+template <class CLane> __attribute__((noinline)) __device__ int build_ankers(CLane &L, const QView qf, const QView qr, int exhaustive, int is_rc, CAnk *V_) {
+	GAnk *const V = (GAnk *) V_;
 	const DevDB &db = *L.db;
 	const int k = L.k, seqlen = qf.L, nN = qf.nN;
 	const int M_ = L.M, MM_ = L.MM, a_cap_ = L.a_cap;
@@ -596,7 +619,7 @@ struct Emit {
 
 // One S2 record. The lanes of a wavefront that emit at the same moment take their slots with ONE atomic per counter: two atomics
 // per record on two addresses, as first written, ran at 17 ns a record -- 35 of the 51 ms the kernel took for 2 M reads.
-template <class CLane> __device__ void emit_record(CLane &L, Emit &E, int rc_flag, int emit_rc, int q_start, int q_end, const int *bt) {
+template <class CLane> __device__ void emit_record(CLane &L, Emit &E, int rc_flag, int emit_rc, int q_start, int q_end, const GInt *bt) {
 	const ChainArgs &A = *E.A;
 	const int nT = bt[0];
 	const int lane = (int) (threadIdx.x & 63);
@@ -621,11 +644,12 @@ template <class CLane> __device__ void emit_record(CLane &L, Emit &E, int rc_fla
 	const unsigned long long slot = (((unsigned long long) hi0 << 32) | lo0) + (unsigned long long) __popcll(below);
 	const unsigned long long toff = (((unsigned long long) hi2 << 32) | lo2) + pre;
 	if((int64_t) slot >= A.rec_cap || (int64_t) (toff + nT) > A.T_cap) { atomicMax(&A.counters[1], 2ull); ++E.ordinal; return; }
-	int32_t *r = A.rec + 8 * slot;
+	KMAHIP_GLOBAL int32_t *r = (KMAHIP_GLOBAL int32_t *) A.rec + 8 * slot;
 	r[0] = (int32_t) (E.read & 0xFFFFFFFFll); r[1] = (int32_t) (E.read >> 32); r[2] = E.ordinal++; r[3] = rc_flag; r[4] = emit_rc;
 	r[5] = q_start; r[6] = q_end; r[7] = nT;
-	A.rec_T[slot] = (int64_t) toff;
-	for(int i = 0; i < nT; ++i) A.T[toff + i] = bt[1 + i];
+	((KMAHIP_GLOBAL int64_t *) A.rec_T)[slot] = (int64_t) toff;
+	KMAHIP_GLOBAL int32_t *To = (KMAHIP_GLOBAL int32_t *) A.T;
+	for(int i = 0; i < nT; ++i) To[toff + i] = bt[1 + i];
 }
 
 // the read's anchors are in L.VF / L.VR (hitF / hitR of them; V[0] holds start 0, end 0, descend -1 when a strand has none):
@@ -648,23 +672,23 @@ template <class CLane> __device__ void chain_read(CLane &L, const ChainArgs &A, 
 }
 
 template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs &A, int64_t r, int seqlen, unsigned hitF, unsigned hitR) {
-	const DevDB &db = *L.db;
+	const DbLite db = L.dbl;
 	const int k = L.k;
-	CAnk *VF = L.VF, *VR = L.VR;
-	int *bestT = L.bestT, *bestT_r = L.bestT_r;
+	GAnk *VF = (GAnk *) L.VF, *VR = (GAnk *) L.VR;
+	GInt *bestT = (GInt *) L.bestT, *bestT_r = (GInt *) L.bestT_r;
 	L.tree_n = 0;
 	Emit E = {&A, A.read_base + r, 0};
 
 	// chains left to right, per strand (savekmers.c:5466-5634)
-	CAnk *best = nullptr, *best_r = &VF[0];
+	GAnk *best = nullptr, *best_r = &VF[0];
 	unsigned ties = 0;
 	int a_min = 0x7fffffff, a_max = 0;          // every anchor of either strand lies inside [a_min, a_max)
 	VF[0].score = 0;
 	{
-		int *bests = bestT;
+		GInt *bests = bestT;
 		bestT[0] = 0; bestT_r[0] = 0;
 		for(int strand = 0; strand < 2; ++strand) {
-			CAnk *V = strand ? VR : VF;
+			GAnk *V = strand ? VR : VF;
 			unsigned HIT = (strand ? hitR : hitF) + 1;
 			if(strand) {
 				V[0].score = 0;          // (score_len / len_len of the anchor in hand live in registers below)
@@ -680,12 +704,12 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			// The next anchor and the head of its value list are asked for while this one is worked on.
 			int b_idx = 0, b_score = 0, b_sl = 0, n_bests = 0;
 			typedef typename CLane::Map Map;
-			CAnk nxt = V[0];
+			CAnk nxt = ank_load(&V[0]);
 			int nxt_n = HIT > 1 ? ank_n<Map>(db, nxt) : 0;
 			while(--HIT) {
 				const CAnk cur = nxt;
 				const int n = nxt_n;
-				if(HIT > 1) { nxt = V[vi + 1]; nxt_n = ank_n<Map>(db, nxt); }
+				if(HIT > 1) { nxt = ank_load(&V[vi + 1]); nxt_n = ank_n<Map>(db, nxt); }
 				const int start = (int) cur.start, end = (int) cur.end, weight = cur.weight;
 				a_min = start < a_min ? start : a_min; a_max = end > a_max ? end : a_max;
 				int a_score = 0, a_sl = 0, a_ll = 1;
@@ -761,7 +785,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 		s = chain_templates(L, VR, bri, bestT_r, L.b_cap);
 		if(s < 0) return;
 		cStart_r = (int) VR[s].start;
-		rc = choose_chain(VF[bi], VR[bri], cStart, cStart_r, A.coverT, &start, &len);
+		rc = choose_chain(ank_load(&VF[bi]), ank_load(&VR[bri]), cStart, cStart_r, A.coverT, &start, &len);
 	}
 	{
 		const int score = VF[bi].score > VR[bri].score ? VF[bi].score : VR[bri].score;
@@ -772,14 +796,14 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 		if(ties) {
 			for(int side = 0; side < 2; ++side) {
 				if(!(rc & (1 << side))) continue;
-				CAnk *V = side ? VR : VF;
-				int *bt = side ? bestT_r : bestT;
+				GAnk *V = side ? VR : VF;
+				GInt *bt = side ? bestT_r : bestT;
 				const int bidx = side ? bri : bi, vstart = side ? VR_start : VF_start;
 				int v = bidx;
 				while((v = tie_anker(V, start < vstart ? vstart : start, v, bidx)) >= 0) {
 					if((double) (unsigned) (V[v].end - (unsigned) start) < A.coverT * len) break;      // (unsigned arithmetic in the reference)
 					for(int i = 1; i <= bt[0]; ++i) { const int th = L.tm.slot(bt[i], L.status); L.tm.I(th) = 1; L.tm.S(th) = 0; L.tm.E(th) = 0; }
-					int *tail = bt + bt[0];
+					GInt *tail = bt + bt[0];
 					const int keep = *tail;
 					*tail = 0;
 					chain_templates(L, V, v, tail, L.b_cap - bt[0]);
@@ -820,8 +844,8 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			// The reference goes through every remaining anchor, walks its chain back and turns it down (savekmers.c:5860-5925);
 			// the usual read ends here.
 			if(A.stop_after == 4) return;
-			if(L.tree_n == 1 && (int) L.tree[0].start <= a_min) {
-				const int d = a_max - (int) L.tree[0].end;
+			if(L.tree_n == 1 && (int) ((const GSeg *) L.tree)[0].start <= a_min) {
+				const int d = a_max - (int) ((const GSeg *) L.tree)[0].end;
 				if(d <= 0 ? (A.coverT < 1.0 && A.minlen > 0) : (d < A.minlen && 1.0 - A.coverT > A.coverT * d + 1e-9)) break;
 			}
 		}
@@ -829,8 +853,8 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 		ties = 0;
 		rc = 0;
 		for(int side = 0; side < 2; ++side) {
-			CAnk *V = side ? VR : VF;
-			int *bt = side ? bestT_r : bestT;
+			GAnk *V = side ? VR : VF;
+			GInt *bt = side ? bestT_r : bestT;
 			int &bidx = side ? bri : bi, &head = side ? headR : headF, &cs = side ? cStart_r : cStart;
 			if(bidx < 0) continue;
 			bool ok = false;
@@ -864,7 +888,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			}
 		}
 		if(bi < 0 && bri < 0) break;
-		if(bi >= 0 && bri >= 0) rc = choose_chain(VF[bi], VR[bri], cStart, cStart_r, A.coverT, &start, &len);
+		if(bi >= 0 && bri >= 0) rc = choose_chain(ank_load(&VF[bi]), ank_load(&VR[bri]), cStart, cStart_r, A.coverT, &start, &len);
 		else if(bi >= 0) { rc = 1; start = cStart; len = (int) VF[bi].end - start; }
 		else { rc = 2; start = cStart_r; len = (int) VR[bri].end - start; }
 	}
@@ -883,6 +907,7 @@ __global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainA
 	const int64_t D = A.db.DB_size;
 	CLaneT<DenseMap> L;
 	L.db = &A.db;
+	L.dbl.values_u16 = A.db.values_u16; L.dbl.mlen = A.db.mlen; L.dbl.values16 = A.db.values16; L.dbl.values32 = A.db.values32;
 	L.VF = (CAnk *) base; base += (size_t) A.a_cap * sizeof(CAnk);
 	L.VR = (CAnk *) base; base += (size_t) A.a_cap * sizeof(CAnk);
 	L.tm.Score = (int *) base; base += (size_t) (D + 1) * 4;
@@ -939,6 +964,7 @@ __global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const 
 	uint8_t *base = A.scratch + lane * A.lane_bytes;
 	CLaneT<LdsMap> L;
 	L.db = &A.db;
+	L.dbl.values_u16 = A.db.values_u16; L.dbl.mlen = A.db.mlen; L.dbl.values16 = A.db.values16; L.dbl.values32 = A.db.values32;
 	CAnk *dummy = (CAnk *) base; base += 2 * sizeof(CAnk);
 	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
 	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
