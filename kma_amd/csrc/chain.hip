@@ -159,6 +159,7 @@ struct CLaneT {
 	TM tm;
 	int *bestT, *bestT_r;
 	CSeg *tree;
+	int *ovf;                    // a word of the lane's scratch: set by the tree code when it runs out of depth
 	int tree_n;
 	int k, M, MM, U, W1, Wl;
 	int a_cap, b_cap, s_cap;
@@ -235,8 +236,9 @@ __device__ __forceinline__ uint32_t rc_kmer(const QView &qr, int pos, int k) {
 
 // ---- segment tree (seqmenttree.c), recursion unrolled by depth -------------------------------------------------------------
 template <int D> struct SegOps {
-	template <class CLane> __device__ __noinline__ static unsigned add(CLane &L, int root, int node) {
-		GSeg *v = (GSeg *) L.tree;
+	// (the tree and the overflow word by pointer, not the lane: a lane whose address goes into a function that is not inlined lives in
+	// scratch as a whole -- every counter, every table pointer a memory access)
+	__device__ __noinline__ static unsigned add(GSeg *v, GInt *ovf, int root, int node) {
 		GSeg &R = v[root], &Nn = v[node];
 		if(R.b0 >= 0) {
 			if(Nn.start < R.start && R.end < Nn.end) {
@@ -245,17 +247,17 @@ template <int D> struct SegOps {
 			} else if(R.end < Nn.end) R.end = Nn.end;
 			else if(Nn.start < R.start) R.start = Nn.start;
 			unsigned pos = v[R.b1].start;
-			if(Nn.end < pos) R.covered = v[R.b1].covered + SegOps<D - 1>::add(L, R.b0, node);
-			else if(pos <= Nn.start) R.covered = v[R.b0].covered + SegOps<D - 1>::add(L, R.b1, node);
+			if(Nn.end < pos) R.covered = v[R.b1].covered + SegOps<D - 1>::add(v, ovf, R.b0, node);
+			else if(pos <= Nn.start) R.covered = v[R.b0].covered + SegOps<D - 1>::add(v, ovf, R.b1, node);
 			else {
 				pos = Nn.start;
 				Nn.start = v[R.b0].end + 1;
 				Nn.covered = Nn.end - Nn.start;
-				const unsigned covered = SegOps<D - 1>::add(L, R.b1, node);
+				const unsigned covered = SegOps<D - 1>::add(v, ovf, R.b1, node);
 				Nn.start = pos;
 				Nn.end = v[R.b0].end;
 				Nn.covered = Nn.end - Nn.start;
-				R.covered = covered + SegOps<D - 1>::add(L, R.b0, node);
+				R.covered = covered + SegOps<D - 1>::add(v, ovf, R.b0, node);
 			}
 		} else if(Nn.end < R.start || R.end < Nn.start) {
 			const int bud = node + 1;
@@ -271,11 +273,11 @@ template <int D> struct SegOps {
 		}
 		return R.covered;
 	}
-	template <class CLane> __device__ __noinline__ static unsigned que(const CLane &L, int i, unsigned start, unsigned end) {
-		const GSeg &s = ((const GSeg *) L.tree)[i];
+	__device__ __noinline__ static unsigned que(const GSeg *v, int i, unsigned start, unsigned end) {
+		const GSeg &s = v[i];
 		if(end < s.start || s.end < start) return 0;
 		if(start <= s.start && s.end <= end) return s.covered;
-		if(s.b0 >= 0) return SegOps<D - 1>::que(L, s.b0, start, end) + SegOps<D - 1>::que(L, s.b1, start, end);
+		if(s.b0 >= 0) return SegOps<D - 1>::que(v, s.b0, start, end) + SegOps<D - 1>::que(v, s.b1, start, end);
 		if(s.start <= start && end <= s.end) return end - start;
 		if(s.start <= start && start < s.end) return s.end - start;
 		if(s.start < end && end <= s.end) return end - s.start;
@@ -283,8 +285,8 @@ template <int D> struct SegOps {
 	}
 };
 template <> struct SegOps<0> {
-	template <class CLane> __device__ static unsigned add(CLane &L, int, int) { L.status = 1; return 0; }
-	template <class CLane> __device__ static unsigned que(const CLane &, int, unsigned, unsigned) { return 0; }
+	__device__ static unsigned add(GSeg *, GInt *ovf, int, int) { *ovf = 1; return 0; }          // (deeper than SEG_DEPTH: the read is given up)
+	__device__ static unsigned que(const GSeg *, int, unsigned, unsigned) { return 0; }
 };
 constexpr int SEG_DEPTH = 24;
 
@@ -298,7 +300,9 @@ template <class CLane> __device__ void seg_grow(CLane &L, unsigned start, unsign
 	}
 	const int node = L.tree_n;
 	v[node].start = start; v[node].end = end; v[node].covered = end - start; v[node].b0 = -1;
-	v[0].covered = SegOps<SEG_DEPTH>::add(L, 0, node);
+	GInt *ovf = (GInt *) L.ovf;
+	v[0].covered = SegOps<SEG_DEPTH>::add(v, ovf, 0, node);
+	if(*ovf) { L.status = 1; *ovf = 0; }
 	if(v[node].covered) L.tree_n += 2;
 }
 
@@ -862,7 +866,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 				const int s = chain_templates(L, V, bidx, bt, L.b_cap);
 				if(s >= 0) {
 					cs = (int) V[s].start;
-					const int cover = (int) SegOps<SEG_DEPTH>::que(L, 0, (unsigned) cs, V[bidx].end);
+					const int cover = (int) SegOps<SEG_DEPTH>::que((const GSeg *) L.tree, 0, (unsigned) cs, V[bidx].end);
 					const int l = (int) V[bidx].end - cs;
 					ok = A.minlen <= l && cover <= A.coverT * l && A.mrs * l <= V[bidx].score;
 				}
@@ -877,7 +881,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 						const int s = chain_templates(L, V, bidx, bt, L.b_cap);
 						if(s >= 0) {
 							cs = (int) V[s].start;
-							const int cover = (int) SegOps<SEG_DEPTH>::que(L, 0, (unsigned) cs, V[bidx].end);
+							const int cover = (int) SegOps<SEG_DEPTH>::que((const GSeg *) L.tree, 0, (unsigned) cs, V[bidx].end);
 							const int l = (int) V[bidx].end - cs;
 							good = A.minlen <= l && cover <= A.coverT * l && A.mrs * l <= V[bidx].score;
 						}
@@ -915,6 +919,8 @@ __global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainA
 	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
 	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
 	L.tree = (CSeg *) base; base += (size_t) A.s_cap * sizeof(CSeg);
+	L.ovf = (int *) (L.tree + (A.s_cap - 1));          // (the last node is never used: seg_grow stops two short of s_cap)
+	*(GInt *) L.ovf = 0;
 	L.tm.include = (int8_t *) base;
 	L.tm.tlen = A.db.tlen;
 	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
@@ -969,6 +975,8 @@ __global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const 
 	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
 	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
 	L.tree = (CSeg *) base;
+	L.ovf = (int *) (L.tree + (A.s_cap - 1));          // (the last node is never used: seg_grow stops two short of s_cap)
+	*(GInt *) L.ovf = 0;
 	L.tm.id = (KMAHIP_LDS uint32_t *) t_id; L.tm.sc = (KMAHIP_LDS int *) t_sc; L.tm.tl = (KMAHIP_LDS int *) t_tl; L.tm.ex = (KMAHIP_LDS uint16_t *) t_ex;
 	L.tm.inc = (KMAHIP_LDS int8_t *) t_inc; L.tm.tlen = A.db.tlen; L.tm.lane = (int) threadIdx.x;
 	L.tm.reset();
