@@ -27,6 +27,7 @@
 #include <string.h>
 #include <time.h>
 #include <pthread.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -212,9 +213,23 @@ static double need_num(int argc, char **argv, int *a, const char *what) {
 	return v;
 }
 
-/* `-gpus N`: N copies of this program, one per device, started before this process has touched a GPU; the exit status is the
- * first non-zero one of the copies. */
+/* a profiler or tool library preloaded into this process (rocprofv3 sets these) initialises the GPU before main() runs */
+static int tool_preloaded(void) {
+	const char *v[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"};
+	for(size_t i = 0; i < sizeof v / sizeof *v; ++i) { const char *e = getenv(v[i]); if(e && *e) return 1; }
+	return 0;
+}
+
+/* `-gpus N`: N copies of this program, one per device, started (fork + exec of this binary) BEFORE this process has touched a GPU;
+ * the exit status is the first non-zero one of the copies, and when a copy fails the others are ended (they would wait for it in
+ * the communicator until its timeout). Never behind a profiler: there the GPU is initialised before main(), and replacing a
+ * GPU-initialised process by exec is what must not happen -- profile one rank instead (tools/README.md). */
 static int launch_ranks(int gpus, char **argv) {
+	if(tool_preloaded()) {
+		fprintf(stderr, "kmahip_map: -gpus starts its ranks by fork + exec, which a process with a preloaded tool library (LD_PRELOAD / ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB: "
+		                "a profiler) must not do. Profile one rank directly: KMAHIP_RANK=r KMAHIP_WORLD=N KMAHIP_KEY=<key> <profiler> -- kmahip_map ... (without -gpus), the other ranks started the same way\n");
+		return 2;
+	}
 	char key[64], val[32];
 	snprintf(key, sizeof key, "%ld_%ld", (long) getpid(), (long) time(NULL));
 	setenv("KMAHIP_KEY", key, 1);
@@ -222,9 +237,10 @@ static int launch_ranks(int gpus, char **argv) {
 	setenv("KMAHIP_WORLD", val, 1);
 	pid_t *pid = calloc((size_t) gpus, sizeof *pid);
 	if(!pid) return 1;
+	int started = 0, status = 0;
 	for(int r = 0; r < gpus; ++r) {
 		pid[r] = fork();
-		if(pid[r] < 0) { perror("kmahip_map: fork"); return 1; }
+		if(pid[r] < 0) { perror("kmahip_map: fork"); status = 1; break; }
 		if(pid[r] == 0) {
 			snprintf(val, sizeof val, "%d", r);
 			setenv("KMAHIP_RANK", val, 1);
@@ -232,11 +248,18 @@ static int launch_ranks(int gpus, char **argv) {
 			perror("kmahip_map: exec");
 			_exit(127);
 		}
+		++started;
 	}
-	int status = 0;
-	for(int r = 0; r < gpus; ++r) {
+	for(int left = started; left > 0; --left) {
 		int st = 0;
-		if(waitpid(pid[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) { if(!status) status = WIFEXITED(st) && WEXITSTATUS(st) ? WEXITSTATUS(st) : 1; }
+		const pid_t w = status ? -1 : wait(&st);
+		if(status || w < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) {
+			if(!status) status = w >= 0 && WIFEXITED(st) && WEXITSTATUS(st) ? WEXITSTATUS(st) : 1;
+			for(int r = 0; r < started; ++r) if(pid[r] > 0 && pid[r] != w) kill(pid[r], SIGTERM);      /* (exactly the ranks started here) */
+			for(int r = 0; r < started; ++r) if(pid[r] > 0 && pid[r] != w) waitpid(pid[r], NULL, 0);
+			break;
+		}
+		for(int r = 0; r < started; ++r) if(pid[r] == w) pid[r] = 0;
 	}
 	free(pid);
 	return status;
@@ -324,11 +347,14 @@ int main(int argc, char **argv) {
 
 	/* ranks */
 	if(gpus > 1 && !getenv("KMAHIP_RANK")) return launch_ranks(gpus, argv);
-	/* The work is done by a child: when every output is closed it says so through a pipe and this process ends with its status;
-	 * the child then gives back what it holds (gigabytes of mapped input, host arrays, the device context: 0.2-0.3 s of kernel
-	 * work after a 10 M-read run) without anybody waiting for that. KMAHIP_MAP_NO_FORK=1: one process, as under a debugger. */
+	/* KMAHIP_MAP_EARLY_RETURN=1 (opt-in; never with a tool library preloaded, which has initialised the GPU already): the work is done
+	 * by a child; when every output is closed it says so through a pipe and this process ends with its status, while the child gives
+	 * back what it holds (gigabytes of mapped input, host arrays, the device context: 0.2-0.3 s of kernel work after a 10 M-read run)
+	 * with nobody waiting. A wall time taken that way leaves the teardown out -- the reference's includes its own -- so it is not
+	 * the default, and bench.py reports the one-process wall as the figure to compare. */
 	int done_fd = -1;
-	if(!getenv("KMAHIP_MAP_NO_FORK") && !getenv("KMAHIP_RANK") && !getenv("RANK")) {
+	const char *early = getenv("KMAHIP_MAP_EARLY_RETURN");
+	if(early && *early == '1' && !tool_preloaded() && !getenv("KMAHIP_MAP_NO_FORK") && !getenv("KMAHIP_RANK") && !getenv("RANK")) {
 		int pfd[2];
 		if(pipe(pfd) == 0) {
 			const pid_t child = fork();
@@ -356,8 +382,11 @@ int main(int argc, char **argv) {
 	}
 	if(getenv("KMAHIP_SHARE_GPU")) local = 0;
 
+	/* KMAHIP_COMM_FORCE_RCCL=1 on one rank: the sharded run over a real one-rank RCCL communicator (kmahip.h, kmahip_comm_describe) --
+	 * every exchange of the N-rank run goes through RCCL, on a box with a single device */
+	const int force_comm = world == 1 && getenv("KMAHIP_COMM_FORCE_RCCL") && getenv("KMAHIP_COMM_FORCE_RCCL")[0] == '1';
 	const double t_start = now_s(), t_before_main = since_process_start();
-	if(world == 1 && !input2 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
+	if(world == 1 && !force_comm && !input2 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
 		/* the single-end run (-1t1, the default mode or -Mt1), batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on
 		 * this one, the host holding one batch at a time. A batch: a million reads or a quarter of a gigabase, whichever comes first */
 		stream_job sj;
@@ -430,14 +459,14 @@ int main(int argc, char **argv) {
 	kmahip_db *db; kmahip_ws *ws; kmahip_db_info info;
 	if(kmahip_init(local) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
 	kmahip_comm *comm = NULL;
-	if(world > 1) {
+	if(world > 1 || force_comm) {
 		const char *backend = getenv("KMAHIP_COMM") ? getenv("KMAHIP_COMM") : "rccl";
 		if(kmahip_comm_init(rank, world, key ? key : "kmahip", backend, &comm)) die("communicator");
 	}
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
 	if(getenv("KMAHIP_MAP_STOP") && !strcmp(getenv("KMAHIP_MAP_STOP"), "open")) { fprintf(stderr, "# kmahip_map: stopped after open: %.3f s in main, entered %.2f s after process start\n", t_open - t_start, t_before_main); finish(0); }
-	if(world == 1) {	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
+	if(world == 1 && !force_comm) {	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
 		 * behind a shorter input the warm-up itself would be what the run waits for) */
 		struct stat sb;
 		const size_t il = strlen(input);
@@ -450,7 +479,7 @@ int main(int argc, char **argv) {
 	kmahip_read_batch b = job.b;
 	const double t_ingest = now_s();
 
-	if(world > 1) {
+	if(world > 1 || force_comm) {
 		/* an input the reader could not cut by bytes was delivered whole: this rank keeps its share of the records */
 		if(job.whole_input) {
 			const int64_t n_all = b.reads.n_reads;
@@ -479,6 +508,11 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "# kmahip_map rank %d of %d: %lld reads; wall: ingest %.2f s beside open %.2f, run %.2f | upload %.1f ms, stages 2+3a %.1f, exchanges 1+2 + ConClave %.1f, "
 		        "traceback %.1f, gather by owner %.1f, pile-up + consensus %.1f, writers %.1f, merge %.1f\n", rank, world, (long long) b.reads.n_reads, job.t_done - t_start,
 		        t_open - t_start, now_s() - t_ingest, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
+		{	/* what carried the exchanges, as the transport itself reports it (a SCALE line can be checked for "RCCL saw N ranks") */
+			char line[256];
+			kmahip_comm_describe(comm, line, sizeof line);
+			fprintf(stderr, "# kmahip_map rank %d comm: %s\n", rank, line);
+		}
 		finish(0);
 	}
 	const int64_t n = b.reads.n_reads;

@@ -556,6 +556,13 @@ void kmahip_comm_destroy(kmahip_comm *c);
 int kmahip_comm_rank(const kmahip_comm *c);
 int kmahip_comm_world(const kmahip_comm *c);
 int kmahip_comm_is_rccl(const kmahip_comm *c);
+/* One line about the communicator for a log or a JSON record: "backend=rccl rank=R world=W rccl_nranks=N rccl_rank=R
+ * rccl_version=V allreduces=A alltoallvs=B" -- nranks / rank / version as RCCL itself reports them (ncclCommCount,
+ * ncclCommUserRank, ncclGetVersion), A and B the exchanges that went through it so far --, or "backend=shm|none rank=R world=W".
+ * Returns what snprintf returns. With KMAHIP_COMM_FORCE_RCCL=1 a ONE-rank communicator of backend "rccl" is a real RCCL
+ * communicator too (kmahip_comm_init runs a SUM all-reduce and a grouped send / recv through it before it returns, as it does
+ * for every RCCL communicator): the transport can be exercised on a box with a single device. */
+int kmahip_comm_describe(const kmahip_comm *c, char *buf, size_t cap);
 int kmahip_comm_barrier(kmahip_comm *c);
 /* every rank posts `bytes` (at most 64 KiB) of HOST memory and gets all ranks' back in rank order */
 int kmahip_comm_allgather(kmahip_comm *c, const void *mine, size_t bytes, void *all);

@@ -2,6 +2,7 @@
 #include "kmahip_internal.h"
 #include <cstring>
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <vector>
 
 extern "C" int kmahip_ws_create(kmahip_db *db, kmahip_ws **out) {
@@ -253,7 +254,7 @@ extern "C" int kmahip_allreduce_scores(void *nccl_comm, uint64_t *alignment_scor
 		}
 		if(!fn) { kmahip_set_error("RCCL (librccl.so) not found"); return KMAHIP_EDEVICE; }
 	}
-	const int ncclUint64 = 5, ncclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+	// (ncclUint64, ncclSum: rccl.h at build time)
 	int rc = fn(alignment_scores, alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
 	if(!rc) rc = fn(uniq_alignment_scores, uniq_alignment_scores, DB_size, ncclUint64, ncclSum, nccl_comm, (hipStream_t) stream);
 	if(rc) { kmahip_set_error("ncclAllReduce failed with code %d", rc); return KMAHIP_EDEVICE; }
