@@ -213,11 +213,14 @@ static double need_num(int argc, char **argv, int *a, const char *what) {
 	return v;
 }
 
-/* a profiler or tool library preloaded into this process (rocprofv3 sets these) initialises the GPU before main() runs */
+/* a profiler's tool library loaded into this process (rocprofv3 sets ROCP_TOOL_LIBRARIES and preloads librocprofiler-sdk-tool; the
+ * older tools set HSA_TOOLS_LIB) initialises the GPU before main() runs. An LD_PRELOAD of anything else (an allocator, a sandbox's
+ * guard library) does not count. */
 static int tool_preloaded(void) {
-	const char *v[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"};
+	const char *v[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"};
 	for(size_t i = 0; i < sizeof v / sizeof *v; ++i) { const char *e = getenv(v[i]); if(e && *e) return 1; }
-	return 0;
+	const char *pre = getenv("LD_PRELOAD");
+	return pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "roctx")) ? 1 : 0;
 }
 
 /* `-gpus N`: N copies of this program, one per device, started (fork + exec of this binary) BEFORE this process has touched a GPU;
@@ -226,8 +229,8 @@ static int tool_preloaded(void) {
  * GPU-initialised process by exec is what must not happen -- profile one rank instead (tools/README.md). */
 static int launch_ranks(int gpus, char **argv) {
 	if(tool_preloaded()) {
-		fprintf(stderr, "kmahip_map: -gpus starts its ranks by fork + exec, which a process with a preloaded tool library (LD_PRELOAD / ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB: "
-		                "a profiler) must not do. Profile one rank directly: KMAHIP_RANK=r KMAHIP_WORLD=N KMAHIP_KEY=<key> <profiler> -- kmahip_map ... (without -gpus), the other ranks started the same way\n");
+		fprintf(stderr, "kmahip_map: -gpus starts its ranks by fork + exec, which a process with a profiler's tool library loaded (ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB / "
+		                "a rocprof library in LD_PRELOAD) must not do. Profile one rank directly: KMAHIP_RANK=r KMAHIP_WORLD=N KMAHIP_KEY=<key> <profiler> -- kmahip_map ... (without -gpus), the other ranks started the same way\n");
 		return 2;
 	}
 	char key[64], val[32];

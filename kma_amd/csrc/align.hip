@@ -81,6 +81,8 @@ struct AlignArgs {
 	int ablate;      // diagnostic builds only (KMAHIP_DIAG): 1 skip DP, 2 skip seeding, 4 skip chaining
 	int gap_m_max;   // Lane::gap_m_max
 	int long_min;    // > 0: the tasks of reads this long (strand known, no N's) are left to the long-read pipeline (long_routed)
+	int64_t *slow_list;      // tasks align_fast_kernel hands on (counters[2] of them); the general kernel run over a list takes its tasks from it
+	int use_list;            // align_tasks_kernel: the tasks are slow_list[0 .. counters[2]), handed out through counters[8]
 };
 
 constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
@@ -413,20 +415,15 @@ __device__ __forceinline__ bool nw_diagonal(const Lane &L, const uint64_t *ts, c
                                             int tspan, Aln &out) {
 	const int g = q_e - q_s;
 	if(L.gap_m_max < 0 || q.nN || t_e - t_s != tspan || g <= 0) return false;
-	int m;
-	if(k == 0) {
-		if(tspan != g) return false;
-		m = diag_mism(ts, q, t_s, q_s, g);
-		if(m > L.gap_m_max) return false;
-	} else if(k == -1) {
-		if(tspan <= g) return false;
-		m = diag_mism(ts, q, t_e - g, q_s, g);
-		if(m > 1 || (m == 1 && diag_mism(ts, q, t_e - 1 - g, q_s, g) == 0)) return false;
-	} else if(k == 1) {
-		if(tspan <= g) return false;
-		m = diag_mism(ts, q, t_s, q_s, g);
-		if(m > 1 || (m == 1 && diag_mism(ts, q, t_s + 1, q_s, g) == 0)) return false;
-	} else return false;
+	// the diagonal in question, the one next to it (tails: a gap of one in front of the seed side) and the mismatches allowed
+	int tp, tp2, lim;
+	if(k == 0) { if(tspan != g) return false; tp = t_s; tp2 = t_s; lim = L.gap_m_max; }
+	else if(k == -1) { if(tspan <= g) return false; tp = t_e - g; tp2 = t_e - 1 - g; lim = 1; }
+	else if(k == 1) { if(tspan <= g) return false; tp = t_s; tp2 = t_s + 1; lim = 1; }
+	else return false;
+	const int m = diag_mism(ts, q, tp, q_s, g);
+	if(m > lim) return false;
+	if(k != 0 && m == 1 && diag_mism(ts, q, tp2, q_s, g) == 0) return false;
 	out.score = (g - m) * L.M + m * L.MM; out.len = g; out.match = g; out.tGaps = 0; out.qGaps = 0; out.pos = 0;
 	return true;
 }
@@ -1185,6 +1182,58 @@ __global__ __launch_bounds__(256, 8) void seed_tasks_kernel(const AlignArgs A) {
 	}
 }
 
+// phase C of a task: the filters of alnFragsSE (alnfrags.c:1127-1168) / the per-record part of alnFragsPenaltyPE (:1630-1775) on the
+// sums of KMA_score, into the task columns the per-read reduction reads. Shared by the general and the register-only kernel.
+template <bool PEM>
+__device__ __forceinline__ void task_finish(const AlignArgs &A, int64_t task, int kind, const Aln &S0, const Aln &S1, int tmpl_out, int t_len,
+                                            int qlen0, int qlen1, int k) {
+	if(PEM && kind == 2) {
+		int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
+		for(int m = 0; m < 2; ++m) {
+			const Aln &st = m ? S1 : S0;
+			const int ql = m ? qlen1 : qlen0;
+			int sc = st.score, s0 = 0, e0 = 0;
+			double nrm = 0.0;
+			if(A.minlen <= st.len && 0 < sc && ((A.mrc * ql <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) {
+				s0 = st.pos; e0 = st.pos + st.len - st.tGaps;
+				if(s0 == 0) sc += A.Wl;
+				if(e0 == t_len) sc += A.Wl;
+				nrm = 1.0 * sc / st.len;
+			} else sc = 0;
+			const bool ok = sc > k && nrm >= A.scoreT;
+			if(m == 0) {
+				if(ok) { bt = sc; bs = s0; be = e0; }
+			} else {
+				if(ok) {
+					btr = sc;
+					if(bt) { if(s0 < bs) bs = s0; else be = e0; }
+					else { bs = s0; be = e0; }
+				}
+				raw_b = sc;
+			}
+		}
+		A.t_tmpl[task] = raw_b;      // couples: raw second-record score (joins the first in compScore, :1771)
+		A.t_score[task] = bt; A.t_alen[task] = btr; A.t_start[task] = bs; A.t_end[task] = be; A.t_norm[task] = 0.0;
+		return;
+	}
+	int rs = 0, alen = 0, start = 0, end = 0;
+	double norm = 0.0;
+	if(kind == 1) {
+		// alnFragsSE, alnfrags.c:1127-1168
+		const Aln &st = S0;
+		const int q_len = qlen0;
+		alen = st.len; start = st.pos;
+		end = start + alen - st.tGaps;
+		if(t_len < end) end -= t_len;
+		const double denom = (q_len <= alen || t_len <= alen) ? (double) alen : (double) min(q_len, t_len);
+		rs = st.score;
+		if(A.minlen <= alen && ((A.mrc * q_len <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) norm = rs / denom;
+		else { rs = 0; norm = 0.0; }
+	}
+	A.t_tmpl[task] = tmpl_out;
+	A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
+}
+
 // PEM: paired records (couples, mate / orientation tables); the single-end instantiation carries none of that code
 template <bool STATS, bool PEM>
 __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArgs A) {
@@ -1218,8 +1267,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	int *const queueX = queueT + (1 + QCAPT * QENT);
 	uint8_t *const tbuf = s_tbuf + wave * TBUF;
 	L.diag_uniform = (s_d[0] == s_d[6] && s_d[0] == s_d[12] && s_d[0] == s_d[18]);
-	const int64_t n_tasks = A.T_off[A.n_reads];
-	if(n_tasks > A.tasks_cap) return;
+	const int64_t n_all = A.T_off[A.n_reads];
+	if(n_all > A.tasks_cap) return;
+	// (run over a list: the tasks the register-only kernel handed on; its launch has ended, the count is final)
+	const int64_t n_tasks = A.use_list ? (int64_t) A.counters[2] : n_all;
+	unsigned long long *const hand_out = &A.counters[A.use_list ? 8 : 7];
 	const int k = (int) A.db.kmersize;
 	// the wave stays together: every round each lane does its own task up to the (deferred) wide DP problems,
 	// then all 64 lanes solve those, then each lane finishes its task
@@ -1227,11 +1279,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	// (a 100-column tail walked by one lane takes milliseconds) would still own its share of the remaining tasks.
 	for(;;) {
 		unsigned long long base = 0;
-		if(lane == 0) base = atomicAdd(&A.counters[7], 64ull);
+		if(lane == 0) base = atomicAdd(hand_out, 64ull);
 		base = __shfl(base, 0);
 		if((int64_t) base >= n_tasks) break;
-		const int64_t task = (int64_t) base + lane;
-		const bool have = task < n_tasks;
+		const bool have = (int64_t) base + lane < n_tasks;
+		const int64_t task = !A.use_list ? (int64_t) base + lane : (have ? A.slow_list[(int64_t) base + lane] : 0);
 		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; queueX[0] = 0; }
 		if(lane < 4) L.xq_cnt[lane] = 0;
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1378,51 +1430,286 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 #endif
 		// ---- phase C ---------------------------------------------------------------------------------
 		if(!have || kind == 3) continue;
-		if(PEM && kind == 2) {
-			int bt = 0, btr = 0, bs = -1, be = -1, raw_b = 0;
-			for(int m = 0; m < 2; ++m) {
-				const Aln &st = m ? S1 : S0;
-				const int ql = m ? qlen1 : qlen0;
-				int sc = st.score, s0 = 0, e0 = 0;
-				double nrm = 0.0;
-				if(A.minlen <= st.len && 0 < sc && ((A.mrc * ql <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) {
-					s0 = st.pos; e0 = st.pos + st.len - st.tGaps;
-					if(s0 == 0) sc += A.Wl;
-					if(e0 == t_len) sc += A.Wl;
-					nrm = 1.0 * sc / st.len;
-				} else sc = 0;
-				const bool ok = sc > k && nrm >= A.scoreT;
-				if(m == 0) {
-					if(ok) { bt = sc; bs = s0; be = e0; }
-				} else {
-					if(ok) {
-						btr = sc;
-						if(bt) { if(s0 < bs) bs = s0; else be = e0; }
-						else { bs = s0; be = e0; }
+		task_finish<PEM>(A, task, kind, S0, S1, tmpl_out, t_len, qlen0, qlen1, k);
+	}
+}
+
+// ---- the register-only kernel (round 4) ------------------------------------------------------------------------------------------
+// align_tasks_kernel above is general -- it seeds what seed_tasks_kernel left out, settles strand ties, walks DP problems of any size
+// in its lane -- and pays for that on every task: MEM arrays in HBM scratch (a dependent round trip per field), a lane struct and the
+// arguments of kma_score in private memory (1 136 B of scratch per lane, 128 VGPRs, 4 waves / SIMD; counter traffic 11x the
+// algorithmic bytes). But what nearly every task of a short-read sample needs is little: the <= SEEDS MEMs seed_tasks_kernel handed
+// over, chainSeeds over those few, and tails / links that are provably diagonal (nw_diagonal), one column wide, or small enough for the
+// wave's cooperative queues. align_fast_kernel does exactly that with the MEMs, the chain and the running sums in registers -- no
+// scratch, nothing of KMA_score in memory -- and hands every task that wants more (no MEMs from the seeding kernel, a strand tie, a DP
+// problem of 64 and more columns or a banded one, a full queue) to align_tasks_kernel through a list: that kernel then runs over the
+// list only. Same arithmetic, statement for statement, as kma_score / chain_seeds above (KMA_score align.c:509-748, chainSeeds
+// chain.c:79-260); tests/test_align_gpu.py runs both routes against the oracle (KMAHIP_ALIGN_FAST=0: the general kernel for all).
+template <class T>
+__device__ __forceinline__ T sel4(const T (&a)[SEEDS], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; }
+
+struct FastCtx {
+	const int *d;              // 25 ints in LDS
+	int M, MM, U, W1;
+};
+
+// nw_auto for the problems this kernel keeps: the degenerate ones (nw.c:662-684), the provably diagonal ones and those of one query
+// column; false: the task is handed on (its other problems meet in the general kernel's cooperative queues)
+__device__ __forceinline__ Aln nw_auto_fast(const FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
+                                            int t_s, int t_e, int q_s, int q_e, int tspan, int band, bool &ok) {
+	const int ql = q_e - q_s;
+	Aln r = {0, 0, 0, 0, 0, 0};
+	ok = true;
+	if(!(ql <= band || tspan <= band)) { ok = false; return r; }             // NW_band_score
+	if(ql == 0 || tspan == 0) return nw_degenerate(tspan, ql, C.U, C.W1);
+	if(nw_diagonal(L, ts, q, k, t_s, t_e, q_s, q_e, tspan, r)) return r;
+	if(ql == 1 && tspan < 998) return nw_col1(L, ts, t_len, q, k, t_s, t_e, q_s);
+	ok = false;
+	return r;
+}
+
+// KMA_score on n <= SEEDS preseeded MEMs (1-based template start, query start, length), everything in registers.
+// *punt: the task needs the general kernel.
+__device__ __forceinline__ Aln kma_score_fast(const FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int mq, int k,
+                                              int n, const uint2 (&mem)[SEEDS], bool *punt) {
+	const Aln FAIL = {0, 1, 0, 0, 0, 0};
+	const int q_len = q.L, bw = 64;
+	const int M = C.M, MM = C.MM, U = C.U, W1 = C.W1;
+	int tS[SEEDS], tE[SEEDS], qS[SEEDS], qE[SEEDS], wt[SEEDS], sc[SEEDS], nx[SEEDS];
+#pragma unroll
+	for(int x = 0; x < SEEDS; ++x) {
+		const int ln = (int) (mem[x].y >> 16);
+		tS[x] = (int) mem[x].x; tE[x] = tS[x] + ln; qS[x] = (int) (mem[x].y & 0xFFFFu); qE[x] = qS[x] + ln; wt[x] = ln; sc[x] = 0; nx[x] = 0;
+	}
+	// chainSeeds (chain.c:79-260) over MEMs n-1 .. 0, the loops unrolled so that every array index is a constant
+	int best = 0, second = 0, bestPos = n - 1;
+#pragma unroll
+	for(int i = SEEDS - 1; i >= 0; --i) {
+		if(i < n) {
+			const int wi = wt[i];
+			const int weight = wi * M, tEnd = tE[i], qEnd = qE[i];
+			int nxt = 0;
+			int span = min(t_len - tEnd, q_len - qEnd);
+			int gap = span - 1;
+			gap = gap ? gap * U + W1 : W1;
+			int sub = mism_score(span, k, M, MM);
+			int score = weight + (sub < gap ? gap : sub);
+#pragma unroll
+			for(int j = i + 1; j < SEEDS; ++j) {
+				if(j < n) {
+					const int qSj = qS[j], tSj = tS[j];
+					if(qEnd < qSj) {
+						if(tEnd < tSj) {
+							const int tGap = tSj - tEnd, qGap = qSj - qEnd;
+							int g = abs(tGap - qGap);
+							if(g) g = (g - 1) * U + W1;
+							g += weight + sc[j] + mism_score(min(tGap, qGap), k, M, MM);
+							if(score <= g) { score = g; nxt = j; }
+						} else if(k <= tE[j] - tEnd) {
+							int g = qSj - qEnd;
+							if(g) g = (g - 1) * U + W1;
+							g += weight + sc[j] - (tSj - tEnd) * M;
+							if(score < g) { score = g; nxt = j; }
+						}
+					} else if(k <= qE[j] - qEnd) {
+						const int tStart = tSj + qEnd - qSj;
+						if(tEnd < tStart) {
+							int g = tStart - tEnd;
+							if(g) g = (g - 1) * U + W1;
+							g += weight + sc[j] - (tStart - tEnd) * M;
+							if(score < g) { score = g; nxt = j; }
+						}
 					}
-					raw_b = sc;
 				}
 			}
-			A.t_tmpl[task] = raw_b;      // couples: raw second-record score (joins the first in compScore, :1771)
-			A.t_score[task] = bt; A.t_alen[task] = btr; A.t_start[task] = bs; A.t_end[task] = be; A.t_norm[task] = 0.0;
+			nx[i] = nxt;
+			wt[i] = nxt ? (wi + sel4(wt, nxt) - k + 1) : (wi - (k - 1));
+			sc[i] = score;
+			span = min(tS[i], qS[i]);
+			gap = span - 1;
+			if(0 < gap) gap = gap * U + W1; else if(gap == 0) gap = W1; else gap = 0;
+			sub = mism_score(span, k, M, MM);
+			score += sub < gap ? gap : sub;
+			if(best <= score) {
+				if(nxt != bestPos) second = best;
+				best = score; bestPos = i;
+			} else if(second <= score && nxt != bestPos) {
+				second = best;
+			}
+		}
+	}
+	unsigned mapQ = 0;
+	if(0 < best) {
+		const double wq = fmin(1.0, sel4(wt, bestPos) / 10.0);
+		mapQ = (unsigned) ceil(40 * (1 - 1.0 * second / best) * wq * log((double) best));
+	}
+	if(mapQ < (unsigned) mq || best < k) return FAIL;
+
+	// the chain from its best start: the MEM in hand in scalars (the reference's write-backs of a clipped start, align.c:694-711, are
+	// only ever read for the MEM in hand). One loop for the leading tail (leadTailAln, align.c:53-131), every MEM with the link behind
+	// it (:640-735) and the trailing tail (trailTailAln, :140-212), so that the DP dispatch exists once.
+	int start = bestPos;
+	int ctS = sel4(tS, start), ctE = sel4(tE, start), cqS = sel4(qS, start), cqE = sel4(qE, start);
+	Aln S = {0, 0, 0, 0, 0, 0};
+	S.pos = ctS - 1;
+	for(int stage = 0;; stage = 1) {
+		int kmode = 0, t_s = 0, t_e = 0, q_s = 0, q_e = 0, tspan = 0;
+		bool dp = false, last = false;
+		if(stage == 0) {
+			t_e = ctS - 1; q_e = cqS;
+			if(q_e) {
+				if((q_e << 1) < t_e || (q_e + bw) < t_e) t_s = t_e - (q_e + (q_e < bw ? q_e : bw));
+				else if((t_e << 1) < q_e || (t_e + bw) < q_e) q_s = q_e - (t_e + (t_e < bw ? t_e : bw));
+				if(t_e - t_s > 0 && q_e - q_s > 0) { dp = true; kmode = -1 - (t_s == 0); tspan = t_e - t_s; }
+			}
+		} else {
+			S.len += cqE - cqS; S.match += cqE - cqS;
+			S.score += (cqE - cqS) * C.d[0];              // (a MEM holds no N and the matrix is uniform on its diagonal: the host checks)
+			const int nxt = sel4(nx, start);
+			q_s = cqE; t_s = ctE - 1;
+			if(nxt) {
+				start = nxt;
+				int qSn = sel4(qS, start), tSn = sel4(tS, start);
+				const int tEn = sel4(tE, start);
+				if(qSn < q_s) { tSn += q_s - qSn; qSn = q_s; }
+				int t_l;
+				t_e = tSn - 1;
+				if(t_e < t_s) {
+					if(t_s <= tEn) { qSn += t_s - t_e; t_e = t_s; t_l = 0; }
+					else t_l = t_len - t_s + t_e;
+				} else t_l = t_e - t_s;
+				ctS = tSn; ctE = tEn; cqS = qSn; cqE = sel4(qE, start);
+				q_e = qSn;
+				if(abs(t_l - q_e + q_s) * U > q_len * M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+				if(t_l > 0 || q_e - q_s > 0) { dp = true; kmode = 0; tspan = t_l; }
+			} else {
+				last = true;
+				q_e = q_len; t_e = t_len;
+				if(((q_len - q_s) << 1) < (t_len - t_s) || (q_len - q_s + bw) < (t_len - t_s)) {
+					t_e = q_len - q_s; t_e = t_s + (t_e + (t_e < bw ? t_e : bw));
+				} else if(((t_len - t_s) << 1) < (q_len - q_s) || (t_len - t_s + bw) < (q_len - q_s)) {
+					q_e = t_len - t_s; q_e = q_s + (q_e + (q_e < bw ? q_e : bw));
+				}
+				if(t_e - t_s > 0 && q_e - q_s > 0) { dp = true; kmode = 1 + (t_e == t_len); tspan = t_e - t_s; }
+			}
+		}
+		if(dp) {
+			const int band = abs(tspan - q_e + q_s) + bw;
+			bool ok;
+			const Aln r = nw_auto_fast(C, L, ts, t_len, q, kmode, t_s, t_e, q_s, q_e, tspan, band, ok);
+			if(!ok) { *punt = true; return FAIL; }
+			if(stage == 0) S.pos -= r.len - r.tGaps;
+			S.score += r.score; S.len += r.len; S.match += r.match; S.tGaps += r.tGaps; S.qGaps += r.qGaps;
+		}
+		if(last) break;
+	}
+	return S;
+}
+
+constexpr int FTHREADS = 256;
+
+template <bool PEM>
+__global__ __launch_bounds__(FTHREADS) void align_fast_kernel(const AlignArgs A) {
+	__shared__ int s_d[25];
+	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
+	__syncthreads();
+	FastCtx C;
+	C.d = s_d; C.M = A.M; C.MM = A.MM; C.U = A.U; C.W1 = A.W1;
+	// (what the shared helpers -- nw_diagonal, nw_col1 -- read of a Lane; both are inlined here, the struct never exists in memory)
+	Lane L;
+	L.s32 = nullptr; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = 0; L.cap1 = 0; L.ncols = 0;
+	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0;
+	L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0; L.gap_m_max = A.gap_m_max; L.diag_uniform = 1; L.cnt = nullptr;
+	const int64_t n_tasks = A.T_off[A.n_reads];
+	if(n_tasks > A.tasks_cap) return;
+	const int k = (int) A.db.kmersize;
+	const int slots = PEM ? 2 : 1;
+	const int64_t stride = (int64_t) gridDim.x * FTHREADS;
+	for(int64_t task = (int64_t) blockIdx.x * FTHREADS + threadIdx.x; task < n_tasks; task += stride) {
+		int kind = 0;                  // 0 nothing, 1 single record, 2 couple, 3 left to the long-read pipeline
+		bool punt = false;
+		Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
+		int t_len = 0, qlen0 = 0, qlen1 = 0;
+		const int64_t r = A.t_rec[task];
+		const int tmpl_out = A.T[task];
+		const int at = abs(tmpl_out);
+		const int rcf = A.rc_flag[r];
+		bool couple = false;
+		int64_t rd = r;
+		int orient;
+		if(PEM) {
+			const int64_t p0 = r & ~1ll;
+			const int mate_r = A.rec_mate[r];
+			rd = p0 + max(0, mate_r);
+			orient = A.rec_rc[r];
+			couple = (r & 1) && A.rec_mate[p0] >= 0 && mate_r >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
+			if(!couple && !(rcf != 0 && mate_r >= 0)) rd = -1;
+		} else {
+			orient = (A.flag[r] & 16) ? 1 : 0;
+			if(long_routed(A, r)) { kind = 3; rd = -1; }
+			else if(rcf == 0) rd = -1;
+		}
+		if(rd >= 0 || couple) {
+			t_len = A.db.tlen[at];
+			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+			if(PEM && couple) {
+				// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate, both flipped once the
+				// list has reached its first negative id (:1633-1647)
+				kind = 2;
+				int rcstate = 0;
+				for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
+				for(int m = 0; m < 2 && !punt; ++m) {
+					const int64_t rec = (r & ~1ll) + m;
+					const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
+					QView q;
+					q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
+					q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
+					Aln st = {0, 1, 0, 0, 0, 0};
+					if(q.L >= k) {
+						const int pre = A.seed_n[task * 2 + m];
+						if(pre < 0) punt = true;
+						else if(pre > 0) {
+							const uint4 *mp = (const uint4 *) (A.seed_mem + (task * 2 + m) * SEEDS);
+							const uint4 m01 = mp[0], m23 = mp[1];
+							const uint2 mem[SEEDS] = {make_uint2(m01.x, m01.y), make_uint2(m01.z, m01.w), make_uint2(m23.x, m23.y), make_uint2(m23.z, m23.w)};
+							st = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
+						}
+					}
+					if(m == 0) { S0 = st; qlen0 = q.L; } else { S1 = st; qlen1 = q.L; }
+				}
+			} else if(A.len[rd] >= k) {
+				kind = 1;
+				if(rcf < 0) punt = true;          // strand tie: anker_rc_comp
+				else {
+					QView q;
+					q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
+					q_set_bounds(q, A.q_start, A.q_end, rd);
+					q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+					qlen0 = q.L;
+					const int pre = A.seed_n[task * slots];
+					if(pre < 0) punt = true;
+					else if(pre == 0) S0 = Aln{0, 1, 0, 0, 0, 0};
+					else {
+						const uint4 *mp = (const uint4 *) (A.seed_mem + task * slots * SEEDS);
+						const uint4 m01 = mp[0], m23 = mp[1];
+						const uint2 mem[SEEDS] = {make_uint2(m01.x, m01.y), make_uint2(m01.z, m01.w), make_uint2(m23.x, m23.y), make_uint2(m23.z, m23.w)};
+						S0 = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
+					}
+				}
+			}
+		}
+		if(kind == 3) continue;
+		if(punt) {
+			// one atomic per wavefront: the lanes that hand on in this turn are counted by ballot
+			const unsigned long long who = __ballot(1);
+			const int leader = __ffsll((long long) who) - 1, lane = (int) (threadIdx.x & 63);
+			unsigned long long first = 0;
+			if(lane == leader) first = atomicAdd(&A.counters[2], (unsigned long long) __popcll(who));
+			first = __shfl(first, leader);
+			A.slow_list[first + __popcll(who & ((1ull << lane) - 1ull))] = task;
 			continue;
 		}
-		int rs = 0, alen = 0, start = 0, end = 0;
-		double norm = 0.0;
-		if(kind == 1) {
-			// alnFragsSE, alnfrags.c:1127-1168
-			const Aln &st = S0;
-			const int q_len = qlen0;
-			alen = st.len; start = st.pos;
-			end = start + alen - st.tGaps;
-			if(t_len < end) end -= t_len;
-			const double denom = (q_len <= alen || t_len <= alen) ? (double) alen : (double) min(q_len, t_len);
-			rs = st.score;
-			if(A.minlen <= alen && ((A.mrc * q_len <= st.len - st.qGaps) || (A.mrc * t_len <= st.len - st.tGaps))) norm = rs / denom;
-			else { rs = 0; norm = 0.0; }
-		}
-		A.t_tmpl[task] = tmpl_out;
-		A.t_score[task] = rs; A.t_alen[task] = alen; A.t_start[task] = start; A.t_end[task] = end; A.t_norm[task] = norm;
+		task_finish<PEM>(A, task, kind, S0, S1, tmpl_out, t_len, qlen0, qlen1, k);
 	}
 }
 
@@ -2322,11 +2609,11 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (8 * 4 + 8 + 2 * SEEDS * 8) + 16));
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (2 * SEEDS * 8 + 8 + 8 + 8 * 4) + 16));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
-	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 6 * sizeof(unsigned long long), stream));
+	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 7 * sizeof(unsigned long long), stream));      // [2] .. [8]
 
 	AlignArgs A;
 	A.db = db->dev;
@@ -2336,12 +2623,15 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1;
 	for(int i = 0; i < 5; ++i) for(int j = 0; j < 5; ++j) A.d[i * 5 + j] = p->rw.d[i][j];
 	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
-	double *norm = (double *) ws->a_task;
-	int32_t *ti = (int32_t *) (norm + tasks_cap);
+	// per task: the MEMs of two seed slots first (32 bytes each: read as two 16-byte loads), the norm, the hand-on list, eight int columns
+	uint2 *seed_mem = (uint2 *) ws->a_task;
+	double *norm = (double *) (seed_mem + (size_t) 2 * SEEDS * tasks_cap);
+	A.slow_list = (int64_t *) (norm + tasks_cap); A.use_list = 0;
+	int32_t *ti = (int32_t *) (A.slow_list + tasks_cap);
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	int32_t *t_rec = ti + 5 * tasks_cap;
 	A.seed_slots = rec_mate ? 2 : 1;
-	A.seed_n = ti + 6 * tasks_cap; A.seed_mem = (uint2 *) (ti + 8 * tasks_cap);
+	A.seed_n = ti + 6 * tasks_cap; A.seed_mem = seed_mem;
 	A.t_rec = t_rec;
 	if(n >= 0x7FFFFFFF) { kmahip_set_error("too many records in one batch"); return KMAHIP_EINVAL; }
 	A.s32 = ws->a_s32; A.s64 = ws->a_s64; A.lanes = lanes; A.mem_cap = mem_cap; A.ncols = ncols;
@@ -2398,12 +2688,23 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 		HIP_TRY(hipEventRecord(ev0, stream));
 	}
 	const dim3 agrid((unsigned) (lanes / ATHREADS));
+	// the register-only kernel for the tasks seed_tasks_kernel has seeded, the general one over what it hands on (KMAHIP_ALIGN_FAST=0: the
+	// general kernel for every task); not for the work-counting launch, nor with a matrix whose diagonal is not uniform
+	bool fast = A.seed_n && !A.stats && A.d[0] == A.d[6] && A.d[0] == A.d[12] && A.d[0] == A.d[18];
+	if(const char *e = getenv("KMAHIP_ALIGN_FAST")) if(!atoi(e)) fast = false;
 	if(A.stats) {
 		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<true, true>), agrid, dim3(ATHREADS), 0, stream, A);
 		else hipLaunchKernelGGL((align_tasks_kernel<true, false>), agrid, dim3(ATHREADS), 0, stream, A);
 	} else {
+		if(fast) {
+			const dim3 fgrid(256 * 8);
+			if(A.pe_mode) hipLaunchKernelGGL((align_fast_kernel<true>), fgrid, dim3(FTHREADS), 0, stream, A);
+			else hipLaunchKernelGGL((align_fast_kernel<false>), fgrid, dim3(FTHREADS), 0, stream, A);
+			A.use_list = 1;
+		}
 		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<false, true>), agrid, dim3(ATHREADS), 0, stream, A);
 		else hipLaunchKernelGGL((align_tasks_kernel<false, false>), agrid, dim3(ATHREADS), 0, stream, A);
+		A.use_list = 0;
 	}
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));

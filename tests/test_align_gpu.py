@@ -77,6 +77,33 @@ def test_align_vs_oracle_indels_and_ragged(tmp_path):
     _vs_oracle(prefix, formats.pack_ragged(reads))
 
 
+@pytest.mark.parametrize("route", ["general", "fast"])
+def test_both_stage3a_kernels_equal_the_oracle(tmp_path, monkeypatch, route):
+    """align_fast_kernel (MEMs, chain and sums in registers; hands the other tasks on) + align_tasks_kernel over what it hands on,
+    against align_tasks_kernel for every task (KMAHIP_ALIGN_FAST=0): the oracle and the reference taps must come out either way --
+    reads with 1-3 % substitutions (several MEMs per task), N's (seeded by the general kernel), indels (DP problems for the queues),
+    reads that hang over template ends, strand ties in an inverted repeat"""
+    monkeypatch.setenv("KMAHIP_ALIGN_FAST", "0" if route == "general" else "1")
+    names, seqs = synth.make_gene_db(n_families=30, variants=4, len_lo=300, len_hi=1200, seed=41)
+    rng = np.random.default_rng(8)
+    pal = seqs[3][:200]
+    seqs.append(np.concatenate([pal, rng.integers(0, 4, 40, dtype=np.uint8), (3 - pal)[::-1]]))      # an inverted repeat: strand ties
+    names.append("inverted")
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads = []
+    for sub, n_rate in ((0.01, 0.0), (0.03, 0.002), (0.002, 0.0)):
+        r, *_ = synth.make_reads(seqs, 2500, read_len=150, sub_rate=sub, random_frac=0.02, n_rate=n_rate, seed=int(sub * 1000) + 3)
+        reads += list(r)
+    cat = np.concatenate(seqs)
+    reads += synth.make_long_reads(cat, 400, read_len=180, sub=0.01, dele=0.01, ins=0.01, seed=12)      # across template ends, with indels
+    reads += [seqs[-1][a:a + 150].copy() for a in rng.integers(0, len(seqs[-1]) - 150, 60)]
+    _vs_oracle(prefix, formats.pack_ragged(reads))
+    golden = golden_util.load_se(tmp_path / "g")
+    (rc_flag, flag, T_off, T), h = _run(golden)
+    assert golden_util.check_align_against_frag_raw(golden["s1"], golden_util.load_frag_raw("se"), T_off, h) > 900
+
+
 def test_shard_invariance_and_determinism_large_batch(tmp_path):
     """Size-independent properties on a batch far larger than the oracle cases: the ConClave vectors of two
     read shards add up to the whole batch's, per-read results do not depend on batching, and a second run is

@@ -64,7 +64,7 @@ def test_one_rank_rccl_communicator_carries_the_allreduce_and_the_grouped_send_r
         assert L.kmahip_comm_alltoallv(c, src.data_ptr(), sb.ctypes.data, dst.data_ptr(), sb.ctypes.data, 1, None) == 0, L.kmahip_last_error()
         assert torch.equal(src[:nbytes], dst[:nbytes])
     d = _describe(L, c)
-    assert d["allreduces"] == "1" and d["alltoallvs"] == "3", d      # (the empty exchange is a group with nothing in it)
+    assert d["allreduces"] == "1" and d["alltoallvs"] == "4", d      # (the empty exchange: a group with nothing in it)
     L.kmahip_comm_destroy(c)
 
 
