@@ -83,6 +83,10 @@ struct AlignArgs {
 	int long_min;    // > 0: the tasks of reads this long (strand known, no N's) are left to the long-read pipeline (long_routed)
 	int64_t *slow_list;      // tasks align_fast_kernel hands on (counters[2] of them); the general kernel run over a list takes its tasks from it
 	int use_list;            // align_tasks_kernel: the tasks are slow_list[0 .. counters[2]), handed out through counters[8]
+	int *dq; int64_t dq_cap; // align_fast_kernel's DP problems: four class queues of dq_cap entries of QENT ints (counters[AC_DQ + class])
+	int32_t *pend;           // its tasks that wait for queued problems (counters[AC_PEND]) ...
+	int *part;               // ... and their sums so far, PART_INTS per TASK
+	int per_round;           // tasks a wavefront takes per round (64; fewer over the list, whose tasks all bring DP problems for the wave's queues)
 };
 
 constexpr int SEEDS = 4;        // MEMs per task the seeding kernel hands over (a 150 bp read has 1-3)
@@ -1279,10 +1283,10 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 	// (a 100-column tail walked by one lane takes milliseconds) would still own its share of the remaining tasks.
 	for(;;) {
 		unsigned long long base = 0;
-		if(lane == 0) base = atomicAdd(hand_out, 64ull);
+		if(lane == 0) base = atomicAdd(hand_out, (unsigned long long) A.per_round);
 		base = __shfl(base, 0);
 		if((int64_t) base >= n_tasks) break;
-		const bool have = (int64_t) base + lane < n_tasks;
+		const bool have = lane < A.per_round && (int64_t) base + lane < n_tasks;
 		const int64_t task = !A.use_list ? (int64_t) base + lane : (have ? A.slow_list[(int64_t) base + lane] : 0);
 		if(lane == 0) { queue[0] = 0; queueN[0] = 0; queueT[0] = 0; queueX[0] = 0; }
 		if(lane < 4) L.xq_cnt[lane] = 0;
@@ -1439,23 +1443,42 @@ __global__ __launch_bounds__(ATHREADS, 4) void align_tasks_kernel(const AlignArg
 // in its lane -- and pays for that on every task: MEM arrays in HBM scratch (a dependent round trip per field), a lane struct and the
 // arguments of kma_score in private memory (1 136 B of scratch per lane, 128 VGPRs, 4 waves / SIMD; counter traffic 11x the
 // algorithmic bytes). But what nearly every task of a short-read sample needs is little: the <= SEEDS MEMs seed_tasks_kernel handed
-// over, chainSeeds over those few, and tails / links that are provably diagonal (nw_diagonal), one column wide, or small enough for the
-// wave's cooperative queues. align_fast_kernel does exactly that with the MEMs, the chain and the running sums in registers -- no
-// scratch, nothing of KMA_score in memory -- and hands every task that wants more (no MEMs from the seeding kernel, a strand tie, a DP
-// problem of 64 and more columns or a banded one, a full queue) to align_tasks_kernel through a list: that kernel then runs over the
-// list only. Same arithmetic, statement for statement, as kma_score / chain_seeds above (KMA_score align.c:509-748, chainSeeds
-// chain.c:79-260); tests/test_align_gpu.py runs both routes against the oracle (KMAHIP_ALIGN_FAST=0: the general kernel for all).
+// over, chainSeeds over those few, and tails / links that are provably diagonal (nw_diagonal) or one column wide. Stage 3a is
+// therefore four launches:
+//   align_fast_kernel    a lane per task, the MEMs, the chain and the running sums in registers -- no scratch, nothing of KMA_score
+//                        in memory. A DP problem of 2..63 columns is not solved here: its descriptor goes to a DEVICE-WIDE queue
+//                        of its width class (results are only ever summed into the task's figures, so the walk goes on), the task's
+//                        sums so far to a row of `part`, the task to the pending list. Queue entries, pending and handed-on tasks
+//                        are staged per wavefront in LDS and appended with one global atomic per list and flush (a lane's own
+//                        atomic per entry on one address would cost more than the kernel).
+//   dp_queue_kernel<W>   per width class, the cooperative anti-diagonal sweep nw_coop<W> over the whole queue -- dense: every
+//                        segment of every wavefront has a problem -- adding each result into its task's row of `part`.
+//   pend_finish_kernel   the filters of phase C for the pending tasks, from their rows.
+//   align_tasks_kernel   the general kernel, over the list of tasks the first handed on: no MEMs from the seeding kernel (N-rich
+//                        or repeat-rich reads, > SEEDS MEMs), a strand tie, a problem of 64 and more columns or a banded one, a
+//                        chain that fails after queueing. It runs last and overwrites whatever the others left for such a task.
+// Same arithmetic, statement for statement, as kma_score / chain_seeds above (KMA_score align.c:509-748, chainSeeds chain.c:79-260);
+// tests/test_align_gpu.py runs both routes against the oracle (KMAHIP_ALIGN_FAST=0: the general kernel for every task).
+constexpr int AC_DQ = 16, AC_PEND = 20, DQ_CLASSES = 4;      // counters: entries of the class queues (wide 33..63 columns, narrow 9..16, tiny 2..8, mid 17..32), pending tasks
+constexpr int DQ_STAGE = 96, PEND_STAGE = 96, PUNT_STAGE = 64;      // per wavefront, in LDS
+constexpr int PART_INTS = 16;                    // a pending task's row: S0 (6), S1 (6), kind, qlen0, qlen1, -
+
 template <class T>
 __device__ __forceinline__ T sel4(const T (&a)[SEEDS], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; }
 
 struct FastCtx {
 	const int *d;              // 25 ints in LDS
 	int M, MM, U, W1;
+	int *st_cnt;               // this wave's staging counters in LDS: [0] queue entries, [1] pending tasks, [2] handed-on tasks
+	int *st_dq;                // DQ_STAGE entries of QENT ints
+	int task32, at, mate, rc;  // the KMA_score call being run, for the queue entries
+	int64_t rd;
+	int n_queued;              // entries this call has staged
 };
 
-// nw_auto for the problems this kernel keeps: the degenerate ones (nw.c:662-684), the provably diagonal ones and those of one query
-// column; false: the task is handed on (its other problems meet in the general kernel's cooperative queues)
-__device__ __forceinline__ Aln nw_auto_fast(const FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
+// nw_auto for a task of this kernel: the degenerate problems (nw.c:662-684), the provably diagonal ones and those of one query column
+// at once; 2..63 columns to the staging queue of the wave (the result is zero for now); ok = false: the task is handed on
+__device__ __forceinline__ Aln nw_auto_fast(FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int k,
                                             int t_s, int t_e, int q_s, int q_e, int tspan, int band, bool &ok) {
 	const int ql = q_e - q_s;
 	Aln r = {0, 0, 0, 0, 0, 0};
@@ -1464,17 +1487,31 @@ __device__ __forceinline__ Aln nw_auto_fast(const FastCtx &C, const Lane &L, con
 	if(ql == 0 || tspan == 0) return nw_degenerate(tspan, ql, C.U, C.W1);
 	if(nw_diagonal(L, ts, q, k, t_s, t_e, q_s, q_e, tspan, r)) return r;
 	if(ql == 1 && tspan < 998) return nw_col1(L, ts, t_len, q, k, t_s, t_e, q_s);
+	if(ql < WCOLS && tspan + ql < 1000) {
+		const bool tiny = ql <= 8 && tspan < TBUF / 8;
+		const bool narrow = !tiny && ql <= 16 && tspan < TBUF / 4;
+		const bool mid = !tiny && !narrow && ql <= 32 && tspan < TBUF / 2;
+		const int slot = atomicAdd(&C.st_cnt[0], 1);
+		if(slot < DQ_STAGE) {
+			int *e = C.st_dq + slot * QENT;
+			e[0] = C.task32; e[1] = C.mate | ((tiny ? 2 : narrow ? 1 : mid ? 3 : 0) << 1); e[2] = k; e[3] = t_s; e[4] = t_e; e[5] = q_s; e[6] = q_e;
+			e[7] = C.at; e[8] = (int) (C.rd & 0xFFFFFFFFll); e[9] = (int) (C.rd >> 32); e[10] = C.rc; e[11] = (k < 0) ? 1 : 0;
+			++C.n_queued;
+			return r;
+		}
+	}
 	ok = false;
 	return r;
 }
 
 // KMA_score on n <= SEEDS preseeded MEMs (1-based template start, query start, length), everything in registers.
 // *punt: the task needs the general kernel.
-__device__ __forceinline__ Aln kma_score_fast(const FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int mq, int k,
+__device__ __forceinline__ Aln kma_score_fast(FastCtx &C, const Lane &L, const uint64_t *ts, int t_len, const QView &q, int mq, int k,
                                               int n, const uint2 (&mem)[SEEDS], bool *punt) {
 	const Aln FAIL = {0, 1, 0, 0, 0, 0};
 	const int q_len = q.L, bw = 64;
 	const int M = C.M, MM = C.MM, U = C.U, W1 = C.W1;
+	C.n_queued = 0;
 	int tS[SEEDS], tE[SEEDS], qS[SEEDS], qE[SEEDS], wt[SEEDS], sc[SEEDS], nx[SEEDS];
 #pragma unroll
 	for(int x = 0; x < SEEDS; ++x) {
@@ -1580,7 +1617,11 @@ __device__ __forceinline__ Aln kma_score_fast(const FastCtx &C, const Lane &L, c
 				} else t_l = t_e - t_s;
 				ctS = tSn; ctE = tEn; cqS = qSn; cqE = sel4(qE, start);
 				q_e = qSn;
-				if(abs(t_l - q_e + q_s) * U > q_len * M || t_l > q_len || q_e - q_s > (q_len >> 1)) return FAIL;
+				if(abs(t_l - q_e + q_s) * U > q_len * M || t_l > q_len || q_e - q_s > (q_len >> 1)) {
+					// (align.c:715; the general kernel drops what such a call has queued: it takes the task)
+					if(C.n_queued) *punt = true;
+					return FAIL;
+				}
 				if(t_l > 0 || q_e - q_s > 0) { dp = true; kmode = 0; tspan = t_l; }
 			} else {
 				last = true;
@@ -1607,14 +1648,79 @@ __device__ __forceinline__ Aln kma_score_fast(const FastCtx &C, const Lane &L, c
 }
 
 constexpr int FTHREADS = 256;
+#ifndef KMAHIP_FAST_WAVES
+#define KMAHIP_FAST_WAVES 4
+#endif
+
+// the staged entries of a wavefront to the device-wide lists: one global atomic per list that has something. Called by all 64 lanes.
+__device__ void fast_flush(const AlignArgs &A, int *st_cnt, const int *st_dq, const int *st_pend, const int *st_punt) {
+	const int lane = (int) (threadIdx.x & 63);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const int nq = min(DQ_STAGE, st_cnt[0]), np = min(PEND_STAGE, st_cnt[1]), nu = min(PUNT_STAGE, st_cnt[2]);
+	for(int c0 = 0; c0 < nq; c0 += 64) {
+		const int i = c0 + lane;
+		const int cls = i < nq ? (st_dq[i * QENT + 1] >> 1) : -1;
+		for(int c = 0; c < DQ_CLASSES; ++c) {
+			const unsigned long long m = __ballot(cls == c);
+			if(!m) continue;
+			const int leader = __ffsll((long long) m) - 1;
+			unsigned long long first = 0;
+			if(lane == leader) first = atomicAdd(&A.counters[AC_DQ + c], (unsigned long long) __popcll(m));
+			first = __shfl(first, leader);
+			if(cls == c) {
+				const int64_t at = (int64_t) first + __popcll(m & ((1ull << lane) - 1ull));
+				if(at < A.dq_cap) {
+					int4 *dst = (int4 *) (A.dq + ((size_t) c * A.dq_cap + at) * QENT);
+					const int4 *src = (const int4 *) (st_dq + i * QENT);
+					dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+				} else {
+					// no room (the host sized the queues for the usual sample): the general kernel takes the task, and its row -- written
+					// by this wavefront before it staged the entry -- says so to pend_finish_kernel
+					A.slow_list[atomicAdd(&A.counters[2], 1ull)] = st_dq[i * QENT];
+					A.part[(int64_t) st_dq[i * QENT] * PART_INTS + 15] = 1;
+				}
+			}
+		}
+	}
+	for(int c0 = 0; c0 < np; c0 += 64) {
+		const int i = c0 + lane;
+		const unsigned long long m = __ballot(i < np);
+		unsigned long long first = 0;
+		if(lane == 0) first = atomicAdd(&A.counters[AC_PEND], (unsigned long long) __popcll(m));
+		first = __shfl(first, 0);
+		if(i < np) A.pend[first + lane] = st_pend[i];
+	}
+	for(int c0 = 0; c0 < nu; c0 += 64) {
+		const int i = c0 + lane;
+		const unsigned long long m = __ballot(i < nu);
+		unsigned long long first = 0;
+		if(lane == 0) first = atomicAdd(&A.counters[2], (unsigned long long) __popcll(m));
+		first = __shfl(first, 0);
+		if(i < nu) A.slow_list[first + lane] = st_punt[i];
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	if(lane < 3) st_cnt[lane] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
 
 template <bool PEM>
-__global__ __launch_bounds__(FTHREADS) void align_fast_kernel(const AlignArgs A) {
+__global__ __launch_bounds__(FTHREADS, KMAHIP_FAST_WAVES) void align_fast_kernel(const AlignArgs A) {
 	__shared__ int s_d[25];
+	__shared__ int s_cnt[(FTHREADS / 64) * 4];
+	__shared__ __attribute__((aligned(16))) int s_dq[(FTHREADS / 64) * DQ_STAGE * QENT];
+	__shared__ int s_pend[(FTHREADS / 64) * PEND_STAGE];
+	__shared__ int s_punt[(FTHREADS / 64) * PUNT_STAGE];
 	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
+	if(threadIdx.x < (FTHREADS / 64) * 4) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
+	const int wave = (int) (threadIdx.x >> 6), lane = (int) (threadIdx.x & 63);
+	int *const st_cnt = s_cnt + wave * 4, *const st_dq = s_dq + wave * DQ_STAGE * QENT, *const st_pend = s_pend + wave * PEND_STAGE, *const st_punt = s_punt + wave * PUNT_STAGE;
 	FastCtx C;
-	C.d = s_d; C.M = A.M; C.MM = A.MM; C.U = A.U; C.W1 = A.W1;
+	C.d = s_d; C.M = A.M; C.MM = A.MM; C.U = A.U; C.W1 = A.W1; C.st_cnt = st_cnt; C.st_dq = st_dq;
+	C.task32 = 0; C.at = 0; C.mate = 0; C.rc = 0; C.rd = 0; C.n_queued = 0;
 	// (what the shared helpers -- nw_diagonal, nw_col1 -- read of a Lane; both are inlined here, the struct never exists in memory)
 	Lane L;
 	L.s32 = nullptr; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = 0; L.cap1 = 0; L.ncols = 0;
@@ -1625,91 +1731,156 @@ __global__ __launch_bounds__(FTHREADS) void align_fast_kernel(const AlignArgs A)
 	const int k = (int) A.db.kmersize;
 	const int slots = PEM ? 2 : 1;
 	const int64_t stride = (int64_t) gridDim.x * FTHREADS;
-	for(int64_t task = (int64_t) blockIdx.x * FTHREADS + threadIdx.x; task < n_tasks; task += stride) {
-		int kind = 0;                  // 0 nothing, 1 single record, 2 couple, 3 left to the long-read pipeline
-		bool punt = false;
-		Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
-		int t_len = 0, qlen0 = 0, qlen1 = 0;
-		const int64_t r = A.t_rec[task];
-		const int tmpl_out = A.T[task];
-		const int at = abs(tmpl_out);
-		const int rcf = A.rc_flag[r];
-		bool couple = false;
-		int64_t rd = r;
-		int orient;
-		if(PEM) {
-			const int64_t p0 = r & ~1ll;
-			const int mate_r = A.rec_mate[r];
-			rd = p0 + max(0, mate_r);
-			orient = A.rec_rc[r];
-			couple = (r & 1) && A.rec_mate[p0] >= 0 && mate_r >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
-			if(!couple && !(rcf != 0 && mate_r >= 0)) rd = -1;
-		} else {
-			orient = (A.flag[r] & 16) ? 1 : 0;
-			if(long_routed(A, r)) { kind = 3; rd = -1; }
-			else if(rcf == 0) rd = -1;
-		}
-		if(rd >= 0 || couple) {
-			t_len = A.db.tlen[at];
-			const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
-			if(PEM && couple) {
-				// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate, both flipped once the
-				// list has reached its first negative id (:1633-1647)
-				kind = 2;
-				int rcstate = 0;
-				for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
-				for(int m = 0; m < 2 && !punt; ++m) {
-					const int64_t rec = (r & ~1ll) + m;
-					const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
-					QView q;
-					q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
-					q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
-					Aln st = {0, 1, 0, 0, 0, 0};
-					if(q.L >= k) {
-						const int pre = A.seed_n[task * 2 + m];
+	// (the trip count is the same for the lanes of a wavefront: the flush inside is a wave-wide step)
+	for(int64_t base = (int64_t) blockIdx.x * FTHREADS + (threadIdx.x & ~63u); base < n_tasks; base += stride) {
+		const int64_t task = base + lane;
+		if(task < n_tasks) {
+			int kind = 0;                  // 0 nothing, 1 single record, 2 couple, 3 left to the long-read pipeline
+			bool punt = false;
+			int queued = 0;
+			Aln S0 = {0, 0, 0, 0, 0, 0}, S1 = {0, 1, 0, 0, 0, 0};
+			int t_len = 0, qlen0 = 0, qlen1 = 0;
+			const int64_t r = A.t_rec[task];
+			const int tmpl_out = A.T[task];
+			const int at = abs(tmpl_out);
+			const int rcf = A.rc_flag[r];
+			bool couple = false;
+			int64_t rd = r;
+			int orient;
+			C.task32 = (int) task; C.at = at;
+			if(PEM) {
+				const int64_t p0 = r & ~1ll;
+				const int mate_r = A.rec_mate[r];
+				rd = p0 + max(0, mate_r);
+				orient = A.rec_rc[r];
+				couple = (r & 1) && A.rec_mate[p0] >= 0 && mate_r >= 0 && A.T_off[p0 + 1] == A.T_off[p0];
+				if(!couple && !(rcf != 0 && mate_r >= 0)) rd = -1;
+			} else {
+				orient = (A.flag[r] & 16) ? 1 : 0;
+				if(long_routed(A, r)) { kind = 3; rd = -1; }
+				else if(rcf == 0) rd = -1;
+			}
+			if(rd >= 0 || couple) {
+				t_len = A.db.tlen[at];
+				const uint64_t *ts = A.db.tseq + A.db.tseq_off[at];
+				if(PEM && couple) {
+					// alnFragsPenaltyPE, alnfrags.c:1630-1775: both records of the pair against this candidate, both flipped once the
+					// list has reached its first negative id (:1633-1647)
+					kind = 2;
+					int rcstate = 0;
+					for(int64_t j = A.T_off[r]; j <= task; ++j) if(A.T[j] < 0) { rcstate = 1; break; }
+					for(int m = 0; m < 2 && !punt; ++m) {
+						const int64_t rec = (r & ~1ll) + m;
+						const int64_t rdm = (r & ~1ll) + A.rec_mate[rec];
+						QView q;
+						q.w = A.seq + A.seq_off[rdm]; q.L = A.len[rdm]; q.rc = A.rec_rc[rec] ^ rcstate;
+						q.N = A.N + A.N_off[rdm]; q.nN = (int) (A.N_off[rdm + 1] - A.N_off[rdm]);
+						Aln st = {0, 1, 0, 0, 0, 0};
+						if(q.L >= k) {
+							const int pre = A.seed_n[task * 2 + m];
+							if(pre < 0) punt = true;
+							else if(pre > 0) {
+								const uint4 *mp = (const uint4 *) (A.seed_mem + (task * 2 + m) * SEEDS);
+								const uint4 m01 = mp[0], m23 = mp[1];
+								const uint2 mem[SEEDS] = {make_uint2(m01.x, m01.y), make_uint2(m01.z, m01.w), make_uint2(m23.x, m23.y), make_uint2(m23.z, m23.w)};
+								C.mate = m; C.rc = q.rc; C.rd = rdm;
+								st = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
+								queued += C.n_queued;
+							}
+						}
+						if(m == 0) { S0 = st; qlen0 = q.L; } else { S1 = st; qlen1 = q.L; }
+					}
+				} else if(A.len[rd] >= k) {
+					kind = 1;
+					if(rcf < 0) punt = true;          // strand tie: anker_rc_comp
+					else {
+						QView q;
+						q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
+						q_set_bounds(q, A.q_start, A.q_end, rd);
+						q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
+						qlen0 = q.L;
+						const int pre = A.seed_n[task * slots];
 						if(pre < 0) punt = true;
-						else if(pre > 0) {
-							const uint4 *mp = (const uint4 *) (A.seed_mem + (task * 2 + m) * SEEDS);
+						else if(pre == 0) S0 = Aln{0, 1, 0, 0, 0, 0};
+						else {
+							const uint4 *mp = (const uint4 *) (A.seed_mem + task * slots * SEEDS);
 							const uint4 m01 = mp[0], m23 = mp[1];
 							const uint2 mem[SEEDS] = {make_uint2(m01.x, m01.y), make_uint2(m01.z, m01.w), make_uint2(m23.x, m23.y), make_uint2(m23.z, m23.w)};
-							st = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
+							C.mate = 0; C.rc = q.rc; C.rd = rd;
+							S0 = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
+							queued = C.n_queued;
 						}
-					}
-					if(m == 0) { S0 = st; qlen0 = q.L; } else { S1 = st; qlen1 = q.L; }
-				}
-			} else if(A.len[rd] >= k) {
-				kind = 1;
-				if(rcf < 0) punt = true;          // strand tie: anker_rc_comp
-				else {
-					QView q;
-					q.w = A.seq + A.seq_off[rd]; q.L = A.len[rd]; q.rc = orient;
-					q_set_bounds(q, A.q_start, A.q_end, rd);
-					q.N = A.N + A.N_off[rd]; q.nN = (int) (A.N_off[rd + 1] - A.N_off[rd]);
-					qlen0 = q.L;
-					const int pre = A.seed_n[task * slots];
-					if(pre < 0) punt = true;
-					else if(pre == 0) S0 = Aln{0, 1, 0, 0, 0, 0};
-					else {
-						const uint4 *mp = (const uint4 *) (A.seed_mem + task * slots * SEEDS);
-						const uint4 m01 = mp[0], m23 = mp[1];
-						const uint2 mem[SEEDS] = {make_uint2(m01.x, m01.y), make_uint2(m01.z, m01.w), make_uint2(m23.x, m23.y), make_uint2(m23.z, m23.w)};
-						S0 = kma_score_fast(C, L, ts, t_len, q, A.mq, k, pre, mem, &punt);
 					}
 				}
 			}
+			if(kind != 3) {
+				if(punt) {
+					const int slot = atomicAdd(&st_cnt[2], 1);
+					if(slot < PUNT_STAGE) st_punt[slot] = (int) task;
+					else A.slow_list[atomicAdd(&A.counters[2], 1ull)] = task;
+				} else if(queued) {
+					// the sums so far; the queues' results are added to this row, pend_finish_kernel filters it
+					int4 *row = (int4 *) (A.part + task * PART_INTS);
+					row[0] = make_int4(S0.score, S0.len, S0.pos, S0.match);
+					row[1] = make_int4(S0.tGaps, S0.qGaps, S1.score, S1.len);
+					row[2] = make_int4(S1.pos, S1.match, S1.tGaps, S1.qGaps);
+					row[3] = make_int4(kind, qlen0, qlen1, 0);
+					const int slot = atomicAdd(&st_cnt[1], 1);
+					if(slot < PEND_STAGE) st_pend[slot] = (int) task;
+					else A.pend[atomicAdd(&A.counters[AC_PEND], 1ull)] = (int) task;
+				} else task_finish<PEM>(A, task, kind, S0, S1, tmpl_out, t_len, qlen0, qlen1, k);
+			}
 		}
-		if(kind == 3) continue;
-		if(punt) {
-			// one atomic per wavefront: the lanes that hand on in this turn are counted by ballot
-			const unsigned long long who = __ballot(1);
-			const int leader = __ffsll((long long) who) - 1, lane = (int) (threadIdx.x & 63);
-			unsigned long long first = 0;
-			if(lane == leader) first = atomicAdd(&A.counters[2], (unsigned long long) __popcll(who));
-			first = __shfl(first, leader);
-			A.slow_list[first + __popcll(who & ((1ull << lane) - 1ull))] = task;
-			continue;
+		// a round can stage 64 x 5 entries at most, usually one or two: flush when half full (a lane that finds no slot hands its task on)
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if(st_cnt[0] >= DQ_STAGE / 2 || st_cnt[1] >= PEND_STAGE / 2 || st_cnt[2] >= PUNT_STAGE / 2 || base + stride >= n_tasks) fast_flush(A, st_cnt, st_dq, st_pend, st_punt);
+	}
+}
+
+// the queue of one width class: nw_coop<W> over every entry, the result added to the task's row
+template <int W>
+__global__ __launch_bounds__(256) void dp_queue_kernel(const AlignArgs A, int cls) {
+	__shared__ int s_d[25];
+	__shared__ uint8_t s_tbuf[4 * TBUF];
+	if(threadIdx.x < 25) s_d[threadIdx.x] = A.d[threadIdx.x];
+	__syncthreads();
+	constexpr int G = 64 / W;
+	const int wave = (int) (threadIdx.x >> 6), lane = (int) (threadIdx.x & 63);
+	Lane L;
+	L.s32 = nullptr; L.s64 = nullptr; L.r32 = nullptr; L.r64 = nullptr; L.lanes = 0; L.cap1 = 0; L.ncols = 0;
+	L.d = s_d; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.wide = nullptr; L.queue = nullptr; L.xq = nullptr; L.xq_cnt = nullptr; L.xq_cap = 0;
+	L.q_at = 0; L.q_mate = 0; L.q_rd = 0; L.ablate = 0; L.gap_m_max = A.gap_m_max; L.diag_uniform = 1; L.cnt = nullptr;
+	const int count = (int) min((unsigned long long) A.dq_cap, A.counters[AC_DQ + cls]);
+	int *const qu = A.dq + (size_t) cls * A.dq_cap * QENT - 1;          // (nw_coop counts its entries from qu + 1)
+	uint8_t *const tbuf = s_tbuf + wave * TBUF;
+	const int n_waves = (int) gridDim.x * 4;
+	for(int first = ((int) blockIdx.x * 4 + wave) * G; first < count; first += n_waves * G) {
+		nw_coop<W>(L, A.db, A, qu, first, count, tbuf);
+		const int g = lane / W;
+		if((lane & (W - 1)) == 0 && first + g < count) {
+			const int *e = qu + 1 + (first + g) * QENT;
+			int *row = A.part + (int64_t) e[0] * PART_INTS + (e[1] & 1) * 6;
+			atomicAdd(&row[0], e[2]); atomicAdd(&row[1], e[3]); atomicAdd(&row[3], e[4]); atomicAdd(&row[4], e[5]); atomicAdd(&row[5], e[6]);
+			if(e[11] & 1) atomicAdd(&row[2], -(e[3] - e[5]));
 		}
-		task_finish<PEM>(A, task, kind, S0, S1, tmpl_out, t_len, qlen0, qlen1, k);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();          // (the staged template bases are the next problem's)
+	}
+}
+
+template <bool PEM>
+__global__ __launch_bounds__(256) void pend_finish_kernel(const AlignArgs A) {
+	const int64_t n = (int64_t) A.counters[AC_PEND];
+	const int k = (int) A.db.kmersize;
+	for(int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+		const int64_t task = A.pend[i];
+		const int4 *row = (const int4 *) (A.part + task * PART_INTS);
+		const int4 a = row[0], b = row[1], c = row[2], d = row[3];
+		if(d.w) continue;          // (handed on after all: a queue had no room)
+		const Aln S0 = {a.x, a.y, a.z, a.w, b.x, b.y}, S1 = {b.z, b.w, c.x, c.y, c.z, c.w};
+		const int tmpl_out = A.T[task];
+		task_finish<PEM>(A, task, d.x, S0, S1, tmpl_out, A.db.tlen[abs(tmpl_out)], d.y, d.z, k);
 	}
 }
 
@@ -2609,11 +2780,13 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	if(ws->a_task_cap < tasks_cap) {
 		(void) hipFree(ws->a_task);
 		ws->a_task = nullptr;
-		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (2 * SEEDS * 8 + 8 + 8 + 8 * 4) + 16));
+		// (per task: seeds 64 B, norm 8, hand-on list 8, eight int columns 32, pending list 4, row of sums 64, class queues 4 x 48 / 4)
+		HIP_TRY(hipMalloc((void **) &ws->a_task, (size_t) tasks_cap * (2 * SEEDS * 8 + 8 + 8 + 8 * 4 + 4 + PART_INTS * 4) + DQ_CLASSES * (size_t) (tasks_cap / 4 + 4096) * QENT * 4 + 64));
 		ws->a_task_cap = tasks_cap;
 	}
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, 7 * sizeof(unsigned long long), stream));      // [2] .. [8]
+	HIP_TRY(hipMemsetAsync(ws->counters + AC_DQ, 0, (DQ_CLASSES + 1) * sizeof(unsigned long long), stream));  // the class queues and the pending list
 
 	AlignArgs A;
 	A.db = db->dev;
@@ -2626,8 +2799,12 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	// per task: the MEMs of two seed slots first (32 bytes each: read as two 16-byte loads), the norm, the hand-on list, eight int columns
 	uint2 *seed_mem = (uint2 *) ws->a_task;
 	double *norm = (double *) (seed_mem + (size_t) 2 * SEEDS * tasks_cap);
-	A.slow_list = (int64_t *) (norm + tasks_cap); A.use_list = 0;
-	int32_t *ti = (int32_t *) (A.slow_list + tasks_cap);
+	A.slow_list = (int64_t *) (norm + tasks_cap); A.use_list = 0; A.per_round = 64;
+	A.part = (int *) (A.slow_list + tasks_cap);                         // (rows of 64 bytes, 16-byte aligned: everything before is)
+	A.dq_cap = std::min<int64_t>(tasks_cap / 4 + 4096, 1ll << 26);
+	A.dq = A.part + (size_t) PART_INTS * tasks_cap;
+	int32_t *ti = (int32_t *) (A.dq + DQ_CLASSES * (size_t) (tasks_cap / 4 + 4096) * QENT);
+	A.pend = ti + 8 * tasks_cap;
 	A.t_norm = norm; A.t_score = ti; A.t_alen = ti + tasks_cap; A.t_start = ti + 2 * tasks_cap; A.t_end = ti + 3 * tasks_cap; A.t_tmpl = ti + 4 * tasks_cap;
 	int32_t *t_rec = ti + 5 * tasks_cap;
 	A.seed_slots = rec_mate ? 2 : 1;
@@ -2690,21 +2867,57 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	const dim3 agrid((unsigned) (lanes / ATHREADS));
 	// the register-only kernel for the tasks seed_tasks_kernel has seeded, the general one over what it hands on (KMAHIP_ALIGN_FAST=0: the
 	// general kernel for every task); not for the work-counting launch, nor with a matrix whose diagonal is not uniform
-	bool fast = A.seed_n && !A.stats && A.d[0] == A.d[6] && A.d[0] == A.d[12] && A.d[0] == A.d[18];
+	bool fast = A.seed_n && !A.stats && A.d[0] == A.d[6] && A.d[0] == A.d[12] && A.d[0] == A.d[18] && tasks_cap < (1ll << 31);
 	if(const char *e = getenv("KMAHIP_ALIGN_FAST")) if(!atoi(e)) fast = false;
 	if(A.stats) {
 		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<true, true>), agrid, dim3(ATHREADS), 0, stream, A);
 		else hipLaunchKernelGGL((align_tasks_kernel<true, false>), agrid, dim3(ATHREADS), 0, stream, A);
 	} else {
+		hipStream_t gstream = stream;
 		if(fast) {
 			const dim3 fgrid(256 * 8);
 			if(A.pe_mode) hipLaunchKernelGGL((align_fast_kernel<true>), fgrid, dim3(FTHREADS), 0, stream, A);
 			else hipLaunchKernelGGL((align_fast_kernel<false>), fgrid, dim3(FTHREADS), 0, stream, A);
-			A.use_list = 1;
+			// the general kernel over the handed-on tasks (a few wavefronts, each a chain of dependent round trips) beside the class
+			// queues: neither reads what the other writes (a task is pending or handed on, never both: see fast_flush)
+			if(!ws->a_side && !getenv("KMAHIP_ALIGN_SERIAL")) {
+				HIP_TRY(hipStreamCreateWithFlags(&ws->a_side, hipStreamNonBlocking));
+				HIP_TRY(hipEventCreateWithFlags(&ws->a_ev[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ws->a_ev[1], hipEventDisableTiming));
+			}
+			if(ws->a_side && !getenv("KMAHIP_ALIGN_SERIAL")) {
+				HIP_TRY(hipEventRecord(ws->a_ev[0], stream));
+				HIP_TRY(hipStreamWaitEvent(ws->a_side, ws->a_ev[0], 0));
+				gstream = ws->a_side;
+			}
+			// the tasks handed on all bring work for the wave's queues; 64 of them in a round would overrun them (8 wide, 20 narrow, 32 tiny
+			// problems) and what does not fit is walked by single lanes: fewer tasks per round, all 64 lanes on their problems
+			A.use_list = 1; A.per_round = getenv("KMAHIP_ALIGN_ROUND") ? std::min(64, std::max(1, atoi(getenv("KMAHIP_ALIGN_ROUND")))) : 16;
 		}
-		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<false, true>), agrid, dim3(ATHREADS), 0, stream, A);
-		else hipLaunchKernelGGL((align_tasks_kernel<false, false>), agrid, dim3(ATHREADS), 0, stream, A);
-		A.use_list = 0;
+		if(A.pe_mode) hipLaunchKernelGGL((align_tasks_kernel<false, true>), agrid, dim3(ATHREADS), 0, gstream, A);
+		else hipLaunchKernelGGL((align_tasks_kernel<false, false>), agrid, dim3(ATHREADS), 0, gstream, A);
+		if(fast) {
+			const dim3 qgrid(1024);
+			hipLaunchKernelGGL((dp_queue_kernel<8>), qgrid, dim3(256), 0, stream, A, 2);
+			hipLaunchKernelGGL((dp_queue_kernel<16>), qgrid, dim3(256), 0, stream, A, 1);
+			hipLaunchKernelGGL((dp_queue_kernel<32>), qgrid, dim3(256), 0, stream, A, 3);
+			hipLaunchKernelGGL((dp_queue_kernel<64>), qgrid, dim3(256), 0, stream, A, 0);
+			if(A.pe_mode) hipLaunchKernelGGL((pend_finish_kernel<true>), dim3(512), dim3(256), 0, stream, A);
+			else hipLaunchKernelGGL((pend_finish_kernel<false>), dim3(512), dim3(256), 0, stream, A);
+			if(gstream != stream) {
+				HIP_TRY(hipEventRecord(ws->a_ev[1], gstream));
+				HIP_TRY(hipStreamWaitEvent(stream, ws->a_ev[1], 0));
+			}
+		}
+		if(fast && getenv("KMAHIP_DEBUG_TIMING")) {
+			unsigned long long c[7];
+			HIP_TRY(hipStreamSynchronize(stream));
+			HIP_TRY(hipMemcpy(c, ws->counters + 2, sizeof c, hipMemcpyDeviceToHost));
+			unsigned long long q[DQ_CLASSES + 1];
+			HIP_TRY(hipMemcpy(q, ws->counters + AC_DQ, sizeof q, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[kmahip] align: %llu tasks handed on to the general kernel (%d per wavefront round); %llu pending on queued problems: %llu wide, %llu mid, %llu narrow, %llu tiny (room for %lld each)\n",
+			        c[0], A.per_round, q[DQ_CLASSES], q[0], q[3], q[1], q[2], (long long) A.dq_cap);
+		}
+		A.use_list = 0; A.per_round = 64;
 	}
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));

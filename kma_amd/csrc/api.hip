@@ -26,6 +26,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 		delete ev;
 	}
 	(void) hipFree(ws->a_s32); (void) hipFree(ws->a_s64); (void) hipFree(ws->a_task); (void) hipFree(ws->a_priv); (void) hipFree(ws->a_xq);
+	if(ws->a_side) { (void) hipStreamDestroy(ws->a_side); (void) hipEventDestroy(ws->a_ev[0]); (void) hipEventDestroy(ws->a_ev[1]); }
 	(void) hipFree(ws->t_s32); (void) hipFree(ws->t_E); (void) hipFree(ws->t_queue);
 	(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_seg); (void) hipFree(ws->p_vals);
 	(void) hipFree(ws->p_nodes); (void) hipFree(ws->p_keys); (void) hipFree(ws->p_rank);

@@ -9,7 +9,7 @@
 
 #define KMAHIP_EMPTY_VI 0xFFFFFFFFu
 #define KMAHIP_BUCKET_SLOTS 4
-#define KMAHIP_N_COUNTERS 16
+#define KMAHIP_N_COUNTERS 24
 #define KMAHIP_KBITS_MUL 0x85EBCA6Bu      // device counter words per workspace
 
 // Probe table in HBM: open hashing over 32-byte buckets of 4 (key, position)
@@ -104,6 +104,8 @@ struct kmahip_ws {
 	int64_t a_task_cap;
 	int *a_xq;                    // spill queues of deferred DP problems (long reads), see align.hip
 	size_t a_xq_bytes;
+	hipStream_t a_side;           // the general kernel over the handed-on tasks runs here, beside the class queues (align.hip)
+	hipEvent_t a_ev[2];           // fork / join of that stream
 	void *a_priv;             // private copies of the ConClave vectors (reduce_reads_kernel)
 	int64_t a_priv_cap;
 	// trace stage (3c) scratch

@@ -78,7 +78,7 @@ def test_align_vs_oracle_indels_and_ragged(tmp_path):
 
 
 @pytest.mark.parametrize("route", ["general", "fast"])
-def test_both_stage3a_kernels_equal_the_oracle(tmp_path, monkeypatch, route):
+def test_both_stage3a_kernels_equal_the_oracle(tmp_path, monkeypatch, route, golden_se):
     """align_fast_kernel (MEMs, chain and sums in registers; hands the other tasks on) + align_tasks_kernel over what it hands on,
     against align_tasks_kernel for every task (KMAHIP_ALIGN_FAST=0): the oracle and the reference taps must come out either way --
     reads with 1-3 % substitutions (several MEMs per task), N's (seeded by the general kernel), indels (DP problems for the queues),
@@ -99,9 +99,8 @@ def test_both_stage3a_kernels_equal_the_oracle(tmp_path, monkeypatch, route):
     reads += synth.make_long_reads(cat, 400, read_len=180, sub=0.01, dele=0.01, ins=0.01, seed=12)      # across template ends, with indels
     reads += [seqs[-1][a:a + 150].copy() for a in rng.integers(0, len(seqs[-1]) - 150, 60)]
     _vs_oracle(prefix, formats.pack_ragged(reads))
-    golden = golden_util.load_se(tmp_path / "g")
-    (rc_flag, flag, T_off, T), h = _run(golden)
-    assert golden_util.check_align_against_frag_raw(golden["s1"], golden_util.load_frag_raw("se"), T_off, h) > 900
+    (rc_flag, flag, T_off, T), h = _run(golden_se)
+    assert golden_util.check_align_against_frag_raw(golden_se["s1"], golden_util.load_frag_raw("se"), T_off, h) > 900
 
 
 def test_shard_invariance_and_determinism_large_batch(tmp_path):
