@@ -35,13 +35,16 @@ namespace {
 
 constexpr int GROUP = 16;             // active items scored together
 constexpr int THREADS = 256;
+// (tools/scan_shape_sweep.sh, round 4, scan_se_kernel per 10 M reads: 256 threads / 7 waves per SIMD 8.74 ms, 64 / 7 8.40, 64 / 8 8.30,
+// 128 / 7 8.33, 128 / 8 8.11 -- a barrier waits for fewer wavefronts, and the smaller tables let eight waves live on a SIMD)
 #ifndef KMAHIP_STHREADS
-#define KMAHIP_STHREADS 256
+#define KMAHIP_STHREADS 128
 #endif
 #ifndef KMAHIP_SCAN_WAVES
-#define KMAHIP_SCAN_WAVES 7
+#define KMAHIP_SCAN_WAVES 8
 #endif
-constexpr int STHREADS = KMAHIP_STHREADS;   // threads of one scan workgroup: GROUP items x STHREADS / GROUP lanes
+constexpr int STHREADS = KMAHIP_STHREADS;   // threads of one scan workgroup: SG items x 16 lanes
+constexpr int SG = STHREADS / 16;           // strand items a scan workgroup scores together (16 at 256 threads; 4 = a workgroup of ONE wavefront, whose barriers cost nothing)
 constexpr int CHUNK = 136;            // k-mer start positions per pass
 constexpr int MW = 5;                 // hit-mask words per candidate (>= CHUNK / 32)
 constexpr int SW = 7;                 // staged u64 words per item and pass
@@ -50,12 +53,12 @@ constexpr int SW = 7;                 // staged u64 words per item and pass
 // database with ten variants per family puts twenty and more templates on half of the reads (one chance k-mer hit in
 // another family brings all its variants), and the wavefront-per-item overflow kernel is 30x slower per item
 constexpr int TS1 = 16, TS2 = 64;
-constexpr unsigned TIER2_GRID = 256 * 3;        // second tier: three workgroups per CU fit its LDS
+constexpr unsigned TIER2_GRID = 256 * 3 * (256 / STHREADS);        // second tier: three workgroups (of 256 threads) per CU fit its LDS
 __host__ __device__ constexpr int ilog2c(int x) { return x <= 1 ? 0 : 1 + ilog2c(x >> 1); }
 constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;
 constexpr int VSLOTS = 16;            // hashed value-list slots per item in LDS (distinct lists seen in one pass); a list
                                       // that finds all of them taken is expanded directly
-constexpr int QCAP = 1024;            // entries of a workgroup's queue of left-over k-mer starts (a fuller one is finished by a rescan)
+constexpr int QCAP = 64 * SG;         // entries of a workgroup's queue of left-over k-mer starts (a fuller one is finished by a rescan)
 constexpr int INL = 2;                // inline result slots per strand item (no allocation round trip for the usual 1-2 ties)
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFEu;
@@ -88,7 +91,13 @@ struct ScanArgs {
 	int64_t pool_tail0;  // pool[0 .. pool_tail0) = INL inline slots per strand item; longer lists are bump-allocated after it
 	int mode;            // 0: best templates per strand (save_kmers); 1: every candidate + score + hit count (get_kmers_for_pair)
 	int32_t *pool_sc;    // mode 1: scores parallel to pool
+	int64_t cat_bases;   // > 0: the prefilter files the template diagonal of its hit with every live strand item (bits 33.. of the
+	                     // list entry: position in `cat` minus strand position of the hit k-mer, + DIAG_BIAS; DIAG_NONE: none) and the
+	                     // scan's lanes try that diagonal before they probe
 };
+
+constexpr int64_t ITEM_MASK = (1ll << 33) - 1;          // a strand item: (read << 1) | strand, reads < 2^31
+constexpr int64_t DIAG_BIAS = 1ll << 20, DIAG_NONE = 0x7FFFFFFFll;      // (reads are at most 2^20 bases, `cat` below 2^30 when diagonals are filed)
 
 enum { C_POOL = 0, C_STATUS = 1, C_NOVER = 2, C_PROBES = 3, C_VALS = 4, C_ACTIVE = 5, C_HASH = 6, C_PPOOL = 7, C_NACT = 8, C_PREF = 9, C_NOVER2 = 10, N_COUNTERS = KMAHIP_N_COUNTERS };
 
@@ -229,7 +238,7 @@ __device__ __forceinline__ int template_slot(uint32_t t, int g, uint32_t *t_id, 
 	// rolled on purpose: unrolled, the 16 probes nest 16 exec masks (SGPR spills) and the body is inlined many times over
 #pragma unroll 1
 	for(int x = 0; x < TSLOTS; ++x) {
-		const int sidx = (int) ((h + x) & (TSLOTS - 1)) * GROUP + g;
+		const int sidx = (int) ((h + x) & (TSLOTS - 1)) * SG + g;
 		const uint32_t old = atomicCAS(&t_id[sidx], T_EMPTY, t);
 		if(old == T_EMPTY) {
 			if(atomicAdd(&t_cnt[g], 1) >= TMAX) return -1;
@@ -251,7 +260,7 @@ __device__ __forceinline__ void expand_list(const DevDB &db, uint32_t vi, int rs
 		for(int w = rs >> 5; w <= (re - 1) >> 5; ++w) {
 			const int lo = max(rs, w << 5) & 31, hi = min(re, (w + 1) << 5) - (w << 5);   // bits [lo, hi)
 			const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & (0xFFFFFFFFu << lo);
-			atomicOr(&t_mask[w * TSLOTS * GROUP + slot], m);
+			atomicOr(&t_mask[w * TSLOTS * SG + slot], m);
 		}
 	}
 }
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 		const int64_t item = (int64_t) blockIdx.x * PF_ITEMS + rd * PF_BLOCK + (tid / PF_PLANES);
 		const int64_t r = item >> 1;
 		bool hit = false;
+		int64_t diag = DIAG_NONE;          // template diagonal of the hit: its position in `cat` minus its strand position in the read
 		if(r < A.n_reads) {
 			const int L = A.len[r], strand = (int) (item & 1), npos = L - k + 1;
 			if(npos > 0) {
@@ -321,7 +331,8 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 							const uint32_t h = (kms[u] * KMAHIP_KBITS_MUL) >> db.kbits_shift;
 							if(!((wd[u] >> (h & 31)) & 1u)) continue;
 							++ntable;
-							if(probe(db, kms[u]) != MISS) first_hit = sb + u;
+							const uint32_t gp = probe(db, kms[u]);
+							if(gp != MISS) { first_hit = sb + u; diag = (int64_t) gp - (int64_t) (sb + u) * k; }
 						}
 						if(first_hit >= 0) break;
 					}
@@ -340,10 +351,10 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 							if(strand) km2 = revcomp_kmer(km2, k);
 							uint32_t r1, r2;
 							probe2(db, (uint32_t) km, (uint32_t) km2, r1, r2);
-							if(r1 != MISS) { hit = true; break; }
+							if(r1 != MISS) { hit = true; diag = (int64_t) r1 - j; break; }
 							++nprobe; ++ntable;
-							if(r2 != MISS) { hit = true; break; }
-						} else if(probe(db, (uint32_t) km) != MISS) { hit = true; break; }
+							if(r2 != MISS) { hit = true; diag = (int64_t) r2 - j2; break; }
+						} else { const uint32_t r1 = probe(db, (uint32_t) km); if(r1 != MISS) { hit = true; diag = (int64_t) r1 - j; break; } }
 					}
 				} else if(plane == 0) {
 					// rare: walk the N-free segments exactly like savekmers.c:2483-2495
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(THREADS) void scan_prefilter_kernel(const ScanArgs 
 		const unsigned long long bal = __ballot(hit);
 		const bool any = ((bal >> ((tid & 63) & ~(PF_PLANES - 1))) & ((1ull << PF_PLANES) - 1ull)) != 0ull;
 		if(plane == 0 && r < A.n_reads) {
-			if(any) s_list[atomicAdd(&s_n, 1u)] = item;
+			if(any) s_list[atomicAdd(&s_n, 1u)] = item | ((A.cat_bases > 0 && diag != DIAG_NONE ? diag + DIAG_BIAS : DIAG_NONE) << 33);
 			else { A.item_score[item] = 0; A.item_n[item] = 0; A.item_off[item] = 0; }
 		}
 	}
@@ -406,22 +417,23 @@ __device__ __forceinline__ int compact_threads(bool flag, int tid, int32_t *wcnt
 }
 
 template <bool STATS, int MODE, int TSLOTS>
-__global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP_SCAN_WAVES : 2) : 4) void scan_se_kernel(const ScanArgs A) {
-	__shared__ uint32_t v_id[VSLOTS * GROUP];              // value-list offset per slot (MISS = free)
-	__shared__ uint32_t v_mask[MW * VSLOTS * GROUP];       // positions of the pass whose k-mer carries that value list
+__global__ __launch_bounds__(STHREADS, TSLOTS == TS1 ? KMAHIP_SCAN_WAVES : (STHREADS == 256 ? 2 : 3)) void scan_se_kernel(const ScanArgs A) {
+	__shared__ uint32_t v_id[VSLOTS * SG];              // value-list offset per slot (MISS = free)
+	__shared__ uint32_t v_mask[MW * VSLOTS * SG];       // positions of the pass whose k-mer carries that value list
 	// forward words: if every read of the group fits in SW-1 words they are staged ONCE and serve all passes;
 	// otherwise (s_anylong) they are staged per pass
-	__shared__ uint64_t w_lds[GROUP * SW];
+	__shared__ uint64_t w_lds[SG * SW];
 	__shared__ int32_t s_anylong;
-	__shared__ uint32_t t_id[TSLOTS * GROUP];
-	__shared__ uint32_t t_mask[MW * TSLOTS * GROUP];
-	__shared__ int32_t t_score[TSLOTS * GROUP];
-	__shared__ int32_t t_last[TSLOTS * GROUP];
-	__shared__ int32_t t_first[TSLOTS * GROUP];
-	__shared__ int32_t t_cnt[GROUP], s_over[GROUP], s_hits[GROUP], s_best[GROUP], s_nb[GROUP];
-	__shared__ int64_t s_off[GROUP];
-	__shared__ int32_t s_len[GROUP], s_nN[GROUP];
-	__shared__ int64_t s_soff[GROUP], s_noff[GROUP], s_item[GROUP];
+	__shared__ uint32_t t_id[TSLOTS * SG];
+	__shared__ uint32_t t_mask[MW * TSLOTS * SG];
+	__shared__ int32_t t_score[TSLOTS * SG];
+	__shared__ int32_t t_last[TSLOTS * SG];
+	__shared__ int32_t t_first[TSLOTS * SG];
+	__shared__ int32_t t_cnt[SG], s_over[SG], s_hits[SG], s_best[SG], s_nb[SG];
+	__shared__ int64_t s_off[SG];
+	__shared__ int32_t s_len[SG], s_nN[SG];
+	__shared__ int64_t s_soff[SG], s_noff[SG], s_item[SG];
+	__shared__ int32_t s_diag[SG];  // the prefilter's diagonal (+ DIAG_BIAS), DIAG_NONE: none
 	__shared__ int32_t s_gmax;
 	__shared__ int32_t s_wcnt[STHREADS / 64];
 	__shared__ uint16_t s_list[STHREADS];
@@ -434,23 +446,26 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 	const int k = (int) db.kmersize;
 	const int64_t n_active = (int64_t) A.counters[A.in_count];
 	// first tier: one group of items per workgroup; second tier: a fixed grid that loops over the (usually few) groups
-	int64_t first = (int64_t) blockIdx.x * GROUP;
+	int64_t first = (int64_t) blockIdx.x * SG;
 	if(first >= n_active) return;
 	do {
-	const int ng = (int) min((int64_t) GROUP, n_active - first);
+	const int ng = (int) min((int64_t) SG, n_active - first);
 
-	if(tid < GROUP) {
+	if(tid < SG) {
 		int L = 0, nN = 0; int64_t so = 0, no = 0, it = 0;
+		int dg = (int) DIAG_NONE;
 		if(tid < ng) {
-			it = A.in_items[first + tid];
+			const int64_t raw = A.in_items[first + tid];
+			it = raw & ITEM_MASK;
+			if(A.cat_bases > 0 && (raw >> 33) != 0) dg = (int) (raw >> 33);          // (the overflow lists carry bare items)
 			const int64_t r = it >> 1;
 			L = A.len[r]; so = A.seq_off[r]; no = A.N_off[r]; nN = (int) (A.N_off[r + 1] - no);
 		}
-		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no; s_item[tid] = it;
+		s_len[tid] = L; s_nN[tid] = nN; s_soff[tid] = so; s_noff[tid] = no; s_item[tid] = it; s_diag[tid] = dg;
 		// the longest read of the group, among the 16 lanes that hold the items (one DPP row: no LDS round, no barrier of its own)
 		int mx = L;
 #pragma unroll
-		for(int d = 8; d; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 16));
+		for(int d = SG / 2; d; d >>= 1) mx = max(mx, __shfl_xor(mx, d, SG));
 		if(tid == 0) { s_gmax = mx - k + 1; s_anylong = mx > (SW - 1) * 32; s_qn = 0; }
 	}
 	if(tid < 3) s_stats[tid] = 0;
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 	// the words are staged in STRAND orientation (word w = strand bases 32w .. 32w+31: for the reverse strand the reverse
 	// complement of the forward words), so the passes below never reverse-complement a k-mer or a walk window
 	if(staged_once) {
-		for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
+		for(int idx = tid; idx < SG * SW; idx += STHREADS) {
 			const int g = idx / SW, w = idx - g * SW;
 			const int L = s_len[g];
 			uint64_t v = 0;
@@ -476,24 +491,24 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 	// ORs its position range into the bitmask of each template of the set, and every
 	// (item, template) then folds its own bitmask -- no serial walk over the positions.
 	{
-		for(int idx = tid; idx < TSLOTS * GROUP; idx += STHREADS) {
+		for(int idx = tid; idx < TSLOTS * SG; idx += STHREADS) {
 			t_id[idx] = T_EMPTY; t_score[idx] = INT_MIN;          // (t_last / t_first are only read behind a score)
 #pragma unroll
-			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+			for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * SG + idx] = 0;
 		}
-		for(int idx = tid; idx < VSLOTS * GROUP; idx += STHREADS) {
+		for(int idx = tid; idx < VSLOTS * SG; idx += STHREADS) {
 			v_id[idx] = MISS;
 #pragma unroll
-			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
+			for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * SG + idx] = 0;
 		}
-		if(tid < GROUP) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; s_best[tid] = 0; s_nb[tid] = 0; }
+		if(tid < SG) { t_cnt[tid] = 0; s_over[tid] = 0; s_hits[tid] = 0; s_best[tid] = 0; s_nb[tid] = 0; }
 		__syncthreads();
 
 		for(int c0 = 0; c0 < gmax; c0 += CHUNK) {
 			const bool more_passes = c0 + CHUNK < gmax;      // (every group starts from cleared tables)
 			// stage the forward words of this pass (only workgroups holding a read too long to be staged once)
 			if(!staged_once) {
-				for(int idx = tid; idx < GROUP * SW; idx += STHREADS) {
+				for(int idx = tid; idx < SG * SW; idx += STHREADS) {
 					const int g = idx / SW, w = idx - g * SW;
 					uint64_t v = 0;
 					if(g < ng) {
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				const uint32_t h = (vi * 0x9E3779B1u) >> 28;
 #pragma unroll 1
 				for(int x = 0; x < VSLOTS; ++x) {
-					const int sidx = (int) ((h + x) & (VSLOTS - 1)) * GROUP + g;
+					const int sidx = (int) ((h + x) & (VSLOTS - 1)) * SG + g;
 					const uint32_t old = atomicCAS(&v_id[sidx], MISS, vi);
 					if(old == MISS || old == vi) { slot = sidx; break; }
 				}
@@ -529,8 +544,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 					// a run inside one lane's segment is at most SEG (9) positions long: two mask words at most
 					const int w = rs >> 5;
 					const uint64_t m = ((1ull << (re - rs)) - 1ull) << (rs & 31);
-					atomicOr(&v_mask[w * VSLOTS * GROUP + slot], (uint32_t) m);
-					if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * GROUP + slot], (uint32_t) (m >> 32));
+					atomicOr(&v_mask[w * VSLOTS * SG + slot], (uint32_t) m);
+					if(m >> 32) atomicOr(&v_mask[(w + 1) * VSLOTS * SG + slot], (uint32_t) (m >> 32));
 				} else {
 					// more distinct lists in this pass than the v-table holds: expand this run directly
 					expand_list<TSLOTS>(db, vi, rs, re, g, t_id, t_cnt, t_mask, s_over);
@@ -561,9 +576,9 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 			};
 			int own_lo = 0, own_n = 0;          // k-mer starts this lane could not queue
 			{
-				constexpr int LPI = STHREADS / GROUP;                 // lanes per item
+				constexpr int LPI = STHREADS / SG;                 // lanes per item
 				constexpr int SEG = (CHUNK + LPI - 1) / LPI;         // positions per lane
-				const int g = tid & (GROUP - 1), sl = tid / GROUP;
+				const int g = tid & (SG - 1), sl = tid / SG;
 				const int j0 = sl * SEG, j1 = min(CHUNK, j0 + SEG);
 				// ONE anchor probe and walk per lane, straight-line. What a lane has left afterwards -- the k-mer starts behind a
 				// miss or behind a walk that a mismatch cut short -- goes into a workgroup-wide queue and is resolved below by all
@@ -578,26 +593,42 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 					int jj = j0, hc = 0;
 					const int p = c0 + jj;
 					const int q = strand ? (L - k - p) : p;       // forward coordinate of the window (the N list is forward)
-					bool hit = false;
 					if(!(nN && window_has_N(Nl, nN, q, k))) {
 						const int w = (p >> 5) - wb;
 						const uint64_t km = kmer_from(wsrc[w], wsrc[w + 1], p, k);
-						uint32_t gp;
+						const uint64_t qw = win2(wsrc, p - (wb << 5));          // the k-mer and the 32 - k bases behind it
+						// Where is this k-mer in `cat`? First on the diagonal of the prefilter's hit (a read that maps lies on ONE template
+						// diagonal: no gather into the probe table, and the 16 lanes of an item read neighbouring bytes of cat / vs_id), then
+						// by its hash probe. A position is right when the k bases there are the k-mer and a k-mer of the index starts there.
+						uint32_t gp = MISS;
+						int attempt = 1;
+						const int dg = s_diag[g];
+						if(dg != (int) DIAG_NONE) {
+							const int64_t at = (int64_t) dg - DIAG_BIAS + p;
+							if(at >= 0 && at < A.cat_bases) { gp = (uint32_t) at; attempt = 0; }
+						}
+						for(;;) {
+							if(attempt) {
 #ifdef KMAHIP_DIAG
-						if(A.ablate & 2) gp = MISS; else
+								if(A.ablate & 2) gp = MISS; else
 #endif
-						gp = probe(db, (uint32_t) km);
-						++nprobe; ++nres;
-						if(gp != MISS) {
-							hit = true;
+								gp = probe(db, (uint32_t) km);
+								++nprobe;
+								if(gp == MISS) break;
+							}
 							// everything the walk needs depends only on gp: issue it all at once (one latency, not one per step)
 							constexpr int WALK = SEG - 1;
+							static_assert(WALK + 16 <= 32, "one 32-base window holds the k-mer (k <= 16) and the walk behind it");
 							uint32_t vv[WALK + 1];
 							const uint32_t *vp = db.vs_id + gp;          // one address, immediate offsets: the loads merge
 #pragma unroll
 							for(int i = 0; i <= WALK; ++i) vv[i] = vp[i];
-							const uint64_t tw = win2(db.cat, (int64_t) gp + k);
-							const uint64_t qw = win2(wsrc, p + k - (wb << 5));
+							const uint64_t tw = win2(db.cat, (int64_t) gp);
+							const uint64_t x = qw ^ tw;
+							const int same = x ? (__clzll((long long) x) >> 1) : 32;
+							if(!attempt && !(same >= k && vv[0] != KMAHIP_EMPTY_VI)) {
+								attempt = 1; continue;          // not on that diagonal: probe
+							}
 							// walk: how many more k-mer starts of this segment continue the same template diagonal
 							int run = 0;
 							int room = min(j1 - jj - 1, npos - (p + 1));
@@ -611,9 +642,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 									if(lo > 0) room = min(room, fq - Nl[lo - 1]); }
 							}
 							if(room > 0) {
-								const uint64_t x = qw ^ tw;
-								const int same = x ? (__clzll((long long) x) >> 1) : 32;
-								run = min(room, same);
+								run = min(room, same - k);
 								// the template ends where vs_id holds no k-mer: nothing after it continues the diagonal
 #pragma unroll
 								for(int i = 1; i <= WALK; ++i) if(i <= run && vv[i] == KMAHIP_EMPTY_VI) run = i - 1;
@@ -637,9 +666,10 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 								add_run(g, vi, jj + i0, jj + i1);            // positions [rs, re) of the pass
 							}
 							jj += run;
+							break;
 						}
+						++nres;
 					}
-					(void) hit;
 					++jj;
 					// what is left of the segment: into the queue; when the queue is full (every read of the group riddled with
 					// mismatches) the lane keeps it and resolves it itself behind the queue round
@@ -664,7 +694,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				for(int it = 0; it < q_iters + own_n; ++it) {
 					uint32_t v = 0xFFFFu;
 					if(it < q_iters) { const uint32_t e = (uint32_t) it * STHREADS + tid; if(e < qn) v = s_q[e]; }
-					else v = (uint32_t) (((tid & (GROUP - 1)) << 8) | (own_lo + it - q_iters));
+					else v = (uint32_t) (((tid & (SG - 1)) << 8) | (own_lo + it - q_iters));
 					if(v != 0xFFFFu) resolve((int) (v >> 8), (int) (v & 255u));
 				}
 			}
@@ -673,20 +703,20 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 			if(tid == 0) s_qn = 0;          // (for the next pass / the next group: barriers lie in between)
 			// phase 2a: one thread per (item, distinct value list): read the list ONCE (all gathers of the workgroup in
 			// flight together) and OR the list's position mask into the hit mask of each listed template
-			static_assert((VSLOTS * GROUP) % STHREADS == 0 && (TSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
-			for(int part = 0; part < VSLOTS * GROUP; part += STHREADS) {
+			static_assert((VSLOTS * SG) % STHREADS == 0 && (TSLOTS * SG) % STHREADS == 0, "table slots per thread");
+			for(int part = 0; part < VSLOTS * SG; part += STHREADS) {
 			const int n_lists = compact_threads(v_id[part + tid] != MISS, tid, s_wcnt, s_list);
 			if(tid < n_lists) {
 				const int idx = part + s_list[tid];
-				const int g = idx & (GROUP - 1);
+				const int g = idx & (SG - 1);
 				const uint32_t vi = v_id[idx];
 				uint32_t mw[MW];
 #pragma unroll
-				for(int w = 0; w < MW; ++w) mw[w] = v_mask[w * VSLOTS * GROUP + idx];
+				for(int w = 0; w < MW; ++w) mw[w] = v_mask[w * VSLOTS * SG + idx];
 				if(more_passes) {          // (the tables of the last pass of a first-tier workgroup are not looked at again)
 					v_id[idx] = MISS;
 #pragma unroll
-					for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * GROUP + idx] = 0;
+					for(int w = 0; w < MW; ++w) v_mask[w * VSLOTS * SG + idx] = 0;
 				}
 				if(g < ng && !s_over[g]) {
 				// list head: count + 7 ids in flight together (the value arrays carry 8 pad elements)
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 					const int slot = template_slot<TSLOTS>(t, g, t_id, t_cnt);
 					if(slot < 0) { s_over[g] = 1; return false; }
 #pragma unroll
-					for(int w = 0; w < MW; ++w) if(mw[w]) atomicOr(&t_mask[w * TSLOTS * GROUP + slot], mw[w]);
+					for(int w = 0; w < MW; ++w) if(mw[w]) atomicOr(&t_mask[w * TSLOTS * SG + slot], mw[w]);
 					return true;
 				};
 				bool ok = true;
@@ -723,8 +753,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 			}
 			__syncthreads();
 			// phase 2b: one thread per (item, template): fold the hit mask into the score
-			for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
-			const int n_tmpl = compact_threads((tid & (GROUP - 1)) < ng && t_id[part + tid] != T_EMPTY, tid, s_wcnt, s_list);
+			for(int part = 0; part < TSLOTS * SG; part += STHREADS) {
+			const int n_tmpl = compact_threads((tid & (SG - 1)) < ng && t_id[part + tid] != T_EMPTY, tid, s_wcnt, s_list);
 #ifdef KMAHIP_DIAG
 			if(!(A.ablate & 8))
 #endif
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				static_assert(MW == 5 && CHUNK < MW * 32, "mask layout");
 				uint32_t mw[MW];
 #pragma unroll
-				for(int w = 0; w < MW; ++w) mw[w] = t_mask[w * TSLOTS * GROUP + idx];
+				for(int w = 0; w < MW; ++w) mw[w] = t_mask[w * TSLOTS * SG + idx];
 				const uint64_t M0 = (uint64_t) mw[0] | ((uint64_t) mw[1] << 32), M1 = (uint64_t) mw[2] | ((uint64_t) mw[3] << 32), M2 = mw[4];
 				const uint64_t X0 = M0 << 1, X1 = (M1 << 1) | (M0 >> 63), X2 = (M2 << 1) | (M1 >> 63);
 				uint64_t S0 = M0 & ~X0, S1 = M1 & ~X1, S2 = M2 & ~X2;
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				if(more_passes) {
 					t_last[idx] = last;
 #pragma unroll
-					for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * GROUP + idx] = 0;
+					for(int w = 0; w < MW; ++w) t_mask[w * TSLOTS * SG + idx] = 0;
 				}
 			}
 			}
@@ -782,9 +812,9 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 		// atomic over its occupied slots, the tied templates counted the same way, one thread per item takes the result slots, and
 		// every tied template finds its place among the others -- first-seen order = ascending (first hit position, template id) --
 		// by counting the smaller keys (one lane per item walking the 16 slots once per tie kept the other three waves waiting)
-		static_assert((TSLOTS * GROUP) % STHREADS == 0, "table slots per thread");
-		for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
-			const int idx = part + tid, g = idx & (GROUP - 1);
+		static_assert((TSLOTS * SG) % STHREADS == 0, "table slots per thread");
+		for(int part = 0; part < TSLOTS * SG; part += STHREADS) {
+			const int idx = part + tid, g = idx & (SG - 1);
 			if(g < ng && !s_over[g] && t_id[idx] != T_EMPTY) {
 				if(MODE) atomicAdd(&s_nb[g], 1);
 				else atomicMax(&s_best[g], max(0, t_score[idx]));
@@ -792,8 +822,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 		}
 		__syncthreads();
 		if(!MODE) {
-			for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
-				const int idx = part + tid, g = idx & (GROUP - 1);
+			for(int part = 0; part < TSLOTS * SG; part += STHREADS) {
+				const int idx = part + tid, g = idx & (SG - 1);
 				if(g < ng && !s_over[g] && t_id[idx] != T_EMPTY) { const int sc = max(0, t_score[idx]); if(sc > 0 && sc == s_best[g]) atomicAdd(&s_nb[g], 1); }
 			}
 			__syncthreads();
@@ -824,8 +854,8 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 			A.item_off[item] = off;
 		}
 		__syncthreads();
-		for(int part = 0; part < TSLOTS * GROUP; part += STHREADS) {
-			const int idx = part + tid, g = idx & (GROUP - 1);
+		for(int part = 0; part < TSLOTS * SG; part += STHREADS) {
+			const int idx = part + tid, g = idx & (SG - 1);
 			if(g >= ng || s_off[g] < 0 || t_id[idx] == T_EMPTY) continue;
 			const int sc = max(0, t_score[idx]), best = s_best[g];
 			if(!MODE && sc != best) continue;
@@ -834,7 +864,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 				const long long key = ((long long) t_first[idx] << 32) | t_id[idx];
 #pragma unroll 1
 				for(int x = 0; x < TSLOTS; ++x) {
-					const int j = x * GROUP + g;
+					const int j = x * SG + g;
 					const uint32_t id = t_id[j];
 					if(id == T_EMPTY || (!MODE && max(0, t_score[j]) != best)) continue;
 					rank += ((((long long) t_first[j] << 32) | id) < key);
@@ -854,7 +884,7 @@ __global__ __launch_bounds__(STHREADS, STHREADS == 256 ? (TSLOTS == TS1 ? KMAHIP
 		__syncthreads();
 	}
 	if(TSLOTS == TS1) break;          // (straight-line code in the first tier)
-	first += (int64_t) gridDim.x * GROUP;
+	first += (int64_t) gridDim.x * SG;
 	} while(first < n_active);
 }
 
@@ -1309,7 +1339,7 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 		int L = 0, npos = 0, strand = 0;
 		bool live = g < ng;
 		if(live) {
-			item = S.in_items[first + g];
+			item = S.in_items[first + g] & ITEM_MASK;
 			r = item >> 1; strand = (int) (item & 1);
 			L = S.len[r]; npos = L - k + 1; so = S.seq_off[r];
 			if(S.N_off[r + 1] != S.N_off[r] || npos > CA_NPMAX || npos <= 0) { if(sl == 0) A.slow[r] = 1; live = false; }
@@ -1475,6 +1505,15 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 }
 } // namespace
 
+
+// the diagonals of the prefilter's hits are filed (ScanArgs::cat_bases) when `cat` is small enough for the list entry's field
+// (KMAHIP_SCAN_DIAG=0: never)
+static int64_t diag_cat_bases(const kmahip_db *db) {
+	if(const char *e = getenv("KMAHIP_SCAN_DIAG")) if(!atoi(e)) return 0;
+	const int64_t total = db->h_cat_off.empty() ? 0 : db->h_cat_off.back();
+	return total > 0 && total < (1ll << 30) ? total : 0;
+}
+
 static int ws_reserve(kmahip_ws *ws, int64_t n_reads) {
 	kmahip_db *db = ws->db;
 	if(n_reads > ws->cap_reads) {
@@ -1522,7 +1561,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots; A.active_items = ws->active_items;
-	A.mode = 0; A.pool_sc = nullptr; A.pool_tail0 = 2 * n * INL;
+	A.mode = 0; A.pool_sc = nullptr; A.pool_tail0 = 2 * n * INL; A.cat_bases = diag_cat_bases(db);
 	A.ablate = 0;
 #ifdef KMAHIP_DIAG
 	if(const char *e = getenv("KMAHIP_ABLATE_SCAN")) A.ablate = atoi(e);
@@ -1536,7 +1575,7 @@ int kmahip_launch_scan_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	}
 	const int64_t items = 2 * n;
 	const unsigned pgrid = (unsigned) ((items + PF_ITEMS - 1) / PF_ITEMS);
-	const unsigned grid = (unsigned) ((items + GROUP - 1) / GROUP);      // scan: upper bound; workgroups past the active count exit
+	const unsigned grid = (unsigned) ((items + SG - 1) / SG);      // scan: upper bound; workgroups past the active count exit
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, evp = nullptr, evq = nullptr;
 	if(ws->timing_on) {
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventCreate(&evp)); HIP_TRY(hipEventCreate(&evq));
@@ -1586,7 +1625,7 @@ int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	S.item_score = ws->item_score; S.item_n = ws->item_n; S.item_off = ws->item_off;
 	S.pool = ws->pool; S.pool_cap = ws->pool_cap; S.counters = ws->counters; S.overflow_items = ws->overflow_items;
 	S.dense = ws->dense; S.dense_slots = ws->dense_slots; S.active_items = ws->active_items;
-	S.mode = 0; S.pool_sc = nullptr; S.pool_tail0 = 2 * n * INL; S.ablate = 0;
+	S.mode = 0; S.pool_sc = nullptr; S.pool_tail0 = 2 * n * INL; S.ablate = 0; S.cat_bases = 0;
 	S.in_items = ws->active_items; S.in_count = C_NACT; S.out_over = ws->overflow_items; S.out_count = C_NOVER;
 	A.pool = pool; A.pool_cap = pool_cap; A.a_off = a_off; A.a_n = a_n; A.slow = slow; A.cnt = cnt;
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
@@ -1623,7 +1662,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.item_score = ws->item_score; A.item_n = ws->item_n; A.item_off = ws->item_off;
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots; A.active_items = ws->active_items;
-	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc; A.pool_tail0 = 0;
+	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc; A.pool_tail0 = 0; A.cat_bases = diag_cat_bases(db);
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
@@ -1634,7 +1673,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	}
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
-	const unsigned grid = (unsigned) ((2 * n + GROUP - 1) / GROUP);
+	const unsigned grid = (unsigned) ((2 * n + SG - 1) / SG);
 	int64_t *over1 = ws->overflow_items, *over2 = ws->overflow_items + 2 * ws->cap_reads;
 	A.in_items = ws->active_items; A.in_count = C_NACT; A.out_over = over1; A.out_count = C_NOVER;
 	hipLaunchKernelGGL((scan_se_kernel<false, 1, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
