@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the file-to-file leg (FASTQ -> .res / .fsa / .frag.gz through "
                     "examples/kmahip_map, whole-process wall clock); 0 = skip")
     ap.add_argument("--e2e-sample", type=int, default=1_000_000, help="reads of it the reference binary is run on (parity of .res + its rates)")
+    ap.add_argument("--pe-pairs", type=int, default=10_000_000, help="pairs of the extra BASELINE config C3 legs (resident step and file to file); 0: skip")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --reads per rank; strong: --reads in total, sharded over the ranks")
     return ap.parse_args()
@@ -237,7 +238,7 @@ def cpu_model():
     return "unknown"
 
 
-def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
+def e2e_leg(tmp, prefix, seqs, n, sample, log=None, pe_pairs=1_000_000, device="cuda:0"):
     """File to file: a FASTQ of n reads -> .res / .fsa / .frag.gz through the C host program (examples/kmahip_map): whole-process
     wall clock including HIP start-up, kmahip_db_open, ingest, the device run and the three writers, plain and gzip-compressed
     input. The compiled reference on the first `sample` reads of the same file: -t 1, -t nproc, and independent -t 1 processes
@@ -281,9 +282,9 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
                 shutil.copyfileobj(g, f, 1 << 24)
             os.unlink(os.path.join(tmp, f"slice{i:02d}.fq.gz"))
 
-    def run_map(inp, outp):
+    def run_map(inp, outp, env=None):
         t0 = time.perf_counter()
-        r = subprocess.run([mapper, "-i", inp, "-t_db", prefix, "-o", outp, "-1t1"], stderr=subprocess.PIPE)
+        r = subprocess.run([mapper, "-i", inp, "-t_db", prefix, "-o", outp, "-1t1"], stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
         dt = time.perf_counter() - t0
         err = r.stderr.decode().strip().splitlines()
         if r.returncode:
@@ -295,8 +296,11 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
 
     out = {"reads": n, "fastq_GB": round(os.path.getsize(fq) / 1e9, 2), "fastq_gz_GB": round(os.path.getsize(gz) / 1e9, 2), "unit": "reads/s",
            "host_threads": min(16, nproc),
-           "what": "examples/kmahip_map -i <fastq> -t_db <index> -o <out> -1t1: process start to exit, incl. HIP start-up, kmahip_db_open, ingest, "
-                   "kmahip_run_se (upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus), .res, .fsa and .frag.gz"}
+           "what": "examples/kmahip_map -i <fastq> -t_db <index> -o <out> -1t1 as ONE process: from its start until it is gone (HIP start-up, "
+                   "kmahip_db_open, ingest, the batched session: upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus; .res, .fsa, "
+                   ".frag.gz; and the teardown of its mappings and of the device context) -- the wall the reference's is compared with. "
+                   "outputs_closed: the same run with KMAHIP_MAP_EARLY_RETURN=1, where the command returns once every output is closed and a "
+                   "child finishes the teardown unwaited-for; reported beside it, never used for a ratio"}
     got = os.path.join(tmp, "e2e_got")
     walls = [run_map(fq, got) for _ in range(2)]
     best = min(walls)
@@ -305,6 +309,14 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
     if m:
         out["plain"]["breakdown"] = m.group(1)
     say(f"e2e: plain {best[0]:.2f} s | {best[1]}")
+    time.sleep(1.0)
+    we = [run_map(fq, got + "_early", env={"KMAHIP_MAP_EARLY_RETURN": "1"})[0]]
+    time.sleep(1.5)          # (the orphan of that run is still giving the device back)
+    we.append(run_map(fq, got + "_early", env={"KMAHIP_MAP_EARLY_RETURN": "1"})[0])
+    time.sleep(1.5)
+    out["outputs_closed"] = {"wall_s": round(min(we), 3), "reads_per_s": n / min(we), "runs_s": [round(w, 3) for w in we],
+                             "teardown_s": round(best[0] - min(we), 3)}
+    say(f"e2e: outputs closed after {min(we):.2f} s (early return); teardown {best[0] - min(we):.2f} s")
     wz = run_map(gz, got + "_gz")
     out["gz"] = {"wall_s": round(wz[0], 3), "reads_per_s": n / wz[0]}
     m = re.search(r"wall: (.*?) \|", wz[1])
@@ -419,15 +431,19 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
             ref["default_mode"] = {"error": str(e)}
         # paired end (`-ipe r1 r2 -apm p -1t1`, the shape of configs C3): both sides file to file
         try:
-            n_pairs, k_ = min(n // 2, 1_000_000), min(m_ // 2, 100_000)
+            from kma_amd import synth_dev
+            n_pairs, k_ = max(1, pe_pairs), min(m_ // 2, 100_000, max(1, pe_pairs))
             r1, r2 = os.path.join(tmp, "e2e_r1.fq"), os.path.join(tmp, "e2e_r2.fq")
+            t0 = time.perf_counter()
             with open(r1, "wb") as f1, open(r2, "wb") as f2:
-                for a_ in range(0, n_pairs, 250_000):
-                    m1, m2, _ = synth.make_pairs(seqs, min(250_000, n_pairs - a_), seed=500 + a_)
-                    for f_, mm in ((f1, m1), (f2, m2)):
+                for c0, both in synth_dev.iter_pair_codes(seqs, n_pairs, seed=500, device=device, chunk=1 << 20):
+                    hb = both.cpu().numpy()
+                    for f_, mm in ((f1, hb[0::2]), (f2, hb[1::2])):
                         write_fastq_fixed(os.path.join(tmp, "part.fq"), mm)
                         with open(os.path.join(tmp, "part.fq"), "rb") as g:
                             shutil.copyfileobj(g, f_, 1 << 24)
+            os.unlink(os.path.join(tmp, "part.fq"))
+            say(f"e2e: two FASTQ files of {n_pairs} pairs, {2 * os.path.getsize(r1) / 1e9:.2f} GB, written in {time.perf_counter() - t0:.1f} s")
             walls = []
             for _ in range(2):
                 t0 = time.perf_counter()
@@ -486,6 +502,96 @@ def e2e_leg(tmp, prefix, seqs, n, sample, log=None):
     for f_ in (fq, gz):
         os.unlink(f_)
     return out, ref
+
+
+def pe_step_leg(db, prefix, seqs, n_pairs, dev, steps, warmup, tmp, cpu_pairs):
+    """BASELINE config C3 beside the headline step (extra key, never `value`): n_pairs pairs of 2 x 150 nt resident in HBM, one step =
+    stage 2 with pairing (`-apm p`: scan_prefilter_kernel + scan_se_kernel in all-candidates mode + pair_penalty_kernel,
+    save_kmers_penaltyPair savekmers.c:3572-3777) + stage 3a (alnFragsPenaltyPE alnfrags.c:1596-1972) + the per-pair reduction into the
+    ConClave vectors. Same contract as the headline: K timed steps between synchronisations, kernel times by HIP events, algorithmic
+    bytes from a counter-enabled launch, the reference's own stage timers on a bounded sample of the same pairs."""
+    import re
+    import torch
+    from kma_amd import synth_dev
+    n = 2 * n_pairs
+    keep = min(n_pairs, cpu_pairs)
+    rd = synth_dev.make_packed_pairs(seqs, n_pairs, seed=4242, device=dev, keep_codes=keep)
+    i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
+    mate, rc, rc_flag, flag, n_hits, best, oflag, out_rc = (i32(n) for _ in range(8))
+    R_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    tcap = 4 * n
+    T, h_t, h_sc, h_s, h_e = (i32(tcap) for _ in range(5))
+    kind = i32(n_pairs)
+    D = int(db.info.DB_size)
+    aln = torch.zeros(D, dtype=torch.int64, device=dev)
+    uniq = torch.zeros(D, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        aln.zero_(); uniq.zero_()
+        db.scan_pe_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], mate, rc, rc_flag, flag, R_off, T, stream=stream)
+        db.align_pe_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], 150, mate, rc, rc_flag, flag, R_off, T,
+                        n_hits, best, oflag, h_t, h_sc, h_s, h_e, aln, uniq, out_rc, kind, stream=stream)
+    for _ in range(max(1, warmup)):
+        step()
+    db.status(stream)
+    db.set_timing(True)
+    for k_ in range(4):
+        db.get_timing(k_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = {name: db.get_timing(i) for i, name in ((2, "prefilter"), (0, "scan"), (3, "seed"), (1, "align"))}
+    db.set_timing(False)
+    db.status(stream)
+    db.set_stats(True)
+    db.scan_pe_dev(rd["seq"], rd["seq_off"], rd["length"], rd["N"], rd["N_off"], mate, rc, rc_flag, flag, R_off, T, stream=stream)
+    st = db.get_stats(stream)
+    db.set_stats(False)
+    step()
+    torch.cuda.synchronize()
+    total_T = int(R_off[-1].item())
+    kinds = torch.bincount(kind, minlength=5).tolist()
+    W = (150 + 31) // 32
+    scan_s = tm["scan"][0] / 1e3 / max(1, tm["scan"][1])
+    # SURVEY 8(d) bytes of the reference layout, as for the headline kernel: 12 B per resolved k-mer start, 2 B per list element,
+    # the packed read in, the record fields and 8 B per candidate (template + score) out
+    scan_bytes = 12 * (st.probes - st.prefilter_probes) + 2 * st.value_elems + st.active_strands * (8 * W + 4 + 8 + 8) + n * (4 + 4 + 8) + 8 * total_T
+    out = {"pairs": n_pairs, "reads": n, "steps": steps, "ms_per_step": dt / steps * 1e3, "pairs_per_s": n_pairs * steps / dt, "reads_per_s": n * steps / dt,
+           "unit": "reads/s", "dtype": "i32",
+           "workload": f"{n_pairs} x 2 x 150 nt pairs (insert 250-450, 0.5 % substitutions) vs the same {len(seqs)}-gene DB, -ipe -apm p -1t1; one step = stage 2 with "
+                       "the pairing penalty + stage 3a for couples and singly filed records, on pairs resident in HBM",
+           "kernel_ms": {k_: (v[0] / max(1, v[1])) for k_, v in tm.items()},
+           "record_tasks": total_T, "pair_kinds_0none_1proper_2unmated_3first_4second": kinds,
+           "roofline": {"bound": "hbm", "kernel": "scan_se_kernel<., 1, .> (all-candidates mode)", "kernel_ms": scan_s * 1e3,
+                        "achieved": scan_bytes / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_bytes / scan_s / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": scan_bytes, "traffic": None,
+                        "probes": int(st.probes - st.prefilter_probes), "hash_probes": int(st.hash_probes - st.prefilter_probes)}}
+    ref = os.path.join(ROOT, "oracle", "_ref", "kma")
+    if keep and os.path.exists(ref):
+        m1, m2 = rd["codes"]
+        r1, r2 = os.path.join(tmp, "pe_s1.fq"), os.path.join(tmp, "pe_s2.fq")
+        write_fastq_fixed(r1, m1); write_fastq_fixed(r2, m2)
+        t0 = time.time()
+        r = subprocess.run([ref, "-ipe", r1, r2, "-o", os.path.join(tmp, "pe_cpu"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1", "-status", "-nc", "-na", "-nf"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True)
+        wall = time.time() - t0
+        err = r.stderr.decode()
+        m2_ = re.search(r"ankering query:\s*([0-9.]+) s", err)
+        m3_ = re.search(r"KMA mapping time\s*([0-9.]+) s", err)
+        if m2_ and m3_:
+            s2, s3 = float(m2_.group(1)), float(m3_.group(1))
+            out["cpu_baseline"] = dict(value=2 * keep / (s2 + s3), unit="reads/s", cores=1, kind="reference",
+                                       sample=f"{keep} of the step's pairs; reference kma -ipe -apm p -1t1 -t 1 -status: stage 2 (ankering) {s2:.2f} s + stage 3a "
+                                              f"(mapping) {s3:.2f} s of CPU time (whole pipeline {wall:.1f} s wall)", stage2_s=s2, stage3a_s=s3)
+        for f_ in (r1, r2):
+            os.unlink(f_)
+    del rd
+    torch.cuda.empty_cache()
+    return out
 
 
 def parity_sample(prefix, codes, got_scan, got_hits):
@@ -715,6 +821,21 @@ def main():
                           "tasks_per_s": ast.tasks / aln_s},
             },
         }
+        # what carried the step's one exchange, as the transport reports it (a SCALE line can be checked for "RCCL saw N ranks")
+        comm = {"backend": "none", "nranks": 1}
+        if world > 1:
+            comm = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "rank0_device": str(dev),
+                    "exchange_per_step": f"SUM all-reduce of alignment_scores and uniq_alignment_scores: 2 x u64[{D}]"}
+            if a.backend == "nccl":
+                try:
+                    comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception:  # noqa: BLE001
+                    pass
+                # every rank adds 1: the sum IS the number of ranks the collective reached
+                one = torch.ones(1, dtype=torch.int64, device=dev)
+                dist.all_reduce(one)
+                comm["ranks_counted_by_allreduce"] = int(one.item())
+        out["config"]["comm"] = comm
         if rank == 0 and world == 1 and not a.no_cpu and keep:
             codes = rd["codes"][:keep]
             k = min(a.parity_sample, keep)
@@ -727,6 +848,11 @@ def main():
             out["config"]["parity_reads_checked"] = k
             # (the device legs first, the reference's CPU runs after them: behind those, copies to the device and the long-read leg --
             # hundreds of launches, host syncs between them -- came out up to twice as slow in some runs of this file and not in others)
+            if a.pe_pairs > 0 and not a.hard:
+                try:
+                    out["paired_end_step"] = pe_step_leg(db, prefix, seqs, a.pe_pairs, dev, a.steps, a.warmup, tmp, min(a.cpu_sample // 2, 500_000))
+                except Exception as e:  # noqa: BLE001  (extra leg only)
+                    out["paired_end_step"] = {"error": str(e)}
             # beyond the benchmarked step (informational, never `value`): the same sample through kmahip_run_se -- host
             # buffers in, `.res` statistics + consensus out: upload, stages 2 + 3a, ConClave, traceback, pile-up, consensus
             try:
@@ -756,7 +882,7 @@ def main():
                 try:
                     db.close()            # the C host program opens the index itself; give it the card's memory back first
                     torch.cuda.empty_cache()
-                    e2e, ref = e2e_leg(tmp, prefix, seqs, a.e2e_reads, a.e2e_sample)
+                    e2e, ref = e2e_leg(tmp, prefix, seqs, a.e2e_reads, a.e2e_sample, pe_pairs=a.pe_pairs if a.pe_pairs > 0 else 1_000_000, device=dev)
                     out["e2e"] = e2e
                     if ref is not None and out.get("cpu_baseline"):
                         out["cpu_baseline"].update(cpu_model=ref["cpu_model"], nproc=ref["nproc"], file_to_file=ref)

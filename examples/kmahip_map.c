@@ -1,5 +1,5 @@
 /* kmahip_map.c -- `kma -i reads.fq[.gz] -o out -t_db db [-1t1]` (or `-ipe r1.fq r2.fq ... -apm p -1t1`, or `-i reads.fq -Mt1 n [-bcNano]`)
- * on MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa and out.frag.gz, byte for
+ * on MI355X without the reference: plain C99 over the C-ABI of libkmahip.so. Writes out.res, out.fsa, out.aln and out.frag.gz, byte for
  * byte what KMA 1.5.1 writes with one thread (the .gz after decompression).
  *
  *     kmahip_map -i reads.fq.gz -t_db db -o out                     (the reference's default mode: chain finder, reads may map in pieces)
@@ -270,7 +270,7 @@ static int launch_ranks(int gpus, char **argv) {
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
-	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, gpus = 0, threads = 0, bcd = 1;
+	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
 	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
 	double support = 0;
 	long long max_frag = 0;
@@ -314,7 +314,7 @@ int main(int argc, char **argv) {
 			if(threads < 1) threads = 1;
 		}
 		else if(!strcmp(o, "-nc")) no_cons = 1;                                                 /* kma.c:1018-1022 */
-		else if(!strcmp(o, "-na")) { /* no .aln file: none is written */ }
+		else if(!strcmp(o, "-na")) no_aln = 1;                                                  /* kma.c:1023: no .aln file */
 		else if(!strcmp(o, "-nf")) no_frag = 1;
 		else if(!strcmp(o, "-mf")) { max_frag = need_int(argc, argv, &a, o); if(max_frag < 0) { fprintf(stderr, "Invalid argument at \"-mf\".\n"); return 1; } }
 		else if(!strcmp(o, "-ml")) { const int v = (int) need_int(argc, argv, &a, o); trim.min_len = v; par.minlen = v; cp.minlen = v; }       /* kma.c:581: one variable */
@@ -406,7 +406,7 @@ int main(int argc, char **argv) {
 		const double t_open = now_s();
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.write_aln = !no_aln; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		int64_t hint = 0;
 		{	/* (a guess at the number of reads from the size of the input: it only sizes the first allocation) */
 			struct stat sb;
@@ -498,7 +498,7 @@ int main(int argc, char **argv) {
 		}
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
-		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
+		so.evalue = evalue; so.bcd = bcd; so.caller = base_call | (dense ? 16 : 0); so.sig90 = sig_mode; so.support = support; so.ref_fsa = ref_fsa; so.write_aln = !no_aln; so.max_frag = max_frag; so.ID_t = ID_t; so.Depth_t = Depth_t;
 		double ms[8];
 		if(mt1 ? kmahip_run_mt1_sharded(db, ws, comm, &b, mt1, one2one, &par, &so, out, ms)
 		       : chain ? kmahip_run_chain_sharded(db, ws, comm, &b, &par, &cp, &so, out, ms)
@@ -507,6 +507,7 @@ int main(int argc, char **argv) {
 			char path[4096];
 			if(no_cons) { snprintf(path, sizeof path, "%s.fsa", out); remove(path); }
 			if(no_frag) { snprintf(path, sizeof path, "%s.frag.gz", out); remove(path); }
+			if(no_aln) { snprintf(path, sizeof path, "%s.aln", out); remove(path); }
 		}
 		fprintf(stderr, "# kmahip_map rank %d of %d: %lld reads; wall: ingest %.2f s beside open %.2f, run %.2f | upload %.1f ms, stages 2+3a %.1f, exchanges 1+2 + ConClave %.1f, "
 		        "traceback %.1f, gather by owner %.1f, pile-up + consensus %.1f, writers %.1f, merge %.1f\n", rank, world, (long long) b.reads.n_reads, job.t_done - t_start,
@@ -542,7 +543,7 @@ int main(int argc, char **argv) {
 	for(int64_t t = 0; t < D; ++t) run.assembly.consensus_off[t] = -1;
 	run.tmpl = xcalloc((size_t) n + 1, 4); run.n_hits = xcalloc((size_t) n + 1, 4); run.rc = xcalloc((size_t) n + 1, 4);
 	run.trace_stats = xcalloc((size_t) n * 10 + 10, 4);
-	run.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0); run.sig90 = sig_mode; run.support = support;      /* -bcNano, -bc90, -bc, -bcg, -ref_fsa (bit 3: mark the trimmed insertion columns) */
+	run.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0) | (no_aln ? 0 : 32); run.sig90 = sig_mode; run.support = support;      /* -bcNano, -bc90, -bc, -bcg, -ref_fsa (bit 3: mark the trimmed insertion columns) */
 	touch_job tj = { { (char *) run.tmpl, (char *) run.n_hits, (char *) run.rc, (char *) run.trace_stats },
 	                 { ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n + 1) * 4, ((size_t) n * 10 + 10) * 4 } };
 	pthread_t touch_thread;
@@ -553,7 +554,7 @@ int main(int argc, char **argv) {
 	if(mt1) {
 		kmahip_assemble_opts ao;
 		memset(&ao, 0, sizeof ao);
-		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0); ao.sig90 = sig_mode; ao.support = support;
+		ao.evalue = evalue; ao.bcd = bcd; ao.order = 1; ao.caller = base_call | (ref_fsa == 2 ? 8 : 0) | (dense ? 16 : 0) | (no_aln ? 0 : 32); ao.sig90 = sig_mode; ao.support = support;
 		if(kmahip_run_mt1(db, ws, &b.reads, mt1, one2one, &par, &ao, &run)) die("kmahip_run_mt1");
 	} else if(chain) {
 		if(kmahip_run_chain(db, ws, &b.reads, b.names, b.name_off, &par, &cp, evalue, bcd, max_frag, dev_frag, &run)) die("kmahip_run_chain");
@@ -576,7 +577,9 @@ int main(int argc, char **argv) {
 	FILE *res = fopen(path, "w");
 	snprintf(path, sizeof path, "%s.fsa", out);
 	FILE *fsa = no_cons ? NULL : fopen(path, "w");
-	if(!names || !res || (!fsa && !no_cons)) fail("cannot open the name file or the outputs");
+	snprintf(path, sizeof path, "%s.aln", out);
+	FILE *aln = no_aln ? NULL : fopen(path, "w");
+	if(!names || !res || (!fsa && !no_cons) || (!aln && !no_aln)) fail("cannot open the name file or the outputs");
 	fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
 	int64_t r = 0;
 	size_t fsa_cap = 1 << 16;
@@ -587,20 +590,32 @@ int main(int argc, char **argv) {
 		if(!(r < run.n_rows && run.rows[r].template_id == t && run.rows[r].significant)) continue;
 		if(!kmahip_res_line(name, &run.rows[r], run.assembly.cover[t], run.assembly.aln_len[t], run.assembly.depth[t], ID_t, Depth_t, line, (1 << 16) + 512)) continue;
 		fputs(line, res);
-		if(!fsa) continue;
-		/* printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line */
-		fprintf(fsa, ">%s\n", name);
 		const char *c = run.assembly.consensus + run.assembly.consensus_off[t];
 		const size_t clen = strlen(c);
-		if(clen + clen / 60 + 2 > fsa_cap) { fsa_cap = 2 * (clen + clen / 60 + 2); free(fsa_buf); fsa_buf = xcalloc(fsa_cap, 1); }
+		if((clen / 60 + 2) * 224 + strlen(name) + 16 > fsa_cap) { fsa_cap = 2 * ((clen / 60 + 2) * 224 + strlen(name) + 16); free(fsa_buf); fsa_buf = xcalloc(fsa_cap, 1); }
+		if(aln) {	/* printConsensus (printconsensus.c:26-37): the template's block of the alignment file */
+			const int64_t got = kmahip_aln_entry(db, (int32_t) t, name, c, fsa_buf, (int64_t) fsa_cap);
+			if(got < 0) die("kmahip_aln_entry");
+			fwrite(fsa_buf, 1, (size_t) got, aln);
+		}
+		if(!fsa) continue;
+		/* printConsensus (printconsensus.c:38-60): the consensus line without its '-' columns, 60 per line (an insertion column carries
+		 * bit 7 when the .aln file was asked for; a gap called there was trimmed from the alignment, assembly.c:2094-2119) */
+		fprintf(fsa, ">%s\n", name);
 		char *o = fsa_buf;
 		int col = 0;
-		for(; *c; ++c) if(*c != '_' && (*c != '-' || ref_fsa == 2)) { *o++ = *c; if(++col == 60) { *o++ = '\n'; col = 0; } }
+		for(; *c; ++c) {
+			const char b = (char) (*c & 0x7F);
+			if(b == '_' || (b == '-' && (ref_fsa != 2 || (*c & 0x80)))) continue;
+			*o++ = b;
+			if(++col == 60) { *o++ = '\n'; col = 0; }
+		}
 		if(col) *o++ = '\n';
 		fwrite(fsa_buf, 1, (size_t) (o - fsa_buf), fsa);
 	}
 	fclose(names); fclose(res);
 	if(fsa) fclose(fsa);
+	if(aln) fclose(aln);
 
 	const double t_res = now_s();
 	/* out.frag.gz (the paired and the default-mode run have written it themselves: their fragments are in record order, not read order) */

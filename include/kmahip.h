@@ -344,7 +344,8 @@ typedef struct kmahip_assemble_opts {
 	                     * -bcNano): assembly.c:162-270. + 8: insertion columns called as gaps -- which the reference trims from its alignment,
 	                     * assembly.c:748-752 -- come out as '_' in the consensus string instead of '-' (for a writer that keeps the gaps of
 	                     * template positions: -ref_fsa 0). + 16: alnToMatDense (-dense, assembly.c:1446-1497): template positions only, no
-	                     * insertion columns */
+	                     * insertion columns. + 32: the character of EVERY insertion column carries bit 7 (what kmahip_aln_entry needs to tell
+	                     * them from template positions; a reader of the string masks with 0x7F) */
 	int32_t sig90;      /* 0 significantNuc, 1 significantAnd90Nuc (-bc90, -bcNano), 2 significantAndSupport (-bc x): `support` below */
 	/* per read: how many filed fragments (ConClave template != 0) precede it in the WHOLE stream -- what the reference's
 	 * chunks of max_frag records are counted in (conclave.c:166, 194). NULL: the batch is the whole stream and the
@@ -599,8 +600,14 @@ typedef struct kmahip_shard_opts {
 	double ID_t, Depth_t; /* -ID (1.0), -md (0.0) */
 	double support;       /* -bc x with sig90 == 2 */
 	int32_t ref_fsa;      /* the consensus file: 0 gap columns left out, 1 gaps as n (-ref_fsa), 2 as they are (-ref_fsa 0; printconsensus.c:38-60) */
-	int32_t pad_;
+	int32_t write_aln;    /* != 0: <prefix>.aln as well (printConsensus printconsensus.c:26-37; the reference writes it unless -na) */
 } kmahip_shard_opts;
+/* One template's block of the `.aln` file: "# name", then per 60 alignment columns the lines "template:", the match line ('|' where
+ * the call equals the template's base, '_' elsewhere) and "query:", of the alignment as assemble_KMA trims it (assembly.c:2094-2119:
+ * without the insertion columns called as gaps). cons: the template's consensus string from kmahip_assemble2 / kmahip_run_* with
+ * caller + 32. Returns the number of bytes written to out (no terminator), -1 on an error (cap too small: (columns / 60 + 2) * 224 +
+ * strlen(name) + 16 always suffices). Host memory; reads <prefix>.seq.b the first time. */
+int64_t kmahip_aln_entry(kmahip_db *db, int32_t tmpl, const char *name, const char *cons, char *out, int64_t cap);
 int kmahip_run_se_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const kmahip_read_batch *batch, const kmahip_params *p,
                           const kmahip_shard_opts *opts, const char *out_prefix, double ms[8]);
 /* The default mode (no -1t1; kmahip_run_chain) over read shards: stage 2 -- save_kmers_chain -- on the rank's reads, its records (a

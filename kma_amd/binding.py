@@ -172,6 +172,9 @@ def lib():
         L.kmahip_align_get_stats.argtypes = [C.c_void_p, C.POINTER(AlignStats), C.c_void_p]
         L.kmahip_scan_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs)]
         L.kmahip_scan_pe_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs), C.c_void_p]
+        L.kmahip_align_pe_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(PeRecs), C.POINTER(Params), C.POINTER(Hits),
+                                          C.c_void_p, C.c_void_p]
+        L.kmahip_scan_pe_dev.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs), C.c_void_p]
         L.kmahip_map_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(PeRecs),
                                     C.POINTER(Hits), C.c_void_p]
         L.kmahip_map_se.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.POINTER(Params), C.POINTER(Cands), C.POINTER(Hits)]
@@ -486,6 +489,28 @@ class KmaHipDB:
                  h_start.data_ptr(), h_end.data_ptr(), aln_scores.data_ptr(), uniq_scores.data_ptr(), None)
         p = Params.from_buffer_copy(self.params)
         _check(lib().kmahip_align_se_dev(self.h, self.ws, C.byref(r), C.byref(c), C.byref(p), C.byref(h),
+                                         C.c_void_p(stream or 0)))
+
+    def scan_pe_dev(self, seq, seq_off, length, N, N_off, mate, rc, rc_flag, flag, R_off, T, exhaustive=0, stream=None):
+        """Stage 2 for interleaved mates (`-apm p`) on device tensors; asynchronous on `stream`. mate / rc / rc_flag / flag: i32[2 pairs],
+        R_off i64[2 pairs + 1], T i32[capacity]."""
+        n = length.numel()
+        r = Reads(n, seq.data_ptr(), seq_off.data_ptr(), length.data_ptr(), N.data_ptr(), N_off.data_ptr(), seq.numel(), N.numel(), 0)
+        out = PeRecs(mate.data_ptr(), rc.data_ptr(), rc_flag.data_ptr(), flag.data_ptr(), R_off.data_ptr(), T.data_ptr(), T.numel())
+        p = Params.from_buffer_copy(self.params)
+        p.exhaustive = exhaustive
+        _check(lib().kmahip_scan_pe_dev(self.h, self.ws, C.byref(r), C.byref(p), C.byref(out), C.c_void_p(stream or 0)))
+
+    def align_pe_dev(self, seq, seq_off, length, N, N_off, max_len, mate, rc, rc_flag, flag, R_off, T,
+                     n_hits, best_score, out_flag, h_tmpl, h_score, h_start, h_end, aln_scores, uniq_scores, out_rc, kind, stream=None):
+        """Stage 3a for the records of scan_pe_dev on device tensors; asynchronous on `stream`. kind: i32[pairs]."""
+        n = length.numel()
+        r = Reads(n, seq.data_ptr(), seq_off.data_ptr(), length.data_ptr(), N.data_ptr(), N_off.data_ptr(), seq.numel(), N.numel(), int(max_len))
+        recs = PeRecs(mate.data_ptr(), rc.data_ptr(), rc_flag.data_ptr(), flag.data_ptr(), R_off.data_ptr(), T.data_ptr(), T.numel())
+        h = Hits(n_hits.data_ptr(), best_score.data_ptr(), out_flag.data_ptr(), h_tmpl.data_ptr(), h_score.data_ptr(),
+                 h_start.data_ptr(), h_end.data_ptr(), aln_scores.data_ptr(), uniq_scores.data_ptr(), out_rc.data_ptr())
+        p = Params.from_buffer_copy(self.params)
+        _check(lib().kmahip_align_pe_dev(self.h, self.ws, C.byref(r), C.byref(recs), C.byref(p), C.byref(h), C.c_void_p(kind.data_ptr()),
                                          C.c_void_p(stream or 0)))
 
     # -- stage 3b (ConClave) -----------------------------------------------------------

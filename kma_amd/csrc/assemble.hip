@@ -751,6 +751,7 @@ struct ConsArgs {
 	int sig90;                   // 1: significantAnd90Nuc instead of significantNuc (-bcNano, -bc90; assembly.c:147-149), 2: significantAndSupport
 	double support;
 	int mark_ins;                // insertion columns called as gaps are written as '_' (kmahip_assemble_opts.caller bit 3)
+	int mark_all;                // every insertion column's character carries bit 7 (caller bit 5: for the `.aln` writer)
 	double qstar;
 	unsigned long long *cover, *aln_len, *depth, *asm_len;      // per template
 	char *cons;                  // pass 2: consensus characters
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(CONS_THREADS) void consensus_kernel(const ConsArgs 
 					call = call_column_dev(C.nodes[h - 1].c, 5, C.bcd, C.qstar, C.caller, C.sig90, C.support, &dep);
 					// (an insertion column called as a gap is trimmed from the reference's alignment, assembly.c:748-752: marked where the
 					// writer keeps the gaps of template positions, `-ref_fsa 0`)
-					if(WRITE && coff >= 0) C.cons[coff + o] = (call == '-' && C.mark_ins) ? '_' : (char) call;
+					if(WRITE && coff >= 0) C.cons[coff + o] = (char) (((call == '-' && C.mark_ins) ? '_' : call) | (C.mark_all ? 0x80 : 0));
 					++o;
 					if(call != '-') { depth += (unsigned long long) dep; ++aln; }
 				}
@@ -1351,7 +1352,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
                                     const kmahip_traces *traces, const kmahip_assemble_opts *opts, kmahip_assembly *out) {
 	if(!opts) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	const int64_t max_frag = opts->max_frag;
-	const int bcd = opts->bcd, caller = opts->caller & 7, sig90 = opts->sig90, mark_ins = (opts->caller >> 3) & 1;
+	const int bcd = opts->bcd, caller = opts->caller & 7, sig90 = opts->sig90, mark_ins = (opts->caller >> 3) & 1, mark_all = (opts->caller >> 5) & 1;
 	const double support = opts->support;
 	const double evalue = opts->evalue;
 	if(!db || !ws || !reads || !d_flag || !d_tmpl || !traces || !out || !out->cover || !out->aln_len || !out->depth || !out->asm_len) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
@@ -1405,7 +1406,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 			DevGuard G;
 			ConsArgs C;
 			C.db = db->dev; C.counts = ws->p_counts; C.chain_head = ws->p_chain; C.nodes = (const InsNode *) ws->p_nodes; C.seg_start = ws->p_seg;
-			C.n_kept = ws->p_kept; C.bcd = bcd; C.caller = caller; C.sig90 = sig90; C.support = support; C.mark_ins = mark_ins; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
+			C.n_kept = ws->p_kept; C.bcd = bcd; C.caller = caller; C.sig90 = sig90; C.support = support; C.mark_ins = mark_ins; C.mark_all = mark_all; C.qstar = qstar; C.cons = nullptr; C.cons_off = nullptr;
 			unsigned long long *fig = nullptr;
 			HIP_TRY(hipMalloc((void **) &fig, (size_t) 4 * D * sizeof(unsigned long long)));
 			G.v.push_back(fig);
@@ -1499,7 +1500,7 @@ extern "C" int kmahip_assemble2_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_r
 			long dep = 0;
 			const unsigned char call = call_column(c, tnuc, bcd, evalue, caller, sig90, support, &dep);
 			++asm_len;
-			if(out->consensus) cons.push_back((call == '-' && !is_template && mark_ins) ? '_' : (char) call);
+			if(out->consensus) cons.push_back((char) (((call == '-' && !is_template && mark_ins) ? '_' : call) | (!is_template && mark_all ? 0x80 : 0)));
 			if(call != '-') {
 				depth += dep; ++aln_len;
 				if(is_template && "ACGTN-"[tnuc] == toupper(call)) ++cover;

@@ -64,6 +64,8 @@ struct kmahip_db {
 	std::vector<int64_t> h_cat_off;
 	std::string prefix;           // index prefix (the `.name` file is read on demand by the text writers)
 	std::vector<std::string> h_names;
+	std::vector<uint64_t> h_tseq;     // <prefix>.seq.b, read when the `.aln` writer first asks (pipeline.hip: load_tseq)
+	std::vector<int64_t> h_tseq_off;
 };
 
 // per-call scratch, grown on demand

@@ -1068,39 +1068,112 @@ int concat_parts(const std::string &prefix, const char *ext, int world, const ch
 
 }  // namespace
 
-// The rows of `.res` (runkma.c:792-809) and the entries of the consensus FASTA (printConsensus, printconsensus.c:38-60: the
-// consensus line without its '-' columns, 60 per line) for the significant templates -- all of them, or those `owner` gives to
-// `rank`. fsa_path NULL: no consensus file (-nc).
+// the 2-bit template store on the host (the t line of the `.aln` file): <prefix>.seq.b, read when first asked for
+static int load_tseq(kmahip_db *db) {
+	if(!db->h_tseq.empty()) return KMAHIP_OK;
+	const size_t D = db->info.DB_size;
+	if(db->h_tlen.size() != D) { kmahip_set_error("index has no .length.b / .seq.b"); return KMAHIP_EINVAL; }
+	db->h_tseq_off.assign(D + 1, 0);
+	for(size_t i = 2; i <= D; ++i) db->h_tseq_off[i] = db->h_tseq_off[i - 1] + (db->h_tlen[i - 1] >> 5) + 1;      // runkma.c:214-220
+	std::vector<uint64_t> w((size_t) db->h_tseq_off[D] + 2, 0);
+	FILE *f = fopen((db->prefix + ".seq.b").c_str(), "rb");
+	if(!f || fread(w.data(), 8, (size_t) db->h_tseq_off[D], f) != (size_t) db->h_tseq_off[D]) { if(f) fclose(f); kmahip_set_error("cannot read %s.seq.b", db->prefix.c_str()); return KMAHIP_EIO; }
+	fclose(f);
+	db->h_tseq.swap(w);
+	return KMAHIP_OK;
+}
+
+// One template's block of the `.aln` file as printConsensus writes it (printconsensus.c:26-37): "# name", then per 60 columns the
+// lines "template:", the match line and "query:" (callConsensus assembly.c:1543-1611: t = the template's base, '-' at an insertion
+// column; s = '|' where a call equals it, else '_'), of the alignment as assemble_KMA trims it (:2094-2119: the insertion columns
+// called as gaps are gone). `cons`: the template's consensus string made with kmahip_assemble_opts.caller + 32 (every insertion
+// column's character carries bit 7). Returns the length of the text written to `out`, -1 when `cap` is too small or on an error.
+extern "C" int64_t kmahip_aln_entry(kmahip_db *db, int32_t tmpl, const char *name, const char *cons, char *out, int64_t cap) {
+	if(!db || !name || !cons || !out || tmpl < 1 || (size_t) tmpl >= db->info.DB_size) { kmahip_set_error("kmahip_aln_entry: bad argument"); return -1; }
+	if(load_tseq(db)) return -1;
+	const uint64_t *ts = db->h_tseq.data() + db->h_tseq_off[(size_t) tmpl];
+	const int t_len = db->h_tlen[(size_t) tmpl];
+	std::string t, sl, q;
+	int p = 0;
+	for(const unsigned char *c = (const unsigned char *) cons; *c; ++c) {
+		const bool ins = (*c & 0x80) != 0;
+		const char b = (char) (*c & 0x7F);
+		if(ins) {
+			if(b == '-' || b == '_') continue;          // trimmed
+			t.push_back('-'); q.push_back(b); sl.push_back('_');
+			continue;
+		}
+		if(p >= t_len) { kmahip_set_error("kmahip_aln_entry: the consensus string has more template columns than template %d has bases (made without caller + 32 ?)", tmpl); return -1; }
+		const char tb = "ACGT"[(ts[p >> 5] >> (62 - ((p & 31) << 1))) & 3ull];
+		++p;
+		t.push_back(tb); q.push_back(b);
+		sl.push_back(b != '-' && tb == (char) toupper((unsigned char) b) ? '|' : '_');
+	}
+	std::string text = "# ";
+	text += name; text += "\n";
+	char head[3][16];
+	snprintf(head[0], sizeof head[0], "%-10s\t", "template:"); snprintf(head[1], sizeof head[1], "%-10s\t", ""); snprintf(head[2], sizeof head[2], "%-10s\t", "query:");
+	for(size_t i = 0; i < t.size(); i += 60) {
+		const size_t n = std::min<size_t>(60, t.size() - i);
+		text += head[0]; text.append(t, i, n); text += "\n";
+		text += head[1]; text.append(sl, i, n); text += "\n";
+		text += head[2]; text.append(q, i, n); text += "\n\n";
+	}
+	if((int64_t) text.size() > cap) { kmahip_set_error("kmahip_aln_entry: %zu bytes needed, room for %lld", text.size(), (long long) cap); return -1; }
+	memcpy(out, text.data(), text.size());
+	return (int64_t) text.size();
+}
+
+// The rows of `.res` (runkma.c:792-809), the entries of the consensus FASTA (printConsensus, printconsensus.c:38-60: the
+// consensus line without its '-' columns, 60 per line) and, with aln_path, the blocks of the `.aln` file (:26-37; the consensus
+// strings were then made with caller + 32) for the significant templates -- all of them, or those `owner` gives to
+// `rank`. fsa_path NULL: no consensus file (-nc); aln_path NULL: no alignment file (-na).
 int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_path, bool header, const kmahip_res_row *rows, int64_t n_rows,
                          const int32_t *owner, int rank, const int64_t *cover, const int64_t *aln_len, const int64_t *depth, const char *cons,
-                         const int64_t *cons_off, double ID_t, double Depth_t, int ref_fsa) {
+                         const int64_t *cons_off, double ID_t, double Depth_t, int ref_fsa, const char *aln_path) {
 	int rc = kmahip_db_load_names(db);
 	if(rc) return rc;
-	FILE *res = fopen(res_path, "w"), *fsa = fsa_path ? fopen(fsa_path, "w") : nullptr;
-	if(!res || (fsa_path && !fsa)) { if(res) fclose(res); if(fsa) fclose(fsa); kmahip_set_error("cannot create %s", res ? fsa_path : res_path); return KMAHIP_EIO; }
+	FILE *res = fopen(res_path, "w"), *fsa = fsa_path ? fopen(fsa_path, "w") : nullptr, *aln = aln_path ? fopen(aln_path, "w") : nullptr;
+	if(!res || (fsa_path && !fsa) || (aln_path && !aln)) { if(res) fclose(res); if(fsa) fclose(fsa); if(aln) fclose(aln); kmahip_set_error("cannot create %s", !res ? res_path : (fsa_path && !fsa) ? fsa_path : aln_path); return KMAHIP_EIO; }
 	if(header) fputs("#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n", res);
-	std::vector<char> line((1 << 16) + 512);
+	std::vector<char> line((1 << 16) + 512), block;
 	std::string entry;
-	for(int64_t r = 0; r < n_rows; ++r) {
+	for(int64_t r = 0; r < n_rows && !rc; ++r) {
 		const kmahip_res_row &row = rows[r];
 		const size_t tt = (size_t) row.template_id;
 		if((owner && owner[tt] != rank) || !row.significant || tt - 1 >= db->h_names.size()) continue;
 		const std::string &name = db->h_names[tt - 1];
 		if(!kmahip_res_line(name.c_str(), &row, cover[tt], aln_len[tt], depth[tt], ID_t, Depth_t, line.data(), (int64_t) line.size())) continue;
 		fputs(line.data(), res);
+		const char *q0 = cons_off[tt] >= 0 ? cons + cons_off[tt] : "";
+		if(aln) {
+			const size_t len = strlen(q0);
+			block.resize((len / 60 + 2) * 224 + name.size() + 16);
+			const int64_t got = kmahip_aln_entry(db, (int32_t) tt, name.c_str(), q0, block.data(), (int64_t) block.size());
+			if(got < 0) { rc = KMAHIP_EINVAL; break; }
+			fwrite(block.data(), 1, (size_t) got, aln);
+		}
 		if(!fsa) continue;
 		entry.clear();
 		entry += ">"; entry += name; entry += "\n";
 		int col = 0;
 		// printConsensus (printconsensus.c:38-60): gap columns left out;
 		// with -ref_fsa 0 (ref_fsa == 2) the gaps of template positions stay; insertion columns called as gaps ('_': the caller was asked to
-		// mark them) were trimmed from the alignment before (assembly.c:748-752). With -ref_fsa refCaller leaves no gap at a template position.
-		for(const char *q = cons_off[tt] >= 0 ? cons + cons_off[tt] : ""; *q; ++q) if(*q != '_' && (*q != '-' || ref_fsa == 2)) { entry.push_back(*q); if(++col == 60) { entry.push_back('\n'); col = 0; } }
+		// mark them; or, with every insertion column flagged by bit 7 for the `.aln` writer, a flagged gap) were trimmed from the alignment
+		// before (assembly.c:748-752). With -ref_fsa refCaller leaves no gap at a template position.
+		for(const char *q = q0; *q; ++q) {
+			const char b = (char) (*q & 0x7F);
+			if(b == '_' || (b == '-' && (ref_fsa != 2 || (*q & 0x80)))) continue;
+			entry.push_back(b);
+			if(++col == 60) { entry.push_back('\n'); col = 0; }
+		}
 		if(col) entry.push_back('\n');
 		fwrite(entry.data(), 1, entry.size(), fsa);
 	}
 	const bool bad = fclose(res) != 0;
-	if((fsa && fclose(fsa) != 0) || bad) { kmahip_set_error("write to %s failed", res_path); return KMAHIP_EIO; }
+	const bool bad2 = fsa && fclose(fsa) != 0, bad3 = aln && fclose(aln) != 0;
+	if(rc) return rc;
+	if(bad || bad2 || bad3) { kmahip_set_error("write to %s failed", res_path); return KMAHIP_EIO; }
 	return KMAHIP_OK;
 }
 
@@ -1265,7 +1338,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
 	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
 	if(m2) {
-		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, order, opts->caller | (opts->ref_fsa == 2 ? 8 : 0), opts->sig90, fr2, opts->support};
+		kmahip_assemble_opts ao = {chunk, opts->evalue, opts->bcd, order, opts->caller | (opts->ref_fsa == 2 ? 8 : 0) | (opts->write_aln ? 32 : 0), opts->sig90, fr2, opts->support};
 		if((rc = kmahip_assemble2_dev(db, ws, &dO, rc2, tm2, &trO, &ao, &asmb))) return rc;
 	}
 	ms[5] = since(t);
@@ -1273,7 +1346,7 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	// the rows of the owned templates: `.res` lines, consensus entries, fragment rows -- parts that rank 0 puts together
 	const std::string prefix(out_prefix), part = prefix + ".part" + std::to_string(rank);
 	if((rc = kmahip_write_res_fsa(db, (part + ".res").c_str(), (part + ".fsa").c_str(), false, rows, n_rows, owner.data(), rank, a_cover.data(), a_len.data(), a_depth.data(),
-	                              cons.data(), c_off.data(), opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, opts->ref_fsa))) return rc;
+	                              cons.data(), c_off.data(), opts->ID_t > 0 ? opts->ID_t : 1.0, opts->Depth_t, opts->ref_fsa, opts->write_aln ? (part + ".aln").c_str() : nullptr))) return rc;
 	{
 		// the fragment rows are formatted on the host from what arrived (kmahip_frag_write3 with the positions the reads had in the whole stream)
 		std::vector<uint64_t> hs((size_t) dO.seq_words + 2, 0);
@@ -1308,7 +1381,8 @@ static int shard_finish(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, DevBloc
 	if((rc = kmahip_comm_barrier(comm))) return rc;
 	if(rank == 0) {
 		if((rc = concat_parts(prefix, ".res", W, "#Template\tScore\tExpected\tTemplate_length\tTemplate_Identity\tTemplate_Coverage\tQuery_Identity\tQuery_Coverage\tDepth\tq_value\tp_value\n")) ||
-		   (rc = concat_parts(prefix, ".fsa", W, nullptr)) || (rc = concat_parts(prefix, ".frag.gz", W, nullptr))) return rc;
+		   (rc = concat_parts(prefix, ".fsa", W, nullptr)) || (rc = concat_parts(prefix, ".frag.gz", W, nullptr)) ||
+		   (opts->write_aln && (rc = concat_parts(prefix, ".aln", W, nullptr)))) return rc;
 	}
 	if((rc = kmahip_comm_barrier(comm))) return rc;
 	ms[7] = since(t);

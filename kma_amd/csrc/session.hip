@@ -22,7 +22,7 @@ void kmahip_gzstream_submit(kmahip_gzstream *g, const char *text, size_t bytes, 
 int kmahip_gzstream_close(kmahip_gzstream *g);
 int kmahip_write_res_fsa(kmahip_db *db, const char *res_path, const char *fsa_path, bool header, const kmahip_res_row *rows, int64_t n_rows,
                          const int32_t *owner, int rank, const int64_t *cover, const int64_t *aln_len, const int64_t *depth, const char *cons,
-                         const int64_t *cons_off, double ID_t, double Depth_t, int ref_fsa);                                    // pipeline.hip
+                         const int64_t *cons_off, double ID_t, double Depth_t, int ref_fsa, const char *aln_path);                                    // pipeline.hip
 
 namespace {
 
@@ -781,13 +781,13 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 		asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
 		asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
 		if(n && score) {
-			kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 1, S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0), S->opts.sig90, nullptr, S->opts.support};
+			kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 1, S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0) | (S->opts.write_aln ? 32 : 0), S->opts.sig90, nullptr, S->opts.support};
 			if((rc = kmahip_assemble2_dev(db, ws, &W, S->t_rc.as<int32_t>(), d_tmpl, &tr, &ao, &asmb))) return rc;
 		}
 		ms[4] = since(t);
 		const std::string prefix(out_prefix);
 		if((rc = kmahip_write_res_fsa(db, (prefix + ".res").c_str(), write_fsa ? (prefix + ".fsa").c_str() : nullptr, true, &row, 1, nullptr, 0, a_cover.data(), a_len.data(),
-		                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa))) return rc;
+		                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa, S->opts.write_aln ? (prefix + ".aln").c_str() : nullptr))) return rc;
 		ms[5] = since(t);
 		if(S->sink) {          // (written batch by batch: what is left is the end of the file)
 			if((rc = mt1_frag_join(S))) return rc;
@@ -869,13 +869,13 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	asmb.cover = a_cover.data(); asmb.aln_len = a_len.data(); asmb.depth = a_depth.data(); asmb.asm_len = a_asm.data();
 	asmb.consensus = cons.data(); asmb.consensus_off = c_off.data(); asmb.consensus_cap = (int64_t) cons.size(); asmb.consensus_used = 0;
 	if(n) {
-		kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 0, S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0), S->opts.sig90, nullptr, S->opts.support};
+		kmahip_assemble_opts ao = {mf, S->opts.evalue, S->opts.bcd, 0, S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0) | (S->opts.write_aln ? 32 : 0), S->opts.sig90, nullptr, S->opts.support};
 		if((rc = kmahip_assemble2_dev(db, ws, &W, rc_all, cc.tmpl, &tr, &ao, &asmb))) return rc;
 	}
 	ms[4] = since(t);
 	const std::string prefix(out_prefix);
 	if((rc = kmahip_write_res_fsa(db, (prefix + ".res").c_str(), write_fsa ? (prefix + ".fsa").c_str() : nullptr, true, rows.data(), n_rows, nullptr, 0, a_cover.data(), a_len.data(),
-	                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa))) return rc;
+	                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa, S->opts.write_aln ? (prefix + ".aln").c_str() : nullptr))) return rc;
 	ms[5] = since(t);
 	if(!write_frag) return KMAHIP_OK;
 

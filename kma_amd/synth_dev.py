@@ -73,6 +73,64 @@ def make_packed_reads(seqs, n_reads, read_len=150, sub_rate=0.005, rc_frac=0.5, 
     )
 
 
+def iter_pair_codes(seqs, n_pairs, read_len=150, ins_lo=250, ins_hi=450, sub_rate=0.005, seed=1, device="cuda", chunk=1 << 20):
+    """Pairs of the shape of synth.make_pairs (mate 1 = the fragment's first read_len bases, mate 2 = the reverse complement of its
+    last read_len, insert U[ins_lo, ins_hi] clipped to the gene, half of the fragments sequenced from the other strand, 0.5 %
+    substitutions), generated in HBM: yields (first pair, u8[2 m, read_len]) with the mates INTERLEAVED (rows 2i, 2i + 1 = pair i)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = np.array([len(s) for s in seqs], np.int64)
+    ok = np.nonzero(lens >= read_len)[0]
+    cat = torch.from_numpy(np.concatenate(seqs)).to(device)
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)])[:-1]).to(device)
+    okt = torch.from_numpy(ok).to(device)
+    lens_t = torch.from_numpy(lens).to(device)
+    ar = torch.arange(read_len, device=device)
+    for c0 in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - c0)
+        gi = okt[torch.randint(0, len(ok), (m,), generator=g, device=device)]
+        ins = torch.minimum(torch.randint(ins_lo, ins_hi + 1, (m,), generator=g, device=device), lens_t[gi])
+        st = (torch.rand(m, generator=g, device=device, dtype=torch.float64) * (lens_t[gi] - ins + 1).double()).long()
+        a = cat[(offs[gi] + st)[:, None] + ar[None, :]]
+        b = 3 - cat[(offs[gi] + st + ins - read_len)[:, None] + ar[None, :]].flip(1)
+        sw = torch.rand(m, generator=g, device=device) < 0.5
+        both = torch.stack([torch.where(sw[:, None], b, a), torch.where(sw[:, None], a, b)], dim=1).view(2 * m, read_len)
+        if sub_rate > 0:
+            mut = torch.rand(both.shape, generator=g, device=device) < sub_rate
+            add = torch.randint(1, 4, both.shape, generator=g, device=device, dtype=torch.uint8)
+            both = torch.where(mut, (both + add) & 3, both)
+        yield c0, both
+
+
+def make_packed_pairs(seqs, n_pairs, read_len=150, seed=1, device="cuda", chunk=1 << 20, keep_codes=0, **kw):
+    """iter_pair_codes packed into the kmahip_reads CSR layout with the mates interleaved (read 2i, 2i + 1 = pair i: what
+    kmahip_scan_pe takes). -> dict like make_packed_reads; codes = (m1 u8[keep, L], m2 u8[keep, L]) of the first keep_codes pairs."""
+    W = (read_len + 31) // 32
+    n = 2 * n_pairs
+    out = torch.zeros((n, W + 1), dtype=torch.int64, device=device)
+    shifts = (62 - 2 * torch.arange(32, device=device, dtype=torch.int64))
+    keep1, keep2 = [], []
+    for c0, both in iter_pair_codes(seqs, n_pairs, read_len=read_len, seed=seed, device=device, chunk=chunk, **kw):
+        m = both.shape[0] // 2
+        if c0 < keep_codes:
+            k = min(m, keep_codes - c0)
+            keep1.append(both[0:2 * k:2].cpu()); keep2.append(both[1:2 * k:2].cpu())
+        pad = W * 32 - read_len
+        r64 = both.long()
+        if pad:
+            r64 = torch.cat([r64, torch.zeros((2 * m, pad), dtype=torch.int64, device=device)], dim=1)
+        out[2 * c0:2 * (c0 + m), :W] = (r64.view(2 * m, W, 32) << shifts[None, None, :]).sum(dim=2)
+        del both, r64
+    return dict(
+        seq=out.view(-1),
+        seq_off=torch.arange(n + 1, device=device, dtype=torch.int64) * (W + 1),
+        length=torch.full((n,), read_len, dtype=torch.int32, device=device),
+        N=torch.zeros(1, dtype=torch.int32, device=device),
+        N_off=torch.zeros(n + 1, dtype=torch.int64, device=device),
+        codes=((torch.cat(keep1).numpy(), torch.cat(keep2).numpy()) if keep1 else None),
+    )
+
+
 def make_long_reads_packed(genome, n_reads, read_len=10000, sub=0.04, dele=0.03, ins=0.03, rc_frac=0.5, seed=8, device="cuda",
                            chunk=2048, keep_codes=0):
     """ONT-like reads of one genome (SURVEY.md §8d "ONT-10k": windows of read_len bases, substitutions / deletions / insertions,

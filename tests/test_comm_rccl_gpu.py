@@ -89,6 +89,7 @@ def _run(args, env=None):
 def _same_files(a, b, min_rows=30):
     assert open(a + ".res", "rb").read() == open(b + ".res", "rb").read() and open(a + ".res").read().count("\n") > min_rows
     assert open(a + ".fsa", "rb").read() == open(b + ".fsa", "rb").read()
+    assert open(a + ".aln", "rb").read() == open(b + ".aln", "rb").read()
     assert gzip.open(a + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
 
 

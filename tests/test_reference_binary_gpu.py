@@ -1,6 +1,6 @@
 """End to end against the compiled reference itself (oracle/_ref/kma, which travels to the GPU box): a seeded read set with
 substitutions, indels, unmappable reads, partly foreign reads, N's and ragged lengths goes through `kma -1t1 -t 1` and through
-examples/kmahip_map (kmahip_ingest_*, kmahip_run_se, the writers); `.res`, `.fsa` and `.frag.gz` must be identical."""
+examples/kmahip_map (kmahip_ingest_*, kmahip_run_se, the writers); `.res`, `.fsa`, `.aln` and `.frag.gz` must be identical."""
 import gzip
 import os
 import subprocess
@@ -71,6 +71,7 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants, m
                    stderr=subprocess.DEVNULL, env=env)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 40000
@@ -117,6 +118,7 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="700") if mf else None)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 50000
@@ -182,6 +184,7 @@ def test_paired_fuzz_equals_reference_binary(tmp_path, seed):
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="300"))
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 3000
@@ -214,6 +217,7 @@ def test_paired_stream_of_singles_equals_reference_binary(tmp_path):
                        check=True, stderr=subprocess.DEVNULL)
         assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
         assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), case
+        assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read(), case
         got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
         assert got == ref, case
         assert (got.count(b"\n") > 3000) == (case == "singles")
@@ -242,6 +246,7 @@ def test_run_where_nothing_maps_equals_reference_binary(tmp_path, mode):
                     "-1t1" if mode == "-1t1" else "-chain"], check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read() == b""
 
 
@@ -310,8 +315,9 @@ def test_empty_input_equals_reference_binary(tmp_path, mode):
         if r.returncode == 0 and os.path.exists(tmp_path / "ref.res"):
             assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), case
             assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), case
+            assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read(), case
             assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read() == b"", case
-        for f in ("ref.res", "ref.fsa", "ref.frag.gz", "got.res", "got.fsa", "got.frag.gz"):
+        for f in ("ref.res", "ref.fsa", "ref.aln", "ref.frag.gz", "got.res", "got.fsa", "got.aln", "got.frag.gz"):
             if os.path.exists(tmp_path / f):
                 os.unlink(tmp_path / f)
 
@@ -370,9 +376,39 @@ def test_whole_mt1_bcnano_run_equals_reference_binary(tmp_path, env):
         assert m and int(m.group(1)) >= 4, run.stderr[-400:]
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
     assert got.count(b"\n") > 1000
+
+
+def test_deep_pile_up_of_long_reads_equals_reference_binary(tmp_path):
+    """The pile-up at the depth BASELINE config C4 has at its own size (1 M reads of 10 kb on 5 Mb: 2 000 x), which no other test reaches:
+    5 200 ONT-like reads of 10 kb (10 % errors: every read brings hundreds of insertion runs) on ONE template of 45 kb -- depth above
+    1 000 x everywhere, insertion chains of dozens of columns between neighbouring template positions whose order and starting depths
+    follow the order of the reads, and base counts that pass the 16-bit saturation of alnToMat's counters with -Mt1's raw piling
+    (assembly.c:1359-1442) -- `kma -Mt1 1 -bcNano -t 1` against `kmahip_map -Mt1 1 -bcNano`: .res, .fsa, .frag.gz."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(23)
+    genome = rng.integers(0, 4, 45_000, dtype=np.uint8)
+    fsa = str(tmp_path / "g.fsa")
+    synth.write_fasta(fsa, ["deep template"], [genome])
+    prefix = str(tmp_path / "db")
+    subprocess.run([KMA, "index", "-i", fsa, "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = synth.make_long_reads(genome, 5200, read_len=10000, sub=0.04, dele=0.03, ins=0.03, seed=6)
+    fq = str(tmp_path / "ont.fq")
+    synth.write_fastq(fq, reads, prefix="r", qual=b"5")
+    subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-Mt1", "1", "-bcNano", "-t", "1"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-Mt1", "1", "-bcNano"], check=True,
+                   stderr=subprocess.PIPE)
+    res = open(tmp_path / "ref.res").read().splitlines()
+    assert len(res) == 2 and float(res[1].split("\t")[8]) > 1000.0, res          # the Depth column
+    assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
+    assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
+    assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read()
 
 
 def _pe_branch_db_and_pairs(rng, n_fam, n):
@@ -451,6 +487,7 @@ def test_pe_unmated_and_single_mate_branches_equal_reference_binary(tmp_path):
                    check=True, stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref
 
@@ -479,5 +516,6 @@ def test_direct_address_index_written_by_kma_index(tmp_path, k, flags):
                    stderr=subprocess.DEVNULL)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
+    assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read()
     got, ref = gzip.open(tmp_path / "got.frag.gz", "rb").read(), gzip.open(tmp_path / "ref.frag.gz", "rb").read()
     assert got == ref and got.count(b"\n") > 10000

@@ -56,6 +56,7 @@ def _run(args, env=None, ok=True):
 def _same_files(a, b):
     assert open(a + ".res", "rb").read() == open(b + ".res", "rb").read() and open(a + ".res").read().count("\n") > 30
     assert open(a + ".fsa", "rb").read() == open(b + ".fsa", "rb").read()
+    assert open(a + ".aln", "rb").read() == open(b + ".aln", "rb").read() and os.path.getsize(a + ".aln") > 1000
     assert gzip.open(a + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
 
 
@@ -131,7 +132,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         subprocess.run([KMA] + args + ["-o", ref] + ([] if "-t" in args else ["-t", "1"]), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         _run(args + ["-o", got])
         assert open(got + ".res", "rb").read() == open(ref + ".res", "rb").read(), args
-        for ext, opener in ((".fsa", open), (".frag.gz", gzip.open)):
+        for ext, opener in ((".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
             assert os.path.exists(got + ext) == os.path.exists(ref + ext), (args, ext)
             if os.path.exists(ref + ext):
                 a, b = opener(got + ext, "rb").read(), opener(ref + ext, "rb").read()
