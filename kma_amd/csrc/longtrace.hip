@@ -116,6 +116,8 @@ struct LtArgs {
 	int32_t *lq;              // the lane queue: problem indices of all lane classes (prob_cap), sorted by lkey before the kernels run
 	uint32_t *lkey;           // (lane class << 24) | iterations of the problem's sweep
 	int stop;                 // diagnosis (KMAHIP_LT_STOP): 1 = reads end after their seeding, 2 = after the chain
+	int lane_turns;           // a lane takes problems of up to this many cells (one per turn, a quarter of a microsecond each: the longest problem of
+	                          // a class is what its kernel lasts; longer ones go to the wavefront-per-problem kernels). KMAHIP_LT_LANE_TURNS
 	int lane_mask;            // diagnosis (KMAHIP_LT_LANE=f / b): 1 = full-matrix classes only, 2 = banded only, 3 = both
 	int lane_tq;              // 0: no lane classes; else the largest rows + columns whose scores stay inside 16 bits
 	uint32_t *tmp;            // per finishing wavefront: tmp_cap words
@@ -582,14 +584,15 @@ __host__ __device__ __forceinline__ LaneGeom lt_lane_geom(int j) {
 	else { g.R = 144; g.RQ = 256; g.TW = 32; g.ecap = 65536; }
 	return g;
 }
-__device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, int tq_max, int mask, int *iters) {
+__device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, int tq_max, int mask, int turn_cap, int *iters) {
 	if(!tq_max || t_l + q_l > tq_max || t_l < 1 || q_l < 1) return -1;
 	if(!(mask & (band ? 2 : 1))) return -1;
 	if(band == 0) {
 		const int64_t e = (int64_t) (q_l + 1) * (t_l + 1) + 4;
 		for(int j = 0; j < LT_LFULL; ++j) {
 			const LaneGeom g = lt_lane_geom(j);
-			if(q_l + 1 <= g.R && e <= g.ecap && t_l < 16 * g.TW) { *iters = (q_l + 1) * t_l; return j; }
+			if(!((mask >> (8 + j)) & 1)) continue;
+			if(q_l + 1 <= g.R && e <= g.ecap && t_l < 16 * g.TW) { *iters = (q_l + 1) * t_l; return *iters <= turn_cap ? j : -1; }
 		}
 		return -1;
 	}
@@ -600,7 +603,8 @@ __device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, 
 	const int64_t e = (int64_t) (band + 2) * (t_l + 1) + 4;
 	for(int j = LT_LFULL; j < LT_LCLS; ++j) {
 		const LaneGeom g = lt_lane_geom(j);
-		if(band + 3 <= g.R && q_l <= g.RQ && e <= g.ecap && t_l < 16 * g.TW) { *iters = (band + 2) * t_l; return j; }
+		if(!((mask >> (8 + j)) & 1)) continue;
+		if(band + 3 <= g.R && q_l <= g.RQ && e <= g.ecap && t_l < 16 * g.TW) { *iters = (band + 2) * t_l; return *iters <= turn_cap ? j : -1; }
 	}
 	return -1;
 }
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					}
 					// queues per class, one atomic per class and round
 					int l_iters = 0;
-					const int lcls = dp && rfit ? lt_lane_class(J.q_l, J.t_l, J.band, J.k, A.lane_tq, A.lane_mask, &l_iters) : -1;
+					const int lcls = dp && rfit ? lt_lane_class(J.q_l, J.t_l, J.band, J.k, A.lane_tq, A.lane_mask, A.lane_turns, &l_iters) : -1;
 					{
 						// the lane classes share one queue (sorted by class and sweep length before their kernels run)
 						const unsigned long long m = __ballot(lcls >= 0);
@@ -1722,6 +1726,141 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 	}
 }
 
+// ---- round 4: the DP row in REGISTERS ---------------------------------------------------------------------------------------------
+// lt_lane_kernel keeps a lane's row in LDS (an address, a read and a write per cell, 4-16 KB of LDS per wavefront: 1-4 wavefronts per
+// SIMD) and takes one flat turn per cell, whose column it has to look up: 72 vector instructions per cell, issued in half of the
+// wavefront's cycles (profiles/r3_c4_sq_counters.txt). Here the row is R registers: the loop over a row's columns is unrolled, so the
+// column of a cell is a constant -- no LDS traffic for the row, no address arithmetic, the query base by a constant shift out of
+// registers filled once per problem, the boundary column and the end of a row straight-line code, four move bytes packed by constant
+// shifts per store. A lane's columns are aligned to the RIGHT (column n sits in register n + R - 1 - q_len: the boundary column in the
+// last one for every lane), the registers to the left of column 0 compute garbage that nothing reads (a cell depends on the cells
+// to its right and below only). The move byte says diagonal / gap in the read / gap in the template, which is all lt_walk asks of
+// it ((e & 7) == 1, >= 4, else), with the reference's tie rules: the diagonal wins every tie (nw.c:150-158 `D <= x`), an
+// extended gap in the read (P) wins against Q exactly when it beat its own opening (`Pn < x`), an opened one loses to Q.
+typedef uint32_t __attribute__((aligned(1))) lt_u32_u;
+
+template <int R>
+__global__ __launch_bounds__(64, (R <= 32 ? 5 : R <= 48 ? 4 : 3)) void lt_reg_kernel(const LtArgs A, const LaneArgs L) {
+	extern __shared__ uint32_t lt_lane_lds[];
+	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
+	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64 query codes
+	const int lane = threadIdx.x;
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
+	uint8_t *const Em = E + 128;                                 // (room below row 0 for the bytes of the registers left of column 0)
+	const int U = A.U, W1 = A.W1;
+	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
+	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
+		const LaneProb X = lt_lane_stage<false>(A, L, base, lane, T, QB);
+		LtProb *P = X.P;
+		const bool live = X.live;
+		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
+		const int pitch = q_len + 1;
+		const int low = (t_len + q_len) * (A.MM + U + W1);
+		const int off = R - 1 - q_len;                           // register of column 0
+		wave_sync();
+		// the query codes, eight to a register; the boundary row (nw.c:60-97)
+		uint32_t qreg[R / 8], row[R];
+#pragma unroll
+		for(int w = 0; w < R / 8; ++w) qreg[w] = 0;
+#pragma unroll
+		for(int j = 0; j < R; ++j) {
+			const int n = j - off;
+			const bool in = live && n >= 0 && n < q_len;
+			const uint32_t code = in ? (uint32_t) QB[n * 64 + lane] : 0u;
+			qreg[j >> 3] |= code << ((j & 7) << 2);
+			const int D = (in && k != 2) ? W1 + (q_len - 1 - n) * U : 0;
+			row[j] = lt_pack16(D, low);
+		}
+		if(live) {
+			for(int n = 0; n <= q_len; ++n) Em[(size_t) pitch * t_len + n] = (uint8_t) ((n < q_len && k != 2) ? ((n == q_len - 1) ? 18 : 3) : 0);
+		}
+		int score = low, best_m = 0, d0 = 0;
+		const int rows = live && !(L.ablate & 4) ? t_len : 0;
+		const int rows_max = wave_max(rows);
+		uint32_t tw = 0;
+		if(rows) tw = T[(((rows - 1) >> 4) << 6) + lane];
+		for(int r = 0; r < rows_max; ++r) {
+			if(r < rows) {
+				const int m = t_len - 1 - r;
+				const int tb = (int) ((tw >> (30 - ((m & 15) << 1))) & 3u);
+				if((m & 15) == 0 && m) tw = T[(((m - 1) >> 4) << 6) + lane];
+				const int bnd = (0 < k) ? 0 : (W1 + r * U);
+				const uint32_t bcode = (0 < k) ? 0u : (r ? 5u : 36u);
+				// the boundary column (nw.c:100-118), then the row right to left
+				int diag = (int) (short) (row[R - 1] & 0xffffu), right = bnd, Qprev = low;
+				row[R - 1] = lt_pack16(bnd, low);
+				uint32_t ew = bcode << 24;
+				// (what depends on the column only -- a register's query code, whether it is column 0 -- is the same in every row: opaque
+				// copies per row keep the compiler from computing all of it in front of the loop, R and 2 R registers that it then spills)
+				const int offr = lt_vgpr(off);
+#pragma unroll
+				for(int w = 0; w < R / 8; ++w) asm volatile("" : "+v"(qreg[w]));
+				uint8_t *const er = Em + (size_t) pitch * m - offr;      // byte of register j: er[j]
+#pragma unroll
+				for(int j = R - 2; j >= 0; --j) {
+					const uint32_t below = row[j];
+					const int Db = (int) (short) (below & 0xffffu), Pb = ((int) below) >> 16;
+					const int qb = (int) ((qreg[j >> 3] >> ((j & 7) << 2)) & 15u);
+					const bool eq = qb == tb;
+					const int sc = eq ? dM : ((qb & 4) ? dN : dX);
+					const int Q0 = right + W1, Qe = Qprev + U;
+					const bool c1 = Q0 < Qe;
+					const int Q = max(Q0, Qe);
+					const int P0 = Db + W1, Pe = Pb + U;
+					const bool c2 = P0 < Pe;
+					const int Pn = max(P0, Pe);
+					const int x = diag + sc;
+					const int G = max(Pn, Q);
+					const int D = max(G, x);
+					const bool pw = Pn + (c2 ? 1 : 0) > Q;          // c2 ? Pn >= Q : Pn > Q
+					uint32_t cell = (G <= x) ? (eq ? 1u : 65u) : (pw ? 4u : 2u);
+					cell |= (c1 ? 0u : 16u) | (c2 ? 0u : 32u);
+					row[j] = lt_pack16(D, Pn);
+					d0 = (j == offr) ? D : d0;
+					ew |= cell << ((j & 3) << 3);
+					if((j & 3) == 0) {
+						// (every word of the row, also those left of column 0: their bytes fall on rows written later, or in front of the
+						// matrix; a store under a condition made the compiler put the four move bytes' arithmetic behind a branch)
+						*(lt_u32_u *) (er + j) = ew;
+						ew = 0;
+					}
+					diag = Db; right = D; Qprev = Q;
+					// (the scheduler would otherwise lift the column-only part of all R cells -- unpacking, query code, P side -- to the
+					// front of the row: hundreds of live registers, spilled)
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				if(k < 0 && score < d0) { score = d0; best_m = m; }
+			}
+		}
+		// result selection (nw.c:218-254)
+		int sm = 0, sn = 0;
+		if(live) {
+			if(k < 0) {
+				sm = best_m;
+				if(k == -2) {
+					const int off2 = lt_vgpr(off);          // (not to be compared with R constants in front of the sweep)
+#pragma unroll
+					for(int j = 0; j < R - 1; ++j) {
+						const int Dn = (int) (short) (row[j] & 0xffffu);
+						if(j >= off2 && score <= Dn) { score = Dn; sm = 0; sn = j - off2; }
+					}
+				}
+			} else score = d0;
+		}
+		wave_sync_hbm();   // the matrix is read back by the lane that wrote it
+		if(live && !(L.ablate & 2)) {
+			RunOut Ro;
+			Ro.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = sn, bad = 0;
+			const int q_pos = lt_walk((const uint8_t *) Em, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : Ro.n;
+			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
+		}
+	}
+}
+
 // ---- per read: the runs of its problems and MEMs in chain order, merged; alignment figures; the read filter of assemble_KMA
 // (assembly.c:1931-1961: + Wl for an alignment that starts at the first / ends at the last template base, minlen, mrc, scoreT)
 __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
@@ -1900,12 +2039,15 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(p->rw.d[i][j] != want) simple_sc = false;
 	}
 	if(getenv("KMAHIP_LT_SCORE_TABLE")) simple_sc = false;
+	const bool reg_rows = simple_sc && !(getenv("KMAHIP_LT_REG") && getenv("KMAHIP_LT_REG")[0] == '0');      // lt_reg_kernel for the classes of up to 64 cells a row
 	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
 	LaneLaunch lg[LT_LCLS];
 	for(int j = 0; j < LT_LCLS; ++j) {
 		lg[j].g = lt_lane_geom(j);
 		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * (j < LT_LFULL ? 64 : 32);
 		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
+		// (lt_reg_kernel keeps no row in LDS: its wavefronts per CU follow from its registers -- 5 / 5 / 4 / 3 per SIMD)
+		if(j <= 3 && reg_rows) lg[j].wgs = 256 * (j <= 1 ? 20 : j == 2 ? 16 : 12);
 		lg[j].e_off = 0;
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
@@ -1944,6 +2086,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4)) ||
 		   (lane_tq && (rc = lt_reserve(ws, 8, (size_t) 4 * prob_cap * 4)))) return rc;
 		A.lq = (int32_t *) ws->lt_buf[8]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[8] + prob_cap : nullptr; A.lane_tq = lane_tq; A.lane_mask = getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'f' ? 1 : (getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'b' ? 2 : 3);
+		A.lane_turns = getenv("KMAHIP_LT_LANE_TURNS") ? atoi(getenv("KMAHIP_LT_LANE_TURNS")) : (1 << 30);          // (tools/c4_time.py, 400 k reads: no cap 579 ms, 16 000 566, 12 000 590, 8 000 716, 5 000 994)
+		// bits 8 + j: lane class j in use (KMAHIP_LT_LCLS: a bit per class, default all nine)
+		A.lane_mask |= (getenv("KMAHIP_LT_LCLS") ? (int) strtol(getenv("KMAHIP_LT_LCLS"), nullptr, 0) & 0x1ff : 0x1ff) << 8;
 		A.r0 = r0; A.n_reads = nb;
 		A.rd = (LtRead *) ws->lt_buf[1]; A.prob = (LtProb *) ws->lt_buf[2]; A.prob_cap = prob_cap;
 		A.runs = (uint32_t *) ws->lt_buf[3]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[4];
@@ -2078,7 +2223,16 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				const void *fn = j < LT_LFULL ? (simple_sc ? (const void *) lt_lane_kernel<true> : (const void *) lt_lane_kernel<false>)
 				                       : (simple_sc ? (const void *) lt_lane_band_kernel<true> : (const void *) lt_lane_band_kernel<false>);
 				if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
-				if(j < LT_LFULL) { if(simple_sc) hipLaunchKernelGGL(lt_lane_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
+				if(j <= 3 && reg_rows) {
+					// rows of up to 64 cells: the row in registers (lt_reg_kernel); no LDS but the staged template rows and query codes
+					const size_t lds = (size_t) (32 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 64;
+					const unsigned rgrid = grid;          // (the move matrices' scratch is sized for lg[j].wgs workgroups)
+					if(j == 0) hipLaunchKernelGGL((lt_reg_kernel<16>), dim3(rgrid), dim3(64), lds, ls, A, La);
+					else if(j == 1) hipLaunchKernelGGL((lt_reg_kernel<32>), dim3(rgrid), dim3(64), lds, ls, A, La);
+					else if(j == 2) hipLaunchKernelGGL((lt_reg_kernel<48>), dim3(rgrid), dim3(64), lds, ls, A, La);
+					else hipLaunchKernelGGL((lt_reg_kernel<64>), dim3(rgrid), dim3(64), lds, ls, A, La);
+				}
+				else if(j < LT_LFULL) { if(simple_sc) hipLaunchKernelGGL(lt_lane_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
 				else { if(simple_sc) hipLaunchKernelGGL(lt_lane_band_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_band_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
 				if(dbg) {
 					std::vector<uint32_t> hk((size_t) cnt);

@@ -828,30 +828,48 @@ __global__ __launch_bounds__(STHREADS, TSLOTS == TS1 ? KMAHIP_SCAN_WAVES : (STHR
 			}
 			__syncthreads();
 		}
-		if(tid < ng) {
+		if(tid < SG) {
+			// (the SG lanes that hold the items: lanes 0 .. SG - 1 of the first wavefront)
 			const int g = tid;
+			const bool mine = g < ng;
 			const int64_t item = s_item[g];
-			int best = 0, nb = 0;
-			int64_t off = 0;
+			int best = 0, nb = 0, want = 0;
+			bool over = false;
 #ifdef KMAHIP_DIAG
-			if(A.ablate & 16) { nb = 0; s_off[g] = -1; } else
+			if(A.ablate & 16) { nb = 0; } else
 #endif
-			if(s_over[g]) {
-				const unsigned long long slot = atomicAdd(&A.counters[A.out_count], 1ull);
-				A.out_over[slot] = item;
-				nb = -1;
-				s_off[g] = -1;
-			} else {
+			if(mine && s_over[g]) { over = true; nb = -1; }
+			else if(mine) {
 				// MODE 1, get_kmers_for_pair (savekmers.c:427-688): all candidates, first-seen order, clamped scores, the hit count
 				best = MODE ? s_hits[g] : s_best[g];
 				nb = (MODE || best > 0) ? s_nb[g] : 0;
-				if(nb) off = (!MODE && nb <= INL) ? item * INL : A.pool_tail0 + (int64_t) atomicAdd(&A.counters[C_POOL], (unsigned long long) nb);
+				if(nb && (MODE || nb > INL)) want = nb;
+			}
+			// pool room for the lists that do not fit the inline slots, and places in the overflow list: ONE atomic per workgroup and
+			// counter (an atomic per item on one address -- every item in the all-candidates mode of paired reads -- took more than the scan)
+			int incl = want, oincl = over ? 1 : 0;
+#pragma unroll
+			for(int d = 1; d < SG; d <<= 1) {
+				const int a = __shfl_up(incl, d, SG), b = __shfl_up(oincl, d, SG);
+				if((tid & (SG - 1)) >= d) { incl += a; oincl += b; }
+			}
+			const int tot = __shfl(incl, SG - 1, SG), otot = __shfl(oincl, SG - 1, SG);
+			unsigned long long pbase = 0, obase = 0;
+			if(tid == 0 && tot) pbase = atomicAdd(&A.counters[C_POOL], (unsigned long long) tot);
+			if(tid == 0 && otot) obase = atomicAdd(&A.counters[A.out_count], (unsigned long long) otot);
+			pbase = __shfl(pbase, 0, SG); obase = __shfl(obase, 0, SG);
+			int64_t off = 0;
+			if(over) { A.out_over[obase + (unsigned long long) (oincl - 1)] = item; s_off[g] = -1; }
+			else if(mine) {
+				if(nb) off = want ? A.pool_tail0 + (int64_t) pbase + (incl - want) : item * INL;
 				if(nb && off + nb > A.pool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); s_off[g] = -1; }
 				else s_off[g] = nb ? off : -1;
 			}
-			A.item_score[item] = best;
-			A.item_n[item] = nb;
-			A.item_off[item] = off;
+			if(mine) {
+				A.item_score[item] = best;
+				A.item_n[item] = nb;
+				A.item_off[item] = off;
+			}
 		}
 		__syncthreads();
 		for(int part = 0; part < TSLOTS * SG; part += STHREADS) {
@@ -1671,12 +1689,14 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 		HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventCreate(&evp)); HIP_TRY(hipEventCreate(&evq));
 		HIP_TRY(hipEventRecord(evp, stream));
 	}
-	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
+	if(ws->stats_on) hipLaunchKernelGGL((scan_prefilter_kernel<true>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((2 * n + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, A);
 	if(ws->timing_on) { HIP_TRY(hipEventRecord(evq, stream)); HIP_TRY(hipEventRecord(ev0, stream)); }
 	const unsigned grid = (unsigned) ((2 * n + SG - 1) / SG);
 	int64_t *over1 = ws->overflow_items, *over2 = ws->overflow_items + 2 * ws->cap_reads;
 	A.in_items = ws->active_items; A.in_count = C_NACT; A.out_over = over1; A.out_count = C_NOVER;
-	hipLaunchKernelGGL((scan_se_kernel<false, 1, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	if(ws->stats_on) hipLaunchKernelGGL((scan_se_kernel<true, 1, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
+	else hipLaunchKernelGGL((scan_se_kernel<false, 1, TS1>), dim3(grid), dim3(STHREADS), 0, stream, A);
 	if(ws->timing_on) {
 		HIP_TRY(hipEventRecord(ev1, stream));
 		if(!ws->events) ws->events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
