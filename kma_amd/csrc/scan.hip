@@ -855,9 +855,19 @@ __global__ __launch_bounds__(STHREADS, TSLOTS == TS1 ? KMAHIP_SCAN_WAVES : (STHR
 			}
 			const int tot = __shfl(incl, SG - 1, SG), otot = __shfl(oincl, SG - 1, SG);
 			unsigned long long pbase = 0, obase = 0;
-			if(tid == 0 && tot) pbase = atomicAdd(&A.counters[C_POOL], (unsigned long long) tot);
+			// all-candidates mode, first tier: every item has a list, and even one atomic per workgroup on the pool's one counter is
+			// 6 ns a workgroup -- as long as the whole scan took. The lists take fixed places instead (the item's place in the active
+			// list x the most a first-tier table holds) whenever the pool has the room; the second tier and the best-templates mode
+			// (a list longer than the inline slots is rare there) keep the counter.
+			const bool fixed = MODE && TSLOTS == TS1 && n_active * (int64_t) (TSLOTS - 2) <= A.pool_cap - A.pool_tail0;
+			if(fixed) {
+				pbase = (unsigned long long) first * (TSLOTS - 2); incl = tid * (TSLOTS - 2) + want;
+				if(first == 0 && tid == 0) atomicAdd(&A.counters[C_POOL], (unsigned long long) (n_active * (int64_t) (TSLOTS - 2)));      // (the later tiers allocate behind the fixed places)
+			}
+			else if(tid == 0 && tot) pbase = atomicAdd(&A.counters[C_POOL], (unsigned long long) tot);
 			if(tid == 0 && otot) obase = atomicAdd(&A.counters[A.out_count], (unsigned long long) otot);
-			pbase = __shfl(pbase, 0, SG); obase = __shfl(obase, 0, SG);
+			if(!fixed) pbase = __shfl(pbase, 0, SG);
+			obase = __shfl(obase, 0, SG);
 			int64_t off = 0;
 			if(over) { A.out_over[obase + (unsigned long long) (oincl - 1)] = item; s_off[g] = -1; }
 			else if(mine) {
@@ -1681,6 +1691,9 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	A.pool = ws->pool; A.pool_cap = ws->pool_cap; A.counters = ws->counters; A.overflow_items = ws->overflow_items;
 	A.dense = ws->dense; A.dense_slots = ws->dense_slots; A.active_items = ws->active_items;
 	A.ablate = 0; A.mode = 1; A.pool_sc = ws->pool_sc; A.pool_tail0 = 0; A.cat_bases = diag_cat_bases(db);
+#ifdef KMAHIP_DIAG
+	if(const char *e = getenv("KMAHIP_ABLATE_SCAN")) A.ablate = atoi(e);
+#endif
 	HIP_TRY(hipMemsetAsync(ws->counters, 0, sizeof(unsigned long long), stream));
 	HIP_TRY(hipMemsetAsync(ws->counters + 2, 0, (N_COUNTERS - 2) * sizeof(unsigned long long), stream));
 	if(n == 0) { HIP_TRY(hipMemsetAsync(out->R_off, 0, sizeof(int64_t), stream)); return KMAHIP_OK; }
