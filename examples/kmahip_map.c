@@ -87,7 +87,7 @@ static void *ingest_main(void *arg) {
 /* stage 1 batch by batch for the session (single end, -1t1, one rank): the reader parses the next batch while the device works on the
  * one before; a batch is handed over (state 1), uploaded by the main thread, and given back (state 0) */
 typedef struct stream_job {
-	const char *in1;
+	const char *in1, *in2;
 	kmahip_trim trim;
 	int64_t batch_reads, batch_bases;
 	kmahip_ingest *ing; kmahip_read_batch b;
@@ -97,7 +97,7 @@ typedef struct stream_job {
 static void *stream_main(void *arg) {
 	stream_job *j = (stream_job *) arg;
 	int whole = 0;
-	int rc = kmahip_ingest_open_part(j->in1, NULL, &j->trim, 0, 1, &j->ing, &whole);
+	int rc = kmahip_ingest_open_part(j->in1, j->in2, &j->trim, 0, 1, &j->ing, &whole);
 	if(!rc && j->batch_bases > 0) rc = kmahip_ingest_set_batch_bases(j->ing, j->batch_bases);
 	for(;;) {
 		if(!rc) rc = kmahip_ingest_next(j->ing, j->batch_reads, &j->b);
@@ -128,50 +128,6 @@ static void *touch_main(void *arg) {
 	touch_job *j = (touch_job *) arg;
 	for(int a = 0; a < 4; ++a) for(size_t i = 0; i < j->n[a]; i += 4096) __atomic_fetch_or(&j->p[a][i], 0, __ATOMIC_RELAXED);
 	return NULL;
-}
-
-/* While stage 1 is still reading: one run on reads cut out of the first template (word-aligned windows of 150 bases, as many reads as the
- * traceback keeps lanes), so that what the device path pays once per process -- the first launch of every kernel, the scratch that does
- * not depend on the batch -- is paid beside the I/O and not after it. The results are thrown away. */
-static void warm_up(kmahip_db *db, kmahip_ws *ws, const char *prefix, int64_t D, const kmahip_params *par) {
-	char path[4096];
-	int32_t hdr[3] = {0, 0, 0};
-	uint64_t w[64];
-	snprintf(path, sizeof path, "%s.length.b", prefix);
-	FILE *f = fopen(path, "rb");
-	if(!f || fread(hdr, 4, 3, f) != 3) { if(f) fclose(f); return; }
-	fclose(f);
-	const int tl = hdr[2];
-	if(tl < 192) return;
-	const int tw = (tl >> 5) + 1 < 64 ? (tl >> 5) + 1 : 64;
-	snprintf(path, sizeof path, "%s.seq.b", prefix);
-	f = fopen(path, "rb");
-	if(!f || fread(w, 8, (size_t) tw, f) != (size_t) tw) { if(f) fclose(f); return; }
-	fclose(f);
-	const int64_t n = 262144, nwin = tw - 5;
-	uint64_t *seq = calloc((size_t) n * 6 + 2, 8);
-	int64_t *off = malloc((size_t) (n + 1) * 8), *noff = calloc((size_t) n + 1, 8);
-	int32_t *len = malloc((size_t) n * 4), none = 0;
-	kmahip_run run;
-	memset(&run, 0, sizeof run);
-	run.rows = calloc((size_t) D, sizeof *run.rows); run.rows_cap = D;
-	run.assembly.cover = calloc((size_t) D, 8); run.assembly.aln_len = calloc((size_t) D, 8);
-	run.assembly.depth = calloc((size_t) D, 8); run.assembly.asm_len = calloc((size_t) D, 8);
-	if(seq && off && noff && len && run.rows && run.assembly.cover && run.assembly.aln_len && run.assembly.depth && run.assembly.asm_len && nwin > 0) {
-		for(int64_t i = 0; i < n; ++i) {
-			const uint64_t *src = w + i % nwin;
-			for(int x = 0; x < 4; ++x) seq[6 * i + x] = src[x];
-			seq[6 * i + 4] = src[4] & (~0ull << (64 - 2 * 22));          /* 150 = 4 x 32 + 22 bases */
-			off[i] = 6 * i; len[i] = 150;
-		}
-		off[n] = 6 * n;
-		kmahip_reads r;
-		memset(&r, 0, sizeof r);
-		r.n_reads = n; r.seq = seq; r.seq_off = off; r.len = len; r.N = &none; r.N_off = noff; r.seq_words = 6 * n; r.N_total = 0; r.max_len = 150;
-		(void) kmahip_run_se(db, ws, &r, par, 0.05, 1, 0, &run);
-	}
-	free(seq); free(off); free(noff); free(len); free(run.rows);
-	free(run.assembly.cover); free(run.assembly.aln_len); free(run.assembly.depth); free(run.assembly.asm_len);
 }
 
 /* the pipe to the waiting parent (see main): one byte = the exit status, written when the outputs are complete or the run has failed */
@@ -389,12 +345,13 @@ int main(int argc, char **argv) {
 	 * every exchange of the N-rank run goes through RCCL, on a box with a single device */
 	const int force_comm = world == 1 && getenv("KMAHIP_COMM_FORCE_RCCL") && getenv("KMAHIP_COMM_FORCE_RCCL")[0] == '1';
 	const double t_start = now_s(), t_before_main = since_process_start();
-	if(world == 1 && !force_comm && !input2 && !getenv("KMAHIP_MAP_ONE_BATCH")) {
-		/* the single-end run (-1t1, the default mode or -Mt1), batch by batch (kmahip_session_*): stage 1 of the next batch beside the device's work on
-		 * this one, the host holding one batch at a time. A batch: a million reads or a quarter of a gigabase, whichever comes first */
+	if(world == 1 && !force_comm && !getenv("KMAHIP_MAP_ONE_BATCH")) {
+		/* the run batch by batch (kmahip_session_*: -1t1 single end and paired, the default mode, -Mt1): stage 1 of the next batch beside the
+		 * device's work on this one, the host holding one batch at a time. A batch: a million records or a quarter of a gigabase,
+		 * whichever comes first */
 		stream_job sj;
 		memset(&sj, 0, sizeof sj);
-		sj.in1 = input; sj.trim = trim;
+		sj.in1 = input; sj.in2 = input2; sj.trim = trim;
 		sj.batch_reads = getenv("KMAHIP_MAP_BATCH") ? atoll(getenv("KMAHIP_MAP_BATCH")) : 1000000;
 		if(sj.batch_reads < 1) sj.batch_reads = 1;
 		sj.batch_bases = getenv("KMAHIP_MAP_BATCH_BASES") ? atoll(getenv("KMAHIP_MAP_BATCH_BASES")) : (256ll << 20);
@@ -416,7 +373,9 @@ int main(int argc, char **argv) {
 		kmahip_session *ses;
 		char mt1_frag[4096];
 		snprintf(mt1_frag, sizeof mt1_frag, "%s.frag.gz", out);
-		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp)) || (mt1 && kmahip_session_set_mt1(ses, mt1, one2one, no_frag ? NULL : mt1_frag))) die("session");
+		if(input2) hint *= 2;
+		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp)) || (mt1 && kmahip_session_set_mt1(ses, mt1, one2one, no_frag ? NULL : mt1_frag)) ||
+		   (input2 && kmahip_session_set_pe(ses))) die("session");
 		int batches = 0;
 		kmahip_db_info sinfo;
 		int64_t unpinned = 0;
@@ -469,13 +428,6 @@ int main(int argc, char **argv) {
 	const int64_t D = info.DB_size;
 	const double t_open = now_s();
 	if(getenv("KMAHIP_MAP_STOP") && !strcmp(getenv("KMAHIP_MAP_STOP"), "open")) { fprintf(stderr, "# kmahip_map: stopped after open: %.3f s in main, entered %.2f s after process start\n", t_open - t_start, t_before_main); finish(0); }
-	if(world == 1 && !force_comm) {	/* (worth it when stage 1 still has a few hundred milliseconds of reading in front of it: a gigabyte of text, or 128 MB of .gz;
-		 * behind a shorter input the warm-up itself would be what the run waits for) */
-		struct stat sb;
-		const size_t il = strlen(input);
-		const int gz = il > 3 && !strcmp(input + il - 3, ".gz");
-		if(!mt1 && !getenv("KMAHIP_MAP_NO_WARMUP") && stat(input, &sb) == 0 && sb.st_size >= (gz ? (128ll << 20) : (1ll << 30))) warm_up(db, ws, prefix, D, &par);
-	}
 	pthread_join(ingest_thread, NULL);
 	if(job.rc) { fprintf(stderr, "kmahip_map: ingest: %s\n", job.err); finish(1); }
 	kmahip_ingest *ing = job.ing;

@@ -643,6 +643,12 @@ int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm, const
  * .res + .fsa, fragment rows. */
 typedef struct kmahip_session kmahip_session;
 int kmahip_session_open(kmahip_db *db, kmahip_ws *ws, const kmahip_params *p, const kmahip_shard_opts *opts, int64_t reads_hint, kmahip_session **out);
+/* Paired input (`-ipe r1 r2 -apm p -1t1`; kmahip_run_pe) through the session: the batches of a paired reader (kmahip_ingest_open with
+ * two files: batch->pair says which reads are mates; a batch never ends inside a couple) are uploaded behind each other like single-end
+ * ones -- the host holds one batch at a time --, the first one is run through the stages once to pay for first launches and scratch
+ * while stage 1 reads on, and kmahip_session_finish runs kmahip_run_pe's stages on everything and writes the files. Before the first
+ * batch. */
+int kmahip_session_set_pe(kmahip_session *s);
 /* The reference's DEFAULT mode (no -1t1: kmahip_run_chain) through the same session: call once, before the first batch. A batch's
  * reads then go through the chain finder, and what the session keeps and maps are its records (a read, or its pieces, with their query
  * bounds); a fragment row carries the header of the read its record came from. cp: NULL = the defaults (kmahip_scan_chain). */

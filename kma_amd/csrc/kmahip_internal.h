@@ -191,3 +191,15 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
                           kmahip_pe_recs *out, hipStream_t stream);
 int kmahip_launch_align_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs,
                            const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, hipStream_t stream);
+
+// the paired run on a batch that is in HBM already (session.hip -> pipeline.hip): batch->reads holds DEVICE arrays (sizes and
+// max_len as usual), batch->pair the host's mate flags; the headers and the fragment writer's pinned text buffers are these
+struct KmaPeDev {
+	const char *d_names;
+	const int64_t *d_name_off;
+	char **h_text;
+	int64_t text_chunk;
+	int64_t *frag_rows;       // out: rows written to the fragment file (may be NULL)
+};
+int kmahip_run_pe_resident(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const KmaPeDev *pd, const kmahip_params *p, double evalue, int bcd,
+                           int64_t max_frag, const char *frag_path, kmahip_run *out);

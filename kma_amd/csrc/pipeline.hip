@@ -322,15 +322,22 @@ static int shard_chunk_token(ShardCtx *sc, bool receive, int64_t state[2]);
 static uint64_t *shard_frag_counts(ShardCtx *sc, size_t D);
 
 static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
-                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc);
+                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc, const KmaPeDev *pd);
 
 extern "C" int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
                              int64_t max_frag, const char *frag_path, kmahip_run *out) {
-	return run_pe_impl(db, ws, batch, p, evalue, bcd, max_frag, frag_path, out, nullptr);
+	return run_pe_impl(db, ws, batch, p, evalue, bcd, max_frag, frag_path, out, nullptr, nullptr);
+}
+
+// the paired run on reads and headers that are in HBM already (the batched session, session.hip: batch->reads holds DEVICE arrays,
+// batch->pair the host's flags, the headers are pd's)
+int kmahip_run_pe_resident(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const KmaPeDev *pd, const kmahip_params *p, double evalue, int bcd,
+                           int64_t max_frag, const char *frag_path, kmahip_run *out) {
+	return run_pe_impl(db, ws, batch, p, evalue, bcd, max_frag, frag_path, out, nullptr, pd);
 }
 
 static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
-                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc) {
+                       int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc, const KmaPeDev *pd) {
 	if(!db || !ws || !batch || !p || !out || !out->rows || !out->assembly.cover || !out->assembly.aln_len || !out->assembly.depth || !out->assembly.asm_len ||
 	   (!batch->pair && batch->reads.n_reads > 0)) {
 		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
@@ -338,7 +345,8 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	const kmahip_reads &R = batch->reads;
 	const int64_t n = R.n_reads;
 	if(n < 0 || n > 0x7ffffff0ll || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("bad batch size"); return KMAHIP_EINVAL; }
-	if(frag_path && n && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	if(frag_path && n && !pd && (!batch->names || !batch->name_off)) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	if(pd && sc) { kmahip_set_error("a resident batch is not sharded"); return KMAHIP_EINVAL; }
 	const size_t D = db->info.DB_size;
 	for(int i = 0; i < 6; ++i) out->ms[i] = 0;
 	out->n_rows = 0;
@@ -368,7 +376,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 		~Pinned() { if(th.joinable()) th.join(); for(int x = 0; x < 3; ++x) if(buf[x]) (void) hipHostFree(buf[x]); }
 	} pinned;
 	const int64_t pin_chunk = 64ll << 20;
-	if(frag_path && !sc && n > 100000 && !getenv("KMAHIP_PE_HOST_FRAG")) {
+	if(frag_path && !sc && !pd && n > 100000 && !getenv("KMAHIP_PE_HOST_FRAG")) {
 		int dev = 0;
 		(void) hipGetDevice(&dev);
 		pinned.th = std::thread([&pinned, dev, pin_chunk] {
@@ -381,8 +389,8 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	B.expect((size_t) R.seq_words * 16 + (size_t) R.N_total * 8 + (size_t) n * 420 + (64u << 20));
 	kmahip_reads dR = R;
 	dR.q_start = nullptr; dR.q_end = nullptr;
-	if((rc = B.up(R.seq, (size_t) R.seq_words, 2, &dR.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
-	   (rc = B.up(R.len, (size_t) n, 1, &dR.len)) || (rc = B.up(R.N, (size_t) R.N_total, 1, &dR.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &dR.N_off))) return rc;
+	if(!pd && ((rc = B.up(R.seq, (size_t) R.seq_words, 2, &dR.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
+	   (rc = B.up(R.len, (size_t) n, 1, &dR.len)) || (rc = B.up(R.N, (size_t) R.N_total, 1, &dR.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &dR.N_off)))) return rc;
 	const int32_t *d_first = nullptr, *d_uidx = nullptr;
 	if((rc = B.up(u_first.get(), (size_t) U, 1, &d_first)) || (rc = B.up(u_idx.get(), (size_t) U, 1, &d_uidx))) return rc;
 	kmahip_reads dP = dR, dS = dR;
@@ -404,7 +412,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	HostCols HC;
 	int64_t *h_src = nullptr, *h_rank = nullptr;
 	int32_t *h_rc = nullptr, *h_t = nullptr, *h_nh = nullptr, *h_stats = nullptr;
-	if(frag_path && n) {
+	if(frag_path && n && !pd) {
 		h_src = HC.get<int64_t>((size_t) n); h_rank = HC.get<int64_t>((size_t) n); h_rc = HC.get<int32_t>((size_t) n); h_t = HC.get<int32_t>((size_t) n);
 		h_nh = HC.get<int32_t>((size_t) n); h_stats = HC.get<int32_t>((size_t) n * 4);
 		if(!h_src || !h_rank || !h_rc || !h_t || !h_nh || !h_stats) { kmahip_set_error("out of host memory"); return KMAHIP_ENOMEM; }
@@ -625,15 +633,17 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	out->ms[4] = since(t);
 
 	// `.frag`: the per-fragment columns come back; the reads and their headers are the host batch's, through the fragments' read numbers
-	if(frag_path && nf > 0 && !getenv("KMAHIP_PE_HOST_FRAG")) {
-		// the fragments and their figures are in HBM: the headers go up, the rows are ordered and formatted there (session.hip); the host
-		// compresses. (KMAHIP_PE_HOST_FRAG: the columns back and the rows made on the host, as in round 2)
-		const char *d_names = nullptr;
-		const int64_t *d_name_off = nullptr;
-		if((rc = B.up(batch->names, (size_t) batch->name_off[n], 1, &d_names)) || (rc = B.up(batch->name_off, (size_t) n + 1, 0, &d_name_off))) return rc;
+	if(frag_path && nf > 0 && (pd || !getenv("KMAHIP_PE_HOST_FRAG"))) {
+		// the fragments and their figures are in HBM: the headers go up (a resident batch has them there), the rows are ordered and
+		// formatted there (session.hip); the host compresses. (KMAHIP_PE_HOST_FRAG: the columns back and the rows made on the host, as in round 2)
+		const char *d_names = pd ? pd->d_names : nullptr;
+		const int64_t *d_name_off = pd ? pd->d_name_off : nullptr;
+		if(!pd && ((rc = B.up(batch->names, (size_t) batch->name_off[n], 1, &d_names)) || (rc = B.up(batch->name_off, (size_t) n + 1, 0, &d_name_off)))) return rc;
 		int64_t rows = 0;
 		if(pinned.th.joinable()) pinned.th.join();
-		if((rc = kmahip_frag_write_dev(db, &dF, d_names, d_name_off, f_src, f_rc, f_t, f_nh, tr.stats, f_rank, mf + 1, frag_path, pin_chunk, pinned.ok ? pinned.buf : nullptr, &rows))) return rc;
+		if((rc = kmahip_frag_write_dev(db, &dF, d_names, d_name_off, f_src, f_rc, f_t, f_nh, tr.stats, f_rank, mf + 1, frag_path, pd ? pd->text_chunk : pin_chunk,
+		                               pd ? pd->h_text : (pinned.ok ? pinned.buf : nullptr), &rows))) return rc;
+		if(pd && pd->frag_rows) *pd->frag_rows = rows;
 	} else if(frag_path && nf > 0) {
 		int32_t *stats4 = nullptr;
 		if((rc = B.get((size_t) nf * 4 + 4, &stats4))) return rc;
@@ -1721,7 +1731,7 @@ extern "C" int kmahip_run_pe_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm *
 	run.assembly.cover = a0.data(); run.assembly.aln_len = a1.data(); run.assembly.depth = a2.data(); run.assembly.asm_len = a3.data();
 	run.caller = opts->caller; run.sig90 = opts->sig90; run.support = opts->support;
 	ShardCtx sc{comm, opts, out_prefix, ms, {}};
-	rc = run_pe_impl(db, ws, batch, p, opts->evalue, opts->bcd, opts->max_frag, nullptr, &run, &sc);
+	rc = run_pe_impl(db, ws, batch, p, opts->evalue, opts->bcd, opts->max_frag, nullptr, &run, &sc, nullptr);
 	for(int i = 0; i < 4; ++i) ms[i] = run.ms[i];
 	return rc;
 }

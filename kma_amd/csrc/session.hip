@@ -207,6 +207,12 @@ struct kmahip_session {
 	// the default mode (kmahip_session_set_chain): the arrays above hold RECORDS, with their query bounds and the read they came from;
 	// names / name_off stay per read
 	bool chain = false;
+	// paired input (kmahip_session_set_pe): the batches' reads and headers wait in HBM like the single-end ones, the mates' flags on the
+	// host (a byte per read); the stages run when the input has ended -- ConClave reads the finished score vectors anyway, and the
+	// stages before it take a tenth of a second per ten million pairs --, the first batch is run through stages 2 and 3a once and
+	// thrown away while stage 1 reads on (first launches, scratch: what a separate warm-up run used to pay for)
+	bool pe = false, pe_warm = false;
+	std::vector<uint8_t> pair;
 	kmahip_chain_params cp{};
 	DevArr qs, qe, rread;
 	int64_t n_reads = 0;
@@ -271,7 +277,7 @@ extern "C" void kmahip_session_close(kmahip_session *S) { delete S; }
 
 extern "C" int kmahip_session_set_mt1(kmahip_session *S, int32_t tmpl, int one2one, const char *frag_path) {
 	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	if(S->n || S->n_reads || !S->uploaded.empty() || S->chain || S->mt1) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty() || S->chain || S->mt1 || S->pe) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
 	if(tmpl < 1 || (size_t) tmpl >= S->db->info.DB_size) { kmahip_set_error("template %d out of range", tmpl); return KMAHIP_EINVAL; }
 	if(hipMalloc((void **) &S->mt1_sum, 8) != hipSuccess || hipMemset(S->mt1_sum, 0, 8) != hipSuccess) { kmahip_set_error("hipMalloc failed"); return KMAHIP_ENOMEM; }
 	if(frag_path) {
@@ -284,9 +290,16 @@ extern "C" int kmahip_session_set_mt1(kmahip_session *S, int32_t tmpl, int one2o
 	return KMAHIP_OK;
 }
 
+extern "C" int kmahip_session_set_pe(kmahip_session *S) {
+	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty() || S->chain || S->mt1) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	S->pe = true;
+	return KMAHIP_OK;
+}
+
 extern "C" int kmahip_session_set_chain(kmahip_session *S, const kmahip_chain_params *cp) {
 	if(!S) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
-	if(S->n || S->n_reads || !S->uploaded.empty() || S->mt1) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
+	if(S->n || S->n_reads || !S->uploaded.empty() || S->mt1 || S->pe) { kmahip_set_error("the mode of a session is chosen before its first batch"); return KMAHIP_EINVAL; }
 	S->chain = true;
 	if(cp) S->cp = *cp; else { S->cp.minlen = 16; S->cp.pad_ = 0; S->cp.coverT = 0.1; S->cp.mrs = 0.5; }
 	return KMAHIP_OK;
@@ -301,6 +314,12 @@ extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch 
 	if(nb < 0 || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("negative size"); return KMAHIP_EINVAL; }
 	if(nb == 0) return KMAHIP_OK;
 	if(!batch->names || !batch->name_off) { kmahip_set_error("the batch carries no read names"); return KMAHIP_EINVAL; }
+	if(S->pe) {
+		if(!batch->pair) { kmahip_set_error("a paired session needs the batch's mate flags"); return KMAHIP_EINVAL; }
+		// (the reader never cuts a couple: a batch ends behind a second mate or a single read)
+		if(batch->pair[nb - 1] == 1) { kmahip_set_error("a batch of a paired session ends inside a couple"); return KMAHIP_EINVAL; }
+		S->pair.insert(S->pair.end(), batch->pair, batch->pair + nb);
+	}
 	hipStream_t s = 0;
 	auto t = std::chrono::steady_clock::now();
 	int rc;
@@ -366,6 +385,7 @@ extern "C" int kmahip_session_upload(kmahip_session *S, const kmahip_read_batch 
 }
 
 static int session_map_one(kmahip_session *S, Batch &B);
+static int session_warm_pe(kmahip_session *S, Batch &B);
 
 // ... second half: stages 2 and 3a on every batch that has been uploaded and not mapped yet
 extern "C" int kmahip_session_map(kmahip_session *S) {
@@ -373,7 +393,7 @@ extern "C" int kmahip_session_map(kmahip_session *S) {
 	while(!S->uploaded.empty()) {
 		Batch B = std::move(S->uploaded.front());
 		S->uploaded.erase(S->uploaded.begin());
-		const int rc = session_map_one(S, B);
+		const int rc = S->pe ? session_warm_pe(S, B) : session_map_one(S, B);
 		if(rc) return rc;
 	}
 	return KMAHIP_OK;
@@ -382,6 +402,41 @@ extern "C" int kmahip_session_map(kmahip_session *S) {
 extern "C" int kmahip_session_add(kmahip_session *S, const kmahip_read_batch *batch) {
 	const int rc = kmahip_session_upload(S, batch);
 	return rc ? rc : kmahip_session_map(S);
+}
+
+// paired session: nothing is mapped before the input has ended (kmahip_session_finish), but the first batch goes through the whole
+// paired run once, results thrown away, while stage 1 reads on: the first launch of every kernel and the workspace's scratch are
+// paid for beside the I/O (what examples/kmahip_map's warm-up on made-up reads was for)
+static int session_pe_view(kmahip_session *S, int64_t r0, int64_t n, kmahip_read_batch *hb) {
+	memset(hb, 0, sizeof *hb);
+	kmahip_reads &W = hb->reads;
+	W.n_reads = n; W.seq = S->seq.as<uint64_t>(); W.seq_off = S->seq_off.as<int64_t>() + r0; W.len = S->len.as<int32_t>() + r0; W.N = S->N.as<int32_t>(); W.N_off = S->N_off.as<int64_t>() + r0;
+	W.seq_words = S->words; W.N_total = S->nN; W.max_len = S->max_len;
+	hb->pair = S->pair.data() + r0;
+	return KMAHIP_OK;
+}
+
+static int session_warm_pe(kmahip_session *S, Batch &B) {
+	if(S->pe_warm || getenv("KMAHIP_SESSION_NO_WARM")) return KMAHIP_OK;
+	S->pe_warm = true;
+	int64_t n = std::min<int64_t>(B.n, 262144);
+	while(n > 0 && S->pair[(size_t) (B.r0 + n - 1)] == 1) --n;          // (not inside a couple)
+	if(n < 2) return KMAHIP_OK;
+	auto t = std::chrono::steady_clock::now();
+	const size_t D = S->db->info.DB_size;
+	kmahip_read_batch hb;
+	session_pe_view(S, B.r0, n, &hb);
+	KmaPeDev pd{S->names.as<char>(), S->name_off.as<int64_t>() + B.r0, S->h_text, S->text_chunk, nullptr};
+	std::vector<kmahip_res_row> rows(D);
+	std::vector<int64_t> a(4 * D, 0);
+	kmahip_run run;
+	memset(&run, 0, sizeof run);
+	run.rows = rows.data(); run.rows_cap = (int64_t) D;
+	run.assembly.cover = a.data(); run.assembly.aln_len = a.data() + D; run.assembly.depth = a.data() + 2 * D; run.assembly.asm_len = a.data() + 3 * D;
+	run.caller = S->opts.caller; run.sig90 = S->opts.sig90; run.support = S->opts.support;
+	const int rc = kmahip_run_pe_resident(S->db, S->ws, &hb, &pd, &S->par, S->opts.evalue, S->opts.bcd, S->opts.max_frag, nullptr, &run);
+	S->ms_map += since(t);
+	return rc;
 }
 
 // `-Mt1`, the fragment rows of one traced batch: one template, stream order -- they follow those of the batches before. Made by a thread
@@ -755,6 +810,35 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 	W.n_reads = n; W.seq = S->seq.as<uint64_t>(); W.seq_off = S->seq_off.as<int64_t>(); W.len = S->len.as<int32_t>(); W.N = S->N.as<int32_t>(); W.N_off = S->N_off.as<int64_t>();
 	W.seq_words = S->words; W.N_total = S->nN; W.max_len = S->max_len;
 	if(S->chain && n) { W.q_start = S->qs.as<int32_t>(); W.q_end = S->qe.as<int32_t>(); }
+
+	if(S->pe) {
+		// paired input: the whole run on what the batches left in HBM (kmahip_run_pe's stages; pipeline.hip), then the text files
+		const std::string prefix(out_prefix);
+		const std::string frag = prefix + ".frag.gz";
+		kmahip_read_batch hb;
+		session_pe_view(S, 0, n, &hb);
+		int64_t n_frag_rows = 0;
+		KmaPeDev pd{S->names.as<char>(), S->name_off.as<int64_t>(), S->h_text, S->text_chunk, &n_frag_rows};
+		std::vector<kmahip_res_row> rows(D);
+		std::vector<int64_t> a_cover(D, 0), a_len(D, 0), a_depth(D, 0), a_asm(D, 0), c_off(D, -1);
+		int64_t tbases = 0;
+		for(size_t tt = 1; tt < D; ++tt) tbases += db->h_tlen[tt];
+		std::vector<char> cons((size_t) (4 * tbases + 4 * (int64_t) D + (1 << 20)));
+		kmahip_run run;
+		memset(&run, 0, sizeof run);
+		run.rows = rows.data(); run.rows_cap = (int64_t) D;
+		run.assembly.cover = a_cover.data(); run.assembly.aln_len = a_len.data(); run.assembly.depth = a_depth.data(); run.assembly.asm_len = a_asm.data();
+		run.assembly.consensus = cons.data(); run.assembly.consensus_off = c_off.data(); run.assembly.consensus_cap = (int64_t) cons.size(); run.assembly.consensus_used = 0;
+		run.caller = S->opts.caller | (S->opts.ref_fsa == 2 ? 8 : 0) | (S->opts.write_aln ? 32 : 0); run.sig90 = S->opts.sig90; run.support = S->opts.support;
+		if((rc = kmahip_run_pe_resident(db, ws, &hb, &pd, p, S->opts.evalue, S->opts.bcd, S->opts.max_frag, write_frag ? frag.c_str() : nullptr, &run))) return rc;
+		(void) since(t);
+		ms[1] += run.ms[0] + run.ms[1]; ms[2] = run.ms[2]; ms[3] = run.ms[3]; ms[4] = run.ms[4]; ms[6] = run.ms[5];
+		if((rc = kmahip_write_res_fsa(db, (prefix + ".res").c_str(), write_fsa ? (prefix + ".fsa").c_str() : nullptr, true, rows.data(), run.n_rows, nullptr, 0, a_cover.data(), a_len.data(),
+		                              a_depth.data(), cons.data(), c_off.data(), S->opts.ID_t > 0 ? S->opts.ID_t : 1.0, S->opts.Depth_t, S->opts.ref_fsa, S->opts.write_aln ? (prefix + ".aln").c_str() : nullptr))) return rc;
+		ms[5] = since(t);
+		if(n_rows_out) *n_rows_out = n_frag_rows;
+		return KMAHIP_OK;
+	}
 
 	if(S->mt1) {
 		// `-Mt1`: the tracebacks are there (kmahip_session_map); the `.res` row, the pile-up in stream order, the files

@@ -239,6 +239,22 @@ def test_batched_session_writes_the_one_batch_files(tmp_path, batch, chunk, mf):
     _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
 
 
+@pytest.mark.parametrize("batch,mf", [(777, 7), (5000, 1001), (1 << 20, None)])
+def test_batched_paired_session_writes_the_one_batch_files(tmp_path, batch, mf):
+    """`-ipe r1 r2 -apm p -1t1` batch by batch (kmahip_session_set_pe: the batches' reads and headers wait in HBM, the host holds one
+    batch at a time, the run's stages on everything when the input has ended) against the same program taking the input as one batch
+    (kmahip_run_pe): couples, singly filed mates (a mate the trim removes), foreign mates, indels; batches of 777 records -- a record is a
+    couple or a single read, so the batches' read counts are ragged -- and chunks of -mf fragments that straddle them"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    prefix, r1, r2 = _pe_case(tmp_path, n_pairs=9000)
+    extra = ["-mf", str(mf)] if mf else []
+    args = ["-ipe", r1, r2, "-apm", "p", "-t_db", prefix, "-1t1"] + extra
+    _run(args + ["-o", str(tmp_path / "one")], env={"KMAHIP_MAP_ONE_BATCH": "1"})
+    r = _run(args + ["-o", str(tmp_path / "many")], env={"KMAHIP_MAP_BATCH": str(batch), "KMAHIP_ROW_GRAIN": "700"})
+    assert b"batches" in r.stderr
+    _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
+
+
 @pytest.mark.parametrize("world,gz,bc", [(2, False, True), (3, True, True), (2, False, False)])
 def test_mt1_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, gz, bc):
     """`-Mt1 1 [-bcNano]` (kmahip_run_mt1_sharded): every rank traces its part of the stream, the kept reads meet at rank 0 with
