@@ -149,7 +149,7 @@ static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(
 
 static void usage(void) {
 	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
-	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-mrs f] [-mrc f] [-mct f]\n"
+	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-ts bases] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
 	                "(the options of kma 1.5.1 this path implements; -apm takes p only, -ipe needs -1t1; everything else is refused)\n");
 }
@@ -279,6 +279,7 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-mi")) trim.hardmask_q = (int) need_int(argc, argv, &a, o);
 		else if(!strcmp(o, "-eq")) trim.min_q = (int) need_int(argc, argv, &a, o);
 		else if(!strcmp(o, "-mq")) par.mq = (int) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-ts")) { par.ts = (int) need_int(argc, argv, &a, o); if(par.ts < 0 || par.ts > 30) { fprintf(stderr, "# Invalid seed trim parsed\n"); return 1; } }   /* kma.c:568-576 */
 		else if(!strcmp(o, "-mrs")) { par.scoreT = need_num(argc, argv, &a, o); cp.mrs = par.scoreT; }
 		else if(!strcmp(o, "-mrc")) par.mrc = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-mct")) cp.coverT = need_num(argc, argv, &a, o);

@@ -68,6 +68,10 @@ typedef struct kmahip_params {
 	double scoreT;        /* -mrs, default 0.5 */
 	double mrc;           /* -mrc, default 0.0 */
 	double minFrac;       /* 1.0 */
+	int32_t ts;           /* -ts, default 0: the traceback aligner trims this many bases off the front of every seed of the best chain but
+	                       * the first one when that starts the read (trimSeeds chain.c:493-528, called by KMA() align.c:413; KMA_score
+	                       * has no such step); at least one base of a seed remains */
+	int32_t pad_;
 } kmahip_params;
 
 typedef struct kmahip_db_info {

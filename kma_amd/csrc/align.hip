@@ -2190,7 +2190,7 @@ struct TraceArgs {
 	// cell, and the kernel lasts as long as its slowest lane. What does not fit LDS is put off once more.
 	const int32_t *q_in; int32_t *q_out;
 	int q_in_cnt, q_out_cnt;        // counter words holding the length of q_in / q_out
-	int fast, gap_m_max;
+	int fast, gap_m_max, ts;
 	int lds_bytes, lds_ncols;
 };
 
@@ -2221,6 +2221,7 @@ struct TLane {
 	Emit em;
 	int status;     // 1: a DP problem did not fit the per-lane move matrix; 32: put off to the second pass
 	int fast, gap_m_max;
+	int ts;                    // -ts: bases trimmed off the front of the chain's seeds (trimSeeds, chain.c:493-528)
 	int ncols;                 // DP columns the rows hold
 	int64_t row_stride;        // distance between neighbouring row elements (the lane count in HBM, 1 in a lane's own LDS)
 };
@@ -2485,6 +2486,15 @@ __device__ Aln kma_trace(TLane &T, const DevDB &db, int t, const uint64_t *ts, i
 	if(!nm) return FAIL;
 	int start = chain_seeds(L, nm, q_len, t_len, k, &mapQ);
 	if(mapQ < (unsigned) mq || MEMA(L, 5, start) < k) return FAIL;
+	if(T.ts) {
+		// trimSeeds (chain.c:493-528; align.c:413): the front of every seed of the chain -- but not of a first seed that starts the read --
+		// is given back to the DP problem before it, one base of a seed stays at least
+		for(int c = MEMA(L, 2, start) ? start : MEMA(L, 6, start); c; c = MEMA(L, 6, c)) {
+			const int len = MEMA(L, 3, c) - MEMA(L, 2, c);
+			const int cut = len < T.ts ? len - 1 : T.ts;
+			MEMA(L, 0, c) += cut; MEMA(L, 2, c) += cut;
+		}
+	}
 
 	Aln S = {0, 0, 0, 0, 0, 0};
 	{	// leading tail (leadTailAln with Frag_align, align.c:53-131)
@@ -2604,7 +2614,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const TraceArgs A) {      //
 		T.E = mine + 16 * A.lds_ncols; T.e_cap = A.lds_bytes - 16 * A.lds_ncols;
 	}
 	T.em.ops = A.ops_s + gtid; T.em.stride = A.lanes; T.em.cap = A.ops_cap;
-	T.fast = A.fast; T.gap_m_max = A.gap_m_max;
+	T.fast = A.fast; T.gap_m_max = A.gap_m_max; T.ts = A.ts;
 	const int lane = threadIdx.x & 63;
 	const int64_t n_items = A.q_in ? (int64_t) A.counters[A.q_in_cnt] : A.n_reads;       // (the list was filled by the launch before this one)
 	const int64_t n_threads = (int64_t) gridDim.x * blockDim.x;
@@ -3090,7 +3100,7 @@ int kmahip_launch_trace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	A.q_start = reads->q_start; A.q_end = reads->q_end;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
-	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
+	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc; A.ts = p->ts;
 	A.s32 = ws->t_s32; A.rows = ws->t_s32 + (size_t) lanes * 7 * (mem_cap + 1);
 	A.ops_s = (uint32_t *) (A.rows + (size_t) lanes * 4 * ncols);
 	A.E = ws->t_E; A.lanes = lanes; A.e_cap = e_cap; A.mem_cap = mem_cap; A.ncols = ncols; A.ops_cap = ops_cap;

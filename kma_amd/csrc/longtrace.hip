@@ -103,6 +103,7 @@ struct LtArgs {
 	int M, MM, U, W1, Wl;
 	int d[25];
 	int minlen, mq;
+	int ts;                   // -ts (trimSeeds, chain.c:493-528): not in score mode (KMA_score has no such step)
 	double scoreT, mrc;
 	// scratch of the pass
 	int32_t *mem;             // per seeding wavefront: 7 arrays of mcap ints (tS tE qS qE weight next chain)
@@ -692,6 +693,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				int c = start;
 				for(;;) {
 					if(lds_next) S.chain[nc] = (uint16_t) c; else Mm.ch[base + nc] = c;
+					if(A.ts && (nc || Mm.qS[base + c])) {
+						// trimSeeds (chain.c:493-528; align.c:413): the front of a seed goes back to the problem before it; the first seed
+						// keeps it when it starts the read; one base of a seed stays
+						const int len = Mm.qE[base + c] - Mm.qS[base + c];
+						const int cut = len < A.ts ? len - 1 : A.ts;
+						Mm.tS[base + c] += cut; Mm.qS[base + c] += cut;
+					}
 					++nc;
 					const int nx = lds_next ? (int) S.next[c] : Mm.nx[base + c];
 					if(!nx || nx <= c || nx >= n || nc >= n) break;        // (links point to later MEMs)
@@ -2066,7 +2074,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	A.q_start = rc_in ? reads->q_start : nullptr; A.q_end = rc_in ? reads->q_end : nullptr;
 	A.M = p->rw.M; A.MM = p->rw.MM; A.U = p->rw.U; A.W1 = p->rw.W1; A.Wl = p->rw.Wl;
 	for(int i = 0; i < 25; ++i) A.d[i] = p->rw.d[i / 5][i % 5];
-	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc;
+	A.minlen = p->minlen; A.mq = p->mq; A.scoreT = p->scoreT; A.mrc = p->mrc; A.ts = score_mode ? 0 : p->ts;
 	A.mem = (int32_t *) ws->lt_buf[0]; A.mcap = mcap;
 	A.tmp = (uint32_t *) ws->lt_buf[5]; A.tmp_cap = tmp_cap;
 	A.xE = (uint8_t *) ws->lt_buf[6]; A.xe_cap = xe_cap; A.xrow = xrow;

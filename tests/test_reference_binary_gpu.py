@@ -411,6 +411,47 @@ def test_deep_pile_up_of_long_reads_equals_reference_binary(tmp_path):
     assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read()
 
 
+@pytest.mark.parametrize("ts", [2, 7, 30])
+def test_seed_trimming_equals_reference_binary(tmp_path, ts):
+    """`-ts n` (trimSeeds, chain.c:493-528, called by KMA() align.c:413 -- not by KMA_score): the front of every seed of the best chain goes
+    back to the DP problem before it, in the short-read traceback and in the long-read pipeline (`-ts 2` is part of the reference's -ont
+    preset). Reads with substitutions and indels (several seeds per read, seeds shorter than the trim), both modes, and long reads with
+    -Mt1: .res, .fsa, .aln and .frag.gz against the binary."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(100 + ts)
+    names, seqs = synth.make_gene_db(n_families=25, variants=3, len_lo=900, len_hi=2500, seed=5)
+    prefix = str(tmp_path / "db")
+    synth.write_fasta(prefix + ".fsa", names, seqs)
+    subprocess.run([KMA, "index", "-i", prefix + ".fsa", "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads, *_ = synth.make_reads(seqs, 2500, read_len=150, sub_rate=0.03, seed=3)
+    reads = list(reads)
+    cat = np.concatenate(seqs)
+    reads += synth.make_long_reads(cat, 500, read_len=250, sub=0.02, dele=0.015, ins=0.015, seed=4)
+    for g in rng.integers(0, len(seqs), 12):
+        reads += synth.make_long_reads(seqs[g], 6, read_len=min(2000, len(seqs[g]) - 10), sub=0.04, dele=0.03, ins=0.03, seed=int(g))
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads, prefix="q")
+    for mode in (["-1t1"], [], ["-Mt1", "4", "-bcNano"]):
+        for f in ("ref", "got"):
+            for ext in (".res", ".fsa", ".aln", ".frag.gz"):
+                if os.path.exists(tmp_path / (f + ext)):
+                    os.unlink(tmp_path / (f + ext))
+        subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1", "-ts", str(ts)] + mode, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "got"), "-ts", str(ts)] + mode, check=True, stderr=subprocess.PIPE)
+        assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read(), mode
+        assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read(), mode
+        assert open(tmp_path / "got.aln", "rb").read() == open(tmp_path / "ref.aln", "rb").read(), mode
+        assert gzip.open(tmp_path / "got.frag.gz", "rb").read() == gzip.open(tmp_path / "ref.frag.gz", "rb").read(), mode
+    if ts == 30:
+        # a trim of 30 changes alignments on this input (giving two exactly matching bases back to a DP problem changes nothing, as a
+        # rule): the comparison above would not pass with the option ignored
+        subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "plain"), "-Mt1", "4", "-bcNano"], check=True, stderr=subprocess.PIPE)
+        assert gzip.open(tmp_path / "plain.frag.gz", "rb").read() != gzip.open(tmp_path / "got.frag.gz", "rb").read()
+
+
 def _pe_branch_db_and_pairs(rng, n_fam, n):
     """A database and pairs built to leave the proper-pair branch of alnFragsPenaltyPE (alnfrags.c:1777-1970). Every family has two
     templates, X and Y = X with a substitution every `gap` bases. A pair takes mate 1 from X and mate 2 from Y, placed so that the
