@@ -769,7 +769,7 @@ def main():
         # --pmc summary of this same command supplies it -- but only while the kernel sources are the ones it was taken on
         # (tools/collect_profiles.py stores their hash); a stale figure is dropped, not reported
         traffic, traffic_src = None, None
-        for prof in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for prof in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if dom["kernel"] in pmc and n == 10_000_000 and a.families == 1000 and pmc.get("_kernel_src_sha256") == kernel_src_sha():

@@ -12,7 +12,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("scan_prefilter_kernel", "scan_se_kernel", "seed_tasks_kernel", "align_tasks_kernel", "scan_dense_kernel", "task_map_kernel", "reduce_reads_kernel")
+KERNELS = ("scan_prefilter_kernel", "scan_se_kernel", "seed_tasks_kernel", "align_fast_kernel", "align_tasks_kernel", "dp_queue_kernel", "pend_finish_kernel", "scan_dense_kernel",
+           "task_map_kernel", "reduce_reads_kernel")
 
 
 def one(pattern):
@@ -50,6 +51,8 @@ def main():
     res = {}
     for name in fetch:
         short = next((k for k in KERNELS if k in name), None)
+        if short == "dp_queue_kernel":
+            short = "dp_queue_kernel" + name[name.index("<"):name.index(">") + 1]
         if short == "scan_se_kernel" and ", 64>" in name:
             short = "scan_se_kernel_tier2"                                # the 64-slot second tier (usually next to nothing to do)
         if short is None or name not in write or "<true" in name:     # <true...> = the stats-counting launches
