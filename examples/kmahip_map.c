@@ -148,10 +148,10 @@ static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fi
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
 
 static void usage(void) {
-	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] -apm p) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
+	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] [-apm p|u]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-ts bases] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
-	                "(the options of kma 1.5.1 this path implements; -apm takes p only, -ipe needs -1t1; everything else is refused)\n");
+	                "(the options of kma 1.5.1 this path implements; -apm takes p or u, -ipe needs -1t1; everything else is refused)\n");
 }
 
 static long long need_int(int argc, char **argv, int *a, const char *what) {
@@ -262,8 +262,8 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
 		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
-			if(a + 1 >= argc || argv[a + 1][0] != 'p') { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) only; u and f are not built\n"); return 1; }
-			++a; apm = 1;
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) or u (union, save_kmers_unionPair / alnFragsUnionPE); f is not built\n"); return 1; }
+			apm = argv[++a][0] == 'p' ? 1 : 2;
 		}
 		else if(!strcmp(o, "-t")) {                                                             /* kma.c:529: a value is optional */
 			if(a + 1 < argc && argv[a + 1][0] != '-') threads = (int) need_int(argc, argv, &a, o);
@@ -295,7 +295,7 @@ int main(int argc, char **argv) {
 	if(ref_fsa == 1) base_call = base_call == 1 ? 4 : 3;      /* kma.c:1278-1284: refNanoCaller / refCaller */
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
-	if(input2 && !apm) { fprintf(stderr, "kmahip_map: -ipe needs -apm p (the reference pairs by union without it, kma.c:206: not built)\n"); return 2; }
+	par.apm = apm == 1 ? 0 : 1;          /* (without -apm the reference pairs by union, kma.c:206) */
 	if(chain && input2) { fprintf(stderr, "kmahip_map: paired input needs -1t1 (the default mode is built for single-end input)\n"); return 2; }
 	if(chain && par.mrc != 0.0) { fprintf(stderr, "kmahip_map: -mrc needs -1t1 (the chain finder's query-coverage variant is not built)\n"); return 2; }
 	if(mt1 && input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
@@ -410,6 +410,18 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "# kmahip_map: %lld reads in %d batches, %lld fragment rows; wall: open %.2f s, ingest done after %.2f, mapped after %.2f, finish %.2f | uploads %.1f ms, stages 2+3a %.1f, "
 		        "ConClave %.1f, traceback %.1f, pile-up + consensus %.1f, .res + .fsa %.1f, .frag.gz %.1f (+ %.1f beside the batches) (main entered %.2f s after process start; peak RSS %.0f MB)\n", (long long) n_reads, batches,
 		        (long long) n_rows, t_open - t_start, sj.t_done - t_start, t_mapped - t_start, now_s() - t_mapped, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7], t_before_main, peak_rss_mb());
+		if(getenv("KMAHIP_MAP_TEARDOWN")) {	/* what the process gives back, piece by piece and timed (the exit does the same in one go) */
+			double t0 = now_s();
+			kmahip_session_close(ses);
+			const double t1 = now_s();
+			kmahip_ws_destroy(ws);
+			const double t2 = now_s();
+			kmahip_db_close(db);
+			const double t3 = now_s();
+			kmahip_ingest_close(sj.ing);
+			const double t4 = now_s();
+			fprintf(stderr, "# kmahip_map: teardown: session %.3f s, workspace %.3f, index %.3f, reader %.3f\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+		}
 		finish(0);
 	}
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */

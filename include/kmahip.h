@@ -71,7 +71,9 @@ typedef struct kmahip_params {
 	int32_t ts;           /* -ts, default 0: the traceback aligner trims this many bases off the front of every seed of the best chain but
 	                       * the first one when that starts the read (trimSeeds chain.c:493-528, called by KMA() align.c:413; KMA_score
 	                       * has no such step); at least one base of a seed remains */
-	int32_t pad_;
+	int32_t apm;          /* paired reads: 0 = the pairing penalty of -apm p (save_kmers_penaltyPair savekmers.c:3572, alnFragsPenaltyPE
+	                       * alnfrags.c:1596), 1 = union, -apm u and what `-ipe` means without -apm (kma.c:206: save_kmers_unionPair
+	                       * savekmers.c:3367 with getF_Best / getR_Best, alnFragsUnionPE alnfrags.c:1220) */
 } kmahip_params;
 
 typedef struct kmahip_db_info {

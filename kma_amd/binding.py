@@ -20,7 +20,7 @@ class Rewards(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("rw", Rewards), ("exhaustive", C.c_int32), ("minlen", C.c_int32), ("mq", C.c_int32),
-                ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double), ("ts", C.c_int32), ("pad_", C.c_int32)]
+                ("scoreT", C.c_double), ("mrc", C.c_double), ("minFrac", C.c_double), ("ts", C.c_int32), ("apm", C.c_int32)]
 
 
 class DBInfo(C.Structure):

@@ -1913,7 +1913,7 @@ struct ReduceArgs {
 	const int32_t *rec_mate, *rec_rc;
 	int32_t *out_rc;      // may be NULL. bit 0: the fragment filed for this record is the reverse complement of the original read;
 	                      // bit 1 (proper pair only): the pair's record is written second slot first (alnfrags.c:1807-1812)
-	int pe_mode, PE;
+	int pe_mode, PE, apm;
 	int64_t tasks_cap;    // as AlignArgs.tasks_cap
 	int32_t *pe_kind;     // per pair: 0 none / records handled singly, 1 proper pair, 2 unmated, 3 first only, 4 second only
 	int32_t *t_score_w, *t_alen_w, *t_start_w, *t_end_w, *t_tmpl_w;   // writable views (unmated shuffle)
@@ -1935,17 +1935,25 @@ __device__ void reduce_couple(const ReduceArgs &R, int64_t p0) {
 	// makes alnFragsPenaltyPE reverse-complement both mates (alnfrags.c:1629-1643); a mate whose first kept template is
 	// positive is turned back (with the flag toggled), one whose first kept template is negative stays turned.
 	int relA = 0, relB = 0, swap_rec = 0;
+	// -apm u (alnFragsUnionPE, alnfrags.c:1220-1594): a proper pair where a template holds BOTH mates' best scores (:1410-1446; its
+	// score the sum of the two), else the unmated / one-mate branches below, which the two functions share
+	int u_hits = 0;
+	if(R.apm == 1 && best && best_r) for(int64_t i = 0; i < nT; ++i) u_hits += (best <= R.t_score[o + i] && best_r <= R.t_alen[o + i]);
 	if(best || best_r) {
-		if(comp && 1.0 * (best + best_r) <= comp + R.PE) {
-			const int bestScore = comp + R.PE;
+		if(R.apm == 1 ? u_hits != 0 : (comp && 1.0 * (best + best_r) <= comp + R.PE)) {
+			const int pe = R.apm == 1 ? 0 : R.PE;
+			const int bestScore = R.apm == 1 ? best + best_r : comp + R.PE;
 			int first = 0, h = 0, c = 0;
-			for(int64_t i = 0; i < nT; ++i) if(R.t_score[o + i] && R.t_alen[o + i]) { if(!h) first = R.T[o + i]; ++h; }
+			for(int64_t i = 0; i < nT; ++i) {
+				const bool in = R.apm == 1 ? (best <= R.t_score[o + i] && best_r <= R.t_alen[o + i]) : (R.t_score[o + i] && R.t_alen[o + i]);
+				if(in) { if(!h) first = R.T[o + i]; ++h; }
+			}
 			const bool swapped = h && first < 0;
 			if(!swapped && rcstate) { fA ^= 48; fB ^= 48; }
 			if(swapped) { relA = relB = 1; swap_rec = 2; }
 			for(int64_t i = 0; i < nT; ++i) {
 				const int bt = R.t_score[o + i], btr = R.t_alen[o + i];
-				if(bt && btr && bt + btr + R.PE == bestScore) {
+				if(bt && btr && bt + btr + pe == bestScore && (R.apm != 1 || (best <= bt && best_r <= btr))) {
 					const int tm = swapped ? -R.T[o + i] : R.T[o + i];
 					R.h_tmpl[o + c] = tm; R.h_score[o + c] = bestScore; R.h_start[o + c] = R.t_start[o + i]; R.h_end[o + c] = R.t_end[o + i];
 					if(R.alignment_scores) atomicAdd(&R.alignment_scores[abs(tm)], (unsigned long long) bestScore);
@@ -2965,7 +2973,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
-	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.pe_kind = pe_kind;
+	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.apm = p->apm; R.pe_kind = pe_kind;
 	R.priv = nullptr; R.priv_copies = 0; R.DB_size = db->info.DB_size; R.tasks_cap = tasks_cap;
 	if(out->alignment_scores || out->uniq_alignment_scores) {
 		const int64_t D = db->info.DB_size;

@@ -37,7 +37,7 @@ extern "C" void kmahip_default_params(kmahip_params *p) {
 	for(int j = 0; j < 5; ++j) p->rw.d[4][j] = p->rw.Mn;
 	p->rw.d[4][4] = 0;
 	p->exhaustive = 0; p->minlen = 16; p->mq = 0;
-	p->scoreT = 0.5; p->mrc = 0.0; p->minFrac = 1.0; p->ts = 0; p->pad_ = 0;
+	p->scoreT = 0.5; p->mrc = 0.0; p->minFrac = 1.0; p->ts = 0; p->apm = 0;
 }
 
 static int g_device = 0;

@@ -1281,6 +1281,110 @@ __global__ __launch_bounds__(256) void pair_penalty_kernel(const PairArgs P) {
 	}
 }
 
+// `-apm u` (and `-ipe` without -apm: the reference's default, kma.c:206): save_kmers_unionPair, savekmers.c:3367-3570, with getF_Best /
+// getR_Best (:1648-1762). Mate 1 keeps its best-scoring templates of either strand; mate 2 its own -- and where a template of mate 1's
+// set is also in mate 2's on the OTHER strand the two are a couple on those templates (moved to the front of the list, in the order
+// met); else each mate is a record of its own. Same inputs and outputs as pair_penalty_kernel.
+__global__ __launch_bounds__(256) void pair_union_kernel(const PairArgs P) {
+	const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(p >= P.n_pairs) return;
+	const ScanArgs &A = P.S;
+	const int k = (int) A.db.kmersize;
+	PList L[4];
+	int hc[4];
+	for(int x = 0; x < 4; ++x) {
+		const int64_t it = 4 * p + x;
+		L[x].n = max(0, A.item_n[it]); L[x].t = A.pool + A.item_off[it]; L[x].s = A.pool_sc + A.item_off[it];
+		hc[x] = A.item_score[it];
+	}
+	const PList &F1 = L[0], &R1 = L[1], &F2 = L[2], &R2 = L[3];
+	const int hc1 = max(hc[0], hc[1]), hc2 = max(hc[2], hc[3]);
+	const int len1 = A.len[2 * p], len2 = A.len[2 * p + 1];
+	const int n1 = F1.n + R1.n, n2 = F2.n + R2.n;
+	const int64_t need = (int64_t) max(n1, n2) + n2;
+	int64_t base = 0;
+	if(need) {
+		base = (int64_t) atomicAdd(&A.counters[C_PPOOL], (unsigned long long) need);
+		if(base + need > P.ppool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); return; }
+	}
+	int32_t *regT = P.ppool + base, *bT = regT + max(n1, n2);
+	// getF_Best: the best score over both strands' candidates and the templates that reach it, forward ones first
+	auto best_of = [&](const PList &F, const PList &R, int32_t *dst, int &cnt) {
+		int best = 0;
+		cnt = 0;
+		for(int i = 0; i < F.n; ++i) { const int sc = F.s[i]; if(best < sc) { best = sc; cnt = 0; dst[cnt++] = F.t[i]; } else if(best == sc) dst[cnt++] = F.t[i]; }
+		for(int i = 0; i < R.n; ++i) { const int sc = R.s[i]; if(best < sc) { best = sc; cnt = 0; dst[cnt++] = -R.t[i]; } else if(best == sc) dst[cnt++] = -R.t[i]; }
+		return best;
+	};
+	// (CompDNA.seqlen is unsigned: the coverage test wraps like the reference's)
+	auto covered = [&](int best, int len) { return !(k < best && (unsigned) (best * k) < (unsigned) len - (unsigned) best); };
+	int nreg = 0, nb2 = 0, best1 = 0, best2 = 0, paired = 0;
+	if(hc1) {
+		best1 = best_of(F1, R1, regT, nreg);
+		if(!covered(best1, len1)) best1 = 0;
+	}
+	if(hc2) {
+		if(best1) {
+			// getR_Best: mate 2's own best set, then the templates of mate 1's set that are in it on the other strand
+			best2 = best_of(F2, R2, bT, nb2);
+			int hits = 0;
+			if(0 < best2) {
+				for(int i = 0; i < nreg; ++i) {
+					const int rt = regT[i];
+					const int sc = rt > 0 ? plist_find(R2, rt) : plist_find(F2, -rt);
+					if(sc == best2) { const int x = regT[hits]; regT[hits] = rt; regT[i] = x; ++hits; }
+				}
+			}
+			if(hits) { paired = 1; nreg = hits; }
+		} else best2 = best_of(F2, R2, regT, nreg);
+		if(!covered(best2, len2)) { best2 = 0; paired = 0; }
+	}
+	int o1 = len1 >= k, o2 = len2 >= k;      // get_kmers_for_pair leaves a scanned mate reverse-complemented
+	int flag = 65, flag_r = 129;
+	int m[2] = {-1, -1}, rcv[2] = {0, 0}, sc[2] = {0, 0}, fl[2] = {0, 0}, nn[2] = {0, 0};
+	int64_t of[2] = {0, 0};
+	if(0 < best1 && 0 < best2) {
+		if(paired) {
+			flag |= 2; flag_r |= 2;
+			if(0 < regT[0]) {
+				flag |= 32; flag_r |= 16; o1 ^= 1;
+				m[0] = 0; rcv[0] = o1; sc[0] = best1; fl[0] = flag; nn[0] = 0;
+				m[1] = 1; rcv[1] = o2; sc[1] = best2; fl[1] = flag_r; nn[1] = nreg; of[1] = base;
+			} else {
+				flag |= 16; flag_r |= 32; o2 ^= 1;
+				for(int i = 0; i < nreg; ++i) regT[i] = -regT[i];
+				m[0] = 1; rcv[0] = o2; sc[0] = best2; fl[0] = flag_r; nn[0] = 0;
+				m[1] = 0; rcv[1] = o1; sc[1] = best1; fl[1] = flag; nn[1] = nreg; of[1] = base;
+			}
+		} else {
+			int s1 = best1, s2 = best2;
+			if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+			else { flag |= 16; flag_r |= 32; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			if(0 < bT[0]) { o2 ^= 1; if(bT[nb2 - 1] < 0) s2 = -s2; }
+			else { flag |= 32; flag_r |= 16; for(int i = 0; i < nb2; ++i) bT[i] = -bT[i]; }
+			m[0] = 0; rcv[0] = o1; sc[0] = s1; fl[0] = flag; nn[0] = nreg; of[0] = base;
+			m[1] = 1; rcv[1] = o2; sc[1] = s2; fl[1] = flag_r; nn[1] = nb2; of[1] = base + max(n1, n2);
+		}
+	} else if(best1) {
+		int s1 = best1;
+		flag |= 8; flag |= 32;
+		if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+		else { flag |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+		m[0] = 0; rcv[0] = o1; sc[0] = s1; fl[0] = flag; nn[0] = nreg; of[0] = base;
+	} else if(best2) {
+		int s2 = best2;
+		flag_r |= 8; flag_r |= 32;
+		if(0 < regT[0]) { o2 ^= 1; if(regT[nreg - 1] < 0) s2 = -s2; }
+		else { flag_r |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+		m[1] = 1; rcv[1] = o2; sc[1] = s2; fl[1] = flag_r; nn[1] = nreg; of[1] = base;
+	}
+	for(int x = 0; x < 2; ++x) {
+		const int64_t r = 2 * p + x;
+		P.r_mate[r] = m[x]; P.r_rc[r] = rcv[x]; P.r_score[r] = sc[x]; P.r_flag[r] = fl[x];
+		P.r_n[r] = (m[x] >= 0) ? nn[x] : 0; P.r_off[r] = of[x];
+	}
+}
+
 // generic CSR compaction of per-record lists: counts -> offsets (3 kernels)
 __global__ __launch_bounds__(CB) void rec_count_kernel(const int32_t *cnt, int64_t n, int64_t *blk_sums) {
 	__shared__ int64_t red[CB];
@@ -1726,7 +1830,8 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	P.ppool = ws->ppool; P.ppool_cap = 2 * ws->pool_cap;
 	P.r_mate = out->mate; P.r_rc = out->rc; P.r_score = out->rc_flag; P.r_flag = out->flag;
 	P.r_off = (int64_t *) ws->pe_rec; P.r_n = (int32_t *) (P.r_off + ws->cap_reads + 2);
-	hipLaunchKernelGGL(pair_penalty_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
+	if(p->apm == 1) hipLaunchKernelGGL(pair_union_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
+	else hipLaunchKernelGGL(pair_penalty_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
 	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
 	hipLaunchKernelGGL(rec_count_kernel, dim3(cgrid), dim3(CB), 0, stream, P.r_n, n, ws->blk_sums);
 	hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, ws->blk_sums, (int64_t) cgrid);

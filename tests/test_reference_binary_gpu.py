@@ -77,9 +77,10 @@ def test_whole_run_equals_reference_binary(tmp_path, seed, families, variants, m
     assert got.count(b"\n") > 40000
 
 
-@pytest.mark.parametrize("mf", [None, 1001, 7])
-def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
-    """`-ipe r1 r2 -apm p -1t1 -t 1`: pairs with substitutions, some mates foreign or too short after trimming (single records in the
+@pytest.mark.parametrize("mf,apm", [(None, ["-apm", "p"]), (1001, ["-apm", "p"]), (7, ["-apm", "p"]), (None, ["-apm", "u"]), (1001, []), (7, ["-apm", "u"])])
+def test_whole_paired_run_equals_reference_binary(tmp_path, mf, apm):
+    """`-ipe r1 r2 -apm p -1t1 -t 1` -- and `-apm u`, and no -apm at all, which is the union pairing too (kma.c:206: save_kmers_unionPair,
+    alnFragsUnionPE) --: pairs with substitutions, some mates foreign or too short after trimming (single records in the
     pair stream), some with an insertion or deletion, through the reference and through examples/kmahip_map -ipe. With -mf 1001
     the assembly chunks close after whole records: couples straddle the limit (chunks of 1002 fragments, conclave.c:164-196); -mf 7
     makes eight thousand chunks, half of them closed by a couple."""
@@ -112,9 +113,9 @@ def test_whole_paired_run_equals_reference_binary(tmp_path, mf):
         with open(path, "wb") as f:
             for i, (r, q) in enumerate(zip(rs, qs)):
                 f.write(b"@p%d" % i + tag + b"\n" + lut[r].tobytes() + b"\n+\n" + q + b"\n")
-    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-t", "1"] + apm + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1"] + apm + extra,
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="700") if mf else None)
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()
@@ -132,11 +133,16 @@ def _fuzz_seeds():
     return [1, 2, 3]
 
 
+def _apm_modes():
+    return ["p", "u"] if not os.environ.get("KMA_PE_FUZZ_APM") else os.environ["KMA_PE_FUZZ_APM"].split(",")
+
+
+@pytest.mark.parametrize("apm", _apm_modes())
 @pytest.mark.parametrize("seed", _fuzz_seeds())
-def test_paired_fuzz_equals_reference_binary(tmp_path, seed):
+def test_paired_fuzz_equals_reference_binary(tmp_path, seed, apm):
     """a random database and pair set per seed: mates of ragged lengths with indels, foreign ends, N's, unmappable mates, mates the
     quality trim removes or shortens, mates drawn from different variants of a family or from different families; maxFrag drawn
-    too. `kma -ipe r1 r2 -apm p -1t1 -t 1` against examples/kmahip_map -ipe: .res, .fsa, .frag.gz."""
+    too. `kma -ipe r1 r2 -apm p|u -1t1 -t 1` against examples/kmahip_map -ipe: .res, .fsa, .frag.gz."""
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
@@ -178,9 +184,9 @@ def test_paired_fuzz_equals_reference_binary(tmp_path, seed):
             f1.write(b"@p%d/1\n" % i + lut[m1].tobytes() + b"\n+\n" + bytes(q1) + b"\n")
             f2.write(b"@p%d/2\n" % i + lut[m2].tobytes() + b"\n+\n" + bytes(q2) + b"\n")
     extra = [] if seed % 3 == 0 else ["-mf", str(int(rng.integers(2, 3000)))]
-    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", "p", "-t", "1"] + extra,
+    subprocess.run([KMA, "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "ref"), "-t_db", prefix, "-1t1", "-apm", apm, "-t", "1"] + extra,
                    check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", "p"] + extra,
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_map"), "-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-o", str(tmp_path / "got"), "-1t1", "-apm", apm] + extra,
                    check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, KMAHIP_ROW_GRAIN="300"))
     assert open(tmp_path / "got.res", "rb").read() == open(tmp_path / "ref.res", "rb").read()
     assert open(tmp_path / "got.fsa", "rb").read() == open(tmp_path / "ref.fsa", "rb").read()

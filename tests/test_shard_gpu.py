@@ -123,6 +123,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         ["-i", fq, "-t_db", prefix, "-1t1"],                                        # C1 / C2
         ["-i", fq, "-t_db", prefix, "-1t1", "-t", "4", "-nc", "-na", "-nf"],       # the output switches of BASELINE.md R2
         ["-ipe", r1, r2, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],         # C3
+        ["-ipe", r1, r2, "-t_db", prefix, "-1t1", "-t", "1"],                      # ... and without -apm: the union pairing (kma.c:206)
         ["-i", fq, "-t_db", prefix, "-1t1", "-mp", "30", "-ml", "40", "-eq", "25", "-mf", "900"],
         ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-bcNano"],                       # C4's switches
         ["-i", fq, "-t_db", prefix, "-t", "2"],                                    # the default mode
@@ -140,7 +141,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
                     a, b = sorted(a.splitlines()), sorted(b.splitlines())      # (the reference's row order depends on its threads' timing)
                 assert a == b, (args, ext)
     # what is not built is refused, not ignored
-    for bad in (["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-apm", "u"], ["-ipe", r1, r2, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1"],
+    for bad in (["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-apm", "f"], ["-ipe", r1, r2, "-t_db", prefix, "-o", str(tmp_path / "x")],
                 ["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-sam"]):
         assert _run(bad, ok=False).returncode != 0
 

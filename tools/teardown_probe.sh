@@ -13,7 +13,7 @@ prefix = os.path.join(tmp, "db")
 formats.write_index(prefix, names, seqs)
 sys.path.insert(0, os.getcwd())
 import bench
-n = 4_000_000
+n = 10_000_000
 codes, *_ = synth.make_reads(seqs, 1_000_000, seed=5)
 fq = os.path.join(tmp, "r.fq")
 with open(fq, "wb") as f:
@@ -27,10 +27,10 @@ def run(env, args=()):
     dt = time.perf_counter() - t0
     last = r.stderr.decode().strip().splitlines()[-1] if r.stderr else ""
     return dt, last
-for label, env, args in (("stop after open", {"KMAHIP_MAP_STOP": "open", "KMAHIP_MAP_ONE_BATCH": "1"}, ()), ("whole run", {}, ()), ("whole run, -nf -na", {}, ("-nf", "-na")),
+for label, env, args in (("whole run, teardown timed", {"KMAHIP_MAP_TEARDOWN": "1"}, ()), ("stop after open", {"KMAHIP_MAP_STOP": "open", "KMAHIP_MAP_ONE_BATCH": "1"}, ()), ("whole run", {}, ()), ("whole run, -nf -na", {}, ("-nf", "-na")),
                          ("whole run, early return", {"KMAHIP_MAP_EARLY_RETURN": "1"}, ())):
     for rep in range(2):
         dt, last = run(env, args)
-        print(f"{label}: {dt:.3f} s | {last[:260]}", flush=True)
+        print(f"{label}: {dt:.3f} s | {last[:200]}", flush=True)
         time.sleep(1.0)
 PY
