@@ -938,6 +938,246 @@ __global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_kernel(const ChainA
 	}
 }
 
+// ---- long reads: the anchors by a wavefront per read and strand, chaining and extraction by a lane per read on ready anchors -----------
+// A lane that walks a 10 kb read alone makes 20 000 lookups one block after the other, and the wavefront lasts as long as its longest
+// read (build_ankers above: 28 ms for 2 000 reads however few they are). The lookups of a read are independent of each other; what is
+// serial is the anchor state machine -- and that is a scan: whether a hit opens an anchor or continues one depends on the hit before it
+// only (the same list, 0 or exactly k starts missed in between, savekmers.c:5262-5300). So a wavefront takes a strand LA_P k-mer starts
+// at a time, LA_SEG to a lane: every lane's buckets travel together, then the lists of the k-mers that are there; the hit before a lane's
+// segment comes from a "last non-empty" scan over the wavefront, the anchor numbers from a prefix sum of the opens, weights and last
+// hits are summed per anchor in LDS (an anchor may span lanes and passes: slot 0 holds the one that is still open when a pass ends).
+// The anchors of a read lie in a region of the pool sized by its k-mer starts (v_off: no counting pass, no atomics), the forward
+// strand's first; chain_long_tail_kernel then runs chain_read_tail on them as chain_kernel does on the ones it built itself.
+// Reads with N's stay with chain_kernel (the reference restarts the reverse strand k bases off behind an N, savekmers.c:5447-5449).
+constexpr int LA_SEG = 8, LA_P = 64 * LA_SEG;
+static_assert(LA_SEG + 15 <= 32, "a lane's k-mers come out of one 32-base window");
+struct LongArgs {
+	const int64_t *list;      // the reads (of ChainArgs' batch) this route takes
+	int64_t first, count;     // list[first .. first + count) in this launch
+	const int64_t *v_off;     // per list entry: first anchor of its region in the pool, counted from v_off[first] (2 * (k-mer starts + 1) anchors each)
+	CAnk *pool;
+	int32_t *hits;            // 2 per list entry: anchors of the forward / the reverse strand
+};
+__device__ __forceinline__ void ank_store(GAnk *p, const CAnk &a) {
+	u32x4 lo, hi;
+	__builtin_memcpy(&lo, &a, 16);
+	__builtin_memcpy(&hi, (const char *) &a + 16, 16);
+	KMAHIP_GLOBAL u32x4 *q = (KMAHIP_GLOBAL u32x4 *) p;
+	q[0] = lo; q[1] = hi;
+}
+__global__ __launch_bounds__(256) void chain_long_sizes_kernel(int64_t n_list, const int64_t *list, const int32_t *len, int k, int64_t *cnt) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x < n_list) cnt[x] = 2 * ((int64_t) max(len[list[x]] - k + 1, 0) + 1);
+}
+__global__ __launch_bounds__(64) void chain_long_anchor_kernel(const ChainArgs A, const LongArgs G) {
+	__shared__ int s_w[LA_P + 1];
+	__shared__ uint32_t s_last[LA_P + 1], s_start[LA_P + 1], s_val[LA_P + 1];
+	const int lane = (int) threadIdx.x;
+	const int64_t x = G.first + (int64_t) (blockIdx.x >> 1);
+	const int strand = (int) (blockIdx.x & 1u);
+	const int64_t r = G.list[x];
+	const int k = (int) A.db.kmersize, L = A.len[r], npos = L - k + 1;
+	GAnk *const V = (GAnk *) (G.pool + (G.v_off[x] - G.v_off[G.first]) + (strand ? (int64_t) max(npos, 0) + 1 : 0));
+	QView q;
+	q.w = A.seq + A.seq_off[r]; q.L = L; q.N = nullptr; q.nN = 0; q.rc = strand;
+	const KMAHIP_GLOBAL u32x4 *const g_slots = (const KMAHIP_GLOBAL u32x4 *) A.db.slots;
+	const KMAHIP_GLOBAL uint32_t *const g_vs_id = (const KMAHIP_GLOBAL uint32_t *) A.db.vs_id;
+	const KMAHIP_GLOBAL uint32_t *const g_kbits = (const KMAHIP_GLOBAL uint32_t *) A.db.kbits;
+	const uint32_t g_sh = 32u - A.db.nb_log2, kb_sh = A.db.kbits_shift;
+	const int kM = k * A.M, M1 = A.M, kMM = k * A.M + A.MM;
+	CAnk none;
+	none.score = 0; none.weight = 0; none.score_len = 0; none.len_len = 0; none.start = 0; none.end = 0; none.values = NOLIST; none.descend = -1;
+	// the reference looks at every k-th k-mer of a strand first and leaves the strand alone when none of them is known (savekmers.c:5216-5232)
+	bool HIT = A.exhaustive != 0;
+	if(!HIT && npos > 0) {
+		bool any = false;
+		for(int j = lane * k; j < npos; j += 64 * k) any = any || db_probe(A.db, (uint32_t) (qwin(q, j) >> (64 - 2 * k))) != NOLIST;
+		HIT = __any(any);
+	}
+	if(!HIT || npos <= 0) {
+		if(lane == 0) { ank_store(&V[0], none); G.hits[2 * x + strand] = 0; }
+		return;
+	}
+	for(int s = lane; s <= LA_P; s += 64) { s_w[s] = 0; s_last[s] = 0; }
+	__syncthreads();
+	int carry_h = -1, carry_cnt = 0;
+	uint32_t carry_v = NOLIST;
+	for(int c0 = 0; c0 < npos; c0 += LA_P) {
+		// the lists of this lane's LA_SEG k-mer starts, forward positions j0 .. j0 + LA_SEG - 1 (on the reverse strand forward position j is
+		// position npos - 1 - j of the reverse complement: the lane's window starts at its LAST position there)
+		const int j0 = c0 + lane * LA_SEG;
+		uint32_t v[LA_SEG];
+		{
+			uint32_t keys[LA_SEG], res[LA_SEG];
+			const int p_hi = npos - 1 - j0, base = max(p_hi - (LA_SEG - 1), 0);
+			const uint64_t w = j0 < npos ? qwin(q, strand ? base : j0) : 0ull;
+#pragma unroll
+			for(int i = 0; i < LA_SEG; ++i) {
+				const int sh = strand ? max(p_hi - i - base, 0) : i;
+				keys[i] = (uint32_t) ((w << (2 * sh)) >> (64 - 2 * k));
+			}
+			// a k-mer the presence bits do not know (small databases have them, db.hip) is not in the table: its lookup goes to bucket 0
+			// with every other such lookup -- one line for all of them instead of a line each -- and its answer is not looked at
+			bool maybe[LA_SEG];
+			if(g_kbits) {
+				uint32_t wd[LA_SEG];
+#pragma unroll
+				for(int i = 0; i < LA_SEG; ++i) wd[i] = g_kbits[((keys[i] * KMAHIP_KBITS_MUL) >> kb_sh) >> 5];
+#pragma unroll
+				for(int i = 0; i < LA_SEG; ++i) maybe[i] = (wd[i] >> (((keys[i] * KMAHIP_KBITS_MUL) >> kb_sh) & 31u)) & 1u;
+			} else {
+#pragma unroll
+				for(int i = 0; i < LA_SEG; ++i) maybe[i] = true;
+			}
+			Bucket bk[LA_SEG];
+#pragma unroll
+			for(int i = 0; i < LA_SEG; ++i) {
+				maybe[i] = maybe[i] && j0 + i < npos;
+				const uint32_t b = maybe[i] ? (keys[i] * 0x9E3779B1u) >> g_sh : 0u;
+				const KMAHIP_GLOBAL u32x4 *pb = g_slots + (size_t) b * (KMAHIP_BUCKET_SLOTS / 2);
+				bk[i].a = pb[0]; bk[i].c = pb[1];
+			}
+#pragma unroll
+			for(int i = 0; i < LA_SEG; ++i) res[i] = maybe[i] ? db_bucket_says(bk[i], keys[i]) : NOLIST;
+#pragma unroll 1
+			for(int i = 0; i < LA_SEG; ++i) if(res[i] == PROBE_MORE) {          // (the bucket is full of other keys: rare)
+				uint32_t g2 = NOLIST;
+#pragma unroll
+				for(int y = 0; y < LA_SEG; ++y) if(y == i) g2 = db_probe_from(A.db, keys[y]);
+#pragma unroll
+				for(int y = 0; y < LA_SEG; ++y) if(y == i) res[y] = g2;
+			}
+			uint32_t lid[LA_SEG];
+#pragma unroll
+			for(int i = 0; i < LA_SEG; ++i) lid[i] = g_vs_id[res[i] != NOLIST ? res[i] : 0u];
+#pragma unroll
+			for(int i = 0; i < LA_SEG; ++i) v[i] = res[i] != NOLIST ? lid[i] : NOLIST;
+		}
+		// the last hit at or before each lane's segment (inclusive scan of "last non-empty"), then the one before the segment
+		int lh = -1;
+		uint32_t lv = NOLIST;
+#pragma unroll
+		for(int i = 0; i < LA_SEG; ++i) if(v[i] != NOLIST) { lh = j0 + i; lv = v[i]; }
+		int h = lh;
+		uint32_t hv = lv;
+#pragma unroll
+		for(int d = 1; d < 64; d <<= 1) {
+			const int oh = __shfl_up(h, d);
+			const uint32_t ov = __shfl_up(hv, d);
+			if(lane >= d && h < 0) { h = oh; hv = ov; }
+		}
+		int ph = __shfl_up(h, 1);
+		uint32_t pv = __shfl_up(hv, 1);
+		if(lane == 0 || ph < 0) { ph = carry_h; pv = carry_v; }
+		// open (1) / continue at once (2) / continue behind exactly k missed starts (3), per hit
+		int opens = 0, th = ph;
+		uint32_t tv = pv, code = 0;
+#pragma unroll
+		for(int i = 0; i < LA_SEG; ++i) {
+			if(v[i] == NOLIST) continue;
+			const int j = j0 + i;
+			uint32_t c = 1;
+			if(th >= 0 && v[i] == tv) { const int gaps = j - th - 1; if(gaps == 0) c = 2; else if(gaps == k) c = 3; }
+			if(c == 1) ++opens;
+			code |= c << (2 * i);
+			th = j; tv = v[i];
+		}
+		int inc = opens;
+#pragma unroll
+		for(int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if(lane >= d) inc += o; }
+		// slot of the anchor in hand where the segment starts: the anchors opened in this pass before it (0: the one carried in)
+		int slot = inc - opens, accw = 0, accl = -1;
+#pragma unroll
+		for(int i = 0; i < LA_SEG; ++i) {
+			const uint32_t c = (code >> (2 * i)) & 3u;
+			if(!c) continue;
+			const int j = j0 + i;
+			if(c == 1) {
+				if(accl >= 0) { atomicAdd(&s_w[slot], accw); atomicMax(&s_last[slot], (uint32_t) accl); }
+				++slot;
+				s_start[slot] = (uint32_t) j; s_val[slot] = v[i];
+				accw = kM;
+			} else accw += c == 2 ? M1 : kMM;
+			accl = j;
+		}
+		if(accl >= 0) { atomicAdd(&s_w[slot], accw); atomicMax(&s_last[slot], (uint32_t) accl); }
+		__syncthreads();
+		const int n_new = __shfl(inc, 63);
+		if(n_new > 0) {
+			// every slot but the last is closed by the anchor behind it: it ends behind its last hit's k-mer + 1 (j - gaps + k at the hit
+			// that opens the next one, savekmers.c:5290-5300)
+			const int g0 = carry_cnt - 1;          // number of slot 0's anchor in the strand
+			for(int s = lane; s < n_new; s += 64) {
+				if(s == 0 && !carry_cnt) continue;
+				CAnk a;
+				a.score = 0; a.weight = s_w[s]; a.score_len = 0; a.len_len = 0;
+				a.start = s_start[s]; a.end = s_last[s] + 1u + (uint32_t) k; a.values = s_val[s]; a.descend = g0 + s + 1;
+				ank_store(&V[g0 + s], a);
+			}
+			const int cw = s_w[n_new];
+			const uint32_t cl = s_last[n_new], cs = s_start[n_new], cv = s_val[n_new];
+			__syncthreads();
+			for(int s = lane; s <= n_new; s += 64) { s_w[s] = 0; s_last[s] = 0; }
+			__syncthreads();
+			if(lane == 0) { s_w[0] = cw; s_last[0] = cl; s_start[0] = cs; s_val[0] = cv; }
+			__syncthreads();
+			carry_cnt += n_new;
+		}
+		const int eh = __shfl(h, 63);
+		const uint32_t ev = __shfl(hv, 63);
+		if(eh >= 0) { carry_h = eh; carry_v = ev; }
+	}
+	if(lane == 0) {
+		if(!carry_cnt) ank_store(&V[0], none);
+		else {
+			// the strand's last anchor ends at its last hit: seqlen - gaps with the k starts the read's end misses counted in (savekmers.c:5316-5330)
+			CAnk a;
+			a.score = 0; a.weight = s_w[0]; a.score_len = 0; a.len_len = 0;
+			a.start = s_start[0]; a.end = s_last[0]; a.values = s_val[0]; a.descend = -1;
+			ank_store(&V[carry_cnt - 1], a);
+		}
+		G.hits[2 * x + strand] = carry_cnt;
+	}
+}
+// chaining and extraction of the reads whose anchors chain_long_anchor_kernel has built: a lane per read, per-template arrays DB_size wide
+// in the lane's scratch as in chain_kernel
+__global__ __launch_bounds__(64, CHAIN_MIN_WAVES) void chain_long_tail_kernel(const ChainArgs A, const LongArgs G) {
+	const int64_t lane = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(lane >= A.lanes) return;
+	uint8_t *base = A.scratch + lane * A.lane_bytes;
+	const int64_t D = A.db.DB_size;
+	CLaneT<DenseMap> L;
+	L.db = &A.db;
+	L.dbl.values_u16 = A.db.values_u16; L.dbl.mlen = A.db.mlen; L.dbl.values16 = A.db.values16; L.dbl.values32 = A.db.values32;
+	L.VF = nullptr; L.VR = nullptr;
+	L.tm.Score = (int *) base; base += (size_t) (D + 1) * 4;
+	L.tm.extend = (int *) base; base += (size_t) (D + 1) * 4;
+	L.bestT = (int *) base; base += (size_t) A.b_cap * 4;
+	L.bestT_r = (int *) base; base += (size_t) A.b_cap * 4;
+	L.tree = (CSeg *) base; base += (size_t) A.s_cap * sizeof(CSeg);
+	L.ovf = (int *) (L.tree + (A.s_cap - 1));
+	*(GInt *) L.ovf = 0;
+	L.tm.include = (int8_t *) base;
+	L.tm.tlen = A.db.tlen;
+	L.k = (int) A.db.kmersize; L.M = A.M; L.MM = A.MM; L.U = A.U; L.W1 = A.W1; L.Wl = A.Wl;
+	L.a_cap = A.a_cap; L.b_cap = A.b_cap; L.s_cap = A.s_cap;
+	L.status = 0; L.tree_n = 0;
+	for(int64_t i = lane; i < G.count; i += A.lanes) {
+		const int64_t x = G.first + i, r = G.list[x];
+		const int hitF = G.hits[2 * x], hitR = G.hits[2 * x + 1];
+		const int seqlen = A.len[r];
+		if(seqlen < L.k || (!hitF && !hitR) || A.stop_after == 1) continue;
+		L.VF = G.pool + (G.v_off[x] - G.v_off[G.first]);
+		L.VR = L.VF + (seqlen - L.k + 2);
+		chain_read_tail(L, A, r, seqlen, (unsigned) hitF, (unsigned) hitR);
+		if(L.status) {
+			atomicMax(&A.counters[1], 40ull);
+			for(int64_t t = 0; t <= D; ++t) { L.tm.Score[t] = 0; L.tm.extend[t] = 0; L.tm.include[t] = 0; }
+			L.status = 0;
+		}
+	}
+}
+
 // The fast path, second kernel: chaining and extraction for the reads whose anchors chain_anchor_kernel (scan.hip) has built -- a
 // lane per read like chain_kernel, but the anchors come ready from a compact pool and the per-template state lives in a hashed
 // table in LDS, so a read costs a few dozen scattered accesses instead of 1 600. Per lane in HBM: two dummy anchors (a strand
@@ -997,9 +1237,17 @@ __global__ __launch_bounds__(64, CHAIN_FAST_WAVES) void chain_fast_kernel(const 
 	}
 }
 
-__global__ __launch_bounds__(256) void slow_list_kernel(int64_t n, const uint8_t *slow, int64_t *list, unsigned long long *count) {
+// the reads the fast route left: those without N's from the front of `list` (count[0]: the long-read route takes them when `split`), the
+// others from its end (count[1]: chain_kernel)
+__global__ __launch_bounds__(256) void slow_list_kernel(int64_t n, const uint8_t *slow, const int64_t *N_off, int split, int64_t *list, unsigned long long *count) {
 	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if(r < n && slow[r]) list[atomicAdd(count, 1ull)] = r;
+	if(r >= n || !slow[r]) return;
+	if(split && N_off[r + 1] == N_off[r]) list[atomicAdd(&count[0], 1ull)] = r;
+	else list[n - 1 - (int64_t) atomicAdd(&count[1], 1ull)] = r;
+}
+__global__ __launch_bounds__(256) void chain_long_keys_kernel(int64_t n_list, const int64_t *list, const int32_t *len, uint32_t *keys) {
+	const int64_t x = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(x < n_list) keys[x] = (uint32_t) len[list[x]];
 }
 
 }  // namespace
@@ -1057,8 +1305,8 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 	const char *route = getenv("KMAHIP_CHAIN");
 	const bool all_slow = route && !strcmp(route, "slow");
 	uint8_t *slow = nullptr;
-	int64_t *slow_list = nullptr;
-	int64_t n_slow = all_slow ? n : 0;
+	int64_t *slow_list = nullptr, *long_list = nullptr;
+	int64_t n_slow = all_slow ? n : 0, n_long = 0;
 	if(!all_slow) {
 		// (KMAHIP_CHAIN_CHUNK: reads per chunk, for the tests: many chunks out of a few thousand reads)
 		const int64_t CHUNK = getenv("KMAHIP_CHAIN_CHUNK") ? std::max<int64_t>(64, atoll(getenv("KMAHIP_CHAIN_CHUNK"))) : 2000000;
@@ -1153,12 +1401,86 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 		// what is left for the lane-per-read kernel
 		unsigned long long *cnt2 = cnt;
 		if((rc = dev((size_t) n * 8, (void **) &slow_list))) return rc;
-		HIP_TRY(hipMemsetAsync(cnt2, 0, 8, 0));
-		hipLaunchKernelGGL(slow_list_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, n, slow, slow_list, cnt2);
-		unsigned long long ns = 0;
-		HIP_TRY(hipMemcpy(&ns, cnt2, 8, hipMemcpyDeviceToHost));
-		n_slow = (int64_t) ns;
-		if(dbg) fprintf(stderr, "[kmahip] scan_chain: %lld of %lld reads left to the lane-per-read kernel\n", (long long) n_slow, (long long) n);
+		HIP_TRY(hipMemsetAsync(cnt2, 0, 16, 0));
+		// (KMAHIP_CHAIN_LONG=0: no long-read route, chain_kernel takes everything the fast route left)
+		const int split = !(getenv("KMAHIP_CHAIN_LONG") && !atoi(getenv("KMAHIP_CHAIN_LONG")));
+		hipLaunchKernelGGL(slow_list_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, n, slow, d->N_off, split, slow_list, cnt2);
+		unsigned long long ns[2] = {0, 0};
+		HIP_TRY(hipMemcpy(ns, cnt2, 16, hipMemcpyDeviceToHost));
+		n_long = (int64_t) ns[0];
+		n_slow = (int64_t) ns[1];
+		long_list = slow_list;
+		slow_list += n - n_slow;
+		if(dbg) fprintf(stderr, "[kmahip] scan_chain: of %lld reads %lld left to the long-read route, %lld to the lane-per-read kernel\n", (long long) n, (long long) n_long, (long long) n_slow);
+	}
+	if(n_long > 0) {
+		// ---- the long-read route: chain_long_anchor_kernel (a wavefront per read and strand) + chain_long_tail_kernel (a lane per read) ----
+		const int k = (int) db->info.kmersize;
+		// the reads by falling length: the 64 lanes of a tail wavefront pay for the longest of their reads
+		uint32_t *l_keys = nullptr, *l_keys2 = nullptr;
+		int64_t *l_list2 = nullptr, *l_cnt = nullptr, *v_off = nullptr;
+		int32_t *l_hits = nullptr;
+		void *l_tmp = nullptr;
+		size_t tmp_a = 0, tmp_b = 0;
+		if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_a, l_keys, l_keys2, long_list, l_list2, (size_t) n_long, 0u, 32u, (hipStream_t) 0) != hipSuccess ||
+		   rocprim::exclusive_scan((void *) nullptr, tmp_b, l_cnt, v_off, (int64_t) 0, (size_t) n_long + 1, rocprim::plus<int64_t>(), (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim size query failed"); return KMAHIP_EDEVICE; }
+		if((rc = dev((size_t) n_long * 4, (void **) &l_keys)) || (rc = dev((size_t) n_long * 4, (void **) &l_keys2)) || (rc = dev((size_t) n_long * 8, (void **) &l_list2)) ||
+		   (rc = dev((size_t) (n_long + 1) * 8, (void **) &l_cnt)) || (rc = dev((size_t) (n_long + 1) * 8, (void **) &v_off)) || (rc = dev((size_t) n_long * 8, (void **) &l_hits)) ||
+		   (rc = dev(std::max<size_t>(std::max(tmp_a, tmp_b), 16), &l_tmp))) return rc;
+		const unsigned gl = (unsigned) ((n_long + 255) / 256);
+		hipLaunchKernelGGL(chain_long_keys_kernel, dim3(gl), dim3(256), 0, 0, n_long, (const int64_t *) long_list, d->len, l_keys);
+		if(rocprim::radix_sort_pairs_desc(l_tmp, tmp_a, l_keys, l_keys2, long_list, l_list2, (size_t) n_long, 0u, 32u, (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
+		HIP_TRY(hipMemsetAsync(l_cnt + n_long, 0, 8, 0));
+		hipLaunchKernelGGL(chain_long_sizes_kernel, dim3(gl), dim3(256), 0, 0, n_long, (const int64_t *) l_list2, d->len, k, l_cnt);
+		if(rocprim::exclusive_scan(l_tmp, tmp_b, l_cnt, v_off, (int64_t) 0, (size_t) n_long + 1, rocprim::plus<int64_t>(), (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::exclusive_scan failed"); return KMAHIP_EDEVICE; }
+		int64_t total = 0;
+		HIP_TRY(hipMemcpy(&total, v_off + n_long, 8, hipMemcpyDeviceToHost));
+		// chunks of reads whose anchor regions fit the pool (KMAHIP_CHAIN_LONG_POOL_MB: 8 192; a read on its own always fits)
+		const int64_t budget = std::max<int64_t>(1, getenv("KMAHIP_CHAIN_LONG_POOL_MB") ? atoll(getenv("KMAHIP_CHAIN_LONG_POOL_MB")) : 8192) * ((1ll << 20) / (int64_t) sizeof(CAnk));
+		std::vector<int64_t> cut = {0, n_long};
+		int64_t pool_n = total;
+		if(total > budget) {
+			std::vector<int64_t> h_off((size_t) n_long + 1);
+			HIP_TRY(hipMemcpy(h_off.data(), v_off, (size_t) (n_long + 1) * 8, hipMemcpyDeviceToHost));
+			cut.assign(1, 0);
+			pool_n = 0;
+			while(cut.back() < n_long) {
+				const int64_t a = cut.back();
+				int64_t b = (int64_t) (std::upper_bound(h_off.begin() + a, h_off.end(), h_off[(size_t) a] + budget) - h_off.begin()) - 1;
+				b = std::min(std::max(b, a + 1), n_long);
+				pool_n = std::max(pool_n, h_off[(size_t) b] - h_off[(size_t) a]);
+				cut.push_back(b);
+			}
+		}
+		CAnk *l_pool = nullptr;
+		if((rc = dev((size_t) pool_n * sizeof(CAnk), (void **) &l_pool))) return rc;
+		ChainArgs Al = A;
+		Al.a_cap = 0; Al.b_cap = (int) std::min<int64_t>(2 * D + 4, 1 << 22); Al.s_cap = s_cap_of_len;
+		Al.lane_bytes = ((D + 1) * 8 + (int64_t) 2 * Al.b_cap * 4 + (int64_t) Al.s_cap * (int64_t) sizeof(CSeg) + (D + 1) + 63) & ~63ll;
+		int64_t lanes = 65536;
+		while(lanes > 64 && lanes * Al.lane_bytes > (16ll << 30)) lanes >>= 1;
+		int64_t most = 0;
+		for(size_t c = 0; c + 1 < cut.size(); ++c) most = std::max(most, cut[c + 1] - cut[c]);
+		lanes = std::min<int64_t>(lanes, ((most + 63) / 64) * 64);
+		Al.lanes = lanes;
+		void *l_scratch = nullptr;
+		if((rc = dev((size_t) (lanes * Al.lane_bytes), &l_scratch))) return rc;
+		HIP_TRY(hipMemsetAsync(l_scratch, 0, (size_t) (lanes * Al.lane_bytes), 0));
+		Al.scratch = (uint8_t *) l_scratch;
+		stamp("long-read route: lists, offsets, buffers");
+		for(size_t c = 0; c + 1 < cut.size(); ++c) {
+			LongArgs G = {l_list2, cut[c], cut[c + 1] - cut[c], v_off, l_pool, l_hits};
+			hipLaunchKernelGGL(chain_long_anchor_kernel, dim3((unsigned) (2 * G.count)), dim3(64), 0, 0, Al, G);
+			HIP_TRY(hipGetLastError());
+			stamp("long-read route: chain_long_anchor_kernel");
+			ChainArgs At = Al;
+			At.lanes = std::min<int64_t>(lanes, ((G.count + 63) / 64) * 64);
+			hipLaunchKernelGGL(chain_long_tail_kernel, dim3((unsigned) (At.lanes / 64)), dim3(64), 0, 0, At, G);
+			HIP_TRY(hipGetLastError());
+			stamp("long-read route: chain_long_tail_kernel");
+		}
+		HIP_TRY(hipStreamSynchronize(0));
+		drop(l_pool); drop(l_scratch);
 	}
 	if(n_slow > 0) {
 		// every list may name all templates of the database (redundant databases: thousands share a k-mer), on either strand

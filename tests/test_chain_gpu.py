@@ -184,3 +184,70 @@ def test_default_mode_session_with_batches_that_hold_no_record_and_with_no_read_
             subprocess.run([KMA, "-i", fq, "-o", str(tmp_path / "ref"), "-t_db", prefix, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             assert a[0] == open(tmp_path / "ref.res", "rb").read() and a[2] == gzip.open(tmp_path / "ref.frag.gz").read(), label
             assert a[2].count(b"\n") > 500
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("kind", ["genome", "genes"])
+def test_long_read_route_equals_lane_kernel_and_oracle(tmp_path, kind):
+    """stage 2 of long reads: chain_long_anchor_kernel (a wavefront per read and strand) + chain_long_tail_kernel against chain_kernel
+    (KMAHIP_CHAIN=slow: a lane per read, anchors included) and the oracle -- lengths on either side of the fast route's limit and of
+    the kernel's passes of 512 k-mer starts, reads shorter than k, unrelated reads, exact copies (one anchor spanning every pass), reads
+    glued from pieces of both strands, exhaustive mode, and the pool cut into many chunks"""
+    rng = np.random.default_rng(11)
+    if kind == "genome":
+        genome = rng.integers(0, 4, 300_000, dtype=np.uint8)
+        names, seqs = ["g"], [genome]
+    else:
+        names, seqs = synth.make_gene_db(40, 6, 800, 3000, 0.03, seed=77)
+        genome = np.concatenate(seqs)
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads = []
+    for L in (15, 16, 17, 303, 304, 305, 526, 527, 528, 529, 1038, 1039, 1040, 1041, 2000, 5000, 9000, 20000):
+        for err in (0.0, 0.1):
+            src = genome if kind == "genome" else seqs[int(rng.integers(0, len(seqs)))]
+            if len(src) < L:
+                src = genome
+            st = int(rng.integers(0, len(src) - L + 1))
+            w = src[st:st + L].copy()
+            m = rng.random(L) < err
+            w[m] = (w[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            reads.append(synth.revcomp_codes(w) if rng.random() < 0.5 else w)
+    reads += synth.make_long_reads(genome, 120, read_len=6000, seed=3) + synth.make_long_reads(genome, 40, read_len=700, seed=4)
+    reads += [rng.integers(0, 4, 4000, dtype=np.uint8) for _ in range(6)]
+    for _ in range(30):          # pieces of both strands glued together: several chains per read
+        parts = []
+        for _ in range(int(rng.integers(2, 7))):
+            src = seqs[int(rng.integers(0, len(seqs)))]
+            L = int(rng.integers(200, min(2500, len(src))))
+            st = int(rng.integers(0, len(src) - L + 1))
+            w = src[st:st + L].copy()
+            parts.append(synth.revcomp_codes(w) if rng.random() < 0.5 else w)
+        reads.append(np.concatenate(parts))
+    b = formats.pack_ragged(reads)
+    odb = oracle.OracleDB(prefix)
+    db = binding.KmaHipDB(prefix)
+    try:
+        for exhaustive in (0, 1):
+            want = [(i, rf, er, qs, qe, tuple(int(t) for t in T)) for i, recs in enumerate(odb.scan_chain(b, exhaustive=exhaustive)) for rf, er, qs, qe, T in recs]
+            slow = _with_env({"KMAHIP_CHAIN": "slow"}, lambda: _records(db.scan_chain(b, exhaustive=exhaustive)))
+            off = _with_env({"KMAHIP_CHAIN_LONG": "0"}, lambda: _records(db.scan_chain(b, exhaustive=exhaustive)))
+            got = _records(db.scan_chain(b, exhaustive=exhaustive))
+            cut = _with_env({"KMAHIP_CHAIN_LONG_POOL_MB": "1"}, lambda: _records(db.scan_chain(b, exhaustive=exhaustive)))
+            assert got == slow and off == slow and cut == slow, exhaustive
+            assert got == want, exhaustive
+            assert len(got) > 150
+    finally:
+        db.close()
