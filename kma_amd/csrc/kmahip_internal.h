@@ -125,8 +125,8 @@ struct kmahip_ws {
 	int64_t *p_rank;
 	int64_t p_total, p_node_cap, p_reads_cap, p_kept, p_nodes_used, p_ent_cap;
 	// long-read trace pipeline (longtrace.hip): per-wavefront MEM arrays, per-pass pools, queues, scratch, counters
-	void *lt_buf[12];
-	size_t lt_bytes[12];
+	void *lt_buf[20];
+	size_t lt_bytes[20];
 	unsigned long long lt_stats[4];   // of the last call: DP problems, DP cells, MEMs chained, reads
 	// slow-path dense scratch
 	int32_t *dense;

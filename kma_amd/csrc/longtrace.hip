@@ -1746,9 +1746,31 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 // it ((e & 7) == 1, >= 4, else), with the reference's tie rules: the diagonal wins every tie (nw.c:150-158 `D <= x`), an
 // extended gap in the read (P) wins against Q exactly when it beat its own opening (`Pn < x`), an opened one loses to Q.
 typedef uint32_t __attribute__((aligned(1))) lt_u32_u;
+__device__ __forceinline__ uint32_t lt_opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+// the new value of a row register INTO that register (the operand is tied): without it the compiler keeps the row before and the row
+// being made in registers of their own -- 2 R of them -- and spills; a reload inside the row loop waits for the move matrix' stores
+// (same counter) to reach HBM
+#define LT_ROW_SET(reg, val) asm volatile("v_mov_b32 %0, %1" : "+v"(reg) : "v"(val))
 
 template <int R>
-__global__ __launch_bounds__(64, (R <= 32 ? 5 : R <= 48 ? 4 : 3)) void lt_reg_kernel(const LtArgs A, const LaneArgs L) {
+// (wavefronts per SIMD: what leaves the row loop without a spilled register -- a reload waits for the move matrix' stores, which
+// count on the same counter, to reach HBM)
+#ifndef LT_REG16_WAVES
+#define LT_REG16_WAVES 4
+#endif
+#ifndef LT_REG32_WAVES
+#define LT_REG32_WAVES 4
+#endif
+#ifndef LT_REG48_WAVES
+#define LT_REG48_WAVES 3
+#endif
+#ifndef LT_REG64_WAVES
+#define LT_REG64_WAVES 2
+#endif
+#ifndef LT_RB72_WAVES
+#define LT_RB72_WAVES 2
+#endif
+__global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_WAVES : R <= 48 ? LT_REG48_WAVES : LT_REG64_WAVES)) void lt_reg_kernel(const LtArgs A, const LaneArgs L) {
 	extern __shared__ uint32_t lt_lane_lds[];
 	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64 query codes
@@ -1821,11 +1843,13 @@ __global__ __launch_bounds__(64, (R <= 32 ? 5 : R <= 48 ? 4 : 3)) void lt_reg_ke
 					const int G = max(Pn, Q);
 					const int D = max(G, x);
 					const bool pw = Pn + (c2 ? 1 : 0) > Q;          // c2 ? Pn >= Q : Pn > Q
-					uint32_t cell = (G <= x) ? (eq ? 1u : 65u) : (pw ? 4u : 2u);
+					// (both sides of the choice computed, then chosen: left to itself the compiler branches around the gap side, per cell)
+					const uint32_t cd = lt_opaque(eq ? 1u : 65u), cg = lt_opaque(pw ? 4u : 2u);
+					uint32_t cell = (G <= x) ? cd : cg;
 					cell |= (c1 ? 0u : 16u) | (c2 ? 0u : 32u);
-					row[j] = lt_pack16(D, Pn);
+					LT_ROW_SET(row[j], lt_pack16(D, Pn));
 					d0 = (j == offr) ? D : d0;
-					ew |= cell << ((j & 3) << 3);
+					ew |= lt_opaque(cell) << ((j & 3) << 3);          // (or every code constant lives in a register four times, shifted)
 					if((j & 3) == 0) {
 						// (every word of the row, also those left of column 0: their bytes fall on rows written later, or in front of the
 						// matrix; a store under a condition made the compiler put the four move bytes' arithmetic behind a branch)
@@ -1865,6 +1889,157 @@ __global__ __launch_bounds__(64, (R <= 32 ? 5 : R <= 48 ? 4 : 3)) void lt_reg_ke
 			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : Ro.n;
 			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
+		}
+	}
+}
+
+// The same for NW_band (lt_lane_band_kernel's recurrence, nw.c:310-640): the band's cells -- index n = column - (c - band / 2), c the
+// band's centre, one column to the left per row -- in R registers, aligned to the RIGHT (index n sits in register n + off, off = R - 2 -
+// band: the index beyond the band's last cell is the last register for every lane). The cell below index n is index n - 1 of the row
+// before and the diagonal one index n of it, so the row is still updated in place, right to left. What moves from row to row is where a
+// row starts (the cell right of the band, or the boundary column once the band reaches the last column: `first`) and where it ends (the
+// leftmost cell, which has no template-gap state: `edge`): two comparisons of a register's number with a lane's value per cell, whose
+// results replace the cell's values. The query codes of the registers move by one column per row: the code array is shifted by four bits
+// (one alignbit per eight registers) and the new code comes from LDS. Registers outside [edge, first] compute garbage that nothing reads;
+// their move bytes fall on cells no walk visits, on rows written later, or in front of the matrix (as in lt_reg_kernel).
+template <int R>
+__global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_kernel(const LtArgs A, const LaneArgs L) {
+	extern __shared__ uint32_t lt_lane_lds[];
+	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
+	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ / 2 x 64 query codes, two columns per byte
+	const int lane = threadIdx.x;
+	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
+	uint8_t *const Em = E + 128;
+	const int U = A.U, W1 = A.W1;
+	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
+	constexpr int NEG = -(1 << 28);
+	constexpr int NW = R / 8;
+	static_assert(R % 8 == 0, "eight query codes per register");
+	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
+		const LaneProb X = lt_lane_stage<true>(A, L, base, lane, T, QB);
+		LtProb *P = X.P;
+		const bool live = X.live;
+		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
+		int band = X.band;
+		if(band & 1) ++band;
+		const int half = band >> 1, bq = band + 1, pitch = bq + 1;
+		const int low = (t_len + q_len) * (A.MM + U + W1);
+		const int off = R - 1 - bq;                              // register of index 0
+		wave_sync();
+		auto qcode = [&](int col) { col = min(max(col, 0), q_len - 1); return (uint32_t) ((QB[(col >> 1) * 64 + lane] >> ((col & 1) << 2)) & 15u); };
+		// the row below the last one (nw.c:386-420): index sn0 is the boundary column; the query codes of the first row's registers
+		int c = (t_len + q_len) >> 1;
+		const int sn0 = q_len - 1 - (c - half);
+		uint32_t qreg[NW], row[R];
+#pragma unroll
+		for(int w = 0; w < NW; ++w) qreg[w] = 0;
+#pragma unroll
+		for(int j = 0; j < R; ++j) {
+			const int n = j - off;
+			qreg[j >> 3] |= (live ? qcode(c - half + n) : 0u) << ((j & 7) << 2);
+			int D = 0, Pn = 0;
+			if(n >= 0 && n <= sn0) {
+				if(n < sn0 && k != 2) D = W1 + (sn0 - n - 1) * U;
+				Pn = (n == sn0 && k != 2) ? 0 : low;
+			}
+			row[j] = lt_pack16(D, Pn);
+		}
+		if(live) for(int n = 0; n <= sn0; ++n) Em[(size_t) pitch * t_len + n] = (uint8_t) ((n < sn0 && k != 2) ? ((n == sn0 - 1) ? 18 : 3) : 0);
+		int en = 0, score = low, bm = 0, bn = 0, d_e = 0;
+		const int rows = live && !(L.ablate & 4) ? t_len : 0;
+		const int rows_max = wave_max(rows);
+		uint32_t tw = 0;
+		if(rows) tw = T[(((rows - 1) >> 4) << 6) + lane];
+		for(int r = 0; r < rows_max; ++r) {
+			if(r < rows) {
+				const int m = t_len - 1 - r;
+				const int tb = (int) ((tw >> (30 - ((m & 15) << 1))) & 3u);
+				if((m & 15) == 0 && m) tw = T[(((m - 1) >> 4) << 6) + lane];
+				// where the row starts and ends (open_row of lt_lane_band_kernel)
+				int sn;
+				bool clipped;
+				{
+					const int sq = c + half;
+					int eq = c - half;
+					if(eq < 0) { eq = 0; ++en; } else en = 0;
+					if(sq < q_len - 1) { sn = bq - 1; clipped = false; }
+					else { sn = en + (q_len - eq) - 1; clipped = true; }
+				}
+				const int fD = clipped ? ((0 < k) ? 0 : (W1 + r * U)) : low;
+				const uint32_t fcode = clipped ? ((0 < k) ? 0u : 37u) : 37u;
+				const int fj = lt_vgpr(sn + 1 + off), ej = lt_vgpr(en + off);
+				const bool col0 = c - half + en == 0;
+				// the code that enters the registers with the next row: column (c - 1) - half - off
+				const uint32_t q_next = qcode(c - 1 - half - off);
+				const uint32_t tbm = (uint32_t) tb * 0x11111111u;
+				uint32_t xq = 0;          // eight query codes ^ template base: 0 = match, bit 2 set = N in the read
+				int diag = (int) (short) (row[R - 1] & 0xffffu), right = 0, Qprev = low;
+				uint32_t ew = 0;
+				uint8_t *const er = Em + (size_t) pitch * m - off;      // byte of register j: er[j]
+#pragma unroll
+				for(int j = R - 1; j >= 0; --j) {
+					const uint32_t below = j ? row[j - 1] : 0u;
+					const int Dbl = (int) (short) (below & 0xffffu), Pbl = ((int) below) >> 16;
+					const bool isf = j == fj, ise = j == ej;
+					if((j & 7) == 7) { asm volatile("" : "+v"(qreg[j >> 3])); xq = qreg[j >> 3] ^ tbm; }
+					const uint32_t t = (xq >> ((j & 7) << 2)) & 15u;
+					const bool eq = t == 0;
+					const int sc = eq ? dM : ((t & 4u) ? dN : dX);
+					const int Q0 = right + W1, Qe = Qprev + U;
+					const bool c1 = Q0 < Qe;
+					int Q = max(Q0, Qe);
+					const int P0 = Dbl + W1, Pe = Pbl + U;
+					const bool c2 = P0 < Pe;
+					const int Pm = max(P0, Pe);
+					const int PnD = ise ? NEG : Pm;                  // the leftmost cell has no cell below it inside the band
+					int PnS = ise ? low : Pm;
+					const int x = diag + sc;
+					const int G = max(PnD, Q);
+					int D = max(G, x);
+					const bool pw = PnD + (c2 ? 1 : 0) > Q;          // c2 ? Pn >= Q : Pn > Q
+					const uint32_t cd = lt_opaque(eq ? 1u : 65u), cg = lt_opaque(pw ? 4u : 2u);
+					uint32_t cell = (G <= x) ? cd : cg;
+					cell |= (c1 ? 0u : 16u) | ((c2 || ise) ? 0u : 32u);
+					// the cell right of the band, or the boundary column where the band reaches it (nw.c:470-500)
+					D = isf ? fD : D; Q = isf ? low : Q; PnS = isf ? low : PnS; cell = isf ? fcode : cell;
+					LT_ROW_SET(row[j], lt_pack16(D, PnS));
+					d_e = ise ? D : d_e;
+					ew |= lt_opaque(cell) << ((j & 3) << 3);
+					if((j & 3) == 0) { *(lt_u32_u *) (er + j) = ew; ew = 0; }
+					diag = Dbl; right = D; Qprev = Q;
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				if(col0 && k < 0 && score < d_e) { score = d_e; bm = m; bn = en; }
+				// the next row's columns: every register one column to the left
+				--c;
+#pragma unroll
+				for(int w = NW - 1; w > 0; --w) qreg[w] = (qreg[w] << 4) | (qreg[w - 1] >> 28);
+				qreg[0] = (qreg[0] << 4) | q_next;
+			}
+		}
+		// result selection (nw.c:557-585): the leftmost cell of the first row unless a row above scored higher in column 0
+		int q_pos = 0;
+		if(live) {
+			if(bm == 0) { bn = en; score = d_e; }
+			if(k == -2) {
+				const int e2 = lt_vgpr(en + off);
+#pragma unroll
+				for(int j = 0; j < R - 1; ++j) {
+					const int Dn = (int) (short) (row[j] & 0xffffu);
+					if(j >= e2 && score <= Dn) { score = Dn; bm = 0; bn = j - (e2 - en); q_pos = j - e2; }
+				}
+			}
+		}
+		wave_sync_hbm();
+		if(live && !(L.ablate & 2)) {
+			RunOut Ro;
+			Ro.init(A.runs + P->runs, t_len + q_len + 1);
+			int clip = q_pos, bad = 0;
+			const int qend = lt_walk((const uint8_t *) Em, pitch, bm, bn, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
+			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			P->score = score; P->n_runs = bad ? 0 : Ro.n;
+			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
 		}
 	}
 }
@@ -2048,6 +2223,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	}
 	if(getenv("KMAHIP_LT_SCORE_TABLE")) simple_sc = false;
 	const bool reg_rows = simple_sc && !(getenv("KMAHIP_LT_REG") && getenv("KMAHIP_LT_REG")[0] == '0');      // lt_reg_kernel for the classes of up to 64 cells a row
+	const bool reg_band = reg_rows && !(getenv("KMAHIP_LT_REGBAND") && getenv("KMAHIP_LT_REGBAND")[0] == '0');  // lt_regband_kernel for the banded classes of up to 96 cells a row
 	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
 	LaneLaunch lg[LT_LCLS];
 	for(int j = 0; j < LT_LCLS; ++j) {
@@ -2055,7 +2231,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		lg[j].lds = (size_t) (32 + lg[j].g.R * 64 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * (j < LT_LFULL ? 64 : 32);
 		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
 		// (lt_reg_kernel keeps no row in LDS: its wavefronts per CU follow from its registers -- 5 / 5 / 4 / 3 per SIMD)
-		if(j <= 3 && reg_rows) lg[j].wgs = 256 * (j <= 1 ? 20 : j == 2 ? 16 : 12);
+		if(j <= 3 && reg_rows) lg[j].wgs = 256 * 4 * (j == 0 ? LT_REG16_WAVES : j == 1 ? LT_REG32_WAVES : j == 2 ? LT_REG48_WAVES : LT_REG64_WAVES);
+		// (lt_regband_kernel likewise: 3 / 2 per SIMD)
+		if((j == LT_LFULL || j == LT_LFULL + 1) && reg_band) lg[j].wgs = 256 * (j == LT_LFULL ? 4 * LT_RB72_WAVES : 8);
 		lg[j].e_off = 0;
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
@@ -2088,24 +2266,75 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(!rec && hipHostMalloc((void **) &rec, 2048 * 16 * 4, hipHostMallocMapped) != hipSuccess) rec = nullptr;
 		if(rec) { memset(rec, 0, 2048 * 16 * 4); uint32_t *drec = nullptr; if(hipHostGetDevicePointer((void **) &drec, rec, 0) == hipSuccess) A.rec = drec; }
 	}
-	for(int64_t r0 = 0; r0 < n;) {
-		const int64_t nb = std::min<int64_t>(B, n - r0);
-		if((rc = lt_reserve(ws, 1, (size_t) B * sizeof(LtRead))) || (rc = lt_reserve(ws, 2, (size_t) prob_cap * sizeof(LtProb))) ||
-		   (rc = lt_reserve(ws, 3, (size_t) runs_cap * 4)) || (rc = lt_reserve(ws, 4, (size_t) LT_NCLS * prob_cap * 4)) ||
-		   (lane_tq && (rc = lt_reserve(ws, 8, (size_t) 4 * prob_cap * 4)))) return rc;
-		A.lq = (int32_t *) ws->lt_buf[8]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[8] + prob_cap : nullptr; A.lane_tq = lane_tq; A.lane_mask = getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'f' ? 1 : (getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'b' ? 2 : 3);
-		A.lane_turns = getenv("KMAHIP_LT_LANE_TURNS") ? atoi(getenv("KMAHIP_LT_LANE_TURNS")) : (1 << 30);          // (tools/c4_time.py, 400 k reads: no cap 579 ms, 16 000 566, 12 000 590, 8 000 716, 5 000 994)
+	// Two sets of a pass's pools and counters: the seeding of pass i + 1 (index lookups: it waits) runs on a stream of its own beside the
+	// DP kernels of pass i (KMAHIP_LT_PIPE=0, one pass, or KMAHIP_DEBUG_TIMING: one set, one after the other). The run pool's top
+	// (ops_top) is one word for all passes, in the first set's counters.
+	const bool dbg0 = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
+	const bool piped = !dbg0 && n > B && !(getenv("KMAHIP_LT_PIPE") && getenv("KMAHIP_LT_PIPE")[0] == '0');
+	static const int SLOT[2][6] = {{1, 2, 3, 4, 8, 7}, {11, 12, 13, 14, 15, 16}};          // rd, prob, runs, queue, lane queue + keys, counters
+	static unsigned long long *hc = nullptr;          // pinned: the counters after the seeding ([x]) and after the finish ([2 + x]) of a set
+	if(!hc && hipHostMalloc((void **) &hc, (size_t) 4 * LC_N * 8, hipHostMallocDefault) != hipSuccess) { hc = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
+	constexpr int NSIDE = 3;
+	static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+	for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
+	struct Evs { hipEvent_t seed[2] = {nullptr, nullptr}, fin[2] = {nullptr, nullptr}; ~Evs() { for(int x = 0; x < 2; ++x) { if(seed[x]) (void) hipEventDestroy(seed[x]); if(fin[x]) (void) hipEventDestroy(fin[x]); } } } ev;
+	for(int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreateWithFlags(&ev.seed[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev.fin[x], hipEventDisableTiming)); }
+	bool fin_pending[2] = {false, false};
+	int64_t fin_nb[2] = {0, 0};
+	LtArgs Ap[2];
+	// the pools of set x at their present sizes, and A pointed at them for reads [r0, r0 + nb)
+	auto set_args = [&](int x, int64_t r0, int64_t nb) -> int {
+		const int *S = SLOT[x];
+		int rc2;
+		if((rc2 = lt_reserve(ws, S[0], (size_t) B * sizeof(LtRead))) || (rc2 = lt_reserve(ws, S[1], (size_t) prob_cap * sizeof(LtProb))) ||
+		   (rc2 = lt_reserve(ws, S[2], (size_t) runs_cap * 4)) || (rc2 = lt_reserve(ws, S[3], (size_t) LT_NCLS * prob_cap * 4)) ||
+		   (lane_tq && (rc2 = lt_reserve(ws, S[4], (size_t) 4 * prob_cap * 4))) || (rc2 = lt_reserve(ws, S[5], (LC_N + 1) * 8))) return rc2;
+		A.lq = (int32_t *) ws->lt_buf[S[4]]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[S[4]] + prob_cap : nullptr; A.lane_tq = lane_tq; A.lane_mask = getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'f' ? 1 : (getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'b' ? 2 : 3);
+		// a lane takes problems of up to this many cells: the longest problem of a class is what its kernel lasts (tools/c4_time.py, 200 k
+		// reads, trace stage: no cap 264 ms, 24 000 234, 16 000 226, 10 000 259, 6 000 409; with the passes overlapped 13 000 214, 16 000 210,
+		// 20 000 204, 24 000 205)
+		A.lane_turns = getenv("KMAHIP_LT_LANE_TURNS") ? atoi(getenv("KMAHIP_LT_LANE_TURNS")) : 20000;
 		// bits 8 + j: lane class j in use (KMAHIP_LT_LCLS: a bit per class, default all nine)
 		A.lane_mask |= (getenv("KMAHIP_LT_LCLS") ? (int) strtol(getenv("KMAHIP_LT_LCLS"), nullptr, 0) & 0x1ff : 0x1ff) << 8;
 		A.r0 = r0; A.n_reads = nb;
-		A.rd = (LtRead *) ws->lt_buf[1]; A.prob = (LtProb *) ws->lt_buf[2]; A.prob_cap = prob_cap;
-		A.runs = (uint32_t *) ws->lt_buf[3]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[4];
-		HIP_TRY(hipMemsetAsync(counters, 0, LC_OUT * 8, stream));
-		if(getenv("KMAHIP_DEBUG_TIMING")) { fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: seeding (prob_cap %lld, runs_cap %lld)\n", (long long) r0, (long long) nb, (long long) prob_cap, (long long) runs_cap); fflush(stderr); }
-		hipLaunchKernelGGL(lt_seed_kernel, dim3((unsigned) std::min<int64_t>(seed_wgs, nb)), dim3(64), 0, stream, A);
-		unsigned long long c[LC_N];
-		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
+		A.rd = (LtRead *) ws->lt_buf[S[0]]; A.prob = (LtProb *) ws->lt_buf[S[1]]; A.prob_cap = prob_cap;
+		A.runs = (uint32_t *) ws->lt_buf[S[2]]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[S[3]];
+		A.counters = (unsigned long long *) ws->lt_buf[S[5]];
+		A.ops_top = (unsigned long long *) ws->lt_buf[7] + LC_OUT;
+		A.mem = (int32_t *) ws->lt_buf[0]; A.mcap = mcap;
+		return KMAHIP_OK;
+	};
+	auto launch_seed = [&](int x, hipStream_t s) -> int {
+		HIP_TRY(hipMemsetAsync(A.counters, 0, LC_OUT * 8, s));
+		if(dbg0) { fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: seeding (prob_cap %lld, runs_cap %lld)\n", (long long) A.r0, (long long) A.n_reads, (long long) prob_cap, (long long) runs_cap); fflush(stderr); }
+		hipLaunchKernelGGL(lt_seed_kernel, dim3((unsigned) std::min<int64_t>(seed_wgs, A.n_reads)), dim3(64), 0, s, A);
+		HIP_TRY(hipMemcpyAsync(hc + (size_t) x * LC_N, A.counters, (size_t) LC_N * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipEventRecord(ev.seed[x], s));
+		Ap[x] = A;
+		return KMAHIP_OK;
+	};
+	// what the finish of set x's last pass left: status, work figures
+	auto fin_check = [&](int x) -> int {
+		if(!fin_pending[x]) return KMAHIP_OK;
+		fin_pending[x] = false;
+		HIP_TRY(hipEventSynchronize(ev.fin[x]));
+		const unsigned long long *cf = hc + (size_t) (2 + x) * LC_N;
+		if(cf[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
+		ws->lt_stats[0] += cf[LC_PROB]; ws->lt_stats[1] += cf[LC_CELLS]; ws->lt_stats[2] += cf[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) fin_nb[x];
+		if(cf[LC_STATUS] == 8 || cf[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", cf[LC_STATUS]); return KMAHIP_EDEVICE; }
+		return KMAHIP_OK;
+	};
+	int px = 0;              // the set of the pass in hand
+	bool seeded = false;     // its seeding was started beside the pass before
+	for(int64_t r0 = 0; r0 < n;) {
+		const int64_t nb = std::min<int64_t>(B, n - r0);
+		if(!seeded) {
+			if((rc = fin_check(px)) || (rc = set_args(px, r0, nb)) || (rc = launch_seed(px, stream))) return rc;
+		}
+		seeded = false;
+		A = Ap[px];
+		HIP_TRY(hipEventSynchronize(ev.seed[px]));
+		const unsigned long long *c = hc + (size_t) px * LC_N;
 		if(c[LC_STATUS] == 5 || c[LC_STATUS] == 6) {
 			// a pool of the pass ran out: larger pools (or a smaller pass), same reads again
 			if(c[LC_STATUS] == 5) prob_cap = std::max<int64_t>(2 * prob_cap, (int64_t) c[LC_PROB] + 1024);
@@ -2169,9 +2398,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(c[LC_LANE]) {
 			// the lane classes: one sort by (class, sweep length), longest first, then a kernel per class (below)
 			const size_t nl = (size_t) c[LC_LANE];
-			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) ws->lt_buf[8] + 3 * prob_cap;
+			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) A.lq + 3 * prob_cap;
 			int32_t *vals_in = A.lq;
-			vals_out = (int32_t *) ws->lt_buf[8] + 2 * prob_cap;
+			vals_out = A.lq + 2 * prob_cap;
 			size_t tmp_bytes = 0;
 			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
 			// the lanes' stretches of move matrix: as many workgroups per class as this pass has work for
@@ -2187,25 +2416,30 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		// (three side streams and the caller's: the runtime maps streams onto four hardware queues, and streams that share a queue
 		// run their kernels one after the other -- with five side streams the stage took 1.5 to 3.6 s for the same million reads,
 		// depending on which streams the process had made before)
-		constexpr int NSIDE = 3;
-		static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+		// (the third side stream is the seeding's: the sweeps use the caller's stream and two more)
 		hipStream_t s1 = stream, s2 = stream, s3 = stream;
 		hipEvent_t fork = nullptr, join[NSIDE] = {nullptr, nullptr, nullptr};
 		if(!dbg) {
-			for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
 			HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
 			HIP_TRY(hipEventRecord(fork, stream));
 			for(int x = 0; x < NSIDE; ++x) HIP_TRY(hipStreamWaitEvent(side[x], fork, 0));
-			s1 = side[0]; s2 = side[1]; s3 = side[2];
+			s1 = side[0]; s2 = side[1]; s3 = side[1];
 		}
+		// the stream of a wave-per-problem class (KMAHIP_LT_XSTREAMS: a digit per class 4 .. 16, 0 = the caller's stream, 1 / 2 = side streams)
+		auto xs = [&](int cls, hipStream_t dflt) -> hipStream_t {
+			const char *map = getenv("KMAHIP_LT_XSTREAMS");
+			if(!map || dbg || (int) strlen(map) <= cls - 4) return dflt;
+			const int x = map[cls - 4] - '0';
+			return x == 0 ? stream : x == 1 ? s1 : x == 2 ? s2 : dflt;
+		};
 		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
 		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
 		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
 		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
-		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s1, A); stage("dpx<2, full>"); }
-		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s1, A); stage("dpx<4, full>"); }
-		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s2, A); stage("dpx<2, banded>"); }
-		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, s2, A); stage("dpx<4, banded>"); }
+		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(4, s1), A); stage("dpx<2, full>"); }
+		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(5, s2), A); stage("dpx<4, full>"); }
+		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(6, s1), A); stage("dpx<2, banded>"); }
+		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(7, s2), A); stage("dpx<4, banded>"); }
 		// (the HBM variants and the one-lane class share the per-workgroup scratch of dpx_wgs workgroups: one stream, in turn)
 		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, s3, A); stage("serial"); }
 		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, full, HBM>"); }
@@ -2224,7 +2458,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				La.E = (uint8_t *) ws->lt_buf[10] + lg[j].e_off;
 				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
 				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
-				hipStream_t ls = j <= 3 ? stream : (j == LT_LFULL ? s1 : ((j == 5 || j == LT_LCLS - 1) ? s3 : s2));
+				hipStream_t ls = j <= 4 ? stream : (j == LT_LCLS - 1 ? s2 : s1);          // (tools/c4_time.py 200 000: class 4 on the second side stream 230 ms, here 210)
 				if(const char *map = getenv("KMAHIP_LT_STREAMS")) {       // diagnosis: a digit per lane class, 0 = the caller's stream, 1-3 = side streams
 					if((int) strlen(map) > j && !dbg) { const int x = map[j] - '0'; const hipStream_t all[4] = {stream, s1, s2, s3}; if(x >= 0 && x < 4) ls = all[x]; }
 				}
@@ -2240,11 +2474,16 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 					else if(j == 2) hipLaunchKernelGGL((lt_reg_kernel<48>), dim3(rgrid), dim3(64), lds, ls, A, La);
 					else hipLaunchKernelGGL((lt_reg_kernel<64>), dim3(rgrid), dim3(64), lds, ls, A, La);
 				}
+				else if((j == LT_LFULL || j == LT_LFULL + 1) && reg_band) {
+					const size_t lds = (size_t) (32 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 32;
+					if(j == LT_LFULL) hipLaunchKernelGGL((lt_regband_kernel<72>), dim3(grid), dim3(64), lds, ls, A, La);
+					else hipLaunchKernelGGL((lt_regband_kernel<96>), dim3(grid), dim3(64), lds, ls, A, La);
+				}
 				else if(j < LT_LFULL) { if(simple_sc) hipLaunchKernelGGL(lt_lane_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
 				else { if(simple_sc) hipLaunchKernelGGL(lt_lane_band_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_band_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
 				if(dbg) {
 					std::vector<uint32_t> hk((size_t) cnt);
-					(void) hipMemcpy(hk.data(), (uint32_t *) ws->lt_buf[8] + 3 * prob_cap + off, (size_t) cnt * 4, hipMemcpyDeviceToHost);
+					(void) hipMemcpy(hk.data(), (uint32_t *) A.lq + 3 * prob_cap + off, (size_t) cnt * 4, hipMemcpyDeviceToHost);
 					unsigned long long turns = 0, rounds = 0;
 					for(size_t x = 0; x < hk.size(); ++x) { turns += hk[x] & 0xFFFFFFu; if(x % 64 == 0) rounds += hk[x] & 0xFFFFFFu; }
 					fprintf(stderr, "[kmahip] longtrace: lane class %d: %llu problems, %llu turns of their sweeps, %llu turns of the wavefronts (x 64 = %.2f of them used), longest %u\n",
@@ -2264,14 +2503,20 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		hipLaunchKernelGGL(lt_finish_kernel, dim3((unsigned) std::min<int64_t>(fin_wgs, nb)), dim3(64), 0, stream, A);
 		stage("finish");
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(c, counters, sizeof c, hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
+		HIP_TRY(hipMemcpyAsync(hc + (size_t) (2 + px) * LC_N, A.counters, (size_t) LC_N * 8, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipEventRecord(ev.fin[px], stream));
+		fin_pending[px] = true; fin_nb[px] = nb;
 		if(fork) { (void) hipEventDestroy(fork); for(int x = 0; x < NSIDE; ++x) (void) hipEventDestroy(join[x]); }
-		if(c[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
-		ws->lt_stats[0] += c[LC_PROB]; ws->lt_stats[1] += c[LC_CELLS]; ws->lt_stats[2] += c[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) nb;
-		if(c[LC_STATUS] == 8 || c[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", c[LC_STATUS]); return KMAHIP_EDEVICE; }
 		r0 += nb;
+		if(piped && r0 < n) {
+			// the next pass's seeding beside this pass's sweeps, in the other set -- once that set's last pass is through
+			if((rc = fin_check(1 - px)) || (rc = set_args(1 - px, r0, std::min<int64_t>(B, n - r0))) || (rc = launch_seed(1 - px, side[2]))) return rc;
+			seeded = true;
+			px = 1 - px;
+		} else if((rc = fin_check(px))) return rc;
 	}
+	if((rc = fin_check(0)) || (rc = fin_check(1))) return rc;
+	HIP_TRY(hipStreamSynchronize(stream));
 	// the caller reads the pool top through the workspace counters like after trace_kernel: [0] = runs used, [1] = status
 	if(score_mode) return KMAHIP_OK;          // (no runs; the workspace's status word is stage 3a's)
 	unsigned long long fin[2] = {0, 0};
