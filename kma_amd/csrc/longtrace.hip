@@ -1770,7 +1770,7 @@ template <int R>
 #ifndef LT_RB72_WAVES
 #define LT_RB72_WAVES 2
 #endif
-__global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_WAVES : R <= 48 ? LT_REG48_WAVES : LT_REG64_WAVES)) void lt_reg_kernel(const LtArgs A, const LaneArgs L) {
+__global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_WAVES : R <= 48 ? LT_REG48_WAVES : R <= 64 ? LT_REG64_WAVES : 1)) void lt_reg_kernel(const LtArgs A, const LaneArgs L) {
 	extern __shared__ uint32_t lt_lane_lds[];
 	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64 query codes
@@ -2223,6 +2223,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	}
 	if(getenv("KMAHIP_LT_SCORE_TABLE")) simple_sc = false;
 	const bool reg_rows = simple_sc && !(getenv("KMAHIP_LT_REG") && getenv("KMAHIP_LT_REG")[0] == '0');      // lt_reg_kernel for the classes of up to 64 cells a row
+	const bool reg_wide = reg_rows && !(getenv("KMAHIP_LT_REG128") && getenv("KMAHIP_LT_REG128")[0] == '0');      // ... and of up to 128 (one wavefront per SIMD: 512 registers)
 	const bool reg_band = reg_rows && !(getenv("KMAHIP_LT_REGBAND") && getenv("KMAHIP_LT_REGBAND")[0] == '0');  // lt_regband_kernel for the banded classes of up to 96 cells a row
 	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
 	LaneLaunch lg[LT_LCLS];
@@ -2232,11 +2233,13 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		lg[j].wgs = 256 * (int) std::min<size_t>(16, (160 * 1024) / lg[j].lds);
 		// (lt_reg_kernel keeps no row in LDS: its wavefronts per CU follow from its registers -- 5 / 5 / 4 / 3 per SIMD)
 		if(j <= 3 && reg_rows) lg[j].wgs = 256 * 4 * (j == 0 ? LT_REG16_WAVES : j == 1 ? LT_REG32_WAVES : j == 2 ? LT_REG48_WAVES : LT_REG64_WAVES);
+		if(j == 4 && reg_wide) lg[j].wgs = 256 * 4;
 		// (lt_regband_kernel likewise: 3 / 2 per SIMD)
 		if((j == LT_LFULL || j == LT_LFULL + 1) && reg_band) lg[j].wgs = 256 * (j == LT_LFULL ? 4 * LT_RB72_WAVES : 8);
 		lg[j].e_off = 0;
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
+	if(const char *e = getenv("KMAHIP_LT_PASS_READS")) B = std::min<int64_t>(n, std::max<int64_t>(1, atoll(e)));          // (the tests: many passes out of a few reads)
 	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
 	int rc;
 	if((rc = lt_reserve(ws, 0, (size_t) seed_wgs * 7 * mcap * 4)) || (rc = lt_reserve(ws, 5, (size_t) fin_wgs * tmp_cap * 4)) ||
@@ -2294,8 +2297,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		// reads, trace stage: no cap 264 ms, 24 000 234, 16 000 226, 10 000 259, 6 000 409; with the passes overlapped 13 000 214, 16 000 210,
 		// 20 000 204, 24 000 205)
 		A.lane_turns = getenv("KMAHIP_LT_LANE_TURNS") ? atoi(getenv("KMAHIP_LT_LANE_TURNS")) : 20000;
-		// bits 8 + j: lane class j in use (KMAHIP_LT_LCLS: a bit per class, default all nine)
-		A.lane_mask |= (getenv("KMAHIP_LT_LCLS") ? (int) strtol(getenv("KMAHIP_LT_LCLS"), nullptr, 0) & 0x1ff : 0x1ff) << 8;
+		// bits 8 + j: lane class j in use (KMAHIP_LT_LCLS: a bit per class). Not class 8 (bands of over 93): a few thousand problems a pass, a
+		// hundred wavefronts that last as long as their longest problem -- the wavefront-per-problem kernels take them in a tenth of the time
+		A.lane_mask |= (getenv("KMAHIP_LT_LCLS") ? (int) strtol(getenv("KMAHIP_LT_LCLS"), nullptr, 0) & 0x1ff : 0x0ff) << 8;
 		A.r0 = r0; A.n_reads = nb;
 		A.rd = (LtRead *) ws->lt_buf[S[0]]; A.prob = (LtProb *) ws->lt_buf[S[1]]; A.prob_cap = prob_cap;
 		A.runs = (uint32_t *) ws->lt_buf[S[2]]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[S[3]];
@@ -2465,14 +2469,15 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				const void *fn = j < LT_LFULL ? (simple_sc ? (const void *) lt_lane_kernel<true> : (const void *) lt_lane_kernel<false>)
 				                       : (simple_sc ? (const void *) lt_lane_band_kernel<true> : (const void *) lt_lane_band_kernel<false>);
 				if(lg[j].lds > 65536) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lg[j].lds));
-				if(j <= 3 && reg_rows) {
+				if((j <= 3 || (j == 4 && reg_wide)) && reg_rows) {
 					// rows of up to 64 cells: the row in registers (lt_reg_kernel); no LDS but the staged template rows and query codes
 					const size_t lds = (size_t) (32 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 64;
 					const unsigned rgrid = grid;          // (the move matrices' scratch is sized for lg[j].wgs workgroups)
 					if(j == 0) hipLaunchKernelGGL((lt_reg_kernel<16>), dim3(rgrid), dim3(64), lds, ls, A, La);
 					else if(j == 1) hipLaunchKernelGGL((lt_reg_kernel<32>), dim3(rgrid), dim3(64), lds, ls, A, La);
 					else if(j == 2) hipLaunchKernelGGL((lt_reg_kernel<48>), dim3(rgrid), dim3(64), lds, ls, A, La);
-					else hipLaunchKernelGGL((lt_reg_kernel<64>), dim3(rgrid), dim3(64), lds, ls, A, La);
+					else if(j == 3) hipLaunchKernelGGL((lt_reg_kernel<64>), dim3(rgrid), dim3(64), lds, ls, A, La);
+					else hipLaunchKernelGGL((lt_reg_kernel<128>), dim3(rgrid), dim3(64), lds, ls, A, La);
 				}
 				else if((j == LT_LFULL || j == LT_LFULL + 1) && reg_band) {
 					const size_t lds = (size_t) (32 + lg[j].g.TW * 64) * 4 + (size_t) lg[j].g.RQ * 32;

@@ -87,7 +87,7 @@ def test_lane_classes_equal_the_wave_per_problem_kernels(setup):
     prefix, batch = setup
     ref = _run(prefix, batch, {"KMAHIP_LT_LANE": "0"})
     assert int((ref[0][:, 3] > 0).sum()) > 100          # most reads align
-    for env in ({}, {"KMAHIP_LT_LANE": "f"}, {"KMAHIP_LT_LANE": "b"}, {"KMAHIP_LT_SCORE_TABLE": "1"}, {"KMAHIP_LT_SEED_WGS": "7"}, {"KMAHIP_LT_REGBAND": "0"}, {"KMAHIP_LT_REG": "0"}):
+    for env in ({}, {"KMAHIP_LT_LCLS": "0x1ff"}, {"KMAHIP_LT_REG128": "0"}, {"KMAHIP_LT_PASS_READS": "23"}, {"KMAHIP_LT_PASS_READS": "23", "KMAHIP_LT_PIPE": "0"}, {"KMAHIP_LT_LANE": "f"}, {"KMAHIP_LT_LANE": "b"}, {"KMAHIP_LT_SCORE_TABLE": "1"}, {"KMAHIP_LT_SEED_WGS": "7"}, {"KMAHIP_LT_REGBAND": "0"}, {"KMAHIP_LT_REG": "0"}):
         _same(ref, _run(prefix, batch, env), str(env))
 
 
