@@ -766,9 +766,14 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 	if(A.stop_after == 2) return;
 
 	const int VF_start = (int) VF[0].start, VR_start = (int) VR[0].start;
-	int headF = prune(VF, 0, k), headR = prune(VR, 0, k);
-	if(headF < 0) best->score = 0;
-	if(headR < 0) best_r->score = 0;
+	// pruneAnkers (kmeranker.c:372-398) drops the anchors below k from the strands' lists, which only the search for the NEXT chain
+	// walks (best_anker): it is put off until a read gets that far -- the usual read ends after its first chain, and the walks are
+	// dependent loads from HBM, an anchor at a time. What the first chain needs of it is whether a strand has an anchor of k or more at
+	// all: its best one has. (Anchors silenced or taken in between have score 0: the search drops those from the lists by itself.)
+	int headF = 0, headR = 0;
+	bool pruned = false;
+	if(best->score < k) best->score = 0;
+	if(best_r->score < k) best_r->score = 0;
 	bestT[0] = 0; bestT_r[0] = 0;
 	int bi = (int) (best - VF), bri = (int) (best_r - VR);
 	int cStart = -1, cStart_r = -1, start = 0, len = 0, rc;
@@ -854,6 +859,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			}
 		}
 		// next chain of either strand (savekmers.c:5827-5925)
+		if(!pruned) { headF = prune(VF, 0, k); headR = prune(VR, 0, k); pruned = true; }
 		ties = 0;
 		rc = 0;
 		for(int side = 0; side < 2; ++side) {

@@ -1451,8 +1451,10 @@ struct AnchorArgs {
 __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorArgs A) {
 	__shared__ uint32_t s_val[GROUP * CA_VSTRIDE];          // value list per forward k-mer start (MISS: none), row stride odd
 	__shared__ uint64_t s_w[GROUP * CA_WORDS];              // the read in strand orientation
-	__shared__ uint32_t a_val[CA_AMAX * GROUP], a_start[CA_AMAX * GROUP], a_last[CA_AMAX * GROUP];
-	__shared__ int32_t a_w[CA_AMAX * GROUP];
+	// (an item's anchors side by side, the items CA_AMAX + 1 apart: as [anchor][item] the lanes of an item -- consecutive anchors -- fell on
+	// four banks, SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE)
+	__shared__ uint32_t a_val[(CA_AMAX + 1) * GROUP], a_start[(CA_AMAX + 1) * GROUP], a_last[(CA_AMAX + 1) * GROUP];
+	__shared__ int32_t a_w[(CA_AMAX + 1) * GROUP];
 	__shared__ int32_t s_npos[GROUP], s_cnt[GROUP], s_off[GROUP];
 	__shared__ int64_t s_item[GROUP];
 	__shared__ unsigned long long s_base;
@@ -1463,7 +1465,7 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 	const int64_t first = (int64_t) blockIdx.x * GROUP;
 	if(first >= n_active) return;
 	const int ng = (int) min((int64_t) GROUP, n_active - first);
-	for(int i = tid; i < CA_AMAX * GROUP; i += THREADS) { a_w[i] = 0; a_last[i] = 0; }
+	for(int i = tid; i < (CA_AMAX + 1) * GROUP; i += THREADS) { a_w[i] = 0; a_last[i] = 0; }
 	{
 		// phase 1 layout: item g = tid & 15, lane sl = tid >> 4 (as in scan_se_kernel: a wave's gathers belong to 16 reads)
 		const int g = tid & (GROUP - 1), sl = tid / GROUP;
@@ -1574,20 +1576,22 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 		int inc = opens;
 #pragma unroll
 		for(int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(inc, d, 16); if(ln >= d) inc += o; }
-		int idx = carry_cnt + inc - opens - 1;
+		// (a lane's hits of one anchor summed in registers: two LDS atomics per anchor and lane, not per hit)
+		int idx = carry_cnt + inc - opens - 1, accw = 0, accl = -1;
 #pragma unroll
 		for(int i = 0; i < CA_SEG; ++i) {
 			const uint32_t c = (code >> (2 * i)) & 3u;
 			if(!c) continue;
 			const int j = j0 + i;
 			if(c == 1) {
+				if(accl >= 0 && idx < CA_AMAX) { atomicAdd(&a_w[gi * (CA_AMAX + 1) + idx], accw); atomicMax(&a_last[gi * (CA_AMAX + 1) + idx], (uint32_t) accl); }
 				++idx;
-				if(idx < CA_AMAX) { a_start[idx * GROUP + gi] = (uint32_t) j; a_val[idx * GROUP + gi] = v[i]; atomicAdd(&a_w[idx * GROUP + gi], k * S.M); atomicMax(&a_last[idx * GROUP + gi], (uint32_t) j); }
-			} else if(idx < CA_AMAX) {
-				atomicAdd(&a_w[idx * GROUP + gi], c == 2 ? S.M : k * S.M + S.MM);
-				atomicMax(&a_last[idx * GROUP + gi], (uint32_t) j);
-			}
+				if(idx < CA_AMAX) { a_start[gi * (CA_AMAX + 1) + idx] = (uint32_t) j; a_val[gi * (CA_AMAX + 1) + idx] = v[i]; }
+				accw = k * S.M;
+			} else accw += c == 2 ? S.M : k * S.M + S.MM;
+			accl = j;
 		}
+		if(accl >= 0 && idx < CA_AMAX) { atomicAdd(&a_w[gi * (CA_AMAX + 1) + idx], accw); atomicMax(&a_last[gi * (CA_AMAX + 1) + idx], (uint32_t) accl); }
 		carry_cnt += __shfl(inc, 15, 16);
 		const int eh = __shfl(h, 15, 16);
 		const uint32_t ev = __shfl(hv, 15, 16);
@@ -1613,8 +1617,8 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 	(void) L;
 	for(int i = ln; i < n; i += 16) {
 		KmaAnk a;
-		const uint32_t last = a_last[i * GROUP + gi];
-		const uint32_t vi = a_val[i * GROUP + gi];
+		const uint32_t last = a_last[gi * (CA_AMAX + 1) + i];
+		const uint32_t vi = a_val[gi * (CA_AMAX + 1) + i];
 		// the head of the anchor's value list rides in the two fields the chaining keeps in registers (score_len: the length,
 		// and with 16-bit lists the first element in its upper half; len_len: the next two, or the first 32-bit one): the lane
 		// that chains the read (chain_fast_kernel) then needs no gather per anchor and listed template for lists of up to three
@@ -1625,8 +1629,8 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 		} else {
 			a.score_len = (int) db.values32[vi]; a.len_len = (int) db.values32[vi + 1];
 		}
-		a.score = 0; a.weight = a_w[i * GROUP + gi];
-		a.start = a_start[i * GROUP + gi];
+		a.score = 0; a.weight = a_w[gi * (CA_AMAX + 1) + i];
+		a.start = a_start[gi * (CA_AMAX + 1) + i];
 		// an anchor closed by the next one ends behind its last hit's k-mer + 1 (j - gaps + k at the opening hit j); the last one
 		// at seqlen - gaps with the k missed starts of the read's end counted in: its last hit (savekmers.c:5316-5330)
 		a.end = i < n - 1 ? last + 1u + (uint32_t) k : last;
