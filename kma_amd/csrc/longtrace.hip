@@ -1746,6 +1746,20 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 // it ((e & 7) == 1, >= 4, else), with the reference's tie rules: the diagonal wins every tie (nw.c:150-158 `D <= x`), an
 // extended gap in the read (P) wins against Q exactly when it beat its own opening (`Pn < x`), an opened one loses to Q.
 typedef uint32_t __attribute__((aligned(1))) lt_u32_u;
+typedef uint32_t lt_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lt_u32x4 __attribute__((ext_vector_type(4)));
+typedef lt_u32x2 __attribute__((aligned(1))) lt_u32x2_u;
+typedef lt_u32x4 __attribute__((aligned(1))) lt_u32x4_u;
+// The move bytes of sixteen registers per store (a lane's store is a line of its own whatever its width: the address path takes the 64
+// lanes of a store one after the other, and at four bytes a store the sweeps waited for it): register j's byte into word (j >> 2) & 3;
+// stored when j is the lowest register of its group of sixteen -- or of eight, where R leaves a group of eight at the top (a wider
+// store there would run into the row above, which is written already)
+#define LT_EW_PUT(R_, j_, cell_) do { const uint32_t sh_ = (cell_) << (((j_) & 3) << 3); \
+	if((((j_) >> 2) & 3) == 0) ew0 |= sh_; else if((((j_) >> 2) & 3) == 1) ew1 |= sh_; else if((((j_) >> 2) & 3) == 2) ew2 |= sh_; else ew3 |= sh_; \
+	if(((j_) & 15) == 0) { \
+		if((R_) - (j_) >= 16) { lt_u32x4 w_; w_.x = ew0; w_.y = ew1; w_.z = ew2; w_.w = ew3; *(lt_u32x4_u *) (er + (j_)) = w_; } \
+		else { lt_u32x2 w_; w_.x = ew0; w_.y = ew1; *(lt_u32x2_u *) (er + (j_)) = w_; } \
+		ew0 = 0; ew1 = 0; ew2 = 0; ew3 = 0; } } while(0)
 __device__ __forceinline__ uint32_t lt_opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 // the new value of a row register INTO that register (the operand is tied): without it the compiler keeps the row before and the row
 // being made in registers of their own -- 2 R of them -- and spills; a reload inside the row loop waits for the move matrix' stores
@@ -1819,7 +1833,8 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 				// the boundary column (nw.c:100-118), then the row right to left
 				int diag = (int) (short) (row[R - 1] & 0xffffu), right = bnd, Qprev = low;
 				row[R - 1] = lt_pack16(bnd, low);
-				uint32_t ew = bcode << 24;
+				uint32_t ew0 = 0, ew1 = 0, ew2 = 0, ew3 = 0;
+				{ const uint32_t b24 = bcode << 24; if((((R - 1) >> 2) & 3) == 3) ew3 = b24; else if((((R - 1) >> 2) & 3) == 2) ew2 = b24; else if((((R - 1) >> 2) & 3) == 1) ew1 = b24; else ew0 = b24; }
 				// (what depends on the column only -- a register's query code, whether it is column 0 -- is the same in every row: opaque
 				// copies per row keep the compiler from computing all of it in front of the loop, R and 2 R registers that it then spills)
 				const int offr = lt_vgpr(off);
@@ -1849,13 +1864,8 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 					cell |= (c1 ? 0u : 16u) | (c2 ? 0u : 32u);
 					LT_ROW_SET(row[j], lt_pack16(D, Pn));
 					d0 = (j == offr) ? D : d0;
-					ew |= lt_opaque(cell) << ((j & 3) << 3);          // (or every code constant lives in a register four times, shifted)
-					if((j & 3) == 0) {
-						// (every word of the row, also those left of column 0: their bytes fall on rows written later, or in front of the
-						// matrix; a store under a condition made the compiler put the four move bytes' arithmetic behind a branch)
-						*(lt_u32_u *) (er + j) = ew;
-						ew = 0;
-					}
+					// (the byte made opaque first, or every code constant lives in a register four times, shifted)
+					LT_EW_PUT(R, j, lt_opaque(cell));
 					diag = Db; right = D; Qprev = Q;
 					// (the scheduler would otherwise lift the column-only part of all R cells -- unpacking, query code, P side -- to the
 					// front of the row: hundreds of live registers, spilled)
@@ -1974,7 +1984,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 				const uint32_t tbm = (uint32_t) tb * 0x11111111u;
 				uint32_t xq = 0;          // eight query codes ^ template base: 0 = match, bit 2 set = N in the read
 				int diag = (int) (short) (row[R - 1] & 0xffffu), right = 0, Qprev = low;
-				uint32_t ew = 0;
+				uint32_t ew0 = 0, ew1 = 0, ew2 = 0, ew3 = 0;
 				uint8_t *const er = Em + (size_t) pitch * m - off;      // byte of register j: er[j]
 #pragma unroll
 				for(int j = R - 1; j >= 0; --j) {
@@ -2004,8 +2014,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 					D = isf ? fD : D; Q = isf ? low : Q; PnS = isf ? low : PnS; cell = isf ? fcode : cell;
 					LT_ROW_SET(row[j], lt_pack16(D, PnS));
 					d_e = ise ? D : d_e;
-					ew |= lt_opaque(cell) << ((j & 3) << 3);
-					if((j & 3) == 0) { *(lt_u32_u *) (er + j) = ew; ew = 0; }
+					LT_EW_PUT(R, j, lt_opaque(cell));
 					diag = Dbl; right = D; Qprev = Q;
 					__builtin_amdgcn_sched_barrier(0);
 				}
