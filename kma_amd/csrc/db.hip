@@ -285,6 +285,10 @@ extern "C" int kmahip_db_open(const char *prefix, kmahip_db **out) {
 	if(n > 0 && 8 * n < (1ull << 25) && !getenv("KMAHIP_NO_KBITS")) {        // (the switch exists for the test that compares both paths)
 		kbits_log2 = 16;
 		while((2ull << kbits_log2) <= 8 * n) ++kbits_log2;
+	} else if(n > 0 && n <= (1ull << 23) && !getenv("KMAHIP_NO_KBITS")) {
+		// up to 8 M k-mers (a bacterial genome): the 2 MiB that stay in L2, at 2-4 bits per k-mer (26 % false positives at 5 M, 39 % at
+		// 8 M) -- still worth it where nine lookups in ten miss: the seeding of long reads against one genome (longtrace.hip)
+		kbits_log2 = 24;
 	}
 
 	int rc;
