@@ -329,13 +329,15 @@ template <class CLane> __device__ __forceinline__ int bridge(const CLane &L, int
 
 // getBestChainTemplates: templates of the chain that ends in V[src] into bests[0 .. ]; the anchors it passes are silenced.
 // Returns the anchor the chain starts at, -1 none. `room`: slots bests may use.
-template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src, GInt *bests, int room) {
+// *cstart (may be NULL): where that anchor starts (the caller's V[prev].start, without the load).
+template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src, GInt *bests, int room, int *cstart = nullptr) {
 	const DbLite db = L.dbl;
 	if(src < 0) return -1;
 	int nextAnker = 0;
 	typedef typename CLane::Map Map;
+	// (the source anchor once: it is the first anchor of the walk and holds the chain's score -- three dependent loads were one)
+	const CAnk a = ank_load(&V[src]);
 	{
-		const CAnk a = ank_load(&V[src]);
 		const int n = ank_n<Map>(db, a);
 		if(n + 1 > room) { L.status = 1; bests[0] = 0; return -1; }
 		bests[0] = n;
@@ -345,10 +347,10 @@ template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src
 			if(++L.tm.I(L.tm.slot(t, L.status)) == 1) nextAnker = 1;
 		}
 	}
-	const int bestScore = V[src].score;
-	int prev = src;
+	const int bestScore = a.score;
+	int prev = src, prev_start = (int) a.start;
 	// (the anchor in hand in registers, the one below it and the head of its list asked for ahead: see the chaining loop)
-	CAnk nxt = ank_load(&V[src]);
+	CAnk nxt = a;
 	int nxt_n = nextAnker ? ank_n<Map>(db, nxt) : 0;
 	for(int node = src; nextAnker && node >= 0; --node) {
 		const CAnk cur = nxt;
@@ -373,7 +375,7 @@ template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src
 					tmp = L.W1 + (start - 1) * L.U;
 					tmp = score + (L.Wl < tmp ? tmp : L.Wl);
 				} else tmp = score;
-				if(tmp == bestScore) { score = bestScore; nextAnker = 0; prev = node; }
+				if(tmp == bestScore) { score = bestScore; nextAnker = 0; prev = node; prev_start = start; }
 			}
 			L.tm.E(th) = start;
 			L.tm.S(th) = score;
@@ -388,6 +390,7 @@ template <class CLane> __device__ int chain_templates(CLane &L, GAnk *V, int src
 		L.tm.S(th) = 0; L.tm.I(th) = 0; L.tm.E(th) = 0;
 	}
 	bests[0] = j;
+	if(cstart) *cstart = prev_start;
 	return j ? prev : -1;
 }
 
@@ -425,7 +428,8 @@ __device__ int tie_anker(const GAnk *V, int stop, int src, int best) {
 	return -1;
 }
 
-__device__ int choose_chain(const CAnk &b, const CAnk &r, int cStart, int cStart_r, double coverT, int *Start, int *Len) {
+struct ChEnd { int score; unsigned end; };      // what choose_chain reads of a strand's best anchor
+__device__ int choose_chain(const ChEnd &b, const ChEnd &r, int cStart, int cStart_r, double coverT, int *Start, int *Len) {
 	int rc = r.score < b.score ? 1 : b.score < r.score ? 2 : 3, start, end;
 	if(rc == 1) { start = cStart; end = (int) b.end; }
 	else if(rc == 2) { start = cStart_r; end = (int) r.end; }
@@ -686,6 +690,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 	// chains left to right, per strand (savekmers.c:5466-5634)
 	GAnk *best = nullptr, *best_r = &VF[0];
 	unsigned ties = 0;
+	int iF = 0, sF = 0, eF = 0, iR = 0, sR = 0, eR = 0;      // index, score and end of the forward / reverse strand's best anchor
 	int a_min = 0x7fffffff, a_max = 0;          // every anchor of either strand lies inside [a_min, a_max)
 	VF[0].score = 0;
 	{
@@ -706,7 +711,7 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			// what the comparisons below read of the best anchor so far; best_r points at V[0] BEFORE that anchor is chained, so the
 			// first comparison of a strand compares the anchor with itself -- an equality, which counts a tie (kept, b_idx == vi).
 			// The next anchor and the head of its value list are asked for while this one is worked on.
-			int b_idx = 0, b_score = 0, b_sl = 0, n_bests = 0;
+			int b_idx = 0, b_score = 0, b_sl = 0, b_end = 0, n_bests = 0;
 			typedef typename CLane::Map Map;
 			CAnk nxt = ank_load(&V[0]);
 			int nxt_n = HIT > 1 ? ank_n<Map>(db, nxt) : 0;
@@ -755,14 +760,16 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 					if(c_sl < a_sl) { best_r = &V[vi]; ties = 0; }
 					else { best_r = &V[vi]; ++ties; }
 				}
-				if(best_r == &V[vi]) { b_idx = vi; b_score = a_score; b_sl = a_sl; }
+				if(best_r == &V[vi]) { b_idx = vi; b_score = a_score; b_sl = a_sl; b_end = end; }
 				++vi;
 			}
+			// (what the extraction asks of the strand's best anchor, kept in registers: each was a dependent load from HBM)
+			if(strand) { iR = b_idx; sR = b_score; eR = b_end; } else { iF = b_idx; sF = b_score; eF = b_end; }
 			bests[0] = n_bests;
 			for(int i = 1; i <= bests[0]; ++i) { const int th = L.tm.slot(bests[i], L.status); L.tm.S(th) = 0; L.tm.E(th) = 0; L.tm.I(th) = 0; }
 		}
 	}
-	if(best->score < k && best_r->score < k) return;
+	if(sF < k && sR < k) return;
 	if(A.stop_after == 2) return;
 
 	const int VF_start = (int) VF[0].start, VR_start = (int) VR[0].start;
@@ -772,34 +779,26 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 	// all: its best one has. (Anchors silenced or taken in between have score 0: the search drops those from the lists by itself.)
 	int headF = 0, headR = 0;
 	bool pruned = false;
-	if(best->score < k) best->score = 0;
-	if(best_r->score < k) best_r->score = 0;
+	if(sF < k) { sF = 0; best->score = 0; }
+	if(sR < k) { sR = 0; best_r->score = 0; }
 	bestT[0] = 0; bestT_r[0] = 0;
-	int bi = (int) (best - VF), bri = (int) (best_r - VR);
+	int bi = iF, bri = iR;
 	int cStart = -1, cStart_r = -1, start = 0, len = 0, rc;
-	if(!best->score || !best_r->score) {
-		if(best->score) {
-			const int s = chain_templates(L, VF, bi, bestT, L.b_cap);
-			if(s < 0) return;
-			cStart = (int) VF[s].start; start = cStart; len = (int) VF[bi].end - start; rc = 1;
+	if(!sF || !sR) {
+		if(sF) {
+			if(chain_templates(L, VF, bi, bestT, L.b_cap, &cStart) < 0) return;
+			start = cStart; len = eF - start; rc = 1;
 		} else {
-			const int s = chain_templates(L, VR, bri, bestT_r, L.b_cap);
-			if(s < 0) return;
-			cStart_r = (int) VR[s].start; start = cStart_r; len = (int) VR[bri].end - start; rc = 2;
+			if(chain_templates(L, VR, bri, bestT_r, L.b_cap, &cStart_r) < 0) return;
+			start = cStart_r; len = eR - start; rc = 2;
 		}
 	} else {
-		int s = chain_templates(L, VF, bi, bestT, L.b_cap);
-		if(s < 0) return;
-		cStart = (int) VF[s].start;
-		s = chain_templates(L, VR, bri, bestT_r, L.b_cap);
-		if(s < 0) return;
-		cStart_r = (int) VR[s].start;
-		rc = choose_chain(ank_load(&VF[bi]), ank_load(&VR[bri]), cStart, cStart_r, A.coverT, &start, &len);
+		if(chain_templates(L, VF, bi, bestT, L.b_cap, &cStart) < 0) return;
+		if(chain_templates(L, VR, bri, bestT_r, L.b_cap, &cStart_r) < 0) return;
+		const ChEnd cb = {sF, (unsigned) eF}, cr = {sR, (unsigned) eR};
+		rc = choose_chain(cb, cr, cStart, cStart_r, A.coverT, &start, &len);
 	}
-	{
-		const int score = VF[bi].score > VR[bri].score ? VF[bi].score : VR[bri].score;
-		if(len < A.minlen || score < k) return;
-	}
+	if(len < A.minlen || (sF > sR ? sF : sR) < k) return;
 	if(A.stop_after == 3) return;
 	while((bi >= 0 || bri >= 0) && !L.status) {
 		if(ties) {
@@ -898,7 +897,11 @@ template <class CLane> __device__ void chain_read_tail(CLane &L, const ChainArgs
 			}
 		}
 		if(bi < 0 && bri < 0) break;
-		if(bi >= 0 && bri >= 0) rc = choose_chain(ank_load(&VF[bi]), ank_load(&VR[bri]), cStart, cStart_r, A.coverT, &start, &len);
+		if(bi >= 0 && bri >= 0) {
+			const CAnk ab = ank_load(&VF[bi]), ar = ank_load(&VR[bri]);
+			const ChEnd cb = {ab.score, ab.end}, cr = {ar.score, ar.end};
+			rc = choose_chain(cb, cr, cStart, cStart_r, A.coverT, &start, &len);
+		}
 		else if(bi >= 0) { rc = 1; start = cStart; len = (int) VF[bi].end - start; }
 		else { rc = 2; start = cStart_r; len = (int) VR[bri].end - start; }
 	}
