@@ -31,7 +31,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_seg); (void) hipFree(ws->p_vals);
 	(void) hipFree(ws->p_nodes); (void) hipFree(ws->p_keys); (void) hipFree(ws->p_rank);
 	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
-	for(int i = 0; i < 20; ++i) (void) hipFree(ws->lt_buf[i]);
+	for(int i = 0; i < 20; ++i) { if(i == 17) (void) hipHostFree(ws->lt_buf[i]); else (void) hipFree(ws->lt_buf[i]); }      // (17: pinned host memory, longtrace.hip)
 	delete ws;
 }
 

@@ -2309,8 +2309,13 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	const bool dbg0 = getenv("KMAHIP_DEBUG_TIMING") != nullptr;
 	const bool piped = !dbg0 && n > B && !(getenv("KMAHIP_LT_PIPE") && getenv("KMAHIP_LT_PIPE")[0] == '0');
 	static const int SLOT[2][6] = {{1, 2, 3, 4, 8, 7}, {11, 12, 13, 14, 15, 16}};          // rd, prob, runs, queue, lane queue + keys, counters
-	static unsigned long long *hc = nullptr;          // pinned: the counters after the seeding ([x]) and after the finish ([2 + x]) of a set
-	if(!hc && hipHostMalloc((void **) &hc, (size_t) 4 * LC_N * 8, hipHostMallocDefault) != hipSuccess) { hc = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
+	// pinned host memory of the workspace (slot 17 of its buffers; api.hip frees it as such): the counters after the seeding ([x]) and
+	// after the finish ([2 + x]) of a set
+	if(!ws->lt_buf[17]) {
+		if(hipHostMalloc(&ws->lt_buf[17], (size_t) 4 * LC_N * 8, hipHostMallocDefault) != hipSuccess) { ws->lt_buf[17] = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
+		ws->lt_bytes[17] = (size_t) 4 * LC_N * 8;
+	}
+	unsigned long long *const hc = (unsigned long long *) ws->lt_buf[17];
 	constexpr int NSIDE = 3;
 	static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
 	for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
