@@ -2209,6 +2209,49 @@ __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
 
 } // namespace
 
+// Streams that run side by side. Which hardware queue a stream lands on is the runtime's business (the first few streams of a process
+// get queues of their own, later ones share, by rules that changed between releases), so it is measured: two short spinning kernels, one
+// wavefront each, on two streams take one spin's time when the streams sit on different queues and two when they share one. Out of
+// eight candidates the first `want` that are pairwise side by side are kept (a few dozen launches of 0.2 ms, once per process).
+namespace {
+__global__ void lt_spin_kernel(long long ticks) {
+	const long long t0 = wall_clock64();
+	while(wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}
+static int lt_pick_streams(hipStream_t *out, int want) {
+	constexpr int NC = 8;
+	hipStream_t cand[NC];
+	for(int i = 0; i < NC; ++i) HIP_TRY(hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+	const long long ticks = 20000;          // 0.2 ms of the 100 MHz wall clock
+	auto pair_ms = [&](hipStream_t a, hipStream_t b) -> double {
+		(void) hipStreamSynchronize(a); (void) hipStreamSynchronize(b);
+		const auto t0 = std::chrono::steady_clock::now();
+		hipLaunchKernelGGL(lt_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+		hipLaunchKernelGGL(lt_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+		(void) hipStreamSynchronize(a); (void) hipStreamSynchronize(b);
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	};
+	(void) pair_ms(cand[0], cand[1]);          // (first launches)
+	int sel[NC], ns = 0;
+	bool used[NC] = {false};
+	sel[ns++] = 0; used[0] = true;
+	for(int c = 1; c < NC && ns < want; ++c) {
+		bool ok = true;
+		for(int x = 0; x < ns && ok; ++x) {
+			// the shorter of two tries: a try that something else delayed must not rule a stream out
+			const double ms = std::min(pair_ms(cand[sel[x]], cand[c]), pair_ms(cand[sel[x]], cand[c]));
+			ok = ms < 0.34;
+		}
+		if(ok) { sel[ns++] = c; used[c] = true; }
+	}
+	for(int c = 1; c < NC && ns < want; ++c) if(!used[c]) { sel[ns++] = c; used[c] = true; }      // (fewer queues than wanted: any)
+	for(int x = 0; x < want; ++x) out[x] = cand[sel[x]];
+	for(int c = 0; c < NC; ++c) if(!used[c]) (void) hipStreamDestroy(cand[c]);
+	if(getenv("KMAHIP_DEBUG_TIMING") || getenv("KMAHIP_LT_STREAM_REPORT")) { fprintf(stderr, "[kmahip] longtrace: streams"); for(int x = 0; x < want; ++x) fprintf(stderr, " %d", sel[x]); fprintf(stderr, " of %d candidates\n", NC); }
+	return KMAHIP_OK;
+}
+
 static int lt_reserve(kmahip_ws *ws, int slot, size_t bytes) {
 	if(ws->lt_bytes[slot] >= bytes) return KMAHIP_OK;
 	(void) hipFree(ws->lt_buf[slot]);
@@ -2316,9 +2359,25 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		ws->lt_bytes[17] = (size_t) 4 * LC_N * 8;
 	}
 	unsigned long long *const hc = (unsigned long long *) ws->lt_buf[17];
+	// FOUR streams of the pipeline's own that were SEEN to run side by side (lt_pick_streams): the runtime maps streams onto a few
+	// hardware queues, and streams that share a queue run their kernels one after the other. With the caller's stream as the first of the
+	// four and three more made on first use, the streams a process had made before decided whether the seeding shared a queue with the
+	// sweeps (tools/lt_streams_exp.py: 176 ms for the stage at 200 k reads with 0 or 4 streams made before, 192-204 with 1-3: the bench's C4
+	// leg, behind its other legs, against the same leg alone). The caller's stream waits for the work; it does none of it.
 	constexpr int NSIDE = 3;
-	static hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
-	for(int x = 0; x < NSIDE; ++x) if(!side[x]) HIP_TRY(hipStreamCreateWithFlags(&side[x], hipStreamNonBlocking));
+	static hipStream_t wk[NSIDE + 1] = {nullptr, nullptr, nullptr, nullptr};
+	if(!wk[0] && !dbg0) { const int rcw = lt_pick_streams(wk, NSIDE + 1); if(rcw) return rcw; }
+	for(int x = 0; x <= NSIDE; ++x) if(!wk[x]) HIP_TRY(hipStreamCreateWithFlags(&wk[x], hipStreamNonBlocking));
+	hipStream_t *const side = wk + 1;
+	const hipStream_t caller = stream;
+	if(!dbg0) {
+		hipEvent_t e0 = nullptr;
+		HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(e0, caller));
+		HIP_TRY(hipStreamWaitEvent(wk[0], e0, 0));
+		(void) hipEventDestroy(e0);
+		stream = wk[0];
+	}
 	struct Evs { hipEvent_t seed[2] = {nullptr, nullptr}, fin[2] = {nullptr, nullptr}; ~Evs() { for(int x = 0; x < 2; ++x) { if(seed[x]) (void) hipEventDestroy(seed[x]); if(fin[x]) (void) hipEventDestroy(fin[x]); } } } ev;
 	for(int x = 0; x < 2; ++x) { HIP_TRY(hipEventCreateWithFlags(&ev.seed[x], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ev.fin[x], hipEventDisableTiming)); }
 	bool fin_pending[2] = {false, false};
