@@ -1261,6 +1261,8 @@ __global__ __launch_bounds__(256) void chain_long_keys_kernel(int64_t n_list, co
 
 }  // namespace
 
+int kmahip_worker_streams(hipStream_t *out, int want);      // longtrace.hip: streams that were measured to run side by side
+
 // ---- the launch, everything in HBM: `d` holds DEVICE pointers; rec (8 ints per record: read lo, read hi, ordinal within the read,
 // rc_flag, emit_rc, q_start, q_end, number of templates), rec_T (first template of the record in T) and T are device buffers of
 // rec_cap / T_cap entries, filled in no particular order. n_recs / n_T: what the batch needs (KMAHIP_EOVERFLOW when that is more).
@@ -1325,11 +1327,13 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 		// KMAHIP_DEBUG_TIMING (stamps per kernel): one set of buffers, one after the other.
 		const int nbuf = (n_chunks > 1 && !dbg && !(getenv("KMAHIP_CHAIN_OVERLAP") && !atoi(getenv("KMAHIP_CHAIN_OVERLAP")))) ? 2 : 1;
 		struct Buf { CAnk *pool = nullptr; int64_t pool_cap = 0; int64_t *a_off = nullptr; int32_t *a_n = nullptr; unsigned long long *cnt = nullptr; } buf[2];
+		// (two of the process's worker streams, which were measured to run side by side: the chaining on the first, the anchors on the
+		// second. On the null stream and a stream made here the two shared a hardware queue or not by what the process had done before.)
 		struct Side {
-			hipStream_t s = nullptr; hipEvent_t e[2] = {nullptr, nullptr}; bool rec[2] = {false, false};
-			~Side() { if(s) { (void) hipStreamSynchronize(s); (void) hipStreamDestroy(s); } for(int x = 0; x < 2; ++x) if(e[x]) (void) hipEventDestroy(e[x]); }
+			hipStream_t s = nullptr, m = nullptr; hipEvent_t e[2] = {nullptr, nullptr}; bool rec[2] = {false, false};
+			~Side() { if(s) (void) hipStreamSynchronize(s); if(m) (void) hipStreamSynchronize(m); for(int x = 0; x < 2; ++x) if(e[x]) (void) hipEventDestroy(e[x]); }
 		} side;
-		HIP_TRY(hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+		{ hipStream_t W[2]; if((rc = kmahip_worker_streams(W, 2))) return rc; side.m = W[0]; side.s = W[1]; }
 		for(int x = 0; x < 2; ++x) HIP_TRY(hipEventCreateWithFlags(&side.e[x], hipEventDisableTiming));
 		if((rc = dev((size_t) n, (void **) &slow))) return rc;
 		for(int x = 0; x < nbuf; ++x) {
@@ -1389,19 +1393,20 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 			Ac.n_reads = m; Ac.seq_off = v.seq_off; Ac.len = v.len; Ac.N_off = v.N_off; Ac.read_base = r0;
 			FastArgs F = {buf[x].pool, buf[x].a_off, buf[x].a_n, slow + r0, nullptr};
 			if(order_on) {
-				hipLaunchKernelGGL(chain_order_keys_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, 0, m, buf[x].a_n, slow + r0, o_keys, o_vals);
-				if(rocprim::radix_sort_pairs_desc(o_tmp, o_tmp_bytes, o_keys, o_keys2, o_vals, o_vals2, (size_t) m, 0u, 8u, (hipStream_t) 0) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
+				hipLaunchKernelGGL(chain_order_keys_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, side.m, m, buf[x].a_n, slow + r0, o_keys, o_vals);
+				if(rocprim::radix_sort_pairs_desc(o_tmp, o_tmp_bytes, o_keys, o_keys2, o_vals, o_vals2, (size_t) m, 0u, 8u, side.m) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
 				F.order = o_vals2;
 				stamp("fast route: reads ordered by their anchors");
 			}
-			hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned) (std::min<int64_t>(Af.lanes, ((m + 63) / 64) * 64) / 64)), dim3(64), 0, 0, Ac, F);
+			hipLaunchKernelGGL(chain_fast_kernel, dim3((unsigned) (std::min<int64_t>(Af.lanes, ((m + 63) / 64) * 64) / 64)), dim3(64), 0, side.m, Ac, F);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipEventRecord(side.e[x], 0));
+			HIP_TRY(hipEventRecord(side.e[x], side.m));
 			side.rec[x] = true;
 			stamp("fast route: chain_fast_kernel");
 			if(nbuf == 1 && i + 1 < n_chunks && (rc = launch_anchors(i + 1))) return rc;
 		}
-		HIP_TRY(hipStreamSynchronize(0));
+		HIP_TRY(hipStreamSynchronize(side.m));
+		HIP_TRY(hipStreamSynchronize(side.s));
 		if(getenv("KMAHIP_CHAIN_TIMING")) fprintf(stderr, "[kmahip] scan_chain: fast route, %lld reads in %lld chunks, %d set(s) of buffers: %.1f ms\n", (long long) n, (long long) n_chunks, nbuf,
 		                                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_route).count());
 		unsigned long long *cnt = buf[0].cnt;

@@ -2252,6 +2252,14 @@ static int lt_pick_streams(hipStream_t *out, int want) {
 	return KMAHIP_OK;
 }
 
+// the process's worker streams (up to four), picked once: for every pipeline that runs kernels side by side (declared where it is used)
+int kmahip_worker_streams(hipStream_t *out, int want) {
+	static hipStream_t wk[4] = {nullptr, nullptr, nullptr, nullptr};
+	if(!wk[0]) { const int rc = lt_pick_streams(wk, 4); if(rc) return rc; }
+	for(int x = 0; x < want && x < 4; ++x) out[x] = wk[x];
+	return KMAHIP_OK;
+}
+
 static int lt_reserve(kmahip_ws *ws, int slot, size_t bytes) {
 	if(ws->lt_bytes[slot] >= bytes) return KMAHIP_OK;
 	(void) hipFree(ws->lt_buf[slot]);
@@ -2365,9 +2373,8 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	// sweeps (tools/lt_streams_exp.py: 176 ms for the stage at 200 k reads with 0 or 4 streams made before, 192-204 with 1-3: the bench's C4
 	// leg, behind its other legs, against the same leg alone). The caller's stream waits for the work; it does none of it.
 	constexpr int NSIDE = 3;
-	static hipStream_t wk[NSIDE + 1] = {nullptr, nullptr, nullptr, nullptr};
-	if(!wk[0] && !dbg0) { const int rcw = lt_pick_streams(wk, NSIDE + 1); if(rcw) return rcw; }
-	for(int x = 0; x <= NSIDE; ++x) if(!wk[x]) HIP_TRY(hipStreamCreateWithFlags(&wk[x], hipStreamNonBlocking));
+	hipStream_t wk[NSIDE + 1];
+	{ const int rcw = kmahip_worker_streams(wk, NSIDE + 1); if(rcw) return rcw; }
 	hipStream_t *const side = wk + 1;
 	const hipStream_t caller = stream;
 	if(!dbg0) {
