@@ -55,6 +55,10 @@ enum { PF_NONE = 1, PF_DEGEN_I = 2, PF_DEGEN_D = 4, PF_LEAD_TRIM = 8, PF_TRAIL_T
 constexpr int LT_LFULL = 6, LT_LCLS = 9;   // lane classes (lt_lane_kernel / lt_lane_band_kernel): 0..5 full matrix with rows of up to
                                       // 16 / 32 / 48 / 64 / 128 / 256 cells, 6..8 banded with rows of up to 72 / 96 / 144 (lt_lane_geom)
 enum { LC_STATUS = 1, LC_PROB = 2, LC_RUNS = 3, LC_CNT = 4, LC_CELLS = 21, LC_MEMS = 22, LC_LANE = 23, LC_LCNT = 24, LC_OUT = 24 + LT_LCLS, LC_N = 25 + LT_LCLS };
+// (a counter per 128-byte line: the seeding's wavefronts take their pool places and queue places with returning atomics, a million and a
+// half of them per pass, and atomics on one line are served one after the other)
+constexpr int LCS = 16;
+#define LCI(x) ((x) * LCS)
 
 struct LtRead {               // per read of the pass
 	int64_t first;            // first problem descriptor
@@ -244,7 +248,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 		bool scanning = false;
 		int carry_pos = -2, carry_v = 0, carry_F = 0, carry_B = 0;
 		for(int guard = 0;; ++guard) {
-			if(guard > q_len + 2) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }     // (cur advances every round)
+			if(guard > q_len + 2) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 11ull); return false; }     // (cur advances every round)
 			if(!scanning) { if(!(cur < segE - kk)) break; scanning = true; }
 			if(cur > segE - k) break;
 			const int p0 = cur;
@@ -375,7 +379,7 @@ __device__ bool lt_seed_strand(const LtArgs &A, SeedLds &S, const MemArr &Mm, co
 					cur = bias + 1;
 				}
 				scanning = false;
-				if(cur <= qs) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 11ull); return false; }
+				if(cur <= qs) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 11ull); return false; }
 				if(!(cur < segE - kk)) break;
 				scanning = true;
 				if(cur >= p0 + LT_TILE) break;
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				else if(bestScore == score) { base = 0; n = plen; H.rc = 0; }
 				else { base = plen; n = mc; H.rc = 1; qf.rc = 1; }
 			}
-			if(!room) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 3ull); n = 0; }
+			if(!room) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 3ull); n = 0; }
 			go = n > 0 && A.stop != 1;
 		}
 		wave_sync_hbm();    // the MEMs written by lane 0 are read by all lanes from here on
@@ -734,12 +738,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			const bool lds_next = n <= LT_NEXT_CAP;
 			const int np = nc + 1;
 			unsigned long long first = 0;
-			if(lane == 0) first = atomicAdd(&A.counters[LC_PROB], (unsigned long long) np);
+			if(lane == 0) first = atomicAdd(&A.counters[LCI(LC_PROB)], (unsigned long long) np);
 			first = __shfl(first, 0);
-			if((int64_t) first + np > A.prob_cap) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 5ull); go = false; }
+			if((int64_t) first + np > A.prob_cap) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 5ull); go = false; }
 			else {
 				H.first = (int64_t) first; H.n_prob = np; H.mapQ = (int) mapQ; H.status = 1;
-				if(lane == 0) atomicAdd(&A.counters[LC_MEMS], (unsigned long long) n);
+				if(lane == 0) atomicAdd(&A.counters[LCI(LC_MEMS)], (unsigned long long) n);
 				for(int l0 = 0; l0 < np; l0 += 64) {
 					const int l = l0 + lane;
 					Join J;
@@ -755,10 +759,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					const int incl = wave_scan_incl(need, lane);
 					const int total = __shfl(incl, 63);
 					unsigned long long rbase = 0;
-					if(lane == 63 && total) rbase = atomicAdd(&A.counters[LC_RUNS], (unsigned long long) total);
+					if(lane == 63 && total) rbase = atomicAdd(&A.counters[LCI(LC_RUNS)], (unsigned long long) total);
 					rbase = __shfl(rbase, 63);
 					const bool rfit = (int64_t) rbase + total <= A.runs_cap;
-					if(!rfit && lane == 0) atomicMax(&A.counters[LC_STATUS], 6ull);
+					if(!rfit && lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 6ull);
 					if(l < np) {
 						LtProb P;
 						P.runs = (int64_t) rbase + incl - need; P.read = (int32_t) rr; P.t_s = J.t_s; P.t_l = J.t_l; P.q_s = J.q_s; P.q_l = J.q_l;
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 						const long long cells = dp ? (long long) J.t_l * (J.band ? (J.band | 1) + 1 : J.q_l) : 0;
 						long long tot = cells;
 						for(int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-						if(lane == 0 && tot) atomicAdd(&A.counters[LC_CELLS], (unsigned long long) tot);
+						if(lane == 0 && tot) atomicAdd(&A.counters[LCI(LC_CELLS)], (unsigned long long) tot);
 					}
 					// queues per class, one atomic per class and round
 					int l_iters = 0;
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 						if(m) {
 							const int leader = __ffsll((long long) m) - 1;
 							unsigned long long qb = 0;
-							if(lane == leader) qb = atomicAdd(&A.counters[LC_LANE], (unsigned long long) __popcll(m));
+							if(lane == leader) qb = atomicAdd(&A.counters[LCI(LC_LANE)], (unsigned long long) __popcll(m));
 							qb = __shfl(qb, leader);
 							if(lcls >= 0) {
 								const size_t at = (size_t) qb + __popcll(m & ((1ull << lane) - 1ull));
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 							}
 							for(int c = 0; c < LT_LCLS; ++c) {
 								const unsigned long long mc = __ballot(lcls == c);
-								if(mc && lane == __ffsll((long long) mc) - 1) atomicAdd(&A.counters[LC_LCNT + c], (unsigned long long) __popcll(mc));
+								if(mc && lane == __ffsll((long long) mc) - 1) atomicAdd(&A.counters[LCI(LC_LCNT + c)], (unsigned long long) __popcll(mc));
 							}
 						}
 					}
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 						if(!m) continue;
 						const int leader = __ffsll((long long) m) - 1;
 						unsigned long long qb = 0;
-						if(lane == leader) qb = atomicAdd(&A.counters[LC_CNT + c], (unsigned long long) __popcll(m));
+						if(lane == leader) qb = atomicAdd(&A.counters[LCI(LC_CNT + c)], (unsigned long long) __popcll(m));
 						qb = __shfl(qb, leader);
 						if(cls == c) A.queue[(size_t) c * A.prob_cap + qb + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t) (first + l);
 					}
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(256) void lt_dp_kernel(const LtArgs A, int cls) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & (W - 1), g = lane / W;
 	uint8_t *const E = S.E[wave] + g * (LT_E_WAVE / G);
 	uint8_t *const tbuf = S.t[wave] + g * (LT_TMAX + 1);
-	const unsigned long long count = A.counters[LC_CNT + cls];
+	const unsigned long long count = A.counters[LCI(LC_CNT + cls)];
 	const int32_t *queue = A.queue + (size_t) cls * A.prob_cap;
 	const int U = A.U, W1 = A.W1;
 	for(unsigned long long base = ((unsigned long long) blockIdx.x * 4 + wave) * G; base < count; base += (unsigned long long) gridDim.x * 4 * G) {
@@ -1022,7 +1026,7 @@ __global__ __launch_bounds__(256) void lt_dp_kernel(const LtArgs A, int cls) {
 			int clip = sn, bad = 0;
 			const int q_pos = lt_walk((const uint8_t *) E, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : R.n;
 			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
 		}
@@ -1316,7 +1320,7 @@ __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
 	const int lane = threadIdx.x;
 	if(lane < 25) S.d[lane] = A.d[lane];
 	wave_sync();
-	const unsigned long long count = A.counters[LC_CNT + cls];
+	const unsigned long long count = A.counters[LCI(LC_CNT + cls)];
 	const int32_t *queue = A.queue + (size_t) cls * A.prob_cap;
 	for(unsigned long long idx = blockIdx.x; idx < count; idx += gridDim.x) {
 		LtProb *P = A.prob + lt_vgpr(queue[idx]);
@@ -1352,7 +1356,7 @@ __global__ __launch_bounds__(64) void lt_dpx_kernel(const LtArgs A) {
 			int clip = q_pos, bad = 0;
 			const int qend = lt_walk(E, pitch, sm, sn, banded ? -1 : 0, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, need, &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : R.n;
 			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
 			LT_REC(1, 5);
@@ -1369,7 +1373,7 @@ __global__ __launch_bounds__(64) void lt_serial_kernel(const LtArgs A) {
 	const int lane = threadIdx.x;
 	if(lane < 25) s_d[lane] = A.d[lane];
 	wave_sync();
-	const unsigned long long count = A.counters[LC_CNT + 8];
+	const unsigned long long count = A.counters[LCI(LC_CNT + 8)];
 	const int32_t *queue = A.queue + (size_t) 8 * A.prob_cap;
 	uint8_t *const xE = A.xE + (size_t) blockIdx.x * ((size_t) A.xe_cap + (size_t) 16 * A.xrow);
 	int32_t *const xrows = (int32_t *) (xE + A.xe_cap);
@@ -1391,7 +1395,7 @@ __global__ __launch_bounds__(64) void lt_serial_kernel(const LtArgs A) {
 		const bool ok = lt_serial(A, s_d, &Pu, q, ts, tlen_total, xE, A.xe_cap, xrows, A.xrow, score, sm, sn, q_pos, wpitch, dn);
 		wave_sync_hbm();
 		if(!LT_U((int) ok)) {
-			if(lane == 0) { atomicMax(&A.counters[LC_STATUS], 8ull); P->score = 0; P->n_runs = 0; P->clip = 0; P->flags |= PF_NONE; }
+			if(lane == 0) { atomicMax(&A.counters[LCI(LC_STATUS)], 8ull); P->score = 0; P->n_runs = 0; P->clip = 0; P->flags |= PF_NONE; }
 		} else {
 			RunOut R;
 			R.init(A.runs + Pu.runs, t_len + q_len + 1, lane == 0);
@@ -1399,7 +1403,7 @@ __global__ __launch_bounds__(64) void lt_serial_kernel(const LtArgs A) {
 			const int qend = lt_walk((const uint8_t *) xE, wpitch, sm, sn, dn, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) wpitch * (t_len + 1), &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
 			if(lane == 0) {
-				if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+				if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 				P->score = score; P->n_runs = bad ? 0 : R.n;
 				P->clip = (k > 0) ? (q_len - qend + cut) : clip;
 			}
@@ -1607,7 +1611,7 @@ __global__ __launch_bounds__(64) void lt_lane_kernel(const LtArgs A, const LaneA
 			int clip = sn, bad = 0;
 			const int q_pos = lt_walk((const uint8_t *) Em, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : R.n;
 			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
 		}
@@ -1752,7 +1756,7 @@ __global__ __launch_bounds__(64) void lt_lane_band_kernel(const LtArgs A, const 
 			int clip = q_pos, bad = 0;
 			const int qend = lt_walk((const uint8_t *) E, pitch, bm, bn, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &R, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = R.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : R.n;
 			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
 		}
@@ -1921,7 +1925,7 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 			int clip = sn, bad = 0;
 			const int q_pos = lt_walk((const uint8_t *) Em, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : Ro.n;
 			P->clip = (k > 0) ? (q_len - q_pos + cut) : clip;
 		}
@@ -2071,7 +2075,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 			int clip = q_pos, bad = 0;
 			const int qend = lt_walk((const uint8_t *) Em, pitch, bm, bn, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
 			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
-			if(bad) atomicMax(&A.counters[LC_STATUS], 10ull);
+			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : Ro.n;
 			P->clip = (k > 0) ? (q_len - qend + cut) : clip;
 		}
@@ -2129,7 +2133,7 @@ __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
 			score += sc;
 			n_ent += tot;
 		}
-		if(over) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 9ull); continue; }
+		if(over) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 9ull); continue; }
 		score = wave_sum(score);
 		lead_cols = __shfl(lead_cols, 0); lead_clip = __shfl(lead_clip, 0);
 		trail_clip = __shfl(trail_clip, (H.n_prob - 1) & 63);
@@ -2165,7 +2169,7 @@ __global__ __launch_bounds__(64) void lt_finish_kernel(const LtArgs A) {
 		unsigned long long ob = 0;
 		if(lane == 0) ob = atomicAdd(A.ops_top, (unsigned long long) n_merged);
 		ob = __shfl(ob, 0);
-		if((int64_t) ob + n_merged > A.ops_cap) { if(lane == 0) atomicMax(&A.counters[LC_STATUS], 2ull); continue; }
+		if((int64_t) ob + n_merged > A.ops_cap) { if(lane == 0) atomicMax(&A.counters[LCI(LC_STATUS)], 2ull); continue; }
 		uint32_t *out = A.ops + ob;
 		int w = 0, carry_cls = -1, carry_len = 0;
 		for(int c0 = 0; c0 < n_ent; c0 += 64) {
@@ -2328,9 +2332,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	int64_t prob_cap = B * (max_len / 16 + 4), runs_cap = B * (3ll * max_len + 64);
 	int rc;
 	if((rc = lt_reserve(ws, 0, (size_t) seed_wgs * 7 * mcap * 4)) || (rc = lt_reserve(ws, 5, (size_t) fin_wgs * tmp_cap * 4)) ||
-	   (rc = lt_reserve(ws, 6, (size_t) dpx_wgs * ((size_t) xe_cap + 16 * (size_t) xrow))) || (rc = lt_reserve(ws, 7, (LC_N + 1) * 8))) return rc;
+	   (rc = lt_reserve(ws, 6, (size_t) dpx_wgs * ((size_t) xe_cap + 16 * (size_t) xrow))) || (rc = lt_reserve(ws, 7, LCI(LC_N + 1) * 8))) return rc;
 	unsigned long long *counters = (unsigned long long *) ws->lt_buf[7];
-	HIP_TRY(hipMemsetAsync(counters, 0, (LC_N + 1) * 8, stream));
+	HIP_TRY(hipMemsetAsync(counters, 0, LCI(LC_N + 1) * 8, stream));
 	for(int i = 0; i < 4; ++i) ws->lt_stats[i] = 0;
 	LtArgs A;
 	A.db = db->dev;
@@ -2346,7 +2350,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	A.xE = (uint8_t *) ws->lt_buf[6]; A.xe_cap = xe_cap; A.xrow = xrow;
 	A.counters = counters;
 	A.o_stats = out->stats; A.o_off = out->ops_off; A.o_nops = out->n_ops; A.ops = out->ops; A.ops_cap = out->ops_cap;
-	A.ops_top = counters + LC_OUT; A.o_rc = rc_out;
+	A.ops_top = counters + LCI(LC_OUT); A.o_rc = rc_out;
 	A.rec = nullptr;
 	A.stop = getenv("KMAHIP_LT_STOP") ? atoi(getenv("KMAHIP_LT_STOP")) : 0;
 	if(getenv("KMAHIP_DEBUG_TIMING")) {
@@ -2363,8 +2367,8 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	// pinned host memory of the workspace (slot 17 of its buffers; api.hip frees it as such): the counters after the seeding ([x]) and
 	// after the finish ([2 + x]) of a set
 	if(!ws->lt_buf[17]) {
-		if(hipHostMalloc(&ws->lt_buf[17], (size_t) 4 * LC_N * 8, hipHostMallocDefault) != hipSuccess) { ws->lt_buf[17] = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
-		ws->lt_bytes[17] = (size_t) 4 * LC_N * 8;
+		if(hipHostMalloc(&ws->lt_buf[17], (size_t) 4 * LCI(LC_N) * 8, hipHostMallocDefault) != hipSuccess) { ws->lt_buf[17] = nullptr; kmahip_set_error("hipHostMalloc failed"); return KMAHIP_ENOMEM; }
+		ws->lt_bytes[17] = (size_t) 4 * LCI(LC_N) * 8;
 	}
 	unsigned long long *const hc = (unsigned long long *) ws->lt_buf[17];
 	// FOUR streams of the pipeline's own that were SEEN to run side by side (lt_pick_streams): the runtime maps streams onto a few
@@ -2396,7 +2400,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		int rc2;
 		if((rc2 = lt_reserve(ws, S[0], (size_t) B * sizeof(LtRead))) || (rc2 = lt_reserve(ws, S[1], (size_t) prob_cap * sizeof(LtProb))) ||
 		   (rc2 = lt_reserve(ws, S[2], (size_t) runs_cap * 4)) || (rc2 = lt_reserve(ws, S[3], (size_t) LT_NCLS * prob_cap * 4)) ||
-		   (lane_tq && (rc2 = lt_reserve(ws, S[4], (size_t) 4 * prob_cap * 4))) || (rc2 = lt_reserve(ws, S[5], (LC_N + 1) * 8))) return rc2;
+		   (lane_tq && (rc2 = lt_reserve(ws, S[4], (size_t) 4 * prob_cap * 4))) || (rc2 = lt_reserve(ws, S[5], LCI(LC_N + 1) * 8))) return rc2;
 		A.lq = (int32_t *) ws->lt_buf[S[4]]; A.lkey = lane_tq ? (uint32_t *) ws->lt_buf[S[4]] + prob_cap : nullptr; A.lane_tq = lane_tq; A.lane_mask = getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'f' ? 1 : (getenv("KMAHIP_LT_LANE") && getenv("KMAHIP_LT_LANE")[0] == 'b' ? 2 : 3);
 		// a lane takes problems of up to this many cells: the longest problem of a class is what its kernel lasts (tools/c4_time.py, 200 k
 		// reads, trace stage: no cap 264 ms, 24 000 234, 16 000 226, 10 000 259, 6 000 409; with the passes overlapped 13 000 214, 16 000 210,
@@ -2409,15 +2413,15 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		A.rd = (LtRead *) ws->lt_buf[S[0]]; A.prob = (LtProb *) ws->lt_buf[S[1]]; A.prob_cap = prob_cap;
 		A.runs = (uint32_t *) ws->lt_buf[S[2]]; A.runs_cap = runs_cap; A.queue = (int32_t *) ws->lt_buf[S[3]];
 		A.counters = (unsigned long long *) ws->lt_buf[S[5]];
-		A.ops_top = (unsigned long long *) ws->lt_buf[7] + LC_OUT;
+		A.ops_top = (unsigned long long *) ws->lt_buf[7] + LCI(LC_OUT);
 		A.mem = (int32_t *) ws->lt_buf[0]; A.mcap = mcap;
 		return KMAHIP_OK;
 	};
 	auto launch_seed = [&](int x, hipStream_t s) -> int {
-		HIP_TRY(hipMemsetAsync(A.counters, 0, LC_OUT * 8, s));
+		HIP_TRY(hipMemsetAsync(A.counters, 0, LCI(LC_OUT) * 8, s));
 		if(dbg0) { fprintf(stderr, "[kmahip] longtrace pass %lld+%lld: seeding (prob_cap %lld, runs_cap %lld)\n", (long long) A.r0, (long long) A.n_reads, (long long) prob_cap, (long long) runs_cap); fflush(stderr); }
 		hipLaunchKernelGGL(lt_seed_kernel, dim3((unsigned) std::min<int64_t>(seed_wgs, A.n_reads)), dim3(64), 0, s, A);
-		HIP_TRY(hipMemcpyAsync(hc + (size_t) x * LC_N, A.counters, (size_t) LC_N * 8, hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(hc + (size_t) x * LCI(LC_N), A.counters, (size_t) LCI(LC_N) * 8, hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipEventRecord(ev.seed[x], s));
 		Ap[x] = A;
 		return KMAHIP_OK;
@@ -2427,10 +2431,10 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(!fin_pending[x]) return KMAHIP_OK;
 		fin_pending[x] = false;
 		HIP_TRY(hipEventSynchronize(ev.fin[x]));
-		const unsigned long long *cf = hc + (size_t) (2 + x) * LC_N;
-		if(cf[LC_STATUS] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
-		ws->lt_stats[0] += cf[LC_PROB]; ws->lt_stats[1] += cf[LC_CELLS]; ws->lt_stats[2] += cf[LC_MEMS]; ws->lt_stats[3] += (unsigned long long) fin_nb[x];
-		if(cf[LC_STATUS] == 8 || cf[LC_STATUS] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", cf[LC_STATUS]); return KMAHIP_EDEVICE; }
+		const unsigned long long *cf = hc + (size_t) (2 + x) * LCI(LC_N);
+		if(cf[LCI(LC_STATUS)] == 10) { kmahip_set_error("long-read trace: a move matrix was left through a non-boundary cell (internal error)"); return KMAHIP_EDEVICE; }
+		ws->lt_stats[0] += cf[LCI(LC_PROB)]; ws->lt_stats[1] += cf[LCI(LC_CELLS)]; ws->lt_stats[2] += cf[LCI(LC_MEMS)]; ws->lt_stats[3] += (unsigned long long) fin_nb[x];
+		if(cf[LCI(LC_STATUS)] == 8 || cf[LCI(LC_STATUS)] == 9) { kmahip_set_error("long-read trace: a DP problem or a read's run list beyond the scratch (status %llu)", cf[LCI(LC_STATUS)]); return KMAHIP_EDEVICE; }
 		return KMAHIP_OK;
 	};
 	int px = 0;              // the set of the pass in hand
@@ -2443,15 +2447,15 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		seeded = false;
 		A = Ap[px];
 		HIP_TRY(hipEventSynchronize(ev.seed[px]));
-		const unsigned long long *c = hc + (size_t) px * LC_N;
-		if(c[LC_STATUS] == 5 || c[LC_STATUS] == 6) {
+		const unsigned long long *c = hc + (size_t) px * LCI(LC_N);
+		if(c[LCI(LC_STATUS)] == 5 || c[LCI(LC_STATUS)] == 6) {
 			// a pool of the pass ran out: larger pools (or a smaller pass), same reads again
-			if(c[LC_STATUS] == 5) prob_cap = std::max<int64_t>(2 * prob_cap, (int64_t) c[LC_PROB] + 1024);
-			else runs_cap = std::max<int64_t>(2 * runs_cap, (int64_t) c[LC_RUNS] + 1024);
+			if(c[LCI(LC_STATUS)] == 5) prob_cap = std::max<int64_t>(2 * prob_cap, (int64_t) c[LCI(LC_PROB)] + 1024);
+			else runs_cap = std::max<int64_t>(2 * runs_cap, (int64_t) c[LCI(LC_RUNS)] + 1024);
 			if(prob_cap * (int64_t) sizeof(LtProb) > (48ll << 30) || runs_cap * 4 > (96ll << 30)) { kmahip_set_error("long-read trace: pools of a pass beyond 96 GB"); return KMAHIP_ENOMEM; }
 			continue;
 		}
-		if(c[LC_STATUS] == 3) {
+		if(c[LCI(LC_STATUS)] == 3) {
 			// a read full of repeats: more MEMs against its template than a wavefront has slots for -- more slots, same reads again
 			if(mcap >= (1 << 16)) { kmahip_set_error("seed (MEM) capacity per read exceeded (%d MEMs)", mcap); return KMAHIP_EOVERFLOW; }
 			mcap *= 4;
@@ -2494,19 +2498,19 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			fflush(stderr);
 		};
 		stage("seed");
-		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu | %llu %llu %llu %llu | %llu %llu %llu %llu\n", c[LC_STATUS], c[LC_PROB], c[LC_RUNS],
-		                  c[LC_CNT], c[LC_CNT + 1], c[LC_CNT + 2], c[LC_CNT + 3], c[LC_CNT + 4], c[LC_CNT + 5], c[LC_CNT + 6], c[LC_CNT + 7], c[LC_CNT + 8],
-		                  c[LC_CNT + 9], c[LC_CNT + 10], c[LC_CNT + 11], c[LC_CNT + 12], c[LC_CNT + 13], c[LC_CNT + 14], c[LC_CNT + 15], c[LC_CNT + 16]); fflush(stderr); }
+		if(dbg) { fprintf(stderr, "[kmahip] longtrace: seeded; status %llu, %llu problems, %llu run words, classes %llu %llu %llu %llu | %llu %llu %llu %llu | %llu | %llu %llu %llu %llu | %llu %llu %llu %llu\n", c[LCI(LC_STATUS)], c[LCI(LC_PROB)], c[LCI(LC_RUNS)],
+		                  c[LCI(LC_CNT)], c[LCI(LC_CNT + 1)], c[LCI(LC_CNT + 2)], c[LCI(LC_CNT + 3)], c[LCI(LC_CNT + 4)], c[LCI(LC_CNT + 5)], c[LCI(LC_CNT + 6)], c[LCI(LC_CNT + 7)], c[LCI(LC_CNT + 8)],
+		                  c[LCI(LC_CNT + 9)], c[LCI(LC_CNT + 10)], c[LCI(LC_CNT + 11)], c[LCI(LC_CNT + 12)], c[LCI(LC_CNT + 13)], c[LCI(LC_CNT + 14)], c[LCI(LC_CNT + 15)], c[LCI(LC_CNT + 16)]); fflush(stderr); }
 		// grids follow the queue lengths: 4 wavefronts per workgroup of lt_dp_kernel, 64 / W problems per wavefront round
-		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LC_CNT + cls] + per_wg - 1) / per_wg)); };
+		auto wgs = [&](int cls, int per_wg, int cap) { return dim3((unsigned) std::min<unsigned long long>((unsigned long long) cap, (c[LCI(LC_CNT + cls)] + per_wg - 1) / per_wg)); };
 		// The size classes are independent of each other: the sweeps that live in LDS run side by side on three streams, the
 		// kernels that share the per-workgroup HBM scratch (classes 9-12 and the one-lane class 8: a few hundred big problems that
 		// take as long as the rest together when they run alone) one after the other on a fourth. With KMAHIP_DEBUG_TIMING
 		// everything stays on the caller's stream so that the stages can be timed.
 		int32_t *vals_out = nullptr;
-		if(c[LC_LANE]) {
+		if(c[LCI(LC_LANE)]) {
 			// the lane classes: one sort by (class, sweep length), longest first, then a kernel per class (below)
-			const size_t nl = (size_t) c[LC_LANE];
+			const size_t nl = (size_t) c[LCI(LC_LANE)];
 			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) A.lq + 3 * prob_cap;
 			int32_t *vals_in = A.lq;
 			vals_out = A.lq + 2 * prob_cap;
@@ -2516,7 +2520,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			size_t lane_e_bytes = 0;
 			for(int j = 0; j < LT_LCLS; ++j) {
 				lg[j].e_off = lane_e_bytes;
-				lane_e_bytes += (size_t) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (c[LC_LCNT + j] + 63) / 64) * 64 * (size_t) (lg[j].g.ecap + 288);
+				lane_e_bytes += (size_t) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (c[LCI(LC_LCNT + j)] + 63) / 64) * 64 * (size_t) (lg[j].g.ecap + 288);
 			}
 			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, std::max<size_t>(lane_e_bytes, 16)))) return rc;
 			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
@@ -2541,26 +2545,26 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			const int x = map[cls - 4] - '0';
 			return x == 0 ? stream : x == 1 ? s1 : x == 2 ? s2 : dflt;
 		};
-		if(c[LC_CNT + 0]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
-		if(c[LC_CNT + 1]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
-		if(c[LC_CNT + 2]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
-		if(c[LC_CNT + 3]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
-		if(c[LC_CNT + 4]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(4, s1), A); stage("dpx<2, full>"); }
-		if(c[LC_CNT + 5]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(5, s2), A); stage("dpx<4, full>"); }
-		if(c[LC_CNT + 6]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(6, s1), A); stage("dpx<2, banded>"); }
-		if(c[LC_CNT + 7]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(7, s2), A); stage("dpx<4, banded>"); }
+		if(c[LCI(LC_CNT + 0)]) { hipLaunchKernelGGL((lt_dp_kernel<8>), wgs(0, 32, dp_wgs), dim3(256), 0, stream, A, 0); stage("dp<8>"); }
+		if(c[LCI(LC_CNT + 1)]) { hipLaunchKernelGGL((lt_dp_kernel<16>), wgs(1, 16, dp_wgs), dim3(256), 0, stream, A, 1); stage("dp<16>"); }
+		if(c[LCI(LC_CNT + 2)]) { hipLaunchKernelGGL((lt_dp_kernel<32>), wgs(2, 8, dp_wgs), dim3(256), 0, stream, A, 2); stage("dp<32>"); }
+		if(c[LCI(LC_CNT + 3)]) { hipLaunchKernelGGL((lt_dp_kernel<64>), wgs(3, 4, dp_wgs), dim3(256), 0, stream, A, 3); stage("dp<64>"); }
+		if(c[LCI(LC_CNT + 4)]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, false>), wgs(4, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(4, s1), A); stage("dpx<2, full>"); }
+		if(c[LCI(LC_CNT + 5)]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, false>), wgs(5, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(5, s2), A); stage("dpx<4, full>"); }
+		if(c[LCI(LC_CNT + 6)]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, false>), wgs(6, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(6, s1), A); stage("dpx<2, banded>"); }
+		if(c[LCI(LC_CNT + 7)]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, false>), wgs(7, 1, 4 * dpx_wgs), dim3(64), LT_XE_LDS, xs(7, s2), A); stage("dpx<4, banded>"); }
 		// (the HBM variants and the one-lane class share the per-workgroup scratch of dpx_wgs workgroups: one stream, in turn)
-		if(c[LC_CNT + 8]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, s3, A); stage("serial"); }
-		if(c[LC_CNT + 9]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, full, HBM>"); }
-		if(c[LC_CNT + 10]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, full, HBM>"); }
-		if(c[LC_CNT + 11]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, banded, HBM>"); }
-		if(c[LC_CNT + 12]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, banded, HBM>"); }
-		if(c[LC_CNT + 15]) { hipLaunchKernelGGL((lt_dpx_kernel<8, true, true>), wgs(15, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<8, banded, HBM>"); }
-		if(c[LC_CNT + 16]) { hipLaunchKernelGGL((lt_dpx_kernel<16, true, true>), wgs(16, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<16, banded, HBM>"); }
-		if(c[LC_LANE]) {
+		if(c[LCI(LC_CNT + 8)]) { hipLaunchKernelGGL(lt_serial_kernel, wgs(8, 1, dpx_wgs), dim3(64), 0, s3, A); stage("serial"); }
+		if(c[LCI(LC_CNT + 9)]) { hipLaunchKernelGGL((lt_dpx_kernel<2, false, true>), wgs(9, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, full, HBM>"); }
+		if(c[LCI(LC_CNT + 10)]) { hipLaunchKernelGGL((lt_dpx_kernel<4, false, true>), wgs(10, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, full, HBM>"); }
+		if(c[LCI(LC_CNT + 11)]) { hipLaunchKernelGGL((lt_dpx_kernel<2, true, true>), wgs(11, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<2, banded, HBM>"); }
+		if(c[LCI(LC_CNT + 12)]) { hipLaunchKernelGGL((lt_dpx_kernel<4, true, true>), wgs(12, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<4, banded, HBM>"); }
+		if(c[LCI(LC_CNT + 15)]) { hipLaunchKernelGGL((lt_dpx_kernel<8, true, true>), wgs(15, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<8, banded, HBM>"); }
+		if(c[LCI(LC_CNT + 16)]) { hipLaunchKernelGGL((lt_dpx_kernel<16, true, true>), wgs(16, 1, dpx_wgs), dim3(64), 0, s3, A); stage("dpx<16, banded, HBM>"); }
+		if(c[LCI(LC_LANE)]) {
 			size_t off = 0;
 			for(int j = LT_LCLS - 1; j >= 0; --j) {
-				const unsigned long long cnt = c[LC_LCNT + j];
+				const unsigned long long cnt = c[LCI(LC_LCNT + j)];
 				if(!cnt) continue;
 				LaneArgs La;
 				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap; La.estride = lg[j].g.ecap + 288;
@@ -2613,7 +2617,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		hipLaunchKernelGGL(lt_finish_kernel, dim3((unsigned) std::min<int64_t>(fin_wgs, nb)), dim3(64), 0, stream, A);
 		stage("finish");
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(hc + (size_t) (2 + px) * LC_N, A.counters, (size_t) LC_N * 8, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(hc + (size_t) (2 + px) * LCI(LC_N), A.counters, (size_t) LCI(LC_N) * 8, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipEventRecord(ev.fin[px], stream));
 		fin_pending[px] = true; fin_nb[px] = nb;
 		if(fork) { (void) hipEventDestroy(fork); for(int x = 0; x < NSIDE; ++x) (void) hipEventDestroy(join[x]); }
@@ -2630,7 +2634,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	// the caller reads the pool top through the workspace counters like after trace_kernel: [0] = runs used, [1] = status
 	if(score_mode) return KMAHIP_OK;          // (no runs; the workspace's status word is stage 3a's)
 	unsigned long long fin[2] = {0, 0};
-	HIP_TRY(hipMemcpy(&fin[0], counters + LC_OUT, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&fin[0], counters + LCI(LC_OUT), 8, hipMemcpyDeviceToHost));
 	if((int64_t) fin[0] > out->ops_cap) fin[1] = 2;
 	if(!ws->counters) { HIP_TRY(hipMalloc((void **) &ws->counters, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); HIP_TRY(hipMemset(ws->counters, 0, KMAHIP_N_COUNTERS * sizeof(unsigned long long))); }
 	HIP_TRY(hipMemcpy(ws->counters, fin, sizeof fin, hipMemcpyHostToDevice));
