@@ -1435,8 +1435,13 @@ __global__ __launch_bounds__(CB) void rec_write_kernel(const int32_t *cnt, const
 //      atomics (a run may span several lanes);
 //   3. the anchors go to a device-wide pool, one allocation per workgroup.
 // Reads with N's (where the reference's reverse strand restarts k bases off, savekmers.c:5447-5449), with more than CA_NPMAX k-mer
-// starts or more than CA_AMAX anchors on a strand are left to the lane-per-read kernel of chain.hip (slow[read] = 1).
-constexpr int CA_SEG = 9, CA_PASS = GROUP * CA_SEG, CA_NPMAX = 2 * CA_PASS, CA_AMAX = 64, CA_WORDS = 12, CA_VSTRIDE = CA_NPMAX + 1;
+// starts or more than CA_AMAX anchors on a strand are left to the other routes of chain.hip (slow[read] = 1).
+// (anchors per strand the tables hold: 32 -- at 64 the tables took 8 kB more of LDS and the kernel ran four workgroups per CU instead of
+// five, 3.4 ms per 2 M reads instead of 3.0; 14 reads in 2 M carry more and take the long-read route, at 20 it is three in a hundred)
+#ifndef KMAHIP_CA_AMAX
+#define KMAHIP_CA_AMAX 32
+#endif
+constexpr int CA_SEG = 9, CA_PASS = GROUP * CA_SEG, CA_NPMAX = 2 * CA_PASS, CA_AMAX = KMAHIP_CA_AMAX, CA_WORDS = 12, CA_VSTRIDE = CA_NPMAX + 1;
 
 struct AnchorArgs {
 	ScanArgs S;
