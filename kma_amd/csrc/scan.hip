@@ -1451,10 +1451,14 @@ struct AnchorArgs {
 	int32_t *a_n;
 	uint8_t *slow;
 	unsigned long long *cnt;      // [0] anchors allocated
+	int vstride;                  // words per item of the list table (dynamic LDS): the batch's most k-mer starts + 1, odd, CA_VSTRIDE at most
 };
 
 __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorArgs A) {
-	__shared__ uint32_t s_val[GROUP * CA_VSTRIDE];          // value list per forward k-mer start (MISS: none), row stride odd
+	// value list per forward k-mer start (MISS: none), row stride odd. Sized by the batch's longest read, not by the longest the kernel
+	// takes: with 150-base reads 9 kB instead of 18, eight workgroups per CU instead of five (the kernel waits for its lookups)
+	extern __shared__ uint32_t s_val[];
+	const int VSTRIDE = A.vstride;
 	__shared__ uint64_t s_w[GROUP * CA_WORDS];              // the read in strand orientation
 	// (an item's anchors side by side, the items CA_AMAX + 1 apart: as [anchor][item] the lanes of an item -- consecutive anchors -- fell on
 	// four banks, SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE)
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 			item = S.in_items[first + g] & ITEM_MASK;
 			r = item >> 1; strand = (int) (item & 1);
 			L = S.len[r]; npos = L - k + 1; so = S.seq_off[r];
-			if(S.N_off[r + 1] != S.N_off[r] || npos > CA_NPMAX || npos <= 0) { if(sl == 0) A.slow[r] = 1; live = false; }
+			if(S.N_off[r + 1] != S.N_off[r] || npos > CA_NPMAX || npos >= VSTRIDE || npos <= 0) { if(sl == 0) A.slow[r] = 1; live = false; }
 		}
 		if(sl == 0) { s_npos[g] = live ? npos : 0; s_item[g] = item; }
 		if(sl < CA_WORDS) {
@@ -1491,7 +1495,7 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 		}
 		__syncthreads();
 		const uint64_t *wsrc = &s_w[g * CA_WORDS];
-		uint32_t *vrow = &s_val[g * CA_VSTRIDE];
+		uint32_t *vrow = &s_val[g * VSTRIDE];
 		auto put = [&](int p, uint32_t vi) { vrow[strand ? npos - 1 - p : p] = vi; };
 		for(int c0 = 0; c0 < CA_NPMAX; c0 += CA_PASS) {
 			const int j0 = c0 + sl * CA_SEG, j1 = j0 + CA_SEG;
@@ -1540,7 +1544,7 @@ __global__ __launch_bounds__(THREADS, 4) void chain_anchor_kernel(const AnchorAr
 	// phase 2 layout: item gi = tid >> 4, lane ln = tid & 15 (the lanes of an item are one DPP row)
 	const int gi = tid >> 4, ln = tid & 15;
 	const int npos = s_npos[gi];              // 0: nothing to do for this item
-	const uint32_t *vrow = &s_val[gi * CA_VSTRIDE];
+	const uint32_t *vrow = &s_val[gi * VSTRIDE];
 	int carry_h = -1, carry_cnt = 0;
 	uint32_t carry_v = MISS;
 	for(int c0 = 0; c0 < CA_NPMAX; c0 += CA_PASS) {
@@ -1776,7 +1780,8 @@ int kmahip_launch_chain_anchors(kmahip_db *db, kmahip_ws *ws, const kmahip_reads
 	HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), stream));
 	const int64_t items = 2 * n;
 	hipLaunchKernelGGL((scan_prefilter_kernel<false>), dim3((unsigned) ((items + PF_ITEMS - 1) / PF_ITEMS)), dim3(THREADS), 0, stream, S);
-	hipLaunchKernelGGL(chain_anchor_kernel, dim3((unsigned) ((items + GROUP - 1) / GROUP)), dim3(THREADS), 0, stream, A);
+	A.vstride = (std::min(CA_NPMAX, std::max(1, reads->max_len - (int) db->info.kmersize + 1)) + 1) | 1;
+	hipLaunchKernelGGL(chain_anchor_kernel, dim3((unsigned) ((items + GROUP - 1) / GROUP)), dim3(THREADS), (size_t) GROUP * A.vstride * sizeof(uint32_t), stream, A);
 	HIP_TRY(hipGetLastError());
 	return KMAHIP_OK;
 }
