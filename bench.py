@@ -176,7 +176,7 @@ def c4_leg(tmp, n_reads, device, n_parity=5000):
     db = binding.KmaHipDB(prefix, device=device)
     t_open = time.perf_counter() - t0
     try:
-        nw = min(n_reads, max(1024, 400_000_000 // L))       # one pass of the long-read traceback: every scratch array reaches its size
+        nw = min(n_reads, 2 * max(1024, 400_000_000 // L) + 1)       # three passes of the long-read traceback: both sets of its pools reach their size
         first = formats.ReadBatch(b.seq[:b.seq_off[nw]], b.seq_off[:nw + 1], b.length[:nw], b.N, b.N_off[:nw + 1])
         db.run_mt1(first, 1, consensus=False)       # scratch allocation, first launches
         t0 = time.perf_counter()

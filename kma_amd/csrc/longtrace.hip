@@ -211,10 +211,12 @@ __device__ __forceinline__ void lt_extend(const uint64_t *ts, int t_len, const Q
 }
 
 struct SeedLds {
-	int v[LT_TILE], F[LT_TILE], B[LT_TILE];
+	// (the seeding's tile and the chain's window are never in use together: one piece of LDS for both, 6.5 kB a wavefront instead of 9.5)
+	union {
+		struct { int v[LT_TILE], F[LT_TILE], B[LT_TILE]; };
+		struct { int ring[6][128]; int stage[5][64]; };
+	};
 	uint16_t next[LT_NEXT_CAP], chain[LT_NEXT_CAP];
-	int ring[6][128];
-	int stage[5][64];
 	int d[25];
 };
 
@@ -628,7 +630,9 @@ __device__ __forceinline__ int lt_lane_class(int q_l, int t_l, int band, int k, 
 	return -1;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lt_seed_kernel(const LtArgs A) {
+// (five wavefronts per SIMD: 94 registers, three spilled dwords; with the tile and the chain's window sharing one piece of LDS twenty
+// wavefronts fit a CU and leave the sweeps that run beside them room -- the stage at 200 k reads 174 -> 161 ms with the LDS alone, 155 with both)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void lt_seed_kernel(const LtArgs A) {
 	__shared__ SeedLds S;
 	const int lane = threadIdx.x;
 	if(lane < 25) S.d[lane] = A.d[lane];
@@ -2289,8 +2293,8 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	if(n == 0) return KMAHIP_OK;
 	const int max_len = reads->max_len;
 	if(max_len <= 0 || max_len > (1 << 24)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^24) for the trace stage"); return KMAHIP_EINVAL; }
-	// (the seeding kernel waits for its index lookups: as many wavefronts as the registers allow, 16 per CU)
-	const int seed_wgs = (int) std::min<int64_t>(getenv("KMAHIP_LT_SEED_WGS") ? atoi(getenv("KMAHIP_LT_SEED_WGS")) : 4096, std::max<int64_t>(1024, 400000000ll / max_len));
+	// (the seeding kernel waits for its index lookups: as many wavefronts as the registers allow, 20 per CU)
+	const int seed_wgs = (int) std::min<int64_t>(getenv("KMAHIP_LT_SEED_WGS") ? atoi(getenv("KMAHIP_LT_SEED_WGS")) : 5120, std::max<int64_t>(1024, 400000000ll / max_len));
 	const int fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
 	int mcap = std::max(1024, max_len / 8 + 256);          // (MEM slots per seeding wavefront: four times more whenever a read runs out, below)
 	const int64_t tmp_cap = 4ll * max_len + 1024;
