@@ -176,9 +176,10 @@ def c4_leg(tmp, n_reads, device, n_parity=5000):
     db = binding.KmaHipDB(prefix, device=device)
     t_open = time.perf_counter() - t0
     try:
-        nw = min(n_reads, 2 * max(1024, 400_000_000 // L) + 1)       # three passes of the long-read traceback: both sets of its pools reach their size
-        first = formats.ReadBatch(b.seq[:b.seq_off[nw]], b.seq_off[:nw + 1], b.length[:nw], b.N, b.N_off[:nw + 1])
-        db.run_mt1(first, 1, consensus=False)       # scratch allocation, first launches
+        # the warm-up is the call itself, once (as the headline step has its warm-up steps): scratch of every pass at its final size, both
+        # sets of the traceback's pools, the output arrays' pages touched -- a first call of this size took 190-220 ms per 200 k reads for the
+        # trace stage where every later one takes 155-158 (tools/mt1_repeat.py)
+        db.run_mt1(b, 1, consensus=False)
         t0 = time.perf_counter()
         o = db.run_mt1(b, 1, consensus=False)
         dt = time.perf_counter() - t0
