@@ -229,6 +229,63 @@ def c4_leg(tmp, n_reads, device, n_parity=5000):
         db.close()
 
 
+def capture_stderr(fn):
+    """fn() with the process's fd 2 in a temporary file (the library prints its timing lines there): (result, text)"""
+    import tempfile
+    sys.stderr.flush()
+    saved = os.dup(2)
+    with tempfile.TemporaryFile(mode="w+b") as tf:
+        os.dup2(tf.fileno(), 2)
+        try:
+            res = fn()
+        finally:
+            sys.stderr.flush()
+            os.dup2(saved, 2)
+            os.close(saved)
+        tf.seek(0)
+        text = tf.read().decode(errors="replace")
+    return res, text
+
+
+def chain_stage2_leg(db, pb, tmp, device):
+    """Stage 2 of the reference's DEFAULT mode (no -1t1: save_kmers_chain) on its own, beside the headline step (extra key, never `value`):
+    (a) the step's 10 M short reads through kmahip_scan_chain -- the library's own figure for its two kernels (anchors + chaining, the
+    chunks overlapped; KMAHIP_CHAIN_TIMING); (b) 20 000 ONT-like reads of 10 kb against one 2 Mb genome -- the wavefront-per-read route."""
+    import re
+    from kma_amd import binding, formats, synth_dev
+    out = {}
+    os.environ["KMAHIP_CHAIN_TIMING"] = "1"
+    try:
+        db.scan_chain(formats.ReadBatch(pb.seq[:pb.seq_off[1000]], pb.seq_off[:1001], pb.length[:1000], pb.N, pb.N_off[:1001]))      # first launches, streams
+        _, text = capture_stderr(lambda: db.scan_chain(pb))
+        m = re.findall(r"fast route, (\d+) reads in (\d+) chunks.*?: ([0-9.]+) ms", text)
+        if m:
+            n_s, chunks, ms = int(m[-1][0]), int(m[-1][1]), float(m[-1][2])
+            out["short_reads"] = {"reads": n_s, "chunks": chunks, "ms": ms, "reads_per_s": n_s / (ms / 1e3),
+                                  "what": "prefilter + chain_anchor_kernel + chain_fast_kernel over the step's reads, device time of the route"}
+        rng = np.random.default_rng(4)
+        genome = rng.integers(0, 4, 2_000_000, dtype=np.uint8)
+        prefix = os.path.join(tmp, "g2mb")
+        formats.write_index(prefix, ["genome2Mb"], [genome])
+        n_l = 20000
+        rd = synth_dev.make_long_reads_packed(genome, n_l, read_len=10000, seed=8, device=f"cuda:{device}", keep_codes=0)
+        lb = formats.ReadBatch(rd["seq"], rd["seq_off"], rd["length"], rd["N"][:0], rd["N_off"])
+        dbl = binding.KmaHipDB(prefix, device=device)
+        try:
+            dbl.scan_chain(formats.ReadBatch(lb.seq[:lb.seq_off[64]], lb.seq_off[:65], lb.length[:64], lb.N, lb.N_off[:65]))
+            _, text = capture_stderr(lambda: dbl.scan_chain(lb))
+        finally:
+            dbl.close()
+        m = re.findall(r"long-read route, (\d+) reads in (\d+) chunk\(s\): ([0-9.]+) ms", text)
+        if m:
+            n_r, chunks, ms = int(m[-1][0]), int(m[-1][1]), float(m[-1][2])
+            out["long_reads"] = {"reads": n_r, "read_len": 10000, "chunks": chunks, "ms": ms, "reads_per_s": n_r / (ms / 1e3),
+                                 "what": "chain_long_anchor_kernel (a wavefront per read and strand) + chain_long_tail_kernel, device time of the route"}
+    finally:
+        os.environ.pop("KMAHIP_CHAIN_TIMING", None)
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -878,6 +935,11 @@ def main():
                     out["c4"] = c4_leg(tmp, a.c4_reads, local, a.c4_parity)
                 except Exception as e:  # noqa: BLE001  (extra leg only)
                     out["c4"] = {"error": str(e)}
+            if not a.hard:
+                try:
+                    out["default_mode_stage2"] = chain_stage2_leg(db, pb, tmp, local)
+                except Exception as e:  # noqa: BLE001  (extra leg only)
+                    out["default_mode_stage2"] = {"error": str(e)}
             out["cpu_baseline"] = cpu_baseline(prefix, codes, tmp)
             if a.e2e_reads > 0 and not a.hard:
                 try:

@@ -1482,6 +1482,8 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 		HIP_TRY(hipMemsetAsync(l_scratch, 0, (size_t) (lanes * Al.lane_bytes), 0));
 		Al.scratch = (uint8_t *) l_scratch;
 		stamp("long-read route: lists, offsets, buffers");
+		HIP_TRY(hipStreamSynchronize(0));
+		const auto t_long = std::chrono::steady_clock::now();
 		for(size_t c = 0; c + 1 < cut.size(); ++c) {
 			LongArgs G = {l_list2, cut[c], cut[c + 1] - cut[c], v_off, l_pool, l_hits};
 			hipLaunchKernelGGL(chain_long_anchor_kernel, dim3((unsigned) (2 * G.count)), dim3(64), 0, 0, Al, G);
@@ -1494,6 +1496,8 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 			stamp("long-read route: chain_long_tail_kernel");
 		}
 		HIP_TRY(hipStreamSynchronize(0));
+		if(getenv("KMAHIP_CHAIN_TIMING")) fprintf(stderr, "[kmahip] scan_chain: long-read route, %lld reads in %zu chunk(s): %.2f ms (anchors + chaining; lists and buffers before it not counted)\n", (long long) n_long,
+		                                          cut.size() - 1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_long).count());
 		drop(l_pool); drop(l_scratch);
 	}
 	if(n_slow > 0) {
