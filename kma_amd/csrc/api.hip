@@ -1,5 +1,6 @@
 // api.hip -- extern "C" entry points of libkmahip.so (see include/kmahip.h).
 #include "kmahip_internal.h"
+void kmahip_devcache_flush();      // pipeline.hip
 #include <cstring>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -31,6 +32,7 @@ extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	(void) hipFree(ws->p_counts); (void) hipFree(ws->p_chain); (void) hipFree(ws->p_seg); (void) hipFree(ws->p_vals);
 	(void) hipFree(ws->p_nodes); (void) hipFree(ws->p_keys); (void) hipFree(ws->p_rank);
 	(void) hipFree(ws->pool_sc); (void) hipFree(ws->ppool); (void) hipFree(ws->pe_rec);
+	kmahip_devcache_flush();          // (the large blocks the runs keep between calls: pipeline.hip)
 	for(int i = 0; i < 20; ++i) { if(i == 17) (void) hipHostFree(ws->lt_buf[i]); else (void) hipFree(ws->lt_buf[i]); }      // (17: pinned host memory, longtrace.hip)
 	delete ws;
 }

@@ -2,6 +2,58 @@
 // out), built from the same launchers as the stage-wise entry points; what runKMA does between its input stream and the
 // `.res` / consensus output (runkma.c:104-900), minus the files.
 #include "pipeline_util.h"
+#include <mutex>
+
+// ---- the large device blocks kept between runs (pipeline_util.h) -------------------------------------------------------------------
+namespace {
+struct DevCache {
+	std::mutex m;
+	std::vector<std::pair<void *, size_t>> kept;
+	size_t total = 0;
+	static constexpr size_t CAP = 64ull << 30;      // bytes kept at most
+	static constexpr size_t MAXN = 12;               // blocks kept at most
+} g_devcache;
+}
+void *kmahip_devcache_take(size_t bytes, size_t *got) {
+	std::lock_guard<std::mutex> lk(g_devcache.m);
+	int best = -1;
+	for(size_t i = 0; i < g_devcache.kept.size(); ++i) {
+		const size_t b = g_devcache.kept[i].second;
+		if(b >= bytes && b <= 2 * bytes && (best < 0 || b < g_devcache.kept[(size_t) best].second)) best = (int) i;
+	}
+	if(best < 0) return nullptr;
+	void *p = g_devcache.kept[(size_t) best].first;
+	*got = g_devcache.kept[(size_t) best].second;
+	g_devcache.total -= *got;
+	g_devcache.kept.erase(g_devcache.kept.begin() + best);
+	return p;
+}
+void kmahip_devcache_give(void *p, size_t bytes) {
+	if(!p) return;
+	{
+		std::lock_guard<std::mutex> lk(g_devcache.m);
+		if(!getenv("KMAHIP_NO_DEVCACHE") && bytes <= DevCache::CAP) {
+			// (room is made by releasing the smallest blocks kept: the large ones are the expensive ones to get back)
+			while(!g_devcache.kept.empty() && (g_devcache.total + bytes > DevCache::CAP || g_devcache.kept.size() >= DevCache::MAXN)) {
+				size_t s = 0;
+				for(size_t i = 1; i < g_devcache.kept.size(); ++i) if(g_devcache.kept[i].second < g_devcache.kept[s].second) s = i;
+				(void) hipFree(g_devcache.kept[s].first);
+				g_devcache.total -= g_devcache.kept[s].second;
+				g_devcache.kept.erase(g_devcache.kept.begin() + (long) s);
+			}
+			g_devcache.kept.push_back({p, bytes});
+			g_devcache.total += bytes;
+			return;
+		}
+	}
+	(void) hipFree(p);
+}
+void kmahip_devcache_flush() {
+	std::lock_guard<std::mutex> lk(g_devcache.m);
+	for(auto &b : g_devcache.kept) (void) hipFree(b.first);
+	g_devcache.kept.clear();
+	g_devcache.total = 0;
+}
 #include <functional>
 #include <memory>
 

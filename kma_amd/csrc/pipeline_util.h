@@ -9,31 +9,53 @@
 #include <thread>
 #include <vector>
 
+// The large device blocks of a run, kept for the next one (pipeline.hip). A hipMalloc of gigabytes is 0.2 ms as a rule and 0.6-1.4 s now
+// and then (tools/malloc_probe.py: one in five of 13 GB) -- the run pool of a million long reads is 13 GB, the reads 2.5 GB, and a run that
+// asked for them anew each time took twice as long whenever the driver had to find the memory again.
+void *kmahip_devcache_take(size_t bytes, size_t *got);      // a kept block of at least `bytes` (and not over twice that), or NULL
+void kmahip_devcache_give(void *p, size_t bytes);           // keep it (or release it, when what is kept would exceed the cache's share)
+void kmahip_devcache_flush();                               // release everything kept
+
 namespace {
 
 // Device buffers of one run, carved out of a few large allocations (a hipMalloc per array cost more than ConClave itself:
-// thirty of them per run). Everything is released when the run ends.
+// thirty of them per run). When the run ends the small ones are released, the large ones kept for the next run.
 struct DevBlock {
-	std::vector<void *> owned;
+	std::vector<std::pair<void *, size_t>> owned;
 	char *slab = nullptr;
 	size_t slab_left = 0, slab_bytes = 256u << 20;
-	~DevBlock() { for(void *p : owned) (void) hipFree(p); }
+	~DevBlock() {
+		// (hipFree waits for the device before it releases; a block that is kept must not be handed on before that either)
+		bool any = false;
+		for(auto &b : owned) any = any || b.second >= (64u << 20);
+		if(any) (void) hipDeviceSynchronize();
+		for(auto &b : owned) { if(b.second >= (64u << 20)) kmahip_devcache_give(b.first, b.second); else (void) hipFree(b.first); }
+	}
 	void expect(size_t bytes) { slab_bytes = std::max(slab_bytes, bytes); }
+	static void *alloc(size_t want, size_t *got) {
+		void *d = want >= (64u << 20) ? kmahip_devcache_take(want, got) : nullptr;
+		if(d) return d;
+		*got = want;
+		if(hipMalloc(&d, want) == hipSuccess) return d;
+		kmahip_devcache_flush();          // (what is kept may be what is missing)
+		return hipMalloc(&d, want) == hipSuccess ? d : nullptr;
+	}
 	template <class T> int get(size_t n, T **dst, bool zero = false) {
 		const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t) 255;
 		if(bytes > slab_left) {
 			const size_t want = std::max(bytes, slab_bytes);
-			void *d = nullptr;
-			if(hipMalloc(&d, want) != hipSuccess) {
+			size_t got = 0;
+			void *d = alloc(want, &got);
+			if(!d) {
 				// (a smaller slab may still fit)
-				if(want == bytes || hipMalloc(&d, bytes) != hipSuccess) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
-				owned.push_back(d);
+				if(want == bytes || !(d = alloc(bytes, &got))) { kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+				owned.push_back({d, got});
 				if(zero && hipMemsetAsync(d, 0, bytes, 0) != hipSuccess) { kmahip_set_error("hipMemset failed"); return KMAHIP_EDEVICE; }
 				*dst = (T *) d;
 				return KMAHIP_OK;
 			}
-			owned.push_back(d);
-			slab = (char *) d; slab_left = want;
+			owned.push_back({d, got});
+			slab = (char *) d; slab_left = got;
 		}
 		void *d = slab;
 		slab += bytes; slab_left -= bytes;

@@ -26,6 +26,6 @@ out = []
 for i in range(calls):
     t0 = time.perf_counter()
     o = db.run_mt1(b, 1, consensus=False)
-    out.append((round(o["ms"][3], 1), round(1e3 * (time.perf_counter() - t0), 1)))
-print("trace ms / call ms:", out)
+    out.append((round(o["ms"][0], 1), round(o["ms"][3], 1), round(1e3 * (time.perf_counter() - t0), 1)))
+print("upload ms / trace ms / call ms:", out)
 db.close()
