@@ -1262,6 +1262,9 @@ __global__ __launch_bounds__(256) void chain_long_keys_kernel(int64_t n_list, co
 }  // namespace
 
 int kmahip_worker_streams(hipStream_t *out, int want);      // longtrace.hip: streams that were measured to run side by side
+void *kmahip_devcache_take(size_t bytes, size_t *got);      // pipeline.hip: the large device blocks kept between runs
+void kmahip_devcache_give(void *p, size_t bytes);
+void kmahip_devcache_flush();
 
 // ---- the launch, everything in HBM: `d` holds DEVICE pointers; rec (8 ints per record: read lo, read hi, ordinal within the read,
 // rc_flag, emit_rc, q_start, q_end, number of templates), rec_T (first template of the record in T) and T are device buffers of
@@ -1289,14 +1292,37 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 		fprintf(stderr, "[kmahip] scan_chain: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
 		t_last = now;
 	};
-	std::vector<void *> owned;
-	struct Free { std::vector<void *> &v; ~Free() { for(void *q : v) (void) hipFree(q); } } guard{owned};
+	// (blocks of 64 MB and more come from, and go back to, the blocks the runs keep between calls -- pipeline.hip: a hipMalloc of
+	// gigabytes takes a second now and then, and this function takes its pools anew for every batch)
+	constexpr size_t KEEP = 64u << 20;
+	std::vector<std::pair<void *, size_t>> owned;
+	auto release = [](void *q, size_t b) { if(b >= KEEP) kmahip_devcache_give(q, b); else (void) hipFree(q); };
+	struct Free {
+		std::vector<std::pair<void *, size_t>> &v;
+		~Free() { bool any = false; for(auto &q : v) any = any || q.second >= KEEP; if(any) (void) hipDeviceSynchronize(); for(auto &q : v) { if(q.second >= KEEP) kmahip_devcache_give(q.first, q.second); else (void) hipFree(q.first); } }
+	} guard{owned};
 	auto dev = [&](size_t bytes, void **out) -> int {
-		if(hipMalloc(out, bytes ? bytes : 16) != hipSuccess) { *out = nullptr; kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
-		owned.push_back(*out);
+		const size_t want = bytes ? bytes : 16;
+		size_t got = want;
+		*out = want >= KEEP ? kmahip_devcache_take(want, &got) : nullptr;
+		if(!*out) {
+			got = want;
+			if(hipMalloc(out, want) != hipSuccess) {
+				kmahip_devcache_flush();
+				if(hipMalloc(out, want) != hipSuccess) { *out = nullptr; kmahip_set_error("hipMalloc of %zu bytes failed", bytes); return KMAHIP_ENOMEM; }
+			}
+		}
+		owned.push_back({*out, got});
 		return KMAHIP_OK;
 	};
-	auto drop = [&](void *q) { for(size_t i = 0; i < owned.size(); ++i) if(owned[i] == q) { (void) hipFree(q); owned.erase(owned.begin() + (ptrdiff_t) i); return; } };
+	auto drop = [&](void *q) {
+		for(size_t i = 0; i < owned.size(); ++i) if(owned[i].first == q) {
+			if(owned[i].second >= KEEP) (void) hipDeviceSynchronize();
+			release(q, owned[i].second);
+			owned.erase(owned.begin() + (ptrdiff_t) i);
+			return;
+		}
+	};
 	int rc;
 	ChainArgs A;
 	A.db = db->dev; A.n_reads = n;
