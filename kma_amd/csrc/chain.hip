@@ -125,8 +125,10 @@ struct ChainArgs {
 	int64_t *rec_T;              // first template of the record in `T`
 	int32_t *T;
 	int64_t rec_cap, T_cap;
-	unsigned long long *counters;   // [0] records, [1] status, [2] templates
+	unsigned long long *counters;   // [0] records, [1] status, [CH_T] templates
 };
+constexpr int CH_T = 16;
+static_assert(CH_T < KMAHIP_N_COUNTERS, "the template counter lies inside the counter block");
 
 // what the chaining reads of the database's description, by value in the lane (read through the lane's pointer to the kernel's argument
 // every field was a FLAT load of its own)
@@ -644,7 +646,7 @@ template <class CLane> __device__ void emit_record(CLane &L, Emit &E, int rc_fla
 	unsigned long long slot0 = 0, toff0 = 0;
 	if(lane == leader) {
 		slot0 = atomicAdd(&A.counters[0], (unsigned long long) __popcll(act));
-		toff0 = atomicAdd(&A.counters[2], (unsigned long long) tot);
+		toff0 = atomicAdd(&A.counters[CH_T], (unsigned long long) tot);      // (a 128-byte line away from the record counter: atomics on one line are served in turn)
 	}
 	// (the first active lane is the leader: a scalar broadcast, no lane index in the instruction stream)
 	const unsigned lo0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (slot0 & 0xFFFFFFFFull)), hi0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (slot0 >> 32));
@@ -1547,7 +1549,8 @@ int kmahip_chain_device(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *d, con
 	}
 	HIP_TRY(hipDeviceSynchronize());
 	unsigned long long c[3] = {0, 0, 0};
-	HIP_TRY(hipMemcpy(c, A.counters, sizeof c, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(c, A.counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&c[2], A.counters + CH_T, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	*n_recs = (int64_t) c[0]; *n_T = (int64_t) c[2];
 	if(c[1] == 40) { kmahip_set_error("default template finder: a per-read capacity ran out (more than %d chains in a read, or chains nested deeper than %d in the tree of covered stretches)", s_cap_of_len / 2, SEG_DEPTH); return KMAHIP_EOVERFLOW; }
 	if(c[1] == 2 || (int64_t) c[0] > rec_cap || (int64_t) c[2] > T_cap) { kmahip_set_error("record capacity: %llu records with %llu templates", c[0], c[2]); return KMAHIP_EOVERFLOW; }
