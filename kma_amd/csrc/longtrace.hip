@@ -2295,7 +2295,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	if(max_len <= 0 || max_len > (1 << 24)) { kmahip_set_error("kmahip_reads.max_len must be set (<= 2^24) for the trace stage"); return KMAHIP_EINVAL; }
 	// (the seeding kernel waits for its index lookups: as many wavefronts as the registers allow, 20 per CU)
 	const int seed_wgs = (int) std::min<int64_t>(getenv("KMAHIP_LT_SEED_WGS") ? atoi(getenv("KMAHIP_LT_SEED_WGS")) : 5120, std::max<int64_t>(1024, 400000000ll / max_len));
-	const int fin_wgs = 4096, dp_wgs = 2048, dpx_wgs = 1024;          // (finish: 16 wavefronts per CU; 8 took 1.5 % longer for the stage)
+	const int fin_wgs = 2048, dp_wgs = 2048, dpx_wgs = 1024;
 	int mcap = std::max(1024, max_len / 8 + 256);          // (MEM slots per seeding wavefront: four times more whenever a read runs out, below)
 	const int64_t tmp_cap = 4ll * max_len + 1024;
 	const int64_t xe_cap = 2ll << 20;
