@@ -878,7 +878,9 @@ struct RunOut {
 // Compiled as a function of its own (not inlined): inlined into the kernels' divergent regions (one lane per problem walks while
 // the others wait) the loop came out of the compiler as one that never ends on gfx950; as a separate function its control flow
 // is a single loop. E is a generic pointer (LDS or HBM).
-__attribute__((noinline)) __device__ int lt_walk(const uint8_t *E, int pitch, int m, int n, int dn, int q_pos, int lead, RunOut *Rp, int *clip, int64_t limit, int *bad) {
+// il != 0: the matrix lies in 16-byte chunks interleaved over the 64 lanes of its wavefront (lt_reg_kernel / lt_regband_kernel: byte b of
+// the lane's matrix at ((b >> 4) * 64 + lane) * 16 + (b & 15), E pointing at the lane's first chunk); rows then run downwards (pitch < 0).
+__attribute__((noinline)) __device__ int lt_walk(const uint8_t *E, int pitch, int m, int n, int dn, int q_pos, int lead, RunOut *Rp, int *clip, int64_t limit, int *bad, int il = 0) {
 	// one flat loop, one cell per iteration: mode 0 = at a cell whose move decides, 1 = inside a run of gaps in the read (template
 	// rows consumed), 2 = inside a run of gaps in the template (query columns consumed); a run counts its cells up to and including
 	// the first one that carries a may-open bit. A correct matrix is left through one of its zero cells; anything else (leaving the
@@ -891,7 +893,7 @@ __attribute__((noinline)) __device__ int lt_walk(const uint8_t *E, int pitch, in
 	// through L2, a thousand times a read): the next three cells down the diagonal are asked for ahead, so that a diagonal run has four
 	// loads in flight; a gap step leaves the diagonal and asks again.
 	const int64_t ds = (int64_t) pitch + 1 + dn;
-	auto cell = [&](int64_t i) -> int { return (i >= 0 && i < limit) ? (int) E[i] : 0; };
+	auto cell = [&](int64_t i) -> int { return (i >= 0 && i < limit) ? (int) E[il ? (((i >> 4) << 10) | (i & 15)) : i] : 0; };
 	int e = cell(at), d1 = cell(at + ds), d2 = cell(at + 2 * ds), d3 = cell(at + 3 * ds);
 	for(int64_t it = 0; !stop; ++it) {
 		if(at < 0 || at >= limit || it > limit) { isbad = 1; stop = true; }
@@ -1783,15 +1785,17 @@ typedef uint32_t lt_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t lt_u32x4 __attribute__((ext_vector_type(4)));
 typedef lt_u32x2 __attribute__((aligned(1))) lt_u32x2_u;
 typedef lt_u32x4 __attribute__((aligned(1))) lt_u32x4_u;
-// The move bytes of sixteen registers per store (a lane's store is a line of its own whatever its width: the address path takes the 64
-// lanes of a store one after the other, and at four bytes a store the sweeps waited for it): register j's byte into word (j >> 2) & 3;
-// stored when j is the lowest register of its group of sixteen -- or of eight, where R leaves a group of eight at the top (a wider
-// store there would run into the row above, which is written already)
+// The move bytes of sixteen registers per store (at four bytes a store the sweeps waited for the address path), and the matrices of a
+// wavefront's 64 lanes INTERLEAVED in chunks of 16 bytes: a row of a lane's matrix is RP = R rounded up to 16 bytes, indexed by register
+// (column n in byte n + off), the rows counted from the boundary row (row 0) in the order they are written -- the same for every lane --
+// so that the 64 lanes of a store write one contiguous kilobyte instead of 64 lines of their own. Register j's byte into word
+// (j >> 2) & 3; stored when j is the lowest register of its group of sixteen (of eight at the top of a 72-register row). `er` = the
+// lane's first chunk of the row.
 #define LT_EW_PUT(R_, j_, cell_) do { const uint32_t sh_ = (cell_) << (((j_) & 3) << 3); \
 	if((((j_) >> 2) & 3) == 0) ew0 |= sh_; else if((((j_) >> 2) & 3) == 1) ew1 |= sh_; else if((((j_) >> 2) & 3) == 2) ew2 |= sh_; else ew3 |= sh_; \
 	if(((j_) & 15) == 0) { \
-		if((R_) - (j_) >= 16) { lt_u32x4 w_; w_.x = ew0; w_.y = ew1; w_.z = ew2; w_.w = ew3; *(lt_u32x4_u *) (er + (j_)) = w_; } \
-		else { lt_u32x2 w_; w_.x = ew0; w_.y = ew1; *(lt_u32x2_u *) (er + (j_)) = w_; } \
+		if((R_) - (j_) >= 16) { lt_u32x4 w_; w_.x = ew0; w_.y = ew1; w_.z = ew2; w_.w = ew3; *(lt_u32x4 *) (er + (size_t) ((j_) >> 4) * 1024) = w_; } \
+		else { lt_u32x2 w_; w_.x = ew0; w_.y = ew1; *(lt_u32x2 *) (er + (size_t) ((j_) >> 4) * 1024) = w_; } \
 		ew0 = 0; ew1 = 0; ew2 = 0; ew3 = 0; } } while(0)
 __device__ __forceinline__ uint32_t lt_opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 // the new value of a row register INTO that register (the operand is tied): without it the compiler keeps the row before and the row
@@ -1822,8 +1826,9 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ x 64 query codes
 	const int lane = threadIdx.x;
-	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
-	uint8_t *const Em = E + 128;                                 // (room below row 0 for the bytes of the registers left of column 0)
+	constexpr int RP = (R + 15) & ~15, CH = RP / 16;             // bytes and chunks per row of the interleaved matrix
+	uint8_t *const El = L.E + (size_t) blockIdx.x * 64 * (size_t) L.estride + (size_t) lane * 16;      // the lane's first chunk
+	auto ebyte = [&](int64_t b) -> uint8_t * { return El + (((b >> 4) << 10) | (b & 15)); };
 	const int U = A.U, W1 = A.W1;
 	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
 	for(unsigned long long base = (unsigned long long) blockIdx.x * 64; base < L.count; base += (unsigned long long) gridDim.x * 64) {
@@ -1831,7 +1836,7 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 		LtProb *P = X.P;
 		const bool live = X.live;
 		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
-		const int pitch = q_len + 1;
+		// (the matrix is indexed by register: no pitch)
 		const int low = (t_len + q_len) * (A.MM + U + W1);
 		const int off = R - 1 - q_len;                           // register of column 0
 		wave_sync();
@@ -1849,7 +1854,7 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 			row[j] = lt_pack16(D, low);
 		}
 		if(live) {
-			for(int n = 0; n <= q_len; ++n) Em[(size_t) pitch * t_len + n] = (uint8_t) ((n < q_len && k != 2) ? ((n == q_len - 1) ? 18 : 3) : 0);
+			for(int n = 0; n <= q_len; ++n) *ebyte(n + off) = (uint8_t) ((n < q_len && k != 2) ? ((n == q_len - 1) ? 18 : 3) : 0);      // row 0
 		}
 		int score = low, best_m = 0, d0 = 0;
 		const int rows = live && !(L.ablate & 4) ? t_len : 0;
@@ -1873,7 +1878,7 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 				const int offr = lt_vgpr(off);
 #pragma unroll
 				for(int w = 0; w < R / 8; ++w) asm volatile("" : "+v"(qreg[w]));
-				uint8_t *const er = Em + (size_t) pitch * m - offr;      // byte of register j: er[j]
+				uint8_t *const er = El + (size_t) (r + 1) * CH * 1024;      // the lane's first chunk of row r + 1
 #pragma unroll
 				for(int j = R - 2; j >= 0; --j) {
 					const uint32_t below = row[j];
@@ -1927,7 +1932,8 @@ __global__ __launch_bounds__(64, (R <= 16 ? LT_REG16_WAVES : R <= 32 ? LT_REG32_
 			RunOut Ro;
 			Ro.init(A.runs + P->runs, t_len + q_len + 1);
 			int clip = sn, bad = 0;
-			const int q_pos = lt_walk((const uint8_t *) Em, pitch, sm, sn, 0, sn, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			// (cell (m, n) lies in row t_len - m, byte n + off: rows run downwards)
+			const int q_pos = lt_walk((const uint8_t *) El, -RP, -(t_len - sm), sn + off, 0, sn, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) RP * (t_len + 1), &bad, 1);
 			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
 			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : Ro.n;
@@ -1951,8 +1957,9 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 	uint32_t *const T = lt_lane_lds + 32;                        // TW x 64 template words
 	uint8_t *const QB = (uint8_t *) (T + (size_t) L.TW * 64);   // RQ / 2 x 64 query codes, two columns per byte
 	const int lane = threadIdx.x;
-	uint8_t *const E = L.E + ((size_t) blockIdx.x * 64 + lane) * (size_t) L.estride;
-	uint8_t *const Em = E + 128;
+	constexpr int RP = (R + 15) & ~15, CH = RP / 16;             // bytes and chunks per row of the interleaved matrix
+	uint8_t *const El = L.E + (size_t) blockIdx.x * 64 * (size_t) L.estride + (size_t) lane * 16;      // the lane's first chunk
+	auto ebyte = [&](int64_t b) -> uint8_t * { return El + (((b >> 4) << 10) | (b & 15)); };
 	const int U = A.U, W1 = A.W1;
 	const int dM = A.d[0], dX = A.d[1], dN = A.d[4];
 	constexpr int NEG = -(1 << 28);
@@ -1965,7 +1972,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 		const int k = X.k, t_len = X.t_len, q_len = X.q_len, flags = X.flags;
 		int band = X.band;
 		if(band & 1) ++band;
-		const int half = band >> 1, bq = band + 1, pitch = bq + 1;
+		const int half = band >> 1, bq = band + 1;
 		const int low = (t_len + q_len) * (A.MM + U + W1);
 		const int off = R - 1 - bq;                              // register of index 0
 		wave_sync();
@@ -1987,7 +1994,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 			}
 			row[j] = lt_pack16(D, Pn);
 		}
-		if(live) for(int n = 0; n <= sn0; ++n) Em[(size_t) pitch * t_len + n] = (uint8_t) ((n < sn0 && k != 2) ? ((n == sn0 - 1) ? 18 : 3) : 0);
+		if(live) for(int n = 0; n <= sn0; ++n) *ebyte(n + off) = (uint8_t) ((n < sn0 && k != 2) ? ((n == sn0 - 1) ? 18 : 3) : 0);      // row 0
 		int en = 0, score = low, bm = 0, bn = 0, d_e = 0;
 		const int rows = live && !(L.ablate & 4) ? t_len : 0;
 		const int rows_max = wave_max(rows);
@@ -2018,7 +2025,7 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 				uint32_t xq = 0;          // eight query codes ^ template base: 0 = match, bit 2 set = N in the read
 				int diag = (int) (short) (row[R - 1] & 0xffffu), right = 0, Qprev = low;
 				uint32_t ew0 = 0, ew1 = 0, ew2 = 0, ew3 = 0;
-				uint8_t *const er = Em + (size_t) pitch * m - off;      // byte of register j: er[j]
+				uint8_t *const er = El + (size_t) (r + 1) * CH * 1024;      // the lane's first chunk of row r + 1
 #pragma unroll
 				for(int j = R - 1; j >= 0; --j) {
 					const uint32_t below = j ? row[j - 1] : 0u;
@@ -2077,7 +2084,8 @@ __global__ __launch_bounds__(64, (R <= 72 ? LT_RB72_WAVES : 2)) void lt_regband_
 			RunOut Ro;
 			Ro.init(A.runs + P->runs, t_len + q_len + 1);
 			int clip = q_pos, bad = 0;
-			const int qend = lt_walk((const uint8_t *) Em, pitch, bm, bn, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) pitch * (t_len + 1), &bad);
+			// (band cell (m, n) lies in row t_len - m, byte n + off: a diagonal step keeps the byte, rows run downwards)
+			const int qend = lt_walk((const uint8_t *) El, -RP, -(t_len - bm), bn + off, -1, q_pos, (flags & PF_LEAD_TRIM) != 0, &Ro, &clip, (int64_t) RP * (t_len + 1), &bad, 1);
 			const int cut = Ro.finish((flags & PF_TRAIL_TRIM) != 0);
 			if(bad) atomicMax(&A.counters[LCI(LC_STATUS)], 10ull);
 			P->score = score; P->n_runs = bad ? 0 : Ro.n;
@@ -2318,7 +2326,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 	const bool reg_rows = simple_sc && !(getenv("KMAHIP_LT_REG") && getenv("KMAHIP_LT_REG")[0] == '0');      // lt_reg_kernel for the classes of up to 64 cells a row
 	const bool reg_wide = reg_rows && !(getenv("KMAHIP_LT_REG128") && getenv("KMAHIP_LT_REG128")[0] == '0');      // ... and of up to 128 (one wavefront per SIMD: 512 registers)
 	const bool reg_band = reg_rows && !(getenv("KMAHIP_LT_REGBAND") && getenv("KMAHIP_LT_REGBAND")[0] == '0');  // lt_regband_kernel for the banded classes of up to 96 cells a row
-	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; };
+	struct LaneLaunch { LaneGeom g; int wgs; size_t lds; size_t e_off; size_t estride; };      // estride: bytes of move matrix per lane
 	LaneLaunch lg[LT_LCLS];
 	for(int j = 0; j < LT_LCLS; ++j) {
 		lg[j].g = lt_lane_geom(j);
@@ -2330,6 +2338,12 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		// (lt_regband_kernel likewise: 3 / 2 per SIMD)
 		if((j == LT_LFULL || j == LT_LFULL + 1) && reg_band) lg[j].wgs = 256 * (j == LT_LFULL ? 4 * LT_RB72_WAVES : 8);
 		lg[j].e_off = 0;
+		lg[j].estride = (size_t) lg[j].g.ecap + 288;
+	}
+	// (the register kernels' matrices: rows of R rounded up to 16 bytes, one per template row the class takes + the boundary row)
+	for(int j = 0; j < LT_LCLS; ++j) {
+		const bool regk = (j <= 3 && reg_rows) || (j == 4 && reg_wide) || ((j == LT_LFULL || j == LT_LFULL + 1) && reg_band);
+		if(regk) lg[j].estride = (size_t) ((lg[j].g.R + 15) & ~15) * (size_t) (16 * lg[j].g.TW + 1) + 32;
 	}
 	int64_t B = std::min<int64_t>(n, std::max<int64_t>(1024, 400000000ll / max_len));
 	if(const char *e = getenv("KMAHIP_LT_PASS_READS")) B = std::min<int64_t>(n, std::max<int64_t>(1, atoll(e)));          // (the tests: many passes out of a few reads)
@@ -2524,7 +2538,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 			size_t lane_e_bytes = 0;
 			for(int j = 0; j < LT_LCLS; ++j) {
 				lg[j].e_off = lane_e_bytes;
-				lane_e_bytes += (size_t) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (c[LCI(LC_LCNT + j)] + 63) / 64) * 64 * (size_t) (lg[j].g.ecap + 288);
+				lane_e_bytes += (size_t) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (c[LCI(LC_LCNT + j)] + 63) / 64) * 64 * lg[j].estride;
 			}
 			if((rc = lt_reserve(ws, 9, std::max<size_t>(tmp_bytes, 16))) || (rc = lt_reserve(ws, 10, std::max<size_t>(lane_e_bytes, 16)))) return rc;
 			if(rocprim::radix_sort_pairs_desc(ws->lt_buf[9], tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc failed"); return KMAHIP_EDEVICE; }
@@ -2571,7 +2585,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				const unsigned long long cnt = c[LCI(LC_LCNT + j)];
 				if(!cnt) continue;
 				LaneArgs La;
-				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap; La.estride = lg[j].g.ecap + 288;
+				La.queue = vals_out + off; La.count = cnt; La.R = lg[j].g.R; La.RQ = lg[j].g.RQ; La.TW = lg[j].g.TW; La.ecap = lg[j].g.ecap; La.estride = (int) lg[j].estride;
 				La.E = (uint8_t *) ws->lt_buf[10] + lg[j].e_off;
 				La.ablate = getenv("KMAHIP_LT_ABLATE") ? atoi(getenv("KMAHIP_LT_ABLATE")) : 0;
 				const unsigned grid = (unsigned) std::min<unsigned long long>((unsigned long long) lg[j].wgs, (cnt + 63) / 64);
