@@ -2529,9 +2529,9 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 		if(c[LCI(LC_LANE)]) {
 			// the lane classes: one sort by (class, sweep length), longest first, then a kernel per class (below)
 			const size_t nl = (size_t) c[LCI(LC_LANE)];
-			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) A.lq + 3 * prob_cap;
+			uint32_t *keys_in = A.lkey, *keys_out = (uint32_t *) A.lq + 3 * A.prob_cap;
 			int32_t *vals_in = A.lq;
-			vals_out = A.lq + 2 * prob_cap;
+			vals_out = A.lq + 2 * A.prob_cap;
 			size_t tmp_bytes = 0;
 			if(rocprim::radix_sort_pairs_desc((void *) nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, nl, 0u, 28u, stream) != hipSuccess) { kmahip_set_error("rocprim::radix_sort_pairs_desc (size query) failed"); return KMAHIP_EDEVICE; }
 			// the lanes' stretches of move matrix: as many workgroups per class as this pass has work for
@@ -2615,7 +2615,7 @@ int kmahip_launch_longtrace(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *re
 				else { if(simple_sc) hipLaunchKernelGGL(lt_lane_band_kernel<true>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); else hipLaunchKernelGGL(lt_lane_band_kernel<false>, dim3(grid), dim3(64), lg[j].lds, ls, A, La); }
 				if(dbg) {
 					std::vector<uint32_t> hk((size_t) cnt);
-					(void) hipMemcpy(hk.data(), (uint32_t *) A.lq + 3 * prob_cap + off, (size_t) cnt * 4, hipMemcpyDeviceToHost);
+					(void) hipMemcpy(hk.data(), (uint32_t *) A.lq + 3 * A.prob_cap + off, (size_t) cnt * 4, hipMemcpyDeviceToHost);
 					unsigned long long turns = 0, rounds = 0;
 					for(size_t x = 0; x < hk.size(); ++x) { turns += hk[x] & 0xFFFFFFu; if(x % 64 == 0) rounds += hk[x] & 0xFFFFFFu; }
 					fprintf(stderr, "[kmahip] longtrace: lane class %d: %llu problems, %llu turns of their sweeps, %llu turns of the wavefronts (x 64 = %.2f of them used), longest %u\n",
