@@ -5,6 +5,7 @@
  *     kmahip_map -i reads.fq.gz -t_db db -o out                     (the reference's default mode: chain finder, reads may map in pieces)
  *     kmahip_map -i reads.fq.gz -t_db db -o out -1t1
  *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out -1t1 -apm p
+ *     kmahip_map -ipe r1.fq.gz r2.fq.gz -t_db db -o out              (paired input in the default mode: couples by union, single records in pieces)
  *     kmahip_map -i ont.fq.gz -t_db db -o out -Mt1 1 -bcNano        (every read against template 1, runKMA_Mt1 mt1.c:86-500)
  *     kmahip_map -gpus 8 -i reads.fq -t_db db -o out -1t1           (one process per GPU, the reads sharded; see below)
  *
@@ -151,7 +152,7 @@ static void usage(void) {
 	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] [-apm p|u]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-ts bases] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
-	                "(the options of kma 1.5.1 this path implements; -apm takes p or u, -ipe needs -1t1; everything else is refused)\n");
+	                "(the options of kma 1.5.1 this path implements; -apm takes p or u; everything else is refused)\n");
 }
 
 static long long need_int(int argc, char **argv, int *a, const char *what) {
@@ -296,7 +297,9 @@ int main(int argc, char **argv) {
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
 	par.apm = apm == 1 ? 0 : 1;          /* (without -apm the reference pairs by union, kma.c:206) */
-	if(chain && input2) { fprintf(stderr, "kmahip_map: paired input needs -1t1 (the default mode is built for single-end input)\n"); return 2; }
+	/* paired input without -1t1: couples are paired as ever, a record that lost its mate goes to the chain finder (savekmers.c:196-200) */
+	const int pe_chain = chain && input2;
+	if(pe_chain) chain = 0;
 	if(chain && par.mrc != 0.0) { fprintf(stderr, "kmahip_map: -mrc needs -1t1 (the chain finder's query-coverage variant is not built)\n"); return 2; }
 	if(mt1 && input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
 	if(threads) {
@@ -361,6 +364,7 @@ int main(int argc, char **argv) {
 		if(pthread_create(&reader, NULL, stream_main, &sj)) fail("cannot start a thread");
 		kmahip_db *db; kmahip_ws *ws;
 		if(kmahip_init(local) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws)) die("open");
+		if(pe_chain && kmahip_ws_set_pe_chain(ws, &cp)) die("open");
 		const double t_open = now_s();
 		kmahip_shard_opts so;
 		memset(&so, 0, sizeof so);
@@ -433,6 +437,7 @@ int main(int argc, char **argv) {
 
 	kmahip_db *db; kmahip_ws *ws; kmahip_db_info info;
 	if(kmahip_init(local) || kmahip_db_open(prefix, &db) || kmahip_ws_create(db, &ws) || kmahip_db_get_info(db, &info)) die("open");
+	if(pe_chain && kmahip_ws_set_pe_chain(ws, &cp)) die("open");
 	kmahip_comm *comm = NULL;
 	if(world > 1 || force_comm) {
 		const char *backend = getenv("KMAHIP_COMM") ? getenv("KMAHIP_COMM") : "rccl";

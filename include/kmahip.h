@@ -541,6 +541,15 @@ int kmahip_run_chain(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, co
 int kmahip_run_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
                   int64_t max_frag, const char *frag_path, kmahip_run *out);
 
+/* Paired input in KMA's DEFAULT mode (`-ipe r1 r2` without -1t1): the reference's batch loop hands a couple to save_kmers_pair
+ * and a record that lost its mate to kmerScan (save_kmers_batch, savekmers.c:171-200), which without -1t1 is save_kmers_chain
+ * (savekmers.c:40) -- the couples are mapped exactly as under -1t1 (one2one only guards a branch of anker_rc / anker_rc_comp no
+ * seeded read reaches, align.c:964,1157), a single record yields the chain finder's records with their query bounds. With `cp`
+ * set on the workspace every paired run on it (kmahip_run_pe, kmahip_run_pe_sharded, a session after kmahip_session_set_pe)
+ * does that: each record of a single read is a unit of the stream where its read stood, and goes through stage 3a, ConClave,
+ * the traceback and the `.frag.gz` like a record of kmahip_run_chain. NULL: back to -1t1 (single records through save_kmers). */
+int kmahip_ws_set_pe_chain(kmahip_ws *ws, const kmahip_chain_params *cp);
+
 /* Multi-GPU (one process per GPU): in-place SUM over all ranks of the two ConClave
  * vectors on `stream`, through RCCL (ncclAllReduce, ncclUint64, ncclSum).
  * `nccl_comm` is an ncclComm_t the host program created (ncclCommInitRank);

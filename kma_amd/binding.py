@@ -200,6 +200,7 @@ def lib():
         L.kmahip_run_pe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadBatchC), C.POINTER(Params), C.c_double, C.c_int, C.c_int64, C.c_char_p,
                                     C.POINTER(Run)]
         L.kmahip_run_mt1.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_int, C.POINTER(Params), C.POINTER(AssembleOpts), C.POINTER(Run)]
+        L.kmahip_ws_set_pe_chain.argtypes = [C.c_void_p, C.POINTER(ChainParams)]
         L.kmahip_assemble2.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.POINTER(Traces), C.POINTER(AssembleOpts),
                                        C.POINTER(Assembly)]
         L.kmahip_frag_write3.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -765,6 +766,11 @@ class KmaHipDB:
         _check(lib().kmahip_frag_write3(os.fsencode(path), self.h, C.byref(r), _p(fl), _p(tm), _p(nh), _p(st), int(max_frag), int(order),
                                         None if fr is None else _p(fr), blob, _p(noff), C.byref(rows)))
         return rows.value
+
+    def set_pe_chain(self, on=True, minlen=16, coverT=0.1, mrs=0.5):
+        """Paired runs on this workspace in the reference's default mode (no -1t1): records that lost their mate go to the chain
+        finder (kmahip_ws_set_pe_chain); on=False: back to -1t1."""
+        _check(lib().kmahip_ws_set_pe_chain(self.ws, C.byref(ChainParams(int(minlen), 0, float(coverT), float(mrs))) if on else None))
 
     def run_pe(self, batch, names, pair, evalue=0.05, bcd=1, max_frag=0, frag_path=None):
         """The paired run in one call (kmahip_run_pe) on what Ingest.next returned for two mate files -> dict(rows, cover, aln_len,

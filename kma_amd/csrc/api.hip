@@ -15,6 +15,13 @@ extern "C" int kmahip_ws_create(kmahip_db *db, kmahip_ws **out) {
 	return KMAHIP_OK;
 }
 
+extern "C" int kmahip_ws_set_pe_chain(kmahip_ws *ws, const kmahip_chain_params *cp) {
+	if(!ws) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	ws->pe_chain_on = cp != nullptr;
+	if(cp) ws->pe_chain = *cp;
+	return KMAHIP_OK;
+}
+
 extern "C" void kmahip_ws_destroy(kmahip_ws *ws) {
 	if(!ws) return;
 	(void) hipFree(ws->item_score); (void) hipFree(ws->item_n); (void) hipFree(ws->item_off);

@@ -93,6 +93,9 @@ struct kmahip_ws {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events2;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events3;   // prefilter kernel
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> *events4;   // seeding kernel
+	// paired input in the default mode (kmahip_ws_set_pe_chain): singly loaded reads of a paired stream go to the chain finder
+	int pe_chain_on;
+	kmahip_chain_params pe_chain;
 	// paired-end stage 2
 	int32_t *pool_sc, *ppool;
 	void *pe_rec;

@@ -253,6 +253,81 @@ int gather_batch(DevBlock &B, const kmahip_reads &src, const int64_t *d_idx, int
 	return KMAHIP_OK;
 }
 
+// the same over two batches in HBM: idx < n0 is a read of `a`, idx >= n0 read idx - n0 of `b` (the paired run of the default mode: the
+// couples' reads are the uploaded batch's, a singly loaded read's fragments are the chain finder's records, which carry their query
+// bounds -- a read of `a` gets the whole read as its bounds)
+struct Gather2 {
+	const uint64_t *seq[2];
+	const int64_t *seq_off[2], *N_off[2];
+	const int32_t *len[2], *N[2];
+	const int32_t *qs, *qe;          // of `b`
+	int64_t n0;
+};
+
+__global__ __launch_bounds__(256) void gather_sizes2_kernel(int64_t m, const int64_t *idx, const Gather2 G, int64_t *words, int64_t *n_N) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i > m) return;
+	if(i == m) { words[i] = 0; n_N[i] = 0; return; }
+	const int k = idx[i] >= G.n0;
+	const int64_t r = idx[i] - (k ? G.n0 : 0);
+	words[i] = ((G.len[k][r] + 31) >> 5) + 1;
+	n_N[i] = G.N_off[k][r + 1] - G.N_off[k][r];
+}
+
+__global__ __launch_bounds__(256) void gather_copy2_kernel(int64_t m, const int64_t *idx, const Gather2 G, uint64_t *o_seq, const int64_t *o_seq_off, int32_t *o_len,
+                                                           int32_t *o_N, const int64_t *o_N_off, int32_t *o_qs, int32_t *o_qe) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= m) return;
+	const int k = idx[i] >= G.n0;
+	const int64_t r = idx[i] - (k ? G.n0 : 0);
+	const int L = G.len[k][r], w = (L + 31) >> 5;
+	const uint64_t *a = G.seq[k] + G.seq_off[k][r];
+	uint64_t *b = o_seq + o_seq_off[i];
+	for(int x = 0; x < w; ++x) b[x] = a[x];
+	b[w] = 0;
+	o_len[i] = L;
+	const int32_t *na = G.N[k] + G.N_off[k][r];
+	int32_t *nb = o_N + o_N_off[i];
+	const int nn = (int) (G.N_off[k][r + 1] - G.N_off[k][r]);
+	for(int x = 0; x < nn; ++x) nb[x] = na[x];
+	o_qs[i] = k ? G.qs[r] : 0; o_qe[i] = k ? G.qe[r] : L;
+}
+
+int gather_batch2(DevBlock &B, const kmahip_reads &a, int64_t n0, const kmahip_reads &b, const int64_t *d_idx, int64_t m, kmahip_reads *dst, hipStream_t s) {
+	int64_t *wc, *nc, *so, *no;
+	int rc;
+	Gather2 G;
+	G.seq[0] = a.seq; G.seq_off[0] = a.seq_off; G.N_off[0] = a.N_off; G.len[0] = a.len; G.N[0] = a.N;
+	G.seq[1] = b.seq; G.seq_off[1] = b.seq_off; G.N_off[1] = b.N_off; G.len[1] = b.len; G.N[1] = b.N;
+	G.qs = b.q_start; G.qe = b.q_end; G.n0 = n0;
+	if((rc = B.get((size_t) m + 1, &wc)) || (rc = B.get((size_t) m + 1, &nc)) || (rc = B.get((size_t) m + 1, &so)) || (rc = B.get((size_t) m + 1, &no))) return rc;
+	hipLaunchKernelGGL(gather_sizes2_kernel, dim3((unsigned) ((m + 256) / 256)), dim3(256), 0, s, m, d_idx, G, wc, nc);
+	if((rc = scan_i64(B, wc, so, (size_t) m + 1, s)) || (rc = scan_i64(B, nc, no, (size_t) m + 1, s))) return rc;
+	int64_t tw = 0, tn = 0;
+	HIP_TRY(hipMemcpyAsync(&tw, so + m, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&tn, no + m, 8, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	uint64_t *seq;
+	int32_t *len, *N, *qs, *qe;
+	if((rc = B.get((size_t) tw + 2, &seq)) || (rc = B.get((size_t) m + 1, &len)) || (rc = B.get((size_t) tn + 1, &N)) || (rc = B.get((size_t) m + 1, &qs)) ||
+	   (rc = B.get((size_t) m + 1, &qe))) return rc;
+	HIP_TRY(hipMemsetAsync(seq + tw, 0, 16, s));
+	HIP_TRY(hipMemsetAsync(len + m, 0, 4, s));
+	if(m) hipLaunchKernelGGL(gather_copy2_kernel, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, m, d_idx, G, seq, so, len, N, no, qs, qe);
+	HIP_TRY(hipGetLastError());
+	*dst = kmahip_reads{};
+	dst->n_reads = m; dst->seq = seq; dst->seq_off = so; dst->len = len; dst->N = N; dst->N_off = no;
+	dst->seq_words = tw; dst->N_total = tn; dst->max_len = a.max_len > b.max_len ? a.max_len : b.max_len;
+	dst->q_start = qs; dst->q_end = qe;
+	return KMAHIP_OK;
+}
+
+// where a fragment's header is: the read itself, or the read a chain record was cut from
+__global__ __launch_bounds__(256) void pe_name_src_kernel(int64_t nf, const int64_t *f_src, int64_t n0, const int64_t *rec_read, int64_t *f_name) {
+	const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < nf) f_name[i] = f_src[i] < n0 ? f_src[i] : rec_read[f_src[i] - n0];
+}
+
 // The frag_raw records of the stream (update_Scores_pe / _se, updatescores.c:300-488), two slots per unit in stream order: a slot
 // left at n = 0, score = 0 is no record. A record's hit list lies at r_off of the joint hit arrays (pairs first, the singles'
 // lists from s_base on); its one or two fragments are reads of the uploaded batch.
@@ -373,6 +448,17 @@ static int shard_carry_in(ShardCtx *sc, const int32_t last[4], int32_t carry[3])
 static int shard_chunk_token(ShardCtx *sc, bool receive, int64_t state[2]);
 static uint64_t *shard_frag_counts(ShardCtx *sc, size_t D);
 
+// stage 2 of the default mode on an uploaded batch and its records as a batch of their own, in stream order: R.d = the read of a
+// record, or its reverse complement where the record prints that, with the record's query bounds; R.c = the template lists
+struct ChainRecs {
+	int64_t m = 0, n_T = 0;
+	kmahip_reads d{};
+	kmahip_cands c{};
+	int64_t *o_read = nullptr;     // device: the read a record comes from
+	int32_t *o_emit = nullptr;     // device: 1 = the record holds the reverse complement
+};
+static int chain_records(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_reads &dR, const kmahip_reads *reads, const kmahip_params *p,
+                         const kmahip_chain_params *cp, ChainRecs &R, const std::function<void(const char *)> &lap);
 static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *batch, const kmahip_params *p, double evalue, int bcd,
                        int64_t max_frag, const char *frag_path, kmahip_run *out, ShardCtx *sc, const KmaPeDev *pd);
 
@@ -410,13 +496,14 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 
 	// units of the stream: a pair (two reads) or a single
 	std::unique_ptr<int32_t[]> u_first(new int32_t[(size_t) n + 1]), u_idx(new int32_t[(size_t) n + 1]);
+	// the default mode (no -1t1): a singly loaded read goes to the chain finder, couples to the pairing as ever (savekmers.c:196-200)
+	const kmahip_chain_params *cp = ws->pe_chain_on ? &ws->pe_chain : nullptr;
 	int64_t U = 0, np = 0, ns = 0;
 	for(int64_t i = 0; i < n; ++U) {
 		u_first[(size_t) U] = (int32_t) i;
 		if(batch->pair[i] == 1 && i + 1 < n && batch->pair[i + 1] == 2) { u_idx[(size_t) U] = (int32_t) np++; i += 2; }
 		else { u_idx[(size_t) U] = -(int32_t) (ns++) - 1; i += 1; }
 	}
-	const int64_t n_slots = 2 * U;
 
 	// the batch, once
 	DevBlock B;
@@ -443,12 +530,11 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	dR.q_start = nullptr; dR.q_end = nullptr;
 	if(!pd && ((rc = B.up(R.seq, (size_t) R.seq_words, 2, &dR.seq)) || (rc = B.up(R.seq_off, (size_t) n + 1, 0, &dR.seq_off)) ||
 	   (rc = B.up(R.len, (size_t) n, 1, &dR.len)) || (rc = B.up(R.N, (size_t) R.N_total, 1, &dR.N)) || (rc = B.up(R.N_off, (size_t) n + 1, 0, &dR.N_off)))) return rc;
-	const int32_t *d_first = nullptr, *d_uidx = nullptr;
-	if((rc = B.up(u_first.get(), (size_t) U, 1, &d_first)) || (rc = B.up(u_idx.get(), (size_t) U, 1, &d_uidx))) return rc;
 	kmahip_reads dP = dR, dS = dR;
 	dS.n_reads = 0;
+	std::vector<int64_t> s_idx;
 	if(ns > 0) {          // pairs and singles as batches of their own (all pairs: the batch as it is)
-		std::vector<int64_t> p_idx, s_idx;
+		std::vector<int64_t> p_idx;
 		p_idx.reserve((size_t) 2 * np); s_idx.reserve((size_t) ns);
 		for(int64_t u = 0; u < U; ++u) {
 			if(u_idx[(size_t) u] < 0) s_idx.push_back(u_first[(size_t) u]);
@@ -495,7 +581,36 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	kmahip_cands cd;
 	if((rc = B.get((size_t) ns + 1, &cd.rc_flag)) || (rc = B.get((size_t) ns + 1, &cd.flag)) || (rc = B.get((size_t) ns + 1, &cd.T_off, true))) return rc;
 	cd.T_cap = 2 * ns + 4096; cd.T = nullptr;
-	for(int attempt = 0; ns > 0; ++attempt) {
+	ChainRecs CR;
+	const int64_t *d_rec_read = nullptr;          // (default mode) the read of the uploaded batch a record was cut from
+	if(cp && ns > 0) {
+		// the singles through save_kmers_chain: zero or more records per read, each a unit of the stream where its read stood, with
+		// its query bounds; a record's fragment is read n + record of the two-part gather below
+		if((rc = chain_records(db, ws, B, dS, &R, p, cp, CR, [&](const char *what) { stamp(what); }))) return rc;
+		const int64_t m = CR.m;
+		if(n + m > 0x7ffffff0ll) { kmahip_set_error("bad batch size"); return KMAHIP_EINVAL; }
+		std::vector<int64_t> h_or((size_t) m + 1), rec_read((size_t) m + 1, 0);
+		if(m) HIP_TRY(hipMemcpy(h_or.data(), CR.o_read, (size_t) m * 8, hipMemcpyDeviceToHost));
+		std::unique_ptr<int32_t[]> nu_first(new int32_t[(size_t) (np + m) + 1]), nu_idx(new int32_t[(size_t) (np + m) + 1]);
+		int64_t U2 = 0, x = 0;
+		for(int64_t u = 0; u < U; ++u) {
+			if(u_idx[(size_t) u] >= 0) { nu_first[(size_t) U2] = u_first[(size_t) u]; nu_idx[(size_t) U2] = u_idx[(size_t) u]; ++U2; continue; }
+			const int64_t j = -(int64_t) u_idx[(size_t) u] - 1;
+			for(; x < m && h_or[(size_t) x] == j; ++x, ++U2) {
+				nu_first[(size_t) U2] = (int32_t) (n + x); nu_idx[(size_t) U2] = -(int32_t) x - 1;
+				rec_read[(size_t) x] = s_idx[(size_t) j];
+			}
+		}
+		if(x != m) { kmahip_set_error("chain records out of stream order"); return KMAHIP_EDEVICE; }
+		U = U2; u_first = std::move(nu_first); u_idx = std::move(nu_idx);
+		if((rc = B.up(rec_read.data(), (size_t) m + 1, 1, &d_rec_read))) return rc;
+		dS = CR.d; dS.n_reads = m; cd = CR.c; ns = m; totS = CR.n_T;
+		if(m == 0) dS.max_len = R.max_len;
+	}
+	const int64_t n_slots = 2 * U;
+	const int32_t *d_first = nullptr, *d_uidx = nullptr;
+	if((rc = B.up(u_first.get(), (size_t) U + 1, 1, &d_first)) || (rc = B.up(u_idx.get(), (size_t) U + 1, 1, &d_uidx))) return rc;
+	for(int attempt = 0; ns > 0 && !cp; ++attempt) {
 		if((rc = B.get((size_t) cd.T_cap, &cd.T))) return rc;
 		if((rc = kmahip_launch_scan_se(db, ws, &dS, p, &cd, s))) return rc;
 		HIP_TRY(hipStreamSynchronize(s));
@@ -631,7 +746,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	stamp("fragment count + chunks");
 	const int64_t *d_starts = nullptr;
 	if((rc = B.up(starts.data(), starts.size(), 1, &d_starts))) return rc;
-	int64_t *f_src, *f_rank;
+	int64_t *f_src, *f_rank, *f_name = nullptr;
 	int32_t *f_rc, *f_t, *f_nh;
 	if((rc = B.get((size_t) nf + 1, &f_src)) || (rc = B.get((size_t) nf + 1, &f_rank)) || (rc = B.get((size_t) nf + 1, &f_rc)) || (rc = B.get((size_t) nf + 1, &f_t)) ||
 	   (rc = B.get((size_t) nf + 1, &f_nh))) return rc;
@@ -642,7 +757,12 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 		hipLaunchKernelGGL(pe_frag_fill_kernel, dim3((unsigned) ((n_slots + 255) / 256)), dim3(256), 0, s, n_slots, cc.tmpl, A.r_n, A.fr_read, A.fr_rc, f_off, d_starts,
 		                   (int) starts.size(), mf, chunk_base, f_src, f_rc, f_t, f_nh, f_rank);
 		HIP_TRY(hipGetLastError());
-		if((rc = gather_batch(B, dR, f_src, nf, &dF, s))) return rc;
+		if((rc = cp ? gather_batch2(B, dR, n, CR.d, f_src, nf, &dF, s) : gather_batch(B, dR, f_src, nf, &dF, s))) return rc;
+		if(cp) {          // (the headers: a record's is its read's)
+			if((rc = B.get((size_t) nf + 1, &f_name))) return rc;
+			hipLaunchKernelGGL(pe_name_src_kernel, dim3((unsigned) ((nf + 255) / 256)), dim3(256), 0, s, nf, f_src, n, d_rec_read, f_name);
+			HIP_TRY(hipGetLastError());
+		}
 		stamp("fragment batch");
 		// stage 3c per fragment; the run pool is sized for a handful of runs per read and grown on demand
 		if((rc = B.get((size_t) 10 * nf + 10, &tr.stats)) || (rc = B.get((size_t) nf + 1, &tr.ops_off)) || (rc = B.get((size_t) nf + 1, &tr.n_ops))) return rc;
@@ -667,7 +787,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	if(sc) {
 		// exchange 3 and the owners' work: the filed fragments travel with their positions (shard_finish)
 		std::vector<int64_t> src((size_t) nf + 1);
-		if(nf) HIP_TRY(hipMemcpy(src.data(), f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
+		if(nf) HIP_TRY(hipMemcpy(src.data(), f_name ? f_name : f_src, (size_t) nf * 8, hipMemcpyDeviceToHost));
 		if(nf == 0) {          // (an empty fragment batch still takes part in the exchanges)
 			if((rc = B.get(1, const_cast<uint64_t **>(&dF.seq), true)) || (rc = B.get(2, const_cast<int64_t **>(&dF.seq_off), true)) || (rc = B.get(1, const_cast<int32_t **>(&dF.len), true)) ||
 			   (rc = B.get(1, const_cast<int32_t **>(&dF.N), true)) || (rc = B.get(2, const_cast<int64_t **>(&dF.N_off), true)) ||
@@ -685,7 +805,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	out->ms[4] = since(t);
 
 	// `.frag`: the per-fragment columns come back; the reads and their headers are the host batch's, through the fragments' read numbers
-	if(frag_path && nf > 0 && (pd || !getenv("KMAHIP_PE_HOST_FRAG"))) {
+	if(frag_path && nf > 0 && (pd || cp || !getenv("KMAHIP_PE_HOST_FRAG"))) {
 		// the fragments and their figures are in HBM: the headers go up (a resident batch has them there), the rows are ordered and
 		// formatted there (session.hip); the host compresses. (KMAHIP_PE_HOST_FRAG: the columns back and the rows made on the host, as in round 2)
 		const char *d_names = pd ? pd->d_names : nullptr;
@@ -693,7 +813,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 		if(!pd && ((rc = B.up(batch->names, (size_t) batch->name_off[n], 1, &d_names)) || (rc = B.up(batch->name_off, (size_t) n + 1, 0, &d_name_off)))) return rc;
 		int64_t rows = 0;
 		if(pinned.th.joinable()) pinned.th.join();
-		if((rc = kmahip_frag_write_dev(db, &dF, d_names, d_name_off, f_src, f_rc, f_t, f_nh, tr.stats, f_rank, mf + 1, frag_path, pd ? pd->text_chunk : pin_chunk,
+		if((rc = kmahip_frag_write_dev(db, &dF, d_names, d_name_off, f_name ? f_name : f_src, f_rc, f_t, f_nh, tr.stats, f_rank, mf + 1, frag_path, pd ? pd->text_chunk : pin_chunk,
 		                               pd ? pd->h_text : (pinned.ok ? pinned.buf : nullptr), &rows))) return rc;
 		if(pd && pd->frag_rows) *pd->frag_rows = rows;
 	} else if(frag_path && nf > 0) {
@@ -800,15 +920,6 @@ __global__ __launch_bounds__(256) void gather_copy_rc_kernel(int64_t m, const in
 
 }  // namespace
 
-// stage 2 of the default mode on an uploaded batch and its records as a batch of their own, in stream order: R.d = the read of a
-// record, or its reverse complement where the record prints that, with the record's query bounds; R.c = the template lists
-struct ChainRecs {
-	int64_t m = 0, n_T = 0;
-	kmahip_reads d{};
-	kmahip_cands c{};
-	int64_t *o_read = nullptr;     // device: the read a record comes from
-	int32_t *o_emit = nullptr;     // device: 1 = the record holds the reverse complement
-};
 static int chain_records(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kmahip_reads &dR, const kmahip_reads *reads, const kmahip_params *p,
                          const kmahip_chain_params *cp, ChainRecs &R, const std::function<void(const char *)> &lap) {
 	const int64_t n = dR.n_reads;

@@ -127,6 +127,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         ["-i", fq, "-t_db", prefix, "-1t1", "-mp", "30", "-ml", "40", "-eq", "25", "-mf", "900"],
         ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-bcNano"],                       # C4's switches
         ["-i", fq, "-t_db", prefix, "-t", "2"],                                    # the default mode
+        ["-ipe", r1, r2, "-t_db", prefix, "-t", "1"],                              # ... with paired input (single records through the chain finder)
     ]
     for i, args in enumerate(cases):
         ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
@@ -141,7 +142,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
                     a, b = sorted(a.splitlines()), sorted(b.splitlines())      # (the reference's row order depends on its threads' timing)
                 assert a == b, (args, ext)
     # what is not built is refused, not ignored
-    for bad in (["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-apm", "f"], ["-ipe", r1, r2, "-t_db", prefix, "-o", str(tmp_path / "x")],
+    for bad in (["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-apm", "f"], ["-ipe", r1, r2, "-t_db", prefix, "-o", str(tmp_path / "x"), "-apm", "f"],
                 ["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "x"), "-1t1", "-sam"]):
         assert _run(bad, ok=False).returncode != 0
 
@@ -161,7 +162,7 @@ def test_input_that_breaks_off_ends_the_run_with_an_error(tmp_path):
         assert b"ingest" in r.stderr
 
 
-def _pe_case(tmp_path, n_pairs=12000):
+def _pe_case(tmp_path, n_pairs=12000, chimeras=False):
     rng = np.random.default_rng(5)
     names, seqs = synth.make_gene_db(30, 5, 700, 1400, 0.04, seed=77)
     prefix = str(tmp_path / "db")
@@ -171,13 +172,19 @@ def _pe_case(tmp_path, n_pairs=12000):
     q1, q2 = [b"I" * 150] * len(r1), [b"I" * 150] * len(r2)
     for i in rng.choice(len(r1), n_pairs // 20, replace=False):                   # a foreign mate
         (r1 if rng.random() < 0.5 else r2)[i] = rng.integers(0, 4, 150, dtype=np.uint8)
-    for i in rng.choice(len(r1), n_pairs // 20, replace=False):                   # a mate that the quality trim shortens below -ml: a single record
+    for x, i in enumerate(rng.choice(len(r1), n_pairs // 20, replace=False)):     # a mate that the quality trim shortens below -ml: a single record
         q = bytearray(b"I" * 150)
         q[10:] = b"#" * 140
-        if rng.random() < 0.5:
+        first = rng.random() < 0.5
+        if first:
             q1[i] = bytes(q)
         else:
             q2[i] = bytes(q)
+        if chimeras and x % 3 == 0:                                               # ... whose mate is made of two genes (the default mode files it in pieces)
+            g1, g2 = (seqs[int(g)] for g in rng.choice(len(seqs), 2, replace=False))
+            a1, a2 = int(rng.integers(0, len(g1) - 80)), int(rng.integers(0, len(g2) - 80))
+            piece2 = g2[a2:a2 + 75] if x % 2 else (3 - g2[a2:a2 + 75])[::-1]
+            (r2 if first else r1)[i] = np.concatenate([g1[a1:a1 + 75], piece2]).astype(np.uint8)
     for i in rng.choice(len(r1), n_pairs // 12, replace=False):                   # an insertion or a deletion in a mate (the pile-up order matters)
         r = r1 if rng.random() < 0.5 else r2
         a = int(rng.integers(30, 120))
@@ -254,6 +261,31 @@ def test_batched_paired_session_writes_the_one_batch_files(tmp_path, batch, mf):
     r = _run(args + ["-o", str(tmp_path / "many")], env={"KMAHIP_MAP_BATCH": str(batch), "KMAHIP_ROW_GRAIN": "700"})
     assert b"batches" in r.stderr
     _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
+
+
+@pytest.mark.parametrize("apm", [None, "p"])
+def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, apm):
+    """`-ipe r1 r2` WITHOUT -1t1, the reference's default: couples go to save_kmers_pair as ever, a record that lost its mate to the
+    trimming goes to kmerScan = save_kmers_chain (savekmers.c:196-200) and is filed in pieces with query bounds -- here a third of
+    those reads are made of two genes (one piece forward, one reversed). One batch, batch by batch and over three ranks against
+    the compiled reference: `.res`, `.fsa`, `.aln` byte for byte, `.frag.gz` after inflating."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    prefix, r1, r2 = _pe_case(tmp_path, n_pairs=6000, chimeras=True)
+    args = ["-ipe", r1, r2, "-t_db", prefix] + (["-apm", apm] if apm else [])
+    ref = str(tmp_path / "ref")
+    subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    one2one = str(tmp_path / "ref1")
+    subprocess.run([KMA] + args + ["-o", one2one, "-t", "1", "-1t1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert gzip.open(ref + ".frag.gz").read() != gzip.open(one2one + ".frag.gz").read()          # (the case tells the two modes apart)
+    _run(args + ["-o", str(tmp_path / "one")], env={"KMAHIP_MAP_ONE_BATCH": "1"})
+    _same_files(ref, str(tmp_path / "one"))
+    r = _run(args + ["-o", str(tmp_path / "many")], env={"KMAHIP_MAP_BATCH": "777", "KMAHIP_ROW_GRAIN": "700"})
+    assert b"batches" in r.stderr
+    _same_files(ref, str(tmp_path / "many"))
+    _run(["-gpus", "3"] + args + ["-o", str(tmp_path / "ranks")], env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
+    _same_files(ref, str(tmp_path / "ranks"))
 
 
 @pytest.mark.parametrize("world,gz,bc", [(2, False, True), (3, True, True), (2, False, False)])
