@@ -300,7 +300,9 @@ int main(int argc, char **argv) {
 	/* paired input without -1t1: couples are paired as ever, a record that lost its mate goes to the chain finder (savekmers.c:196-200) */
 	const int pe_chain = chain && input2;
 	if(pe_chain) chain = 0;
-	if(chain && par.mrc != 0.0) { fprintf(stderr, "kmahip_map: -mrc needs -1t1 (the chain finder's query-coverage variant is not built)\n"); return 2; }
+	/* -mrc in the default mode: mrchain (kmeranker.c:57-81) only drops templates when q_len < mrc * (the chain's span on the read), which
+	 * no mrc <= 1 can make true -- stage 2 is as without it, the coverage test of stages 3a / 3c (mrcheck) is the aligner's own */
+	if((chain || pe_chain) && par.mrc > 1.0) { fprintf(stderr, "kmahip_map: -mrc above 1 needs -1t1 (the chain finder's mrchain filter is not built)\n"); return 2; }
 	if(mt1 && input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
 	if(threads) {
 		char v[16];

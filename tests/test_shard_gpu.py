@@ -322,8 +322,8 @@ def test_mt1_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_pat
         assert gzip.open(r + ".frag.gz").read() == gzip.open(b + ".frag.gz").read()
 
 
-@pytest.mark.parametrize("world,mf,seed", [(2, None, 1), (3, 777, 2), (5, 60, 3)])
-def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, mf, seed):
+@pytest.mark.parametrize("world,mf,seed,more", [(2, None, 1, []), (3, 777, 2, ["-mrc", "0.7"]), (5, 60, 3, [])])
+def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, mf, seed, more):
     """no -1t1 (kmahip_run_chain_sharded): reads that map in pieces -- several records per read, strand ties, query bounds -- with N's
     and indels; the records of the shards must come out as the records of the one stream (their pile-up and fragment rows follow the
     order of the whole stream, the chunks of -mf filed fragments straddle the shards)"""
@@ -339,7 +339,7 @@ def test_default_mode_over_ranks_writes_the_single_rank_files_and_the_reference_
     reads = _chimeric_reads(seqs, 9000, rng, with_n=seed > 1)
     fq = str(tmp_path / "r.fq")
     synth.write_fastq(fq, reads)
-    extra = ["-mf", str(mf)] if mf else []
+    extra = (["-mf", str(mf)] if mf else []) + more          # (-mrc: stage 2 is as without it, kmeranker.c:57-81; the pieces of a read fail the aligner's test)
     _run(["-i", fq, "-t_db", prefix, "-o", str(tmp_path / "one")] + extra)
     _run(["-gpus", str(world), "-i", fq, "-t_db", prefix, "-o", str(tmp_path / "many")] + extra, env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
     a, b = str(tmp_path / "one"), str(tmp_path / "many")
