@@ -149,7 +149,7 @@ static void fail(const char *msg) { fprintf(stderr, "kmahip_map: %s\n", msg); fi
 static void *xcalloc(size_t n, size_t sz) { void *p = calloc(n ? n : 1, sz); if(!p) fail("out of memory"); return p; }
 
 static void usage(void) {
-	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] [-apm p|u]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
+	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] [-apm p|u] | -int interleaved.fq[.gz] [-apm p|u]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-ts bases] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
 	                "(the options of kma 1.5.1 this path implements; -apm takes p or u; everything else is refused)\n");
@@ -261,6 +261,7 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-t_db") && a + 1 < argc) prefix = argv[++a];
 		else if(!strcmp(o, "-i") && a + 1 < argc) input = argv[++a];
 		else if(!strcmp(o, "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
+		else if(!strcmp(o, "-int") && a + 1 < argc) { input = argv[++a]; input2 = ""; }          /* interleaved: the paired reader on one file (kmahip_ingest_open_part with path2 = "") */
 		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
 			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) or u (union, save_kmers_unionPair / alnFragsUnionPE); f is not built\n"); return 1; }
@@ -292,7 +293,7 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-gpus")) gpus = (int) need_int(argc, argv, &a, o);
 		else { fprintf(stderr, "kmahip_map: option %s is not one this program implements\n", o); usage(); return 2; }
 	}
-	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe), -t_db and -o are required\n"); usage(); return 2; }
+	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe / -int), -t_db and -o are required\n"); usage(); return 2; }
 	if(ref_fsa == 1) base_call = base_call == 1 ? 4 : 3;      /* kma.c:1278-1284: refNanoCaller / refCaller */
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;

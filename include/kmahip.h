@@ -478,6 +478,12 @@ typedef struct kmahip_read_batch {
 /* path2 == NULL: single end (run_input); otherwise the two mate files are read in lockstep (run_input_PE): both mates
  * long enough -> a pair record, one of them -> a single record, none -> dropped. */
 int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *trim, kmahip_ingest **out);
+/* `-int file` (run_input_INT, runinput.c:608-740): ONE file whose records are taken two at a time as the mates of a couple, trimmed
+ * and gated like the two files of -ipe (both long enough -> a pair record, one -> a single record); the last record of a file with
+ * an odd number of them meets an empty mate (FileBuffgetFq clears the length before it finds the end, seqparse.c:249) and is filed
+ * singly. The batches are those of a paired reader (pair[] = 1 / 2 / 0). FASTQ only: for FASTA the reference cuts mate 2 with
+ * mate 1's bounds (runinput.c:705), which may reach past what it read -- KMAHIP_EFORMAT. */
+int kmahip_ingest_open_interleaved(const char *path, const kmahip_trim *trim, kmahip_ingest **out);
 /* up to max_records further S1 records; batch->reads.n_reads == 0 at the end of the input. A record that does not start
  * with '@' ends the input like in the reference ("Malformed input.", seqparse.c:256-260): the records before it are
  * delivered, then one call returns KMAHIP_EFORMAT. */
@@ -593,7 +599,8 @@ int kmahip_comm_alltoallv(kmahip_comm *c, const void *send, const int64_t *send_
  * parses only its byte range -- ranges are cut at record starts found by the reader's own guess (a line beginning with '@' whose
  * next line but one begins with '+'), the same on every rank, so the parts tile the file; *whole_input = 0. Anything else (.gz,
  * FASTA, two mate files): the reader delivers the whole input and *whole_input = 1 -- the caller keeps the records
- * [n part / parts, n (part + 1) / parts) of it. */
+ * [n part / parts, n (part + 1) / parts) of it. path2 == "" (the empty string) asks for the interleaved reader of
+ * kmahip_ingest_open_interleaved on path1. */
 int kmahip_ingest_open_part(const char *path1, const char *path2, const kmahip_trim *trim, int part, int parts, kmahip_ingest **out,
                             int *whole_input);
 

@@ -255,10 +255,16 @@ class Ingest:
     """Stage 1 on the host (kmahip_ingest_*): FASTQ / FASTA(.gz) -> trimmed, packed formats.ReadBatch batches, the
     records the reference's run_input / run_input_PE write into the S1 stream, in the same order."""
 
-    def __init__(self, path1, path2=None, min_phred=20, min_q=0, hardmask_q=0, min_len=16, max_len=2**31 - 1):
+    def __init__(self, path1, path2=None, min_phred=20, min_q=0, hardmask_q=0, min_len=16, max_len=2**31 - 1, interleaved=False):
         L = lib()
         t = Trim(min_phred, min_q, hardmask_q, min_len, max_len)
         self._h = C.c_void_p()
+        if interleaved:          # `-int file`: the records of one file two at a time (run_input_INT)
+            if path2:
+                raise ValueError("interleaved input is one file")
+            L.kmahip_ingest_open_interleaved.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]
+            _check(L.kmahip_ingest_open_interleaved(os.fsencode(path1), C.byref(t), C.byref(self._h)))
+            return
         _check(L.kmahip_ingest_open(os.fsencode(path1), os.fsencode(path2) if path2 else None, C.byref(t), C.byref(self._h)))
 
     @property

@@ -459,6 +459,7 @@ struct kmahip_ingest {
 	Stream s[2];                // FASTA input, and the first bytes of any input (format, phred scale)
 	Mate m[2];                  // FASTQ input
 	bool paired = false, fastq = true;
+	bool interleaved = false;   // `-int file`: paired, the mates alternate in ONE file (run_input_INT, runinput.c:608-740); m[0] / s[0] only
 	kmahip_trim trim;
 	int phred = 33;
 	int threads = 1;
@@ -722,12 +723,14 @@ void pack_fastq(const kmahip_ingest *in, const Span *const *spans, size_t a, siz
 	const int mates = in->paired ? 2 : 1;
 	std::vector<uint8_t> *codes = P.codes;
 	const bool plain = !T.min_q && !T.hardmask_q;       // only the ends are trimmed, by quality alone (runinput.c:144-171)
+	const bool il = in->interleaved;                     // (mate m of record i is record 2 i + m of the one file)
+	auto span_of = [&](int m, size_t i) -> const Span & { return il ? spans[0][2 * i + (size_t) m] : spans[m][i]; };
 	for(size_t i = a; i < b; ++i) {
 		int st[2] = {0, 0}, en[2] = {0, 0}, len[2] = {0, 0};
 		if(plain) {
 			const int minPhred = in->phred + T.min_phred;
 			for(int m = 0; m < mates; ++m) {
-				const Span &r = spans[m][i];
+				const Span &r = span_of(m, i);
 				const uint8_t *q = r.qual;
 				const int L = r.got ? (int) r.seq_len : 0;
 				if(T.max_len < L) continue;
@@ -738,7 +741,7 @@ void pack_fastq(const kmahip_ingest *in, const Span *const *spans, size_t a, siz
 			}
 			const bool ok0 = T.min_len <= len[0], ok1 = in->paired && T.min_len <= len[1];
 			auto put = [&](int m, uint8_t pair) {
-				const Span &r = spans[m][i];
+				const Span &r = span_of(m, i);
 				append_raw(P, r.seq + st[m], en[m] - st[m], (const char *) r.name, r.got ? r.name_len : 0, pair);
 			};
 			if(ok0 && ok1) { put(0, 1); put(1, 2); }
@@ -749,7 +752,7 @@ void pack_fastq(const kmahip_ingest *in, const Span *const *spans, size_t a, siz
 			continue;
 		}
 		for(int m = 0; m < mates; ++m) {
-			const Span &r = spans[m][i];
+			const Span &r = span_of(m, i);
 			const int L = r.got ? (int) r.seq_len : 0;       // a mate file that ran out yields empty mates (the `|` at :516)
 			codes[m].resize((size_t) L);
 			for(int x = 0; x < L; ++x) codes[m][(size_t) x] = g_trans.t[r.seq[x]];
@@ -758,7 +761,7 @@ void pack_fastq(const kmahip_ingest *in, const Span *const *spans, size_t a, siz
 		}
 		const bool ok0 = T.min_len <= len[0], ok1 = in->paired && T.min_len <= len[1];
 		auto put = [&](int m, uint8_t pair) {
-			const Span &r = spans[m][i];
+			const Span &r = span_of(m, i);
 			append_read(P, codes[m].data() + st[m], en[m] - st[m], (const char *) r.name, r.got ? r.name_len : 0, pair);
 		};
 		if(ok0 && ok1) { put(0, 1); put(1, 2); }
@@ -945,14 +948,36 @@ extern "C" void kmahip_trim_default(kmahip_trim *t) {
 	t->min_phred = 20; t->min_q = 0; t->hardmask_q = 0; t->min_len = 16; t->max_len = INT_MAX;
 }
 
+static int ingest_open_impl(const char *path1, const char *path2, bool interleaved, const kmahip_trim *trim, kmahip_ingest **out);
+
 extern "C" int kmahip_ingest_open(const char *path1, const char *path2, const kmahip_trim *trim, kmahip_ingest **out) {
-	if(!path1 || !out) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
+	return ingest_open_impl(path1, path2, false, trim, out);
+}
+
+// `-int file` (run_input_INT, runinput.c:608-740): the records of ONE file taken two at a time as the mates of a couple, trimmed and
+// gated like the two files of -ipe; a last record without a partner meets an empty mate (FileBuffgetFq sets qseq->len = 0 before it
+// finds the end of the file, seqparse.c:249) and is filed singly. FASTQ only: for FASTA the reference cuts mate 2 with mate 1's
+// bounds (runinput.c:705: `qseq2->len = end - start`), which may reach past what it read.
+extern "C" int kmahip_ingest_open_interleaved(const char *path, const kmahip_trim *trim, kmahip_ingest **out) {
+	int rc = ingest_open_impl(path, nullptr, true, trim, out);
+	if(!rc && !(*out)->fastq) {
+		kmahip_ingest_close(*out); *out = nullptr;
+		kmahip_set_error("%s: interleaved input is taken as FASTQ only", path);
+		return KMAHIP_EFORMAT;
+	}
+	return rc;
+}
+
+static int ingest_open_impl(const char *path1, const char *path2, bool interleaved, const kmahip_trim *trim, kmahip_ingest **out) {
+	if(!path1 || !out || (interleaved && path2)) { kmahip_set_error("null argument"); return KMAHIP_EINVAL; }
 	kmahip_ingest *in = new kmahip_ingest();
 	if(trim) in->trim = *trim; else kmahip_trim_default(&in->trim);
 	// kma.c:1555-1557, runinput.c:380-382
 	if(in->trim.min_phred < in->trim.hardmask_q) in->trim.min_phred = in->trim.hardmask_q;
 	if(in->trim.min_phred < in->trim.min_q) in->trim.min_phred = in->trim.min_q;
-	in->paired = path2 != nullptr;
+	in->paired = path2 != nullptr || interleaved;
+	in->interleaved = interleaved;
+	const int files = path2 ? 2 : 1;
 	{	// worker threads for trimming + packing: KMAHIP_INGEST_THREADS, else the hardware threads, at most 16
 		const char *e = getenv("KMAHIP_INGEST_THREADS");
 		const int hw = (int) std::thread::hardware_concurrency();
@@ -961,22 +986,22 @@ extern "C" int kmahip_ingest_open(const char *path1, const char *path2, const km
 	}
 	const char *paths[2] = {path1, path2};
 	int kind[2] = {0, 0};
-	for(int i = 0; i < (in->paired ? 2 : 1); ++i) {
+	for(int i = 0; i < files; ++i) {
 		if(!in->s[i].open(paths[i])) { kmahip_set_error("cannot open %s", paths[i]); kmahip_ingest_close(in); return KMAHIP_EIO; }
 		const size_t have = in->s[i].ensure(FIRST_CHUNK);
 		const uint8_t c = have ? *in->s[i].at() : 0;
 		kind[i] = c == '@' ? 1 : (c == '>' ? 2 : 0);
 		if(have && !kind[i]) { kmahip_set_error("cannot determine format of file %s", paths[i]); kmahip_ingest_close(in); return KMAHIP_EFORMAT; }
 	}
-	if(in->paired && kind[0] != kind[1]) { kmahip_set_error("%s and %s are in different formats", path1, path2); kmahip_ingest_close(in); return KMAHIP_EFORMAT; }
+	if(files == 2 && kind[0] != kind[1]) { kmahip_set_error("%s and %s are in different formats", path1, path2); kmahip_ingest_close(in); return KMAHIP_EFORMAT; }
 	in->fastq = kind[0] != 2;
 	if(kind[0] == 1) {
 		in->phred = guess_phred(in->s[0].at(), std::min(in->s[0].end - in->s[0].pos, FIRST_CHUNK));
-		if(in->paired && in->phred == 0) in->phred = guess_phred(in->s[1].at(), std::min(in->s[1].end - in->s[1].pos, FIRST_CHUNK));
+		if(files == 2 && in->phred == 0) in->phred = guess_phred(in->s[1].at(), std::min(in->s[1].end - in->s[1].pos, FIRST_CHUNK));
 	}
 	if(in->fastq) {
 		// FASTQ is read again from the start, in chunks: a mapped file or a thread that inflates ahead of the parser
-		for(int i = 0; i < (in->paired ? 2 : 1); ++i) {
+		for(int i = 0; i < files; ++i) {
 			in->s[i].close();
 			in->s[i].buf.release();
 			if(!in->m[i].feed.open(paths[i])) { kmahip_set_error("cannot open %s", paths[i]); kmahip_ingest_close(in); return KMAHIP_EIO; }
@@ -993,7 +1018,8 @@ extern "C" int kmahip_ingest_open_part(const char *path1, const char *path2, con
                                        int *whole_input) {
 	if(!whole_input || parts < 1 || part < 0 || part >= parts) { kmahip_set_error("bad part"); return KMAHIP_EINVAL; }
 	*whole_input = 1;
-	int rc = kmahip_ingest_open(path1, path2, trim, out);
+	// (path2 == "" asks for the interleaved reader: the records of path1 two at a time, kmahip_ingest_open_interleaved)
+	int rc = (path2 && !*path2) ? kmahip_ingest_open_interleaved(path1, trim, out) : kmahip_ingest_open(path1, path2, trim, out);
 	if(rc || parts == 1) { if(!rc) *whole_input = 0; return rc; }
 	kmahip_ingest *in = *out;
 	Chunk *w = (in->fastq && !in->paired) ? in->m[0].feed.whole : nullptr;
@@ -1017,7 +1043,8 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 	in->seq_off.clear(); in->N_off.clear(); in->name_off.clear();
 	in->seq_off.push_back(0); in->N_off.push_back(0); in->name_off.push_back(0);
 	const kmahip_trim &T = in->trim;
-	const int mates = in->paired ? 2 : 1;
+	const bool il = in->interleaved;
+	const int mates = (in->paired && !il) ? 2 : 1;          // mate FILES
 	int64_t records = 0;
 	int max_len = 0;
 	if(in->fastq) {
@@ -1038,9 +1065,13 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 				}
 				avail = in->m[0].spans.size() - in->m[0].head;
 				if(mates == 2) avail = std::min(avail, in->m[1].spans.size() - in->m[1].head);
+				if(il) {          // couples of consecutive records; the last record of an odd file meets an empty mate
+					if(avail == 1 && in->m[0].eof) in->m[0].spans.resize(in->m[0].head + 2);
+					avail = (in->m[0].spans.size() - in->m[0].head) / 2;
+				}
 				if(avail) break;
 				bool more = false;
-				for(int m = 0; m < mates; ++m) if(in->m[m].spans.size() == in->m[m].head) more |= fill_wave(in, in->m[m]);
+				for(int m = 0; m < mates; ++m) if(in->m[m].spans.size() - in->m[m].head < (il ? 2u : 1u)) more |= fill_wave(in, in->m[m]);
 				if(!more) {
 					bool pending = false;
 					for(int m = 0; m < mates; ++m) pending |= in->m[m].spans.size() > in->m[m].head;
@@ -1064,7 +1095,7 @@ extern "C" int kmahip_ingest_next(kmahip_ingest *in, int64_t max_records, kmahip
 			const auto t2 = std::chrono::steady_clock::now();
 			append_parts(in, parts, nt);
 			for(int t = 0; t < nt; ++t) { records += parts[(size_t) t].records; max_len = std::max(max_len, parts[(size_t) t].max_len); }
-			for(int m = 0; m < mates; ++m) { in->m[m].head += n; release_chunks(in->m[m]); }
+			for(int m = 0; m < mates; ++m) { in->m[m].head += il ? 2 * n : n; release_chunks(in->m[m]); }
 			const auto t3 = std::chrono::steady_clock::now();
 			ms_locate += ms(t0, t1); ms_pack += ms(t1, t2); ms_gather += ms(t2, t3);
 		}

@@ -103,6 +103,11 @@ def main():
         write_fq(os.path.join(OUT, "m1.fq"), 250, 5)
         write_fq(os.path.join(OUT, "m2.fq"), 250, 6)
         cases["pe"] = ["-ipe", "m1.fq", "m2.fq"]
+        # interleaved input (-int): couples of consecutive records, and a file with an odd number of records (its last one is filed singly)
+        write_fq(os.path.join(OUT, "ilv.fq"), 300, 7)
+        cases["int"] = ["-int", "ilv.fq"]
+        write_fq(os.path.join(OUT, "ilvodd.fq"), 151, 8)
+        cases["intodd"] = ["-int", "ilvodd.fq"]
         with open(os.path.join(OUT, "p33.fq"), "rb") as f, gzip.GzipFile(os.path.join(OUT, "p33gz.fq.gz"), "wb", mtime=0) as g:
             shutil.copyfileobj(f, g)
         cases["p33gz"] = ["-i", "p33gz.fq.gz"]

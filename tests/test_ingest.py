@@ -26,6 +26,8 @@ CASES = {
     "wrap": ("wrap.fa", None, None),
     "pe": ("m1.fq", "m2.fq", 33),
     "p33gz": ("p33gz.fq.gz", None, 33),
+    "int": ("ilv.fq", "", 33),          # ("" = interleaved: the records of one file two at a time, run_input_INT)
+    "intodd": ("ilvodd.fq", "", 33),
 }
 
 
@@ -49,7 +51,7 @@ def _compare(batch, names, pair, s1):
 def test_ingest_matches_reference_s1(case, setting):
     f1, f2, phred = CASES[case]
     s1 = formats.parse_s1(gzip.open(os.path.join(ING, f"{case}.{setting}.s1.gz")).read())
-    with binding.Ingest(os.path.join(ING, f1), os.path.join(ING, f2) if f2 else None, **SETTINGS[setting]) as ing:
+    with binding.Ingest(os.path.join(ING, f1), os.path.join(ING, f2) if f2 else None, interleaved=f2 == "", **SETTINGS[setting]) as ing:
         if phred is not None:
             assert ing.phred_scale == phred
         got = ing.next(1 << 30)
@@ -163,6 +165,18 @@ def test_ingest_differential_against_reference_binary(tmp_path):
                 _compare(*got, s1)
         except AssertionError as e:
             raise AssertionError(f"case {case} {kw}: {str(e)[:300]}")
+        # the same file as interleaved input (`-int`: its records two at a time; an odd last one is filed singly)
+        cmd[1] = "-int"
+        s1 = formats.parse_s1(subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout)
+        with binding.Ingest(fq, None, interleaved=True, **kw) as ing:
+            got = ing.next(1 << 30)
+        try:
+            if got is None:
+                assert len(s1) == 0
+            else:
+                _compare(*got, s1)
+        except AssertionError as e:
+            raise AssertionError(f"case {case} -int {kw}: {str(e)[:300]}")
 
 
 def test_ingest_reports_malformed_input_after_the_good_records(tmp_path):
@@ -177,9 +191,9 @@ def test_ingest_reports_malformed_input_after_the_good_records(tmp_path):
 
 
 def _all(path1, path2=None, step=1 << 30, **kw):
-    """every batch of a file concatenated: (lengths, names, pair flags, packed words per read)"""
+    """every batch of a file concatenated: (lengths, names, pair flags, packed words per read); path2 == "": interleaved"""
     out = ([], [], [], [])
-    with binding.Ingest(path1, path2, **kw) as ing:
+    with binding.Ingest(path1, path2 or None, interleaved=path2 == "", **kw) as ing:
         err = None
         while True:
             try:
@@ -215,7 +229,7 @@ def test_ingest_chunked_reader_equals_one_pass(tmp_path, tiny_chunks, chunk, reg
     """the same files read whole (default sizes: one region each) and in tiny chunks / regions, plain and gzip-compressed"""
     import shutil
     import subprocess
-    files = [("p33.fq", None), ("dos.fq", None), ("p64.fq", None), ("m1.fq", "m2.fq"), ("p33gz.fq.gz", None)]
+    files = [("p33.fq", None), ("dos.fq", None), ("p64.fq", None), ("m1.fq", "m2.fq"), ("p33gz.fq.gz", None), ("ilv.fq", ""), ("ilvodd.fq", "")]
     # a file with hostile lines: qualities that begin with '@' and '+', a header that is only '@', long and empty reads
     rng = np.random.default_rng(5)
     rec = []
@@ -237,7 +251,7 @@ def test_ingest_chunked_reader_equals_one_pass(tmp_path, tiny_chunks, chunk, reg
         files.append((str(f) + ".copy.gz", None))
     for f1, f2 in files:
         p1 = f1 if os.path.isabs(f1) else os.path.join(ING, f1)
-        p2 = os.path.join(ING, f2) if f2 else None
+        p2 = os.path.join(ING, f2) if f2 else f2
         want = _all(p1, p2, min_phred=0, min_len=0)
         tiny_chunks(chunk, region)
         assert _all(p1, p2, min_phred=0, min_len=0) == want, (f1, "one batch")

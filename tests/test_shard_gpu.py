@@ -263,17 +263,24 @@ def test_batched_paired_session_writes_the_one_batch_files(tmp_path, batch, mf):
     _same_files(str(tmp_path / "one"), str(tmp_path / "many"))
 
 
-@pytest.mark.parametrize("apm", [None, "p"])
-def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, apm):
+@pytest.mark.parametrize("apm,interleaved", [(None, False), ("p", False), (None, True)])
+def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, apm, interleaved):
     """`-ipe r1 r2` WITHOUT -1t1, the reference's default: couples go to save_kmers_pair as ever, a record that lost its mate to the
     trimming goes to kmerScan = save_kmers_chain (savekmers.c:196-200) and is filed in pieces with query bounds -- here a third of
     those reads are made of two genes (one piece forward, one reversed). One batch, batch by batch and over three ranks against
-    the compiled reference: `.res`, `.fsa`, `.aln` byte for byte, `.frag.gz` after inflating."""
+    the compiled reference: `.res`, `.fsa`, `.aln` byte for byte, `.frag.gz` after inflating. interleaved: the same couples as ONE
+    file given with `-int` (run_input_INT, runinput.c:608-740; kmahip_ingest_open_interleaved)."""
     if not os.path.exists(KMA):
         pytest.skip("oracle/_ref/kma not built")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
     prefix, r1, r2 = _pe_case(tmp_path, n_pairs=6000, chimeras=True)
     args = ["-ipe", r1, r2, "-t_db", prefix] + (["-apm", apm] if apm else [])
+    if interleaved:
+        with open(r1, "rb") as f1, open(r2, "rb") as f2, open(tmp_path / "ilv.fq", "wb") as o:
+            l1, l2 = f1.read().split(b"\n"), f2.read().split(b"\n")
+            for i in range(0, len(l1) - 1, 4):
+                o.write(b"\n".join(l1[i:i + 4]) + b"\n" + b"\n".join(l2[i:i + 4]) + b"\n")
+        args = ["-int", str(tmp_path / "ilv.fq"), "-t_db", prefix]
     ref = str(tmp_path / "ref")
     subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     one2one = str(tmp_path / "ref1")
