@@ -152,6 +152,7 @@ static void usage(void) {
 	fprintf(stderr, "usage: kmahip_map (-i reads.fq[.gz] | -ipe r1.fq[.gz] r2.fq[.gz] [-apm p|u] | -int interleaved.fq[.gz] [-apm p|u]) -t_db <index prefix> -o <output prefix> [-1t1] [-Mt1 <template>] [-bcNano] [-bc90] [-bc <support>] [-bcg] [-ref_fsa [n]] [-dense]\n"
 	                "       [-t threads] [-nc] [-na] [-nf] [-mf fragments] [-ml len] [-xl len] [-mp phred] [-mi phred] [-eq q] [-mq q] [-ts bases] [-mrs f] [-mrc f] [-mct f]\n"
 	                "       [-e evalue] [-bcd depth] [-ID id] [-md depth] [-ex_mode] [-gpus N]\n"
+	                "       [-reward n] [-gapopen n] [-gapextend n] [-localopen n] [-Npenalty n] [-per n] [-transition n] [-transversion n] [-penalty n] [-cge]\n"
 	                "(the options of kma 1.5.1 this path implements; -apm takes p or u; everything else is refused)\n");
 }
 
@@ -227,6 +228,7 @@ static int launch_ranks(int gpus, char **argv) {
 
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
+	int Ts = -2, Tv = -2;          /* -transition / -transversion (kma.c:335-336) */
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
 	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
 	double support = 0;
@@ -290,10 +292,33 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-ID")) ID_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-md")) Depth_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-ex_mode")) par.exhaustive = 1;
+		/* the scoring scheme (kma.c:821-915, 1024-1030): signs are forced like the reference's; -penalty is read and then overwritten
+		 * by the mean of -transition and -transversion below, as there (kma.c:1308) */
+		else if(!strcmp(o, "-reward")) par.rw.M = abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-penalty")) (void) need_int(argc, argv, &a, o);
+		else if(!strcmp(o, "-gapopen")) par.rw.W1 = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-gapextend")) par.rw.U = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-localopen")) par.rw.Wl = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-Npenalty")) par.rw.Mn = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-per")) par.rw.PE = abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-transition")) Ts = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-transversion")) Tv = -abs((int) need_int(argc, argv, &a, o));
+		else if(!strcmp(o, "-cge")) { par.scoreT = 0.5; cp.mrs = 0.5; par.rw.M = 1; par.rw.W1 = -5; par.rw.U = -1; par.rw.PE = 17; }      /* (its MM = -3 does not survive kma.c:1308) */
 		else if(!strcmp(o, "-gpus")) gpus = (int) need_int(argc, argv, &a, o);
 		else { fprintf(stderr, "kmahip_map: option %s is not one this program implements\n", o); usage(); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe / -int), -t_db and -o are required\n"); usage(); return 2; }
+	{	/* the substitution matrix (kma.c:1307-1328) */
+		par.rw.MM = (Ts + Tv - 1) / 2;
+		for(int i = 0; i < 4; ++i) {
+			for(int j = 0; j < 4; ++j) par.rw.d[i][j] = Tv;
+			par.rw.d[i][4] = par.rw.Mn;
+			par.rw.d[i][i ^ 2] = Ts;
+			par.rw.d[i][i] = par.rw.M;
+		}
+		for(int j = 0; j < 5; ++j) par.rw.d[4][j] = par.rw.Mn;
+		par.rw.d[4][4] = 0;
+	}
 	if(ref_fsa == 1) base_call = base_call == 1 ? 4 : 3;      /* kma.c:1278-1284: refNanoCaller / refCaller */
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;

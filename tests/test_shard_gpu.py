@@ -295,6 +295,48 @@ def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, a
     _same_files(ref, str(tmp_path / "ranks"))
 
 
+SCHEMES = {
+    "cge": ["-cge"],                                                                                  # kma.c:1024-1030 (what CGE's tools pass)
+    "own": ["-reward", "2", "-penalty", "7", "-gapopen", "5", "-gapextend", "2", "-transition", "1", "-transversion", "4", "-localopen", "8",
+            "-Npenalty", "1", "-per", "9"],
+}
+
+
+@pytest.mark.parametrize("scheme", sorted(SCHEMES))
+def test_scoring_scheme_options_equal_the_reference(tmp_path, scheme):
+    """-reward / -gapopen / -gapextend / -localopen / -Npenalty / -per / -transition / -transversion and the -cge preset (kma.c:821-915,
+    1024-1030; -penalty is parsed and then replaced by the mean of transition and transversion, kma.c:1308): every stage reads its
+    scores from kmahip_params.rw, so the files must be the reference's under another scheme too -- -1t1, the default mode on reads
+    that map in pieces, couples with the pairing reward, and -Mt1."""
+    import sys
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import _chimeric_reads
+    opts = SCHEMES[scheme]
+    (tmp_path / "se").mkdir(); (tmp_path / "pe").mkdir(); (tmp_path / "ch").mkdir()
+    prefix, fq = _case(tmp_path / "se", n=6000)
+    pprefix, r1, r2 = _pe_case(tmp_path / "pe", n_pairs=4000, chimeras=True)
+    rng = np.random.default_rng(31)
+    names, seqs = synth.make_gene_db(40, 5, 300, 900, 0.05, seed=912)
+    cprefix = str(tmp_path / "ch" / "db")
+    formats.write_index(cprefix, names, seqs)
+    cfq = str(tmp_path / "ch" / "r.fq")
+    synth.write_fastq(cfq, _chimeric_reads(seqs, 5000, rng, with_n=True))
+    cases = [["-i", fq, "-t_db", prefix, "-1t1"], ["-i", cfq, "-t_db", cprefix], ["-ipe", r1, r2, "-t_db", pprefix, "-apm", "p", "-1t1"],
+             ["-ipe", r1, r2, "-t_db", pprefix], ["-i", fq, "-t_db", prefix, "-Mt1", "7", "-bcNano"]]
+    for i, args in enumerate(cases):
+        ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
+        subprocess.run([KMA] + args + opts + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        plain = str(tmp_path / f"plain{i}")
+        subprocess.run([KMA] + args + ["-o", plain, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if scheme == "own":
+            assert gzip.open(ref + ".frag.gz").read() != gzip.open(plain + ".frag.gz").read(), args      # (the scheme shows in the files)
+        _run(args + opts + ["-o", got])
+        for ext, opener in ((".res", open), (".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
+            assert opener(got + ext, "rb").read() == opener(ref + ext, "rb").read(), (args, ext)
+
+
 @pytest.mark.parametrize("world,gz,bc", [(2, False, True), (3, True, True), (2, False, False)])
 def test_mt1_over_ranks_writes_the_single_rank_files_and_the_reference_s(tmp_path, world, gz, bc):
     """`-Mt1 1 [-bcNano]` (kmahip_run_mt1_sharded): every rank traces its part of the stream, the kept reads meet at rank 0 with
