@@ -89,6 +89,7 @@ static void *ingest_main(void *arg) {
  * one before; a batch is handed over (state 1), uploaded by the main thread, and given back (state 0) */
 typedef struct stream_job {
 	const char *in1, *in2;
+	char **list1, **list2; int n_files;      /* (more than one input file: read one after the other, kma.c:370-460 run_input*) */
 	kmahip_trim trim;
 	int64_t batch_reads, batch_bases;
 	kmahip_ingest *ing; kmahip_read_batch b;
@@ -97,13 +98,23 @@ typedef struct stream_job {
 } stream_job;
 static void *stream_main(void *arg) {
 	stream_job *j = (stream_job *) arg;
-	int whole = 0;
+	int whole = 0, file = 0;
 	int rc = kmahip_ingest_open_part(j->in1, j->in2, &j->trim, 0, 1, &j->ing, &whole);
 	if(!rc && j->batch_bases > 0) rc = kmahip_ingest_set_batch_bases(j->ing, j->batch_bases);
 	for(;;) {
 		if(!rc) rc = kmahip_ingest_next(j->ing, j->batch_reads, &j->b);
-		const int end = rc || j->b.reads.n_reads == 0;
+		int end = rc || j->b.reads.n_reads == 0;
 		if(end && !rc) rc = kmahip_ingest_status(j->ing);
+		if(end && !rc && file + 1 < j->n_files) {
+			/* the next file of the list (its own phred scale, like the reference's loop over the files; a batch never spans two files).
+			 * The batch handed over last has been given back (state 0), so nothing points into this reader any more */
+			++file;
+			kmahip_ingest_close(j->ing); j->ing = NULL;
+			rc = kmahip_ingest_open_part(j->list1[file], j->in2 ? (j->in2[0] ? j->list2[file] : "") : NULL, &j->trim, 0, 1, &j->ing, &whole);
+			if(!rc && j->batch_bases > 0) rc = kmahip_ingest_set_batch_bases(j->ing, j->batch_bases);
+			if(!rc) continue;
+			end = 1;
+		}
 		pthread_mutex_lock(&j->mu);
 		if(end) {
 			j->rc = rc;
@@ -229,6 +240,7 @@ static int launch_ranks(int gpus, char **argv) {
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	int Ts = -2, Tv = -2;          /* -transition / -transversion (kma.c:335-336) */
+	char *list1[256], *list2[256]; int n_files = 0;          /* the input files (mate files side by side) */
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
 	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
 	double support = 0;
@@ -261,9 +273,20 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-1t1")) one2one = 1;                                                /* kma.c:686 */
 		else if(!strcmp(o, "-chain")) chain = 1;                                                /* (our own: the same as leaving -1t1 out) */
 		else if(!strcmp(o, "-t_db") && a + 1 < argc) prefix = argv[++a];
-		else if(!strcmp(o, "-i") && a + 1 < argc) input = argv[++a];
-		else if(!strcmp(o, "-ipe") && a + 2 < argc) { input = argv[++a]; input2 = argv[++a]; }
-		else if(!strcmp(o, "-int") && a + 1 < argc) { input = argv[++a]; input2 = ""; }          /* interleaved: the paired reader on one file (kmahip_ingest_open_part with path2 = "") */
+		else if(!strcmp(o, "-i") || !strcmp(o, "-int") || !strcmp(o, "-ipe")) {                 /* kma.c:371-435: each takes a list of files */
+			const int pe = o[2] == 'p';
+			if(n_files) { fprintf(stderr, "kmahip_map: one of -i, -ipe and -int, once\n"); return 2; }
+			while(a + 1 < argc && argv[a + 1][0] != '-' && n_files < 256) {
+				list1[n_files] = argv[++a]; list2[n_files] = NULL;
+				if(pe) {
+					if(!(a + 1 < argc && argv[a + 1][0] != '-')) { fprintf(stderr, "Uneven number of paired end files.\n"); return 1; }
+					list2[n_files] = argv[++a];
+				}
+				++n_files;
+			}
+			if(!n_files) { fprintf(stderr, "kmahip_map: %s needs a file\n", o); return 1; }
+			input = list1[0]; input2 = pe ? list2[0] : (o[2] == 'n' ? "" : NULL);      /* interleaved: the paired reader on one file (kmahip_ingest_open_part with path2 = "") */
+		}
 		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
 			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) or u (union, save_kmers_unionPair / alnFragsUnionPE); f is not built\n"); return 1; }
@@ -384,6 +407,7 @@ int main(int argc, char **argv) {
 		stream_job sj;
 		memset(&sj, 0, sizeof sj);
 		sj.in1 = input; sj.in2 = input2; sj.trim = trim;
+		sj.list1 = list1; sj.list2 = list2; sj.n_files = n_files;
 		sj.batch_reads = getenv("KMAHIP_MAP_BATCH") ? atoll(getenv("KMAHIP_MAP_BATCH")) : 1000000;
 		if(sj.batch_reads < 1) sj.batch_reads = 1;
 		sj.batch_bases = getenv("KMAHIP_MAP_BATCH_BASES") ? atoll(getenv("KMAHIP_MAP_BATCH_BASES")) : (256ll << 20);
@@ -400,8 +424,10 @@ int main(int argc, char **argv) {
 		int64_t hint = 0;
 		{	/* (a guess at the number of reads from the size of the input: it only sizes the first allocation) */
 			struct stat sb;
-			const size_t il = strlen(input);
-			if(stat(input, &sb) == 0) hint = (int64_t) (sb.st_size / (il > 3 && !strcmp(input + il - 3, ".gz") ? 60 : 300));
+			for(int f = 0; f < n_files; ++f) {
+				const size_t il = strlen(list1[f]);
+				if(stat(list1[f], &sb) == 0) hint += (int64_t) (sb.st_size / (il > 3 && !strcmp(list1[f] + il - 3, ".gz") ? 60 : 300));
+			}
 		}
 		kmahip_session *ses;
 		char mt1_frag[4096];
@@ -456,6 +482,7 @@ int main(int argc, char **argv) {
 		}
 		finish(0);
 	}
+	if(n_files > 1) { fprintf(stderr, "kmahip_map: several input files are read batch by batch on one rank (not with -gpus, KMAHIP_MAP_ONE_BATCH or KMAHIP_COMM_FORCE_RCCL)\n"); finish(2); }
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */
 	ingest_job job;
 	memset(&job, 0, sizeof job);

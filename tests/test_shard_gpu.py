@@ -128,6 +128,8 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-bcNano"],                       # C4's switches
         ["-i", fq, "-t_db", prefix, "-t", "2"],                                    # the default mode
         ["-ipe", r1, r2, "-t_db", prefix, "-t", "1"],                              # ... with paired input (single records through the chain finder)
+        ["-i", fq, r1, r2, "-t_db", prefix, "-1t1", "-t", "1"],                    # lists of files (kma.c:371-435), read one after the other
+        ["-ipe", r1, r2, r2, r1, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],
     ]
     for i, args in enumerate(cases):
         ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
