@@ -240,6 +240,7 @@ static int launch_ranks(int gpus, char **argv) {
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	int Ts = -2, Tv = -2;          /* -transition / -transversion (kma.c:335-336) */
+	int cmp_mode = 0;              /* -and / -oa */
 	char *list1[256], *list2[256]; int n_files = 0;          /* the input files (mate files side by side) */
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
 	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
@@ -315,6 +316,9 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-ID")) ID_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-md")) Depth_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-ex_mode")) par.exhaustive = 1;
+		else if(!strcmp(o, "-and")) cmp_mode = 1;                                               /* kma.c:915-920 */
+		else if(!strcmp(o, "-oa")) { cmp_mode = 2; ID_t = 1e-300; Depth_t = 0.0; }               /* (ID_t = 0 there; a row needs 0 < id anyway, and 0 means "the default" to kmahip_shard_opts) */
+		else if(!strcmp(o, "-5p") || !strcmp(o, "-3p")) (void) need_int(argc, argv, &a, o);     /* parsed and handed to run_input*, where nothing reads them (runinput.c:127-368: phredStat never touches fiveClip / threeClip) */
 		/* the scoring scheme (kma.c:821-915, 1024-1030): signs are forced like the reference's; -penalty is read and then overwritten
 		 * by the mean of -transition and -transversion below, as there (kma.c:1308) */
 		else if(!strcmp(o, "-reward")) par.rw.M = abs((int) need_int(argc, argv, &a, o));
@@ -331,6 +335,7 @@ int main(int argc, char **argv) {
 		else { fprintf(stderr, "kmahip_map: option %s is not one this program implements\n", o); usage(); return 2; }
 	}
 	if(!prefix || !input || !out) { fprintf(stderr, "kmahip_map: -i (or -ipe / -int), -t_db and -o are required\n"); usage(); return 2; }
+	if(kmahip_set_cmp(cmp_mode)) { fprintf(stderr, "kmahip_map: %s\n", kmahip_last_error()); return 1; }
 	{	/* the substitution matrix (kma.c:1307-1328) */
 		par.rw.MM = (Ts + Tv - 1) / 2;
 		for(int i = 0; i < 4; ++i) {

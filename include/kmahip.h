@@ -268,6 +268,10 @@ typedef struct kmahip_res_row {
 	double q_value;
 	double p_value;
 } kmahip_res_row;
+/* How a template's p-value test and its score test combine into `significant` -- the reference's `cmp` pointer (stdstat.c:23-35,
+ * kma.c:915-920): 0 = or (default), 1 = and (`-and`), 2 = always true (`-oa`, which also sets -ID and -md to 0). One setting per
+ * process, read by kmahip_res_rows and by every run entry point (runkma.c:783, mt1.c:419). */
+int kmahip_set_cmp(int mode);
 int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
                     kmahip_res_row *rows, int64_t cap, int64_t *n_rows);
 

@@ -148,6 +148,16 @@ static int launch_conclave(kmahip_db *db, const CCArgs &A0, const kmahip_hits *h
 	return KMAHIP_OK;
 }
 
+// the reference's `cmp` (stdstat.c:23-35): how the p-value test and the score test of a template combine -- or (default), and
+// (`-and`), always true (`-oa`); one setting per process, like the reference's function pointer
+static int g_cmp_mode = 0;
+int kmahip_cmp(bool t, bool q) { return g_cmp_mode == 0 ? (t || q) : (g_cmp_mode == 1 ? (t && q) : 1); }
+extern "C" int kmahip_set_cmp(int mode) {
+	if(mode < 0 || mode > 2) { kmahip_set_error("cmp mode %d (0 = or, 1 = and, 2 = true)", mode); return KMAHIP_EINVAL; }
+	g_cmp_mode = mode;
+	return KMAHIP_OK;
+}
+
 extern "C" int kmahip_conclave_se_dev(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands,
                                       const kmahip_hits *hits, kmahip_conclave *out, void *stream) {
 	(void) ws;
@@ -334,7 +344,7 @@ extern "C" int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, do
 			kmahip_res_row &r = rows[n];
 			r.template_id = t; r.template_length = t_len; r.score = w_scores[t];
 			r.expected = (unsigned) expected; r.q_value = (double) q_value; r.p_value = p_value;
-			r.significant = ((p_value <= evalue && read_score > expected) || (read_score >= scoreT * t_len)) ? 1 : 0;
+			r.significant = kmahip_cmp(p_value <= evalue && read_score > expected, read_score >= scoreT * t_len);
 		}
 		++n;
 	}

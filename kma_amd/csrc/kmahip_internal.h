@@ -147,6 +147,7 @@ struct kmahip_ws {
 struct KmaAnk { int score, weight, score_len, len_len; unsigned start, end; uint32_t values; int descend; };
 
 void kmahip_set_error(const char *fmt, ...);
+int kmahip_cmp(bool t, bool q);          // conclave.hip: the reference's `cmp` (or / and / true, kmahip_set_cmp)
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if(e__ != hipSuccess) { \
 	kmahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return KMAHIP_EDEVICE; } } while(0)
 

@@ -1124,7 +1124,7 @@ extern "C" int kmahip_run_mt1(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *
 	kmahip_res_row &row = out->rows[0];
 	row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
 	row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
-	row.significant = ((row.p_value <= aopts->evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+	row.significant = kmahip_cmp(row.p_value <= aopts->evalue && score > 0, (double) score >= p->scoreT * t_len);     // mt1.c:419
 	out->n_rows = 1;
 	out->ms[2] = since(t);
 	kmahip_assemble_opts ao = *aopts;
@@ -1824,7 +1824,7 @@ extern "C" int kmahip_run_mt1_sharded(kmahip_db *db, kmahip_ws *ws, kmahip_comm 
 	memset(&row, 0, sizeof row);
 	row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
 	row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
-	row.significant = ((row.p_value <= opts->evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+	row.significant = kmahip_cmp(row.p_value <= opts->evalue && score > 0, (double) score >= p->scoreT * t_len);     // mt1.c:419
 	std::vector<uint64_t> frag_counts(D, 0);
 	frag_counts[(size_t) tmpl] = h_sums[1];
 	ms[2] = since(t);

@@ -855,7 +855,7 @@ extern "C" int kmahip_session_finish(kmahip_session *S, const char *out_prefix, 
 		memset(&row, 0, sizeof row);
 		row.template_id = tmpl; row.template_length = t_len; row.score = score; row.expected = 0;
 		row.q_value = (double) score; row.p_value = kmahip_p_chisqr((long double) score);
-		row.significant = ((row.p_value <= S->opts.evalue && score > 0) || (double) score >= p->scoreT * t_len) ? 1 : 0;     // mt1.c:434 (cmp = cmp_or)
+		row.significant = kmahip_cmp(row.p_value <= S->opts.evalue && score > 0, (double) score >= p->scoreT * t_len);     // mt1.c:419
 		ms[2] = since(t);
 		kmahip_traces tr{};
 		tr.stats = S->t_stats.as<int32_t>(); tr.ops_off = S->t_off.as<int64_t>(); tr.n_ops = S->t_nops.as<int32_t>(); tr.ops = S->t_pool.as<uint32_t>(); tr.ops_cap = (int64_t) (S->t_pool.cap / 4);

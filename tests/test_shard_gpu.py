@@ -129,6 +129,9 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         ["-i", fq, "-t_db", prefix, "-t", "2"],                                    # the default mode
         ["-ipe", r1, r2, "-t_db", prefix, "-t", "1"],                              # ... with paired input (single records through the chain finder)
         ["-i", fq, r1, r2, "-t_db", prefix, "-1t1", "-t", "1"],                    # lists of files (kma.c:371-435), read one after the other
+        ["-i", fq, "-t_db", prefix, "-1t1", "-and"],                               # p-value AND score decide a template (kma.c:915: two thirds of the rows go)
+        ["-i", fq, "-t_db", prefix, "-1t1", "-oa", "-5p", "3", "-3p", "2"],        # ... neither does; -5p / -3p are read and never used (runinput.c:127)
+        ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-and"],
         ["-ipe", r1, r2, r2, r1, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],
     ]
     for i, args in enumerate(cases):
