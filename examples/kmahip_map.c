@@ -66,9 +66,34 @@ static double peak_rss_mb(void) {
 	return mb;
 }
 
+/* -Mt1 with paired input (printFsa_pairMt1, mt1.c:61-83): the mates of a couple are two records of their own, the second one reverse
+ * complemented (strrc on the bases: an N stays an N) -- done here on the packed batch, in the reader's own arrays: 32 bases per word from
+ * the top bits down, N packed as A with its position listed, the bits behind the last base zero */
+static void rc_second_mates(kmahip_read_batch *b) {
+	uint64_t *seq = (uint64_t *) b->reads.seq;
+	int32_t *N = (int32_t *) b->reads.N;
+	for(int64_t r = 0; r < b->reads.n_reads; ++r) {
+		if(b->pair[r] != 2) continue;
+		uint64_t *w = seq + b->reads.seq_off[r];
+		const int L = b->reads.len[r], nw = (L + 31) >> 5;
+		int32_t *n = N + b->reads.N_off[r];
+		const int nn = (int) (b->reads.N_off[r + 1] - b->reads.N_off[r]);
+		for(int i = 0, j = L - 1; i < j; ++i, --j) {          /* swap and complement base by base (reads are short here; this is not the hot path) */
+			const int si = 62 - ((i & 31) << 1), sj = 62 - ((j & 31) << 1);
+			const uint64_t bi = (w[i >> 5] >> si) & 3u, bj = (w[j >> 5] >> sj) & 3u;
+			w[i >> 5] = (w[i >> 5] & ~(3ull << si)) | ((3u - bj) << si);
+			w[j >> 5] = (w[j >> 5] & ~(3ull << sj)) | ((3u - bi) << sj);
+		}
+		if(L & 1) { const int m = L >> 1, sm = 62 - ((m & 31) << 1); w[m >> 5] ^= 3ull << sm; }
+		(void) nw;
+		for(int x = 0, y = nn - 1; x <= y; ++x, --y) { const int32_t a = L - 1 - n[y], c = L - 1 - n[x]; n[x] = a; n[y] = c; }
+		for(int x = 0; x < nn; ++x) { const int q = n[x], sq = 62 - ((q & 31) << 1); w[q >> 5] &= ~(3ull << sq); }      /* N packed as A */
+	}
+}
+
 /* stage 1 on a thread of its own, beside HIP start-up and the loading of the index */
 typedef struct ingest_job {
-	const char *in1, *in2;
+	const char *in1, *in2; int rc_mates;
 	kmahip_trim trim;
 	int part, parts, whole_input;
 	kmahip_ingest *ing; kmahip_read_batch b; int rc; char err[512]; double t_done;
@@ -77,6 +102,7 @@ static void *ingest_main(void *arg) {
 	ingest_job *j = (ingest_job *) arg;
 	j->rc = kmahip_ingest_open_part(j->in1, j->in2, &j->trim, j->part, j->parts, &j->ing, &j->whole_input);
 	if(!j->rc) j->rc = kmahip_ingest_next(j->ing, INT64_MAX, &j->b);
+	if(!j->rc && j->rc_mates) rc_second_mates(&j->b);
 	/* the whole input in one batch: an input that breaks off (a truncated .gz, a record that is no FASTQ) delivers what came before
 	 * it; whether it did has to be asked, or the run would end well on half the reads */
 	if(!j->rc) j->rc = kmahip_ingest_status(j->ing);
@@ -88,7 +114,7 @@ static void *ingest_main(void *arg) {
 /* stage 1 batch by batch for the session (single end, -1t1, one rank): the reader parses the next batch while the device works on the
  * one before; a batch is handed over (state 1), uploaded by the main thread, and given back (state 0) */
 typedef struct stream_job {
-	const char *in1, *in2;
+	const char *in1, *in2; int rc_mates;
 	char **list1, **list2; int n_files;      /* (more than one input file: read one after the other, kma.c:370-460 run_input*) */
 	kmahip_trim trim;
 	int64_t batch_reads, batch_bases;
@@ -103,6 +129,7 @@ static void *stream_main(void *arg) {
 	if(!rc && j->batch_bases > 0) rc = kmahip_ingest_set_batch_bases(j->ing, j->batch_bases);
 	for(;;) {
 		if(!rc) rc = kmahip_ingest_next(j->ing, j->batch_reads, &j->b);
+		if(!rc && j->rc_mates) rc_second_mates(&j->b);
 		int end = rc || j->b.reads.n_reads == 0;
 		if(end && !rc) rc = kmahip_ingest_status(j->ing);
 		if(end && !rc && file + 1 < j->n_files) {
@@ -357,7 +384,10 @@ int main(int argc, char **argv) {
 	/* -mrc in the default mode: mrchain (kmeranker.c:57-81) only drops templates when q_len < mrc * (the chain's span on the read), which
 	 * no mrc <= 1 can make true -- stage 2 is as without it, the coverage test of stages 3a / 3c (mrcheck) is the aligner's own */
 	if((chain || pe_chain) && par.mrc > 1.0) { fprintf(stderr, "kmahip_map: -mrc above 1 needs -1t1 (the chain finder's mrchain filter is not built)\n"); return 2; }
-	if(mt1 && input2) { fprintf(stderr, "kmahip_map: -Mt1 with -ipe is not supported\n"); return 2; }
+	/* -Mt1 with paired input: the reader is the paired one, the run is the single-end -Mt1 run over records of their own */
+	const char *reader2 = input2;
+	const int rc_mates = mt1 && input2;
+	if(mt1) input2 = NULL;
 	if(threads) {
 		char v[16];
 		snprintf(v, sizeof v, "%d", threads);
@@ -411,7 +441,7 @@ int main(int argc, char **argv) {
 		 * whichever comes first */
 		stream_job sj;
 		memset(&sj, 0, sizeof sj);
-		sj.in1 = input; sj.in2 = input2; sj.trim = trim;
+		sj.in1 = input; sj.in2 = reader2; sj.rc_mates = rc_mates; sj.trim = trim;
 		sj.list1 = list1; sj.list2 = list2; sj.n_files = n_files;
 		sj.batch_reads = getenv("KMAHIP_MAP_BATCH") ? atoll(getenv("KMAHIP_MAP_BATCH")) : 1000000;
 		if(sj.batch_reads < 1) sj.batch_reads = 1;
@@ -437,7 +467,7 @@ int main(int argc, char **argv) {
 		kmahip_session *ses;
 		char mt1_frag[4096];
 		snprintf(mt1_frag, sizeof mt1_frag, "%s.frag.gz", out);
-		if(input2) hint *= 2;
+		if(reader2) hint *= 2;
 		if(kmahip_session_open(db, ws, &par, &so, hint, &ses) || (chain && kmahip_session_set_chain(ses, &cp)) || (mt1 && kmahip_session_set_mt1(ses, mt1, one2one, no_frag ? NULL : mt1_frag)) ||
 		   (input2 && kmahip_session_set_pe(ses))) die("session");
 		int batches = 0;
@@ -491,7 +521,7 @@ int main(int argc, char **argv) {
 	/* stage 1: this rank's part of the input as one batch (the arrays stay owned by the reader), while the device and the index come up */
 	ingest_job job;
 	memset(&job, 0, sizeof job);
-	job.in1 = input; job.in2 = input2; job.trim = trim; job.part = rank; job.parts = world;
+	job.in1 = input; job.in2 = reader2; job.rc_mates = rc_mates; job.trim = trim; job.part = rank; job.parts = world;
 	pthread_t ingest_thread;
 	if(pthread_create(&ingest_thread, NULL, ingest_main, &job)) fail("cannot start a thread");
 

@@ -300,6 +300,25 @@ def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, a
     _same_files(ref, str(tmp_path / "ranks"))
 
 
+def test_mt1_with_paired_input_equals_the_reference(tmp_path):
+    """`-Mt1 n -ipe r1 r2` (printFsa_pairMt1, mt1.c:61-83): the mates of a couple are records of their own, the second one reverse
+    complemented; a mate that lost its partner to the trimming is a record as it is. One batch, batch by batch, three ranks."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    prefix, r1, r2 = _pe_case(tmp_path, n_pairs=4000, chimeras=True)
+    args = ["-ipe", r1, r2, "-t_db", prefix, "-Mt1", "12", "-bcNano"]
+    ref = str(tmp_path / "ref")
+    subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert gzip.open(ref + ".frag.gz").read().count(b"\n") > 100
+    for name, pre, env in (("one", [], {"KMAHIP_MAP_ONE_BATCH": "1"}), ("many", [], {"KMAHIP_MAP_BATCH": "777"}),
+                           ("ranks", ["-gpus", "3"], {"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})):
+        got = str(tmp_path / name)
+        _run(pre + args + ["-o", got], env=env)
+        for ext, opener in ((".res", open), (".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
+            assert opener(got + ext, "rb").read() == opener(ref + ext, "rb").read(), (name, ext)
+
+
 SCHEMES = {
     "cge": ["-cge"],                                                                                  # kma.c:1024-1030 (what CGE's tools pass)
     "own": ["-reward", "2", "-penalty", "7", "-gapopen", "5", "-gapextend", "2", "-transition", "1", "-transversion", "4", "-localopen", "8",
