@@ -268,6 +268,7 @@ int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	int Ts = -2, Tv = -2;          /* -transition / -transversion (kma.c:335-336) */
 	int cmp_mode = 0;              /* -and / -oa */
+	int pm = 0, fpm = 0;           /* -pm / -fpm (1 p, 2 u; 0: not given) */
 	char *list1[256], *list2[256]; int n_files = 0;          /* the input files (mate files side by side) */
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
 	int base_call = 0, sig_mode = 0, ref_fsa = 0, dense = 0;      /* as kmahip_assemble_opts.caller (0-2 here) / .sig90; printconsensus.c's ref_fsa */
@@ -319,6 +320,11 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
 			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) or u (union, save_kmers_unionPair / alnFragsUnionPE); f is not built\n"); return 1; }
 			apm = argv[++a][0] == 'p' ? 1 : 2;
+			pm = fpm = 0;
+		}
+		else if(!strcmp(o, "-pm") || !strcmp(o, "-fpm")) {                                      /* kma.c:437-465: the two stages apart */
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: %s takes p or u; f is not built\n", o); return 1; }
+			if(o[1] == 'p') pm = argv[++a][0] == 'p' ? 1 : 2; else fpm = argv[++a][0] == 'p' ? 1 : 2;
 		}
 		else if(!strcmp(o, "-t")) {                                                             /* kma.c:529: a value is optional */
 			if(a + 1 < argc && argv[a + 1][0] != '-') threads = (int) need_int(argc, argv, &a, o);
@@ -377,7 +383,12 @@ int main(int argc, char **argv) {
 	if(ref_fsa == 1) base_call = base_call == 1 ? 4 : 3;      /* kma.c:1278-1284: refNanoCaller / refCaller */
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
-	par.apm = apm == 1 ? 0 : 1;          /* (without -apm the reference pairs by union, kma.c:206) */
+	{	/* (without -apm the reference pairs by union, kma.c:206; -apm sets both stages, -pm stage 2 and -fpm stage 3a alone) */
+		int s2 = apm == 1 ? 0 : 1, s3 = s2;
+		if(pm) s2 = pm == 1 ? 0 : 1;
+		if(fpm) s3 = fpm == 1 ? 0 : 1;
+		par.apm = s2 | ((s3 + 1) << 4);          /* kmahip_params.apm: bits 0-1 stage 2, bits 4-5 stage 3a + 1 */
+	}
 	/* paired input without -1t1: couples are paired as ever, a record that lost its mate goes to the chain finder (savekmers.c:196-200) */
 	const int pe_chain = chain && input2;
 	if(pe_chain) chain = 0;

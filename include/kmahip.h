@@ -73,7 +73,9 @@ typedef struct kmahip_params {
 	                       * has no such step); at least one base of a seed remains */
 	int32_t apm;          /* paired reads: 0 = the pairing penalty of -apm p (save_kmers_penaltyPair savekmers.c:3572, alnFragsPenaltyPE
 	                       * alnfrags.c:1596), 1 = union, -apm u and what `-ipe` means without -apm (kma.c:206: save_kmers_unionPair
-	                       * savekmers.c:3367 with getF_Best / getR_Best, alnFragsUnionPE alnfrags.c:1220) */
+	                       * savekmers.c:3367 with getF_Best / getR_Best, alnFragsUnionPE alnfrags.c:1220). The reference can set the two
+	                       * stages apart (-pm x: save_kmers_pair only, -fpm x: alnFragsPE only, kma.c:437-465): bits 0-1 = stage 2 as
+	                       * above, bits 4-5 = stage 3a + 1 (0: the same as stage 2, 1: p, 2: u) */
 } kmahip_params;
 
 typedef struct kmahip_db_info {

@@ -2973,7 +2973,7 @@ static int launch_align(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads,
 	R.h_tmpl = out->tmpl; R.h_score = out->score; R.h_start = out->start; R.h_end = out->end;
 	R.alignment_scores = (unsigned long long *) out->alignment_scores;
 	R.uniq_alignment_scores = (unsigned long long *) out->uniq_alignment_scores;
-	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.apm = p->apm; R.pe_kind = pe_kind;
+	R.rec_mate = rec_mate; R.rec_rc = rec_rc; R.out_rc = out->rc; R.pe_mode = rec_mate != nullptr; R.PE = p->rw.PE; R.apm = ((p->apm >> 4) & 3) ? ((p->apm >> 4) & 3) - 1 : (p->apm & 3); R.pe_kind = pe_kind;
 	R.priv = nullptr; R.priv_copies = 0; R.DB_size = db->info.DB_size; R.tasks_cap = tasks_cap;
 	if(out->alignment_scores || out->uniq_alignment_scores) {
 		const int64_t D = db->info.DB_size;

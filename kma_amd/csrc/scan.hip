@@ -1844,7 +1844,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	P.ppool = ws->ppool; P.ppool_cap = 2 * ws->pool_cap;
 	P.r_mate = out->mate; P.r_rc = out->rc; P.r_score = out->rc_flag; P.r_flag = out->flag;
 	P.r_off = (int64_t *) ws->pe_rec; P.r_n = (int32_t *) (P.r_off + ws->cap_reads + 2);
-	if(p->apm == 1) hipLaunchKernelGGL(pair_union_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
+	if((p->apm & 3) == 1) hipLaunchKernelGGL(pair_union_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
 	else hipLaunchKernelGGL(pair_penalty_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
 	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
 	hipLaunchKernelGGL(rec_count_kernel, dim3(cgrid), dim3(CB), 0, stream, P.r_n, n, ws->blk_sums);

@@ -133,6 +133,9 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
         ["-i", fq, "-t_db", prefix, "-1t1", "-oa", "-5p", "3", "-3p", "2"],        # ... neither does; -5p / -3p are read and never used (runinput.c:127)
         ["-i", fq, "-t_db", prefix, "-Mt1", "3", "-and"],
         ["-ipe", r1, r2, r2, r1, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],
+        ["-ipe", r1, r2, "-t_db", prefix, "-pm", "p", "-1t1", "-t", "1"],         # the stages' pairing set apart (kma.c:437-465): penalty in stage 2, union in 3a
+        ["-ipe", r1, r2, "-t_db", prefix, "-apm", "p", "-pm", "u", "-1t1", "-t", "1"],
+        ["-ipe", r1, r2, "-t_db", prefix, "-fpm", "p", "-t", "1"],
     ]
     for i, args in enumerate(cases):
         ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
@@ -298,6 +301,25 @@ def test_paired_input_in_the_default_mode_writes_the_reference_files(tmp_path, a
     _same_files(ref, str(tmp_path / "many"))
     _run(["-gpus", "3"] + args + ["-o", str(tmp_path / "ranks")], env={"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})
     _same_files(ref, str(tmp_path / "ranks"))
+
+
+def test_pairing_of_the_two_stages_set_apart(tmp_path):
+    """-pm x sets save_kmers_pair alone, -fpm x alnFragsPE alone (kma.c:437-465; kmahip_params.apm bits 0-1 / 4-5): couples, foreign
+    mates, singly filed mates and indels through the penalty pairing in one stage and the union in the other -- the reference's
+    four combinations give four different `.res` files on this input, and ours must be those"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    prefix, r1, r2 = _pe_case(tmp_path, n_pairs=3000, chimeras=True)
+    seen = set()
+    for i, opts in enumerate((["-pm", "p"], ["-fpm", "p"], ["-apm", "p", "-pm", "u"], ["-pm", "u", "-fpm", "u"])):
+        args = ["-ipe", r1, r2, "-t_db", prefix, "-1t1"] + opts
+        ref, got = str(tmp_path / f"ref{i}"), str(tmp_path / f"got{i}")
+        subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _run(args + ["-o", got])
+        _same_files(ref, got)
+        seen.add(open(ref + ".res", "rb").read())
+    assert len(seen) >= 3
 
 
 def test_mt1_with_paired_input_equals_the_reference(tmp_path):
