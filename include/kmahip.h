@@ -274,6 +274,10 @@ typedef struct kmahip_res_row {
  * kma.c:915-920): 0 = or (default), 1 = and (`-and`), 2 = always true (`-oa`, which also sets -ID and -md to 0). One setting per
  * process, read by kmahip_res_rows and by every run entry point (runkma.c:783, mt1.c:419). */
 int kmahip_set_cmp(int mode);
+/* `-lc` outside the chain finder: ConClavePtr = runConClave_lc (kma.c:694-701, conclave.c:215-385) -- among a read's equally good
+ * templates the ConClave score per template base decides before the score itself. One setting per process; every ConClave entry
+ * point reads it. (The chain finder's length-corrected helpers, kmeranker.c:37-55, 432-510, are not built: -lc needs -1t1.) */
+int kmahip_set_conclave_lc(int on);
 int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
                     kmahip_res_row *rows, int64_t cap, int64_t *n_rows);
 

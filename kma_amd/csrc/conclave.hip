@@ -9,6 +9,10 @@
 
 namespace {
 
+// -lc (kma.c:694-701) points ConClavePtr to runConClave_lc: one setting per process, like the reference's function pointer
+static int g_conclave_lc = 0;
+extern "C" int kmahip_set_conclave_lc(int on) { g_conclave_lc = on != 0; return KMAHIP_OK; }
+
 struct CCArgs {
 	int64_t n_slots;             // SE: reads; PE: 2 * pairs (record slots in stream order)
 	int pe;                      // 0: one slot per single-end read; 1: record slots of kmahip_align_pe_dev; 2: explicit records
@@ -21,6 +25,7 @@ struct CCArgs {
 	const int32_t *h_tmpl, *h_start, *h_end;
 	const uint64_t *as, *us;     // alignment_scores, uniq_alignment_scores
 	const int32_t *tlen;
+	int lc;                      // -lc: runConClave_lc's order of the tests
 	int32_t *o_tmpl, *o_start, *o_end;
 	unsigned long long *w_scores, *depth;
 	uint32_t *frag_counts, *read_counts;
@@ -87,10 +92,15 @@ __global__ __launch_bounds__(256) void conclave_kernel(const CCArgs A) {
 				const uint64_t a = A.as[t], u = A.us[t];
 				const double sc = 1.0 * (double) a / (double) A.tlen[t];
 				bool take = false;
-				if(a > (uint64_t) (int64_t) best_read_score) take = true;
-				else if(a == (uint64_t) (int64_t) best_read_score) {
-					if(sc > best_score) take = true;
-					else if(sc == best_score) {
+				// (-lc, runConClave_lc conclave.c:215-385: the score per template base decides before the score itself)
+				const bool first_gt = A.lc ? sc > best_score : a > (uint64_t) (int64_t) best_read_score;
+				const bool first_eq = A.lc ? sc == best_score : a == (uint64_t) (int64_t) best_read_score;
+				const bool second_gt = A.lc ? a > (uint64_t) (int64_t) best_read_score : sc > best_score;
+				const bool second_eq = A.lc ? a == (uint64_t) (int64_t) best_read_score : sc == best_score;
+				if(first_gt) take = true;
+				else if(first_eq) {
+					if(second_gt) take = true;
+					else if(second_eq) {
 						if(u > (uint64_t) (int64_t) best_num) take = true;
 						else if(u == (uint64_t) (int64_t) best_num && t < abs(best_tmpl)) take = true;
 					}
@@ -138,7 +148,7 @@ static int launch_conclave(kmahip_db *db, const CCArgs &A0, const kmahip_hits *h
 	if(!db->dev.tlen) { kmahip_set_error("index has no .length.b: stage 3b unavailable"); return KMAHIP_EINVAL; }
 	CCArgs A = A0;
 	A.n_hits = hits->n_hits; A.best_score = hits->best_score; A.h_tmpl = hits->tmpl; A.h_start = hits->start; A.h_end = hits->end;
-	A.as = hits->alignment_scores; A.us = hits->uniq_alignment_scores; A.tlen = db->dev.tlen;
+	A.as = hits->alignment_scores; A.us = hits->uniq_alignment_scores; A.tlen = db->dev.tlen; A.lc = g_conclave_lc;
 	A.o_tmpl = out->tmpl; A.o_start = out->start; A.o_end = out->end;
 	A.w_scores = (unsigned long long *) out->w_scores; A.depth = (unsigned long long *) out->depth;
 	A.frag_counts = out->fragment_counts; A.read_counts = out->read_counts;

@@ -322,6 +322,47 @@ def test_pairing_of_the_two_stages_set_apart(tmp_path):
     assert len(seen) >= 3
 
 
+def test_lc_with_1t1_equals_the_reference(tmp_path):
+    """-lc outside the chain finder = runConClave_lc (conclave.c:215-385): among a read's tied templates the ConClave score per
+    template base decides before the score itself. Genes with a half-length copy as a template of its own and twice the reads on
+    that half: without -lc no read goes to a half, with -lc the halves take theirs (twenty more rows in the `.res`)."""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(20, 3, 600, 1200, 0.05, seed=5)
+    names, seqs = list(names), list(seqs)
+    rng = np.random.default_rng(3)
+    n_genes = len(seqs)
+    for g in range(0, n_genes, 3):
+        names.append(names[g] + "_half")
+        seqs.append(seqs[g][:len(seqs[g]) // 2].copy())
+    prefix = str(tmp_path / "db")
+    formats.write_index(prefix, names, seqs)
+    reads = []
+    for g in range(n_genes):
+        L = len(seqs[g])
+        for _ in range(L // 30):
+            a = int(rng.integers(0, L - 150))
+            reads.append(seqs[g][a:a + 150].copy())
+        if g % 3 == 0:
+            for _ in range(L // 30):
+                a = int(rng.integers(0, L // 2 - 150))
+                reads.append(seqs[g][a:a + 150].copy())
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, [reads[i] for i in rng.permutation(len(reads))], prefix="q")
+    res = {}
+    for tag, opts in (("plain", []), ("lc", ["-lc"])):
+        args = ["-i", fq, "-t_db", prefix, "-1t1"] + opts
+        ref, got = str(tmp_path / ("ref" + tag)), str(tmp_path / ("got" + tag))
+        subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _run(args + ["-o", got])
+        for ext, opener in ((".res", open), (".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
+            assert opener(got + ext, "rb").read() == opener(ref + ext, "rb").read(), (tag, ext)
+        res[tag] = open(ref + ".res").read()
+    assert res["plain"].count("_half") == 0 and res["lc"].count("_half") >= 10
+    assert _run(["-i", fq, "-t_db", prefix, "-lc", "-o", str(tmp_path / "x")], ok=False).returncode != 0      # (the chain finder's -lc is not built: refused)
+
+
 def test_mt1_with_paired_input_equals_the_reference(tmp_path):
     """`-Mt1 n -ipe r1 r2` (printFsa_pairMt1, mt1.c:61-83): the mates of a couple are records of their own, the second one reverse
     complemented; a mate that lost its partner to the trimming is a record as it is. One batch, batch by batch, three ranks."""
