@@ -349,6 +349,10 @@ int main(int argc, char **argv) {
 		else if(!strcmp(o, "-ID")) ID_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-md")) Depth_t = need_num(argc, argv, &a, o);
 		else if(!strcmp(o, "-ex_mode")) par.exhaustive = 1;
+		/* switches of the reference that change nothing in its result files: how the index is held (-mmap / -swap, kma.c:526), where its
+		 * temporary files go (-tmp [dir/], kma.c:1031-1050: this program writes none), what it says on stderr (-status, -verbose [n]) */
+		else if(!strcmp(o, "-mmap") || !strcmp(o, "-swap") || !strcmp(o, "-status")) { }
+		else if(!strcmp(o, "-tmp") || !strcmp(o, "-verbose")) { if(a + 1 < argc && argv[a + 1][0] != '-') ++a; }
 		else if(!strcmp(o, "-lc")) lc = 1;                                                      /* kma.c:694-701 */
 		else if(!strcmp(o, "-and")) cmp_mode = 1;                                               /* kma.c:915-920 */
 		else if(!strcmp(o, "-oa")) { cmp_mode = 2; ID_t = 1e-300; Depth_t = 0.0; }               /* (ID_t = 0 there; a row needs 0 < id anyway, and 0 means "the default" to kmahip_shard_opts) */

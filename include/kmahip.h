@@ -453,7 +453,8 @@ int kmahip_chain_unpinned_reads(const int32_t *len, const int32_t *N, const int6
  * made unique there (rocPRIM); grouping, list sharing and the bucket directory are one pass on the host. The files hold the
  * same k-mer -> template-list mapping as the reference's (tests compare the two) and the reference maps against them with
  * identical results; bucket count, key order inside a bucket and list order are the builder's own. FASTA input, plain or .gz.
- * Not covered: -Sparse / prefixes, minimizers (-m), homopolymer compression (-hc), -batch, -deCon, appending (-t_db). */
+ * Not covered: -Sparse / prefixes, minimizers (-m), homopolymer compression (-hc), -deCon, appending (-t_db); `-batch list` is the
+ * host program's (examples/kmahip_index: the listed paths become fasta_paths). */
 int kmahip_index_build(const char *const *fasta_paths, int n_files, const char *out_prefix, int kmersize);
 
 /* ---- stage 1: FASTQ / FASTA ingest into packed read batches -------------------------------------------

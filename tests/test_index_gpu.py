@@ -92,6 +92,30 @@ def test_index_build_errors(tmp_path):
         binding.index_build(str(p), str(tmp_path / "x"), k=20)
 
 
+def test_index_host_program_takes_a_batch_file(tmp_path):
+    """`-batch list.txt` (index.c:351-401: a file of input paths, one a line) against `kma index -batch` and against the same files given with -i"""
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+    names, seqs = synth.make_gene_db(30, 4, 400, 900, 0.04, seed=77)
+    paths = []
+    for part in range(3):
+        p = str(tmp_path / f"part{part}.fsa")
+        synth.write_fasta(p, names[part::3], seqs[part::3])
+        paths.append(p)
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    subprocess.run([KMA, "index", "-batch", str(tmp_path / "list.txt"), "-o", str(tmp_path / "ref")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_index"), "-batch", str(tmp_path / "list.txt"), "-o", str(tmp_path / "got")], check=True)
+    subprocess.run([os.path.join(ROOT, "examples", "kmahip_index"), "-i"] + paths + ["-o", str(tmp_path / "got_i")], check=True)
+    for ext in (".length.b", ".name"):
+        assert open(str(tmp_path / "got") + ext, "rb").read() == open(str(tmp_path / "ref") + ext, "rb").read(), ext
+    a, b, c = (formats.read_comp_b(str(tmp_path / t) + ".comp.b") for t in ("got", "ref", "got_i"))
+    assert formats.comp_db_mapping(a) == formats.comp_db_mapping(b) and a.v_index == b.v_index
+    for ext in (".comp.b", ".length.b", ".name", ".seq.b"):
+        assert open(str(tmp_path / "got") + ext, "rb").read() == open(str(tmp_path / "got_i") + ext, "rb").read(), ext
+    assert c.n == a.n
+
+
 def test_index_host_program_and_speed(tmp_path):
     """examples/kmahip_index on the 5 k-gene database of the benchmark: loads, and is timed next to `kma index` (printed with -s)"""
     import time

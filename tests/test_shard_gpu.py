@@ -121,7 +121,7 @@ def test_baseline_command_lines_give_the_reference_files(tmp_path):
     r1, r2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
     cases = [
         ["-i", fq, "-t_db", prefix, "-1t1"],                                        # C1 / C2
-        ["-i", fq, "-t_db", prefix, "-1t1", "-t", "4", "-nc", "-na", "-nf"],       # the output switches of BASELINE.md R2
+        ["-i", fq, "-t_db", prefix, "-1t1", "-t", "4", "-nc", "-na", "-nf", "-mmap", "-status", "-verbose", "2", "-tmp", str(tmp_path) + "/"],   # the output switches of BASELINE.md R2 (+ switches without an effect on the files)
         ["-ipe", r1, r2, "-t_db", prefix, "-apm", "p", "-1t1", "-t", "1"],         # C3
         ["-ipe", r1, r2, "-t_db", prefix, "-1t1", "-t", "1"],                      # ... and without -apm: the union pairing (kma.c:206)
         ["-i", fq, "-t_db", prefix, "-1t1", "-mp", "30", "-ml", "40", "-eq", "25", "-mf", "900"],
