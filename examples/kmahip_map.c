@@ -75,7 +75,7 @@ static void rc_second_mates(kmahip_read_batch *b) {
 	for(int64_t r = 0; r < b->reads.n_reads; ++r) {
 		if(b->pair[r] != 2) continue;
 		uint64_t *w = seq + b->reads.seq_off[r];
-		const int L = b->reads.len[r], nw = (L + 31) >> 5;
+		const int L = b->reads.len[r];
 		int32_t *n = N + b->reads.N_off[r];
 		const int nn = (int) (b->reads.N_off[r + 1] - b->reads.N_off[r]);
 		for(int i = 0, j = L - 1; i < j; ++i, --j) {          /* swap and complement base by base (reads are short here; this is not the hot path) */
@@ -85,7 +85,6 @@ static void rc_second_mates(kmahip_read_batch *b) {
 			w[j >> 5] = (w[j >> 5] & ~(3ull << sj)) | ((3u - bi) << sj);
 		}
 		if(L & 1) { const int m = L >> 1, sm = 62 - ((m & 31) << 1); w[m >> 5] ^= 3ull << sm; }
-		(void) nw;
 		for(int x = 0, y = nn - 1; x <= y; ++x, --y) { const int32_t a = L - 1 - n[y], c = L - 1 - n[x]; n[x] = a; n[y] = c; }
 		for(int x = 0; x < nn; ++x) { const int q = n[x], sq = 62 - ((q & 31) << 1); w[q >> 5] &= ~(3ull << sq); }      /* N packed as A */
 	}
