@@ -260,6 +260,26 @@ def test_ingest_chunked_reader_equals_one_pass(tmp_path, tiny_chunks, chunk, reg
             os.environ.pop(k, None)
 
 
+def test_ingest_interleaved_gzip_members_that_cut_a_couple(tmp_path, tiny_chunks):
+    """the interleaved reader on a .gz of one member and on one of several members whose borders fall between the mates of a couple
+    (an odd number of records in front of each border): the same batches as the plain file, whole and in tiny chunks"""
+    raw = open(os.path.join(ING, "ilvodd.fq"), "rb").read()
+    recs = raw.split(b"\n@q")
+    recs = [recs[0] + b"\n"] + [b"@q" + r + b"\n" for r in recs[1:-1]] + [b"@q" + recs[-1]]
+    assert b"".join(recs) == raw and len(recs) == 151
+    (tmp_path / "one.fq.gz").write_bytes(gzip.compress(raw, 1))
+    cuts = [0, 7, 40, 41, 96, 151]                                    # members of 7, 33, 1, 55 and 55 records
+    (tmp_path / "many.fq.gz").write_bytes(b"".join(gzip.compress(b"".join(recs[a:b]), 1) for a, b in zip(cuts, cuts[1:])))
+    want = _all(os.path.join(ING, "ilvodd.fq"), "", min_phred=0, min_len=1)
+    assert sum(1 for x in want[0][2] if x == 1) > 50 and want[0][2][-1] == 0      # couples, and the odd last record filed singly
+    for f in ("one.fq.gz", "many.fq.gz"):
+        assert _all(str(tmp_path / f), "", min_phred=0, min_len=1) == want, f
+        tiny_chunks(300, 40)
+        assert _all(str(tmp_path / f), "", step=5, min_phred=0, min_len=1) == want, (f, "tiny chunks")
+        for k in ("KMAHIP_INGEST_CHUNK", "KMAHIP_INGEST_REGION", "KMAHIP_INGEST_THREADS"):
+            os.environ.pop(k, None)
+
+
 def test_ingest_chunked_reader_malformed_and_short_mate(tmp_path, tiny_chunks):
     good = b"".join(b"@r%d\nACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIII\n" % i for i in range(200))
     bad = tmp_path / "bad.fq"
