@@ -357,6 +357,56 @@ def test_one_call_paired_run_matches_reference_files(golden_pe, tmp_path):
     sam = golden_util.load_sam("pe")
     assert len(rows) == sum(len(v) for v in sam.values()) > 1000          # one row per SAM record of the reference run
 
+def test_paired_fixture_in_the_default_mode_matches_the_committed_reference_files(golden_pe, tmp_path):
+    """`kma -ipe r1 r2` without -1t1 on the committed paired fixture (tests/golden/pe/out_default.*, written by
+    tests/golden/make_golden_pe_default.py from the compiled reference): couples by union pairing, the nineteen records that lost their
+    mate through the chain finder (kmahip_ws_set_pe_chain) -- through the C host program and through the C-ABI from Python."""
+    import gzip
+    import os
+    import subprocess
+    from kma_amd import binding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(golden_util.GOLD, "pe")
+    want_res = open(os.path.join(src, "out_default.res")).read()
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    out = str(tmp_path / "out")
+    subprocess.run([os.path.join(root, "examples", "kmahip_map"), "-ipe", os.path.join(src, "r1.fq.gz"), os.path.join(src, "r2.fq.gz"), "-t_db", golden_pe["prefix"], "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    assert open(out + ".res").read() == want_res
+    assert open(out + ".fsa", "rb").read() == gzip.open(os.path.join(src, "out_default.fsa.gz")).read()
+    assert gzip.open(out + ".frag.gz").read() == gzip.open(os.path.join(src, "out_default.frag.gz")).read()
+    with binding.Ingest(os.path.join(src, "r1.fq.gz"), os.path.join(src, "r2.fq.gz")) as ing:
+        batch, names, pair = ing.next(1 << 30)
+    db = binding.KmaHipDB(golden_pe["prefix"])
+    try:
+        db.params.apm = 1                                    # (no -apm: union pairing, kma.c:206)
+        db.set_pe_chain()
+        o = db.run_pe(batch, names, pair, frag_path=str(tmp_path / "x.frag.gz"))
+        tn = golden_util.template_names("pe")
+        lines = [want_res.splitlines(True)[0]]
+        for r in o["rows"]:
+            if r.significant:
+                t = r.template_id
+                line = db.res_line(tn[t - 1], r, o["cover"][t], o["aln_len"][t], o["depth"][t])
+                if line:
+                    lines.append(line)
+        assert "".join(lines) == want_res
+        assert gzip.open(tmp_path / "x.frag.gz").read() == gzip.open(os.path.join(src, "out_default.frag.gz")).read()
+        db.set_pe_chain(False)                               # ... and back: the -1t1 files again
+        db.params.apm = 0
+        o = db.run_pe(batch, names, pair)
+        lines = [want_res.splitlines(True)[0]]
+        for r in o["rows"]:
+            if r.significant:
+                t = r.template_id
+                line = db.res_line(tn[t - 1], r, o["cover"][t], o["aln_len"][t], o["depth"][t])
+                if line:
+                    lines.append(line)
+        assert "".join(lines) == open(os.path.join(src, "out.res")).read()
+    finally:
+        db.close()
+
+
 def test_pileup_in_lds_equals_pileup_in_hbm(golden_se, golden_long, monkeypatch):
     """The pile-up keeps a template's columns (and its insertion columns) in LDS when they fit; a template too long for it, or
     a launch whose insertion columns overflowed the LDS table (repeated on HBM), works on HBM. Same result either way:
