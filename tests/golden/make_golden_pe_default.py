@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Expected files of the committed paired fixture (tests/golden/pe: r1.fq.gz, r2.fq.gz and the index) in the reference's DEFAULT mode --
 `kma -ipe r1 r2 -t_db db -o out -t 1`, no -1t1: couples by union pairing, the records that lost their mate through the chain finder --
-written next to the `-1t1 -apm p` ones: out_default.res, out_default.fsa.gz, out_default.frag.gz, s2_default.bin.gz (the `-s2` tap).
+written next to the `-1t1 -apm p` ones: out_default.res, out_default.fsa.gz, out_default.frag.gz, s2_default.bin.gz (the `-s2` tap),
+s2_default_p.bin.gz (the `-s2` tap with `-apm p`).
 
     python3 tests/golden/make_golden_pe_default.py        (needs oracle/_ref/kma: `make -C oracle ref`)
 """
@@ -31,6 +32,10 @@ def main():
         base = [KMA, "-ipe", os.path.join(PE, "r1.fq.gz"), os.path.join(PE, "r2.fq.gz"), "-o", os.path.join(tmp, "out"), "-t_db", db, "-t", "1"]
         subprocess.run(base, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         s2 = subprocess.run(base + ["-s2"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        # (the same stream with the pairing penalty, -apm p: what oracle/scan.c's paired half restates; for tests/test_oracle_golden.py)
+        s2p = subprocess.run(base + ["-apm", "p", "-s2"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        with gzip.GzipFile(os.path.join(PE, "s2_default_p.bin.gz"), "wb", mtime=0) as g:
+            g.write(s2p)
         shutil.copy(os.path.join(tmp, "out.res"), os.path.join(PE, "out_default.res"))
         for name, data in (("out_default.fsa.gz", open(os.path.join(tmp, "out.fsa"), "rb").read()),
                            ("out_default.frag.gz", gzip.open(os.path.join(tmp, "out.frag.gz")).read()), ("s2_default.bin.gz", s2)):

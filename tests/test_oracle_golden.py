@@ -136,6 +136,35 @@ def test_oracle_pe_scan_matches_s2_tap_bytes(golden_pe):
     assert got == golden_pe["s2_bytes"]
 
 
+def test_oracle_pe_scan_in_the_default_mode_matches_s2_tap_bytes(golden_pe):
+    """`-ipe r1 r2 -apm p` WITHOUT -1t1 (tests/golden/pe/s2_default_p.bin.gz, make_golden_pe_default.py): the couples as above, a record
+    that lost its mate through the chain finder (save_kmers_batch hands it to kmerScan = save_kmers_chain, savekmers.c:196-200) -- zero
+    or more records each, flag 0, the query bounds behind the header; the rebuilt stream equals the reference's byte for byte"""
+    import gzip
+    import struct
+    db = oracle.OracleDB(golden_pe["prefix"])
+    want = gzip.open(os.path.join(golden_pe["dir"], "s2_default_p.bin.gz")).read()
+    out, n_chain = b"", 0
+    for u in golden_pe["units"]:
+        if u[0] == "se":
+            r = golden_pe["s1"][u[1]]
+            codes = formats.unpack_words(r["seq"], r["seqlen"]).copy()
+            codes[r["N"]] = 4
+            for rc_flag, emit_rc, q_start, q_end, T in db.scan_chain(formats.pack_ragged([codes]))[0]:
+                words, N = (oracle.rc_packed(r["seq"], r["seqlen"], r["N"]) if emit_rc else (r["seq"], r["N"]))
+                out += golden_util.s2_record_bytes(r["seqlen"], words, N, rc_flag, T, r["hdr"] + b"\x00" + struct.pack("<2i", q_start, q_end), 0)
+                n_chain += 1
+        else:
+            a, b = golden_pe["s1"][u[1]], golden_pe["s1"][u[2]]
+            for rec in db.scan_pe(a["seq"], a["seqlen"], a["N"], b["seq"], b["seqlen"], b["N"])[1]:
+                r = (a, b)[rec["mate"]]
+                words, N = (oracle.rc_packed(r["seq"], r["seqlen"], r["N"]) if rec["rc"] else (r["seq"], r["N"]))
+                out += golden_util.s2_record_bytes(r["seqlen"], words, N, int(rec["rc_flag"]), rec["T"], r["hdr"], int(rec["flag"]))
+    out += struct.pack("<i", -len(golden_pe["units"]))
+    assert n_chain >= 15
+    assert out == want
+
+
 def test_oracle_pe_align_matches_frag_raw_tap(golden_pe):
     # stage 3a for `-ipe ... -apm p`: alnFragsPenaltyPE + update_Scores_pe (proper pairs) and alnFragsSE for
     # the records stage 2 wrote singly; compared line by line with the reference's `-a` tap.
