@@ -52,6 +52,48 @@ def test_pe_scan_matches_reference_s2_stream(golden_pe):
     assert got == golden_pe["s2_bytes"]
 
 
+@pytest.mark.parametrize("apm,tap", [(1, "s2_default.bin.gz"), (0, "s2_default_p.bin.gz")])
+def test_pe_scan_in_the_default_mode_matches_reference_s2_stream(golden_pe, apm, tap):
+    """the S2 stream of `kma -ipe r1 r2 [-apm p]` WITHOUT -1t1 (tests/golden/make_golden_pe_default.py): the couples through
+    kmahip_scan_pe (union pairing without -apm, kma.c:206), the records that lost their mate through kmahip_scan_chain -- zero or more
+    records each with flag 0 and the query bounds behind the header (savekmers.c:196-200) -- rebuilt byte for byte"""
+    import gzip
+    import os
+    import struct
+    import oracle
+    from kma_amd import binding
+    g = golden_pe
+    want = gzip.open(os.path.join(g["dir"], tap)).read()
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        db.params.apm = apm
+        pair_res, _ = _device_results(g, db)
+        singles = [u for u in g["units"] if u[0] == "se"]
+        ch = db.scan_chain(formats.pack_ragged([_codes(g["s1"][u[1]]) for u in singles]))
+    finally:
+        db.close()
+    by_single = {}
+    for x in range(len(ch["read"])):
+        by_single.setdefault(int(ch["read"][x]), []).append(x)
+    out, j = b"", 0
+    for u in g["units"]:
+        if u[0] == "se":
+            r = g["s1"][u[1]]
+            for x in by_single.get(j, []):
+                words, N = (oracle.rc_packed(r["seq"], r["seqlen"], r["N"]) if ch["emit_rc"][x] else (r["seq"], r["N"]))
+                out += golden_util.s2_record_bytes(r["seqlen"], words, N, int(ch["rc_flag"][x]), ch["T"][ch["T_off"][x]:ch["T_off"][x + 1]],
+                                                   r["hdr"] + b"\x00" + struct.pack("<2i", int(ch["q_start"][x]), int(ch["q_end"][x])), 0)
+            j += 1
+        else:
+            a, b = g["s1"][u[1]], g["s1"][u[2]]
+            for rec in pair_res[u[1]]:
+                r = (a, b)[rec["mate"]]
+                words, N = (oracle.rc_packed(r["seq"], r["seqlen"], r["N"]) if rec["rc"] else (r["seq"], r["N"]))
+                out += golden_util.s2_record_bytes(r["seqlen"], words, N, int(rec["rc_flag"]), rec["T"], r["hdr"], int(rec["flag"]))
+    out += struct.pack("<i", -len(g["units"]))
+    assert len(ch["read"]) >= 15 and out == want
+
+
 def test_pe_scan_vs_oracle_redundant_db(tmp_path):
     """Wide candidate lists (overflow path) and short mates."""
     import oracle
