@@ -458,3 +458,106 @@ int orc_scan_pe(const orc_db *db, const orc_rewards *rw, int exhaustive,
 	ws_free(w);
 	return ret;
 }
+
+/* `-apm u`, and what `-ipe` means without -apm (kma.c:206): save_kmers_unionPair (savekmers.c:3367-3570) with getF_Best / getR_Best
+ * (:1648-1762). Mate 1 keeps the templates of either strand that reach its best score; mate 2 its own best set -- and where a template
+ * of mate 1's set is in mate 2's set on the OTHER strand (getR_Best leaves a score standing only for mate 2's best ones, so "is
+ * there a score" = "has the best score") those move to the front of mate 1's list and the two are printed as a couple; otherwise
+ * each mate is a record of its own. Same in / out as orc_scan_pe. */
+int orc_scan_pe_union(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                      const uint64_t *seq1, int len1, const int *N1, int nN1,
+                      const uint64_t *seq2, int len2, const int *N2, int nN2,
+                      orc_pe_rec out[2], int *T1, int *T2) {
+	const int k = db->kmersize, D = db->DB_size;
+	scan_ws *w = ws_new(db);
+	int *buf = malloc(sizeof(int) * (size_t) (8 * D + 32));
+	plist F1 = {0, buf, buf + D}, R1 = {0, buf + 2 * D, buf + 3 * D}, F2 = {0, buf + 4 * D, buf + 5 * D}, R2 = {0, buf + 6 * D, buf + 7 * D};
+	int hc1 = 0, hc2 = 0;
+	for(int m = 0; m < 2; ++m) {
+		const uint64_t *seq = m ? seq2 : seq1; const int len = m ? len2 : len1; const int *N = m ? N2 : N1; const int nN = m ? nN2 : nN1;
+		plist *F = m ? &F2 : &F1, *R = m ? &R2 : &R1;
+		if(len < k) continue;
+		const int words = (len + 31) >> 5;
+		uint64_t *rs = calloc((size_t) words + 2, 8);
+		int *fN = malloc(sizeof(int) * (size_t) (2 * nN + 4)), *rN = fN + nN + 2;
+		fN[0] = nN; memcpy(fN + 1, N, sizeof(int) * (size_t) nN);
+		orc_rc(seq, len, fN, rs, rN);
+		int hf = 0, hr = 0;
+		scan_strand_x(db, rw, exhaustive, 0, seq, len, fN, &w->st, F->t, &F->n, F->s, &hf);
+		scan_strand_x(db, rw, exhaustive, 1, rs, len, rN, &w->st, R->t, &R->n, R->s, &hr);
+		if(m) hc2 = hf > hr ? hf : hr; else hc1 = hf > hr ? hf : hr;
+		free(rs); free(fN);
+	}
+	/* getF_Best: the best score over both strands' candidates, its templates in the order met, the forward strand's first */
+	#define BEST_OF(F, R, DST, CNT, BEST) do { BEST = 0; CNT = 0; \
+		for(int i_ = 0; i_ < (F).n; ++i_) { const int sc_ = (F).s[i_]; if(BEST < sc_) { BEST = sc_; CNT = 0; DST[CNT++] = (F).t[i_]; } else if(BEST == sc_) DST[CNT++] = (F).t[i_]; } \
+		for(int i_ = 0; i_ < (R).n; ++i_) { const int sc_ = (R).s[i_]; if(BEST < sc_) { BEST = sc_; CNT = 0; DST[CNT++] = -(R).t[i_]; } else if(BEST == sc_) DST[CNT++] = -(R).t[i_]; } } while(0)
+	int *regT = T1, *bT = T2, nreg = 0, nb2 = 0, best1 = 0, best2 = 0, paired = 0;
+	if(hc1) {
+		BEST_OF(F1, R1, regT, nreg, best1);
+		if(k < best1 && (unsigned) (best1 * k) < (unsigned) len1 - (unsigned) best1) best1 = 0;      /* (CompDNA.seqlen is unsigned) */
+	}
+	if(hc2) {
+		if(best1) {
+			BEST_OF(F2, R2, bT, nb2, best2);
+			int hits = 0;
+			if(0 < best2) {
+				for(int i = 0; i < nreg; ++i) {
+					const int rt = regT[i];
+					const int sc = rt > 0 ? plist_find(&R2, rt) : plist_find(&F2, -rt);
+					if(sc == best2) { const int x = regT[hits]; regT[hits] = rt; regT[i] = x; ++hits; }
+				}
+			}
+			if(hits) { paired = 1; nreg = hits; }
+		} else BEST_OF(F2, R2, regT, nreg, best2);
+		if(k < best2 && (unsigned) (best2 * k) < (unsigned) len2 - (unsigned) best2) { best2 = 0; paired = 0; }
+	}
+	#undef BEST_OF
+	int o1 = len1 >= k, o2 = len2 >= k;          /* get_kmers_for_pair leaves a scanned mate reverse-complemented */
+	int flag = 65, flag_r = 129, ret = 3;
+	memset(out, 0, 2 * sizeof(orc_pe_rec));
+	#define EMIT(slot, MATE, RC, SCORE, FLAG, TP, NT) do { out[slot].present = 1; out[slot].mate = MATE; out[slot].rc = RC; \
+		out[slot].rc_flag = SCORE; out[slot].flag = FLAG; out[slot].nT = NT; out[slot].T = TP; } while(0)
+	if(0 < best1 && 0 < best2) {
+		if(paired) {
+			flag |= 2; flag_r |= 2;
+			if(0 < regT[0]) {
+				flag |= 32; flag_r |= 16; o1 ^= 1;
+				EMIT(0, 0, o1, best1, flag, regT, 0);
+				EMIT(1, 1, o2, best2, flag_r, regT, nreg);
+			} else {
+				flag |= 16; flag_r |= 32; o2 ^= 1;
+				for(int i = 0; i < nreg; ++i) regT[i] = -regT[i];
+				EMIT(0, 1, o2, best2, flag_r, regT, 0);
+				EMIT(1, 0, o1, best1, flag, regT, nreg);
+			}
+		} else {
+			int s1 = best1, s2 = best2;
+			if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+			else { flag |= 16; flag_r |= 32; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+			if(0 < bT[0]) { o2 ^= 1; if(bT[nb2 - 1] < 0) s2 = -s2; }
+			else { flag |= 32; flag_r |= 16; for(int i = 0; i < nb2; ++i) bT[i] = -bT[i]; }
+			EMIT(0, 0, o1, s1, flag, regT, nreg);
+			EMIT(1, 1, o2, s2, flag_r, bT, nb2);
+		}
+		ret = 0;
+	} else if(best1) {
+		int s1 = best1;
+		flag |= 8; flag |= 32;
+		if(0 < regT[0]) { o1 ^= 1; if(regT[nreg - 1] < 0) s1 = -s1; }
+		else { flag |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+		EMIT(0, 0, o1, s1, flag, regT, nreg);
+		ret = 2;
+	} else if(best2) {
+		int s2 = best2;
+		flag_r |= 8; flag_r |= 32;
+		if(0 < regT[0]) { o2 ^= 1; if(regT[nreg - 1] < 0) s2 = -s2; }
+		else { flag_r |= 16; for(int i = 0; i < nreg; ++i) regT[i] = -regT[i]; }
+		EMIT(1, 1, o2, s2, flag_r, regT, nreg);
+		ret = 1;
+	}
+	#undef EMIT
+	free(buf);
+	ws_free(w);
+	return ret;
+}

@@ -136,14 +136,16 @@ def test_oracle_pe_scan_matches_s2_tap_bytes(golden_pe):
     assert got == golden_pe["s2_bytes"]
 
 
-def test_oracle_pe_scan_in_the_default_mode_matches_s2_tap_bytes(golden_pe):
-    """`-ipe r1 r2 -apm p` WITHOUT -1t1 (tests/golden/pe/s2_default_p.bin.gz, make_golden_pe_default.py): the couples as above, a record
-    that lost its mate through the chain finder (save_kmers_batch hands it to kmerScan = save_kmers_chain, savekmers.c:196-200) -- zero
-    or more records each, flag 0, the query bounds behind the header; the rebuilt stream equals the reference's byte for byte"""
+@pytest.mark.parametrize("union,tap", [(False, "s2_default_p.bin.gz"), (True, "s2_default.bin.gz")])
+def test_oracle_pe_scan_in_the_default_mode_matches_s2_tap_bytes(golden_pe, union, tap):
+    """`-ipe r1 r2 [-apm p]` WITHOUT -1t1 (tests/golden/pe/s2_default*.bin.gz, make_golden_pe_default.py): the couples by the pairing
+    penalty as above or, without -apm, by the union pairing (save_kmers_unionPair, oracle/scan.c orc_scan_pe_union); a record that lost
+    its mate through the chain finder (save_kmers_batch hands it to kmerScan = save_kmers_chain, savekmers.c:196-200) -- zero or more
+    records each, flag 0, the query bounds behind the header; the rebuilt stream equals the reference's byte for byte"""
     import gzip
     import struct
     db = oracle.OracleDB(golden_pe["prefix"])
-    want = gzip.open(os.path.join(golden_pe["dir"], "s2_default_p.bin.gz")).read()
+    want = gzip.open(os.path.join(golden_pe["dir"], tap)).read()
     out, n_chain = b"", 0
     for u in golden_pe["units"]:
         if u[0] == "se":
@@ -156,7 +158,7 @@ def test_oracle_pe_scan_in_the_default_mode_matches_s2_tap_bytes(golden_pe):
                 n_chain += 1
         else:
             a, b = golden_pe["s1"][u[1]], golden_pe["s1"][u[2]]
-            for rec in db.scan_pe(a["seq"], a["seqlen"], a["N"], b["seq"], b["seqlen"], b["N"])[1]:
+            for rec in db.scan_pe(a["seq"], a["seqlen"], a["N"], b["seq"], b["seqlen"], b["N"], union=union)[1]:
                 r = (a, b)[rec["mate"]]
                 words, N = (oracle.rc_packed(r["seq"], r["seqlen"], r["N"]) if rec["rc"] else (r["seq"], r["N"]))
                 out += golden_util.s2_record_bytes(r["seqlen"], words, N, int(rec["rc_flag"]), rec["T"], r["hdr"], int(rec["flag"]))
