@@ -266,7 +266,7 @@ static int launch_ranks(int gpus, char **argv) {
 int main(int argc, char **argv) {
 	const char *prefix = NULL, *input = NULL, *input2 = NULL, *out = NULL;
 	int Ts = -2, Tv = -2;          /* -transition / -transversion (kma.c:335-336) */
-	int cmp_mode = 0, lc = 0;      /* -and / -oa, -lc */
+	int cmp_mode = 0, lc = 0, mem_mode = 0;      /* -and / -oa, -lc, -mem_mode */
 	int pm = 0, fpm = 0;           /* -pm / -fpm (1 p, 2 u; 0: not given) */
 	char *list1[256], *list2[256]; int n_files = 0;          /* the input files (mate files side by side) */
 	int mt1 = 0, one2one = 0, chain = 0, apm = 0, no_cons = 0, no_frag = 0, no_aln = 0, gpus = 0, threads = 0, bcd = 1;
@@ -352,6 +352,7 @@ int main(int argc, char **argv) {
 		 * temporary files go (-tmp [dir/], kma.c:1031-1050: this program writes none), what it says on stderr (-status, -verbose [n]) */
 		else if(!strcmp(o, "-mmap") || !strcmp(o, "-swap") || !strcmp(o, "-status")) { }
 		else if(!strcmp(o, "-tmp") || !strcmp(o, "-verbose")) { if(a + 1 < argc && argv[a + 1][0] != '-') ++a; }
+		else if(!strcmp(o, "-mem_mode")) mem_mode = 1;                                           /* kma.c:547 */
 		else if(!strcmp(o, "-lc")) lc = 1;                                                      /* kma.c:694-701 */
 		else if(!strcmp(o, "-and")) cmp_mode = 1;                                               /* kma.c:915-920 */
 		else if(!strcmp(o, "-oa")) { cmp_mode = 2; ID_t = 1e-300; Depth_t = 0.0; }               /* (ID_t = 0 there; a row needs 0 < id anyway, and 0 means "the default" to kmahip_shard_opts) */
@@ -397,6 +398,10 @@ int main(int argc, char **argv) {
 	const int pe_chain = chain && input2;
 	if(lc && chain) { fprintf(stderr, "kmahip_map: -lc needs -1t1 (the chain finder's length-corrected anchors are not built)\n"); return 2; }
 	if(kmahip_set_conclave_lc(lc)) return 1;
+	if(mem_mode && !mt1) {          /* (runKMA_Mt1 comes before runKMA_MEM, kma.c:1598-1623: -Mt1 leaves -mem_mode without effect) */
+		if(input2) { fprintf(stderr, "kmahip_map: -mem_mode with paired input is not built (update_Scores_pe_MEM)\n"); return 2; }
+		if(kmahip_set_mem_mode(1)) return 1;
+	}
 	if(pe_chain) chain = 0;
 	/* -mrc in the default mode: mrchain (kmeranker.c:57-81) only drops templates when q_len < mrc * (the chain's span on the read), which
 	 * no mrc <= 1 can make true -- stage 2 is as without it, the coverage test of stages 3a / 3c (mrcheck) is the aligner's own */

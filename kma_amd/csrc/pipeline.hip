@@ -58,6 +58,48 @@ void kmahip_devcache_flush() {
 #include <memory>
 
 
+// ---- `-mem_mode` (runKMA_MEM, runkma.c:910-1250): no alignment before ConClave. A stage-2 record IS the frag_raw record -- its template
+// list as the hits, each from 0 to the template's length, the record's k-mer score as the read score, added to the ConClave vectors
+// (update_Scores_MEM, updatescores.c:31-67); ConClave, the `.res` statistics, and the traceback of stage 3c against the chosen template
+// follow as ever. One setting per process, like the reference's choice of runKMA_MEM over runKMA (kma.c:1619-1623).
+static int g_mem_mode = 0;
+extern "C" int kmahip_set_mem_mode(int on) { g_mem_mode = on != 0; return KMAHIP_OK; }
+int kmahip_mem_mode() { return g_mem_mode; }
+
+namespace {
+__global__ __launch_bounds__(256) void mem_hits_kernel(int64_t n, int k, const int32_t *len, const int32_t *rc_flag, const int32_t *flag, const int64_t *T_off, const int32_t *T,
+                                                        const int32_t *tlen, kmahip_hits h, unsigned long long *AS, unsigned long long *US) {
+	const int64_t r = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(r >= n) return;
+	const int64_t o = T_off[r], e = T_off[r + 1];
+	const int fl = flag[r];
+	h.flag[r] = fl;
+	if(h.rc) h.rc[r] = 0;
+	if(e == o || len[r] < k) { h.n_hits[r] = 0; h.best_score[r] = 0; return; }          // (runkma.c:1101: a read shorter than k leaves no record)
+	const int score = abs(rc_flag[r]);
+	for(int64_t t = o; t < e; ++t) {
+		const int tm = T[t];
+		h.tmpl[t] = tm; h.score[t] = score; h.start[t] = 0; h.end[t] = tlen[abs(tm)];
+		if(AS) atomicAdd(&AS[abs(tm)], (unsigned long long) score);
+	}
+	if(e - o == 1 && US) atomicAdd(&US[abs(T[o])], (unsigned long long) score);
+	h.n_hits[r] = (int32_t) (e - o); h.best_score[r] = score;
+	if(h.rc) h.rc[r] = (fl & 16) != 0;          // (the record holds the read as stage 2 passed it on)
+}
+}  // namespace
+
+int kmahip_stage3a_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands, const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
+	if(!g_mem_mode) return kmahip_launch_align_se(db, ws, reads, cands, p, out, stream);
+	if(!db->dev.tlen) { kmahip_set_error("index has no .length.b"); return KMAHIP_EINVAL; }
+	const int64_t n = reads->n_reads;
+	// (a strand tie whose list ends on a forward template would be filed with a negative count and take anker_rc in stage 3c,
+	// runkma.c:1124: no template finder here writes such a list -- the reverse strand's templates come last)
+	if(n) hipLaunchKernelGGL(mem_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, n, (int) db->info.kmersize, reads->len, cands->rc_flag, cands->flag, cands->T_off,
+	                         cands->T, db->dev.tlen, *out, (unsigned long long *) out->alignment_scores, (unsigned long long *) out->uniq_alignment_scores);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}
+
 // everything behind stage 2 on a batch that is in HBM with its candidate lists: stage 3a, ConClave + the `.res` statistics, the
 // traceback, the pile-up. per_read: host arrays for the columns a `.frag` writer needs (any may be NULL).
 struct PerRead { int32_t *tmpl, *n_hits, *rc, *trace_stats; };
@@ -77,7 +119,7 @@ static int run_after_stage2(kmahip_db *db, kmahip_ws *ws, DevBlock &B, const kma
 	   (rc = B.get(D, &h.alignment_scores, true)) || (rc = B.get(D, &h.uniq_alignment_scores, true))) return rc;
 	if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a buffers after %.2f ms\n", since(t2)); }
 	for(;;) {
-		if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+		if(n && (rc = kmahip_stage3a_se(db, ws, &d, &c, p, &h, s))) return rc;
 		if(dbg) { auto t2 = t; fprintf(stderr, "[kmahip] run_se: stage 3a launched after %.2f ms\n", since(t2)); }
 		HIP_TRY(hipStreamSynchronize(s));
 		if(ws_status(ws, nullptr) != 3) break;
@@ -480,6 +522,7 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	   (!batch->pair && batch->reads.n_reads > 0)) {
 		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
 	}
+	if(g_mem_mode) { kmahip_set_error("-mem_mode with paired input is not built (update_Scores_pe_MEM)"); return KMAHIP_EINVAL; }
 	const kmahip_reads &R = batch->reads;
 	const int64_t n = R.n_reads;
 	if(n < 0 || n > 0x7ffffff0ll || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("bad batch size"); return KMAHIP_EINVAL; }
@@ -1582,7 +1625,7 @@ static int sharded_after_stage2(kmahip_db *db, kmahip_ws *ws, kmahip_comm *comm,
 	   (rc = B.get((size_t) total + 1, &h.start, true)) || (rc = B.get((size_t) total + 1, &h.end, true)) || (rc = B.get(2 * D, &AS, true))) return rc;
 	h.alignment_scores = AS; h.uniq_alignment_scores = AS + D;
 	for(;;) {
-		if(n && (rc = kmahip_launch_align_se(db, ws, &d, &c, p, &h, s))) return rc;
+		if(n && (rc = kmahip_stage3a_se(db, ws, &d, &c, p, &h, s))) return rc;
 		HIP_TRY(hipStreamSynchronize(s));
 		if(ws_status(ws, nullptr) != 3) break;
 		if(!grow_mem_cap(ws)) { kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }

@@ -15,6 +15,9 @@
 void *kmahip_devcache_take(size_t bytes, size_t *got);      // a kept block of at least `bytes` (and not over twice that), or NULL
 void kmahip_devcache_give(void *p, size_t bytes);           // keep it (or release it, when what is kept would exceed the cache's share)
 void kmahip_devcache_flush();                               // release everything kept
+// stage 3a of a single-end batch: kmahip_launch_align_se, or under -mem_mode (kmahip_set_mem_mode) the records of runKMA_MEM
+int kmahip_stage3a_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands, const kmahip_params *p, kmahip_hits *out, hipStream_t stream);
+int kmahip_mem_mode();
 
 namespace {
 

@@ -590,7 +590,7 @@ static int session_map_one(kmahip_session *S, Batch &B) {
 	   (rc = dev_new(B.owned, (size_t) B.total + 1, &h.start, true, s)) || (rc = dev_new(B.owned, (size_t) B.total + 1, &h.end, true, s))) { B.release(); return rc; }
 	h.alignment_scores = S->AS_batch; h.uniq_alignment_scores = S->AS_batch + D;
 	for(;;) {
-		if(hipMemsetAsync(S->AS_batch, 0, 2 * D * 8, s) != hipSuccess || (rc = kmahip_launch_align_se(db, ws, &d, &B.c, &S->par, &h, s))) { B.release(); return rc ? rc : KMAHIP_EDEVICE; }
+		if(hipMemsetAsync(S->AS_batch, 0, 2 * D * 8, s) != hipSuccess || (rc = kmahip_stage3a_se(db, ws, &d, &B.c, &S->par, &h, s))) { B.release(); return rc ? rc : KMAHIP_EDEVICE; }
 		if(hipStreamSynchronize(s) != hipSuccess) { B.release(); kmahip_set_error("stage 3a failed"); return KMAHIP_EDEVICE; }
 		if(ws_status(ws, nullptr) != 3) break;
 		if(!grow_mem_cap(ws)) { B.release(); kmahip_set_error("seed (MEM) capacity per read/template pair exceeded"); return KMAHIP_EOVERFLOW; }

@@ -363,6 +363,45 @@ def test_lc_with_1t1_equals_the_reference(tmp_path):
     assert _run(["-i", fq, "-t_db", prefix, "-lc", "-o", str(tmp_path / "x")], ok=False).returncode != 0      # (the chain finder's -lc is not built: refused)
 
 
+@pytest.mark.parametrize("mode", ["1t1", "default"])
+def test_mem_mode_equals_the_reference(tmp_path, mode):
+    """-mem_mode (runKMA_MEM, runkma.c:910-1250): ConClave on the template finder's own scores, no alignment before it -- the `.res`
+    scores are sums of k-mer scores and differ from the plain run's. -1t1 on reads with indels and N's, the default mode on reads that
+    map in pieces; one batch, batch by batch and over three ranks against the compiled reference."""
+    import sys
+    if not os.path.exists(KMA):
+        pytest.skip("oracle/_ref/kma not built")
+    if mode == "1t1":
+        prefix, fq = _case(tmp_path, n=9000)
+        args = ["-i", fq, "-t_db", prefix, "-1t1", "-mem_mode"]
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_oracle_golden import _chimeric_reads
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+        rng = np.random.default_rng(77)
+        names, seqs = synth.make_gene_db(40, 5, 300, 900, 0.05, seed=913)
+        prefix = str(tmp_path / "db")
+        formats.write_index(prefix, names, seqs)
+        fq = str(tmp_path / "r.fq")
+        synth.write_fastq(fq, _chimeric_reads(seqs, 7000, rng, with_n=False))
+        args = ["-i", fq, "-t_db", prefix, "-mem_mode"]
+    ref, plain = str(tmp_path / "ref"), str(tmp_path / "plain")
+    subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([KMA] + args[:-1] + ["-o", plain, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert open(ref + ".res").read() != open(plain + ".res").read()
+    for name, pre, env in (("one", [], {"KMAHIP_MAP_ONE_BATCH": "1"}), ("many", [], {"KMAHIP_MAP_BATCH": "777"}),
+                           ("ranks", ["-gpus", "3"], {"KMAHIP_COMM": "shm", "KMAHIP_SHARE_GPU": "1"})):
+        got = str(tmp_path / name)
+        _run(pre + args + ["-o", got], env=env)
+        for ext, opener in ((".res", open), (".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
+            assert opener(got + ext, "rb").read() == opener(ref + ext, "rb").read(), (name, ext)
+    if mode == "1t1":
+        m1, m2, _ = synth.make_pairs(synth.make_gene_db(n_families=40, variants=5, seed=77)[1], 200, seed=9)
+        synth.write_fastq(str(tmp_path / "r1.fq"), list(m1), prefix="p")
+        synth.write_fastq(str(tmp_path / "r2.fq"), list(m2), prefix="p")
+        assert _run(["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-1t1", "-mem_mode", "-o", str(tmp_path / "x")], ok=False).returncode != 0
+
+
 def test_mt1_with_paired_input_equals_the_reference(tmp_path):
     """`-Mt1 n -ipe r1 r2` (printFsa_pairMt1, mt1.c:61-83): the mates of a couple are records of their own, the second one reverse
     complemented; a mate that lost its partner to the trimming is a record as it is. One batch, batch by batch, three ranks."""
