@@ -399,7 +399,6 @@ int main(int argc, char **argv) {
 	if(lc && chain) { fprintf(stderr, "kmahip_map: -lc needs -1t1 (the chain finder's length-corrected anchors are not built)\n"); return 2; }
 	if(kmahip_set_conclave_lc(lc)) return 1;
 	if(mem_mode && !mt1) {          /* (runKMA_Mt1 comes before runKMA_MEM, kma.c:1598-1623: -Mt1 leaves -mem_mode without effect) */
-		if(input2) { fprintf(stderr, "kmahip_map: -mem_mode with paired input is not built (update_Scores_pe_MEM)\n"); return 2; }
 		if(kmahip_set_mem_mode(1)) return 1;
 	}
 	if(pe_chain) chain = 0;

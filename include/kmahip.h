@@ -281,8 +281,9 @@ int kmahip_set_conclave_lc(int on);
 /* `-mem_mode` (runKMA_MEM instead of runKMA, kma.c:1619-1623, runkma.c:910-1250): ConClave is based on the template finder's own
  * scores -- a stage-2 record is the frag_raw record (its templates as the hits, each spanning its template, the k-mer score as the
  * read score; update_Scores_MEM updatescores.c:31-67), no alignment happens before ConClave; stage 3c aligns every read against the
- * template ConClave gave it as ever. One setting per process, read by the single-end run entry points (kmahip_run_se, kmahip_run_chain,
- * the sessions, the sharded runs); paired runs refuse it (update_Scores_pe_MEM is not built). */
+ * template ConClave gave it as ever. A couple of a paired stream -- a first record without a list, then its mate with the templates --
+ * is one record with both scores added up (update_Scores_pe_MEM :69-107, runkma.c:1090-1134). One setting per process, read by the
+ * whole-run entry points (kmahip_run_se / _pe / _chain, the sessions, the sharded runs). */
 int kmahip_set_mem_mode(int on);
 int kmahip_res_rows(const kmahip_db *db, const uint64_t *w_scores, double evalue, double scoreT,
                     kmahip_res_row *rows, int64_t cap, int64_t *n_rows);

@@ -86,7 +86,70 @@ __global__ __launch_bounds__(256) void mem_hits_kernel(int64_t n, int k, const i
 	h.n_hits[r] = (int32_t) (e - o); h.best_score[r] = score;
 	if(h.rc) h.rc[r] = (fl & 16) != 0;          // (the record holds the read as stage 2 passed it on)
 }
+// the records of a paired stream (runkma.c:1090-1134, update_Scores_pe_MEM updatescores.c:69-107): a couple -- a first record without a
+// list, then its mate with the templates -- is one frag_raw record with both mates' scores added up (negated there: two reads); any other
+// record is a single one. Outputs in the layout of kmahip_launch_align_pe (pe_records_kernel reads them): kind 1 = couple, hits at the
+// second slot's list; 0 = every present record by itself.
+__global__ __launch_bounds__(256) void mem_hits_pe_kernel(int64_t np, int k, const int32_t *len, kmahip_pe_recs R, const int32_t *tlen, kmahip_hits h, int32_t *kind,
+                                                           unsigned long long *AS, unsigned long long *US) {
+	const int64_t j = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(j >= np) return;
+	const int64_t r0 = 2 * j, r1 = r0 + 1;
+	int64_t nl[2];
+	int L[2];
+	for(int x = 0; x < 2; ++x) {
+		const int64_t r = r0 + x;
+		const bool here = R.mate[r] >= 0;
+		h.n_hits[r] = 0; h.best_score[r] = 0; h.flag[r] = R.flag[r];
+		if(h.rc) h.rc[r] = here && R.rc[r] != 0;
+		nl[x] = here ? R.R_off[r + 1] - R.R_off[r] : 0;
+		L[x] = here ? len[2 * j + R.mate[r]] : 0;
+	}
+	auto file = [&](int64_t o, int64_t n, int score) {
+		for(int64_t t = o; t < o + n; ++t) {
+			const int tm = R.T[t];
+			h.tmpl[t] = tm; h.score[t] = score; h.start[t] = 0; h.end[t] = tlen[abs(tm)];
+			if(AS) atomicAdd(&AS[abs(tm)], (unsigned long long) score);
+		}
+		if(n == 1 && US) atomicAdd(&US[abs(R.T[o])], (unsigned long long) score);
+	};
+	int kd = 0;
+	if(R.mate[r0] >= 0 && R.mate[r1] >= 0 && nl[0] == 0 && nl[1] > 0) {
+		if(L[0] >= k) {
+			const int s0 = abs(R.rc_flag[r0]), s1 = abs(R.rc_flag[r1]);
+			if(s1 && L[1] >= k) {
+				kd = 1;
+				file(R.R_off[r1], nl[1], s0 + s1);
+				h.n_hits[r0] = h.n_hits[r1] = (int32_t) nl[1]; h.best_score[r0] = h.best_score[r1] = s0 + s1;
+			} else {          // (the mate too short for a k-mer: the first record is filed singly, with the list its mate brought)
+				kd = 3;
+				file(R.R_off[r1], nl[1], s0);
+				h.n_hits[r0] = (int32_t) nl[1]; h.best_score[r0] = s0;
+			}
+		}
+	} else {
+		for(int x = 0; x < 2; ++x) {
+			const int64_t r = r0 + x;
+			if(nl[x] == 0 || L[x] < k) continue;
+			const int s = abs(R.rc_flag[r]);
+			file(R.R_off[r], nl[x], s);
+			h.n_hits[r] = (int32_t) nl[x]; h.best_score[r] = s;
+		}
+	}
+	kind[j] = kd;
+}
+
 }  // namespace
+
+int kmahip_stage3a_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_pe_recs *recs, const kmahip_params *p, kmahip_hits *out, int32_t *pe_kind, hipStream_t stream) {
+	if(!g_mem_mode) return kmahip_launch_align_pe(db, ws, reads, recs, p, out, pe_kind, stream);
+	if(!db->dev.tlen) { kmahip_set_error("index has no .length.b"); return KMAHIP_EINVAL; }
+	const int64_t np = reads->n_reads / 2;
+	if(np) hipLaunchKernelGGL(mem_hits_pe_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, np, (int) db->info.kmersize, reads->len, *recs, db->dev.tlen, *out, pe_kind,
+	                          (unsigned long long *) out->alignment_scores, (unsigned long long *) out->uniq_alignment_scores);
+	HIP_TRY(hipGetLastError());
+	return KMAHIP_OK;
+}
 
 int kmahip_stage3a_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, const kmahip_cands *cands, const kmahip_params *p, kmahip_hits *out, hipStream_t stream) {
 	if(!g_mem_mode) return kmahip_launch_align_se(db, ws, reads, cands, p, out, stream);
@@ -522,7 +585,6 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	   (!batch->pair && batch->reads.n_reads > 0)) {
 		kmahip_set_error("null argument"); return KMAHIP_EINVAL;
 	}
-	if(g_mem_mode) { kmahip_set_error("-mem_mode with paired input is not built (update_Scores_pe_MEM)"); return KMAHIP_EINVAL; }
 	const kmahip_reads &R = batch->reads;
 	const int64_t n = R.n_reads;
 	if(n < 0 || n > 0x7ffffff0ll || R.seq_words < 0 || R.N_total < 0) { kmahip_set_error("bad batch size"); return KMAHIP_EINVAL; }
@@ -685,13 +747,13 @@ static int run_pe_impl(kmahip_db *db, kmahip_ws *ws, const kmahip_read_batch *ba
 	for(;;) {
 		bool again = false;
 		if(np > 0) {
-			if((rc = kmahip_launch_align_pe(db, ws, &dP, &recs, p, &ph, kind, s))) return rc;
+			if((rc = kmahip_stage3a_pe(db, ws, &dP, &recs, p, &ph, kind, s))) return rc;
 			HIP_TRY(hipStreamSynchronize(s));
 			again = ws_status(ws, nullptr) == 3;
 		}
 		stamp("stage 3a of the pairs");
 		if(ns > 0 && !again) {
-			if((rc = kmahip_launch_align_se(db, ws, &dS, &cd, p, &sh, s))) return rc;
+			if((rc = kmahip_stage3a_se(db, ws, &dS, &cd, p, &sh, s))) return rc;
 			HIP_TRY(hipStreamSynchronize(s));
 			again = ws_status(ws, nullptr) == 3;
 		}

@@ -363,7 +363,7 @@ def test_lc_with_1t1_equals_the_reference(tmp_path):
     assert _run(["-i", fq, "-t_db", prefix, "-lc", "-o", str(tmp_path / "x")], ok=False).returncode != 0      # (the chain finder's -lc is not built: refused)
 
 
-@pytest.mark.parametrize("mode", ["1t1", "default"])
+@pytest.mark.parametrize("mode", ["1t1", "default", "pe_p", "pe_default"])
 def test_mem_mode_equals_the_reference(tmp_path, mode):
     """-mem_mode (runKMA_MEM, runkma.c:910-1250): ConClave on the template finder's own scores, no alignment before it -- the `.res`
     scores are sums of k-mer scores and differ from the plain run's. -1t1 on reads with indels and N's, the default mode on reads that
@@ -374,6 +374,10 @@ def test_mem_mode_equals_the_reference(tmp_path, mode):
     if mode == "1t1":
         prefix, fq = _case(tmp_path, n=9000)
         args = ["-i", fq, "-t_db", prefix, "-1t1", "-mem_mode"]
+    elif mode.startswith("pe"):          # couples (one record with both scores, update_Scores_pe_MEM), foreign mates, mates filed singly -- and, in the default mode, in pieces
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
+        prefix, r1, r2 = _pe_case(tmp_path, n_pairs=5000, chimeras=True)
+        args = ["-ipe", r1, r2, "-t_db", prefix] + (["-apm", "p", "-1t1"] if mode == "pe_p" else []) + ["-mem_mode"]
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_oracle_golden import _chimeric_reads
@@ -395,11 +399,6 @@ def test_mem_mode_equals_the_reference(tmp_path, mode):
         _run(pre + args + ["-o", got], env=env)
         for ext, opener in ((".res", open), (".fsa", open), (".aln", open), (".frag.gz", gzip.open)):
             assert opener(got + ext, "rb").read() == opener(ref + ext, "rb").read(), (name, ext)
-    if mode == "1t1":
-        m1, m2, _ = synth.make_pairs(synth.make_gene_db(n_families=40, variants=5, seed=77)[1], 200, seed=9)
-        synth.write_fastq(str(tmp_path / "r1.fq"), list(m1), prefix="p")
-        synth.write_fastq(str(tmp_path / "r2.fq"), list(m2), prefix="p")
-        assert _run(["-ipe", str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-t_db", prefix, "-1t1", "-mem_mode", "-o", str(tmp_path / "x")], ok=False).returncode != 0
 
 
 def test_mt1_with_paired_input_equals_the_reference(tmp_path):

@@ -95,6 +95,8 @@ def main():
                 opts += ["-reward", "2", "-gapopen", "6", "-gapextend", "2", "-transition", "2", "-transversion", "5", "-per", "11"]
             if rng.random() < 0.3:
                 opts += ["-1t1"]
+            if rng.random() < 0.3:
+                opts += ["-mem_mode"]
             args = inp + ["-t_db", prefix] + opts
             ref, got = os.path.join(tmp, "ref"), os.path.join(tmp, "got")
             subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
