@@ -198,6 +198,58 @@ def test_oracle_conclave_matches_res_and_frags(golden_se):
     assert seen > 900 and rows > 50
 
 
+def test_oracle_conclave_in_mem_mode_matches_res(golden_se):
+    """`-mem_mode` (runKMA_MEM, runkma.c:1090-1134): a stage-2 record is the frag_raw record -- its templates as the hits, each from 0
+    to the template's length, the k-mer score as the read score, added to the ConClave vectors by update_Scores_MEM (updatescores.c:
+    31-67) -- then ConClave and the `.res` statistics as ever: Score, Expected, Template_length, q_value and p_value of every row of the
+    reference's own file (tests/golden/se/mem.res, make_golden_mem.py), and the template and tie count of every `.frag.gz` row"""
+    import gzip
+    g = golden_se
+    db = oracle.OracleDB(g["prefix"])
+    b = g["batch"]
+    rc_flag, flag, T_off, T = db.scan_se(b)
+    tlen = formats.read_lengths(g["prefix"])
+    n = b.n
+    n_hits = np.zeros(n, np.int32); score = np.abs(rc_flag).astype(np.int32)
+    AS = np.zeros(len(tlen), np.uint64); US = np.zeros(len(tlen), np.uint64)
+    for r in range(n):
+        lst = T[T_off[r]:T_off[r + 1]]
+        if len(lst) == 0 or b.length[r] < 16:
+            score[r] = 0
+            continue
+        n_hits[r] = len(lst)
+        for t in lst:
+            AS[abs(int(t))] += np.uint64(score[r])
+        if len(lst) == 1:
+            US[abs(int(lst[0]))] += np.uint64(score[r])
+    start = np.zeros(len(T), np.int32)
+    end = tlen[np.abs(T)].astype(np.int32) if len(T) else np.zeros(0, np.int32)
+    cc = oracle.conclave(n_hits, score, b.length, np.zeros(n, np.int32), T_off[:-1], T, start, end, AS, US, tlen)
+    st = oracle.res_stats(cc["w_scores"], tlen)
+    names = golden_util.template_names("se")
+    want = {}
+    for line in open(os.path.join(g["dir"], "mem.res")):
+        if not line.startswith("#"):
+            c = [x.strip() for x in line.rstrip("\n").split("\t")]
+            want[c[0]] = (int(c[1]), int(c[2]), int(c[3]), c[9], c[10])
+    assert len(want) > 50 and want != golden_util.load_res("se")
+    rows = 0
+    for t in range(1, len(tlen)):
+        if cc["w_scores"][t] and names[t - 1] in want:
+            rows += 1
+            got = (int(cc["w_scores"][t]), int(st["expected"][t]), int(tlen[t]), "%.2f" % st["q_value"][t], "%4.1e" % st["p_value"][t])
+            assert got == want[names[t - 1]], (names[t - 1], got, want[names[t - 1]])
+    assert rows == len(want)
+    hdrs = {r["hdr"].rstrip(b"\0").decode(): i for i, r in enumerate(g["s1"])}
+    seen = 0
+    for line in gzip.open(os.path.join(g["dir"], "mem.frag.gz"), "rt"):
+        c = line.rstrip("\n").split("\t")
+        i = hdrs[c[6]]
+        seen += 1
+        assert int(c[1]) == n_hits[i] and c[5] == names[abs(int(cc["tmpl"][i])) - 1], (c[6], c[1], c[5])
+    assert seen > 900
+
+
 def test_oracle_conclave_matches_res_and_frags_long_reads(golden_long):
     res, cc, st, tlen = _oracle_conclave_se(golden_long)
     hdrs = [r["hdr"].rstrip(b"\0").decode() for r in golden_long["s1"]]

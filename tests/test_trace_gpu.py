@@ -327,6 +327,24 @@ def test_c_program_from_fastq_to_all_three_output_files(golden_se, tmp_path):
     assert gzip.open(out + ".frag.gz", "rb").read() == gzip.open(os.path.join(g["dir"], "out.frag.gz"), "rb").read()
 
 
+def test_host_program_in_mem_mode_matches_the_committed_reference_files(golden_se, tmp_path):
+    """`-1t1 -mem_mode` on the committed single-end fixture against tests/golden/se/mem.* (the compiled reference's files, written by
+    tests/golden/make_golden_mem.py): ConClave on the template finder's scores (kmahip_set_mem_mode), then stage 3c as ever"""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    g = golden_se
+    for env in ({"KMAHIP_MAP_ONE_BATCH": "1"}, {"KMAHIP_MAP_BATCH": "300"}):
+        out = str(tmp_path / ("out_" + next(iter(env))))
+        subprocess.run([os.path.join(root, "examples", "kmahip_map"), "-i", os.path.join(g["dir"], "reads.fq.gz"), "-t_db", g["prefix"], "-o", out, "-1t1", "-mem_mode"],
+                       check=True, stderr=subprocess.DEVNULL, env=dict(os.environ, **env))
+        assert open(out + ".res", "rb").read() == open(os.path.join(g["dir"], "mem.res"), "rb").read()
+        assert open(out + ".fsa", "rb").read() == gzip.open(os.path.join(g["dir"], "mem.fsa.gz")).read()
+        assert gzip.open(out + ".frag.gz", "rb").read() == gzip.open(os.path.join(g["dir"], "mem.frag.gz"), "rb").read()
+
+
 def test_one_call_paired_run_matches_reference_files(golden_pe, tmp_path):
     """kmahip_run_pe on the two mate files as kmahip_ingest_* reads them: the `.res` and consensus FASTA of `kma -ipe r1 r2 -apm p -1t1`."""
     import gzip
