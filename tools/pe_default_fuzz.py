@@ -82,9 +82,13 @@ def main():
     for seed in range(n):
         with tempfile.TemporaryDirectory() as tmp:
             prefix, (r1, r2, ilv), rng = case(tmp, seed)
-            inp = ["-int", ilv] if seed % 4 == 3 else ["-ipe", r1, r2]
+            single = len(sys.argv) > 2 and sys.argv[2] == "se"          # (second argument "se": the interleaved file as single-end input -- -1t1 / default mode, -mem_mode, -lc, -and)
+            inp = ["-i", ilv] if single else (["-int", ilv] if seed % 4 == 3 else ["-ipe", r1, r2])
             opts = []
-            opts += [[], ["-apm", "p"], ["-apm", "u"], ["-pm", "p"], ["-fpm", "p"]][int(rng.integers(0, 5))]
+            if not single:
+                opts += [[], ["-apm", "p"], ["-apm", "u"], ["-pm", "p"], ["-fpm", "p"]][int(rng.integers(0, 5))]
+            elif rng.random() < 0.3:
+                opts += ["-and"]
             if rng.random() < 0.4:
                 opts += ["-mrc", "0.6"]
             if rng.random() < 0.4:
@@ -97,6 +101,8 @@ def main():
                 opts += ["-1t1"]
             if rng.random() < 0.3:
                 opts += ["-mem_mode"]
+            if single and "-1t1" in opts and rng.random() < 0.4:
+                opts += ["-lc"]
             args = inp + ["-t_db", prefix] + opts
             ref, got = os.path.join(tmp, "ref"), os.path.join(tmp, "got")
             subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
