@@ -317,13 +317,14 @@ int main(int argc, char **argv) {
 		}
 		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
-			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE) or u (union, save_kmers_unionPair / alnFragsUnionPE); f is not built\n"); return 1; }
-			apm = argv[++a][0] == 'p' ? 1 : 2;
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE), u (union, save_kmers_unionPair / alnFragsUnionPE) or, with -mem_mode, f (forced, save_kmers_forcePair)\n"); return 1; }
+			apm = argv[++a][0] == 'p' ? 1 : (argv[a][0] == 'u' ? 2 : 3);
 			pm = fpm = 0;
 		}
 		else if(!strcmp(o, "-pm") || !strcmp(o, "-fpm")) {                                      /* kma.c:437-465: the two stages apart */
-			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u')) { fprintf(stderr, "kmahip_map: %s takes p or u; f is not built\n", o); return 1; }
-			if(o[1] == 'p') pm = argv[++a][0] == 'p' ? 1 : 2; else fpm = argv[++a][0] == 'p' ? 1 : 2;
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: %s takes p, u or (with -mem_mode) f\n", o); return 1; }
+			const int v = argv[++a][0] == 'p' ? 1 : (argv[a][0] == 'u' ? 2 : 3);
+			if(o[1] == 'p') pm = v; else fpm = v;
 		}
 		else if(!strcmp(o, "-t")) {                                                             /* kma.c:529: a value is optional */
 			if(a + 1 < argc && argv[a + 1][0] != '-') threads = (int) need_int(argc, argv, &a, o);
@@ -389,9 +390,12 @@ int main(int argc, char **argv) {
 	/* like the reference: without -1t1 (and without -Mt1) the template finder is save_kmers_chain, reads may map in pieces */
 	if(!one2one && !mt1) chain = 1;
 	{	/* (without -apm the reference pairs by union, kma.c:206; -apm sets both stages, -pm stage 2 and -fpm stage 3a alone) */
-		int s2 = apm == 1 ? 0 : 1, s3 = s2;
-		if(pm) s2 = pm == 1 ? 0 : 1;
-		if(fpm) s3 = fpm == 1 ? 0 : 1;
+		int s2 = apm == 1 ? 0 : (apm == 3 ? 2 : 1), s3 = s2;          /* 0 p, 1 u, 2 f */
+		if(pm) s2 = pm == 1 ? 0 : (pm == 3 ? 2 : 1);
+		if(fpm) s3 = fpm == 1 ? 0 : (fpm == 3 ? 2 : 1);
+		/* forced pairing: stage 2 is built (save_kmers_forcePair), alnFragsForcePE is not -- under -mem_mode no alnFragsPE runs at all */
+		if(s3 == 2 && input2 && !mem_mode && !mt1) { fprintf(stderr, "kmahip_map: forced pairing (-apm f / -fpm f) needs -mem_mode: alnFragsForcePE is not built\n"); return 2; }
+		if(s3 == 2) s3 = 1;
 		par.apm = s2 | ((s3 + 1) << 4);          /* kmahip_params.apm: bits 0-1 stage 2, bits 4-5 stage 3a + 1 */
 	}
 	/* paired input without -1t1: couples are paired as ever, a record that lost its mate goes to the chain finder (savekmers.c:196-200) */

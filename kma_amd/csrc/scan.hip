@@ -1385,6 +1385,67 @@ __global__ __launch_bounds__(256) void pair_union_kernel(const PairArgs P) {
 	}
 }
 
+// `-apm f` / `-pm f`: save_kmers_forcePair, savekmers.c:3779-3864, with getFirstForce (:1254) / getSecondBestForce (:1275). Mate 1's
+// candidates of both strands with their scores; those that mate 2 also hits on the OTHER strand, at the best sum of the two scores, are
+// the couple's templates -- or there is no record at all: forced pairing files nothing singly. Both records of a couple carry the sum
+// (negated when the list ends on a reverse template). Same inputs and outputs as pair_penalty_kernel.
+__global__ __launch_bounds__(256) void pair_force_kernel(const PairArgs P) {
+	const int64_t p = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if(p >= P.n_pairs) return;
+	const ScanArgs &A = P.S;
+	const int k = (int) A.db.kmersize;
+	PList L[4];
+	int hc[4];
+	for(int x = 0; x < 4; ++x) {
+		const int64_t it = 4 * p + x;
+		L[x].n = max(0, A.item_n[it]); L[x].t = A.pool + A.item_off[it]; L[x].s = A.pool_sc + A.item_off[it];
+		hc[x] = A.item_score[it];
+	}
+	const PList &F1 = L[0], &R1 = L[1], &F2 = L[2], &R2 = L[3];
+	const int hc1 = max(hc[0], hc[1]), hc2 = max(hc[2], hc[3]);
+	const int len1 = A.len[2 * p], len2 = A.len[2 * p + 1];
+	int m[2] = {-1, -1}, rcv[2] = {0, 0}, sc[2] = {0, 0}, fl[2] = {0, 0}, nn[2] = {0, 0};
+	int64_t of[2] = {0, 0};
+	const int n1 = F1.n + R1.n;
+	if(hc1 && hc2 && n1) {          // (without a hit of mate 1 the reference does not even scan mate 2: no record either way)
+		const int64_t base = (int64_t) atomicAdd(&A.counters[C_PPOOL], (unsigned long long) n1);
+		if(base + n1 > P.ppool_cap) { atomicMax(&A.counters[C_STATUS], 1ull); return; }
+		int32_t *regT = P.ppool + base;
+		// getSecondBestForce over getFirstForce's list (mate 1's forward candidates, then its reverse ones as negative ids)
+		int best = 0, hits = 0;
+		for(int i = 0; i < n1; ++i) {
+			const bool fw = i < F1.n;
+			const int t = fw ? F1.t[i] : R1.t[i - F1.n], s1 = fw ? F1.s[i] : R1.s[i - F1.n];
+			const int s2 = fw ? plist_find(R2, t) : plist_find(F2, t);
+			if(!s2) continue;
+			const int sum = s1 + s2;
+			if(best < sum) { best = sum; hits = 0; regT[hits++] = fw ? t : -t; }
+			else if(best == sum) regT[hits++] = fw ? t : -t;
+		}
+		// (CompDNA.seqlen is unsigned: the coverage test wraps like the reference's)
+		if(best && (k <= best || (unsigned) len1 + (unsigned) len2 - (unsigned) best < (unsigned) (best * k))) {
+			int o1 = len1 >= k, o2 = len2 >= k;      // get_kmers_for_pair leaves a scanned mate reverse-complemented
+			int flag = 67, flag_r = 131;
+			const int s = regT[hits - 1] < 0 ? -best : best;
+			if(0 < regT[0]) {
+				flag |= 32; flag_r |= 16; o1 ^= 1;
+				m[0] = 0; rcv[0] = o1; sc[0] = s; fl[0] = flag; nn[0] = 0;
+				m[1] = 1; rcv[1] = o2; sc[1] = s; fl[1] = flag_r; nn[1] = hits; of[1] = base;
+			} else {
+				flag |= 16; flag_r |= 32; o2 ^= 1;
+				for(int i = 0; i < hits; ++i) regT[i] = -regT[i];
+				m[0] = 1; rcv[0] = o2; sc[0] = s; fl[0] = flag_r; nn[0] = 0;
+				m[1] = 0; rcv[1] = o1; sc[1] = s; fl[1] = flag; nn[1] = hits; of[1] = base;
+			}
+		}
+	}
+	for(int x = 0; x < 2; ++x) {
+		const int64_t r = 2 * p + x;
+		P.r_mate[r] = m[x]; P.r_rc[r] = rcv[x]; P.r_score[r] = sc[x]; P.r_flag[r] = fl[x];
+		P.r_n[r] = (m[x] >= 0) ? nn[x] : 0; P.r_off[r] = of[x];
+	}
+}
+
 // generic CSR compaction of per-record lists: counts -> offsets (3 kernels)
 __global__ __launch_bounds__(CB) void rec_count_kernel(const int32_t *cnt, int64_t n, int64_t *blk_sums) {
 	__shared__ int64_t red[CB];
@@ -1845,6 +1906,7 @@ int kmahip_launch_scan_pe(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *read
 	P.r_mate = out->mate; P.r_rc = out->rc; P.r_score = out->rc_flag; P.r_flag = out->flag;
 	P.r_off = (int64_t *) ws->pe_rec; P.r_n = (int32_t *) (P.r_off + ws->cap_reads + 2);
 	if((p->apm & 3) == 1) hipLaunchKernelGGL(pair_union_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
+	else if((p->apm & 3) == 2) hipLaunchKernelGGL(pair_force_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
 	else hipLaunchKernelGGL(pair_penalty_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, stream, P);
 	const unsigned cgrid = (unsigned) ((n + CB - 1) / CB);
 	hipLaunchKernelGGL(rec_count_kernel, dim3(cgrid), dim3(CB), 0, stream, P.r_n, n, ws->blk_sums);

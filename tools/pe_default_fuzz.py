@@ -103,6 +103,8 @@ def main():
                 opts += ["-mem_mode"]
             if single and "-1t1" in opts and rng.random() < 0.4:
                 opts += ["-lc"]
+            if not single and "-mem_mode" in opts and rng.random() < 0.5:          # forced pairing: stage 2 only is built, which is all -mem_mode runs
+                opts = [o for i, o in enumerate(opts) if o not in ("-apm", "-pm", "-fpm") and (i == 0 or opts[i - 1] not in ("-apm", "-pm", "-fpm"))] + ["-apm", "f"]
             args = inp + ["-t_db", prefix] + opts
             ref, got = os.path.join(tmp, "ref"), os.path.join(tmp, "got")
             subprocess.run([KMA] + args + ["-o", ref, "-t", "1"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
