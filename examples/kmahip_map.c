@@ -317,12 +317,12 @@ int main(int argc, char **argv) {
 		}
 		else if(!strcmp(o, "-o") && a + 1 < argc) out = argv[++a];
 		else if(!strcmp(o, "-apm")) {                                                           /* kma.c:472: p, u or f */
-			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE), u (union, save_kmers_unionPair / alnFragsUnionPE) or, with -mem_mode, f (forced, save_kmers_forcePair)\n"); return 1; }
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: -apm takes p (pairing reward, save_kmers_penaltyPair / alnFragsPenaltyPE), u (union, save_kmers_unionPair / alnFragsUnionPE) ; f (forced) is read and refused below\n"); return 1; }
 			apm = argv[++a][0] == 'p' ? 1 : (argv[a][0] == 'u' ? 2 : 3);
 			pm = fpm = 0;
 		}
 		else if(!strcmp(o, "-pm") || !strcmp(o, "-fpm")) {                                      /* kma.c:437-465: the two stages apart */
-			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: %s takes p, u or (with -mem_mode) f\n", o); return 1; }
+			if(a + 1 >= argc || (argv[a + 1][0] != 'p' && argv[a + 1][0] != 'u' && argv[a + 1][0] != 'f')) { fprintf(stderr, "kmahip_map: %s takes p or u (f is read and refused below)\n", o); return 1; }
 			const int v = argv[++a][0] == 'p' ? 1 : (argv[a][0] == 'u' ? 2 : 3);
 			if(o[1] == 'p') pm = v; else fpm = v;
 		}
@@ -393,9 +393,11 @@ int main(int argc, char **argv) {
 		int s2 = apm == 1 ? 0 : (apm == 3 ? 2 : 1), s3 = s2;          /* 0 p, 1 u, 2 f */
 		if(pm) s2 = pm == 1 ? 0 : (pm == 3 ? 2 : 1);
 		if(fpm) s3 = fpm == 1 ? 0 : (fpm == 3 ? 2 : 1);
-		/* forced pairing: stage 2 is built (save_kmers_forcePair), alnFragsForcePE is not -- under -mem_mode no alnFragsPE runs at all */
-		if(s3 == 2 && input2 && !mem_mode && !mt1) { fprintf(stderr, "kmahip_map: forced pairing (-apm f / -fpm f) needs -mem_mode: alnFragsForcePE is not built\n"); return 2; }
-		if(s3 == 2) s3 = 1;
+		/* forced pairing: stage 2 is built (save_kmers_forcePair: kmahip_scan_pe with apm = 2, pinned on the reference's -s2 tap); the whole
+		 * run is not -- alnFragsForcePE is not built, and under -mem_mode a forced couple whose templates lie on both strands is filed with a
+		 * negative count (runkma.c:1124), which sends its reads through anker_rc in stage 3c */
+		if(s2 == 2 || s3 == 2) { fprintf(stderr, "kmahip_map: forced pairing (-apm f / -pm f / -fpm f) is not built beyond stage 2\n"); return 2; }
+
 		par.apm = s2 | ((s3 + 1) << 4);          /* kmahip_params.apm: bits 0-1 stage 2, bits 4-5 stage 3a + 1 */
 	}
 	/* paired input without -1t1: couples are paired as ever, a record that lost its mate goes to the chain finder (savekmers.c:196-200) */

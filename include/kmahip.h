@@ -77,8 +77,8 @@ typedef struct kmahip_params {
 	                       * stages apart (-pm x: save_kmers_pair only, -fpm x: alnFragsPE only, kma.c:437-465): bits 0-1 = stage 2 as
 	                       * above, bits 4-5 = stage 3a + 1 (0: the same as stage 2, 1: p, 2: u). Stage 2 also takes 2 = forced pairing
 	                       * (-apm f / -pm f: save_kmers_forcePair savekmers.c:3779 with getFirstForce / getSecondBestForce -- a couple on the
-	                       * templates both mates hit on opposite strands at the best summed score, or no record at all); stage 3a of
-	                       * forced pairing (alnFragsForcePE) is not built, so it goes with -mem_mode, where no stage 3a runs */
+	                       * templates both mates hit on opposite strands at the best summed score, or no record at all) -- for kmahip_scan_pe
+	                       * only: stage 3a of forced pairing (alnFragsForcePE) is not built */
 } kmahip_params;
 
 typedef struct kmahip_db_info {

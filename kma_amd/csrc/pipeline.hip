@@ -155,8 +155,9 @@ int kmahip_stage3a_se(kmahip_db *db, kmahip_ws *ws, const kmahip_reads *reads, c
 	if(!g_mem_mode) return kmahip_launch_align_se(db, ws, reads, cands, p, out, stream);
 	if(!db->dev.tlen) { kmahip_set_error("index has no .length.b"); return KMAHIP_EINVAL; }
 	const int64_t n = reads->n_reads;
-	// (a strand tie whose list ends on a forward template would be filed with a negative count and take anker_rc in stage 3c,
-	// runkma.c:1124: no template finder here writes such a list -- the reverse strand's templates come last)
+	// (a record with a negative score whose list ends on a forward template would be filed with a negative count and take anker_rc in
+	// stage 3c, runkma.c:1124: only forced pairing writes such a list, and the whole runs refuse it -- the single-end finders and the
+	// penalty / union pairing put the reverse strand's templates last)
 	if(n) hipLaunchKernelGGL(mem_hits_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, n, (int) db->info.kmersize, reads->len, cands->rc_flag, cands->flag, cands->T_off,
 	                         cands->T, db->dev.tlen, *out, (unsigned long long *) out->alignment_scores, (unsigned long long *) out->uniq_alignment_scores);
 	HIP_TRY(hipGetLastError());

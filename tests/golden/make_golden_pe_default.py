@@ -2,7 +2,7 @@
 """Expected files of the committed paired fixture (tests/golden/pe: r1.fq.gz, r2.fq.gz and the index) in the reference's DEFAULT mode --
 `kma -ipe r1 r2 -t_db db -o out -t 1`, no -1t1: couples by union pairing, the records that lost their mate through the chain finder --
 written next to the `-1t1 -apm p` ones: out_default.res, out_default.fsa.gz, out_default.frag.gz, s2_default.bin.gz (the `-s2` tap),
-s2_default_p.bin.gz (the `-s2` tap with `-apm p`).
+s2_default_p.bin.gz (the `-s2` tap with `-apm p`), s2_force.bin.gz (the `-s2` tap of `-apm f -1t1`: stage 2 of forced pairing).
 
     python3 tests/golden/make_golden_pe_default.py        (needs oracle/_ref/kma: `make -C oracle ref`)
 """
@@ -36,6 +36,10 @@ def main():
         s2p = subprocess.run(base + ["-apm", "p", "-s2"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
         with gzip.GzipFile(os.path.join(PE, "s2_default_p.bin.gz"), "wb", mtime=0) as g:
             g.write(s2p)
+        # (stage 2 of forced pairing, -apm f with -1t1: save_kmers_forcePair -- what kmahip_scan_pe restates with apm = 2)
+        s2f = subprocess.run(base + ["-apm", "f", "-1t1", "-s2"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        with gzip.GzipFile(os.path.join(PE, "s2_force.bin.gz"), "wb", mtime=0) as g:
+            g.write(s2f)
         shutil.copy(os.path.join(tmp, "out.res"), os.path.join(PE, "out_default.res"))
         for name, data in (("out_default.fsa.gz", open(os.path.join(tmp, "out.fsa"), "rb").read()),
                            ("out_default.frag.gz", gzip.open(os.path.join(tmp, "out.frag.gz")).read()), ("s2_default.bin.gz", s2)):

@@ -52,6 +52,28 @@ def test_pe_scan_matches_reference_s2_stream(golden_pe):
     assert got == golden_pe["s2_bytes"]
 
 
+def test_pe_scan_forced_pairing_matches_reference_s2_stream(golden_pe):
+    """stage 2 of `-apm f -1t1` (save_kmers_forcePair, savekmers.c:3779-3864: pair_force_kernel, kmahip_params.apm = 2): a couple on the
+    templates both mates hit on opposite strands at the best summed score, both records carrying the sum, or no record at all; the
+    records stage 1 filed singly go through save_kmers as ever. Rebuilt S2 stream against tests/golden/pe/s2_force.bin.gz. (The whole
+    run with forced pairing stays refused: alnFragsForcePE is not built.)"""
+    import gzip
+    import os
+    import oracle
+    from kma_amd import binding
+    g = golden_pe
+    db = binding.KmaHipDB(g["prefix"])
+    try:
+        db.params.apm = 2
+        pair_res, single_res = _device_results(g, db)
+    finally:
+        db.close()
+    idx = {id(r): i for i, r in enumerate(g["s1"])}
+    got = golden_util.pe_stream_from(g, lambda a, b: pair_res[idx[id(a)]], lambda r: single_res[idx[id(r)]], oracle.rc_packed)
+    want = gzip.open(os.path.join(g["dir"], "s2_force.bin.gz")).read()
+    assert sum(1 for v in pair_res.values() if len(v) == 2) > 500 and got == want
+
+
 @pytest.mark.parametrize("apm,tap", [(1, "s2_default.bin.gz"), (0, "s2_default_p.bin.gz")])
 def test_pe_scan_in_the_default_mode_matches_reference_s2_stream(golden_pe, apm, tap):
     """the S2 stream of `kma -ipe r1 r2 [-apm p]` WITHOUT -1t1 (tests/golden/make_golden_pe_default.py): the couples through

@@ -363,7 +363,7 @@ def test_lc_with_1t1_equals_the_reference(tmp_path):
     assert _run(["-i", fq, "-t_db", prefix, "-lc", "-o", str(tmp_path / "x")], ok=False).returncode != 0      # (the chain finder's -lc is not built: refused)
 
 
-@pytest.mark.parametrize("mode", ["1t1", "default", "pe_p", "pe_default", "pe_f", "pe_f_default"])
+@pytest.mark.parametrize("mode", ["1t1", "default", "pe_p", "pe_default"])
 def test_mem_mode_equals_the_reference(tmp_path, mode):
     """-mem_mode (runKMA_MEM, runkma.c:910-1250): ConClave on the template finder's own scores, no alignment before it -- the `.res`
     scores are sums of k-mer scores and differ from the plain run's. -1t1 on reads with indels and N's, the default mode on reads that
@@ -377,8 +377,7 @@ def test_mem_mode_equals_the_reference(tmp_path, mode):
     elif mode.startswith("pe"):          # couples (one record with both scores, update_Scores_pe_MEM), foreign mates, mates filed singly -- and, in the default mode, in pieces
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")], stdout=subprocess.DEVNULL)
         prefix, r1, r2 = _pe_case(tmp_path, n_pairs=5000, chimeras=True)
-        # (pe_f: forced pairing, save_kmers_forcePair -- stage 2 only is built, and under -mem_mode no alnFragsPE runs: CCMetagen's command line)
-        args = ["-ipe", r1, r2, "-t_db", prefix] + {"pe_p": ["-apm", "p", "-1t1"], "pe_default": [], "pe_f": ["-apm", "f", "-1t1", "-and"], "pe_f_default": ["-apm", "f"]}[mode] + ["-mem_mode"]
+        args = ["-ipe", r1, r2, "-t_db", prefix] + (["-apm", "p", "-1t1"] if mode == "pe_p" else []) + ["-mem_mode"]
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_oracle_golden import _chimeric_reads
