@@ -92,6 +92,11 @@ int orc_scan_pe_union(const orc_db *db, const orc_rewards *rw, int exhaustive,
                 const uint64_t *seq1, int len1, const int *N1, int nN1,
                 const uint64_t *seq2, int len2, const int *N2, int nN2,
                 orc_pe_rec out[2], int *T1, int *T2);
+/* ... and for stage 2 of forced pairing (-apm f) */
+int orc_scan_pe_force(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                const uint64_t *seq1, int len1, const int *N1, int nN1,
+                const uint64_t *seq2, int len2, const int *N2, int nN2,
+                orc_pe_rec out[2], int *T1, int *T2);
 
 /* ---- stage 3a (oracle/align.c) ------------------------------------------ */
 typedef struct orc_aligner orc_aligner;

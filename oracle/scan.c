@@ -459,6 +459,77 @@ int orc_scan_pe(const orc_db *db, const orc_rewards *rw, int exhaustive,
 	return ret;
 }
 
+/* `-apm f`: save_kmers_forcePair (savekmers.c:3779-3864) with getFirstForce (:1254) and getSecondBestForce (:1275). Mate 1's candidates
+ * of both strands go into the region list with their scores; mate 2 is scanned only if mate 1 had a hit; a region template that mate 2
+ * hits on the OTHER strand scores the sum, the best sums stay (in the order met). A couple is printed when the best sum reaches k or
+ * covers enough of the two reads -- both records with the sum, negated when the list ends on a reverse template (decided BEFORE the
+ * list is turned for a couple that starts on a reverse template) -- and nothing is printed otherwise. Same in / out as orc_scan_pe. */
+int orc_scan_pe_force(const orc_db *db, const orc_rewards *rw, int exhaustive,
+                      const uint64_t *seq1, int len1, const int *N1, int nN1,
+                      const uint64_t *seq2, int len2, const int *N2, int nN2,
+                      orc_pe_rec out[2], int *T1, int *T2) {
+	const int k = db->kmersize, D = db->DB_size;
+	(void) T2;
+	scan_ws *w = ws_new(db);
+	int *buf = malloc(sizeof(int) * (size_t) (8 * D + 32));
+	plist F1 = {0, buf, buf + D}, R1 = {0, buf + 2 * D, buf + 3 * D}, F2 = {0, buf + 4 * D, buf + 5 * D}, R2 = {0, buf + 6 * D, buf + 7 * D};
+	int hc1 = 0, hc2 = 0;
+	for(int m = 0; m < 2; ++m) {
+		const uint64_t *seq = m ? seq2 : seq1; const int len = m ? len2 : len1; const int *N = m ? N2 : N1; const int nN = m ? nN2 : nN1;
+		plist *F = m ? &F2 : &F1, *R = m ? &R2 : &R1;
+		if(len < k || (m && !hc1)) continue;          /* (savekmers.c:3797: without a hit of mate 1 the function returns before mate 2 is looked at) */
+		const int words = (len + 31) >> 5;
+		uint64_t *rs = calloc((size_t) words + 2, 8);
+		int *fN = malloc(sizeof(int) * (size_t) (2 * nN + 4)), *rN = fN + nN + 2;
+		fN[0] = nN; memcpy(fN + 1, N, sizeof(int) * (size_t) nN);
+		orc_rc(seq, len, fN, rs, rN);
+		int hf = 0, hr = 0;
+		scan_strand_x(db, rw, exhaustive, 0, seq, len, fN, &w->st, F->t, &F->n, F->s, &hf);
+		scan_strand_x(db, rw, exhaustive, 1, rs, len, rN, &w->st, R->t, &R->n, R->s, &hr);
+		if(m) hc2 = hf > hr ? hf : hr; else hc1 = hf > hr ? hf : hr;
+		free(rs); free(fN);
+	}
+	memset(out, 0, 2 * sizeof(orc_pe_rec));
+	int ret = 3;
+	if(hc1 && hc2) {
+		/* getFirstForce: the region list; getSecondBestForce over it */
+		int nreg = 0, *regT = T1, *regS = malloc(sizeof(int) * (size_t) (2 * D + 4));
+		for(int i = 0; i < F1.n; ++i) { regT[nreg] = F1.t[i]; regS[nreg++] = F1.s[i]; }
+		for(int i = 0; i < R1.n; ++i) { regT[nreg] = -R1.t[i]; regS[nreg++] = R1.s[i]; }
+		int best = 0, hits = 0;
+		for(int i = 0; i < nreg; ++i) {
+			const int rt = regT[i];
+			int sc = rt > 0 ? plist_find(&R2, rt) : plist_find(&F2, -rt);
+			if(!sc) continue;
+			sc += regS[i];
+			if(best < sc) { best = sc; hits = 1; regT[0] = rt; }
+			else if(best == sc) regT[hits++] = rt;
+		}
+		if(best && (k <= best || (unsigned) len1 + (unsigned) len2 - (unsigned) best < (unsigned) (best * k))) {
+			int o1 = len1 >= k, o2 = len2 >= k, flag = 67, flag_r = 131;
+			const int s = regT[hits - 1] < 0 ? -best : best;
+			#define EMIT(slot, MATE, RC, SCORE, FLAG, TP, NT) do { out[slot].present = 1; out[slot].mate = MATE; out[slot].rc = RC; \
+				out[slot].rc_flag = SCORE; out[slot].flag = FLAG; out[slot].nT = NT; out[slot].T = TP; } while(0)
+			if(0 < regT[0]) {
+				flag |= 32; flag_r |= 16; o1 ^= 1;
+				EMIT(0, 0, o1, s, flag, regT, 0);
+				EMIT(1, 1, o2, s, flag_r, regT, hits);
+			} else {
+				flag |= 16; flag_r |= 32; o2 ^= 1;
+				for(int i = 0; i < hits; ++i) regT[i] = -regT[i];
+				EMIT(0, 1, o2, s, flag_r, regT, 0);
+				EMIT(1, 0, o1, s, flag, regT, hits);
+			}
+			#undef EMIT
+			ret = 0;
+		}
+		free(regS);
+	}
+	free(buf);
+	ws_free(w);
+	return ret;
+}
+
 /* `-apm u`, and what `-ipe` means without -apm (kma.c:206): save_kmers_unionPair (savekmers.c:3367-3570) with getF_Best / getR_Best
  * (:1648-1762). Mate 1 keeps the templates of either strand that reach its best score; mate 2 its own best set -- and where a template
  * of mate 1's set is in mate 2's set on the OTHER strand (getR_Best leaves a score standing only for mate 2's best ones, so "is

@@ -175,7 +175,7 @@ class OracleDB:
                                  _p(out["alignment_scores"]), _p(out["uniq_alignment_scores"]))
         return out
 
-    def scan_pe(self, seq1, len1, N1, seq2, len2, N2, exhaustive=0, union=False):
+    def scan_pe(self, seq1, len1, N1, seq2, len2, N2, exhaustive=0, union=False, force=False):
         """One pair (padded u64 word arrays + N position arrays) -> list of up to two record dicts in stream order.
         union: the union pairing (-apm u, and `-ipe` without -apm) instead of the pairing penalty (-apm p)"""
         import struct
@@ -186,7 +186,7 @@ class OracleDB:
         s2 = np.ascontiguousarray(np.concatenate([seq2, np.zeros(2, np.uint64)]))
         n1 = np.ascontiguousarray(N1 if len(N1) else np.zeros(1, np.int32), np.int32)
         n2 = np.ascontiguousarray(N2 if len(N2) else np.zeros(1, np.int32), np.int32)
-        fn = lib().orc_scan_pe_union if union else lib().orc_scan_pe
+        fn = lib().orc_scan_pe_force if force else (lib().orc_scan_pe_union if union else lib().orc_scan_pe)          # (force: stage 2 of -apm f)
         fn.restype = C.c_int
         fn.argtypes = lib().orc_scan_pe.argtypes
         ret = fn(self.h, C.byref(self.rw), exhaustive, _p(s1), len1, _p(n1), len(N1),

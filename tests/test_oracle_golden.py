@@ -136,6 +136,25 @@ def test_oracle_pe_scan_matches_s2_tap_bytes(golden_pe):
     assert got == golden_pe["s2_bytes"]
 
 
+def test_oracle_pe_scan_forced_pairing_matches_s2_tap_bytes(golden_pe):
+    """stage 2 of `-ipe r1 r2 -apm f -1t1` (save_kmers_forcePair: oracle/scan.c orc_scan_pe_force) against the reference's `-s2` tap
+    (tests/golden/pe/s2_force.bin.gz): couples or nothing; the records stage 1 filed singly through save_kmers"""
+    import gzip
+    db = oracle.OracleDB(golden_pe["prefix"])
+
+    def single(r):
+        codes = formats.unpack_words(r["seq"], r["seqlen"]).copy()
+        codes[r["N"]] = 4
+        rf, fl, To, T = db.scan_se(formats.pack_ragged([codes]))
+        return (int(rf[0]), int(fl[0]), T) if To[1] > To[0] else None
+
+    def pair(a, b):
+        return db.scan_pe(a["seq"], a["seqlen"], a["N"], b["seq"], b["seqlen"], b["N"], force=True)[1]
+
+    got = golden_util.pe_stream_from(golden_pe, pair, single, oracle.rc_packed)
+    assert got == gzip.open(os.path.join(golden_pe["dir"], "s2_force.bin.gz")).read()
+
+
 @pytest.mark.parametrize("union,tap", [(False, "s2_default_p.bin.gz"), (True, "s2_default.bin.gz")])
 def test_oracle_pe_scan_in_the_default_mode_matches_s2_tap_bytes(golden_pe, union, tap):
     """`-ipe r1 r2 [-apm p]` WITHOUT -1t1 (tests/golden/pe/s2_default*.bin.gz, make_golden_pe_default.py): the couples by the pairing
