@@ -116,10 +116,11 @@ def test_pe_scan_in_the_default_mode_matches_reference_s2_stream(golden_pe, apm,
     assert len(ch["read"]) >= 15 and out == want
 
 
-@pytest.mark.parametrize("union", [False, True])
-def test_pe_scan_vs_oracle_redundant_db(tmp_path, union):
+@pytest.mark.parametrize("mode", ["p", "u", "f"])
+def test_pe_scan_vs_oracle_redundant_db(tmp_path, mode):
     """Wide candidate lists (overflow path) and short mates; the pairing penalty and the union pairing (pair_union_kernel against
-    oracle/scan.c's orc_scan_pe_union, which the reference's default `-ipe` tap pins)."""
+    oracle/scan.c's orc_scan_pe_union, which the reference's default `-ipe` tap pins) and stage 2 of forced pairing (pair_force_kernel
+    against orc_scan_pe_force, pinned by the `-apm f` tap)."""
     import oracle
     from kma_amd import binding, synth
     names, seqs = synth.make_gene_db(n_families=5, variants=30, len_lo=500, len_hi=900, max_div=0.03, seed=77)
@@ -137,7 +138,7 @@ def test_pe_scan_vs_oracle_redundant_db(tmp_path, union):
     batch = formats.pack_ragged(reads)
     db = binding.KmaHipDB(prefix)
     try:
-        db.params.apm = 1 if union else 0
+        db.params.apm = {"p": 0, "u": 1, "f": 2}[mode]
         mate, rc, rc_flag, flag, R_off, T = db.scan_pe(batch)
     finally:
         db.close()
@@ -145,7 +146,7 @@ def test_pe_scan_vs_oracle_redundant_db(tmp_path, union):
     for j in range(len(reads) // 2):
         w = lambda i: batch.seq[batch.seq_off[i]:batch.seq_off[i + 1] - 1]
         Nn = lambda i: batch.N[batch.N_off[i]:batch.N_off[i + 1]]
-        _, recs = odb.scan_pe(w(2 * j), int(batch.length[2 * j]), Nn(2 * j), w(2 * j + 1), int(batch.length[2 * j + 1]), Nn(2 * j + 1), union=union)
+        _, recs = odb.scan_pe(w(2 * j), int(batch.length[2 * j]), Nn(2 * j), w(2 * j + 1), int(batch.length[2 * j + 1]), Nn(2 * j + 1), union=mode == "u", force=mode == "f")
         got = []
         for x in (2 * j, 2 * j + 1):
             if mate[x] >= 0:
